@@ -1,0 +1,79 @@
+"""Loader for tests/golden/*.npz (written by tests/golden/make_golden.py from the imported reference)."""
+import ast
+import os
+
+import numpy as np
+import torch
+
+from oracle.gaot_oracle import OracleConfig
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+MODEL_CASES = ["fx2d_base", "fx2d_base_s1", "fx2d_zero_deg", "fx2d_headdim32", "fx2d_inproj", "vx2d",
+               "ms_mean", "ms_weighted", "attn_dot", "no_attn_mean", "no_geoembed", "nonlinear",
+               "node_embed", "pointnet", "fx3d", "even_layers"]
+
+
+class Golden:
+    def __init__(self, case):
+        self.case = case
+        z = np.load(os.path.join(GOLDEN_DIR, f"{case}.npz"), allow_pickle=False)
+        self.raw = {k: z[k] for k in z.files}
+        self.magno = ast.literal_eval(str(self.raw["meta.magno"]))
+        self.transformer = ast.literal_eval(str(self.raw["meta.transformer"]))
+        self.attn = ast.literal_eval(str(self.raw["meta.attn"]))
+
+    def t(self, key):
+        return torch.from_numpy(np.array(self.raw[key]))
+
+    def has(self, key):
+        return key in self.raw
+
+    def group(self, prefix):
+        return {k[len(prefix):]: torch.from_numpy(np.array(v)) for k, v in self.raw.items() if k.startswith(prefix)}
+
+    @property
+    def state_dict(self):
+        return self.group("w.")
+
+    @property
+    def latent_tokens_size(self):
+        lat = self.raw["in.latent"]
+        d = lat.shape[1]
+        n = round(lat.shape[0] ** (1.0 / d))
+        return [n] * d
+
+    def oracle_config(self) -> OracleConfig:
+        m, t, a = self.magno, self.transformer, self.attn
+        return OracleConfig(
+            coord_dim=m.get("coord_dim", 2), radius=m["radius"], hidden_size=m["hidden_size"],
+            mlp_layers=m["mlp_layers"], lifting_channels=m["lifting_channels"], scales=m.get("scales", [1.0]),
+            use_scale_weights=m.get("use_scale_weights", False), use_attention=m.get("use_attention", True),
+            attention_type=m.get("attention_type", "cosine"), use_geoembed=m.get("use_geoembed", True),
+            embedding_method=m.get("embedding_method", "statistical"), pooling=m.get("pooling", "max"),
+            transform_type=m.get("transform_type", "linear"), node_embedding=m.get("node_embedding", False),
+            precompute_edges=m.get("precompute_edges", False),
+            patch_size=t["patch_size"], tf_hidden_size=t["hidden_size"], num_layers=t.get("num_layers", 3),
+            num_heads=a["num_heads"], num_kv_heads=a["num_kv_heads"],
+            use_conditional_norm=a.get("use_conditional_norm", False),
+            latent_tokens_size=self.latent_tokens_size)
+
+    def csr_lists(self):
+        """(encoder_nbrs, decoder_nbrs) in the reference's list layout, or (None, None) when absent."""
+        nsc = len(self.magno.get("scales", [1.0]))
+        if self.has("csr.enc.b0.s0.index"):
+            B = self.raw["in.pndata"].shape[0]
+            mk = lambda side: [[(self.t(f"csr.{side}.b{b}.s{s}.index"), self.t(f"csr.{side}.b{b}.s{s}.splits"))
+                                for s in range(nsc)] for b in range(B)]
+            return mk("enc"), mk("dec")
+        if self.has("csr.enc.s0.index"):
+            mk = lambda side: [(self.t(f"csr.{side}.s{s}.index"), self.t(f"csr.{side}.s{s}.splits")) for s in range(nsc)]
+            return mk("enc"), mk("dec")
+        return None, None
+
+
+def rel_l2(a, b):
+    a = a.double().flatten()
+    b = b.double().flatten()
+    den = b.norm().item()
+    return (a - b).norm().item() / (den if den > 0 else 1.0)
