@@ -1,0 +1,92 @@
+"""ctypes binding of libgaot_hip.so (include/gaot_hip.h).  Fails loudly: there is NO CPU or eager fallback."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgaot_hip.so")
+
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD, ACT_RELU_BWD = 0, 1, 2, 3, 4
+
+_f = C.c_void_p   # device float*
+_i = C.c_void_p   # device int*
+_s = C.c_void_p   # hipStream_t
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("A", _f), ("lda", C.c_int64), ("a_kmajor", C.c_int32),
+        ("A2", _f), ("lda2", C.c_int64), ("k_split", C.c_int32),
+        ("B", _f), ("ldb", C.c_int64), ("b_kmajor", C.c_int32),
+        ("C", _f), ("ldc", C.c_int64),
+        ("bias", _f),
+        ("rowbias", _f), ("rowbias_period", C.c_int32), ("ld_rowbias", C.c_int64),
+        ("rowscale", _f),
+        ("act", C.c_int32),
+        ("aux_in", _f), ("aux_out", _f), ("ld_aux", C.c_int64),
+        ("residual", _f), ("ldr", C.c_int64),
+        ("split_k", C.c_int32), ("workspace", _f),
+    ]
+
+
+# name -> (restype, argtypes): every symbol include/gaot_hip.h declares
+PROTOTYPES = {
+    "gaot_abi_version": (C.c_int, []),
+    "gaot_last_error": (C.c_char_p, []),
+    "gaot_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _s]),
+    "gaot_csr_prepare": (C.c_int, [_i, _i, C.c_int32, C.c_int32, C.c_int32, _i, _i, _i, _i, _s]),
+    "gaot_csr_transpose": (C.c_int, [_i, C.c_int32, C.c_int32, _i, _i, _i, _s]),
+    "gaot_edge_attention_cosine": (C.c_int, [_f, _f, C.c_int32, _i, _i, C.c_int32, _f, _s]),
+    "gaot_segment_softmax_fwd": (C.c_int, [_f, _i, C.c_int32, _f, _s]),
+    "gaot_segment_softmax_bwd": (C.c_int, [_f, _f, _i, C.c_int32, _f, _s]),
+    "gaot_edge_features": (C.c_int, [_f, _f, C.c_int32, _i, _i, C.c_int32, _f, _s]),
+    "gaot_geo_stats": (C.c_int, [_f, _f, C.c_int32, _i, _i, C.c_int32, _f, C.c_void_p, _s]),
+    "gaot_gno_gather_reduce": (C.c_int, [_f, _f, C.c_int32, C.c_int32, C.c_int32, _i, _i, _i, C.c_int32, _f, _f, _s]),
+    "gaot_gno_edge_grad": (C.c_int, [_f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i, _i, C.c_int32, _f, _f, _s]),
+    "gaot_gno_segment_sum": (C.c_int, [_f, C.c_int32, C.c_int32, C.c_int32, _i, C.c_int32, _f, _f, _s]),
+    "gaot_rmsnorm_fwd": (C.c_int, [_f, _f, C.c_int32, C.c_int32, C.c_float, _f, _f, _s]),
+    "gaot_rmsnorm_bwd_partials": (C.c_int, [C.c_int32]),
+    "gaot_rmsnorm_bwd": (C.c_int, [_f, _f, _f, _f, _f, C.c_int32, C.c_int32, _f, _f, _s]),
+    "gaot_swiglu_fwd": (C.c_int, [_f, C.c_int32, C.c_int32, _f, _s]),
+    "gaot_swiglu_bwd": (C.c_int, [_f, _f, C.c_int32, C.c_int32, _f, _s]),
+    "gaot_attention_fwd": (C.c_int, [_f, _f, _f, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_int32, C.c_int32, _f, C.c_int64, _f, _s]),
+    "gaot_attention_bwd_workspace": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "gaot_attention_bwd": (C.c_int, [_f, _f, _f, C.c_int64, C.c_int64, C.c_int64, _f, _f, C.c_int64, _f,
+                                     C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                     _f, _f, _f, C.c_int64, C.c_int64, C.c_int64, _f, _s]),
+    "gaot_colsum_scratch": (C.c_int64, [C.c_int32, C.c_int32]),
+    "gaot_colsum": (C.c_int, [_f, C.c_int64, C.c_int32, C.c_int32, _f, _f, _s]),
+    "gaot_batchsum": (C.c_int, [_f, C.c_int32, C.c_int64, _f, _s]),
+    "gaot_patchify": (C.c_int, [_f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f, C.c_int32, _s]),
+}
+
+_lib = None
+
+
+class GaotLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the in-tree library and bind every prototype.  Raises if it is missing (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GaotLibraryError(
+            f"{LIB_PATH} not found: build it with `python -m gaot_amd.build` (hipcc --offload-arch=gfx950). "
+            "gaot_amd has no CPU / eager fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)   # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().gaot_last_error()
+        raise GaotLibraryError(f"{what} failed (status {rc}): {msg.decode() if msg else '?'}")

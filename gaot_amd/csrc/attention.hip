@@ -1,0 +1,479 @@
+// Softmax attention (no mask) forward + backward in exact fp32 on the gfx950 matrix cores.
+// Replaces F.scaled_dot_product_attention at attn.py:114 and its autograd.
+//
+// f32-input MFMA (v_mfma_f32_32x32x2_f32) takes ONE value per lane per operand and its C/D fragment
+// puts column (lane&31) in the lane and 16 rows crow(r, lane>>5) in registers.  That makes the flash
+// pipeline register-resident with no shuffles:
+//   forward : S^T = K Q^T  -> each lane owns one query column, softmax row-max/sum are in-register
+//             (+1 cross-half exchange); the SAME registers are the B operand of O^T += V^T P^T.
+//   backward: S = Q K^T and dP = dO V^T have one key column per lane; P and dS feed dV^T += dO^T P and
+//             dK^T += Q^T dS straight from registers; only dQ = dS K needs dS transposed (through LDS).
+// Reduction order inside a tile is free, so k-slots are chosen to make every LDS read conflict-free
+// (ds_read_b128 on +4-padded rows for A operands, row-contiguous ds_read_b32 otherwise).
+// Everything is deterministic: no atomics; dQ partials per key block are reduced in a fixed order.
+#include "common.h"
+
+namespace gaot {
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+struct AttnArgs {
+    const float *q, *k, *v;
+    long ldq, ldk, ldv;
+    int B, S, H, Hkv, D;
+    float* o; long ldo; float* lse;
+    // backward
+    const float *oin, *dout; float *dq, *dk, *dv; long lddq, lddk, lddv;
+    float* delta; float* dq_part; int n_kblocks;
+    float scale; int vec;
+};
+
+__device__ __forceinline__ f32x4 load4(const float* __restrict__ row, int d, int D, bool row_ok, bool vec) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (!row_ok) return v;
+    if (vec) { if (d < D) v = *reinterpret_cast<const f32x4*>(row + d); }
+    else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (d + j < D) v[j] = row[d + j];
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward: workgroup = 4 waves x 32 queries; key/value tiles of 64 rows staged through LDS
+// ---------------------------------------------------------------------------------------------
+template <int DP>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
+    constexpr int ND = DP / 32;          // 32-wide d tiles
+    constexpr int LDT = DP + 4;          // LDS row stride (floats)
+    constexpr int KT = 64;               // keys per staged tile
+    constexpr int NF4 = KT * DP / 4 / 256;   // float4 per thread per operand tile
+    __shared__ __attribute__((aligned(16))) float smem[2 * KT * LDT];
+    float* Ks = smem;
+    float* Vs = smem + KT * LDT;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H, hk = h / (p.H / p.Hkv);
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int D = p.D;
+    const bool vec = p.vec != 0;
+    const float c = p.scale * LOG2E;
+
+    // Q^T operand: lane (q = li, half lh) keeps Q[q][8g + 4lh + s]
+    float qreg[DP / 2];
+    {
+        const int qi = q0 + li;
+        const float* qrow = p.q + ((long)b * p.S + qi) * p.ldq + (long)h * D;
+#pragma unroll
+        for (int g = 0; g < DP / 8; ++g) {
+            const f32x4 v = load4(qrow, 8 * g + 4 * lh, D, qi < p.S, vec);
+            qreg[4 * g + 0] = v[0]; qreg[4 * g + 1] = v[1]; qreg[4 * g + 2] = v[2]; qreg[4 * g + 3] = v[3];
+        }
+    }
+    f32x16 oacc[ND];
+#pragma unroll
+    for (int t = 0; t < ND; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const float* kbase = p.k + (long)b * p.S * p.ldk + (long)hk * D;
+    const float* vbase = p.v + (long)b * p.S * p.ldv + (long)hk * D;
+    f32x4 rk[NF4], rv[NF4];
+    auto fetch = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < NF4; ++i) {
+            const int t = tid + i * 256;
+            const int row = t / (DP / 4), d = (t % (DP / 4)) * 4;
+            const bool ok = kv0 + row < p.S;
+            rk[i] = load4(kbase + (long)(kv0 + row) * p.ldk, d, D, ok, vec);
+            rv[i] = load4(vbase + (long)(kv0 + row) * p.ldv, d, D, ok, vec);
+        }
+    };
+    const int ntiles = (p.S + KT - 1) / KT;
+    fetch(0);
+    for (int kt = 0; kt < ntiles; ++kt) {
+#pragma unroll
+        for (int i = 0; i < NF4; ++i) {
+            const int t = tid + i * 256;
+            const int row = t / (DP / 4), d = (t % (DP / 4)) * 4;
+            *reinterpret_cast<f32x4*>(Ks + row * LDT + d) = rk[i];
+            *reinterpret_cast<f32x4*>(Vs + row * LDT + d) = rv[i];
+        }
+        __syncthreads();
+        if (kt + 1 < ntiles) fetch((kt + 1) * KT);
+#pragma unroll
+        for (int sub = 0; sub < KT / 32; ++sub) {
+            const int kvs = kt * KT + sub * 32;   // first key of this 32-row sub-tile
+            if (kvs >= p.S) break;
+            // ---- S^T[kv][q] = sum_d K[kv][d] Q[q][d]
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            const float* krow = Ks + (sub * 32 + li) * LDT + 4 * lh;
+#pragma unroll
+            for (int g = 0; g < DP / 8; ++g) {
+                const f32x4 kv = *reinterpret_cast<const f32x4*>(krow + 8 * g);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[t], qreg[4 * g + t], s, 0, 0, 0);
+            }
+            // ---- online softmax over the key rows this lane holds (16) + the other half-wave (16)
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (kvs + crow(r, lh) >= p.S) s[r] = -INFINITY;
+                mx = fmaxf(mx, s[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = exp2f((m_run - m_new) * c);
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = exp2f((s[r] - m_new) * c); ps += s[r]; }
+            ps += __shfl_xor(ps, 32, 64);
+            l_run = l_run * alpha + ps;
+            m_run = m_new;
+#pragma unroll
+            for (int t = 0; t < ND; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+            // ---- O^T[d][q] += sum_kv V[kv][d] P^T[kv][q]   (P^T registers are the B operand as they are)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float* vrow = Vs + (sub * 32 + crow(r, lh)) * LDT + li;
+#pragma unroll
+                for (int t = 0; t < ND; ++t)
+                    oacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32 * t], s[r], oacc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- epilogue: normalise, transpose O^T through LDS (wave-private 32 x (DP+1)), coalesced row stores
+    const float inv_l = 1.0f / l_run;
+    float* Os = smem + wave * 32 * (DP + 1);     // 4 * 32 * (DP+1) floats <= 2*64*(DP+4)
+#pragma unroll
+    for (int t = 0; t < ND; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Os[li * (DP + 1) + 32 * t + crow(r, lh)] = oacc[t][r] * inv_l;
+    __syncthreads();
+    for (int rr = lh; rr < 32; rr += 2) {
+        const int qi = q0 + rr;
+        if (qi >= p.S) break;
+        float* orow = p.o + ((long)b * p.S + qi) * p.ldo + (long)h * D;
+#pragma unroll
+        for (int t = 0; t < ND; ++t) {
+            const int d = 32 * t + li;
+            if (d < D) orow[d] = Os[rr * (DP + 1) + d];
+        }
+    }
+    if (lh == 0 && q0 + li < p.S)
+        p.lse[((long)b * p.H + h) * p.S + q0 + li] = m_run * p.scale + logf(l_run);
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward helpers
+// ---------------------------------------------------------------------------------------------
+// delta[b,h,s] = sum_d dO * O       (one thread per (b,s,h); rows are short)
+__global__ void attn_delta_kernel(const AttnArgs p) {
+    const long total = (long)p.B * p.S * p.H;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int h = (int)(gid % p.H);
+    const long bs = gid / p.H;
+    const int s = (int)(bs % p.S), b = (int)(bs / p.S);
+    const float* o = p.oin + bs * p.ldo + (long)h * p.D;
+    const float* g = p.dout + bs * p.ldo + (long)h * p.D;
+    float acc = 0.f;
+    for (int d = 0; d < p.D; ++d) acc += o[d] * g[d];
+    p.delta[((long)b * p.H + h) * p.S + s] = acc;
+}
+
+// dq[b,s,h,:] = scale * sum_kb part[kb][b,h,s,:]
+__global__ void attn_dq_reduce_kernel(const AttnArgs p, int DP) {
+    const long total = (long)p.B * p.H * p.S * DP;
+    for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long)gridDim.x * blockDim.x) {
+        const int d = (int)(gid % DP);
+        if (d >= p.D) continue;
+        const long bhs = gid / DP;
+        const int s = (int)(bhs % p.S);
+        const long bh = bhs / p.S;
+        const int h = (int)(bh % p.H), b = (int)(bh / p.H);
+        float acc = 0.f;
+        for (int kb = 0; kb < p.n_kblocks; ++kb) acc += p.dq_part[(long)kb * total + gid];
+        p.dq[((long)b * p.S + s) * p.lddq + (long)h * p.D + d] = acc * p.scale;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward main: workgroup = 4 waves, each owns 32 keys (block = 128 keys); loops over query tiles of 32
+// ---------------------------------------------------------------------------------------------
+template <int DP>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs p) {
+    constexpr int ND = DP / 32;
+    constexpr int LDT = DP + 4;
+    constexpr int NF4 = (32 * DP / 4 + 255) / 256;   // float4 per thread per 32-row tile (1 for DP=32, 2 for 64)
+    constexpr int F4_PER_TILE = 32 * DP / 4;
+    extern __shared__ __attribute__((aligned(16))) float dyn[];
+    float* Qs = dyn;                               // [32][LDT]
+    float* Gs = Qs + 32 * LDT;                     // dO tile [32][LDT]
+    float* lse_s = Gs + 32 * LDT;                  // [32]
+    float* del_s = lse_s + 32;                     // [32]
+    float* Kw = del_s + 32;                        // per wave [32][DP]
+    float* Sw = Kw + 4 * 32 * DP;                  // per wave dS^T staging [32][33]
+    float* Pq = Sw + 4 * 32 * 33;                  // per wave dQ partial [32][DP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H, hk = h / (p.H / p.Hkv);
+    const int kv0 = blockIdx.x * 128 + wave * 32;
+    const int D = p.D;
+    const bool vec = p.vec != 0;
+    const float c = p.scale * LOG2E;
+    float* Kmine = Kw + wave * 32 * DP;
+    float* Smine = Sw + wave * 32 * 33;
+    float* Pmine = Pq + wave * 32 * DP;
+
+    // K^T / V^T operands for this lane's key (column li): K[kv][8g + 4lh + s]
+    float kreg[DP / 2], vreg[DP / 2];
+    const bool kv_ok = kv0 + li < p.S;
+    {
+        const float* krow = p.k + ((long)b * p.S + kv0 + li) * p.ldk + (long)hk * D;
+        const float* vrow = p.v + ((long)b * p.S + kv0 + li) * p.ldv + (long)hk * D;
+#pragma unroll
+        for (int g = 0; g < DP / 8; ++g) {
+            const f32x4 a = load4(krow, 8 * g + 4 * lh, D, kv_ok, vec);
+            const f32x4 w = load4(vrow, 8 * g + 4 * lh, D, kv_ok, vec);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { kreg[4 * g + t] = a[t]; vreg[4 * g + t] = w[t]; }
+        }
+        // the wave's K tile, row-major, for the dQ product (B operand read row-contiguously)
+        for (int t = lane; t < 32 * DP / 4; t += 64) {
+            const int row = t / (DP / 4), d = (t % (DP / 4)) * 4;
+            const f32x4 a = load4(p.k + ((long)b * p.S + kv0 + row) * p.ldk + (long)hk * D, d, D, kv0 + row < p.S, vec);
+            *reinterpret_cast<f32x4*>(Kmine + row * DP + d) = a;
+        }
+    }
+    f32x16 dvacc[ND], dkacc[ND];
+#pragma unroll
+    for (int t = 0; t < ND; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dvacc[t][r] = 0.f; dkacc[t][r] = 0.f; }
+
+    const float* qbase = p.q + (long)b * p.S * p.ldq + (long)h * D;
+    const float* gbase = p.dout + (long)b * p.S * p.ldo + (long)h * D;
+    const float* lse_b = p.lse + ((long)b * p.H + h) * p.S;
+    const float* del_b = p.delta + ((long)b * p.H + h) * p.S;
+    f32x4 rq[NF4], rg[NF4];
+    float rl = 0.f, rd = 0.f;
+    auto fetch = [&](int q0) {
+#pragma unroll
+        for (int i = 0; i < NF4; ++i) {
+            const int t = tid + i * 256;
+            if (t < F4_PER_TILE) {
+                const int row = t / (DP / 4), d = (t % (DP / 4)) * 4;
+                const bool ok = q0 + row < p.S;
+                rq[i] = load4(qbase + (long)(q0 + row) * p.ldq, d, D, ok, vec);
+                rg[i] = load4(gbase + (long)(q0 + row) * p.ldo, d, D, ok, vec);
+            }
+        }
+        if (tid < 32) {
+            const bool ok = q0 + tid < p.S;
+            rl = ok ? lse_b[q0 + tid] * LOG2E : INFINITY;   // +inf -> P = 0 for padded queries
+            rd = ok ? del_b[q0 + tid] : 0.f;
+        }
+    };
+    const int nq = (p.S + 31) / 32;
+    const long part_stride = (long)p.B * p.H * p.S * DP;
+    float* part = p.dq_part + (long)blockIdx.x * part_stride + ((long)b * p.H + h) * p.S * DP;
+
+    fetch(0);
+    for (int qt = 0; qt < nq; ++qt) {
+        const int q0 = qt * 32;
+#pragma unroll
+        for (int i = 0; i < NF4; ++i) {
+            const int t = tid + i * 256;
+            if (t < F4_PER_TILE) {
+                const int row = t / (DP / 4), d = (t % (DP / 4)) * 4;
+                *reinterpret_cast<f32x4*>(Qs + row * LDT + d) = rq[i];
+                *reinterpret_cast<f32x4*>(Gs + row * LDT + d) = rg[i];
+            }
+        }
+        if (tid < 32) { lse_s[tid] = rl; del_s[tid] = rd; }
+        __syncthreads();                                    // barrier A
+        if (qt + 1 < nq) fetch(q0 + 32);
+
+        // ---- S[q][kv] and dP[q][kv]
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        {
+            const float* qrow = Qs + li * LDT + 4 * lh;
+            const float* grow = Gs + li * LDT + 4 * lh;
+#pragma unroll
+            for (int g = 0; g < DP / 8; ++g) {
+                const f32x4 qa = *reinterpret_cast<const f32x4*>(qrow + 8 * g);
+                const f32x4 ga = *reinterpret_cast<const f32x4*>(grow + 8 * g);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[t], kreg[4 * g + t], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[t], vreg[4 * g + t], dp, 0, 0, 0);
+                }
+            }
+        }
+        // ---- P = exp(S*scale - lse), dS = P * (dP - delta)   (rows q = crow(r,lh), column kv = li)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qr = crow(r, lh);
+            float pv = exp2f(s[r] * c - lse_s[qr]);
+            if (!kv_ok) pv = 0.f;
+            s[r] = pv;
+            dp[r] = pv * (dp[r] - del_s[qr]);
+        }
+        // ---- dV^T[d][kv] += dO^T[d][q] P[q][kv] ; dK^T[d][kv] += Q^T[d][q] dS[q][kv]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float* grow = Gs + crow(r, lh) * LDT + li;
+            const float* qrow = Qs + crow(r, lh) * LDT + li;
+#pragma unroll
+            for (int t = 0; t < ND; ++t) {
+                dvacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(grow[32 * t], s[r], dvacc[t], 0, 0, 0);
+                dkacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[32 * t], dp[r], dkacc[t], 0, 0, 0);
+            }
+        }
+        // ---- dQ[q][d] partial = sum_kv dS[q][kv] K[kv][d] : dS goes through wave-private LDS to flip lanes
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Smine[crow(r, lh) * 33 + li] = dp[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        f32x16 dq[ND];
+#pragma unroll
+        for (int t = 0; t < ND; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dq[t][r] = 0.f;
+#pragma unroll
+        for (int t16 = 0; t16 < 16; ++t16) {
+            const int kvs = t16 + 16 * lh;
+            const float a = Smine[li * 33 + kvs];
+#pragma unroll
+            for (int t = 0; t < ND; ++t)
+                dq[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Kmine[kvs * DP + 32 * t + li], dq[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < ND; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Pmine[crow(r, lh) * DP + 32 * t + li] = dq[t][r];
+        __syncthreads();                                    // barrier B
+        // fixed-order sum of the four waves' partials -> this key block's slice of the dQ workspace
+        for (int t = tid; t < 32 * DP; t += 256) {
+            const int row = t / DP;
+            if (q0 + row < p.S)
+                part[(long)(q0 + row) * DP + (t % DP)] = Pq[t] + Pq[32 * DP + t] + Pq[2 * 32 * DP + t] + Pq[3 * 32 * DP + t];
+        }
+    }
+    // ---- epilogue: dK^T, dV^T -> [kv][d] through wave-private LDS, coalesced row stores (per QUERY head h)
+    __syncthreads();
+    float* T = Kmine;   // 32*DP floats; transposed staging with stride DP+1 would overflow -> two passes over Smine-sized rows
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int t = 0; t < ND; ++t) {
+            // stage one 32(d) x 32(kv) block transposed into Smine [kv][33]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Smine[li * 33 + crow(r, lh)] = (pass == 0 ? dkacc[t][r] * p.scale : dvacc[t][r]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int rr = lh; rr < 32; rr += 2) {
+                const int kv = kv0 + rr;
+                const int d = 32 * t + li;
+                if (kv < p.S && d < D) {
+                    if (pass == 0) p.dk[((long)b * p.S + kv) * p.lddk + (long)h * D + d] = Smine[rr * 33 + li];
+                    else           p.dv[((long)b * p.S + kv) * p.lddv + (long)h * D + d] = Smine[rr * 33 + li];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+    (void)T;
+}
+
+template <int DP> static size_t bwd_lds_bytes() {
+    return sizeof(float) * (2 * 32 * (DP + 4) + 64 + 4 * 32 * DP + 4 * 32 * 33 + 4 * 32 * DP);
+}
+
+static int fill_common(AttnArgs& a, const float* q, const float* k, const float* v, int64_t ldq, int64_t ldk, int64_t ldv,
+                       int B, int S, int H, int Hkv, int D) {
+    a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
+    a.B = B; a.S = S; a.H = H; a.Hkv = Hkv; a.D = D;
+    a.scale = 1.0f / sqrtf((float)D);
+    a.vec = (D % 4 == 0) && (ldq % 4 == 0) && (ldk % 4 == 0) && (ldv % 4 == 0) && aligned16(q) && aligned16(k) && aligned16(v);
+    return 0;
+}
+
+}  // namespace gaot
+
+using namespace gaot;
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int gaot_attention_fwd(const float* q, const float* k, const float* v, int64_t ldq, int64_t ldk, int64_t ldv,
+                                  int32_t B, int32_t S, int32_t H, int32_t Hkv, int32_t head_dim, float* o, int64_t ldo,
+                                  float* lse, gaot_stream_t stream) {
+    GAOT_REQUIRE(q && k && v && o && lse, "attention_fwd: null pointer");
+    GAOT_REQUIRE(B > 0 && S > 0 && H > 0 && Hkv > 0 && H % Hkv == 0, "attention_fwd: bad sizes B=%d S=%d H=%d Hkv=%d", B, S, H, Hkv);
+    GAOT_REQUIRE(head_dim > 0 && head_dim <= 64, "attention_fwd: head_dim %d not in 1..64", head_dim);
+    AttnArgs a = {};
+    fill_common(a, q, k, v, ldq, ldk, ldv, B, S, H, Hkv, head_dim);
+    a.o = o; a.ldo = ldo; a.lse = lse;
+    dim3 grid(cdiv(S, 128), B * H), block(256);
+    if (head_dim <= 32) hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, block, 0, ST(stream), a);
+    else                hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, block, 0, ST(stream), a);
+    GAOT_CHECK_LAUNCH("gaot_attention_fwd");
+    return GAOT_OK;
+}
+
+extern "C" int64_t gaot_attention_bwd_workspace(int32_t B, int32_t S, int32_t H, int32_t head_dim) {
+    const int DP = head_dim <= 32 ? 32 : 64;
+    const int64_t nkb = cdiv(S, 128);
+    return (int64_t)B * H * S + nkb * B * H * S * DP;   // delta + dQ partials per key block
+}
+
+extern "C" int gaot_attention_bwd(const float* q, const float* k, const float* v, int64_t ldq, int64_t ldk, int64_t ldv,
+                                  const float* o, const float* dout, int64_t ldo, const float* lse, int32_t B, int32_t S,
+                                  int32_t H, int32_t Hkv, int32_t head_dim, float* dq, float* dk, float* dv, int64_t lddq,
+                                  int64_t lddk, int64_t lddv, float* workspace, gaot_stream_t stream) {
+    GAOT_REQUIRE(q && k && v && o && dout && lse && dq && dk && dv && workspace, "attention_bwd: null pointer");
+    GAOT_REQUIRE(B > 0 && S > 0 && H > 0 && Hkv > 0 && H % Hkv == 0, "attention_bwd: bad sizes");
+    GAOT_REQUIRE(head_dim > 0 && head_dim <= 64, "attention_bwd: head_dim %d not in 1..64", head_dim);
+    AttnArgs a = {};
+    fill_common(a, q, k, v, ldq, ldk, ldv, B, S, H, Hkv, head_dim);
+    a.vec = a.vec && (ldo % 4 == 0) && aligned16(dout);
+    a.oin = o; a.dout = dout; a.ldo = ldo; a.lse = const_cast<float*>(lse);
+    a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+    a.delta = workspace;
+    a.dq_part = workspace + (int64_t)B * H * S;
+    a.n_kblocks = cdiv(S, 128);
+    const int DP = head_dim <= 32 ? 32 : 64;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv((long)B * S * H, 256)), dim3(256), 0, ST(stream), a);
+    dim3 grid(a.n_kblocks, B * H), block(256);
+    if (DP == 32) {
+        hipLaunchKernelGGL(attn_bwd_kernel<32>, grid, block, bwd_lds_bytes<32>(), ST(stream), a);
+    } else {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)bwd_lds_bytes<64>());
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(attn_bwd_kernel<64>, grid, block, bwd_lds_bytes<64>(), ST(stream), a);
+    }
+    const long total = (long)B * H * S * DP;
+    int nb = cdiv(total, 256); if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(attn_dq_reduce_kernel, dim3(nb), dim3(256), 0, ST(stream), a, DP);
+    GAOT_CHECK_LAUNCH("gaot_attention_bwd");
+    return GAOT_OK;
+}

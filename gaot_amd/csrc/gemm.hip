@@ -1,0 +1,277 @@
+// fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32), fused epilogue, optional split-K.
+//
+// Design notes (MI355X):
+//  * f32-input MFMA takes ONE f32 per lane per operand, so any operand can be fed from LDS in either
+//    orientation; reduction order inside a k-tile is free as long as A and B agree.  We use that:
+//      - an operand whose reduction dim is contiguous in HBM ("k-major") is staged as [row][k] with a
+//        +4 pad (stride 36 dwords: 16 consecutive rows land on 16 distinct 4-bank slots -> conflict-free
+//        ds_read_b128) and each 128-bit read feeds FOUR MFMAs (k-slots: half-wave h takes k = 8g+4h+s);
+//      - an operand whose row dim is contiguous ("m-major", the transposed products of backward) is staged
+//        as [k][row] and read with one conflict-free ds_read_b32 per MFMA at the same k = 8g+4h+s.
+//  * 256 threads = 4 waves; 64-cycle MFMA issue makes the kernel matrix-pipe bound with register-prefetched
+//    single-buffer staging (next k-tile's global loads in flight under 16*TM*TN MFMAs).
+//  * workgroup ids are remapped so that one XCD (private L2) owns whole row-panels of A.
+#include "common.h"
+
+namespace gaot {
+
+struct GemmArgs {
+    int M, N, K;
+    const float* A; long lda; const float* A2; long lda2; int k_split;
+    const float* B; long ldb;
+    float* C; long ldc;
+    const float* bias; const float* rowbias; int rb_period; long ld_rb;
+    const float* rowscale; int act; const float* aux_in; float* aux_out; long ld_aux;
+    const float* residual; long ldr;
+    int split_k; int ktiles_per_split; float* ws;
+    int tiles_m, tiles_n;
+};
+
+constexpr int BK = 32;
+
+__device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, float v) {
+    if (p.bias) v += p.bias[n];
+    if (p.rowbias) v += p.rowbias[(long)(m % p.rb_period) * p.ld_rb + n];
+    if (p.rowscale) v *= p.rowscale[m];
+    if (p.aux_out) p.aux_out[(long)m * p.ld_aux + n] = v;
+    switch (p.act) {
+        case GAOT_ACT_GELU: v = gelu_f(v); break;
+        case GAOT_ACT_RELU: v = fmaxf(v, 0.0f); break;
+        case GAOT_ACT_GELU_BWD: v *= gelu_grad_f(p.aux_in[(long)m * p.ld_aux + n]); break;
+        case GAOT_ACT_RELU_BWD: v = (p.aux_in[(long)m * p.ld_aux + n] > 0.0f) ? v : 0.0f; break;
+        default: break;
+    }
+    if (p.residual) v += p.residual[(long)m * p.ldr + n];
+    p.C[(long)m * p.ldc + n] = v;
+}
+
+// global -> registers for one [ROWS x BK] operand tile.  KMAJ: elem(row,k) = base[row*ld + k].
+template <bool KMAJ, bool VEC, int ROWS>
+__device__ __forceinline__ void load_tile(f32x4 (&r)[ROWS / 32], const float* __restrict__ base, long ld,
+                                          int row0, int nrows, int k0, int klim, int tid) {
+#pragma unroll
+    for (int p = 0; p < ROWS / 32; ++p) {
+        const int t = tid + p * 256;
+        int row, k;
+        if (KMAJ) { row = row0 + (t >> 3); k = k0 + (t & 7) * 4; }
+        else      { k = k0 + t / (ROWS / 4); row = row0 + (t % (ROWS / 4)) * 4; }
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (VEC) {
+            if (row < nrows && k < klim) {
+                const float* src = KMAJ ? base + (long)row * ld + k : base + (long)k * ld + row;
+                v = *reinterpret_cast<const f32x4*>(src);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rr = KMAJ ? row : row + j;
+                const int kk = KMAJ ? k + j : k;
+                if (rr < nrows && kk < klim) v[j] = KMAJ ? base[(long)rr * ld + kk] : base[(long)kk * ld + rr];
+            }
+        }
+        r[p] = v;
+    }
+}
+
+template <bool KMAJ, int ROWS>
+__device__ __forceinline__ void store_tile(float* __restrict__ s, const f32x4 (&r)[ROWS / 32], int tid) {
+#pragma unroll
+    for (int p = 0; p < ROWS / 32; ++p) {
+        const int t = tid + p * 256;
+        if (KMAJ) *reinterpret_cast<f32x4*>(s + (t >> 3) * (BK + 4) + (t & 7) * 4) = r[p];
+        else      *reinterpret_cast<f32x4*>(s + (t / (ROWS / 4)) * ROWS + (t % (ROWS / 4)) * 4) = r[p];
+    }
+}
+
+// bijective "one XCD owns a contiguous chunk of logical tiles" remap (dispatcher places id on XCD id%8)
+__device__ __forceinline__ int xcd_remap(int id, int total) {
+    const int q = total >> 3, r = total & 7, x = id & 7, slot = id >> 3;
+    const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return start + slot;
+}
+
+template <int BM, int BN, int WAVES_M, bool AK, bool BKM, bool VEC>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
+    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int LDA_S = AK ? BK + 4 : BM;
+    constexpr int LDB_S = BKM ? BK + 4 : BN;
+    constexpr int A_ELEMS = AK ? BM * (BK + 4) : BK * BM;
+    constexpr int B_ELEMS = BKM ? BN * (BK + 4) : BK * BN;
+    __shared__ __attribute__((aligned(16))) float smem[A_ELEMS + B_ELEMS];
+    float* As = smem;
+    float* Bs = smem + A_ELEMS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    const int tiles = p.tiles_m * p.tiles_n;
+    const int logical = xcd_remap(blockIdx.x, tiles);
+    const int m0 = (logical / p.tiles_n) * BM;
+    const int n0 = (logical % p.tiles_n) * BN;
+
+    const int nkt = (p.K + BK - 1) / BK;
+    int kt_begin = 0, kt_end = nkt;
+    if (p.split_k > 1) {
+        kt_begin = blockIdx.z * p.ktiles_per_split;
+        kt_end = min(nkt, kt_begin + p.ktiles_per_split);
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[BM / 32], rb[BN / 32];
+
+    auto fetch = [&](int kt) {
+        const int k0 = kt * BK;
+        if (p.A2 != nullptr && k0 >= p.k_split)
+            load_tile<AK, VEC, BM>(ra, p.A2, p.lda2, m0, p.M, k0 - p.k_split, p.K - p.k_split, tid);
+        else
+            load_tile<AK, VEC, BM>(ra, p.A, p.lda, m0, p.M, k0, p.A2 ? p.k_split : p.K, tid);
+        load_tile<BKM, VEC, BN>(rb, p.B, p.ldb, n0, p.N, k0, p.K, tid);
+    };
+
+    if (kt_begin < kt_end) fetch(kt_begin);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        store_tile<AK, BM>(As, ra, tid);
+        store_tile<BKM, BN>(Bs, rb, tid);
+        __syncthreads();
+        if (kt + 1 < kt_end) fetch(kt + 1);
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
+            float a[TM][4], b[TN][4];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = wm * WM + i * 32 + li;
+                if (AK) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(As + row * LDA_S + 8 * g + 4 * lh);
+                    a[i][0] = v[0]; a[i][1] = v[1]; a[i][2] = v[2]; a[i][3] = v[3];
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) a[i][s] = As[(8 * g + 4 * lh + s) * LDA_S + row];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = wn * WN + j * 32 + li;
+                if (BKM) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(Bs + col * LDB_S + 8 * g + 4 * lh);
+                    b[j][0] = v[0]; b[j][1] = v[1]; b[j][2] = v[2]; b[j][3] = v[3];
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) b[j][s] = Bs[(8 * g + 4 * lh + s) * LDB_S + col];
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C-layout rows crow(r, lh), column li -> each half-wave writes 128 contiguous bytes per r
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * WN + j * 32 + li;
+            if (n >= p.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WM + i * 32 + crow(r, lh);
+                if (m >= p.M) continue;
+                if (p.split_k > 1) p.ws[((long)blockIdx.z * p.M + m) * p.N + n] = acc[i][j][r];
+                else epilogue_store(p, m, n, acc[i][j][r]);
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
+    const long total = (long)p.M * p.N;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int z = 0; z < p.split_k; ++z) v += p.ws[(long)z * total + idx];
+        epilogue_store(p, (int)(idx / p.N), (int)(idx % p.N), v);
+    }
+}
+
+template <int BM, int BN, int WAVES_M>
+static int launch_cfg(GemmArgs& a, bool ak, bool bk, bool vec, hipStream_t st) {
+    a.tiles_m = cdiv(a.M, BM);
+    a.tiles_n = cdiv(a.N, BN);
+    dim3 grid(a.tiles_m * a.tiles_n, 1, a.split_k > 1 ? a.split_k : 1);
+    dim3 block(256);
+#define GAOT_LAUNCH(AKv, BKv, Vv) hipLaunchKernelGGL((gemm_kernel<BM, BN, WAVES_M, AKv, BKv, Vv>), grid, block, 0, st, a)
+    if (ak && bk)        { if (vec) GAOT_LAUNCH(true, true, true);   else GAOT_LAUNCH(true, true, false); }
+    else if (ak && !bk)  { if (vec) GAOT_LAUNCH(true, false, true);  else GAOT_LAUNCH(true, false, false); }
+    else if (!ak && !bk) { if (vec) GAOT_LAUNCH(false, false, true); else GAOT_LAUNCH(false, false, false); }
+    else                 { if (vec) GAOT_LAUNCH(false, true, true);  else GAOT_LAUNCH(false, true, false); }
+#undef GAOT_LAUNCH
+    return 0;
+}
+
+}  // namespace gaot
+
+using namespace gaot;
+
+extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
+    GAOT_REQUIRE(d != nullptr, "gemm: null descriptor");
+    GAOT_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm: M,N,K must be positive (got %d,%d,%d)", d->M, d->N, d->K);
+    GAOT_REQUIRE(d->A && d->B && d->C, "gemm: A, B, C must be non-null");
+    GAOT_REQUIRE(d->act >= GAOT_ACT_NONE && d->act <= GAOT_ACT_RELU_BWD, "gemm: bad act %d", d->act);
+    if (d->act == GAOT_ACT_GELU_BWD || d->act == GAOT_ACT_RELU_BWD)
+        GAOT_REQUIRE(d->aux_in != nullptr, "gemm: *_BWD activation needs aux_in");
+    if (d->rowbias) GAOT_REQUIRE(d->rowbias_period > 0, "gemm: rowbias needs rowbias_period > 0");
+    if (d->A2) GAOT_REQUIRE(d->k_split > 0 && d->k_split < d->K && d->k_split % BK == 0,
+                            "gemm: A2 needs 0 < k_split < K and k_split %% %d == 0 (got %d)", BK, d->k_split);
+    const int nkt = cdiv(d->K, BK);
+    int split = d->split_k > 1 ? d->split_k : 1;
+    if (split > nkt) split = nkt;
+    if (split > 1) GAOT_REQUIRE(d->workspace != nullptr, "gemm: split_k > 1 needs a workspace");
+
+    GemmArgs a;
+    a.M = d->M; a.N = d->N; a.K = d->K;
+    a.A = d->A; a.lda = d->lda; a.A2 = d->A2; a.lda2 = d->lda2; a.k_split = d->k_split;
+    a.B = d->B; a.ldb = d->ldb; a.C = d->C; a.ldc = d->ldc;
+    a.bias = d->bias; a.rowbias = d->rowbias; a.rb_period = d->rowbias_period; a.ld_rb = d->ld_rowbias;
+    a.rowscale = d->rowscale; a.act = d->act; a.aux_in = d->aux_in; a.aux_out = d->aux_out; a.ld_aux = d->ld_aux;
+    a.residual = d->residual; a.ldr = d->ldr;
+    a.split_k = split; a.ktiles_per_split = cdiv(nkt, split); a.ws = d->workspace;
+    a.split_k = cdiv(nkt, a.ktiles_per_split);  // no empty splits
+
+    const bool ak = d->a_kmajor != 0, bk = d->b_kmajor != 0;
+    // 16-byte vector path: contiguous extents and leading dims multiples of 4 floats, bases 16B aligned
+    bool vec = aligned16(d->A) && aligned16(d->B) && (d->lda % 4 == 0) && (d->ldb % 4 == 0);
+    vec = vec && (ak ? (d->K % 4 == 0) : (d->M % 4 == 0)) && (bk ? (d->K % 4 == 0) : (d->N % 4 == 0));
+    if (d->A2) vec = vec && aligned16(d->A2) && (d->lda2 % 4 == 0) && ((d->K - d->k_split) % 4 == 0);
+
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // tile choice: the largest tile that still gives every CU (256) a workgroup; skinny N gets a 128x32 tile
+    const long z = a.split_k;
+    auto blocks = [&](int bm, int bn) { return (long)cdiv(a.M, bm) * cdiv(a.N, bn) * z; };
+    if (a.N <= 32)                      launch_cfg<128, 32, 4>(a, ak, bk, vec, st);
+    else if (blocks(128, 128) >= 256)   launch_cfg<128, 128, 2>(a, ak, bk, vec, st);
+    else if (blocks(128, 64) >= 256)    launch_cfg<128, 64, 2>(a, ak, bk, vec, st);
+    else                                launch_cfg<64, 64, 2>(a, ak, bk, vec, st);
+    GAOT_CHECK_LAUNCH("gaot_gemm_f32");
+    if (a.split_k > 1) {
+        const long total = (long)a.M * a.N;
+        int nb = cdiv(total, 256);
+        if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, a);
+        GAOT_CHECK_LAUNCH("gaot_gemm_f32(split-k reduce)");
+    }
+    return GAOT_OK;
+}

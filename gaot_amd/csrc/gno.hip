@@ -1,0 +1,523 @@
+// Graph-neural-operator kernels: geometry plan (int32 CSR, transposed CSR, edge attention, geometry
+// statistics) and the gather / per-edge-weight / segment-reduce integral transform with its two backward
+// products.  All of this is HBM/L2-bound index work: lanes run along the channel dim (16 B per lane,
+// 256 B per feature row), segments are reduced in registers in CSR order (no atomics, deterministic),
+// and workgroups of one batch sample are pinned to one XCD so the sample's feature matrix (N*C*4 B,
+// 4 MiB at the 16k-node config) stays resident in that XCD's private L2.
+#include "common.h"
+
+namespace gaot {
+
+// ---------------------------------------------------------------------------------------------
+// plan: int64 -> int32 CSR + edge -> query map
+// ---------------------------------------------------------------------------------------------
+__global__ void csr_prepare_kernel(const int64_t* __restrict__ idx64, const int64_t* __restrict__ sp64, int Q, int E,
+                                   int n_src, int* __restrict__ idx32, int* __restrict__ sp32,
+                                   int* __restrict__ eq, int* __restrict__ flag) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid <= Q) {
+        const int64_t s = sp64[gid];
+        sp32[gid] = (int)s;
+        if (s < 0 || s > E || (gid > 0 && sp64[gid - 1] > s) || (gid == Q && s != E) || (gid == 0 && s != 0))
+            atomicOr(flag, 1);
+    }
+    if (gid < E) {
+        const int64_t j = idx64[gid];
+        if (j < 0 || j >= n_src) atomicOr(flag, 2);
+        idx32[gid] = (int)j;
+        // upper_bound(splits, gid) - 1
+        int lo = 0, hi = Q;  // invariant: sp[lo] <= gid < sp[hi]  (hi == Q holds since sp[Q] == E > gid)
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (sp64[mid] <= gid) lo = mid; else hi = mid;
+        }
+        eq[gid] = lo;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// plan: transposed CSR (edges grouped by SOURCE node, ascending edge id inside a group)
+// ---------------------------------------------------------------------------------------------
+__global__ void zero_i32_kernel(int* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+__global__ void count_kernel(const int* __restrict__ idx, int E, int* __restrict__ cnt) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E) atomicAdd(&cnt[idx[e]], 1);
+}
+// single-workgroup exclusive scan of cnt[0..n) -> out[0..n]; fine for a once-per-geometry pass
+__global__ __launch_bounds__(1024) void exscan_kernel(const int* __restrict__ cnt, int n, int* __restrict__ out) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int chunk = (n + 1023) / 1024;
+    const int b = t * chunk, e = min(n, b + chunk);
+    int s = 0;
+    for (int i = b; i < e; ++i) s += cnt[i];
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int v = (t >= off) ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = (t == 0) ? 0 : part[t - 1];
+    for (int i = b; i < e; ++i) { out[i] = run; run += cnt[i]; }
+    if (t == 1023) out[n] = part[1023];
+}
+__global__ void fill_kernel(const int* __restrict__ idx, int E, const int* __restrict__ tsp, int* __restrict__ cnt,
+                            int* __restrict__ tedge) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E) {
+        const int j = idx[e];
+        const int slot = atomicSub(&cnt[j], 1) - 1;
+        tedge[tsp[j] + slot] = e;
+    }
+}
+__global__ void sort_segments_kernel(const int* __restrict__ tsp, int n, int* __restrict__ tedge) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int b = tsp[j], e = tsp[j + 1];
+    for (int i = b + 1; i < e; ++i) {  // insertion sort; segments are short
+        const int v = tedge[i];
+        int k = i - 1;
+        while (k >= b && tedge[k] > v) { tedge[k + 1] = tedge[k]; --k; }
+        tedge[k + 1] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// plan: cosine attention + segment softmax (agno.py:112-146,218-224).  One thread per query.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float cos_score(const float* __restrict__ x, const float* __restrict__ y, int dim, float xinv) {
+    float yy = 0.f, xy = 0.f;
+    for (int d = 0; d < dim; ++d) { const float v = y[d]; yy += v * v; }
+    const float yinv = 1.0f / fmaxf(sqrtf(yy), 1e-12f);   // F.normalize: v / max(||v||, eps)
+    for (int d = 0; d < dim; ++d) xy += (x[d] * xinv) * (y[d] * yinv);
+    return xy;
+}
+__global__ void edge_attention_cosine_kernel(const float* __restrict__ src, const float* __restrict__ qry, int dim,
+                                             const int* __restrict__ idx, const int* __restrict__ sp, int Q,
+                                             float* __restrict__ attn) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    const int b = sp[q], e = sp[q + 1];
+    if (b == e) return;
+    const float* x = qry + (long)q * dim;
+    float xx = 0.f;
+    for (int d = 0; d < dim; ++d) xx += x[d] * x[d];
+    const float xinv = 1.0f / fmaxf(sqrtf(xx), 1e-12f);
+    float mx = -INFINITY;
+    for (int t = b; t < e; ++t) {
+        const float s = cos_score(x, src + (long)idx[t] * dim, dim, xinv);
+        attn[t] = s;
+        mx = fmaxf(mx, s);
+    }
+    float den = 0.f;
+    for (int t = b; t < e; ++t) { const float v = expf(attn[t] - mx); attn[t] = v; den += v; }
+    for (int t = b; t < e; ++t) attn[t] = attn[t] / den;
+}
+__global__ void segment_softmax_fwd_kernel(const float* __restrict__ score, const int* __restrict__ sp, int Q,
+                                           float* __restrict__ attn) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    const int b = sp[q], e = sp[q + 1];
+    if (b == e) return;
+    float mx = -INFINITY;
+    for (int t = b; t < e; ++t) mx = fmaxf(mx, score[t]);
+    float den = 0.f;
+    for (int t = b; t < e; ++t) { const float v = expf(score[t] - mx); attn[t] = v; den += v; }
+    for (int t = b; t < e; ++t) attn[t] = attn[t] / den;
+}
+__global__ void segment_softmax_bwd_kernel(const float* __restrict__ attn, const float* __restrict__ dattn,
+                                           const int* __restrict__ sp, int Q, float* __restrict__ dscore) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    const int b = sp[q], e = sp[q + 1];
+    float dot = 0.f;
+    for (int t = b; t < e; ++t) dot += attn[t] * dattn[t];
+    for (int t = b; t < e; ++t) dscore[t] = attn[t] * (dattn[t] - dot);
+}
+
+__global__ void edge_features_kernel(const float* __restrict__ src, const float* __restrict__ qry, int dim,
+                                     const int* __restrict__ idx, const int* __restrict__ eq, int E,
+                                     float* __restrict__ feat) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int w = 2 * dim;
+    if (gid >= (long)E * w) return;
+    const int e = (int)(gid / w), c = (int)(gid % w);
+    feat[gid] = (c < dim) ? src[(long)idx[e] * dim + c] : qry[(long)eq[e] * dim + (c - dim)];
+}
+
+// ---------------------------------------------------------------------------------------------
+// plan: geometry statistics (gemb.py:83-171).  fp64 inside (once per geometry), fp32 out.
+// ---------------------------------------------------------------------------------------------
+template <int DIM>
+__device__ void sym_eig_desc(const double (&c)[DIM][DIM], double (&ev)[DIM]);
+
+template <>
+__device__ void sym_eig_desc<2>(const double (&c)[2][2], double (&ev)[2]) {
+    const double tr = 0.5 * (c[0][0] + c[1][1]);
+    const double df = 0.5 * (c[0][0] - c[1][1]);
+    const double rad = sqrt(df * df + c[0][1] * c[0][1]);
+    ev[0] = tr + rad;
+    ev[1] = tr - rad;
+}
+template <>
+__device__ void sym_eig_desc<3>(const double (&c)[3][3], double (&ev)[3]) {
+    double a[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) a[i][j] = c[i][j];
+    for (int sweep = 0; sweep < 12; ++sweep) {           // cyclic Jacobi
+        const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+        const double dg = a[0][0] * a[0][0] + a[1][1] * a[1][1] + a[2][2] * a[2][2];
+        if (off <= 1e-40 * (dg + 1e-300) || off == 0.0) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (a[p][q] == 0.0) continue;
+                const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+                for (int k = 0; k < 3; ++k) {            // A <- A J
+                    const double akp = a[k][p], akq = a[k][q];
+                    a[k][p] = cs * akp - sn * akq;
+                    a[k][q] = sn * akp + cs * akq;
+                }
+                for (int k = 0; k < 3; ++k) {            // A <- J^T A
+                    const double apk = a[p][k], aqk = a[q][k];
+                    a[p][k] = cs * apk - sn * aqk;
+                    a[q][k] = sn * apk + cs * aqk;
+                }
+            }
+    }
+    double e0 = a[0][0], e1 = a[1][1], e2 = a[2][2], t;
+    if (e0 < e1) { t = e0; e0 = e1; e1 = t; }
+    if (e1 < e2) { t = e1; e1 = e2; e2 = t; }
+    if (e0 < e1) { t = e0; e0 = e1; e1 = t; }
+    ev[0] = e0; ev[1] = e1; ev[2] = e2;
+}
+
+template <int DIM>
+__global__ void geo_stats_raw_kernel(const float* __restrict__ geom, const float* __restrict__ qry,
+                                     const int* __restrict__ idx, const int* __restrict__ sp, int Q,
+                                     float* __restrict__ raw) {
+    constexpr int F = 3 + 2 * DIM;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    float* o = raw + (long)q * F;
+    const int b = sp[q], e = sp[q + 1];
+    const int n = e - b;
+    if (n == 0) { for (int f = 0; f < F; ++f) o[f] = 0.f; return; }
+    double x[DIM], cen[DIM];
+    for (int d = 0; d < DIM; ++d) { x[d] = qry[(long)q * DIM + d]; cen[d] = 0.0; }
+    double sd = 0.0, sd2 = 0.0;
+    for (int t = b; t < e; ++t) {
+        const float* y = geom + (long)idx[t] * DIM;
+        double d2 = 0.0;
+        for (int d = 0; d < DIM; ++d) { const double dv = (double)y[d] - x[d]; d2 += dv * dv; cen[d] += y[d]; }
+        sd += sqrt(d2);
+        sd2 += d2;
+    }
+    const double inv = 1.0 / n;
+    for (int d = 0; d < DIM; ++d) cen[d] *= inv;
+    double cov[DIM][DIM];
+    for (int i = 0; i < DIM; ++i) for (int j = 0; j < DIM; ++j) cov[i][j] = 0.0;
+    for (int t = b; t < e; ++t) {
+        const float* y = geom + (long)idx[t] * DIM;
+        double c[DIM];
+        for (int d = 0; d < DIM; ++d) c[d] = (double)y[d] - cen[d];
+        for (int i = 0; i < DIM; ++i) for (int j = 0; j < DIM; ++j) cov[i][j] += c[i] * c[j];
+    }
+    for (int i = 0; i < DIM; ++i) for (int j = 0; j < DIM; ++j) cov[i][j] *= inv;
+    double ev[DIM];
+    sym_eig_desc<DIM>(cov, ev);
+    const double mean = sd * inv;
+    double var = sd2 * inv - mean * mean;
+    if (var < 0.0) var = 0.0;
+    o[0] = (float)n; o[1] = (float)mean; o[2] = (float)var;
+    for (int d = 0; d < DIM; ++d) { o[3 + d] = (float)(cen[d] - x[d]); o[3 + DIM + d] = (float)ev[d]; }
+}
+// column sums (pass 0: sum x -> acc[f]; pass 1: sum (x-mean)^2 -> acc[F+f]) in fp64 via block reduce + atomics
+__global__ __launch_bounds__(256) void geo_colstat_kernel(const float* __restrict__ raw, int Q, int F, int pass,
+                                                          double* __restrict__ acc) {
+    __shared__ double red[4];
+    for (int f = 0; f < F; ++f) {
+        const double mean = pass ? acc[f] / Q : 0.0;
+        double s = 0.0;
+        for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < Q; q += gridDim.x * blockDim.x) {
+            const double v = raw[(long)q * F + f];
+            s += pass ? (v - mean) * (v - mean) : v;
+        }
+        s = wave_sum_d(s);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(&acc[pass * F + f], red[0] + red[1] + red[2] + red[3]);
+        __syncthreads();
+    }
+}
+__global__ void zero_f64_kernel(double* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.0;
+}
+__global__ void geo_standardise_kernel(float* __restrict__ raw, int Q, int F, const double* __restrict__ acc) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)Q * F) return;
+    const int f = (int)(gid % F);
+    const double mean = acc[f] / Q;
+    // torch.std: unbiased; cast to fp32 before the 1e-6 test like the reference's fp32 tensor (gemb.py:165-166)
+    float sd = (float)sqrt(acc[F + f] / (double)(Q - 1));
+    if (sd < 1e-6f) sd = 1.0f;
+    raw[gid] = (float)(((double)raw[gid] - mean) / (double)sd);
+}
+
+// ---------------------------------------------------------------------------------------------
+// integral transform: out[b,r,:] = sum_t escale[edge(t)] * w[edge(t),:] * src[b, col(t), :]
+// one thread per (r, b, channel-vector); workgroup id -> (row block, b) with b = id % B so that with
+// B == 8 sample b lives on XCD b (dispatcher places workgroup id on XCD id % 8).
+// ---------------------------------------------------------------------------------------------
+template <int VW> struct Vec;
+template <> struct Vec<4> { typedef f32x4 T; };
+template <> struct Vec<2> { typedef float T __attribute__((ext_vector_type(2))); };
+template <> struct Vec<1> { typedef float T; };
+
+template <int VW> __device__ __forceinline__ typename Vec<VW>::T vzero();
+template <> __device__ __forceinline__ f32x4 vzero<4>() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+template <> __device__ __forceinline__ Vec<2>::T vzero<2>() { return Vec<2>::T{0.f, 0.f}; }
+template <> __device__ __forceinline__ float vzero<1>() { return 0.f; }
+
+template <int VW, bool HAS_W, bool HAS_MAP>
+__global__ __launch_bounds__(256) void gather_reduce_kernel(const float* __restrict__ w, const float* __restrict__ src,
+                                                            int B, int n_src_rows, int C,
+                                                            const int* __restrict__ sp, const int* __restrict__ cols,
+                                                            const int* __restrict__ emap, int n_out,
+                                                            const float* __restrict__ escale, float* __restrict__ out,
+                                                            int lanes_per_row, int rows_per_block) {
+    typedef typename Vec<VW>::T V;
+    const int b = blockIdx.x % B;
+    const int rblk = blockIdx.x / B;
+    const int r = rblk * rows_per_block + threadIdx.x / lanes_per_row;
+    const int c = (threadIdx.x % lanes_per_row) * VW;
+    if (r >= n_out || c >= C) return;
+    const int t0 = sp[r], t1 = sp[r + 1];
+    const float* sb = src + (long)b * n_src_rows * C + c;
+    V acc = vzero<VW>();
+    int t = t0;
+    for (; t + 1 < t1; t += 2) {   // two edges in flight
+        const int e0 = HAS_MAP ? emap[t] : t, e1 = HAS_MAP ? emap[t + 1] : t + 1;
+        const int j0 = cols[e0], j1 = cols[e1];
+        V s0 = *reinterpret_cast<const V*>(sb + (long)j0 * C);
+        V s1 = *reinterpret_cast<const V*>(sb + (long)j1 * C);
+        if (escale) { s0 *= escale[e0]; s1 *= escale[e1]; }
+        if (HAS_W) {
+            const V w0 = *reinterpret_cast<const V*>(w + (long)e0 * C + c);
+            const V w1 = *reinterpret_cast<const V*>(w + (long)e1 * C + c);
+            acc += w0 * s0;
+            acc += w1 * s1;
+        } else { acc += s0; acc += s1; }
+    }
+    if (t < t1) {
+        const int e0 = HAS_MAP ? emap[t] : t;
+        const int j0 = cols[e0];
+        V s0 = *reinterpret_cast<const V*>(sb + (long)j0 * C);
+        if (escale) s0 *= escale[e0];
+        if (HAS_W) acc += (*reinterpret_cast<const V*>(w + (long)e0 * C + c)) * s0;
+        else acc += s0;
+    }
+    *reinterpret_cast<V*>(out + ((long)b * n_out + r) * C + c) = acc;
+}
+
+// dW[e,:] = escale[e] * sum_b dOut[b, eq[e], :] * f[b, idx[e], :]
+template <int VW>
+__global__ __launch_bounds__(256) void edge_grad_kernel(const float* __restrict__ dout, const float* __restrict__ f,
+                                                        int B, int Q, int n_src, int C, const int* __restrict__ idx,
+                                                        const int* __restrict__ eq, int E,
+                                                        const float* __restrict__ escale, float* __restrict__ dw,
+                                                        int lanes_per_row, int rows_per_block) {
+    typedef typename Vec<VW>::T V;
+    const int e = blockIdx.x * rows_per_block + threadIdx.x / lanes_per_row;
+    const int c = (threadIdx.x % lanes_per_row) * VW;
+    if (e >= E || c >= C) return;
+    const int q = eq[e], j = idx[e];
+    V acc = vzero<VW>();
+    for (int b = 0; b < B; ++b) {
+        const V g = *reinterpret_cast<const V*>(dout + ((long)b * Q + q) * C + c);
+        const V v = *reinterpret_cast<const V*>(f + ((long)b * n_src + j) * C + c);
+        acc += g * v;
+    }
+    if (escale) acc *= escale[e];
+    *reinterpret_cast<V*>(dw + (long)e * C + c) = acc;
+}
+
+// out[b,q,:] = rowscale[q] * sum_{e in seg(q)} x[b,e,:]
+template <int VW>
+__global__ __launch_bounds__(256) void segment_sum_kernel(const float* __restrict__ x, int B, int E, int C,
+                                                          const int* __restrict__ sp, int Q,
+                                                          const float* __restrict__ rowscale, float* __restrict__ out,
+                                                          int lanes_per_row, int rows_per_block) {
+    typedef typename Vec<VW>::T V;
+    const int b = blockIdx.x % B;
+    const int q = (blockIdx.x / B) * rows_per_block + threadIdx.x / lanes_per_row;
+    const int c = (threadIdx.x % lanes_per_row) * VW;
+    if (q >= Q || c >= C) return;
+    V acc = vzero<VW>();
+    const float* xb = x + (long)b * E * C + c;
+    for (int t = sp[q]; t < sp[q + 1]; ++t) acc += *reinterpret_cast<const V*>(xb + (long)t * C);
+    if (rowscale) acc *= rowscale[q];
+    *reinterpret_cast<V*>(out + ((long)b * Q + q) * C + c) = acc;
+}
+
+static inline int pow2_ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+static inline int pick_vw(int C, const void* a, const void* b, const void* c) {
+    if (C % 4 == 0 && aligned16(a) && aligned16(b) && aligned16(c)) return 4;
+    if (C % 2 == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 7u) == 0) return 2;
+    return 1;
+}
+
+}  // namespace gaot
+
+using namespace gaot;
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int gaot_csr_prepare(const int64_t* index_i64, const int64_t* splits_i64, int32_t Q, int32_t E, int32_t n_src,
+                                int32_t* index32, int32_t* splits32, int32_t* edge_query, int32_t* status_flag,
+                                gaot_stream_t stream) {
+    GAOT_REQUIRE(splits_i64 && splits32 && status_flag, "csr_prepare: null pointer");
+    GAOT_REQUIRE(Q >= 0 && E >= 0 && n_src >= 0, "csr_prepare: negative size");
+    GAOT_REQUIRE(E == 0 || (index_i64 && index32 && edge_query), "csr_prepare: null index pointer with E > 0");
+    const int n = (E > Q + 1) ? E : Q + 1;
+    hipLaunchKernelGGL(zero_i32_kernel, dim3(1), dim3(64), 0, ST(stream), status_flag, 1);
+    hipLaunchKernelGGL(csr_prepare_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ST(stream), index_i64, splits_i64, Q, E,
+                       n_src, index32, splits32, edge_query, status_flag);
+    GAOT_CHECK_LAUNCH("gaot_csr_prepare");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_csr_transpose(const int32_t* index32, int32_t E, int32_t n_src, int32_t* t_splits, int32_t* t_edge,
+                                  int32_t* scratch, gaot_stream_t stream) {
+    GAOT_REQUIRE(t_splits && scratch && n_src > 0 && E >= 0, "csr_transpose: bad arguments");
+    hipLaunchKernelGGL(zero_i32_kernel, dim3(cdiv(n_src + 1, 256)), dim3(256), 0, ST(stream), scratch, n_src + 1);
+    if (E > 0) hipLaunchKernelGGL(count_kernel, dim3(cdiv(E, 256)), dim3(256), 0, ST(stream), index32, E, scratch);
+    hipLaunchKernelGGL(exscan_kernel, dim3(1), dim3(1024), 0, ST(stream), scratch, n_src, t_splits);
+    if (E > 0) {
+        hipLaunchKernelGGL(fill_kernel, dim3(cdiv(E, 256)), dim3(256), 0, ST(stream), index32, E, t_splits, scratch, t_edge);
+        hipLaunchKernelGGL(sort_segments_kernel, dim3(cdiv(n_src, 256)), dim3(256), 0, ST(stream), t_splits, n_src, t_edge);
+    }
+    GAOT_CHECK_LAUNCH("gaot_csr_transpose");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_edge_attention_cosine(const float* src, const float* qry, int32_t dim, const int32_t* index32,
+                                          const int32_t* splits32, int32_t Q, float* attn, gaot_stream_t stream) {
+    GAOT_REQUIRE(src && qry && splits32 && dim > 0 && Q >= 0, "edge_attention_cosine: bad arguments");
+    if (Q == 0) return GAOT_OK;
+    hipLaunchKernelGGL(edge_attention_cosine_kernel, dim3(cdiv(Q, 128)), dim3(128), 0, ST(stream), src, qry, dim,
+                       index32, splits32, Q, attn);
+    GAOT_CHECK_LAUNCH("gaot_edge_attention_cosine");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_segment_softmax_fwd(const float* score, const int32_t* splits32, int32_t Q, float* attn,
+                                        gaot_stream_t stream) {
+    GAOT_REQUIRE(splits32 && Q >= 0, "segment_softmax_fwd: bad arguments");
+    if (Q == 0) return GAOT_OK;
+    hipLaunchKernelGGL(segment_softmax_fwd_kernel, dim3(cdiv(Q, 128)), dim3(128), 0, ST(stream), score, splits32, Q, attn);
+    GAOT_CHECK_LAUNCH("gaot_segment_softmax_fwd");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_segment_softmax_bwd(const float* attn, const float* dattn, const int32_t* splits32, int32_t Q,
+                                        float* dscore, gaot_stream_t stream) {
+    GAOT_REQUIRE(splits32 && Q >= 0, "segment_softmax_bwd: bad arguments");
+    if (Q == 0) return GAOT_OK;
+    hipLaunchKernelGGL(segment_softmax_bwd_kernel, dim3(cdiv(Q, 128)), dim3(128), 0, ST(stream), attn, dattn, splits32, Q,
+                       dscore);
+    GAOT_CHECK_LAUNCH("gaot_segment_softmax_bwd");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_edge_features(const float* src, const float* qry, int32_t dim, const int32_t* index32,
+                                  const int32_t* edge_query, int32_t E, float* feat, gaot_stream_t stream) {
+    GAOT_REQUIRE(dim > 0 && E >= 0, "edge_features: bad arguments");
+    if (E == 0) return GAOT_OK;
+    GAOT_REQUIRE(src && qry && index32 && edge_query && feat, "edge_features: null pointer");
+    hipLaunchKernelGGL(edge_features_kernel, dim3(cdiv((long)E * 2 * dim, 256)), dim3(256), 0, ST(stream), src, qry, dim,
+                       index32, edge_query, E, feat);
+    GAOT_CHECK_LAUNCH("gaot_edge_features");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_geo_stats(const float* geom, const float* qry, int32_t dim, const int32_t* index32,
+                              const int32_t* splits32, int32_t Q, float* stats, double* scratch, gaot_stream_t stream) {
+    GAOT_REQUIRE(dim == 2 || dim == 3, "geo_stats: coord dim must be 2 or 3 (got %d)", dim);
+    GAOT_REQUIRE(geom && qry && splits32 && stats && scratch && Q > 0, "geo_stats: bad arguments");
+    const int F = 3 + 2 * dim;
+    if (dim == 2)
+        hipLaunchKernelGGL(geo_stats_raw_kernel<2>, dim3(cdiv(Q, 128)), dim3(128), 0, ST(stream), geom, qry, index32, splits32, Q, stats);
+    else
+        hipLaunchKernelGGL(geo_stats_raw_kernel<3>, dim3(cdiv(Q, 128)), dim3(128), 0, ST(stream), geom, qry, index32, splits32, Q, stats);
+    hipLaunchKernelGGL(zero_f64_kernel, dim3(1), dim3(64), 0, ST(stream), scratch, 2 * F);
+    int nb = cdiv(Q, 256); if (nb > 256) nb = 256;
+    hipLaunchKernelGGL(geo_colstat_kernel, dim3(nb), dim3(256), 0, ST(stream), stats, Q, F, 0, scratch);
+    hipLaunchKernelGGL(geo_colstat_kernel, dim3(nb), dim3(256), 0, ST(stream), stats, Q, F, 1, scratch);
+    hipLaunchKernelGGL(geo_standardise_kernel, dim3(cdiv((long)Q * F, 256)), dim3(256), 0, ST(stream), stats, Q, F, scratch);
+    GAOT_CHECK_LAUNCH("gaot_geo_stats");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_gno_gather_reduce(const float* w, const float* src, int32_t B, int32_t n_src_rows, int32_t C,
+                                      const int32_t* splits, const int32_t* cols, const int32_t* edge_map,
+                                      int32_t n_out_rows, const float* escale, float* out, gaot_stream_t stream) {
+    GAOT_REQUIRE(src && splits && out, "gno_gather_reduce: null pointer");
+    GAOT_REQUIRE(B > 0 && C > 0 && n_out_rows >= 0 && n_src_rows >= 0, "gno_gather_reduce: bad sizes");
+    if (n_out_rows == 0) return GAOT_OK;
+    const int vw = pick_vw(C, w ? (const void*)w : (const void*)src, src, out);
+    const int lpr = pow2_ceil(cdiv(C, vw));
+    GAOT_REQUIRE(lpr <= 256, "gno_gather_reduce: channel count %d too large", C);
+    const int rpb = 256 / lpr;
+    dim3 grid((unsigned)(cdiv(n_out_rows, rpb) * (long)B)), block(256);
+#define GR(VW, HW, HM) hipLaunchKernelGGL((gather_reduce_kernel<VW, HW, HM>), grid, block, 0, ST(stream), w, src, B, \
+                                          n_src_rows, C, splits, cols, edge_map, n_out_rows, escale, out, lpr, rpb)
+#define GR_V(VW) do { if (w && edge_map) GR(VW, true, true); else if (w) GR(VW, true, false); \
+                      else if (edge_map) GR(VW, false, true); else GR(VW, false, false); } while (0)
+    if (vw == 4) GR_V(4); else if (vw == 2) GR_V(2); else GR_V(1);
+#undef GR_V
+#undef GR
+    GAOT_CHECK_LAUNCH("gaot_gno_gather_reduce");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_gno_edge_grad(const float* dout, const float* f, int32_t B, int32_t Q, int32_t n_src, int32_t C,
+                                  const int32_t* index32, const int32_t* edge_query, int32_t E, const float* escale,
+                                  float* dw, gaot_stream_t stream) {
+    GAOT_REQUIRE(B > 0 && C > 0 && E >= 0, "gno_edge_grad: bad sizes");
+    if (E == 0) return GAOT_OK;
+    GAOT_REQUIRE(dout && f && index32 && edge_query && dw, "gno_edge_grad: null pointer");
+    const int vw = pick_vw(C, dout, f, dw);
+    const int lpr = pow2_ceil(cdiv(C, vw));
+    GAOT_REQUIRE(lpr <= 256, "gno_edge_grad: channel count %d too large", C);
+    const int rpb = 256 / lpr;
+    dim3 grid(cdiv(E, rpb)), block(256);
+#define EG(VW) hipLaunchKernelGGL((edge_grad_kernel<VW>), grid, block, 0, ST(stream), dout, f, B, Q, n_src, C, index32, \
+                                  edge_query, E, escale, dw, lpr, rpb)
+    if (vw == 4) EG(4); else if (vw == 2) EG(2); else EG(1);
+#undef EG
+    GAOT_CHECK_LAUNCH("gaot_gno_edge_grad");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_gno_segment_sum(const float* x, int32_t B, int32_t E, int32_t C, const int32_t* splits, int32_t Q,
+                                    const float* rowscale, float* out, gaot_stream_t stream) {
+    GAOT_REQUIRE(B > 0 && C > 0 && Q >= 0 && E >= 0, "gno_segment_sum: bad sizes");
+    if (Q == 0) return GAOT_OK;
+    GAOT_REQUIRE(splits && out, "gno_segment_sum: null pointer");
+    const int vw = pick_vw(C, x ? (const void*)x : (const void*)out, out, out);
+    const int lpr = pow2_ceil(cdiv(C, vw));
+    GAOT_REQUIRE(lpr <= 256, "gno_segment_sum: channel count %d too large", C);
+    const int rpb = 256 / lpr;
+    dim3 grid((unsigned)(cdiv(Q, rpb) * (long)B)), block(256);
+#define SS(VW) hipLaunchKernelGGL((segment_sum_kernel<VW>), grid, block, 0, ST(stream), x, B, E, C, splits, Q, rowscale, out, lpr, rpb)
+    if (vw == 4) SS(4); else if (vw == 2) SS(2); else SS(1);
+#undef SS
+    GAOT_CHECK_LAUNCH("gaot_gno_segment_sum");
+    return GAOT_OK;
+}

@@ -1,0 +1,242 @@
+// HBM-bound row/elementwise kernels of the processor: RMSNorm fwd/bwd, SwiGLU gate fwd/bwd, column and
+// batch reductions (bias gradients), patchify / unpatchify.  One wave per row, lanes along the feature
+// dim (coalesced 256 B per wave-load), wave reductions by DPP shuffles.
+#include "common.h"
+
+namespace gaot {
+
+// ---------------------------------------------------------------- RMSNorm (attn.py:161-172)
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          int M, int D, float eps, float* __restrict__ y,
+                                                          float* __restrict__ rstd) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float* xr = x + (long)row * D;
+    float ss = 0.f;
+    for (int d = lane; d < D; d += 64) { const float v = xr[d]; ss += v * v; }
+    ss = wave_sum(ss);
+    const float r = rsqrtf(ss / (float)D + eps);
+    if (lane == 0) rstd[row] = r;
+    float* yr = y + (long)row * D;
+    for (int d = lane; d < D; d += 64) yr[d] = xr[d] * r * w[d];
+}
+
+constexpr int RMS_ROWS_PER_BLOCK = 32;
+constexpr int RMS_MAX_D = 2048;
+
+// dx = r*(w*dy) - x*r^3*mean(w*dy*x) (+dx_add) ; dw partial per block = sum_rows dy*x*r
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ rstd, const float* __restrict__ dy,
+                                                          const float* __restrict__ dx_add, int M, int D,
+                                                          float* __restrict__ dx, float* __restrict__ dwp) {
+    __shared__ float red[4][RMS_MAX_D];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float dwacc[RMS_MAX_D / 64];
+#pragma unroll
+    for (int i = 0; i < RMS_MAX_D / 64; ++i) dwacc[i] = 0.f;
+    const int row_base = blockIdx.x * RMS_ROWS_PER_BLOCK;
+    for (int rr = wave; rr < RMS_ROWS_PER_BLOCK; rr += 4) {
+        const int row = row_base + rr;
+        if (row >= M) break;
+        const float* xr = x + (long)row * D;
+        const float* gr = dy + (long)row * D;
+        const float r = rstd[row];
+        float dot = 0.f;
+        for (int d = lane; d < D; d += 64) dot += w[d] * gr[d] * xr[d];
+        dot = wave_sum(dot);
+        const float coef = r * r * r * dot / (float)D;
+        float* or_ = dx + (long)row * D;
+        const float* ar = dx_add ? dx_add + (long)row * D : nullptr;
+#pragma unroll
+        for (int i = 0; i < RMS_MAX_D / 64; ++i) {
+            const int d = lane + i * 64;
+            if (d < D) {
+                const float xv = xr[d], gv = gr[d];
+                float v = r * w[d] * gv - xv * coef;
+                if (ar) v += ar[d];
+                or_[d] = v;
+                dwacc[i] += gv * xv * r;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < RMS_MAX_D / 64; ++i) {
+        const int d = lane + i * 64;
+        if (d < D) red[wave][d] = dwacc[i];
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += 256)
+        dwp[(long)blockIdx.x * D + d] = red[0][d] + red[1][d] + red[2][d] + red[3][d];
+}
+
+// ---------------------------------------------------------------- SwiGLU gate (attn.py:151)
+__global__ void swiglu_fwd_kernel(const float* __restrict__ u, long M, int F, float* __restrict__ g) {
+    const long total4 = M * F / 4;
+    const int F4 = F / 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / F4;
+        const int f = (int)(i % F4) * 4;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(u + m * 2 * F + f);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(u + m * 2 * F + F + f);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (a[j] / (1.0f + expf(-a[j]))) * b[j];
+        *reinterpret_cast<f32x4*>(g + m * F + f) = o;
+    }
+}
+__global__ void swiglu_bwd_kernel(const float* __restrict__ u, const float* __restrict__ dg, long M, int F,
+                                  float* __restrict__ du) {
+    const long total4 = M * F / 4;
+    const int F4 = F / 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / F4;
+        const int f = (int)(i % F4) * 4;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(u + m * 2 * F + f);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(u + m * 2 * F + F + f);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dg + m * F + f);
+        f32x4 d1, d3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float sg = 1.0f / (1.0f + expf(-a[j]));
+            d1[j] = g[j] * b[j] * sg * (1.0f + a[j] * (1.0f - sg));
+            d3[j] = g[j] * a[j] * sg;
+        }
+        *reinterpret_cast<f32x4*>(du + m * 2 * F + f) = d1;
+        *reinterpret_cast<f32x4*>(du + m * 2 * F + F + f) = d3;
+    }
+}
+
+// ---------------------------------------------------------------- reductions
+constexpr int COLSUM_ROWS = 128;
+// partial[p, n] = sum over rows [p*128, p*128+128) ; block = 4 waves x 64 columns
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, long ld, int M, int N,
+                                                             float* __restrict__ part) {
+    __shared__ float red[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * COLSUM_ROWS;
+    float s = 0.f;
+    if (n < N)
+        for (int r = r0 + wave; r < min(M, r0 + COLSUM_ROWS); r += 4) s += x[(long)r * ld + n];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && n < N) part[(long)blockIdx.y * N + n] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int P, int N, float* __restrict__ out) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += part[(long)p * N + n];
+    out[n] = s;
+}
+__global__ void batchsum_kernel(const float* __restrict__ x, int B, long RN, float* __restrict__ out) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < RN; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += x[(long)b * RN + i];
+        out[i] = s;
+    }
+}
+
+// ---------------------------------------------------------------- patchify (gaot.py:182-185,202-205,224-231)
+// tokens[b, s, k]: s = patch id (row-major over patch grid), k = (within-patch offsets row-major, c)
+__global__ void patchify_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int Dz,
+                                int P, int C, int inverse) {
+    const int dim = Dz > 0 ? 3 : 2;
+    const int D1 = Dz > 0 ? Dz : 1;
+    const long nodes = (long)H * W * D1;
+    const long total = (long)B * nodes * C;
+    const int pw = W / P, pd = D1 > 1 ? D1 / P : 1;
+    const int pvol = dim == 3 ? P * P * P : P * P;
+    for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long)gridDim.x * blockDim.x) {
+        // gid enumerates the GRID layout [b, node, c]
+        const int c = (int)(gid % C);
+        const long node = (gid / C) % nodes;
+        const long b = gid / (C * nodes);
+        int h, w_, z = 0;
+        if (dim == 3) { z = (int)(node % D1); w_ = (int)((node / D1) % W); h = (int)(node / ((long)D1 * W)); }
+        else { w_ = (int)(node % W); h = (int)(node / W); }
+        const int ph = h / P, i = h % P, pwi = w_ / P, j = w_ % P;
+        long s, k;
+        if (dim == 3) {
+            const int pz = z / P, l = z % P;
+            s = ((long)ph * pw + pwi) * pd + pz;
+            k = (((long)i * P + j) * P + l) * C + c;
+        } else {
+            s = (long)ph * pw + pwi;
+            k = ((long)i * P + j) * C + c;
+        }
+        const long tok = (b * (nodes / pvol) + s) * ((long)pvol * C) + k;
+        if (inverse) out[gid] = in[tok]; else out[tok] = in[gid];
+    }
+}
+
+}  // namespace gaot
+
+using namespace gaot;
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+static inline int cap_blocks(long n, int per, int cap) { long b = (n + per - 1) / per; return (int)(b > cap ? cap : (b < 1 ? 1 : b)); }
+
+extern "C" int gaot_rmsnorm_fwd(const float* x, const float* w, int32_t M, int32_t D, float eps, float* y, float* rstd,
+                                gaot_stream_t stream) {
+    GAOT_REQUIRE(x && w && y && rstd && M > 0 && D > 0, "rmsnorm_fwd: bad arguments");
+    hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, ST(stream), x, w, M, D, eps, y, rstd);
+    GAOT_CHECK_LAUNCH("gaot_rmsnorm_fwd");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_rmsnorm_bwd_partials(int32_t M) { return cdiv(M, RMS_ROWS_PER_BLOCK); }
+
+extern "C" int gaot_rmsnorm_bwd(const float* x, const float* w, const float* rstd, const float* dy, const float* dx_add,
+                                int32_t M, int32_t D, float* dx, float* dw_partial, gaot_stream_t stream) {
+    GAOT_REQUIRE(x && w && rstd && dy && dx && dw_partial && M > 0 && D > 0, "rmsnorm_bwd: bad arguments");
+    GAOT_REQUIRE(D <= RMS_MAX_D, "rmsnorm_bwd: D=%d exceeds %d", D, RMS_MAX_D);
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(cdiv(M, RMS_ROWS_PER_BLOCK)), dim3(256), 0, ST(stream), x, w, rstd, dy,
+                       dx_add, M, D, dx, dw_partial);
+    GAOT_CHECK_LAUNCH("gaot_rmsnorm_bwd");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_swiglu_fwd(const float* u, int32_t M, int32_t F, float* g, gaot_stream_t stream) {
+    GAOT_REQUIRE(u && g && M > 0 && F > 0 && F % 4 == 0 && aligned16(u) && aligned16(g), "swiglu_fwd: bad arguments (F %% 4 == 0, 16B aligned)");
+    hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(cap_blocks((long)M * F / 4, 256, 4096)), dim3(256), 0, ST(stream), u, (long)M, F, g);
+    GAOT_CHECK_LAUNCH("gaot_swiglu_fwd");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_swiglu_bwd(const float* u, const float* dg, int32_t M, int32_t F, float* du, gaot_stream_t stream) {
+    GAOT_REQUIRE(u && dg && du && M > 0 && F > 0 && F % 4 == 0 && aligned16(u) && aligned16(dg) && aligned16(du),
+                 "swiglu_bwd: bad arguments (F %% 4 == 0, 16B aligned)");
+    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(cap_blocks((long)M * F / 4, 256, 4096)), dim3(256), 0, ST(stream), u, dg, (long)M, F, du);
+    GAOT_CHECK_LAUNCH("gaot_swiglu_bwd");
+    return GAOT_OK;
+}
+
+extern "C" int64_t gaot_colsum_scratch(int32_t M, int32_t N) { return (int64_t)cdiv(M, COLSUM_ROWS) * N; }
+
+extern "C" int gaot_colsum(const float* x, int64_t ld, int32_t M, int32_t N, float* out, float* scratch,
+                           gaot_stream_t stream) {
+    GAOT_REQUIRE(x && out && scratch && M > 0 && N > 0, "colsum: bad arguments");
+    const int P = cdiv(M, COLSUM_ROWS);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 64), P), dim3(256), 0, ST(stream), x, (long)ld, M, N, scratch);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, ST(stream), scratch, P, N, out);
+    GAOT_CHECK_LAUNCH("gaot_colsum");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_batchsum(const float* x, int32_t B, int64_t RN, float* out, gaot_stream_t stream) {
+    GAOT_REQUIRE(x && out && B > 0 && RN > 0, "batchsum: bad arguments");
+    hipLaunchKernelGGL(batchsum_kernel, dim3(cap_blocks(RN, 256, 4096)), dim3(256), 0, ST(stream), x, B, (long)RN, out);
+    GAOT_CHECK_LAUNCH("gaot_batchsum");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_patchify(const float* in, int32_t B, int32_t H, int32_t W, int32_t Dz, int32_t P, int32_t C,
+                             float* out, int32_t inverse, gaot_stream_t stream) {
+    GAOT_REQUIRE(in && out && B > 0 && H > 0 && W > 0 && Dz >= 0 && P > 0 && C > 0, "patchify: bad arguments");
+    GAOT_REQUIRE(H % P == 0 && W % P == 0 && (Dz == 0 || Dz % P == 0), "patchify: grid %dx%dx%d not divisible by patch %d", H, W, Dz, P);
+    const long total = (long)B * H * W * (Dz > 0 ? Dz : 1) * C;
+    hipLaunchKernelGGL(patchify_kernel, dim3(cap_blocks(total, 256, 8192)), dim3(256), 0, ST(stream), in, out, B, H, W, Dz, P, C, inverse);
+    GAOT_CHECK_LAUNCH("gaot_patchify");
+    return GAOT_OK;
+}

@@ -1,0 +1,153 @@
+"""GAOT = MAGNO encoder -> patch ViT processor -> MAGNO decoder, with the reference's operator API
+(reference src/model/gaot.py: constructor, forward / encode / process / decode / autoregressive_predict, and
+state_dict keys), running on libgaot_hip.so."""
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .layers.attn import Transformer
+from .layers.magno import MAGNODecoder, MAGNOEncoder
+
+
+class GAOT(nn.Module):
+    def __init__(self, input_size: int, output_size: int, config=None):
+        super().__init__()
+        magno_cfg = config.args.magno
+        tf_cfg = config.args.transformer
+        coord_dim = magno_cfg.coord_dim
+        if coord_dim not in (2, 3):
+            raise ValueError(f"coord_dim must be 2 or 3, got {coord_dim}")
+        lts = list(config.latent_tokens_size)
+        if len(lts) != coord_dim:
+            raise ValueError(f"For {coord_dim}D, latent_tokens_size must have {coord_dim} dimensions, got {len(lts)}")
+        self.input_size = input_size
+        self.output_size = output_size
+        self.coord_dim = coord_dim
+        self.node_latent_size = magno_cfg.lifting_channels
+        self.patch_size = tf_cfg.patch_size
+        self.H, self.W = lts[0], lts[1]
+        self.D = lts[2] if coord_dim == 3 else None
+        self.encoder = self.init_encoder(input_size, self.node_latent_size, magno_cfg)
+        self.processor = self.init_processor(self.node_latent_size, tf_cfg)
+        self.decoder = self.init_decoder(output_size, self.node_latent_size, magno_cfg)
+
+    # ---- construction (same order as the reference so a seeded build draws identical weights)
+    def init_encoder(self, input_size, latent_size, config):
+        return MAGNOEncoder(in_channels=input_size, out_channels=latent_size, config=config)
+
+    def init_processor(self, node_latent_size, config):
+        tok = (self.patch_size ** self.coord_dim) * node_latent_size
+        self.patch_linear = nn.Linear(tok, tok)
+        self.positional_embedding_name = config.positional_embedding
+        self.positions = self._get_patch_positions()         # plain attribute, not a buffer (not in state_dict)
+        self._pos_emb_cache = None
+        return Transformer(input_size=tok, output_size=tok, config=config)
+
+    def init_decoder(self, output_size, latent_size, config):
+        return MAGNODecoder(in_channels=latent_size, out_channels=output_size, config=config)
+
+    def _grid_sizes(self) -> List[int]:
+        return [self.H, self.W] if self.coord_dim == 2 else [self.H, self.W, self.D]
+
+    def _get_patch_positions(self) -> torch.Tensor:
+        axes = [torch.arange(n // self.patch_size, dtype=torch.float32) for n in self._grid_sizes()]
+        return torch.stack(torch.meshgrid(*axes, indexing='ij'), dim=-1).reshape(-1, self.coord_dim)
+
+    def _compute_absolute_embeddings(self, positions: torch.Tensor, embed_dim: int) -> torch.Tensor:
+        nd = positions.size(1)
+        n = embed_dim // (2 * nd)
+        inv = 1.0 / (10000 ** (torch.arange(n, dtype=torch.float32, device=positions.device) / n))
+        ang = positions[:, :, None] * inv[None, None, :]
+        return torch.cat([torch.sin(ang), torch.cos(ang)], dim=-1).view(positions.size(0), -1)
+
+    def _pos_emb(self, device, width: int) -> torch.Tensor:
+        """sinusoidal table [S, P^d C]: constant, so built once per device and fused as a row-periodic bias
+        into the patch_linear GEMM epilogue (reference recomputes it every call, gaot.py:209-215)."""
+        c = self._pos_emb_cache
+        if c is None or c.device != device or c.shape[1] != width:
+            c = self._compute_absolute_embeddings(self.positions.to(device), width).contiguous()
+            if c.shape[1] != width:
+                raise ValueError(f"absolute positional embedding width {c.shape[1]} != token width {width} "
+                                 f"(needs P^d*C divisible by 2*d)")
+            self._pos_emb_cache = c
+        return c
+
+    # ---- the three stages
+    def encode(self, x_coord, pndata, latent_tokens_coord, encoder_nbrs):
+        return self.encoder(x_coord=x_coord, pndata=pndata, latent_tokens_coord=latent_tokens_coord, encoder_nbrs=encoder_nbrs)
+
+    def process(self, rndata: Optional[torch.Tensor] = None, condition: Optional[float] = None) -> torch.Tensor:
+        B, n, C = rndata.shape
+        P = self.patch_size
+        sizes = self._grid_sizes()
+        assert n == math.prod(sizes), f"n_regional_nodes ({n}) != {'*'.join(map(str, sizes))}"
+        assert all(s % P == 0 for s in sizes), f"latent grid {sizes} must be divisible by P({P})"
+        tok = ops.patchify(rndata, sizes, P)                                      # [B, S, P^d C]
+        if self.positional_embedding_name == 'absolute':
+            tok = ops.linear(tok, self.patch_linear.weight, self.patch_linear.bias, rowbias=self._pos_emb(tok.device, tok.shape[-1]))
+            rel = None
+        elif self.positional_embedding_name == 'rope':
+            raise NotImplementedError("rope positional embedding is not built (SURVEY 8f rank 4)")
+        else:
+            raise ValueError(f"unknown positional_embedding {self.positional_embedding_name!r}")
+        tok = self.processor(tok, condition=condition, relative_positions=rel)
+        return ops.unpatchify(tok, sizes, P)
+
+    def decode(self, latent_tokens_coord, rndata, query_coord, decoder_nbrs):
+        return self.decoder(latent_tokens_coord=latent_tokens_coord, rndata=rndata, query_coord=query_coord, decoder_nbrs=decoder_nbrs)
+
+    def forward(self, latent_tokens_coord: torch.Tensor, xcoord: torch.Tensor, pndata: torch.Tensor,
+                query_coord: Optional[torch.Tensor] = None, encoder_nbrs: Optional[list] = None,
+                decoder_nbrs: Optional[list] = None, condition: Optional[float] = None) -> torch.Tensor:
+        rn = self.encode(x_coord=xcoord, pndata=pndata, latent_tokens_coord=latent_tokens_coord, encoder_nbrs=encoder_nbrs)
+        rn = self.process(rndata=rn, condition=condition)
+        if query_coord is None:
+            query_coord = xcoord
+        return self.decode(latent_tokens_coord=latent_tokens_coord, rndata=rn, query_coord=query_coord, decoder_nbrs=decoder_nbrs)
+
+    # ---- rollout (reference gaot.py:307-476)
+    def autoregressive_predict(self, x_batch: torch.Tensor, time_indices: np.ndarray, t_values: np.ndarray, stats: Dict,
+                               stepper_mode: str = "output", latent_tokens_coord: Optional[torch.Tensor] = None,
+                               fixed_coord: Optional[torch.Tensor] = None, encoder_nbrs: Optional[List] = None,
+                               decoder_nbrs: Optional[List] = None, use_conditional_norm: bool = False) -> torch.Tensor:
+        if stepper_mode not in ("output", "residual", "time_der"):
+            raise ValueError(f"Unsupported stepper_mode: {stepper_mode}")
+        dev, dt_ = x_batch.device, x_batch.dtype
+        B, N, _ = x_batch.shape
+        u_mean, u_std = stats["u"]["mean"].to(dev), stats["u"]["std"].to(dev)
+        udim = u_mean.shape[0]
+        cdim = stats["c"]["mean"].shape[0] if "c" in stats else 0
+        static = x_batch[..., udim:udim + cdim] if cdim > 0 else None
+        state = x_batch[..., :udim]
+        graphs = dict(encoder_nbrs=encoder_nbrs, decoder_nbrs=decoder_nbrs) \
+            if (encoder_nbrs is not None and decoder_nbrs is not None) else {}
+        aux = {k: (stats[k]["mean"].to(dev), stats[k]["std"].to(dev)) for k in ("res", "der") if k in stats}
+        preds = []
+        with torch.no_grad():
+            for i in range(1, len(time_indices)):
+                t0 = t_values[time_indices[i - 1]]
+                dt = t_values[time_indices[i]] - t0
+                t0n = (t0 - stats["start_time"]["mean"]) / stats["start_time"]["std"]
+                dtn = (dt - stats["time_diffs"]["mean"]) / stats["time_diffs"]["std"]
+                cols = [state] + ([static] if static is not None else [])
+                cols += [torch.full((B, N, 1), float(t0n), dtype=dt_, device=dev),
+                         torch.full((B, N, 1), float(dtn), dtype=dt_, device=dev)]
+                xin = torch.cat(cols, dim=-1)
+                if use_conditional_norm:          # last column (dt) becomes the conditioning scalar
+                    pred = self.forward(latent_tokens_coord=latent_tokens_coord, xcoord=fixed_coord,
+                                        pndata=xin[..., :-1].contiguous(), condition=xin[..., 0, -2:-1], **graphs)
+                else:
+                    pred = self.forward(latent_tokens_coord=latent_tokens_coord, xcoord=fixed_coord, pndata=xin, **graphs)
+                if stepper_mode == "output":
+                    den = pred * u_std + u_mean
+                elif stepper_mode == "residual":
+                    den = (state * u_std + u_mean) + (pred * aux["res"][1] + aux["res"][0])
+                else:
+                    den = (state * u_std + u_mean) + float(dt) * (pred * aux["der"][1] + aux["der"][0])
+                preds.append(den)
+                state = (den - u_mean) / u_std
+        return torch.stack(preds, dim=1)

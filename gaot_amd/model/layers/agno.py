@@ -1,0 +1,101 @@
+"""Attentional graph neural operator (reference agno.py) on the HIP gather / segment-reduce kernels.
+
+    out[b,i,:] = sum_{e in N(i)} a_e * k_e (*) f[b, j(e), :]
+with k_e = MLP([y_j, x_i]) (GEMM chain over the E edge rows, batch independent for the default 'linear'
+transform) and a_e the per-edge scalar: cosine segment-softmax (geometry only -> cached in the plan),
+learned dot-product segment-softmax, quadrature weight, or 1/deg for the plain mean.
+"""
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import ops
+from ...plan import plan_for
+from .mlp import LinearChannelMLP
+
+_TRANSFORMS = ("linear_kernelonly", "linear", "nonlinear_kernelonly", "nonlinear")
+
+
+class AGNO(nn.Module):
+    def __init__(self, channel_mlp=None, channel_mlp_layers=None, channel_mlp_non_linearity=F.gelu,
+                 transform_type="linear", use_attn=None, attention_type='cosine', coord_dim=None, use_torch_scatter=True):
+        super().__init__()
+        if channel_mlp is None and channel_mlp_layers is None:
+            raise ValueError("Either channel_mlp or channel_mlp_layers must be provided.")
+        if transform_type not in _TRANSFORMS:
+            raise ValueError(f"Invalid transform_type: {transform_type}")
+        if channel_mlp_non_linearity is not F.gelu:
+            raise NotImplementedError("the fused kernel MLP implements the reference default (exact-erf GELU) only")
+        self.transform_type = transform_type
+        self.use_attn = use_attn
+        self.attention_type = attention_type
+        self.use_torch_scatter = use_torch_scatter     # accepted for signature compatibility; unused
+        if use_attn:
+            if coord_dim is None:
+                raise ValueError("coord_dim must be specified when use_attn is True")
+            if attention_type not in ('cosine', 'dot_product'):
+                raise ValueError(f"Invalid attention_type: {attention_type}")
+            self.coord_dim = coord_dim
+        self.channel_mlp = channel_mlp if channel_mlp is not None else LinearChannelMLP(layers=channel_mlp_layers)
+        if use_attn and attention_type == 'dot_product':
+            self.query_proj = nn.Linear(coord_dim, 64)
+            self.key_proj = nn.Linear(coord_dim, 64)
+            self.scaling_factor = 1.0 / math.sqrt(64.0)
+
+    # per-edge scalar a_e (None => plain sum)
+    def _edge_scale(self, plan, y, x, weights):
+        a = None
+        if self.use_attn:
+            # the reference slices [:coord_dim] (agno.py:212-213); coord_dim is the full kernel-coordinate width,
+            # so the slice is normally the tensor itself (kept identical for the plan's identity-keyed cache)
+            ys = y if y.shape[1] == self.coord_dim else y[:, :self.coord_dim]
+            xs = x if x.shape[1] == self.coord_dim else x[:, :self.coord_dim]
+            if self.attention_type == 'cosine':
+                a = plan.cosine_attention(ys, xs)
+            else:
+                # <Wq x_i + bq, Wk y_j + bk> / 8: project the NODES (small GEMMs), gather per edge, segment softmax
+                qn = ops.linear(xs, self.query_proj.weight, self.query_proj.bias)
+                kn = ops.linear(ys, self.key_proj.weight, self.key_proj.bias)
+                score = (qn[plan.edge_query_long] * kn[plan.index_long]).sum(-1) * self.scaling_factor
+                a = ops.segment_softmax(score, plan)
+        if weights is not None:
+            assert weights.ndim == 1, "Weights must be of dimension 1 in all cases"
+            wq = weights[plan.index_long]
+            a = wq if a is None else a * wq
+        elif not self.use_attn:
+            a = plan.inv_deg_edge                      # 'mean' reduction (agno.py:264)
+        return a
+
+    def forward(self, y: torch.Tensor, neighbors: Dict[str, torch.Tensor], x: Optional[torch.Tensor] = None,
+                f_y: Optional[torch.Tensor] = None, weights: Optional[torch.Tensor] = None):
+        if x is None:
+            x = y
+        plan = plan_for(neighbors, y.shape[0])
+        a = self._edge_scale(plan, y, x, weights)
+        feat = plan.edge_features(y, x)                                      # [E, 2*kd]  (y_j first, then x_i)
+        batched = f_y is not None and f_y.ndim == 3
+        if f_y is not None and f_y.ndim not in (2, 3):
+            raise ValueError(f"f_y has unexpected ndim: {f_y.ndim}")
+        f3 = None if f_y is None else (f_y if batched else f_y[None])
+
+        if f3 is not None and self.transform_type in ("nonlinear", "nonlinear_kernelonly"):
+            # kernel sees f(y_j): k is [B,E,C]; a batched GEMM chain over B*E rows, then a plain segment sum
+            B = f3.shape[0]
+            fj = f3[:, plan.index_long, :]
+            k = self.channel_mlp(torch.cat([feat[None].expand(B, -1, -1), fj], dim=-1))
+            if self.transform_type == "nonlinear":
+                k = k * fj
+            if a is not None:
+                k = k * a[None, :plan.E, None]
+            out = ops.segment_sum(k, plan)
+        else:
+            k = self.channel_mlp(feat)                                       # [E, C]
+            if f3 is None:                                                   # transform (a): integrate the kernel itself
+                kk = k if a is None else k * a[:plan.E, None]
+                out = ops.segment_sum(kk[None], plan)
+            else:
+                out = ops.gno_transform(k, f3, plan, a)
+        return out if batched else out[0]

@@ -1,0 +1,178 @@
+"""ViT processor of GAOT on the HIP kernels (mirrors the module/parameter layout of reference attn.py)."""
+from dataclasses import dataclass, field, fields, is_dataclass
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+from .mlp import ConditionedNorm
+
+
+@dataclass
+class AttentionConfig:
+    num_heads: int = 8
+    num_kv_heads: int = 8
+    use_conditional_norm: bool = False
+    cond_norm_hidden_size: int = 4
+    atten_dropout: float = 0.0
+
+
+@dataclass
+class TransformerConfig:
+    patch_size: int = 8
+    hidden_size: int = 256
+    use_attn_norm: bool = True
+    use_ffn_norm: bool = True
+    norm_eps: float = 1e-6
+    num_layers: int = 3
+    positional_embedding: str = 'absolute'
+    use_long_range_skip: bool = True
+    ffn_multiplier: int = 4
+    attn_config: AttentionConfig = field(default_factory=AttentionConfig)
+
+
+def _cfg_get(cfg, name):
+    return cfg[name] if isinstance(cfg, dict) else getattr(cfg, name)
+
+
+def shallow_asdict(obj) -> dict:
+    if is_dataclass(obj):
+        return {f.name: getattr(obj, f.name) for f in fields(obj)}
+    if isinstance(obj, dict):
+        return dict(obj)
+    raise TypeError(f"Unsupported type for shallow_asdict: {type(obj)}")
+
+
+class RMSNorm(nn.Module):
+    def __init__(self, dim: int, eps: float = 1e-6):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim))
+
+    def forward(self, x):
+        return ops.rms_norm(x, self.weight, self.eps)
+
+
+class GroupQueryFlashAttention(nn.Module):
+    """q/k/v projection as ONE GEMM over the concatenated weights, fp32 flash attention, o_proj with the block's
+    residual fused into its epilogue (attn.py:78-119)."""
+
+    def __init__(self, input_size: int, hidden_size: int, num_heads: int = 8, num_kv_heads: int = 8,
+                 use_conditional_norm: bool = False, cond_norm_hidden_size: int = 4, atten_dropout: float = 0.0,
+                 positional_embedding: str = "absolute"):
+        super().__init__()
+        assert hidden_size % num_heads == 0, f"hidden_size {hidden_size} must be divisible by num_heads {num_heads}"
+        assert num_heads % num_kv_heads == 0, f"num_heads {num_heads} must be divisible by num_kv_heads {num_kv_heads}"
+        self.num_heads = num_heads
+        self.num_kv_heads = num_kv_heads
+        self.num_repeat = num_heads // num_kv_heads
+        self.head_dim = hidden_size // num_heads
+        self.atten_dropout = atten_dropout
+        kv = self.head_dim * num_kv_heads
+        self.q_proj = nn.Linear(input_size, hidden_size, bias=False)
+        self.k_proj = nn.Linear(input_size, kv, bias=False)
+        self.v_proj = nn.Linear(input_size, kv, bias=False)
+        self.o_proj = nn.Linear(hidden_size, input_size, bias=False)
+        self.correction = ConditionedNorm(1, input_size, cond_norm_hidden_size) if use_conditional_norm else None
+        if positional_embedding == "rope":
+            raise NotImplementedError("rotary embedding is outside the built path (SURVEY 8f rank 4); use 'absolute'")
+        if self.head_dim > 64:
+            raise NotImplementedError("attention kernel supports head_dim <= 64")
+
+    def forward(self, x, condition=None, relative_positions=None, residual=None):
+        if relative_positions is not None:
+            raise NotImplementedError("rope positions are not supported")
+        if self.training and self.atten_dropout > 0.0:
+            raise NotImplementedError("attention dropout > 0 is not supported by the HIP attention kernel")
+        if self.correction is not None:
+            x = self.correction(c=condition, x=x)
+        wqkv = torch.cat([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight], dim=0)
+        qkv = ops.linear(x, wqkv)
+        o = ops.attention(qkv, self.num_heads, self.num_kv_heads, self.head_dim)
+        return ops.linear(o, self.o_proj.weight, residual=residual)
+
+    @classmethod
+    def from_config(cls, input_size: int, hidden_size: int, config: AttentionConfig, positional_embedding: str = "absolute"):
+        return cls(input_size=input_size, hidden_size=hidden_size, positional_embedding=positional_embedding,
+                   **shallow_asdict(config))
+
+
+class FFN(nn.Module):
+    """SwiGLU: w2(silu(w1 x) * w3 x)  (attn.py:150-156); w1|w3 run as one GEMM, the residual rides w2's epilogue."""
+
+    def __init__(self, input_size: int, ffn_hidden_size: int, use_conditional_norm: bool = False, cond_norm_hidden_size: int = 4):
+        super().__init__()
+        self.w1 = nn.Linear(input_size, ffn_hidden_size, bias=False)
+        self.w2 = nn.Linear(ffn_hidden_size, input_size, bias=False)
+        self.w3 = nn.Linear(input_size, ffn_hidden_size, bias=False)
+        self.correction = ConditionedNorm(1, input_size, cond_norm_hidden_size) if use_conditional_norm else None
+
+    def forward(self, x, condition=None, residual=None):
+        u = ops.linear(x, torch.cat([self.w1.weight, self.w3.weight], dim=0))
+        g = ops.swiglu(u)
+        if self.correction is None:
+            return ops.linear(g, self.w2.weight, residual=residual)
+        y = self.correction(c=condition, x=ops.linear(g, self.w2.weight))
+        return y if residual is None else residual + y
+
+
+class TransformerBlock(nn.Module):
+    def __init__(self, input_size: int, config: TransformerConfig, skip_connection: bool = False):
+        super().__init__()
+        hidden = _cfg_get(config, "hidden_size")
+        acfg = _cfg_get(config, "attn_config")
+        self.attn = GroupQueryFlashAttention.from_config(input_size=input_size, hidden_size=hidden, config=acfg,
+                                                         positional_embedding=_cfg_get(config, "positional_embedding"))
+        self.ffn = FFN(input_size=input_size, ffn_hidden_size=hidden * _cfg_get(config, "ffn_multiplier"),
+                       use_conditional_norm=_cfg_get(acfg, "use_conditional_norm"),
+                       cond_norm_hidden_size=_cfg_get(acfg, "cond_norm_hidden_size"))
+        eps = _cfg_get(config, "norm_eps")
+        self.attn_norm = RMSNorm(input_size, eps=eps) if _cfg_get(config, "use_attn_norm") else None
+        self.ffn_norm = RMSNorm(input_size, eps=eps) if _cfg_get(config, "use_ffn_norm") else None
+        self.skip_connection = skip_connection
+        if skip_connection:
+            self.skip_proj = nn.Linear(input_size * 2, input_size)
+
+    def forward(self, x, condition=None, relative_positions=None, skip=None):
+        if self.skip_connection and skip is not None:          # cat([x, skip]) @ W^T + b as a split-K-operand GEMM
+            x = ops.linear(x, self.skip_proj.weight, self.skip_proj.bias, x2=skip)
+        h = x if self.attn_norm is None else self.attn_norm(x)
+        h = self.attn(h, condition=condition, relative_positions=relative_positions, residual=x)   # x + attn(h)
+        h = h if self.ffn_norm is None else self.ffn_norm(h)
+        return self.ffn(h, condition=condition, residual=h)    # residual on the NORMALISED stream (attn.py:231-232)
+
+
+class Transformer(nn.Module):
+    def __init__(self, input_size: int, output_size: int, config: TransformerConfig = None):
+        super().__init__()
+        config = TransformerConfig() if config is None else config
+        hidden = _cfg_get(config, "hidden_size")
+        n = _cfg_get(config, "num_layers")
+        self.use_long_range_skip = _cfg_get(config, "use_long_range_skip")
+        if input_size != hidden:
+            self.input_proj = nn.Linear(input_size, hidden)
+            work = hidden
+        else:
+            self.input_proj = nn.Identity()
+            work = input_size
+        self.output_proj = nn.Linear(work, output_size) if work != output_size else nn.Identity()
+        self.encoder_layers = nn.ModuleList(TransformerBlock(work, config, False) for _ in range(n // 2))
+        self.middle_layer = TransformerBlock(work, config, False) if n % 2 == 1 else None
+        self.decoder_layers = nn.ModuleList(TransformerBlock(work, config, True) for _ in range(n // 2))
+
+    def forward(self, x, condition=None, relative_positions=None):
+        if isinstance(self.input_proj, nn.Linear):
+            x = ops.linear(x, self.input_proj.weight, self.input_proj.bias)
+        skips = []
+        for blk in self.encoder_layers:
+            x = blk(x, condition=condition, relative_positions=relative_positions)
+            skips.append(x)
+        if self.middle_layer is not None:
+            x = self.middle_layer(x, condition=condition, relative_positions=relative_positions)
+        for blk in self.decoder_layers:
+            s = skips.pop() if self.use_long_range_skip else None
+            x = blk(x, condition=condition, relative_positions=relative_positions, skip=s)
+        if isinstance(self.output_proj, nn.Linear):
+            x = ops.linear(x, self.output_proj.weight, self.output_proj.bias)
+        return x

@@ -1,0 +1,63 @@
+"""Geometric embedding (reference gemb.py) on the HIP geometry-statistics kernel + GEMM MLP."""
+import math
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ...plan import plan_for
+
+
+def node_pos_encode(x: torch.Tensor, freq: int = 4) -> torch.Tensor:
+    """sin/cos features of pi*(x+1) at integer frequencies 1..freq -> [n, freq*2*d] (gemb.py:12-34).
+    Geometry-only (no parameters, no grad); evaluated once per geometry with torch elementwise ops."""
+    assert x.ndim == 2, f"The x is expected to be 2D tensor, but got shape {x.shape}"
+    k = torch.arange(1, freq + 1, device=x.device)
+    ang = k[None, :, None] * (math.pi * (x + 1))[:, None, :]
+    return torch.cat([ang.sin(), ang.cos()], dim=2).reshape(x.shape[0], -1)
+
+
+class GeometricEmbedding(nn.Module):
+    def __init__(self, input_dim, output_dim, method='statistical', pooling='max', **kwargs):
+        super().__init__()
+        self.input_dim = input_dim
+        self.output_dim = output_dim
+        self.method = method.lower()
+        self.pooling = pooling.lower()
+        if self.pooling not in ('max', 'mean'):
+            raise ValueError(f"Unsupported pooling method: {self.pooling}. Supported methods: 'max', 'mean'.")
+        if self.method == 'statistical':
+            self.mlp = nn.Sequential(nn.Linear(3 + 2 * input_dim, 64), nn.ReLU(), nn.Linear(64, output_dim), nn.ReLU())
+        elif self.method == 'pointnet':
+            self.pointnet_mlp = nn.Sequential(nn.Linear(input_dim, 64), nn.ReLU(), nn.Linear(64, 64), nn.ReLU())
+            self.fc = nn.Sequential(nn.Linear(64, output_dim), nn.ReLU())
+        else:
+            raise ValueError(f"Unknown method: {self.method}")
+
+    def forward(self, input_geom, latent_queries, spatial_nbrs):
+        plan = plan_for(spatial_nbrs, input_geom.shape[0])
+        if self.method == 'statistical':
+            stats = plan.geo_stats(input_geom, latent_queries)          # [Q, 3+2d], cached per geometry
+            return ops.mlp_chain(stats, [self.mlp[0].weight, self.mlp[2].weight],
+                                 [self.mlp[0].bias, self.mlp[2].bias], ["relu", "relu"])
+        return self._pointnet(plan, input_geom, latent_queries)
+
+    def _pointnet(self, plan, geom, queries):
+        """Per-edge MLP on centred neighbour coordinates, pooled per query (gemb.py:173-228)."""
+        Q = queries.shape[0]
+        out = torch.zeros(Q, self.output_dim, device=geom.device, dtype=torch.float32)
+        if plan.E == 0:
+            return out
+        feat = plan.edge_features(geom, queries)
+        d = geom.shape[1]
+        rel = feat[:, :d] - feat[:, d:]
+        h = ops.mlp_chain(rel, [self.pointnet_mlp[0].weight, self.pointnet_mlp[2].weight],
+                          [self.pointnet_mlp[0].bias, self.pointnet_mlp[2].bias], ["relu", "relu"])
+        if self.pooling == 'mean':
+            pooled = ops.segment_sum(h[None], plan, 1.0 / plan.deg.clamp(min=1).to(torch.float32))[0]
+        else:
+            qid = plan.edge_query_long
+            pooled = torch.zeros(Q, h.shape[1], device=h.device, dtype=h.dtype).scatter_reduce(
+                0, qid[:, None].expand_as(h), h, reduce="amax", include_self=False)
+        emb = ops.mlp_chain(pooled, [self.fc[0].weight], [self.fc[0].bias], ["relu"])
+        return torch.where((plan.deg > 0)[:, None], emb, out)

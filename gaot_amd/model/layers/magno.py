@@ -1,0 +1,254 @@
+"""MAGNO encoder / decoder (reference magno.py) on the HIP GNO kernels.
+
+Differences in *how* (not what) it computes:
+  * geometry-only work (int32/transposed CSR, kernel-MLP input rows, cosine attention, geometry statistics)
+    lives in a GeometryPlan cached on the neighbour dict instead of being redone every forward;
+  * the `cat([agno, geoembed]) -> recovery` Conv1d is evaluated as
+        agno @ Wr[:, :C]^T + (geoembed @ Wr[:, C:]^T + b)        (second term is batch independent, [Q, C])
+    i.e. one GEMM over B*Q rows with a Q-periodic row bias; the [B, Q, 2C] concat is never materialised;
+  * tensors stay channels-last; no permutes around the point-wise convolutions.
+"""
+from dataclasses import dataclass, field
+from typing import List, Literal, Optional, Union
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+from .agno import AGNO
+from .gemb import GeometricEmbedding, node_pos_encode
+from .mlp import ChannelMLP
+from .utils.edge_drop import apply_edge_drop_csr
+from .utils.neighbor_search import NeighborSearch
+
+
+@dataclass
+class MAGNOConfig:
+    # field names/defaults are the operator API (reference magno.py:31-60)
+    coord_dim: int = 2
+    radius: float = 0.033
+    hidden_size: int = 64
+    mlp_layers: int = 3
+    lifting_channels: int = 32
+    scales: List[float] = field(default_factory=lambda: [1.0])
+    use_scale_weights: bool = False
+    use_attention: bool = True
+    attention_type: str = 'cosine'
+    use_geoembed: bool = True
+    embedding_method: str = 'statistical'
+    pooling: str = 'max'
+    transform_type: str = 'linear'
+    sampling_strategy: Optional[str] = None
+    max_neighbors: Optional[int] = None
+    sample_ratio: Optional[float] = None
+    node_embedding: bool = False
+    neighbor_search_method: str = 'auto'
+    use_torch_scatter: bool = True
+    neighbor_strategy: str = 'radius'
+    precompute_edges: bool = False
+
+    def __post_init__(self):
+        if self.coord_dim not in [2, 3]:
+            raise ValueError(f"coord_dim must be 2 or 3, got {self.coord_dim}")
+        if self.sampling_strategy == 'ratio' and (self.sample_ratio is None or not 0 < self.sample_ratio <= 1):
+            raise ValueError("sample_ratio must be in (0, 1] when using 'ratio' sampling")
+        if self.sampling_strategy == 'max_neighbors' and (self.max_neighbors is None or self.max_neighbors <= 0):
+            raise ValueError("max_neighbors must be > 0 when using 'max_neighbors' sampling")
+
+
+class _MAGNOBase(nn.Module):
+    """Pieces shared by encoder and decoder: neighbour cache, per-(geometry, scale) transform, scale mixing."""
+
+    def _setup(self, config: MAGNOConfig, feat_channels: int, kernel_out: int, kernel_extra_in: int):
+        self.config = config
+        self.coord_dim = config.coord_dim
+        self.scales = config.scales
+        self.use_scale_weights = config.use_scale_weights
+        self.precompute_edges = config.precompute_edges
+        self.use_geoembed = config.use_geoembed
+        self.node_embedding = config.node_embedding
+        self.nb_search = NeighborSearch(method=config.neighbor_search_method)
+        self.neighbor_cache = {}
+        self._coord_enc_cache = {}
+        self.sampling_strategy = config.sampling_strategy
+        self.max_neighbors = config.max_neighbors
+        self.sample_ratio = config.sample_ratio
+        kd = self._compute_kernel_coord_dim()
+        kin = 2 * kd + (kernel_extra_in if config.transform_type in ("nonlinear", "nonlinear_kernelonly") else 0)
+        sizes = [kin] + [config.hidden_size] * config.mlp_layers + [kernel_out]
+        self.agno = AGNO(channel_mlp_layers=sizes, transform_type=config.transform_type, use_attn=config.use_attention,
+                         attention_type=config.attention_type, coord_dim=kd, use_torch_scatter=config.use_torch_scatter)
+        return kd
+
+    def _finish_setup(self, config: MAGNOConfig, kd: int, feat_channels: int):
+        if self.use_geoembed:
+            self.geoembed = GeometricEmbedding(input_dim=self.coord_dim, output_dim=feat_channels,
+                                               method=config.embedding_method, pooling=config.pooling)
+            self.recovery = ChannelMLP(in_channels=2 * feat_channels, out_channels=feat_channels, n_layers=1)
+        if self.use_scale_weights:
+            self.scale_weighting = nn.Sequential(nn.Linear(kd, config.hidden_size // 4), nn.ReLU(),
+                                                 nn.Linear(config.hidden_size // 4, len(self.scales)))
+            self.scale_weight_activation = nn.Softmax(dim=-1)
+
+    def _compute_kernel_coord_dim(self) -> int:
+        return self.coord_dim * 4 * 2 if self.node_embedding else self.coord_dim
+
+    @staticmethod
+    def _mode(coord: torch.Tensor, what: str) -> Literal['fx', 'vx']:
+        if coord.ndim == 2:
+            return 'fx'
+        if coord.ndim == 3:
+            return 'vx'
+        raise ValueError(f"{what} must be 2D or 3D tensor, got shape {coord.shape}")
+
+    def _search(self, key: str, data, queries, mode):
+        """radius graphs per scale, cached by SHAPE like the reference (magno.py:177-180, 513-516)."""
+        if key in self.neighbor_cache:
+            return self.neighbor_cache[key]
+        if mode == 'fx':
+            nbrs = [self.nb_search(data=data, queries=queries, radius=self.config.radius * s) for s in self.scales]
+        else:
+            B = data.shape[0] if data.ndim == 3 else queries.shape[0]
+            nbrs = [[self.nb_search(data=data[b] if data.ndim == 3 else data,
+                                    queries=queries[b] if queries.ndim == 3 else queries,
+                                    radius=self.config.radius * s) for s in self.scales] for b in range(B)]
+        self.neighbor_cache[key] = nbrs
+        return nbrs
+
+    def _kcoord(self, c: torch.Tensor) -> torch.Tensor:
+        """kernel coordinates: raw or node_pos_encode()d (cached per tensor identity: geometry only)."""
+        if not self.node_embedding:
+            return c
+        key = (id(c), c._version)
+        hit = self._coord_enc_cache.get(key)
+        if hit is None:
+            if len(self._coord_enc_cache) > 64:
+                self._coord_enc_cache.clear()
+            hit = (c, node_pos_encode(c))
+            self._coord_enc_cache[key] = hit
+        return hit[1]
+
+    def _transform(self, src_coord, dst_coord, feats, neighbors):
+        """AGNO (+ geoembed + recovery) for ONE geometry at ONE scale.  feats [B, n_src, C] -> [B, n_dst, C]."""
+        nb = apply_edge_drop_csr(neighbors, self.sampling_strategy, self.max_neighbors, self.sample_ratio, self.training)
+        out = self.agno(y=self._kcoord(src_coord), x=self._kcoord(dst_coord), f_y=feats, neighbors=nb)
+        if self.use_geoembed:
+            ge = self.geoembed(input_geom=src_coord, latent_queries=dst_coord, spatial_nbrs=nb)     # [n_dst, C]
+            w = self.recovery.fcs[0].weight.squeeze(-1)                                             # [C, 2C]
+            C = out.shape[-1]
+            rowb = ops.linear(ge, w[:, C:], self.recovery.fcs[0].bias)                              # [n_dst, C]
+            out = ops.linear(out, w[:, :C], rowbias=rowb)
+        return out
+
+    def _scale_mix_weights(self, coords: torch.Tensor) -> torch.Tensor:
+        h = ops.mlp_chain(coords, [self.scale_weighting[0].weight, self.scale_weighting[2].weight],
+                          [self.scale_weighting[0].bias, self.scale_weighting[2].bias], ["relu", "none"])
+        return self.scale_weight_activation(h)
+
+    def _combine(self, per_scale: List[torch.Tensor], weights: Optional[torch.Tensor]) -> torch.Tensor:
+        if len(per_scale) == 1:
+            return per_scale[0]
+        if self.use_scale_weights:
+            acc = None
+            for i, t in enumerate(per_scale):
+                term = weights[None, :, i:i + 1] * t
+                acc = term if acc is None else acc + term
+            return acc
+        return torch.stack(per_scale, dim=0).mean(dim=0)
+
+    def _all_scales(self, mode, src, dst, feats, nbrs):
+        per_scale = []
+        for si in range(len(self.scales)):
+            if mode == 'fx':
+                per_scale.append(self._transform(src, dst, feats, nbrs[si]))
+            else:
+                B = feats.shape[0]
+                per_scale.append(torch.cat([
+                    self._transform(src[b] if src.ndim == 3 else src, dst[b] if dst.ndim == 3 else dst,
+                                    feats[b:b + 1], nbrs[b][si]) for b in range(B)], dim=0))
+        return per_scale
+
+
+class MAGNOEncoder(_MAGNOBase):
+    """physical nodes -> latent tokens."""
+
+    def __init__(self, in_channels: int, out_channels: int, config: MAGNOConfig):
+        super().__init__()
+        kd = self._setup(config, out_channels, kernel_out=out_channels, kernel_extra_in=in_channels)
+        self.lifting = ChannelMLP(in_channels=in_channels, hidden_channels=config.hidden_size,
+                                  out_channels=out_channels, n_layers=1)
+        self._finish_setup(config, kd, out_channels)
+
+    def _detect_coordinate_mode(self, x_coord):
+        return self._mode(x_coord, "x_coord")
+
+    def _compute_neighbors(self, x_coord, latent_coord, mode):
+        key = f"{mode}_{x_coord.shape}_{latent_coord.shape}_{tuple(self.scales)}"
+        return self._search(key, x_coord, latent_coord, mode)
+
+    def forward(self, x_coord: torch.Tensor, pndata: torch.Tensor, latent_tokens_coord: torch.Tensor,
+                encoder_nbrs: Optional[Union[List, List[List]]] = None) -> torch.Tensor:
+        mode = self._detect_coordinate_mode(x_coord)
+        B = pndata.shape[0]
+        if mode == 'fx':
+            if x_coord.shape[1] != self.coord_dim:
+                raise ValueError(f"Expected x_coord shape [num_nodes, {self.coord_dim}], got {x_coord.shape}")
+            n = x_coord.shape[0]
+        else:
+            if x_coord.shape[0] != B or x_coord.shape[2] != self.coord_dim:
+                raise ValueError(f"Expected x_coord shape [{B}, num_nodes, {self.coord_dim}], got {x_coord.shape}")
+            n = x_coord.shape[1]
+        if tuple(pndata.shape[:2]) != (B, n):
+            raise ValueError(f"pndata shape mismatch: expected [{B}, {n}, in_channels], got {pndata.shape}")
+        if latent_tokens_coord.shape[1] != self.coord_dim:
+            raise ValueError(f"Expected latent_tokens_coord shape [num_latent, {self.coord_dim}], got {latent_tokens_coord.shape}")
+        if self.precompute_edges:
+            if encoder_nbrs is None:
+                raise ValueError("encoder_nbrs required when precompute_edges=True")
+            nbrs = encoder_nbrs
+        else:
+            nbrs = self._compute_neighbors(x_coord, latent_tokens_coord, mode)
+        lifted = self.lifting.forward_channels_last(pndata)                                     # [B, n, C]
+        w = self._scale_mix_weights(self._kcoord(latent_tokens_coord)) if self.use_scale_weights else None
+        return self._combine(self._all_scales(mode, x_coord, latent_tokens_coord, lifted, nbrs), w)
+
+
+class MAGNODecoder(_MAGNOBase):
+    """latent tokens -> query nodes, then the output projection."""
+
+    def __init__(self, in_channels: int, out_channels: int, config: MAGNOConfig):
+        super().__init__()
+        kd = self._setup(config, in_channels, kernel_out=in_channels, kernel_extra_in=in_channels)
+        self.projection = ChannelMLP(in_channels=in_channels, hidden_channels=config.hidden_size,
+                                     out_channels=out_channels, n_layers=1)
+        self._finish_setup(config, kd, in_channels)
+
+    def _detect_coordinate_mode(self, query_coord):
+        return self._mode(query_coord, "query_coord")
+
+    def _compute_neighbors(self, latent_coord, query_coord, mode):
+        key = f"dec_{mode}_{latent_coord.shape}_{query_coord.shape}_{tuple(self.scales)}"
+        return self._search(key, latent_coord, query_coord, mode)
+
+    def forward(self, latent_tokens_coord: torch.Tensor, rndata: torch.Tensor, query_coord: torch.Tensor,
+                decoder_nbrs: Optional[Union[List, List[List]]] = None) -> torch.Tensor:
+        mode = self._detect_coordinate_mode(query_coord)
+        B = rndata.shape[0]
+        if mode == 'fx':
+            if query_coord.shape[1] != self.coord_dim:
+                raise ValueError(f"Expected query_coord shape [num_query, {self.coord_dim}], got {query_coord.shape}")
+        elif query_coord.shape[0] != B or query_coord.shape[2] != self.coord_dim:
+            raise ValueError(f"Expected query_coord shape [{B}, num_query, {self.coord_dim}], got {query_coord.shape}")
+        if latent_tokens_coord.shape[1] != self.coord_dim:
+            raise ValueError(f"Expected latent_tokens_coord shape [num_latent, {self.coord_dim}], got {latent_tokens_coord.shape}")
+        if self.precompute_edges:
+            if decoder_nbrs is None:
+                raise ValueError("decoder_nbrs required when precompute_edges=True")
+            nbrs = decoder_nbrs
+        else:
+            nbrs = self._compute_neighbors(latent_tokens_coord, query_coord, mode)
+        w = None
+        if self.use_scale_weights:        # vx: the FIRST sample's coordinates (reference magno.py:610-612)
+            w = self._scale_mix_weights(self._kcoord(query_coord if mode == 'fx' else query_coord[0]))
+        dec = self._combine(self._all_scales(mode, latent_tokens_coord, query_coord, rndata, nbrs), w)
+        return self.projection.forward_channels_last(dec)

@@ -1,0 +1,533 @@
+"""Host-side op layer: thin ctypes calls into libgaot_hip.so + the torch.autograd.Functions the layers use.
+
+PyTorch is plumbing here (device memory, streams, autograd tape).  Every arithmetic op on the hot path is a
+hand-written gfx950 kernel reached through the C ABI in include/gaot_hip.h.  There is no CPU / eager
+fallback: calling an op without the library or with host tensors raises.
+"""
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+ACT = {"none": L.ACT_NONE, "gelu": L.ACT_GELU, "relu": L.ACT_RELU}
+_ACT_BWD = {L.ACT_GELU: L.ACT_GELU_BWD, L.ACT_RELU: L.ACT_RELU_BWD}
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("gaot_amd ops take device tensors only (no CPU fallback); got a host tensor")
+
+
+def _f32(*ts):
+    for t in ts:
+        if t is not None and t.dtype != torch.float32:
+            raise TypeError(f"gaot_amd kernels are fp32; got {t.dtype}")
+
+
+def _rowmajor(t: torch.Tensor) -> Tuple[torch.Tensor, int]:
+    """2-D tensor with unit inner stride -> (tensor, leading dim)."""
+    assert t.dim() == 2
+    if t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        t = t.contiguous()
+    ld = t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+    return t, ld
+
+
+# --------------------------------------------------------------------------------------------
+# raw calls
+# --------------------------------------------------------------------------------------------
+def gemm(M: int, N: int, K: int, A, lda, a_kmajor, B, ldb, b_kmajor, out, ldc, *, bias=None, rowbias=None,
+         rowbias_period=0, ld_rowbias=0, rowscale=None, act=L.ACT_NONE, aux_in=None, aux_out=None, ld_aux=0,
+         residual=None, ldr=0, A2=None, lda2=0, k_split=0, split_k=1):
+    _dev(A, B, out, bias, rowbias, rowscale, aux_in, aux_out, residual, A2)
+    _f32(A, B, out)
+    ws = None
+    if split_k > 1:
+        ws = torch.empty(split_k * M * N, device=out.device, dtype=torch.float32)
+    d = L.GemmDesc(M, N, K, _p(A), lda, int(a_kmajor), _p(A2), lda2, k_split, _p(B), ldb, int(b_kmajor),
+                   _p(out), ldc, _p(bias), _p(rowbias), rowbias_period, ld_rowbias, _p(rowscale), act,
+                   _p(aux_in), _p(aux_out), ld_aux, _p(residual), ldr, split_k, _p(ws))
+    L.check(L.load().gaot_gemm_f32(C.byref(d), _stream()), "gaot_gemm_f32")
+    return out
+
+
+def _split_for_reduction(Mo: int, No: int, K: int) -> int:
+    """split-K factor for weight-gradient products (tiny output, long reduction)."""
+    tiles = ((Mo + 63) // 64) * ((No + 63) // 64)
+    want = max(1, 1024 // max(1, tiles))
+    return int(max(1, min(want, (K + 255) // 256)))
+
+
+def linear_nt(x2: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, **epi) -> torch.Tensor:
+    """out[M,N] = x2[M,K] @ w[N,K]^T (+ epilogue)."""
+    x2, lda = _rowmajor(x2)
+    w, ldb = _rowmajor(w)
+    M, K = x2.shape
+    N = w.shape[0]
+    assert w.shape[1] == K, (x2.shape, w.shape)
+    if out is None:
+        out = torch.empty(M, N, device=x2.device, dtype=torch.float32)
+    return gemm(M, N, K, x2, lda, 1, w, ldb, 1, out, out.stride(0) if M > 1 else N, **epi)
+
+
+def matmul_nn(g: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, **epi) -> torch.Tensor:
+    """out[M,K] = g[M,N] @ w[N,K]   (input gradient of a Linear with weight w)."""
+    g, lda = _rowmajor(g)
+    w, ldb = _rowmajor(w)
+    M, N = g.shape
+    K = w.shape[1]
+    assert w.shape[0] == N
+    if out is None:
+        out = torch.empty(M, K, device=g.device, dtype=torch.float32)
+    return gemm(M, K, N, g, lda, 1, w, ldb, 0, out, out.stride(0) if M > 1 else K, **epi)
+
+
+def matmul_tn(g: torch.Tensor, x2: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[N,K] = g[M,N]^T @ x2[M,K]   (weight gradient); split-K over the long M reduction."""
+    g, lda = _rowmajor(g)
+    x2, ldb = _rowmajor(x2)
+    M, N = g.shape
+    K = x2.shape[1]
+    assert x2.shape[0] == M
+    if out is None:
+        out = torch.empty(N, K, device=g.device, dtype=torch.float32)
+    ldc = out.stride(0) if N > 1 else K
+    return gemm(N, K, M, g, lda, 0, x2, ldb, 0, out, ldc, split_k=_split_for_reduction(N, K, M))
+
+
+def colsum(x2: torch.Tensor) -> torch.Tensor:
+    x2, ld = _rowmajor(x2)
+    M, N = x2.shape
+    lib = L.load()
+    out = torch.empty(N, device=x2.device, dtype=torch.float32)
+    scratch = torch.empty(int(lib.gaot_colsum_scratch(M, N)), device=x2.device, dtype=torch.float32)
+    L.check(lib.gaot_colsum(_p(x2), ld, M, N, _p(out), _p(scratch), _stream()), "gaot_colsum")
+    return out
+
+
+def batchsum(x: torch.Tensor, B: int) -> torch.Tensor:
+    """x [B, ...] contiguous -> sum over the leading dim."""
+    x = x.contiguous()
+    rn = x.numel() // B
+    out = torch.empty(x.shape[1:] if x.shape[0] == B else (rn,), device=x.device, dtype=torch.float32)
+    L.check(L.load().gaot_batchsum(_p(x), B, rn, _p(out), _stream()), "gaot_batchsum")
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# Linear (nn.Linear / Conv1d k=1) with fused bias, periodic row bias, residual and split input
+# --------------------------------------------------------------------------------------------
+class _Linear(torch.autograd.Function):
+    """y = x @ w[:, :K]^T (+ x2 @ w[:, K:]^T) + b + rowbias[m % P] + residual"""
+
+    @staticmethod
+    def forward(ctx, x, w, b, residual, rowbias, x2):
+        _dev(x, w)
+        shp = x.shape
+        K = shp[-1]
+        xm = x.reshape(-1, K)
+        M = xm.shape[0]
+        N = w.shape[0]
+        w2d = w.reshape(N, -1)            # Conv1d weights carry a trailing singleton dim
+        res2 = residual.reshape(M, N) if residual is not None else None
+        epi = dict(bias=b)
+        if res2 is not None:
+            res2, ldr = _rowmajor(res2)
+            epi.update(residual=res2, ldr=ldr)
+        if rowbias is not None:
+            rb, ldrb = _rowmajor(rowbias.reshape(-1, N))
+            epi.update(rowbias=rb, rowbias_period=rb.shape[0], ld_rowbias=ldrb)
+        if x2 is None:
+            assert w2d.shape[1] == K
+            y = linear_nt(xm, w2d, **epi)
+            x2m = None
+        else:
+            K2 = x2.shape[-1]
+            x2m = x2.reshape(-1, K2)
+            assert w2d.shape[1] == K + K2
+            xm_, lda = _rowmajor(xm)
+            x2m_, lda2 = _rowmajor(x2m)
+            wc, ldb = _rowmajor(w2d)
+            y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+            if K % 32 == 0:
+                gemm(M, N, K + K2, xm_, lda, 1, wc, ldb, 1, y, N, A2=x2m_, lda2=lda2, k_split=K, **epi)
+            else:
+                linear_nt(xm_, wc[:, :K], out=y, **epi)
+                linear_nt(x2m_, wc[:, K:], out=y, residual=y, ldr=N)
+        ctx.save_for_backward(xm, x2m, w2d)
+        ctx.meta = (shp, x2.shape if x2 is not None else None, w.shape, b is not None,
+                    residual.shape if residual is not None else None,
+                    rowbias.shape if rowbias is not None else None)
+        return y.reshape(*shp[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xm, x2m, w2d = ctx.saved_tensors
+        shp, shp2, wshape, has_b, res_shape, rb_shape = ctx.meta
+        N = w2d.shape[0]
+        g = dy.reshape(-1, N)
+        g, _ = _rowmajor(g)
+        K = xm.shape[1]
+        need = ctx.needs_input_grad
+        dx = dw = db = dres = drb = dx2 = None
+        if need[0]:
+            dx = matmul_nn(g, w2d[:, :K]).reshape(shp)
+        if need[5] and x2m is not None:
+            dx2 = matmul_nn(g, w2d[:, K:]).reshape(shp2)
+        if need[1]:
+            dw = torch.empty(N, w2d.shape[1], device=g.device, dtype=torch.float32)
+            matmul_tn(g, xm, out=dw[:, :K])
+            if x2m is not None:
+                matmul_tn(g, x2m, out=dw[:, K:])
+            dw = dw.reshape(wshape)
+        if has_b and need[2]:
+            db = colsum(g)
+        if res_shape is not None and need[3]:
+            dres = dy.reshape(res_shape)
+        if rb_shape is not None and need[4]:
+            P = 1
+            for s in rb_shape[:-1]:
+                P *= s
+            drb = batchsum(g.reshape(-1, P * N), g.shape[0] // P).reshape(rb_shape)
+        return dx, dw, db, dres, drb, dx2
+
+
+def linear(x, w, b=None, residual=None, rowbias=None, x2=None):
+    return _Linear.apply(x, w, b, residual, rowbias, x2)
+
+
+# --------------------------------------------------------------------------------------------
+# MLP chain: z_i = h_{i-1} W_i^T + b_i, h_i = act_i(z_i); activation derivative of layer i is fused into the
+# epilogue of layer i+1's input-gradient GEMM.
+# --------------------------------------------------------------------------------------------
+class _MLPChain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, acts, *wb):
+        _dev(x)
+        n = len(wb) // 2
+        shp = x.shape
+        h = x.reshape(-1, shp[-1])
+        saved_in, saved_aux, ws = [], [], []
+        for i in range(n):
+            w, b = wb[2 * i], wb[2 * i + 1]
+            w2d = w.reshape(w.shape[0], -1)
+            act = ACT[acts[i]]
+            saved_in.append(h)
+            M, N = h.shape[0], w2d.shape[0]
+            y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+            if act == L.ACT_GELU:
+                z = torch.empty_like(y)
+                linear_nt(h, w2d, out=y, bias=b, act=act, aux_out=z, ld_aux=N)
+                saved_aux.append(z)
+            else:
+                linear_nt(h, w2d, out=y, bias=b, act=act)
+                saved_aux.append(y if act == L.ACT_RELU else None)
+            ws.append(w2d)
+            h = y
+        ctx.acts = acts
+        ctx.n = n
+        ctx.shapes = (shp, [w.shape for w in wb[0::2]], [b is not None for b in wb[1::2]])
+        ctx.save_for_backward(*saved_in, *[a if a is not None else saved_in[0].new_empty(0) for a in saved_aux], *ws)
+        return h.reshape(*shp[:-1], h.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        n = ctx.n
+        sv = ctx.saved_tensors
+        ins, auxs, ws = sv[:n], sv[n:2 * n], sv[2 * n:]
+        shp, wshapes, has_b = ctx.shapes
+        g = dy.reshape(-1, ws[-1].shape[0])
+        g, _ = _rowmajor(g)
+        last_act = ACT[ctx.acts[-1]]
+        if last_act == L.ACT_RELU:      # derivative of the final activation (not fusable: no following GEMM)
+            g = g * (auxs[-1] > 0)
+        elif last_act == L.ACT_GELU:
+            raise NotImplementedError("final GELU in an MLP chain")
+        grads: List[Optional[torch.Tensor]] = [None] * (2 * n)
+        for i in range(n - 1, -1, -1):
+            if ctx.needs_input_grad[2 + 2 * i]:
+                grads[2 * i] = matmul_tn(g, ins[i]).reshape(wshapes[i])
+            if has_b[i] and ctx.needs_input_grad[3 + 2 * i]:
+                grads[2 * i + 1] = colsum(g)
+            if i > 0:
+                pa = ACT[ctx.acts[i - 1]]
+                if pa == L.ACT_NONE:
+                    g = matmul_nn(g, ws[i])
+                else:
+                    g = matmul_nn(g, ws[i], act=_ACT_BWD[pa], aux_in=auxs[i - 1], ld_aux=auxs[i - 1].shape[1])
+            elif ctx.needs_input_grad[0]:
+                g = matmul_nn(g, ws[0])
+        dx = g.reshape(shp) if ctx.needs_input_grad[0] else None
+        return (dx, None, *grads)
+
+
+def mlp_chain(x, weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]], acts: Sequence[str]):
+    wb = []
+    for w, b in zip(weights, biases):
+        wb += [w, b]
+    return _MLPChain.apply(x, tuple(acts), *wb)
+
+
+# --------------------------------------------------------------------------------------------
+# GNO integral transform
+# --------------------------------------------------------------------------------------------
+def gno_gather_reduce(w, src, splits, cols, edge_map, n_out, escale=None):
+    _dev(src, splits)
+    B, n_src_rows, Cc = src.shape
+    src = src.contiguous()
+    out = torch.empty(B, n_out, Cc, device=src.device, dtype=torch.float32)
+    L.check(L.load().gaot_gno_gather_reduce(_p(w), _p(src), B, n_src_rows, Cc, _p(splits), _p(cols), _p(edge_map),
+                                            n_out, _p(escale), _p(out), _stream()), "gaot_gno_gather_reduce")
+    return out
+
+
+class _GNOTransform(torch.autograd.Function):
+    """out[b,q,:] = sum_{e in seg(q)} a_e * k[e,:] * f[b, j(e), :]     (agno.py:198,245-271)"""
+
+    @staticmethod
+    def forward(ctx, k, f, plan, escale):
+        k = k.contiguous()
+        f = f.contiguous()
+        out = gno_gather_reduce(k, f, plan.splits, plan.index, None, plan.Q, escale)
+        ctx.plan = plan
+        ctx.save_for_backward(k, f, escale if escale is not None else k.new_empty(0))
+        ctx.has_scale = escale is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        k, f, esc = ctx.saved_tensors
+        esc = esc if ctx.has_scale else None
+        plan = ctx.plan
+        dout = dout.contiguous()
+        dk = df = da = None
+        B, n_src, Cc = f.shape
+        lib = L.load()
+        need_a = ctx.has_scale and ctx.needs_input_grad[3]      # learned (dot-product) attention only
+        if ctx.needs_input_grad[0] or need_a:
+            dk = torch.empty_like(k)
+            L.check(lib.gaot_gno_edge_grad(_p(dout), _p(f), B, plan.Q, n_src, Cc, _p(plan.index), _p(plan.edge_query),
+                                           plan.E, None if need_a else _p(esc), _p(dk), _stream()), "gaot_gno_edge_grad")
+            if need_a:      # d/da_e = <sum_b dOut*f , k_e> ; then dk_e = a_e * (sum_b dOut*f)
+                da = torch.zeros_like(esc)
+                da[:plan.E] = (dk * k).sum(-1)
+                dk = dk * esc[:plan.E, None]
+        if ctx.needs_input_grad[1]:
+            df = gno_gather_reduce(k, dout, plan.t_splits, plan.edge_query, plan.t_edge, n_src, esc)
+        return dk, df, None, da
+
+
+def gno_transform(k, f, plan, escale=None):
+    return _GNOTransform.apply(k, f, plan, escale)
+
+
+class _SegmentSoftmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, score, plan):
+        score = score.contiguous()
+        attn = torch.zeros_like(score)
+        L.check(L.load().gaot_segment_softmax_fwd(_p(score), _p(plan.splits), plan.Q, _p(attn), _stream()), "gaot_segment_softmax_fwd")
+        ctx.plan = plan
+        ctx.save_for_backward(attn)
+        return attn
+
+    @staticmethod
+    def backward(ctx, dattn):
+        (attn,) = ctx.saved_tensors
+        ds = torch.zeros_like(attn)
+        L.check(L.load().gaot_segment_softmax_bwd(_p(attn), _p(dattn.contiguous()), _p(ctx.plan.splits), ctx.plan.Q, _p(ds),
+                                                  _stream()), "gaot_segment_softmax_bwd")
+        return ds, None
+
+
+def segment_softmax(score, plan):
+    return _SegmentSoftmax.apply(score, plan)
+
+
+class _SegmentSum(torch.autograd.Function):
+    """out[b,q,:] = rowscale[q] * sum_{e in seg(q)} x[b,e,:]  (batched per-edge values: 'nonlinear' transforms)"""
+
+    @staticmethod
+    def forward(ctx, x, plan, rowscale):
+        x = x.contiguous()
+        B, E, Cc = x.shape
+        out = torch.empty(B, plan.Q, Cc, device=x.device, dtype=torch.float32)
+        L.check(L.load().gaot_gno_segment_sum(_p(x), B, E, Cc, _p(plan.splits), plan.Q, _p(rowscale), _p(out), _stream()),
+                "gaot_gno_segment_sum")
+        ctx.plan = plan
+        ctx.rowscale = rowscale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        g = dout
+        if ctx.rowscale is not None:
+            g = g * ctx.rowscale[None, :, None]
+        return g[:, ctx.plan.edge_query_long, :], None, None
+
+
+def segment_sum(x, plan, rowscale=None):
+    return _SegmentSum.apply(x, plan, rowscale)
+
+
+# --------------------------------------------------------------------------------------------
+# processor ops
+# --------------------------------------------------------------------------------------------
+class _RMSNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, eps):
+        _dev(x, w)
+        shp = x.shape
+        D = shp[-1]
+        xm = x.reshape(-1, D).contiguous()
+        M = xm.shape[0]
+        y = torch.empty_like(xm)
+        rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+        L.check(L.load().gaot_rmsnorm_fwd(_p(xm), _p(w), M, D, float(eps), _p(y), _p(rstd), _stream()), "gaot_rmsnorm_fwd")
+        ctx.save_for_backward(xm, w, rstd)
+        ctx.shp = shp
+        return y.reshape(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xm, w, rstd = ctx.saved_tensors
+        M, D = xm.shape
+        lib = L.load()
+        g = dy.reshape(M, D).contiguous()
+        dx = torch.empty_like(xm)
+        P = int(lib.gaot_rmsnorm_bwd_partials(M))
+        part = torch.empty(P, D, device=xm.device, dtype=torch.float32)
+        L.check(lib.gaot_rmsnorm_bwd(_p(xm), _p(w), _p(rstd), _p(g), None, M, D, _p(dx), _p(part), _stream()), "gaot_rmsnorm_bwd")
+        dw = colsum(part) if ctx.needs_input_grad[1] else None
+        return dx.reshape(ctx.shp), dw, None
+
+
+def rms_norm(x, w, eps):
+    return _RMSNorm.apply(x, w, eps)
+
+
+class _SwiGLU(torch.autograd.Function):
+    """u = [u1 | u3] -> silu(u1) * u3   (attn.py:151)"""
+
+    @staticmethod
+    def forward(ctx, u):
+        _dev(u)
+        shp = u.shape
+        F2 = shp[-1]
+        um = u.reshape(-1, F2).contiguous()
+        M, F = um.shape[0], F2 // 2
+        g = torch.empty(M, F, device=u.device, dtype=torch.float32)
+        L.check(L.load().gaot_swiglu_fwd(_p(um), M, F, _p(g), _stream()), "gaot_swiglu_fwd")
+        ctx.save_for_backward(um)
+        ctx.shp = shp
+        return g.reshape(*shp[:-1], F)
+
+    @staticmethod
+    def backward(ctx, dg):
+        (um,) = ctx.saved_tensors
+        M, F2 = um.shape
+        d = dg.reshape(M, F2 // 2).contiguous()
+        du = torch.empty_like(um)
+        L.check(L.load().gaot_swiglu_bwd(_p(um), _p(d), M, F2 // 2, _p(du), _stream()), "gaot_swiglu_bwd")
+        return du.reshape(ctx.shp)
+
+
+def swiglu(u):
+    return _SwiGLU.apply(u)
+
+
+class _Attention(torch.autograd.Function):
+    """qkv [B,S,(H + 2 Hkv) * D] fused projection output -> softmax(q k^T / sqrt(D)) v  as [B,S,H*D]."""
+
+    @staticmethod
+    def forward(ctx, qkv, H, Hkv, D):
+        _dev(qkv)
+        qkv = qkv.contiguous()
+        B, S, W = qkv.shape
+        assert W == (H + 2 * Hkv) * D
+        o = torch.empty(B, S, H * D, device=qkv.device, dtype=torch.float32)
+        lse = torch.empty(B, H, S, device=qkv.device, dtype=torch.float32)
+        q = qkv.view(-1)
+        kq = q[H * D:]
+        vq = q[(H + Hkv) * D:]
+        L.check(L.load().gaot_attention_fwd(_p(q), _p(kq), _p(vq), W, W, W, B, S, H, Hkv, D, _p(o), H * D, _p(lse), _stream()),
+                "gaot_attention_fwd")
+        ctx.save_for_backward(qkv, o, lse)
+        ctx.dims = (B, S, H, Hkv, D)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, o, lse = ctx.saved_tensors
+        B, S, H, Hkv, D = ctx.dims
+        W = (H + 2 * Hkv) * D
+        lib = L.load()
+        do = do.contiguous()
+        dqkv = torch.empty_like(qkv)
+        ws = torch.empty(int(lib.gaot_attention_bwd_workspace(B, S, H, D)), device=qkv.device, dtype=torch.float32)
+        flat = qkv.view(-1)
+        dflat = dqkv.view(-1)
+        if Hkv == H:
+            dk_t, dv_t, ldk, ldv = dflat[H * D:], dflat[2 * H * D:], W, W
+        else:   # kernel emits per-query-head dK/dV; reduce over the group afterwards
+            dk_full = torch.empty(B, S, H * D, device=qkv.device, dtype=torch.float32)
+            dv_full = torch.empty_like(dk_full)
+            dk_t, dv_t, ldk, ldv = dk_full.view(-1), dv_full.view(-1), H * D, H * D
+        L.check(lib.gaot_attention_bwd(_p(flat), _p(flat[H * D:]), _p(flat[(H + Hkv) * D:]), W, W, W, _p(o), _p(do), H * D,
+                                       _p(lse), B, S, H, Hkv, D, _p(dflat), _p(dk_t), _p(dv_t), W, ldk, ldv, _p(ws), _stream()),
+                "gaot_attention_bwd")
+        if Hkv != H:
+            r = H // Hkv
+            dqkv[..., H * D:(H + Hkv) * D] = dk_full.view(B, S, Hkv, r, D).sum(3).reshape(B, S, Hkv * D)
+            dqkv[..., (H + Hkv) * D:] = dv_full.view(B, S, Hkv, r, D).sum(3).reshape(B, S, Hkv * D)
+        return dqkv, None, None, None
+
+
+def attention(qkv, H, Hkv, D):
+    return _Attention.apply(qkv, H, Hkv, D)
+
+
+class _Patchify(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, sizes, P, inverse):
+        _dev(x)
+        x = x.contiguous()
+        B = x.shape[0]
+        dim = len(sizes)
+        H, W = sizes[0], sizes[1]
+        Dz = sizes[2] if dim == 3 else 0
+        nodes = H * W * (Dz if dim == 3 else 1)
+        pvol = P ** dim
+        if inverse:
+            Cc = x.shape[2] // pvol
+            out = torch.empty(B, nodes, Cc, device=x.device, dtype=torch.float32)
+        else:
+            Cc = x.shape[2]
+            out = torch.empty(B, nodes // pvol, pvol * Cc, device=x.device, dtype=torch.float32)
+        L.check(L.load().gaot_patchify(_p(x), B, H, W, Dz, P, Cc, _p(out), int(inverse), _stream()), "gaot_patchify")
+        ctx.args = (tuple(sizes), P, inverse)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        sizes, P, inverse = ctx.args
+        return _Patchify.apply(g, sizes, P, not inverse), None, None, None
+
+
+def patchify(x, sizes, P):
+    return _Patchify.apply(x, tuple(sizes), P, False)
+
+
+def unpatchify(x, sizes, P):
+    return _Patchify.apply(x, tuple(sizes), P, True)

@@ -1,0 +1,122 @@
+"""GeometryPlan: everything the GNO kernels need that depends only on the mesh geometry.
+
+The reference recomputes these per forward with repeat_interleave / torch_scatter (agno.py:188-224,
+gemb.py:103-171); here they are device arrays built once per neighbour list and cached on it:
+  index / splits (int32 CSR), edge_query (edge -> query id), transposed CSR (t_splits, t_edge) for the
+  scatter-free backward, 1/deg per edge ('mean' reduction), and -- per coordinate pair -- the kernel-MLP
+  input rows, the cosine attention weights and the standardised geometry statistics.
+"""
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib as L
+from .ops import _p, _stream
+
+_PLAN_KEY = "_gaot_amd_plan"
+
+
+class GeometryPlan:
+    def __init__(self, index_i64: torch.Tensor, splits_i64: torch.Tensor, n_src: int):
+        if not index_i64.is_cuda or not splits_i64.is_cuda:
+            raise RuntimeError("GeometryPlan needs the CSR on the GPU (gaot_amd has no CPU path)")
+        lib = L.load()
+        dev = splits_i64.device
+        index_i64 = index_i64.contiguous().long()
+        splits_i64 = splits_i64.contiguous().long()
+        self.Q = int(splits_i64.numel() - 1)
+        self.E = int(index_i64.numel())
+        self.n_src = int(n_src)
+        E1 = max(self.E, 1)
+        self.index = torch.empty(E1, dtype=torch.int32, device=dev)
+        self.splits = torch.empty(self.Q + 1, dtype=torch.int32, device=dev)
+        self.edge_query = torch.empty(E1, dtype=torch.int32, device=dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        L.check(lib.gaot_csr_prepare(_p(index_i64), _p(splits_i64), self.Q, self.E, self.n_src, _p(self.index),
+                                     _p(self.splits), _p(self.edge_query), _p(flag), _stream()), "gaot_csr_prepare")
+        self.t_splits = torch.empty(self.n_src + 1, dtype=torch.int32, device=dev)
+        self.t_edge = torch.empty(E1, dtype=torch.int32, device=dev)
+        scratch = torch.empty(self.n_src + 1, dtype=torch.int32, device=dev)
+        L.check(lib.gaot_csr_transpose(_p(self.index), self.E, self.n_src, _p(self.t_splits), _p(self.t_edge), _p(scratch),
+                                       _stream()), "gaot_csr_transpose")
+        bad = int(flag.item())     # one sync per geometry: the CSR contract is checked on device
+        if bad:
+            raise ValueError(f"invalid CSR neighbour list (flag {bad}: 1 = row_splits not monotone 0..E, 2 = index outside [0, n_src))")
+        deg = (splits_i64[1:] - splits_i64[:-1])
+        self.deg = deg
+        self._inv_deg_edge: Optional[torch.Tensor] = None
+        self._edge_query_long: Optional[torch.Tensor] = None
+        self._index_long = index_i64
+        self._coord_cache: Dict[str, Tuple[tuple, torch.Tensor]] = {}
+
+    # ---- lazily derived
+    @property
+    def edge_query_long(self) -> torch.Tensor:
+        if self._edge_query_long is None:
+            self._edge_query_long = self.edge_query[:self.E].long()
+        return self._edge_query_long
+
+    @property
+    def index_long(self) -> torch.Tensor:
+        return self._index_long
+
+    @property
+    def inv_deg_edge(self) -> torch.Tensor:
+        """1/deg(query(e)) per edge -- the 'mean' reduction of agno.py:264 as a per-edge scale."""
+        if self._inv_deg_edge is None:
+            inv = 1.0 / self.deg.clamp(min=1).to(torch.float32)
+            self._inv_deg_edge = inv[self.edge_query_long].contiguous() if self.E > 0 else inv.new_zeros(1)
+        return self._inv_deg_edge
+
+    def _cached(self, name: str, tensors, build):
+        key = tuple((id(t), t._version) for t in tensors)
+        hit = self._coord_cache.get(name)
+        if hit is not None and hit[0] == key:
+            return hit[2]
+        val = build()
+        self._coord_cache[name] = (key, tuple(tensors), val)   # hold the tensors: ids stay unique while cached
+        return val
+
+    def edge_features(self, src: torch.Tensor, qry: torch.Tensor) -> torch.Tensor:
+        """[y_j, x_i] rows of the kernel MLP (agno.py:229)."""
+        def build():
+            s, q = src.contiguous(), qry.contiguous()
+            dim = s.shape[1]
+            feat = torch.empty(max(self.E, 1), 2 * dim, device=s.device, dtype=torch.float32)
+            L.check(L.load().gaot_edge_features(_p(s), _p(q), dim, _p(self.index), _p(self.edge_query), self.E, _p(feat),
+                                                _stream()), "gaot_edge_features")
+            return feat[:self.E]
+        return self._cached("feat", (src, qry), build)
+
+    def cosine_attention(self, src: torch.Tensor, qry: torch.Tensor) -> torch.Tensor:
+        def build():
+            s, q = src.contiguous(), qry.contiguous()
+            attn = torch.zeros(max(self.E, 1), device=s.device, dtype=torch.float32)
+            L.check(L.load().gaot_edge_attention_cosine(_p(s), _p(q), s.shape[1], _p(self.index), _p(self.splits), self.Q,
+                                                        _p(attn), _stream()), "gaot_edge_attention_cosine")
+            return attn
+        return self._cached("cos", (src, qry), build)
+
+    def geo_stats(self, geom: torch.Tensor, qry: torch.Tensor) -> torch.Tensor:
+        def build():
+            g, q = geom.contiguous(), qry.contiguous()
+            dim = g.shape[1]
+            F = 3 + 2 * dim
+            stats = torch.empty(self.Q, F, device=g.device, dtype=torch.float32)
+            scratch = torch.empty(4 * F, device=g.device, dtype=torch.float64)
+            L.check(L.load().gaot_geo_stats(_p(g), _p(q), dim, _p(self.index), _p(self.splits), self.Q, _p(stats), _p(scratch),
+                                            _stream()), "gaot_geo_stats")
+            return stats
+        return self._cached("stats", (geom, qry), build)
+
+
+def plan_for(neighbors: dict, n_src: int) -> GeometryPlan:
+    """Plan attached to (and cached on) a reference-style neighbour dict."""
+    plan = neighbors.get(_PLAN_KEY)
+    idx = neighbors["neighbors_index"]
+    if plan is None or plan._src_id != (id(idx), idx._version) or plan.n_src != n_src:
+        plan = GeometryPlan(idx, neighbors["neighbors_row_splits"], n_src)
+        plan._src_id = (id(idx), idx._version)
+        neighbors[_PLAN_KEY] = plan
+    return plan

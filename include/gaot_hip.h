@@ -1,0 +1,172 @@
+/*
+ * gaot_hip.h -- C ABI of libgaot_hip.so: the MI355X (gfx950 / CDNA4) kernels behind the GAOT
+ * forward/backward hot path (camlab-ethz/GAOT src/model; citations are file:line in that repo).
+ *
+ * Conventions
+ *   - every entry point returns 0 on success, a negative gaot_status on failure;
+ *     gaot_last_error() returns a thread-local message for the last failure.
+ *   - all pointers are DEVICE pointers owned by the caller; the library never allocates, frees or
+ *     synchronises (graph-capture safe).  `stream` is a hipStream_t passed as void*.
+ *   - dense tensors are row-major fp32; index arrays are int32 unless the name says i64.
+ *   - "CSR" = the reference's neighbour dict (neighbor_search.py:139-140): index[E] holds, for each
+ *     query segment, the indices into the SOURCE point set; splits[Q+1] the segment bounds.
+ */
+#ifndef GAOT_HIP_H
+#define GAOT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* gaot_stream_t;
+
+enum gaot_status {
+    GAOT_OK = 0,
+    GAOT_ERR_BAD_ARG = -1,     /* shape / pointer / alignment contract violated */
+    GAOT_ERR_LAUNCH = -2,      /* hipLaunch / hipGetLastError failed            */
+    GAOT_ERR_UNSUPPORTED = -3  /* valid request this build does not implement   */
+};
+
+enum gaot_act {
+    GAOT_ACT_NONE = 0,
+    GAOT_ACT_GELU = 1,      /* exact erf GELU, mlp.py:307-337 (F.gelu default)            */
+    GAOT_ACT_RELU = 2,      /* gemb.py:54-59                                              */
+    GAOT_ACT_GELU_BWD = 3,  /* out = acc * gelu'(aux)   (aux = saved pre-activation)      */
+    GAOT_ACT_RELU_BWD = 4   /* out = acc * (aux > 0)    (aux = saved post-activation)     */
+};
+
+int gaot_abi_version(void);
+const char* gaot_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32), fused prologue/epilogue.
+ * Replaces every nn.Linear / Conv1d(k=1) on the path and their backward products:
+ *   ChannelMLP mlp.py:283-305, LinearChannelMLP mlp.py:329-337, q/k/v/o_proj attn.py:92-117,
+ *   FFN attn.py:150-156, skip_proj attn.py:225-227, patch_linear gaot.py:208.
+ *
+ *   acc[m,n] = sum_k Aop[m,k] * Bop[k,n]
+ *     Aop[m,k] = a_kmajor ? A[m*lda + k] : A[k*lda + m];  for k >= k_split (if A2): A2 with k-k_split
+ *     Bop[k,n] = b_kmajor ? B[n*ldb + k] : B[k*ldb + n]   (b_kmajor=1 is an nn.Linear weight [N,K])
+ *   v = acc (+ bias[n]) (+ rowbias[(m % rowbias_period)*ld_rowbias + n]);  v *= rowscale[m]
+ *   if aux_out: aux_out[m*ld_aux + n] = v;      v = act(v)  (or v *= act'(aux_in[m*ld_aux+n]))
+ *   v += residual[m*ldr + n];   C[m*ldc + n] = v
+ * Optional pointers may be NULL.  split_k > 1 needs workspace >= split_k*M*N floats.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct gaot_gemm_desc {
+    int32_t M, N, K;
+    const float* A;  int64_t lda;  int32_t a_kmajor;
+    const float* A2; int64_t lda2; int32_t k_split;
+    const float* B;  int64_t ldb;  int32_t b_kmajor;
+    float* C;        int64_t ldc;
+    const float* bias;
+    const float* rowbias; int32_t rowbias_period; int64_t ld_rowbias;
+    const float* rowscale;
+    int32_t act;
+    const float* aux_in; float* aux_out; int64_t ld_aux;
+    const float* residual; int64_t ldr;
+    int32_t split_k; float* workspace;
+} gaot_gemm_desc;
+
+int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Geometry plan pieces (once per mesh geometry; torch_scatter / repeat_interleave call sites
+ * agno.py:131-141,206-207, gemb.py:110-143 become precomputed index arrays).
+ * ------------------------------------------------------------------------------------------ */
+/* int64 CSR -> int32 CSR + per-edge query id.  index32[E], splits32[Q+1], edge_query[E]. */
+int gaot_csr_prepare(const int64_t* index_i64, const int64_t* splits_i64, int32_t Q, int32_t E, int32_t n_src,
+                     int32_t* index32, int32_t* splits32, int32_t* edge_query, int32_t* status_flag,
+                     gaot_stream_t stream);
+/* transposed (by-source) CSR: t_splits[n_src+1], t_edge[E] (edge ids ascending inside a source).
+ * scratch: n_src+1 int32. */
+int gaot_csr_transpose(const int32_t* index32, int32_t E, int32_t n_src,
+                       int32_t* t_splits, int32_t* t_edge, int32_t* scratch, gaot_stream_t stream);
+/* cosine edge attention + segment softmax (agno.py:112-146, 211-224): attn[E].
+ * src [n_src,dim], qry [Q,dim] are the (possibly node_pos_encoded) kernel coordinates. */
+int gaot_edge_attention_cosine(const float* src, const float* qry, int32_t dim,
+                               const int32_t* index32, const int32_t* splits32, int32_t Q,
+                               float* attn, gaot_stream_t stream);
+/* segment softmax of given scores (dot-product attention, agno.py:215-217,224): fwd and bwd.
+ * bwd: dscore = attn * (dattn - sum_seg(attn*dattn)). */
+int gaot_segment_softmax_fwd(const float* score, const int32_t* splits32, int32_t Q, float* attn, gaot_stream_t stream);
+int gaot_segment_softmax_bwd(const float* attn, const float* dattn, const int32_t* splits32, int32_t Q,
+                             float* dscore, gaot_stream_t stream);
+/* kernel-MLP input rows [y_j , x_i] (agno.py:188,206-207,229): feat[E, 2*dim]. */
+int gaot_edge_features(const float* src, const float* qry, int32_t dim,
+                       const int32_t* index32, const int32_t* edge_query, int32_t E,
+                       float* feat, gaot_stream_t stream);
+/* GeometricEmbedding statistics, standardised (gemb.py:83-171): stats[Q, 3+2*dim], dim in {2,3}.
+ * scratch: 4*(3+2*dim) doubles. */
+int gaot_geo_stats(const float* geom, const float* qry, int32_t dim,
+                   const int32_t* index32, const int32_t* splits32, int32_t Q,
+                   float* stats, double* scratch, gaot_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GNO integral transform = gather / per-edge weight / CSR segment reduce (agno.py:198,245-271).
+ *   out[b,r,:] = sum_{t in [splits[r],splits[r+1])} escale[edge(t)] * w[edge(t),:] * src[b, col(t), :]
+ *     edge(t) = edge_map ? edge_map[t] : t ;  col(t) = cols[edge(t)] when edge_map else cols[t]
+ * forward  : splits/cols = CSR, edge_map = NULL, src = f_y                 -> out [B,Q,C]
+ * backward : splits = t_splits, edge_map = t_edge, cols = edge_query, src = dOut -> dF [B,n_src,C]
+ * w may be NULL (all ones).  escale[E] may be NULL; it carries the edge attention weight (agno.py:249-250)
+ * or 1/deg(query) for the 'mean' reduction (agno.py:264).  Any C (16-byte lanes when C % 4 == 0).
+ * ------------------------------------------------------------------------------------------ */
+int gaot_gno_gather_reduce(const float* w, const float* src, int32_t B, int32_t n_src_rows, int32_t C,
+                           const int32_t* splits, const int32_t* cols, const int32_t* edge_map,
+                           int32_t n_out_rows, const float* escale, float* out, gaot_stream_t stream);
+/* dW[e,:] = escale[e] * sum_b dOut[b, edge_query[e], :] * f[b, index[e], :]   (escale may be NULL) */
+int gaot_gno_edge_grad(const float* dout, const float* f, int32_t B, int32_t Q, int32_t n_src, int32_t C,
+                       const int32_t* index32, const int32_t* edge_query, int32_t E,
+                       const float* escale, float* dw, gaot_stream_t stream);
+/* per-edge batched variants used by the 'nonlinear' transforms (agno.py:230-246):
+ *   prod[b,e,:] = k[b,e,:] * f[b,index[e],:] (mul_f) * attn[e]      and the segment sum over e. */
+int gaot_gno_segment_sum(const float* x, int32_t B, int32_t E, int32_t C, const int32_t* splits, int32_t Q,
+                         const float* rowscale, float* out, gaot_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * processor pieces (attn.py)
+ * ------------------------------------------------------------------------------------------ */
+/* RMSNorm attn.py:161-172.  y = x * rstd * w ; rstd[M] saved for backward. */
+int gaot_rmsnorm_fwd(const float* x, const float* w, int32_t M, int32_t D, float eps,
+                     float* y, float* rstd, gaot_stream_t stream);
+/* dx = rstd*(w*dy - x*rstd^2*mean(w*dy*x)) (+ dx_add) ; dw_partial[P,D] column partials (P returned rows =
+ * gaot_rmsnorm_bwd_partials(M)); caller sums them. */
+int gaot_rmsnorm_bwd_partials(int32_t M);
+int gaot_rmsnorm_bwd(const float* x, const float* w, const float* rstd, const float* dy, const float* dx_add,
+                     int32_t M, int32_t D, float* dx, float* dw_partial, gaot_stream_t stream);
+/* SwiGLU gate attn.py:151: u = [u1 | u3] ([M,2F]); g = silu(u1)*u3 ; bwd writes du [M,2F]. */
+int gaot_swiglu_fwd(const float* u, int32_t M, int32_t F, float* g, gaot_stream_t stream);
+int gaot_swiglu_bwd(const float* u, const float* dg, int32_t M, int32_t F, float* du, gaot_stream_t stream);
+/* softmax attention, no mask, scale 1/sqrt(head_dim) (attn.py:98-116, F.scaled_dot_product_attention).
+ * q/k/v are strided views: element (b,s,h,d) at ptr[(b*S+s)*ld + h*head_dim + d]; kv head = h / (H/Hkv).
+ * o has the same addressing with ldo.  lse[B,H,S] (natural-log-sum-exp of scaled scores) saved for bwd.
+ * head_dim <= 64, S arbitrary. */
+int gaot_attention_fwd(const float* q, const float* k, const float* v, int64_t ldq, int64_t ldk, int64_t ldv,
+                       int32_t B, int32_t S, int32_t H, int32_t Hkv, int32_t head_dim,
+                       float* o, int64_t ldo, float* lse, gaot_stream_t stream);
+/* workspace floats needed by gaot_attention_bwd */
+int64_t gaot_attention_bwd_workspace(int32_t B, int32_t S, int32_t H, int32_t head_dim);
+int gaot_attention_bwd(const float* q, const float* k, const float* v, int64_t ldq, int64_t ldk, int64_t ldv,
+                       const float* o, const float* dout, int64_t ldo, const float* lse,
+                       int32_t B, int32_t S, int32_t H, int32_t Hkv, int32_t head_dim,
+                       float* dq, float* dk, float* dv, int64_t lddq, int64_t lddk, int64_t lddv,
+                       float* workspace, gaot_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * reductions / layout
+ * ------------------------------------------------------------------------------------------ */
+/* out[n] = sum_m x[m*ld + n]  (bias gradients).  scratch: gaot_colsum_scratch(M,N) floats. */
+int64_t gaot_colsum_scratch(int32_t M, int32_t N);
+int gaot_colsum(const float* x, int64_t ld, int32_t M, int32_t N, float* out, float* scratch, gaot_stream_t stream);
+/* out[r,:] = sum_b x[b,r,:]   (row-periodic bias gradients; x is [B,R,N] contiguous) */
+int gaot_batchsum(const float* x, int32_t B, int64_t RN, float* out, gaot_stream_t stream);
+/* patchify gaot.py:182-185,202-205 and its inverse gaot.py:224-231.  Latent grid H x W (x Dz; Dz = 0 for 2-D).
+ * inverse = 0: in = grid[b, (h,w[,z]), c]  -> out = tokens[b, s, (p..., c)];  inverse = 1: the other way. */
+int gaot_patchify(const float* in, int32_t B, int32_t H, int32_t W, int32_t Dz, int32_t P, int32_t C,
+                  float* out, int32_t inverse, gaot_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAOT_HIP_H */

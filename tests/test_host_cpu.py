@@ -1,0 +1,143 @@
+"""CPU-only checks: the C-ABI library loads and exports exactly what include/gaot_hip.h declares, the host
+mirror has the reference's module surface / state_dict / seeded init, and nothing falls back to the CPU."""
+import os
+import re
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+import torch
+
+from tests._golden import GOLDEN_DIR, Golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SEEDS = {"fx2d_base": 0, "fx2d_base_s1": 1, "attn_dot": 0, "ms_weighted": 1, "fx3d": 0, "pointnet": 0,
+         "fx2d_inproj": 3, "even_layers": 4, "nonlinear": 0, "node_embed": 0, "vx2d": 0, "no_geoembed": 0}
+
+
+def _model(g):
+    from gaot_amd.model.gaot import GAOT
+    from gaot_amd.model.layers.magno import MAGNOConfig
+    from gaot_amd.model.layers.attn import TransformerConfig, AttentionConfig
+    cfg = NS(args=NS(magno=MAGNOConfig(**g.magno), transformer=TransformerConfig(attn_config=AttentionConfig(**g.attn), **g.transformer)),
+             latent_tokens_size=g.latent_tokens_size)
+    return GAOT(g.raw["in.pndata"].shape[2], g.raw["in.target"].shape[2], cfg)
+
+
+def test_library_builds_loads_and_exports_header_symbols():
+    from gaot_amd.build import build
+    from gaot_amd import _lib
+    build(verbose=False)
+    lib = _lib.load()
+    assert lib.gaot_abi_version() == 1
+    header = open(os.path.join(ROOT, "include", "gaot_hip.h")).read()
+    declared = set(re.findall(r"\b(gaot_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_gemm_desc_layout_matches_header():
+    """field order of the ctypes struct == field order in the C struct"""
+    from gaot_amd._lib import GemmDesc
+    header = open(os.path.join(ROOT, "include", "gaot_hip.h")).read()
+    body = header[header.index("typedef struct gaot_gemm_desc {"):header.index("} gaot_gemm_desc;")]
+    names = re.findall(r"(?:\*|\s)([A-Za-z_][A-Za-z0-9_]*)\s*[;,]", body)
+    assert names == [f[0] for f in GemmDesc._fields_], names
+
+
+@pytest.mark.parametrize("case", sorted(SEEDS))
+def test_state_dict_keys_order_and_seeded_init_equal_reference(case):
+    g = Golden(case)
+    torch.manual_seed(1000 + SEEDS[case])
+    sd = _model(g).state_dict()
+    ref = g.state_dict
+    assert list(sd.keys()) == list(ref.keys())
+    for k in ref:
+        assert sd[k].shape == ref[k].shape and torch.equal(sd[k], ref[k]), k
+
+
+def test_checkpoint_roundtrip_with_module_prefix():
+    """trainer_utils.py:43-46,78-89 tolerate a DDP 'module.' prefix; the key names are the compat surface"""
+    g = Golden("fx2d_base")
+    m = _model(g)
+    r = m.load_state_dict({k: v for k, v in g.state_dict.items()}, strict=True)
+    assert not r.missing_keys and not r.unexpected_keys
+    assert "positions" not in m.state_dict() and not any("pos_emb" in k for k in m.state_dict())
+
+
+def test_no_cpu_fallback():
+    g = Golden("fx2d_base")
+    m = _model(g)
+    with pytest.raises(RuntimeError, match="no CPU"):
+        m(latent_tokens_coord=g.t("in.latent"), xcoord=g.t("in.xcoord"), pndata=g.t("in.pndata"))
+
+
+def test_product_never_imports_oracle():
+    for dp, _, files in os.walk(os.path.join(ROOT, "gaot_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert "oracle" not in src.replace("# oracle", ""), os.path.join(dp, f)
+
+
+def test_config_validation_and_errors():
+    from gaot_amd.model.layers.magno import MAGNOConfig, MAGNOEncoder
+    from gaot_amd.model.layers.attn import TransformerConfig, AttentionConfig, GroupQueryFlashAttention
+    from gaot_amd.model.gaot import GAOT
+    with pytest.raises(ValueError):
+        MAGNOConfig(coord_dim=4)
+    with pytest.raises(ValueError):
+        MAGNOConfig(sampling_strategy="ratio", sample_ratio=1.5)
+    with pytest.raises(ValueError):
+        MAGNOConfig(sampling_strategy="max_neighbors")
+    with pytest.raises(AssertionError):
+        GroupQueryFlashAttention(64, 60, num_heads=8)
+    with pytest.raises(ValueError):
+        GAOT(1, 1, NS(args=NS(magno=MAGNOConfig(), transformer=TransformerConfig()), latent_tokens_size=[8, 8, 8]))
+    enc = MAGNOEncoder(1, 8, MAGNOConfig(lifting_channels=8, precompute_edges=True))
+    with pytest.raises(ValueError, match="encoder_nbrs required"):
+        enc(torch.zeros(5, 2), torch.zeros(1, 5, 1), torch.zeros(4, 2))
+    with pytest.raises(ValueError, match="pndata shape mismatch"):
+        enc(torch.zeros(5, 2), torch.zeros(1, 6, 1), torch.zeros(4, 2), encoder_nbrs=[])
+    assert [f for f in MAGNOConfig.__dataclass_fields__][:5] == ["coord_dim", "radius", "hidden_size", "mlp_layers", "lifting_channels"]
+    assert len(MAGNOConfig.__dataclass_fields__) == 21 and len(TransformerConfig.__dataclass_fields__) == 10
+    assert len(AttentionConfig.__dataclass_fields__) == 5
+
+
+def test_neighbor_search_known_answers_cpu():
+    from gaot_amd.model.layers.utils.neighbor_search import NeighborSearch
+    z = np.load(os.path.join(GOLDEN_DIR, "neighbor_kats.npz"))
+    ns = NeighborSearch("auto")
+    for name in ("lattice", "rand2d", "rand3d"):
+        data, q, r = torch.from_numpy(z[f"{name}.data"]), torch.from_numpy(z[f"{name}.queries"]), float(z[f"{name}.radius"])
+        out = ns(data, q, r)
+        ref_i, ref_s = torch.from_numpy(z[f"{name}.native.index"]), torch.from_numpy(z[f"{name}.native.splits"])
+        if torch.equal(out["neighbors_row_splits"], ref_s):
+            assert torch.equal(out["neighbors_index"], ref_i)
+        else:   # only pairs within rounding of the radius may differ (reference uses cdist's expansion)
+            a = set(zip(np.repeat(np.arange(len(ref_s) - 1), np.diff(ref_s.numpy())).tolist(), ref_i.tolist()))
+            qid = np.repeat(np.arange(q.shape[0]), np.diff(out["neighbors_row_splits"].numpy()))
+            b = set(zip(qid.tolist(), out["neighbors_index"].tolist()))
+            for (qi, di) in a ^ b:
+                assert abs(float((q[qi] - data[di]).norm()) - r) < 1e-5
+
+
+def test_edge_drop_semantics():
+    from gaot_amd.model.layers.utils.edge_drop import apply_edge_drop_csr
+    torch.manual_seed(0)
+    deg = torch.tensor([0, 5, 2, 9, 1])
+    sp = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(deg, 0)])
+    idx = torch.arange(int(deg.sum()))
+    nb = {"neighbors_index": idx, "neighbors_row_splits": sp}
+    assert apply_edge_drop_csr(nb, "max_neighbors", max_neighbors=3, training=False) is nb
+    assert apply_edge_drop_csr(nb, None) is nb
+    out = apply_edge_drop_csr(nb, "max_neighbors", max_neighbors=3)
+    nd = out["neighbors_row_splits"][1:] - out["neighbors_row_splits"][:-1]
+    assert nd.tolist() == [0, 3, 2, 3, 1]
+    for i in range(5):       # kept edges come from the right segment, no duplicates
+        seg = out["neighbors_index"][out["neighbors_row_splits"][i]:out["neighbors_row_splits"][i + 1]].tolist()
+        assert len(set(seg)) == len(seg) and all(sp[i] <= e < sp[i + 1] for e in seg)
+    out = apply_edge_drop_csr(nb, "ratio", sample_ratio=0.5)
+    assert int(out["neighbors_row_splits"][-1]) == out["neighbors_index"].numel() <= idx.numel()
+    assert apply_edge_drop_csr(nb, "ratio", sample_ratio=1.0) is nb

@@ -1,0 +1,199 @@
+"""-m gpu: the whole GAOT path on the HIP kernels against (a) the golden vectors exported from the imported
+reference and (b) the CPU oracle at sizes the oracle finishes in seconds.
+
+Tolerance (north_star): relative L2 output error <= 1e-5 in fp32.  Gradients are compared per tensor,
+relative to that tensor's largest reference entry."""
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+import torch
+
+from tests._golden import Golden, MODEL_CASES, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+OUT_TOL = 1e-5
+GRAD_TOL = 2e-4
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def build_model(g: Golden):
+    from gaot_amd.model.gaot import GAOT
+    from gaot_amd.model.layers.magno import MAGNOConfig
+    from gaot_amd.model.layers.attn import TransformerConfig, AttentionConfig
+    cfg = NS(args=NS(magno=MAGNOConfig(**g.magno), transformer=TransformerConfig(attn_config=AttentionConfig(**g.attn), **g.transformer)),
+             latent_tokens_size=g.latent_tokens_size)
+    cin = g.raw["in.pndata"].shape[2] if g.has("in.pndata") else g.raw["in.x_batch"].shape[2] - 1
+    cout = g.raw["in.target"].shape[2] if g.has("in.target") else g.raw["out.pair_forward"].shape[2]
+    m = GAOT(cin, cout, cfg)
+    missing = m.load_state_dict(g.state_dict, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return m.to(dev())
+
+
+def to_dicts(lists):
+    def one(c):
+        return {"neighbors_index": c[0].to(dev()), "neighbors_row_splits": c[1].to(dev())}
+    if isinstance(lists[0], tuple):
+        return [one(c) for c in lists]
+    return [[one(c) for c in row] for row in lists]
+
+
+def seed_neighbor_cache(model, g: Golden, x, lat):
+    """fx cases: hand the model the reference's own radius graph (same cache key the module would compute)."""
+    enc, dec = g.csr_lists()
+    scales = tuple(g.magno.get("scales", [1.0]))
+    model.encoder.neighbor_cache[f"fx_{x.shape}_{lat.shape}_{scales}"] = to_dicts(enc)
+    model.decoder.neighbor_cache[f"dec_fx_{lat.shape}_{x.shape}_{scales}"] = to_dicts(dec)
+
+
+@pytest.mark.parametrize("case", MODEL_CASES)
+def test_forward_loss_grads_vs_golden(case):
+    g = Golden(case)
+    model = build_model(g)
+    model.train()
+    lat, x, p, tgt = [g.t(k).to(dev()) for k in ("in.latent", "in.xcoord", "in.pndata", "in.target")]
+    kw = {}
+    if g.magno.get("precompute_edges", False):
+        enc, dec = g.csr_lists()
+        kw = dict(encoder_nbrs=to_dicts(enc), decoder_nbrs=to_dicts(dec))
+    else:
+        seed_neighbor_cache(model, g, x, lat)
+    pred = model(latent_tokens_coord=lat, xcoord=x, pndata=p, **kw)
+    assert rel_l2(pred.cpu(), g.t("out.pred")) < OUT_TOL
+    loss = torch.nn.functional.mse_loss(pred, tgt)
+    loss.backward()
+    assert abs(float(loss) - float(g.t("out.loss"))) < 1e-5 * abs(float(g.t("out.loss")))
+    gg, gn = g.group("g."), g.group("gnorm.")
+    for k, prm in model.named_parameters():
+        got = prm.grad.cpu() if prm.grad is not None else torch.zeros_like(prm).cpu()
+        if k in gg:
+            ref = gg[k]
+            assert float((got - ref).abs().max()) / max(float(ref.abs().max()), 1e-4) < GRAD_TOL, k
+        elif k in gn:
+            assert abs(float(got.norm()) - float(gn[k])) <= GRAD_TOL * max(float(gn[k]), 1e-6) + 1e-8, k
+
+
+def test_adamw_step_matches_reference_update():
+    """row T of SURVEY 8a: MSE -> backward -> torch AdamW on the HIP-computed grads reproduces the reference's weights."""
+    g = Golden("fx2d_base")
+    model = build_model(g)
+    model.train()
+    lat, x, p, tgt = [g.t(k).to(dev()) for k in ("in.latent", "in.xcoord", "in.pndata", "in.target")]
+    seed_neighbor_cache(model, g, x, lat)
+    opt = torch.optim.AdamW(model.parameters(), lr=8e-4, weight_decay=1e-5)
+    opt.zero_grad()
+    torch.nn.functional.mse_loss(model(latent_tokens_coord=lat, xcoord=x, pndata=p), tgt).backward()
+    opt.step()
+    w1 = g.group("w1.")
+    for k, prm in model.named_parameters():
+        assert float((prm.detach().cpu() - w1[k]).abs().max()) < 5e-6, k
+
+
+def test_own_neighbor_search_gives_reference_graph():
+    """device radius search (exact differences) vs the reference's native backend on the golden geometry"""
+    from gaot_amd.model.layers.utils.neighbor_search import NeighborSearch
+    g = Golden("fx2d_base")
+    enc, dec = g.csr_lists()
+    ns = NeighborSearch("native")
+    r = ns(g.t("in.xcoord").to(dev()), g.t("in.latent").to(dev()), g.magno["radius"])
+    assert torch.equal(r["neighbors_row_splits"].cpu(), enc[0][1]) and torch.equal(r["neighbors_index"].cpu(), enc[0][0])
+    z = np.load(__import__("os").path.join(__import__("tests._golden", fromlist=["x"]).GOLDEN_DIR, "neighbor_kats.npz"))
+    out = ns(torch.from_numpy(z["lattice.data"]).to(dev()), torch.from_numpy(z["lattice.queries"]).to(dev()), 1.0)
+    assert torch.equal(out["neighbors_index"].cpu(), torch.from_numpy(z["lattice.native.index"]))
+    assert torch.equal(out["neighbors_row_splits"].cpu(), torch.from_numpy(z["lattice.native.splits"]))
+
+
+def test_condnorm_pair_forward_and_rollouts():
+    g = Golden("condnorm_rollout")
+    model = build_model(g)
+    model.eval()
+    lat, x, xb = g.t("in.latent").to(dev()), g.t("in.xcoord").to(dev()), g.t("in.x_batch").to(dev())
+    with torch.no_grad():
+        pf = model(latent_tokens_coord=lat, xcoord=x, pndata=xb[..., :-1].contiguous(), condition=xb[..., 0, -2:-1])
+    assert rel_l2(pf.cpu(), g.t("out.pair_forward")) < OUT_TOL
+    stats = {}
+    for grp in ("u", "c", "res", "der"):
+        stats[grp] = {"mean": g.t(f"stats.{grp}.mean"), "std": g.t(f"stats.{grp}.std")}
+    for grp in ("start_time", "time_diffs"):
+        stats[grp] = {"mean": float(g.raw[f"stats.{grp}.mean"]), "std": float(g.raw[f"stats.{grp}.std"])}
+    for mode in ("output", "residual", "time_der"):
+        r = model.autoregressive_predict(x_batch=xb[..., :3], time_indices=g.raw["in.time_indices"], t_values=g.raw["in.t_values"],
+                                         stats=stats, stepper_mode=mode, latent_tokens_coord=lat, fixed_coord=x,
+                                         use_conditional_norm=True)
+        assert rel_l2(r.cpu(), g.t(f"out.rollout.{mode}")) < 5e-5, mode
+
+
+def _oracle_vs_hip(N, lat_sizes, B, C, hidden, heads, radius, seed, cin=1, cout=1, d=2, P=2):
+    from gaot_amd.model.gaot import GAOT
+    from gaot_amd.model.layers.magno import MAGNOConfig
+    from gaot_amd.model.layers.attn import TransformerConfig, AttentionConfig
+    from oracle import gaot_oracle as O
+    torch.manual_seed(seed)
+    mcfg = MAGNOConfig(coord_dim=d, radius=radius, hidden_size=64, mlp_layers=3, lifting_channels=C, precompute_edges=True)
+    tcfg = TransformerConfig(patch_size=P, hidden_size=hidden, attn_config=AttentionConfig(num_heads=heads, num_kv_heads=heads))
+    model = GAOT(cin, cout, NS(args=NS(magno=mcfg, transformer=tcfg), latent_tokens_size=lat_sizes))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(seed)
+    lat = O.latent_grid(lat_sizes)
+    x = torch.rand(N, d, generator=g) * 2 - 1
+    p = torch.randn(B, N, cin, generator=g)
+    tgt = torch.randn(B, N, cout, generator=g)
+    enc, dec = [O.radius_csr(x, lat, radius)], [O.radius_csr(lat, x, radius)]
+    ocfg = O.OracleConfig(coord_dim=d, radius=radius, hidden_size=64, lifting_channels=C, patch_size=P, tf_hidden_size=hidden,
+                          num_heads=heads, num_kv_heads=heads, latent_tokens_size=lat_sizes, precompute_edges=True)
+    loss_ref, grads_ref, _, _ = O.train_step(sd, ocfg, dict(latent=lat, xcoord=x, pndata=p, target=tgt, encoder_nbrs=enc, decoder_nbrs=dec))
+    pred_ref = O.gaot_forward(sd, ocfg, lat, x, p, encoder_nbrs=enc, decoder_nbrs=dec)
+    model.to(dev()).train()
+    pred = model(latent_tokens_coord=lat.to(dev()), xcoord=x.to(dev()), pndata=p.to(dev()),
+                 encoder_nbrs=to_dicts(enc), decoder_nbrs=to_dicts(dec))
+    loss = torch.nn.functional.mse_loss(pred, tgt.to(dev()))
+    loss.backward()
+    assert rel_l2(pred.cpu(), pred_ref) < OUT_TOL
+    assert abs(float(loss) - float(loss_ref)) < 1e-5 * abs(float(loss_ref))
+    for k, prm in model.named_parameters():
+        ref = grads_ref[k]
+        assert float((prm.grad.cpu() - ref).abs().max()) / max(float(ref.abs().max()), 1e-4) < GRAD_TOL, k
+
+
+def test_example_config_shape_small_mesh():
+    """the reference's example hyper-parameters (C=64, hidden 256, 8 heads x 32, latent 64x64, P=2) on a 2k-node mesh"""
+    _oracle_vs_hip(N=2048, lat_sizes=[64, 64], B=2, C=64, hidden=256, heads=8, radius=0.06, seed=0)
+
+
+def test_3d_point_cloud_small():
+    _oracle_vs_hip(N=1500, lat_sizes=[8, 8, 8], B=2, C=48, hidden=384, heads=8, radius=0.5, seed=1, cin=3, d=3)
+
+
+def test_full_size_properties_16k():
+    """BASELINE config 2 (16 384 nodes, batch 8): size-independent properties instead of an oracle run:
+    (i) batch independence -- sample b of a batch-8 call equals a batch-1 call on that sample;
+    (ii) linearity of the encoder in pndata given fixed geometry; (iii) determinism (bitwise repeatable)."""
+    from gaot_amd.model.gaot import GAOT
+    from gaot_amd.model.layers.magno import MAGNOConfig
+    from gaot_amd.model.layers.attn import TransformerConfig
+    torch.manual_seed(0)
+    model = GAOT(1, 1, NS(args=NS(magno=MAGNOConfig(lifting_channels=64), transformer=TransformerConfig(patch_size=2, hidden_size=256)),
+                          latent_tokens_size=[64, 64])).to(dev()).eval()
+    g = torch.Generator().manual_seed(0)
+    lat = torch.stack(torch.meshgrid(torch.linspace(-1, 1, 64), torch.linspace(-1, 1, 64), indexing="ij"), -1).reshape(-1, 2).to(dev())
+    x = (torch.rand(16384, 2, generator=g) * 2 - 1).to(dev())
+    p = torch.randn(8, 16384, 1, generator=g).to(dev())
+    with torch.no_grad():
+        y8 = model(latent_tokens_coord=lat, xcoord=x, pndata=p)
+        y8b = model(latent_tokens_coord=lat, xcoord=x, pndata=p)
+        y1 = model(latent_tokens_coord=lat, xcoord=x, pndata=p[3:4])
+        e1 = model.encode(x, p, lat, None)
+        e2 = model.encode(x, 2.5 * p, lat, None)
+        e0 = model.encode(x, torch.zeros_like(p), lat, None)
+    assert torch.equal(y8, y8b)
+    assert rel_l2(y8[3:4].cpu(), y1.cpu()) < 1e-6
+    assert rel_l2((e2 - e0).cpu(), (2.5 * (e1 - e0)).cpu()) < 1e-5
+    assert torch.isfinite(y8).all() and y8.shape == (8, 16384, 1)
+    enc_nb = list(model.encoder.neighbor_cache.values())[0][0]
+    deg = enc_nb["neighbors_row_splits"][1:] - enc_nb["neighbors_row_splits"][:-1]
+    assert int(deg.sum()) == enc_nb["neighbors_index"].numel() and int(deg.max()) < 64

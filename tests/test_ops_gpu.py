@@ -1,0 +1,327 @@
+"""-m gpu: every HIP kernel behind the C ABI against a float64 / oracle computation of the same op."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu().flatten(), b.detach().double().cpu().flatten()
+    return float((a - b).norm() / max(float(b.norm()), 1e-30))
+
+
+def maxrel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-30))
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 70, 45), (8192, 256, 256), (1000, 1, 64), (77, 33, 7),
+                                   (2048, 64, 4), (513, 257, 130), (64, 1024, 256)])
+def test_gemm_nt_nn_tn(M, N, K):
+    from gaot_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g)
+    gy = torch.randn(M, N, generator=g)
+    xd, wd, gd = x.to(dev()), w.to(dev()), gy.to(dev())
+    y = ops.linear_nt(xd, wd)
+    assert rel(y, x.double() @ w.double().t()) < 2e-6
+    dx = ops.matmul_nn(gd, wd)
+    assert rel(dx, gy.double() @ w.double()) < 2e-6
+    dw = ops.matmul_tn(gd, xd)
+    assert rel(dw, gy.double().t() @ x.double()) < 2e-6
+
+
+def test_gemm_epilogues():
+    from gaot_amd import ops, _lib as L
+    g = torch.Generator().manual_seed(5)
+    M, N, K, P = 384, 96, 64, 128
+    x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / 8
+    b, rb, rs, res = torch.randn(N, generator=g), torch.randn(P, N, generator=g), torch.rand(M, generator=g) + 0.5, torch.randn(M, N, generator=g)
+    X, W, Bv, RB, RS, RES = [t.to(dev()) for t in (x, w, b, rb, rs, res)]
+    z_ref = ((x.double() @ w.double().t() + b.double() + rb.double().repeat(M // P, 1)) * rs.double()[:, None])
+    aux = torch.empty(M, N, device=dev())
+    y = ops.linear_nt(X, W, bias=Bv, rowbias=RB, rowbias_period=P, ld_rowbias=N, rowscale=RS, act=L.ACT_GELU, aux_out=aux,
+                      ld_aux=N, residual=RES, ldr=N)
+    assert rel(aux, z_ref) < 2e-6
+    assert rel(y, torch.nn.functional.gelu(z_ref) + res.double()) < 2e-6
+    y2 = ops.linear_nt(X, W, bias=Bv, act=L.ACT_RELU)
+    assert rel(y2, torch.relu(x.double() @ w.double().t() + b.double())) < 2e-6
+    # backward activations fused into the input-gradient product
+    zz = torch.randn(M, K, generator=g)
+    gy = torch.randn(M, N, generator=g)
+    zt = zz.double().requires_grad_(True)
+    torch.nn.functional.gelu(zt).backward(gy.double() @ w.double())
+    d = ops.matmul_nn(gy.to(dev()), W, act=L.ACT_GELU_BWD, aux_in=zz.to(dev()), ld_aux=K)
+    assert rel(d, zt.grad) < 3e-6
+    d2 = ops.matmul_nn(gy.to(dev()), W, act=L.ACT_RELU_BWD, aux_in=zz.to(dev()), ld_aux=K)
+    assert rel(d2, (gy.double() @ w.double()) * (zz.double() > 0)) < 2e-6
+    # split input (cat([x, x2]) @ W^T) and explicit split-K
+    x2 = torch.randn(M, 32, generator=g)
+    w2 = torch.randn(N, K + 32, generator=g)
+    y3 = torch.empty(M, N, device=dev())
+    ops.gemm(M, N, K + 32, X, K, 1, w2.to(dev()), K + 32, 1, y3, N, A2=x2.to(dev()), lda2=32, k_split=K)
+    assert rel(y3, torch.cat([x, x2], 1).double() @ w2.double().t()) < 2e-6
+    y4 = torch.empty(M, N, device=dev())
+    ops.gemm(M, N, K, X, K, 1, W, K, 1, y4, N, bias=Bv, split_k=2)
+    assert rel(y4, x.double() @ w.double().t() + b.double()) < 2e-6
+
+
+def test_gemm_strided_views():
+    from gaot_amd import ops
+    g = torch.Generator().manual_seed(9)
+    big = torch.randn(200, 160, generator=g).to(dev())
+    w = torch.randn(48, 128, generator=g).to(dev())
+    y = ops.linear_nt(big[:, 32:96], w[:, 64:])            # lda = 160, ldb = 128, offsets
+    assert rel(y, big[:, 32:96].double().cpu() @ w[:, 64:].double().cpu().t()) < 2e-6
+
+
+def test_linear_autograd_matches_torch():
+    from gaot_amd import ops
+    g = torch.Generator().manual_seed(11)
+    B, S, K, K2, N = 3, 64, 32, 32, 40
+    x, x2 = torch.randn(B, S, K, generator=g), torch.randn(B, S, K2, generator=g)
+    w, b = torch.randn(N, K + K2, generator=g) / 6, torch.randn(N, generator=g)
+    res, rb = torch.randn(B, S, N, generator=g), torch.randn(S, N, generator=g)
+    leaves = [t.clone().double().requires_grad_(True) for t in (x, w, b, res, rb, x2)]
+    ref = torch.cat([leaves[0], leaves[5]], -1) @ leaves[1].t() + leaves[2] + leaves[3] + leaves[4][None]
+    go = torch.randn(B, S, N, generator=g)
+    ref.backward(go.double())
+    dl = [t.clone().to(dev()).requires_grad_(True) for t in (x, w, b, res, rb, x2)]
+    out = ops.linear(dl[0], dl[1], dl[2], residual=dl[3], rowbias=dl[4], x2=dl[5])
+    out.backward(go.to(dev()))
+    assert rel(out, ref) < 2e-6
+    for a, r in zip(dl, leaves):
+        assert rel(a.grad, r.grad) < 3e-6
+
+
+def test_mlp_chain_autograd():
+    from gaot_amd import ops
+    g = torch.Generator().manual_seed(13)
+    E = 777
+    x = torch.randn(E, 4, generator=g)
+    ws = [torch.randn(16, 4, generator=g) / 2, torch.randn(16, 16, generator=g) / 4, torch.randn(8, 16, generator=g) / 4]
+    bs = [torch.randn(16, generator=g) * 0.1, torch.randn(16, generator=g) * 0.1, torch.randn(8, generator=g) * 0.1]
+    for acts in (["gelu", "gelu", "none"], ["relu", "relu", "relu"]):
+        lw = [t.clone().double().requires_grad_(True) for t in ws]
+        lb = [t.clone().double().requires_grad_(True) for t in bs]
+        lx = x.clone().double().requires_grad_(True)
+        h = lx
+        for w_, b_, a in zip(lw, lb, acts):
+            h = h @ w_.t() + b_
+            h = torch.nn.functional.gelu(h) if a == "gelu" else (torch.relu(h) if a == "relu" else h)
+        go = torch.randn(E, 8, generator=g)
+        h.backward(go.double())
+        dw = [t.clone().to(dev()).requires_grad_(True) for t in ws]
+        db = [t.clone().to(dev()).requires_grad_(True) for t in bs]
+        dx = x.clone().to(dev()).requires_grad_(True)
+        out = ops.mlp_chain(dx, dw, db, acts)
+        out.backward(go.to(dev()))
+        assert rel(out, h) < 3e-6
+        assert rel(dx.grad, lx.grad) < 1e-5
+        for a_, r_ in zip(dw + db, lw + lb):
+            assert rel(a_.grad, r_.grad) < 1e-5
+
+
+# ------------------------------------------------------------------ geometry plan + GNO
+def _random_geometry(seed, n, lat_sizes, radius, d=2):
+    from oracle import gaot_oracle as O
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(n, d, generator=g) * 2 - 1
+    lat = O.latent_grid(lat_sizes)
+    return x, lat, O.radius_csr(x, lat, radius), O.radius_csr(lat, x, radius)
+
+
+def _dict(csr):
+    return {"neighbors_index": csr[0].to(dev()), "neighbors_row_splits": csr[1].to(dev())}
+
+
+@pytest.mark.parametrize("d,n,lat,r", [(2, 500, [16, 16], 0.15), (2, 40, [16, 16], 0.1), (3, 400, [6, 6, 6], 0.5)])
+def test_plan_arrays_attention_stats(d, n, lat, r):
+    from gaot_amd.plan import plan_for
+    from oracle import gaot_oracle as O
+    x, latc, enc, _ = _random_geometry(3, n, lat, r, d)
+    idx, sp = enc
+    plan = plan_for(_dict(enc), n)
+    assert torch.equal(plan.index[:plan.E].cpu().long(), idx) and torch.equal(plan.splits.cpu().long(), sp)
+    qid, deg = O.edge_query_ids(sp)
+    assert torch.equal(plan.edge_query[:plan.E].cpu().long(), qid)
+    # transposed CSR: for every source j the ascending list of edges pointing at it
+    tsp, te = plan.t_splits.cpu().long(), plan.t_edge[:plan.E].cpu().long()
+    order = torch.argsort(idx * (plan.E + 1) + torch.arange(plan.E))
+    assert torch.equal(te, order)
+    assert torch.equal(tsp, torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(torch.bincount(idx, minlength=n), 0)]))
+    X, Lc = x.to(dev()), latc.to(dev())
+    # cosine attention
+    xi, yj = latc[qid], x[idx]
+    s = ((xi / xi.norm(dim=-1, keepdim=True).clamp_min(1e-12)) * (yj / yj.norm(dim=-1, keepdim=True).clamp_min(1e-12))).sum(-1)
+    att = O.segment_softmax(s, qid, sp.numel() - 1)
+    assert maxrel(plan.cosine_attention(X, Lc)[:plan.E], att) < 5e-6
+    assert torch.equal(plan.edge_features(X, Lc).cpu(), torch.cat([yj, xi], -1))
+    # geometry statistics (standardised): fp64 on device vs the oracle's fp32 LAPACK path
+    st = plan.geo_stats(X, Lc).cpu()
+    ref = O.geo_stats(x, latc, enc)
+    assert (st - ref).abs().max() < 2e-4, (st - ref).abs().max()
+    assert rel(st, ref) < 2e-5
+
+
+def test_invalid_csr_is_rejected():
+    from gaot_amd.plan import GeometryPlan
+    idx = torch.tensor([0, 5, 1], device=dev())
+    sp = torch.tensor([0, 2, 3], device=dev())
+    with pytest.raises(ValueError):
+        GeometryPlan(idx, sp, n_src=3)
+    with pytest.raises(ValueError):
+        GeometryPlan(torch.tensor([0, 1, 1], device=dev()), torch.tensor([0, 2, 1], device=dev()), n_src=3)
+
+
+@pytest.mark.parametrize("C,B", [(64, 8), (16, 3), (6, 2), (10, 1)])
+def test_gno_transform_fwd_bwd(C, B):
+    from gaot_amd import ops
+    from gaot_amd.plan import plan_for
+    from oracle import gaot_oracle as O
+    x, latc, enc, _ = _random_geometry(7, 600, [16, 16], 0.13)
+    idx, sp = enc
+    Q = sp.numel() - 1
+    qid, _ = O.edge_query_ids(sp)
+    g = torch.Generator().manual_seed(C)
+    k = torch.randn(idx.numel(), C, generator=g)
+    f = torch.randn(B, 600, C, generator=g)
+    a = torch.rand(idx.numel(), generator=g)
+    go = torch.randn(B, Q, C, generator=g)
+    kr, fr = k.clone().double().requires_grad_(True), f.clone().double().requires_grad_(True)
+    ref = O.seg_sum(kr[None] * fr[:, idx, :] * a.double()[None, :, None], qid, Q)
+    ref.backward(go.double())
+    plan = plan_for(_dict(enc), 600)
+    kd, fd = k.to(dev()).requires_grad_(True), f.to(dev()).requires_grad_(True)
+    out = ops.gno_transform(kd, fd, plan, a.to(dev()))
+    out.backward(go.to(dev()))
+    assert rel(out, ref) < 2e-6
+    assert rel(kd.grad, kr.grad) < 3e-6
+    assert rel(fd.grad, fr.grad) < 3e-6
+    assert float(out[:, (sp[1:] - sp[:-1]) == 0].abs().max() if ((sp[1:] - sp[:-1]) == 0).any() else 0.0) == 0.0
+
+
+def test_segment_softmax_and_sum():
+    from gaot_amd import ops
+    from gaot_amd.plan import plan_for
+    from oracle import gaot_oracle as O
+    x, latc, enc, _ = _random_geometry(8, 300, [16, 16], 0.16)
+    idx, sp = enc
+    Q = sp.numel() - 1
+    qid, deg = O.edge_query_ids(sp)
+    g = torch.Generator().manual_seed(1)
+    s = torch.randn(idx.numel(), generator=g)
+    gy = torch.randn(idx.numel(), generator=g)
+    sr = s.clone().double().requires_grad_(True)
+    O.segment_softmax(sr, qid, Q).backward(gy.double())
+    plan = plan_for(_dict(enc), 300)
+    sd_ = s.to(dev()).requires_grad_(True)
+    a = ops.segment_softmax(sd_, plan)
+    a.backward(gy.to(dev()))
+    assert rel(a, O.segment_softmax(s.double(), qid, Q)) < 2e-6
+    assert rel(sd_.grad, sr.grad) < 1e-5
+    xx = torch.randn(2, idx.numel(), 12, generator=g)
+    inv = 1.0 / deg.clamp(min=1).float()
+    out = ops.segment_sum(xx.to(dev()), plan, inv.to(dev()))
+    assert rel(out, O.seg_sum(xx.double(), qid, Q) * inv.double()[None, :, None]) < 2e-6
+
+
+# ------------------------------------------------------------------ processor kernels
+@pytest.mark.parametrize("M,D", [(1000, 256), (37, 48), (8192, 64)])
+def test_rmsnorm(M, D):
+    from gaot_amd import ops
+    from oracle import gaot_oracle as O
+    g = torch.Generator().manual_seed(M + D)
+    x, w, go = torch.randn(M, D, generator=g), torch.rand(D, generator=g) + 0.5, torch.randn(M, D, generator=g)
+    xr, wr = x.clone().double().requires_grad_(True), w.clone().double().requires_grad_(True)
+    O.rms_norm(xr, wr, 1e-6).backward(go.double())
+    xd, wd = x.to(dev()).requires_grad_(True), w.to(dev()).requires_grad_(True)
+    y = ops.rms_norm(xd, wd, 1e-6)
+    y.backward(go.to(dev()))
+    assert rel(y, O.rms_norm(x.double(), w.double(), 1e-6)) < 2e-6
+    assert rel(xd.grad, xr.grad) < 3e-6 and rel(wd.grad, wr.grad) < 3e-6
+
+
+def test_swiglu():
+    from gaot_amd import ops
+    g = torch.Generator().manual_seed(2)
+    u, go = torch.randn(5, 64, 128, generator=g), torch.randn(5, 64, 64, generator=g)
+    ur = u.clone().double().requires_grad_(True)
+    ref = torch.nn.functional.silu(ur[..., :64]) * ur[..., 64:]
+    ref.backward(go.double())
+    ud = u.to(dev()).requires_grad_(True)
+    out = ops.swiglu(ud)
+    out.backward(go.to(dev()))
+    assert rel(out, ref) < 2e-6 and rel(ud.grad, ur.grad) < 3e-6
+
+
+@pytest.mark.parametrize("B,S,H,Hkv,D", [(2, 256, 4, 4, 32), (1, 1024, 8, 8, 32), (2, 64, 4, 4, 8), (2, 200, 4, 4, 12),
+                                         (1, 130, 2, 2, 64), (2, 96, 4, 2, 16), (1, 33, 1, 1, 32)])
+def test_attention_fwd_bwd(B, S, H, Hkv, D):
+    from gaot_amd import ops
+    g = torch.Generator().manual_seed(S + D)
+    W = (H + 2 * Hkv) * D
+    qkv = torch.randn(B, S, W, generator=g)
+    go = torch.randn(B, S, H * D, generator=g)
+    r = qkv.clone().double().requires_grad_(True)
+    q = r[..., :H * D].reshape(B, S, H, D).transpose(1, 2)
+    k = r[..., H * D:(H + Hkv) * D].reshape(B, S, Hkv, D).transpose(1, 2).repeat_interleave(H // Hkv, dim=1)
+    v = r[..., (H + Hkv) * D:].reshape(B, S, Hkv, D).transpose(1, 2).repeat_interleave(H // Hkv, dim=1)
+    p = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(D), dim=-1)
+    ref = (p @ v).transpose(1, 2).reshape(B, S, H * D)
+    ref.backward(go.double())
+    d = qkv.to(dev()).requires_grad_(True)
+    out = ops.attention(d, H, Hkv, D)
+    out.backward(go.to(dev()))
+    assert rel(out, ref) < 3e-6
+    assert rel(d.grad, r.grad) < 1e-5
+
+
+def test_attention_peaked_softmax():
+    """one key dominates one query (running-max rescale path) -- full-tensor check against fp64"""
+    from gaot_amd import ops
+    g = torch.Generator().manual_seed(4)
+    B, S, H, D = 1, 256, 2, 32
+    qkv = torch.randn(B, S, 3 * H * D, generator=g)
+    qkv[0, 17, :D] *= 6.0
+    qkv[0, 201, H * D:H * D + D] = qkv[0, 17, :D] * 1.5
+    r = qkv.double()
+    q = r[..., :H * D].reshape(B, S, H, D).transpose(1, 2)
+    k = r[..., H * D:2 * H * D].reshape(B, S, H, D).transpose(1, 2)
+    v = r[..., 2 * H * D:].reshape(B, S, H, D).transpose(1, 2)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(D), -1) @ v).transpose(1, 2).reshape(B, S, H * D)
+    out = ops.attention(qkv.to(dev()), H, H, D)
+    assert rel(out, ref) < 3e-6 and torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize("sizes,P,C", [([16, 16], 2, 8), ([8, 12], 4, 5), ([8, 8, 8], 2, 6), ([64, 64], 2, 64)])
+def test_patchify_roundtrip(sizes, P, C):
+    from gaot_amd import ops
+    from oracle import gaot_oracle as O
+    n = math.prod(sizes)
+    x = torch.randn(2, n, C)
+    t = ops.patchify(x.to(dev()), sizes, P)
+    assert torch.equal(t.cpu(), O.patchify(x, sizes, P))
+    assert torch.equal(ops.unpatchify(t, sizes, P).cpu(), x)
+
+
+def test_reductions():
+    from gaot_amd import ops
+    x = torch.randn(1000, 70)
+    assert rel(ops.colsum(x.to(dev())), x.double().sum(0)) < 2e-6
+    y = torch.randn(5, 33, 7)
+    assert rel(ops.batchsum(y.to(dev()), 5), y.double().sum(0)) < 2e-6
+
+
+def test_host_tensors_are_refused():
+    from gaot_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.linear(torch.randn(4, 4), torch.randn(4, 4))
