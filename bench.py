@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- GAOT training throughput on MI355X (contract: see the task statement).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = one reference-trainer step (forward + MSE + backward + AdamW, plus the flat-gradient RCCL all-reduce
+when N > 1) on BASELINE config 2: 2-D mesh with 16 384 nodes, batch 8 PER GPU (weak scaling), the reference's
+example model (config/examples/time_indep/poisson_gauss.json: latent 64x64, C=64, patch 2, transformer 256 x 3
+blocks, 8 heads; 3 396 033 parameters), synthetic data, random-init weights, inputs resident in HBM.
+Arithmetic is fp32 end to end (the reference has no reduced-precision path; parity tolerance 1e-5 is fp32).
+
+Extra objects on the JSON line:
+  roofline     dominant kernel family = the fp32-MFMA GEMM (gaot_gemm_f32): algorithmic FLOPs of its launches in
+               one step / their summed duration, timed live with HIP events on the launch stream in an
+               instrumented eager step; peak = 157.3 TFLOP/s (dense f32 matrix rate, MI355X_MICROARCH.md)
+  cpu_baseline the CPU oracle (oracle/gaot_oracle.py, a parity-checked port of the reference path) timed on the
+               host cores of this box on the same workload, a few steps (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace as NS
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_NODES, BATCH, LATENT, C_LIFT, HIDDEN, PATCH, RADIUS = 16384, 8, [64, 64], 64, 256, 2, 0.033
+PEAK_F32_MATRIX_TFLOPS = 157.3
+
+
+def build_model():
+    from gaot_amd.model.gaot import GAOT
+    from gaot_amd.model.layers.magno import MAGNOConfig
+    from gaot_amd.model.layers.attn import TransformerConfig
+    mcfg = MAGNOConfig(coord_dim=2, radius=RADIUS, hidden_size=64, mlp_layers=3, lifting_channels=C_LIFT)
+    tcfg = TransformerConfig(patch_size=PATCH, hidden_size=HIDDEN)
+    return GAOT(1, 1, NS(args=NS(magno=mcfg, transformer=tcfg), latent_tokens_size=LATENT))
+
+
+def synthetic(seed: int, device):
+    g = torch.Generator().manual_seed(seed)
+    ax = torch.linspace(-1, 1, LATENT[0])
+    lat = torch.stack(torch.meshgrid(ax, torch.linspace(-1, 1, LATENT[1]), indexing="ij"), -1).reshape(-1, 2)
+    x = torch.rand(N_NODES, 2, generator=torch.Generator().manual_seed(0)) * 2 - 1      # same mesh on every rank
+    p = torch.randn(BATCH, N_NODES, 1, generator=g)
+    t = torch.randn(BATCH, N_NODES, 1, generator=g)
+    return lat.to(device), x.to(device), p.to(device), t.to(device)
+
+
+def gemm_roofline(ts):
+    """Instrumented EAGER step: HIP events (torch.cuda.Event on the launch stream = torch's current stream) around
+    every gaot_gemm_f32 call; returns achieved TFLOP/s of the GEMM family over one step."""
+    from gaot_amd import ops
+    records = []
+    raw = ops.gemm
+
+    def timed_gemm(M, N, K, *a, **kw):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        out = raw(M, N, K, *a, **kw)
+        e.record()
+        records.append((s, e, 2.0 * M * N * K))
+        return out
+
+    use_graph = ts.use_graph
+    ts.use_graph = False
+    ts.step()                      # untimed eager step (allocator warm)
+    ops.gemm = timed_gemm
+    try:
+        torch.cuda.synchronize()
+        ts.step()
+        torch.cuda.synchronize()
+    finally:
+        ops.gemm = raw
+        ts.use_graph = use_graph
+    ms = sum(s.elapsed_time(e) for s, e, _ in records)
+    flops = sum(f for _, _, f in records)
+    return {"launches": len(records), "flops": flops, "ms": ms, "tflops": flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0}
+
+
+def cpu_baseline(steps: int = 3):
+    from oracle import gaot_oracle as O
+    torch.manual_seed(0)
+    model = build_model()
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    lat, x, p, t = synthetic(0, torch.device("cpu"))
+    cfg = O.OracleConfig(radius=RADIUS, hidden_size=64, lifting_channels=C_LIFT, patch_size=PATCH, tf_hidden_size=HIDDEN,
+                         latent_tokens_size=LATENT, precompute_edges=True)
+    enc, dec = [O.radius_csr(x, lat, RADIUS)], [O.radius_csr(lat, x, RADIUS)]
+    batch = dict(latent=lat, xcoord=x, pndata=p, target=t, encoder_nbrs=enc, decoder_nbrs=dec)
+    state = None
+    _, _, sd, state = O.train_step(sd, cfg, batch, state=state)          # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        _, _, sd, state = O.train_step(sd, cfg, batch, state=state)
+    dt = time.perf_counter() - t0
+    return {"value": BATCH * steps / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} full train steps (fwd+MSE+bwd+AdamW) of the same workload (16384 nodes, batch {BATCH}) "
+                      f"on the CPU oracle, {dt / steps:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs a torch.distributed.run launch with --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)      # RCCL over xGMI
+
+    from gaot_amd.trainer import TrainStep
+    torch.manual_seed(0)                      # identical weights on every rank (and broadcast from rank 0 anyway)
+    model = build_model().to(dev).train()
+    lat, x, p, t = synthetic(1234 + rank, dev)
+    ts = TrainStep(model, lr=8e-4, weight_decay=1e-5, use_graph=not args.no_graph)
+    ts.bind(p, t, latent_tokens_coord=lat, xcoord=x)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1)):
+        ts.step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ts.step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    loss = float(ts._loss if ts.use_graph else ts.step())
+
+    roof = gemm_roofline(ts)
+    if rank == 0:
+        n_params = sum(q.numel() for q in model.parameters())
+        line = {
+            "metric": "train samples/sec (2D 16k-node mesh, bs=8 per GPU)",
+            "value": BATCH * world * args.steps / elapsed,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (uniform-random 16384-point 2-D mesh in [-1,1]^2, N(0,1) fields, random-init weights)",
+            "config": {"workload": "BASELINE configs[1]: Poisson-Gauss-shaped 2D, 16384 nodes/mesh, batch 8 per GPU, fx mode; "
+                                   "example model latent 64x64, C=64, patch 2, transformer 256x3, 8 heads",
+                       "params": n_params, "global_batch": BATCH * world, "parallelism": f"dp{world}",
+                       "step": "fwd + MSE + bwd + AdamW" + (" + flat-grad RCCL all-reduce" if world > 1 else ""),
+                       "hipgraph": ts.use_graph, "final_loss": loss},
+            "roofline": {"bound": "mfma", "kernel": "gaot::gemm_kernel (v_mfma_f32_32x32x2_f32), all launches of one step",
+                         "achieved": roof["tflops"], "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                         "frac": roof["tflops"] / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
+                         "launches_per_step": roof["launches"], "gflop_per_step": roof["flops"] / 1e9,
+                         "gemm_ms_per_step": roof["ms"]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -206,6 +206,27 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
         epilogue_store(p, (int)(idx / p.N), (int)(idx % p.N), v);
     }
 }
+// plain-sum fast path (no epilogue extras, N % 4 == 0, 16-byte aligned rows): 16 B per lane, fixed z order
+__global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const GemmArgs p) {
+    const long total4 = (long)p.M * p.N / 4;
+    const int n4 = p.N / 4;
+    const f32x4* ws = reinterpret_cast<const f32x4*>(p.ws);
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total4; idx += (long)gridDim.x * blockDim.x) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        int z = 0;
+        for (; z + 8 <= p.split_k; z += 8) {          // 8 independent loads in flight, summed in a fixed order
+            f32x4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = ws[(long)(z + u) * total4 + idx];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += t[u];
+        }
+        for (; z < p.split_k; ++z) v += ws[(long)z * total4 + idx];
+        const long m = idx / n4;
+        const int n = (int)(idx - m * n4) * 4;
+        *reinterpret_cast<f32x4*>(p.C + m * p.ldc + n) = v;
+    }
+}
 
 template <int BM, int BN, int WAVES_M>
 static int launch_cfg(GemmArgs& a, bool ak, bool bk, bool vec, hipStream_t st) {
@@ -225,6 +246,9 @@ static int launch_cfg(GemmArgs& a, bool ak, bool bk, bool vec, hipStream_t st) {
 }  // namespace gaot
 
 using namespace gaot;
+
+static int g_tile_override = 0;   // tuning hook: 0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 128x32
+extern "C" int gaot_debug_set_gemm_tile(int cfg) { const int old = g_tile_override; g_tile_override = cfg; return old; }
 
 extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
     GAOT_REQUIRE(d != nullptr, "gemm: null descriptor");
@@ -261,16 +285,26 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
     // tile choice: the largest tile that still gives every CU (256) a workgroup; skinny N gets a 128x32 tile
     const long z = a.split_k;
     auto blocks = [&](int bm, int bn) { return (long)cdiv(a.M, bm) * cdiv(a.N, bn) * z; };
-    if (a.N <= 32)                      launch_cfg<128, 32, 4>(a, ak, bk, vec, st);
-    else if (blocks(128, 128) >= 256)   launch_cfg<128, 128, 2>(a, ak, bk, vec, st);
-    else if (blocks(128, 64) >= 256)    launch_cfg<128, 64, 2>(a, ak, bk, vec, st);
-    else                                launch_cfg<64, 64, 2>(a, ak, bk, vec, st);
+    (void)z;
+    if (g_tile_override == 1)           launch_cfg<128, 128, 2>(a, ak, bk, vec, st);
+    else if (g_tile_override == 2)      launch_cfg<128, 64, 2>(a, ak, bk, vec, st);
+    else if (g_tile_override == 3)      launch_cfg<64, 64, 2>(a, ak, bk, vec, st);
+    else if (g_tile_override == 4)      launch_cfg<128, 32, 4>(a, ak, bk, vec, st);
+    else if (a.N <= 32)                 launch_cfg<128, 32, 4>(a, ak, bk, vec, st);
+    // measured on MI355X (tools/gemm_bench.py): short reductions want SEVERAL block-waves in flight so that the
+    // load / MFMA / store phases of different workgroups overlap; big tiles only pay off on large outputs.
+    else if (blocks(64, 64) <= 1536)    launch_cfg<64, 64, 2>(a, ak, bk, vec, st);
+    else if (blocks(128, 64) <= 3072)   launch_cfg<128, 64, 2>(a, ak, bk, vec, st);
+    else                                launch_cfg<128, 128, 2>(a, ak, bk, vec, st);
     GAOT_CHECK_LAUNCH("gaot_gemm_f32");
     if (a.split_k > 1) {
         const long total = (long)a.M * a.N;
-        int nb = cdiv(total, 256);
+        const bool plain = !a.bias && !a.rowbias && !a.rowscale && !a.aux_out && !a.residual && a.act == GAOT_ACT_NONE &&
+                           a.N % 4 == 0 && a.ldc % 4 == 0 && aligned16(a.C) && aligned16(a.ws);
+        int nb = cdiv(plain ? total / 4 : total, 256);
         if (nb > 2048) nb = 2048;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, a);
+        if (plain) hipLaunchKernelGGL(splitk_reduce_vec_kernel, dim3(nb), dim3(256), 0, st, a);
+        else       hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, a);
         GAOT_CHECK_LAUNCH("gaot_gemm_f32(split-k reduce)");
     }
     return GAOT_OK;

@@ -108,27 +108,56 @@ __global__ void swiglu_bwd_kernel(const float* __restrict__ u, const float* __re
 }
 
 // ---------------------------------------------------------------- reductions
-constexpr int COLSUM_ROWS = 128;
-// partial[p, n] = sum over rows [p*128, p*128+128) ; block = 4 waves x 64 columns
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, long ld, int M, int N,
+// Column sums out[n] = sum_m x[m,n] for tall matrices (bias / norm-weight gradients).
+// Stage 1: grid (column tiles of 64, R row chunks); a wave's lanes run along columns (coalesced 256 B rows) or,
+// for narrow matrices (N <= 32), along (row, column) pairs so all 64 lanes stay busy; waves interleave rows.
+// Stage 2: one block per 64 columns sums the R partial rows (R <= 256) with all 4 waves.
+constexpr int COLSUM_MAX_CHUNKS = 256;
+__host__ __device__ inline int colsum_chunks(int M, int N) {
+    const int ctiles = (N + 63) / 64;
+    int r = 1024 / ctiles;                       // ~1024 blocks in flight
+    const int by_rows = (M + 63) / 64;           // at least 64 rows per chunk
+    if (r > by_rows) r = by_rows;
+    if (r > COLSUM_MAX_CHUNKS) r = COLSUM_MAX_CHUNKS;
+    return r < 1 ? 1 : r;
+}
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, long ld, int M, int N, int R,
                                                              float* __restrict__ part) {
     __shared__ float red[4][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int rows_per_chunk = (M + R - 1) / R;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+    float s = 0.f;
+    if (N > 32) {
+        const int n = blockIdx.x * 64 + lane;
+        if (n < N)
+            for (int r = r0 + wave; r < r1; r += 4) s += x[(long)r * ld + n];
+        red[wave][lane] = s;
+        __syncthreads();
+        if (wave == 0 && n < N) part[(long)blockIdx.y * N + n] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    } else {
+        int lpr = 1;
+        while (lpr < N) lpr <<= 1;               // lanes per row (power of two <= 32)
+        const int rpw = 64 / lpr;                // rows per wave-step
+        const int n = lane % lpr, sub = lane / lpr;
+        if (n < N)
+            for (int r = r0 + wave * rpw + sub; r < r1; r += 4 * rpw) s += x[(long)r * ld + n];
+        for (int off = 32; off >= lpr; off >>= 1) s += __shfl_xor(s, off, 64);
+        red[wave][lane] = s;
+        __syncthreads();
+        if (wave == 0 && lane < N) part[(long)blockIdx.y * N + lane] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    }
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int P, int N, float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = blockIdx.x * 64 + lane;
-    const int r0 = blockIdx.y * COLSUM_ROWS;
     float s = 0.f;
     if (n < N)
-        for (int r = r0 + wave; r < min(M, r0 + COLSUM_ROWS); r += 4) s += x[(long)r * ld + n];
+        for (int p = wave; p < P; p += 4) s += part[(long)p * N + n];
     red[wave][lane] = s;
     __syncthreads();
-    if (wave == 0 && n < N) part[(long)blockIdx.y * N + n] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
-}
-__global__ void colsum_final_kernel(const float* __restrict__ part, int P, int N, float* __restrict__ out) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    float s = 0.f;
-    for (int p = 0; p < P; ++p) s += part[(long)p * N + n];
-    out[n] = s;
+    if (wave == 0 && n < N) out[n] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
 }
 __global__ void batchsum_kernel(const float* __restrict__ x, int B, long RN, float* __restrict__ out) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < RN; i += (long)gridDim.x * blockDim.x) {
@@ -212,14 +241,14 @@ extern "C" int gaot_swiglu_bwd(const float* u, const float* dg, int32_t M, int32
     return GAOT_OK;
 }
 
-extern "C" int64_t gaot_colsum_scratch(int32_t M, int32_t N) { return (int64_t)cdiv(M, COLSUM_ROWS) * N; }
+extern "C" int64_t gaot_colsum_scratch(int32_t M, int32_t N) { return (int64_t)colsum_chunks(M, N) * N; }
 
 extern "C" int gaot_colsum(const float* x, int64_t ld, int32_t M, int32_t N, float* out, float* scratch,
                            gaot_stream_t stream) {
     GAOT_REQUIRE(x && out && scratch && M > 0 && N > 0, "colsum: bad arguments");
-    const int P = cdiv(M, COLSUM_ROWS);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 64), P), dim3(256), 0, ST(stream), x, (long)ld, M, N, scratch);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, ST(stream), scratch, P, N, out);
+    const int P = colsum_chunks(M, N);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 64), P), dim3(256), 0, ST(stream), x, (long)ld, M, N, P, scratch);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 64)), dim3(256), 0, ST(stream), scratch, P, N, out);
     GAOT_CHECK_LAUNCH("gaot_colsum");
     return GAOT_OK;
 }
