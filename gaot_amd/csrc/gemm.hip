@@ -11,39 +11,11 @@
 //  * 256 threads = 4 waves; 64-cycle MFMA issue makes the kernel matrix-pipe bound with register-prefetched
 //    single-buffer staging (next k-tile's global loads in flight under 16*TM*TN MFMAs).
 //  * workgroup ids are remapped so that one XCD (private L2) owns whole row-panels of A.
-#include "common.h"
+#include "gemm_common.h"
 
 namespace gaot {
 
-struct GemmArgs {
-    int M, N, K;
-    const float* A; long lda; const float* A2; long lda2; int k_split;
-    const float* B; long ldb;
-    float* C; long ldc;
-    const float* bias; const float* rowbias; int rb_period; long ld_rb;
-    const float* rowscale; int act; const float* aux_in; float* aux_out; long ld_aux;
-    const float* residual; long ldr;
-    int split_k; int ktiles_per_split; float* ws;
-    int tiles_m, tiles_n;
-};
-
 constexpr int BK = 32;
-
-__device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, float v) {
-    if (p.bias) v += p.bias[n];
-    if (p.rowbias) v += p.rowbias[(long)(m % p.rb_period) * p.ld_rb + n];
-    if (p.rowscale) v *= p.rowscale[m];
-    if (p.aux_out) p.aux_out[(long)m * p.ld_aux + n] = v;
-    switch (p.act) {
-        case GAOT_ACT_GELU: v = gelu_f(v); break;
-        case GAOT_ACT_RELU: v = fmaxf(v, 0.0f); break;
-        case GAOT_ACT_GELU_BWD: v *= gelu_grad_f(p.aux_in[(long)m * p.ld_aux + n]); break;
-        case GAOT_ACT_RELU_BWD: v = (p.aux_in[(long)m * p.ld_aux + n] > 0.0f) ? v : 0.0f; break;
-        default: break;
-    }
-    if (p.residual) v += p.residual[(long)m * p.ldr + n];
-    p.C[(long)m * p.ldc + n] = v;
-}
 
 // global -> registers for one [ROWS x BK] operand tile.  KMAJ: elem(row,k) = base[row*ld + k].
 template <bool KMAJ, bool VEC, int ROWS>
@@ -185,15 +157,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * WN + j * 32 + li;
-            if (n >= p.N) continue;
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * WM + i * 32 + crow(r, lh);
+            if (m >= p.M) continue;
+            if (p.split_k > 1) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WM + i * 32 + crow(r, lh);
-                if (m >= p.M) continue;
-                if (p.split_k > 1) p.ws[((long)blockIdx.z * p.M + m) * p.N + n] = acc[i][j][r];
-                else epilogue_store(p, m, n, acc[i][j][r]);
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + wn * WN + j * 32 + li;
+                    if (n < p.N) p.ws[((long)blockIdx.z * p.M + m) * p.N + n] = acc[i][j][r];
+                }
+            } else {
+                const RowCtx rc = row_ctx(p, m);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + wn * WN + j * 32 + li;
+                    if (n < p.N) epilogue_store_row(p, rc, m, n, acc[i][j][r]);
+                }
             }
         }
 }
@@ -282,6 +261,10 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
     if (d->A2) vec = vec && aligned16(d->A2) && (d->lda2 % 4 == 0) && ((d->K - d->k_split) % 4 == 0);
 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (g_tile_override == 0 && launch_skinny(a, ak, bk, st)) {
+        GAOT_CHECK_LAUNCH("gaot_gemm_f32(skinny)");
+        return GAOT_OK;
+    }
     // tile choice: the largest tile that still gives every CU (256) a workgroup; skinny N gets a 128x32 tile
     const long z = a.split_k;
     auto blocks = [&](int bm, int bn) { return (long)cdiv(a.M, bm) * cdiv(a.N, bn) * z; };

@@ -1,0 +1,133 @@
+// Skinny products that do not belong on 32x32 MFMA tiles (they are HBM-bound, a few flops per byte):
+//   A) tiny reduction  K <= 16        : lifting (K = in_channels), first kernel-MLP layer (K = 2d), geoembed (K = 3+2d)
+//   B) tiny output     N <= 4         : output projection (N = out_channels) and its relatives
+//   C) tiny weight gradient           : out[M,N] = sum_r A[r,m] B[r,n] with min(M,N) <= 8 over a LONG r (tens of
+//                                       thousands of rows) -- a handful of scaled column sums
+// All three keep the GEMM descriptor semantics (same epilogue) so callers never see the difference.
+#include "gemm_common.h"
+
+namespace gaot {
+
+// ---- A: thread per output element, lanes along n (coalesced stores; A row is a broadcast load)
+template <bool BKM>
+__global__ __launch_bounds__(256) void skinny_k_kernel(const GemmArgs p) {
+    const long total = (long)p.M * p.N;
+    for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(gid / p.N), n = (int)(gid - (long)m * p.N);
+        const float* a = p.A + (long)m * p.lda;
+        float acc = 0.f;
+        if (BKM) { const float* b = p.B + (long)n * p.ldb; for (int k = 0; k < p.K; ++k) acc = fmaf(a[k], b[k], acc); }
+        else     { for (int k = 0; k < p.K; ++k) acc = fmaf(a[k], p.B[(long)k * p.ldb + n], acc); }
+        epilogue_store(p, m, n, acc);
+    }
+}
+
+// ---- B: LPR lanes per output row, each lane strides over k, shuffle-reduce, lane 0 of the group finishes
+template <bool BKM>
+__global__ __launch_bounds__(256) void skinny_n_kernel(const GemmArgs p, int lpr) {
+    const int rows_per_block = 256 / lpr;
+    const int sub = threadIdx.x % lpr;
+    const int m = blockIdx.x * rows_per_block + threadIdx.x / lpr;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (m < p.M) {
+        const float* a = p.A + (long)m * p.lda;
+        for (int k = sub; k < p.K; k += lpr) {
+            const float av = a[k];
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                if (n < p.N) acc[n] = fmaf(av, BKM ? p.B[(long)n * p.ldb + k] : p.B[(long)k * p.ldb + n], acc[n]);
+        }
+    }
+    for (int off = lpr >> 1; off > 0; off >>= 1)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[n] += __shfl_xor(acc[n], off, 64);
+    if (m < p.M && sub == 0)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+            if (n < p.N) epilogue_store(p, m, n, acc[n]);
+}
+
+// ---- C: out[m,n] = sum_r A[r*lda + m] * B[r*ldb + n]; lanes along the WIDE output dim, J <= 8 accumulators along the
+// narrow one; grid (wide tiles of 64, row chunks); 4 waves interleave rows; partials -> ws[chunk][M*N]
+template <bool WIDE_IS_M>
+__global__ __launch_bounds__(256) void skinny_tn_partial_kernel(const GemmArgs p, int chunks) {
+    __shared__ float red[4][8][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int W = WIDE_IS_M ? p.M : p.N, J = WIDE_IS_M ? p.N : p.M;
+    const int w = blockIdx.x * 64 + lane;
+    const int rows = (p.K + chunks - 1) / chunks;
+    const int r0 = blockIdx.y * rows, r1 = min(p.K, r0 + rows);
+    const float* wide = WIDE_IS_M ? p.A : p.B;
+    const float* nar = WIDE_IS_M ? p.B : p.A;
+    const long ldw = WIDE_IS_M ? p.lda : p.ldb, ldn = WIDE_IS_M ? p.ldb : p.lda;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    if (w < W) {
+        int r = r0 + wave;
+        for (; r + 4 < r1; r += 8) {              // two rows in flight per wave
+            const float v0 = wide[(long)r * ldw + w], v1 = wide[(long)(r + 4) * ldw + w];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < J) { acc[j] = fmaf(v0, nar[(long)r * ldn + j], acc[j]); acc[j] = fmaf(v1, nar[(long)(r + 4) * ldn + j], acc[j]); }
+        }
+        for (; r < r1; r += 4) {
+            const float v0 = wide[(long)r * ldw + w];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < J) acc[j] = fmaf(v0, nar[(long)r * ldn + j], acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[wave][j][lane] = acc[j];
+    __syncthreads();
+    if (wave == 0 && w < W)
+        for (int j = 0; j < J; ++j) {
+            const float v = red[0][j][lane] + red[1][j][lane] + red[2][j][lane] + red[3][j][lane];
+            const long o = WIDE_IS_M ? (long)w * p.N + j : (long)j * p.N + w;      // [m][n] within the chunk slab
+            p.ws[(long)blockIdx.y * p.M * p.N + o] = v;
+        }
+}
+__global__ __launch_bounds__(256) void skinny_tn_final_kernel(const GemmArgs p, int chunks) {
+    __shared__ float red[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long total = (long)p.M * p.N;
+    const long o = (long)blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (o < total)
+        for (int c = wave; c < chunks; c += 4) s += p.ws[(long)c * total + o];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && o < total) epilogue_store(p, (int)(o / p.N), (int)(o % p.N), red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+}
+
+bool launch_skinny(const GemmArgs& a, bool ak, bool bk, hipStream_t st) {
+    if (a.A2 != nullptr) return false;
+    // C: transposed-A weight gradient with a tiny side and a long reduction (needs the split-K workspace)
+    if (!ak && !bk && a.split_k > 1 && a.ws != nullptr && (a.N <= 8 || a.M <= 8) && (long)a.M * a.N <= 4096 && a.K >= 1024) {
+        const int chunks = a.split_k;
+        if (a.N <= 8) hipLaunchKernelGGL(skinny_tn_partial_kernel<true>, dim3(cdiv(a.M, 64), chunks), dim3(256), 0, st, a, chunks);
+        else          hipLaunchKernelGGL(skinny_tn_partial_kernel<false>, dim3(cdiv(a.N, 64), chunks), dim3(256), 0, st, a, chunks);
+        hipLaunchKernelGGL(skinny_tn_final_kernel, dim3(cdiv((long)a.M * a.N, 64)), dim3(256), 0, st, a, chunks);
+        return true;
+    }
+    if (!ak || a.split_k > 1) return false;
+    if (a.K <= 16) {                                   // A
+        long nb = ((long)a.M * a.N + 255) / 256;
+        if (nb > 16384) nb = 16384;
+        if (bk) hipLaunchKernelGGL(skinny_k_kernel<true>, dim3((unsigned)nb), dim3(256), 0, st, a);
+        else    hipLaunchKernelGGL(skinny_k_kernel<false>, dim3((unsigned)nb), dim3(256), 0, st, a);
+        return true;
+    }
+    if (a.N <= 4) {                                    // B
+        int lpr = 1;
+        while (lpr < 64 && lpr * 4 < a.K) lpr <<= 1;   // ~4 k per lane, at most one wave per row
+        const int rpb = 256 / lpr;
+        if (bk) hipLaunchKernelGGL(skinny_n_kernel<true>, dim3(cdiv(a.M, rpb)), dim3(256), 0, st, a, lpr);
+        else    hipLaunchKernelGGL(skinny_n_kernel<false>, dim3(cdiv(a.M, rpb)), dim3(256), 0, st, a, lpr);
+        return true;
+    }
+    return false;
+}
+
+}  // namespace gaot

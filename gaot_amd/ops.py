@@ -66,7 +66,7 @@ def _split_for_reduction(Mo: int, No: int, K: int) -> int:
     """split-K factor for weight-gradient products (tiny output, long reduction)."""
     tiles = ((Mo + 63) // 64) * ((No + 63) // 64)
     want = max(1, 1024 // max(1, tiles))          # ~1024 workgroups of 64x64 (tools/gemm_bench.py sweep)
-    return int(max(1, min(want, 64, (K + 255) // 256)))
+    return int(max(1, min(want, 256, (K + 255) // 256)))
 
 
 def linear_nt(x2: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, **epi) -> torch.Tensor:

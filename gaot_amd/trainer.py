@@ -25,20 +25,39 @@ def shard_indices(n_samples: int, rank: int, world: int, epoch: int = 0, shuffle
 
 
 class FlatGradBucket:
-    """All gradients in one contiguous buffer; `param.grad` are views into it."""
+    """All gradients in one contiguous fp32 buffer (one RCCL all-reduce per step, one fused optimizer pass).
+
+    Autograd is left to hand over freshly produced gradient tensors (param.grad is None before backward, so
+    AccumulateGrad steals instead of launching one add per parameter); `pack()` then gathers them with ONE
+    multi-tensor copy and re-points param.grad at views of the flat buffer for the all-reduce / optimizer."""
 
     def __init__(self, params: List[torch.nn.Parameter]):
         self.params = [p for p in params if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         ref = self.params[0]
         self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
+        self.views = []
         off = 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
 
-    def zero(self):
-        self.flat.zero_()
+    def clear(self):
+        for p in self.params:
+            p.grad = None
+
+    def pack(self):
+        srcs, dsts = [], []
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                srcs.append(p.grad)
+                dsts.append(v)
+        if srcs:
+            torch._foreach_copy_(dsts, srcs)
+        for p, v in zip(self.params, self.views):
+            p.grad = v
 
     def all_reduce_mean(self, group=None):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
@@ -82,10 +101,11 @@ class TrainStep:
 
     # ---- the eager pieces
     def _forward_backward(self):
-        self.bucket.zero()
+        self.bucket.clear()
         pred = self.model(pndata=self._x, **self._kwargs)
         loss = torch.nn.functional.mse_loss(pred, self._y)
         loss.backward()
+        self.bucket.pack()
         return loss.detach()
 
     def bind(self, pndata: torch.Tensor, target: torch.Tensor, **forward_kwargs):
