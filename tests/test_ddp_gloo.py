@@ -49,7 +49,7 @@ def _worker(rank, world, port, out):
     gathered = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
     if rank == 0:
-        out.put((gathered[0].clone(), gathered[1].clone(), losses))
+        out.put((gathered[0].tolist(), gathered[1].tolist(), losses))     # plain lists: no shared-memory handles
     dist.barrier()
     dist.destroy_process_group()
 
@@ -62,6 +62,7 @@ def test_two_rank_gloo_step_matches_single_process():
     for p in procs:
         p.start()
     p0, p1, _ = q.get(timeout=120)
+    p0, p1 = torch.tensor(p0), torch.tensor(p1)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
