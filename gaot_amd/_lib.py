@@ -26,6 +26,7 @@ class GemmDesc(C.Structure):
         ("aux_in", _f), ("aux_out", _f), ("ld_aux", C.c_int64),
         ("residual", _f), ("ldr", C.c_int64),
         ("split_k", C.c_int32), ("workspace", _f),
+        ("colsum", _f),
     ]
 
 

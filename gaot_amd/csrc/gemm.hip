@@ -101,6 +101,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     f32x4 ra[BM / 32], rb[BN / 32];
+    // fused column sum of the m-major A operand (= bias gradient when A is dY): every thread owns 4 consecutive
+    // rows (m) of the tile at some k; blocks of the first n-tile column do the work
+    const bool do_colsum = !AK && p.colsum != nullptr && (logical % p.tiles_n) == 0;
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f};
 
     auto fetch = [&](int kt) {
         const int k0 = kt * BK;
@@ -115,6 +119,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         store_tile<AK, BM>(As, ra, tid);
         store_tile<BKM, BN>(Bs, rb, tid);
+        if (!AK && do_colsum) {
+#pragma unroll
+            for (int q = 0; q < BM / 32; ++q) csum += ra[q];
+        }
         __syncthreads();
         if (kt + 1 < kt_end) fetch(kt + 1);
 #pragma unroll
@@ -153,6 +161,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         __syncthreads();
     }
 
+    if (!AK && do_colsum) {      // threads with equal (tid % (BM/4)) hold partials of the same 4 rows: reduce through LDS
+        constexpr int G = BM / 4, NG = 256 / G;
+        __syncthreads();
+        *reinterpret_cast<f32x4*>(smem + (tid / G) * BM + (tid % G) * 4) = csum;
+        __syncthreads();
+        if (tid < BM) {
+            float v = 0.f;
+#pragma unroll
+            for (int g2 = 0; g2 < NG; ++g2) v += smem[g2 * BM + tid];
+            const int m = m0 + tid;
+            if (m < p.M) {
+                if (p.split_k > 1) p.ws[(long)p.split_k * p.M * p.N + (long)blockIdx.z * p.M + m] = v;
+                else p.colsum[m] = v;
+            }
+        }
+    }
     // epilogue: C-layout rows crow(r, lh), column li -> each half-wave writes 128 contiguous bytes per r
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -184,26 +208,58 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
         for (int z = 0; z < p.split_k; ++z) v += p.ws[(long)z * total + idx];
         epilogue_store(p, (int)(idx / p.N), (int)(idx % p.N), v);
     }
+    if (p.colsum) {
+        const float* cs = p.ws + (long)p.split_k * total;
+        for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < p.M; m += (long)gridDim.x * blockDim.x) {
+            float v = 0.f;
+            for (int z = 0; z < p.split_k; ++z) v += cs[(long)z * p.M + m];
+            p.colsum[m] = v;
+        }
+    }
 }
-// plain-sum fast path (no epilogue extras, N % 4 == 0, 16-byte aligned rows): 16 B per lane, fixed z order
+// z-parallel sum of `nz` slabs of `count` floats each: wave w takes z = w, w+4, ... with 8 loads in flight,
+// partial sums meet in LDS.  One lane per output element (VEC: per 4 elements).  Fixed order -> deterministic.
+template <typename T>
+__device__ __forceinline__ T zsum(const T* __restrict__ base, long stride, int nz, int wave) {
+    T v = T{};
+    int z = wave;
+    for (; z + 28 < nz; z += 32) {
+        T t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = base[(long)(z + 4 * u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    for (; z < nz; z += 4) v += base[(long)z * stride];
+    return v;
+}
+// plain-sum fast path (no epilogue extras, N % 4 == 0, 16-byte aligned rows); block = 4 z-waves x 64 outputs
 __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const GemmArgs p) {
+    __shared__ f32x4 red[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long total4 = (long)p.M * p.N / 4;
     const int n4 = p.N / 4;
-    const f32x4* ws = reinterpret_cast<const f32x4*>(p.ws);
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total4; idx += (long)gridDim.x * blockDim.x) {
+    const long nblk_main = (total4 + 63) / 64;
+    if (blockIdx.x < nblk_main) {
+        const long idx = (long)blockIdx.x * 64 + lane;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        int z = 0;
-        for (; z + 8 <= p.split_k; z += 8) {          // 8 independent loads in flight, summed in a fixed order
-            f32x4 t[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = ws[(long)(z + u) * total4 + idx];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v += t[u];
+        if (idx < total4) v = zsum(reinterpret_cast<const f32x4*>(p.ws) + idx, total4, p.split_k, wave);
+        red[wave][lane] = v;
+        __syncthreads();
+        if (wave == 0 && idx < total4) {
+            const f32x4 r = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+            const long m = idx / n4;
+            const int n = (int)(idx - m * n4) * 4;
+            *reinterpret_cast<f32x4*>(p.C + m * p.ldc + n) = r;
         }
-        for (; z < p.split_k; ++z) v += ws[(long)z * total4 + idx];
-        const long m = idx / n4;
-        const int n = (int)(idx - m * n4) * 4;
-        *reinterpret_cast<f32x4*>(p.C + m * p.ldc + n) = v;
+    } else {                                     // trailing blocks: the fused column-sum slab [split_k][M]
+        float* redf = reinterpret_cast<float*>(&red[0][0]);
+        const long m = (long)(blockIdx.x - nblk_main) * 64 + lane;
+        float v = 0.f;
+        if (m < p.M) v = zsum(p.ws + (long)p.split_k * p.M * p.N + m, (long)p.M, p.split_k, wave);
+        redf[wave * 64 + lane] = v;
+        __syncthreads();
+        if (wave == 0 && m < p.M) p.colsum[m] = redf[lane] + redf[64 + lane] + redf[128 + lane] + redf[192 + lane];
     }
 }
 
@@ -243,6 +299,7 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
     int split = d->split_k > 1 ? d->split_k : 1;
     if (split > nkt) split = nkt;
     if (split > 1) GAOT_REQUIRE(d->workspace != nullptr, "gemm: split_k > 1 needs a workspace");
+    if (d->colsum) GAOT_REQUIRE(d->a_kmajor == 0 && d->A2 == nullptr, "gemm: colsum needs an m-major A operand (a_kmajor = 0)");
 
     GemmArgs a;
     a.M = d->M; a.N = d->N; a.K = d->K;
@@ -252,6 +309,7 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
     a.rowscale = d->rowscale; a.act = d->act; a.aux_in = d->aux_in; a.aux_out = d->aux_out; a.ld_aux = d->ld_aux;
     a.residual = d->residual; a.ldr = d->ldr;
     a.split_k = split; a.ktiles_per_split = cdiv(nkt, split); a.ws = d->workspace;
+    a.colsum = d->colsum;
     a.split_k = cdiv(nkt, a.ktiles_per_split);  // no empty splits
 
     const bool ak = d->a_kmajor != 0, bk = d->b_kmajor != 0;
@@ -284,10 +342,14 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
         const long total = (long)a.M * a.N;
         const bool plain = !a.bias && !a.rowbias && !a.rowscale && !a.aux_out && !a.residual && a.act == GAOT_ACT_NONE &&
                            a.N % 4 == 0 && a.ldc % 4 == 0 && aligned16(a.C) && aligned16(a.ws);
-        int nb = cdiv(plain ? total / 4 : total, 256);
-        if (nb > 2048) nb = 2048;
-        if (plain) hipLaunchKernelGGL(splitk_reduce_vec_kernel, dim3(nb), dim3(256), 0, st, a);
-        else       hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, a);
+        if (plain) {
+            const long nb = cdiv(total / 4, 64) + (a.colsum ? cdiv(a.M, 64) : 0);
+            hipLaunchKernelGGL(splitk_reduce_vec_kernel, dim3((unsigned)nb), dim3(256), 0, st, a);
+        } else {
+            int nb = cdiv(total, 256);
+            if (nb > 2048) nb = 2048;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, a);
+        }
         GAOT_CHECK_LAUNCH("gaot_gemm_f32(split-k reduce)");
     }
     return GAOT_OK;

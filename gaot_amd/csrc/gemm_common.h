@@ -13,6 +13,7 @@ struct GemmArgs {
     const float* rowscale; int act; const float* aux_in; float* aux_out; long ld_aux;
     const float* residual; long ldr;
     int split_k; int ktiles_per_split; float* ws;
+    float* colsum;          // optional (A m-major only): colsum[m] = sum_k Aop[m,k]  (bias gradient fused into dW = dY^T X)
     int tiles_m, tiles_n;
 };
 

@@ -60,22 +60,32 @@ __global__ __launch_bounds__(256) void skinny_tn_partial_kernel(const GemmArgs p
     const float* wide = WIDE_IS_M ? p.A : p.B;
     const float* nar = WIDE_IS_M ? p.B : p.A;
     const long ldw = WIDE_IS_M ? p.lda : p.ldb, ldn = WIDE_IS_M ? p.ldb : p.lda;
-    float acc[8];
+    float acc[8], cs[8];     // cs: fused column sum of the A operand (WIDE_IS_M: cs[0] per lane; else per narrow index)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int j = 0; j < 8; ++j) { acc[j] = 0.f; cs[j] = 0.f; }
     if (w < W) {
         int r = r0 + wave;
         for (; r + 4 < r1; r += 8) {              // two rows in flight per wave
             const float v0 = wide[(long)r * ldw + w], v1 = wide[(long)(r + 4) * ldw + w];
+            if (WIDE_IS_M) cs[0] += v0 + v1;
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                if (j < J) { acc[j] = fmaf(v0, nar[(long)r * ldn + j], acc[j]); acc[j] = fmaf(v1, nar[(long)(r + 4) * ldn + j], acc[j]); }
+                if (j < J) {
+                    const float n0 = nar[(long)r * ldn + j], n1 = nar[(long)(r + 4) * ldn + j];
+                    acc[j] = fmaf(v0, n0, acc[j]); acc[j] = fmaf(v1, n1, acc[j]);
+                    if (!WIDE_IS_M) cs[j] += n0 + n1;
+                }
         }
         for (; r < r1; r += 4) {
             const float v0 = wide[(long)r * ldw + w];
+            if (WIDE_IS_M) cs[0] += v0;
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                if (j < J) acc[j] = fmaf(v0, nar[(long)r * ldn + j], acc[j]);
+                if (j < J) {
+                    const float n0 = nar[(long)r * ldn + j];
+                    acc[j] = fmaf(v0, n0, acc[j]);
+                    if (!WIDE_IS_M) cs[j] += n0;
+                }
         }
     }
 #pragma unroll
@@ -87,6 +97,19 @@ __global__ __launch_bounds__(256) void skinny_tn_partial_kernel(const GemmArgs p
             const long o = WIDE_IS_M ? (long)w * p.N + j : (long)j * p.N + w;      // [m][n] within the chunk slab
             p.ws[(long)blockIdx.y * p.M * p.N + o] = v;
         }
+    if (p.colsum) {             // uniform over the block
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[wave][j][lane] = cs[j];
+        __syncthreads();
+        float* slab = p.ws + (long)chunks * p.M * p.N + (long)blockIdx.y * p.M;
+        if (WIDE_IS_M) {
+            if (wave == 0 && w < W) slab[w] = red[0][0][lane] + red[1][0][lane] + red[2][0][lane] + red[3][0][lane];
+        } else if (blockIdx.x == 0 && threadIdx.x < J) {     // every lane of a wave holds the same narrow sums: take lane 0
+            const int j = threadIdx.x;
+            slab[j] = red[0][j][0] + red[1][j][0] + red[2][j][0] + red[3][j][0];
+        }
+    }
 }
 __global__ __launch_bounds__(256) void skinny_tn_final_kernel(const GemmArgs p, int chunks) {
     __shared__ float red[4][64];
@@ -94,11 +117,38 @@ __global__ __launch_bounds__(256) void skinny_tn_final_kernel(const GemmArgs p, 
     const long total = (long)p.M * p.N;
     const long o = (long)blockIdx.x * 64 + lane;
     float s = 0.f;
-    if (o < total)
-        for (int c = wave; c < chunks; c += 4) s += p.ws[(long)c * total + o];
+    if (o < total) {
+        int c = wave;
+        for (; c + 12 < chunks; c += 16) {
+            const float t0 = p.ws[(long)c * total + o], t1 = p.ws[(long)(c + 4) * total + o];
+            const float t2 = p.ws[(long)(c + 8) * total + o], t3 = p.ws[(long)(c + 12) * total + o];
+            s += t0; s += t1; s += t2; s += t3;
+        }
+        for (; c < chunks; c += 4) s += p.ws[(long)c * total + o];
+    }
     red[wave][lane] = s;
     __syncthreads();
     if (wave == 0 && o < total) epilogue_store(p, (int)(o / p.N), (int)(o % p.N), red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+    if (p.colsum && blockIdx.x == 0) {          // [chunks][M] slab: waves split the chunks, lanes the rows
+        const float* slab = p.ws + (long)chunks * total;
+        for (int mb = 0; mb < p.M; mb += 64) {
+            const int m = mb + lane;
+            float v = 0.f;
+            if (m < p.M) {
+                int c = wave;
+                for (; c + 12 < chunks; c += 16) {
+                    const float t0 = slab[(long)c * p.M + m], t1 = slab[(long)(c + 4) * p.M + m];
+                    const float t2 = slab[(long)(c + 8) * p.M + m], t3 = slab[(long)(c + 12) * p.M + m];
+                    v += t0; v += t1; v += t2; v += t3;
+                }
+                for (; c < chunks; c += 4) v += slab[(long)c * p.M + m];
+            }
+            __syncthreads();
+            red[wave][lane] = v;
+            __syncthreads();
+            if (wave == 0 && m < p.M) p.colsum[m] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        }
+    }
 }
 
 bool launch_skinny(const GemmArgs& a, bool ak, bool bk, hipStream_t st) {
@@ -111,7 +161,7 @@ bool launch_skinny(const GemmArgs& a, bool ak, bool bk, hipStream_t st) {
         hipLaunchKernelGGL(skinny_tn_final_kernel, dim3(cdiv((long)a.M * a.N, 64)), dim3(256), 0, st, a, chunks);
         return true;
     }
-    if (!ak || a.split_k > 1) return false;
+    if (!ak || a.split_k > 1 || a.colsum != nullptr) return false;
     if (a.K <= 16) {                                   // A
         long nb = ((long)a.M * a.N + 255) / 256;
         if (nb > 16384) nb = 16384;

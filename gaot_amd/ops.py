@@ -49,15 +49,15 @@ def _rowmajor(t: torch.Tensor) -> Tuple[torch.Tensor, int]:
 # --------------------------------------------------------------------------------------------
 def gemm(M: int, N: int, K: int, A, lda, a_kmajor, B, ldb, b_kmajor, out, ldc, *, bias=None, rowbias=None,
          rowbias_period=0, ld_rowbias=0, rowscale=None, act=L.ACT_NONE, aux_in=None, aux_out=None, ld_aux=0,
-         residual=None, ldr=0, A2=None, lda2=0, k_split=0, split_k=1):
-    _dev(A, B, out, bias, rowbias, rowscale, aux_in, aux_out, residual, A2)
+         residual=None, ldr=0, A2=None, lda2=0, k_split=0, split_k=1, colsum=None):
+    _dev(A, B, out, bias, rowbias, rowscale, aux_in, aux_out, residual, A2, colsum)
     _f32(A, B, out)
     ws = None
     if split_k > 1:
-        ws = torch.empty(split_k * M * N, device=out.device, dtype=torch.float32)
+        ws = torch.empty(split_k * (M * N + M), device=out.device, dtype=torch.float32)
     d = L.GemmDesc(M, N, K, _p(A), lda, int(a_kmajor), _p(A2), lda2, k_split, _p(B), ldb, int(b_kmajor),
                    _p(out), ldc, _p(bias), _p(rowbias), rowbias_period, ld_rowbias, _p(rowscale), act,
-                   _p(aux_in), _p(aux_out), ld_aux, _p(residual), ldr, split_k, _p(ws))
+                   _p(aux_in), _p(aux_out), ld_aux, _p(residual), ldr, split_k, _p(ws), _p(colsum))
     L.check(L.load().gaot_gemm_f32(C.byref(d), _stream()), "gaot_gemm_f32")
     return out
 
@@ -93,8 +93,10 @@ def matmul_nn(g: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = No
     return gemm(M, K, N, g, lda, 1, w, ldb, 0, out, out.stride(0) if M > 1 else K, **epi)
 
 
-def matmul_tn(g: torch.Tensor, x2: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[N,K] = g[M,N]^T @ x2[M,K]   (weight gradient); split-K over the long M reduction."""
+def matmul_tn(g: torch.Tensor, x2: torch.Tensor, out: Optional[torch.Tensor] = None,
+              colsum_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[N,K] = g[M,N]^T @ x2[M,K]   (weight gradient); split-K over the long M reduction.
+    colsum_out[N] (optional) receives sum_m g[m,:] -- the bias gradient -- from the same pass over g."""
     g, lda = _rowmajor(g)
     x2, ldb = _rowmajor(x2)
     M, N = g.shape
@@ -103,7 +105,7 @@ def matmul_tn(g: torch.Tensor, x2: torch.Tensor, out: Optional[torch.Tensor] = N
     if out is None:
         out = torch.empty(N, K, device=g.device, dtype=torch.float32)
     ldc = out.stride(0) if N > 1 else K
-    return gemm(N, K, M, g, lda, 0, x2, ldb, 0, out, ldc, split_k=_split_for_reduction(N, K, M))
+    return gemm(N, K, M, g, lda, 0, x2, ldb, 0, out, ldc, split_k=_split_for_reduction(N, K, M), colsum=colsum_out)
 
 
 def colsum(x2: torch.Tensor) -> torch.Tensor:
@@ -185,13 +187,16 @@ class _Linear(torch.autograd.Function):
             dx = matmul_nn(g, w2d[:, :K]).reshape(shp)
         if need[5] and x2m is not None:
             dx2 = matmul_nn(g, w2d[:, K:]).reshape(shp2)
+        want_db = has_b and need[2]
         if need[1]:
             dw = torch.empty(N, w2d.shape[1], device=g.device, dtype=torch.float32)
-            matmul_tn(g, xm, out=dw[:, :K])
+            if want_db:      # bias gradient rides the weight-gradient product (same pass over dY)
+                db = torch.empty(N, device=g.device, dtype=torch.float32)
+            matmul_tn(g, xm, out=dw[:, :K], colsum_out=db)
             if x2m is not None:
                 matmul_tn(g, x2m, out=dw[:, K:])
             dw = dw.reshape(wshape)
-        if has_b and need[2]:
+        elif want_db:
             db = colsum(g)
         if res_shape is not None and need[3]:
             dres = dy.reshape(res_shape)
@@ -256,9 +261,12 @@ class _MLPChain(torch.autograd.Function):
             raise NotImplementedError("final GELU in an MLP chain")
         grads: List[Optional[torch.Tensor]] = [None] * (2 * n)
         for i in range(n - 1, -1, -1):
+            want_db = has_b[i] and ctx.needs_input_grad[3 + 2 * i]
             if ctx.needs_input_grad[2 + 2 * i]:
-                grads[2 * i] = matmul_tn(g, ins[i]).reshape(wshapes[i])
-            if has_b[i] and ctx.needs_input_grad[3 + 2 * i]:
+                db = torch.empty(g.shape[1], device=g.device, dtype=torch.float32) if want_db else None
+                grads[2 * i] = matmul_tn(g, ins[i], colsum_out=db).reshape(wshapes[i])
+                grads[2 * i + 1] = db
+            elif want_db:
                 grads[2 * i + 1] = colsum(g)
             if i > 0:
                 pa = ACT[ctx.acts[i - 1]]

@@ -52,7 +52,7 @@ const char* gaot_last_error(void);
  *   v = acc (+ bias[n]) (+ rowbias[(m % rowbias_period)*ld_rowbias + n]);  v *= rowscale[m]
  *   if aux_out: aux_out[m*ld_aux + n] = v;      v = act(v)  (or v *= act'(aux_in[m*ld_aux+n]))
  *   v += residual[m*ldr + n];   C[m*ldc + n] = v
- * Optional pointers may be NULL.  split_k > 1 needs workspace >= split_k*M*N floats.
+ * Optional pointers may be NULL.  split_k > 1 needs workspace >= split_k*(M*N + M) floats.
  * ------------------------------------------------------------------------------------------ */
 typedef struct gaot_gemm_desc {
     int32_t M, N, K;
@@ -67,6 +67,7 @@ typedef struct gaot_gemm_desc {
     const float* aux_in; float* aux_out; int64_t ld_aux;
     const float* residual; int64_t ldr;
     int32_t split_k; float* workspace;
+    float* colsum;   /* optional, a_kmajor = 0 only: colsum[m] = sum_k Aop[m,k] (bias gradient fused into dW = dY^T X) */
 } gaot_gemm_desc;
 
 int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream);

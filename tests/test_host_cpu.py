@@ -42,6 +42,7 @@ def test_gemm_desc_layout_matches_header():
     from gaot_amd._lib import GemmDesc
     header = open(os.path.join(ROOT, "include", "gaot_hip.h")).read()
     body = header[header.index("typedef struct gaot_gemm_desc {"):header.index("} gaot_gemm_desc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     names = re.findall(r"(?:\*|\s)([A-Za-z_][A-Za-z0-9_]*)\s*[;,]", body)
     assert names == [f[0] for f in GemmDesc._fields_], names
 

@@ -325,3 +325,15 @@ def test_host_tensors_are_refused():
     from gaot_amd import ops
     with pytest.raises(RuntimeError):
         ops.linear(torch.randn(4, 4), torch.randn(4, 4))
+
+
+@pytest.mark.parametrize("N,K,M", [(256, 256, 8192), (64, 64, 55592), (64, 1, 131072), (1, 64, 70000), (64, 7, 4096), (96, 40, 1000)])
+def test_weight_grad_with_fused_bias_grad(N, K, M):
+    """dW = dY^T X with the bias gradient (column sums of dY) produced by the same kernel (MFMA and skinny paths)"""
+    from gaot_amd import ops
+    g = torch.Generator().manual_seed(N + K)
+    gy, x = torch.randn(M, N, generator=g), torch.randn(M, K, generator=g)
+    db = torch.empty(N, device=dev())
+    dw = ops.matmul_tn(gy.to(dev()), x.to(dev()), colsum_out=db)
+    assert rel(dw, gy.double().t() @ x.double()) < 3e-6
+    assert rel(db, gy.double().sum(0)) < 3e-6
