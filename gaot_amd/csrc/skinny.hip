@@ -65,16 +65,23 @@ __global__ __launch_bounds__(256) void skinny_tn_partial_kernel(const GemmArgs p
     for (int j = 0; j < 8; ++j) { acc[j] = 0.f; cs[j] = 0.f; }
     if (w < W) {
         int r = r0 + wave;
-        for (; r + 4 < r1; r += 8) {              // two rows in flight per wave
-            const float v0 = wide[(long)r * ldw + w], v1 = wide[(long)(r + 4) * ldw + w];
-            if (WIDE_IS_M) cs[0] += v0 + v1;
+        for (; r + 12 < r1; r += 16) {             // four rows in flight per wave (HBM latency, not bandwidth, limits here)
+            float v[4], nn[4][8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (j < J) {
-                    const float n0 = nar[(long)r * ldn + j], n1 = nar[(long)(r + 4) * ldn + j];
-                    acc[j] = fmaf(v0, n0, acc[j]); acc[j] = fmaf(v1, n1, acc[j]);
-                    if (!WIDE_IS_M) cs[j] += n0 + n1;
+            for (int u = 0; u < 4; ++u) {
+                v[u] = wide[(long)(r + 4 * u) * ldw + w];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) nn[u][j] = (j < J) ? nar[(long)(r + 4 * u) * ldn + j] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (WIDE_IS_M) cs[0] += v[u];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    acc[j] = fmaf(v[u], nn[u][j], acc[j]);
+                    if (!WIDE_IS_M) cs[j] += nn[u][j];
                 }
+            }
         }
         for (; r < r1; r += 4) {
             const float v0 = wide[(long)r * ldw + w];

@@ -66,6 +66,8 @@ def _split_for_reduction(Mo: int, No: int, K: int) -> int:
     """split-K factor for weight-gradient products (tiny output, long reduction)."""
     tiles = ((Mo + 63) // 64) * ((No + 63) // 64)
     want = max(1, 1024 // max(1, tiles))          # ~1024 workgroups of 64x64 (tools/gemm_bench.py sweep)
+    if Mo * No <= 4096 and min(Mo, No) <= 8:      # skinny path: HBM-latency bound, wants many short row chunks
+        return int(max(1, min(1024, (K + 127) // 128)))
     return int(max(1, min(want, 256, (K + 255) // 256)))
 
 

@@ -336,4 +336,5 @@ def test_weight_grad_with_fused_bias_grad(N, K, M):
     db = torch.empty(N, device=dev())
     dw = ops.matmul_tn(gy.to(dev()), x.to(dev()), colsum_out=db)
     assert rel(dw, gy.double().t() @ x.double()) < 3e-6
-    assert rel(db, gy.double().sum(0)) < 3e-6
+    # column sums of N(0,1) data nearly cancel: measure the error against the summed magnitudes
+    assert float((db.double().cpu() - gy.double().sum(0)).abs().max() / gy.double().abs().sum(0).max()) < 1e-6
