@@ -75,6 +75,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch must load ITS HIP runtime (libamdhip64) first: libgaot_hip.so then binds to the same runtime instance, so
+    # streams and device pointers are interchangeable.  Loading us first would pull in a second runtime by path.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise GaotLibraryError(
             f"{LIB_PATH} not found: build it with `python -m gaot_amd.build` (hipcc --offload-arch=gfx950). "

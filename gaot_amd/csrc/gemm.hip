@@ -18,12 +18,12 @@ namespace gaot {
 constexpr int BK = 32;
 
 // global -> registers for one [ROWS x BK] operand tile.  KMAJ: elem(row,k) = base[row*ld + k].
-template <bool KMAJ, bool VEC, int ROWS>
-__device__ __forceinline__ void load_tile(f32x4 (&r)[ROWS / 32], const float* __restrict__ base, long ld,
+template <bool KMAJ, bool VEC, int ROWS, int NT>
+__device__ __forceinline__ void load_tile(f32x4 (&r)[ROWS * 8 / NT], const float* __restrict__ base, long ld,
                                           int row0, int nrows, int k0, int klim, int tid) {
 #pragma unroll
-    for (int p = 0; p < ROWS / 32; ++p) {
-        const int t = tid + p * 256;
+    for (int p = 0; p < ROWS * 8 / NT; ++p) {
+        const int t = tid + p * NT;
         int row, k;
         if (KMAJ) { row = row0 + (t >> 3); k = k0 + (t & 7) * 4; }
         else      { k = k0 + t / (ROWS / 4); row = row0 + (t % (ROWS / 4)) * 4; }
@@ -45,11 +45,11 @@ __device__ __forceinline__ void load_tile(f32x4 (&r)[ROWS / 32], const float* __
     }
 }
 
-template <bool KMAJ, int ROWS>
-__device__ __forceinline__ void store_tile(float* __restrict__ s, const f32x4 (&r)[ROWS / 32], int tid) {
+template <bool KMAJ, int ROWS, int NT>
+__device__ __forceinline__ void store_tile(float* __restrict__ s, const f32x4 (&r)[ROWS * 8 / NT], int tid) {
 #pragma unroll
-    for (int p = 0; p < ROWS / 32; ++p) {
-        const int t = tid + p * 256;
+    for (int p = 0; p < ROWS * 8 / NT; ++p) {
+        const int t = tid + p * NT;
         if (KMAJ) *reinterpret_cast<f32x4*>(s + (t >> 3) * (BK + 4) + (t & 7) * 4) = r[p];
         else      *reinterpret_cast<f32x4*>(s + (t / (ROWS / 4)) * ROWS + (t % (ROWS / 4)) * 4) = r[p];
     }
@@ -62,9 +62,10 @@ __device__ __forceinline__ int xcd_remap(int id, int total) {
     return start + slot;
 }
 
-template <int BM, int BN, int WAVES_M, bool AK, bool BKM, bool VEC>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
-    constexpr int WAVES_N = 4 / WAVES_M;
+template <int BM, int BN, int WAVES_M, bool AK, bool BKM, bool VEC, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void gemm_kernel(const GemmArgs p) {
+    constexpr int NT = 64 * NW;
+    constexpr int WAVES_N = NW / WAVES_M;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int LDA_S = AK ? BK + 4 : BM;
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    f32x4 ra[BM / 32], rb[BN / 32];
+    f32x4 ra[BM * 8 / NT], rb[BN * 8 / NT];
     // fused column sum of the m-major A operand (= bias gradient when A is dY): every thread owns 4 consecutive
     // rows (m) of the tile at some k; blocks of the first n-tile column do the work
     const bool do_colsum = !AK && p.colsum != nullptr && (logical % p.tiles_n) == 0;
@@ -109,19 +110,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     auto fetch = [&](int kt) {
         const int k0 = kt * BK;
         if (p.A2 != nullptr && k0 >= p.k_split)
-            load_tile<AK, VEC, BM>(ra, p.A2, p.lda2, m0, p.M, k0 - p.k_split, p.K - p.k_split, tid);
+            load_tile<AK, VEC, BM, NT>(ra, p.A2, p.lda2, m0, p.M, k0 - p.k_split, p.K - p.k_split, tid);
         else
-            load_tile<AK, VEC, BM>(ra, p.A, p.lda, m0, p.M, k0, p.A2 ? p.k_split : p.K, tid);
-        load_tile<BKM, VEC, BN>(rb, p.B, p.ldb, n0, p.N, k0, p.K, tid);
+            load_tile<AK, VEC, BM, NT>(ra, p.A, p.lda, m0, p.M, k0, p.A2 ? p.k_split : p.K, tid);
+        load_tile<BKM, VEC, BN, NT>(rb, p.B, p.ldb, n0, p.N, k0, p.K, tid);
     };
 
     if (kt_begin < kt_end) fetch(kt_begin);
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-        store_tile<AK, BM>(As, ra, tid);
-        store_tile<BKM, BN>(Bs, rb, tid);
+        store_tile<AK, BM, NT>(As, ra, tid);
+        store_tile<BKM, BN, NT>(Bs, rb, tid);
         if (!AK && do_colsum) {
 #pragma unroll
-            for (int q = 0; q < BM / 32; ++q) csum += ra[q];
+            for (int q = 0; q < BM * 8 / NT; ++q) csum += ra[q];
         }
         __syncthreads();
         if (kt + 1 < kt_end) fetch(kt + 1);
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     }
 
     if (!AK && do_colsum) {      // threads with equal (tid % (BM/4)) hold partials of the same 4 rows: reduce through LDS
-        constexpr int G = BM / 4, NG = 256 / G;
+        constexpr int G = BM / 4, NG = NT / G;
         __syncthreads();
         *reinterpret_cast<f32x4*>(smem + (tid / G) * BM + (tid % G) * 4) = csum;
         __syncthreads();
@@ -177,28 +178,75 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             }
         }
     }
-    // epilogue: C-layout rows crow(r, lh), column li -> each half-wave writes 128 contiguous bytes per r
+    // epilogue: C-layout rows crow(r, lh), column li -> each half-wave writes 128 contiguous bytes per r.
+    // All extra operands of a 32x32 fragment (row bias, row scale, saved activation, residual) are loaded FIRST with
+    // predicated, branch-free loads so that 16 independent loads are in flight; then the math; then the stores.
+    if (p.split_k > 1) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * WM + i * 32 + crow(r, lh);
-            if (m >= p.M) continue;
-            if (p.split_k > 1) {
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int n = n0 + wn * WN + j * 32 + li;
-                    if (n < p.N) p.ws[((long)blockIdx.z * p.M + m) * p.N + n] = acc[i][j][r];
-                }
-            } else {
-                const RowCtx rc = row_ctx(p, m);
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WM + i * 32 + crow(r, lh);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int n = n0 + wn * WN + j * 32 + li;
-                    if (n < p.N) epilogue_store_row(p, rc, m, n, acc[i][j][r]);
+                    if (m < p.M && n < p.N) p.ws[((long)blockIdx.z * p.M + m) * p.N + n] = acc[i][j][r];
                 }
             }
+        return;
+    }
+    const bool has_rb = p.rowbias != nullptr, has_rs = p.rowscale != nullptr, has_res = p.residual != nullptr;
+    const bool has_auxin = (p.act == GAOT_ACT_GELU_BWD || p.act == GAOT_ACT_RELU_BWD);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int mbase = m0 + wm * WM + i * 32;
+        int rbrow[16];
+        float rsv[16];
+        if (has_rb) {
+            int mm = (mbase + 4 * lh) % p.rb_period;          // one integer division per fragment, then increments
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {                    // crow(r, lh) - 4*lh = (r & 3) + 8 * (r >> 2): ascending in r
+                int v = mm + (r & 3) + 8 * (r >> 2);
+                while (v >= p.rb_period) v -= p.rb_period;
+                rbrow[r] = v;
+            }
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mbase + crow(r, lh);
+            rsv[r] = (has_rs && m < p.M) ? p.rowscale[m] : 1.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * WN + j * 32 + li;
+            const bool nok = n < p.N;
+            const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
+            float rbv[16], resv[16], auxv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mbase + crow(r, lh);
+                const bool ok = nok && m < p.M;
+                rbv[r] = (has_rb && ok) ? p.rowbias[(long)rbrow[r] * p.ld_rb + n] : 0.f;
+                resv[r] = (has_res && ok) ? p.residual[(long)m * p.ldr + n] : 0.f;
+                auxv[r] = (has_auxin && ok) ? p.aux_in[(long)m * p.ld_aux + n] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mbase + crow(r, lh);
+                if (!(nok && m < p.M)) continue;
+                float v = (acc[i][j][r] + bv + rbv[r]) * rsv[r];
+                if (p.aux_out) p.aux_out[(long)m * p.ld_aux + n] = v;
+                switch (p.act) {
+                    case GAOT_ACT_GELU: v = gelu_f(v); break;
+                    case GAOT_ACT_RELU: v = fmaxf(v, 0.0f); break;
+                    case GAOT_ACT_GELU_BWD: v *= gelu_grad_f(auxv[r]); break;
+                    case GAOT_ACT_RELU_BWD: v = (auxv[r] > 0.0f) ? v : 0.0f; break;
+                    default: break;
+                }
+                p.C[(long)m * p.ldc + n] = v + resv[r];
+            }
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
@@ -217,6 +265,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
         }
     }
 }
+
 // z-parallel sum of `nz` slabs of `count` floats each: wave w takes z = w, w+4, ... with 8 loads in flight,
 // partial sums meet in LDS.  One lane per output element (VEC: per 4 elements).  Fixed order -> deterministic.
 template <typename T>
@@ -263,13 +312,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const GemmArgs p
     }
 }
 
-template <int BM, int BN, int WAVES_M>
+template <int BM, int BN, int WAVES_M, int NW = 4>
 static int launch_cfg(GemmArgs& a, bool ak, bool bk, bool vec, hipStream_t st) {
     a.tiles_m = cdiv(a.M, BM);
     a.tiles_n = cdiv(a.N, BN);
     dim3 grid(a.tiles_m * a.tiles_n, 1, a.split_k > 1 ? a.split_k : 1);
-    dim3 block(256);
-#define GAOT_LAUNCH(AKv, BKv, Vv) hipLaunchKernelGGL((gemm_kernel<BM, BN, WAVES_M, AKv, BKv, Vv>), grid, block, 0, st, a)
+    dim3 block(64 * NW);
+#define GAOT_LAUNCH(AKv, BKv, Vv) hipLaunchKernelGGL((gemm_kernel<BM, BN, WAVES_M, AKv, BKv, Vv, NW>), grid, block, 0, st, a)
     if (ak && bk)        { if (vec) GAOT_LAUNCH(true, true, true);   else GAOT_LAUNCH(true, true, false); }
     else if (ak && !bk)  { if (vec) GAOT_LAUNCH(true, false, true);  else GAOT_LAUNCH(true, false, false); }
     else if (!ak && !bk) { if (vec) GAOT_LAUNCH(false, false, true); else GAOT_LAUNCH(false, false, false); }
@@ -331,9 +380,13 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
     else if (g_tile_override == 2)      launch_cfg<128, 64, 2>(a, ak, bk, vec, st);
     else if (g_tile_override == 3)      launch_cfg<64, 64, 2>(a, ak, bk, vec, st);
     else if (g_tile_override == 4)      launch_cfg<128, 32, 4>(a, ak, bk, vec, st);
+    else if (g_tile_override == 5)      launch_cfg<128, 128, 2, 8>(a, ak, bk, vec, st);
+    else if (g_tile_override == 6)      launch_cfg<128, 64, 4, 8>(a, ak, bk, vec, st);
     else if (a.N <= 32)                 launch_cfg<128, 32, 4>(a, ak, bk, vec, st);
     // measured on MI355X (tools/gemm_bench.py): short reductions want SEVERAL block-waves in flight so that the
     // load / MFMA / store phases of different workgroups overlap; big tiles only pay off on large outputs.
+    // transposed-A weight gradients (long reduction, split-K): 128x64 measured 10-17 % ahead of 64x64 once it fills the chip
+    else if (!ak && !bk && blocks(128, 64) >= 256 && a.M >= 128) launch_cfg<128, 64, 2>(a, ak, bk, vec, st);
     else if (blocks(64, 64) <= 1536)    launch_cfg<64, 64, 2>(a, ak, bk, vec, st);
     else if (blocks(128, 64) <= 3072)   launch_cfg<128, 64, 2>(a, ak, bk, vec, st);
     else                                launch_cfg<128, 128, 2>(a, ak, bk, vec, st);

@@ -126,10 +126,12 @@ __global__ __launch_bounds__(256) void skinny_tn_final_kernel(const GemmArgs p, 
     float s = 0.f;
     if (o < total) {
         int c = wave;
-        for (; c + 12 < chunks; c += 16) {
-            const float t0 = p.ws[(long)c * total + o], t1 = p.ws[(long)(c + 4) * total + o];
-            const float t2 = p.ws[(long)(c + 8) * total + o], t3 = p.ws[(long)(c + 12) * total + o];
-            s += t0; s += t1; s += t2; s += t3;
+        for (; c + 60 < chunks; c += 64) {            // 16 loads in flight per lane
+            float t[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t[u] = p.ws[(long)(c + 4 * u) * total + o];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += t[u];
         }
         for (; c < chunks; c += 4) s += p.ws[(long)c * total + o];
     }
@@ -143,10 +145,12 @@ __global__ __launch_bounds__(256) void skinny_tn_final_kernel(const GemmArgs p, 
             float v = 0.f;
             if (m < p.M) {
                 int c = wave;
-                for (; c + 12 < chunks; c += 16) {
-                    const float t0 = slab[(long)c * p.M + m], t1 = slab[(long)(c + 4) * p.M + m];
-                    const float t2 = slab[(long)(c + 8) * p.M + m], t3 = slab[(long)(c + 12) * p.M + m];
-                    v += t0; v += t1; v += t2; v += t3;
+                for (; c + 60 < chunks; c += 64) {
+                    float t[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) t[u] = slab[(long)(c + 4 * u) * p.M + m];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v += t[u];
                 }
                 for (; c < chunks; c += 4) v += slab[(long)c * p.M + m];
             }

@@ -126,10 +126,11 @@ class TrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._g_fb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_fb):
+        # thread_local: the RCCL watchdog thread's event queries must not invalidate the capture
+        with torch.cuda.graph(self._g_fb, capture_error_mode="thread_local"):
             self._loss = self._forward_backward()
         self._g_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_opt):
+        with torch.cuda.graph(self._g_opt, capture_error_mode="thread_local"):
             self.opt.step()
 
     def step(self, pndata: Optional[torch.Tensor] = None, target: Optional[torch.Tensor] = None) -> torch.Tensor:

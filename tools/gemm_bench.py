@@ -7,7 +7,7 @@ from gaot_amd import ops, _lib as L
 
 dev = torch.device("cuda:0")
 lib = L.load()
-TILES = {1: "128x128", 2: "128x64", 3: "64x64", 4: "128x32"}
+TILES = {1: "128x128", 2: "128x64", 3: "64x64", 4: "128x32", 5: "128x128w8", 6: "128x64w8"}
 
 def timeit(fn, iters=20):
     for _ in range(3): fn()
@@ -42,6 +42,16 @@ def run(kind, M, N, K, tiles=(1, 2, 3), split=None):
     us = timeit(lambda: call(splits[0] if kind != 'tn' else ops._split_for_reduction(M, N, K)))
     print(f"{kind} M={M:6d} N={N:5d} K={K:6d} {fl/1e9:7.2f}GF | " + " | ".join(res) + f" | auto: {us:7.1f}us {fl/us/1e6:6.1f}TF", flush=True)
 
+import os
+if os.environ.get("FOCUS"):
+    run("nt", 4096, 4096, 4096, tiles=(1, 5))
+    for (N, K) in [(256, 256), (768, 256), (2048, 256), (256, 1024)]:
+        run("nt", 8192, N, K, tiles=(2, 3, 5, 6))
+    for (N, K) in [(256, 2048), (1024, 256)]:
+        run("nn", 8192, N, K, tiles=(2, 3, 5, 6))
+    for (M, N) in [(2048, 256), (256, 1024)]:
+        run("tn", M, N, 8192, tiles=(2, 3, 5, 6), split=[ops._split_for_reduction(M, N, 8192)])
+    sys.exit(0)
 print("== big squares (kernel ceiling)")
 run("nt", 4096, 4096, 4096, tiles=(1,))
 run("nt", 8192, 8192, 512, tiles=(1, 2))
