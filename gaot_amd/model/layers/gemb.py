@@ -34,10 +34,11 @@ class GeometricEmbedding(nn.Module):
         else:
             raise ValueError(f"Unknown method: {self.method}")
 
-    def forward(self, input_geom, latent_queries, spatial_nbrs):
+    def forward(self, input_geom, latent_queries, spatial_nbrs, stats=None):
         plan = plan_for(spatial_nbrs, input_geom.shape[0])
         if self.method == 'statistical':
-            stats = plan.geo_stats(input_geom, latent_queries)          # [Q, 3+2d], cached per geometry
+            if stats is None:
+                stats = plan.geo_stats(input_geom, latent_queries)      # [Q, 3+2d], cached per geometry
             return ops.mlp_chain(stats, [self.mlp[0].weight, self.mlp[2].weight],
                                  [self.mlp[0].bias, self.mlp[2].bias], ["relu", "relu"])
         return self._pointnet(plan, input_geom, latent_queries)

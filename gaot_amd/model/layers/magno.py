@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
+from ...plan import merged_geometry
 from .agno import AGNO
 from .gemb import GeometricEmbedding, node_pos_encode
 from .mlp import ChannelMLP
@@ -128,12 +129,13 @@ class _MAGNOBase(nn.Module):
             self._coord_enc_cache[key] = hit
         return hit[1]
 
-    def _transform(self, src_coord, dst_coord, feats, neighbors):
+    def _transform(self, src_coord, dst_coord, feats, neighbors, stats=None):
         """AGNO (+ geoembed + recovery) for ONE geometry at ONE scale.  feats [B, n_src, C] -> [B, n_dst, C]."""
         nb = apply_edge_drop_csr(neighbors, self.sampling_strategy, self.max_neighbors, self.sample_ratio, self.training)
         out = self.agno(y=self._kcoord(src_coord), x=self._kcoord(dst_coord), f_y=feats, neighbors=nb)
         if self.use_geoembed:
-            ge = self.geoembed(input_geom=src_coord, latent_queries=dst_coord, spatial_nbrs=nb)     # [n_dst, C]
+            ge = self.geoembed(input_geom=src_coord, latent_queries=dst_coord, spatial_nbrs=nb,
+                               stats=stats if nb is neighbors else None)                          # [n_dst, C]
             w = self.recovery.fcs[0].weight.squeeze(-1)                                             # [C, 2C]
             C = out.shape[-1]
             rowb = ops.linear(ge, w[:, C:], self.recovery.fcs[0].bias)                              # [n_dst, C]
@@ -162,10 +164,17 @@ class _MAGNOBase(nn.Module):
             if mode == 'fx':
                 per_scale.append(self._transform(src, dst, feats, nbrs[si]))
             else:
+                # vx: block-diagonal union of the B per-sample graphs -> one launch per kernel for the whole batch
                 B = feats.shape[0]
-                per_scale.append(torch.cat([
-                    self._transform(src[b] if src.ndim == 3 else src, dst[b] if dst.ndim == 3 else dst,
-                                    feats[b:b + 1], nbrs[b][si]) for b in range(B)], dim=0))
+                srcs = [src[b] if src.ndim == 3 else src for b in range(B)]
+                dsts = [dst[b] if dst.ndim == 3 else dst for b in range(B)]
+                mg = merged_geometry([nbrs[b][si] for b in range(B)], srcs, dsts, parents=(src, dst))
+                n_dst = mg.n_dst_each[0]
+                if any(n != n_dst for n in mg.n_dst_each) or any(n != feats.shape[1] for n in mg.n_src_each):
+                    raise ValueError("vx mode needs the same number of source / query points in every sample of a batch")
+                stats = mg.geo_stats() if (self.use_geoembed and self.geoembed.method == 'statistical') else None
+                out = self._transform(mg.src, mg.dst, feats.reshape(1, B * feats.shape[1], feats.shape[2]), mg.neighbors, stats)
+                per_scale.append(out.reshape(B, n_dst, out.shape[-1]))
         return per_scale
 
 

@@ -18,7 +18,7 @@ _PLAN_KEY = "_gaot_amd_plan"
 
 
 class GeometryPlan:
-    def __init__(self, index_i64: torch.Tensor, splits_i64: torch.Tensor, n_src: int):
+    def __init__(self, index_i64: torch.Tensor, splits_i64: torch.Tensor, n_src: int, validate: bool = True):
         if not index_i64.is_cuda or not splits_i64.is_cuda:
             raise RuntimeError("GeometryPlan needs the CSR on the GPU (gaot_amd has no CPU path)")
         lib = L.load()
@@ -40,7 +40,7 @@ class GeometryPlan:
         scratch = torch.empty(self.n_src + 1, dtype=torch.int32, device=dev)
         L.check(lib.gaot_csr_transpose(_p(self.index), self.E, self.n_src, _p(self.t_splits), _p(self.t_edge), _p(scratch),
                                        _stream()), "gaot_csr_transpose")
-        bad = int(flag.item())     # one sync per geometry: the CSR contract is checked on device
+        bad = int(flag.item()) if validate else 0     # one sync per geometry: the CSR contract is checked on device
         if bad:
             raise ValueError(f"invalid CSR neighbour list (flag {bad}: 1 = row_splits not monotone 0..E, 2 = index outside [0, n_src))")
         deg = (splits_i64[1:] - splits_i64[:-1])
@@ -120,3 +120,60 @@ def plan_for(neighbors: dict, n_src: int) -> GeometryPlan:
         plan._src_id = (id(idx), idx._version)
         neighbors[_PLAN_KEY] = plan
     return plan
+
+
+class MergedGeometry:
+    """Block-diagonal union of per-sample geometries (vx mode, reference magno.py:356-413 / 694-751 loops over
+    samples in Python): sources and queries of all samples are concatenated, CSR indices are offset per sample, so
+    the whole minibatch goes through ONE launch of each GNO kernel with a batch dimension of 1.
+
+    Per-sample quantities that the reference normalises per geometry (the geometry statistics' global
+    standardisation, gemb.py:164-169) are computed per sample and concatenated."""
+
+    def __init__(self, nbr_dicts, src_coords, dst_coords):
+        idx, sp, self.n_src_each, self.n_dst_each = [], [], [], []
+        e_off = s_off = 0
+        dev = nbr_dicts[0]["neighbors_row_splits"].device
+        for nb, sc, dc in zip(nbr_dicts, src_coords, dst_coords):
+            i, s_ = nb["neighbors_index"], nb["neighbors_row_splits"]
+            idx.append(i + s_off)
+            sp.append(s_[:-1] + e_off)
+            e_off += int(i.numel())
+            s_off += int(sc.shape[0])
+            self.n_src_each.append(int(sc.shape[0]))
+            self.n_dst_each.append(int(dc.shape[0]))
+        sp.append(torch.tensor([e_off], dtype=torch.long, device=dev))
+        self.neighbors = {"neighbors_index": torch.cat(idx), "neighbors_row_splits": torch.cat(sp)}
+        self.src = torch.cat(list(src_coords), dim=0).contiguous()
+        self.dst = torch.cat(list(dst_coords), dim=0).contiguous()
+        for nb, sc in zip(nbr_dicts, src_coords):          # validates each part once (cached on the per-sample dict)
+            plan_for(nb, sc.shape[0])
+        plan = GeometryPlan(self.neighbors["neighbors_index"], self.neighbors["neighbors_row_splits"], self.src.shape[0],
+                            validate=False)                # parts are valid => the offset union is valid: no host sync
+        plan._src_id = (id(self.neighbors["neighbors_index"]), self.neighbors["neighbors_index"]._version)
+        self.neighbors[_PLAN_KEY] = plan
+        self.plan = plan
+        self._parts = (list(nbr_dicts), list(src_coords), list(dst_coords))
+        self._stats = None
+
+    def geo_stats(self) -> torch.Tensor:
+        if self._stats is None:
+            nbs, scs, dcs = self._parts
+            self._stats = torch.cat([plan_for(nb, sc.shape[0]).geo_stats(sc, dc) for nb, sc, dc in zip(nbs, scs, dcs)], dim=0)
+        return self._stats
+
+
+_MERGE_CACHE = {}
+
+
+def merged_geometry(nbr_dicts, src_coords, dst_coords, parents=()) -> MergedGeometry:
+    """Cached on the identity of the per-sample neighbour dicts and of the PARENT coordinate tensors (per-sample
+    slices are new objects on every call).  A re-shuffled batch is a new combination and is merged afresh."""
+    key = tuple(id(n) for n in nbr_dicts) + tuple((id(c), c._version) for c in parents)
+    hit = _MERGE_CACHE.get(key)
+    if hit is None or any(a is not b for a, b in zip(hit[1], parents)):
+        if len(_MERGE_CACHE) > 64:
+            _MERGE_CACHE.clear()
+        hit = (MergedGeometry(nbr_dicts, src_coords, dst_coords), tuple(parents), list(nbr_dicts))   # hold refs: ids stay unique
+        _MERGE_CACHE[key] = hit
+    return hit[0]
