@@ -28,6 +28,19 @@ struct AttnArgs {
     float scale; int vec;
 };
 
+// id -> (group, member): groups are dealt to XCDs round-robin, all members of a group stay on the group's XCD.
+// With G groups of n members: XCD x = id % 8 serves groups x, x+8, ...; falls back to the plain order when G % 8 != 0.
+__device__ __forceinline__ void xcd_group_decode(int id, int G, int n, int& group, int& member) {
+    if ((G & 7) == 0) {
+        const int x = id & 7, t = id >> 3;        // t-th workgroup on XCD x
+        group = x + 8 * (t / n);
+        member = t % n;
+    } else {
+        group = id / n;
+        member = id % n;
+    }
+}
+
 __device__ __forceinline__ f32x4 load4(const float* __restrict__ row, int d, int D, bool row_ok, bool vec) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (!row_ok) return v;
@@ -54,8 +67,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H, hk = h / (p.H / p.Hkv);
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    // XCD-aware decode of the 1-D grid: the dispatcher places workgroup id on XCD id % 8; keep all query blocks of one
+    // (batch, head) on ONE XCD so its K/V (2 x S x D x 4 B) is fetched into that XCD's L2 once, not eight times.
+    int bh, blk;
+    xcd_group_decode(blockIdx.x, p.B * p.H, (p.S + 127) / 128, bh, blk);
+    const int b = bh / p.H, h = bh % p.H, hk = h / (p.H / p.Hkv);
+    const int q0 = blk * 128 + wave * 32;
     const int D = p.D;
     const bool vec = p.vec != 0;
     const float c = p.scale * LOG2E;
@@ -226,8 +243,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H, hk = h / (p.H / p.Hkv);
-    const int kv0 = blockIdx.x * 128 + wave * 32;
+    int bh, kblk;
+    xcd_group_decode(blockIdx.x, p.B * p.H, p.n_kblocks, bh, kblk);     // key blocks of one (b,h) share Q / dO: same XCD
+    const int b = bh / p.H, h = bh % p.H, hk = h / (p.H / p.Hkv);
+    const int kv0 = kblk * 128 + wave * 32;
     const int D = p.D;
     const bool vec = p.vec != 0;
     const float c = p.scale * LOG2E;
@@ -286,7 +305,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs p) {
     };
     const int nq = (p.S + 31) / 32;
     const long part_stride = (long)p.B * p.H * p.S * DP;
-    float* part = p.dq_part + (long)blockIdx.x * part_stride + ((long)b * p.H + h) * p.S * DP;
+    float* part = p.dq_part + (long)kblk * part_stride + ((long)b * p.H + h) * p.S * DP;
 
     fetch(0);
     for (int qt = 0; qt < nq; ++qt) {
@@ -429,7 +448,7 @@ extern "C" int gaot_attention_fwd(const float* q, const float* k, const float* v
     AttnArgs a = {};
     fill_common(a, q, k, v, ldq, ldk, ldv, B, S, H, Hkv, head_dim);
     a.o = o; a.ldo = ldo; a.lse = lse;
-    dim3 grid(cdiv(S, 128), B * H), block(256);
+    dim3 grid(cdiv(S, 128) * B * H), block(256);
     if (head_dim <= 32) hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, block, 0, ST(stream), a);
     else                hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, block, 0, ST(stream), a);
     GAOT_CHECK_LAUNCH("gaot_attention_fwd");
@@ -459,7 +478,7 @@ extern "C" int gaot_attention_bwd(const float* q, const float* k, const float* v
     a.n_kblocks = cdiv(S, 128);
     const int DP = head_dim <= 32 ? 32 : 64;
     hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv((long)B * S * H, 256)), dim3(256), 0, ST(stream), a);
-    dim3 grid(a.n_kblocks, B * H), block(256);
+    dim3 grid(a.n_kblocks * B * H), block(256);
     if (DP == 32) {
         hipLaunchKernelGGL(attn_bwd_kernel<32>, grid, block, bwd_lds_bytes<32>(), ST(stream), a);
     } else {

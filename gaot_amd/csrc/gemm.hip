@@ -72,7 +72,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_kernel(const GemmArgs p) {
     constexpr int LDB_S = BKM ? BK + 4 : BN;
     constexpr int A_ELEMS = AK ? BM * (BK + 4) : BK * BM;
     constexpr int B_ELEMS = BKM ? BN * (BK + 4) : BK * BN;
-    __shared__ __attribute__((aligned(16))) float smem[A_ELEMS + B_ELEMS];
+    constexpr int EPI_ELEMS = NW * 32 * (WN + 4);          // per-wave transposition slabs of the vector epilogue
+    constexpr int SMEM_ELEMS = (A_ELEMS + B_ELEMS) > EPI_ELEMS ? (A_ELEMS + B_ELEMS) : EPI_ELEMS;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_ELEMS];
     float* As = smem;
     float* Bs = smem + A_ELEMS;
 
@@ -117,15 +119,22 @@ __global__ __launch_bounds__(64 * NW) void gemm_kernel(const GemmArgs p) {
     };
 
     if (kt_begin < kt_end) fetch(kt_begin);
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
+    if (p.ablate & 2) {          // ablation: stage once, then compute on the same LDS contents without barriers
         store_tile<AK, BM, NT>(As, ra, tid);
         store_tile<BKM, BN, NT>(Bs, rb, tid);
+        __syncthreads();
+    }
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        if (!(p.ablate & 2)) {
+        store_tile<AK, BM, NT>(As, ra, tid);
+        store_tile<BKM, BN, NT>(Bs, rb, tid);
+        }
         if (!AK && do_colsum) {
 #pragma unroll
             for (int q = 0; q < BM * 8 / NT; ++q) csum += ra[q];
         }
-        __syncthreads();
-        if (kt + 1 < kt_end) fetch(kt + 1);
+        if (!(p.ablate & 2)) __syncthreads();
+        if (kt + 1 < kt_end && !(p.ablate & 1)) fetch(kt + 1);
 #pragma unroll
         for (int g = 0; g < BK / 8; ++g) {
             float a[TM][4], b[TN][4];
@@ -159,7 +168,18 @@ __global__ __launch_bounds__(64 * NW) void gemm_kernel(const GemmArgs p) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
+        if (!(p.ablate & 2)) __syncthreads();
+    }
+    if (p.ablate & 4) {          // ablation: keep the accumulators alive but store (almost) nothing
+        float keep = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) keep += acc[i][j][r];
+        if (keep == 123.456f) p.C[0] = keep;
+        return;
     }
 
     if (!AK && do_colsum) {      // threads with equal (tid % (BM/4)) hold partials of the same 4 rows: reduce through LDS
@@ -177,6 +197,66 @@ __global__ __launch_bounds__(64 * NW) void gemm_kernel(const GemmArgs p) {
                 else p.colsum[m] = v;
             }
         }
+    }
+    // ---- vector epilogue: each wave transposes its 32-row fragment band through a private LDS slab (C-layout puts a
+    // COLUMN in a lane; stores want 4 consecutive columns per lane) and then does bias / row bias / row scale /
+    // activation / residual / store on 16-byte vectors: 4x fewer store instructions, 128-256 B contiguous per row.
+    if (p.vec_epi) {
+        __syncthreads();                                   // all waves are done with As / Bs
+        constexpr int LDC_S = WN + 4;
+        constexpr int LPR = WN / 4;                        // lanes per output row
+        constexpr int RPP = 64 / LPR;                      // rows per pass
+        float* Cw = smem + wave * 32 * LDC_S;
+        const int lr = lane / LPR, lc = (lane % LPR) * 4;
+        const int n = n0 + wn * WN + lc;
+        const bool nok = n < p.N;                          // N % 4 == 0: the whole vector is in or out
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && nok && p.split_k <= 1) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+        const bool has_auxin = (p.act == GAOT_ACT_GELU_BWD || p.act == GAOT_ACT_RELU_BWD);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Cw[crow(r, lh) * LDC_S + j * 32 + li] = acc[i][j][r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int ps = 0; ps < 32 / RPP; ++ps) {
+                const int row = ps * RPP + lr;
+                const int m = m0 + wm * WM + i * 32 + row;
+                if (nok && m < p.M) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(Cw + row * LDC_S + lc);
+                    if (p.split_k > 1) {
+                        *reinterpret_cast<f32x4*>(p.ws + ((long)blockIdx.z * p.M + m) * p.N + n) = v;
+                    } else {
+                        v += bv;
+                        if (p.rowbias) v += *reinterpret_cast<const f32x4*>(p.rowbias + (long)(m % p.rb_period) * p.ld_rb + n);
+                        if (p.rowscale) v *= p.rowscale[m];
+                        if (p.aux_out) *reinterpret_cast<f32x4*>(p.aux_out + (long)m * p.ld_aux + n) = v;
+                        if (p.act == GAOT_ACT_GELU) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) v[q] = gelu_f(v[q]);
+                        } else if (p.act == GAOT_ACT_RELU) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+                        } else if (has_auxin) {
+                            const f32x4 ax = *reinterpret_cast<const f32x4*>(p.aux_in + (long)m * p.ld_aux + n);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                v[q] = (p.act == GAOT_ACT_GELU_BWD) ? v[q] * gelu_grad_f(ax[q]) : (ax[q] > 0.f ? v[q] : 0.f);
+                        }
+                        if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (long)m * p.ldr + n);
+                        *reinterpret_cast<f32x4*>(p.C + (long)m * p.ldc + n) = v;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        return;
     }
     // epilogue: C-layout rows crow(r, lh), column li -> each half-wave writes 128 contiguous bytes per r.
     // All extra operands of a 32x32 fragment (row bias, row scale, saved activation, residual) are loaded FIRST with
@@ -331,6 +411,8 @@ static int launch_cfg(GemmArgs& a, bool ak, bool bk, bool vec, hipStream_t st) {
 
 using namespace gaot;
 
+static int g_ablate = 0;
+extern "C" int gaot_debug_set_gemm_ablate(int bits) { const int old = g_ablate; g_ablate = bits; return old; }
 static int g_tile_override = 0;   // tuning hook: 0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 128x32
 extern "C" int gaot_debug_set_gemm_tile(int cfg) { const int old = g_tile_override; g_tile_override = cfg; return old; }
 
@@ -359,6 +441,12 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
     a.residual = d->residual; a.ldr = d->ldr;
     a.split_k = split; a.ktiles_per_split = cdiv(nkt, split); a.ws = d->workspace;
     a.colsum = d->colsum;
+    a.ablate = g_ablate;
+    {
+        auto ok4 = [](const void* ptr, long ld) { return ptr == nullptr || (aligned16(ptr) && ld % 4 == 0); };
+        a.vec_epi = (a.N % 4 == 0) && aligned16(a.C) && (a.ldc % 4 == 0) && ok4(a.bias, 4) && ok4(a.rowbias, a.ld_rb) &&
+                    ok4(a.aux_in, a.ld_aux) && ok4(a.aux_out, a.ld_aux) && ok4(a.residual, a.ldr) && ok4(a.ws, 4);
+    }
     a.split_k = cdiv(nkt, a.ktiles_per_split);  // no empty splits
 
     const bool ak = d->a_kmajor != 0, bk = d->b_kmajor != 0;

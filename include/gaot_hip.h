@@ -73,6 +73,8 @@ typedef struct gaot_gemm_desc {
 int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream);
 /* tuning hook (not part of the data path): force the GEMM tile; 0 = heuristic. Returns the previous value. */
 int gaot_debug_set_gemm_tile(int cfg);
+/* tuning hook: ablate parts of the GEMM kernel (results become WRONG): 1 no in-loop loads, 2 no LDS staging, 4 no stores */
+int gaot_debug_set_gemm_ablate(int bits);
 
 /* ------------------------------------------------------------------------------------------
  * Geometry plan pieces (once per mesh geometry; torch_scatter / repeat_interleave call sites
