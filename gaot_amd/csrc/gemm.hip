@@ -103,13 +103,16 @@ __global__ __launch_bounds__(64 * NW) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    f32x4 ra[BM * 8 / NT], rb[BN * 8 / NT];
+    // Two register sets: tile kt+2 is in flight while tile kt is computed and tile kt+1 waits in the other set, so a
+    // load has TWO compute phases to land (HBM misses take ~2-3k cycles; with ~2 resident waves per SIMD a one-deep
+    // prefetch left the matrix pipe idle 13-42 % of the time -- tools/gemm_ablate.py).
+    f32x4 ra0[BM * 8 / NT], rb0[BN * 8 / NT], ra1[BM * 8 / NT], rb1[BN * 8 / NT];
     // fused column sum of the m-major A operand (= bias gradient when A is dY): every thread owns 4 consecutive
     // rows (m) of the tile at some k; blocks of the first n-tile column do the work
     const bool do_colsum = !AK && p.colsum != nullptr && (logical % p.tiles_n) == 0;
     f32x4 csum = {0.f, 0.f, 0.f, 0.f};
 
-    auto fetch = [&](int kt) {
+    auto fetch = [&](f32x4 (&ra)[BM * 8 / NT], f32x4 (&rb)[BN * 8 / NT], int kt) {
         const int k0 = kt * BK;
         if (p.A2 != nullptr && k0 >= p.k_split)
             load_tile<AK, VEC, BM, NT>(ra, p.A2, p.lda2, m0, p.M, k0 - p.k_split, p.K - p.k_split, tid);
@@ -117,24 +120,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_kernel(const GemmArgs p) {
             load_tile<AK, VEC, BM, NT>(ra, p.A, p.lda, m0, p.M, k0, p.A2 ? p.k_split : p.K, tid);
         load_tile<BKM, VEC, BN, NT>(rb, p.B, p.ldb, n0, p.N, k0, p.K, tid);
     };
-
-    if (kt_begin < kt_end) fetch(kt_begin);
-    if (p.ablate & 2) {          // ablation: stage once, then compute on the same LDS contents without barriers
-        store_tile<AK, BM, NT>(As, ra, tid);
-        store_tile<BKM, BN, NT>(Bs, rb, tid);
-        __syncthreads();
-    }
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        if (!(p.ablate & 2)) {
-        store_tile<AK, BM, NT>(As, ra, tid);
-        store_tile<BKM, BN, NT>(Bs, rb, tid);
-        }
-        if (!AK && do_colsum) {
-#pragma unroll
-            for (int q = 0; q < BM * 8 / NT; ++q) csum += ra[q];
-        }
-        if (!(p.ablate & 2)) __syncthreads();
-        if (kt + 1 < kt_end && !(p.ablate & 1)) fetch(kt + 1);
+    auto compute = [&]() {
 #pragma unroll
         for (int g = 0; g < BK / 8; ++g) {
             float a[TM][4], b[TN][4];
@@ -168,8 +154,36 @@ __global__ __launch_bounds__(64 * NW) void gemm_kernel(const GemmArgs p) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
         }
+    };
+    // one pipeline step: stage the set holding tile kt, refill it with tile kt+2, compute tile kt
+    auto step = [&](f32x4 (&ra)[BM * 8 / NT], f32x4 (&rb)[BN * 8 / NT], int kt) {
+        if (!(p.ablate & 2)) {
+            store_tile<AK, BM, NT>(As, ra, tid);
+            store_tile<BKM, BN, NT>(Bs, rb, tid);
+        }
+        if (!AK && do_colsum) {
+#pragma unroll
+            for (int q = 0; q < BM * 8 / NT; ++q) csum += ra[q];
+        }
         if (!(p.ablate & 2)) __syncthreads();
+        if (kt + 2 < kt_end && !(p.ablate & 1)) fetch(ra, rb, kt + 2);
+        compute();
+        if (!(p.ablate & 2)) __syncthreads();
+    };
+
+    if (kt_begin < kt_end) fetch(ra0, rb0, kt_begin);
+    if (kt_begin + 1 < kt_end) fetch(ra1, rb1, kt_begin + 1);
+    if (p.ablate & 2) {          // ablation: stage once, then compute on the same LDS contents without barriers
+        store_tile<AK, BM, NT>(As, ra0, tid);
+        store_tile<BKM, BN, NT>(Bs, rb0, tid);
+        __syncthreads();
     }
+    int kt = kt_begin;
+    for (; kt + 1 < kt_end; kt += 2) {
+        step(ra0, rb0, kt);
+        step(ra1, rb1, kt + 1);
+    }
+    if (kt < kt_end) step(ra0, rb0, kt);
     if (p.ablate & 4) {          // ablation: keep the accumulators alive but store (almost) nothing
         float keep = 0.f;
 #pragma unroll
@@ -222,7 +236,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_kernel(const GemmArgs p) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
+#pragma unroll 2
             for (int ps = 0; ps < 32 / RPP; ++ps) {
                 const int row = ps * RPP + lr;
                 const int m = m0 + wm * WM + i * 32 + row;
@@ -258,75 +272,28 @@ __global__ __launch_bounds__(64 * NW) void gemm_kernel(const GemmArgs p) {
         }
         return;
     }
-    // epilogue: C-layout rows crow(r, lh), column li -> each half-wave writes 128 contiguous bytes per r.
-    // All extra operands of a 32x32 fragment (row bias, row scale, saved activation, residual) are loaded FIRST with
-    // predicated, branch-free loads so that 16 independent loads are in flight; then the math; then the stores.
-    if (p.split_k > 1) {
+    // scalar fallback epilogue (odd N / unaligned operands): C-layout rows crow(r, lh), column li
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WM + i * 32 + crow(r, lh);
+        for (int r = 0; r < 16; ++r) {          // static indices only: runtime-indexed accumulators would go to scratch
+            const int m = m0 + wm * WM + i * 32 + crow(r, lh);
+            if (m >= p.M) continue;
+            if (p.split_k > 1) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int n = n0 + wn * WN + j * 32 + li;
-                    if (m < p.M && n < p.N) p.ws[((long)blockIdx.z * p.M + m) * p.N + n] = acc[i][j][r];
+                    if (n < p.N) p.ws[((long)blockIdx.z * p.M + m) * p.N + n] = acc[i][j][r];
+                }
+            } else {
+                const RowCtx rc = row_ctx(p, m);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + wn * WN + j * 32 + li;
+                    if (n < p.N) epilogue_store_row(p, rc, m, n, acc[i][j][r]);
                 }
             }
-        return;
-    }
-    const bool has_rb = p.rowbias != nullptr, has_rs = p.rowscale != nullptr, has_res = p.residual != nullptr;
-    const bool has_auxin = (p.act == GAOT_ACT_GELU_BWD || p.act == GAOT_ACT_RELU_BWD);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int mbase = m0 + wm * WM + i * 32;
-        int rbrow[16];
-        float rsv[16];
-        if (has_rb) {
-            int mm = (mbase + 4 * lh) % p.rb_period;          // one integer division per fragment, then increments
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {                    // crow(r, lh) - 4*lh = (r & 3) + 8 * (r >> 2): ascending in r
-                int v = mm + (r & 3) + 8 * (r >> 2);
-                while (v >= p.rb_period) v -= p.rb_period;
-                rbrow[r] = v;
-            }
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = mbase + crow(r, lh);
-            rsv[r] = (has_rs && m < p.M) ? p.rowscale[m] : 1.0f;
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * WN + j * 32 + li;
-            const bool nok = n < p.N;
-            const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
-            float rbv[16], resv[16], auxv[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mbase + crow(r, lh);
-                const bool ok = nok && m < p.M;
-                rbv[r] = (has_rb && ok) ? p.rowbias[(long)rbrow[r] * p.ld_rb + n] : 0.f;
-                resv[r] = (has_res && ok) ? p.residual[(long)m * p.ldr + n] : 0.f;
-                auxv[r] = (has_auxin && ok) ? p.aux_in[(long)m * p.ld_aux + n] : 0.f;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mbase + crow(r, lh);
-                if (!(nok && m < p.M)) continue;
-                float v = (acc[i][j][r] + bv + rbv[r]) * rsv[r];
-                if (p.aux_out) p.aux_out[(long)m * p.ld_aux + n] = v;
-                switch (p.act) {
-                    case GAOT_ACT_GELU: v = gelu_f(v); break;
-                    case GAOT_ACT_RELU: v = fmaxf(v, 0.0f); break;
-                    case GAOT_ACT_GELU_BWD: v *= gelu_grad_f(auxv[r]); break;
-                    case GAOT_ACT_RELU_BWD: v = (auxv[r] > 0.0f) ? v : 0.0f; break;
-                    default: break;
-                }
-                p.C[(long)m * p.ldc + n] = v + resv[r];
-            }
-        }
-    }
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
@@ -411,6 +378,8 @@ static int launch_cfg(GemmArgs& a, bool ak, bool bk, bool vec, hipStream_t st) {
 
 using namespace gaot;
 
+static thread_local int g_last_path = 0;   // 1 = MFMA tile kernel, 2 = skinny VALU path (for the bench's roofline accounting)
+extern "C" int gaot_debug_last_gemm_path(void) { return g_last_path; }
 static int g_ablate = 0;
 extern "C" int gaot_debug_set_gemm_ablate(int bits) { const int old = g_ablate; g_ablate = bits; return old; }
 static int g_tile_override = 0;   // tuning hook: 0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 128x32
@@ -457,9 +426,11 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (g_tile_override == 0 && launch_skinny(a, ak, bk, st)) {
+        g_last_path = 2;
         GAOT_CHECK_LAUNCH("gaot_gemm_f32(skinny)");
         return GAOT_OK;
     }
+    g_last_path = 1;
     // tile choice: the largest tile that still gives every CU (256) a workgroup; skinny N gets a 128x32 tile
     const long z = a.split_k;
     auto blocks = [&](int bm, int bn) { return (long)cdiv(a.M, bm) * cdiv(a.N, bn) * z; };

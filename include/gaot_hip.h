@@ -75,6 +75,8 @@ int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream);
 int gaot_debug_set_gemm_tile(int cfg);
 /* tuning hook: ablate parts of the GEMM kernel (results become WRONG): 1 no in-loop loads, 2 no LDS staging, 4 no stores */
 int gaot_debug_set_gemm_ablate(int bits);
+/* which kernel family served the calling thread's last gaot_gemm_f32: 1 = MFMA tiles, 2 = skinny VALU path */
+int gaot_debug_last_gemm_path(void);
 
 /* ------------------------------------------------------------------------------------------
  * Geometry plan pieces (once per mesh geometry; torch_scatter / repeat_interleave call sites
