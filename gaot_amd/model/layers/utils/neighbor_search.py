@@ -1,11 +1,71 @@
 """Radius neighbour search -> reference-style CSR dict (neighbor_search.py:65-146 semantics: inclusive
-`dist <= r`, unbounded degree, neighbours in ascending data index).
+`dist <= r`, unbounded degree, neighbours in ascending data index like the `native` backend).
 
-This is the BOUNDARY of the hot path: the result is cached by the MAGNO modules and consumed by the HIP
-kernels through a GeometryPlan; it is not part of the steady-state step.  It runs as chunked exact pairwise distances on
-whatever device the coordinates live on (a HIP cell-list builder is SURVEY 8f rank 1)."""
+This is the BOUNDARY of the hot path: the result is cached by the MAGNO modules and consumed by the HIP kernels
+through a GeometryPlan; it is not part of the steady-state step.  On the GPU it runs the HIP cell-list builder
+(gaot_cells_build / gaot_radius_count / gaot_radius_fill: O(Q * points in the 3^d surrounding cells)); host tensors
+(CPU tests, dataset preparation) use exact chunked pairwise distances with the same arithmetic."""
+import ctypes as C
+
 import torch
 from torch import nn
+
+
+def _exact_pairwise(data: torch.Tensor, queries: torch.Tensor, r, per_query: bool):
+    # exact per-pair differences (torch.cdist switches to a |q|^2+|d|^2-2qd expansion for large inputs, which
+    # is fuzzy right at dist == r); bound the [chunk, n, d] difference tensor to ~256 MB
+    step = max(1, min(queries.shape[0], (64 << 20) // max(1, data.shape[0] * data.shape[1])))
+    cols, counts = [], []
+    for s in range(0, queries.shape[0], step):
+        d = (queries[s:s + step, None, :] - data[None, :, :]).square().sum(-1).sqrt()
+        hit = d <= (r[s:s + step, None] if per_query else r)
+        cols.append(hit.nonzero()[:, 1])
+        counts.append(hit.sum(dim=1))
+    index = torch.cat(cols).long()
+    splits = torch.zeros(queries.shape[0] + 1, dtype=torch.long, device=queries.device)
+    torch.cumsum(torch.cat(counts), dim=0, out=splits[1:])
+    return {'neighbors_index': index, 'neighbors_row_splits': splits}
+
+
+def _hip_cell_list(data: torch.Tensor, queries: torch.Tensor, radius: float):
+    from .... import _lib as L
+    from ....ops import _p, _stream
+    lib = L.load()
+    data = data.contiguous().float()
+    queries = queries.contiguous().float()
+    n, dim = data.shape
+    m = queries.shape[0]
+    dev = data.device
+    lo = data.min(dim=0).values.cpu()
+    hi = data.max(dim=0).values.cpu()
+    extent = float((hi - lo).max())
+    # cell slightly larger than r: the +-1 cell reach then holds with margin against the rounding of (v - o) / cell
+    cell = max(float(radius) * 1.001, extent / 2048.0, 1e-30)
+    while True:
+        dims = [int((float(hi[k]) - float(lo[k])) / cell) + 1 for k in range(dim)]
+        ncell = 1
+        for v in dims:
+            ncell *= v
+        if ncell <= (1 << 23):
+            break
+        cell *= 1.5
+    origin = (C.c_float * dim)(*[float(lo[k]) for k in range(dim)])
+    cdims = (C.c_int32 * dim)(*dims)
+    cell_start = torch.empty(ncell + 1, dtype=torch.int32, device=dev)
+    cell_points = torch.empty(n, dtype=torch.int32, device=dev)
+    scratch = torch.empty(n + ncell + 1, dtype=torch.int32, device=dev)
+    L.check(lib.gaot_cells_build(_p(data), n, dim, origin, cell, cdims, _p(cell_start), _p(cell_points), _p(scratch), _stream()),
+            "gaot_cells_build")
+    deg = torch.empty(m, dtype=torch.int32, device=dev)
+    splits = torch.empty(m + 1, dtype=torch.long, device=dev)
+    L.check(lib.gaot_radius_count(_p(queries), m, _p(data), dim, float(radius), origin, cell, cdims, _p(cell_start),
+                                  _p(cell_points), _p(deg), _p(splits), _stream()), "gaot_radius_count")
+    E = int(splits[-1].item())
+    index = torch.empty(E, dtype=torch.long, device=dev)
+    if E > 0:
+        L.check(lib.gaot_radius_fill(_p(queries), m, _p(data), dim, float(radius), origin, cell, cdims, _p(cell_start),
+                                     _p(cell_points), _p(splits), _p(index), _stream()), "gaot_radius_fill")
+    return {'neighbors_index': index, 'neighbors_row_splits': splits}
 
 
 class NeighborSearch(nn.Module):
@@ -22,20 +82,10 @@ class NeighborSearch(nn.Module):
 
     @torch.no_grad()
     def forward(self, data: torch.Tensor, queries: torch.Tensor, radius):
-        r = radius if isinstance(radius, torch.Tensor) else torch.tensor(radius, device=queries.device, dtype=queries.dtype)
         per_query = isinstance(radius, torch.Tensor) and radius.dim() == 1
         if per_query and radius.numel() != queries.shape[0]:
             raise ValueError("If radius is a tensor, it must be one-dimensional and match the number of queries.")
-        # exact per-pair differences (torch.cdist switches to a |q|^2+|d|^2-2qd expansion for large inputs, which
-        # is fuzzy right at dist == r); bound the [chunk, n, d] difference tensor to ~256 MB
-        step = max(1, min(queries.shape[0], (64 << 20) // max(1, data.shape[0] * data.shape[1])))
-        cols, counts = [], []
-        for s in range(0, queries.shape[0], step):
-            d = (queries[s:s + step, None, :] - data[None, :, :]).square().sum(-1).sqrt()
-            hit = d <= (r[s:s + step, None] if per_query else r)
-            cols.append(hit.nonzero()[:, 1])
-            counts.append(hit.sum(dim=1))
-        index = torch.cat(cols).long()
-        splits = torch.zeros(queries.shape[0] + 1, dtype=torch.long, device=queries.device)
-        torch.cumsum(torch.cat(counts), dim=0, out=splits[1:])
-        return {'neighbors_index': index, 'neighbors_row_splits': splits}
+        if data.is_cuda and not per_query and data.shape[1] in (2, 3) and data.shape[0] > 0 and queries.shape[0] > 0:
+            return _hip_cell_list(data, queries, float(radius))
+        r = radius if isinstance(radius, torch.Tensor) else torch.tensor(radius, device=queries.device, dtype=queries.dtype)
+        return _exact_pairwise(data, queries, r, per_query)

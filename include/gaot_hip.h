@@ -110,6 +110,21 @@ int gaot_geo_stats(const float* geom, const float* qry, int32_t dim,
                    const int32_t* index32, const int32_t* splits32, int32_t Q,
                    float* stats, double* scratch, gaot_stream_t stream);
 
+/* radius graph by cell list (replaces NeighborSearch backends, neighbor_search.py:65-335; `dist <= r` inclusive,
+ * unbounded degree, ascending data index per query like `_native_neighbor_search`).  origin[dim] / dims[dim] are HOST
+ * arrays describing a uniform grid with cell size `cell` >= radius that covers the data points.
+ *   1. gaot_cells_build : cell_start[ncell+1], cell_points[n]           (scratch: n + ncell + 1 int32)
+ *   2. gaot_radius_count: deg[m], splits[m+1] (int64; caller reads splits[m] = E to size the index array)
+ *   3. gaot_radius_fill : index[E] (int64) */
+int gaot_cells_build(const float* data, int32_t n, int32_t dim, const float* origin, float cell, const int32_t* dims,
+                     int32_t* cell_start, int32_t* cell_points, int32_t* scratch, gaot_stream_t stream);
+int gaot_radius_count(const float* queries, int32_t m, const float* data, int32_t dim, float radius,
+                      const float* origin, float cell, const int32_t* dims, const int32_t* cell_start,
+                      const int32_t* cell_points, int32_t* deg, int64_t* splits, gaot_stream_t stream);
+int gaot_radius_fill(const float* queries, int32_t m, const float* data, int32_t dim, float radius,
+                     const float* origin, float cell, const int32_t* dims, const int32_t* cell_start,
+                     const int32_t* cell_points, const int64_t* splits, int64_t* index, gaot_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * GNO integral transform = gather / per-edge weight / CSR segment reduce (agno.py:198,245-271).
  *   out[b,r,:] = sum_{t in [splits[r],splits[r+1])} escale[edge(t)] * w[edge(t),:] * src[b, col(t), :]

@@ -338,3 +338,27 @@ def test_weight_grad_with_fused_bias_grad(N, K, M):
     assert rel(dw, gy.double().t() @ x.double()) < 3e-6
     # column sums of N(0,1) data nearly cancel: measure the error against the summed magnitudes
     assert float((db.double().cpu() - gy.double().sum(0)).abs().max() / gy.double().abs().sum(0).max()) < 1e-6
+
+
+@pytest.mark.parametrize("d,n,m,r", [(2, 16384, 4096, 0.033), (2, 3000, 5000, 0.05), (3, 20000, 4096, 0.12), (3, 500, 64, 0.9),
+                                     (2, 50, 200, 1e-4)])
+def test_hip_radius_search_equals_exact_search(d, n, m, r):
+    from gaot_amd.model.layers.utils.neighbor_search import NeighborSearch, _exact_pairwise
+    g = torch.Generator().manual_seed(n + m)
+    data = (torch.rand(n, d, generator=g) * 2 - 1).to(dev())
+    q = (torch.rand(m, d, generator=g) * 2.6 - 1.3).to(dev())          # some queries outside the data's bounding box
+    q[:5] = data[:5]                                                       # coincident points (distance exactly 0)
+    got = NeighborSearch("auto")(data, q, r)
+    ref = _exact_pairwise(data, q, torch.tensor(r, device=dev()), False)
+    assert torch.equal(got["neighbors_row_splits"], ref["neighbors_row_splits"])
+    assert torch.equal(got["neighbors_index"], ref["neighbors_index"])
+
+
+def test_hip_radius_search_inclusive_boundary():
+    from gaot_amd.model.layers.utils.neighbor_search import NeighborSearch
+    lattice = torch.stack(torch.meshgrid(torch.arange(5.), torch.arange(5.), indexing="ij"), -1).reshape(-1, 2).to(dev())
+    qs = torch.tensor([[2., 2.], [0., 0.], [4., 1.], [10., 10.], [2.5, 2.5]], device=dev())
+    out = NeighborSearch("native")(lattice, qs, 1.0)
+    deg = (out["neighbors_row_splits"][1:] - out["neighbors_row_splits"][:-1]).tolist()
+    assert deg == [5, 3, 4, 0, 4]                  # axis neighbours at distance exactly r are included
+    assert out["neighbors_index"][:5].tolist() == [7, 11, 12, 13, 17]
