@@ -71,6 +71,7 @@ class _MAGNOBase(nn.Module):
         self.nb_search = NeighborSearch(method=config.neighbor_search_method)
         self.neighbor_cache = {}
         self._coord_enc_cache = {}
+        self._infer_cache = {}       # no_grad only: geoembed row-bias per (plan, parameter versions) -- rollouts reuse it
         self.sampling_strategy = config.sampling_strategy
         self.max_neighbors = config.max_neighbors
         self.sample_ratio = config.sample_ratio
@@ -134,11 +135,23 @@ class _MAGNOBase(nn.Module):
         nb = apply_edge_drop_csr(neighbors, self.sampling_strategy, self.max_neighbors, self.sample_ratio, self.training)
         out = self.agno(y=self._kcoord(src_coord), x=self._kcoord(dst_coord), f_y=feats, neighbors=nb)
         if self.use_geoembed:
-            ge = self.geoembed(input_geom=src_coord, latent_queries=dst_coord, spatial_nbrs=nb,
-                               stats=stats if nb is neighbors else None)                          # [n_dst, C]
             w = self.recovery.fcs[0].weight.squeeze(-1)                                             # [C, 2C]
             C = out.shape[-1]
-            rowb = ops.linear(ge, w[:, C:], self.recovery.fcs[0].bias)                              # [n_dst, C]
+            rowb = None
+            key = None
+            if not torch.is_grad_enabled() and nb is neighbors:
+                # inference (autoregressive rollouts): geometry and weights are fixed across steps -> keep the row bias
+                key = (id(nb), tuple(p._version for p in self.geoembed.parameters()), self.recovery.fcs[0].weight._version,
+                       self.recovery.fcs[0].bias._version)
+                hit = self._infer_cache.get("rowb")
+                if hit is not None and hit[0] == key and hit[1] is nb:
+                    rowb = hit[2]
+            if rowb is None:
+                ge = self.geoembed(input_geom=src_coord, latent_queries=dst_coord, spatial_nbrs=nb,
+                                   stats=stats if nb is neighbors else None)                      # [n_dst, C]
+                rowb = ops.linear(ge, w[:, C:], self.recovery.fcs[0].bias)                          # [n_dst, C]
+                if key is not None:
+                    self._infer_cache["rowb"] = (key, nb, rowb)
             out = ops.linear(out, w[:, :C], rowbias=rowb)
         return out
 
