@@ -212,64 +212,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_kernel(const GemmArgs p) {
             }
         }
     }
-    // ---- vector epilogue: each wave transposes its 32-row fragment band through a private LDS slab (C-layout puts a
-    // COLUMN in a lane; stores want 4 consecutive columns per lane) and then does bias / row bias / row scale /
-    // activation / residual / store on 16-byte vectors: 4x fewer store instructions, 128-256 B contiguous per row.
     if (p.vec_epi) {
         __syncthreads();                                   // all waves are done with As / Bs
-        constexpr int LDC_S = WN + 4;
-        constexpr int LPR = WN / 4;                        // lanes per output row
-        constexpr int RPP = 64 / LPR;                      // rows per pass
-        float* Cw = smem + wave * 32 * LDC_S;
-        const int lr = lane / LPR, lc = (lane % LPR) * 4;
-        const int n = n0 + wn * WN + lc;
-        const bool nok = n < p.N;                          // N % 4 == 0: the whole vector is in or out
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias && nok && p.split_k <= 1) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
-        const bool has_auxin = (p.act == GAOT_ACT_GELU_BWD || p.act == GAOT_ACT_RELU_BWD);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) Cw[crow(r, lh) * LDC_S + j * 32 + li] = acc[i][j][r];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll 2
-            for (int ps = 0; ps < 32 / RPP; ++ps) {
-                const int row = ps * RPP + lr;
-                const int m = m0 + wm * WM + i * 32 + row;
-                if (nok && m < p.M) {
-                    f32x4 v = *reinterpret_cast<const f32x4*>(Cw + row * LDC_S + lc);
-                    if (p.split_k > 1) {
-                        *reinterpret_cast<f32x4*>(p.ws + ((long)blockIdx.z * p.M + m) * p.N + n) = v;
-                    } else {
-                        v += bv;
-                        if (p.rowbias) v += *reinterpret_cast<const f32x4*>(p.rowbias + (long)(m % p.rb_period) * p.ld_rb + n);
-                        if (p.rowscale) v *= p.rowscale[m];
-                        if (p.aux_out) *reinterpret_cast<f32x4*>(p.aux_out + (long)m * p.ld_aux + n) = v;
-                        if (p.act == GAOT_ACT_GELU) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) v[q] = gelu_f(v[q]);
-                        } else if (p.act == GAOT_ACT_RELU) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
-                        } else if (has_auxin) {
-                            const f32x4 ax = *reinterpret_cast<const f32x4*>(p.aux_in + (long)m * p.ld_aux + n);
-#pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                v[q] = (p.act == GAOT_ACT_GELU_BWD) ? v[q] * gelu_grad_f(ax[q]) : (ax[q] > 0.f ? v[q] : 0.f);
-                        }
-                        if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (long)m * p.ldr + n);
-                        *reinterpret_cast<f32x4*>(p.C + (long)m * p.ldc + n) = v;
-                    }
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
+        epilogue_vec<TM, TN, WM, WN>(p, smem, acc, m0, n0, wm, wn, wave, lane);
         return;
     }
     // scalar fallback epilogue (odd N / unaligned operands): C-layout rows crow(r, lh), column li
@@ -380,6 +325,8 @@ using namespace gaot;
 
 static thread_local int g_last_path = 0;   // 1 = MFMA tile kernel, 2 = skinny VALU path (for the bench's roofline accounting)
 extern "C" int gaot_debug_last_gemm_path(void) { return g_last_path; }
+static int g_use_glds = 1;   // eligible products run on the LDS-direct kernels (gemm_glds.hip); 0 = register-staged only
+extern "C" int gaot_debug_set_gemm_glds(int on) { const int old = g_use_glds; g_use_glds = on; return old; }
 static int g_ablate = 0;
 extern "C" int gaot_debug_set_gemm_ablate(int bits) { const int old = g_ablate; g_ablate = bits; return old; }
 static int g_tile_override = 0;   // tuning hook: 0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 128x32
@@ -435,7 +382,18 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
     const long z = a.split_k;
     auto blocks = [&](int bm, int bn) { return (long)cdiv(a.M, bm) * cdiv(a.N, bn) * z; };
     (void)z;
-    if (g_tile_override == 1)           launch_cfg<128, 128, 2>(a, ak, bk, vec, st);
+    const bool glds_ok = g_use_glds && vec && a.vec_epi && a.K % 32 == 0 && a.colsum == nullptr && a.M >= 4 && a.N >= 4;
+    if (glds_ok && g_tile_override >= 0 && g_tile_override <= 3) {
+        int tile = g_tile_override;
+        if (tile == 0) {      // from the on-box sweep (tools/gemm_glds_test.py)
+            if (!ak && !bk) tile = blocks(128, 128) >= 256 ? 1 : (blocks(128, 64) >= 256 && a.M >= 128 ? 2 : 3);
+            else if (blocks(128, 128) >= 1024) tile = 1;
+            else if (blocks(64, 64) <= 1536) tile = 3;
+            else tile = 2;
+        }
+        launch_glds(a, ak, bk, tile, st);
+    }
+    else if (g_tile_override == 1)      launch_cfg<128, 128, 2>(a, ak, bk, vec, st);
     else if (g_tile_override == 2)      launch_cfg<128, 64, 2>(a, ak, bk, vec, st);
     else if (g_tile_override == 3)      launch_cfg<64, 64, 2>(a, ak, bk, vec, st);
     else if (g_tile_override == 4)      launch_cfg<128, 32, 4>(a, ak, bk, vec, st);

@@ -64,7 +64,76 @@ __device__ __forceinline__ void epilogue_store_row(const GemmArgs& p, const RowC
     p.C[(long)m * p.ldc + n] = v;
 }
 
+
+// ---- vector epilogue shared by the GEMM kernels: each wave transposes its 32-row fragment band through a private LDS
+// slab (the MFMA C-layout puts a COLUMN in a lane; stores want 4 consecutive columns per lane) and then does bias / row
+// bias / row scale / activation / residual / store on 16-byte vectors: 4x fewer store instructions, 128-256 B per row.
+// The caller must have synchronised the workgroup (smem is reused) and smem must hold NW * 32 * (WN + 4) floats.
+template <int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void epilogue_vec(const GemmArgs& p, float* smem, const f32x16 (&acc)[TM][TN], int m0, int n0,
+                                         int wm, int wn, int wave, int lane) {
+    const int li = lane & 31, lh = lane >> 5;
+    // ---- vector epilogue: each wave transposes its 32-row fragment band through a private LDS slab (C-layout puts a
+    // COLUMN in a lane; stores want 4 consecutive columns per lane) and then does bias / row bias / row scale /
+    // activation / residual / store on 16-byte vectors: 4x fewer store instructions, 128-256 B contiguous per row.
+    constexpr int LDC_S = WN + 4;
+    constexpr int LPR = WN / 4;                        // lanes per output row
+    constexpr int RPP = 64 / LPR;                      // rows per pass
+    float* Cw = smem + wave * 32 * LDC_S;
+    const int lr = lane / LPR, lc = (lane % LPR) * 4;
+    const int n = n0 + wn * WN + lc;
+    const bool nok = n < p.N;                          // N % 4 == 0: the whole vector is in or out
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && nok && p.split_k <= 1) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+    const bool has_auxin = (p.act == GAOT_ACT_GELU_BWD || p.act == GAOT_ACT_RELU_BWD);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Cw[crow(r, lh) * LDC_S + j * 32 + li] = acc[i][j][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 2
+        for (int ps = 0; ps < 32 / RPP; ++ps) {
+            const int row = ps * RPP + lr;
+            const int m = m0 + wm * WM + i * 32 + row;
+            if (nok && m < p.M) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(Cw + row * LDC_S + lc);
+                if (p.split_k > 1) {
+                    *reinterpret_cast<f32x4*>(p.ws + ((long)blockIdx.z * p.M + m) * p.N + n) = v;
+                } else {
+                    v += bv;
+                    if (p.rowbias) v += *reinterpret_cast<const f32x4*>(p.rowbias + (long)(m % p.rb_period) * p.ld_rb + n);
+                    if (p.rowscale) v *= p.rowscale[m];
+                    if (p.aux_out) *reinterpret_cast<f32x4*>(p.aux_out + (long)m * p.ld_aux + n) = v;
+                    if (p.act == GAOT_ACT_GELU) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = gelu_f(v[q]);
+                    } else if (p.act == GAOT_ACT_RELU) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+                    } else if (has_auxin) {
+                        const f32x4 ax = *reinterpret_cast<const f32x4*>(p.aux_in + (long)m * p.ld_aux + n);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            v[q] = (p.act == GAOT_ACT_GELU_BWD) ? v[q] * gelu_grad_f(ax[q]) : (ax[q] > 0.f ? v[q] : 0.f);
+                    }
+                    if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (long)m * p.ldr + n);
+                    *reinterpret_cast<f32x4*>(p.C + (long)m * p.ldc + n) = v;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 // skinny VALU paths (skinny.hip); return true if they handled the product
 bool launch_skinny(const GemmArgs& a, bool a_kmajor, bool b_kmajor, hipStream_t st);
+// LDS-direct (global_load_lds) tile kernels (gemm_glds.hip); tile: 1 = 128x128 (8 waves), 2 = 128x64, 3 = 64x64
+void launch_glds(GemmArgs& a, bool a_kmajor, bool b_kmajor, int tile, hipStream_t st);
 
 }  // namespace gaot

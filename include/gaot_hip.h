@@ -77,6 +77,8 @@ int gaot_debug_set_gemm_tile(int cfg);
 int gaot_debug_set_gemm_ablate(int bits);
 /* which kernel family served the calling thread's last gaot_gemm_f32: 1 = MFMA tiles, 2 = skinny VALU path */
 int gaot_debug_last_gemm_path(void);
+/* tuning hook: 1 = route eligible products (16-byte aligned, K % 32 == 0) to the LDS-direct tile kernels */
+int gaot_debug_set_gemm_glds(int on);
 
 /* ------------------------------------------------------------------------------------------
  * Geometry plan pieces (once per mesh geometry; torch_scatter / repeat_interleave call sites
