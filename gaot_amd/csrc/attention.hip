@@ -207,6 +207,30 @@ __global__ void attn_delta_kernel(const AttnArgs p) {
     p.delta[((long)b * p.H + h) * p.S + s] = acc;
 }
 
+// 16-byte variant: LPR lanes per (b,s,h) row, shuffle-reduced (coalesced 16 B per lane)
+__global__ void attn_delta_vec_kernel(const AttnArgs p, int lpr) {
+    const long total = (long)p.B * p.S * p.H;
+    const long gid = ((long)blockIdx.x * blockDim.x + threadIdx.x) / lpr;
+    const int sub = threadIdx.x % lpr;
+    float acc = 0.f;
+    if (gid < total) {
+        const int h = (int)(gid % p.H);
+        const long bs = gid / p.H;
+        const float* o = p.oin + bs * p.ldo + (long)h * p.D;
+        const float* g = p.dout + bs * p.ldo + (long)h * p.D;
+        for (int d = sub * 4; d < p.D; d += lpr * 4) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(o + d), b = *reinterpret_cast<const f32x4*>(g + d);
+            acc += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+        }
+    }
+    for (int off = lpr >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (gid < total && sub == 0) {
+        const int h = (int)(gid % p.H);
+        const long bs = gid / p.H;
+        p.delta[((long)(bs / p.S) * p.H + h) * p.S + (bs % p.S)] = acc;
+    }
+}
+
 // dq[b,s,h,:] = scale * sum_kb part[kb][b,h,s,:]
 __global__ void attn_dq_reduce_kernel(const AttnArgs p, int DP) {
     const long total = (long)p.B * p.H * p.S * DP;
@@ -477,7 +501,12 @@ extern "C" int gaot_attention_bwd(const float* q, const float* k, const float* v
     a.dq_part = workspace + (int64_t)B * H * S;
     a.n_kblocks = cdiv(S, 128);
     const int DP = head_dim <= 32 ? 32 : 64;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv((long)B * S * H, 256)), dim3(256), 0, ST(stream), a);
+    if (a.vec && aligned16(o)) {
+        const int lpr = 8;
+        hipLaunchKernelGGL(attn_delta_vec_kernel, dim3(cdiv((long)B * S * H * lpr, 256)), dim3(256), 0, ST(stream), a, lpr);
+    } else {
+        hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv((long)B * S * H, 256)), dim3(256), 0, ST(stream), a);
+    }
     dim3 grid(a.n_kblocks * B * H), block(256);
     if (DP == 32) {
         hipLaunchKernelGGL(attn_bwd_kernel<32>, grid, block, bwd_lds_bytes<32>(), ST(stream), a);

@@ -70,6 +70,79 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
         dwp[(long)blockIdx.x * D + d] = red[0][d] + red[1][d] + red[2][d] + red[3][d];
 }
 
+// 16-byte variants for D = 256 * NV: a lane owns float4 columns lane*4 + 256*v; one pass over x / dy.
+template <int NV>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ w, int M,
+                                                              float eps, float* __restrict__ y, float* __restrict__ rstd) {
+    constexpr int D = 256 * NV;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    f32x4 xv[NV];
+    float ss = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        xv[v] = *reinterpret_cast<const f32x4*>(x + (long)row * D + v * 256 + lane * 4);
+        ss += xv[v][0] * xv[v][0] + xv[v][1] * xv[v][1] + xv[v][2] * xv[v][2] + xv[v][3] * xv[v][3];
+    }
+    ss = wave_sum(ss);
+    const float r = rsqrtf(ss / (float)D + eps);
+    if (lane == 0) rstd[row] = r;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + v * 256 + lane * 4);
+        *reinterpret_cast<f32x4*>(y + (long)row * D + v * 256 + lane * 4) = xv[v] * r * wv;
+    }
+}
+template <int NV>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ rstd, const float* __restrict__ dy,
+                                                              const float* __restrict__ dx_add, int M,
+                                                              float* __restrict__ dx, float* __restrict__ dwp) {
+    constexpr int D = 256 * NV;
+    __shared__ f32x4 red[4][NV][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    f32x4 wv[NV], dwacc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        wv[v] = *reinterpret_cast<const f32x4*>(w + v * 256 + lane * 4);
+        dwacc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int row_base = blockIdx.x * RMS_ROWS_PER_BLOCK;
+    for (int rr = wave; rr < RMS_ROWS_PER_BLOCK; rr += 4) {
+        const int row = row_base + rr;
+        if (row >= M) break;
+        f32x4 xv[NV], gv[NV];
+        float dot = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            xv[v] = *reinterpret_cast<const f32x4*>(x + (long)row * D + v * 256 + lane * 4);
+            gv[v] = *reinterpret_cast<const f32x4*>(dy + (long)row * D + v * 256 + lane * 4);
+            const f32x4 t = wv[v] * gv[v] * xv[v];
+            dot += t[0] + t[1] + t[2] + t[3];
+        }
+        dot = wave_sum(dot);
+        const float r = rstd[row];
+        const float coef = r * r * r * dot / (float)D;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            f32x4 o = wv[v] * gv[v] * r - xv[v] * coef;
+            if (dx_add) o += *reinterpret_cast<const f32x4*>(dx_add + (long)row * D + v * 256 + lane * 4);
+            *reinterpret_cast<f32x4*>(dx + (long)row * D + v * 256 + lane * 4) = o;
+            dwacc[v] += gv[v] * xv[v] * r;
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) red[wave][v][lane] = dwacc[v];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            *reinterpret_cast<f32x4*>(dwp + (long)blockIdx.x * D + v * 256 + lane * 4) =
+                red[0][v][lane] + red[1][v][lane] + red[2][v][lane] + red[3][v][lane];
+    }
+}
+
 // ---------------------------------------------------------------- SwiGLU gate (attn.py:151)
 __global__ void swiglu_fwd_kernel(const float* __restrict__ u, long M, int F, float* __restrict__ g) {
     const long total4 = M * F / 4;
@@ -200,6 +273,40 @@ __global__ void patchify_kernel(const float* __restrict__ in, float* __restrict_
     }
 }
 
+// 16-byte patchify: one thread per 4 channels of a grid node (C % 4 == 0); a node's C channels stay contiguous on both sides
+__global__ void patchify_vec_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int Dz, int P,
+                                    int C, int inverse) {
+    const int dim = Dz > 0 ? 3 : 2;
+    const int D1 = Dz > 0 ? Dz : 1;
+    const int C4 = C / 4;
+    const long nodes = (long)H * W * D1;
+    const long total = (long)B * nodes * C4;
+    const int pw = W / P, pd = D1 > 1 ? D1 / P : 1;
+    const int pvol = dim == 3 ? P * P * P : P * P;
+    for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(gid % C4) * 4;
+        const long node = (gid / C4) % nodes;
+        const long b = gid / (C4 * nodes);
+        int h, w_, z = 0;
+        if (dim == 3) { z = (int)(node % D1); w_ = (int)((node / D1) % W); h = (int)(node / ((long)D1 * W)); }
+        else { w_ = (int)(node % W); h = (int)(node / W); }
+        const int ph = h / P, i = h % P, pwi = w_ / P, j = w_ % P;
+        long s, k;
+        if (dim == 3) {
+            const int pz = z / P, l = z % P;
+            s = ((long)ph * pw + pwi) * pd + pz;
+            k = (((long)i * P + j) * P + l) * C + c;
+        } else {
+            s = (long)ph * pw + pwi;
+            k = ((long)i * P + j) * C + c;
+        }
+        const long tok = (b * (nodes / pvol) + s) * ((long)pvol * C) + k;
+        const long g = (b * nodes + node) * C + c;
+        if (inverse) *reinterpret_cast<f32x4*>(out + g) = *reinterpret_cast<const f32x4*>(in + tok);
+        else *reinterpret_cast<f32x4*>(out + tok) = *reinterpret_cast<const f32x4*>(in + g);
+    }
+}
+
 }  // namespace gaot
 
 using namespace gaot;
@@ -209,7 +316,10 @@ static inline int cap_blocks(long n, int per, int cap) { long b = (n + per - 1) 
 extern "C" int gaot_rmsnorm_fwd(const float* x, const float* w, int32_t M, int32_t D, float eps, float* y, float* rstd,
                                 gaot_stream_t stream) {
     GAOT_REQUIRE(x && w && y && rstd && M > 0 && D > 0, "rmsnorm_fwd: bad arguments");
-    hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, ST(stream), x, w, M, D, eps, y, rstd);
+    const bool v16 = aligned16(x) && aligned16(w) && aligned16(y);
+    if (v16 && D == 256)      hipLaunchKernelGGL(rmsnorm_fwd_vec_kernel<1>, dim3(cdiv(M, 4)), dim3(256), 0, ST(stream), x, w, M, eps, y, rstd);
+    else if (v16 && D == 512) hipLaunchKernelGGL(rmsnorm_fwd_vec_kernel<2>, dim3(cdiv(M, 4)), dim3(256), 0, ST(stream), x, w, M, eps, y, rstd);
+    else hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, ST(stream), x, w, M, D, eps, y, rstd);
     GAOT_CHECK_LAUNCH("gaot_rmsnorm_fwd");
     return GAOT_OK;
 }
@@ -220,8 +330,11 @@ extern "C" int gaot_rmsnorm_bwd(const float* x, const float* w, const float* rst
                                 int32_t M, int32_t D, float* dx, float* dw_partial, gaot_stream_t stream) {
     GAOT_REQUIRE(x && w && rstd && dy && dx && dw_partial && M > 0 && D > 0, "rmsnorm_bwd: bad arguments");
     GAOT_REQUIRE(D <= RMS_MAX_D, "rmsnorm_bwd: D=%d exceeds %d", D, RMS_MAX_D);
-    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(cdiv(M, RMS_ROWS_PER_BLOCK)), dim3(256), 0, ST(stream), x, w, rstd, dy,
-                       dx_add, M, D, dx, dw_partial);
+    const bool v16 = aligned16(x) && aligned16(w) && aligned16(dy) && aligned16(dx) && aligned16(dw_partial) && (!dx_add || aligned16(dx_add));
+    const dim3 grid(cdiv(M, RMS_ROWS_PER_BLOCK));
+    if (v16 && D == 256)      hipLaunchKernelGGL(rmsnorm_bwd_vec_kernel<1>, grid, dim3(256), 0, ST(stream), x, w, rstd, dy, dx_add, M, dx, dw_partial);
+    else if (v16 && D == 512) hipLaunchKernelGGL(rmsnorm_bwd_vec_kernel<2>, grid, dim3(256), 0, ST(stream), x, w, rstd, dy, dx_add, M, dx, dw_partial);
+    else hipLaunchKernelGGL(rmsnorm_bwd_kernel, grid, dim3(256), 0, ST(stream), x, w, rstd, dy, dx_add, M, D, dx, dw_partial);
     GAOT_CHECK_LAUNCH("gaot_rmsnorm_bwd");
     return GAOT_OK;
 }
@@ -265,7 +378,10 @@ extern "C" int gaot_patchify(const float* in, int32_t B, int32_t H, int32_t W, i
     GAOT_REQUIRE(in && out && B > 0 && H > 0 && W > 0 && Dz >= 0 && P > 0 && C > 0, "patchify: bad arguments");
     GAOT_REQUIRE(H % P == 0 && W % P == 0 && (Dz == 0 || Dz % P == 0), "patchify: grid %dx%dx%d not divisible by patch %d", H, W, Dz, P);
     const long total = (long)B * H * W * (Dz > 0 ? Dz : 1) * C;
-    hipLaunchKernelGGL(patchify_kernel, dim3(cap_blocks(total, 256, 8192)), dim3(256), 0, ST(stream), in, out, B, H, W, Dz, P, C, inverse);
+    if (C % 4 == 0 && aligned16(in) && aligned16(out))
+        hipLaunchKernelGGL(patchify_vec_kernel, dim3(cap_blocks(total / 4, 256, 8192)), dim3(256), 0, ST(stream), in, out, B, H, W, Dz, P, C, inverse);
+    else
+        hipLaunchKernelGGL(patchify_kernel, dim3(cap_blocks(total, 256, 8192)), dim3(256), 0, ST(stream), in, out, B, H, W, Dz, P, C, inverse);
     GAOT_CHECK_LAUNCH("gaot_patchify");
     return GAOT_OK;
 }
