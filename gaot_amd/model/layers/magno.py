@@ -130,8 +130,12 @@ class _MAGNOBase(nn.Module):
             self._coord_enc_cache[key] = hit
         return hit[1]
 
-    def _transform(self, src_coord, dst_coord, feats, neighbors, stats=None):
-        """AGNO (+ geoembed + recovery) for ONE geometry at ONE scale.  feats [B, n_src, C] -> [B, n_dst, C]."""
+    def _transform(self, src_coord, dst_coord, feats, neighbors, stats=None, head=None):
+        """AGNO (+ geoembed + recovery) for ONE geometry at ONE scale.  feats [B, n_src, C] -> [B, n_dst, C].
+        `head` = (W [out, C], b [out]) of a following point-wise linear layer (the decoder's projection): recovery and
+        head are both linear with nothing in between, so they are applied as ONE map
+            agno @ (W Wr1)^T + (rowb @ W^T + b)
+        and the [B, n_dst, C] recovery output (33.5 MB at 16k nodes x 8) is never produced."""
         nb = apply_edge_drop_csr(neighbors, self.sampling_strategy, self.max_neighbors, self.sample_ratio, self.training)
         out = self.agno(y=self._kcoord(src_coord), x=self._kcoord(dst_coord), f_y=feats, neighbors=nb)
         if self.use_geoembed:
@@ -152,7 +156,14 @@ class _MAGNOBase(nn.Module):
                 rowb = ops.linear(ge, w[:, C:], self.recovery.fcs[0].bias)                          # [n_dst, C]
                 if key is not None:
                     self._infer_cache["rowb"] = (key, nb, rowb)
+            if head is not None:
+                hw, hb = head
+                w_eff = ops.linear(hw, w[:, :C].t())                 # [out, C] = W @ Wr1   (tiny)
+                rowb_h = ops.linear(rowb, hw, hb)                    # [n_dst, out]
+                return ops.linear(out, w_eff, rowbias=rowb_h)
             out = ops.linear(out, w[:, :C], rowbias=rowb)
+        elif head is not None:
+            return ops.linear(out, head[0], head[1])
         return out
 
     def _scale_mix_weights(self, coords: torch.Tensor) -> torch.Tensor:
@@ -171,11 +182,11 @@ class _MAGNOBase(nn.Module):
             return acc
         return torch.stack(per_scale, dim=0).mean(dim=0)
 
-    def _all_scales(self, mode, src, dst, feats, nbrs):
+    def _all_scales(self, mode, src, dst, feats, nbrs, head=None):
         per_scale = []
         for si in range(len(self.scales)):
             if mode == 'fx':
-                per_scale.append(self._transform(src, dst, feats, nbrs[si]))
+                per_scale.append(self._transform(src, dst, feats, nbrs[si], head=head))
             else:
                 # vx: block-diagonal union of the B per-sample graphs -> one launch per kernel for the whole batch
                 B = feats.shape[0]
@@ -186,7 +197,8 @@ class _MAGNOBase(nn.Module):
                 if any(n != n_dst for n in mg.n_dst_each) or any(n != feats.shape[1] for n in mg.n_src_each):
                     raise ValueError("vx mode needs the same number of source / query points in every sample of a batch")
                 stats = mg.geo_stats() if (self.use_geoembed and self.geoembed.method == 'statistical') else None
-                out = self._transform(mg.src, mg.dst, feats.reshape(1, B * feats.shape[1], feats.shape[2]), mg.neighbors, stats)
+                out = self._transform(mg.src, mg.dst, feats.reshape(1, B * feats.shape[1], feats.shape[2]), mg.neighbors, stats,
+                                      head=head)
                 per_scale.append(out.reshape(B, n_dst, out.shape[-1]))
         return per_scale
 
@@ -272,5 +284,9 @@ class MAGNODecoder(_MAGNOBase):
         w = None
         if self.use_scale_weights:        # vx: the FIRST sample's coordinates (reference magno.py:610-612)
             w = self._scale_mix_weights(self._kcoord(query_coord if mode == 'fx' else query_coord[0]))
+        if len(self.scales) == 1 and self.projection.n_layers == 1:
+            # single scale: fold the output projection into the recovery map (see _transform)
+            pw = self.projection.fcs[0].weight.squeeze(-1)
+            return self._all_scales(mode, latent_tokens_coord, query_coord, rndata, nbrs, head=(pw, self.projection.fcs[0].bias))[0]
         dec = self._combine(self._all_scales(mode, latent_tokens_coord, query_coord, rndata, nbrs), w)
         return self.projection.forward_channels_last(dec)
