@@ -190,6 +190,149 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// forward, LDS-direct variant for head_dim == 32 with 16-byte aligned q/k/v: K and V tiles (64 keys) go HBM/L2 -> LDS
+// with global_load_lds through a 3-stage ring (one raw s_barrier per tile, counted vmcnt); K is stored [key][32] with
+// its 16-byte chunks XOR-swizzled by ((key >> 1) & 7) (source-side swizzle, conflict-free ds_read_b128 A operand),
+// V is stored as it comes (row-contiguous ds_read_b32).  The online softmax runs once per 64 keys.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_fwd_glds_kernel(const AttnArgs p) {
+    constexpr int KT = 64, NS = 3;
+    constexpr int ST = 2 * KT * 32;                    // floats per stage (K + V)
+    __shared__ __attribute__((aligned(16))) float smem[NS * ST];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    int bh, blk;
+    xcd_group_decode(blockIdx.x, p.B * p.H, (p.S + 127) / 128, bh, blk);
+    const int b = bh / p.H, h = bh % p.H, hk = h / (p.H / p.Hkv);
+    const int q0 = blk * 128 + wave * 32;
+    const float c = p.scale * LOG2E;
+
+    float qreg[16];
+    {
+        const int qi = q0 + li;
+        const float* qrow = p.q + ((long)b * p.S + qi) * p.ldq + (long)h * 32;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = load4(qrow, 8 * g + 4 * lh, 32, qi < p.S, true);
+            qreg[4 * g + 0] = v[0]; qreg[4 * g + 1] = v[1]; qreg[4 * g + 2] = v[2]; qreg[4 * g + 3] = v[3];
+        }
+    }
+    // this wave's DMA pieces: chunks t = (q*4 + wave)*64 + lane, q = 0,1 for K and for V; row = t >> 3, chunk = t & 7
+    const float* kbase = p.k + (long)b * p.S * p.ldk + (long)hk * 32;
+    const float* vbase = p.v + (long)b * p.S * p.ldv + (long)hk * 32;
+    int prow[2], kch[2], vch[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int t = (q * 4 + wave) * 64 + lane;
+        prow[q] = t >> 3;
+        vch[q] = t & 7;
+        kch[q] = (t & 7) ^ ((prow[q] >> 1) & 7);
+    }
+    auto issue = [&](int kt, int stage) {
+        float* Ks = smem + stage * ST;
+        float* Vs = Ks + KT * 32;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int row = min(kt * KT + prow[q], p.S - 1);       // clamp: padded keys are masked to -inf below
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + (long)row * p.ldk + kch[q] * 4),
+                                             (__attribute__((address_space(3))) void*)(Ks + (q * 4 + wave) * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + (long)row * p.ldv + vch[q] * 4),
+                                             (__attribute__((address_space(3))) void*)(Vs + (q * 4 + wave) * 256), 16, 0, 0);
+        }
+    };
+
+    f32x16 oacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const int ntiles = (p.S + KT - 1) / KT;
+    const int ksw = (li >> 1) & 7;                    // swizzle of this lane's key row (li and li+32 share it)
+    issue(0, 0);
+    if (ntiles > 1) issue(1, 1);
+    int stage = 0;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        if (kt + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 2 < ntiles) issue(kt + 2, stage >= 1 ? stage - 1 : 2);
+        const float* Ks = smem + stage * ST;
+        const float* Vs = Ks + KT * 32;
+        // ---- S^T for 64 keys: two 32-key fragments
+        f32x16 s0, s1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ch = ((2 * g + lh) ^ ksw) << 2;
+            const f32x4 k0 = *reinterpret_cast<const f32x4*>(Ks + li * 32 + ch);
+            const f32x4 k1 = *reinterpret_cast<const f32x4*>(Ks + (32 + li) * 32 + ch);      // (32+li)>>1 &7 == ksw
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(k0[t], qreg[4 * g + t], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(k1[t], qreg[4 * g + t], s1, 0, 0, 0);
+            }
+        }
+        // ---- online softmax over the 64 keys.  VALU budget matters here (PMC: 10 VALU per MFMA kept the matrix pipe at
+        // 57 %): padded keys are masked only on the last tile, exp is the raw v_exp_f32 on fma(s, c, -m*c), and the
+        // O rescale is skipped (exactly) whenever no lane's running max moved.
+        const int kv0 = kt * KT;
+        if (__builtin_amdgcn_readfirstlane(kv0 + KT > p.S)) {      // scalar branch; the asm keeps it from being if-converted
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (kv0 + crow(r, lh) >= p.S) s0[r] = -INFINITY;
+                if (kv0 + 32 + crow(r, lh) >= p.S) s1[r] = -INFINITY;
+            }
+        }
+        float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float mc = -m_new * c;
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c, mc));
+            s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], c, mc));
+            ps += s0[r] + s1[r];
+        }
+        ps += __shfl_xor(ps, 32, 64);
+        if (__any(m_new != m_run)) {                   // wave-uniform branch; alpha == 1 exactly when the max is unchanged
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            l_run *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+            m_run = m_new;
+        }
+        l_run += ps;
+        // ---- O^T += V^T P^T
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = crow(r, lh);
+            oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[row * 32 + li], s0[r], oacc, 0, 0, 0);
+            oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[(32 + row) * 32 + li], s1[r], oacc, 0, 0, 0);
+        }
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+    __syncthreads();
+    const float inv_l = 1.0f / l_run;
+    float* Os = smem + wave * 32 * 33;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Os[li * 33 + crow(r, lh)] = oacc[r] * inv_l;
+    __syncthreads();
+    for (int rr = lh; rr < 32; rr += 2) {
+        const int qi = q0 + rr;
+        if (qi >= p.S) break;
+        p.o[((long)b * p.S + qi) * p.ldo + (long)h * 32 + li] = Os[rr * 33 + li];
+    }
+    if (lh == 0 && q0 + li < p.S)
+        p.lse[((long)b * p.H + h) * p.S + q0 + li] = m_run * p.scale + logf(l_run);
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward helpers
 // ---------------------------------------------------------------------------------------------
 // delta[b,h,s] = sum_d dO * O       (one thread per (b,s,h); rows are short)
@@ -369,7 +512,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qr = crow(r, lh);
-            float pv = exp2f(s[r] * c - lse_s[qr]);
+            float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c, -lse_s[qr]));
             if (!kv_ok) pv = 0.f;
             s[r] = pv;
             dp[r] = pv * (dp[r] - del_s[qr]);
@@ -473,7 +616,8 @@ extern "C" int gaot_attention_fwd(const float* q, const float* k, const float* v
     fill_common(a, q, k, v, ldq, ldk, ldv, B, S, H, Hkv, head_dim);
     a.o = o; a.ldo = ldo; a.lse = lse;
     dim3 grid(cdiv(S, 128) * B * H), block(256);
-    if (head_dim <= 32) hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, block, 0, ST(stream), a);
+    if (head_dim == 32 && a.vec) hipLaunchKernelGGL(attn_fwd_glds_kernel, grid, block, 0, ST(stream), a);
+    else if (head_dim <= 32) hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, block, 0, ST(stream), a);
     else                hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, block, 0, ST(stream), a);
     GAOT_CHECK_LAUNCH("gaot_attention_fwd");
     return GAOT_OK;
