@@ -326,7 +326,9 @@ using namespace gaot;
 static thread_local int g_last_path = 0;   // 1 = MFMA tile kernel, 2 = skinny VALU path (for the bench's roofline accounting)
 extern "C" int gaot_debug_last_gemm_path(void) { return g_last_path; }
 static int g_use_glds = 1;   // eligible products run on the LDS-direct kernels (gemm_glds.hip); 0 = register-staged only
-extern "C" int gaot_debug_set_gemm_glds(int on) { const int old = g_use_glds; g_use_glds = on; return old; }
+namespace gaot { void set_glds_stages(int n); }
+// on: 0 = register-staged kernels only, 1 = LDS-direct with the default 2-stage ring, 3 = LDS-direct with a 3-stage ring
+extern "C" int gaot_debug_set_gemm_glds(int on) { const int old = g_use_glds; g_use_glds = on != 0; gaot::set_glds_stages(on == 3 ? 3 : 2); return old; }
 static int g_ablate = 0;
 extern "C" int gaot_debug_set_gemm_ablate(int bits) { const int old = g_ablate; g_ablate = bits; return old; }
 static int g_tile_override = 0;   // tuning hook: 0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 128x32
@@ -385,11 +387,11 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
     const bool glds_ok = g_use_glds && vec && a.vec_epi && a.K % 32 == 0 && a.colsum == nullptr && a.M >= 4 && a.N >= 4;
     if (glds_ok && g_tile_override >= 0 && g_tile_override <= 3) {
         int tile = g_tile_override;
-        if (tile == 0) {      // from the on-box sweep (tools/gemm_glds_test.py)
+        if (tile == 0) {      // from the on-box sweep (tools/gemm_glds_test.py, 2-stage ring)
             if (!ak && !bk) tile = blocks(128, 128) >= 256 ? 1 : (blocks(128, 64) >= 256 && a.M >= 128 ? 2 : 3);
-            else if (blocks(128, 128) >= 1024) tile = 1;
-            else if (blocks(64, 64) <= 1536) tile = 3;
-            else tile = 2;
+            else if (blocks(128, 128) >= 512) tile = 1;
+            else if (blocks(128, 64) >= 512) tile = 2;
+            else tile = 3;
         }
         launch_glds(a, ak, bk, tile, st);
     }

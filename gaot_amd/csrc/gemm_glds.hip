@@ -1,6 +1,6 @@
 // fp32 MFMA GEMM, LDS-direct variant: operand tiles go HBM/L2 -> LDS with `global_load_lds_dwordx4` (no VGPR round
-// trip, no ds_write pass), through a 3-stage LDS ring so a tile has two compute phases to land, with ONE raw
-// s_barrier per k-tile and counted s_waitcnt vmcnt (never 0 in steady state).
+// trip, no ds_write pass), through a 2- (default) or 3-stage LDS ring, with ONE raw s_barrier per k-tile and explicit
+// s_waitcnt vmcnt (counted, never 0 in steady state, for the 3-stage ring).
 //
 // The LDS-DMA destination is lane-linear (wave-uniform base + lane*16 B), so no row padding is possible:
 //   * a k-contiguous operand tile is stored [row][32 floats] with the 16-byte chunks of a row XOR-swizzled by
@@ -16,9 +16,8 @@ namespace gaot {
 
 constexpr int GBK = 32;
 
-template <int BM, int BN, int WAVES_M, bool AK, bool BKM, int NW>
+template <int BM, int BN, int WAVES_M, bool AK, bool BKM, int NW, int NS>
 __global__ __launch_bounds__(64 * NW) void gemm_glds_kernel(const GemmArgs p) {
-    constexpr int NS = 3;                                  // LDS ring depth
     constexpr int WAVES_N = NW / WAVES_M;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -115,15 +114,16 @@ __global__ __launch_bounds__(64 * NW) void gemm_glds_kernel(const GemmArgs p) {
     for (int j = 0; j < TN; ++j) { b_row[j] = wn * WN + j * 32 + li; b_sw[j] = (b_row[j] >> 1) & 7; }
 
     if (kt_begin < kt_end) issue(kt_begin, 0);
-    if (kt_begin + 1 < kt_end) issue(kt_begin + 1, 1);
+    if (NS == 3 && kt_begin + 1 < kt_end) issue(kt_begin + 1, 1);
     int stage = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-        // tile kt must have landed (this wave's pieces): at most the LA+LB pieces of tile kt+1 may still be in flight
-        if (kt + 1 < kt_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LA + LB) : "memory");
-        else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();      // everyone's pieces landed; everyone is done reading stage (kt+2)%3 = (kt-1)%3
+        // tile kt must have landed (this wave's pieces); with a 3-deep ring the pieces of tile kt+1 may still be in flight
+        if (NS == 3 && kt + 1 < kt_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LA + LB) : "memory");
+        else                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();      // everyone's pieces landed; everyone is done reading the stage refilled next
         asm volatile("" ::: "memory");
-        if (kt + 2 < kt_end) issue(kt + 2, stage >= 1 ? stage - 1 : 2);      // (stage + 2) % 3
+        if (NS == 3) { if (kt + 2 < kt_end) issue(kt + 2, stage >= 1 ? stage - 1 : 2); }      // (stage + 2) % 3
+        else         { if (kt + 1 < kt_end) issue(kt + 1, stage ^ 1); }
         const float* As = smem + stage * STAGE;
         const float* Bs = As + A_ST;
 #pragma unroll
@@ -157,22 +157,31 @@ __global__ __launch_bounds__(64 * NW) void gemm_glds_kernel(const GemmArgs p) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
         }
-        stage = stage == 2 ? 0 : stage + 1;
+        stage = (NS == 3) ? (stage == 2 ? 0 : stage + 1) : (stage ^ 1);
     }
     __syncthreads();
     epilogue_vec<TM, TN, WM, WN>(p, smem, acc, m0, n0, wm, wn, wave, lane);
+}
+
+static int g_glds_stages = 2;     // 2-stage ring: half the LDS -> twice the resident workgroups; measured ahead of 3 stages
+void set_glds_stages(int n) { g_glds_stages = n; }
+
+template <int BM, int BN, int WAVES_M, int NW, int NS>
+static void launch_glds_ns(GemmArgs& a, bool ak, bool bk, hipStream_t st) {
+    dim3 grid(a.tiles_m * a.tiles_n, 1, a.split_k > 1 ? a.split_k : 1);
+    dim3 block(64 * NW);
+    if (ak && bk)        hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WAVES_M, true, true, NW, NS>), grid, block, 0, st, a);
+    else if (ak && !bk)  hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WAVES_M, true, false, NW, NS>), grid, block, 0, st, a);
+    else if (!ak && !bk) hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WAVES_M, false, false, NW, NS>), grid, block, 0, st, a);
+    else                 hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WAVES_M, false, true, NW, NS>), grid, block, 0, st, a);
 }
 
 template <int BM, int BN, int WAVES_M, int NW>
 static void launch_glds_cfg(GemmArgs& a, bool ak, bool bk, hipStream_t st) {
     a.tiles_m = cdiv(a.M, BM);
     a.tiles_n = cdiv(a.N, BN);
-    dim3 grid(a.tiles_m * a.tiles_n, 1, a.split_k > 1 ? a.split_k : 1);
-    dim3 block(64 * NW);
-    if (ak && bk)        hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WAVES_M, true, true, NW>), grid, block, 0, st, a);
-    else if (ak && !bk)  hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WAVES_M, true, false, NW>), grid, block, 0, st, a);
-    else if (!ak && !bk) hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WAVES_M, false, false, NW>), grid, block, 0, st, a);
-    else                 hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WAVES_M, false, true, NW>), grid, block, 0, st, a);
+    if (g_glds_stages == 2) launch_glds_ns<BM, BN, WAVES_M, NW, 2>(a, ak, bk, st);
+    else                    launch_glds_ns<BM, BN, WAVES_M, NW, 3>(a, ak, bk, st);
 }
 
 // tile: 1 = 128x128 (8 waves), 2 = 128x64, 3 = 64x64

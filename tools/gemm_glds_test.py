@@ -37,8 +37,9 @@ for (kind, M, N, K) in [("nt", 4096, 4096, 4096), ("nt", 8192, 2048, 256), ("nt"
         A, B = torch.randn(K, M, device=dev), torch.randn(K, N, device=dev); sk = ops._split_for_reduction(M, N, K); f = lambda: ops.gemm(M, N, K, A, M, 0, B, N, 0, out, N, split_k=sk)
     row = []
     lib.gaot_debug_set_gemm_glds(0); us0 = timeit(f); row.append(f"reg {us0:7.1f}us {2.0*M*N*K/us0/1e6:6.1f}TF")
-    for tile in (0, 1, 2, 3):
-        lib.gaot_debug_set_gemm_glds(1); lib.gaot_debug_set_gemm_tile(tile); us = timeit(f)
-        row.append(f"glds t{tile} {us:7.1f}us {2.0*M*N*K/us/1e6:6.1f}TF")
-    lib.gaot_debug_set_gemm_glds(0); lib.gaot_debug_set_gemm_tile(0)
+    for st in (3, 1):
+      for tile in (0, 1, 2, 3):
+        lib.gaot_debug_set_gemm_glds(st); lib.gaot_debug_set_gemm_tile(tile); us = timeit(f)
+        row.append(f"ring{3 if st==3 else 2}t{tile} {us:6.1f}us {2.0*M*N*K/us/1e6:5.1f}")
+    lib.gaot_debug_set_gemm_glds(1); lib.gaot_debug_set_gemm_tile(0)
     print(f"{kind} M={M} N={N} K={K} | " + " | ".join(row), flush=True)
