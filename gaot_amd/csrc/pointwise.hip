@@ -273,6 +273,45 @@ __global__ void patchify_kernel(const float* __restrict__ in, float* __restrict_
     }
 }
 
+// ---------------------------------------------------------------- AdamW over flat buffers (torch.optim.AdamW semantics,
+// the optimizer at optimizers.py:196): decoupled weight decay, bias-corrected moments, eps added after the bias correction
+// of sqrt(v).  `step` lives on the device so the launch is hipGraph-replayable; a 1-thread kernel advances it first.
+__global__ void adamw_tick_kernel(float* step) { step[0] += 1.0f; }
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                                    float wd, const float* __restrict__ step) {
+    const float t = step[0];
+    const float bc1 = 1.0f - powf(b1, t);
+    const float bc2 = 1.0f - powf(b2, t);
+    const float step_size = lr / bc1;
+    const float inv_bc2_sqrt = 1.0f / sqrtf(bc2);
+    const long n4 = n / 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+        const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+        f32x4 mv = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            pv[q] *= 1.0f - lr * wd;
+            mv[q] = mv[q] + (gv[q] - mv[q]) * (1.0f - b1);          // lerp form, as torch's fused kernel
+            vv[q] = b2 * vv[q] + (1.0f - b2) * gv[q] * gv[q];
+            const float denom = sqrtf(vv[q]) * inv_bc2_sqrt + eps;
+            pv[q] -= step_size * (mv[q] / denom);
+        }
+        reinterpret_cast<f32x4*>(p)[i] = pv;
+        reinterpret_cast<f32x4*>(m)[i] = mv;
+        reinterpret_cast<f32x4*>(v)[i] = vv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {      // scalar tail
+        const long i = n4 * 4 + threadIdx.x;
+        float pv = p[i] * (1.0f - lr * wd);
+        const float mv = m[i] + (g[i] - m[i]) * (1.0f - b1);
+        const float vv = b2 * v[i] + (1.0f - b2) * g[i] * g[i];
+        pv -= step_size * (mv / (sqrtf(vv) * inv_bc2_sqrt + eps));
+        p[i] = pv; m[i] = mv; v[i] = vv;
+    }
+}
+
 // 16-byte patchify: one thread per 4 channels of a grid node (C % 4 == 0); a node's C channels stay contiguous on both sides
 __global__ void patchify_vec_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int Dz, int P,
                                     int C, int inverse) {
@@ -383,5 +422,16 @@ extern "C" int gaot_patchify(const float* in, int32_t B, int32_t H, int32_t W, i
     else
         hipLaunchKernelGGL(patchify_kernel, dim3(cap_blocks(total, 256, 8192)), dim3(256), 0, ST(stream), in, out, B, H, W, Dz, P, C, inverse);
     GAOT_CHECK_LAUNCH("gaot_patchify");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                               float eps, float weight_decay, float* step, gaot_stream_t stream) {
+    GAOT_REQUIRE(p && g && m && v && step && n > 0, "adamw_step: bad arguments");
+    GAOT_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), "adamw_step: flat buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(adamw_tick_kernel, dim3(1), dim3(1), 0, ST(stream), step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(cap_blocks(n / 4 + 1, 256, 2048)), dim3(256), 0, ST(stream), p, g, m, v, (long)n, lr, beta1,
+                       beta2, eps, weight_decay, step);
+    GAOT_CHECK_LAUNCH("gaot_adamw_step");
     return GAOT_OK;
 }

@@ -65,6 +65,35 @@ class FlatGradBucket:
             self.flat.div_(dist.get_world_size(group))
 
 
+class FlatAdamW:
+    """torch.optim.AdamW semantics (reference optimizers.py:196) as ONE HIP kernel over flat buffers.
+
+    The parameters are re-pointed at views of one flat fp32 buffer (values, names and state_dict are unchanged), the
+    gradients already live in the FlatGradBucket, the moments are flat: an update is a single streaming pass
+    (7 x 4 B per parameter) instead of torch's multi-tensor launches over ~60 tensors."""
+
+    def __init__(self, bucket: "FlatGradBucket", lr: float, weight_decay: float, betas=(0.9, 0.999), eps: float = 1e-8):
+        self.bucket = bucket
+        self.lr, self.wd, self.betas, self.eps = float(lr), float(weight_decay), betas, float(eps)
+        ps = bucket.params
+        with torch.no_grad():
+            self.flat_p = torch.cat([p.detach().reshape(-1) for p in ps]).contiguous()
+            off = 0
+            for p in ps:
+                p.data = self.flat_p[off:off + p.numel()].view_as(p)
+                off += p.numel()
+        self.m = torch.zeros_like(self.flat_p)
+        self.v = torch.zeros_like(self.flat_p)
+        self.step_count = torch.zeros(1, dtype=torch.float32, device=self.flat_p.device)
+
+    def step(self):
+        from . import _lib as L
+        from .ops import _p, _stream
+        L.check(L.load().gaot_adamw_step(_p(self.flat_p), _p(self.bucket.flat), _p(self.m), _p(self.v), self.flat_p.numel(),
+                                         self.lr, self.betas[0], self.betas[1], self.eps, self.wd, _p(self.step_count), _stream()),
+                "gaot_adamw_step")
+
+
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
@@ -89,10 +118,10 @@ class TrainStep:
         self.bucket = FlatGradBucket(list(model.parameters()))
         dev = self.bucket.flat.device
         on_gpu = dev.type == "cuda"
-        kw = dict(lr=lr, weight_decay=weight_decay)
         if on_gpu:
-            kw.update(capturable=True, fused=True)
-        self.opt = torch.optim.AdamW(self.bucket.params, **kw)
+            self.opt = FlatAdamW(self.bucket, lr=lr, weight_decay=weight_decay)
+        else:           # CPU (gloo tests of the data-parallel plumbing): torch's own AdamW
+            self.opt = torch.optim.AdamW(self.bucket.params, lr=lr, weight_decay=weight_decay)
         self.use_graph = use_graph and on_gpu
         self._g_fb: Optional[torch.cuda.CUDAGraph] = None
         self._g_opt: Optional[torch.cuda.CUDAGraph] = None
@@ -116,6 +145,8 @@ class TrainStep:
         self._g_fb = self._g_opt = None
 
     def _capture(self):
+        # warm-up iterations must not advance training: snapshot weights + optimizer state, restore after capture
+        snap = [t.clone() for t in (self.opt.flat_p, self.opt.m, self.opt.v, self.opt.step_count)]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):          # warm-up: builds GeometryPlans (they sync once), fills the allocator
@@ -132,6 +163,8 @@ class TrainStep:
         self._g_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g_opt, capture_error_mode="thread_local"):
             self.opt.step()
+        for dst, src in zip((self.opt.flat_p, self.opt.m, self.opt.v, self.opt.step_count), snap):
+            dst.copy_(src)
 
     def step(self, pndata: Optional[torch.Tensor] = None, target: Optional[torch.Tensor] = None) -> torch.Tensor:
         if pndata is not None:

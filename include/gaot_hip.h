@@ -185,6 +185,11 @@ int64_t gaot_colsum_scratch(int32_t M, int32_t N);
 int gaot_colsum(const float* x, int64_t ld, int32_t M, int32_t N, float* out, float* scratch, gaot_stream_t stream);
 /* out[r,:] = sum_b x[b,r,:]   (row-periodic bias gradients; x is [B,R,N] contiguous) */
 int gaot_batchsum(const float* x, int32_t B, int64_t RN, float* out, gaot_stream_t stream);
+/* One AdamW update over flat fp32 buffers with torch.optim.AdamW semantics (the reference's optimizer, optimizers.py:196;
+ * defaults beta = (0.9, 0.999), eps = 1e-8).  step[1] is a DEVICE counter (float) advanced by the call itself, so the launch
+ * replays inside a hipGraph. */
+int gaot_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, float* step, gaot_stream_t stream);
 /* patchify gaot.py:182-185,202-205 and its inverse gaot.py:224-231.  Latent grid H x W (x Dz; Dz = 0 for 2-D).
  * inverse = 0: in = grid[b, (h,w[,z]), c]  -> out = tokens[b, s, (p..., c)];  inverse = 1: the other way. */
 int gaot_patchify(const float* in, int32_t B, int32_t H, int32_t W, int32_t Dz, int32_t P, int32_t C,
