@@ -384,7 +384,7 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
     const long z = a.split_k;
     auto blocks = [&](int bm, int bn) { return (long)cdiv(a.M, bm) * cdiv(a.N, bn) * z; };
     (void)z;
-    const bool glds_ok = g_use_glds && vec && a.vec_epi && a.K % 32 == 0 && a.colsum == nullptr && a.M >= 4 && a.N >= 4;
+    const bool glds_ok = g_use_glds && vec && a.vec_epi && a.K % 32 == 0 && a.M >= 4 && a.N >= 4;
     if (glds_ok && g_tile_override >= 0 && g_tile_override <= 3) {
         int tile = g_tile_override;
         if (tile == 0) {      // from the on-box sweep (tools/gemm_glds_test.py, 2-stage ring)

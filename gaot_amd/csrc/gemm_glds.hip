@@ -113,6 +113,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_glds_kernel(const GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) { b_row[j] = wn * WN + j * 32 + li; b_sw[j] = (b_row[j] >> 1) & 7; }
 
+    // fused column sum of an m-major A operand (bias gradient when A = dY): thread t < BM owns column t of the staged tile
+    const bool do_colsum = !AK && p.colsum != nullptr && (logical % p.tiles_n) == 0;
+    float csum = 0.f;
+
     if (kt_begin < kt_end) issue(kt_begin, 0);
     if (NS == 3 && kt_begin + 1 < kt_end) issue(kt_begin + 1, 1);
     int stage = 0;
@@ -126,6 +130,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_glds_kernel(const GemmArgs p) {
         else         { if (kt + 1 < kt_end) issue(kt + 1, stage ^ 1); }
         const float* As = smem + stage * STAGE;
         const float* Bs = As + A_ST;
+        if (!AK && do_colsum && tid < BM) {
+#pragma unroll
+            for (int kk = 0; kk < GBK; ++kk) csum += As[kk * BM + tid];      // consecutive lanes -> consecutive banks
+        }
 #pragma unroll
         for (int g = 0; g < GBK / 8; ++g) {
             float a[TM][4], b[TN][4];
@@ -158,6 +166,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_glds_kernel(const GemmArgs p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
         }
         stage = (NS == 3) ? (stage == 2 ? 0 : stage + 1) : (stage ^ 1);
+    }
+    if (!AK && do_colsum && tid < BM && m0 + tid < p.M) {
+        if (p.split_k > 1) p.ws[(long)p.split_k * p.M * p.N + (long)blockIdx.z * p.M + m0 + tid] = csum;
+        else p.colsum[m0 + tid] = csum;
     }
     __syncthreads();
     epilogue_vec<TM, TN, WM, WN>(p, smem, acc, m0, n0, wm, wn, wave, lane);
