@@ -5,7 +5,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgaot_hip.so")
 
-ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD, ACT_RELU_BWD = 0, 1, 2, 3, 4
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD, ACT_RELU_BWD, ACT_SWIGLU_BWD, ACT_SWIGLU = 0, 1, 2, 3, 4, 5, 6
 
 _f = C.c_void_p   # device float*
 _i = C.c_void_p   # device int*

@@ -338,9 +338,20 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
     GAOT_REQUIRE(d != nullptr, "gemm: null descriptor");
     GAOT_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm: M,N,K must be positive (got %d,%d,%d)", d->M, d->N, d->K);
     GAOT_REQUIRE(d->A && d->B && d->C, "gemm: A, B, C must be non-null");
-    GAOT_REQUIRE(d->act >= GAOT_ACT_NONE && d->act <= GAOT_ACT_RELU_BWD, "gemm: bad act %d", d->act);
-    if (d->act == GAOT_ACT_GELU_BWD || d->act == GAOT_ACT_RELU_BWD)
+    GAOT_REQUIRE(d->act >= GAOT_ACT_NONE && d->act <= GAOT_ACT_SWIGLU, "gemm: bad act %d", d->act);
+    if (d->act == GAOT_ACT_GELU_BWD || d->act == GAOT_ACT_RELU_BWD || d->act == GAOT_ACT_SWIGLU_BWD)
         GAOT_REQUIRE(d->aux_in != nullptr, "gemm: *_BWD activation needs aux_in");
+    if (d->act == GAOT_ACT_SWIGLU_BWD)
+        GAOT_REQUIRE(!d->residual && !d->aux_out && d->ldc >= 2 * (int64_t)d->N && d->ld_aux >= 2 * (int64_t)d->N,
+                     "gemm: SWIGLU_BWD writes [M,2N] (ldc, ld_aux >= 2N) and takes no residual / aux_out");
+    if (d->act == GAOT_ACT_SWIGLU) {
+        const bool ok = d->b_kmajor && d->K % 32 == 0 && d->N % 8 == 0 && !d->bias && !d->rowbias && !d->rowscale &&
+                        !d->residual && !d->colsum && d->split_k <= 1 && d->A2 == nullptr && aligned16(d->A) && aligned16(d->B) &&
+                        aligned16(d->C) && d->lda % 4 == 0 && d->ldb % 4 == 0 && d->ldc % 4 == 0 &&
+                        (d->a_kmajor || d->M % 4 == 0) && (!d->aux_out || (aligned16(d->aux_out) && d->ld_aux % 4 == 0));
+        GAOT_REQUIRE(ok, "gemm: SWIGLU needs a k-major [2F,K] weight, K %% 32 == 0, F %% 4 == 0, 16-byte aligned operands and no "
+                         "bias / row bias / row scale / residual / colsum / split_k / A2");
+    }
     if (d->rowbias) GAOT_REQUIRE(d->rowbias_period > 0, "gemm: rowbias needs rowbias_period > 0");
     if (d->A2) GAOT_REQUIRE(d->k_split > 0 && d->k_split < d->K && d->k_split % BK == 0,
                             "gemm: A2 needs 0 < k_split < K and k_split %% %d == 0 (got %d)", BK, d->k_split);
@@ -374,6 +385,14 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
     if (d->A2) vec = vec && aligned16(d->A2) && (d->lda2 % 4 == 0) && ((d->K - d->k_split) % 4 == 0);
 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (a.act == GAOT_ACT_SWIGLU) {          // only the LDS-direct kernel stages the gate's band layout
+        g_last_path = 1;
+        const long nb128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
+        a.vec_epi = 1;
+        launch_glds(a, ak, bk, nb128 >= 512 ? 1 : ((long)cdiv(a.M, 128) * cdiv(a.N, 64) >= 512 ? 2 : 3), st);
+        GAOT_CHECK_LAUNCH("gaot_gemm_f32(swiglu)");
+        return GAOT_OK;
+    }
     if (g_tile_override == 0 && launch_skinny(a, ak, bk, st)) {
         g_last_path = 2;
         GAOT_CHECK_LAUNCH("gaot_gemm_f32(skinny)");

@@ -19,6 +19,14 @@ struct GemmArgs {
     int ablate;             // tuning only (gaot_debug_set_gemm_ablate): 1 = no in-loop global loads, 2 = no LDS staging/barriers, 4 = no stores
 };
 
+// SwiGLU gate and its gradient (attn.py:151): g = silu(u1) * u3
+__device__ __forceinline__ float swiglu_f(float u1, float u3) { return (u1 / (1.0f + expf(-u1))) * u3; }
+__device__ __forceinline__ void swiglu_grad_f(float dg, float u1, float u3, float& d1, float& d3) {
+    const float sg = 1.0f / (1.0f + expf(-u1));
+    d1 = dg * u3 * sg * (1.0f + u1 * (1.0f - sg));
+    d3 = dg * u1 * sg;
+}
+
 __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, float v) {
     if (p.bias) v += p.bias[n];
     if (p.rowbias) v += p.rowbias[(long)(m % p.rb_period) * p.ld_rb + n];
@@ -29,6 +37,14 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int m, int n, 
         case GAOT_ACT_RELU: v = fmaxf(v, 0.0f); break;
         case GAOT_ACT_GELU_BWD: v *= gelu_grad_f(p.aux_in[(long)m * p.ld_aux + n]); break;
         case GAOT_ACT_RELU_BWD: v = (p.aux_in[(long)m * p.ld_aux + n] > 0.0f) ? v : 0.0f; break;
+        case GAOT_ACT_SWIGLU_BWD: {
+            const float u1 = p.aux_in[(long)m * p.ld_aux + n], u3 = p.aux_in[(long)m * p.ld_aux + p.N + n];
+            float d1, d3;
+            swiglu_grad_f(v, u1, u3, d1, d3);
+            p.C[(long)m * p.ldc + p.N + n] = d3;
+            v = d1;
+            break;
+        }
         default: break;
     }
     if (p.residual) v += p.residual[(long)m * p.ldr + n];
@@ -58,6 +74,14 @@ __device__ __forceinline__ void epilogue_store_row(const GemmArgs& p, const RowC
         case GAOT_ACT_RELU: v = fmaxf(v, 0.0f); break;
         case GAOT_ACT_GELU_BWD: v *= gelu_grad_f(p.aux_in[(long)m * p.ld_aux + n]); break;
         case GAOT_ACT_RELU_BWD: v = (p.aux_in[(long)m * p.ld_aux + n] > 0.0f) ? v : 0.0f; break;
+        case GAOT_ACT_SWIGLU_BWD: {
+            const float u1 = p.aux_in[(long)m * p.ld_aux + n], u3 = p.aux_in[(long)m * p.ld_aux + p.N + n];
+            float d1, d3;
+            swiglu_grad_f(v, u1, u3, d1, d3);
+            p.C[(long)m * p.ldc + p.N + n] = d3;
+            v = d1;
+            break;
+        }
         default: break;
     }
     if (p.residual) v += p.residual[(long)m * p.ldr + n];
@@ -119,10 +143,64 @@ __device__ __forceinline__ void epilogue_vec(const GemmArgs& p, float* smem, con
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
                             v[q] = (p.act == GAOT_ACT_GELU_BWD) ? v[q] * gelu_grad_f(ax[q]) : (ax[q] > 0.f ? v[q] : 0.f);
+                    } else if (p.act == GAOT_ACT_SWIGLU_BWD) {
+                        const f32x4 u1 = *reinterpret_cast<const f32x4*>(p.aux_in + (long)m * p.ld_aux + n);
+                        const f32x4 u3 = *reinterpret_cast<const f32x4*>(p.aux_in + (long)m * p.ld_aux + p.N + n);
+                        f32x4 d3;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { float d1, d3q; swiglu_grad_f(v[q], u1[q], u3[q], d1, d3q); v[q] = d1; d3[q] = d3q; }
+                        *reinterpret_cast<f32x4*>(p.C + (long)m * p.ldc + p.N + n) = d3;
                     }
                     if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (long)m * p.ldr + n);
                     *reinterpret_cast<f32x4*>(p.C + (long)m * p.ldc + n) = v;
                 }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// SwiGLU forward epilogue (GAOT_ACT_SWIGLU): the kernel staged the B rows so that every wave's WN-column band holds
+// u1 of WN/2 gate columns followed by u3 of the same columns; the gate is applied while the band sits in the wave's
+// LDS slab, so u is written once (for the backward pass) and never read back.
+template <int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void epilogue_swiglu(const GemmArgs& p, float* smem, const f32x16 (&acc)[TM][TN], int m0, int n0,
+                                            int wm, int wn, int wave, int lane) {
+    const int li = lane & 31, lh = lane >> 5;
+    constexpr int LDC_S = WN + 4;
+    constexpr int HW = WN / 2;                         // gate columns per band
+    constexpr int LPR = HW / 4, RPP = 64 / LPR;
+    float* Cw = smem + wave * 32 * LDC_S;
+    const int lr = lane / LPR, lc = (lane % LPR) * 4;
+    const int F = p.N >> 1;
+    const int gcol = (n0 >> 1) + wn * HW + lc;
+    const bool nok = gcol < F;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Cw[crow(r, lh) * LDC_S + j * 32 + li] = acc[i][j][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 2
+        for (int ps = 0; ps < 32 / RPP; ++ps) {
+            const int row = ps * RPP + lr;
+            const int m = m0 + wm * WM + i * 32 + row;
+            if (nok && m < p.M) {
+                const f32x4 u1 = *reinterpret_cast<const f32x4*>(Cw + row * LDC_S + lc);
+                const f32x4 u3 = *reinterpret_cast<const f32x4*>(Cw + row * LDC_S + HW + lc);
+                if (p.aux_out) {
+                    *reinterpret_cast<f32x4*>(p.aux_out + (long)m * p.ld_aux + gcol) = u1;
+                    *reinterpret_cast<f32x4*>(p.aux_out + (long)m * p.ld_aux + F + gcol) = u3;
+                }
+                f32x4 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = swiglu_f(u1[q], u3[q]);
+                *reinterpret_cast<f32x4*>(p.C + (long)m * p.ldc + gcol) = o;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

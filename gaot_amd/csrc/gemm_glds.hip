@@ -69,7 +69,13 @@ __global__ __launch_bounds__(64 * NW) void gemm_glds_kernel(const GemmArgs p) {
         const int t = (q * NW + wave) * 64 + lane;
         if (BKM) {
             const int row = t >> 3, pc = t & 7, lc = pc ^ ((row >> 1) & 7);
-            b_off[q] = (((long)min(n0 + row, p.N - 1)) << 8) | lc;
+            int nrow = min(n0 + row, p.N - 1);
+            if (p.act == GAOT_ACT_SWIGLU) {      // band layout [u1 cols | u3 cols] per wave band (epilogue_swiglu)
+                const int F = p.N >> 1, within = row % WN;
+                const int gcol = (n0 >> 1) + (row / WN) * (WN / 2) + within % (WN / 2);
+                nrow = (within / (WN / 2)) * F + min(gcol, F - 1);
+            }
+            b_off[q] = ((long)nrow << 8) | lc;
         } else {
             const int kk = t / (BN / 4), r4 = t % (BN / 4);
             b_off[q] = (((long)min(n0 + r4 * 4, p.N - 4)) << 8) | kk;
@@ -172,7 +178,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_glds_kernel(const GemmArgs p) {
         else p.colsum[m0 + tid] = csum;
     }
     __syncthreads();
-    epilogue_vec<TM, TN, WM, WN>(p, smem, acc, m0, n0, wm, wn, wave, lane);
+    if (BKM && p.act == GAOT_ACT_SWIGLU) epilogue_swiglu<TM, TN, WM, WN>(p, smem, acc, m0, n0, wm, wn, wave, lane);
+    else                                 epilogue_vec<TM, TN, WM, WN>(p, smem, acc, m0, n0, wm, wn, wave, lane);
 }
 
 static int g_glds_stages = 2;     // 2-stage ring: half the LDS -> twice the resident workgroups; measured ahead of 3 stages

@@ -99,7 +99,8 @@ class GroupQueryFlashAttention(nn.Module):
 
 
 class FFN(nn.Module):
-    """SwiGLU: w2(silu(w1 x) * w3 x)  (attn.py:150-156); w1|w3 run as one GEMM, the residual rides w2's epilogue."""
+    """SwiGLU: w2(silu(w1 x) * w3 x)  (attn.py:150-156); w1|w3 run as one GEMM with the gate as its epilogue, the residual
+    rides w2's epilogue, the gate's gradient rides the epilogue of dY w2 (ops._SwiGLUFFN)."""
 
     def __init__(self, input_size: int, ffn_hidden_size: int, use_conditional_norm: bool = False, cond_norm_hidden_size: int = 4):
         super().__init__()
@@ -109,11 +110,9 @@ class FFN(nn.Module):
         self.correction = ConditionedNorm(1, input_size, cond_norm_hidden_size) if use_conditional_norm else None
 
     def forward(self, x, condition=None, residual=None):
-        u = ops.linear(x, torch.cat([self.w1.weight, self.w3.weight], dim=0))
-        g = ops.swiglu(u)
         if self.correction is None:
-            return ops.linear(g, self.w2.weight, residual=residual)
-        y = self.correction(c=condition, x=ops.linear(g, self.w2.weight))
+            return ops.swiglu_ffn(x, self.w1.weight, self.w3.weight, self.w2.weight, residual=residual)
+        y = self.correction(c=condition, x=ops.swiglu_ffn(x, self.w1.weight, self.w3.weight, self.w2.weight))
         return y if residual is None else residual + y
 
 

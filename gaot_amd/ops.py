@@ -457,6 +457,63 @@ def swiglu(u):
     return _SwiGLU.apply(u)
 
 
+class _SwiGLUFFN(torch.autograd.Function):
+    """y = (silu(x w1^T) * (x w3^T)) w2^T (+ residual)   (attn.py:150-156) as three GEMMs forward / four backward:
+    the gate is the epilogue of the [w1;w3] product (u is written once for the backward pass and never re-read) and the
+    gate's gradient is the epilogue of dg = dy w2, so neither g's gradient nor a separate gate pass ever touches HBM."""
+
+    @staticmethod
+    def fusable(K: int, F: int) -> bool:
+        return K % 32 == 0 and F % 4 == 0
+
+    @staticmethod
+    def forward(ctx, x, w1, w3, w2, residual):
+        _dev(x, w1, w3, w2)
+        shp = x.shape
+        K = shp[-1]
+        xm, lda = _rowmajor(x.reshape(-1, K))
+        M, F, No = xm.shape[0], w1.shape[0], w2.shape[0]
+        w13 = torch.cat([w1, w3], dim=0)
+        u = torch.empty(M, 2 * F, device=x.device, dtype=torch.float32)
+        g = torch.empty(M, F, device=x.device, dtype=torch.float32)
+        gemm(M, 2 * F, K, xm, lda, 1, w13, K, 1, g, F, act=L.ACT_SWIGLU, aux_out=u, ld_aux=2 * F)
+        epi = {}
+        if residual is not None:
+            res2, ldr = _rowmajor(residual.reshape(M, No))
+            epi.update(residual=res2, ldr=ldr)
+        y = linear_nt(g, w2, **epi)
+        ctx.save_for_backward(xm, u, g, w13, w2)
+        ctx.meta = (shp, residual.shape if residual is not None else None)
+        return y.reshape(*shp[:-1], No)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xm, u, g, w13, w2 = ctx.saved_tensors
+        shp, res_shape = ctx.meta
+        M, F = g.shape
+        No, K = w2.shape[0], xm.shape[1]
+        d, ldd = _rowmajor(dy.reshape(M, No))
+        need = ctx.needs_input_grad
+        w2c, ldw2 = _rowmajor(w2)
+        du = torch.empty(M, 2 * F, device=d.device, dtype=torch.float32)
+        gemm(M, F, No, d, ldd, 1, w2c, ldw2, 0, du, 2 * F, act=L.ACT_SWIGLU_BWD, aux_in=u, ld_aux=2 * F)
+        dw2 = matmul_tn(d, g) if need[3] else None
+        dx = matmul_nn(du, w13).reshape(shp) if need[0] else None
+        dw1 = dw3 = None
+        if need[1] or need[2]:
+            dw13 = matmul_tn(du, xm)
+            dw1, dw3 = dw13[:F], dw13[F:]
+        dres = dy.reshape(res_shape) if (res_shape is not None and need[4]) else None
+        return dx, dw1, dw3, dw2, dres
+
+
+def swiglu_ffn(x, w1, w3, w2, residual=None):
+    """SwiGLU feed-forward; falls back to the unfused HIP kernels when the fused epilogues' shape rules do not hold."""
+    if _SwiGLUFFN.fusable(x.shape[-1], w1.shape[0]):
+        return _SwiGLUFFN.apply(x, w1, w3, w2, residual)
+    return linear(swiglu(linear(x, torch.cat([w1, w3], dim=0))), w2, residual=residual)
+
+
 class _Attention(torch.autograd.Function):
     """qkv [B,S,(H + 2 Hkv) * D] fused projection output -> softmax(q k^T / sqrt(D)) v  as [B,S,H*D]."""
 

@@ -34,7 +34,11 @@ enum gaot_act {
     GAOT_ACT_GELU = 1,      /* exact erf GELU, mlp.py:307-337 (F.gelu default)            */
     GAOT_ACT_RELU = 2,      /* gemb.py:54-59                                              */
     GAOT_ACT_GELU_BWD = 3,  /* out = acc * gelu'(aux)   (aux = saved pre-activation)      */
-    GAOT_ACT_RELU_BWD = 4   /* out = acc * (aux > 0)    (aux = saved post-activation)     */
+    GAOT_ACT_RELU_BWD = 4,  /* out = acc * (aux > 0)    (aux = saved post-activation)     */
+    /* SwiGLU gate of the transformer FFN (attn.py:150-156) fused into the two GEMMs either side of it:            */
+    GAOT_ACT_SWIGLU_BWD = 5,/* acc = dg [M,N]; aux_in = u = [u1|u3] [M,2N]; C [M,2N] = [dg*u3*silu'(u1) | dg*silu(u1)] */
+    GAOT_ACT_SWIGLU = 6     /* B = [w1;w3] (2F rows, N = 2F, k-major); C [M,F] = silu(u1)*u3; aux_out [M,2F] = u (optional).
+                               Needs K % 32 == 0, F % 4 == 0, no bias/rowbias/rowscale/residual/split_k.             */
 };
 
 int gaot_abi_version(void);

@@ -362,3 +362,33 @@ def test_hip_radius_search_inclusive_boundary():
     deg = (out["neighbors_row_splits"][1:] - out["neighbors_row_splits"][:-1]).tolist()
     assert deg == [5, 3, 4, 0, 4]                  # axis neighbours at distance exactly r are included
     assert out["neighbors_index"][:5].tolist() == [7, 11, 12, 13, 17]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,F", [(8192, 256, 1024), (300, 64, 132), (77, 32, 20), (1024, 96, 256)])
+def test_swiglu_ffn_fused_matches_unfused(M, K, F):
+    """gate fused into the [w1;w3] GEMM epilogue / gate gradient fused into the dY w2 epilogue (attn.py:150-156)
+    against the separate HIP kernels (same accumulators -> identical) and a float64 torch reference."""
+    from gaot_amd import ops
+    torch.manual_seed(M + K + F)
+    dev = "cuda"
+    x = torch.randn(M, K, device=dev, requires_grad=True)
+    w1 = (torch.randn(F, K, device=dev) / K ** 0.5).requires_grad_()
+    w3 = (torch.randn(F, K, device=dev) / K ** 0.5).requires_grad_()
+    w2 = (torch.randn(K, F, device=dev) / F ** 0.5).requires_grad_()
+    res = torch.randn(M, K, device=dev, requires_grad=True)
+    dy = torch.randn(M, K, device=dev)
+    assert ops._SwiGLUFFN.fusable(K, F)
+    y = ops.swiglu_ffn(x, w1, w3, w2, residual=res)
+    gf = torch.autograd.grad(y, [x, w1, w3, w2, res], dy)
+    y0 = ops.linear(ops.swiglu(ops.linear(x, torch.cat([w1, w3], 0))), w2, residual=res)
+    g0 = torch.autograd.grad(y0, [x, w1, w3, w2, res], dy)
+    assert torch.equal(y, y0)
+    for a, b in zip(gf, g0):
+        assert rel(a, b) < 2e-6
+    xd, w1d, w3d, w2d, rd = [t.detach().double().requires_grad_() for t in (x, w1, w3, w2, res)]
+    yd = (torch.nn.functional.silu(xd @ w1d.T) * (xd @ w3d.T)) @ w2d.T + rd
+    gd = torch.autograd.grad(yd, [xd, w1d, w3d, w2d, rd], dy.double())
+    assert rel(y, yd) < 1e-5
+    for a, b in zip(gf, gd):
+        assert rel(a, b) < 1e-5
