@@ -11,7 +11,8 @@ blocks, 8 heads; 3 396 033 parameters), synthetic data, random-init weights, inp
 Arithmetic is fp32 end to end (the reference has no reduced-precision path; parity tolerance 1e-5 is fp32).
 
 Extra objects on the JSON line:
-  roofline     dominant kernel family = the fp32-MFMA GEMM (gaot_gemm_f32): algorithmic FLOPs of its launches in
+  roofline     dominant kernel family = the MFMA GEMM tiles behind gaot_gemm_f32 (fp32 MFMA, and fp32-exact products
+               on the bf16 MFMA pipe from 3-way split operands): algorithmic FLOPs of its launches in
                one step / their summed duration, timed live with HIP events on the launch stream in an
                instrumented eager step; peak = 157.3 TFLOP/s (dense f32 matrix rate, MI355X_MICROARCH.md)
   cpu_baseline the CPU oracle (oracle/gaot_oracle.py, a parity-checked port of the reference path) timed on the
@@ -84,7 +85,8 @@ def gemm_roofline(ts):
     finally:
         ops.gemm = raw
         ts.use_graph = use_graph
-    mfma = [r for r in records if r[4] == 1]          # launches served by the MFMA tile kernel (the dominant kernel)
+    mfma = [r for r in records if r[4] in (1, 3)]     # launches served by the MFMA tile kernels (1 = fp32 MFMA, 3 = split-bf16 MFMA)
+    n_split = sum(1 for r in records if r[4] == 3)
     ms = sum(r[0].elapsed_time(r[1]) for r in mfma)
     flops = sum(r[2] for r in mfma)
     ms_all = sum(r[0].elapsed_time(r[1]) for r in records)
@@ -93,7 +95,7 @@ def gemm_roofline(ts):
         for us, fl, (M, N, K, ak, bk, sk) in rows:
             print(f"# gemm M={M:6d} N={N:5d} K={K:6d} a_k={ak} b_k={bk} split={sk:3d} {us:8.1f}us {fl / us / 1e6:6.1f}TF", file=sys.stderr)
     return {"launches": len(mfma), "flops": flops, "ms": ms, "tflops": flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
-            "skinny_launches": len(records) - len(mfma), "all_gemm_ms": ms_all}
+            "skinny_launches": len(records) - len(mfma), "all_gemm_ms": ms_all, "split_launches": n_split}
 
 
 def recorded_traffic():
@@ -208,7 +210,10 @@ def main():
                        "params": n_params, "global_batch": BATCH * world, "parallelism": f"dp{world}",
                        "step": "fwd + MSE + bwd + AdamW" + (" + flat-grad RCCL all-reduce" if world > 1 else ""),
                        "hipgraph": ts.use_graph, "final_loss": loss},
-            "roofline": {"bound": "mfma", "kernel": "gaot::gemm_kernel (v_mfma_f32_32x32x2_f32): every launch of one step",
+            "roofline": {"bound": "mfma", "kernel": "gaot_gemm_f32 MFMA tile kernels, every launch of one step: gemm_glds_kernel (v_mfma_f32_32x32x2_f32) and "
+                                   "gemm_split_kernel (fp32 operands split exactly into 3 bf16 pieces, 6 x v_mfma_f32_32x32x16_bf16 per product)",
+                         "peak_note": "peak = dense f32 matrix rate; the split-bf16 kernel's own ceiling is bf16 dense / 6 = 419 TFLOP/s of f32 work",
+                         "split_bf16_launches_per_step": roof["split_launches"],
                          "achieved": roof["tflops"], "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": roof["tflops"] / PEAK_F32_MATRIX_TFLOPS, "traffic": recorded_traffic(),
                          "traffic_note": "HBM bytes per launch, PMC FETCH_SIZE(x2, gfx950)+WRITE_SIZE from profiles/r1_gemm_traffic.json; "

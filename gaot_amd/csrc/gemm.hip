@@ -327,8 +327,16 @@ static thread_local int g_last_path = 0;   // 1 = MFMA tile kernel, 2 = skinny V
 extern "C" int gaot_debug_last_gemm_path(void) { return g_last_path; }
 static int g_use_glds = 1;   // eligible products run on the LDS-direct kernels (gemm_glds.hip); 0 = register-staged only
 namespace gaot { void set_glds_stages(int n); }
-// on: 0 = register-staged kernels only, 1 = LDS-direct with the default 2-stage ring, 3 = LDS-direct with a 3-stage ring
-extern "C" int gaot_debug_set_gemm_glds(int on) { const int old = g_use_glds; g_use_glds = on != 0; gaot::set_glds_stages(on == 3 ? 3 : 2); return old; }
+// on: 0 = register-staged kernels only, 1 = LDS-direct with the default 2-stage ring, 3 = LDS-direct with a 3-stage ring,
+// 4 = + split-bf16 tiles by heuristic, 5 = split-bf16 wherever eligible.  Default 1: on the GAOT step the split tiles are
+// 1.2-1.4x faster per launch but every OTHER kernel of the step then runs ~3 % slower (same-box A/B), net zero.
+static int g_use_split = 0;  // 1: eligible products run on the split-bf16 kernel (gemm_split.hip) per the heuristic; 2: always when eligible
+extern "C" int gaot_debug_set_gemm_glds(int on) {
+    const int old = g_use_split ? 3 + g_use_split : g_use_glds;
+    g_use_glds = on != 0; g_use_split = on == 4 ? 1 : (on == 5 ? 2 : 0);
+    gaot::set_glds_stages(on == 3 ? 3 : 2);
+    return old;
+}
 static int g_ablate = 0;
 extern "C" int gaot_debug_set_gemm_ablate(int bits) { const int old = g_ablate; g_ablate = bits; return old; }
 static int g_tile_override = 0;   // tuning hook: 0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 128x32
@@ -385,11 +393,11 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
     if (d->A2) vec = vec && aligned16(d->A2) && (d->lda2 % 4 == 0) && ((d->K - d->k_split) % 4 == 0);
 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (a.act == GAOT_ACT_SWIGLU) {          // only the LDS-direct kernel stages the gate's band layout
-        g_last_path = 1;
+    if (a.act == GAOT_ACT_SWIGLU) {          // only the LDS-staged kernels lay the gate's bands out
         const long nb128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
         a.vec_epi = 1;
-        launch_glds(a, ak, bk, nb128 >= 512 ? 1 : ((long)cdiv(a.M, 128) * cdiv(a.N, 64) >= 512 ? 2 : 3), st);
+        if (g_use_split == 2 || (g_use_split && nb128 >= 256)) { g_last_path = 3; launch_split(a, ak, bk, st); }
+        else { g_last_path = 1; launch_glds(a, ak, bk, nb128 >= 512 ? 1 : ((long)cdiv(a.M, 128) * cdiv(a.N, 64) >= 512 ? 2 : 3), st); }
         GAOT_CHECK_LAUNCH("gaot_gemm_f32(swiglu)");
         return GAOT_OK;
     }
@@ -404,7 +412,15 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
     auto blocks = [&](int bm, int bn) { return (long)cdiv(a.M, bm) * cdiv(a.N, bn) * z; };
     (void)z;
     const bool glds_ok = g_use_glds && vec && a.vec_epi && a.K % 32 == 0 && a.M >= 4 && a.N >= 4;
-    if (glds_ok && g_tile_override >= 0 && g_tile_override <= 3) {
+    const bool split_ok = g_use_split && glds_ok && a.A2 == nullptr && g_tile_override == 0;
+    // measured (tools/gemm_split_test.py): the 128x128 split-bf16 tiles win once they fill the chip (>= 256 workgroups
+    // counting split-K slabs) on outputs at least one tile wide; narrower / smaller products stay on the fp32 MFMA tiles
+    if (split_ok && (g_use_split == 2 || (blocks(128, 128) >= 250 && a.M >= 128 && a.N >= 128 &&
+                                          (long)cdiv(a.M, 128) * cdiv(a.N, 128) >= 8))) {
+        g_last_path = 3;
+        launch_split(a, ak, bk, st);
+    }
+    else if (glds_ok && g_tile_override >= 0 && g_tile_override <= 3) {
         int tile = g_tile_override;
         if (tile == 0) {      // from the on-box sweep (tools/gemm_glds_test.py, 2-stage ring)
             if (!ak && !bk) tile = blocks(128, 128) >= 256 ? 1 : (blocks(128, 64) >= 256 && a.M >= 128 ? 2 : 3);

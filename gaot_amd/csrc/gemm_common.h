@@ -214,4 +214,7 @@ bool launch_skinny(const GemmArgs& a, bool a_kmajor, bool b_kmajor, hipStream_t 
 // LDS-direct (global_load_lds) tile kernels (gemm_glds.hip); tile: 1 = 128x128 (8 waves), 2 = 128x64, 3 = 64x64
 void launch_glds(GemmArgs& a, bool a_kmajor, bool b_kmajor, int tile, hipStream_t st);
 
+// split-bf16 kernel (gemm_split.hip): fp32 product from six bf16 MFMA piece products, 128x128 tiles
+void launch_split(GemmArgs& a, bool a_kmajor, bool b_kmajor, hipStream_t st);
+
 }  // namespace gaot

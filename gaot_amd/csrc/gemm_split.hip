@@ -1,0 +1,252 @@
+// fp32 GEMM on the bf16 matrix pipe: every fp32 operand is split EXACTLY into three bf16 pieces
+//     x = x1 + x2 + x3        (8 + 8 + 8 significant bits, by truncation: h = x & 0xffff0000, r = x - h, ...)
+// and the product is accumulated in fp32 from the six piece products whose weight is >= 2^-16:
+//     x*y ~= x1y1 + (x1y2 + x2y1) + (x1y3 + x2y2 + x3y1)          (dropped: x2y3 + x3y2 + x3y3 <= 2^-23 |x||y|)
+// i.e. the result carries fp32-level error (one fp32 rounding is 2^-24) while running on
+// v_mfma_f32_32x32x16_bf16, whose rate is 16x the fp32 MFMA's: six of them per fp32 product = 2.67x the fp32-MFMA
+// peak (157 -> ~400 TFLOP/s effective on MI355X).  The split is done ONCE per element per workgroup, on the way from
+// the global-load registers into LDS; LDS holds three bf16 planes per operand.
+//
+// Tile: 128x128 per workgroup, 4 waves of 64x64 (2x2 MFMA tiles -> every 16-byte operand read feeds 2 MFMAs x 3),
+// k-tile 16, two LDS stages, one barrier per k-tile.  LDS plane layouts (bf16):
+//   k-contiguous operand : [row][16 k], row stride 48 B (conflict-free ds_read_b128: lane (i, kh) reads 8 k)
+//   row-contiguous operand: [k pair][row] of packed (k, k+1) dwords (ds_write_b128 of 4 rows, 4 x ds_read_b32)
+// The reduction order inside a k-tile is free, and both operands use the same one.
+#include "gemm_common.h"
+
+namespace gaot {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int SBK = 16;                 // k per tile
+constexpr int S_BM = 128, S_BN = 128;
+constexpr int S_PLANE = 128 * 48;       // bytes per plane (k-contiguous layout is the larger one)
+constexpr int S_STAGE = 6 * S_PLANE;    // 3 planes x 2 operands
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// two elements at a time so that the residual subtractions are v_pk_add_f32; returns the three packed bf16 pairs
+// (element 0 in the low half).  Only the pieces that feed a subtraction are masked; packing is a byte permute.
+template <int ABL = 0>
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& ph, unsigned& pm, unsigned& pl) {
+    if (ABL & 1) { ph = pm = pl = __float_as_uint(x0) ^ __float_as_uint(x1); return; }
+    const f32x2 x = {x0, x1};
+    const unsigned h0 = __float_as_uint(x0) & 0xffff0000u, h1 = __float_as_uint(x1) & 0xffff0000u;
+    const f32x2 r = x - f32x2{__uint_as_float(h0), __uint_as_float(h1)};
+    const unsigned m0 = __float_as_uint(r[0]) & 0xffff0000u, m1 = __float_as_uint(r[1]) & 0xffff0000u;
+    const f32x2 r2 = r - f32x2{__uint_as_float(m0), __uint_as_float(m1)};      // <= 8 significant bits left: exact in bf16
+    ph = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
+    pm = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
+    pl = __builtin_amdgcn_perm(__float_as_uint(r2[1]), __float_as_uint(r2[0]), 0x07060302u);
+}
+template <int ABL>
+__device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+    if (ABL & 2) { c[0] += __builtin_bit_cast(u32x4, a)[0] * 1e-30f + __builtin_bit_cast(u32x4, b)[1] * 1e-30f; return c; }
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// ABL (tuning builds only, tools/split_bench.hip): 1 = no split arithmetic (raw words to LDS), 2 = no MFMA, 4 = no
+// epilogue stores, 8 = no LDS fragment reads, 16 = no global loads in the loop
+template <bool AK, bool BKM, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
+    constexpr int BM = S_BM, BN = S_BN, NW = 4, WAVES_N = 2, WM = 64, WN = 64, TM = 2, TN = 2;
+    constexpr int EPI_BYTES = NW * 32 * (WN + 4) * 4;
+    constexpr int SMEM_BYTES = 2 * S_STAGE > EPI_BYTES ? 2 * S_STAGE : EPI_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    const int tiles = p.tiles_m * p.tiles_n;
+    int logical;
+    {   // XCD-aware tile order (as gemm.hip)
+        const int q = tiles >> 3, r = tiles & 7, x = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        logical = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + slot;
+    }
+    const int m0 = (logical / p.tiles_n) * BM;
+    const int n0 = (logical % p.tiles_n) * BN;
+
+    const int nkt = p.K / SBK;
+    int kt_begin = 0, kt_end = nkt;
+    if (p.split_k > 1) {                     // ktiles_per_split counts 32-wide tiles
+        kt_begin = blockIdx.z * p.ktiles_per_split * 2;
+        kt_end = min(nkt, kt_begin + p.ktiles_per_split * 2);
+    }
+
+    // ---- global -> register staging (2 float4 per operand per thread per k-tile)
+    // k-contiguous: row = tid >> 1, k half = tid & 1 (8 k = two float4 q = 0, 1 -> one 16-byte write per plane)
+    // row-contiguous: kp = tid >> 5 (k pair), r4 = tid & 31 (4 rows); q = which k of the pair
+    const float* a_src[2]; const float* b_src[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        if (AK) { a_src[q] = p.A + (long)min(m0 + (tid >> 1), p.M - 1) * p.lda + (tid & 1) * 8 + q * 4; }
+        else    { a_src[q] = p.A + (long)(2 * (tid >> 5) + q) * p.lda + min(m0 + (tid & 31) * 4, p.M - 4); }
+        if (BKM) {
+            int nrow = min(n0 + (tid >> 1), p.N - 1);
+            if (p.act == GAOT_ACT_SWIGLU) {      // band layout [u1 cols | u3 cols] per wave band (epilogue_swiglu)
+                const int F = p.N >> 1, row = tid >> 1, within = row % WN;
+                const int gcol = (n0 >> 1) + (row / WN) * (WN / 2) + within % (WN / 2);
+                nrow = (within / (WN / 2)) * F + min(gcol, F - 1);
+            }
+            b_src[q] = p.B + (long)nrow * p.ldb + (tid & 1) * 8 + q * 4;
+        }
+        else     { b_src[q] = p.B + (long)(2 * (tid >> 5) + q) * p.ldb + min(n0 + (tid & 31) * 4, p.N - 4); }
+    }
+    // two register sets: tile j lives in set j & 1 (loads run two k-tiles ahead of the MFMAs, the split one ahead)
+    f32x4 ra[2][2], rb[2][2];
+    auto gload = [&](int kt, f32x4 (&xa)[2], f32x4 (&xb)[2]) {
+        const long k0 = (long)min(kt, kt_end - 1) * SBK;      // past the end: re-load the last tile (never consumed)
+        if ((ABL & 16) && kt > kt_begin + 1) return;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            xa[q] = *reinterpret_cast<const f32x4*>(AK ? a_src[q] + k0 : a_src[q] + k0 * p.lda);
+            xb[q] = *reinterpret_cast<const f32x4*>(BKM ? b_src[q] + k0 : b_src[q] + k0 * p.ldb);
+        }
+    };
+
+    // fused column sums of a row-contiguous A (bias gradient): this thread's 4 rows, its k pair
+    const bool do_colsum = !AK && p.colsum != nullptr && (logical % p.tiles_n) == 0;
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+
+    // split + store one operand's registers into its three planes
+    auto stage_store = [&](unsigned char* base, const f32x4 (&r)[2], bool kmajor) {
+        if (kmajor) {
+            u32x4 h, m, l;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    unsigned a_, b_, c_;
+                    split3_pair<ABL>(r[q][2 * e], r[q][2 * e + 1], a_, b_, c_);
+                    h[2 * q + e] = a_; m[2 * q + e] = b_; l[2 * q + e] = c_;
+                }
+            unsigned char* dst = base + (tid >> 1) * 48 + (tid & 1) * 16;
+            *reinterpret_cast<u32x4*>(dst) = h;
+            *reinterpret_cast<u32x4*>(dst + S_PLANE) = m;
+            *reinterpret_cast<u32x4*>(dst + 2 * S_PLANE) = l;
+        } else {
+            u32x4 h, m, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { unsigned a_, b_, c_; split3_pair<ABL>(r[0][e], r[1][e], a_, b_, c_); h[e] = a_; m[e] = b_; l[e] = c_; }
+            unsigned char* dst = base + (tid >> 5) * 512 + (tid & 31) * 16;
+            *reinterpret_cast<u32x4*>(dst) = h;
+            *reinterpret_cast<u32x4*>(dst + S_PLANE) = m;
+            *reinterpret_cast<u32x4*>(dst + 2 * S_PLANE) = l;
+        }
+    };
+    auto sstore = [&](int stage, const f32x4 (&xa)[2], const f32x4 (&xb)[2], bool live) {
+        unsigned char* sa = smem_raw + stage * S_STAGE;
+        stage_store(sa, xa, AK);
+        stage_store(sa + 3 * S_PLANE, xb, BKM);
+        if (!AK) { const float w = (do_colsum && live) ? 1.f : 0.f; csum += (xa[0] + xa[1]) * w; }   // branch-free: keeps the k-loop one block
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto frag = [&](const unsigned char* plane, int row, bool kmajor) -> bf16x8 {
+        if (ABL & 8) { u32x4 v = {(unsigned)row, (unsigned)lh, 1u, 2u}; asm volatile("" : "+v"(v)); return __builtin_bit_cast(bf16x8, v); }
+        if (kmajor) return *reinterpret_cast<const bf16x8*>(plane + row * 48 + lh * 16);
+        u32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const unsigned*>(plane + (lh * 4 + j) * 512 + row * 4);
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    // one k-tile: MFMAs on `stage` while the NEXT tile (registers xa/xb) is split into the other stage and the tile
+    // after that is fetched into (ya/yb).  Branch-free, so the scheduler can interleave the three streams.
+    auto step = [&](int kt, int stage, f32x4 (&xa)[2], f32x4 (&xb)[2], f32x4 (&ya)[2], f32x4 (&yb)[2]) {
+        gload(kt + 2, ya, yb);
+        const unsigned char* sa = smem_raw + stage * S_STAGE;
+        const unsigned char* sb = sa + 3 * S_PLANE;
+        bf16x8 a[TM][3], b[TN][3];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) a[i][pl] = frag(sa + pl * S_PLANE, wm * WM + i * 32 + li, AK);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) b[j][pl] = frag(sb + pl * S_PLANE, wn * WN + j * 32 + li, BKM);
+        // small terms first
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[i][j] = mfma<ABL>(a[i][2], b[j][0], acc[i][j]);
+                acc[i][j] = mfma<ABL>(a[i][0], b[j][2], acc[i][j]);
+            }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[i][j] = mfma<ABL>(a[i][1], b[j][1], acc[i][j]);
+                acc[i][j] = mfma<ABL>(a[i][1], b[j][0], acc[i][j]);
+            }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[i][j] = mfma<ABL>(a[i][0], b[j][1], acc[i][j]);
+                acc[i][j] = mfma<ABL>(a[i][0], b[j][0], acc[i][j]);
+            }
+        sstore(stage ^ 1, xa, xb, kt + 1 < kt_end);
+        // interleave: one MFMA, a few VALU ops of the split, now and then one of its LDS writes
+        __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);       // the prefetch loads go first: a whole k-tile to land
+#pragma unroll
+        for (int g = 0; g < 24; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+        __syncthreads();
+    };
+
+    gload(kt_begin, ra[0], rb[0]);
+    sstore(0, ra[0], rb[0], kt_begin < kt_end);
+    gload(kt_begin + 1, ra[1], rb[1]);
+    __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; kt += 2) {
+        step(kt, 0, ra[1], rb[1], ra[0], rb[0]);
+        if (kt + 1 < kt_end) step(kt + 1, 1, ra[0], rb[0], ra[1], rb[1]);
+    }
+
+    if (!AK && do_colsum) {          // reduce the 8 k-pair groups through LDS (the stages are free now)
+        float* cs = reinterpret_cast<float*>(smem_raw);
+        *reinterpret_cast<f32x4*>(cs + (tid >> 5) * 128 + (tid & 31) * 4) = csum;
+        __syncthreads();
+        if (tid < BM && m0 + tid < p.M) {
+            float s = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) s += cs[g * 128 + tid];
+            if (p.split_k > 1) p.ws[(long)p.split_k * p.M * p.N + (long)blockIdx.z * p.M + m0 + tid] = s;
+            else p.colsum[m0 + tid] = s;
+        }
+        __syncthreads();
+    }
+    if (ABL & 4) { if (acc[0][0][0] + acc[1][1][3] + acc[0][1][5] + acc[1][0][7] == 123.456f) p.C[tid] = 1.f; return; }
+    if (BKM && p.act == GAOT_ACT_SWIGLU) epilogue_swiglu<TM, TN, WM, WN>(p, reinterpret_cast<float*>(smem_raw), acc, m0, n0, wm, wn, wave, lane);
+    else epilogue_vec<TM, TN, WM, WN>(p, reinterpret_cast<float*>(smem_raw), acc, m0, n0, wm, wn, wave, lane);
+}
+
+void launch_split(GemmArgs& a, bool ak, bool bk, hipStream_t st) {
+    a.tiles_m = cdiv(a.M, S_BM);
+    a.tiles_n = cdiv(a.N, S_BN);
+    dim3 grid(a.tiles_m * a.tiles_n, 1, a.split_k > 1 ? a.split_k : 1);
+    dim3 block(256);
+    if (ak && bk)        hipLaunchKernelGGL((gemm_split_kernel<true, true>), grid, block, 0, st, a);
+    else if (ak && !bk)  hipLaunchKernelGGL((gemm_split_kernel<true, false>), grid, block, 0, st, a);
+    else if (!ak && !bk) hipLaunchKernelGGL((gemm_split_kernel<false, false>), grid, block, 0, st, a);
+    else                 hipLaunchKernelGGL((gemm_split_kernel<false, true>), grid, block, 0, st, a);
+}
+
+}  // namespace gaot

@@ -5,6 +5,7 @@ hand-written gfx950 kernel reached through the C ABI in include/gaot_hip.h.  The
 fallback: calling an op without the library or with host tensors raises.
 """
 import ctypes as C
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -62,8 +63,19 @@ def gemm(M: int, N: int, K: int, A, lda, a_kmajor, B, ldb, b_kmajor, out, ldc, *
     return out
 
 
+# tuning switch (tools / A-B runs only): GAOT_GEMM_MODE = argument of gaot_debug_set_gemm_glds (default 1: fp32 MFMA
+# tiles; 4 adds the split-bf16 tiles where the heuristic picks them); the split-K choice below follows it
+_GEMM_MODE = int(os.environ.get("GAOT_GEMM_MODE", "1"))
+if _GEMM_MODE != 1:
+    L.load().gaot_debug_set_gemm_glds(_GEMM_MODE)
+
+
 def _split_for_reduction(Mo: int, No: int, K: int) -> int:
     """split-K factor for weight-gradient products (tiny output, long reduction)."""
+    t128 = ((Mo + 127) // 128) * ((No + 127) // 128)
+    if _GEMM_MODE >= 4 and K % 32 == 0 and Mo % 4 == 0 and No % 4 == 0 and min(Mo, No) >= 128 and t128 >= 8:
+        # split-bf16 128x128 tiles (gemm_split.hip): ~512 workgroups, at least 256 reduction rows per slab
+        return int(max(1, min(512 // t128, K // 256)))
     tiles = ((Mo + 63) // 64) * ((No + 63) // 64)
     want = max(1, 1024 // max(1, tiles))          # ~1024 workgroups of 64x64 (tools/gemm_bench.py sweep)
     if Mo * No <= 4096 and min(Mo, No) <= 8:      # skinny path: HBM-latency bound, wants many short row chunks

@@ -79,9 +79,11 @@ int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream);
 int gaot_debug_set_gemm_tile(int cfg);
 /* tuning hook: ablate parts of the GEMM kernel (results become WRONG): 1 no in-loop loads, 2 no LDS staging, 4 no stores */
 int gaot_debug_set_gemm_ablate(int bits);
-/* which kernel family served the calling thread's last gaot_gemm_f32: 1 = MFMA tiles, 2 = skinny VALU path */
+/* which kernel family served the calling thread's last gaot_gemm_f32: 1 = fp32 MFMA tiles, 2 = skinny VALU path,
+ * 3 = split-bf16 MFMA tiles (fp32 operands split exactly into three bf16 pieces, six bf16 MFMAs per product, fp32-level error) */
 int gaot_debug_last_gemm_path(void);
-/* tuning hook: 1 = route eligible products (16-byte aligned, K % 32 == 0) to the LDS-direct tile kernels */
+/* tuning hook: 0 = register-staged fp32 tiles only, 1 = + LDS-direct fp32 tiles (2-stage ring), 3 = same with a 3-stage
+ * ring (1 is the DEFAULT), 4 = + split-bf16 tiles where the heuristic picks them, 5 = split-bf16 wherever eligible */
 int gaot_debug_set_gemm_glds(int on);
 
 /* ------------------------------------------------------------------------------------------

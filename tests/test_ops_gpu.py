@@ -392,3 +392,69 @@ def test_swiglu_ffn_fused_matches_unfused(M, K, F):
     assert rel(y, yd) < 1e-5
     for a, b in zip(gf, gd):
         assert rel(a, b) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(200, 132, 64), (520, 260, 96), (1000, 64, 256), (4096, 512, 1024)])
+def test_gemm_split_bf16_kernel(M, N, K):
+    """gemm_split.hip: fp32 operands split exactly into three bf16 pieces, six bf16 MFMAs per product.  Forced on
+    (mode 5) for every layout / epilogue it serves; must be as accurate as the fp32 MFMA kernel (float64 reference),
+    including operands whose rows differ by orders of magnitude."""
+    from gaot_amd import ops, _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g) * torch.exp(3 * torch.randn(M, 1, generator=g))
+    w, gy = torch.randn(N, K, generator=g), torch.randn(M, N, generator=g)
+    b, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    Mk = M - M % 32
+    xd, wd, gd = x.double(), w.double(), gy.double()
+    z_ref = xd @ wd.t() + b.double()
+    refs = dict(y=torch.nn.functional.gelu(z_ref) + res.double(), z=z_ref,
+                dx=(gd @ wd), dxg=(gd @ wd) * 1.0, dw=gd[:Mk].t() @ xd[:Mk], db=gd[:Mk].sum(0))
+    old = lib.gaot_debug_set_gemm_glds(5)
+    try:
+        d = "cuda"
+        z = torch.empty(M, N, device=d)
+        y = ops.linear_nt(x.to(d), w.to(d), bias=b.to(d), act=_lib.ACT_GELU, aux_out=z, ld_aux=N, residual=res.to(d), ldr=N)
+        assert lib.gaot_debug_last_gemm_path() == 3
+        dx = ops.matmul_nn(gy.to(d), w.to(d))
+        assert lib.gaot_debug_last_gemm_path() == (3 if N % 32 == 0 else 1)     # the reduction must be a multiple of 32
+        dw, db = torch.empty(N, K, device=d), torch.empty(N, device=d)
+        ops.gemm(N, K, Mk, gy.to(d), N, 0, x.to(d), K, 0, dw, K, split_k=3, colsum=db)
+        assert lib.gaot_debug_last_gemm_path() == 3
+        dw1 = torch.empty(N, K, device=d)
+        ops.gemm(N, K, Mk, gy.to(d), N, 0, x.to(d), K, 0, dw1, K)          # no split-K: direct epilogue
+        # mixed layout: A m-major, B k-major  (x^T stored [K, M] against w)
+        xt = x.t().contiguous().to(d)
+        y2 = torch.empty(M, N, device=d)
+        ops.gemm(M, N, K, xt, M, 0, w.to(d), K, 1, y2, N) if M % 4 == 0 else None
+    finally:
+        lib.gaot_debug_set_gemm_glds(old)
+    assert rel(y, refs["y"]) < 2e-6 and rel(z, refs["z"]) < 2e-6
+    assert rel(dx, refs["dx"]) < 2e-6
+    assert rel(dw, refs["dw"]) < 2e-6 and rel(dw1, refs["dw"]) < 2e-6
+    assert float((db.double().cpu() - refs["db"]).abs().max() / gd[:Mk].abs().sum(0).max()) < 1e-6
+    if M % 4 == 0:
+        assert rel(y2, xd @ wd.t()) < 2e-6
+    # element-wise: error relative to sum |a||b| stays at the fp32 rounding level (no lost low-order pieces)
+    scale = xd.abs() @ wd.abs().t()
+    assert float(((z.double().cpu() - z_ref).abs() / (scale + 1)).max()) < 2e-6
+
+
+@pytest.mark.gpu
+def test_gemm_split_bf16_exactness_of_the_split():
+    """x = x1 + x2 + x3 is exact, so products of values with <= 8 significant bits are reproduced EXACTLY, and
+    integer-valued operands (|sum| < 2^24) give the exact integer result."""
+    from gaot_amd import ops, _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 256, 256, 64
+    a = torch.randint(-2047, 2048, (M, K), generator=g).float()        # 12 significant bits: needs two pieces
+    b = torch.randint(-15, 16, (N, K), generator=g).float()
+    old = lib.gaot_debug_set_gemm_glds(5)
+    try:
+        out = ops.linear_nt(a.cuda(), b.cuda())
+        assert lib.gaot_debug_last_gemm_path() == 3
+    finally:
+        lib.gaot_debug_set_gemm_glds(old)
+    assert torch.equal(out.cpu().double(), a.double() @ b.double().t())
