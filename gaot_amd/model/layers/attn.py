@@ -87,10 +87,13 @@ class GroupQueryFlashAttention(nn.Module):
             raise NotImplementedError("attention dropout > 0 is not supported by the HIP attention kernel")
         if self.correction is not None:
             x = self.correction(c=condition, x=x)
-        wqkv = torch.cat([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight], dim=0)
-        qkv = ops.linear(x, wqkv)
+        qkv = ops.linear_cat(x, [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight])
         o = ops.attention(qkv, self.num_heads, self.num_kv_heads, self.head_dim)
         return ops.linear(o, self.o_proj.weight, residual=residual)
+
+    def fused_weight_groups(self):
+        """weights read as one matrix by the fused projection: trainer.FlatGradBucket keeps them back to back"""
+        return [[self.q_proj.weight, self.k_proj.weight, self.v_proj.weight]]
 
     @classmethod
     def from_config(cls, input_size: int, hidden_size: int, config: AttentionConfig, positional_embedding: str = "absolute"):
@@ -108,6 +111,9 @@ class FFN(nn.Module):
         self.w2 = nn.Linear(ffn_hidden_size, input_size, bias=False)
         self.w3 = nn.Linear(input_size, ffn_hidden_size, bias=False)
         self.correction = ConditionedNorm(1, input_size, cond_norm_hidden_size) if use_conditional_norm else None
+
+    def fused_weight_groups(self):
+        return [[self.w1.weight, self.w3.weight]]
 
     def forward(self, x, condition=None, residual=None):
         if self.correction is None:
@@ -136,7 +142,10 @@ class TransformerBlock(nn.Module):
     def forward(self, x, condition=None, relative_positions=None, skip=None):
         if self.skip_connection and skip is not None:          # cat([x, skip]) @ W^T + b as a split-K-operand GEMM
             x = ops.linear(x, self.skip_proj.weight, self.skip_proj.bias, x2=skip)
-        h = x if self.attn_norm is None else self.attn_norm(x)
+        if self.attn_norm is None:
+            h = x
+        else:       # (x, norm(x)) from one node: the residual's gradient is added inside the norm-gradient kernel
+            x, h = ops.rms_norm_fork(x, self.attn_norm.weight, self.attn_norm.eps)
         h = self.attn(h, condition=condition, relative_positions=relative_positions, residual=x)   # x + attn(h)
         h = h if self.ffn_norm is None else self.ffn_norm(h)
         return self.ffn(h, condition=condition, residual=h)    # residual on the NORMALISED stream (attn.py:231-232)

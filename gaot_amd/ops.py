@@ -226,6 +226,56 @@ def linear(x, w, b=None, residual=None, rowbias=None, x2=None):
     return _Linear.apply(x, w, b, residual, rowbias, x2)
 
 
+def adjacent_rows(ws: Sequence[torch.Tensor]) -> Optional[torch.Tensor]:
+    """[sum N_i, K] view over weights that already sit back to back in one storage (the flat parameter buffer of
+    trainer.FlatAdamW lays fused groups out that way), or None.  Replaces a torch.cat per step by pointer checks."""
+    base = ws[0].detach()
+    K = base.shape[-1]
+    sp, off, rows = base.untyped_storage().data_ptr(), base.storage_offset(), 0
+    for w in ws:
+        if (w.dim() != 2 or w.shape[1] != K or not w.is_contiguous() or w.untyped_storage().data_ptr() != sp
+                or w.storage_offset() != off + rows * K):
+            return None
+        rows += w.shape[0]
+    return base.as_strided((rows, K), (K, 1), off)
+
+
+def stacked_rows(ws: Sequence[torch.Tensor]) -> torch.Tensor:
+    v = adjacent_rows(ws)
+    return v if v is not None else torch.cat([w.detach() for w in ws], dim=0)
+
+
+class _LinearCat(torch.autograd.Function):
+    """y = x @ cat(ws, 0)^T for several bias-free Linear layers sharing an input (q|k|v): one GEMM forward, one
+    input-gradient GEMM and ONE weight-gradient GEMM backward (the per-layer gradients are row blocks of it)."""
+
+    @staticmethod
+    def forward(ctx, x, *ws):
+        _dev(x, *ws)
+        shp = x.shape
+        xm = x.reshape(-1, shp[-1])
+        W = stacked_rows(ws)
+        y = linear_nt(xm, W)
+        ctx.save_for_backward(xm, W)
+        ctx.meta = (shp, [w.shape[0] for w in ws])
+        return y.reshape(*shp[:-1], W.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        xm, W = ctx.saved_tensors
+        shp, rows = ctx.meta
+        g, _ = _rowmajor(dy.reshape(-1, W.shape[0]))
+        dx = matmul_nn(g, W).reshape(shp) if ctx.needs_input_grad[0] else None
+        dws = [None] * len(rows)
+        if any(ctx.needs_input_grad[1:]):
+            dws = list(matmul_tn(g, xm).split(rows, dim=0))
+        return (dx, *dws)
+
+
+def linear_cat(x, ws):
+    return _LinearCat.apply(x, *ws)
+
+
 # --------------------------------------------------------------------------------------------
 # MLP chain: z_i = h_{i-1} W_i^T + b_i, h_i = act_i(z_i); activation derivative of layer i is fused into the
 # epilogue of layer i+1's input-gradient GEMM.
@@ -439,6 +489,47 @@ def rms_norm(x, w, eps):
     return _RMSNorm.apply(x, w, eps)
 
 
+class _RMSNormFork(torch.autograd.Function):
+    """(x, rmsnorm(x)): the pre-norm residual fork.  Handing the untouched stream back through the SAME node lets the
+    backward add the residual branch's gradient inside the norm-gradient kernel (dx_add) instead of autograd launching
+    a separate elementwise add per fork."""
+
+    @staticmethod
+    def forward(ctx, x, w, eps):
+        _dev(x, w)
+        shp = x.shape
+        D = shp[-1]
+        xm = x.reshape(-1, D).contiguous()
+        M = xm.shape[0]
+        y = torch.empty_like(xm)
+        rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+        L.check(L.load().gaot_rmsnorm_fwd(_p(xm), _p(w), M, D, float(eps), _p(y), _p(rstd), _stream()), "gaot_rmsnorm_fwd")
+        ctx.save_for_backward(xm, w, rstd)
+        ctx.shp = shp
+        return x.view_as(x), y.reshape(shp)
+
+    @staticmethod
+    def backward(ctx, dres, dy):
+        xm, w, rstd = ctx.saved_tensors
+        M, D = xm.shape
+        if dy is None:
+            return dres, None, None
+        lib = L.load()
+        g = dy.reshape(M, D).contiguous()
+        add = dres.reshape(M, D).contiguous() if dres is not None else None
+        dx = torch.empty_like(xm)
+        P = int(lib.gaot_rmsnorm_bwd_partials(M))
+        part = torch.empty(P, D, device=xm.device, dtype=torch.float32)
+        L.check(lib.gaot_rmsnorm_bwd(_p(xm), _p(w), _p(rstd), _p(g), _p(add), M, D, _p(dx), _p(part), _stream()), "gaot_rmsnorm_bwd")
+        dw = colsum(part) if ctx.needs_input_grad[1] else None
+        return dx.reshape(ctx.shp), dw, None
+
+
+def rms_norm_fork(x, w, eps):
+    """returns (x, rmsnorm(x)); use the returned x for the residual branch."""
+    return _RMSNormFork.apply(x, w, eps)
+
+
 class _SwiGLU(torch.autograd.Function):
     """u = [u1 | u3] -> silu(u1) * u3   (attn.py:151)"""
 
@@ -479,13 +570,15 @@ class _SwiGLUFFN(torch.autograd.Function):
         return K % 32 == 0 and F % 4 == 0
 
     @staticmethod
-    def forward(ctx, x, w1, w3, w2, residual):
+    def forward(ctx, x, w1, w3, w2, residual, res_is_x):
         _dev(x, w1, w3, w2)
         shp = x.shape
         K = shp[-1]
         xm, lda = _rowmajor(x.reshape(-1, K))
         M, F, No = xm.shape[0], w1.shape[0], w2.shape[0]
-        w13 = torch.cat([w1, w3], dim=0)
+        w13 = stacked_rows([w1, w3])
+        if res_is_x:          # y = x + ffn(x): the stream's gradient is added in the epilogue of du @ w13 (backward)
+            residual = x
         u = torch.empty(M, 2 * F, device=x.device, dtype=torch.float32)
         g = torch.empty(M, F, device=x.device, dtype=torch.float32)
         gemm(M, 2 * F, K, xm, lda, 1, w13, K, 1, g, F, act=L.ACT_SWIGLU, aux_out=u, ld_aux=2 * F)
@@ -495,13 +588,13 @@ class _SwiGLUFFN(torch.autograd.Function):
             epi.update(residual=res2, ldr=ldr)
         y = linear_nt(g, w2, **epi)
         ctx.save_for_backward(xm, u, g, w13, w2)
-        ctx.meta = (shp, residual.shape if residual is not None else None)
+        ctx.meta = (shp, residual.shape if (residual is not None and not res_is_x) else None, bool(res_is_x))
         return y.reshape(*shp[:-1], No)
 
     @staticmethod
     def backward(ctx, dy):
         xm, u, g, w13, w2 = ctx.saved_tensors
-        shp, res_shape = ctx.meta
+        shp, res_shape, res_is_x = ctx.meta
         M, F = g.shape
         No, K = w2.shape[0], xm.shape[1]
         d, ldd = _rowmajor(dy.reshape(M, No))
@@ -510,19 +603,24 @@ class _SwiGLUFFN(torch.autograd.Function):
         du = torch.empty(M, 2 * F, device=d.device, dtype=torch.float32)
         gemm(M, F, No, d, ldd, 1, w2c, ldw2, 0, du, 2 * F, act=L.ACT_SWIGLU_BWD, aux_in=u, ld_aux=2 * F)
         dw2 = matmul_tn(d, g) if need[3] else None
-        dx = matmul_nn(du, w13).reshape(shp) if need[0] else None
+        dx = None
+        if need[0]:
+            dx = (matmul_nn(du, w13, residual=d, ldr=ldd) if res_is_x else matmul_nn(du, w13)).reshape(shp)
         dw1 = dw3 = None
         if need[1] or need[2]:
             dw13 = matmul_tn(du, xm)
             dw1, dw3 = dw13[:F], dw13[F:]
         dres = dy.reshape(res_shape) if (res_shape is not None and need[4]) else None
-        return dx, dw1, dw3, dw2, dres
+        return dx, dw1, dw3, dw2, dres, None
 
 
 def swiglu_ffn(x, w1, w3, w2, residual=None):
-    """SwiGLU feed-forward; falls back to the unfused HIP kernels when the fused epilogues' shape rules do not hold."""
+    """SwiGLU feed-forward; falls back to the unfused HIP kernels when the fused epilogues' shape rules do not hold.
+    `residual is x` (the reference block adds the FFN to its own normalised input, attn.py:231-232) is fused both ways."""
     if _SwiGLUFFN.fusable(x.shape[-1], w1.shape[0]):
-        return _SwiGLUFFN.apply(x, w1, w3, w2, residual)
+        if residual is x and w2.shape[0] == x.shape[-1]:
+            return _SwiGLUFFN.apply(x, w1, w3, w2, None, True)
+        return _SwiGLUFFN.apply(x, w1, w3, w2, residual, False)
     return linear(swiglu(linear(x, torch.cat([w1, w3], dim=0))), w2, residual=residual)
 
 

@@ -31,16 +31,32 @@ class FlatGradBucket:
     AccumulateGrad steals instead of launching one add per parameter); `pack()` then gathers them with ONE
     multi-tensor copy and re-points param.grad at views of the flat buffer for the all-reduce / optimizer."""
 
-    def __init__(self, params: List[torch.nn.Parameter]):
-        self.params = [p for p in params if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
-        ref = self.params[0]
-        self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
-        self.views = []
+    ALIGN = 64      # floats: every parameter (or fused group) starts on a 256-byte boundary -> 16-byte vector kernels apply
+
+    def __init__(self, params: List[torch.nn.Parameter], groups: Optional[List[List[torch.nn.Parameter]]] = None):
+        """`groups`: lists of parameters that must sit back to back (in the given order, no padding) so that a fused
+        GEMM can read them as ONE matrix (q|k|v, w1|w3: ops.adjacent_rows) instead of concatenating every step."""
+        params = [p for p in params if p.requires_grad]
+        pos = {id(p): i for i, p in enumerate(params)}
+        follow, skip = {}, set()
+        for g in groups or []:
+            if len(g) > 1 and all(id(p) in pos for p in g) and not any(id(p) in skip or id(p) in follow for p in g):
+                follow[id(g[0])] = list(g[1:])
+                skip.update(id(p) for p in g[1:])
+        self.params, self.offsets = [], []
         off = 0
-        for p in self.params:
-            self.views.append(self.flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
+        for p in params:
+            if id(p) in skip:
+                continue
+            off = -(-off // self.ALIGN) * self.ALIGN
+            for q in [p] + follow.get(id(p), []):
+                self.params.append(q)
+                self.offsets.append(off)
+                off += q.numel()
+        self.numel = -(-off // 4) * 4
+        ref = self.params[0]
+        self.flat = torch.zeros(self.numel, dtype=ref.dtype, device=ref.device)
+        self.views = [self.flat[o:o + p.numel()].view_as(p) for p, o in zip(self.params, self.offsets)]
 
     def clear(self):
         for p in self.params:
@@ -76,12 +92,12 @@ class FlatAdamW:
         self.bucket = bucket
         self.lr, self.wd, self.betas, self.eps = float(lr), float(weight_decay), betas, float(eps)
         ps = bucket.params
-        with torch.no_grad():
-            self.flat_p = torch.cat([p.detach().reshape(-1) for p in ps]).contiguous()
-            off = 0
-            for p in ps:
-                p.data = self.flat_p[off:off + p.numel()].view_as(p)
-                off += p.numel()
+        with torch.no_grad():       # same layout as the gradient bucket (aligned starts, fused groups back to back)
+            self.flat_p = torch.zeros_like(bucket.flat)
+            for p, off in zip(ps, bucket.offsets):
+                v = self.flat_p[off:off + p.numel()].view_as(p)
+                v.copy_(p.detach())
+                p.data = v
         self.m = torch.zeros_like(self.flat_p)
         self.v = torch.zeros_like(self.flat_p)
         self.step_count = torch.zeros(1, dtype=torch.float32, device=self.flat_p.device)
@@ -115,7 +131,8 @@ class TrainStep:
         self.group = group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         broadcast_parameters(model, 0, group)
-        self.bucket = FlatGradBucket(list(model.parameters()))
+        groups = [g for m in model.modules() if hasattr(m, "fused_weight_groups") for g in m.fused_weight_groups()]
+        self.bucket = FlatGradBucket(list(model.parameters()), groups)
         dev = self.bucket.flat.device
         on_gpu = dev.type == "cuda"
         if on_gpu:

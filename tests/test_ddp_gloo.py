@@ -95,10 +95,38 @@ def test_flat_bucket_views_and_missing_grads():
     m(pndata=torch.randn(2, 3)).sum().backward()
     grads = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
     b.pack()
-    off = 0
-    for n, p in m.named_parameters():
+    names = {id(p): n for n, p in m.named_parameters()}
+    assert [id(p) for p in b.params] == [id(p) for p in m.parameters()]        # no fused groups: model order
+    covered = torch.zeros(b.flat.numel(), dtype=torch.bool)
+    for p, off in zip(b.params, b.offsets):
+        assert off % FlatGradBucket.ALIGN == 0                                # every parameter starts on a 256-byte boundary
         seg = b.flat[off:off + p.numel()].view_as(p)
+        n = names[id(p)]
         assert p.grad.data_ptr() == seg.data_ptr()
         assert torch.equal(seg, grads[n]) if n in grads else bool((seg == 0).all())
-        off += p.numel()
+        assert not covered[off:off + p.numel()].any()
+        covered[off:off + p.numel()] = True
+    assert bool((b.flat[~covered] == 0).all())                                 # padding stays zero
     broadcast_parameters(m)      # no process group: a no-op
+
+
+def test_flat_bucket_fused_groups_are_back_to_back():
+    """parameters named by fused_weight_groups() sit contiguously (q|k|v, w1|w3) so ops.adjacent_rows can view them as
+    one matrix; everything else keeps model order."""
+    from gaot_amd import ops
+    lin = [torch.nn.Linear(8, n, bias=False) for n in (4, 12, 4, 8)]
+    extra = torch.nn.Parameter(torch.zeros(3))
+    params = [lin[0].weight, extra, lin[1].weight, lin[2].weight, lin[3].weight]
+    b = FlatGradBucket(params, groups=[[lin[0].weight, lin[2].weight, lin[3].weight]])
+    assert [id(p) for p in b.params] == [id(x) for x in (lin[0].weight, lin[2].weight, lin[3].weight, extra, lin[1].weight)]
+    o = dict(zip(map(id, b.params), b.offsets))
+    assert o[id(lin[2].weight)] == o[id(lin[0].weight)] + 32 and o[id(lin[3].weight)] == o[id(lin[2].weight)] + 32
+    # re-point the parameters at a flat buffer with that layout (what FlatAdamW does) and view the group as one matrix
+    flat = torch.arange(b.numel, dtype=torch.float32)
+    for p, off in zip(b.params, b.offsets):
+        p.data = flat[off:off + p.numel()].view_as(p)
+    W = ops.adjacent_rows([lin[0].weight, lin[2].weight, lin[3].weight])
+    assert W is not None and W.shape == (16, 8) and W.data_ptr() == lin[0].weight.data_ptr()
+    assert torch.equal(W, torch.cat([lin[0].weight, lin[2].weight, lin[3].weight]).detach())
+    assert ops.adjacent_rows([lin[0].weight, lin[1].weight]) is None          # not adjacent: caller concatenates
+    assert torch.equal(ops.stacked_rows([lin[0].weight, lin[1].weight]), torch.cat([lin[0].weight, lin[1].weight]).detach())
