@@ -141,6 +141,7 @@ class _MAGNOBase(nn.Module):
         if self.use_geoembed:
             w = self.recovery.fcs[0].weight.squeeze(-1)                                             # [C, 2C]
             C = out.shape[-1]
+            w_agno, w_geo = ops.split_cols(w, C)      # one gradient assembly instead of two slice-backward chains
             rowb = None
             key = None
             if not torch.is_grad_enabled() and nb is neighbors:
@@ -153,15 +154,15 @@ class _MAGNOBase(nn.Module):
             if rowb is None:
                 ge = self.geoembed(input_geom=src_coord, latent_queries=dst_coord, spatial_nbrs=nb,
                                    stats=stats if nb is neighbors else None)                      # [n_dst, C]
-                rowb = ops.linear(ge, w[:, C:], self.recovery.fcs[0].bias)                          # [n_dst, C]
+                rowb = ops.linear(ge, w_geo, self.recovery.fcs[0].bias)                          # [n_dst, C]
                 if key is not None:
                     self._infer_cache["rowb"] = (key, nb, rowb)
             if head is not None:
                 hw, hb = head
-                w_eff = ops.linear(hw, w[:, :C].t())                 # [out, C] = W @ Wr1   (tiny)
+                w_eff = ops.linear(hw, w_agno.t())                 # [out, C] = W @ Wr1   (tiny)
                 rowb_h = ops.linear(rowb, hw, hb)                    # [n_dst, out]
                 return ops.linear(out, w_eff, rowbias=rowb_h)
-            out = ops.linear(out, w[:, :C], rowbias=rowb)
+            out = ops.linear(out, w_agno, rowbias=rowb)
         elif head is not None:
             return ops.linear(out, head[0], head[1])
         return out

@@ -144,6 +144,36 @@ def batchsum(x: torch.Tensor, B: int) -> torch.Tensor:
 # --------------------------------------------------------------------------------------------
 # Linear (nn.Linear / Conv1d k=1) with fused bias, periodic row bias, residual and split input
 # --------------------------------------------------------------------------------------------
+# --------------------------------------------------------------------------------------------
+# Gradient slots: trainer.FlatGradBucket registers, per parameter, the view of the flat gradient buffer where that
+# parameter's gradient has to end up.  The FIRST use of a parameter in a forward pass claims its slot and the matching
+# backward writes the weight gradient straight into it (no per-parameter temporary + pack copy); any further use of the
+# same parameter before the next FlatGradBucket.clear() takes the ordinary path and autograd accumulates as usual.
+# --------------------------------------------------------------------------------------------
+_GRAD_SLOTS: dict = {}
+
+
+def register_grad_slots(params, views):
+    _GRAD_SLOTS.clear()
+    for p, v in zip(params, views):
+        _GRAD_SLOTS[id(p)] = [v, False, p]       # holding p keeps id(p) unique while registered
+
+
+def release_grad_slots():
+    for s in _GRAD_SLOTS.values():
+        s[1] = False
+
+
+def _claim(w) -> Optional[torch.Tensor]:
+    if w is None or not w.requires_grad:
+        return None
+    s = _GRAD_SLOTS.get(id(w))
+    if s is None or s[1] or s[2] is not w or s[0].device != w.device:
+        return None
+    s[1] = True
+    return s[0]
+
+
 class _Linear(torch.autograd.Function):
     """y = x @ w[:, :K]^T (+ x2 @ w[:, K:]^T) + b + rowbias[m % P] + residual"""
 
@@ -182,6 +212,7 @@ class _Linear(torch.autograd.Function):
                 linear_nt(xm_, wc[:, :K], out=y, **epi)
                 linear_nt(x2m_, wc[:, K:], out=y, residual=y, ldr=N)
         ctx.save_for_backward(xm, x2m, w2d)
+        ctx.slots = (_claim(w), _claim(b))
         ctx.meta = (shp, x2.shape if x2 is not None else None, w.shape, b is not None,
                     residual.shape if residual is not None else None,
                     rowbias.shape if rowbias is not None else None)
@@ -202,10 +233,11 @@ class _Linear(torch.autograd.Function):
         if need[5] and x2m is not None:
             dx2 = matmul_nn(g, w2d[:, K:]).reshape(shp2)
         want_db = has_b and need[2]
+        wslot, bslot = ctx.slots
         if need[1]:
-            dw = torch.empty(N, w2d.shape[1], device=g.device, dtype=torch.float32)
+            dw = wslot.detach().view(N, w2d.shape[1]) if wslot is not None else torch.empty(N, w2d.shape[1], device=g.device, dtype=torch.float32)
             if want_db:      # bias gradient rides the weight-gradient product (same pass over dY)
-                db = torch.empty(N, device=g.device, dtype=torch.float32)
+                db = bslot.detach() if bslot is not None else torch.empty(N, device=g.device, dtype=torch.float32)
             matmul_tn(g, xm, out=dw[:, :K], colsum_out=db)
             if x2m is not None:
                 matmul_tn(g, x2m, out=dw[:, K:])
@@ -224,6 +256,30 @@ class _Linear(torch.autograd.Function):
 
 def linear(x, w, b=None, residual=None, rowbias=None, x2=None):
     return _Linear.apply(x, w, b, residual, rowbias, x2)
+
+
+class _SplitCols(torch.autograd.Function):
+    """w [N, K] -> (w[:, :c], w[:, c:]) as views; the backward writes both column blocks into ONE gradient (autograd's
+    own slice nodes would zero-fill two full-size gradients, copy a block into each and add them)."""
+
+    @staticmethod
+    def forward(ctx, w, c):
+        ctx.c, ctx.shape = c, w.shape
+        return w[:, :c], w[:, c:]
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        N, K = ctx.shape
+        ref = g1 if g1 is not None else g2
+        if g1 is None:
+            g1 = ref.new_zeros(N, ctx.c)
+        if g2 is None:
+            g2 = ref.new_zeros(N, K - ctx.c)
+        return torch.cat([g1, g2], dim=1), None
+
+
+def split_cols(w, c: int):
+    return _SplitCols.apply(w, c)
 
 
 def adjacent_rows(ws: Sequence[torch.Tensor]) -> Optional[torch.Tensor]:
@@ -257,6 +313,8 @@ class _LinearCat(torch.autograd.Function):
         W = stacked_rows(ws)
         y = linear_nt(xm, W)
         ctx.save_for_backward(xm, W)
+        slots = [_claim(w) for w in ws]
+        ctx.slot = adjacent_rows(slots) if all(s_ is not None for s_ in slots) else None
         ctx.meta = (shp, [w.shape[0] for w in ws])
         return y.reshape(*shp[:-1], W.shape[0])
 
@@ -268,7 +326,7 @@ class _LinearCat(torch.autograd.Function):
         dx = matmul_nn(g, W).reshape(shp) if ctx.needs_input_grad[0] else None
         dws = [None] * len(rows)
         if any(ctx.needs_input_grad[1:]):
-            dws = list(matmul_tn(g, xm).split(rows, dim=0))
+            dws = list(matmul_tn(g, xm, out=ctx.slot).split(rows, dim=0))
         return (dx, *dws)
 
 
@@ -306,6 +364,7 @@ class _MLPChain(torch.autograd.Function):
             h = y
         ctx.acts = acts
         ctx.n = n
+        ctx.slots = [(_claim(wb[2 * i]), _claim(wb[2 * i + 1])) for i in range(n)]
         ctx.shapes = (shp, [w.shape for w in wb[0::2]], [b is not None for b in wb[1::2]])
         ctx.save_for_backward(*saved_in, *[a if a is not None else saved_in[0].new_empty(0) for a in saved_aux], *ws)
         return h.reshape(*shp[:-1], h.shape[-1])
@@ -320,15 +379,19 @@ class _MLPChain(torch.autograd.Function):
         g, _ = _rowmajor(g)
         last_act = ACT[ctx.acts[-1]]
         if last_act == L.ACT_RELU:      # derivative of the final activation (not fusable: no following GEMM)
-            g = g * (auxs[-1] > 0)
+            g = torch.ops.aten.threshold_backward(g, auxs[-1], 0.0)
         elif last_act == L.ACT_GELU:
             raise NotImplementedError("final GELU in an MLP chain")
         grads: List[Optional[torch.Tensor]] = [None] * (2 * n)
         for i in range(n - 1, -1, -1):
             want_db = has_b[i] and ctx.needs_input_grad[3 + 2 * i]
+            wslot, bslot = ctx.slots[i]
             if ctx.needs_input_grad[2 + 2 * i]:
-                db = torch.empty(g.shape[1], device=g.device, dtype=torch.float32) if want_db else None
-                grads[2 * i] = matmul_tn(g, ins[i], colsum_out=db).reshape(wshapes[i])
+                db = None
+                if want_db:
+                    db = bslot.detach() if bslot is not None else torch.empty(g.shape[1], device=g.device, dtype=torch.float32)
+                out = wslot.detach().view(g.shape[1], ins[i].shape[1]) if wslot is not None else None
+                grads[2 * i] = matmul_tn(g, ins[i], out=out, colsum_out=db).reshape(wshapes[i])
                 grads[2 * i + 1] = db
             elif want_db:
                 grads[2 * i + 1] = colsum(g)
@@ -588,6 +651,8 @@ class _SwiGLUFFN(torch.autograd.Function):
             epi.update(residual=res2, ldr=ldr)
         y = linear_nt(g, w2, **epi)
         ctx.save_for_backward(xm, u, g, w13, w2)
+        s1, s3, s2 = _claim(w1), _claim(w3), _claim(w2)
+        ctx.slots = (adjacent_rows([s1, s3]) if (s1 is not None and s3 is not None) else None, s2)
         ctx.meta = (shp, residual.shape if (residual is not None and not res_is_x) else None, bool(res_is_x))
         return y.reshape(*shp[:-1], No)
 
@@ -602,13 +667,14 @@ class _SwiGLUFFN(torch.autograd.Function):
         w2c, ldw2 = _rowmajor(w2)
         du = torch.empty(M, 2 * F, device=d.device, dtype=torch.float32)
         gemm(M, F, No, d, ldd, 1, w2c, ldw2, 0, du, 2 * F, act=L.ACT_SWIGLU_BWD, aux_in=u, ld_aux=2 * F)
-        dw2 = matmul_tn(d, g) if need[3] else None
+        slot13, slot2 = ctx.slots
+        dw2 = matmul_tn(d, g, out=slot2.detach() if slot2 is not None else None) if need[3] else None
         dx = None
         if need[0]:
             dx = (matmul_nn(du, w13, residual=d, ldr=ldd) if res_is_x else matmul_nn(du, w13)).reshape(shp)
         dw1 = dw3 = None
         if need[1] or need[2]:
-            dw13 = matmul_tn(du, xm)
+            dw13 = matmul_tn(du, xm, out=slot13)
             dw1, dw3 = dw13[:F], dw13[F:]
         dres = dy.reshape(res_shape) if (res_shape is not None and need[4]) else None
         return dx, dw1, dw3, dw2, dres, None

@@ -57,19 +57,29 @@ class FlatGradBucket:
         ref = self.params[0]
         self.flat = torch.zeros(self.numel, dtype=ref.dtype, device=ref.device)
         self.views = [self.flat[o:o + p.numel()].view_as(p) for p, o in zip(self.params, self.offsets)]
+        self._dirty = [False] * len(self.params)      # view holds a gradient from an earlier step
 
     def clear(self):
         for p in self.params:
             p.grad = None
+        if self.flat.is_cuda:         # weight-gradient GEMMs of the HIP ops write straight into their views (ops._claim)
+            from . import ops
+            if ops._GRAD_SLOTS.get(id(self.params[0]), [None])[0] is not self.views[0]:
+                ops.register_grad_slots(self.params, self.views)
+            ops.release_grad_slots()
 
     def pack(self):
         srcs, dsts = [], []
-        for p, v in zip(self.params, self.views):
+        for i, (p, v) in enumerate(zip(self.params, self.views)):
             if p.grad is None:
-                v.zero_()
-            elif p.grad.data_ptr() != v.data_ptr():
-                srcs.append(p.grad)
-                dsts.append(v)
+                if self._dirty[i]:      # a parameter that got no gradient this step: zero (once; the buffer starts zeroed)
+                    v.zero_()
+                    self._dirty[i] = False
+            else:
+                self._dirty[i] = True
+                if p.grad.data_ptr() != v.data_ptr():
+                    srcs.append(p.grad)
+                    dsts.append(v)
         if srcs:
             torch._foreach_copy_(dsts, srcs)
         for p, v in zip(self.params, self.views):
