@@ -1,0 +1,418 @@
+// Fused kernel MLP of the graph neural operator (reference mlp.py:307-337 via agno.py:229-231): per edge
+//     k_e = W_L ... gelu(W_2 gelu(W_1 [y_j, x_i] + b_1) + b_2) ... + b_L          (every width 64, c_in <= 16)
+// as ONE kernel forward and ONE kernel backward instead of a chain of skinny GEMM launches over the E ~ 5*10^4 edge rows.
+//
+// Orientation: activations are kept TRANSPOSED, [feature][edge], so that a layer is  Z^T = W * H^T  on
+// v_mfma_f32_32x32x2_f32 with A = W (lane -> output feature) and B = H^T (lane -> edge).  The MFMA result fragment
+// (lane = edge column, 16 registers = features crow(r, hi)) then IS the B operand of the next layer: the k-slot of
+// half-wave hi is defined as feature crow(t, hi), the weights are read to match, and no activation ever moves between
+// lanes or through LDS on the forward chain / the input-gradient chain (same trick as P in the attention kernels).
+// A wave owns 32 edges; weights sit in LDS once per workgroup as plain [64][68] images that serve both W (forward,
+// ds_read_b128 along k) and W^T (backward, ds_read_b32 along the output feature).
+//
+// Backward recomputes the forward chain from the edge coordinates (keeps the pre-activations in registers), then per
+// layer: G and H go through a wave-private LDS tile [feature][edge] (the weight gradient reduces over EDGES, so edges
+// must become the k index), dW_m += G_m H_{m-1}^T on MFMA into per-wave accumulators that live for the whole kernel
+// (192 registers for 3 layers: the accumulator half of the register file), db_m and dW_1 (c_in columns) from the same
+// operand registers on the VALU, dH = W^T G from registers again.  Workgroups are persistent; per-workgroup partial
+// gradients go to a workspace and a second kernel sums them in fixed order (deterministic, no atomics).
+#include "common.h"
+
+namespace gaot {
+
+constexpr int KM_WLD = 68;     // floats per LDS weight row (16-byte aligned rows, conflict-free b128 / b32 reads)
+constexpr int KM_TLD = 36;     // floats per LDS [feature][32 edges] tile row
+constexpr int KM_MAXC = 16;    // c_in of the first layer
+
+struct KMArgs {
+    const float* x; int cin; int E;
+    const float* w1; const float* b1;
+    const float* w[3]; const float* b[3];
+    float* out;            // forward: k [E, 64]
+    const float* dk;       // backward: upstream gradient [E, 64]
+    float* ws;             // backward: per-workgroup partial gradients [grid][psize]
+    int psize;
+    int ntiles;            // 128-edge tiles
+};
+
+__device__ __forceinline__ void gelu_both(float z, float& h, float& d) {
+    const float cdf = 0.5f * (1.0f + erf_nb(z * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * z * z);
+    h = z * cdf;
+    d = cdf + z * pdf;
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// stage the weights of the workgroup: Ws[m] = W_{m+1} as [64][KM_WLD], W1s [64][cin], biases
+template <int NL>
+__device__ __forceinline__ void km_stage_weights(const KMArgs& p, float* Ws, float* W1s, float* Bs, int tid) {
+#pragma unroll
+    for (int m = 0; m < NL; ++m)
+        for (int i = tid; i < 64 * 16; i += 256) {          // 16 float4 per row
+            const int r = i >> 4, c4 = (i & 15) * 4;
+            *reinterpret_cast<f32x4*>(Ws + m * 64 * KM_WLD + r * KM_WLD + c4) = *reinterpret_cast<const f32x4*>(p.w[m] + r * 64 + c4);
+        }
+    for (int i = tid; i < 64 * p.cin; i += 256) W1s[i] = p.w1[i];
+    if (tid < 64) {
+        Bs[tid] = p.b1[tid];
+#pragma unroll
+        for (int m = 0; m < NL; ++m) Bs[64 * (m + 1) + tid] = p.b[m][tid];
+    }
+}
+
+// first layer on the VALU: z0[kt][t] = b1[f] + sum_c W1[f][c] x[c], f = kt*32 + crow(t, hi)
+template <int CM>
+__device__ __forceinline__ void km_layer0(const float* W1s, const float* Bs, const float (&xr)[CM], int cin, int hi, f32x16 (&z)[2]) {
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int f = kt * 32 + crow(t, hi);
+            float v = Bs[f];
+            const float* wr = W1s + f * cin;
+            if (CM == 4) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr);
+                v += w4[0] * xr[0] + w4[1] * xr[1] + w4[2] * xr[2] + w4[3] * xr[3];
+            } else {
+#pragma unroll
+                for (int c = 0; c < CM; ++c) if (c < cin) v += wr[c] * xr[c];
+            }
+            z[kt][t] = v;
+            if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // keep the scheduler from hoisting all 32 weight-row reads
+        }
+}
+
+// one MFMA layer: acc[io] = b + W * h   (h: [kt][t] fragment registers of this lane's edge)
+__device__ __forceinline__ void km_layer(const float* W, const float* bias, const f32x16 (&h)[2], int li, int hi, f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int io = 0; io < 2; ++io)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[io][r] = bias[io * 32 + crow(r, hi)];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 a[2];
+#pragma unroll
+            for (int io = 0; io < 2; ++io)
+                a[io] = *reinterpret_cast<const f32x4*>(W + (io * 32 + li) * KM_WLD + kt * 32 + 8 * q + 4 * hi);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int io = 0; io < 2; ++io)
+                    acc[io] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[io][s], h[kt][4 * q + s], acc[io], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+}
+
+template <int CM>
+__device__ __forceinline__ void km_load_x(const KMArgs& p, int e, float (&xr)[CM]) {
+    const float* src = p.x + (long)e * p.cin;
+    if (CM == 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+        xr[0] = v[0]; xr[1] = v[1]; xr[2] = v[2]; xr[3] = v[3];
+    } else {
+#pragma unroll
+        for (int c = 0; c < CM; ++c) xr[c] = c < p.cin ? src[c] : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ forward
+template <int NL, int CM>
+__global__ __launch_bounds__(256) void kernel_mlp_fwd_kernel(const KMArgs p) {
+    __shared__ __attribute__((aligned(16))) float Ws[NL * 64 * KM_WLD];
+    __shared__ __attribute__((aligned(16))) float W1s[64 * KM_MAXC];
+    __shared__ float Bs[64 * (NL + 1)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, hi = lane >> 5;
+    km_stage_weights<NL>(p, Ws, W1s, Bs, tid);
+    __syncthreads();
+    const int e0 = (blockIdx.x * 4 + wave) * 32;
+    if (e0 >= p.E) return;
+    const int e = min(e0 + li, p.E - 1);
+    float xr[CM];
+    km_load_x<CM>(p, e, xr);
+    f32x16 z[2], h[2];
+    km_layer0<CM>(W1s, Bs, xr, p.cin, hi, z);
+#pragma unroll
+    for (int m = 0; m < NL; ++m) {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) h[kt][t] = gelu_f(z[kt][t]);
+        km_layer(Ws + m * 64 * KM_WLD, Bs + 64 * (m + 1), h, li, hi, z);
+    }
+    if (e0 + li < p.E) {
+        float* dst = p.out + (long)(e0 + li) * 64;
+#pragma unroll
+        for (int io = 0; io < 2; ++io)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<f32x4*>(dst + io * 32 + 8 * q + 4 * hi) = f32x4{z[io][4 * q], z[io][4 * q + 1], z[io][4 * q + 2], z[io][4 * q + 3]};
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward
+// partial-gradient vector of a workgroup: [m = 0..NL-1] dW_{m+1} [64][64] | dW_1 [64][cin] | db_1 [64] | db_{m+1} [64]
+//
+// A workgroup walks 128-edge tiles; wave w owns edges [32w, 32w+32) of the tile for the recompute and the input-gradient
+// chain (registers only), and QUADRANT (io_w, kt_w) = (w >> 1, w & 1) of every layer's weight gradient over all 128
+// edges (operands from the workgroup's [feature][128 edges] LDS tiles), so its accumulators are 16 registers per layer.
+constexpr int KM_TLD128 = 132;   // floats per row of a [64 features][128 edges] tile
+template <int NL, int CM>
+__global__ __launch_bounds__(256, 1) void kernel_mlp_bwd_kernel(const KMArgs p) {
+    constexpr int WS_FLOATS = NL * 64 * KM_WLD;
+    constexpr int TILE = 64 * KM_TLD128;
+    __shared__ __attribute__((aligned(16))) float Ws[WS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float W1s[64 * KM_MAXC];
+    __shared__ float Bs[64 * (NL + 1)];
+    __shared__ __attribute__((aligned(16))) float Gt[TILE];
+    __shared__ __attribute__((aligned(16))) float Ht[TILE];
+    __shared__ __attribute__((aligned(16))) float Xt[128 * KM_MAXC];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, hi = lane >> 5;
+    const int io_w = wave >> 1, kt_w = wave & 1;
+    const int cin = p.cin;
+    km_stage_weights<NL>(p, Ws, W1s, Bs, tid);
+    __syncthreads();
+
+    f32x16 dW[NL];                       // quadrant (io_w, kt_w): rows = output feature crow(r, hi), column = input feature li
+#pragma unroll
+    for (int m = 0; m < NL; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dW[m][r] = 0.f;
+    float db[NL + 1];                    // feature io_w*32 + li, this half-wave's edges (MFMA layers: kept by kt_w == 0 waves)
+    float dw1[CM];                       // feature io_w*32 + li, edges of half (kt_w) of the tile
+#pragma unroll
+    for (int m = 0; m <= NL; ++m) db[m] = 0.f;
+#pragma unroll
+    for (int c = 0; c < CM; ++c) dw1[c] = 0.f;
+
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        asm volatile("" ::: "memory");      // the weight images are loop-invariant: stop LICM from parking them in 400 registers
+        const int e0 = tile * 128 + wave * 32;
+        const bool valid = e0 + li < p.E;
+        const int e = min(e0 + li, p.E - 1);
+        float xr[CM];
+        km_load_x<CM>(p, e, xr);
+        if (hi == 0) {
+#pragma unroll
+            for (int c = 0; c < CM; ++c) if (c < cin) Xt[(wave * 32 + li) * KM_MAXC + c] = valid ? xr[c] : 0.f;
+        }
+        // recompute the forward chain, keeping the pre-activations of the GELU layers
+        f32x16 z[NL][2];
+        km_layer0<CM>(W1s, Bs, xr, cin, hi, z[0]);
+#pragma unroll
+        for (int m = 1; m < NL; ++m) {
+            f32x16 h[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    h[kt][t] = gelu_f(z[m - 1][kt][t]);
+                    if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+            km_layer(Ws + (m - 1) * 64 * KM_WLD, Bs + 64 * m, h, li, hi, z[m]);
+        }
+        // upstream gradient in fragment layout (zero for edges past the end: they add nothing to any gradient)
+        f32x16 g[2];
+        {
+            const float* src = p.dk + (long)e * 64;
+#pragma unroll
+            for (int io = 0; io < 2; ++io)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(src + io * 32 + 8 * q + 4 * hi);
+                    if (!valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                    g[io][4 * q] = v[0]; g[io][4 * q + 1] = v[1]; g[io][4 * q + 2] = v[2]; g[io][4 * q + 3] = v[3];
+                }
+        }
+        // layers NL .. 1 (layer m: weights Ws[m-1], input H_{m-1} = gelu(Z_{m-1}))
+#pragma unroll
+        for (int m = NL; m >= 1; --m) {
+            // G_m and H_{m-1} -> workgroup tiles [feature][edge]; Z_{m-1} is replaced in place by gelu'(Z_{m-1})
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    float hv, dv;
+                    gelu_both(z[m - 1][kt][t], hv, dv);
+                    z[m - 1][kt][t] = dv;
+                    Ht[(kt * 32 + crow(t, hi)) * KM_TLD128 + wave * 32 + li] = hv;
+                    Gt[(kt * 32 + crow(t, hi)) * KM_TLD128 + wave * 32 + li] = g[kt][t];
+                    if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // bound the erf temporaries in flight
+                }
+            __syncthreads();
+            // dW_m quadrant += G_m[io_w rows] H_{m-1}[kt_w rows]^T over the 128 edges (k = 8q + 4hi + s)
+            {
+                const float* ga = Gt + (io_w * 32 + li) * KM_TLD128 + 4 * hi;
+                const float* hb = Ht + (kt_w * 32 + li) * KM_TLD128 + 4 * hi;
+                float dsum = 0.f;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(ga + 8 * q);
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(hb + 8 * q);
+                    dsum += (a[0] + a[1]) + (a[2] + a[3]);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) dW[m - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], dW[m - 1], 0, 0, 0);
+                    if (q & 1) __builtin_amdgcn_sched_barrier(0);
+                }
+                db[m] += dsum;
+            }
+            // dH_{m-1} = W_m^T G_m  (A = W^T: lane -> input feature, k-slot of half hi = output feature crow(t, hi))
+            f32x16 dh[2];
+#pragma unroll
+            for (int io = 0; io < 2; ++io)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dh[io][r] = 0.f;
+            const float* W = Ws + (m - 1) * 64 * KM_WLD;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const float* wr = W + (kt * 32 + crow(t, hi)) * KM_WLD + li;
+#pragma unroll
+                    for (int io = 0; io < 2; ++io)
+                        dh[io] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[io * 32], g[kt][t], dh[io], 0, 0, 0);
+                    if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+            for (int io = 0; io < 2; ++io)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) g[io][r] = dh[io][r] * z[m - 1][io][r];
+            __syncthreads();          // the tiles are rewritten by the next layer
+        }
+        // first layer: dW_1 = G_0 x^T, db_1: wave (io_w, kt_w) takes feature tile io_w over edge half kt_w of the tile
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) Gt[(kt * 32 + crow(t, hi)) * KM_TLD128 + wave * 32 + li] = g[kt][t];
+        __syncthreads();
+        {
+            const float* ga = Gt + (io_w * 32 + li) * KM_TLD128 + kt_w * 64 + 4 * hi;
+            float dsum = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(ga + 8 * q);
+                dsum += (a[0] + a[1]) + (a[2] + a[3]);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float* xe = Xt + (kt_w * 64 + 8 * q + 4 * hi + s) * KM_MAXC;
+                    if (CM == 4) {
+                        const f32x4 xv = *reinterpret_cast<const f32x4*>(xe);
+                        dw1[0] += a[s] * xv[0]; dw1[1] += a[s] * xv[1]; dw1[2] += a[s] * xv[2]; dw1[3] += a[s] * xv[3];
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < CM; ++c) if (c < cin) dw1[c] += a[s] * xe[c];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            db[0] += dsum;
+        }
+        __syncthreads();
+    }
+
+    // ---- the workgroup's partial: weight-gradient quadrants straight from their owners; the small vectors through LDS
+    float* dst = p.ws + (long)blockIdx.x * p.psize;
+#pragma unroll
+    for (int m = 0; m < NL; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[m * 4096 + (io_w * 32 + crow(r, hi)) * 64 + kt_w * 32 + li] = dW[m][r];
+    float* R = Gt;                                   // [64][cin] dW_1 | db_1 [64] | db_m [64] ...
+    const int off_b = 64 * cin, nsmall = 64 * cin + 64 * (NL + 1);
+#pragma unroll
+    for (int c = 0; c < CM; ++c) dw1[c] += __shfl_xor(dw1[c], 32, 64);       // fold the two half-waves (different edges)
+#pragma unroll
+    for (int m = 0; m <= NL; ++m) db[m] += __shfl_xor(db[m], 32, 64);
+    for (int pass = 0; pass < 2; ++pass) {            // edge half 0 stores, edge half 1 adds
+        if (kt_w == pass && hi == 0) {
+#pragma unroll
+            for (int c = 0; c < CM; ++c)
+                if (c < cin) { float* d = R + (io_w * 32 + li) * cin + c; *d = pass == 0 ? dw1[c] : *d + dw1[c]; }
+            float* d0 = R + off_b + io_w * 32 + li;
+            *d0 = pass == 0 ? db[0] : *d0 + db[0];
+            if (pass == 0) {
+#pragma unroll
+                for (int m = 1; m <= NL; ++m) R[off_b + m * 64 + io_w * 32 + li] = db[m];
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < nsmall; i += 256) dst[NL * 4096 + i] = R[i];
+}
+
+__global__ __launch_bounds__(256) void kernel_mlp_reduce_kernel(const float* __restrict__ ws, int nparts, int psize, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= psize) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = 0;
+    for (; b + 4 <= nparts; b += 4) {
+        s0 += ws[(long)b * psize + i]; s1 += ws[(long)(b + 1) * psize + i];
+        s2 += ws[(long)(b + 2) * psize + i]; s3 += ws[(long)(b + 3) * psize + i];
+    }
+    for (; b < nparts; ++b) s0 += ws[(long)b * psize + i];
+    out[i] = (s0 + s1) + (s2 + s3);
+}
+
+static int km_check(const float* x, int E, int cin, int n_layers, const float* const* w, const float* const* b) {
+    GAOT_REQUIRE(x && E > 0 && cin >= 1 && cin <= KM_MAXC, "kernel_mlp: need x, E > 0 and 1 <= c_in <= %d (got %d)", KM_MAXC, cin);
+    GAOT_REQUIRE(n_layers >= 2 && n_layers <= 4, "kernel_mlp: 2..4 layers (got %d)", n_layers);
+    for (int i = 0; i < n_layers; ++i) GAOT_REQUIRE(w[i] && b[i] && aligned16(w[i]), "kernel_mlp: weights / biases must be non-null, weights 16-byte aligned");
+    if (cin == 4) GAOT_REQUIRE(aligned16(x) && aligned16(w[0]), "kernel_mlp: x and W_1 must be 16-byte aligned for c_in = 4");
+    return GAOT_OK;
+}
+
+static void km_fill(KMArgs& a, const float* x, int E, int cin, int n_layers, const float* const* w, const float* const* b) {
+    a.x = x; a.cin = cin; a.E = E; a.w1 = w[0]; a.b1 = b[0];
+    for (int m = 0; m < 3; ++m) { a.w[m] = m + 1 < n_layers ? w[m + 1] : nullptr; a.b[m] = m + 1 < n_layers ? b[m + 1] : nullptr; }
+    a.ntiles = cdiv(E, 128);
+    a.psize = (n_layers - 1) * 4096 + 64 * cin + 64 * n_layers;
+}
+
+}  // namespace gaot
+
+using namespace gaot;
+
+extern "C" int gaot_kernel_mlp_fwd(const float* x, int32_t E, int32_t cin, int32_t n_layers, const float* const* w,
+                                   const float* const* b, float* out, gaot_stream_t stream) {
+    if (int rc = km_check(x, E, cin, n_layers, w, b)) return rc;
+    GAOT_REQUIRE(out && aligned16(out), "kernel_mlp_fwd: out must be non-null and 16-byte aligned");
+    KMArgs a{}; km_fill(a, x, E, cin, n_layers, w, b); a.out = out;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid(a.ntiles), block(256);
+#define KM_FWD(NL) do { if (cin == 4) hipLaunchKernelGGL((kernel_mlp_fwd_kernel<NL, 4>), grid, block, 0, st, a); \
+                        else hipLaunchKernelGGL((kernel_mlp_fwd_kernel<NL, KM_MAXC>), grid, block, 0, st, a); } while (0)
+    if (n_layers == 2) KM_FWD(1); else if (n_layers == 3) KM_FWD(2); else KM_FWD(3);
+#undef KM_FWD
+    GAOT_CHECK_LAUNCH("gaot_kernel_mlp_fwd");
+    return GAOT_OK;
+}
+
+extern "C" int64_t gaot_kernel_mlp_bwd_workspace(int32_t E, int32_t cin, int32_t n_layers) {
+    const int64_t psize = (int64_t)(n_layers - 1) * 4096 + 64 * cin + 64 * n_layers;
+    int grid = cdiv(E, 128); if (grid > 256) grid = 256;
+    return (int64_t)grid * psize;
+}
+
+extern "C" int gaot_kernel_mlp_bwd(const float* x, int32_t E, int32_t cin, int32_t n_layers, const float* const* w,
+                                   const float* const* b, const float* dk, float* grads, float* workspace, gaot_stream_t stream) {
+    if (int rc = km_check(x, E, cin, n_layers, w, b)) return rc;
+    GAOT_REQUIRE(dk && grads && workspace && aligned16(dk), "kernel_mlp_bwd: dk (16-byte aligned), grads, workspace must be non-null");
+    KMArgs a{}; km_fill(a, x, E, cin, n_layers, w, b); a.dk = dk; a.ws = workspace;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int grid = a.ntiles > 256 ? 256 : a.ntiles;
+#define KM_BWD(NL) do { if (cin == 4) hipLaunchKernelGGL((kernel_mlp_bwd_kernel<NL, 4>), dim3(grid), dim3(256), 0, st, a); \
+                        else hipLaunchKernelGGL((kernel_mlp_bwd_kernel<NL, KM_MAXC>), dim3(grid), dim3(256), 0, st, a); } while (0)
+    if (n_layers == 2) KM_BWD(1); else if (n_layers == 3) KM_BWD(2); else KM_BWD(3);
+#undef KM_BWD
+    hipLaunchKernelGGL(kernel_mlp_reduce_kernel, dim3(cdiv(a.psize, 256)), dim3(256), 0, st, workspace, grid, a.psize, grads);
+    GAOT_CHECK_LAUNCH("gaot_kernel_mlp_bwd");
+    return GAOT_OK;
+}

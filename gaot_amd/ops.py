@@ -65,6 +65,7 @@ def gemm(M: int, N: int, K: int, A, lda, a_kmajor, B, ldb, b_kmajor, out, ldc, *
 
 # tuning switch (tools / A-B runs only): GAOT_GEMM_MODE = argument of gaot_debug_set_gemm_glds (default 1: fp32 MFMA
 # tiles; 4 adds the split-bf16 tiles where the heuristic picks them); the split-K choice below follows it
+_FUSED_KERNEL_MLP = os.environ.get("GAOT_FUSED_KERNEL_MLP", "1") != "0"     # A/B switch for tools; the chain path is also HIP
 _GEMM_MODE = int(os.environ.get("GAOT_GEMM_MODE", "1"))
 if _GEMM_MODE != 1:
     L.load().gaot_debug_set_gemm_glds(_GEMM_MODE)
@@ -407,7 +408,66 @@ class _MLPChain(torch.autograd.Function):
         return (dx, None, *grads)
 
 
+class _KernelMLP(torch.autograd.Function):
+    """Fused kernel MLP over edge rows (csrc/kernel_mlp.hip): x [E, c_in <= 16] -> 64 -> ... -> 64, GELU between layers.
+    One launch forward; backward recomputes the chain and returns every parameter gradient from one launch (+ reduce)."""
+
+    @staticmethod
+    def eligible(x, weights, biases, acts) -> bool:
+        n = len(weights)
+        if not (2 <= n <= 4) or x.dim() != 2 or x.requires_grad or not x.is_cuda or x.shape[0] == 0:
+            return False
+        if list(acts) != ["gelu"] * (n - 1) + ["none"] or any(b is None for b in biases):
+            return False
+        cin = x.shape[1]
+        if cin > 16 or tuple(weights[0].shape) != (64, cin):
+            return False
+        return all(tuple(w.shape) == (64, 64) for w in weights[1:]) and all(tuple(b.shape) == (64,) for b in biases)
+
+    @staticmethod
+    def _ptrs(ts):
+        arr = (C.c_void_p * len(ts))()
+        for i, t in enumerate(ts):
+            arr[i] = t.data_ptr()
+        return arr
+
+    @staticmethod
+    def forward(ctx, x, n, *wb):
+        x = x.contiguous()
+        ws = [w.contiguous() for w in wb[:n]]
+        bs = [b.contiguous() for b in wb[n:]]
+        _dev(x, *ws, *bs)
+        E, cin = x.shape
+        out = torch.empty(E, 64, device=x.device, dtype=torch.float32)
+        L.check(L.load().gaot_kernel_mlp_fwd(_p(x), E, cin, n, _KernelMLP._ptrs(ws), _KernelMLP._ptrs(bs), _p(out), _stream()),
+                "gaot_kernel_mlp_fwd")
+        ctx.save_for_backward(x, *ws, *bs)
+        ctx.n = n
+        return out
+
+    @staticmethod
+    def backward(ctx, dk):
+        n = ctx.n
+        sv = ctx.saved_tensors
+        x, ws, bs = sv[0], list(sv[1:1 + n]), list(sv[1 + n:])
+        E, cin = x.shape
+        lib = L.load()
+        dk = dk.contiguous()
+        psize = (n - 1) * 4096 + 64 * cin + 64 * n
+        grads = torch.empty(psize, device=x.device, dtype=torch.float32)
+        wsp = torch.empty(int(lib.gaot_kernel_mlp_bwd_workspace(E, cin, n)), device=x.device, dtype=torch.float32)
+        L.check(lib.gaot_kernel_mlp_bwd(_p(x), E, cin, n, _KernelMLP._ptrs(ws), _KernelMLP._ptrs(bs), _p(dk), _p(grads), _p(wsp),
+                                        _stream()), "gaot_kernel_mlp_bwd")
+        o = (n - 1) * 4096
+        dws = [grads[o:o + 64 * cin].view(64, cin)] + [grads[m * 4096:(m + 1) * 4096].view(64, 64) for m in range(n - 1)]
+        ob = o + 64 * cin
+        dbs = [grads[ob + 64 * i:ob + 64 * (i + 1)] for i in range(n)]
+        return (None, None, *dws, *dbs)
+
+
 def mlp_chain(x, weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]], acts: Sequence[str]):
+    if _FUSED_KERNEL_MLP and _KernelMLP.eligible(x, weights, biases, acts):
+        return _KernelMLP.apply(x, len(weights), *weights, *biases)
     wb = []
     for w, b in zip(weights, biases):
         wb += [w, b]
