@@ -37,7 +37,7 @@ struct KMArgs {
 
 __device__ __forceinline__ void gelu_both(float z, float& h, float& d) {
     const float cdf = 0.5f * (1.0f + erf_nb(z * 0.70710678118654752440f));
-    const float pdf = 0.39894228040143267794f * __expf(-0.5f * z * z);
+    const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * z * z);
     h = z * cdf;
     d = cdf + z * pdf;
 }
@@ -236,17 +236,33 @@ __global__ __launch_bounds__(256, 1) void kernel_mlp_bwd_kernel(const KMArgs p) 
         // layers NL .. 1 (layer m: weights Ws[m-1], input H_{m-1} = gelu(Z_{m-1}))
 #pragma unroll
         for (int m = NL; m >= 1; --m) {
-            // G_m and H_{m-1} -> workgroup tiles [feature][edge]; Z_{m-1} is replaced in place by gelu'(Z_{m-1})
+            // (1) G_m -> workgroup tile.  (2) dH_{m-1} = W_m^T G_m straight from registers: 64 MFMAs with nothing but weight
+            // reads around them, so the H_{m-1} = gelu(Z_{m-1}) / gelu'(Z_{m-1}) evaluation (VALU, independent) is issued in
+            // their shadow; Z_{m-1} is replaced in place by gelu'.  (3) H tile, workgroup sync, dW_m quadrant on MFMA.
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) Gt[(kt * 32 + crow(t, hi)) * KM_TLD128 + wave * 32 + li] = g[kt][t];
+            f32x16 dh[2];
+#pragma unroll
+            for (int io = 0; io < 2; ++io)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dh[io][r] = 0.f;
+            const float* W = Ws + (m - 1) * 64 * KM_WLD;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int t = 0; t < 16; ++t) {
+                    const float* wr = W + (kt * 32 + crow(t, hi)) * KM_WLD + li;
+#pragma unroll
+                    for (int io = 0; io < 2; ++io)
+                        dh[io] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[io * 32], g[kt][t], dh[io], 0, 0, 0);
+                    // one GELU pair per MFMA pair (same element index: its Z is dead for the MFMAs)
                     float hv, dv;
                     gelu_both(z[m - 1][kt][t], hv, dv);
                     z[m - 1][kt][t] = dv;
                     Ht[(kt * 32 + crow(t, hi)) * KM_TLD128 + wave * 32 + li] = hv;
-                    Gt[(kt * 32 + crow(t, hi)) * KM_TLD128 + wave * 32 + li] = g[kt][t];
-                    if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // bound the erf temporaries in flight
+                    if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
             __syncthreads();
             // dW_m quadrant += G_m[io_w rows] H_{m-1}[kt_w rows]^T over the 128 edges (k = 8q + 4hi + s)
@@ -265,23 +281,6 @@ __global__ __launch_bounds__(256, 1) void kernel_mlp_bwd_kernel(const KMArgs p) 
                 }
                 db[m] += dsum;
             }
-            // dH_{m-1} = W_m^T G_m  (A = W^T: lane -> input feature, k-slot of half hi = output feature crow(t, hi))
-            f32x16 dh[2];
-#pragma unroll
-            for (int io = 0; io < 2; ++io)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dh[io][r] = 0.f;
-            const float* W = Ws + (m - 1) * 64 * KM_WLD;
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    const float* wr = W + (kt * 32 + crow(t, hi)) * KM_WLD + li;
-#pragma unroll
-                    for (int io = 0; io < 2; ++io)
-                        dh[io] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[io * 32], g[kt][t], dh[io], 0, 0, 0);
-                    if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-                }
 #pragma unroll
             for (int io = 0; io < 2; ++io)
 #pragma unroll
@@ -349,16 +348,18 @@ __global__ __launch_bounds__(256, 1) void kernel_mlp_bwd_kernel(const KMArgs p) 
 }
 
 __global__ __launch_bounds__(256) void kernel_mlp_reduce_kernel(const float* __restrict__ ws, int nparts, int psize, float* __restrict__ out) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= psize) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int b = 0;
-    for (; b + 4 <= nparts; b += 4) {
-        s0 += ws[(long)b * psize + i]; s1 += ws[(long)(b + 1) * psize + i];
-        s2 += ws[(long)(b + 2) * psize + i]; s3 += ws[(long)(b + 3) * psize + i];
+    // 64 columns per workgroup, the partials dealt round-robin to 4 row groups (fixed order: deterministic)
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    float s0 = 0.f, s1 = 0.f;
+    if (col < psize) {
+        int b = grp;
+        for (; b + 4 < nparts; b += 8) { s0 += ws[(long)b * psize + col]; s1 += ws[(long)(b + 4) * psize + col]; }
+        if (b < nparts) s0 += ws[(long)b * psize + col];
     }
-    for (; b < nparts; ++b) s0 += ws[(long)b * psize + i];
-    out[i] = (s0 + s1) + (s2 + s3);
+    red[grp][threadIdx.x & 63] = s0 + s1;
+    __syncthreads();
+    if (grp == 0 && col < psize) out[col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 static int km_check(const float* x, int E, int cin, int n_layers, const float* const* w, const float* const* b) {
@@ -412,7 +413,7 @@ extern "C" int gaot_kernel_mlp_bwd(const float* x, int32_t E, int32_t cin, int32
                         else hipLaunchKernelGGL((kernel_mlp_bwd_kernel<NL, KM_MAXC>), dim3(grid), dim3(256), 0, st, a); } while (0)
     if (n_layers == 2) KM_BWD(1); else if (n_layers == 3) KM_BWD(2); else KM_BWD(3);
 #undef KM_BWD
-    hipLaunchKernelGGL(kernel_mlp_reduce_kernel, dim3(cdiv(a.psize, 256)), dim3(256), 0, st, workspace, grid, a.psize, grads);
+    hipLaunchKernelGGL(kernel_mlp_reduce_kernel, dim3(cdiv(a.psize, 64)), dim3(256), 0, st, workspace, grid, a.psize, grads);
     GAOT_CHECK_LAUNCH("gaot_kernel_mlp_bwd");
     return GAOT_OK;
 }
