@@ -33,6 +33,7 @@ struct KMArgs {
     float* ws;             // backward: per-workgroup partial gradients [grid][psize]
     int psize;
     int ntiles;            // 128-edge tiles
+    int abl;               // tuning only (gaot_debug_set_kernel_mlp_ablate): forward 1 = no stores, 2 = no GELU, 4 = no MFMA layers, 8 = no weight staging
 };
 
 __device__ __forceinline__ void gelu_both(float z, float& h, float& d) {
@@ -106,7 +107,6 @@ __device__ __forceinline__ void km_layer(const float* W, const float* bias, cons
 #pragma unroll
                 for (int io = 0; io < 2; ++io)
                     acc[io] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[io][s], h[kt][4 * q + s], acc[io], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
         }
 }
 
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void kernel_mlp_fwd_kernel(const KMArgs p) {
     __shared__ float Bs[64 * (NL + 1)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, hi = lane >> 5;
-    km_stage_weights<NL>(p, Ws, W1s, Bs, tid);
+    if (!(p.abl & 8)) km_stage_weights<NL>(p, Ws, W1s, Bs, tid);
     __syncthreads();
     const int e0 = (blockIdx.x * 4 + wave) * 32;
     if (e0 >= p.E) return;
@@ -144,10 +144,11 @@ __global__ __launch_bounds__(256) void kernel_mlp_fwd_kernel(const KMArgs p) {
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int t = 0; t < 16; ++t) h[kt][t] = gelu_f(z[kt][t]);
-        km_layer(Ws + m * 64 * KM_WLD, Bs + 64 * (m + 1), h, li, hi, z);
+            for (int t = 0; t < 16; ++t) h[kt][t] = (p.abl & 2) ? z[kt][t] : gelu_f(z[kt][t]);
+        if (p.abl & 4) { z[0] = h[0]; z[1] = h[1]; }
+        else km_layer(Ws + m * 64 * KM_WLD, Bs + 64 * (m + 1), h, li, hi, z);
     }
-    if (e0 + li < p.E) {
+    if (e0 + li < p.E && (!(p.abl & 1) || z[0][0] == 123.456f)) {
         float* dst = p.out + (long)(e0 + li) * 64;
 #pragma unroll
         for (int io = 0; io < 2; ++io)
@@ -277,7 +278,6 @@ __global__ __launch_bounds__(256, 1) void kernel_mlp_bwd_kernel(const KMArgs p) 
                     dsum += (a[0] + a[1]) + (a[2] + a[3]);
 #pragma unroll
                     for (int s = 0; s < 4; ++s) dW[m - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], dW[m - 1], 0, 0, 0);
-                    if (q & 1) __builtin_amdgcn_sched_barrier(0);
                 }
                 db[m] += dsum;
             }
@@ -370,16 +370,20 @@ static int km_check(const float* x, int E, int cin, int n_layers, const float* c
     return GAOT_OK;
 }
 
+static int g_km_abl = 0;
 static void km_fill(KMArgs& a, const float* x, int E, int cin, int n_layers, const float* const* w, const float* const* b) {
     a.x = x; a.cin = cin; a.E = E; a.w1 = w[0]; a.b1 = b[0];
     for (int m = 0; m < 3; ++m) { a.w[m] = m + 1 < n_layers ? w[m + 1] : nullptr; a.b[m] = m + 1 < n_layers ? b[m + 1] : nullptr; }
     a.ntiles = cdiv(E, 128);
+    a.abl = g_km_abl;
     a.psize = (n_layers - 1) * 4096 + 64 * cin + 64 * n_layers;
 }
 
 }  // namespace gaot
 
 using namespace gaot;
+
+extern "C" int gaot_debug_set_kernel_mlp_ablate(int bits) { const int old = g_km_abl; g_km_abl = bits; return old; }
 
 extern "C" int gaot_kernel_mlp_fwd(const float* x, int32_t E, int32_t cin, int32_t n_layers, const float* const* w,
                                    const float* const* b, float* out, gaot_stream_t stream) {

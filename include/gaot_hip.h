@@ -200,6 +200,8 @@ int gaot_batchsum(const float* x, int32_t B, int64_t RN, float* out, gaot_stream
  * per-workgroup partials summed in fixed order).  x gets no gradient (edge coordinates). */
 int gaot_kernel_mlp_fwd(const float* x, int32_t E, int32_t c_in, int32_t n_layers, const float* const* w,
                         const float* const* b, float* out, gaot_stream_t stream);
+/* tuning hook (results become WRONG): forward kernel 1 = no stores, 2 = no GELU, 4 = no MFMA layers, 8 = no weight staging */
+int gaot_debug_set_kernel_mlp_ablate(int bits);
 int64_t gaot_kernel_mlp_bwd_workspace(int32_t E, int32_t c_in, int32_t n_layers);
 int gaot_kernel_mlp_bwd(const float* x, int32_t E, int32_t c_in, int32_t n_layers, const float* const* w,
                         const float* const* b, const float* dk, float* grads, float* workspace, gaot_stream_t stream);
