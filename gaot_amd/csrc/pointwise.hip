@@ -232,6 +232,32 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
     __syncthreads();
     if (wave == 0 && n < N) out[n] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
 }
+// short matrices (M <= 1024 rows, e.g. per-workgroup partial rows): ONE launch; 64 columns per workgroup as 16 float4
+// lanes x 16 row groups, unrolled x4 so every thread has 4 independent 16-byte loads in flight, fixed-order LDS sum
+__global__ __launch_bounds__(256) void colsum_small_kernel(const float* __restrict__ x, int M, int N, float* __restrict__ out) {
+    __shared__ f32x4 red[16][16];
+    const int c4 = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int n = blockIdx.x * 64 + c4 * 4;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    if (n < N) {
+        int r = rg;
+        for (; r + 48 < M; r += 64) {
+            s0 += *reinterpret_cast<const f32x4*>(x + (long)r * N + n);
+            s1 += *reinterpret_cast<const f32x4*>(x + (long)(r + 16) * N + n);
+            s2 += *reinterpret_cast<const f32x4*>(x + (long)(r + 32) * N + n);
+            s3 += *reinterpret_cast<const f32x4*>(x + (long)(r + 48) * N + n);
+        }
+        for (; r < M; r += 16) s0 += *reinterpret_cast<const f32x4*>(x + (long)r * N + n);
+    }
+    red[rg][c4] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rg == 0 && n < N) {
+        f32x4 t = red[0][c4];
+#pragma unroll
+        for (int g = 1; g < 16; ++g) t += red[g][c4];
+        *reinterpret_cast<f32x4*>(out + n) = t;
+    }
+}
 __global__ void batchsum_kernel(const float* __restrict__ x, int B, long RN, float* __restrict__ out) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < RN; i += (long)gridDim.x * blockDim.x) {
         float s = 0.f;
@@ -398,6 +424,11 @@ extern "C" int64_t gaot_colsum_scratch(int32_t M, int32_t N) { return (int64_t)c
 extern "C" int gaot_colsum(const float* x, int64_t ld, int32_t M, int32_t N, float* out, float* scratch,
                            gaot_stream_t stream) {
     GAOT_REQUIRE(x && out && scratch && M > 0 && N > 0, "colsum: bad arguments");
+    if (M <= 1024 && ld == N && N % 4 == 0 && aligned16(x) && aligned16(out)) {   // per-workgroup partial rows of the norm-weight gradients
+        hipLaunchKernelGGL(colsum_small_kernel, dim3(cdiv(N, 64)), dim3(256), 0, ST(stream), x, M, N, out);
+        GAOT_CHECK_LAUNCH("gaot_colsum");
+        return GAOT_OK;
+    }
     const int P = colsum_chunks(M, N);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 64), P), dim3(256), 0, ST(stream), x, (long)ld, M, N, P, scratch);
     hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 64)), dim3(256), 0, ST(stream), scratch, P, N, out);
@@ -422,6 +453,55 @@ extern "C" int gaot_patchify(const float* in, int32_t B, int32_t H, int32_t W, i
     else
         hipLaunchKernelGGL(patchify_kernel, dim3(cap_blocks(total, 256, 8192)), dim3(256), 0, ST(stream), in, out, B, H, W, Dz, P, C, inverse);
     GAOT_CHECK_LAUNCH("gaot_patchify");
+    return GAOT_OK;
+}
+
+// ---------------------------------------------------------------- MSE loss (base_trainer.py:71 nn.MSELoss(), mean reduction)
+__global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restrict__ p, const float* __restrict__ y, long n, float* __restrict__ part) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const long n4 = n / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(p)[i], b = reinterpret_cast<const f32x4*>(y)[i];
+        const f32x4 d = a - b;
+        s += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) { const float d = p[n4 * 4 + threadIdx.x] - y[n4 * 4 + threadIdx.x]; s += d * d; }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(64) void mse_final_kernel(const float* __restrict__ part, int nparts, float inv_n, float* __restrict__ loss) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 64) s += part[i];      // fixed assignment + fixed-order butterfly: deterministic
+    s = wave_sum(s);
+    if (threadIdx.x == 0) loss[0] = s * inv_n;
+}
+__global__ void mse_bwd_kernel(const float* __restrict__ p, const float* __restrict__ y, long n, const float* __restrict__ gout, float two_over_n,
+                               float* __restrict__ dp) {
+    const float c = two_over_n * gout[0];
+    const long n4 = n / 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(p)[i], b = reinterpret_cast<const f32x4*>(y)[i];
+        reinterpret_cast<f32x4*>(dp)[i] = (a - b) * c;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) dp[n4 * 4 + threadIdx.x] = (p[n4 * 4 + threadIdx.x] - y[n4 * 4 + threadIdx.x]) * c;
+}
+static int mse_blocks(int64_t n) { long b = (n / 4 + 1023) / 1024; return (int)(b < 1 ? 1 : (b > 256 ? 256 : b)); }
+
+extern "C" int gaot_mse_loss_fwd(const float* pred, const float* target, int64_t n, float* partial, float* loss, gaot_stream_t stream) {
+    GAOT_REQUIRE(pred && target && partial && loss && n > 0 && aligned16(pred) && aligned16(target), "mse_loss_fwd: bad arguments (16-byte aligned inputs, partial[256])");
+    const int nb = mse_blocks(n);
+    hipLaunchKernelGGL(mse_partial_kernel, dim3(nb), dim3(256), 0, ST(stream), pred, target, (long)n, partial);
+    hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(64), 0, ST(stream), partial, nb, 1.0f / (float)n, loss);
+    GAOT_CHECK_LAUNCH("gaot_mse_loss_fwd");
+    return GAOT_OK;
+}
+extern "C" int gaot_mse_loss_bwd(const float* pred, const float* target, int64_t n, const float* grad_loss, float* dpred, gaot_stream_t stream) {
+    GAOT_REQUIRE(pred && target && grad_loss && dpred && n > 0 && aligned16(pred) && aligned16(target) && aligned16(dpred), "mse_loss_bwd: bad arguments");
+    hipLaunchKernelGGL(mse_bwd_kernel, dim3(cap_blocks(n / 4 + 1, 256, 1024)), dim3(256), 0, ST(stream), pred, target, (long)n, grad_loss, 2.0f / (float)n, dpred);
+    GAOT_CHECK_LAUNCH("gaot_mse_loss_bwd");
     return GAOT_OK;
 }
 

@@ -408,6 +408,32 @@ class _MLPChain(torch.autograd.Function):
         return (dx, None, *grads)
 
 
+class _MSELoss(torch.autograd.Function):
+    """nn.MSELoss() (mean) of the reference trainers (base_trainer.py:71): two small launches forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        _dev(pred, target)
+        p, t = pred.contiguous(), target.contiguous()
+        assert p.shape == t.shape, (p.shape, t.shape)
+        part = torch.empty(256, device=p.device, dtype=torch.float32)
+        loss = torch.empty((), device=p.device, dtype=torch.float32)
+        L.check(L.load().gaot_mse_loss_fwd(_p(p), _p(t), p.numel(), _p(part), _p(loss), _stream()), "gaot_mse_loss_fwd")
+        ctx.save_for_backward(p, t)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gl):
+        p, t = ctx.saved_tensors
+        dp = torch.empty_like(p)
+        L.check(L.load().gaot_mse_loss_bwd(_p(p), _p(t), p.numel(), _p(gl.contiguous()), _p(dp), _stream()), "gaot_mse_loss_bwd")
+        return dp, None
+
+
+def mse_loss(pred, target):
+    return _MSELoss.apply(pred, target)
+
+
 class _KernelMLP(torch.autograd.Function):
     """Fused kernel MLP over edge rows (csrc/kernel_mlp.hip): x [E, c_in <= 16] -> 64 -> ... -> 64, GELU between layers.
     One launch forward; backward recomputes the chain and returns every parameter gradient from one launch (+ reduce)."""

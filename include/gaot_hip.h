@@ -205,6 +205,11 @@ int gaot_debug_set_kernel_mlp_ablate(int bits);
 int64_t gaot_kernel_mlp_bwd_workspace(int32_t E, int32_t c_in, int32_t n_layers);
 int gaot_kernel_mlp_bwd(const float* x, int32_t E, int32_t c_in, int32_t n_layers, const float* const* w,
                         const float* const* b, const float* dk, float* grads, float* workspace, gaot_stream_t stream);
+/* nn.MSELoss() with mean reduction (the reference trainers' loss, base_trainer.py:71): loss[0] = mean((pred - target)^2) over
+ * n elements through `partial` (>= 256 floats; fixed-order two-stage sum, deterministic); backward
+ * dpred = 2 (pred - target) / n * grad_loss[0] with grad_loss a DEVICE scalar (so the launch replays inside a hipGraph). */
+int gaot_mse_loss_fwd(const float* pred, const float* target, int64_t n, float* partial, float* loss, gaot_stream_t stream);
+int gaot_mse_loss_bwd(const float* pred, const float* target, int64_t n, const float* grad_loss, float* dpred, gaot_stream_t stream);
 /* One AdamW update over flat fp32 buffers with torch.optim.AdamW semantics (the reference's optimizer, optimizers.py:196;
  * defaults beta = (0.9, 0.999), eps = 1e-8).  step[1] is a DEVICE counter (float) advanced by the call itself, so the launch
  * replays inside a hipGraph. */

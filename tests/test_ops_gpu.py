@@ -315,8 +315,11 @@ def test_patchify_roundtrip(sizes, P, C):
 
 def test_reductions():
     from gaot_amd import ops
-    x = torch.randn(1000, 70)
-    assert rel(ops.colsum(x.to(dev())), x.double().sum(0)) < 2e-6
+    for shape in [(1000, 72), (256, 256), (37, 4), (1000, 70)]:
+        x = torch.randn(*shape)
+        assert rel(ops.colsum(x.to(dev())), x.double().sum(0)) < 2e-6      # short matrix: single launch when N % 4 == 0
+    x = torch.randn(5000, 70)
+    assert rel(ops.colsum(x.to(dev())), x.double().sum(0)) < 2e-6          # two-stage path
     y = torch.randn(5, 33, 7)
     assert rel(ops.batchsum(y.to(dev()), 5), y.double().sum(0)) < 2e-6
 
@@ -519,3 +522,19 @@ def test_branch_free_erf_accuracy():
     cdf = 0.5 * (1.0 + torch.erf(xd * 0.70710678118654752440))
     dref = cdf + xd * torch.exp(-0.5 * xd * xd) * 0.3989422804014327
     assert float((dx.double().cpu() - dref).abs().max()) < 4e-7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(8, 16384, 1), (3, 1001, 2), (1, 5, 1)])
+def test_mse_loss_kernel(shape):
+    """nn.MSELoss() (mean) as two small launches forward, one backward, with a device-scalar upstream gradient."""
+    from gaot_amd import ops
+    torch.manual_seed(sum(shape))
+    p = torch.randn(*shape, device="cuda", requires_grad=True)
+    y = torch.randn(*shape, device="cuda")
+    loss = ops.mse_loss(p, y)
+    (g,) = torch.autograd.grad(loss * 3.0, p)
+    pd, yd = p.detach().double().cpu(), y.double().cpu()
+    assert abs(float(loss) - float(((pd - yd) ** 2).mean())) < 1e-6 * float(((pd - yd) ** 2).mean())
+    assert rel(g, 3.0 * 2.0 * (pd - yd) / pd.numel()) < 1e-6
+    assert float(ops.mse_loss(p, y)) == float(loss)          # deterministic
