@@ -37,6 +37,7 @@ class FlatGradBucket:
         """`groups`: lists of parameters that must sit back to back (in the given order, no padding) so that a fused
         GEMM can read them as ONE matrix (q|k|v, w1|w3: ops.adjacent_rows) instead of concatenating every step."""
         params = [p for p in params if p.requires_grad]
+        self.model_order = list(params)           # the order torch optimizers index parameters by (checkpoint compatibility)
         pos = {id(p): i for i, p in enumerate(params)}
         follow, skip = {}, set()
         for g in groups or []:
@@ -111,6 +112,43 @@ class FlatAdamW:
         self.m = torch.zeros_like(self.flat_p)
         self.v = torch.zeros_like(self.flat_p)
         self.step_count = torch.zeros(1, dtype=torch.float32, device=self.flat_p.device)
+
+    # ---- checkpoint compatibility with torch.optim.AdamW (what the reference's save_ckpt / load_ckpt move around,
+    # trainer_utils.py:23-92 with optimizers.py:196): same state_dict layout, parameters indexed in model order
+    def _views(self, flat):
+        off = {id(p): o for p, o in zip(self.bucket.params, self.bucket.offsets)}
+        return [flat[off[id(p)]:off[id(p)] + p.numel()].view_as(p) for p in self.bucket.model_order]
+
+    def state_dict(self):
+        order = self.bucket.model_order
+        ref = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=self.lr, betas=self.betas, eps=self.eps,
+                                weight_decay=self.wd)
+        group = dict(ref.param_groups[0])          # every key this torch version expects, with AdamW's defaults
+        group["params"] = list(range(len(order)))
+        step = float(self.step_count.item())
+        state = {}
+        if step > 0:
+            for i, (m, v) in enumerate(zip(self._views(self.m), self._views(self.v))):
+                state[i] = {"step": torch.tensor(step), "exp_avg": m.clone(), "exp_avg_sq": v.clone()}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(self.bucket.model_order):
+            raise ValueError("FlatAdamW.load_state_dict: expected one parameter group covering every trainable parameter")
+        g = groups[0]
+        self.lr, self.wd, self.eps = float(g["lr"]), float(g["weight_decay"]), float(g["eps"])
+        self.betas = tuple(float(b) for b in g["betas"])
+        steps = {float(st["step"]) for st in sd["state"].values()}
+        if len(steps) > 1:
+            raise ValueError("FlatAdamW.load_state_dict: per-parameter step counts differ; the flat update has one counter")
+        with torch.no_grad():
+            self.m.zero_(); self.v.zero_()
+            for i, (m, v) in enumerate(zip(self._views(self.m), self._views(self.v))):
+                st = sd["state"].get(i, sd["state"].get(str(i)))
+                if st is not None:
+                    m.copy_(st["exp_avg"]); v.copy_(st["exp_avg_sq"])
+            self.step_count.fill_(steps.pop() if steps else 0.0)
 
     def step(self):
         from . import _lib as L

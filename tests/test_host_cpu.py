@@ -142,3 +142,54 @@ def test_edge_drop_semantics():
     out = apply_edge_drop_csr(nb, "ratio", sample_ratio=0.5)
     assert int(out["neighbors_row_splits"][-1]) == out["neighbors_index"].numel() <= idx.numel()
     assert apply_edge_drop_csr(nb, "ratio", sample_ratio=1.0) is nb
+
+
+def test_flat_adamw_state_dict_is_torch_adamw_compatible(tmp_path):
+    """FlatAdamW.state_dict() has torch.optim.AdamW's layout (parameters indexed in MODEL order even though fused groups
+    are stored back to back), so the reference's save_ckpt / load_ckpt files (trainer_utils.py:23-92) interchange."""
+    from gaot_amd.trainer import FlatGradBucket, FlatAdamW
+    from gaot_amd.checkpoint import save_ckpt, load_ckpt
+    torch.manual_seed(0)
+    lin = torch.nn.ModuleList([torch.nn.Linear(8, n, bias=(n == 12)) for n in (4, 12, 4, 8)])
+    params = list(lin.parameters())
+    bucket = FlatGradBucket(params, groups=[[lin[0].weight, lin[2].weight, lin[3].weight]])     # storage order != model order
+    opt = FlatAdamW(bucket, lr=3e-4, weight_decay=1e-5)
+    before = [p.detach().clone() for p in params]
+    assert all(torch.equal(a, p) for a, p in zip(before, params))                               # re-pointing kept the values
+    opt.m.copy_(torch.randn_like(opt.m)); opt.v.copy_(torch.rand_like(opt.v)); opt.step_count.fill_(7.0)
+    sd = opt.state_dict()
+    ref = torch.optim.AdamW([torch.nn.Parameter(p.detach().clone()) for p in params], lr=1.0)
+    ref.load_state_dict(sd)                                                                     # torch accepts the layout
+    assert ref.param_groups[0]["lr"] == 3e-4 and ref.param_groups[0]["weight_decay"] == 1e-5
+    off = {id(p): o for p, o in zip(bucket.params, bucket.offsets)}
+    for i, p in enumerate(params):
+        st = ref.state[ref.param_groups[0]["params"][i]]
+        assert float(st["step"]) == 7.0
+        assert torch.equal(st["exp_avg"], opt.m[off[id(p)]:off[id(p)] + p.numel()].view_as(p))
+        assert torch.equal(st["exp_avg_sq"], opt.v[off[id(p)]:off[id(p)] + p.numel()].view_as(p))
+    # and back: a torch AdamW state loads into the flat buffers; through a checkpoint file with the model next to it
+    path = str(tmp_path / "ck.pt")
+    save_ckpt(path, model=lin, optimizer=ref)
+    opt2 = FlatAdamW(FlatGradBucket(list(lin.parameters()), groups=[[lin[0].weight, lin[2].weight, lin[3].weight]]), lr=1.0, weight_decay=0.0)
+    wrapped = torch.nn.DataParallel(lin) if False else lin
+    load_ckpt(path, model=wrapped, optimizer=opt2)
+    assert opt2.lr == 3e-4 and opt2.wd == 1e-5 and float(opt2.step_count) == 7.0
+    for a, b in zip(opt2._views(opt2.m) + opt2._views(opt2.v), opt._views(opt.m) + opt._views(opt.v)):
+        assert torch.equal(a, b)                                                                # (alignment padding is not state)
+
+
+def test_load_ckpt_reconciles_module_prefix(tmp_path):
+    from gaot_amd.checkpoint import save_ckpt, load_ckpt
+    src = torch.nn.Linear(3, 2)
+    class Wrap(torch.nn.Module):
+        def __init__(self, m):
+            super().__init__(); self.module = m
+    path = str(tmp_path / "w.pt")
+    save_ckpt(path, model=Wrap(src))                       # keys 'module.weight', 'module.bias' (DDP-style file)
+    dst = torch.nn.Linear(3, 2)
+    load_ckpt(path, model=dst)
+    assert torch.equal(dst.weight, src.weight) and torch.equal(dst.bias, src.bias)
+    save_ckpt(path, model=src)
+    w = Wrap(torch.nn.Linear(3, 2))
+    load_ckpt(path, model=w)
+    assert torch.equal(w.module.weight, src.weight)

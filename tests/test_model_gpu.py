@@ -230,3 +230,40 @@ def test_trainstep_flat_adamw_matches_reference_weights():
     for (k, a), (_, b) in zip(m_a.named_parameters(), m_b.named_parameters()):
         assert float((a.detach() - b.detach()).abs().max()) < 2e-5, k
     assert list(m_a.state_dict().keys()) == list(g.state_dict.keys())
+
+
+@pytest.mark.gpu
+def test_checkpoint_interchange_with_torch_adamw(tmp_path):
+    """Resume across implementations (reference save_ckpt / load_ckpt, trainer_utils.py:23-92): two steps with the flat HIP
+    AdamW, checkpoint {model, optimizer}, load into a twin model + torch.optim.AdamW, a third step on each -> same weights;
+    and the other direction."""
+    from gaot_amd.trainer import TrainStep
+    from gaot_amd.checkpoint import save_ckpt, load_ckpt
+    g = Golden("fx2d_base")
+    lat, x, p, tgt = [g.t(k).to(dev()) for k in ("in.latent", "in.xcoord", "in.pndata", "in.target")]
+    m_a, m_b, m_c = build_model(g), build_model(g), build_model(g)
+    for m in (m_a, m_b, m_c):
+        m.train()
+        seed_neighbor_cache(m, g, x, lat)
+    ts = TrainStep(m_a, lr=8e-4, weight_decay=1e-5, use_graph=False)
+    ts.bind(p, tgt, latent_tokens_coord=lat, xcoord=x)
+    ts.step(); ts.step()
+    path = str(tmp_path / "resume.pt")
+    save_ckpt(path, model=m_a, optimizer=ts.opt)
+    opt_b = torch.optim.AdamW(m_b.parameters(), lr=1.0)
+    load_ckpt(path, map_location=dev(), model=m_b, optimizer=opt_b)
+    ts.step()
+    opt_b.zero_grad()
+    torch.nn.functional.mse_loss(m_b(latent_tokens_coord=lat, xcoord=x, pndata=p), tgt).backward()
+    opt_b.step()
+    for (k, a), (_, b) in zip(m_a.named_parameters(), m_b.named_parameters()):
+        assert float((a.detach() - b.detach()).abs().max()) < 2e-5, k
+    # torch -> flat: resume m_c from the torch-side state after that third step, take a fourth step on both
+    save_ckpt(path, model=m_b, optimizer=opt_b)
+    ts_c = TrainStep(m_c, lr=1.0, weight_decay=0.0, use_graph=False)
+    ts_c.bind(p, tgt, latent_tokens_coord=lat, xcoord=x)
+    load_ckpt(path, map_location=dev(), model=m_c, optimizer=ts_c.opt)
+    ts_c.step()
+    ts.step()
+    for (k, a), (_, c) in zip(m_a.named_parameters(), m_c.named_parameters()):
+        assert float((a.detach() - c.detach()).abs().max()) < 2e-5, k
