@@ -89,13 +89,15 @@ def gemm_roofline(ts):
     n_split = sum(1 for r in records if r[4] == 3)
     ms = sum(r[0].elapsed_time(r[1]) for r in mfma)
     flops = sum(r[2] for r in mfma)
+    abytes = sum(4.0 * (r[3][0] * r[3][2] + r[3][1] * r[3][2] + r[3][0] * r[3][1]) for r in mfma)   # A + B + C touched once
     ms_all = sum(r[0].elapsed_time(r[1]) for r in records)
     if os.environ.get("GAOT_BENCH_GEMM_TABLE"):
         rows = sorted(((r[0].elapsed_time(r[1]) * 1e3, r[2], r[3]) for r in records), key=lambda t: -t[0])
         for us, fl, (M, N, K, ak, bk, sk) in rows:
             print(f"# gemm M={M:6d} N={N:5d} K={K:6d} a_k={ak} b_k={bk} split={sk:3d} {us:8.1f}us {fl / us / 1e6:6.1f}TF", file=sys.stderr)
     return {"launches": len(mfma), "flops": flops, "ms": ms, "tflops": flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
-            "skinny_launches": len(records) - len(mfma), "all_gemm_ms": ms_all, "split_launches": n_split}
+            "skinny_launches": len(records) - len(mfma), "all_gemm_ms": ms_all, "split_launches": n_split,
+            "alg_bytes_per_launch": abytes / max(1, len(mfma))}
 
 
 def recorded_traffic():
@@ -216,8 +218,9 @@ def main():
                          "split_bf16_launches_per_step": roof["split_launches"],
                          "achieved": roof["tflops"], "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": roof["tflops"] / PEAK_F32_MATRIX_TFLOPS, "traffic": recorded_traffic(),
-                         "traffic_note": "HBM bytes per launch, PMC FETCH_SIZE(x2, gfx950)+WRITE_SIZE from profiles/r1_gemm_traffic.json; "
-                                         "algorithmic operand bytes per launch (A+B+C once) = 31.5e6",
+                         "traffic_note": "HBM bytes per launch, PMC FETCH_SIZE(x2, gfx950)+WRITE_SIZE from profiles/r1_gemm_traffic.json "
+                                         "(separate --pmc passes over the same launches, eager step)",
+                         "algorithmic_bytes_per_launch": roof["alg_bytes_per_launch"],
                          "launches_per_step": roof["launches"], "gflop_per_step": roof["flops"] / 1e9,
                          "kernel_ms_per_step": roof["ms"], "avg_launch_us": 1e3 * roof["ms"] / max(1, roof["launches"]),
                          "skinny_valu_launches_per_step": roof["skinny_launches"], "all_gemm_entry_ms_per_step": roof["all_gemm_ms"]},
