@@ -505,6 +505,160 @@ extern "C" int gaot_gno_edge_grad(const float* dout, const float* f, int32_t B, 
     return GAOT_OK;
 }
 
+// ---------------------------------------------------------------- lifting fused into the encoder's integral transform
+// The encoder's features are a point-wise LINEAR lifting of the raw node data (magno.py:334 -> ChannelMLP, one Conv1d(k=1)):
+//     f[b,j,:] = Wl pn[b,j,:] + bl            (pn has CI <= 4 input channels)
+// so   out[b,q,:] = sum_e a_e k_e (*) f[b,j(e),:]  =  sum_ci Wl[:,ci] (*) S_ci[b,q,:]  +  bl (*) S_0[q,:]
+// with S_ci[b,q,:] = sum_e a_e pn[b,j(e),ci] k_e  and  S_0[q,:] = sum_e a_e k_e.
+// The [B,n,C] lifted tensor (33.5 MB at 16 k nodes x 8) is never written or gathered: per edge and sample the kernel
+// reads CI scalars instead of a 256-byte feature row.  Threads: (query row, 4-channel quad); grid.y = batch chunks of BCH.
+template <int CI, int BCH>
+__global__ __launch_bounds__(256) void lift_gather_reduce_kernel(const float* __restrict__ k, const float* __restrict__ pn,
+                                                                 const float* __restrict__ wl, const float* __restrict__ bl,
+                                                                 int B, int n_src, int C, const int* __restrict__ sp,
+                                                                 const int* __restrict__ cols, int Q, const float* __restrict__ escale,
+                                                                 float* __restrict__ out, int lanes_per_row, int rows_per_block) {
+    const int r = blockIdx.x * rows_per_block + threadIdx.x / lanes_per_row;
+    const int c = (threadIdx.x % lanes_per_row) * 4;
+    const int b0 = blockIdx.y * BCH;
+    if (r >= Q || c >= C) return;
+    const int t0 = sp[r], t1 = sp[r + 1];
+    f32x4 acc[BCH][CI], s0 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < BCH; ++b)
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) acc[b][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = t0; t < t1; ++t) {
+        const int j = cols[t];
+        f32x4 kq = *reinterpret_cast<const f32x4*>(k + (long)t * C + c);
+        if (escale) kq *= escale[t];
+        s0 += kq;
+#pragma unroll
+        for (int b = 0; b < BCH; ++b) {
+            const int bb = min(b0 + b, B - 1);
+            const float* pr = pn + ((long)bb * n_src + j) * CI;
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci) acc[b][ci] += kq * pr[ci];
+        }
+    }
+    f32x4 wq[CI];
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci) wq[ci] = f32x4{wl[(c + 0) * CI + ci], wl[(c + 1) * CI + ci], wl[(c + 2) * CI + ci], wl[(c + 3) * CI + ci]};
+    const f32x4 bq = bl ? *reinterpret_cast<const f32x4*>(bl + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < BCH; ++b) {
+        if (b0 + b >= B) break;
+        f32x4 o = bq * s0;
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) o += wq[ci] * acc[b][ci];
+        *reinterpret_cast<f32x4*>(out + ((long)(b0 + b) * Q + r) * C + c) = o;
+    }
+}
+
+// backward of the above for one edge row and channel quad: t_ci = sum_b dOut[b,q,:] pn[b,j,ci], u = sum_b dOut[b,q,:]
+//   dk[e,:]   = a_e (sum_ci Wl[:,ci] t_ci + bl u)
+//   dWl[:,ci] += a_e k_e t_ci ,  dbl += a_e k_e u         (per-workgroup partial rows [C*(CI+1)], summed by gaot_colsum)
+template <int CI>
+__global__ __launch_bounds__(256) void lift_edge_grad_kernel(const float* __restrict__ dout, const float* __restrict__ k,
+                                                             const float* __restrict__ pn, const float* __restrict__ wl,
+                                                             const float* __restrict__ bl, int B, int Q, int n_src, int C,
+                                                             const int* __restrict__ idx, const int* __restrict__ eq, int E,
+                                                             const float* __restrict__ escale, float* __restrict__ dk,
+                                                             float* __restrict__ part, int lanes_per_row, int rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float red[];      // [rows_per_block][(CI + 1) * C]
+    const int row = threadIdx.x / lanes_per_row;
+    const int c = (threadIdx.x % lanes_per_row) * 4;
+    const bool cok = c < C;
+    f32x4 wq[CI], pw[CI], pb = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci) {
+        pw[ci] = f32x4{0.f, 0.f, 0.f, 0.f};
+        wq[ci] = cok ? f32x4{wl[(c + 0) * CI + ci], wl[(c + 1) * CI + ci], wl[(c + 2) * CI + ci], wl[(c + 3) * CI + ci]} : pb;
+    }
+    if (cok && bl) bq = *reinterpret_cast<const f32x4*>(bl + c);
+    for (int e = blockIdx.x * rows_per_block + row; e < E && cok; e += gridDim.x * rows_per_block) {
+        const int q = eq[e], j = idx[e];
+        f32x4 t[CI], u = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) t[ci] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < B; ++b) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(dout + ((long)b * Q + q) * C + c);
+            const float* pr = pn + ((long)b * n_src + j) * CI;
+            u += g;
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci) t[ci] += g * pr[ci];
+        }
+        const float a = escale ? escale[e] : 1.0f;
+        f32x4 d = bq * u;
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) d += wq[ci] * t[ci];
+        *reinterpret_cast<f32x4*>(dk + (long)e * C + c) = d * a;
+        const f32x4 ka = *reinterpret_cast<const f32x4*>(k + (long)e * C + c) * a;
+        pb += ka * u;
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) pw[ci] += ka * t[ci];
+    }
+    // fixed-order sum over the workgroup's rows, then one partial row per workgroup: [ci][C] weights, then [C] bias
+    const int W = (CI + 1) * C;
+    if (cok) {
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) *reinterpret_cast<f32x4*>(red + row * W + ci * C + c) = pw[ci];
+        *reinterpret_cast<f32x4*>(red + row * W + CI * C + c) = pb;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < W; i += 256) {
+        float sacc = 0.f;
+        for (int rr = 0; rr < rows_per_block; ++rr) sacc += red[rr * W + i];
+        part[(long)blockIdx.x * W + i] = sacc;
+    }
+}
+
+extern "C" int gaot_gno_lift_gather_reduce(const float* k, const float* pn, const float* wl, const float* bl, int32_t B,
+                                           int32_t n_src, int32_t c_in, int32_t C, const int32_t* splits, const int32_t* cols,
+                                           int32_t Q, const float* escale, float* out, gaot_stream_t stream) {
+    GAOT_REQUIRE(B > 0 && n_src > 0 && Q >= 0 && c_in >= 1 && c_in <= 4 && C > 0 && C % 4 == 0 && C <= 1024,
+                 "gno_lift_gather_reduce: need 1 <= c_in <= 4 and C %% 4 == 0 (got c_in %d, C %d)", c_in, C);
+    if (Q == 0) return GAOT_OK;
+    GAOT_REQUIRE(k && pn && wl && splits && cols && out && aligned16(k) && aligned16(out) && (!bl || aligned16(bl)),
+                 "gno_lift_gather_reduce: null or misaligned pointer");
+    const int lpr = pow2_ceil(C / 4), rpb = 256 / lpr;
+    constexpr int BCH = 2;
+    dim3 grid(cdiv(Q, rpb), cdiv(B, BCH)), block(256);
+#define LG(CI) hipLaunchKernelGGL((lift_gather_reduce_kernel<CI, BCH>), grid, block, 0, ST(stream), k, pn, wl, bl, B, n_src, C, splits, \
+                                  cols, Q, escale, out, lpr, rpb)
+    if (c_in == 1) LG(1); else if (c_in == 2) LG(2); else if (c_in == 3) LG(3); else LG(4);
+#undef LG
+    GAOT_CHECK_LAUNCH("gaot_gno_lift_gather_reduce");
+    return GAOT_OK;
+}
+
+extern "C" int32_t gaot_gno_lift_edge_grad_parts(int32_t E, int32_t C) {
+    const int lpr = pow2_ceil(C / 4), rpb = 256 / lpr;
+    int nb = cdiv(E > 0 ? E : 1, rpb);
+    return nb > 1024 ? 1024 : nb;
+}
+
+extern "C" int gaot_gno_lift_edge_grad(const float* dout, const float* k, const float* pn, const float* wl, const float* bl,
+                                       int32_t B, int32_t Q, int32_t n_src, int32_t c_in, int32_t C, const int32_t* index32,
+                                       const int32_t* edge_query, int32_t E, const float* escale, float* dk, float* partial,
+                                       gaot_stream_t stream) {
+    GAOT_REQUIRE(B > 0 && E > 0 && c_in >= 1 && c_in <= 4 && C > 0 && C % 4 == 0 && C <= 1024,
+                 "gno_lift_edge_grad: need E > 0, 1 <= c_in <= 4 and C %% 4 == 0 (got c_in %d, C %d)", c_in, C);
+    GAOT_REQUIRE(dout && k && pn && wl && index32 && edge_query && dk && partial && aligned16(dout) && aligned16(k) && aligned16(dk) &&
+                 (!bl || aligned16(bl)), "gno_lift_edge_grad: null or misaligned pointer");
+    const int lpr = pow2_ceil(C / 4), rpb = 256 / lpr;
+    const int nb = gaot_gno_lift_edge_grad_parts(E, C);
+    const size_t lds = sizeof(float) * (size_t)rpb * (c_in + 1) * C;
+    GAOT_REQUIRE(lds <= 64 * 1024, "gno_lift_edge_grad: C = %d too wide for the workgroup reduction", C);
+#define LE(CI) hipLaunchKernelGGL((lift_edge_grad_kernel<CI>), dim3(nb), dim3(256), lds, ST(stream), dout, k, pn, wl, bl, B, Q, n_src, C, \
+                                  index32, edge_query, E, escale, dk, partial, lpr, rpb)
+    if (c_in == 1) LE(1); else if (c_in == 2) LE(2); else if (c_in == 3) LE(3); else LE(4);
+#undef LE
+    GAOT_CHECK_LAUNCH("gaot_gno_lift_edge_grad");
+    return GAOT_OK;
+}
+
 extern "C" int gaot_gno_segment_sum(const float* x, int32_t B, int32_t E, int32_t C, const int32_t* splits, int32_t Q,
                                     const float* rowscale, float* out, gaot_stream_t stream) {
     GAOT_REQUIRE(B > 0 && C > 0 && Q >= 0 && E >= 0, "gno_segment_sum: bad sizes");

@@ -70,9 +70,18 @@ class AGNO(nn.Module):
         return a
 
     def forward(self, y: torch.Tensor, neighbors: Dict[str, torch.Tensor], x: Optional[torch.Tensor] = None,
-                f_y: Optional[torch.Tensor] = None, weights: Optional[torch.Tensor] = None):
+                f_y: Optional[torch.Tensor] = None, weights: Optional[torch.Tensor] = None, lift=None):
+        """`lift` = (pn [B,n,c_in], W [C,c_in(,1)], b [C] or None): f_y is the point-wise LINEAR map W pn + b of raw node data
+        (the encoder's lifting, magno.py:334).  When the fused kernels apply, f_y is never formed; otherwise it is computed here."""
         if x is None:
             x = y
+        if lift is not None and f_y is None:
+            pn, lw, lb = lift
+            fusable = (self.transform_type == "linear" and ops._GNOLiftTransform.eligible(pn, lw, lw.shape[0], None)
+                       and not (self.use_attn and self.attention_type == 'dot_product') and weights is None)
+            if not fusable:
+                f_y = ops.linear(pn, lw, lb)
+                lift = None
         plan = plan_for(neighbors, y.shape[0])
         a = self._edge_scale(plan, y, x, weights)
         feat = plan.edge_features(y, x)                                      # [E, 2*kd]  (y_j first, then x_i)
@@ -102,6 +111,8 @@ class AGNO(nn.Module):
                 k = self.channel_mlp(feat)                                   # [E, C]
                 if not torch.is_grad_enabled():
                     self._infer_k = (key, feat, k)
+            if lift is not None:
+                return ops.gno_lift_transform(k, lift[0], lift[1], lift[2], plan, a)         # [B, Q, C]
             if f3 is None:                                                   # transform (a): integrate the kernel itself
                 kk = k if a is None else k * a[:plan.E, None]
                 out = ops.segment_sum(kk[None], plan)

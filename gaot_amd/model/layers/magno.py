@@ -130,14 +130,14 @@ class _MAGNOBase(nn.Module):
             self._coord_enc_cache[key] = hit
         return hit[1]
 
-    def _transform(self, src_coord, dst_coord, feats, neighbors, stats=None, head=None):
+    def _transform(self, src_coord, dst_coord, feats, neighbors, stats=None, head=None, lift=None):
         """AGNO (+ geoembed + recovery) for ONE geometry at ONE scale.  feats [B, n_src, C] -> [B, n_dst, C].
         `head` = (W [out, C], b [out]) of a following point-wise linear layer (the decoder's projection): recovery and
         head are both linear with nothing in between, so they are applied as ONE map
             agno @ (W Wr1)^T + (rowb @ W^T + b)
         and the [B, n_dst, C] recovery output (33.5 MB at 16k nodes x 8) is never produced."""
         nb = apply_edge_drop_csr(neighbors, self.sampling_strategy, self.max_neighbors, self.sample_ratio, self.training)
-        out = self.agno(y=self._kcoord(src_coord), x=self._kcoord(dst_coord), f_y=feats, neighbors=nb)
+        out = self.agno(y=self._kcoord(src_coord), x=self._kcoord(dst_coord), f_y=feats, neighbors=nb, lift=lift)
         if self.use_geoembed:
             w = self.recovery.fcs[0].weight.squeeze(-1)                                             # [C, 2C]
             C = out.shape[-1]
@@ -183,13 +183,16 @@ class _MAGNOBase(nn.Module):
             return acc
         return torch.stack(per_scale, dim=0).mean(dim=0)
 
-    def _all_scales(self, mode, src, dst, feats, nbrs, head=None):
+    def _all_scales(self, mode, src, dst, feats, nbrs, head=None, lift=None):
+        """`lift` = (pn, W, b) replaces `feats` = W pn + b (encoder): the lifting is folded into the transform kernels."""
         per_scale = []
         for si in range(len(self.scales)):
             if mode == 'fx':
-                per_scale.append(self._transform(src, dst, feats, nbrs[si], head=head))
+                per_scale.append(self._transform(src, dst, feats, nbrs[si], head=head, lift=lift))
             else:
                 # vx: block-diagonal union of the B per-sample graphs -> one launch per kernel for the whole batch
+                if lift is not None:
+                    feats = lift[0]
                 B = feats.shape[0]
                 srcs = [src[b] if src.ndim == 3 else src for b in range(B)]
                 dsts = [dst[b] if dst.ndim == 3 else dst for b in range(B)]
@@ -198,8 +201,11 @@ class _MAGNOBase(nn.Module):
                 if any(n != n_dst for n in mg.n_dst_each) or any(n != feats.shape[1] for n in mg.n_src_each):
                     raise ValueError("vx mode needs the same number of source / query points in every sample of a batch")
                 stats = mg.geo_stats() if (self.use_geoembed and self.geoembed.method == 'statistical') else None
-                out = self._transform(mg.src, mg.dst, feats.reshape(1, B * feats.shape[1], feats.shape[2]), mg.neighbors, stats,
-                                      head=head)
+                flat = feats.reshape(1, B * feats.shape[1], feats.shape[2])
+                if lift is not None:
+                    out = self._transform(mg.src, mg.dst, None, mg.neighbors, stats, head=head, lift=(flat, lift[1], lift[2]))
+                else:
+                    out = self._transform(mg.src, mg.dst, flat, mg.neighbors, stats, head=head)
                 per_scale.append(out.reshape(B, n_dst, out.shape[-1]))
         return per_scale
 
@@ -243,8 +249,12 @@ class MAGNOEncoder(_MAGNOBase):
             nbrs = encoder_nbrs
         else:
             nbrs = self._compute_neighbors(x_coord, latent_tokens_coord, mode)
-        lifted = self.lifting.forward_channels_last(pndata)                                     # [B, n, C]
         w = self._scale_mix_weights(self._kcoord(latent_tokens_coord)) if self.use_scale_weights else None
+        if self.lifting.n_layers == 1:
+            # one point-wise linear map: folded into the integral transform (AGNO decides; falls back to forming it)
+            lift = (pndata, self.lifting.fcs[0].weight, self.lifting.fcs[0].bias)
+            return self._combine(self._all_scales(mode, x_coord, latent_tokens_coord, None, nbrs, lift=lift), w)
+        lifted = self.lifting.forward_channels_last(pndata)                                     # [B, n, C]
         return self._combine(self._all_scales(mode, x_coord, latent_tokens_coord, lifted, nbrs), w)
 
 

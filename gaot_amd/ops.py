@@ -553,6 +553,59 @@ def gno_transform(k, f, plan, escale=None):
     return _GNOTransform.apply(k, f, plan, escale)
 
 
+class _GNOLiftTransform(torch.autograd.Function):
+    """Encoder transform with the linear lifting folded in (csrc/gno.hip lift_* kernels):
+        out[b,q,:] = sum_e a_e k_e (*) (Wl pn[b,j(e),:] + bl)
+    without ever forming the lifted [B,n,C] tensor; backward gives dk, dWl, dbl from one launch + one column sum."""
+
+    @staticmethod
+    def eligible(pn, wl, C: int, escale) -> bool:
+        return (pn.dim() == 3 and 1 <= pn.shape[-1] <= 4 and C % 4 == 0 and not pn.requires_grad
+                and (escale is None or not escale.requires_grad) and wl.reshape(wl.shape[0], -1).shape[1] == pn.shape[-1])
+
+    @staticmethod
+    def forward(ctx, k, pn, wl, bl, plan, escale):
+        _dev(k, pn, wl)
+        k, pn = k.contiguous(), pn.contiguous()
+        B, n_src, ci = pn.shape
+        Cc = k.shape[1]
+        w2 = wl.reshape(Cc, ci).contiguous()
+        out = torch.empty(B, plan.Q, Cc, device=k.device, dtype=torch.float32)
+        L.check(L.load().gaot_gno_lift_gather_reduce(_p(k), _p(pn), _p(w2), _p(bl), B, n_src, ci, Cc, _p(plan.splits),
+                                                     _p(plan.index), plan.Q, _p(escale), _p(out), _stream()),
+                "gaot_gno_lift_gather_reduce")
+        ctx.plan = plan
+        ctx.save_for_backward(k, pn, w2, bl if bl is not None else k.new_empty(0), escale if escale is not None else k.new_empty(0))
+        ctx.meta = (wl.shape, bl is not None, escale is not None, _claim(wl), _claim(bl))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        k, pn, w2, bl, esc = ctx.saved_tensors
+        wshape, has_b, has_e, wslot, bslot = ctx.meta
+        plan = ctx.plan
+        B, n_src, ci = pn.shape
+        Cc = k.shape[1]
+        lib = L.load()
+        dout = dout.contiguous()
+        dk = torch.empty_like(k)
+        if plan.E == 0:
+            return dk, None, torch.zeros(wshape, device=k.device), (torch.zeros(Cc, device=k.device) if has_b else None), None, None
+        nparts = int(lib.gaot_gno_lift_edge_grad_parts(plan.E, Cc))
+        part = torch.empty(nparts, (ci + 1) * Cc, device=k.device, dtype=torch.float32)
+        L.check(lib.gaot_gno_lift_edge_grad(_p(dout), _p(k), _p(pn), _p(w2), _p(bl) if has_b else None, B, plan.Q, n_src, ci, Cc,
+                                            _p(plan.index), _p(plan.edge_query), plan.E, _p(esc) if has_e else None, _p(dk),
+                                            _p(part), _stream()), "gaot_gno_lift_edge_grad")
+        sums = colsum(part)                                  # [(ci + 1) * C] = [dWl^T | dbl]
+        dwl = sums[:ci * Cc].reshape(ci, Cc).t().reshape(wshape) if ci > 1 else sums[:Cc].reshape(wshape)
+        dbl = sums[ci * Cc:] if has_b else None
+        return dk, None, dwl, dbl, None, None
+
+
+def gno_lift_transform(k, pn, wl, bl, plan, escale=None):
+    return _GNOLiftTransform.apply(k, pn, wl, bl, plan, escale)
+
+
 class _SegmentSoftmax(torch.autograd.Function):
     @staticmethod
     def forward(ctx, score, plan):

@@ -145,6 +145,19 @@ int gaot_radius_fill(const float* queries, int32_t m, const float* data, int32_t
 int gaot_gno_gather_reduce(const float* w, const float* src, int32_t B, int32_t n_src_rows, int32_t C,
                            const int32_t* splits, const int32_t* cols, const int32_t* edge_map,
                            int32_t n_out_rows, const float* escale, float* out, gaot_stream_t stream);
+/* Encoder variant with the point-wise LINEAR lifting (magno.py:334, one Conv1d(k=1): f = Wl pn + bl, c_in <= 4) folded in:
+ *   out[b,q,:] = sum_ci Wl[:,ci] * (sum_e a_e pn[b,j(e),ci] k_e) + bl * (sum_e a_e k_e)
+ * -- identical to gaot_gno_gather_reduce(k, f) on the lifted f, which is never materialised.  pn [B,n_src,c_in], wl [C,c_in].
+ * Backward: dk [E,C] plus gaot_gno_lift_edge_grad_parts(E,C) partial rows [(c_in+1)*C] = [dWl^T (c_in x C) | dbl (C)]
+ * that the caller sums (gaot_colsum); pn gets no gradient (raw input data). */
+int gaot_gno_lift_gather_reduce(const float* k, const float* pn, const float* wl, const float* bl, int32_t B, int32_t n_src,
+                                int32_t c_in, int32_t C, const int32_t* splits, const int32_t* cols, int32_t Q,
+                                const float* escale, float* out, gaot_stream_t stream);
+int32_t gaot_gno_lift_edge_grad_parts(int32_t E, int32_t C);
+int gaot_gno_lift_edge_grad(const float* dout, const float* k, const float* pn, const float* wl, const float* bl, int32_t B,
+                            int32_t Q, int32_t n_src, int32_t c_in, int32_t C, const int32_t* index32,
+                            const int32_t* edge_query, int32_t E, const float* escale, float* dk, float* partial,
+                            gaot_stream_t stream);
 /* dW[e,:] = escale[e] * sum_b dOut[b, edge_query[e], :] * f[b, index[e], :]   (escale may be NULL) */
 int gaot_gno_edge_grad(const float* dout, const float* f, int32_t B, int32_t Q, int32_t n_src, int32_t C,
                        const int32_t* index32, const int32_t* edge_query, int32_t E,

@@ -538,3 +538,41 @@ def test_mse_loss_kernel(shape):
     assert abs(float(loss) - float(((pd - yd) ** 2).mean())) < 1e-6 * float(((pd - yd) ** 2).mean())
     assert rel(g, 3.0 * 2.0 * (pd - yd) / pd.numel()) < 1e-6
     assert float(ops.mse_loss(p, y)) == float(loss)          # deterministic
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,n_src,Q,ci,C", [(8, 2000, 500, 1, 64), (3, 300, 200, 4, 64), (1, 50, 40, 2, 32), (5, 400, 64, 3, 128)])
+def test_lifted_gno_transform_matches_unfused(B, n_src, Q, ci, C):
+    """Encoder transform with the linear lifting folded in (gno.hip lift_* kernels) against the same op on the materialised
+    lifted features (magno.py:334 + agno.py:198,245-271): output, dk, dWl, dbl; empty segments included."""
+    from gaot_amd import ops
+    from gaot_amd.plan import GeometryPlan
+    g = torch.Generator().manual_seed(B * 1000 + Q + ci)
+    deg = torch.randint(0, 9, (Q,), generator=g)
+    deg[::7] = 0                                                     # empty segments
+    splits = torch.cat([torch.zeros(1, dtype=torch.long), deg.cumsum(0)])
+    E = int(splits[-1])
+    index = torch.randint(0, n_src, (E,), generator=g)
+    d = "cuda"
+    plan = GeometryPlan(index.to(d), splits.to(d), n_src)
+    k = torch.randn(E, C, generator=g).to(d).requires_grad_()
+    pn = torch.randn(B, n_src, ci, generator=g).to(d)
+    wl = (torch.randn(C, ci, 1, generator=g) * 0.5).to(d).requires_grad_()
+    bl = torch.randn(C, generator=g).to(d).requires_grad_()
+    a = torch.rand(max(E, 1), generator=g).to(d)
+    dout = torch.randn(B, Q, C, generator=g).to(d)
+    assert ops._GNOLiftTransform.eligible(pn, wl, C, a)
+    y = ops.gno_lift_transform(k, pn, wl, bl, plan, a)
+    gf = torch.autograd.grad(y, [k, wl, bl], dout)
+    y0 = ops.gno_transform(k, ops.linear(pn, wl, bl), plan, a)
+    g0 = torch.autograd.grad(y0, [k, wl, bl], dout)
+    kd, wd, bd = k.detach().double().cpu().requires_grad_(), wl.detach().double().cpu().requires_grad_(), bl.detach().double().cpu().requires_grad_()
+    f = pn.double().cpu() @ wd.reshape(C, ci).t() + bd
+    eq = torch.repeat_interleave(torch.arange(Q), deg)
+    contrib = a[:E].double().cpu()[None, :, None] * kd[None] * f[:, index, :]
+    yd = torch.zeros(B, Q, C, dtype=torch.float64).index_add_(1, eq, contrib)
+    gd = torch.autograd.grad(yd, [kd, wd, bd], dout.double().cpu())
+    assert rel(y, yd) < 2e-6 and rel(y0, yd) < 2e-6
+    for u, v, w in zip(gf, g0, gd):
+        assert u.shape == w.shape
+        assert rel(u, w) < 1e-5, (rel(u, w), rel(v, w))
