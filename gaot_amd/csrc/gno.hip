@@ -301,27 +301,26 @@ __global__ __launch_bounds__(256) void gather_reduce_kernel(const float* __restr
     const int t0 = sp[r], t1 = sp[r + 1];
     const float* sb = src + (long)b * n_src_rows * C + c;
     V acc = vzero<VW>();
-    int t = t0;
-    for (; t + 1 < t1; t += 2) {   // two edges in flight
-        const int e0 = HAS_MAP ? emap[t] : t, e1 = HAS_MAP ? emap[t + 1] : t + 1;
-        const int j0 = cols[e0], j1 = cols[e1];
-        V s0 = *reinterpret_cast<const V*>(sb + (long)j0 * C);
-        V s1 = *reinterpret_cast<const V*>(sb + (long)j1 * C);
-        if (escale) { s0 *= escale[e0]; s1 *= escale[e1]; }
-        if (HAS_W) {
-            const V w0 = *reinterpret_cast<const V*>(w + (long)e0 * C + c);
-            const V w1 = *reinterpret_cast<const V*>(w + (long)e1 * C + c);
-            acc += w0 * s0;
-            acc += w1 * s1;
-        } else { acc += s0; acc += s1; }
-    }
-    if (t < t1) {
-        const int e0 = HAS_MAP ? emap[t] : t;
-        const int j0 = cols[e0];
-        V s0 = *reinterpret_cast<const V*>(sb + (long)j0 * C);
-        if (escale) s0 *= escale[e0];
-        if (HAS_W) acc += (*reinterpret_cast<const V*>(w + (long)e0 * C + c)) * s0;
-        else acc += s0;
+    // four edges in flight: (edge map ->) column index -> feature row is a dependent load chain and segments are short
+    for (int t = t0; t < t1; t += 4) {
+        int e[4], j[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int tt = min(t + u, t1 - 1); e[u] = HAS_MAP ? emap[tt] : tt; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) j[u] = cols[e[u]];
+        V sv[4], wv[4];
+        float a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            sv[u] = *reinterpret_cast<const V*>(sb + (long)j[u] * C);
+            if (HAS_W) wv[u] = *reinterpret_cast<const V*>(w + (long)e[u] * C + c);
+            a[u] = (t + u < t1) ? (escale ? escale[e[u]] : 1.0f) : 0.0f;            // padding edges weigh nothing
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            V sc = sv[u] * a[u];
+            if (HAS_W) acc += wv[u] * sc; else acc += sc;
+        }
     }
     *reinterpret_cast<V*>(out + ((long)b * n_out + r) * C + c) = acc;
 }
@@ -505,6 +504,7 @@ extern "C" int gaot_gno_edge_grad(const float* dout, const float* f, int32_t B, 
     return GAOT_OK;
 }
 
+namespace gaot {
 // ---------------------------------------------------------------- lifting fused into the encoder's integral transform
 // The encoder's features are a point-wise LINEAR lifting of the raw node data (magno.py:334 -> ChannelMLP, one Conv1d(k=1)):
 //     f[b,j,:] = Wl pn[b,j,:] + bl            (pn has CI <= 4 input channels)
@@ -528,17 +528,31 @@ __global__ __launch_bounds__(256) void lift_gather_reduce_kernel(const float* __
     for (int b = 0; b < BCH; ++b)
 #pragma unroll
         for (int ci = 0; ci < CI; ++ci) acc[b][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int t = t0; t < t1; ++t) {
-        const int j = cols[t];
-        f32x4 kq = *reinterpret_cast<const f32x4*>(k + (long)t * C + c);
-        if (escale) kq *= escale[t];
-        s0 += kq;
+    // four edges in flight: the index -> node-data loads are a dependent chain, the segment is short (3-30 edges)
+    for (int t = t0; t < t1; t += 4) {
+        int j[4]; f32x4 kq[4]; float pv[4][BCH][CI];
 #pragma unroll
-        for (int b = 0; b < BCH; ++b) {
-            const int bb = min(b0 + b, B - 1);
-            const float* pr = pn + ((long)bb * n_src + j) * CI;
+        for (int u = 0; u < 4; ++u) j[u] = cols[min(t + u, t1 - 1)];
 #pragma unroll
-            for (int ci = 0; ci < CI; ++ci) acc[b][ci] += kq * pr[ci];
+        for (int u = 0; u < 4; ++u) {
+            const int tt = min(t + u, t1 - 1);
+            kq[u] = *reinterpret_cast<const f32x4*>(k + (long)tt * C + c);
+            const float a = (t + u < t1) ? (escale ? escale[tt] : 1.0f) : 0.0f;       // padding edges weigh nothing
+            kq[u] *= a;
+#pragma unroll
+            for (int b = 0; b < BCH; ++b) {
+                const float* pr = pn + ((long)min(b0 + b, B - 1) * n_src + j[u]) * CI;
+#pragma unroll
+                for (int ci = 0; ci < CI; ++ci) pv[u][b][ci] = pr[ci];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            s0 += kq[u];
+#pragma unroll
+            for (int b = 0; b < BCH; ++b)
+#pragma unroll
+                for (int ci = 0; ci < CI; ++ci) acc[b][ci] += kq[u] * pv[u][b][ci];
         }
     }
     f32x4 wq[CI];
@@ -613,6 +627,8 @@ __global__ __launch_bounds__(256) void lift_edge_grad_kernel(const float* __rest
         part[(long)blockIdx.x * W + i] = sacc;
     }
 }
+
+}  // namespace gaot
 
 extern "C" int gaot_gno_lift_gather_reduce(const float* k, const float* pn, const float* wl, const float* bl, int32_t B,
                                            int32_t n_src, int32_t c_in, int32_t C, const int32_t* splits, const int32_t* cols,
