@@ -628,6 +628,141 @@ __global__ __launch_bounds__(256) void lift_edge_grad_kernel(const float* __rest
     }
 }
 
+// ---------------------------------------------------------------- output projection fused into the decoder's transform
+// The decoder's integral transform is followed by point-wise LINEAR maps only (recovery Conv1d, projection Conv1d:
+// magno.py:640-668), folded on the host into one [OC, C] matrix weff and a per-query row bias.  With OC <= 4 output channels
+//     y[b,q,o] = sum_ch weff[o,ch] * (sum_e a_e k[e,ch] f[b,j(e),ch]) + rowb[q,o] + bias[o]
+// is produced directly: the [B,Nq,C] transform output (33.5 MB at 16 k query nodes x 8) is never written, and in the backward
+// its gradient G[b,q,ch] = sum_o dY[b,q,o] weff[o,ch] is formed on the fly from the OC scalars of a row.
+template <int OC>
+__global__ __launch_bounds__(256) void proj_gather_reduce_kernel(const float* __restrict__ k, const float* __restrict__ f,
+                                                                 const float* __restrict__ weff, const float* __restrict__ rowb,
+                                                                 const float* __restrict__ bias, int B, int n_src, int C,
+                                                                 const int* __restrict__ sp, const int* __restrict__ cols, int Q,
+                                                                 const float* __restrict__ escale, float* __restrict__ y,
+                                                                 int lanes_per_row, int rows_per_block) {
+    const int b = blockIdx.x % B;
+    const int r = (blockIdx.x / B) * rows_per_block + threadIdx.x / lanes_per_row;
+    const int lr = threadIdx.x % lanes_per_row;
+    const int c = lr * 4;
+    const bool ok = r < Q && c < C;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+        const int t0 = sp[r], t1 = sp[r + 1];
+        const float* fb = f + (long)b * n_src * C + c;
+        for (int t = t0; t < t1; t += 4) {
+            int j[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) j[u] = cols[min(t + u, t1 - 1)];
+            f32x4 fv[4], kv[4]; float a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int tt = min(t + u, t1 - 1);
+                fv[u] = *reinterpret_cast<const f32x4*>(fb + (long)j[u] * C);
+                kv[u] = *reinterpret_cast<const f32x4*>(k + (long)tt * C + c);
+                a[u] = (t + u < t1) ? (escale ? escale[tt] : 1.0f) : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += kv[u] * (fv[u] * a[u]);
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < OC; ++o) {
+        float d = 0.f;
+        if (ok) { const f32x4 w = *reinterpret_cast<const f32x4*>(weff + (long)o * C + c); d = (acc[0] * w[0] + acc[1] * w[1]) + (acc[2] * w[2] + acc[3] * w[3]); }
+        for (int off = lanes_per_row >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
+        if (lr == 0 && r < Q) y[((long)b * Q + r) * OC + o] = d + (rowb ? rowb[(long)r * OC + o] : 0.f) + (bias ? bias[o] : 0.f);
+    }
+}
+
+// per edge row: T_o[e,:] = a_e sum_b dY[b,q,o] f[b,j,:];  dk[e,:] = sum_o weff[o,:] T_o;  dweff[o,:] += k[e,:] T_o (partials)
+template <int OC>
+__global__ __launch_bounds__(256) void proj_edge_grad_kernel(const float* __restrict__ dy, const float* __restrict__ k,
+                                                             const float* __restrict__ f, const float* __restrict__ weff, int B,
+                                                             int Q, int n_src, int C, const int* __restrict__ idx,
+                                                             const int* __restrict__ eq, int E, const float* __restrict__ escale,
+                                                             float* __restrict__ dk, float* __restrict__ part, int lanes_per_row,
+                                                             int rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float red[];      // [rows_per_block][OC * C]
+    const int row = threadIdx.x / lanes_per_row;
+    const int c = (threadIdx.x % lanes_per_row) * 4;
+    const bool cok = c < C;
+    f32x4 wq[OC], pw[OC];
+#pragma unroll
+    for (int o = 0; o < OC; ++o) {
+        pw[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+        wq[o] = cok ? *reinterpret_cast<const f32x4*>(weff + (long)o * C + c) : pw[o];
+    }
+    for (int e = blockIdx.x * rows_per_block + row; e < E && cok; e += gridDim.x * rows_per_block) {
+        const int q = eq[e], j = idx[e];
+        f32x4 t[OC];
+#pragma unroll
+        for (int o = 0; o < OC; ++o) t[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < B; ++b) {
+            const f32x4 fv = *reinterpret_cast<const f32x4*>(f + ((long)b * n_src + j) * C + c);
+            const float* gy = dy + ((long)b * Q + q) * OC;
+#pragma unroll
+            for (int o = 0; o < OC; ++o) t[o] += fv * gy[o];
+        }
+        const float a = escale ? escale[e] : 1.0f;
+        const f32x4 kv = *reinterpret_cast<const f32x4*>(k + (long)e * C + c);
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int o = 0; o < OC; ++o) { t[o] *= a; d += wq[o] * t[o]; pw[o] += kv * t[o]; }
+        *reinterpret_cast<f32x4*>(dk + (long)e * C + c) = d;
+    }
+    const int W = OC * C;
+    if (cok) {
+#pragma unroll
+        for (int o = 0; o < OC; ++o) *reinterpret_cast<f32x4*>(red + row * W + o * C + c) = pw[o];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < W; i += 256) {
+        float sacc = 0.f;
+        for (int rr = 0; rr < rows_per_block; ++rr) sacc += red[rr * W + i];
+        part[(long)blockIdx.x * W + i] = sacc;
+    }
+}
+
+// dF[b,j,:] = sum_{t in tseg(j)} a_e k[e,:] (*) (sum_o dY[b,q(e),o] weff[o,:]),  e = t_edge[t]
+template <int OC>
+__global__ __launch_bounds__(256) void proj_gather_t_kernel(const float* __restrict__ k, const float* __restrict__ dy,
+                                                            const float* __restrict__ weff, int B, int Q, int C,
+                                                            const int* __restrict__ tsp, const int* __restrict__ tedge,
+                                                            const int* __restrict__ eq, int n_src, const float* __restrict__ escale,
+                                                            float* __restrict__ df, int lanes_per_row, int rows_per_block) {
+    const int b = blockIdx.x % B;
+    const int r = (blockIdx.x / B) * rows_per_block + threadIdx.x / lanes_per_row;
+    const int c = (threadIdx.x % lanes_per_row) * 4;
+    if (r >= n_src || c >= C) return;
+    f32x4 wq[OC];
+#pragma unroll
+    for (int o = 0; o < OC; ++o) wq[o] = *reinterpret_cast<const f32x4*>(weff + (long)o * C + c);
+    const float* dyb = dy + (long)b * Q * OC;
+    const int t0 = tsp[r], t1 = tsp[r + 1];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int t = t0; t < t1; t += 4) {
+        int e[4], q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e[u] = tedge[min(t + u, t1 - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) q[u] = eq[e[u]];
+        f32x4 kv[4], g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            kv[u] = *reinterpret_cast<const f32x4*>(k + (long)e[u] * C + c);
+            const float a = (t + u < t1) ? (escale ? escale[e[u]] : 1.0f) : 0.0f;
+            kv[u] *= a;
+            g[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int o = 0; o < OC; ++o) g[u] += wq[o] * dyb[(long)q[u] * OC + o];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += kv[u] * g[u];
+    }
+    *reinterpret_cast<f32x4*>(df + ((long)b * n_src + r) * C + c) = acc;
+}
+
 }  // namespace gaot
 
 extern "C" int gaot_gno_lift_gather_reduce(const float* k, const float* pn, const float* wl, const float* bl, int32_t B,
@@ -672,6 +807,56 @@ extern "C" int gaot_gno_lift_edge_grad(const float* dout, const float* k, const 
     if (c_in == 1) LE(1); else if (c_in == 2) LE(2); else if (c_in == 3) LE(3); else LE(4);
 #undef LE
     GAOT_CHECK_LAUNCH("gaot_gno_lift_edge_grad");
+    return GAOT_OK;
+}
+
+static int proj_check(int B, int C, int OC) {
+    GAOT_REQUIRE(B > 0 && OC >= 1 && OC <= 4 && C > 0 && C % 4 == 0 && C <= 1024,
+                 "gno_proj_*: need 1 <= out_channels <= 4 and C %% 4 == 0 (got %d, C %d)", OC, C);
+    return GAOT_OK;
+}
+
+extern "C" int gaot_gno_proj_gather_reduce(const float* k, const float* f, const float* weff, const float* rowbias, const float* bias,
+                                           int32_t B, int32_t n_src, int32_t C, int32_t out_channels, const int32_t* splits,
+                                           const int32_t* cols, int32_t Q, const float* escale, float* y, gaot_stream_t stream) {
+    if (int rc = proj_check(B, C, out_channels)) return rc;
+    if (Q == 0) return GAOT_OK;
+    GAOT_REQUIRE(k && f && weff && splits && cols && y && aligned16(k) && aligned16(f) && aligned16(weff), "gno_proj_gather_reduce: null or misaligned pointer");
+    const int lpr = pow2_ceil(C / 4), rpb = 256 / lpr;
+    GAOT_REQUIRE(lpr <= 64, "gno_proj_gather_reduce: C = %d too wide (the row reduction is one wave)", C);
+    dim3 grid((unsigned)(cdiv(Q, rpb) * (long)B)), block(256);
+#define PG(OC) hipLaunchKernelGGL((proj_gather_reduce_kernel<OC>), grid, block, 0, ST(stream), k, f, weff, rowbias, bias, B, n_src, C, splits, \
+                                  cols, Q, escale, y, lpr, rpb)
+    if (out_channels == 1) PG(1); else if (out_channels == 2) PG(2); else if (out_channels == 3) PG(3); else PG(4);
+#undef PG
+    GAOT_CHECK_LAUNCH("gaot_gno_proj_gather_reduce");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_gno_proj_backward(const float* dy, const float* k, const float* f, const float* weff, int32_t B, int32_t Q,
+                                      int32_t n_src, int32_t C, int32_t out_channels, const int32_t* index32,
+                                      const int32_t* edge_query, int32_t E, const int32_t* t_splits, const int32_t* t_edge,
+                                      const float* escale, float* dk, float* dweff_partial, float* df, gaot_stream_t stream) {
+    if (int rc = proj_check(B, C, out_channels)) return rc;
+    GAOT_REQUIRE(E > 0 && dy && k && f && weff && index32 && edge_query && dk && dweff_partial && aligned16(k) && aligned16(f) && aligned16(weff) &&
+                 aligned16(dk), "gno_proj_backward: E > 0 and non-null 16-byte aligned operands required");
+    const int lpr = pow2_ceil(C / 4), rpb = 256 / lpr;
+    const int nb = gaot_gno_lift_edge_grad_parts(E, C);
+    const size_t lds = sizeof(float) * (size_t)rpb * out_channels * C;
+    GAOT_REQUIRE(lds <= 64 * 1024, "gno_proj_backward: C = %d too wide for the workgroup reduction", C);
+#define PE(OC) hipLaunchKernelGGL((proj_edge_grad_kernel<OC>), dim3(nb), dim3(256), lds, ST(stream), dy, k, f, weff, B, Q, n_src, C, index32, \
+                                  edge_query, E, escale, dk, dweff_partial, lpr, rpb)
+    if (out_channels == 1) PE(1); else if (out_channels == 2) PE(2); else if (out_channels == 3) PE(3); else PE(4);
+#undef PE
+    if (df) {
+        GAOT_REQUIRE(t_splits && t_edge && aligned16(df), "gno_proj_backward: dF needs the transposed CSR");
+        dim3 grid((unsigned)(cdiv(n_src, rpb) * (long)B)), block(256);
+#define PT(OC) hipLaunchKernelGGL((proj_gather_t_kernel<OC>), grid, block, 0, ST(stream), k, dy, weff, B, Q, C, t_splits, t_edge, edge_query, \
+                                  n_src, escale, df, lpr, rpb)
+        if (out_channels == 1) PT(1); else if (out_channels == 2) PT(2); else if (out_channels == 3) PT(3); else PT(4);
+#undef PT
+    }
+    GAOT_CHECK_LAUNCH("gaot_gno_proj_backward");
     return GAOT_OK;
 }
 

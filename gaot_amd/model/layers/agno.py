@@ -70,11 +70,12 @@ class AGNO(nn.Module):
         return a
 
     def forward(self, y: torch.Tensor, neighbors: Dict[str, torch.Tensor], x: Optional[torch.Tensor] = None,
-                f_y: Optional[torch.Tensor] = None, weights: Optional[torch.Tensor] = None, lift=None):
+                f_y: Optional[torch.Tensor] = None, weights: Optional[torch.Tensor] = None, lift=None, proj=None):
         """`lift` = (pn [B,n,c_in], W [C,c_in(,1)], b [C] or None): f_y is the point-wise LINEAR map W pn + b of raw node data
         (the encoder's lifting, magno.py:334).  When the fused kernels apply, f_y is never formed; otherwise it is computed here."""
         if x is None:
             x = y
+        self.applied_proj = False           # set when `proj` = (weff [OC,C], rowbias [Q,OC] | None, bias [OC] | None) was folded in
         if lift is not None and f_y is None:
             pn, lw, lb = lift
             fusable = (self.transform_type == "linear" and ops._GNOLiftTransform.eligible(pn, lw, lw.shape[0], None)
@@ -113,6 +114,11 @@ class AGNO(nn.Module):
                     self._infer_k = (key, feat, k)
             if lift is not None:
                 return ops.gno_lift_transform(k, lift[0], lift[1], lift[2], plan, a)         # [B, Q, C]
+            if (proj is not None and f3 is not None and batched and self.transform_type == "linear" and weights is None
+                    and not (self.use_attn and self.attention_type == 'dot_product')
+                    and ops._GNOProjTransform.eligible(f3, proj[0], None)):
+                self.applied_proj = True
+                return ops.gno_proj_transform(k, f3, proj[0], proj[1], proj[2], plan, a)     # [B, Q, OC]
             if f3 is None:                                                   # transform (a): integrate the kernel itself
                 kk = k if a is None else k * a[:plan.E, None]
                 out = ops.segment_sum(kk[None], plan)

@@ -137,12 +137,11 @@ class _MAGNOBase(nn.Module):
             agno @ (W Wr1)^T + (rowb @ W^T + b)
         and the [B, n_dst, C] recovery output (33.5 MB at 16k nodes x 8) is never produced."""
         nb = apply_edge_drop_csr(neighbors, self.sampling_strategy, self.max_neighbors, self.sample_ratio, self.training)
-        out = self.agno(y=self._kcoord(src_coord), x=self._kcoord(dst_coord), f_y=feats, neighbors=nb, lift=lift)
+        proj = rowb = w_agno = None
         if self.use_geoembed:
             w = self.recovery.fcs[0].weight.squeeze(-1)                                             # [C, 2C]
-            C = out.shape[-1]
+            C = w.shape[0]
             w_agno, w_geo = ops.split_cols(w, C)      # one gradient assembly instead of two slice-backward chains
-            rowb = None
             key = None
             if not torch.is_grad_enabled() and nb is neighbors:
                 # inference (autoregressive rollouts): geometry and weights are fixed across steps -> keep the row bias
@@ -159,12 +158,16 @@ class _MAGNOBase(nn.Module):
                     self._infer_cache["rowb"] = (key, nb, rowb)
             if head is not None:
                 hw, hb = head
-                w_eff = ops.linear(hw, w_agno.t())                 # [out, C] = W @ Wr1   (tiny)
-                rowb_h = ops.linear(rowb, hw, hb)                    # [n_dst, out]
-                return ops.linear(out, w_eff, rowbias=rowb_h)
-            out = ops.linear(out, w_agno, rowbias=rowb)
+                proj = (ops.linear(hw, w_agno.t()),              # [out, C] = W @ Wr1   (tiny)
+                        ops.linear(rowb, hw, hb), None)          # [n_dst, out]
         elif head is not None:
-            return ops.linear(out, head[0], head[1])
+            proj = (head[0], None, head[1])
+        # with few output channels the folded map is applied INSIDE the transform kernels (AGNO decides: `applied_proj`)
+        out = self.agno(y=self._kcoord(src_coord), x=self._kcoord(dst_coord), f_y=feats, neighbors=nb, lift=lift, proj=proj)
+        if proj is not None:
+            return out if self.agno.applied_proj else ops.linear(out, proj[0], proj[2], rowbias=proj[1])
+        if self.use_geoembed:
+            out = ops.linear(out, w_agno, rowbias=rowb)
         return out
 
     def _scale_mix_weights(self, coords: torch.Tensor) -> torch.Tensor:

@@ -602,6 +602,69 @@ class _GNOLiftTransform(torch.autograd.Function):
         return dk, None, dwl, dbl, None, None
 
 
+class _GNOProjTransform(torch.autograd.Function):
+    """Decoder transform with the following point-wise linear maps folded in (csrc/gno.hip proj_* kernels):
+        y[b,q,o] = sum_ch weff[o,ch] (sum_e a_e k[e,ch] f[b,j(e),ch]) + rowb[q,o] + bias[o]        (o < 4)
+    The [B,Q,C] transform output and its gradient never exist."""
+
+    @staticmethod
+    def eligible(f, weff, escale) -> bool:
+        return (f.dim() == 3 and weff.dim() == 2 and 1 <= weff.shape[0] <= 4 and f.shape[-1] % 4 == 0 and f.shape[-1] <= 256
+                and weff.shape[1] == f.shape[-1] and (escale is None or not escale.requires_grad))
+
+    @staticmethod
+    def forward(ctx, k, f, weff, rowb, bias, plan, escale):
+        _dev(k, f, weff)
+        k, f, weff = k.contiguous(), f.contiguous(), weff.contiguous()
+        B, n_src, Cc = f.shape
+        OC = weff.shape[0]
+        rb = rowb.contiguous() if rowb is not None else None
+        y = torch.empty(B, plan.Q, OC, device=k.device, dtype=torch.float32)
+        L.check(L.load().gaot_gno_proj_gather_reduce(_p(k), _p(f), _p(weff), _p(rb), _p(bias), B, n_src, Cc, OC, _p(plan.splits),
+                                                     _p(plan.index), plan.Q, _p(escale), _p(y), _stream()),
+                "gaot_gno_proj_gather_reduce")
+        ctx.plan = plan
+        ctx.save_for_backward(k, f, weff, escale if escale is not None else k.new_empty(0))
+        ctx.meta = (escale is not None, rowb.shape if rowb is not None else None, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        k, f, weff, esc = ctx.saved_tensors
+        has_e, rb_shape, has_bias = ctx.meta
+        plan = ctx.plan
+        B, n_src, Cc = f.shape
+        OC = weff.shape[0]
+        lib = L.load()
+        dy = dy.contiguous()
+        need = ctx.needs_input_grad
+        dk = torch.empty_like(k)
+        df = torch.empty_like(f) if need[1] else None
+        drowb = dbias = None
+        if plan.E == 0:
+            dk.zero_()
+            dweff = torch.zeros_like(weff)
+            if df is not None:
+                df.zero_()
+        else:
+            nparts = int(lib.gaot_gno_lift_edge_grad_parts(plan.E, Cc))
+            part = torch.empty(nparts, OC * Cc, device=k.device, dtype=torch.float32)
+            L.check(lib.gaot_gno_proj_backward(_p(dy), _p(k), _p(f), _p(weff), B, plan.Q, n_src, Cc, OC, _p(plan.index),
+                                               _p(plan.edge_query), plan.E, _p(plan.t_splits), _p(plan.t_edge),
+                                               _p(esc) if has_e else None, _p(dk), _p(part), _p(df), _stream()),
+                    "gaot_gno_proj_backward")
+            dweff = colsum(part).reshape(OC, Cc)
+        if rb_shape is not None and need[3]:
+            drowb = batchsum(dy.reshape(B, -1), B).reshape(rb_shape)
+        if has_bias and need[4]:
+            dbias = colsum(dy.reshape(-1, OC))
+        return dk, df, dweff, drowb, dbias, None, None
+
+
+def gno_proj_transform(k, f, weff, rowb, bias, plan, escale=None):
+    return _GNOProjTransform.apply(k, f, weff, rowb, bias, plan, escale)
+
+
 def gno_lift_transform(k, pn, wl, bl, plan, escale=None):
     return _GNOLiftTransform.apply(k, pn, wl, bl, plan, escale)
 

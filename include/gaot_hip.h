@@ -158,6 +158,18 @@ int gaot_gno_lift_edge_grad(const float* dout, const float* k, const float* pn, 
                             int32_t Q, int32_t n_src, int32_t c_in, int32_t C, const int32_t* index32,
                             const int32_t* edge_query, int32_t E, const float* escale, float* dk, float* partial,
                             gaot_stream_t stream);
+/* Decoder variant with the point-wise LINEAR maps that follow the transform (recovery + projection, magno.py:640-668, folded
+ * by the caller into weff [OC,C] and a per-query row bias [Q,OC]; OC = out_channels <= 4) applied inside the kernel:
+ *   y[b,q,o] = sum_ch weff[o,ch] * (sum_e a_e k[e,ch] f[b,j(e),ch]) + rowbias[q,o] + bias[o]        (rowbias / bias may be NULL)
+ * The [B,Q,C] transform output is never written.  Backward from dy [B,Q,OC]: dk [E,C], dF [B,n_src,C] (df may be NULL),
+ * and gaot_gno_lift_edge_grad_parts(E,C) partial rows [OC*C] of dweff (caller sums them with gaot_colsum). */
+int gaot_gno_proj_gather_reduce(const float* k, const float* f, const float* weff, const float* rowbias, const float* bias,
+                                int32_t B, int32_t n_src, int32_t C, int32_t out_channels, const int32_t* splits,
+                                const int32_t* cols, int32_t Q, const float* escale, float* y, gaot_stream_t stream);
+int gaot_gno_proj_backward(const float* dy, const float* k, const float* f, const float* weff, int32_t B, int32_t Q,
+                           int32_t n_src, int32_t C, int32_t out_channels, const int32_t* index32, const int32_t* edge_query,
+                           int32_t E, const int32_t* t_splits, const int32_t* t_edge, const float* escale, float* dk,
+                           float* dweff_partial, float* df, gaot_stream_t stream);
 /* dW[e,:] = escale[e] * sum_b dOut[b, edge_query[e], :] * f[b, index[e], :]   (escale may be NULL) */
 int gaot_gno_edge_grad(const float* dout, const float* f, int32_t B, int32_t Q, int32_t n_src, int32_t C,
                        const int32_t* index32, const int32_t* edge_query, int32_t E,

@@ -576,3 +576,49 @@ def test_lifted_gno_transform_matches_unfused(B, n_src, Q, ci, C):
     for u, v, w in zip(gf, g0, gd):
         assert u.shape == w.shape
         assert rel(u, w) < 1e-5, (rel(u, w), rel(v, w))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,n_src,Q,OC,C,rb,bias", [(8, 500, 2000, 1, 64, True, False), (3, 200, 300, 4, 64, False, True),
+                                                    (1, 40, 50, 2, 32, True, True), (5, 64, 400, 3, 128, False, False)])
+def test_projected_gno_transform_matches_unfused(B, n_src, Q, OC, C, rb, bias):
+    """Decoder transform with the trailing point-wise linear maps folded in (gno.hip proj_* kernels) against transform + GEMM
+    (magno.py:640-668 after agno.py:245-271): y, dk, dF, dweff, d rowbias, d bias; empty segments included."""
+    from gaot_amd import ops
+    from gaot_amd.plan import GeometryPlan
+    g = torch.Generator().manual_seed(B * 1000 + Q + OC)
+    deg = torch.randint(0, 7, (Q,), generator=g)
+    deg[::5] = 0
+    splits = torch.cat([torch.zeros(1, dtype=torch.long), deg.cumsum(0)])
+    E = int(splits[-1])
+    index = torch.randint(0, n_src, (E,), generator=g)
+    d = "cuda"
+    plan = GeometryPlan(index.to(d), splits.to(d), n_src)
+    k = torch.randn(E, C, generator=g).to(d).requires_grad_()
+    f = torch.randn(B, n_src, C, generator=g).to(d).requires_grad_()
+    weff = (torch.randn(OC, C, generator=g) * 0.3).to(d).requires_grad_()
+    rowb = torch.randn(Q, OC, generator=g).to(d).requires_grad_() if rb else None
+    bs = torch.randn(OC, generator=g).to(d).requires_grad_() if bias else None
+    a = torch.rand(max(E, 1), generator=g).to(d)
+    dy = torch.randn(B, Q, OC, generator=g).to(d)
+    params = [k, f, weff] + ([rowb] if rb else []) + ([bs] if bias else [])
+    assert ops._GNOProjTransform.eligible(f, weff, a)
+    y = ops.gno_proj_transform(k, f, weff, rowb, bs, plan, a)
+    gf = torch.autograd.grad(y, params, dy)
+    y0 = ops.linear(ops.gno_transform(k, f, plan, a), weff, bs, rowbias=rowb)
+    g0 = torch.autograd.grad(y0, params, dy)
+    pd = [p.detach().double().cpu().requires_grad_() for p in params]
+    kd, fd, wd = pd[:3]
+    eq = torch.repeat_interleave(torch.arange(Q), deg)
+    A = torch.zeros(B, Q, C, dtype=torch.float64).index_add_(1, eq, a[:E].double().cpu()[None, :, None] * kd[None] * fd[:, index, :])
+    yd = A @ wd.t()
+    i = 3
+    if rb:
+        yd = yd + pd[i][None]; i += 1
+    if bias:
+        yd = yd + pd[i]
+    gd = torch.autograd.grad(yd, pd, dy.double().cpu())
+    assert rel(y, yd) < 2e-6 and rel(y0, yd) < 2e-6
+    for u, v, w in zip(gf, g0, gd):
+        assert u.shape == w.shape
+        assert rel(u, w) < 1e-5, (rel(u, w), rel(v, w))
