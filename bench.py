@@ -158,11 +158,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit(f"--gpus {args.gpus} needs a torch.distributed.run launch with --nproc-per-node {args.gpus}")
+    # test hooks (1-GPU boxes only): run the N > 1 code path with every rank on device 0 over gloo
+    if os.environ.get("GAOT_BENCH_FORCE_DEVICE") is not None:
+        local = int(os.environ["GAOT_BENCH_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)      # RCCL over xGMI
+        backend = os.environ.get("GAOT_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)      # RCCL over xGMI
+        else:
+            dist.init_process_group(backend=backend)
 
     from gaot_amd.trainer import TrainStep
     torch.manual_seed(0)                      # identical weights on every rank (and broadcast from rank 0 anyway)
