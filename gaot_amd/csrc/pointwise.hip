@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
     for (int d = lane; d < D; d += 64) yr[d] = xr[d] * r * w[d];
 }
 
-constexpr int RMS_ROWS_PER_BLOCK = 32;
+constexpr int RMS_ROWS_PER_BLOCK = 8;
 constexpr int RMS_MAX_D = 2048;
 
 // dx = r*(w*dy) - x*r^3*mean(w*dy*x) (+dx_add) ; dw partial per block = sum_rows dy*x*r
@@ -232,31 +232,34 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
     __syncthreads();
     if (wave == 0 && n < N) out[n] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
 }
-// short matrices (M <= 1024 rows, e.g. per-workgroup partial rows): ONE launch; 64 columns per workgroup as 16 float4
-// lanes x 16 row groups, unrolled x4 so every thread has 4 independent 16-byte loads in flight, fixed-order LDS sum
+// short matrices (M <= 1024 rows, e.g. per-workgroup partial rows): ONE launch; 16 columns per workgroup as 4 float4
+// lanes x 64 row groups (N / 16 workgroups: the matrix is tiny, parallelism comes from splitting the columns finely),
+// four independent 16-byte loads in flight per thread, fixed-order LDS sum
 __global__ __launch_bounds__(256) void colsum_small_kernel(const float* __restrict__ x, int M, int N, float* __restrict__ out) {
-    __shared__ f32x4 red[16][16];
-    const int c4 = threadIdx.x & 15, rg = threadIdx.x >> 4;
-    const int n = blockIdx.x * 64 + c4 * 4;
+    __shared__ f32x4 red[64][4];
+    const int c4 = threadIdx.x & 3, rg = threadIdx.x >> 2;
+    const int n = blockIdx.x * 16 + c4 * 4;
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
     if (n < N) {
         int r = rg;
-        for (; r + 48 < M; r += 64) {
+        for (; r + 192 < M; r += 256) {
             s0 += *reinterpret_cast<const f32x4*>(x + (long)r * N + n);
-            s1 += *reinterpret_cast<const f32x4*>(x + (long)(r + 16) * N + n);
-            s2 += *reinterpret_cast<const f32x4*>(x + (long)(r + 32) * N + n);
-            s3 += *reinterpret_cast<const f32x4*>(x + (long)(r + 48) * N + n);
+            s1 += *reinterpret_cast<const f32x4*>(x + (long)(r + 64) * N + n);
+            s2 += *reinterpret_cast<const f32x4*>(x + (long)(r + 128) * N + n);
+            s3 += *reinterpret_cast<const f32x4*>(x + (long)(r + 192) * N + n);
         }
-        for (; r < M; r += 16) s0 += *reinterpret_cast<const f32x4*>(x + (long)r * N + n);
+        for (; r < M; r += 64) s0 += *reinterpret_cast<const f32x4*>(x + (long)r * N + n);
     }
     red[rg][c4] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (rg == 0 && n < N) {
-        f32x4 t = red[0][c4];
+    if (rg < 4) {                      // 4 threads per float4 column: 16 row groups each, then a 2-step exchange
+        f32x4 t = red[rg][c4];
 #pragma unroll
-        for (int g = 1; g < 16; ++g) t += red[g][c4];
-        *reinterpret_cast<f32x4*>(out + n) = t;
+        for (int g = 1; g < 16; ++g) t += red[rg + 4 * g][c4];
+        red[rg][c4] = t;
     }
+    __syncthreads();
+    if (rg == 0 && n < N) *reinterpret_cast<f32x4*>(out + n) = (red[0][c4] + red[1][c4]) + (red[2][c4] + red[3][c4]);
 }
 __global__ void batchsum_kernel(const float* __restrict__ x, int B, long RN, float* __restrict__ out) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < RN; i += (long)gridDim.x * blockDim.x) {
@@ -425,7 +428,7 @@ extern "C" int gaot_colsum(const float* x, int64_t ld, int32_t M, int32_t N, flo
                            gaot_stream_t stream) {
     GAOT_REQUIRE(x && out && scratch && M > 0 && N > 0, "colsum: bad arguments");
     if (M <= 1024 && ld == N && N % 4 == 0 && aligned16(x) && aligned16(out)) {   // per-workgroup partial rows of the norm-weight gradients
-        hipLaunchKernelGGL(colsum_small_kernel, dim3(cdiv(N, 64)), dim3(256), 0, ST(stream), x, M, N, out);
+        hipLaunchKernelGGL(colsum_small_kernel, dim3(cdiv(N, 16)), dim3(256), 0, ST(stream), x, M, N, out);
         GAOT_CHECK_LAUNCH("gaot_colsum");
         return GAOT_OK;
     }
