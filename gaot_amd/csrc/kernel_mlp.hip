@@ -15,7 +15,7 @@
 // must become the k index), dW_m += G_m H_{m-1}^T on MFMA into per-wave accumulators that live for the whole kernel
 // (192 registers for 3 layers: the accumulator half of the register file), db_m and dW_1 (c_in columns) from the same
 // operand registers on the VALU, dH = W^T G from registers again.  Workgroups are persistent; per-workgroup partial
-// gradients go to a workspace and a second kernel sums them in fixed order (deterministic, no atomics).
+// gradients go to a workspace and the short-matrix column sum (pointwise.hip) adds them in fixed order (deterministic, no atomics).
 #include "common.h"
 
 namespace gaot {
@@ -347,21 +347,6 @@ __global__ __launch_bounds__(256, 1) void kernel_mlp_bwd_kernel(const KMArgs p) 
     for (int i = tid; i < nsmall; i += 256) dst[NL * 4096 + i] = R[i];
 }
 
-__global__ __launch_bounds__(256) void kernel_mlp_reduce_kernel(const float* __restrict__ ws, int nparts, int psize, float* __restrict__ out) {
-    // 64 columns per workgroup, the partials dealt round-robin to 4 row groups (fixed order: deterministic)
-    __shared__ float red[4][64];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
-    float s0 = 0.f, s1 = 0.f;
-    if (col < psize) {
-        int b = grp;
-        for (; b + 4 < nparts; b += 8) { s0 += ws[(long)b * psize + col]; s1 += ws[(long)(b + 4) * psize + col]; }
-        if (b < nparts) s0 += ws[(long)b * psize + col];
-    }
-    red[grp][threadIdx.x & 63] = s0 + s1;
-    __syncthreads();
-    if (grp == 0 && col < psize) out[col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-}
-
 static int km_check(const float* x, int E, int cin, int n_layers, const float* const* w, const float* const* b) {
     GAOT_REQUIRE(x && E > 0 && cin >= 1 && cin <= KM_MAXC, "kernel_mlp: need x, E > 0 and 1 <= c_in <= %d (got %d)", KM_MAXC, cin);
     GAOT_REQUIRE(n_layers >= 2 && n_layers <= 4, "kernel_mlp: 2..4 layers (got %d)", n_layers);
@@ -417,7 +402,8 @@ extern "C" int gaot_kernel_mlp_bwd(const float* x, int32_t E, int32_t cin, int32
                         else hipLaunchKernelGGL((kernel_mlp_bwd_kernel<NL, KM_MAXC>), dim3(grid), dim3(256), 0, st, a); } while (0)
     if (n_layers == 2) KM_BWD(1); else if (n_layers == 3) KM_BWD(2); else KM_BWD(3);
 #undef KM_BWD
-    hipLaunchKernelGGL(kernel_mlp_reduce_kernel, dim3(cdiv(a.psize, 64)), dim3(256), 0, st, workspace, grid, a.psize, grads);
+    // fixed-order sum of the per-workgroup partial rows: the short-matrix column sum of pointwise.hip (<= 256 rows)
+    if (int rc = gaot_colsum(workspace, a.psize, grid, a.psize, grads, workspace, stream)) return rc;
     GAOT_CHECK_LAUNCH("gaot_kernel_mlp_bwd");
     return GAOT_OK;
 }
