@@ -88,8 +88,11 @@ class FlatGradBucket:
 
     def all_reduce_mean(self, group=None):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-            self.flat.div_(dist.get_world_size(group))
+            if dist.get_backend(group) == "nccl":       # RCCL averages in the collective: no separate scaling pass
+                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=group)
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+                self.flat.div_(dist.get_world_size(group))
 
 
 class FlatAdamW:
