@@ -43,6 +43,13 @@ __device__ __forceinline__ void gelu_both(float z, float& h, float& d) {
     d = cdf + z * pdf;
 }
 
+// hidden activation: ACT = GAOT_ACT_GELU (kernel MLP of the integral transform) or GAOT_ACT_RELU (geometry embedding)
+template <int ACT> __device__ __forceinline__ float act_f(float z) { return ACT == GAOT_ACT_RELU ? fmaxf(z, 0.f) : gelu_f(z); }
+template <int ACT> __device__ __forceinline__ void act_both(float z, float& h, float& d) {
+    if (ACT == GAOT_ACT_RELU) { h = fmaxf(z, 0.f); d = z > 0.f ? 1.f : 0.f; }
+    else gelu_both(z, h, d);
+}
+
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -123,7 +130,7 @@ __device__ __forceinline__ void km_load_x(const KMArgs& p, int e, float (&xr)[CM
 }
 
 // ------------------------------------------------------------------------------------------ forward
-template <int NL, int CM>
+template <int NL, int CM, int ACT>
 __global__ __launch_bounds__(256) void kernel_mlp_fwd_kernel(const KMArgs p) {
     __shared__ __attribute__((aligned(16))) float Ws[NL * 64 * KM_WLD];
     __shared__ __attribute__((aligned(16))) float W1s[64 * KM_MAXC];
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(256) void kernel_mlp_fwd_kernel(const KMArgs p) {
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int t = 0; t < 16; ++t) h[kt][t] = (p.abl & 2) ? z[kt][t] : gelu_f(z[kt][t]);
+            for (int t = 0; t < 16; ++t) h[kt][t] = (p.abl & 2) ? z[kt][t] : act_f<ACT>(z[kt][t]);
         if (p.abl & 4) { z[0] = h[0]; z[1] = h[1]; }
         else km_layer(Ws + m * 64 * KM_WLD, Bs + 64 * (m + 1), h, li, hi, z);
     }
@@ -165,7 +172,7 @@ __global__ __launch_bounds__(256) void kernel_mlp_fwd_kernel(const KMArgs p) {
 // chain (registers only), and QUADRANT (io_w, kt_w) = (w >> 1, w & 1) of every layer's weight gradient over all 128
 // edges (operands from the workgroup's [feature][128 edges] LDS tiles), so its accumulators are 16 registers per layer.
 constexpr int KM_TLD128 = 132;   // floats per row of a [64 features][128 edges] tile
-template <int NL, int CM>
+template <int NL, int CM, int ACT>
 __global__ __launch_bounds__(256, 1) void kernel_mlp_bwd_kernel(const KMArgs p) {
     constexpr int WS_FLOATS = NL * 64 * KM_WLD;
     constexpr int TILE = 64 * KM_TLD128;
@@ -216,7 +223,7 @@ __global__ __launch_bounds__(256, 1) void kernel_mlp_bwd_kernel(const KMArgs p) 
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int t = 0; t < 16; ++t) {
-                    h[kt][t] = gelu_f(z[m - 1][kt][t]);
+                    h[kt][t] = act_f<ACT>(z[m - 1][kt][t]);
                     if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
             km_layer(Ws + (m - 1) * 64 * KM_WLD, Bs + 64 * m, h, li, hi, z[m]);
@@ -260,7 +267,7 @@ __global__ __launch_bounds__(256, 1) void kernel_mlp_bwd_kernel(const KMArgs p) 
                         dh[io] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[io * 32], g[kt][t], dh[io], 0, 0, 0);
                     // one GELU pair per MFMA pair (same element index: its Z is dead for the MFMAs)
                     float hv, dv;
-                    gelu_both(z[m - 1][kt][t], hv, dv);
+                    act_both<ACT>(z[m - 1][kt][t], hv, dv);
                     z[m - 1][kt][t] = dv;
                     Ht[(kt * 32 + crow(t, hi)) * KM_TLD128 + wave * 32 + li] = hv;
                     if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
@@ -371,16 +378,19 @@ using namespace gaot;
 extern "C" int gaot_debug_set_kernel_mlp_ablate(int bits) { const int old = g_km_abl; g_km_abl = bits; return old; }
 
 extern "C" int gaot_kernel_mlp_fwd(const float* x, int32_t E, int32_t cin, int32_t n_layers, const float* const* w,
-                                   const float* const* b, float* out, gaot_stream_t stream) {
+                                   const float* const* b, int32_t act, float* out, gaot_stream_t stream) {
     if (int rc = km_check(x, E, cin, n_layers, w, b)) return rc;
+    GAOT_REQUIRE(act == GAOT_ACT_GELU || act == GAOT_ACT_RELU, "kernel_mlp: hidden activation must be GAOT_ACT_GELU or GAOT_ACT_RELU (got %d)", act);
     GAOT_REQUIRE(out && aligned16(out), "kernel_mlp_fwd: out must be non-null and 16-byte aligned");
     KMArgs a{}; km_fill(a, x, E, cin, n_layers, w, b); a.out = out;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid(a.ntiles), block(256);
-#define KM_FWD(NL) do { if (cin == 4) hipLaunchKernelGGL((kernel_mlp_fwd_kernel<NL, 4>), grid, block, 0, st, a); \
-                        else hipLaunchKernelGGL((kernel_mlp_fwd_kernel<NL, KM_MAXC>), grid, block, 0, st, a); } while (0)
+#define KM_FWD2(NL, A) do { if (cin == 4) hipLaunchKernelGGL((kernel_mlp_fwd_kernel<NL, 4, A>), grid, block, 0, st, a); \
+                            else hipLaunchKernelGGL((kernel_mlp_fwd_kernel<NL, KM_MAXC, A>), grid, block, 0, st, a); } while (0)
+#define KM_FWD(NL) do { if (act == GAOT_ACT_RELU) KM_FWD2(NL, GAOT_ACT_RELU); else KM_FWD2(NL, GAOT_ACT_GELU); } while (0)
     if (n_layers == 2) KM_FWD(1); else if (n_layers == 3) KM_FWD(2); else KM_FWD(3);
 #undef KM_FWD
+#undef KM_FWD2
     GAOT_CHECK_LAUNCH("gaot_kernel_mlp_fwd");
     return GAOT_OK;
 }
@@ -392,16 +402,20 @@ extern "C" int64_t gaot_kernel_mlp_bwd_workspace(int32_t E, int32_t cin, int32_t
 }
 
 extern "C" int gaot_kernel_mlp_bwd(const float* x, int32_t E, int32_t cin, int32_t n_layers, const float* const* w,
-                                   const float* const* b, const float* dk, float* grads, float* workspace, gaot_stream_t stream) {
+                                   const float* const* b, int32_t act, const float* dk, float* grads, float* workspace,
+                                   gaot_stream_t stream) {
     if (int rc = km_check(x, E, cin, n_layers, w, b)) return rc;
+    GAOT_REQUIRE(act == GAOT_ACT_GELU || act == GAOT_ACT_RELU, "kernel_mlp: hidden activation must be GAOT_ACT_GELU or GAOT_ACT_RELU (got %d)", act);
     GAOT_REQUIRE(dk && grads && workspace && aligned16(dk), "kernel_mlp_bwd: dk (16-byte aligned), grads, workspace must be non-null");
     KMArgs a{}; km_fill(a, x, E, cin, n_layers, w, b); a.dk = dk; a.ws = workspace;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int grid = a.ntiles > 256 ? 256 : a.ntiles;
-#define KM_BWD(NL) do { if (cin == 4) hipLaunchKernelGGL((kernel_mlp_bwd_kernel<NL, 4>), dim3(grid), dim3(256), 0, st, a); \
-                        else hipLaunchKernelGGL((kernel_mlp_bwd_kernel<NL, KM_MAXC>), dim3(grid), dim3(256), 0, st, a); } while (0)
+#define KM_BWD2(NL, A) do { if (cin == 4) hipLaunchKernelGGL((kernel_mlp_bwd_kernel<NL, 4, A>), dim3(grid), dim3(256), 0, st, a); \
+                            else hipLaunchKernelGGL((kernel_mlp_bwd_kernel<NL, KM_MAXC, A>), dim3(grid), dim3(256), 0, st, a); } while (0)
+#define KM_BWD(NL) do { if (act == GAOT_ACT_RELU) KM_BWD2(NL, GAOT_ACT_RELU); else KM_BWD2(NL, GAOT_ACT_GELU); } while (0)
     if (n_layers == 2) KM_BWD(1); else if (n_layers == 3) KM_BWD(2); else KM_BWD(3);
 #undef KM_BWD
+#undef KM_BWD2
     // fixed-order sum of the per-workgroup partial rows: the short-matrix column sum of pointwise.hip (<= 256 rows)
     if (int rc = gaot_colsum(workspace, a.psize, grid, a.psize, grads, workspace, stream)) return rc;
     GAOT_CHECK_LAUNCH("gaot_kernel_mlp_bwd");

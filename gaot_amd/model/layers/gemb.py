@@ -34,14 +34,21 @@ class GeometricEmbedding(nn.Module):
         else:
             raise ValueError(f"Unknown method: {self.method}")
 
-    def forward(self, input_geom, latent_queries, spatial_nbrs, stats=None):
+    def forward(self, input_geom, latent_queries, spatial_nbrs, stats=None, head=None):
+        """`head` = (W [C_out, output_dim], b [C_out]): a Linear applied to the embedding by the caller (the geoembed half of
+        the recovery block, magno.py:345-350); with it the statistical branch is ONE chain relu, relu, none that the fused
+        row-wise MLP kernels serve when every width is 64."""
         plan = plan_for(spatial_nbrs, input_geom.shape[0])
         if self.method == 'statistical':
             if stats is None:
                 stats = plan.geo_stats(input_geom, latent_queries)      # [Q, 3+2d], cached per geometry
+            if head is not None:
+                return ops.mlp_chain(stats, [self.mlp[0].weight, self.mlp[2].weight, head[0]],
+                                     [self.mlp[0].bias, self.mlp[2].bias, head[1]], ["relu", "relu", "none"])
             return ops.mlp_chain(stats, [self.mlp[0].weight, self.mlp[2].weight],
                                  [self.mlp[0].bias, self.mlp[2].bias], ["relu", "relu"])
-        return self._pointnet(plan, input_geom, latent_queries)
+        emb = self._pointnet(plan, input_geom, latent_queries)
+        return emb if head is None else ops.linear(emb, head[0], head[1])
 
     def _pointnet(self, plan, geom, queries):
         """Per-edge MLP on centred neighbour coordinates, pooled per query (gemb.py:173-228)."""

@@ -151,9 +151,9 @@ class _MAGNOBase(nn.Module):
                 if hit is not None and hit[0] == key and hit[1] is nb:
                     rowb = hit[2]
             if rowb is None:
-                ge = self.geoembed(input_geom=src_coord, latent_queries=dst_coord, spatial_nbrs=nb,
-                                   stats=stats if nb is neighbors else None)                      # [n_dst, C]
-                rowb = ops.linear(ge, w_geo, self.recovery.fcs[0].bias)                          # [n_dst, C]
+                # embedding MLP and the geoembed half of the recovery block as one chain: [n_dst, C]
+                rowb = self.geoembed(input_geom=src_coord, latent_queries=dst_coord, spatial_nbrs=nb,
+                                     stats=stats if nb is neighbors else None, head=(w_geo, self.recovery.fcs[0].bias))
                 if key is not None:
                     self._infer_cache["rowb"] = (key, nb, rowb)
             if head is not None:

@@ -443,7 +443,7 @@ class _KernelMLP(torch.autograd.Function):
         n = len(weights)
         if not (2 <= n <= 4) or x.dim() != 2 or x.requires_grad or not x.is_cuda or x.shape[0] == 0:
             return False
-        if list(acts) != ["gelu"] * (n - 1) + ["none"] or any(b is None for b in biases):
+        if list(acts) not in (["gelu"] * (n - 1) + ["none"], ["relu"] * (n - 1) + ["none"]) or any(b is None for b in biases):
             return False
         cin = x.shape[1]
         if cin > 16 or tuple(weights[0].shape) != (64, cin):
@@ -458,17 +458,17 @@ class _KernelMLP(torch.autograd.Function):
         return arr
 
     @staticmethod
-    def forward(ctx, x, n, *wb):
+    def forward(ctx, x, n, act, *wb):
         x = x.contiguous()
         ws = [w.contiguous() for w in wb[:n]]
         bs = [b.contiguous() for b in wb[n:]]
         _dev(x, *ws, *bs)
         E, cin = x.shape
         out = torch.empty(E, 64, device=x.device, dtype=torch.float32)
-        L.check(L.load().gaot_kernel_mlp_fwd(_p(x), E, cin, n, _KernelMLP._ptrs(ws), _KernelMLP._ptrs(bs), _p(out), _stream()),
+        L.check(L.load().gaot_kernel_mlp_fwd(_p(x), E, cin, n, _KernelMLP._ptrs(ws), _KernelMLP._ptrs(bs), act, _p(out), _stream()),
                 "gaot_kernel_mlp_fwd")
         ctx.save_for_backward(x, *ws, *bs)
-        ctx.n = n
+        ctx.n, ctx.act = n, act
         return out
 
     @staticmethod
@@ -482,18 +482,18 @@ class _KernelMLP(torch.autograd.Function):
         psize = (n - 1) * 4096 + 64 * cin + 64 * n
         grads = torch.empty(psize, device=x.device, dtype=torch.float32)
         wsp = torch.empty(int(lib.gaot_kernel_mlp_bwd_workspace(E, cin, n)), device=x.device, dtype=torch.float32)
-        L.check(lib.gaot_kernel_mlp_bwd(_p(x), E, cin, n, _KernelMLP._ptrs(ws), _KernelMLP._ptrs(bs), _p(dk), _p(grads), _p(wsp),
-                                        _stream()), "gaot_kernel_mlp_bwd")
+        L.check(lib.gaot_kernel_mlp_bwd(_p(x), E, cin, n, _KernelMLP._ptrs(ws), _KernelMLP._ptrs(bs), ctx.act, _p(dk), _p(grads),
+                                        _p(wsp), _stream()), "gaot_kernel_mlp_bwd")
         o = (n - 1) * 4096
         dws = [grads[o:o + 64 * cin].view(64, cin)] + [grads[m * 4096:(m + 1) * 4096].view(64, 64) for m in range(n - 1)]
         ob = o + 64 * cin
         dbs = [grads[ob + 64 * i:ob + 64 * (i + 1)] for i in range(n)]
-        return (None, None, *dws, *dbs)
+        return (None, None, None, *dws, *dbs)
 
 
 def mlp_chain(x, weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]], acts: Sequence[str]):
     if _FUSED_KERNEL_MLP and _KernelMLP.eligible(x, weights, biases, acts):
-        return _KernelMLP.apply(x, len(weights), *weights, *biases)
+        return _KernelMLP.apply(x, len(weights), ACT[acts[0]], *weights, *biases)
     wb = []
     for w, b in zip(weights, biases):
         wb += [w, b]

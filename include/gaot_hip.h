@@ -216,20 +216,22 @@ int64_t gaot_colsum_scratch(int32_t M, int32_t N);
 int gaot_colsum(const float* x, int64_t ld, int32_t M, int32_t N, float* out, float* scratch, gaot_stream_t stream);
 /* out[r,:] = sum_b x[b,r,:]   (row-periodic bias gradients; x is [B,R,N] contiguous) */
 int gaot_batchsum(const float* x, int32_t B, int64_t RN, float* out, gaot_stream_t stream);
-/* Fused kernel MLP of the integral transform (LinearChannelMLP, mlp.py:307-337, called per edge at agno.py:229-231):
- *   out[e,:] = W_L(... gelu(W_2 gelu(W_1 x[e,:] + b_1) + b_2) ...) + b_L,   exact-erf GELU after every layer but the last.
+/* Fused row-wise MLP, every width 64: the kernel MLP of the integral transform (LinearChannelMLP, mlp.py:307-337, called per
+ * edge at agno.py:229-231; act = GAOT_ACT_GELU) and the statistical geometry embedding followed by its recovery block
+ * (gemb.py:54-59 + magno.py:345-350; act = GAOT_ACT_RELU):
+ *   out[e,:] = W_L(... act(W_2 act(W_1 x[e,:] + b_1) + b_2) ...) + b_L,   `act` after every layer but the last.
  * x [E, c_in] (c_in <= 16), n_layers = 2..4, W_1 [64, c_in], every other W_i [64, 64], b_i [64]; w / b are HOST arrays of
  * n_layers device pointers.  Forward: one launch, activations never leave registers.  Backward: recomputes the chain,
  * returns the packed parameter gradient  grads = [dW_2 | .. | dW_L | dW_1 (64 x c_in) | db_1 | db_2 | .. | db_L]
  * ((n_layers-1)*4096 + 64*c_in + 64*n_layers floats) through `workspace` (gaot_kernel_mlp_bwd_workspace() floats:
  * per-workgroup partials summed in fixed order).  x gets no gradient (edge coordinates). */
 int gaot_kernel_mlp_fwd(const float* x, int32_t E, int32_t c_in, int32_t n_layers, const float* const* w,
-                        const float* const* b, float* out, gaot_stream_t stream);
+                        const float* const* b, int32_t act, float* out, gaot_stream_t stream);
 /* tuning hook (results become WRONG): forward kernel 1 = no stores, 2 = no GELU, 4 = no MFMA layers, 8 = no weight staging */
 int gaot_debug_set_kernel_mlp_ablate(int bits);
 int64_t gaot_kernel_mlp_bwd_workspace(int32_t E, int32_t c_in, int32_t n_layers);
 int gaot_kernel_mlp_bwd(const float* x, int32_t E, int32_t c_in, int32_t n_layers, const float* const* w,
-                        const float* const* b, const float* dk, float* grads, float* workspace, gaot_stream_t stream);
+                        const float* const* b, int32_t act, const float* dk, float* grads, float* workspace, gaot_stream_t stream);
 /* nn.MSELoss() with mean reduction (the reference trainers' loss, base_trainer.py:71): loss[0] = mean((pred - target)^2) over
  * n elements through `partial` (>= 256 floats; fixed-order two-stage sum, deterministic); backward
  * dpred = 2 (pred - target) / n * grad_loss[0] with grad_loss a DEVICE scalar (so the launch replays inside a hipGraph). */

@@ -464,8 +464,10 @@ def test_gemm_split_bf16_exactness_of_the_split():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("E,cin,n", [(55592, 4, 4), (1000, 4, 4), (131, 6, 4), (4097, 4, 3), (300, 12, 2), (31, 4, 4)])
-def test_fused_kernel_mlp_matches_chain_and_float64(E, cin, n):
+@pytest.mark.parametrize("E,cin,n,act", [(55592, 4, 4, "gelu"), (1000, 4, 4, "gelu"), (131, 6, 4, "gelu"), (4097, 4, 3, "gelu"),
+                                         (300, 12, 2, "gelu"), (31, 4, 4, "gelu"), (4096, 7, 3, "relu"), (16384, 7, 3, "relu"),
+                                         (77, 9, 3, "relu")])
+def test_fused_kernel_mlp_matches_chain_and_float64(E, cin, n, act):
     """csrc/kernel_mlp.hip (one launch forward, one backward) against the GEMM-chain path of the same op and a float64
     torch reference: output, every weight / bias gradient (mlp.py:307-337 semantics, exact-erf GELU)."""
     from gaot_amd import ops
@@ -475,7 +477,7 @@ def test_fused_kernel_mlp_matches_chain_and_float64(E, cin, n):
     dims = [cin] + [64] * n
     ws = [(torch.randn(dims[i + 1], dims[i], device=d) / dims[i] ** 0.5).requires_grad_() for i in range(n)]
     bs = [(0.1 * torch.randn(64, device=d)).requires_grad_() for _ in range(n)]
-    acts = ["gelu"] * (n - 1) + ["none"]
+    acts = [act] * (n - 1) + ["none"]
     dk = torch.randn(E, 64, device=d)
     assert ops._KernelMLP.eligible(x, ws, bs, acts)
     y = ops.mlp_chain(x, ws, bs, acts)
@@ -493,7 +495,7 @@ def test_fused_kernel_mlp_matches_chain_and_float64(E, cin, n):
     for i in range(n):
         h = h @ wd[i].t() + bd[i]
         if i < n - 1:
-            h = torch.nn.functional.gelu(h)
+            h = torch.nn.functional.gelu(h) if act == "gelu" else torch.relu(h)
     gd = torch.autograd.grad(h, wd + bd, dk.double())
     assert rel(y, h) < 2e-6 and rel(y, y0) < 2e-6
     for a, b, c in zip(gf, g0, gd):
