@@ -57,7 +57,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 // stage the weights of the workgroup: Ws[m] = W_{m+1} as [64][KM_WLD], W1s [64][cin], biases
-template <int NL>
+template <int NL, int CM>
 __device__ __forceinline__ void km_stage_weights(const KMArgs& p, float* Ws, float* W1s, float* Bs, int tid) {
 #pragma unroll
     for (int m = 0; m < NL; ++m)
@@ -65,7 +65,7 @@ __device__ __forceinline__ void km_stage_weights(const KMArgs& p, float* Ws, flo
             const int r = i >> 4, c4 = (i & 15) * 4;
             *reinterpret_cast<f32x4*>(Ws + m * 64 * KM_WLD + r * KM_WLD + c4) = *reinterpret_cast<const f32x4*>(p.w[m] + r * 64 + c4);
         }
-    for (int i = tid; i < 64 * p.cin; i += 256) W1s[i] = p.w1[i];
+    for (int i = tid; i < 64 * CM; i += 256) { const int f = i / CM, c = i % CM; W1s[i] = c < p.cin ? p.w1[f * p.cin + c] : 0.f; }   // rows padded to CM
     if (tid < 64) {
         Bs[tid] = p.b1[tid];
 #pragma unroll
@@ -82,13 +82,11 @@ __device__ __forceinline__ void km_layer0(const float* W1s, const float* Bs, con
         for (int t = 0; t < 16; ++t) {
             const int f = kt * 32 + crow(t, hi);
             float v = Bs[f];
-            const float* wr = W1s + f * cin;
-            if (CM == 4) {
-                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr);
-                v += w4[0] * xr[0] + w4[1] * xr[1] + w4[2] * xr[2] + w4[3] * xr[3];
-            } else {
+            const float* wr = W1s + f * CM;              // zero-padded row: whole 16-byte chunks, no per-column predicate
 #pragma unroll
-                for (int c = 0; c < CM; ++c) if (c < cin) v += wr[c] * xr[c];
+            for (int c4 = 0; c4 < CM / 4; ++c4) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + 4 * c4);
+                v += (w4[0] * xr[4 * c4] + w4[1] * xr[4 * c4 + 1]) + (w4[2] * xr[4 * c4 + 2] + w4[3] * xr[4 * c4 + 3]);
             }
             z[kt][t] = v;
             if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // keep the scheduler from hoisting all 32 weight-row reads
@@ -137,7 +135,7 @@ __global__ __launch_bounds__(256) void kernel_mlp_fwd_kernel(const KMArgs p) {
     __shared__ float Bs[64 * (NL + 1)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, hi = lane >> 5;
-    if (!(p.abl & 8)) km_stage_weights<NL>(p, Ws, W1s, Bs, tid);
+    if (!(p.abl & 8)) km_stage_weights<NL, CM>(p, Ws, W1s, Bs, tid);
     __syncthreads();
     const int e0 = (blockIdx.x * 4 + wave) * 32;
     if (e0 >= p.E) return;
@@ -187,7 +185,7 @@ __global__ __launch_bounds__(256, 1) void kernel_mlp_bwd_kernel(const KMArgs p) 
     const int li = lane & 31, hi = lane >> 5;
     const int io_w = wave >> 1, kt_w = wave & 1;
     const int cin = p.cin;
-    km_stage_weights<NL>(p, Ws, W1s, Bs, tid);
+    km_stage_weights<NL, CM>(p, Ws, W1s, Bs, tid);
     __syncthreads();
 
     f32x16 dW[NL];                       // quadrant (io_w, kt_w): rows = output feature crow(r, hi), column = input feature li
@@ -211,7 +209,7 @@ __global__ __launch_bounds__(256, 1) void kernel_mlp_bwd_kernel(const KMArgs p) 
         km_load_x<CM>(p, e, xr);
         if (hi == 0) {
 #pragma unroll
-            for (int c = 0; c < CM; ++c) if (c < cin) Xt[(wave * 32 + li) * KM_MAXC + c] = valid ? xr[c] : 0.f;
+            for (int c = 0; c < CM; ++c) Xt[(wave * 32 + li) * KM_MAXC + c] = valid ? xr[c] : 0.f;          // xr is zero beyond c_in
         }
         // recompute the forward chain, keeping the pre-activations of the GELU layers
         f32x16 z[NL][2];
@@ -310,12 +308,10 @@ __global__ __launch_bounds__(256, 1) void kernel_mlp_bwd_kernel(const KMArgs p) 
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const float* xe = Xt + (kt_w * 64 + 8 * q + 4 * hi + s) * KM_MAXC;
-                    if (CM == 4) {
-                        const f32x4 xv = *reinterpret_cast<const f32x4*>(xe);
-                        dw1[0] += a[s] * xv[0]; dw1[1] += a[s] * xv[1]; dw1[2] += a[s] * xv[2]; dw1[3] += a[s] * xv[3];
-                    } else {
 #pragma unroll
-                        for (int c = 0; c < CM; ++c) if (c < cin) dw1[c] += a[s] * xe[c];
+                    for (int c4 = 0; c4 < CM / 4; ++c4) {             // x rows are zero beyond c_in
+                        const f32x4 xv = *reinterpret_cast<const f32x4*>(xe + 4 * c4);
+                        dw1[4 * c4] += a[s] * xv[0]; dw1[4 * c4 + 1] += a[s] * xv[1]; dw1[4 * c4 + 2] += a[s] * xv[2]; dw1[4 * c4 + 3] += a[s] * xv[3];
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -386,6 +382,7 @@ extern "C" int gaot_kernel_mlp_fwd(const float* x, int32_t E, int32_t cin, int32
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid(a.ntiles), block(256);
 #define KM_FWD2(NL, A) do { if (cin == 4) hipLaunchKernelGGL((kernel_mlp_fwd_kernel<NL, 4, A>), grid, block, 0, st, a); \
+                            else if (cin <= 8) hipLaunchKernelGGL((kernel_mlp_fwd_kernel<NL, 8, A>), grid, block, 0, st, a); \
                             else hipLaunchKernelGGL((kernel_mlp_fwd_kernel<NL, KM_MAXC, A>), grid, block, 0, st, a); } while (0)
 #define KM_FWD(NL) do { if (act == GAOT_ACT_RELU) KM_FWD2(NL, GAOT_ACT_RELU); else KM_FWD2(NL, GAOT_ACT_GELU); } while (0)
     if (n_layers == 2) KM_FWD(1); else if (n_layers == 3) KM_FWD(2); else KM_FWD(3);
@@ -411,6 +408,7 @@ extern "C" int gaot_kernel_mlp_bwd(const float* x, int32_t E, int32_t cin, int32
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int grid = a.ntiles > 256 ? 256 : a.ntiles;
 #define KM_BWD2(NL, A) do { if (cin == 4) hipLaunchKernelGGL((kernel_mlp_bwd_kernel<NL, 4, A>), dim3(grid), dim3(256), 0, st, a); \
+                            else if (cin <= 8) hipLaunchKernelGGL((kernel_mlp_bwd_kernel<NL, 8, A>), dim3(grid), dim3(256), 0, st, a); \
                             else hipLaunchKernelGGL((kernel_mlp_bwd_kernel<NL, KM_MAXC, A>), dim3(grid), dim3(256), 0, st, a); } while (0)
 #define KM_BWD(NL) do { if (act == GAOT_ACT_RELU) KM_BWD2(NL, GAOT_ACT_RELU); else KM_BWD2(NL, GAOT_ACT_GELU); } while (0)
     if (n_layers == 2) KM_BWD(1); else if (n_layers == 3) KM_BWD(2); else KM_BWD(3);
