@@ -328,12 +328,12 @@ extern "C" int gaot_debug_last_gemm_path(void) { return g_last_path; }
 static int g_use_glds = 1;   // eligible products run on the LDS-direct kernels (gemm_glds.hip); 0 = register-staged only
 namespace gaot { void set_glds_stages(int n); }
 // on: 0 = register-staged kernels only, 1 = LDS-direct with the default 2-stage ring, 3 = LDS-direct with a 3-stage ring,
-// 4 = + split-bf16 tiles by heuristic, 5 = split-bf16 wherever eligible.  Default 1: on the GAOT step the split tiles are
-// 1.2-1.4x faster per launch but every OTHER kernel of the step then runs ~3 % slower (same-box A/B), net zero.
-static int g_use_split = 0;  // 1: eligible products run on the split-bf16 kernel (gemm_split.hip) per the heuristic; 2: always when eligible
+// 4 = + split-bf16 tiles by heuristic (DEFAULT: +5 % on the GAOT step, same-box A/B on two boxes),
+// 5 = split-bf16 wherever eligible, 6 = split-bf16 for the SwiGLU-gate product only.
+static int g_use_split = 1;  // 1: eligible products run on the split-bf16 kernel (gemm_split.hip) per the heuristic; 2: always when eligible
 extern "C" int gaot_debug_set_gemm_glds(int on) {
     const int old = g_use_split ? 3 + g_use_split : g_use_glds;
-    g_use_glds = on != 0; g_use_split = on == 4 ? 1 : (on == 5 ? 2 : 0);
+    g_use_glds = on != 0; g_use_split = on == 4 ? 1 : (on == 5 ? 2 : (on == 6 ? 3 : 0));      // 6: SwiGLU-gate product only
     gaot::set_glds_stages(on == 3 ? 3 : 2);
     return old;
 }
@@ -412,7 +412,7 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
     auto blocks = [&](int bm, int bn) { return (long)cdiv(a.M, bm) * cdiv(a.N, bn) * z; };
     (void)z;
     const bool glds_ok = g_use_glds && vec && a.vec_epi && a.K % 32 == 0 && a.M >= 4 && a.N >= 4;
-    const bool split_ok = g_use_split && glds_ok && a.A2 == nullptr && g_tile_override == 0;
+    const bool split_ok = g_use_split && g_use_split != 3 && glds_ok && a.A2 == nullptr && g_tile_override == 0;
     // measured (tools/gemm_split_test.py): the 128x128 split-bf16 tiles win once they fill the chip (>= 256 workgroups
     // counting split-K slabs) on outputs at least one tile wide; narrower / smaller products stay on the fp32 MFMA tiles
     if (split_ok && (g_use_split == 2 || (blocks(128, 128) >= 250 && a.M >= 128 && a.N >= 128 &&

@@ -83,7 +83,8 @@ int gaot_debug_set_gemm_ablate(int bits);
  * 3 = split-bf16 MFMA tiles (fp32 operands split exactly into three bf16 pieces, six bf16 MFMAs per product, fp32-level error) */
 int gaot_debug_last_gemm_path(void);
 /* tuning hook: 0 = register-staged fp32 tiles only, 1 = + LDS-direct fp32 tiles (2-stage ring), 3 = same with a 3-stage
- * ring (1 is the DEFAULT), 4 = + split-bf16 tiles where the heuristic picks them, 5 = split-bf16 wherever eligible */
+ * ring, 4 = + split-bf16 tiles where the heuristic picks them (DEFAULT), 5 = split-bf16 wherever eligible, 6 = split-bf16
+ * for the SwiGLU-gate product only */
 int gaot_debug_set_gemm_glds(int on);
 
 /* ------------------------------------------------------------------------------------------
