@@ -48,9 +48,11 @@ __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
 
 // ABL (tuning builds only, tools/split_bench.hip): 1 = no split arithmetic (raw words to LDS), 2 = no MFMA, 4 = no
 // epilogue stores, 8 = no LDS fragment reads, 16 = no global loads in the loop
-template <bool AK, bool BKM, int ABL = 0>
+// BM = 128 (4 waves of 64x64) or 64 (4 waves of 32x64: twice the workgroups for outputs only two tiles wide, N = 256)
+template <bool AK, bool BKM, int BM = 128, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
-    constexpr int BM = S_BM, BN = S_BN, NW = 4, WAVES_N = 2, WM = 64, WN = 64, TM = 2, TN = 2;
+    constexpr int BN = S_BN, NW = 4, WAVES_N = 2, WM = BM / 2, WN = 64, TM = WM / 32, TN = 2;
+    constexpr int ABYTES = BM * 4;       // row stride of a row-contiguous A plane ([k pair][BM rows] of packed dwords)
     constexpr int EPI_BYTES = NW * 32 * (WN + 4) * 4;
     constexpr int SMEM_BYTES = 2 * S_STAGE > EPI_BYTES ? 2 * S_STAGE : EPI_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
@@ -83,8 +85,13 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
     const float* a_src[2]; const float* b_src[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        if (AK) { a_src[q] = p.A + (long)min(m0 + (tid >> 1), p.M - 1) * p.lda + (tid & 1) * 8 + q * 4; }
-        else    { a_src[q] = p.A + (long)(2 * (tid >> 5) + q) * p.lda + min(m0 + (tid & 31) * 4, p.M - 4); }
+        if (AK) {
+            if (BM == 128) a_src[q] = p.A + (long)min(m0 + (tid >> 1), p.M - 1) * p.lda + (tid & 1) * 8 + q * 4;
+            else           a_src[q] = p.A + (long)min(m0 + (tid >> 2), p.M - 1) * p.lda + (tid & 3) * 4;      // one float4 per thread (q = 0)
+        } else {
+            if (BM == 128) a_src[q] = p.A + (long)(2 * (tid >> 5) + q) * p.lda + min(m0 + (tid & 31) * 4, p.M - 4);
+            else           a_src[q] = p.A + (long)(2 * ((tid >> 4) & 7) + q) * p.lda + min(m0 + (tid & 15) * 4, p.M - 4);   // threads 0..127
+        }
         if (BKM) {
             int nrow = min(n0 + (tid >> 1), p.N - 1);
             if (p.act == GAOT_ACT_SWIGLU) {      // band layout [u1 cols | u3 cols] per wave band (epilogue_swiglu)
@@ -103,7 +110,9 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
         if ((ABL & 16) && kt > kt_begin + 1) return;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            xa[q] = *reinterpret_cast<const f32x4*>(AK ? a_src[q] + k0 : a_src[q] + k0 * p.lda);
+            const bool a_live = BM == 128 || (AK ? q == 0 : tid < 128);
+            if (a_live) xa[q] = *reinterpret_cast<const f32x4*>(AK ? a_src[q] + k0 : a_src[q] + k0 * p.lda);
+            else xa[q] = f32x4{0.f, 0.f, 0.f, 0.f};
             xb[q] = *reinterpret_cast<const f32x4*>(BKM ? b_src[q] + k0 : b_src[q] + k0 * p.ldb);
         }
     };
@@ -112,27 +121,42 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
     const bool do_colsum = !AK && p.colsum != nullptr && (logical % p.tiles_n) == 0;
     f32x4 csum = {0.f, 0.f, 0.f, 0.f};
 
-    // split + store one operand's registers into its three planes
-    auto stage_store = [&](unsigned char* base, const f32x4 (&r)[2], bool kmajor) {
+    // split + store one operand's registers into its three planes (ROWS = 128: two float4 per thread; ROWS = 64: half of that)
+    auto stage_store = [&](unsigned char* base, const f32x4 (&r)[2], bool kmajor, int rows) {
         if (kmajor) {
-            u32x4 h, m, l;
+            if (rows == 128) {
+                u32x4 h, m, l;
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        unsigned a_, b_, c_;
+                        split3_pair<ABL>(r[q][2 * e], r[q][2 * e + 1], a_, b_, c_);
+                        h[2 * q + e] = a_; m[2 * q + e] = b_; l[2 * q + e] = c_;
+                    }
+                unsigned char* dst = base + (tid >> 1) * 48 + (tid & 1) * 16;
+                *reinterpret_cast<u32x4*>(dst) = h;
+                *reinterpret_cast<u32x4*>(dst + S_PLANE) = m;
+                *reinterpret_cast<u32x4*>(dst + 2 * S_PLANE) = l;
+            } else {
+                u32x2 h, m, l;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     unsigned a_, b_, c_;
-                    split3_pair<ABL>(r[q][2 * e], r[q][2 * e + 1], a_, b_, c_);
-                    h[2 * q + e] = a_; m[2 * q + e] = b_; l[2 * q + e] = c_;
+                    split3_pair<ABL>(r[0][2 * e], r[0][2 * e + 1], a_, b_, c_);
+                    h[e] = a_; m[e] = b_; l[e] = c_;
                 }
-            unsigned char* dst = base + (tid >> 1) * 48 + (tid & 1) * 16;
-            *reinterpret_cast<u32x4*>(dst) = h;
-            *reinterpret_cast<u32x4*>(dst + S_PLANE) = m;
-            *reinterpret_cast<u32x4*>(dst + 2 * S_PLANE) = l;
+                unsigned char* dst = base + (tid >> 2) * 48 + (tid & 3) * 8;
+                *reinterpret_cast<u32x2*>(dst) = h;
+                *reinterpret_cast<u32x2*>(dst + S_PLANE) = m;
+                *reinterpret_cast<u32x2*>(dst + 2 * S_PLANE) = l;
+            }
         } else {
+            if (rows == 64 && tid >= 128) return;
             u32x4 h, m, l;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { unsigned a_, b_, c_; split3_pair<ABL>(r[0][e], r[1][e], a_, b_, c_); h[e] = a_; m[e] = b_; l[e] = c_; }
-            unsigned char* dst = base + (tid >> 5) * 512 + (tid & 31) * 16;
+            unsigned char* dst = rows == 128 ? base + (tid >> 5) * 512 + (tid & 31) * 16 : base + (tid >> 4) * 256 + (tid & 15) * 16;
             *reinterpret_cast<u32x4*>(dst) = h;
             *reinterpret_cast<u32x4*>(dst + S_PLANE) = m;
             *reinterpret_cast<u32x4*>(dst + 2 * S_PLANE) = l;
@@ -140,9 +164,9 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
     };
     auto sstore = [&](int stage, const f32x4 (&xa)[2], const f32x4 (&xb)[2], bool live) {
         unsigned char* sa = smem_raw + stage * S_STAGE;
-        stage_store(sa, xa, AK);
-        stage_store(sa + 3 * S_PLANE, xb, BKM);
-        if (!AK) { const float w = (do_colsum && live) ? 1.f : 0.f; csum += (xa[0] + xa[1]) * w; }   // branch-free: keeps the k-loop one block
+        stage_store(sa, xa, AK, BM);
+        stage_store(sa + 3 * S_PLANE, xb, BKM, 128);
+        if (!AK) { const float w = (do_colsum && live && (BM == 128 || tid < 128)) ? 1.f : 0.f; csum += (xa[0] + xa[1]) * w; }   // branch-free: keeps the k-loop one block
     };
 
     f32x16 acc[TM][TN];
@@ -153,12 +177,12 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    auto frag = [&](const unsigned char* plane, int row, bool kmajor) -> bf16x8 {
+    auto frag = [&](const unsigned char* plane, int row, bool kmajor, int rowbytes) -> bf16x8 {
         if (ABL & 8) { u32x4 v = {(unsigned)row, (unsigned)lh, 1u, 2u}; asm volatile("" : "+v"(v)); return __builtin_bit_cast(bf16x8, v); }
         if (kmajor) return *reinterpret_cast<const bf16x8*>(plane + row * 48 + lh * 16);
         u32x4 v;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const unsigned*>(plane + (lh * 4 + j) * 512 + row * 4);
+        for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const unsigned*>(plane + (lh * 4 + j) * rowbytes + row * 4);
         return __builtin_bit_cast(bf16x8, v);
     };
 
@@ -172,11 +196,11 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) a[i][pl] = frag(sa + pl * S_PLANE, wm * WM + i * 32 + li, AK);
+            for (int pl = 0; pl < 3; ++pl) a[i][pl] = frag(sa + pl * S_PLANE, wm * WM + i * 32 + li, AK, ABYTES);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) b[j][pl] = frag(sb + pl * S_PLANE, wn * WN + j * 32 + li, BKM);
+            for (int pl = 0; pl < 3; ++pl) b[j][pl] = frag(sb + pl * S_PLANE, wn * WN + j * 32 + li, BKM, 512);
         // small terms first
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -203,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
         // interleave: one MFMA, a few VALU ops of the split, now and then one of its LDS writes
         __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);       // the prefetch loads go first: a whole k-tile to land
 #pragma unroll
-        for (int g = 0; g < 24; ++g) {
+        for (int g = 0; g < TM * TN * 6; ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
@@ -222,12 +246,13 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
 
     if (!AK && do_colsum) {          // reduce the 8 k-pair groups through LDS (the stages are free now)
         float* cs = reinterpret_cast<float*>(smem_raw);
-        *reinterpret_cast<f32x4*>(cs + (tid >> 5) * 128 + (tid & 31) * 4) = csum;
+        if (BM == 128) *reinterpret_cast<f32x4*>(cs + (tid >> 5) * BM + (tid & 31) * 4) = csum;
+        else if (tid < 128) *reinterpret_cast<f32x4*>(cs + (tid >> 4) * BM + (tid & 15) * 4) = csum;
         __syncthreads();
         if (tid < BM && m0 + tid < p.M) {
             float s = 0.f;
 #pragma unroll
-            for (int g = 0; g < 8; ++g) s += cs[g * 128 + tid];
+            for (int g = 0; g < 8; ++g) s += cs[g * BM + tid];
             if (p.split_k > 1) p.ws[(long)p.split_k * p.M * p.N + (long)blockIdx.z * p.M + m0 + tid] = s;
             else p.colsum[m0 + tid] = s;
         }
@@ -238,15 +263,21 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
     else epilogue_vec<TM, TN, WM, WN>(p, reinterpret_cast<float*>(smem_raw), acc, m0, n0, wm, wn, wave, lane);
 }
 
-void launch_split(GemmArgs& a, bool ak, bool bk, hipStream_t st) {
-    a.tiles_m = cdiv(a.M, S_BM);
+template <int BM>
+static void launch_split_bm(GemmArgs& a, bool ak, bool bk, hipStream_t st) {
+    a.tiles_m = cdiv(a.M, BM);
     a.tiles_n = cdiv(a.N, S_BN);
     dim3 grid(a.tiles_m * a.tiles_n, 1, a.split_k > 1 ? a.split_k : 1);
     dim3 block(256);
-    if (ak && bk)        hipLaunchKernelGGL((gemm_split_kernel<true, true>), grid, block, 0, st, a);
-    else if (ak && !bk)  hipLaunchKernelGGL((gemm_split_kernel<true, false>), grid, block, 0, st, a);
-    else if (!ak && !bk) hipLaunchKernelGGL((gemm_split_kernel<false, false>), grid, block, 0, st, a);
-    else                 hipLaunchKernelGGL((gemm_split_kernel<false, true>), grid, block, 0, st, a);
+    if (ak && bk)        hipLaunchKernelGGL((gemm_split_kernel<true, true, BM>), grid, block, 0, st, a);
+    else if (ak && !bk)  hipLaunchKernelGGL((gemm_split_kernel<true, false, BM>), grid, block, 0, st, a);
+    else if (!ak && !bk) hipLaunchKernelGGL((gemm_split_kernel<false, false, BM>), grid, block, 0, st, a);
+    else                 hipLaunchKernelGGL((gemm_split_kernel<false, true, BM>), grid, block, 0, st, a);
+}
+
+void launch_split(GemmArgs& a, bool ak, bool bk, hipStream_t st, int bm) {
+    if (bm == 64) launch_split_bm<64>(a, ak, bk, st);
+    else          launch_split_bm<128>(a, ak, bk, st);
 }
 
 }  // namespace gaot

@@ -63,11 +63,11 @@ def gemm(M: int, N: int, K: int, A, lda, a_kmajor, B, ldb, b_kmajor, out, ldc, *
     return out
 
 
-# tuning switch (tools / A-B runs only): GAOT_GEMM_MODE = argument of gaot_debug_set_gemm_glds (default 1: fp32 MFMA
-# tiles; 4 adds the split-bf16 tiles where the heuristic picks them); the split-K choice below follows it
+# tuning switch (tools / A-B runs only): GAOT_GEMM_MODE = argument of gaot_debug_set_gemm_glds (default 4: fp32 MFMA tiles
+# + the split-bf16 tiles where the heuristic picks them; 1 = fp32 MFMA tiles only); the split-K choice below follows it
 _FUSED_KERNEL_MLP = os.environ.get("GAOT_FUSED_KERNEL_MLP", "1") != "0"     # A/B switch for tools; the chain path is also HIP
-_GEMM_MODE = int(os.environ.get("GAOT_GEMM_MODE", "1"))
-if _GEMM_MODE != 1:
+_GEMM_MODE = int(os.environ.get("GAOT_GEMM_MODE", "4"))
+if _GEMM_MODE != 4:
     L.load().gaot_debug_set_gemm_glds(_GEMM_MODE)
 
 

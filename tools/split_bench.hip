@@ -13,9 +13,9 @@ static float run(GemmArgs a, int iters) {
     a.tiles_m = cdiv(a.M, S_BM); a.tiles_n = cdiv(a.N, S_BN);
     dim3 grid(a.tiles_m * a.tiles_n, 1, a.split_k > 1 ? a.split_k : 1), block(256);
     hipEvent_t s, e; hipEventCreate(&s); hipEventCreate(&e);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gemm_split_kernel<AK, BKM, ABL>), grid, block, 0, 0, a);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gemm_split_kernel<AK, BKM, 128, ABL>), grid, block, 0, 0, a);
     hipEventRecord(s, 0);
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((gemm_split_kernel<AK, BKM, ABL>), grid, block, 0, 0, a);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((gemm_split_kernel<AK, BKM, 128, ABL>), grid, block, 0, 0, a);
     hipEventRecord(e, 0); hipEventSynchronize(e);
     float ms; hipEventElapsedTime(&ms, s, e);
     return ms * 1e3f / iters;
