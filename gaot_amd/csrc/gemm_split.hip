@@ -81,7 +81,9 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
 
     // ---- global -> register staging (2 float4 per operand per thread per k-tile)
     // k-contiguous: row = tid >> 1, k half = tid & 1 (8 k = two float4 q = 0, 1 -> one 16-byte write per plane)
-    // row-contiguous: kp = tid >> 5 (k pair), r4 = tid & 31 (4 rows); q = which k of the pair
+    // row-contiguous (128-row tiles): kp = tid & 7 (k pair), r4 = tid >> 3 (4 rows); q = which k of the pair.  The packed
+    // (k, k+1) dwords are written TRANSPOSED into the k-contiguous plane layout (4 x ds_write_b32 per plane), so every
+    // operand is read back with ds_read_b128 whatever its layout in memory
     const float* a_src[2]; const float* b_src[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
             if (BM == 128) a_src[q] = p.A + (long)min(m0 + (tid >> 1), p.M - 1) * p.lda + (tid & 1) * 8 + q * 4;
             else           a_src[q] = p.A + (long)min(m0 + (tid >> 2), p.M - 1) * p.lda + (tid & 3) * 4;      // one float4 per thread (q = 0)
         } else {
-            if (BM == 128) a_src[q] = p.A + (long)(2 * (tid >> 5) + q) * p.lda + min(m0 + (tid & 31) * 4, p.M - 4);
+            if (BM == 128) a_src[q] = p.A + (long)(2 * (tid & 7) + q) * p.lda + min(m0 + (tid >> 3) * 4, p.M - 4);
             else           a_src[q] = p.A + (long)(2 * ((tid >> 4) & 7) + q) * p.lda + min(m0 + (tid & 15) * 4, p.M - 4);   // threads 0..127
         }
         if (BKM) {
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
             }
             b_src[q] = p.B + (long)nrow * p.ldb + (tid & 1) * 8 + q * 4;
         }
-        else     { b_src[q] = p.B + (long)(2 * (tid >> 5) + q) * p.ldb + min(n0 + (tid & 31) * 4, p.N - 4); }
+        else     { b_src[q] = p.B + (long)(2 * (tid & 7) + q) * p.ldb + min(n0 + (tid >> 3) * 4, p.N - 4); }
     }
     // two register sets: tile j lives in set j & 1 (loads run two k-tiles ahead of the MFMAs, the split one ahead)
     f32x4 ra[2][2], rb[2][2];
@@ -156,10 +158,20 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
             u32x4 h, m, l;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { unsigned a_, b_, c_; split3_pair<ABL>(r[0][e], r[1][e], a_, b_, c_); h[e] = a_; m[e] = b_; l[e] = c_; }
-            unsigned char* dst = rows == 128 ? base + (tid >> 5) * 512 + (tid & 31) * 16 : base + (tid >> 4) * 256 + (tid & 15) * 16;
-            *reinterpret_cast<u32x4*>(dst) = h;
-            *reinterpret_cast<u32x4*>(dst + S_PLANE) = m;
-            *reinterpret_cast<u32x4*>(dst + 2 * S_PLANE) = l;
+            if (rows == 128) {
+                unsigned char* dst = base + (tid >> 3) * 4 * 48 + (tid & 7) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    *reinterpret_cast<unsigned*>(dst + e * 48) = h[e];
+                    *reinterpret_cast<unsigned*>(dst + e * 48 + S_PLANE) = m[e];
+                    *reinterpret_cast<unsigned*>(dst + e * 48 + 2 * S_PLANE) = l[e];
+                }
+            } else {
+                unsigned char* dst = base + (tid >> 4) * 256 + (tid & 15) * 16;
+                *reinterpret_cast<u32x4*>(dst) = h;
+                *reinterpret_cast<u32x4*>(dst + S_PLANE) = m;
+                *reinterpret_cast<u32x4*>(dst + 2 * S_PLANE) = l;
+            }
         }
     };
     auto sstore = [&](int stage, const f32x4 (&xa)[2], const f32x4 (&xb)[2], bool live) {
@@ -196,11 +208,11 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) a[i][pl] = frag(sa + pl * S_PLANE, wm * WM + i * 32 + li, AK, ABYTES);
+            for (int pl = 0; pl < 3; ++pl) a[i][pl] = frag(sa + pl * S_PLANE, wm * WM + i * 32 + li, AK || BM == 128, ABYTES);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) b[j][pl] = frag(sb + pl * S_PLANE, wn * WN + j * 32 + li, BKM, 512);
+            for (int pl = 0; pl < 3; ++pl) b[j][pl] = frag(sb + pl * S_PLANE, wn * WN + j * 32 + li, true, 512);
         // small terms first
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -246,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
 
     if (!AK && do_colsum) {          // reduce the 8 k-pair groups through LDS (the stages are free now)
         float* cs = reinterpret_cast<float*>(smem_raw);
-        if (BM == 128) *reinterpret_cast<f32x4*>(cs + (tid >> 5) * BM + (tid & 31) * 4) = csum;
+        if (BM == 128) *reinterpret_cast<f32x4*>(cs + (tid & 7) * BM + (tid >> 3) * 4) = csum;
         else if (tid < 128) *reinterpret_cast<f32x4*>(cs + (tid >> 4) * BM + (tid & 15) * 4) = csum;
         __syncthreads();
         if (tid < BM && m0 + tid < p.M) {
