@@ -332,6 +332,209 @@ __global__ __launch_bounds__(256) void attn_fwd_glds_kernel(const AttnArgs p) {
         p.lse[((long)b * p.H + h) * p.S + q0 + li] = m_run * p.scale + logf(l_run);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// forward on the bf16 matrix pipe, fp32-exact (head_dim == 32, 16-byte aligned q/k/v): every fp32 operand is split exactly
+// into three bf16 pieces (common.h split3_pair) and each product is accumulated in fp32 from the six piece products of weight
+// >= 2^-16, exactly as in gemm_split.hip: 2.67x the fp32-MFMA rate for the two products of the kernel.
+//   S^T = K Q^T : A = K planes from LDS ([key][32 d] bf16, row stride 80 B, one ds_read_b128 per plane and 16-wide d step),
+//                 B = the wave's Q rows, split once into registers.
+//   O^T += V^T P^T : B = P, split in registers right after the softmax (the k-slot of half-wave hi in step u is key
+//                 crow(8u + e, hi), i.e. keys 16u + 4hi + {0..3, 8..11} of the 32-key tile: the lane's own result registers),
+//                 A = V^T planes from LDS ([d][64 keys] bf16, row stride 136 B: two conflict-free ds_read_b64 per plane / step).
+// K / V tiles (64 keys) are split by all 256 threads on the way from the prefetch registers into one of two LDS stages.
+// ---------------------------------------------------------------------------------------------
+constexpr int AS_KROW = 80, AS_VROW = 136;
+constexpr int AS_KPL = 64 * AS_KROW, AS_VPL = 32 * AS_VROW;
+constexpr int AS_STAGE = 3 * AS_KPL + 3 * AS_VPL;          // bytes
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_split_kernel(const AttnArgs p) {
+    constexpr int KT = 64;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * AS_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    int bh, blk;
+    xcd_group_decode(blockIdx.x, p.B * p.H, (p.S + 127) / 128, bh, blk);
+    const int b = bh / p.H, h = bh % p.H, hk = h / (p.H / p.Hkv);
+    const int q0 = blk * 128 + wave * 32;
+    const float c = p.scale * LOG2E;
+
+    // Q fragments: lane (q = li, hi) holds d = 16u + 8hi + e (e = 0..7) for u = 0, 1, as three packed bf16 planes
+    bf16x8 qf[3][2];
+    {
+        const int qi = q0 + li;
+        const float* qrow = p.q + ((long)b * p.S + qi) * p.ldq + (long)h * 32;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const f32x4 v0 = load4(qrow, 16 * u + 8 * lh, 32, qi < p.S, true);
+            const f32x4 v1 = load4(qrow, 16 * u + 8 * lh + 4, 32, qi < p.S, true);
+            u32x4 ph, pm, pl;
+            unsigned a_, b_, c_;
+            split3_pair(v0[0], v0[1], a_, b_, c_); ph[0] = a_; pm[0] = b_; pl[0] = c_;
+            split3_pair(v0[2], v0[3], a_, b_, c_); ph[1] = a_; pm[1] = b_; pl[1] = c_;
+            split3_pair(v1[0], v1[1], a_, b_, c_); ph[2] = a_; pm[2] = b_; pl[2] = c_;
+            split3_pair(v1[2], v1[3], a_, b_, c_); ph[3] = a_; pm[3] = b_; pl[3] = c_;
+            qf[0][u] = __builtin_bit_cast(bf16x8, ph); qf[1][u] = __builtin_bit_cast(bf16x8, pm); qf[2][u] = __builtin_bit_cast(bf16x8, pl);
+        }
+    }
+    // staging: K float4 (key = idx >> 3, chunk = idx & 7) x 2; V: key PAIR kp = tid >> 3, chunk = tid & 7 (two float4)
+    const float* kbase = p.k + (long)b * p.S * p.ldk + (long)hk * 32;
+    const float* vbase = p.v + (long)b * p.S * p.ldv + (long)hk * 32;
+    f32x4 rk[2], rv[2];
+    auto fetch = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * 256;
+            const int krow = min(kt * KT + (idx >> 3), p.S - 1);
+            rk[i] = *reinterpret_cast<const f32x4*>(kbase + (long)krow * p.ldk + (idx & 7) * 4);
+            const int vrow = min(kt * KT + 2 * (tid >> 3) + i, p.S - 1);
+            rv[i] = *reinterpret_cast<const f32x4*>(vbase + (long)vrow * p.ldv + (tid & 7) * 4);
+        }
+    };
+    auto stage = [&](int stg) {
+        unsigned char* Kp = smem + stg * AS_STAGE;
+        unsigned char* Vp = Kp + 3 * AS_KPL;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * 256;
+            u32x2 h, m, l;
+            unsigned a_, b_, c_;
+            split3_pair(rk[i][0], rk[i][1], a_, b_, c_); h[0] = a_; m[0] = b_; l[0] = c_;
+            split3_pair(rk[i][2], rk[i][3], a_, b_, c_); h[1] = a_; m[1] = b_; l[1] = c_;
+            unsigned char* dst = Kp + (idx >> 3) * AS_KROW + (idx & 7) * 8;
+            *reinterpret_cast<u32x2*>(dst) = h;
+            *reinterpret_cast<u32x2*>(dst + AS_KPL) = m;
+            *reinterpret_cast<u32x2*>(dst + 2 * AS_KPL) = l;
+        }
+        // V^T: (key 2kp, key 2kp+1) pairs of the thread's 4 d columns -> one dword per d row and plane
+        {
+            const int kp = tid >> 3, d0 = (tid & 7) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned a_, b_, c_;
+                split3_pair(rv[0][e], rv[1][e], a_, b_, c_);
+                unsigned char* dst = Vp + (d0 + e) * AS_VROW + kp * 4;
+                *reinterpret_cast<unsigned*>(dst) = a_;
+                *reinterpret_cast<unsigned*>(dst + AS_VPL) = b_;
+                *reinterpret_cast<unsigned*>(dst + 2 * AS_VPL) = c_;
+            }
+        }
+    };
+
+    f32x16 oacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const int ntiles = (p.S + KT - 1) / KT;
+    fetch(0);
+    stage(0);
+    if (ntiles > 1) fetch(1);
+    __syncthreads();
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int stg = kt & 1;
+        const unsigned char* Kp = smem + stg * AS_STAGE;
+        const unsigned char* Vp = Kp + 3 * AS_KPL;
+        // ---- S^T for 64 keys: two 32-key fragments, d in two 16-wide steps, six piece products each
+        f32x16 s[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const unsigned char* kr = Kp + (32 * t + li) * AS_KROW + u * 32 + lh * 16;
+                const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(kr);
+                const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(kr + AS_KPL);
+                const bf16x8 k2 = *reinterpret_cast<const bf16x8*>(kr + 2 * AS_KPL);
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k2, qf[0][u], s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[2][u], s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[1][u], s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[0][u], s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[1][u], s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[0][u], s[t], 0, 0, 0);
+            }
+        }
+        // ---- online softmax over the 64 keys (fp32)
+        const int kv0 = kt * KT;
+        if (__builtin_amdgcn_readfirstlane(kv0 + KT > p.S)) {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (kv0 + crow(r, lh) >= p.S) s[0][r] = -INFINITY;
+                if (kv0 + 32 + crow(r, lh) >= p.S) s[1][r] = -INFINITY;
+            }
+        }
+        float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s[0][r], s[1][r]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float mc = -m_new * c;
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[0][r] = __builtin_amdgcn_exp2f(fmaf(s[0][r], c, mc));
+            s[1][r] = __builtin_amdgcn_exp2f(fmaf(s[1][r], c, mc));
+            ps += s[0][r] + s[1][r];
+        }
+        ps += __shfl_xor(ps, 32, 64);
+        if (__any(m_new != m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            l_run *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+            m_run = m_new;
+        }
+        l_run += ps;
+        // ---- O^T += V^T P^T: P split in registers; step u of tile t covers the lane's registers r = 8u .. 8u+7
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                u32x4 ph, pm, pl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    unsigned a_, b_, c_;
+                    split3_pair(s[t][8 * u + 2 * e], s[t][8 * u + 2 * e + 1], a_, b_, c_);
+                    ph[e] = a_; pm[e] = b_; pl[e] = c_;
+                }
+                const bf16x8 p0 = __builtin_bit_cast(bf16x8, ph), p1 = __builtin_bit_cast(bf16x8, pm), p2 = __builtin_bit_cast(bf16x8, pl);
+                // V^T[d = li][keys 32t + 16u + 4hi + {0..3}] and [.. + 8 + {0..3}]
+                const unsigned char* vr = Vp + li * AS_VROW + (32 * t + 16 * u + 4 * lh) * 2;
+                bf16x8 v[3];
+#pragma unroll
+                for (int pl_ = 0; pl_ < 3; ++pl_) {
+                    const u32x2 lo = *reinterpret_cast<const u32x2*>(vr + pl_ * AS_VPL);
+                    const u32x2 hi2 = *reinterpret_cast<const u32x2*>(vr + pl_ * AS_VPL + 16);
+                    v[pl_] = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi2[0], hi2[1]});
+                }
+                oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[2], p0, oacc, 0, 0, 0);
+                oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0], p2, oacc, 0, 0, 0);
+                oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[1], p1, oacc, 0, 0, 0);
+                oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[1], p0, oacc, 0, 0, 0);
+                oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0], p1, oacc, 0, 0, 0);
+                oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0], p0, oacc, 0, 0, 0);
+            }
+        // next tile: registers -> the other stage (its previous readers finished before the last barrier), prefetch the one after
+        if (kt + 1 < ntiles) stage(stg ^ 1);
+        if (kt + 2 < ntiles) fetch(kt + 2);
+        __syncthreads();
+    }
+    const float inv_l = 1.0f / l_run;
+    float* Os = reinterpret_cast<float*>(smem) + wave * 32 * 33;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Os[li * 33 + crow(r, lh)] = oacc[r] * inv_l;
+    __syncthreads();
+    for (int rr = lh; rr < 32; rr += 2) {
+        const int qi = q0 + rr;
+        if (qi >= p.S) break;
+        p.o[((long)b * p.S + qi) * p.ldo + (long)h * 32 + li] = Os[rr * 33 + li];
+    }
+    if (lh == 0 && q0 + li < p.S)
+        p.lse[((long)b * p.H + h) * p.S + q0 + li] = m_run * p.scale + logf(l_run);
+}
+
 // ---------------------------------------------------------------------------------------------
 // backward helpers
 // ---------------------------------------------------------------------------------------------
@@ -606,6 +809,9 @@ static int fill_common(AttnArgs& a, const float* q, const float* k, const float*
 using namespace gaot;
 #define ST(s) reinterpret_cast<hipStream_t>(s)
 
+static int g_attn_split = 1;     // head_dim 32: 1 = split-bf16 forward kernel, 0 = fp32-MFMA LDS-direct kernel
+extern "C" int gaot_debug_set_attention_split(int on) { const int old = g_attn_split; g_attn_split = on; return old; }
+
 extern "C" int gaot_attention_fwd(const float* q, const float* k, const float* v, int64_t ldq, int64_t ldk, int64_t ldv,
                                   int32_t B, int32_t S, int32_t H, int32_t Hkv, int32_t head_dim, float* o, int64_t ldo,
                                   float* lse, gaot_stream_t stream) {
@@ -616,7 +822,8 @@ extern "C" int gaot_attention_fwd(const float* q, const float* k, const float* v
     fill_common(a, q, k, v, ldq, ldk, ldv, B, S, H, Hkv, head_dim);
     a.o = o; a.ldo = ldo; a.lse = lse;
     dim3 grid(cdiv(S, 128) * B * H), block(256);
-    if (head_dim == 32 && a.vec) hipLaunchKernelGGL(attn_fwd_glds_kernel, grid, block, 0, ST(stream), a);
+    if (head_dim == 32 && a.vec && g_attn_split) hipLaunchKernelGGL(attn_fwd_split_kernel, grid, block, 0, ST(stream), a);
+    else if (head_dim == 32 && a.vec) hipLaunchKernelGGL(attn_fwd_glds_kernel, grid, block, 0, ST(stream), a);
     else if (head_dim <= 32) hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, block, 0, ST(stream), a);
     else                hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, block, 0, ST(stream), a);
     GAOT_CHECK_LAUNCH("gaot_attention_fwd");

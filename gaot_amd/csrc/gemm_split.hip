@@ -16,30 +16,12 @@
 
 namespace gaot {
 
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int SBK = 16;                 // k per tile
 constexpr int S_BM = 128, S_BN = 128;
 constexpr int S_PLANE = 128 * 48;       // bytes per plane (k-contiguous layout is the larger one)
 constexpr int S_STAGE = 6 * S_PLANE;    // 3 planes x 2 operands
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-// two elements at a time so that the residual subtractions are v_pk_add_f32; returns the three packed bf16 pairs
-// (element 0 in the low half).  Only the pieces that feed a subtraction are masked; packing is a byte permute.
-template <int ABL = 0>
-__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& ph, unsigned& pm, unsigned& pl) {
-    if (ABL & 1) { ph = pm = pl = __float_as_uint(x0) ^ __float_as_uint(x1); return; }
-    const f32x2 x = {x0, x1};
-    const unsigned h0 = __float_as_uint(x0) & 0xffff0000u, h1 = __float_as_uint(x1) & 0xffff0000u;
-    const f32x2 r = x - f32x2{__uint_as_float(h0), __uint_as_float(h1)};
-    const unsigned m0 = __float_as_uint(r[0]) & 0xffff0000u, m1 = __float_as_uint(r[1]) & 0xffff0000u;
-    const f32x2 r2 = r - f32x2{__uint_as_float(m0), __uint_as_float(m1)};      // <= 8 significant bits left: exact in bf16
-    ph = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
-    pm = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
-    pl = __builtin_amdgcn_perm(__float_as_uint(r2[1]), __float_as_uint(r2[0]), 0x07060302u);
-}
 template <int ABL>
 __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
     if (ABL & 2) { c[0] += __builtin_bit_cast(u32x4, a)[0] * 1e-30f + __builtin_bit_cast(u32x4, b)[1] * 1e-30f; return c; }
