@@ -791,6 +791,260 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs p) {
     (void)T;
 }
 
+// ---------------------------------------------------------------------------------------------
+// backward on the bf16 matrix pipe (head_dim == 32, 16-byte aligned operands), same structure as attn_bwd_kernel: a
+// workgroup = 4 waves x 32 keys, loop over 32-query tiles.  S, dP, dV^T, dK^T run as six bf16 piece products each
+// (fp32-exact, see gemm_split.hip): K / V live in registers as split B operands; the Q / dO tile is staged as split planes in
+// BOTH orientations ([q][d] for S / dP, [d][q] for dV^T / dK^T, whose k-slots are the lane's own P / dS registers); P and dS
+// are split in registers.  dQ keeps the fp32 MFMA path (dS through the wave-private LDS transpose against the fp32 K tile):
+// its operand would need a third, per-wave set of planes and the workgroup would no longer fit twice on a CU.
+// ---------------------------------------------------------------------------------------------
+constexpr int AB_KROW = 80, AB_TROW = 72;
+constexpr int AB_KPL = 32 * AB_KROW, AB_TPL = 32 * AB_TROW;
+constexpr int AB_LDS = 2 * 3 * AB_KPL + 2 * 3 * AB_TPL + 64 * 4 + 4 * 32 * 32 * 4 + 4 * 32 * 33 * 4;
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_split_kernel(const AttnArgs p) {
+    constexpr int DP = 32;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[AB_LDS];
+    unsigned char* Qk = smem;                       // 3 planes [q][32 d]
+    unsigned char* Gk = Qk + 3 * AB_KPL;            // dO
+    unsigned char* Qt = Gk + 3 * AB_KPL;            // 3 planes [d][32 q]
+    unsigned char* Gt = Qt + 3 * AB_TPL;
+    float* lse_s = reinterpret_cast<float*>(Gt + 3 * AB_TPL);
+    float* del_s = lse_s + 32;
+    float* Kw = del_s + 32;                         // per wave fp32 K tile [32][32] (dQ product)
+    float* Sw = Kw + 4 * 32 * 32;                   // per wave dS^T staging [32][33]; reused as the wave's dQ partial [32][32]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    int bh, kblk;
+    xcd_group_decode(blockIdx.x, p.B * p.H, p.n_kblocks, bh, kblk);
+    const int b = bh / p.H, h = bh % p.H, hk = h / (p.H / p.Hkv);
+    const int kv0 = kblk * 128 + wave * 32;
+    const float c = p.scale * LOG2E;
+    float* Kmine = Kw + wave * 32 * 32;
+    float* Smine = Sw + wave * 32 * 33;
+    float* Pmine = Smine;
+
+    // K^T / V^T as split B operands: lane (kv = li, hi) holds d = 16u + 8hi + e
+    bf16x8 kf[3][2], vf[3][2];
+    const bool kv_ok = kv0 + li < p.S;
+    {
+        const float* krow = p.k + ((long)b * p.S + min(kv0 + li, p.S - 1)) * p.ldk + (long)hk * 32;
+        const float* vrow = p.v + ((long)b * p.S + min(kv0 + li, p.S - 1)) * p.ldv + (long)hk * 32;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(krow + 16 * u + 8 * lh), a1 = *reinterpret_cast<const f32x4*>(krow + 16 * u + 8 * lh + 4);
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(vrow + 16 * u + 8 * lh), w1 = *reinterpret_cast<const f32x4*>(vrow + 16 * u + 8 * lh + 4);
+            u32x4 ph, pm, pl, vh, vm, vl;
+            unsigned a_, b_, c_;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                split3_pair(a0[2 * e], a0[2 * e + 1], a_, b_, c_); ph[e] = a_; pm[e] = b_; pl[e] = c_;
+                split3_pair(a1[2 * e], a1[2 * e + 1], a_, b_, c_); ph[2 + e] = a_; pm[2 + e] = b_; pl[2 + e] = c_;
+                split3_pair(w0[2 * e], w0[2 * e + 1], a_, b_, c_); vh[e] = a_; vm[e] = b_; vl[e] = c_;
+                split3_pair(w1[2 * e], w1[2 * e + 1], a_, b_, c_); vh[2 + e] = a_; vm[2 + e] = b_; vl[2 + e] = c_;
+            }
+            kf[0][u] = __builtin_bit_cast(bf16x8, ph); kf[1][u] = __builtin_bit_cast(bf16x8, pm); kf[2][u] = __builtin_bit_cast(bf16x8, pl);
+            vf[0][u] = __builtin_bit_cast(bf16x8, vh); vf[1][u] = __builtin_bit_cast(bf16x8, vm); vf[2][u] = __builtin_bit_cast(bf16x8, vl);
+        }
+        // the wave's fp32 K tile, row-major, for the dQ product
+        for (int t = lane; t < 32 * 8; t += 64) {
+            const int row = t >> 3, d = (t & 7) * 4;
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            if (kv0 + row < p.S) a = *reinterpret_cast<const f32x4*>(p.k + ((long)b * p.S + kv0 + row) * p.ldk + (long)hk * 32 + d);
+            *reinterpret_cast<f32x4*>(Kmine + row * 32 + d) = a;
+        }
+    }
+    f32x16 dvacc, dkacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dvacc[r] = 0.f; dkacc[r] = 0.f; }
+
+    const float* qbase = p.q + (long)b * p.S * p.ldq + (long)h * 32;
+    const float* gbase = p.dout + (long)b * p.S * p.ldo + (long)h * 32;
+    const float* lse_b = p.lse + ((long)b * p.H + h) * p.S;
+    const float* del_b = p.delta + ((long)b * p.H + h) * p.S;
+    // prefetch registers: k-major pieces (row = tid >> 3, chunk = tid & 7) of Q and dO; transposed pieces: threads 0..127 take
+    // Q rows (2qp, 2qp+1), threads 128..255 the same of dO (qp = (tid & 127) >> 3, chunk = tid & 7)
+    f32x4 rq, rg, rt[2];
+    float rl = 0.f, rd = 0.f;
+    auto fetch = [&](int q0) {
+        {
+            const int row = tid >> 3, d = (tid & 7) * 4;
+            const bool ok = q0 + row < p.S;
+            const long r = min(q0 + row, p.S - 1);
+            rq = *reinterpret_cast<const f32x4*>(qbase + r * p.ldq + d);
+            rg = *reinterpret_cast<const f32x4*>(gbase + r * p.ldo + d);
+            if (!ok) { rq = f32x4{0.f, 0.f, 0.f, 0.f}; rg = rq; }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = 2 * ((tid & 127) >> 3) + i, d = (tid & 7) * 4;
+            const bool ok = q0 + row < p.S;
+            const long r = min(q0 + row, p.S - 1);
+            rt[i] = tid < 128 ? *reinterpret_cast<const f32x4*>(qbase + r * p.ldq + d) : *reinterpret_cast<const f32x4*>(gbase + r * p.ldo + d);
+            if (!ok) rt[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (tid < 32) {
+            const bool ok = q0 + tid < p.S;
+            rl = ok ? lse_b[q0 + tid] * LOG2E : INFINITY;   // +inf -> P = 0 for padded queries
+            rd = ok ? del_b[q0 + tid] : 0.f;
+        }
+    };
+    const int nq = (p.S + 31) / 32;
+    const long part_stride = (long)p.B * p.H * p.S * DP;
+    float* part = p.dq_part + (long)kblk * part_stride + ((long)b * p.H + h) * p.S * DP;
+
+    fetch(0);
+    for (int qt = 0; qt < nq; ++qt) {
+        const int q0 = qt * 32;
+        // ---- stage the tile as split planes, both orientations
+        {
+            const int row = tid >> 3, ch = tid & 7;
+            u32x2 h2, m2, l2;
+            unsigned a_, b_, c_;
+            split3_pair(rq[0], rq[1], a_, b_, c_); h2[0] = a_; m2[0] = b_; l2[0] = c_;
+            split3_pair(rq[2], rq[3], a_, b_, c_); h2[1] = a_; m2[1] = b_; l2[1] = c_;
+            unsigned char* dq_ = Qk + row * AB_KROW + ch * 8;
+            *reinterpret_cast<u32x2*>(dq_) = h2; *reinterpret_cast<u32x2*>(dq_ + AB_KPL) = m2; *reinterpret_cast<u32x2*>(dq_ + 2 * AB_KPL) = l2;
+            split3_pair(rg[0], rg[1], a_, b_, c_); h2[0] = a_; m2[0] = b_; l2[0] = c_;
+            split3_pair(rg[2], rg[3], a_, b_, c_); h2[1] = a_; m2[1] = b_; l2[1] = c_;
+            unsigned char* dg_ = Gk + row * AB_KROW + ch * 8;
+            *reinterpret_cast<u32x2*>(dg_) = h2; *reinterpret_cast<u32x2*>(dg_ + AB_KPL) = m2; *reinterpret_cast<u32x2*>(dg_ + 2 * AB_KPL) = l2;
+            // transposed: (q = 2qp, 2qp+1) pairs of this thread's 4 d columns
+            const int qp = (tid & 127) >> 3, d0 = ch * 4;
+            unsigned char* tb = (tid < 128 ? Qt : Gt) + qp * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                split3_pair(rt[0][e], rt[1][e], a_, b_, c_);
+                unsigned char* dst = tb + (d0 + e) * AB_TROW;
+                *reinterpret_cast<unsigned*>(dst) = a_;
+                *reinterpret_cast<unsigned*>(dst + AB_TPL) = b_;
+                *reinterpret_cast<unsigned*>(dst + 2 * AB_TPL) = c_;
+            }
+        }
+        if (tid < 32) { lse_s[tid] = rl; del_s[tid] = rd; }
+        __syncthreads();                                    // barrier A
+        if (qt + 1 < nq) fetch(q0 + 32);
+
+        // ---- S[q][kv] and dP[q][kv]: A = Q / dO planes (lane -> query row), B = K^T / V^T register planes
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const unsigned char* qr = Qk + li * AB_KROW + u * 32 + lh * 16;
+            const unsigned char* gr = Gk + li * AB_KROW + u * 32 + lh * 16;
+            const bf16x8 q0_ = *reinterpret_cast<const bf16x8*>(qr), q1_ = *reinterpret_cast<const bf16x8*>(qr + AB_KPL), q2_ = *reinterpret_cast<const bf16x8*>(qr + 2 * AB_KPL);
+            const bf16x8 g0_ = *reinterpret_cast<const bf16x8*>(gr), g1_ = *reinterpret_cast<const bf16x8*>(gr + AB_KPL), g2_ = *reinterpret_cast<const bf16x8*>(gr + 2 * AB_KPL);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q2_, kf[0][u], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g2_, vf[0][u], dp, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0_, kf[2][u], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0_, vf[2][u], dp, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q1_, kf[1][u], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1_, vf[1][u], dp, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q1_, kf[0][u], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1_, vf[0][u], dp, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0_, kf[1][u], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0_, vf[1][u], dp, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0_, kf[0][u], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0_, vf[0][u], dp, 0, 0, 0);
+        }
+        // ---- P = exp(S*scale - lse), dS = P * (dP - delta)   (rows q = crow(r,lh), column kv = li)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qr = crow(r, lh);
+            float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c, -lse_s[qr]));
+            if (!kv_ok) pv = 0.f;
+            s[r] = pv;
+            dp[r] = pv * (dp[r] - del_s[qr]);
+        }
+        // ---- dV^T[d][kv] += dO^T[d][q] P[q][kv] ; dK^T[d][kv] += Q^T[d][q] dS[q][kv]: the k-slots of step u are the lane's own
+        // registers r = 8u .. 8u+7 (queries 16u + 4hi + {0..3, 8..11}); A from the transposed planes (two 8-byte reads each)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            u32x4 ph, pm, pl, sh, sm, sl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned a_, b_, c_;
+                split3_pair(s[8 * u + 2 * e], s[8 * u + 2 * e + 1], a_, b_, c_); ph[e] = a_; pm[e] = b_; pl[e] = c_;
+                split3_pair(dp[8 * u + 2 * e], dp[8 * u + 2 * e + 1], a_, b_, c_); sh[e] = a_; sm[e] = b_; sl[e] = c_;
+            }
+            const bf16x8 p0 = __builtin_bit_cast(bf16x8, ph), p1 = __builtin_bit_cast(bf16x8, pm), p2 = __builtin_bit_cast(bf16x8, pl);
+            const bf16x8 d0 = __builtin_bit_cast(bf16x8, sh), d1 = __builtin_bit_cast(bf16x8, sm), d2 = __builtin_bit_cast(bf16x8, sl);
+            const unsigned char* gr = Gt + li * AB_TROW + (16 * u + 4 * lh) * 2;
+            const unsigned char* qr = Qt + li * AB_TROW + (16 * u + 4 * lh) * 2;
+            bf16x8 ga[3], qa[3];
+#pragma unroll
+            for (int pl_ = 0; pl_ < 3; ++pl_) {
+                const u32x2 g_lo = *reinterpret_cast<const u32x2*>(gr + pl_ * AB_TPL), g_hi = *reinterpret_cast<const u32x2*>(gr + pl_ * AB_TPL + 16);
+                const u32x2 q_lo = *reinterpret_cast<const u32x2*>(qr + pl_ * AB_TPL), q_hi = *reinterpret_cast<const u32x2*>(qr + pl_ * AB_TPL + 16);
+                ga[pl_] = __builtin_bit_cast(bf16x8, u32x4{g_lo[0], g_lo[1], g_hi[0], g_hi[1]});
+                qa[pl_] = __builtin_bit_cast(bf16x8, u32x4{q_lo[0], q_lo[1], q_hi[0], q_hi[1]});
+            }
+            dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[2], p0, dvacc, 0, 0, 0);
+            dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[2], d0, dkacc, 0, 0, 0);
+            dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p2, dvacc, 0, 0, 0);
+            dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d2, dkacc, 0, 0, 0);
+            dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1], p1, dvacc, 0, 0, 0);
+            dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1], d1, dkacc, 0, 0, 0);
+            dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1], p0, dvacc, 0, 0, 0);
+            dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1], d0, dkacc, 0, 0, 0);
+            dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p1, dvacc, 0, 0, 0);
+            dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d1, dkacc, 0, 0, 0);
+            dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p0, dvacc, 0, 0, 0);
+            dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d0, dkacc, 0, 0, 0);
+        }
+        // ---- dQ[q][d] partial = sum_kv dS[q][kv] K[kv][d] on the fp32 MFMA: dS through wave-private LDS to flip lanes
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Smine[crow(r, lh) * 33 + li] = dp[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        f32x16 dq;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+        float sa[16];
+#pragma unroll
+        for (int t16 = 0; t16 < 16; ++t16) sa[t16] = Smine[li * 33 + t16 + 16 * lh];
+#pragma unroll
+        for (int t16 = 0; t16 < 16; ++t16)
+            dq = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[t16], Kmine[(t16 + 16 * lh) * 32 + li], dq, 0, 0, 0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                     // every lane has read its dS row before the tile is overwritten
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Pmine[crow(r, lh) * 32 + li] = dq[r];
+        __syncthreads();                                    // barrier B
+        for (int t = tid; t < 32 * DP; t += 256) {
+            const int row = t / DP;
+            if (q0 + row < p.S)
+                part[(long)(q0 + row) * DP + (t % DP)] = (Sw[t] + Sw[32 * 33 + t]) + (Sw[2 * 32 * 33 + t] + Sw[3 * 32 * 33 + t]);
+        }
+    }
+    // ---- epilogue: dK^T, dV^T -> [kv][d] through wave-private LDS, coalesced row stores (per QUERY head h)
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Smine[li * 33 + crow(r, lh)] = (pass == 0 ? dkacc[r] * p.scale : dvacc[r]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int rr = lh; rr < 32; rr += 2) {
+            const int kv = kv0 + rr;
+            if (kv < p.S) {
+                if (pass == 0) p.dk[((long)b * p.S + kv) * p.lddk + (long)h * 32 + li] = Smine[rr * 33 + li];
+                else           p.dv[((long)b * p.S + kv) * p.lddv + (long)h * 32 + li] = Smine[rr * 33 + li];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 template <int DP> static size_t bwd_lds_bytes() {
     return sizeof(float) * (2 * 32 * (DP + 4) + 64 + 4 * 32 * DP + 4 * 32 * 33 + 4 * 32 * DP);
 }
@@ -859,7 +1113,9 @@ extern "C" int gaot_attention_bwd(const float* q, const float* k, const float* v
         hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv((long)B * S * H, 256)), dim3(256), 0, ST(stream), a);
     }
     dim3 grid(a.n_kblocks * B * H), block(256);
-    if (DP == 32) {
+    if (head_dim == 32 && a.vec && g_attn_split && aligned16(dq) && aligned16(dk) && aligned16(dv)) {
+        hipLaunchKernelGGL(attn_bwd_split_kernel, grid, block, 0, ST(stream), a);
+    } else if (DP == 32) {
         hipLaunchKernelGGL(attn_bwd_kernel<32>, grid, block, bwd_lds_bytes<32>(), ST(stream), a);
     } else {
         static bool attr_set = false;
