@@ -264,9 +264,10 @@ def test_swiglu():
 
 
 @pytest.mark.parametrize("B,S,H,Hkv,D", [(2, 256, 4, 4, 32), (1, 1024, 8, 8, 32), (2, 64, 4, 4, 8), (2, 200, 4, 4, 12),
-                                         (1, 130, 2, 2, 64), (2, 96, 4, 2, 16), (1, 33, 1, 1, 32)])
+                                         (1, 130, 2, 2, 64), (2, 96, 4, 2, 16), (1, 33, 1, 1, 32), (2, 203, 4, 2, 32),
+                                         (1, 129, 2, 1, 32)])
 def test_attention_fwd_bwd(B, S, H, Hkv, D):
-    from gaot_amd import ops
+    from gaot_amd import ops, _lib
     g = torch.Generator().manual_seed(S + D)
     W = (H + 2 * Hkv) * D
     qkv = torch.randn(B, S, W, generator=g)
@@ -283,6 +284,16 @@ def test_attention_fwd_bwd(B, S, H, Hkv, D):
     out.backward(go.to(dev()))
     assert rel(out, ref) < 3e-6
     assert rel(d.grad, r.grad) < 1e-5
+    if D == 32:        # the default above is the split-bf16 pair of kernels; the fp32-MFMA kernels stay covered too
+        old = _lib.load().gaot_debug_set_attention_split(0)
+        try:
+            d2 = qkv.to(dev()).requires_grad_(True)
+            out2 = ops.attention(d2, H, Hkv, D)
+            out2.backward(go.to(dev()))
+        finally:
+            _lib.load().gaot_debug_set_attention_split(old)
+        assert rel(out2, ref) < 3e-6 and rel(d2.grad, r.grad) < 1e-5
+        assert rel(out, ref) < 2 * rel(out2, ref) + 1e-7 and rel(d.grad, r.grad) < 2 * rel(d2.grad, r.grad) + 1e-7     # as accurate as fp32 MFMA
 
 
 def test_attention_peaked_softmax():
