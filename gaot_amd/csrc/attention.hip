@@ -348,16 +348,19 @@ constexpr int AS_KROW = 80, AS_VROW = 136;
 constexpr int AS_KPL = 64 * AS_KROW, AS_VPL = 32 * AS_VROW;
 constexpr int AS_STAGE = 3 * AS_KPL + 3 * AS_VPL;          // bytes
 
-__global__ __launch_bounds__(256, 2) void attn_fwd_split_kernel(const AttnArgs p) {
-    constexpr int KT = 64;
+// NW = 4 (128 queries per workgroup, two workgroups per CU) or 8 (256 queries, one workgroup per CU: every K / V tile is split
+// half as often per head and each thread stages half as much)
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_fwd_split_kernel(const AttnArgs p) {
+    constexpr int KT = 64, NT = 64 * NW, QB = 32 * NW;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * AS_STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
     int bh, blk;
-    xcd_group_decode(blockIdx.x, p.B * p.H, (p.S + 127) / 128, bh, blk);
+    xcd_group_decode(blockIdx.x, p.B * p.H, (p.S + QB - 1) / QB, bh, blk);
     const int b = bh / p.H, h = bh % p.H, hk = h / (p.H / p.Hkv);
-    const int q0 = blk * 128 + wave * 32;
+    const int q0 = blk * QB + wave * 32;
     const float c = p.scale * LOG2E;
 
     // Q fragments: lane (q = li, hi) holds d = 16u + 8hi + e (e = 0..7) for u = 0, 1, as three packed bf16 planes
@@ -381,23 +384,30 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_split_kernel(const AttnArgs p
     // staging: K float4 (key = idx >> 3, chunk = idx & 7) x 2; V: key PAIR kp = tid >> 3, chunk = tid & 7 (two float4)
     const float* kbase = p.k + (long)b * p.S * p.ldk + (long)hk * 32;
     const float* vbase = p.v + (long)b * p.S * p.ldv + (long)hk * 32;
-    f32x4 rk[2], rv[2];
+    constexpr int NKF = 512 / NT;                 // K float4 per thread per tile (2 or 1)
+    const bool vthread = tid < 256;               // V pairs: 256 (key pair, chunk) items
+    f32x4 rk[NKF], rv[2];
     auto fetch = [&](int kt) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + i * 256;
+        for (int i = 0; i < NKF; ++i) {
+            const int idx = tid + i * NT;
             const int krow = min(kt * KT + (idx >> 3), p.S - 1);
             rk[i] = *reinterpret_cast<const f32x4*>(kbase + (long)krow * p.ldk + (idx & 7) * 4);
-            const int vrow = min(kt * KT + 2 * (tid >> 3) + i, p.S - 1);
-            rv[i] = *reinterpret_cast<const f32x4*>(vbase + (long)vrow * p.ldv + (tid & 7) * 4);
+        }
+        if (vthread) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int vrow = min(kt * KT + 2 * (tid >> 3) + i, p.S - 1);
+                rv[i] = *reinterpret_cast<const f32x4*>(vbase + (long)vrow * p.ldv + (tid & 7) * 4);
+            }
         }
     };
     auto stage = [&](int stg) {
         unsigned char* Kp = smem + stg * AS_STAGE;
         unsigned char* Vp = Kp + 3 * AS_KPL;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + i * 256;
+        for (int i = 0; i < NKF; ++i) {
+            const int idx = tid + i * NT;
             u32x2 h, m, l;
             unsigned a_, b_, c_;
             split3_pair(rk[i][0], rk[i][1], a_, b_, c_); h[0] = a_; m[0] = b_; l[0] = c_;
@@ -408,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_split_kernel(const AttnArgs p
             *reinterpret_cast<u32x2*>(dst + 2 * AS_KPL) = l;
         }
         // V^T: (key 2kp, key 2kp+1) pairs of the thread's 4 d columns -> one dword per d row and plane
-        {
+        if (vthread) {
             const int kp = tid >> 3, d0 = (tid & 7) * 4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -522,7 +532,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_split_kernel(const AttnArgs p
         __syncthreads();
     }
     const float inv_l = 1.0f / l_run;
-    float* Os = reinterpret_cast<float*>(smem) + wave * 32 * 33;
+    float* Os = reinterpret_cast<float*>(smem) + wave * 32 * 33;          // NW * 4224 B <= 2 stages
 #pragma unroll
     for (int r = 0; r < 16; ++r) Os[li * 33 + crow(r, lh)] = oacc[r] * inv_l;
     __syncthreads();
@@ -1063,7 +1073,8 @@ static int fill_common(AttnArgs& a, const float* q, const float* k, const float*
 using namespace gaot;
 #define ST(s) reinterpret_cast<hipStream_t>(s)
 
-static int g_attn_split = 1;     // head_dim 32: 1 = split-bf16 forward kernel, 0 = fp32-MFMA LDS-direct kernel
+static int g_attn_split = 1;     // head_dim 32: 1 = split-bf16 kernels (default; 8-wave forward when it fills the chip), 0 = fp32-MFMA kernels,
+                                 // 2 = split with the 8-wave forward always, 3 = split with the 4-wave forward always
 extern "C" int gaot_debug_set_attention_split(int on) { const int old = g_attn_split; g_attn_split = on; return old; }
 
 extern "C" int gaot_attention_fwd(const float* q, const float* k, const float* v, int64_t ldq, int64_t ldk, int64_t ldv,
@@ -1076,7 +1087,10 @@ extern "C" int gaot_attention_fwd(const float* q, const float* k, const float* v
     fill_common(a, q, k, v, ldq, ldk, ldv, B, S, H, Hkv, head_dim);
     a.o = o; a.ldo = ldo; a.lse = lse;
     dim3 grid(cdiv(S, 128) * B * H), block(256);
-    if (head_dim == 32 && a.vec && g_attn_split) hipLaunchKernelGGL(attn_fwd_split_kernel, grid, block, 0, ST(stream), a);
+    // 256-query workgroups once they still fill the chip (one per CU): half the K / V tile splits per head
+    if (head_dim == 32 && a.vec && g_attn_split && g_attn_split != 3 && (g_attn_split == 2 || (long)cdiv(S, 256) * B * H >= 256))
+        hipLaunchKernelGGL(attn_fwd_split_kernel<8>, dim3(cdiv(S, 256) * B * H), dim3(512), 0, ST(stream), a);
+    else if (head_dim == 32 && a.vec && g_attn_split) hipLaunchKernelGGL(attn_fwd_split_kernel<4>, grid, block, 0, ST(stream), a);
     else if (head_dim == 32 && a.vec) hipLaunchKernelGGL(attn_fwd_glds_kernel, grid, block, 0, ST(stream), a);
     else if (head_dim <= 32) hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, block, 0, ST(stream), a);
     else                hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, block, 0, ST(stream), a);

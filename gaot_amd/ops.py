@@ -69,8 +69,8 @@ _FUSED_KERNEL_MLP = os.environ.get("GAOT_FUSED_KERNEL_MLP", "1") != "0"     # A/
 _GEMM_MODE = int(os.environ.get("GAOT_GEMM_MODE", "4"))
 if _GEMM_MODE != 4:
     L.load().gaot_debug_set_gemm_glds(_GEMM_MODE)
-if os.environ.get("GAOT_ATTN_SPLIT", "1") == "0":          # A/B switch: head_dim-32 attention on the fp32-MFMA kernels
-    L.load().gaot_debug_set_attention_split(0)
+if os.environ.get("GAOT_ATTN_SPLIT", "1") != "1":          # A/B switch: argument of gaot_debug_set_attention_split (0 = fp32 MFMA)
+    L.load().gaot_debug_set_attention_split(int(os.environ["GAOT_ATTN_SPLIT"]))
 
 
 def _split_for_reduction(Mo: int, No: int, K: int) -> int:

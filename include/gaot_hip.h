@@ -198,7 +198,8 @@ int gaot_swiglu_bwd(const float* u, const float* dg, int32_t M, int32_t F, float
  * q/k/v are strided views: element (b,s,h,d) at ptr[(b*S+s)*ld + h*head_dim + d]; kv head = h / (H/Hkv).
  * o has the same addressing with ldo.  lse[B,H,S] (natural-log-sum-exp of scaled scores) saved for bwd.
  * head_dim <= 64, S arbitrary. */
-/* tuning hook: head_dim 32 forward, 1 = split-bf16 MFMA kernel (default), 0 = fp32-MFMA kernel.  Returns the previous value. */
+/* tuning hook: head_dim 32 attention, 1 = split-bf16 MFMA kernels (default), 0 = fp32-MFMA kernels, 2 / 3 = split with the
+ * 8-wave / 4-wave forward workgroup forced.  Returns the previous value. */
 int gaot_debug_set_attention_split(int on);
 int gaot_attention_fwd(const float* q, const float* k, const float* v, int64_t ldq, int64_t ldk, int64_t ldv,
                        int32_t B, int32_t S, int32_t H, int32_t Hkv, int32_t head_dim,
