@@ -1055,6 +1055,284 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_split_kernel(const AttnArgs p
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// backward, 8 waves x 32 keys = 256 keys per workgroup (one workgroup per CU): the Q / dO tile is staged once per 256 keys,
+// the dQ slabs halve, and with 150 KB of LDS per workgroup the dQ product moves onto the bf16 pipe as well: dS is written as
+// three bf16 planes [q][kv] (2-byte stores straight from the packed split registers), K^T planes [d][kv] are built once per
+// wave, dQ = dS K is six bf16 piece products like the other four.
+// ---------------------------------------------------------------------------------------------
+constexpr int AB8_SHARED = 2 * 3 * AB_KPL + 2 * 3 * AB_TPL + 64 * 4;          // Q / dO planes (both orientations) + lse / delta
+constexpr int AB8_WAVE = 2 * 3 * AB_KPL;                                        // K^T planes + dS planes (dQ partial aliases dS)
+constexpr int AB8_LDS = AB8_SHARED + 8 * AB8_WAVE;
+
+__global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs p) {
+    constexpr int DP = 32, NW = 8;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[AB8_LDS];
+    unsigned char* Qk = smem;
+    unsigned char* Gk = Qk + 3 * AB_KPL;
+    unsigned char* Qt = Gk + 3 * AB_KPL;
+    unsigned char* Gt = Qt + 3 * AB_TPL;
+    float* lse_s = reinterpret_cast<float*>(Gt + 3 * AB_TPL);
+    float* del_s = lse_s + 32;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    int bh, kblk;
+    xcd_group_decode(blockIdx.x, p.B * p.H, p.n_kblocks, bh, kblk);
+    const int b = bh / p.H, h = bh % p.H, hk = h / (p.H / p.Hkv);
+    const int kv0 = kblk * 256 + wave * 32;
+    const float c = p.scale * LOG2E;
+    unsigned char* Ktp = smem + AB8_SHARED + wave * AB8_WAVE;        // 3 planes [d][32 kv]
+    unsigned char* dSp = Ktp + 3 * AB_KPL;                           // 3 planes [q][32 kv]
+    float* Pmine = reinterpret_cast<float*>(dSp);                    // [32 q][32 d] fp32 after the dQ MFMAs
+
+    bf16x8 kf[3][2], vf[3][2];
+    const bool kv_ok = kv0 + li < p.S;
+    {
+        const float* krow = p.k + ((long)b * p.S + min(kv0 + li, p.S - 1)) * p.ldk + (long)hk * 32;
+        const float* vrow = p.v + ((long)b * p.S + min(kv0 + li, p.S - 1)) * p.ldv + (long)hk * 32;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(krow + 16 * u + 8 * lh), a1 = *reinterpret_cast<const f32x4*>(krow + 16 * u + 8 * lh + 4);
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(vrow + 16 * u + 8 * lh), w1 = *reinterpret_cast<const f32x4*>(vrow + 16 * u + 8 * lh + 4);
+            u32x4 ph, pm, pl, vh, vm, vl;
+            unsigned a_, b_, c_;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                split3_pair(a0[2 * e], a0[2 * e + 1], a_, b_, c_); ph[e] = a_; pm[e] = b_; pl[e] = c_;
+                split3_pair(a1[2 * e], a1[2 * e + 1], a_, b_, c_); ph[2 + e] = a_; pm[2 + e] = b_; pl[2 + e] = c_;
+                split3_pair(w0[2 * e], w0[2 * e + 1], a_, b_, c_); vh[e] = a_; vm[e] = b_; vl[e] = c_;
+                split3_pair(w1[2 * e], w1[2 * e + 1], a_, b_, c_); vh[2 + e] = a_; vm[2 + e] = b_; vl[2 + e] = c_;
+            }
+            kf[0][u] = __builtin_bit_cast(bf16x8, ph); kf[1][u] = __builtin_bit_cast(bf16x8, pm); kf[2][u] = __builtin_bit_cast(bf16x8, pl);
+            vf[0][u] = __builtin_bit_cast(bf16x8, vh); vf[1][u] = __builtin_bit_cast(bf16x8, vm); vf[2][u] = __builtin_bit_cast(bf16x8, vl);
+        }
+        // K^T planes of this wave's 32 keys: item (key pair kp, 4-d chunk ch), two items per lane
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int item = lane + 64 * it, kp = item >> 3, d0 = (item & 7) * 4;
+            f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
+            if (kv0 + 2 * kp < p.S) r0 = *reinterpret_cast<const f32x4*>(p.k + ((long)b * p.S + kv0 + 2 * kp) * p.ldk + (long)hk * 32 + d0);
+            if (kv0 + 2 * kp + 1 < p.S) r1 = *reinterpret_cast<const f32x4*>(p.k + ((long)b * p.S + kv0 + 2 * kp + 1) * p.ldk + (long)hk * 32 + d0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned a_, b_, c_;
+                split3_pair(r0[e], r1[e], a_, b_, c_);
+                unsigned char* dst = Ktp + (d0 + e) * AB_KROW + kp * 4;
+                *reinterpret_cast<unsigned*>(dst) = a_;
+                *reinterpret_cast<unsigned*>(dst + AB_KPL) = b_;
+                *reinterpret_cast<unsigned*>(dst + 2 * AB_KPL) = c_;
+            }
+        }
+    }
+    f32x16 dvacc, dkacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dvacc[r] = 0.f; dkacc[r] = 0.f; }
+
+    const float* qbase = p.q + (long)b * p.S * p.ldq + (long)h * 32;
+    const float* gbase = p.dout + (long)b * p.S * p.ldo + (long)h * 32;
+    const float* lse_b = p.lse + ((long)b * p.H + h) * p.S;
+    const float* del_b = p.delta + ((long)b * p.H + h) * p.S;
+    // staging roles: kind = tid >> 8 (0: Q, 1: dO); k-major piece (row = (tid & 255) >> 3, chunk = tid & 7) for everyone;
+    // transposed piece (rows 2qp, 2qp+1; qp = (tid & 127) >> 3) for the threads with (tid & 255) < 128
+    const int kind = tid >> 8, t8 = tid & 255;
+    const bool tthread = t8 < 128;
+    const float* sbase = kind == 0 ? qbase : gbase;
+    const long sld = kind == 0 ? p.ldq : p.ldo;
+    f32x4 rk1, rt[2];
+    float rl = 0.f, rd = 0.f;
+    auto fetch = [&](int q0) {
+        {
+            const int row = t8 >> 3, d = (tid & 7) * 4;
+            rk1 = *reinterpret_cast<const f32x4*>(sbase + (long)min(q0 + row, p.S - 1) * sld + d);
+            if (q0 + row >= p.S) rk1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (tthread) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = 2 * (t8 >> 3) + i, d = (tid & 7) * 4;
+                rt[i] = *reinterpret_cast<const f32x4*>(sbase + (long)min(q0 + row, p.S - 1) * sld + d);
+                if (q0 + row >= p.S) rt[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        if (tid < 32) {
+            const bool ok = q0 + tid < p.S;
+            rl = ok ? lse_b[q0 + tid] * LOG2E : INFINITY;
+            rd = ok ? del_b[q0 + tid] : 0.f;
+        }
+    };
+    const int nq = (p.S + 31) / 32;
+    const long part_stride = (long)p.B * p.H * p.S * DP;
+    float* part = p.dq_part + (long)kblk * part_stride + ((long)b * p.H + h) * p.S * DP;
+
+    fetch(0);
+    for (int qt = 0; qt < nq; ++qt) {
+        const int q0 = qt * 32;
+        {
+            const int row = t8 >> 3, ch = tid & 7;
+            u32x2 h2, m2, l2;
+            unsigned a_, b_, c_;
+            split3_pair(rk1[0], rk1[1], a_, b_, c_); h2[0] = a_; m2[0] = b_; l2[0] = c_;
+            split3_pair(rk1[2], rk1[3], a_, b_, c_); h2[1] = a_; m2[1] = b_; l2[1] = c_;
+            unsigned char* dk_ = (kind == 0 ? Qk : Gk) + row * AB_KROW + ch * 8;
+            *reinterpret_cast<u32x2*>(dk_) = h2; *reinterpret_cast<u32x2*>(dk_ + AB_KPL) = m2; *reinterpret_cast<u32x2*>(dk_ + 2 * AB_KPL) = l2;
+            if (tthread) {
+                const int qp = t8 >> 3, d0 = ch * 4;
+                unsigned char* tb = (kind == 0 ? Qt : Gt) + qp * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    split3_pair(rt[0][e], rt[1][e], a_, b_, c_);
+                    unsigned char* dst = tb + (d0 + e) * AB_TROW;
+                    *reinterpret_cast<unsigned*>(dst) = a_;
+                    *reinterpret_cast<unsigned*>(dst + AB_TPL) = b_;
+                    *reinterpret_cast<unsigned*>(dst + 2 * AB_TPL) = c_;
+                }
+            }
+        }
+        if (tid < 32) { lse_s[tid] = rl; del_s[tid] = rd; }
+        __syncthreads();                                    // barrier A
+        if (qt + 1 < nq) fetch(q0 + 32);
+
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const unsigned char* qr = Qk + li * AB_KROW + u * 32 + lh * 16;
+            const unsigned char* gr = Gk + li * AB_KROW + u * 32 + lh * 16;
+            const bf16x8 q0_ = *reinterpret_cast<const bf16x8*>(qr), q1_ = *reinterpret_cast<const bf16x8*>(qr + AB_KPL), q2_ = *reinterpret_cast<const bf16x8*>(qr + 2 * AB_KPL);
+            const bf16x8 g0_ = *reinterpret_cast<const bf16x8*>(gr), g1_ = *reinterpret_cast<const bf16x8*>(gr + AB_KPL), g2_ = *reinterpret_cast<const bf16x8*>(gr + 2 * AB_KPL);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q2_, kf[0][u], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g2_, vf[0][u], dp, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0_, kf[2][u], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0_, vf[2][u], dp, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q1_, kf[1][u], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1_, vf[1][u], dp, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q1_, kf[0][u], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1_, vf[0][u], dp, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0_, kf[1][u], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0_, vf[1][u], dp, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0_, kf[0][u], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0_, vf[0][u], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qr = crow(r, lh);
+            float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c, -lse_s[qr]));
+            if (!kv_ok) pv = 0.f;
+            s[r] = pv;
+            dp[r] = pv * (dp[r] - del_s[qr]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            u32x4 ph, pm, pl, sh, sm, sl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned a_, b_, c_;
+                split3_pair(s[8 * u + 2 * e], s[8 * u + 2 * e + 1], a_, b_, c_); ph[e] = a_; pm[e] = b_; pl[e] = c_;
+                split3_pair(dp[8 * u + 2 * e], dp[8 * u + 2 * e + 1], a_, b_, c_); sh[e] = a_; sm[e] = b_; sl[e] = c_;
+                // dS pieces for the dQ product: rows q = crow(8u + 2e, hi) and q + 1, column kv = li, 2-byte stores
+                unsigned char* dst = dSp + crow(8 * u + 2 * e, lh) * AB_KROW + li * 2;
+                *reinterpret_cast<unsigned short*>(dst) = (unsigned short)(a_ & 0xffffu);
+                *reinterpret_cast<unsigned short*>(dst + AB_KROW) = (unsigned short)(a_ >> 16);
+                *reinterpret_cast<unsigned short*>(dst + AB_KPL) = (unsigned short)(b_ & 0xffffu);
+                *reinterpret_cast<unsigned short*>(dst + AB_KPL + AB_KROW) = (unsigned short)(b_ >> 16);
+                *reinterpret_cast<unsigned short*>(dst + 2 * AB_KPL) = (unsigned short)(c_ & 0xffffu);
+                *reinterpret_cast<unsigned short*>(dst + 2 * AB_KPL + AB_KROW) = (unsigned short)(c_ >> 16);
+            }
+            const bf16x8 p0 = __builtin_bit_cast(bf16x8, ph), p1 = __builtin_bit_cast(bf16x8, pm), p2 = __builtin_bit_cast(bf16x8, pl);
+            const bf16x8 d0 = __builtin_bit_cast(bf16x8, sh), d1 = __builtin_bit_cast(bf16x8, sm), d2 = __builtin_bit_cast(bf16x8, sl);
+            const unsigned char* gr = Gt + li * AB_TROW + (16 * u + 4 * lh) * 2;
+            const unsigned char* qr = Qt + li * AB_TROW + (16 * u + 4 * lh) * 2;
+            bf16x8 ga[3], qa[3];
+#pragma unroll
+            for (int pl_ = 0; pl_ < 3; ++pl_) {
+                const u32x2 g_lo = *reinterpret_cast<const u32x2*>(gr + pl_ * AB_TPL), g_hi = *reinterpret_cast<const u32x2*>(gr + pl_ * AB_TPL + 16);
+                const u32x2 q_lo = *reinterpret_cast<const u32x2*>(qr + pl_ * AB_TPL), q_hi = *reinterpret_cast<const u32x2*>(qr + pl_ * AB_TPL + 16);
+                ga[pl_] = __builtin_bit_cast(bf16x8, u32x4{g_lo[0], g_lo[1], g_hi[0], g_hi[1]});
+                qa[pl_] = __builtin_bit_cast(bf16x8, u32x4{q_lo[0], q_lo[1], q_hi[0], q_hi[1]});
+            }
+            dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[2], p0, dvacc, 0, 0, 0);
+            dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[2], d0, dkacc, 0, 0, 0);
+            dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p2, dvacc, 0, 0, 0);
+            dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d2, dkacc, 0, 0, 0);
+            dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1], p1, dvacc, 0, 0, 0);
+            dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1], d1, dkacc, 0, 0, 0);
+            dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1], p0, dvacc, 0, 0, 0);
+            dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1], d0, dkacc, 0, 0, 0);
+            dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p1, dvacc, 0, 0, 0);
+            dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d1, dkacc, 0, 0, 0);
+            dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p0, dvacc, 0, 0, 0);
+            dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d0, dkacc, 0, 0, 0);
+        }
+        // ---- dQ[q][d] partial = sum_kv dS[q][kv] K[kv][d]: A = dS planes (lane -> q), B = K^T planes (lane -> d), kv = 16u + 8hi + e
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        f32x16 dq;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+        bf16x8 da[2][3], kb[2][3];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int pl_ = 0; pl_ < 3; ++pl_) {
+                da[u][pl_] = *reinterpret_cast<const bf16x8*>(dSp + pl_ * AB_KPL + li * AB_KROW + u * 32 + lh * 16);
+                kb[u][pl_] = *reinterpret_cast<const bf16x8*>(Ktp + pl_ * AB_KPL + li * AB_KROW + u * 32 + lh * 16);
+            }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[u][2], kb[u][0], dq, 0, 0, 0);
+            dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[u][0], kb[u][2], dq, 0, 0, 0);
+            dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[u][1], kb[u][1], dq, 0, 0, 0);
+            dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[u][1], kb[u][0], dq, 0, 0, 0);
+            dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[u][0], kb[u][1], dq, 0, 0, 0);
+            dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[u][0], kb[u][0], dq, 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                     // every lane holds its dS fragments: the planes may be overwritten
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Pmine[crow(r, lh) * 32 + li] = dq[r];
+        __syncthreads();                                    // barrier B
+        // fixed-order sum of the eight waves' partials -> this key block's slice of the dQ workspace
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int t = tid + i * 512;
+            const int row = t / DP;
+            if (q0 + row < p.S) {
+                float acc = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w)
+                    acc += reinterpret_cast<const float*>(smem + AB8_SHARED + w * AB8_WAVE + 3 * AB_KPL)[t];
+                part[(long)(q0 + row) * DP + (t % DP)] = acc;
+            }
+        }
+    }
+    // ---- epilogue: dK^T, dV^T -> [kv][d] through the wave's (now free) dS region, coalesced row stores
+    __syncthreads();
+    float* Smine = reinterpret_cast<float*>(dSp);            // [32][33] floats = 4224 B <= 7680
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Smine[li * 33 + crow(r, lh)] = (pass == 0 ? dkacc[r] * p.scale : dvacc[r]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int rr = lh; rr < 32; rr += 2) {
+            const int kv = kv0 + rr;
+            if (kv < p.S) {
+                if (pass == 0) p.dk[((long)b * p.S + kv) * p.lddk + (long)h * 32 + li] = Smine[rr * 33 + li];
+                else           p.dv[((long)b * p.S + kv) * p.lddv + (long)h * 32 + li] = Smine[rr * 33 + li];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 template <int DP> static size_t bwd_lds_bytes() {
     return sizeof(float) * (2 * 32 * (DP + 4) + 64 + 4 * 32 * DP + 4 * 32 * 33 + 4 * 32 * DP);
 }
@@ -1127,7 +1405,11 @@ extern "C" int gaot_attention_bwd(const float* q, const float* k, const float* v
         hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv((long)B * S * H, 256)), dim3(256), 0, ST(stream), a);
     }
     dim3 grid(a.n_kblocks * B * H), block(256);
-    if (head_dim == 32 && a.vec && g_attn_split && aligned16(dq) && aligned16(dk) && aligned16(dv)) {
+    const bool split_ok = head_dim == 32 && a.vec && g_attn_split && aligned16(dq) && aligned16(dk) && aligned16(dv);
+    if (split_ok && g_attn_split != 3 && (g_attn_split == 2 || (long)cdiv(S, 256) * B * H >= 256)) {
+        a.n_kblocks = cdiv(S, 256);          // 256 keys per workgroup: half the dQ slabs (the workspace is sized for 128)
+        hipLaunchKernelGGL(attn_bwd_split8_kernel, dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a);
+    } else if (split_ok) {
         hipLaunchKernelGGL(attn_bwd_split_kernel, grid, block, 0, ST(stream), a);
     } else if (DP == 32) {
         hipLaunchKernelGGL(attn_bwd_kernel<32>, grid, block, bwd_lds_bytes<32>(), ST(stream), a);

@@ -294,6 +294,15 @@ def test_attention_fwd_bwd(B, S, H, Hkv, D):
             _lib.load().gaot_debug_set_attention_split(old)
         assert rel(out2, ref) < 3e-6 and rel(d2.grad, r.grad) < 1e-5
         assert rel(out, ref) < 2 * rel(out2, ref) + 1e-7 and rel(d.grad, r.grad) < 2 * rel(d2.grad, r.grad) + 1e-7     # as accurate as fp32 MFMA
+        # the 256-query / 256-key workgroup variants (picked by the heuristic only when they fill the chip) forced on
+        old = _lib.load().gaot_debug_set_attention_split(2)
+        try:
+            d3 = qkv.to(dev()).requires_grad_(True)
+            out3 = ops.attention(d3, H, Hkv, D)
+            out3.backward(go.to(dev()))
+        finally:
+            _lib.load().gaot_debug_set_attention_split(old)
+        assert rel(out3, ref) < 3e-6 and rel(d3.grad, r.grad) < 1e-5
 
 
 def test_attention_peaked_softmax():
