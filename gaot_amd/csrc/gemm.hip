@@ -333,7 +333,7 @@ namespace gaot { void set_glds_stages(int n); }
 static int g_use_split = 1;  // 1: eligible products run on the split-bf16 kernel (gemm_split.hip) per the heuristic; 2: always when eligible
 extern "C" int gaot_debug_set_gemm_glds(int on) {
     const int old = g_use_split ? 3 + g_use_split : g_use_glds;
-    g_use_glds = on != 0; g_use_split = on == 4 ? 1 : (on == 5 ? 2 : (on == 6 ? 3 : (on == 7 ? 4 : (on == 8 ? 5 : 0))));   // 6: SwiGLU product only, 7: 64-row tiles wherever eligible, 8: as 4 without the 64-row tiles
+    g_use_glds = on != 0; g_use_split = on == 4 ? 1 : (on == 5 ? 2 : (on == 6 ? 3 : (on == 7 ? 4 : (on == 8 ? 5 : (on == 9 ? 6 : 0)))));   // 6: SwiGLU product only, 7: 64-row tiles wherever eligible, 8: as 4 without the 64-row tiles
     gaot::set_glds_stages(on == 3 ? 3 : 2);
     return old;
 }
@@ -419,7 +419,7 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
                           (g_use_split == 2 || (blocks(128, 128) >= 250 && a.M >= 128 && a.N >= 128 && (long)cdiv(a.M, 128) * cdiv(a.N, 128) >= 8));
     // outputs only a few 128-wide tiles across (N = 256): 64-row tiles double the workgroup count
     const bool split64 = split_ok && !split128 && g_use_split != 5 && g_use_split != 2 &&
-                         (g_use_split == 4 || (ak && bk && blocks(64, 128) >= 250 && a.M >= 64 && a.N >= 128 && a.split_k <= 1));   // measured: NT +6-14 %, NN +-0
+                         (g_use_split == 4 || ((ak && (bk || g_use_split == 6)) && blocks(64, 128) >= 250 && a.M >= 64 && a.N >= 128 && a.split_k <= 1));   // measured: NT +6-14 %, NN +-0
     if (split128 || split64) {
         g_last_path = 3;
         launch_split(a, ak, bk, st, split64 ? 64 : 128);
