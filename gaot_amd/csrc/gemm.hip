@@ -330,10 +330,14 @@ namespace gaot { void set_glds_stages(int n); }
 // on: 0 = register-staged kernels only, 1 = LDS-direct with the default 2-stage ring, 3 = LDS-direct with a 3-stage ring,
 // 4 = + split-bf16 tiles by heuristic (DEFAULT: +5 % on the GAOT step, same-box A/B on two boxes),
 // 5 = split-bf16 wherever eligible, 6 = split-bf16 for the SwiGLU-gate product only.
+static int g_split_bm256 = 0;    // 1: 256x128 (8-wave) split tiles when they still fill the chip, 2: wherever M >= 256 (tuning)
 static int g_use_split = 1;  // 1: eligible products run on the split-bf16 kernel (gemm_split.hip) per the heuristic; 2: always when eligible
 extern "C" int gaot_debug_set_gemm_glds(int on) {
     const int old = g_use_split ? 3 + g_use_split : g_use_glds;
     g_use_glds = on != 0; g_use_split = on == 4 ? 1 : (on == 5 ? 2 : (on == 6 ? 3 : (on == 7 ? 4 : (on == 8 ? 5 : (on == 9 ? 6 : 0)))));   // 6: SwiGLU product only, 7: 64-row tiles wherever eligible, 8: as 4 without the 64-row tiles
+    g_split_bm256 = on == 10 ? 1 : (on == 11 ? 2 : 0);
+    if (on == 10) g_use_split = 1;
+    if (on == 11) g_use_split = 2;
     gaot::set_glds_stages(on == 3 ? 3 : 2);
     return old;
 }
@@ -396,7 +400,11 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
     if (a.act == GAOT_ACT_SWIGLU) {          // only the LDS-staged kernels lay the gate's bands out
         const long nb128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
         a.vec_epi = 1;
-        if (g_use_split == 2 || (g_use_split && nb128 >= 256)) { g_last_path = 3; launch_split(a, ak, bk, st); }
+        if (g_use_split == 2 || (g_use_split && nb128 >= 256)) {
+            g_last_path = 3;
+            const bool big = a.M >= 256 && (g_split_bm256 == 2 || (g_split_bm256 == 1 && nb128 >= 500));
+            launch_split(a, ak, bk, st, big ? 256 : 128);
+        }
         else { g_last_path = 1; launch_glds(a, ak, bk, nb128 >= 512 ? 1 : ((long)cdiv(a.M, 128) * cdiv(a.N, 64) >= 512 ? 2 : 3), st); }
         GAOT_CHECK_LAUNCH("gaot_gemm_f32(swiglu)");
         return GAOT_OK;
@@ -422,7 +430,9 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
                          (g_use_split == 4 || ((ak && (bk || g_use_split == 6)) && blocks(64, 128) >= 250 && a.M >= 64 && a.N >= 128 && a.split_k <= 1));   // measured: NT +6-14 %, NN +-0
     if (split128 || split64) {
         g_last_path = 3;
-        launch_split(a, ak, bk, st, split64 ? 64 : 128);
+        // 256x128 (8-wave) tiles: measured +3-7 % on the NT / TN products that still give ~200 workgroups, -2 % on NN
+        const bool big = split128 && a.M >= 512 && (g_split_bm256 == 2 || (g_split_bm256 == 1 && ak == bk && blocks(256, 128) >= 190));
+        launch_split(a, ak, bk, st, split64 ? 64 : (big ? 256 : 128));
     }
     else if (glds_ok && g_tile_override >= 0 && g_tile_override <= 3) {
         int tile = g_tile_override;

@@ -31,12 +31,17 @@ __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
 // ABL (tuning builds only, tools/split_bench.hip): 1 = no split arithmetic (raw words to LDS), 2 = no MFMA, 4 = no
 // epilogue stores, 8 = no LDS fragment reads, 16 = no global loads in the loop
 // BM = 128 (4 waves of 64x64) or 64 (4 waves of 32x64: twice the workgroups for outputs only two tiles wide, N = 256)
+// BM = 256: 8 waves (4 x 2) of 64x64, one workgroup per CU: a quarter less split work and LDS write traffic per MFMA
 template <bool AK, bool BKM, int BM = 128, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
-    constexpr int BN = S_BN, NW = 4, WAVES_N = 2, WM = BM / 2, WN = 64, TM = WM / 32, TN = 2;
-    constexpr int ABYTES = BM * 4;       // row stride of a row-contiguous A plane ([k pair][BM rows] of packed dwords)
+__global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 1 : 2) void gemm_split_kernel(const GemmArgs p) {
+    constexpr int BN = S_BN, NW = BM == 256 ? 8 : 4, NT = 64 * NW, WAVES_N = 2, WM = BM / (NW / 2), WN = 64, TM = WM / 32, TN = 2;
+    constexpr int ABYTES = BM * 4;       // row stride of a row-contiguous A plane ([k pair][BM rows] of packed dwords; BM = 64 only)
+    constexpr int PA = (BM > 128 ? BM : 128) * 48, PB = 128 * 48;      // bytes per plane
+    constexpr int STAGE = 3 * PA + 3 * PB;
+    constexpr bool A_FULL = BM * 2 == NT;        // two float4 per thread (else one / half the threads)
+    constexpr bool B_FULL = 128 * 2 == NT;
     constexpr int EPI_BYTES = NW * 32 * (WN + 4) * 4;
-    constexpr int SMEM_BYTES = 2 * S_STAGE > EPI_BYTES ? 2 * S_STAGE : EPI_BYTES;
+    constexpr int SMEM_BYTES = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
 
     const int tid = threadIdx.x;
@@ -70,22 +75,24 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         if (AK) {
-            if (BM == 128) a_src[q] = p.A + (long)min(m0 + (tid >> 1), p.M - 1) * p.lda + (tid & 1) * 8 + q * 4;
-            else           a_src[q] = p.A + (long)min(m0 + (tid >> 2), p.M - 1) * p.lda + (tid & 3) * 4;      // one float4 per thread (q = 0)
+            if (A_FULL) a_src[q] = p.A + (long)min(m0 + (tid >> 1), p.M - 1) * p.lda + (tid & 1) * 8 + q * 4;
+            else        a_src[q] = p.A + (long)min(m0 + (tid >> 2), p.M - 1) * p.lda + (tid & 3) * 4;      // one float4 per thread (q = 0)
         } else {
-            if (BM == 128) a_src[q] = p.A + (long)(2 * (tid & 7) + q) * p.lda + min(m0 + (tid >> 3) * 4, p.M - 4);
-            else           a_src[q] = p.A + (long)(2 * ((tid >> 4) & 7) + q) * p.lda + min(m0 + (tid & 15) * 4, p.M - 4);   // threads 0..127
+            if (A_FULL) a_src[q] = p.A + (long)(2 * (tid & 7) + q) * p.lda + min(m0 + (tid >> 3) * 4, p.M - 4);
+            else        a_src[q] = p.A + (long)(2 * ((tid >> 4) & 7) + q) * p.lda + min(m0 + (tid & 15) * 4, p.M - 4);   // BM = 64: threads 0..127
         }
         if (BKM) {
-            int nrow = min(n0 + (tid >> 1), p.N - 1);
+            const int row = B_FULL ? tid >> 1 : tid >> 2;
+            int nrow = min(n0 + row, p.N - 1);
             if (p.act == GAOT_ACT_SWIGLU) {      // band layout [u1 cols | u3 cols] per wave band (epilogue_swiglu)
-                const int F = p.N >> 1, row = tid >> 1, within = row % WN;
+                const int F = p.N >> 1, within = row % WN;
                 const int gcol = (n0 >> 1) + (row / WN) * (WN / 2) + within % (WN / 2);
                 nrow = (within / (WN / 2)) * F + min(gcol, F - 1);
             }
-            b_src[q] = p.B + (long)nrow * p.ldb + (tid & 1) * 8 + q * 4;
+            b_src[q] = B_FULL ? p.B + (long)nrow * p.ldb + (tid & 1) * 8 + q * 4 : p.B + (long)nrow * p.ldb + (tid & 3) * 4;
+        } else {      // 128 rows: (k pair = tid & 7, row quad = tid >> 3) for the first 256 threads
+            b_src[q] = p.B + (long)(2 * (tid & 7) + q) * p.ldb + min(n0 + ((tid >> 3) & 31) * 4, p.N - 4);
         }
-        else     { b_src[q] = p.B + (long)(2 * (tid & 7) + q) * p.ldb + min(n0 + (tid >> 3) * 4, p.N - 4); }
     }
     // two register sets: tile j lives in set j & 1 (loads run two k-tiles ahead of the MFMAs, the split one ahead)
     f32x4 ra[2][2], rb[2][2];
@@ -94,10 +101,12 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
         if ((ABL & 16) && kt > kt_begin + 1) return;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const bool a_live = BM == 128 || (AK ? q == 0 : tid < 128);
+            const bool a_live = A_FULL || (AK ? q == 0 : tid < 128);
+            const bool b_live = B_FULL || (BKM ? q == 0 : tid < 256);
             if (a_live) xa[q] = *reinterpret_cast<const f32x4*>(AK ? a_src[q] + k0 : a_src[q] + k0 * p.lda);
             else xa[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            xb[q] = *reinterpret_cast<const f32x4*>(BKM ? b_src[q] + k0 : b_src[q] + k0 * p.ldb);
+            if (b_live) xb[q] = *reinterpret_cast<const f32x4*>(BKM ? b_src[q] + k0 : b_src[q] + k0 * p.ldb);
+            else xb[q] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
 
@@ -105,10 +114,12 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
     const bool do_colsum = !AK && p.colsum != nullptr && (logical % p.tiles_n) == 0;
     f32x4 csum = {0.f, 0.f, 0.f, 0.f};
 
-    // split + store one operand's registers into its three planes (ROWS = 128: two float4 per thread; ROWS = 64: half of that)
-    auto stage_store = [&](unsigned char* base, const f32x4 (&r)[2], bool kmajor, int rows) {
+    // split + store one operand's registers into its three planes of `plane` bytes.  full: two float4 per thread; else one
+    // float4 (k-contiguous) or the first `half_threads` threads with two (row-contiguous).  Row-contiguous operands are written
+    // TRANSPOSED into the k-contiguous layout, except the 64-row A tile (legacy [k pair][row] layout, not picked by the heuristic).
+    auto stage_store = [&](unsigned char* base, const f32x4 (&r)[2], bool kmajor, bool full, int plane, int half_threads, bool legacy64) {
         if (kmajor) {
-            if (rows == 128) {
+            if (full) {
                 u32x4 h, m, l;
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
@@ -120,8 +131,8 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
                     }
                 unsigned char* dst = base + (tid >> 1) * 48 + (tid & 1) * 16;
                 *reinterpret_cast<u32x4*>(dst) = h;
-                *reinterpret_cast<u32x4*>(dst + S_PLANE) = m;
-                *reinterpret_cast<u32x4*>(dst + 2 * S_PLANE) = l;
+                *reinterpret_cast<u32x4*>(dst + plane) = m;
+                *reinterpret_cast<u32x4*>(dst + 2 * plane) = l;
             } else {
                 u32x2 h, m, l;
 #pragma unroll
@@ -132,35 +143,35 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
                 }
                 unsigned char* dst = base + (tid >> 2) * 48 + (tid & 3) * 8;
                 *reinterpret_cast<u32x2*>(dst) = h;
-                *reinterpret_cast<u32x2*>(dst + S_PLANE) = m;
-                *reinterpret_cast<u32x2*>(dst + 2 * S_PLANE) = l;
+                *reinterpret_cast<u32x2*>(dst + plane) = m;
+                *reinterpret_cast<u32x2*>(dst + 2 * plane) = l;
             }
         } else {
-            if (rows == 64 && tid >= 128) return;
+            if (!full && tid >= half_threads) return;
             u32x4 h, m, l;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { unsigned a_, b_, c_; split3_pair<ABL>(r[0][e], r[1][e], a_, b_, c_); h[e] = a_; m[e] = b_; l[e] = c_; }
-            if (rows == 128) {
+            if (!legacy64) {
                 unsigned char* dst = base + (tid >> 3) * 4 * 48 + (tid & 7) * 4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     *reinterpret_cast<unsigned*>(dst + e * 48) = h[e];
-                    *reinterpret_cast<unsigned*>(dst + e * 48 + S_PLANE) = m[e];
-                    *reinterpret_cast<unsigned*>(dst + e * 48 + 2 * S_PLANE) = l[e];
+                    *reinterpret_cast<unsigned*>(dst + e * 48 + plane) = m[e];
+                    *reinterpret_cast<unsigned*>(dst + e * 48 + 2 * plane) = l[e];
                 }
             } else {
                 unsigned char* dst = base + (tid >> 4) * 256 + (tid & 15) * 16;
                 *reinterpret_cast<u32x4*>(dst) = h;
-                *reinterpret_cast<u32x4*>(dst + S_PLANE) = m;
-                *reinterpret_cast<u32x4*>(dst + 2 * S_PLANE) = l;
+                *reinterpret_cast<u32x4*>(dst + plane) = m;
+                *reinterpret_cast<u32x4*>(dst + 2 * plane) = l;
             }
         }
     };
     auto sstore = [&](int stage, const f32x4 (&xa)[2], const f32x4 (&xb)[2], bool live) {
-        unsigned char* sa = smem_raw + stage * S_STAGE;
-        stage_store(sa, xa, AK, BM);
-        stage_store(sa + 3 * S_PLANE, xb, BKM, 128);
-        if (!AK) { const float w = (do_colsum && live && (BM == 128 || tid < 128)) ? 1.f : 0.f; csum += (xa[0] + xa[1]) * w; }   // branch-free: keeps the k-loop one block
+        unsigned char* sa = smem_raw + stage * STAGE;
+        stage_store(sa, xa, AK, A_FULL, PA, 128, BM == 64);
+        stage_store(sa + 3 * PA, xb, BKM, B_FULL, PB, 256, false);
+        if (!AK) { const float w = (do_colsum && live && (A_FULL || tid < 128)) ? 1.f : 0.f; csum += (xa[0] + xa[1]) * w; }   // branch-free: keeps the k-loop one block
     };
 
     f32x16 acc[TM][TN];
@@ -184,17 +195,17 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
     // after that is fetched into (ya/yb).  Branch-free, so the scheduler can interleave the three streams.
     auto step = [&](int kt, int stage, f32x4 (&xa)[2], f32x4 (&xb)[2], f32x4 (&ya)[2], f32x4 (&yb)[2]) {
         gload(kt + 2, ya, yb);
-        const unsigned char* sa = smem_raw + stage * S_STAGE;
-        const unsigned char* sb = sa + 3 * S_PLANE;
+        const unsigned char* sa = smem_raw + stage * STAGE;
+        const unsigned char* sb = sa + 3 * PA;
         bf16x8 a[TM][3], b[TN][3];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) a[i][pl] = frag(sa + pl * S_PLANE, wm * WM + i * 32 + li, AK || BM == 128, ABYTES);
+            for (int pl = 0; pl < 3; ++pl) a[i][pl] = frag(sa + pl * PA, wm * WM + i * 32 + li, AK || BM != 64, ABYTES);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) b[j][pl] = frag(sb + pl * S_PLANE, wn * WN + j * 32 + li, true, 512);
+            for (int pl = 0; pl < 3; ++pl) b[j][pl] = frag(sb + pl * PB, wn * WN + j * 32 + li, true, 512);
         // small terms first
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -240,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs p) {
 
     if (!AK && do_colsum) {          // reduce the 8 k-pair groups through LDS (the stages are free now)
         float* cs = reinterpret_cast<float*>(smem_raw);
-        if (BM == 128) *reinterpret_cast<f32x4*>(cs + (tid & 7) * BM + (tid >> 3) * 4) = csum;
+        if (A_FULL) *reinterpret_cast<f32x4*>(cs + (tid & 7) * BM + (tid >> 3) * 4) = csum;
         else if (tid < 128) *reinterpret_cast<f32x4*>(cs + (tid >> 4) * BM + (tid & 15) * 4) = csum;
         __syncthreads();
         if (tid < BM && m0 + tid < p.M) {
@@ -262,7 +273,7 @@ static void launch_split_bm(GemmArgs& a, bool ak, bool bk, hipStream_t st) {
     a.tiles_m = cdiv(a.M, BM);
     a.tiles_n = cdiv(a.N, S_BN);
     dim3 grid(a.tiles_m * a.tiles_n, 1, a.split_k > 1 ? a.split_k : 1);
-    dim3 block(256);
+    dim3 block(BM == 256 ? 512 : 256);
     if (ak && bk)        hipLaunchKernelGGL((gemm_split_kernel<true, true, BM>), grid, block, 0, st, a);
     else if (ak && !bk)  hipLaunchKernelGGL((gemm_split_kernel<true, false, BM>), grid, block, 0, st, a);
     else if (!ak && !bk) hipLaunchKernelGGL((gemm_split_kernel<false, false, BM>), grid, block, 0, st, a);
@@ -270,8 +281,9 @@ static void launch_split_bm(GemmArgs& a, bool ak, bool bk, hipStream_t st) {
 }
 
 void launch_split(GemmArgs& a, bool ak, bool bk, hipStream_t st, int bm) {
-    if (bm == 64) launch_split_bm<64>(a, ak, bk, st);
-    else          launch_split_bm<128>(a, ak, bk, st);
+    if (bm == 64)       launch_split_bm<64>(a, ak, bk, st);
+    else if (bm == 256) launch_split_bm<256>(a, ak, bk, st);
+    else                launch_split_bm<128>(a, ak, bk, st);
 }
 
 }  // namespace gaot

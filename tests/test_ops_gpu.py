@@ -418,11 +418,13 @@ def test_swiglu_ffn_fused_matches_unfused(M, K, F):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", [5, 7, 11])
 @pytest.mark.parametrize("M,N,K", [(200, 132, 64), (520, 260, 96), (1000, 64, 256), (4096, 512, 1024)])
-def test_gemm_split_bf16_kernel(M, N, K):
+def test_gemm_split_bf16_kernel(M, N, K, mode):
     """gemm_split.hip: fp32 operands split exactly into three bf16 pieces, six bf16 MFMAs per product.  Forced on
     (mode 5) for every layout / epilogue it serves; must be as accurate as the fp32 MFMA kernel (float64 reference),
-    including operands whose rows differ by orders of magnitude."""
+    including operands whose rows differ by orders of magnitude.  mode 5 = 128x128 tiles, 7 = 64-row tiles, 11 = 256-row (8-wave)
+    tiles wherever M >= 512."""
     from gaot_amd import ops, _lib
     lib = _lib.load()
     g = torch.Generator().manual_seed(M + N + K)
@@ -434,7 +436,7 @@ def test_gemm_split_bf16_kernel(M, N, K):
     z_ref = xd @ wd.t() + b.double()
     refs = dict(y=torch.nn.functional.gelu(z_ref) + res.double(), z=z_ref,
                 dx=(gd @ wd), dxg=(gd @ wd) * 1.0, dw=gd[:Mk].t() @ xd[:Mk], db=gd[:Mk].sum(0))
-    old = lib.gaot_debug_set_gemm_glds(5)
+    old = lib.gaot_debug_set_gemm_glds(mode)
     try:
         d = "cuda"
         z = torch.empty(M, N, device=d)

@@ -23,7 +23,7 @@ for (M, N, K) in [(200, 132, 64), (520, 260, 96), (1000, 64, 256), (4096, 512, 1
     Mk = M - M % 32
     ref = (x.double() @ w.double().t() + 1, gy.double() @ w.double(), gy[:Mk].double().t() @ x[:Mk].double())
     sc = (x.double().abs() @ w.double().abs().t() + 1, gy.double().abs() @ w.double().abs(), gy[:Mk].double().abs().t() @ x[:Mk].double().abs())
-    for mode in (1, 5, 7):
+    for mode in (1, 5, 7, 11):
         lib.gaot_debug_set_gemm_glds(mode)
         y = ops.linear_nt(x.to(dev), w.to(dev), bias=torch.ones(N, device=dev)); p1 = lib.gaot_debug_last_gemm_path()
         dx = ops.matmul_nn(gy.to(dev), w.to(dev)); p2 = lib.gaot_debug_last_gemm_path()
@@ -52,8 +52,8 @@ for (kind, M, N, K) in [("nt", 4096, 4096, 4096), ("nt", 8192, 2048, 256), ("nt"
     sks = [1] if kind != "tn" else sorted({max(1, sk0 // 4), max(1, sk0 // 2), sk0, sk0 * 2, sk0 * 4})
     for sk in sks:
         us = timeit(lambda: f(sk)); row.append(f"split sk{sk} {us:6.1f}us {2.0*M*N*K/us/1e6:6.1f}TF")
-    lib.gaot_debug_set_gemm_glds(7)
+    lib.gaot_debug_set_gemm_glds(11)
     for sk in ([1] if kind != "tn" else [sk0, sk0 * 2]):
-        us = timeit(lambda: f(sk)); row.append(f"split64 sk{sk} {us:6.1f}us {2.0*M*N*K/us/1e6:6.1f}TF")
+        us = timeit(lambda: f(sk)); row.append(f"split256 sk{sk} {us:6.1f}us {2.0*M*N*K/us/1e6:6.1f}TF")
     lib.gaot_debug_set_gemm_glds(1)
     print(f"{kind} M={M} N={N} K={K} | " + " | ".join(row), flush=True)
