@@ -34,6 +34,7 @@ if ROOT not in sys.path:
 
 N_NODES, BATCH, LATENT, C_LIFT, HIDDEN, PATCH, RADIUS = 16384, 8, [64, 64], 64, 256, 2, 0.033
 PEAK_F32_MATRIX_TFLOPS = 157.3
+PEAK_HBM_GBPS = 8000.0
 
 
 def build_model():
@@ -71,9 +72,31 @@ def gemm_roofline(ts):
         records.append((s, e, 2.0 * M * N * K, (M, N, K, int(a[2]), int(a[5]), kw.get("split_k", 1)), lib.gaot_debug_last_gemm_path()))
         return out
 
+    # the HBM regime: the fused gather / segment-reduce / edge-gradient kernels of the integral transforms (csrc/gno.hip)
+    gno = []
+    GNO_CALLS = {"gaot_gno_lift_gather_reduce": "encoder fwd", "gaot_gno_lift_edge_grad": "encoder bwd",
+                 "gaot_gno_proj_gather_reduce": "decoder fwd", "gaot_gno_proj_backward": "decoder bwd",
+                 "gaot_gno_gather_reduce": "unfused transform", "gaot_gno_edge_grad": "unfused edge grad"}
+    saved = {}
+    for name in GNO_CALLS:
+        fn = getattr(lib, name)
+        saved[name] = fn
+
+        def wrap(fn=fn, name=name):
+            def call(*a):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                rc = fn(*a)
+                e.record()
+                gno.append((name, s, e))
+                return rc
+            return call
+        setattr(lib, name, wrap())
+
     use_graph = ts.use_graph
     ts.use_graph = False
     ts.step()                      # untimed eager step (allocator warm)
+    gno.clear()
     ops.gemm = timed_gemm
     try:
         torch.cuda.synchronize()
@@ -85,6 +108,11 @@ def gemm_roofline(ts):
     finally:
         ops.gemm = raw
         ts.use_graph = use_graph
+        for name, fn in saved.items():
+            setattr(lib, name, fn)
+    gno_us = {}
+    for name, s_, e_ in gno:
+        gno_us[GNO_CALLS[name]] = gno_us.get(GNO_CALLS[name], 0.0) + 1e3 * s_.elapsed_time(e_)
     mfma = [r for r in records if r[4] in (1, 3)]     # launches served by the MFMA tile kernels (1 = fp32 MFMA, 3 = split-bf16 MFMA)
     n_split = sum(1 for r in records if r[4] == 3)
     ms = sum(r[0].elapsed_time(r[1]) for r in mfma)
@@ -97,32 +125,44 @@ def gemm_roofline(ts):
             print(f"# gemm M={M:6d} N={N:5d} K={K:6d} a_k={ak} b_k={bk} split={sk:3d} {us:8.1f}us {fl / us / 1e6:6.1f}TF", file=sys.stderr)
     return {"launches": len(mfma), "flops": flops, "ms": ms, "tflops": flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
             "skinny_launches": len(records) - len(mfma), "all_gemm_ms": ms_all, "split_launches": n_split,
-            "alg_bytes_per_launch": abytes / max(1, len(mfma))}
+            "alg_bytes_per_launch": abytes / max(1, len(mfma)), "gno_us": gno_us, "gno_launches": len(gno)}
 
 
-def recorded_traffic():
-    """HBM bytes per GEMM launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, see
-    tools/pmc_traffic.py); bench.py cannot run the profiler on itself."""
-    path = os.path.join(ROOT, "profiles", "r1_gemm_traffic.json")
+def recorded_traffic(family: str = "gemm"):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, see
+    tools/pmc_traffic.py); bench.py cannot run the profiler on itself.  profiles/current_traffic.json names, per family, the
+    file the number comes from and the commit it was measured at, so a stale figure is visible as such."""
     try:
-        with open(path) as f:
-            return json.load(f)["hbm_bytes_per_launch"]
+        with open(os.path.join(ROOT, "profiles", "current_traffic.json")) as f:
+            cur = json.load(f)[family]
+        with open(os.path.join(ROOT, "profiles", cur["file"])) as f:
+            return json.load(f)["hbm_bytes_per_launch"], f"profiles/{cur['file']} (measured at commit {cur['commit']})"
     except Exception:
-        return None
+        return None, None
 
 
-def cpu_baseline(steps: int = 3):
+def cpu_baseline(sd, tensors, hip, steps: int = 3):
+    """the CPU oracle on the same weights and the same batch: timed as the baseline, and its FIRST step (same initial
+    weights as `hip` = prediction / loss / gradients of the HIP path before any update) is the reference of the
+    rel-L2 half of BASELINE's metric."""
     from oracle import gaot_oracle as O
-    torch.manual_seed(0)
-    model = build_model()
-    sd = {k: v.clone() for k, v in model.state_dict().items()}
-    lat, x, p, t = synthetic(0, torch.device("cpu"))
+    lat, x, p, t = [v.cpu() for v in tensors]
     cfg = O.OracleConfig(radius=RADIUS, hidden_size=64, lifting_channels=C_LIFT, patch_size=PATCH, tf_hidden_size=HIDDEN,
                          latent_tokens_size=LATENT, precompute_edges=True)
-    enc, dec = [O.radius_csr(x, lat, RADIUS)], [O.radius_csr(lat, x, RADIUS)]
+    # explicit-difference distance test (the reference's `grid` backend = method 'auto'); the HIP cell list must have built
+    # exactly this graph (checked), so both sides integrate over the same edges
+    enc, dec = [O.radius_csr(x, lat, RADIUS, exact=True)], [O.radius_csr(lat, x, RADIUS, exact=True)]
+    same_graph = all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in ((enc[0], hip["enc_csr"]), (dec[0], hip["dec_csr"])))
     batch = dict(latent=lat, xcoord=x, pndata=p, target=t, encoder_nbrs=enc, decoder_nbrs=dec)
-    state = None
-    _, _, sd, state = O.train_step(sd, cfg, batch, state=state)          # warm-up
+    loss0, grads0, sd, state, pred0 = O.train_step(sd, cfg, batch, state=None, return_pred=True)      # warm-up + parity reference
+    top = max(float(g.double().norm()) for g in grads0.values())
+    gerr = {k: float((hip["grads"][k].double() - g.double()).norm()) / max(float(g.double().norm()), 1e-3 * top) for k, g in grads0.items()}
+    worst = max(gerr, key=gerr.get)
+    parity = {"output": float((hip["pred"].double() - pred0.double()).norm() / pred0.double().norm()),
+              "loss": abs(hip["loss"] - float(loss0)) / abs(float(loss0)),
+              "grad_worst_tensor": gerr[worst], "grad_worst_name": worst, "radius_graph_identical": bool(same_graph),
+              "what": "HIP path vs CPU oracle, same initial weights and batch as the timed run (rank 0): relative L2 of the "
+                      "[8,16384,1] prediction, relative loss error, worst per-tensor relative L2 over the 72 gradient tensors"}
     # the oracle is plain torch ops: oversubscribing a big host slows it down, so take the best of a few thread counts
     all_threads = torch.get_num_threads()
     best, best_dt = all_threads, None
@@ -138,9 +178,26 @@ def cpu_baseline(steps: int = 3):
     for _ in range(steps):
         _, _, sd, state = O.train_step(sd, cfg, batch, state=state)
     dt = time.perf_counter() - t0
-    return {"value": BATCH * steps / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+    base = {"value": BATCH * steps / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{steps} full train steps (fwd+MSE+bwd+AdamW) of the same workload (16384 nodes, batch {BATCH}) "
                       f"on the CPU oracle, {dt / steps:.2f} s/step"}
+    return base, parity
+
+
+def hip_reference_pass(model, tensors):
+    """prediction, loss and every gradient of the HIP path at the INITIAL weights (eager, before TrainStep touches them)"""
+    from gaot_amd import ops
+    lat, x, p, t = tensors
+    model.zero_grad(set_to_none=True)
+    pred = model(latent_tokens_coord=lat, xcoord=x, pndata=p)
+    loss = ops.mse_loss(pred, t)
+    loss.backward()
+    torch.cuda.synchronize()
+    csr = lambda m: tuple(list(m.neighbor_cache.values())[0][0][k].cpu() for k in ("neighbors_index", "neighbors_row_splits"))
+    out = {"pred": pred.detach().cpu(), "loss": float(loss.detach()), "grads": {k: q.grad.detach().cpu().clone() for k, q in model.named_parameters()},
+           "enc_csr": csr(model.encoder), "dec_csr": csr(model.decoder)}
+    model.zero_grad(set_to_none=True)
+    return out
 
 
 def main():
@@ -175,6 +232,9 @@ def main():
     torch.manual_seed(0)                      # identical weights on every rank (and broadcast from rank 0 anyway)
     model = build_model().to(dev).train()
     lat, x, p, t = synthetic(1234 + rank, dev)
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()} if want_cpu else None
+    hip0 = hip_reference_pass(model, (lat, x, p, t)) if want_cpu else None
     ts = TrainStep(model, lr=8e-4, weight_decay=1e-5, use_graph=not args.no_graph)
     ts.bind(p, t, latent_tokens_coord=lat, xcoord=x)
 
@@ -201,6 +261,29 @@ def main():
     roof = gemm_roofline(ts)
     if rank == 0:
         n_params = sum(q.numel() for q in model.parameters())
+        ms_step = 1e3 * elapsed / args.steps
+        traffic, traffic_src = recorded_traffic("gemm")
+        # HBM regime: the four fused integral-transform kernels of one step.  Algorithmic bytes = every operand
+        # of a launch touched once (k_e rows, node features, CSR arrays, outputs) -- fewer than SURVEY 8d's 42 MB per train
+        # sample because the lifted [B,N,C] tensor and the [B,Nq,C] transform output no longer exist.
+        enc_nb = list(model.encoder.neighbor_cache.values())[0][0]
+        dec_nb = list(model.decoder.neighbor_cache.values())[0][0]
+        Ee, Ed = int(enc_nb["neighbors_index"].numel()), int(dec_nb["neighbors_index"].numel())
+        Q, C, B_ = LATENT[0] * LATENT[1], C_LIFT, BATCH
+        gno_bytes = {
+            "encoder fwd": 4.0 * (Ee * C + B_ * N_NODES * 1 + 3 * Ee + Q + B_ * Q * C),
+            "encoder bwd": 4.0 * (B_ * Q * C + Ee * C + B_ * N_NODES * 1 + 3 * Ee + Ee * C),
+            "decoder fwd": 4.0 * (Ed * C + B_ * Q * C + 3 * Ed + N_NODES + B_ * N_NODES * 1),
+            "decoder bwd": 4.0 * (B_ * N_NODES * 1 + Ed * C + B_ * Q * C + 5 * Ed + Ed * C + B_ * Q * C),
+        }
+        gno_rows = {k: {"us": roof["gno_us"].get(k), "algorithmic_MB": gno_bytes[k] / 1e6,
+                        "GBps": (gno_bytes[k] / (roof["gno_us"][k] * 1e-6) / 1e9) if roof["gno_us"].get(k) else None} for k in gno_bytes}
+        gno_total_us = sum(v for k, v in roof["gno_us"].items() if k in gno_bytes)
+        gno_total_b = sum(gno_bytes.values())
+        hbm_achieved = gno_total_b / (gno_total_us * 1e-6) / 1e9 if gno_total_us > 0 else 0.0
+        gno_traffic, gno_src = recorded_traffic("gno")
+        t_mfma_ideal = 259.0e9 / (PEAK_F32_MATRIX_TFLOPS * 1e12) * 1e3           # 259 GFLOP per B = 8 step
+        t_hbm_ideal = (8 * (42 + 120) + 13) * 1e6 / (PEAK_HBM_GBPS * 1e9) * 1e3   # ~1.31 GB per step
         line = {
             "metric": "train samples/sec (2D 16k-node mesh, bs=8 per GPU)",
             "value": BATCH * world * args.steps / elapsed,
@@ -208,7 +291,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step": ms_step,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -217,23 +300,33 @@ def main():
             "config": {"workload": "BASELINE configs[1]: Poisson-Gauss-shaped 2D, 16384 nodes/mesh, batch 8 per GPU, fx mode; "
                                    "example model latent 64x64, C=64, patch 2, transformer 256x3, 8 heads",
                        "params": n_params, "global_batch": BATCH * world, "parallelism": f"dp{world}",
-                       "step": "fwd + MSE + bwd + AdamW" + (" + flat-grad RCCL all-reduce" if world > 1 else ""),
-                       "hipgraph": ts.use_graph, "final_loss": loss},
+                       "step": "fwd + MSE + bwd + AdamW" + (" + staged flat-grad RCCL all-reduce (one async slice per backward phase)" if world > 1 else ""),
+                       "hipgraph": ts.use_graph, "staged_backward_phases": ts.bucket.n_phases, "final_loss": loss},
             "roofline": {"bound": "mfma", "kernel": "gaot_gemm_f32 MFMA tile kernels, every launch of one step: gemm_glds_kernel (v_mfma_f32_32x32x2_f32) and "
                                    "gemm_split_kernel (fp32 operands split exactly into 3 bf16 pieces, 6 x v_mfma_f32_32x32x16_bf16 per product)",
                          "peak_note": "peak = dense f32 matrix rate; the split-bf16 kernel's own ceiling is bf16 dense / 6 = 419 TFLOP/s of f32 work",
                          "split_bf16_launches_per_step": roof["split_launches"],
                          "achieved": roof["tflops"], "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                         "frac": roof["tflops"] / PEAK_F32_MATRIX_TFLOPS, "traffic": recorded_traffic(),
-                         "traffic_note": "HBM bytes per launch, PMC FETCH_SIZE(x2, gfx950)+WRITE_SIZE from profiles/r1_gemm_traffic.json "
-                                         "(separate --pmc passes over the same launches, eager step)",
+                         "frac": roof["tflops"] / PEAK_F32_MATRIX_TFLOPS, "traffic": traffic,
+                         "traffic_note": "HBM bytes per launch, PMC FETCH_SIZE(x2, gfx950)+WRITE_SIZE, separate --pmc passes over the same "
+                                         f"launches (eager step): {traffic_src}",
                          "algorithmic_bytes_per_launch": roof["alg_bytes_per_launch"],
                          "launches_per_step": roof["launches"], "gflop_per_step": roof["flops"] / 1e9,
                          "kernel_ms_per_step": roof["ms"], "avg_launch_us": 1e3 * roof["ms"] / max(1, roof["launches"]),
                          "skinny_valu_launches_per_step": roof["skinny_launches"], "all_gemm_entry_ms_per_step": roof["all_gemm_ms"]},
+            "roofline_hbm": {"bound": "hbm", "kernel": "fused integral-transform kernels of one step (csrc/gno.hip): lift_gather_reduce, "
+                                                        "lift_edge_grad, proj_gather_reduce, proj_edge_grad + proj_gather_t",
+                             "achieved": hbm_achieved, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": hbm_achieved / PEAK_HBM_GBPS,
+                             "traffic": gno_traffic, "traffic_note": gno_src,
+                             "algorithmic_bytes_per_step": gno_total_b, "kernel_us_per_step": gno_total_us, "per_kernel": gno_rows,
+                             "edges": {"encoder": Ee, "decoder": Ed}},
+            "roofline_step": {"t_mfma_ideal_ms": t_mfma_ideal, "t_hbm_ideal_ms": t_hbm_ideal,
+                              "achieved": max(t_mfma_ideal, t_hbm_ideal) / ms_step,
+                              "note": "SURVEY 8d: max(t_HBM, t_MFMA)_ideal / t_measured with 259 GFLOP and ~1.31 GB of algorithmic work per "
+                                      "8-sample step against 157.3 TFLOP/s (f32 matrix) and 8 TB/s"},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+        if want_cpu:
+            line["cpu_baseline"], line["rel_l2_vs_oracle"] = cpu_baseline(sd0, (lat, x, p, t), hip0)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

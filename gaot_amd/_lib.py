@@ -81,6 +81,7 @@ PROTOTYPES = {
     "gaot_mse_loss_fwd": (C.c_int, [_f, _f, C.c_int64, _f, _f, _s]),
     "gaot_mse_loss_bwd": (C.c_int, [_f, _f, C.c_int64, _f, _f, _s]),
     "gaot_adamw_step": (C.c_int, [_f, _f, _f, _f, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _f, _s]),
+    "gaot_adamw_step_dev": (C.c_int, [_f, _f, _f, _f, C.c_int64, _f, _f, _s]),
     "gaot_patchify": (C.c_int, [_f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f, C.c_int32, _s]),
 }
 

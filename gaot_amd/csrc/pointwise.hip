@@ -306,9 +306,12 @@ __global__ void patchify_kernel(const float* __restrict__ in, float* __restrict_
 // the optimizer at optimizers.py:196): decoupled weight decay, bias-corrected moments, eps added after the bias correction
 // of sqrt(v).  `step` lives on the device so the launch is hipGraph-replayable; a 1-thread kernel advances it first.
 __global__ void adamw_tick_kernel(float* step) { step[0] += 1.0f; }
+// hyper (optional, DEVICE): {lr, beta1, beta2, eps, weight_decay} read at run time, so a captured launch follows a learning-rate
+// schedule without re-capture (the scalar arguments are ignored then)
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
-                                                    float wd, const float* __restrict__ step) {
+                                                    float wd, const float* __restrict__ step, const float* __restrict__ hyper) {
+    if (hyper) { lr = hyper[0]; b1 = hyper[1]; b2 = hyper[2]; eps = hyper[3]; wd = hyper[4]; }
     const float t = step[0];
     const float bc1 = 1.0f - powf(b1, t);
     const float bc2 = 1.0f - powf(b2, t);
@@ -514,7 +517,18 @@ extern "C" int gaot_adamw_step(float* p, const float* g, float* m, float* v, int
     GAOT_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), "adamw_step: flat buffers must be 16-byte aligned");
     hipLaunchKernelGGL(adamw_tick_kernel, dim3(1), dim3(1), 0, ST(stream), step);
     hipLaunchKernelGGL(adamw_kernel, dim3(cap_blocks(n / 4 + 1, 256, 2048)), dim3(256), 0, ST(stream), p, g, m, v, (long)n, lr, beta1,
-                       beta2, eps, weight_decay, step);
+                       beta2, eps, weight_decay, step, (const float*)nullptr);
     GAOT_CHECK_LAUNCH("gaot_adamw_step");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_adamw_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, float* step,
+                                   gaot_stream_t stream) {
+    GAOT_REQUIRE(p && g && m && v && step && hyper && n > 0, "adamw_step_dev: bad arguments");
+    GAOT_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), "adamw_step_dev: flat buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(adamw_tick_kernel, dim3(1), dim3(1), 0, ST(stream), step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(cap_blocks(n / 4 + 1, 256, 2048)), dim3(256), 0, ST(stream), p, g, m, v, (long)n, 0.f, 0.f,
+                       0.f, 0.f, 0.f, step, hyper);
+    GAOT_CHECK_LAUNCH("gaot_adamw_step_dev");
     return GAOT_OK;
 }

@@ -104,10 +104,26 @@ class GAOT(nn.Module):
                 query_coord: Optional[torch.Tensor] = None, encoder_nbrs: Optional[list] = None,
                 decoder_nbrs: Optional[list] = None, condition: Optional[float] = None) -> torch.Tensor:
         rn = self.encode(x_coord=xcoord, pndata=pndata, latent_tokens_coord=latent_tokens_coord, encoder_nbrs=encoder_nbrs)
+        rn = ops.cut(rn)                      # staged backward (data-parallel training): encoder gradients complete last
         rn = self.process(rndata=rn, condition=condition)
         if query_coord is None:
             query_coord = xcoord
         return self.decode(latent_tokens_coord=latent_tokens_coord, rndata=rn, query_coord=query_coord, decoder_nbrs=decoder_nbrs)
+
+    def backward_phases(self) -> List[List[nn.Parameter]]:
+        """parameters in backward-COMPLETION order, one list per stretch between cut points (forward(): after the encoder;
+        Transformer.forward(): after every block but the last): [last block + output_proj + decoder], ..., [first block +
+        input_proj + patch_linear], [encoder].  trainer.TrainStep reduces each list's gradients while the next one is computed."""
+        blocks = self.processor.blocks_in_order()
+        phases = [list(b.parameters()) for b in reversed(blocks)]
+        if isinstance(self.processor.output_proj, nn.Linear):
+            phases[0] += list(self.processor.output_proj.parameters())
+        phases[0] += list(self.decoder.parameters())
+        if isinstance(self.processor.input_proj, nn.Linear):
+            phases[-1] += list(self.processor.input_proj.parameters())
+        phases[-1] += list(self.patch_linear.parameters())
+        phases.append(list(self.encoder.parameters()))
+        return phases
 
     # ---- rollout (reference gaot.py:307-476)
     def autoregressive_predict(self, x_batch: torch.Tensor, time_indices: np.ndarray, t_values: np.ndarray, stats: Dict,
@@ -169,7 +185,7 @@ class _RolloutRunner:
         self.graph = None
 
     def _versions(self):
-        return tuple(p._version for p in self.model.parameters())
+        return tuple(p._version for p in self.model.parameters()) + (ops.weights_generation(),)
 
     def __call__(self, pn: torch.Tensor, cond: Optional[torch.Tensor]):
         m = self.model

@@ -169,18 +169,28 @@ class Transformer(nn.Module):
         self.middle_layer = TransformerBlock(work, config, False) if n % 2 == 1 else None
         self.decoder_layers = nn.ModuleList(TransformerBlock(work, config, True) for _ in range(n // 2))
 
+    def blocks_in_order(self):
+        return list(self.encoder_layers) + ([self.middle_layer] if self.middle_layer is not None else []) + list(self.decoder_layers)
+
     def forward(self, x, condition=None, relative_positions=None):
         if isinstance(self.input_proj, nn.Linear):
             x = ops.linear(x, self.input_proj.weight, self.input_proj.bias)
         skips = []
+        left = len(self.blocks_in_order())          # a cut point (staged backward, trainer.TrainStep) after every block but the last
         for blk in self.encoder_layers:
             x = blk(x, condition=condition, relative_positions=relative_positions)
+            left -= 1
+            x = ops.cut(x) if left else x
             skips.append(x)
         if self.middle_layer is not None:
             x = self.middle_layer(x, condition=condition, relative_positions=relative_positions)
+            left -= 1
+            x = ops.cut(x) if left else x
         for blk in self.decoder_layers:
             s = skips.pop() if self.use_long_range_skip else None
             x = blk(x, condition=condition, relative_positions=relative_positions, skip=s)
+            left -= 1
+            x = ops.cut(x) if left else x
         if isinstance(self.output_proj, nn.Linear):
             x = ops.linear(x, self.output_proj.weight, self.output_proj.bias)
         return x

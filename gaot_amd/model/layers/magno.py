@@ -130,13 +130,15 @@ class _MAGNOBase(nn.Module):
             self._coord_enc_cache[key] = hit
         return hit[1]
 
-    def _transform(self, src_coord, dst_coord, feats, neighbors, stats=None, head=None, lift=None):
+    def _transform(self, src_coord, dst_coord, feats, neighbors, stats=None, head=None, lift=None, drop=True):
         """AGNO (+ geoembed + recovery) for ONE geometry at ONE scale.  feats [B, n_src, C] -> [B, n_dst, C].
         `head` = (W [out, C], b [out]) of a following point-wise linear layer (the decoder's projection): recovery and
         head are both linear with nothing in between, so they are applied as ONE map
             agno @ (W Wr1)^T + (rowb @ W^T + b)
         and the [B, n_dst, C] recovery output (33.5 MB at 16k nodes x 8) is never produced."""
-        nb = apply_edge_drop_csr(neighbors, self.sampling_strategy, self.max_neighbors, self.sample_ratio, self.training)
+        nb = neighbors
+        if drop:
+            nb = apply_edge_drop_csr(neighbors, self.sampling_strategy, self.max_neighbors, self.sample_ratio, self.training)
         proj = rowb = w_agno = None
         if self.use_geoembed:
             w = self.recovery.fcs[0].weight.squeeze(-1)                                             # [C, 2C]
@@ -146,7 +148,7 @@ class _MAGNOBase(nn.Module):
             if not torch.is_grad_enabled() and nb is neighbors:
                 # inference (autoregressive rollouts): geometry and weights are fixed across steps -> keep the row bias
                 key = (id(nb), tuple(p._version for p in self.geoembed.parameters()), self.recovery.fcs[0].weight._version,
-                       self.recovery.fcs[0].bias._version)
+                       self.recovery.fcs[0].bias._version, ops.weights_generation())
                 hit = self._infer_cache.get("rowb")
                 if hit is not None and hit[0] == key and hit[1] is nb:
                     rowb = hit[2]
@@ -199,16 +201,21 @@ class _MAGNOBase(nn.Module):
                 B = feats.shape[0]
                 srcs = [src[b] if src.ndim == 3 else src for b in range(B)]
                 dsts = [dst[b] if dst.ndim == 3 else dst for b in range(B)]
-                mg = merged_geometry([nbrs[b][si] for b in range(B)], srcs, dsts, parents=(src, dst))
+                parts = [nbrs[b][si] for b in range(B)]
+                if self.training and self.sampling_strategy is not None:
+                    # neighbour sub-sampling is drawn PER SAMPLE (magno.py:372-378), and the geometry statistics of the dropped
+                    # graph are standardised per sample (gemb.py:164-169): drop first, then merge the dropped graphs
+                    parts = [apply_edge_drop_csr(nb_, self.sampling_strategy, self.max_neighbors, self.sample_ratio, True) for nb_ in parts]
+                mg = merged_geometry(parts, srcs, dsts, parents=(src, dst))
                 n_dst = mg.n_dst_each[0]
                 if any(n != n_dst for n in mg.n_dst_each) or any(n != feats.shape[1] for n in mg.n_src_each):
                     raise ValueError("vx mode needs the same number of source / query points in every sample of a batch")
                 stats = mg.geo_stats() if (self.use_geoembed and self.geoembed.method == 'statistical') else None
                 flat = feats.reshape(1, B * feats.shape[1], feats.shape[2])
                 if lift is not None:
-                    out = self._transform(mg.src, mg.dst, None, mg.neighbors, stats, head=head, lift=(flat, lift[1], lift[2]))
+                    out = self._transform(mg.src, mg.dst, None, mg.neighbors, stats, head=head, lift=(flat, lift[1], lift[2]), drop=False)
                 else:
-                    out = self._transform(mg.src, mg.dst, flat, mg.neighbors, stats, head=head)
+                    out = self._transform(mg.src, mg.dst, flat, mg.neighbors, stats, head=head, drop=False)
                 per_scale.append(out.reshape(B, n_dst, out.shape[-1]))
         return per_scale
 

@@ -46,6 +46,38 @@ def _rowmajor(t: torch.Tensor) -> Tuple[torch.Tensor, int]:
 
 
 # --------------------------------------------------------------------------------------------
+# weights generation: kernels that update parameters through raw pointers (trainer.FlatAdamW, its hipGraph replay) do not
+# move Parameter._version, so every cache of weight-derived values (AGNO kernel values, geoembed row bias, rollout graphs)
+# keys on (Parameter._version..., weights_generation()).
+# --------------------------------------------------------------------------------------------
+_WEIGHTS_GEN = [0]
+
+
+def weights_generation() -> int:
+    return _WEIGHTS_GEN[0]
+
+
+def bump_weights_generation() -> None:
+    _WEIGHTS_GEN[0] += 1
+
+
+# --------------------------------------------------------------------------------------------
+# cut points of a staged backward (trainer.TrainStep with > 1 rank): the model calls cut(t) where the backward pass may be
+# split; without a hook it is the identity.
+# --------------------------------------------------------------------------------------------
+_CUT_HOOK = [None]
+
+
+def set_cut_hook(fn) -> None:
+    _CUT_HOOK[0] = fn
+
+
+def cut(t: torch.Tensor) -> torch.Tensor:
+    fn = _CUT_HOOK[0]
+    return t if fn is None else fn(t)
+
+
+# --------------------------------------------------------------------------------------------
 # raw calls
 # --------------------------------------------------------------------------------------------
 def gemm(M: int, N: int, K: int, A, lda, a_kmajor, B, ldb, b_kmajor, out, ldc, *, bias=None, rowbias=None,
@@ -71,6 +103,19 @@ if _GEMM_MODE != 4:
     L.load().gaot_debug_set_gemm_glds(_GEMM_MODE)
 if os.environ.get("GAOT_ATTN_SPLIT", "1") != "1":          # A/B switch: argument of gaot_debug_set_attention_split (0 = fp32 MFMA)
     L.load().gaot_debug_set_attention_split(int(os.environ["GAOT_ATTN_SPLIT"]))
+
+
+def set_gemm_mode(mode: int) -> int:
+    """runtime form of GAOT_GEMM_MODE (tests / A-B runs): returns the previous mode"""
+    global _GEMM_MODE
+    old, _GEMM_MODE = _GEMM_MODE, int(mode)
+    L.load().gaot_debug_set_gemm_glds(int(mode))
+    return old
+
+
+def set_attention_split(mode: int) -> int:
+    """runtime form of GAOT_ATTN_SPLIT: 1 = split-bf16 attention kernels for head_dim 32 (default), 0 = fp32-MFMA kernels"""
+    return int(L.load().gaot_debug_set_attention_split(int(mode)))
 
 
 def _split_for_reduction(Mo: int, No: int, K: int) -> int:

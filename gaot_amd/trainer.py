@@ -8,6 +8,12 @@ gradients live in ONE flat fp32 buffer (param.grad are views), so the exchange i
 (13.6 MB at the example config) per step; parameters are broadcast from rank 0 at start (the reference seeds
 with seed+rank and never synchronises).  With static shapes the forward+backward and the optimizer update are
 captured as hipGraphs (geometry-only work is cached in GeometryPlans and stays outside the graph).
+
+With more than one rank the backward pass is STAGED: the model marks cut points (`ops.cut`, after the encoder
+and between transformer blocks) and lists its parameters in backward-completion order (`backward_phases()`: decoder +
+last block first, encoder last).  The flat gradient buffer is laid out in that order, one contiguous slice per phase;
+after the backward of phase k has been enqueued its slice is all-reduced asynchronously (RCCL runs it on its own stream)
+while the main stream already runs the backward of phase k+1 -- one captured hipGraph per phase, nothing waits on the host.
 """
 from typing import Dict, List, Optional
 
@@ -20,45 +26,70 @@ def shard_indices(n_samples: int, rank: int, world: int, epoch: int = 0, shuffle
     g = torch.Generator().manual_seed(seed + epoch)
     order = torch.randperm(n_samples, generator=g).tolist() if shuffle else list(range(n_samples))
     total = ((n_samples + world - 1) // world) * world
-    order += order[: total - n_samples]
+    if n_samples > 0 and total > n_samples:      # repeat the list as often as needed (world > n_samples): no rank stays empty
+        order = (order * (-(-total // n_samples)))[:total]
     return order[rank:total:world]
 
 
 class FlatGradBucket:
-    """All gradients in one contiguous fp32 buffer (one RCCL all-reduce per step, one fused optimizer pass).
+    """All gradients in one contiguous fp32 buffer (RCCL all-reduce payload, one fused optimizer pass).
 
     Autograd is left to hand over freshly produced gradient tensors (param.grad is None before backward, so
     AccumulateGrad steals instead of launching one add per parameter); `pack()` then gathers them with ONE
-    multi-tensor copy and re-points param.grad at views of the flat buffer for the all-reduce / optimizer."""
+    multi-tensor copy and re-points param.grad at views of the flat buffer for the all-reduce / optimizer.
+
+    `phases` (optional): lists of parameters in backward-COMPLETION order.  The buffer is laid out phase by phase
+    (`segments[k]` = the contiguous slice of phase k), so a phase's gradients can be reduced while later phases of the
+    backward pass are still running."""
 
     ALIGN = 64      # floats: every parameter (or fused group) starts on a 256-byte boundary -> 16-byte vector kernels apply
 
-    def __init__(self, params: List[torch.nn.Parameter], groups: Optional[List[List[torch.nn.Parameter]]] = None):
+    def __init__(self, params: List[torch.nn.Parameter], groups: Optional[List[List[torch.nn.Parameter]]] = None,
+                 phases: Optional[List[List[torch.nn.Parameter]]] = None):
         """`groups`: lists of parameters that must sit back to back (in the given order, no padding) so that a fused
         GEMM can read them as ONE matrix (q|k|v, w1|w3: ops.adjacent_rows) instead of concatenating every step."""
         params = [p for p in params if p.requires_grad]
         self.model_order = list(params)           # the order torch optimizers index parameters by (checkpoint compatibility)
         pos = {id(p): i for i, p in enumerate(params)}
+        phase_of = {}
+        for k, ph in enumerate(phases or []):
+            for p in ph:
+                if id(p) in pos:
+                    phase_of[id(p)] = k
+        n_ph = (max(phase_of.values()) + 1) if phase_of else 1
+        for p in params:                          # parameters the model did not list complete with the LAST phase
+            phase_of.setdefault(id(p), n_ph - 1)
         follow, skip = {}, set()
         for g in groups or []:
-            if len(g) > 1 and all(id(p) in pos for p in g) and not any(id(p) in skip or id(p) in follow for p in g):
+            if (len(g) > 1 and all(id(p) in pos for p in g) and not any(id(p) in skip or id(p) in follow for p in g)
+                    and len({phase_of[id(p)] for p in g}) == 1):
                 follow[id(g[0])] = list(g[1:])
                 skip.update(id(p) for p in g[1:])
-        self.params, self.offsets = [], []
+        self.params, self.offsets, self.phase, self.segments = [], [], [], []
         off = 0
-        for p in params:
-            if id(p) in skip:
-                continue
+        for k in range(n_ph):
             off = -(-off // self.ALIGN) * self.ALIGN
-            for q in [p] + follow.get(id(p), []):
-                self.params.append(q)
-                self.offsets.append(off)
-                off += q.numel()
+            start = off
+            for p in params:
+                if id(p) in skip or phase_of[id(p)] != k:
+                    continue
+                off = -(-off // self.ALIGN) * self.ALIGN
+                for q in [p] + follow.get(id(p), []):
+                    self.params.append(q)
+                    self.offsets.append(off)
+                    self.phase.append(k)
+                    off += q.numel()
+            self.segments.append((start, off))
         self.numel = -(-off // 4) * 4
+        self.segments[-1] = (self.segments[-1][0], self.numel)
         ref = self.params[0]
         self.flat = torch.zeros(self.numel, dtype=ref.dtype, device=ref.device)
         self.views = [self.flat[o:o + p.numel()].view_as(p) for p, o in zip(self.params, self.offsets)]
         self._dirty = [False] * len(self.params)      # view holds a gradient from an earlier step
+
+    @property
+    def n_phases(self) -> int:
+        return len(self.segments)
 
     def clear(self):
         for p in self.params:
@@ -69,9 +100,12 @@ class FlatGradBucket:
                 ops.register_grad_slots(self.params, self.views)
             ops.release_grad_slots()
 
-    def pack(self):
+    def pack(self, phase: Optional[int] = None):
+        """gather the gradients (of one backward phase, or of all) into their views of the flat buffer"""
         srcs, dsts = [], []
         for i, (p, v) in enumerate(zip(self.params, self.views)):
+            if phase is not None and self.phase[i] != phase:
+                continue
             if p.grad is None:
                 if self._dirty[i]:      # a parameter that got no gradient this step: zero (once; the buffer starts zeroed)
                     v.zero_()
@@ -81,30 +115,54 @@ class FlatGradBucket:
                 if p.grad.data_ptr() != v.data_ptr():
                     srcs.append(p.grad)
                     dsts.append(v)
+            p.grad = v
         if srcs:
             torch._foreach_copy_(dsts, srcs)
-        for p, v in zip(self.params, self.views):
-            p.grad = v
 
-    def all_reduce_mean(self, group=None):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            if dist.get_backend(group) == "nccl":       # RCCL averages in the collective: no separate scaling pass
-                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=group)
-            else:
-                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-                self.flat.div_(dist.get_world_size(group))
+    def all_reduce_mean(self, group=None, phase: Optional[int] = None, async_op: bool = False, _force: bool = False):
+        """mean over ranks of the whole buffer or of one phase's slice; with async_op returns a handle with .wait()
+        (`_force`: issue the collective even in a one-rank group -- tests of the RCCL branch on one-GPU boxes)"""
+        if not (dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or _force)):
+            return None
+        buf = self.flat if phase is None else self.flat[self.segments[phase][0]:self.segments[phase][1]]
+        if buf.numel() == 0:
+            return None
+        if dist.get_backend(group) == "nccl":       # RCCL averages in the collective: no separate scaling pass
+            work = dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=group, async_op=async_op)
+            return work if async_op else None
+        world = dist.get_world_size(group)
+        work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        if not async_op:
+            buf.div_(world)
+            return None
+        return _ScaledWork(work, buf, world)
 
 
-class FlatAdamW:
+class _ScaledWork:
+    """async SUM all-reduce + the division that turns it into a mean (backends without ReduceOp.AVG: gloo)"""
+
+    def __init__(self, work, buf, world):
+        self.work, self.buf, self.world = work, buf, world
+
+    def wait(self):
+        self.work.wait()
+        self.buf.div_(self.world)
+
+
+class FlatAdamW(torch.optim.Optimizer):
     """torch.optim.AdamW semantics (reference optimizers.py:196) as ONE HIP kernel over flat buffers.
 
     The parameters are re-pointed at views of one flat fp32 buffer (values, names and state_dict are unchanged), the
     gradients already live in the FlatGradBucket, the moments are flat: an update is a single streaming pass
-    (7 x 4 B per parameter) instead of torch's multi-tensor launches over ~60 tensors."""
+    (7 x 4 B per parameter) instead of torch's multi-tensor launches over ~60 tensors.
+
+    It IS a torch.optim.Optimizer with one param_group, so the reference's LR schedulers (optimizers.py:199-245) attach to
+    it unchanged; lr / betas / eps / weight_decay are read by the kernel from a 5-float DEVICE buffer that `step()` refreshes
+    from `param_groups[0]` whenever they changed -- a captured (hipGraph) update follows the schedule without re-capture."""
 
     def __init__(self, bucket: "FlatGradBucket", lr: float, weight_decay: float, betas=(0.9, 0.999), eps: float = 1e-8):
         self.bucket = bucket
-        self.lr, self.wd, self.betas, self.eps = float(lr), float(weight_decay), betas, float(eps)
+        super().__init__(bucket.model_order, dict(lr=float(lr), betas=tuple(betas), eps=float(eps), weight_decay=float(weight_decay)))
         ps = bucket.params
         with torch.no_grad():       # same layout as the gradient bucket (aligned starts, fused groups back to back)
             self.flat_p = torch.zeros_like(bucket.flat)
@@ -115,6 +173,29 @@ class FlatAdamW:
         self.m = torch.zeros_like(self.flat_p)
         self.v = torch.zeros_like(self.flat_p)
         self.step_count = torch.zeros(1, dtype=torch.float32, device=self.flat_p.device)
+        self.hyper = torch.zeros(5, dtype=torch.float32, device=self.flat_p.device)
+        self._hyper_host = None
+        self.sync_hyper()
+
+    # ---- hyper-parameters live in param_groups[0] (what schedulers write) and are mirrored to the device buffer
+    def _g(self):
+        return self.param_groups[0]
+
+    lr = property(lambda self: float(self._g()["lr"]), lambda self, v: self._g().__setitem__("lr", float(v)))
+    wd = property(lambda self: float(self._g()["weight_decay"]), lambda self, v: self._g().__setitem__("weight_decay", float(v)))
+    eps = property(lambda self: float(self._g()["eps"]), lambda self, v: self._g().__setitem__("eps", float(v)))
+    betas = property(lambda self: tuple(self._g()["betas"]), lambda self, v: self._g().__setitem__("betas", tuple(v)))
+
+    def set_lr(self, lr: float):
+        self.lr = lr
+
+    def sync_hyper(self):
+        """upload {lr, beta1, beta2, eps, weight_decay} if they changed since the last upload (NOT capturable: call before replay)"""
+        g = self._g()
+        cur = (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]))
+        if cur != self._hyper_host:
+            self.hyper.copy_(torch.tensor(cur, dtype=torch.float32), non_blocking=False)
+            self._hyper_host = cur
 
     # ---- checkpoint compatibility with torch.optim.AdamW (what the reference's save_ckpt / load_ckpt move around,
     # trainer_utils.py:23-92 with optimizers.py:196): same state_dict layout, parameters indexed in model order
@@ -127,6 +208,9 @@ class FlatAdamW:
         ref = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=self.lr, betas=self.betas, eps=self.eps,
                                 weight_decay=self.wd)
         group = dict(ref.param_groups[0])          # every key this torch version expects, with AdamW's defaults
+        for k, v in self._g().items():             # scheduler bookkeeping (initial_lr, ...) travels with the group
+            if k != "params" and k not in ("lr", "betas", "eps", "weight_decay"):
+                group.setdefault(k, v)
         group["params"] = list(range(len(order)))
         step = float(self.step_count.item())
         state = {}
@@ -142,6 +226,8 @@ class FlatAdamW:
         g = groups[0]
         self.lr, self.wd, self.eps = float(g["lr"]), float(g["weight_decay"]), float(g["eps"])
         self.betas = tuple(float(b) for b in g["betas"])
+        if "initial_lr" in g:
+            self._g()["initial_lr"] = g["initial_lr"]
         steps = {float(st["step"]) for st in sd["state"].values()}
         if len(steps) > 1:
             raise ValueError("FlatAdamW.load_state_dict: per-parameter step counts differ; the flat update has one counter")
@@ -152,13 +238,20 @@ class FlatAdamW:
                 if st is not None:
                     m.copy_(st["exp_avg"]); v.copy_(st["exp_avg_sq"])
             self.step_count.fill_(steps.pop() if steps else 0.0)
+        self.sync_hyper()
 
-    def step(self):
+    def zero_grad(self, set_to_none: bool = True):
+        self.bucket.clear()
+
+    def step(self, closure=None, _sync: bool = True):
         from . import _lib as L
+        from . import ops
         from .ops import _p, _stream
-        L.check(L.load().gaot_adamw_step(_p(self.flat_p), _p(self.bucket.flat), _p(self.m), _p(self.v), self.flat_p.numel(),
-                                         self.lr, self.betas[0], self.betas[1], self.eps, self.wd, _p(self.step_count), _stream()),
-                "gaot_adamw_step")
+        if _sync:
+            self.sync_hyper()
+        L.check(L.load().gaot_adamw_step_dev(_p(self.flat_p), _p(self.bucket.flat), _p(self.m), _p(self.v), self.flat_p.numel(),
+                                             _p(self.hyper), _p(self.step_count), _stream()), "gaot_adamw_step_dev")
+        ops.bump_weights_generation()      # the kernel writes through raw pointers: Parameter._version does not move
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None):
@@ -173,48 +266,129 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None):
             off += p.numel()
 
 
+class _Cuts:
+    """cut points of a staged backward: `ops.cut(t)` hands the model a detached leaf and remembers (t, leaf); the trainer
+    later continues with t.backward(leaf.grad), one phase at a time, newest cut first."""
+
+    def __init__(self):
+        self.pairs = []
+
+    def __call__(self, t: torch.Tensor) -> torch.Tensor:
+        if not (torch.is_grad_enabled() and t.requires_grad):
+            return t
+        leaf = t.detach().requires_grad_(True)
+        self.pairs.append((t, leaf))
+        return leaf
+
+
 class TrainStep:
     """One reference-trainer step on fixed shapes.  `static` holds everything forward() needs except pndata."""
 
     def __init__(self, model: torch.nn.Module, lr: float = 8e-4, weight_decay: float = 1e-5, use_graph: bool = True,
-                 group=None):
+                 group=None, staged: Optional[bool] = None):
+        """`staged`: split the backward at the model's cut points and reduce each phase's gradient slice while the next phase
+        runs (default: whenever there is more than one rank and the model offers `backward_phases()`)."""
         self.model = model
         self.group = group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         broadcast_parameters(model, 0, group)
         groups = [g for m in model.modules() if hasattr(m, "fused_weight_groups") for g in m.fused_weight_groups()]
-        self.bucket = FlatGradBucket(list(model.parameters()), groups)
+        phases = model.backward_phases() if hasattr(model, "backward_phases") else None
+        if staged is None:
+            staged = self.world > 1
+        self.staged = bool(staged and phases is not None and len(phases) > 1)
+        self.bucket = FlatGradBucket(list(model.parameters()), groups, phases if self.staged else None)
         dev = self.bucket.flat.device
         on_gpu = dev.type == "cuda"
         if on_gpu:
             self.opt = FlatAdamW(self.bucket, lr=lr, weight_decay=weight_decay)
-        else:           # CPU (gloo tests of the data-parallel plumbing): torch's own AdamW
-            self.opt = torch.optim.AdamW(self.bucket.params, lr=lr, weight_decay=weight_decay)
-        self.use_graph = use_graph and on_gpu
-        self._g_fb: Optional[torch.cuda.CUDAGraph] = None
+        else:           # CPU (gloo tests of the data-parallel plumbing): torch's own AdamW, parameters in MODEL order
+            self.opt = torch.optim.AdamW(self.bucket.model_order, lr=lr, weight_decay=weight_decay)
+        # per-step random neighbour sub-sampling (MAGNOConfig.sampling_strategy) draws masks and syncs: not capturable
+        sampling = any(getattr(m, "sampling_strategy", None) is not None for m in model.modules())
+        self.use_graph = use_graph and on_gpu and not sampling
+        self._graphs: Optional[List[torch.cuda.CUDAGraph]] = None
         self._g_opt: Optional[torch.cuda.CUDAGraph] = None
         self._x = self._y = self._loss = None
         self._kwargs: Dict = {}
+        self._cuts: Optional[_Cuts] = None
+        self._checked_phases = False
 
     # ---- the eager pieces
-    def _forward_backward(self):
+    def _forward_loss(self):
         self.bucket.clear()
         pred = self.model(pndata=self._x, **self._kwargs)
         if pred.is_cuda:
             from . import ops
-            loss = ops.mse_loss(pred, self._y)
-        else:           # CPU: gloo tests of the data-parallel plumbing
-            loss = torch.nn.functional.mse_loss(pred, self._y)
+            return ops.mse_loss(pred, self._y)
+        return torch.nn.functional.mse_loss(pred, self._y)          # CPU: gloo tests of the data-parallel plumbing
+
+    def _forward_backward(self):
+        """unstaged: forward, loss, the whole backward, gradients packed"""
+        loss = self._forward_loss()
         loss.backward()
         self.bucket.pack()
         return loss.detach()
+
+    def _phase0(self):
+        """staged: forward with cut points + the backward of phase 0 (everything after the last cut)"""
+        from . import ops
+        self._cuts = _Cuts()
+        ops.set_cut_hook(self._cuts)
+        try:
+            loss = self._forward_loss()
+        finally:
+            ops.set_cut_hook(None)
+        if len(self._cuts.pairs) != self.bucket.n_phases - 1:
+            raise RuntimeError(f"model marked {len(self._cuts.pairs)} cut points but lists {self.bucket.n_phases} backward phases")
+        loss.backward()
+        self._check_phase(0)
+        self.bucket.pack(0)
+        return loss.detach()
+
+    def _phase(self, k: int):
+        t, leaf = self._cuts.pairs[-k]
+        if leaf.grad is None:
+            raise RuntimeError(f"cut point {len(self._cuts.pairs) - k} received no gradient")
+        t.backward(leaf.grad)
+        self._check_phase(k)
+        self.bucket.pack(k)
+        if k == self.bucket.n_phases - 1:
+            self._cuts = None
+
+    def _check_phase(self, k: int):
+        """first eager pass only: after phase k no parameter of a LATER phase may hold a gradient yet (the slices reduced
+        so far are final) -- guards a model whose backward_phases() and cut points disagree"""
+        if self._checked_phases:
+            return
+        for p, ph in zip(self.bucket.params, self.bucket.phase):
+            if ph > k and p.grad is not None:
+                raise RuntimeError("backward_phases() disagrees with the cut points: a later-phase parameter already has a gradient")
+        if k == self.bucket.n_phases - 1:
+            self._checked_phases = True
+
+    def _eager_step(self):
+        if not self.staged:
+            loss = self._forward_backward()
+            self.bucket.all_reduce_mean(self.group)
+        else:
+            loss = self._phase0()
+            works = [self.bucket.all_reduce_mean(self.group, 0, async_op=True)]
+            for k in range(1, self.bucket.n_phases):
+                self._phase(k)
+                works.append(self.bucket.all_reduce_mean(self.group, k, async_op=True))
+            for w in works:
+                if w is not None:
+                    w.wait()
+        self.opt.step()
+        return loss
 
     def bind(self, pndata: torch.Tensor, target: torch.Tensor, **forward_kwargs):
         """Fix the static buffers (shapes) of the step; later `step()` calls copy new data into them."""
         self._x = pndata.clone()
         self._y = target.clone()
         self._kwargs = forward_kwargs
-        self._g_fb = self._g_opt = None
+        self._graphs = self._g_opt = None
 
     def _capture(self):
         # warm-up iterations must not advance training: snapshot weights + optimizer state, restore after capture
@@ -223,18 +397,24 @@ class TrainStep:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):          # warm-up: builds GeometryPlans (they sync once), fills the allocator
             for _ in range(2):
-                self._forward_backward()
-                self.bucket.all_reduce_mean(self.group)
-                self.opt.step()
+                self._eager_step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self._g_fb = torch.cuda.CUDAGraph()
         # thread_local: the RCCL watchdog thread's event queries must not invalidate the capture
-        with torch.cuda.graph(self._g_fb, capture_error_mode="thread_local"):
-            self._loss = self._forward_backward()
+        pool = torch.cuda.graph_pool_handle()
+        self._graphs = []
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+            self._loss = self._phase0() if self.staged else self._forward_backward()
+        self._graphs.append(g)
+        for k in range(1, self.bucket.n_phases if self.staged else 1):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                self._phase(k)
+            self._graphs.append(g)
         self._g_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_opt, capture_error_mode="thread_local"):
-            self.opt.step()
+        with torch.cuda.graph(self._g_opt, pool=pool, capture_error_mode="thread_local"):
+            self.opt.step(_sync=False)
         for dst, src in zip((self.opt.flat_p, self.opt.m, self.opt.v, self.opt.step_count), snap):
             dst.copy_(src)
 
@@ -243,14 +423,25 @@ class TrainStep:
             self._x.copy_(pndata, non_blocking=True)
         if target is not None:
             self._y.copy_(target, non_blocking=True)
-        if self.use_graph:
-            if self._g_fb is None:
-                self._capture()
-            self._g_fb.replay()
+        if not self.use_graph:
+            return self._eager_step()
+        if self._graphs is None:
+            self._capture()
+        self.opt.sync_hyper()                    # a scheduler may have moved lr since the last step (device buffer, no re-capture)
+        if not self.staged:
+            self._graphs[0].replay()
             self.bucket.all_reduce_mean(self.group)      # one flat RCCL all-reduce between the two graphs
-            self._g_opt.replay()
-            return self._loss
-        loss = self._forward_backward()
-        self.bucket.all_reduce_mean(self.group)
-        self.opt.step()
-        return loss
+        else:
+            # everything below is enqueued without a host wait: phase k's slice is reduced on RCCL's stream while the main
+            # stream replays the backward of phase k+1
+            works = []
+            for k, g in enumerate(self._graphs):
+                g.replay()
+                works.append(self.bucket.all_reduce_mean(self.group, k, async_op=True))
+            for w in works:
+                if w is not None:
+                    w.wait()
+        self._g_opt.replay()
+        from . import ops
+        ops.bump_weights_generation()
+        return self._loss

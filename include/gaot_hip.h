@@ -246,6 +246,10 @@ int gaot_mse_loss_bwd(const float* pred, const float* target, int64_t n, const f
  * replays inside a hipGraph. */
 int gaot_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                     float eps, float weight_decay, float* step, gaot_stream_t stream);
+/* Same update with the hyper-parameters read from DEVICE memory at run time: hyper[5] = {lr, beta1, beta2, eps, weight_decay}.
+ * A captured launch therefore follows the reference's per-epoch LR schedulers (optimizers.py:199-245) without re-capture. */
+int gaot_adamw_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, float* step,
+                        gaot_stream_t stream);
 /* patchify gaot.py:182-185,202-205 and its inverse gaot.py:224-231.  Latent grid H x W (x Dz; Dz = 0 for 2-D).
  * inverse = 0: in = grid[b, (h,w[,z]), c]  -> out = tokens[b, s, (p..., c)];  inverse = 1: the other way. */
 int gaot_patchify(const float* in, int32_t B, int32_t H, int32_t W, int32_t Dz, int32_t P, int32_t C,

@@ -68,6 +68,10 @@ class OracleConfig:
     use_conditional_norm: bool = False
     # model
     latent_tokens_size: List[int] = field(default_factory=lambda: [64, 64])
+    # test instrument, not a reference option: evaluate the geometry statistics (gemb.py:103-171) in this dtype before the
+    # embedding MLP.  "float64" separates the CONDITIONING of a result w.r.t. the reference's fp32 rounding of those
+    # statistics (ReLU gates of geoembed.mlp.0 sit right behind them) from an implementation error.
+    stats_dtype: str = "float32"
 
 
 def as_csr(n) -> CSR:
@@ -81,11 +85,21 @@ def as_csr(n) -> CSR:
 # radius graph -- restates _native_neighbor_search (neighbor_search.py:108-146):
 # inclusive `dist <= r`, unbounded degree, neighbours in ascending data index.
 # --------------------------------------------------------------------------------------
-def radius_csr(data: Tensor, queries: Tensor, radius: float, chunk: int = 4096) -> CSR:
+def radius_csr(data: Tensor, queries: Tensor, radius: float, chunk: int = 4096, exact: bool = False) -> CSR:
+    """exact=False: the `native` backend's test, torch.cdist(...) <= r (neighbor_search.py:108-146; cdist expands
+    |q|^2 + |d|^2 - 2 q.d for large inputs, so pairs within ~1e-6 of r can fall either side).
+    exact=True: the distance test of the `grid` backend -- what method='auto' resolves to without torch_cluster --
+    torch.norm(query - data[j]) <= r on explicit differences (neighbor_search.py:250-253); neighbours are returned in
+    ascending data index here (the grid backend lists them cell by cell: same sets, different order inside a row)."""
     r = torch.tensor(radius, dtype=queries.dtype)
     cols, counts = [], []
+    if exact:
+        chunk = max(1, min(chunk, (32 << 20) // max(1, data.shape[0] * data.shape[1])))
     for s in range(0, queries.shape[0], chunk):
-        d = torch.cdist(queries[s:s + chunk], data)
+        if exact:
+            d = torch.linalg.vector_norm(queries[s:s + chunk, None, :] - data[None, :, :], dim=-1)
+        else:
+            d = torch.cdist(queries[s:s + chunk], data)
         hit = d <= r
         cols.append(hit.nonzero()[:, 1])
         counts.append(hit.sum(dim=1))
@@ -251,7 +265,10 @@ def geo_stats(geom: Tensor, queries: Tensor, nbrs: CSR) -> Tensor:
 def geoembed(sd, prefix: str, cfg: OracleConfig, geom: Tensor, queries: Tensor, nbrs: CSR,
              rec: Optional[dict] = None, tag: str = "") -> Tensor:
     if cfg.embedding_method == "statistical":                      # gemb.py:54-59,230-233
-        st = geo_stats(geom, queries, nbrs)
+        if cfg.stats_dtype == "float64":
+            st = geo_stats(geom.double(), queries.double(), nbrs).to(geom.dtype)
+        else:
+            st = geo_stats(geom, queries, nbrs)
         if rec is not None:
             rec[f"{tag}geo_stats"] = st.detach()
         h = torch.relu(st @ sd[f"{prefix}.mlp.0.weight"].t() + sd[f"{prefix}.mlp.0.bias"])
@@ -526,9 +543,9 @@ def adamw_update(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: floa
 
 
 def train_step(sd: Dict[str, Tensor], cfg: OracleConfig, batch: dict, lr: float = 8e-4,
-               weight_decay: float = 1e-5, state: Optional[dict] = None):
+               weight_decay: float = 1e-5, state: Optional[dict] = None, return_pred: bool = False):
     """One step: zero_grad -> forward -> MSE(mean) -> backward -> AdamW.
-    Returns (loss, grads, new_sd, state)."""
+    Returns (loss, grads, new_sd, state) (+ the prediction when return_pred)."""
     params = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
     pred = gaot_forward(params, cfg, batch["latent"], batch["xcoord"], batch["pndata"],
                         batch.get("query_coord"), batch.get("encoder_nbrs"), batch.get("decoder_nbrs"),
@@ -545,6 +562,8 @@ def train_step(sd: Dict[str, Tensor], cfg: OracleConfig, batch: dict, lr: float 
     for k in names:
         p, m, v = adamw_update(sd[k].detach(), grads[k], state["m"][k], state["v"][k], state["step"], lr, weight_decay)
         new_sd[k], state["m"][k], state["v"][k] = p, m, v
+    if return_pred:
+        return loss.detach(), grads, new_sd, state, pred.detach()
     return loss.detach(), grads, new_sd, state
 
 

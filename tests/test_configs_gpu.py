@@ -1,0 +1,431 @@
+"""-m gpu: every BASELINE.json configuration as a workload, HIP path vs the CPU oracle on identical weights and inputs.
+
+  C2  the bench configuration itself: 16 384 uniform nodes, batch 8, radius 0.033, the reference's example model
+      (forward rel-L2, loss, every gradient per tensor, post-AdamW weights; default kernels and the fp32-only kernel modes)
+  C3  NACA0012-shaped degree-skewed meshes, vx mode (a different mesh per sample), 3 input channels, max encoder degree
+      > 256 next to thousands of empty latent rows; also with training-time neighbour sub-sampling on
+  C1  1 024-node meshes, batch 4: 43 % of the latent tokens have no neighbour
+  C5  3-D surface cloud, 32^3 latent grid = 4 096 tokens of width 384, head_dim 48
+  C4  is covered by test_model_gpu.py (rollout goldens) and test_train_eval_train_eval below.
+
+Tolerances (north_star: <= 1e-5 relative output error, fp32): output rel-L2 <= 1e-5, loss <= 1e-5 relative, every gradient
+tensor rel-L2 <= 1e-4 (denominator floored at 1e-3 of the largest gradient norm of the model: a tensor whose true gradient
+is zero up to rounding -- e.g. the key bias under a softmax -- is compared absolutely, at 1e-7 of the model's gradient scale).
+Radius graphs: the oracle's `exact=True` search (explicit differences, the reference's `grid` backend = method 'auto') is the
+graph the HIP cell list must reproduce bit for bit; the cdist-based `native` backend differs from it only in pairs within
+rounding of the radius (checked below), so numeric parity is always taken on ONE graph.
+"""
+from types import SimpleNamespace as NS
+
+import pytest
+import torch
+
+from tests._golden import rel_l2
+from tests._workloads import grid, naca_points, shell_points, uniform_points
+
+pytestmark = pytest.mark.gpu
+
+OUT_TOL, LOSS_TOL, GRAD_TOL = 1e-5, 1e-5, 1e-4
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def make_model(cin, cout, lat_sizes, d=2, C=64, hidden=256, heads=8, radius=0.033, P=2, precompute=True, seed=0, **magno_kw):
+    from gaot_amd.model.gaot import GAOT
+    from gaot_amd.model.layers.magno import MAGNOConfig
+    from gaot_amd.model.layers.attn import TransformerConfig, AttentionConfig
+    from oracle import gaot_oracle as O
+    torch.manual_seed(seed)
+    mcfg = MAGNOConfig(coord_dim=d, radius=radius, hidden_size=64, mlp_layers=3, lifting_channels=C, precompute_edges=precompute, **magno_kw)
+    tcfg = TransformerConfig(patch_size=P, hidden_size=hidden, attn_config=AttentionConfig(num_heads=heads, num_kv_heads=heads))
+    model = GAOT(cin, cout, NS(args=NS(magno=mcfg, transformer=tcfg), latent_tokens_size=lat_sizes))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    ocfg = O.OracleConfig(coord_dim=d, radius=radius, hidden_size=64, lifting_channels=C, patch_size=P, tf_hidden_size=hidden,
+                          num_heads=heads, num_kv_heads=heads, latent_tokens_size=lat_sizes, precompute_edges=True)
+    return model, sd, ocfg
+
+
+def csr_dict(c):
+    return {"neighbors_index": c[0].to(dev()), "neighbors_row_splits": c[1].to(dev())}
+
+
+def grad_errors(model, grads_ref):
+    """per-tensor rel-L2 of the gradients; the denominator is floored at 1e-3 of the largest reference gradient norm"""
+    top = max(float(g.double().norm()) for g in grads_ref.values())
+    out = {}
+    for k, prm in model.named_parameters():
+        got = prm.grad.detach().cpu().double() if prm.grad is not None else torch.zeros_like(prm).cpu().double()
+        ref = grads_ref[k].double()
+        out[k] = float((got - ref).norm()) / max(float(ref.norm()), 1e-3 * top)
+    return out
+
+
+def check_step(model, oracle_out, fwd_kwargs, p, tgt, what=""):
+    """one eager forward + MSE + backward of the HIP path against (loss, grads, pred) of the oracle"""
+    from gaot_amd import ops
+    loss_ref, grads_ref, pred_ref = oracle_out
+    model.zero_grad(set_to_none=True)
+    pred = model(pndata=p, **fwd_kwargs)
+    loss = ops.mse_loss(pred, tgt)
+    loss.backward()
+    torch.cuda.synchronize()
+    e_out = rel_l2(pred.detach().cpu(), pred_ref)
+    e_loss = abs(float(loss.detach()) - float(loss_ref)) / abs(float(loss_ref))
+    errs = grad_errors(model, grads_ref)
+    worst = max(errs, key=errs.get)
+    print(f"[{what}] out rel-L2 {e_out:.2e}  loss rel {e_loss:.2e}  worst grad rel-L2 {errs[worst]:.2e} ({worst})")
+    assert e_out < OUT_TOL, (what, e_out)
+    assert e_loss < LOSS_TOL, (what, e_loss)
+    assert errs[worst] < GRAD_TOL, (what, worst, errs[worst])
+    return e_out, e_loss, errs[worst]
+
+
+# ------------------------------------------------------------------------------------------------ C2: the bench configuration
+@pytest.fixture(scope="module")
+def c2():
+    """bench.py's own model / data builders (BASELINE configs[1]) + ONE oracle train step on them"""
+    import bench
+    from oracle import gaot_oracle as O
+    torch.manual_seed(0)
+    model = bench.build_model()
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    lat, x, p, t = bench.synthetic(1234, torch.device("cpu"))
+    assert x.shape == (16384, 2) and p.shape == (8, 16384, 1) and lat.shape == (4096, 2)
+    ocfg = O.OracleConfig(radius=bench.RADIUS, hidden_size=64, lifting_channels=bench.C_LIFT, patch_size=bench.PATCH,
+                          tf_hidden_size=bench.HIDDEN, latent_tokens_size=bench.LATENT, precompute_edges=True)
+    enc, dec = [O.radius_csr(x, lat, bench.RADIUS, exact=True)], [O.radius_csr(lat, x, bench.RADIUS, exact=True)]
+    batch = dict(latent=lat, xcoord=x, pndata=p, target=t, encoder_nbrs=enc, decoder_nbrs=dec)
+    loss, grads, new_sd, _, pred = O.train_step(sd, ocfg, batch, lr=8e-4, weight_decay=1e-5, return_pred=True)
+    # the same step with the geometry statistics evaluated in float64 (test instrument, see OracleConfig.stats_dtype)
+    ocfg64 = O.OracleConfig(**{**ocfg.__dict__, "stats_dtype": "float64"})
+    loss64, grads64, new_sd64, _, pred64 = O.train_step(sd, ocfg64, batch, lr=8e-4, weight_decay=1e-5, return_pred=True)
+    return NS(sd=sd, lat=lat, x=x, p=p, t=t, enc=enc, dec=dec, loss=loss, grads=grads, new_sd=new_sd, pred=pred,
+              loss64=loss64, grads64=grads64, new_sd64=new_sd64, pred64=pred64)
+
+
+def _c2_model(c2):
+    import bench
+    m = bench.build_model()
+    m.load_state_dict(c2.sd)
+    return m.to(dev()).train()
+
+
+# gradient tensors right behind the ReLU gates that read the geometry statistics: their value moves by ~2e-4 (relative L2)
+# when the ORACLE ITSELF evaluates those statistics in float64 instead of float32 (16 384 x 64 gates, a few of them within
+# rounding of zero flip) -- the reference's own conditioning.  The HIP path computes the statistics in float64.
+STATS_GATED = ("encoder.geoembed.mlp.0.weight", "encoder.geoembed.mlp.0.bias", "decoder.geoembed.mlp.0.weight", "decoder.geoembed.mlp.0.bias")
+
+
+@pytest.mark.parametrize("mode", ["default", "gemm_fp32_tiles", "attention_fp32"])
+def test_c2_bench_config_forward_loss_grads_vs_oracle(c2, mode):
+    """the bench line's workload, tile heuristics and all: 25 split-bf16 GEMM launches, 256-query attention workgroups,
+    split-K weight gradients -- against the oracle at full size.  The model runs its OWN radius search here (as in bench.py).
+      * vs the oracle with float64 geometry statistics: output, loss and EVERY gradient tensor within the bar;
+      * vs the plain fp32 oracle: output, loss and every gradient tensor within the bar, except the four statistics-gated
+        tensors, which must be within twice the oracle's own fp32-vs-fp64 movement."""
+    from gaot_amd import ops
+    old_g = ops.set_gemm_mode(1) if mode == "gemm_fp32_tiles" else None
+    old_a = ops.set_attention_split(0) if mode == "attention_fp32" else None
+    try:
+        m = _c2_model(c2)
+        kw = dict(latent_tokens_coord=c2.lat.to(dev()), xcoord=c2.x.to(dev()))
+        check_step(m, (c2.loss64, c2.grads64, c2.pred64), kw, c2.p.to(dev()), c2.t.to(dev()), f"C2 {mode} vs oracle(f64 statistics)")
+        e_out = rel_l2(m(pndata=c2.p.to(dev()), **kw).detach().cpu(), c2.pred)
+        errs = grad_errors(m, c2.grads)
+        top = max(float(g.double().norm()) for g in c2.grads.values())
+        own = {k: float((c2.grads[k].double() - c2.grads64[k].double()).norm()) / max(float(c2.grads[k].double().norm()), 1e-3 * top)
+               for k in STATS_GATED}
+        plain = {k: v for k, v in errs.items() if k not in STATS_GATED}
+        worst = max(plain, key=plain.get)
+        print(f"[C2 {mode} vs plain fp32 oracle] out rel-L2 {e_out:.2e}  worst grad rel-L2 {plain[worst]:.2e} ({worst}); statistics-gated: "
+              + ", ".join(f"{k.split('.')[0][:3]}.{k.split('.')[-1][0]} {errs[k]:.1e} (oracle's own {own[k]:.1e})" for k in STATS_GATED))
+        assert e_out < OUT_TOL and plain[worst] < GRAD_TOL, (worst, plain[worst])
+        for k in STATS_GATED:
+            assert errs[k] < max(GRAD_TOL, 2 * own[k]), (k, errs[k], own[k])
+        for cache, want in ((m.encoder.neighbor_cache, c2.enc), (m.decoder.neighbor_cache, c2.dec)):
+            nb = list(cache.values())[0][0]                         # the HIP cell list built the oracle's (exact) graph
+            assert torch.equal(nb["neighbors_row_splits"].cpu(), want[0][1]) and torch.equal(nb["neighbors_index"].cpu(), want[0][0])
+    finally:
+        if old_g is not None:
+            ops.set_gemm_mode(old_g)
+        if old_a is not None:
+            ops.set_attention_split(old_a)
+
+
+def test_c2_radius_graph_backends_differ_only_at_the_boundary(c2):
+    """`native` (cdist <= r) vs the exact-difference test at the bench geometry: a handful of the 55.6 k pairs, every one
+    within 2e-6 of the radius -- the reference's own backends disagree there, the HIP builder follows the exact ones."""
+    import numpy as np
+    from oracle import gaot_oracle as O
+    for data, q, exact in ((c2.x, c2.lat, c2.enc[0]), (c2.lat, c2.x, c2.dec[0])):
+        nat = O.radius_csr(data, q, 0.033)
+        pairs = lambda c: set(zip(np.repeat(np.arange(q.shape[0]), np.diff(c[1].numpy())).tolist(), c[0].tolist()))
+        diff = pairs(nat) ^ pairs(exact)
+        assert len(diff) < 20
+        for qi, di in diff:
+            assert abs(float((q[qi].double() - data[di].double()).norm()) - 0.033) < 2e-6
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_c2_trainstep_post_adamw_weights(c2, graph):
+    """TrainStep (flat HIP AdamW; eager and hipGraph replay) at the bench configuration:
+    (a) the update applied to the HIP gradients is AdamW's formula to fp32 rounding;
+    (b) the step Delta-w agrees with the oracle's per tensor (first step: -lr*(g/(|g|+eps) + wd*w), a sign-like function of g,
+        so entries with |g| ~ eps move with rounding noise -- compared in rel-L2 over the tensor against the float64-statistics oracle, 5e-4; measured 1.0e-4)."""
+    from gaot_amd.trainer import TrainStep
+    from oracle import gaot_oracle as O
+    m = _c2_model(c2)
+    ts = TrainStep(m, lr=8e-4, weight_decay=1e-5, use_graph=graph)
+    ts.bind(c2.p.to(dev()), c2.t.to(dev()), latent_tokens_coord=c2.lat.to(dev()), xcoord=c2.x.to(dev()))
+    loss = ts.step()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(c2.loss)) < LOSS_TOL * abs(float(c2.loss))
+    worst_a = worst_b = 0.0
+    for k, prm in m.named_parameters():
+        w0, g = c2.sd[k], prm.grad.detach().cpu()
+        want, _, _ = O.adamw_update(w0, g, torch.zeros_like(w0), torch.zeros_like(w0), 1, 8e-4, 1e-5)
+        got = prm.detach().cpu()
+        worst_a = max(worst_a, float((got - want).abs().max()))
+        dw, dw_ref = (got - w0).double(), (c2.new_sd64[k] - w0).double()
+        if w0.numel() >= 64:
+            worst_b = max(worst_b, float((dw - dw_ref).norm() / dw_ref.norm()))
+    print(f"[C2 adamw graph={graph}] max |w - adamw(w0, g_hip)| {worst_a:.2e}; worst rel-L2 of the step vs oracle {worst_b:.2e}")
+    assert worst_a < 2e-7 and worst_b < 5e-4
+
+
+# ------------------------------------------------------------------------------------------------ C3: skewed meshes, vx mode
+def _c3_case(B=4, N=8192, spread=0.15, seed=0, **magno_kw):
+    from oracle import gaot_oracle as O
+    model, sd, ocfg = make_model(3, 1, [64, 64], seed=seed, **magno_kw)
+    g = torch.Generator().manual_seed(seed)
+    lat = grid([64, 64])
+    x = torch.stack([naca_points(N, g, spread) for _ in range(B)])
+    p, tgt = torch.randn(B, N, 3, generator=g), torch.randn(B, N, 1, generator=g)
+    enc = [[O.radius_csr(x[b], lat, 0.033)] for b in range(B)]
+    dec = [[O.radius_csr(lat, x[b], 0.033)] for b in range(B)]
+    return model, sd, ocfg, lat, x, p, tgt, enc, dec
+
+
+def test_c3_naca_vx_degree_skew_vs_oracle():
+    """BASELINE configs[2]: per-sample airfoil-like meshes through the block-diagonal batched CSR; rows of > 256 edges sit
+    next to empty rows in the encoder CSR, and the same skew appears in the decoder's TRANSPOSED CSR (backward)."""
+    from oracle import gaot_oracle as O
+    model, sd, ocfg, lat, x, p, tgt, enc, dec = _c3_case()
+    deg = torch.cat([e[0][1][1:] - e[0][1][:-1] for e in enc])
+    assert int(deg.max()) > 256 and int((deg == 0).sum()) > 1000, (int(deg.max()), int((deg == 0).sum()))
+    batch = dict(latent=lat, xcoord=x, pndata=p, target=tgt, encoder_nbrs=enc, decoder_nbrs=dec)
+    loss, grads, _, _, pred = O.train_step(sd, ocfg, batch, return_pred=True)
+    model.to(dev()).train()
+    kw = dict(latent_tokens_coord=lat.to(dev()), xcoord=x.to(dev()),
+              encoder_nbrs=[[csr_dict(c) for c in row] for row in enc], decoder_nbrs=[[csr_dict(c) for c in row] for row in dec])
+    check_step(model, (loss, grads, pred), kw, p.to(dev()), tgt.to(dev()), f"C3 vx B=4 max degree {int(deg.max())}")
+    # a re-shuffled batch (what a shuffling DataLoader hands over next step): permuted samples give permuted outputs
+    perm = [2, 0, 3, 1]
+    kw2 = dict(latent_tokens_coord=kw["latent_tokens_coord"], xcoord=x[perm].to(dev()),
+               encoder_nbrs=[kw["encoder_nbrs"][i] for i in perm], decoder_nbrs=[kw["decoder_nbrs"][i] for i in perm])
+    with torch.no_grad():
+        y = model(pndata=p.to(dev()), **kw)
+        y2 = model(pndata=p[perm].to(dev()), **kw2)
+    assert rel_l2(y2.cpu(), y[perm].cpu()) < 1e-6
+
+
+@pytest.mark.parametrize("vx", [False, True])
+def test_c3_max_neighbors_sampling_on_gpu(vx, monkeypatch):
+    """row A12 on the device: training-time neighbour sub-sampling (sampling_strategy='max_neighbors') runs inside the
+    model; the CSR lists it drew are recorded and handed to the oracle, which must then agree on output, loss and gradients."""
+    from gaot_amd.model.layers import magno as M
+    from oracle import gaot_oracle as O
+    B, N = 2, 4096
+    model, sd, ocfg, lat, x, p, tgt, enc, dec = _c3_case(B=B, N=N, spread=0.2, seed=3, sampling_strategy="max_neighbors", max_neighbors=6)
+    if not vx:
+        x = x[0]
+        enc, dec = [enc[0][0]], [dec[0][0]]
+    drawn = []
+    real = M.apply_edge_drop_csr
+
+    def recording(nb, *a, **k):
+        out = real(nb, *a, **k)
+        drawn.append((out["neighbors_index"].cpu(), out["neighbors_row_splits"].cpu()))
+        return out
+
+    monkeypatch.setattr(M, "apply_edge_drop_csr", recording)
+    model.to(dev()).train()
+    todev = (lambda rows: [[csr_dict(c) for c in row] for row in rows]) if vx else (lambda rows: [csr_dict(c) for c in rows])
+    kw = dict(latent_tokens_coord=lat.to(dev()), xcoord=x.to(dev()), encoder_nbrs=todev(enc), decoder_nbrs=todev(dec))
+    from gaot_amd import ops
+    pred = model(pndata=p.to(dev()), **kw)
+    loss = ops.mse_loss(pred, tgt.to(dev()))
+    loss.backward()
+    if vx:                                      # drawn per sample (magno.py:372-378): B encoder graphs, then B decoder graphs
+        assert len(drawn) == 2 * B
+        enc_d, dec_d = [[c] for c in drawn[:B]], [[c] for c in drawn[B:]]
+        full = torch.cat([e[0][1][1:] - e[0][1][:-1] for e in enc])
+        kept = torch.cat([e[0][1][1:] - e[0][1][:-1] for e in enc_d])
+    else:
+        assert len(drawn) == 2
+        enc_d, dec_d = [drawn[0]], [drawn[1]]
+        full, kept = enc[0][1][1:] - enc[0][1][:-1], drawn[0][1][1:] - drawn[0][1][:-1]
+    assert int(full.max()) > 6 and int(kept.max()) == 6 and torch.equal(kept, full.clamp(max=6))
+    batch = dict(latent=lat, xcoord=x, pndata=p, target=tgt, encoder_nbrs=enc_d, decoder_nbrs=dec_d)
+    loss_ref, grads_ref, _, _, pred_ref = O.train_step(sd, ocfg, batch, return_pred=True)
+    assert rel_l2(pred.detach().cpu(), pred_ref) < OUT_TOL
+    assert abs(float(loss) - float(loss_ref)) < LOSS_TOL * abs(float(loss_ref))
+    errs = grad_errors(model, grads_ref)
+    assert max(errs.values()) < GRAD_TOL, max(errs, key=errs.get)
+    # TrainStep notices the sampling and stays eager (a captured graph would replay one fixed draw)
+    from gaot_amd.trainer import TrainStep
+    assert TrainStep(model, use_graph=True).use_graph is False
+
+
+# ------------------------------------------------------------------------------------------------ C1 and C5
+def test_c1_poisson_1k_nodes_batch4_many_empty_tokens():
+    """BASELINE configs[0] at its stated shape: 1 024 nodes, batch 4, example model; ~43 % of the 4 096 latent tokens have
+    no physical node within the radius (empty CSR rows -> zeros through AGNO, statistics and the geometry embedding)."""
+    from oracle import gaot_oracle as O
+    model, sd, ocfg = make_model(1, 1, [64, 64], seed=5)
+    g = torch.Generator().manual_seed(5)
+    lat, x = grid([64, 64]), uniform_points(1024, 2, g)
+    p, tgt = torch.randn(4, 1024, 1, generator=g), torch.randn(4, 1024, 1, generator=g)
+    enc, dec = [O.radius_csr(x, lat, 0.033)], [O.radius_csr(lat, x, 0.033)]
+    deg = enc[0][1][1:] - enc[0][1][:-1]
+    assert 0.35 < float((deg == 0).float().mean()) < 0.5
+    loss, grads, _, _, pred = O.train_step(sd, ocfg, dict(latent=lat, xcoord=x, pndata=p, target=tgt, encoder_nbrs=enc, decoder_nbrs=dec),
+                                           return_pred=True)
+    model.to(dev()).train()
+    kw = dict(latent_tokens_coord=lat.to(dev()), xcoord=x.to(dev()), encoder_nbrs=[csr_dict(enc[0])], decoder_nbrs=[csr_dict(dec[0])])
+    check_step(model, (loss, grads, pred), kw, p.to(dev()), tgt.to(dev()), "C1 1k nodes B=4")
+
+
+def test_c5_3d_cloud_4096_tokens_headdim48():
+    """BASELINE configs[4] shape at a size the oracle finishes: 3-D surface cloud, 32^3 latent grid -> 4 096 tokens of width
+    8*48 = 384, 8 heads x 48 (the fp32-MFMA attention kernels: head_dim 48 is not a split-bf16 shape), 92 % empty latent rows."""
+    from oracle import gaot_oracle as O
+    model, sd, ocfg = make_model(3, 1, [32, 32, 32], d=3, C=48, hidden=384, heads=8, radius=0.067, seed=7)
+    g = torch.Generator().manual_seed(7)
+    lat, x = grid([32, 32, 32]), shell_points(16384, g)
+    p, tgt = torch.randn(1, 16384, 3, generator=g), torch.randn(1, 16384, 1, generator=g)
+    enc, dec = [O.radius_csr(x, lat, 0.067)], [O.radius_csr(lat, x, 0.067)]
+    loss, grads, _, _, pred = O.train_step(sd, ocfg, dict(latent=lat, xcoord=x, pndata=p, target=tgt, encoder_nbrs=enc, decoder_nbrs=dec),
+                                           return_pred=True)
+    model.to(dev()).train()
+    kw = dict(latent_tokens_coord=lat.to(dev()), xcoord=x.to(dev()), encoder_nbrs=[csr_dict(enc[0])], decoder_nbrs=[csr_dict(dec[0])])
+    check_step(model, (loss, grads, pred), kw, p.to(dev()), tgt.to(dev()), "C5 3-D 4096 tokens head_dim 48")
+
+
+# ------------------------------------------------------------------------------------------------ caches vs in-place optimizers
+def test_train_eval_train_eval_sees_new_weights():
+    """The reference's loop (eval_every_eps): validate / roll out, train some more, validate again on the SAME neighbour
+    dicts and coordinates.  FlatAdamW (and its hipGraph replay) update weights through raw pointers, which does not move
+    Parameter._version: the no_grad caches (AGNO kernel values, geoembed row bias, the rollout hipGraph) must still notice."""
+    from gaot_amd.model.gaot import GAOT
+    from gaot_amd.trainer import TrainStep
+    model, sd, _ = make_model(3, 2, [32, 32], C=32, hidden=128, heads=4, radius=0.08, precompute=False, seed=11)
+    model.to(dev())
+    g = torch.Generator().manual_seed(11)
+    lat, x = grid([32, 32]).to(dev()), uniform_points(1500, 2, g).to(dev())
+    p, tgt = torch.randn(2, 1500, 3, generator=g).to(dev()), torch.randn(2, 1500, 2, generator=g).to(dev())
+    def evaluate(m):
+        m.eval()
+        with torch.no_grad():
+            y = m(latent_tokens_coord=lat, xcoord=x, pndata=p)
+        m.train()
+        return y.clone()
+
+    for graph in (False, True):
+        m = GAOT(3, 2, model_cfg(model))
+        m.load_state_dict(sd)
+        m.to(dev()).train()
+        ts = TrainStep(m, lr=5e-3, weight_decay=1e-5, use_graph=graph)
+        ts.bind(p, tgt, latent_tokens_coord=lat, xcoord=x)
+        y0 = evaluate(m)
+        for _ in range(3):
+            ts.step()
+        y1 = evaluate(m)
+        fresh = GAOT(3, 2, model_cfg(model))
+        fresh.load_state_dict({k: v.detach().clone() for k, v in m.state_dict().items()})
+        fresh.to(dev())
+        y1_ref = evaluate(fresh)
+        assert rel_l2(y1.cpu(), y0.cpu()) > 1e-3                    # training moved the prediction ...
+        assert rel_l2(y1.cpu(), y1_ref.cpu()) < 1e-6, graph         # ... and the evaluation reflects the CURRENT weights
+
+
+def model_cfg(model):
+    from gaot_amd.model.layers.attn import TransformerConfig, AttentionConfig
+    enc = model.encoder.config
+    blk = model.processor.blocks_in_order()[0]
+    hidden = blk.attn.q_proj.weight.shape[0]
+    tcfg = TransformerConfig(patch_size=model.patch_size, hidden_size=hidden,
+                             attn_config=AttentionConfig(num_heads=blk.attn.num_heads, num_kv_heads=blk.attn.num_kv_heads))
+    return NS(args=NS(magno=enc, transformer=tcfg), latent_tokens_size=[model.H, model.W] + ([model.D] if model.D else []))
+
+
+def test_rollout_graph_follows_weight_updates():
+    """autoregressive_predict's captured step must be re-captured (or refreshed) after raw-pointer weight updates"""
+    import numpy as np
+    from gaot_amd.model.gaot import GAOT
+    from gaot_amd.trainer import TrainStep
+    model, sd, _ = make_model(3, 1, [32, 32], C=32, hidden=128, heads=4, radius=0.08, precompute=False, seed=12)
+    g = torch.Generator().manual_seed(12)
+    lat, x = grid([32, 32]).to(dev()), uniform_points(1200, 2, g).to(dev())
+    xb = torch.randn(2, 1200, 1, generator=g).to(dev())                   # u only; the model input is [u, t0, dt] = 3 columns
+    p3, tgt = torch.randn(2, 1200, 3, generator=g).to(dev()), torch.randn(2, 1200, 1, generator=g).to(dev())
+    stats = {"u": {"mean": torch.zeros(1), "std": torch.ones(1)}, "start_time": {"mean": 0.0, "std": 1.0}, "time_diffs": {"mean": 0.0, "std": 1.0}}
+    tv, ti = np.linspace(0, 1, 5), np.arange(4)
+    roll = lambda m: m.autoregressive_predict(x_batch=xb, time_indices=ti, t_values=tv, stats=stats, stepper_mode="output",
+                                              latent_tokens_coord=lat, fixed_coord=x)
+    m = model.to(dev())
+    m.eval()
+    r0 = roll(m)
+    m.train()
+    ts = TrainStep(m, lr=5e-3, weight_decay=1e-5, use_graph=True)
+    ts.bind(p3, tgt, latent_tokens_coord=lat, xcoord=x)
+    for _ in range(3):
+        ts.step()
+    m.eval()
+    r1 = roll(m)
+    fresh = GAOT(3, 1, model_cfg(m))
+    fresh.load_state_dict({k: v.detach().clone() for k, v in m.state_dict().items()})
+    fresh.to(dev()).eval()
+    r1_ref = roll(fresh)
+    assert rel_l2(r1.cpu(), r0.cpu()) > 1e-3 and rel_l2(r1.cpu(), r1_ref.cpu()) < 1e-6
+
+
+def test_lr_schedule_reaches_the_captured_optimizer():
+    """torch LR schedulers attach to FlatAdamW (a torch.optim.Optimizer with one param_group) and the captured update reads
+    lr from device memory: three graph-replayed steps under StepLR equal three torch.optim.AdamW steps under the same schedule."""
+    from gaot_amd.model.gaot import GAOT
+    from gaot_amd.trainer import TrainStep
+    model, sd, _ = make_model(1, 1, [16, 16], C=16, hidden=64, heads=2, radius=0.2, precompute=False, seed=13)
+    g = torch.Generator().manual_seed(13)
+    lat, x = grid([16, 16]).to(dev()), uniform_points(300, 2, g).to(dev())
+    p, tgt = torch.randn(2, 300, 1, generator=g).to(dev()), torch.randn(2, 300, 1, generator=g).to(dev())
+    ms = []
+    for _ in range(2):
+        m = GAOT(1, 1, model_cfg(model))
+        m.load_state_dict(sd)
+        ms.append(m.to(dev()).train())
+    ts = TrainStep(ms[0], lr=4e-3, weight_decay=1e-2, use_graph=True)
+    ts.bind(p, tgt, latent_tokens_coord=lat, xcoord=x)
+    sched_a = torch.optim.lr_scheduler.StepLR(ts.opt, step_size=1, gamma=0.5)
+    opt_b = torch.optim.AdamW(ms[1].parameters(), lr=4e-3, weight_decay=1e-2)
+    sched_b = torch.optim.lr_scheduler.StepLR(opt_b, step_size=1, gamma=0.5)
+    for _ in range(3):
+        ts.step()
+        sched_a.step()
+        opt_b.zero_grad()
+        torch.nn.functional.mse_loss(ms[1](latent_tokens_coord=lat, xcoord=x, pndata=p), tgt).backward()
+        opt_b.step()
+        sched_b.step()
+    assert ts.opt.param_groups[0]["lr"] == opt_b.param_groups[0]["lr"] == 5e-4
+    for (k, a), (_, b) in zip(ms[0].named_parameters(), ms[1].named_parameters()):
+        assert float((a.detach() - b.detach()).abs().max()) < 2e-5, k
+    # and a frozen-lr twin would NOT match: the schedule really reached the kernel
+    m3 = GAOT(1, 1, model_cfg(model))
+    m3.load_state_dict(sd)
+    ts3 = TrainStep(m3.to(dev()).train(), lr=4e-3, weight_decay=1e-2, use_graph=True)
+    ts3.bind(p, tgt, latent_tokens_coord=lat, xcoord=x)
+    for _ in range(3):
+        ts3.step()
+    assert max(float((a.detach() - b.detach()).abs().max()) for a, b in zip(ms[0].parameters(), m3.parameters())) > 1e-3

@@ -23,7 +23,12 @@ class TinyOperator(torch.nn.Module):
         self.unused = torch.nn.Parameter(torch.ones(4))     # a parameter that never receives a gradient
 
     def forward(self, pndata, scale=1.0):
-        return self.b(torch.tanh(self.a(pndata))) * scale
+        from gaot_amd import ops
+        h = ops.cut(torch.tanh(self.a(pndata)))             # cut point of the staged backward (identity without a hook)
+        return self.b(h) * scale
+
+    def backward_phases(self):
+        return [[self.b.weight], [self.a.weight, self.a.bias, self.unused]]
 
 
 def _free_port():
@@ -34,12 +39,13 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, staged=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
     model = TinyOperator(seed=100 + rank)             # reference behaviour: seed + rank -> ranks start DIFFERENT
-    ts = TrainStep(model, lr=1e-2, weight_decay=1e-3)
+    ts = TrainStep(model, lr=1e-2, weight_decay=1e-3, staged=staged)
+    assert ts.staged == (staged is not False) and ts.bucket.n_phases == (2 if ts.staged else 1)
     g = torch.Generator().manual_seed(7)
     x_all, y_all = torch.randn(8, 5, 3, generator=g), torch.randn(8, 5, 2, generator=g)
     idx = shard_indices(8, rank, world, shuffle=False)
@@ -54,11 +60,14 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_step_matches_single_process():
+@pytest.mark.parametrize("staged", [None, False])
+def test_two_rank_gloo_step_matches_single_process(staged):
+    """staged=None: the default for > 1 rank -- backward split at the cut point, one async all-reduce per phase slice;
+    staged=False: one all-reduce of the whole flat buffer after the backward pass.  Both equal single-process training."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, staged)) for r in range(2)]
     for p in procs:
         p.start()
     p0, p1, _ = q.get(timeout=120)
@@ -80,7 +89,7 @@ def test_two_rank_gloo_step_matches_single_process():
 
 
 def test_shard_indices_partition():
-    for n, w in [(10, 2), (7, 2), (16, 8), (5, 8)]:
+    for n, w in [(10, 2), (7, 2), (16, 8), (5, 8), (3, 8), (1, 4)]:
         shards = [shard_indices(n, r, w, epoch=3, seed=1) for r in range(w)]
         assert len({len(s) for s in shards}) == 1
         assert set(i for s in shards for i in s) == set(range(n))
@@ -130,3 +139,33 @@ def test_flat_bucket_fused_groups_are_back_to_back():
     assert torch.equal(W, torch.cat([lin[0].weight, lin[2].weight, lin[3].weight]).detach())
     assert ops.adjacent_rows([lin[0].weight, lin[1].weight]) is None          # not adjacent: caller concatenates
     assert torch.equal(ops.stacked_rows([lin[0].weight, lin[1].weight]), torch.cat([lin[0].weight, lin[1].weight]).detach())
+
+
+def test_flat_bucket_phase_layout():
+    """backward phases get contiguous slices in completion order; fused groups stay back to back inside their phase"""
+    lin = [torch.nn.Linear(8, n, bias=False) for n in (4, 12, 4, 8)]
+    params = [l.weight for l in lin]
+    b = FlatGradBucket(params, groups=[[lin[0].weight, lin[2].weight]], phases=[[lin[3].weight, lin[1].weight], [lin[0].weight, lin[2].weight]])
+    assert [id(p) for p in b.params] == [id(lin[i].weight) for i in (1, 3, 0, 2)]       # phase 0 in model order, then phase 1
+    assert b.phase == [0, 0, 1, 1] and b.n_phases == 2
+    (s0, e0), (s1, e1) = b.segments
+    assert s0 == 0 and e0 <= s1 and s1 % FlatGradBucket.ALIGN == 0 and e1 == b.numel
+    for p, off, ph in zip(b.params, b.offsets, b.phase):
+        s_, e_ = b.segments[ph]
+        assert s_ <= off and off + p.numel() <= e_
+    assert b.model_order == params
+
+
+def test_staged_backward_equals_plain_backward_single_process():
+    """the cut-point machinery alone (no process group): phase-by-phase backward gives the same update as one backward"""
+    xs, ys = torch.randn(4, 5, 3), torch.randn(4, 5, 2)
+    out = []
+    for staged in (False, True):
+        m = TinyOperator(3)
+        ts = TrainStep(m, lr=1e-2, weight_decay=1e-3, staged=staged)
+        assert ts.staged == staged
+        ts.bind(xs, ys, scale=2.0)
+        for _ in range(2):
+            ts.step()
+        out.append(torch.cat([p.detach().reshape(-1) for p in m.parameters()]))
+    assert torch.equal(out[0], out[1])

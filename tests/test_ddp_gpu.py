@@ -1,0 +1,141 @@
+"""-m gpu: the data-parallel step with GAOT ITSELF under more than one rank.
+
+A GPU box of the test pool has ONE device, so both ranks run on cuda:0 and exchange gradients over gloo (RCCL refuses two
+ranks on one device); everything else is the N > 1 path of bench.py: parameter broadcast, phase-ordered flat gradient
+bucket, staged backward with one asynchronous all-reduce per phase slice, hipGraph replay per phase, flat HIP AdamW.
+Checked: ranks end bit-identical, and equal to single-process training on the concatenated global batch.
+The RCCL branch (ReduceOp.AVG on the flat buffer) is exercised with a one-rank nccl group."""
+import os
+import socket
+from types import SimpleNamespace as NS
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build(seed):
+    from gaot_amd.model.gaot import GAOT
+    from gaot_amd.model.layers.magno import MAGNOConfig
+    from gaot_amd.model.layers.attn import TransformerConfig, AttentionConfig
+    torch.manual_seed(seed)
+    mcfg = MAGNOConfig(coord_dim=2, radius=0.08, hidden_size=64, mlp_layers=3, lifting_channels=32)
+    tcfg = TransformerConfig(patch_size=2, hidden_size=128, attn_config=AttentionConfig(num_heads=4, num_kv_heads=4))
+    return GAOT(2, 1, NS(args=NS(magno=mcfg, transformer=tcfg), latent_tokens_size=[32, 32]))
+
+
+def _data():
+    g = torch.Generator().manual_seed(21)
+    ax = torch.linspace(-1, 1, 32)
+    lat = torch.stack(torch.meshgrid(ax, ax, indexing="ij"), -1).reshape(-1, 2)
+    x = torch.rand(1500, 2, generator=g) * 2 - 1
+    return lat, x, torch.randn(4, 1500, 2, generator=g), torch.randn(4, 1500, 1, generator=g)
+
+
+def _flat(model):
+    return torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+
+
+def _worker(rank, world, port, out, graph, staged):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gaot_amd.trainer import TrainStep, shard_indices
+    dev = torch.device("cuda:0")
+    model = _build(seed=300 + rank).to(dev).train()           # ranks start DIFFERENT (reference: seed + rank); rank 0 is broadcast
+    lat, x, p, t = _data()
+    idx = shard_indices(4, rank, world, shuffle=False)
+    ts = TrainStep(model, lr=2e-3, weight_decay=1e-4, use_graph=graph, staged=staged)
+    assert ts.staged == (staged is not False)
+    if ts.staged:                                             # 3 blocks + encoder -> 4 backward phases, 4 slices of the flat buffer
+        assert ts.bucket.n_phases == 4 and ts.bucket.segments[-1][1] == ts.bucket.numel
+    ts.bind(p[idx].to(dev), t[idx].to(dev), latent_tokens_coord=lat.to(dev), xcoord=x.to(dev))
+    losses = [float(ts.step()) for _ in range(3)]
+    torch.cuda.synchronize()
+    flat = _flat(model).cpu()
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    if rank == 0:
+        out.put((gathered[0].tolist(), gathered[1].tolist(), losses))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("graph,staged", [(True, None), (False, None), (True, False)])
+def test_gaot_two_ranks_one_gpu_equals_single_process_global_batch(graph, staged):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, graph, staged)) for r in range(2)]
+    for p in procs:
+        p.start()
+    p0, p1, losses = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    p0, p1 = torch.tensor(p0), torch.tensor(p1)
+    assert torch.equal(p0, p1)                                # identical after the all-reduced updates
+    from gaot_amd.trainer import TrainStep
+    dev = torch.device("cuda:0")
+    model = _build(seed=300).to(dev).train()
+    lat, x, p, t = _data()
+    ts = TrainStep(model, lr=2e-3, weight_decay=1e-4, use_graph=False)
+    assert ts.staged is False and ts.bucket.n_phases == 1
+    ts.bind(p.to(dev), t.to(dev), latent_tokens_coord=lat.to(dev), xcoord=x.to(dev))
+    for _ in range(3):
+        ts.step()
+    ref = _flat(model).cpu()
+    # 3 AdamW steps of 2e-3 each: the weights moved by ~6e-3 per entry; agreement to 2e-5 absolute = gradients agree
+    assert float((p0 - ref).abs().max()) < 2e-5, float((p0 - ref).abs().max())
+
+
+def test_staged_single_rank_equals_unstaged():
+    """cut points + per-phase graphs without any process group: same weights as the single-graph step, bit for bit"""
+    from gaot_amd.trainer import TrainStep
+    dev = torch.device("cuda:0")
+    lat, x, p, t = _data()
+    res = []
+    for staged, graph in ((False, True), (True, True), (True, False)):
+        model = _build(seed=5).to(dev).train()
+        ts = TrainStep(model, lr=2e-3, weight_decay=1e-4, use_graph=graph, staged=staged)
+        assert ts.staged == staged
+        ts.bind(p.to(dev), t.to(dev), latent_tokens_coord=lat.to(dev), xcoord=x.to(dev))
+        for _ in range(3):
+            ts.step()
+        torch.cuda.synchronize()
+        res.append(_flat(model).cpu())
+    assert torch.equal(res[0], res[1]) and torch.equal(res[0], res[2])
+
+
+def test_rccl_avg_all_reduce_on_flat_bucket_one_rank():
+    """the `nccl` (= RCCL) branch of FlatGradBucket.all_reduce_mean: ReduceOp.AVG on the flat buffer and on a phase slice,
+    synchronous and async_op, with a one-rank group (all this box can host)."""
+    from gaot_amd.trainer import FlatGradBucket
+    port = _free_port()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        lin = [torch.nn.Linear(8, 8, bias=False).to(dev) for _ in range(3)]
+        b = FlatGradBucket([l.weight for l in lin], phases=[[lin[2].weight], [lin[0].weight, lin[1].weight]])
+        b.flat.copy_(torch.arange(b.numel, dtype=torch.float32))
+        want = b.flat.clone()
+        b.all_reduce_mean(None, _force=True)
+        w = b.all_reduce_mean(None, phase=0, async_op=True, _force=True)
+        assert w is not None
+        w.wait()
+        b.all_reduce_mean(None, phase=1, _force=True)
+        torch.cuda.synchronize()
+        assert torch.equal(b.flat, want)          # the mean over one rank is the identity
+    finally:
+        dist.destroy_process_group()

@@ -14,7 +14,18 @@ from tests._golden import Golden, MODEL_CASES, rel_l2
 pytestmark = pytest.mark.gpu
 
 OUT_TOL = 1e-5
-GRAD_TOL = 2e-4
+GRAD_TOL = 2e-4          # max-abs error of a gradient tensor / its largest reference entry
+GRAD_L2_TOL = 1e-4       # per-tensor rel-L2 (denominator floored at 1e-3 of the largest gradient norm of the model)
+
+
+def grad_l2_errors(named_params, ref):
+    top = max(float(v.double().norm()) for v in ref.values())
+    out = {}
+    for k, prm in named_params:
+        if k in ref:
+            got = prm.grad.detach().cpu().double() if prm.grad is not None else torch.zeros_like(prm).cpu().double()
+            out[k] = float((got - ref[k].double()).norm()) / max(float(ref[k].double().norm()), 1e-3 * top)
+    return out
 
 
 def dev():
@@ -69,6 +80,9 @@ def test_forward_loss_grads_vs_golden(case):
     loss.backward()
     assert abs(float(loss) - float(g.t("out.loss"))) < 1e-5 * abs(float(g.t("out.loss")))
     gg, gn = g.group("g."), g.group("gnorm.")
+    if gg:
+        errs = grad_l2_errors(model.named_parameters(), gg)
+        assert max(errs.values()) < GRAD_L2_TOL, max(errs, key=errs.get)
     for k, prm in model.named_parameters():
         got = prm.grad.cpu() if prm.grad is not None else torch.zeros_like(prm).cpu()
         if k in gg:
@@ -158,6 +172,8 @@ def _oracle_vs_hip(N, lat_sizes, B, C, hidden, heads, radius, seed, cin=1, cout=
     for k, prm in model.named_parameters():
         ref = grads_ref[k]
         assert float((prm.grad.cpu() - ref).abs().max()) / max(float(ref.abs().max()), 1e-4) < GRAD_TOL, k
+    errs = grad_l2_errors(model.named_parameters(), grads_ref)
+    assert max(errs.values()) < GRAD_L2_TOL, max(errs, key=errs.get)
 
 
 def test_example_config_shape_small_mesh():

@@ -11,6 +11,7 @@ from gaot_amd.model.layers.magno import MAGNOConfig
 from gaot_amd.model.layers.attn import TransformerConfig, AttentionConfig
 from gaot_amd.model.layers.utils.neighbor_search import NeighborSearch
 from gaot_amd.trainer import TrainStep
+from tests._workloads import naca_points, shell_points
 
 dev = torch.device("cuda:0")
 
@@ -29,22 +30,6 @@ def timed(fn, warm, iters):
         fn()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / iters
-
-
-def naca_points(n, g):
-    """points with density ~ 1/(distance to a NACA0012 contour + eps): degree skew like an airfoil mesh"""
-    t = torch.rand(n * 6, generator=g)
-    xc = t ** 2
-    yt = 0.6 * (0.2969 * xc.sqrt() - 0.1260 * xc - 0.3516 * xc ** 2 + 0.2843 * xc ** 3 - 0.1015 * xc ** 4)
-    side = (torch.rand(n * 6, generator=g) < 0.5).float() * 2 - 1
-    r = torch.empty(n * 6).exponential_(1.0, generator=g) * 0.25
-    ang = torch.rand(n * 6, generator=g) * 6.2832
-    px = (xc - 0.5) * 0.9 + r * torch.cos(ang)
-    py = side * yt * 0.9 + r * torch.sin(ang)
-    keep = (px.abs() <= 1) & (py.abs() <= 1)
-    pts = torch.stack([px[keep], py[keep]], -1)[:n]
-    assert pts.shape[0] == n
-    return pts
 
 
 def c3():
@@ -90,16 +75,6 @@ def c4():
     dt_roll = timed(roll, 2, 5)
     return {"config": "C4 NS-Gauss-like fx, 16384 nodes, batch 4", "pair_train_samples_per_s": B / dt_train, "train_ms_per_step": dt_train * 1e3,
             "rollout_10_steps_ms": dt_roll * 1e3, "rollout_ms_per_step": dt_roll * 1e3 / 10}
-
-
-def shell_points(n, g):
-    """car-ish surface: union of three ellipsoid shells in [-1,1]^3"""
-    v = torch.randn(n, 3, generator=g)
-    v = v / v.norm(dim=1, keepdim=True)
-    which = torch.randint(0, 3, (n,), generator=g)
-    ax = torch.tensor([[0.9, 0.4, 0.3], [0.5, 0.35, 0.25], [0.3, 0.3, 0.2]])[which]
-    ctr = torch.tensor([[0.0, 0.0, -0.1], [-0.1, 0.0, 0.2], [0.5, 0.0, 0.15]])[which]
-    return (v * ax + ctr).clamp(-1, 1)
 
 
 def c5():
