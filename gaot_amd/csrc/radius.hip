@@ -32,6 +32,17 @@ __device__ __forceinline__ bool within(const float* __restrict__ q, const float*
     return __fsqrt_rn(s) <= r;
 }
 
+// torch_cluster.radius semantics (its CUDA kernel, what the reference's `torch_cluster` backend calls with the default
+// max_num_neighbors = 32, neighbor_search.py:163-165): STRICT test on the squared distance accumulated with fused multiply-adds
+__device__ __forceinline__ bool within_sq_strict(const float* __restrict__ q, const float* __restrict__ d, int dim, float r) {
+    float s = 0.f;
+    for (int k = 0; k < dim; ++k) {
+        const float df = __fsub_rn(d[k], q[k]);
+        s = __fmaf_rn(df, df, s);
+    }
+    return s < __fmul_rn(r, r);
+}
+
 __global__ void cell_count_kernel(const float* __restrict__ data, int n, CellGrid g, int* __restrict__ cell_id, int* __restrict__ cnt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -86,11 +97,13 @@ __global__ __launch_bounds__(1024) void exscan_i32_kernel(const int* __restrict_
     if (t == 1023) { if (out32) out32[n] = (int)part[1023]; if (out64) out64[n] = part[1023]; }
 }
 
-// one thread per query; FILL = false: count, FILL = true: write ascending neighbour indices at splits[q]
+// one thread per query; FILL = false: count, FILL = true: write ascending neighbour indices at splits[q].
+// cap > 0: keep only the `cap` SMALLEST data indices of a row (torch_cluster scans the data points in index order and stops at
+// max_num_neighbors); strict: torch_cluster's `d^2 < r^2` instead of the in-repo backends' `d <= r`.
 template <bool FILL>
 __global__ void radius_query_kernel(const float* __restrict__ qry, int m, const float* __restrict__ data, CellGrid g, float r,
                                     const int* __restrict__ start, const int* __restrict__ pts, int* __restrict__ deg,
-                                    const int64_t* __restrict__ splits, int64_t* __restrict__ index) {
+                                    const int64_t* __restrict__ splits, int64_t* __restrict__ index, int cap, int strict) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= m) return;
     const float* x = qry + (long)q * g.dim;
@@ -116,13 +129,25 @@ __global__ void radius_query_kernel(const float* __restrict__ qry, int m, const 
                     const int c = (cz * g.ny + cy) * g.nx + cx;
                     for (int t = start[c]; t < start[c + 1]; ++t) {
                         const int j = pts[t];
-                        if (within(x, data + (long)j * g.dim, g.dim, r)) {
-                            if (FILL) index[base + count] = j;
+                        const float* dj = data + (long)j * g.dim;
+                        if (strict ? within_sq_strict(x, dj, g.dim, r) : within(x, dj, g.dim, r)) {
+                            if (FILL) {
+                                if (cap > 0) {      // sorted insertion into the row's <= cap slots; a full row drops its largest index
+                                    int k = count < cap ? count : cap - 1;
+                                    if (count >= cap && index[base + k] <= j) continue;
+                                    while (k > 0 && index[base + k - 1] > j) { index[base + k] = index[base + k - 1]; --k; }
+                                    index[base + k] = j;
+                                    if (count < cap) ++count;
+                                    continue;
+                                }
+                                index[base + count] = j;
+                            }
                             ++count;
                         }
                     }
                 }
-    if (!FILL) { deg[q] = count; return; }
+    if (!FILL) { deg[q] = (cap > 0 && count > cap) ? cap : count; return; }
+    if (cap > 0) return;          // already in ascending order
     // ascending data index inside the segment (cells were visited in grid order)
     for (int i = 1; i < count; ++i) {
         const int64_t v = index[base + i];
@@ -169,13 +194,14 @@ extern "C" int gaot_cells_build(const float* data, int32_t n, int32_t dim, const
 // degree per query + row splits (int64, [m+1]).  The caller reads splits[m] to size the index array.
 extern "C" int gaot_radius_count(const float* queries, int32_t m, const float* data, int32_t dim, float radius,
                                  const float* origin, float cell, const int32_t* dims, const int32_t* cell_start,
-                                 const int32_t* cell_points, int32_t* deg, int64_t* splits, gaot_stream_t stream) {
+                                 const int32_t* cell_points, int32_t* deg, int64_t* splits, int32_t max_neighbors, int32_t strict,
+                                 gaot_stream_t stream) {
     GAOT_REQUIRE(queries && data && origin && dims && cell_start && cell_points && deg && splits, "radius_count: null pointer");
-    GAOT_REQUIRE(m > 0 && radius >= 0.f && cell >= radius, "radius_count: need cell >= radius");
+    GAOT_REQUIRE(m > 0 && radius >= 0.f && cell >= radius && max_neighbors >= 0, "radius_count: need cell >= radius, max_neighbors >= 0");
     CellGrid g;
     make_grid(g, dim, origin, cell, dims);
     hipLaunchKernelGGL(radius_query_kernel<false>, dim3(cdiv(m, 128)), dim3(128), 0, ST(stream), queries, m, data, g, radius,
-                       cell_start, cell_points, deg, (const int64_t*)nullptr, (int64_t*)nullptr);
+                       cell_start, cell_points, deg, (const int64_t*)nullptr, (int64_t*)nullptr, (int)max_neighbors, (int)strict);
     hipLaunchKernelGGL(exscan_i32_kernel, dim3(1), dim3(1024), 0, ST(stream), deg, m, (int*)nullptr, splits);
     GAOT_CHECK_LAUNCH("gaot_radius_count");
     return GAOT_OK;
@@ -183,12 +209,13 @@ extern "C" int gaot_radius_count(const float* queries, int32_t m, const float* d
 
 extern "C" int gaot_radius_fill(const float* queries, int32_t m, const float* data, int32_t dim, float radius,
                                 const float* origin, float cell, const int32_t* dims, const int32_t* cell_start,
-                                const int32_t* cell_points, const int64_t* splits, int64_t* index, gaot_stream_t stream) {
-    GAOT_REQUIRE(queries && data && origin && dims && cell_start && cell_points && splits, "radius_fill: null pointer");
+                                const int32_t* cell_points, const int64_t* splits, int64_t* index, int32_t max_neighbors,
+                                int32_t strict, gaot_stream_t stream) {
+    GAOT_REQUIRE(queries && data && origin && dims && cell_start && cell_points && splits && max_neighbors >= 0, "radius_fill: bad arguments");
     CellGrid g;
     make_grid(g, dim, origin, cell, dims);
     hipLaunchKernelGGL(radius_query_kernel<true>, dim3(cdiv(m, 128)), dim3(128), 0, ST(stream), queries, m, data, g, radius,
-                       cell_start, cell_points, (int*)nullptr, splits, index);
+                       cell_start, cell_points, (int*)nullptr, splits, index, (int)max_neighbors, (int)strict);
     GAOT_CHECK_LAUNCH("gaot_radius_fill");
     return GAOT_OK;
 }

@@ -124,15 +124,21 @@ int gaot_geo_stats(const float* geom, const float* qry, int32_t dim,
  * arrays describing a uniform grid with cell size `cell` >= radius that covers the data points.
  *   1. gaot_cells_build : cell_start[ncell+1], cell_points[n]           (scratch: n + ncell + 1 int32)
  *   2. gaot_radius_count: deg[m], splits[m+1] (int64; caller reads splits[m] = E to size the index array)
- *   3. gaot_radius_fill : index[E] (int64) */
+ *   3. gaot_radius_fill : index[E] (int64)
+ * max_neighbors > 0 with strict = 1 reproduces the `torch_cluster` backend (neighbor_search.py:148-175: torch_cluster.radius
+ * with its default max_num_neighbors = 32): squared distance strictly below r^2, and of a query's neighbours only the
+ * max_neighbors with the SMALLEST data indices (its kernel scans the data in index order and stops at the cap).
+ * max_neighbors = 0, strict = 0: the in-repo backends (native / chunked / grid). */
 int gaot_cells_build(const float* data, int32_t n, int32_t dim, const float* origin, float cell, const int32_t* dims,
                      int32_t* cell_start, int32_t* cell_points, int32_t* scratch, gaot_stream_t stream);
 int gaot_radius_count(const float* queries, int32_t m, const float* data, int32_t dim, float radius,
                       const float* origin, float cell, const int32_t* dims, const int32_t* cell_start,
-                      const int32_t* cell_points, int32_t* deg, int64_t* splits, gaot_stream_t stream);
+                      const int32_t* cell_points, int32_t* deg, int64_t* splits, int32_t max_neighbors, int32_t strict,
+                      gaot_stream_t stream);
 int gaot_radius_fill(const float* queries, int32_t m, const float* data, int32_t dim, float radius,
                      const float* origin, float cell, const int32_t* dims, const int32_t* cell_start,
-                     const int32_t* cell_points, const int64_t* splits, int64_t* index, gaot_stream_t stream);
+                     const int32_t* cell_points, const int64_t* splits, int64_t* index, int32_t max_neighbors, int32_t strict,
+                     gaot_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * GNO integral transform = gather / per-edge weight / CSR segment reduce (agno.py:198,245-271).

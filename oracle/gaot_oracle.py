@@ -108,6 +108,24 @@ def radius_csr(data: Tensor, queries: Tensor, radius: float, chunk: int = 4096, 
     return idx, splits
 
 
+def radius_csr_torch_cluster(data: Tensor, queries: Tensor, radius: float, max_num_neighbors: int = 32) -> CSR:
+    """What `_torch_cluster_neighbor_search` (neighbor_search.py:148-175) gets from `torch_cluster.radius(data, queries, r)`.
+    torch_cluster is NOT vendored or version-pinned by the reference and is absent here: PARITY UNPINNED for this function.
+    Restated from the published CUDA kernel (rusty1s/pytorch_cluster, csrc/cuda/radius_cuda.cu, 1.6.x): one thread per
+    query scans the data points in index order, keeps a point when the squared distance is STRICTLY below r*r and stops
+    once max_num_neighbors (default 32) are found.  The reference then turns (row, col) into CSR with bincount/cumsum."""
+    r2 = torch.tensor(radius, dtype=queries.dtype) ** 2
+    idx, counts = [], []
+    for q in range(queries.shape[0]):                 # a literal restatement: small cases only
+        d2 = ((data - queries[q]) ** 2).sum(-1)
+        hit = (d2 < r2).nonzero()[:, 0][:max_num_neighbors]
+        idx.append(hit)
+        counts.append(hit.numel())
+    index = torch.cat(idx).long() if idx else torch.zeros(0, dtype=torch.long)
+    splits = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(torch.tensor(counts, dtype=torch.long), 0)])
+    return index, splits
+
+
 def latent_grid(sizes: Sequence[int], lo: float = -1.0, hi: float = 1.0) -> Tensor:
     """meshgrid(linspace)... 'ij' then flattened (data_processor.py:289-294)."""
     axes = [torch.linspace(lo, hi, n) for n in sizes]

@@ -193,3 +193,37 @@ def test_load_ckpt_reconciles_module_prefix(tmp_path):
     w = Wrap(torch.nn.Linear(3, 2))
     load_ckpt(path, model=w)
     assert torch.equal(w.module.weight, src.weight)
+
+
+def test_torch_cluster_capped_search_known_answers():
+    """method='torch_cluster': strict d^2 < r^2 and at most 32 neighbours per query, the 32 smallest data indices
+    (neighbor_search.py:148-175 via torch_cluster.radius; dependency absent -> pinned to its published kernel semantics,
+    oracle.radius_csr_torch_cluster, plus answers worked out by hand)."""
+    from gaot_amd.model.layers.utils.neighbor_search import NeighborSearch
+    from oracle import gaot_oracle as O
+    z = np.load(os.path.join(GOLDEN_DIR, "neighbor_kats.npz"))
+    lattice, qs = torch.from_numpy(z["lattice.data"]), torch.from_numpy(z["lattice.queries"])
+    out = NeighborSearch("torch_cluster")(lattice, qs, 1.0)
+    # by hand: on the unit lattice with r = 1 the axis neighbours sit at distance exactly r -> excluded by the strict test;
+    # queries (2,2), (0,0), (4,1) keep only themselves (indices 12, 0, 21), (10,10) nothing, (2.5,2.5) its 4 cell corners
+    assert out["neighbors_row_splits"].tolist() == [0, 1, 2, 3, 3, 7]
+    assert out["neighbors_index"].tolist() == [12, 0, 21, 12, 13, 17, 18]
+    # a cluster of 50 points around one query and 5 around another: cap at 32 keeps indices 0..31 of the first
+    g = torch.Generator().manual_seed(3)
+    data = torch.cat([torch.rand(50, 2, generator=g) * 0.01, torch.rand(5, 2, generator=g) * 0.01 + 0.5])
+    q = torch.tensor([[0.005, 0.005], [0.505, 0.505], [0.9, 0.9]])
+    out = NeighborSearch("torch_cluster")(data, q, 0.1)
+    assert out["neighbors_row_splits"].tolist() == [0, 32, 37, 37]
+    assert out["neighbors_index"].tolist() == list(range(32)) + list(range(50, 55))
+    out8 = NeighborSearch("native", max_num_neighbors=8)(data, q, 0.1)
+    assert out8["neighbors_row_splits"].tolist() == [0, 8, 13, 13] and out8["neighbors_index"][:8].tolist() == list(range(8))
+    # random clouds against the literal restatement of the published kernel
+    for d, n, m, r in ((2, 600, 80, 0.25), (3, 800, 60, 0.5)):
+        data, q = torch.rand(n, d, generator=g) * 2 - 1, torch.rand(m, d, generator=g) * 2 - 1
+        got = NeighborSearch("torch_cluster")(data, q, r)
+        idx, sp = O.radius_csr_torch_cluster(data, q, r)
+        assert int((sp[1:] - sp[:-1]).max()) == 32                       # the cap binds somewhere
+        assert torch.equal(got["neighbors_index"], idx) and torch.equal(got["neighbors_row_splits"], sp)
+    # 'auto' stays uncapped and inclusive
+    full = NeighborSearch("auto")(data, q, r)
+    assert int((full["neighbors_row_splits"][1:] - full["neighbors_row_splits"][:-1]).max()) > 32

@@ -387,6 +387,36 @@ def test_hip_radius_search_inclusive_boundary():
     assert out["neighbors_index"][:5].tolist() == [7, 11, 12, 13, 17]
 
 
+@pytest.mark.parametrize("d,n,m,r,cap", [(2, 8192, 4096, 0.09, 32), (3, 20000, 4096, 0.2, 32), (2, 3000, 500, 0.3, 8)])
+def test_hip_radius_search_torch_cluster_cap(d, n, m, r, cap):
+    """the cell-list builder with the torch_cluster option: strict d^2 < r^2, the `cap` smallest data indices per query --
+    against the host search with the same rule and (small slice) the literal restatement of the published kernel"""
+    from gaot_amd.model.layers.utils.neighbor_search import NeighborSearch, _exact_pairwise
+    from oracle import gaot_oracle as O
+    g = torch.Generator().manual_seed(n + m + cap)
+    data = (torch.rand(n, d, generator=g) * 2 - 1)
+    q = (torch.rand(m, d, generator=g) * 2.6 - 1.3)
+    ns = NeighborSearch("torch_cluster") if cap == 32 else NeighborSearch("torch_cluster", max_num_neighbors=cap)
+    got = ns(data.to(dev()), q.to(dev()), r)
+    deg = got["neighbors_row_splits"][1:] - got["neighbors_row_splits"][:-1]
+    assert int(deg.max()) == cap and int((deg == cap).sum()) > 10           # the cap binds on many rows
+    ref = _exact_pairwise(data, q, torch.tensor(r), False, cap, True)
+    # squared distances within rounding of r^2 may fall either side (fused vs separate multiply-add): compare as sets off the boundary
+    if not (torch.equal(got["neighbors_row_splits"].cpu(), ref["neighbors_row_splits"]) and torch.equal(got["neighbors_index"].cpu(), ref["neighbors_index"])):
+        gi, gs, ri, rs = got["neighbors_index"].cpu(), got["neighbors_row_splits"].cpu(), ref["neighbors_index"], ref["neighbors_row_splits"]
+        bad = 0
+        for i in range(m):
+            a, b = set(gi[gs[i]:gs[i + 1]].tolist()), set(ri[rs[i]:rs[i + 1]].tolist())
+            for j in a ^ b:
+                bad += 1
+                full = ((data - q[i]) ** 2).sum(-1)
+                near = ((full - r * r).abs() < 1e-6 * r * r)
+                assert bool(near.any()), (i, j)                                # a boundary point shifted the first-`cap` window
+        assert bad < 20
+    idx, sp = O.radius_csr_torch_cluster(data, q[:64], r, cap)
+    assert torch.equal(got["neighbors_row_splits"][:65].cpu(), sp) and torch.equal(got["neighbors_index"][:int(sp[-1])].cpu(), idx)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,K,F", [(8192, 256, 1024), (300, 64, 132), (77, 32, 20), (1024, 96, 256)])
 def test_swiglu_ffn_fused_matches_unfused(M, K, F):
