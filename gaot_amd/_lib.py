@@ -41,11 +41,14 @@ PROTOTYPES = {
     "gaot_debug_set_gemm_glds": (C.c_int, [C.c_int]),
     "gaot_csr_prepare": (C.c_int, [_i, _i, C.c_int32, C.c_int32, C.c_int32, _i, _i, _i, _i, _s]),
     "gaot_csr_transpose": (C.c_int, [_i, C.c_int32, C.c_int32, _i, _i, _i, _s]),
-    "gaot_edge_attention_cosine": (C.c_int, [_f, _f, C.c_int32, _i, _i, C.c_int32, _f, _s]),
+    "gaot_guard_begin": (C.c_int, [_i, _s]),
+    "gaot_guard_compare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _i, _s]),
+    "gaot_guard_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _i, _s]),
+    "gaot_edge_attention_cosine": (C.c_int, [_f, _f, C.c_int32, _i, _i, C.c_int32, _f, _i, _s]),
     "gaot_segment_softmax_fwd": (C.c_int, [_f, _i, C.c_int32, _f, _s]),
     "gaot_segment_softmax_bwd": (C.c_int, [_f, _f, _i, C.c_int32, _f, _s]),
-    "gaot_edge_features": (C.c_int, [_f, _f, C.c_int32, _i, _i, C.c_int32, _f, _s]),
-    "gaot_geo_stats": (C.c_int, [_f, _f, C.c_int32, _i, _i, C.c_int32, _f, C.c_void_p, _s]),
+    "gaot_edge_features": (C.c_int, [_f, _f, C.c_int32, _i, _i, C.c_int32, _f, _i, _s]),
+    "gaot_geo_stats": (C.c_int, [_f, _f, C.c_int32, _i, _i, C.c_int32, _f, C.c_void_p, _i, _s]),
     "gaot_cells_build": (C.c_int, [_f, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_float, C.POINTER(C.c_int32), _i, _i, _i, _s]),
     "gaot_radius_count": (C.c_int, [_f, C.c_int32, _f, C.c_int32, C.c_float, C.POINTER(C.c_float), C.c_float, C.POINTER(C.c_int32),
                                     _i, _i, _i, _i, C.c_int32, C.c_int32, _s]),

@@ -92,3 +92,6 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 
 }  // namespace gaot
+
+// grid size for grid-stride kernels: ceil(n / per) workgroups, at least 1, at most cap
+static inline int cap_blocks(long n, int per, int cap) { long b = (n + per - 1) / per; return (int)(b > cap ? cap : (b < 1 ? 1 : b)); }

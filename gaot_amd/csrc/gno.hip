@@ -99,7 +99,8 @@ __device__ __forceinline__ float cos_score(const float* __restrict__ x, const fl
 }
 __global__ void edge_attention_cosine_kernel(const float* __restrict__ src, const float* __restrict__ qry, int dim,
                                              const int* __restrict__ idx, const int* __restrict__ sp, int Q,
-                                             float* __restrict__ attn) {
+                                             float* __restrict__ attn, const int* __restrict__ guard) {
+    if (guard && *guard == 0) return;
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= Q) return;
     const int b = sp[q], e = sp[q + 1];
@@ -142,7 +143,8 @@ __global__ void segment_softmax_bwd_kernel(const float* __restrict__ attn, const
 
 __global__ void edge_features_kernel(const float* __restrict__ src, const float* __restrict__ qry, int dim,
                                      const int* __restrict__ idx, const int* __restrict__ eq, int E,
-                                     float* __restrict__ feat) {
+                                     float* __restrict__ feat, const int* __restrict__ guard) {
+    if (guard && *guard == 0) return;
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int w = 2 * dim;
     if (gid >= (long)E * w) return;
@@ -200,8 +202,9 @@ __device__ void sym_eig_desc<3>(const double (&c)[3][3], double (&ev)[3]) {
 template <int DIM>
 __global__ void geo_stats_raw_kernel(const float* __restrict__ geom, const float* __restrict__ qry,
                                      const int* __restrict__ idx, const int* __restrict__ sp, int Q,
-                                     float* __restrict__ raw) {
+                                     float* __restrict__ raw, const int* __restrict__ guard) {
     constexpr int F = 3 + 2 * DIM;
+    if (guard && *guard == 0) return;
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= Q) return;
     float* o = raw + (long)q * F;
@@ -239,8 +242,9 @@ __global__ void geo_stats_raw_kernel(const float* __restrict__ geom, const float
 }
 // column sums (pass 0: sum x -> acc[f]; pass 1: sum (x-mean)^2 -> acc[F+f]) in fp64 via block reduce + atomics
 __global__ __launch_bounds__(256) void geo_colstat_kernel(const float* __restrict__ raw, int Q, int F, int pass,
-                                                          double* __restrict__ acc) {
+                                                          double* __restrict__ acc, const int* __restrict__ guard) {
     __shared__ double red[4];
+    if (guard && *guard == 0) return;
     for (int f = 0; f < F; ++f) {
         const double mean = pass ? acc[f] / Q : 0.0;
         double s = 0.0;
@@ -259,7 +263,9 @@ __global__ void zero_f64_kernel(double* p, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0.0;
 }
-__global__ void geo_standardise_kernel(float* __restrict__ raw, int Q, int F, const double* __restrict__ acc) {
+__global__ void geo_standardise_kernel(float* __restrict__ raw, int Q, int F, const double* __restrict__ acc,
+                                       const int* __restrict__ guard) {
+    if (guard && *guard == 0) return;
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long)Q * F) return;
     const int f = (int)(gid % F);
@@ -268,6 +274,25 @@ __global__ void geo_standardise_kernel(float* __restrict__ raw, int Q, int F, co
     float sd = (float)sqrt(acc[F + f] / (double)(Q - 1));
     if (sd < 1e-6f) sd = 1.0f;
     raw[gid] = (float)(((double)raw[gid] - mean) / (double)sd);
+}
+
+// ---------------------------------------------------------------------------------------------
+// content guard of the geometry caches: a caller that uploads the coordinates anew every step (the reference trainer,
+// static_trainer.py:167-170) hands over NEW tensors with the OLD bytes.  The plan keeps a copy of the bytes its cached arrays
+// were computed from; guard_compare raises *flag when the new bytes differ, guard_update refreshes the copy, and the plan
+// kernels above take the flag as `guard`: they return at once when it is 0.  Nothing is read back by the host.
+// ---------------------------------------------------------------------------------------------
+__global__ void guard_compare_kernel(const uint32_t* __restrict__ cur, const uint32_t* __restrict__ kept, long nwords,
+                                     int* __restrict__ flag) {
+    bool diff = false;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (long)gridDim.x * blockDim.x)
+        diff |= cur[i] != kept[i];
+    if (__any(diff) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+__global__ void guard_update_kernel(const uint32_t* __restrict__ cur, uint32_t* __restrict__ kept, long nwords,
+                                    const int* __restrict__ flag) {
+    if (*flag == 0) return;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (long)gridDim.x * blockDim.x) kept[i] = cur[i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -406,11 +431,12 @@ extern "C" int gaot_csr_transpose(const int32_t* index32, int32_t E, int32_t n_s
 }
 
 extern "C" int gaot_edge_attention_cosine(const float* src, const float* qry, int32_t dim, const int32_t* index32,
-                                          const int32_t* splits32, int32_t Q, float* attn, gaot_stream_t stream) {
+                                          const int32_t* splits32, int32_t Q, float* attn, const int32_t* guard,
+                                          gaot_stream_t stream) {
     GAOT_REQUIRE(src && qry && splits32 && dim > 0 && Q >= 0, "edge_attention_cosine: bad arguments");
     if (Q == 0) return GAOT_OK;
     hipLaunchKernelGGL(edge_attention_cosine_kernel, dim3(cdiv(Q, 128)), dim3(128), 0, ST(stream), src, qry, dim,
-                       index32, splits32, Q, attn);
+                       index32, splits32, Q, attn, guard);
     GAOT_CHECK_LAUNCH("gaot_edge_attention_cosine");
     return GAOT_OK;
 }
@@ -435,31 +461,59 @@ extern "C" int gaot_segment_softmax_bwd(const float* attn, const float* dattn, c
 }
 
 extern "C" int gaot_edge_features(const float* src, const float* qry, int32_t dim, const int32_t* index32,
-                                  const int32_t* edge_query, int32_t E, float* feat, gaot_stream_t stream) {
+                                  const int32_t* edge_query, int32_t E, float* feat, const int32_t* guard, gaot_stream_t stream) {
     GAOT_REQUIRE(dim > 0 && E >= 0, "edge_features: bad arguments");
     if (E == 0) return GAOT_OK;
     GAOT_REQUIRE(src && qry && index32 && edge_query && feat, "edge_features: null pointer");
     hipLaunchKernelGGL(edge_features_kernel, dim3(cdiv((long)E * 2 * dim, 256)), dim3(256), 0, ST(stream), src, qry, dim,
-                       index32, edge_query, E, feat);
+                       index32, edge_query, E, feat, guard);
     GAOT_CHECK_LAUNCH("gaot_edge_features");
     return GAOT_OK;
 }
 
 extern "C" int gaot_geo_stats(const float* geom, const float* qry, int32_t dim, const int32_t* index32,
-                              const int32_t* splits32, int32_t Q, float* stats, double* scratch, gaot_stream_t stream) {
+                              const int32_t* splits32, int32_t Q, float* stats, double* scratch, const int32_t* guard,
+                              gaot_stream_t stream) {
     GAOT_REQUIRE(dim == 2 || dim == 3, "geo_stats: coord dim must be 2 or 3 (got %d)", dim);
     GAOT_REQUIRE(geom && qry && splits32 && stats && scratch && Q > 0, "geo_stats: bad arguments");
     const int F = 3 + 2 * dim;
     if (dim == 2)
-        hipLaunchKernelGGL(geo_stats_raw_kernel<2>, dim3(cdiv(Q, 128)), dim3(128), 0, ST(stream), geom, qry, index32, splits32, Q, stats);
+        hipLaunchKernelGGL(geo_stats_raw_kernel<2>, dim3(cdiv(Q, 128)), dim3(128), 0, ST(stream), geom, qry, index32, splits32, Q, stats, guard);
     else
-        hipLaunchKernelGGL(geo_stats_raw_kernel<3>, dim3(cdiv(Q, 128)), dim3(128), 0, ST(stream), geom, qry, index32, splits32, Q, stats);
+        hipLaunchKernelGGL(geo_stats_raw_kernel<3>, dim3(cdiv(Q, 128)), dim3(128), 0, ST(stream), geom, qry, index32, splits32, Q, stats, guard);
     hipLaunchKernelGGL(zero_f64_kernel, dim3(1), dim3(64), 0, ST(stream), scratch, 2 * F);
     int nb = cdiv(Q, 256); if (nb > 256) nb = 256;
-    hipLaunchKernelGGL(geo_colstat_kernel, dim3(nb), dim3(256), 0, ST(stream), stats, Q, F, 0, scratch);
-    hipLaunchKernelGGL(geo_colstat_kernel, dim3(nb), dim3(256), 0, ST(stream), stats, Q, F, 1, scratch);
-    hipLaunchKernelGGL(geo_standardise_kernel, dim3(cdiv((long)Q * F, 256)), dim3(256), 0, ST(stream), stats, Q, F, scratch);
+    hipLaunchKernelGGL(geo_colstat_kernel, dim3(nb), dim3(256), 0, ST(stream), stats, Q, F, 0, scratch, guard);
+    hipLaunchKernelGGL(geo_colstat_kernel, dim3(nb), dim3(256), 0, ST(stream), stats, Q, F, 1, scratch, guard);
+    hipLaunchKernelGGL(geo_standardise_kernel, dim3(cdiv((long)Q * F, 256)), dim3(256), 0, ST(stream), stats, Q, F, scratch, guard);
     GAOT_CHECK_LAUNCH("gaot_geo_stats");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_guard_begin(int32_t* flag, gaot_stream_t stream) {
+    GAOT_REQUIRE(flag != nullptr, "guard_begin: null flag");
+    hipLaunchKernelGGL(zero_i32_kernel, dim3(1), dim3(64), 0, ST(stream), flag, 1);
+    GAOT_CHECK_LAUNCH("gaot_guard_begin");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_guard_compare(const void* current, const void* kept, int64_t nbytes, int32_t* flag, gaot_stream_t stream) {
+    GAOT_REQUIRE(current && kept && flag && nbytes >= 0 && nbytes % 4 == 0, "guard_compare: bad arguments (nbytes %% 4 == 0)");
+    if (nbytes == 0) return GAOT_OK;
+    const long nw = nbytes / 4;
+    hipLaunchKernelGGL(guard_compare_kernel, dim3(cap_blocks(nw, 256, 512)), dim3(256), 0, ST(stream), (const uint32_t*)current,
+                       (const uint32_t*)kept, nw, flag);
+    GAOT_CHECK_LAUNCH("gaot_guard_compare");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_guard_update(const void* current, void* kept, int64_t nbytes, const int32_t* flag, gaot_stream_t stream) {
+    GAOT_REQUIRE(current && kept && flag && nbytes >= 0 && nbytes % 4 == 0, "guard_update: bad arguments (nbytes %% 4 == 0)");
+    if (nbytes == 0) return GAOT_OK;
+    const long nw = nbytes / 4;
+    hipLaunchKernelGGL(guard_update_kernel, dim3(cap_blocks(nw, 256, 512)), dim3(256), 0, ST(stream), (const uint32_t*)current,
+                       (uint32_t*)kept, nw, flag);
+    GAOT_CHECK_LAUNCH("gaot_guard_update");
     return GAOT_OK;
 }
 

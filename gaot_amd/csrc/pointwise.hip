@@ -382,7 +382,6 @@ __global__ void patchify_vec_kernel(const float* __restrict__ in, float* __restr
 
 using namespace gaot;
 #define ST(s) reinterpret_cast<hipStream_t>(s)
-static inline int cap_blocks(long n, int per, int cap) { long b = (n + per - 1) / per; return (int)(b > cap ? cap : (b < 1 ? 1 : b)); }
 
 extern "C" int gaot_rmsnorm_fwd(const float* x, const float* w, int32_t M, int32_t D, float eps, float* y, float* rstd,
                                 gaot_stream_t stream) {

@@ -104,7 +104,7 @@ class AGNO(nn.Module):
         else:
             k = None
             if not torch.is_grad_enabled():      # rollouts: k_e depends on geometry + weights only -> reuse across steps
-                key = (id(feat), tuple(p._version for p in self.channel_mlp.parameters()), ops.weights_generation())
+                key = (id(feat), plan.epoch, tuple(p._version for p in self.channel_mlp.parameters()), ops.weights_generation())
                 hit = getattr(self, "_infer_k", None)
                 if hit is not None and hit[0] == key and hit[1] is feat:
                     k = hit[2]

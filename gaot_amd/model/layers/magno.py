@@ -147,7 +147,8 @@ class _MAGNOBase(nn.Module):
             key = None
             if not torch.is_grad_enabled() and nb is neighbors:
                 # inference (autoregressive rollouts): geometry and weights are fixed across steps -> keep the row bias
-                key = (id(nb), tuple(p._version for p in self.geoembed.parameters()), self.recovery.fcs[0].weight._version,
+                key = (id(nb), id(src_coord), src_coord._version, id(dst_coord), dst_coord._version,
+                       tuple(p._version for p in self.geoembed.parameters()), self.recovery.fcs[0].weight._version,
                        self.recovery.fcs[0].bias._version, ops.weights_generation())
                 hit = self._infer_cache.get("rowb")
                 if hit is not None and hit[0] == key and hit[1] is nb:
@@ -157,7 +158,7 @@ class _MAGNOBase(nn.Module):
                 rowb = self.geoembed(input_geom=src_coord, latent_queries=dst_coord, spatial_nbrs=nb,
                                      stats=stats if nb is neighbors else None, head=(w_geo, self.recovery.fcs[0].bias))
                 if key is not None:
-                    self._infer_cache["rowb"] = (key, nb, rowb)
+                    self._infer_cache["rowb"] = (key, nb, rowb, (src_coord, dst_coord))      # hold the tensors: ids stay unique
             if head is not None:
                 hw, hb = head
                 proj = (ops.linear(hw, w_agno.t()),              # [out, C] = W @ Wr1   (tiny)

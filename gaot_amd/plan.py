@@ -48,7 +48,8 @@ class GeometryPlan:
         self._inv_deg_edge: Optional[torch.Tensor] = None
         self._edge_query_long: Optional[torch.Tensor] = None
         self._index_long = index_i64
-        self._coord_cache: Dict[str, Tuple[tuple, torch.Tensor]] = {}
+        self._coord_cache: Dict[str, dict] = {}
+        self.epoch = 0                # bumped whenever a coordinate-derived array may have been refreshed in place
 
     # ---- lazily derived
     @property
@@ -69,46 +70,70 @@ class GeometryPlan:
             self._inv_deg_edge = inv[self.edge_query_long].contiguous() if self.E > 0 else inv.new_zeros(1)
         return self._inv_deg_edge
 
-    def _cached(self, name: str, tensors, build):
+    def _cached(self, name: str, tensors, alloc, compute):
+        """geometry-only array `name` derived from coordinate tensors.
+          * same tensor objects (and versions) as last time            -> the cached array, no launch;
+          * NEW objects of the same shape (a trainer that re-uploads the coordinates every step,
+            static_trainer.py:167-170)                                  -> device-side content guard: the bytes are compared
+            with the kept copy and the array is recomputed IN PLACE only if they differ -- no host synchronisation;
+          * otherwise                                                   -> fresh allocation and computation."""
         key = tuple((id(t), t._version) for t in tensors)
         hit = self._coord_cache.get(name)
-        if hit is not None and hit[0] == key:
-            return hit[2]
-        val = build()
-        self._coord_cache[name] = (key, tuple(tensors), val)   # hold the tensors: ids stay unique while cached
+        if hit is not None and hit["key"] == key:
+            return hit["val"]
+        lib = L.load()
+        if hit is not None and all(t.shape == k.shape and t.dtype == k.dtype and t.device == k.device for t, k in zip(tensors, hit["kept"])):
+            flag = hit["flag"]
+            cur = [t.contiguous() for t in tensors]
+            L.check(lib.gaot_guard_begin(_p(flag), _stream()), "gaot_guard_begin")
+            for t, k in zip(cur, hit["kept"]):
+                L.check(lib.gaot_guard_compare(_p(t), _p(k), t.numel() * t.element_size(), _p(flag), _stream()), "gaot_guard_compare")
+            for t, k in zip(cur, hit["kept"]):
+                L.check(lib.gaot_guard_update(_p(t), _p(k), t.numel() * t.element_size(), _p(flag), _stream()), "gaot_guard_update")
+            compute(hit["full"], cur, flag)
+            hit["key"], hit["hold"] = key, tuple(tensors)
+            self.epoch += 1           # dependants cached on the host (inference-time kernel values, row bias) must re-derive
+            return hit["val"]
+        cur = [t.contiguous() for t in tensors]
+        full, val = alloc(cur)
+        compute(full, cur, None)
+        self._coord_cache[name] = {"key": key, "hold": tuple(tensors), "val": val, "full": full,
+                                   "kept": [t.clone() for t in cur],
+                                   "flag": torch.zeros(1, dtype=torch.int32, device=cur[0].device)}
         return val
 
     def edge_features(self, src: torch.Tensor, qry: torch.Tensor) -> torch.Tensor:
         """[y_j, x_i] rows of the kernel MLP (agno.py:229)."""
-        def build():
-            s, q = src.contiguous(), qry.contiguous()
-            dim = s.shape[1]
-            feat = torch.empty(max(self.E, 1), 2 * dim, device=s.device, dtype=torch.float32)
-            L.check(L.load().gaot_edge_features(_p(s), _p(q), dim, _p(self.index), _p(self.edge_query), self.E, _p(feat),
-                                                _stream()), "gaot_edge_features")
-            return feat[:self.E]
-        return self._cached("feat", (src, qry), build)
+        def alloc(ts):
+            feat = torch.empty(max(self.E, 1), 2 * ts[0].shape[1], device=ts[0].device, dtype=torch.float32)
+            return feat, feat[:self.E]
+
+        def compute(feat, ts, guard):
+            L.check(L.load().gaot_edge_features(_p(ts[0]), _p(ts[1]), ts[0].shape[1], _p(self.index), _p(self.edge_query), self.E,
+                                                _p(feat), _p(guard), _stream()), "gaot_edge_features")
+        return self._cached("feat", (src, qry), alloc, compute)
 
     def cosine_attention(self, src: torch.Tensor, qry: torch.Tensor) -> torch.Tensor:
-        def build():
-            s, q = src.contiguous(), qry.contiguous()
-            attn = torch.zeros(max(self.E, 1), device=s.device, dtype=torch.float32)
-            L.check(L.load().gaot_edge_attention_cosine(_p(s), _p(q), s.shape[1], _p(self.index), _p(self.splits), self.Q,
-                                                        _p(attn), _stream()), "gaot_edge_attention_cosine")
-            return attn
-        return self._cached("cos", (src, qry), build)
+        def alloc(ts):
+            attn = torch.zeros(max(self.E, 1), device=ts[0].device, dtype=torch.float32)
+            return attn, attn
+
+        def compute(attn, ts, guard):
+            L.check(L.load().gaot_edge_attention_cosine(_p(ts[0]), _p(ts[1]), ts[0].shape[1], _p(self.index), _p(self.splits), self.Q,
+                                                        _p(attn), _p(guard), _stream()), "gaot_edge_attention_cosine")
+        return self._cached("cos", (src, qry), alloc, compute)
 
     def geo_stats(self, geom: torch.Tensor, qry: torch.Tensor) -> torch.Tensor:
-        def build():
-            g, q = geom.contiguous(), qry.contiguous()
-            dim = g.shape[1]
-            F = 3 + 2 * dim
-            stats = torch.empty(self.Q, F, device=g.device, dtype=torch.float32)
-            scratch = torch.empty(4 * F, device=g.device, dtype=torch.float64)
-            L.check(L.load().gaot_geo_stats(_p(g), _p(q), dim, _p(self.index), _p(self.splits), self.Q, _p(stats), _p(scratch),
-                                            _stream()), "gaot_geo_stats")
-            return stats
-        return self._cached("stats", (geom, qry), build)
+        def alloc(ts):
+            F = 3 + 2 * ts[0].shape[1]
+            stats = torch.empty(self.Q, F, device=ts[0].device, dtype=torch.float32)
+            return (stats, torch.empty(4 * F, device=ts[0].device, dtype=torch.float64)), stats
+
+        def compute(full, ts, guard):
+            stats, scratch = full
+            L.check(L.load().gaot_geo_stats(_p(ts[0]), _p(ts[1]), ts[0].shape[1], _p(self.index), _p(self.splits), self.Q, _p(stats),
+                                            _p(scratch), _p(guard), _stream()), "gaot_geo_stats")
+        return self._cached("stats", (geom, qry), alloc, compute)
 
 
 def plan_for(neighbors: dict, n_src: int) -> GeometryPlan:

@@ -99,11 +99,22 @@ int gaot_csr_prepare(const int64_t* index_i64, const int64_t* splits_i64, int32_
  * scratch: n_src+1 int32. */
 int gaot_csr_transpose(const int32_t* index32, int32_t E, int32_t n_src,
                        int32_t* t_splits, int32_t* t_edge, int32_t* scratch, gaot_stream_t stream);
+/* Content guard of the per-geometry caches.  The reference trainer uploads the (unchanged) coordinates anew every step
+ * (static_trainer.py:167-170), i.e. NEW tensors with the OLD bytes.  The plan keeps a copy of the bytes its cached arrays were
+ * computed from:
+ *   gaot_guard_begin(flag)                      *flag = 0
+ *   gaot_guard_compare(current, kept, n, flag)  *flag |= (current != kept)        (any number of operands)
+ *   gaot_guard_update(current, kept, n, flag)   if (*flag) kept = current
+ * and the plan kernels below take `guard` = that flag: with a non-null guard whose value is 0 they return immediately and the
+ * cached output stays; guard = NULL always computes.  Nothing is read back by the host (no synchronisation). */
+int gaot_guard_begin(int32_t* flag, gaot_stream_t stream);
+int gaot_guard_compare(const void* current, const void* kept, int64_t nbytes, int32_t* flag, gaot_stream_t stream);
+int gaot_guard_update(const void* current, void* kept, int64_t nbytes, const int32_t* flag, gaot_stream_t stream);
 /* cosine edge attention + segment softmax (agno.py:112-146, 211-224): attn[E].
  * src [n_src,dim], qry [Q,dim] are the (possibly node_pos_encoded) kernel coordinates. */
 int gaot_edge_attention_cosine(const float* src, const float* qry, int32_t dim,
                                const int32_t* index32, const int32_t* splits32, int32_t Q,
-                               float* attn, gaot_stream_t stream);
+                               float* attn, const int32_t* guard, gaot_stream_t stream);
 /* segment softmax of given scores (dot-product attention, agno.py:215-217,224): fwd and bwd.
  * bwd: dscore = attn * (dattn - sum_seg(attn*dattn)). */
 int gaot_segment_softmax_fwd(const float* score, const int32_t* splits32, int32_t Q, float* attn, gaot_stream_t stream);
@@ -112,12 +123,12 @@ int gaot_segment_softmax_bwd(const float* attn, const float* dattn, const int32_
 /* kernel-MLP input rows [y_j , x_i] (agno.py:188,206-207,229): feat[E, 2*dim]. */
 int gaot_edge_features(const float* src, const float* qry, int32_t dim,
                        const int32_t* index32, const int32_t* edge_query, int32_t E,
-                       float* feat, gaot_stream_t stream);
+                       float* feat, const int32_t* guard, gaot_stream_t stream);
 /* GeometricEmbedding statistics, standardised (gemb.py:83-171): stats[Q, 3+2*dim], dim in {2,3}.
  * scratch: 4*(3+2*dim) doubles. */
 int gaot_geo_stats(const float* geom, const float* qry, int32_t dim,
                    const int32_t* index32, const int32_t* splits32, int32_t Q,
-                   float* stats, double* scratch, gaot_stream_t stream);
+                   float* stats, double* scratch, const int32_t* guard, gaot_stream_t stream);
 
 /* radius graph by cell list (replaces NeighborSearch backends, neighbor_search.py:65-335; `dist <= r` inclusive,
  * unbounded degree, ascending data index per query like `_native_neighbor_search`).  origin[dim] / dims[dim] are HOST

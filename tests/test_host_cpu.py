@@ -29,7 +29,7 @@ def test_library_builds_loads_and_exports_header_symbols():
     from gaot_amd import _lib
     build(verbose=False)
     lib = _lib.load()
-    assert lib.gaot_abi_version() == 1
+    assert lib.gaot_abi_version() == 2
     header = open(os.path.join(ROOT, "include", "gaot_hip.h")).read()
     declared = set(re.findall(r"\b(gaot_[a-z0-9_]+)\s*\(", header))
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
