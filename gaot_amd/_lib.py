@@ -85,6 +85,21 @@ PROTOTYPES = {
     "gaot_mse_loss_bwd": (C.c_int, [_f, _f, C.c_int64, _f, _f, _s]),
     "gaot_adamw_step": (C.c_int, [_f, _f, _f, _f, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _f, _s]),
     "gaot_adamw_step_dev": (C.c_int, [_f, _f, _f, _f, C.c_int64, _f, _f, _s]),
+    "gaot_rope_inplace": (C.c_int, [_f, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _f, C.c_int32, _s]),
+    "gaot_edge_dot_score": (C.c_int, [_f, _f, C.c_int32, _i, _i, C.c_int32, C.c_float, _f, _s]),
+    "gaot_edge_rowdot_scale": (C.c_int, [_f, _f, _f, C.c_int32, C.c_int32, _f, _s]),
+    "gaot_segment_max_fwd": (C.c_int, [_f, C.c_int32, _i, C.c_int32, _f, _s]),
+    "gaot_segment_max_bwd": (C.c_int, [_f, _f, _f, C.c_int32, _i, C.c_int32, _f, _s]),
+    "gaot_segment_broadcast": (C.c_int, [_f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i, _f, _f, _s]),
+    "gaot_scale_mix_fwd": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, _f, C.c_int32, C.c_int32, C.c_int32, _f, _s]),
+    "gaot_scale_mix_bwd": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, _f, C.c_int32, C.c_int32, C.c_int32, _f, _f, _s]),
+    "gaot_edge_cat": (C.c_int, [_f, C.c_int32, _f, C.c_int32, C.c_int32, C.c_int32, _i, C.c_int32, _f, _s]),
+    "gaot_gno_bk_reduce": (C.c_int, [_f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i, _i, C.c_int32, _f, C.c_int32, _f, _s]),
+    "gaot_gno_bk_backward": (C.c_int, [_f, _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i, _i, _i, _i, _f,
+                                       C.c_int32, _f, _f, _f, _s]),
+    "gaot_cond_affine_fwd": (C.c_int, [_f, _f, _f, C.c_int32, C.c_int64, C.c_int32, _f, _s]),
+    "gaot_cond_affine_bwd_chunks": (C.c_int32, [C.c_int64]),
+    "gaot_cond_affine_bwd": (C.c_int, [_f, _f, _f, C.c_int32, C.c_int64, C.c_int32, _f, _f, _s]),
     "gaot_patchify": (C.c_int, [_f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f, C.c_int32, _s]),
 }
 

@@ -1,0 +1,456 @@
+// Small HBM-bound kernels for the operator variants off the default configuration: rotary position
+// embedding, dot-product edge scores, PointNet max pooling, per-edge broadcast, multiscale mixing, and the batched-kernel
+// ('nonlinear') integral transform.  One pass over the big operand each, lanes along the contiguous (channel) dimension,
+// 16-byte accesses where the shapes allow, no atomics (deterministic), no allocation, no synchronisation.
+#include "common.h"
+
+namespace gaot {
+
+// ---------------------------------------------------------------------------------------------
+// RoPE (attn.py:106-108 -> rotary_embedding_torch.RotaryEmbedding(dim=head_dim).rotate_queries_or_keys):
+// position = sequence index, pairs (2i, 2i+1) of every head rotated by pos * theta^(-2i/D).  In place on the first
+// `n_heads` heads of each row of the fused projection output [B*S, ld]; cs = [S, D/2] (cos, sin) interleaved.
+// inverse = 1 applies the transposed rotation (the backward of an orthogonal map).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rope_kernel(float* __restrict__ x, long rows, int S, long ld, int n_heads, int D,
+                                                   const float2* __restrict__ cs, int inverse) {
+    const int half = D / 2;
+    const long per_row = (long)n_heads * half;
+    const long total = rows * per_row;
+    for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long)gridDim.x * blockDim.x) {
+        const long row = gid / per_row;
+        const int rem = (int)(gid % per_row);
+        const int h = rem / half, i = rem % half;
+        const int s = (int)(row % S);
+        const float2 c = cs[(long)s * half + i];
+        const float sn = inverse ? -c.y : c.y;
+        float2* p = reinterpret_cast<float2*>(x + row * ld + (long)h * D) + i;
+        const float2 v = *p;
+        // t * cos + rotate_half(t) * sin with rotate_half(x0, x1) = (-x1, x0); products rounded before the sum like the reference
+        float2 o;
+        o.x = __fadd_rn(__fmul_rn(v.x, c.x), __fmul_rn(-v.y, sn));
+        o.y = __fadd_rn(__fmul_rn(v.y, c.x), __fmul_rn(v.x, sn));
+        *p = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dot-product edge score (agno.py:215-217): score[e] = scale * <qn[eq[e], :], kn[idx[e], :]>, C channels (64 in the reference).
+// 16 lanes per edge when C == 64 (one float4 each), DPP-free butterfly over the lane group.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void edge_dot_kernel(const float* __restrict__ qn, const float* __restrict__ kn, int C,
+                                                       const int* __restrict__ idx, const int* __restrict__ eq, int E, float scale,
+                                                       float* __restrict__ score, int lanes) {
+    const int per_block = 256 / lanes;
+    const int e = blockIdx.x * per_block + threadIdx.x / lanes;
+    const int l = threadIdx.x % lanes;
+    float acc = 0.f;
+    if (e < E) {
+        const float* a = qn + (long)eq[e] * C;
+        const float* b = kn + (long)idx[e] * C;
+        for (int c = l; c < C; c += lanes) acc += a[c] * b[c];
+    }
+    for (int off = lanes >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (e < E && l == 0) score[e] = acc * scale;
+}
+
+// ---------------------------------------------------------------------------------------------
+// segment max pooling over edge rows (PointNet geoembed, gemb.py:217): out[q, c] = max_{e in seg(q)} h[e, c]; empty -> 0.
+// backward: the gradient of (q, c) is shared EVENLY by the edges that attain the maximum (the semantics of the stand-in the
+// golden vectors were made with, torch scatter_reduce(amax); ties are common: ReLU outputs that are all zero).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void segment_max_fwd_kernel(const float* __restrict__ h, int C, const int* __restrict__ sp, int Q,
+                                                              float* __restrict__ out) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)Q * C) return;
+    const int q = (int)(gid / C), c = (int)(gid % C);
+    const int b = sp[q], e = sp[q + 1];
+    float m = 0.f;
+    if (e > b) {
+        m = h[(long)b * C + c];
+        for (int t = b + 1; t < e; ++t) m = fmaxf(m, h[(long)t * C + c]);
+    }
+    out[gid] = m;
+}
+__global__ __launch_bounds__(256) void segment_max_bwd_kernel(const float* __restrict__ h, const float* __restrict__ out,
+                                                              const float* __restrict__ dout, int C, const int* __restrict__ sp, int Q,
+                                                              float* __restrict__ dh) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)Q * C) return;
+    const int q = (int)(gid / C), c = (int)(gid % C);
+    const int b = sp[q], e = sp[q + 1];
+    if (e == b) return;
+    const float m = out[gid];
+    int ties = 0;
+    for (int t = b; t < e; ++t) ties += (h[(long)t * C + c] == m) ? 1 : 0;
+    const float g = dout[gid] / (float)ties;
+    for (int t = b; t < e; ++t) dh[(long)t * C + c] = (h[(long)t * C + c] == m) ? g : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-edge broadcast (backward of the plain segment sum): dx[b, e, :] = rowscale[eq[e]] * dout[b, eq[e], :]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void segment_broadcast_kernel(const float* __restrict__ dout, int B, int E, int C, int Q,
+                                                                const int* __restrict__ eq, const float* __restrict__ rowscale,
+                                                                float* __restrict__ dx) {
+    const long total = (long)B * E * C;
+    for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(gid % C);
+        const long be = gid / C;
+        const int e = (int)(be % E);
+        const long b = be / E;
+        const int q = eq[e];
+        const float s = rowscale ? rowscale[q] : 1.0f;
+        dx[gid] = s * dout[(b * Q + q) * C + c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// multiscale mixing (magno.py:291-303): out[b, q, :] = sum_i w[q, i] * t_i[b, q, :]  (w == nullptr: plain mean over scales)
+// backward: dt_i = w[q, i] * dout;  dw[q, i] = sum_b sum_c dout[b, q, c] * t_i[b, q, c]   (one wave per query row)
+// ---------------------------------------------------------------------------------------------
+struct ScalePtrs { const float* t[8]; float* d[8]; };
+
+__global__ __launch_bounds__(256) void scale_mix_fwd_kernel(ScalePtrs p, int n, const float* __restrict__ w, int B, int Q, int C,
+                                                            float* __restrict__ out) {
+    const long total = (long)B * Q * C;
+    const float inv = 1.0f / (float)n;
+    for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long)gridDim.x * blockDim.x) {
+        const int q = (int)((gid / C) % Q);
+        float acc = 0.f;
+        if (w) { for (int i = 0; i < n; ++i) acc += w[(long)q * n + i] * p.t[i][gid]; }
+        else { for (int i = 0; i < n; ++i) acc += p.t[i][gid]; acc *= inv; }       // torch.stack(...).mean(0)
+        out[gid] = acc;
+    }
+}
+__global__ __launch_bounds__(256) void scale_mix_bwd_kernel(ScalePtrs p, int n, const float* __restrict__ w, int B, int Q, int C,
+                                                            const float* __restrict__ dout, float* __restrict__ dw) {
+    // one wave per query row q: lanes stride over (b, c)
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (q >= Q) return;
+    const float inv = 1.0f / (float)n;
+    float acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (int b = 0; b < B; ++b)
+        for (int c = lane; c < C; c += 64) {
+            const long off = ((long)b * Q + q) * C + c;
+            const float g = dout[off];
+            for (int i = 0; i < n; ++i) {
+                if (dw) acc[i] += g * p.t[i][off];
+                if (p.d[i]) p.d[i][off] = (w ? w[(long)q * n + i] : inv) * g;
+            }
+        }
+    if (dw)
+        for (int i = 0; i < n; ++i) {
+            const float s = wave_sum(acc[i]);
+            if (lane == 0) dw[(long)q * n + i] = s;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 'nonlinear' transforms (agno.py:230-271): the kernel MLP sees f(y_j), so kernel values are per SAMPLE, k[b, e, :].
+//   edge_cat      : rows of the kernel MLP  x[b, e, :] = [feat[e, :W0], f[b, idx[e], :C]]
+//   bk_reduce     : out[b, q, :] = sum_{e in seg(q)} a_e * k[b, e, :] * (MUL ? f[b, idx[e], :] : 1)
+//   bk_edge_grad  : dk[b, e, :] = a_e * dout[b, eq[e], :] * (MUL ? f[b, idx[e], :] : 1)
+//   bk_src_grad   : df[b, j, :] = sum_{e : idx[e] = j} ( MUL ? a_e * k[b, e, :] * dout[b, eq[e], :] : 0 ) + dx[b, e, W0:]   (transposed CSR)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void edge_cat_kernel(const float* __restrict__ feat, int W0, const float* __restrict__ f, int B,
+                                                       int n_src, int C, const int* __restrict__ idx, int E, float* __restrict__ x) {
+    const int W = W0 + C;
+    const long total = (long)B * E * W;
+    for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(gid % W);
+        const long be = gid / W;
+        const int e = (int)(be % E);
+        const long b = be / E;
+        x[gid] = c < W0 ? feat[(long)e * W0 + c] : f[(b * n_src + idx[e]) * C + (c - W0)];
+    }
+}
+template <bool MUL>
+__global__ __launch_bounds__(256) void bk_reduce_kernel(const float* __restrict__ k, const float* __restrict__ f, int B, int n_src,
+                                                        int C, int E, const int* __restrict__ sp, const int* __restrict__ idx, int Q,
+                                                        const float* __restrict__ a, float* __restrict__ out) {
+    const long total = (long)B * Q * C;
+    for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(gid % C);
+        const long bq = gid / C;
+        const int q = (int)(bq % Q);
+        const long b = bq / Q;
+        float acc = 0.f;
+        for (int t = sp[q]; t < sp[q + 1]; ++t) {
+            float v = k[(b * E + t) * C + c];
+            if (MUL) v *= f[(b * n_src + idx[t]) * C + c];
+            acc += (a ? a[t] : 1.0f) * v;
+        }
+        out[gid] = acc;
+    }
+}
+template <bool MUL>
+__global__ __launch_bounds__(256) void bk_edge_grad_kernel(const float* __restrict__ dout, const float* __restrict__ f, int B, int n_src,
+                                                           int C, int E, int Q, const int* __restrict__ idx, const int* __restrict__ eq,
+                                                           const float* __restrict__ a, float* __restrict__ dk) {
+    const long total = (long)B * E * C;
+    for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(gid % C);
+        const long be = gid / C;
+        const int e = (int)(be % E);
+        const long b = be / E;
+        float v = (a ? a[e] : 1.0f) * dout[(b * Q + eq[e]) * C + c];
+        if (MUL) v *= f[(b * n_src + idx[e]) * C + c];
+        dk[gid] = v;
+    }
+}
+template <bool MUL>
+__global__ __launch_bounds__(256) void bk_src_grad_kernel(const float* __restrict__ dout, const float* __restrict__ k,
+                                                          const float* __restrict__ dx, int W0, int B, int n_src, int C, int E, int Q,
+                                                          const int* __restrict__ tsp, const int* __restrict__ tedge,
+                                                          const int* __restrict__ eq, const float* __restrict__ a,
+                                                          float* __restrict__ df) {
+    const int W = W0 + C;
+    const long total = (long)B * n_src * C;
+    for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(gid % C);
+        const long bj = gid / C;
+        const int j = (int)(bj % n_src);
+        const long b = bj / n_src;
+        float acc = 0.f;
+        for (int t = tsp[j]; t < tsp[j + 1]; ++t) {
+            const int e = tedge[t];
+            if (MUL) acc += (a ? a[e] : 1.0f) * k[(b * E + e) * C + c] * dout[(b * Q + eq[e]) * C + c];
+            if (dx) acc += dx[(b * E + e) * W + W0 + c];
+        }
+        df[gid] = acc;
+    }
+}
+// da[e] = sum_b sum_c dout[b, eq[e], c] * k[b, e, c] * (MUL ? f[b, idx[e], c] : 1)       (learned attention only)
+template <bool MUL>
+__global__ __launch_bounds__(256) void bk_scale_grad_kernel(const float* __restrict__ dout, const float* __restrict__ k,
+                                                            const float* __restrict__ f, int B, int n_src, int C, int E, int Q,
+                                                            const int* __restrict__ idx, const int* __restrict__ eq,
+                                                            float* __restrict__ da) {
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (e >= E) return;
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b)
+        for (int c = lane; c < C; c += 64) {
+            float v = dout[((long)b * Q + eq[e]) * C + c] * k[((long)b * E + e) * C + c];
+            if (MUL) v *= f[((long)b * n_src + idx[e]) * C + c];
+            acc += v;
+        }
+    acc = wave_sum(acc);
+    if (lane == 0) da[e] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ConditionedNorm (mlp.py:74-124): y[b, s, :] = x[b, s, :] * scale[b, :] + shift[b, :]
+// backward: dx = dy * scale;  dscale[b, :] = sum_s dy * x;  dshift[b, :] = sum_s dy      (partials over row chunks, summed by the caller)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cond_affine_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, int B, long S, int D, float* __restrict__ y) {
+    const long total = (long)B * S * D;
+    for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long)gridDim.x * blockDim.x) {
+        const int d = (int)(gid % D);
+        const long b = gid / (S * D);
+        y[gid] = x[gid] * scale[b * D + d] + shift[b * D + d];
+    }
+}
+// grid (chunks, B); block 256 threads = D-strided lanes; part[(chunk * B + b) * 2 * D + {0..D-1: dscale, D..2D-1: dshift}]
+__global__ __launch_bounds__(256) void cond_affine_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              const float* __restrict__ scale, int B, long S, int D, int rows_per_chunk,
+                                                              float* __restrict__ dx, float* __restrict__ part) {
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const long s0 = (long)chunk * rows_per_chunk, s1 = min(S, s0 + rows_per_chunk);
+    for (int d = threadIdx.x; d < D; d += 256) {
+        const float sc = scale[(long)b * D + d];
+        float a0 = 0.f, a1 = 0.f;
+        for (long s = s0; s < s1; ++s) {
+            const long off = ((long)b * S + s) * D + d;
+            const float g = dy[off];
+            a0 += g * x[off];
+            a1 += g;
+            dx[off] = g * sc;
+        }
+        float* o = part + ((long)chunk * B + b) * 2 * D;
+        o[d] = a0;
+        o[D + d] = a1;
+    }
+}
+
+}  // namespace gaot
+
+using namespace gaot;
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int gaot_rope_inplace(float* x, int32_t B, int32_t S, int64_t ld, int32_t n_heads, int32_t head_dim, const float* cos_sin,
+                                 int32_t inverse, gaot_stream_t stream) {
+    GAOT_REQUIRE(x && cos_sin && B > 0 && S > 0 && n_heads > 0 && head_dim > 0 && head_dim % 2 == 0, "rope: bad arguments (head_dim even)");
+    GAOT_REQUIRE(ld >= (int64_t)n_heads * head_dim && ld % 2 == 0 && (reinterpret_cast<uintptr_t>(x) & 7u) == 0 &&
+                 (reinterpret_cast<uintptr_t>(cos_sin) & 7u) == 0, "rope: rows must hold n_heads*head_dim floats, 8-byte aligned");
+    const long total = (long)B * S * n_heads * (head_dim / 2);
+    hipLaunchKernelGGL(rope_kernel, dim3(cap_blocks(total, 256, 8192)), dim3(256), 0, ST(stream), x, (long)B * S, S, (long)ld, n_heads,
+                       head_dim, reinterpret_cast<const float2*>(cos_sin), inverse);
+    GAOT_CHECK_LAUNCH("gaot_rope_inplace");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_edge_dot_score(const float* qn, const float* kn, int32_t C, const int32_t* index32, const int32_t* edge_query,
+                                   int32_t E, float scale, float* score, gaot_stream_t stream) {
+    GAOT_REQUIRE(C > 0 && E >= 0, "edge_dot_score: bad arguments");
+    if (E == 0) return GAOT_OK;
+    GAOT_REQUIRE(qn && kn && index32 && edge_query && score, "edge_dot_score: null pointer");
+    int lanes = 1;
+    while (lanes < 64 && lanes * 4 < C) lanes <<= 1;
+    hipLaunchKernelGGL(edge_dot_kernel, dim3(cdiv(E, 256 / lanes)), dim3(256), 0, ST(stream), qn, kn, C, index32, edge_query, E, scale,
+                       score, lanes);
+    GAOT_CHECK_LAUNCH("gaot_edge_dot_score");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_segment_max_fwd(const float* h, int32_t C, const int32_t* splits32, int32_t Q, float* out, gaot_stream_t stream) {
+    GAOT_REQUIRE(splits32 && out && C > 0 && Q >= 0, "segment_max_fwd: bad arguments");
+    if (Q == 0) return GAOT_OK;
+    hipLaunchKernelGGL(segment_max_fwd_kernel, dim3(cdiv((long)Q * C, 256)), dim3(256), 0, ST(stream), h, C, splits32, Q, out);
+    GAOT_CHECK_LAUNCH("gaot_segment_max_fwd");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_segment_max_bwd(const float* h, const float* out, const float* dout, int32_t C, const int32_t* splits32, int32_t Q,
+                                    float* dh, gaot_stream_t stream) {
+    GAOT_REQUIRE(splits32 && out && dout && C > 0 && Q >= 0, "segment_max_bwd: bad arguments");
+    if (Q == 0) return GAOT_OK;
+    hipLaunchKernelGGL(segment_max_bwd_kernel, dim3(cdiv((long)Q * C, 256)), dim3(256), 0, ST(stream), h, out, dout, C, splits32, Q, dh);
+    GAOT_CHECK_LAUNCH("gaot_segment_max_bwd");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_segment_broadcast(const float* dout, int32_t B, int32_t E, int32_t C, int32_t Q, const int32_t* edge_query,
+                                      const float* rowscale, float* dx, gaot_stream_t stream) {
+    GAOT_REQUIRE(B > 0 && E >= 0 && C > 0 && Q >= 0, "segment_broadcast: bad arguments");
+    if (E == 0) return GAOT_OK;
+    GAOT_REQUIRE(dout && edge_query && dx, "segment_broadcast: null pointer");
+    hipLaunchKernelGGL(segment_broadcast_kernel, dim3(cap_blocks((long)B * E * C, 256, 8192)), dim3(256), 0, ST(stream), dout, B, E, C, Q,
+                       edge_query, rowscale, dx);
+    GAOT_CHECK_LAUNCH("gaot_segment_broadcast");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_scale_mix_fwd(const float* const* scales, int32_t n, const float* w, int32_t B, int32_t Q, int32_t C, float* out,
+                                  gaot_stream_t stream) {
+    GAOT_REQUIRE(scales && out && n >= 1 && n <= 8 && B > 0 && Q > 0 && C > 0, "scale_mix_fwd: 1..8 scales");
+    ScalePtrs p;
+    for (int i = 0; i < 8; ++i) { p.t[i] = i < n ? scales[i] : nullptr; p.d[i] = nullptr; }
+    hipLaunchKernelGGL(scale_mix_fwd_kernel, dim3(cap_blocks((long)B * Q * C, 256, 8192)), dim3(256), 0, ST(stream), p, n, w, B, Q, C, out);
+    GAOT_CHECK_LAUNCH("gaot_scale_mix_fwd");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_scale_mix_bwd(const float* const* scales, float* const* dscales, int32_t n, const float* w, int32_t B, int32_t Q,
+                                  int32_t C, const float* dout, float* dw, gaot_stream_t stream) {
+    GAOT_REQUIRE(scales && dscales && dout && n >= 1 && n <= 8 && B > 0 && Q > 0 && C > 0, "scale_mix_bwd: 1..8 scales");
+    ScalePtrs p;
+    for (int i = 0; i < 8; ++i) { p.t[i] = i < n ? scales[i] : nullptr; p.d[i] = i < n ? dscales[i] : nullptr; }
+    hipLaunchKernelGGL(scale_mix_bwd_kernel, dim3(cdiv(Q, 4)), dim3(256), 0, ST(stream), p, n, w, B, Q, C, dout, dw);
+    GAOT_CHECK_LAUNCH("gaot_scale_mix_bwd");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_edge_cat(const float* feat, int32_t W0, const float* f, int32_t B, int32_t n_src, int32_t C, const int32_t* index32,
+                             int32_t E, float* x, gaot_stream_t stream) {
+    GAOT_REQUIRE(W0 >= 0 && B > 0 && C > 0 && E >= 0, "edge_cat: bad arguments");
+    if (E == 0) return GAOT_OK;
+    GAOT_REQUIRE(f && index32 && x && (W0 == 0 || feat), "edge_cat: null pointer");
+    hipLaunchKernelGGL(edge_cat_kernel, dim3(cap_blocks((long)B * E * (W0 + C), 256, 8192)), dim3(256), 0, ST(stream), feat, W0, f, B,
+                       n_src, C, index32, E, x);
+    GAOT_CHECK_LAUNCH("gaot_edge_cat");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_gno_bk_reduce(const float* k, const float* f, int32_t B, int32_t n_src, int32_t C, int32_t E, const int32_t* splits32,
+                                  const int32_t* index32, int32_t Q, const float* escale, int32_t mul_f, float* out, gaot_stream_t stream) {
+    GAOT_REQUIRE(splits32 && out && B > 0 && C > 0 && Q >= 0 && E >= 0 && (!mul_f || f), "gno_bk_reduce: bad arguments");
+    if (Q == 0) return GAOT_OK;
+    const dim3 grid(cap_blocks((long)B * Q * C, 256, 16384));
+    if (mul_f) hipLaunchKernelGGL(bk_reduce_kernel<true>, grid, dim3(256), 0, ST(stream), k, f, B, n_src, C, E, splits32, index32, Q, escale, out);
+    else hipLaunchKernelGGL(bk_reduce_kernel<false>, grid, dim3(256), 0, ST(stream), k, f, B, n_src, C, E, splits32, index32, Q, escale, out);
+    GAOT_CHECK_LAUNCH("gaot_gno_bk_reduce");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_gno_bk_backward(const float* dout, const float* k, const float* f, const float* dx, int32_t W0, int32_t B, int32_t n_src,
+                                    int32_t C, int32_t E, int32_t Q, const int32_t* index32, const int32_t* edge_query,
+                                    const int32_t* t_splits, const int32_t* t_edge, const float* escale, int32_t mul_f, float* dk,
+                                    float* df, float* dscale, gaot_stream_t stream) {
+    GAOT_REQUIRE(dout && B > 0 && C > 0 && E >= 0 && Q >= 0 && n_src > 0, "gno_bk_backward: bad arguments");
+    if (E == 0) return GAOT_OK;
+    if (dk) {
+        const dim3 grid(cap_blocks((long)B * E * C, 256, 16384));
+        if (mul_f) hipLaunchKernelGGL(bk_edge_grad_kernel<true>, grid, dim3(256), 0, ST(stream), dout, f, B, n_src, C, E, Q, index32, edge_query, escale, dk);
+        else hipLaunchKernelGGL(bk_edge_grad_kernel<false>, grid, dim3(256), 0, ST(stream), dout, f, B, n_src, C, E, Q, index32, edge_query, escale, dk);
+    }
+    if (df) {
+        GAOT_REQUIRE(t_splits && t_edge, "gno_bk_backward: df needs the transposed CSR");
+        const dim3 grid(cap_blocks((long)B * n_src * C, 256, 16384));
+        if (mul_f) hipLaunchKernelGGL(bk_src_grad_kernel<true>, grid, dim3(256), 0, ST(stream), dout, k, dx, W0, B, n_src, C, E, Q, t_splits, t_edge, edge_query, escale, df);
+        else hipLaunchKernelGGL(bk_src_grad_kernel<false>, grid, dim3(256), 0, ST(stream), dout, k, dx, W0, B, n_src, C, E, Q, t_splits, t_edge, edge_query, escale, df);
+    }
+    if (dscale) {
+        if (mul_f) hipLaunchKernelGGL(bk_scale_grad_kernel<true>, dim3(cdiv(E, 4)), dim3(256), 0, ST(stream), dout, k, f, B, n_src, C, E, Q, index32, edge_query, dscale);
+        else hipLaunchKernelGGL(bk_scale_grad_kernel<false>, dim3(cdiv(E, 4)), dim3(256), 0, ST(stream), dout, k, f, B, n_src, C, E, Q, index32, edge_query, dscale);
+    }
+    GAOT_CHECK_LAUNCH("gaot_gno_bk_backward");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_cond_affine_fwd(const float* x, const float* scale, const float* shift, int32_t B, int64_t S, int32_t D, float* y,
+                                    gaot_stream_t stream) {
+    GAOT_REQUIRE(x && scale && shift && y && B > 0 && S > 0 && D > 0, "cond_affine_fwd: bad arguments");
+    hipLaunchKernelGGL(cond_affine_fwd_kernel, dim3(cap_blocks((long)B * S * D, 256, 8192)), dim3(256), 0, ST(stream), x, scale, shift, B,
+                       (long)S, D, y);
+    GAOT_CHECK_LAUNCH("gaot_cond_affine_fwd");
+    return GAOT_OK;
+}
+
+extern "C" int32_t gaot_cond_affine_bwd_chunks(int64_t S) { return (int32_t)(S >= 4096 ? 64 : (S >= 256 ? 16 : 1)); }
+
+extern "C" int gaot_cond_affine_bwd(const float* x, const float* dy, const float* scale, int32_t B, int64_t S, int32_t D, float* dx,
+                                    float* part, gaot_stream_t stream) {
+    GAOT_REQUIRE(x && dy && scale && dx && part && B > 0 && S > 0 && D > 0, "cond_affine_bwd: bad arguments");
+    const int chunks = gaot_cond_affine_bwd_chunks(S);
+    const int rows = (int)((S + chunks - 1) / chunks);
+    hipLaunchKernelGGL(cond_affine_bwd_kernel, dim3(chunks, B), dim3(256), 0, ST(stream), x, dy, scale, B, (long)S, D, rows, dx, part);
+    GAOT_CHECK_LAUNCH("gaot_cond_affine_bwd");
+    return GAOT_OK;
+}
+
+// da[e] = <T[e,:], k[e,:]>;  T[e,:] *= a[e]   (learned attention in the linear transform: T = sum_b dOut (*) f from gaot_gno_edge_grad)
+namespace gaot {
+__global__ __launch_bounds__(256) void edge_rowdot_scale_kernel(float* __restrict__ T, const float* __restrict__ k, const float* __restrict__ a,
+                                                                int E, int C, float* __restrict__ da, int lanes) {
+    const int per_block = 256 / lanes;
+    const int e = blockIdx.x * per_block + threadIdx.x / lanes;
+    const int l = threadIdx.x % lanes;
+    float acc = 0.f;
+    const float ae = e < E ? a[e] : 0.f;
+    if (e < E)
+        for (int c = l; c < C; c += lanes) {
+            const float t = T[(long)e * C + c];
+            acc += t * k[(long)e * C + c];
+            T[(long)e * C + c] = t * ae;
+        }
+    for (int off = lanes >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (e < E && l == 0) da[e] = acc;
+}
+}  // namespace gaot
+
+extern "C" int gaot_edge_rowdot_scale(float* T, const float* k, const float* a, int32_t E, int32_t C, float* da, gaot_stream_t stream) {
+    GAOT_REQUIRE(C > 0 && E >= 0, "edge_rowdot_scale: bad arguments");
+    if (E == 0) return GAOT_OK;
+    GAOT_REQUIRE(T && k && a && da, "edge_rowdot_scale: null pointer");
+    int lanes = 1;
+    while (lanes < 64 && lanes * 4 < C) lanes <<= 1;
+    hipLaunchKernelGGL(gaot::edge_rowdot_scale_kernel, dim3(cdiv(E, 256 / lanes)), dim3(256), 0, ST(stream), T, k, a, E, C, da, lanes);
+    GAOT_CHECK_LAUNCH("gaot_edge_rowdot_scale");
+    return GAOT_OK;
+}

@@ -91,7 +91,8 @@ class GAOT(nn.Module):
             tok = ops.linear(tok, self.patch_linear.weight, self.patch_linear.bias, rowbias=self._pos_emb(tok.device, tok.shape[-1]))
             rel = None
         elif self.positional_embedding_name == 'rope':
-            raise NotImplementedError("rope positional embedding is not built (SURVEY 8f rank 4)")
+            tok = ops.linear(tok, self.patch_linear.weight, self.patch_linear.bias)
+            rel = self.positions                      # gaot.py:217-218: only its presence matters downstream
         else:
             raise ValueError(f"unknown positional_embedding {self.positional_embedding_name!r}")
         tok = self.processor(tok, condition=condition, relative_positions=rel)

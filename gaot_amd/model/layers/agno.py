@@ -59,8 +59,7 @@ class AGNO(nn.Module):
                 # <Wq x_i + bq, Wk y_j + bk> / 8: project the NODES (small GEMMs), gather per edge, segment softmax
                 qn = ops.linear(xs, self.query_proj.weight, self.query_proj.bias)
                 kn = ops.linear(ys, self.key_proj.weight, self.key_proj.bias)
-                score = (qn[plan.edge_query_long] * kn[plan.index_long]).sum(-1) * self.scaling_factor
-                a = ops.segment_softmax(score, plan)
+                a = ops.segment_softmax(ops.edge_dot_score(qn, kn, plan, self.scaling_factor), plan)
         if weights is not None:
             assert weights.ndim == 1, "Weights must be of dimension 1 in all cases"
             wq = weights[plan.index_long]
@@ -93,14 +92,8 @@ class AGNO(nn.Module):
 
         if f3 is not None and self.transform_type in ("nonlinear", "nonlinear_kernelonly"):
             # kernel sees f(y_j): k is [B,E,C]; a batched GEMM chain over B*E rows, then a plain segment sum
-            B = f3.shape[0]
-            fj = f3[:, plan.index_long, :]
-            k = self.channel_mlp(torch.cat([feat[None].expand(B, -1, -1), fj], dim=-1))
-            if self.transform_type == "nonlinear":
-                k = k * fj
-            if a is not None:
-                k = k * a[None, :plan.E, None]
-            out = ops.segment_sum(k, plan)
+            k = self.channel_mlp(ops.edge_cat(feat, f3, plan))                # [B, E, C]: rows [y_j, x_i, f(y_j)] per sample
+            out = ops.nonlinear_transform(k, f3, plan, a, self.transform_type == "nonlinear")
         else:
             k = None
             if not torch.is_grad_enabled():      # rollouts: k_e depends on geometry + weights only -> reuse across steps

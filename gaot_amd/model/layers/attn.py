@@ -54,6 +54,27 @@ class RMSNorm(nn.Module):
         return ops.rms_norm(x, self.weight, self.eps)
 
 
+class RotaryEmbedding(nn.Module):
+    """State and angles of `rotary_embedding_torch.RotaryEmbedding(dim=head_dim)` as the reference constructs it
+    (attn.py:75-76; library defaults freqs_for='lang', theta=10000, learned_freq=False): `freqs` is a non-trainable
+    nn.Parameter (so it appears in the state_dict as `...attn.rotary_emb.freqs`), position = sequence index.
+    The dependency is not vendored or pinned by the reference: restated from its published source, parity unpinned."""
+
+    def __init__(self, dim: int, theta: float = 10000.0):
+        super().__init__()
+        freqs = 1.0 / (theta ** (torch.arange(0, dim, 2)[:dim // 2].float() / dim))
+        self.freqs = nn.Parameter(freqs, requires_grad=False)
+        self._table = None
+
+    def cos_sin(self, S: int, device) -> torch.Tensor:
+        """[S, dim/2, 2] (cos, sin) of pos * freqs: no learnable input, built once per (S, device, freqs version)"""
+        key = (S, device, self.freqs._version)
+        if self._table is None or self._table[0] != key:
+            ang = torch.arange(S, device=device, dtype=torch.float32)[:, None] * self.freqs.to(device)[None, :]
+            self._table = (key, torch.stack([ang.cos(), ang.sin()], dim=-1).contiguous())
+        return self._table[1]
+
+
 class GroupQueryFlashAttention(nn.Module):
     """q/k/v projection as ONE GEMM over the concatenated weights, fp32 flash attention, o_proj with the block's
     residual fused into its epilogue (attn.py:78-119)."""
@@ -76,18 +97,21 @@ class GroupQueryFlashAttention(nn.Module):
         self.o_proj = nn.Linear(hidden_size, input_size, bias=False)
         self.correction = ConditionedNorm(1, input_size, cond_norm_hidden_size) if use_conditional_norm else None
         if positional_embedding == "rope":
-            raise NotImplementedError("rotary embedding is outside the built path (SURVEY 8f rank 4); use 'absolute'")
+            if self.head_dim % 2:
+                raise ValueError("rope needs an even head_dim")
+            self.rotary_emb = RotaryEmbedding(dim=self.head_dim)
         if self.head_dim > 64:
             raise NotImplementedError("attention kernel supports head_dim <= 64")
 
     def forward(self, x, condition=None, relative_positions=None, residual=None):
-        if relative_positions is not None:
-            raise NotImplementedError("rope positions are not supported")
         if self.training and self.atten_dropout > 0.0:
             raise NotImplementedError("attention dropout > 0 is not supported by the HIP attention kernel")
         if self.correction is not None:
             x = self.correction(c=condition, x=x)
         qkv = ops.linear_cat(x, [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight])
+        if relative_positions is not None:       # the reference only tests for None: the rotation angle is the SEQUENCE index
+            qkv = ops.rope_(qkv.contiguous(), self.num_heads + self.num_kv_heads, self.head_dim,
+                            self.rotary_emb.cos_sin(qkv.shape[-2], qkv.device))
         o = ops.attention(qkv, self.num_heads, self.num_kv_heads, self.head_dim)
         return ops.linear(o, self.o_proj.weight, residual=residual)
 

@@ -64,8 +64,6 @@ class GeometricEmbedding(nn.Module):
         if self.pooling == 'mean':
             pooled = ops.segment_sum(h[None], plan, 1.0 / plan.deg.clamp(min=1).to(torch.float32))[0]
         else:
-            qid = plan.edge_query_long
-            pooled = torch.zeros(Q, h.shape[1], device=h.device, dtype=h.dtype).scatter_reduce(
-                0, qid[:, None].expand_as(h), h, reduce="amax", include_self=False)
+            pooled = ops.segment_max(h, plan)
         emb = ops.mlp_chain(pooled, [self.fc[0].weight], [self.fc[0].bias], ["relu"])
         return torch.where((plan.deg > 0)[:, None], emb, out)

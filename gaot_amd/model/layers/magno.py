@@ -181,13 +181,7 @@ class _MAGNOBase(nn.Module):
     def _combine(self, per_scale: List[torch.Tensor], weights: Optional[torch.Tensor]) -> torch.Tensor:
         if len(per_scale) == 1:
             return per_scale[0]
-        if self.use_scale_weights:
-            acc = None
-            for i, t in enumerate(per_scale):
-                term = weights[None, :, i:i + 1] * t
-                acc = term if acc is None else acc + term
-            return acc
-        return torch.stack(per_scale, dim=0).mean(dim=0)
+        return ops.scale_mix(per_scale, weights if self.use_scale_weights else None)
 
     def _all_scales(self, mode, src, dst, feats, nbrs, head=None, lift=None):
         """`lift` = (pn, W, b) replaces `feats` = W pn + b (encoder): the lifting is folded into the transform kernels."""

@@ -587,10 +587,9 @@ class _GNOTransform(torch.autograd.Function):
             dk = torch.empty_like(k)
             L.check(lib.gaot_gno_edge_grad(_p(dout), _p(f), B, plan.Q, n_src, Cc, _p(plan.index), _p(plan.edge_query),
                                            plan.E, None if need_a else _p(esc), _p(dk), _stream()), "gaot_gno_edge_grad")
-            if need_a:      # d/da_e = <sum_b dOut*f , k_e> ; then dk_e = a_e * (sum_b dOut*f)
+            if need_a:      # d/da_e = <sum_b dOut*f , k_e> ; then dk_e = a_e * (sum_b dOut*f): one pass over the [E,C] rows
                 da = torch.zeros_like(esc)
-                da[:plan.E] = (dk * k).sum(-1)
-                dk = dk * esc[:plan.E, None]
+                L.check(lib.gaot_edge_rowdot_scale(_p(dk), _p(k), _p(esc), plan.E, Cc, _p(da), _stream()), "gaot_edge_rowdot_scale")
         if ctx.needs_input_grad[1]:
             df = gno_gather_reduce(k, dout, plan.t_splits, plan.edge_query, plan.t_edge, n_src, esc)
         return dk, df, None, da
@@ -751,18 +750,252 @@ class _SegmentSum(torch.autograd.Function):
                 "gaot_gno_segment_sum")
         ctx.plan = plan
         ctx.rowscale = rowscale
+        ctx.E = E
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        g = dout
-        if ctx.rowscale is not None:
-            g = g * ctx.rowscale[None, :, None]
-        return g[:, ctx.plan.edge_query_long, :], None, None
+        plan = ctx.plan
+        dout = dout.contiguous()
+        B, _, Cc = dout.shape
+        dx = torch.empty(B, ctx.E, Cc, device=dout.device, dtype=torch.float32)
+        L.check(L.load().gaot_segment_broadcast(_p(dout), B, ctx.E, Cc, plan.Q, _p(plan.edge_query), _p(ctx.rowscale), _p(dx), _stream()),
+                "gaot_segment_broadcast")
+        return dx, None, None
 
 
 def segment_sum(x, plan, rowscale=None):
     return _SegmentSum.apply(x, plan, rowscale)
+
+
+class _EdgeDotScore(torch.autograd.Function):
+    """score[e] = scale * <qn[query(e)], kn[j(e)]>  (dot-product attention, agno.py:215-217): one gather-dot kernel; the two
+    node gradients are segment reductions over the CSR / transposed CSR (no atomics)."""
+
+    @staticmethod
+    def forward(ctx, qn, kn, plan, scale):
+        _dev(qn, kn)
+        qn, kn = qn.contiguous(), kn.contiguous()
+        score = torch.zeros(max(plan.E, 1), device=qn.device, dtype=torch.float32)
+        L.check(L.load().gaot_edge_dot_score(_p(qn), _p(kn), qn.shape[1], _p(plan.index), _p(plan.edge_query), plan.E, float(scale),
+                                             _p(score), _stream()), "gaot_edge_dot_score")
+        ctx.plan, ctx.scale = plan, float(scale)
+        ctx.save_for_backward(qn, kn)
+        return score
+
+    @staticmethod
+    def backward(ctx, ds):
+        qn, kn = ctx.saved_tensors
+        plan = ctx.plan
+        ds = (ds * ctx.scale).contiguous()
+        dqn = gno_gather_reduce(None, kn[None], plan.splits, plan.index, None, plan.Q, ds)[0]
+        dkn = gno_gather_reduce(None, qn[None], plan.t_splits, plan.edge_query, plan.t_edge, plan.n_src, ds)[0]
+        return dqn, dkn, None, None
+
+
+def edge_dot_score(qn, kn, plan, scale):
+    return _EdgeDotScore.apply(qn, kn, plan, scale)
+
+
+class _SegmentMax(torch.autograd.Function):
+    """PointNet pooling (gemb.py:217): per-query maximum over the edge rows, 0 for queries without neighbours."""
+
+    @staticmethod
+    def forward(ctx, h, plan):
+        _dev(h)
+        h = h.contiguous()
+        out = torch.empty(plan.Q, h.shape[1], device=h.device, dtype=torch.float32)
+        L.check(L.load().gaot_segment_max_fwd(_p(h), h.shape[1], _p(plan.splits), plan.Q, _p(out), _stream()), "gaot_segment_max_fwd")
+        ctx.plan = plan
+        ctx.save_for_backward(h, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        h, out = ctx.saved_tensors
+        dh = torch.empty_like(h)
+        L.check(L.load().gaot_segment_max_bwd(_p(h), _p(out), _p(dout.contiguous()), h.shape[1], _p(ctx.plan.splits), ctx.plan.Q, _p(dh),
+                                              _stream()), "gaot_segment_max_bwd")
+        return dh, None
+
+
+def segment_max(h, plan):
+    return _SegmentMax.apply(h, plan)
+
+
+def _ptr_array(ts):
+    arr = (C.c_void_p * len(ts))()
+    for i, t in enumerate(ts):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+class _ScaleMix(torch.autograd.Function):
+    """multiscale combination (magno.py:291-303): sum_i w[q,i] * t_i, or the plain mean over scales when w is None"""
+
+    @staticmethod
+    def forward(ctx, w, *ts):
+        _dev(*ts)
+        ts = [t.contiguous() for t in ts]
+        B, Q, Cc = ts[0].shape
+        wc = w.contiguous() if w is not None else None
+        out = torch.empty_like(ts[0])
+        L.check(L.load().gaot_scale_mix_fwd(_ptr_array(ts), len(ts), _p(wc), B, Q, Cc, _p(out), _stream()), "gaot_scale_mix_fwd")
+        ctx.save_for_backward(*ts, *( [wc] if wc is not None else []))
+        ctx.n, ctx.has_w = len(ts), wc is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        sv = ctx.saved_tensors
+        ts, wc = list(sv[:ctx.n]), (sv[ctx.n] if ctx.has_w else None)
+        B, Q, Cc = ts[0].shape
+        dout = dout.contiguous()
+        dts = [torch.empty_like(t) if ctx.needs_input_grad[1 + i] else None for i, t in enumerate(ts)]
+        dw = torch.empty_like(wc) if (ctx.has_w and ctx.needs_input_grad[0]) else None
+        L.check(L.load().gaot_scale_mix_bwd(_ptr_array(ts), _ptr_array(dts), ctx.n, _p(wc), B, Q, Cc, _p(dout), _p(dw), _stream()),
+                "gaot_scale_mix_bwd")
+        return (dw, *dts)
+
+
+def scale_mix(ts, w=None):
+    return _ScaleMix.apply(w, *ts)
+
+
+class _NonlinearTransform(torch.autograd.Function):
+    """'nonlinear' / 'nonlinear_kernelonly' integral transform (agno.py:230-271) around a caller-supplied kernel MLP:
+    out[b,q,:] = sum_e a_e k[b,e,:] (*) f[b,j(e),:]   with k = MLP([y_j, x_i, f(y_j)]) evaluated per sample.
+    This Function covers the two ends (the gather+concat that builds the MLP rows is `edge_cat`, the product/reduction is
+    here); the MLP in between is the ordinary HIP GEMM chain with its own autograd."""
+
+    @staticmethod
+    def forward(ctx, k, f, plan, escale, mul_f):
+        _dev(k, f)
+        k, f = k.contiguous(), f.contiguous()
+        B, n_src, Cc = f.shape
+        out = torch.empty(B, plan.Q, Cc, device=k.device, dtype=torch.float32)
+        L.check(L.load().gaot_gno_bk_reduce(_p(k), _p(f), B, n_src, Cc, plan.E, _p(plan.splits), _p(plan.index), plan.Q, _p(escale),
+                                            int(mul_f), _p(out), _stream()), "gaot_gno_bk_reduce")
+        ctx.plan, ctx.mul_f = plan, bool(mul_f)
+        ctx.save_for_backward(k, f, escale if escale is not None else k.new_empty(0))
+        ctx.has_e = escale is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        k, f, esc = ctx.saved_tensors
+        esc = esc if ctx.has_e else None
+        plan = ctx.plan
+        B, n_src, Cc = f.shape
+        dout = dout.contiguous()
+        need = ctx.needs_input_grad
+        dk = torch.empty_like(k) if need[0] else None
+        df = torch.empty_like(f) if (need[1] and ctx.mul_f) else None
+        da = torch.zeros_like(esc) if (ctx.has_e and need[3]) else None
+        if plan.E == 0:
+            return (dk.zero_() if dk is not None else None), (df.zero_() if df is not None else None), None, da, None
+        L.check(L.load().gaot_gno_bk_backward(_p(dout), _p(k), _p(f), None, 0, B, n_src, Cc, plan.E, plan.Q, _p(plan.index), _p(plan.edge_query),
+                                              _p(plan.t_splits), _p(plan.t_edge), _p(esc), int(ctx.mul_f), _p(dk), _p(df), _p(da), _stream()),
+                "gaot_gno_bk_backward")
+        return dk, df, None, da, None
+
+
+def nonlinear_transform(k, f, plan, escale, mul_f: bool):
+    return _NonlinearTransform.apply(k, f, plan, escale, mul_f)
+
+
+class _EdgeCat(torch.autograd.Function):
+    """rows of the 'nonlinear' kernel MLP: x[b,e,:] = [feat[e,:], f[b,j(e),:]]; backward sums the f-slice of the row gradients
+    per source node over the transposed CSR (feat carries no gradient: geometry only)."""
+
+    @staticmethod
+    def forward(ctx, feat, f, plan):
+        _dev(feat, f)
+        feat, f = feat.contiguous(), f.contiguous()
+        B, n_src, Cc = f.shape
+        W0 = feat.shape[1]
+        x = torch.empty(B, plan.E, W0 + Cc, device=f.device, dtype=torch.float32)
+        L.check(L.load().gaot_edge_cat(_p(feat), W0, _p(f), B, n_src, Cc, _p(plan.index), plan.E, _p(x), _stream()), "gaot_edge_cat")
+        ctx.plan, ctx.dims = plan, (B, n_src, Cc, W0)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        plan = ctx.plan
+        B, n_src, Cc, W0 = ctx.dims
+        dx = dx.contiguous()
+        df = torch.empty(B, n_src, Cc, device=dx.device, dtype=torch.float32)
+        if plan.E == 0:
+            return None, df.zero_(), None
+        L.check(L.load().gaot_gno_bk_backward(_p(dx), None, None, _p(dx), W0, B, n_src, Cc, plan.E, plan.Q, _p(plan.index), _p(plan.edge_query),
+                                              _p(plan.t_splits), _p(plan.t_edge), None, 0, None, _p(df), None, _stream()), "gaot_gno_bk_backward")
+        return None, df, None
+
+
+def edge_cat(feat, f, plan):
+    return _EdgeCat.apply(feat, f, plan)
+
+
+class _CondAffine(torch.autograd.Function):
+    """ConditionedNorm's modulation (mlp.py:118-124): y[b,s,:] = x[b,s,:] * scale[b,:] + shift[b,:]"""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift):
+        _dev(x, scale, shift)
+        x, scale, shift = x.contiguous(), scale.contiguous(), shift.contiguous()
+        B, D = scale.shape
+        S = x.numel() // (B * D)
+        y = torch.empty_like(x)
+        L.check(L.load().gaot_cond_affine_fwd(_p(x), _p(scale), _p(shift), B, S, D, _p(y), _stream()), "gaot_cond_affine_fwd")
+        ctx.save_for_backward(x, scale)
+        ctx.dims = (B, S, D)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, scale = ctx.saved_tensors
+        B, S, D = ctx.dims
+        lib = L.load()
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        chunks = int(lib.gaot_cond_affine_bwd_chunks(S))
+        part = torch.empty(chunks, B, 2 * D, device=x.device, dtype=torch.float32)
+        L.check(lib.gaot_cond_affine_bwd(_p(x), _p(dy), _p(scale), B, S, D, _p(dx), _p(part), _stream()), "gaot_cond_affine_bwd")
+        sums = batchsum(part, chunks) if chunks > 1 else part[0]
+        return dx, sums[:, :D], sums[:, D:]
+
+
+def cond_affine(x, scale, shift):
+    return _CondAffine.apply(x, scale, shift)
+
+
+class _Rope(torch.autograd.Function):
+    """rotary embedding of q and k IN PLACE on the fused projection output (attn.py:106-108); an orthogonal map, so the backward
+    is the transposed rotation of the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, qkv, n_heads, D, cos_sin):
+        _dev(qkv, cos_sin)
+        assert qkv.is_contiguous() and qkv.dim() == 3
+        B, S, W = qkv.shape
+        L.check(L.load().gaot_rope_inplace(_p(qkv), B, S, W, n_heads, D, _p(cos_sin), 0, _stream()), "gaot_rope_inplace")
+        ctx.mark_dirty(qkv)
+        ctx.args = (n_heads, D)
+        ctx.save_for_backward(cos_sin)
+        return qkv
+
+    @staticmethod
+    def backward(ctx, g):
+        (cos_sin,) = ctx.saved_tensors
+        n_heads, D = ctx.args
+        g = g.contiguous().clone()
+        B, S, W = g.shape
+        L.check(L.load().gaot_rope_inplace(_p(g), B, S, W, n_heads, D, _p(cos_sin), 1, _stream()), "gaot_rope_inplace")
+        return g, None, None, None
+
+
+def rope_(qkv, n_heads, D, cos_sin):
+    return _Rope.apply(qkv, n_heads, D, cos_sin)
 
 
 # --------------------------------------------------------------------------------------------

@@ -272,6 +272,58 @@ int gaot_adamw_step_dev(float* p, const float* g, float* m, float* v, int64_t n,
 int gaot_patchify(const float* in, int32_t B, int32_t H, int32_t W, int32_t Dz, int32_t P, int32_t C,
                   float* out, int32_t inverse, gaot_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Operator variants off the default configuration (csrc/glue.hip).
+ * ------------------------------------------------------------------------------------------ */
+/* RoPE on queries and keys (attn.py:106-108; rotary_embedding_torch.RotaryEmbedding(dim=head_dim).rotate_queries_or_keys: the
+ * position is the SEQUENCE INDEX, pairs (2i, 2i+1) of a head are rotated by pos * theta^(-2i/head_dim)).  In place on the first
+ * n_heads heads of every row of x [B*S, ld] (the fused q|k|v projection output: n_heads = H + H_kv).
+ * cos_sin [S, head_dim/2, 2] = (cos, sin) of the angles.  inverse = 1: the transposed rotation (backward pass). */
+int gaot_rope_inplace(float* x, int32_t B, int32_t S, int64_t ld, int32_t n_heads, int32_t head_dim, const float* cos_sin,
+                      int32_t inverse, gaot_stream_t stream);
+/* dot-product attention scores (agno.py:215-217): score[e] = scale * <qn[edge_query[e], :], kn[index[e], :]>, qn [Q,C], kn [n_src,C]. */
+int gaot_edge_dot_score(const float* qn, const float* kn, int32_t C, const int32_t* index32, const int32_t* edge_query,
+                        int32_t E, float scale, float* score, gaot_stream_t stream);
+/* learned attention through the linear transform: with T[e,:] = sum_b dOut[b,eq[e],:] * f[b,index[e],:] (gaot_gno_edge_grad without a
+ * scale), da[e] = <T[e,:], k[e,:]> and T[e,:] *= a[e] in place (T becomes dk). */
+int gaot_edge_rowdot_scale(float* T, const float* k, const float* a, int32_t E, int32_t C, float* da, gaot_stream_t stream);
+/* PointNet pooling (gemb.py:217, scatter_max): out[q,c] = max over the CSR segment of h[e,c], 0 for an empty segment;
+ * backward shares the gradient evenly among the edges attaining the maximum. */
+int gaot_segment_max_fwd(const float* h, int32_t C, const int32_t* splits32, int32_t Q, float* out, gaot_stream_t stream);
+int gaot_segment_max_bwd(const float* h, const float* out, const float* dout, int32_t C, const int32_t* splits32, int32_t Q,
+                         float* dh, gaot_stream_t stream);
+/* backward of gaot_gno_segment_sum: dx[b,e,:] = rowscale[edge_query[e]] * dout[b, edge_query[e], :]. */
+int gaot_segment_broadcast(const float* dout, int32_t B, int32_t E, int32_t C, int32_t Q, const int32_t* edge_query,
+                           const float* rowscale, float* dx, gaot_stream_t stream);
+/* multiscale mixing (magno.py:291-303): out = sum_i w[q,i] * scales[i][b,q,:] (w NULL: mean over the n <= 8 scales);
+ * backward: dscales[i] = w[q,i] * dout (NULL entries skipped), dw[q,i] = sum_{b,c} dout * scales[i] (dw NULL: skipped).
+ * `scales` / `dscales` are HOST arrays of device pointers. */
+int gaot_scale_mix_fwd(const float* const* scales, int32_t n, const float* w, int32_t B, int32_t Q, int32_t C, float* out,
+                       gaot_stream_t stream);
+int gaot_scale_mix_bwd(const float* const* scales, float* const* dscales, int32_t n, const float* w, int32_t B, int32_t Q,
+                       int32_t C, const float* dout, float* dw, gaot_stream_t stream);
+/* 'nonlinear' / 'nonlinear_kernelonly' transforms (agno.py:230-271): kernel values per sample, k [B,E,C].
+ *   gaot_edge_cat      x[b,e,:] = [feat[e,:W0], f[b,index[e],:C]]                       (rows of the kernel MLP)
+ *   gaot_gno_bk_reduce out[b,q,:] = sum_{e in seg(q)} escale[e] * k[b,e,:] * (mul_f ? f[b,index[e],:] : 1)
+ *   gaot_gno_bk_backward  dk[b,e,:] = escale[e] * dout[b,eq[e],:] * (mul_f ? f : 1);
+ *                         df[b,j,:] = sum_{e: index[e]=j} (mul_f ? escale[e] k dout : 0) + dx[b,e,W0:]   (dx = gradient of the MLP rows, may be NULL);
+ *                         dscale[e] = sum_{b,c} dout * k * (mul_f ? f : 1)              (NULL outputs are skipped) */
+int gaot_edge_cat(const float* feat, int32_t W0, const float* f, int32_t B, int32_t n_src, int32_t C, const int32_t* index32,
+                  int32_t E, float* x, gaot_stream_t stream);
+int gaot_gno_bk_reduce(const float* k, const float* f, int32_t B, int32_t n_src, int32_t C, int32_t E, const int32_t* splits32,
+                       const int32_t* index32, int32_t Q, const float* escale, int32_t mul_f, float* out, gaot_stream_t stream);
+int gaot_gno_bk_backward(const float* dout, const float* k, const float* f, const float* dx, int32_t W0, int32_t B, int32_t n_src,
+                         int32_t C, int32_t E, int32_t Q, const int32_t* index32, const int32_t* edge_query,
+                         const int32_t* t_splits, const int32_t* t_edge, const float* escale, int32_t mul_f, float* dk,
+                         float* df, float* dscale, gaot_stream_t stream);
+/* ConditionedNorm (mlp.py:74-124): y[b,s,:] = x[b,s,:] * scale[b,:] + shift[b,:]; backward writes dx and per-chunk partial sums
+ * part[chunks, B, 2*D] = (sum_s dy*x | sum_s dy) with chunks = gaot_cond_affine_bwd_chunks(S). */
+int gaot_cond_affine_fwd(const float* x, const float* scale, const float* shift, int32_t B, int64_t S, int32_t D, float* y,
+                         gaot_stream_t stream);
+int32_t gaot_cond_affine_bwd_chunks(int64_t S);
+int gaot_cond_affine_bwd(const float* x, const float* dy, const float* scale, int32_t B, int64_t S, int32_t D, float* dx,
+                         float* part, gaot_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

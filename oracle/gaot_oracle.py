@@ -459,6 +459,21 @@ def cond_norm(sd, prefix: str, c: Tensor, x: Tensor) -> Tensor:
     return x * sc[:, None, :] + bi[:, None, :]
 
 
+def rotate_queries_or_keys(t: Tensor, freqs: Tensor) -> Tensor:
+    """`RotaryEmbedding(dim=head_dim).rotate_queries_or_keys(t)` as called at attn.py:106-108 on [B, heads, S, head_dim].
+    The package (lucidrains/rotary-embedding-torch) is a runtime dependency the reference neither vendors nor pins and it is
+    absent here: PARITY UNPINNED for this function; restated from its published source --
+      freqs = 1 / theta^(arange(0, dim, 2) / dim), theta = 10000       (freqs_for='lang'; a non-trainable nn.Parameter)
+      angle[s, 2i] = angle[s, 2i+1] = s * freqs[i]                      (positions = arange(seq_len); repeat '... n -> ... (n r)', r=2)
+      out = t * cos(angle) + rotate_half(t) * sin(angle),   rotate_half: (x_{2i}, x_{2i+1}) -> (-x_{2i+1}, x_{2i})."""
+    S = t.shape[-2]
+    ang = torch.arange(S, dtype=t.dtype)[:, None] * freqs[None, :]
+    ang = ang.repeat_interleave(2, dim=-1)
+    x = t.reshape(*t.shape[:-1], -1, 2)
+    rot = torch.stack((-x[..., 1], x[..., 0]), dim=-1).reshape(t.shape)
+    return t * ang.cos() + rot * ang.sin()
+
+
 def attention(sd, prefix: str, cfg: OracleConfig, x: Tensor, condition) -> Tensor:
     """GroupQueryFlashAttention.forward (attn.py:78-119), softmax attention written out."""
     if cfg.use_conditional_norm:
@@ -475,6 +490,9 @@ def attention(sd, prefix: str, cfg: OracleConfig, x: Tensor, condition) -> Tenso
     if Hkv != H:
         k = k.repeat_interleave(H // Hkv, dim=1)
         v = v.repeat_interleave(H // Hkv, dim=1)
+    if cfg.positional_embedding == "rope":                              # attn.py:106-108
+        q = rotate_queries_or_keys(q, sd[f"{prefix}.rotary_emb.freqs"])
+        k = rotate_queries_or_keys(k, sd[f"{prefix}.rotary_emb.freqs"])
     p = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(dh), dim=-1)
     o = (p @ v).transpose(1, 2).reshape(B, S, H * dh)
     return o @ sd[f"{prefix}.o_proj.weight"].t()
@@ -525,9 +543,10 @@ def process(sd, cfg: OracleConfig, rndata: Tensor, condition=None, rec: Optional
     P, C = cfg.patch_size, rndata.shape[2]
     tok = patchify(rndata, cfg.latent_tokens_size, P)
     tok = tok @ sd["patch_linear.weight"].t() + sd["patch_linear.bias"]   # gaot.py:208
-    if cfg.positional_embedding != "absolute":
-        raise NotImplementedError("oracle restates the default 'absolute' embedding only")
-    tok = tok + absolute_pos_embedding(patch_positions(cfg.latent_tokens_size, P), tok.shape[-1])
+    if cfg.positional_embedding == "absolute":                            # gaot.py:212-216
+        tok = tok + absolute_pos_embedding(patch_positions(cfg.latent_tokens_size, P), tok.shape[-1])
+    elif cfg.positional_embedding != "rope":                              # gaot.py:217-218: rope acts inside attention
+        raise ValueError(cfg.positional_embedding)
     if rec is not None:
         rec["proc.tokens"] = tok.detach()
     tok = transformer(sd, cfg, tok, condition, rec)
@@ -564,19 +583,21 @@ def train_step(sd: Dict[str, Tensor], cfg: OracleConfig, batch: dict, lr: float 
                weight_decay: float = 1e-5, state: Optional[dict] = None, return_pred: bool = False):
     """One step: zero_grad -> forward -> MSE(mean) -> backward -> AdamW.
     Returns (loss, grads, new_sd, state) (+ the prediction when return_pred)."""
-    params = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+    params = {k: v.detach().clone().requires_grad_(not k.endswith("rotary_emb.freqs")) for k, v in sd.items()}
     pred = gaot_forward(params, cfg, batch["latent"], batch["xcoord"], batch["pndata"],
                         batch.get("query_coord"), batch.get("encoder_nbrs"), batch.get("decoder_nbrs"),
                         batch.get("condition"))
     loss = torch.mean((pred - batch["target"]) ** 2)
-    names = list(params.keys())
+    names = [k for k in params if params[k].requires_grad]                # rotary_emb.freqs is a frozen parameter
     gs = torch.autograd.grad(loss, [params[k] for k in names], allow_unused=True)
     grads = {k: (g if g is not None else torch.zeros_like(params[k])) for k, g in zip(names, gs)}
+    frozen = [k for k in params if not params[k].requires_grad]
+    grads.update({k: torch.zeros_like(params[k]) for k in frozen})        # the reference reports no gradient for them
     if state is None:
         state = {"step": 0, "m": {k: torch.zeros_like(v) for k, v in sd.items()},
                  "v": {k: torch.zeros_like(v) for k, v in sd.items()}}
     state["step"] += 1
-    new_sd = {}
+    new_sd = {k: sd[k] for k in frozen}                                   # torch.optim.AdamW skips parameters without a gradient
     for k in names:
         p, m, v = adamw_update(sd[k].detach(), grads[k], state["m"][k], state["v"][k], state["step"], lr, weight_decay)
         new_sd[k], state["m"][k], state["v"][k] = p, m, v
@@ -688,6 +709,9 @@ def make_state_dict(cfg: OracleConfig, input_size: int, output_size: int, seed: 
         lin(f"{b}.attn.k_proj", kvd, D, bias=False)
         lin(f"{b}.attn.v_proj", kvd, D, bias=False)
         lin(f"{b}.attn.o_proj", D, D, bias=False)
+        if cfg.positional_embedding == "rope":
+            hd = D // cfg.num_heads
+            sd[f"{b}.attn.rotary_emb.freqs"] = 1.0 / (10000.0 ** (torch.arange(0, hd, 2)[:hd // 2].float() / hd))
         lin(f"{b}.ffn.w1", D * cfg.ffn_multiplier, D, bias=False)
         lin(f"{b}.ffn.w2", D, D * cfg.ffn_multiplier, bias=False)
         lin(f"{b}.ffn.w3", D * cfg.ffn_multiplier, D, bias=False)

@@ -11,7 +11,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 MODEL_CASES = ["fx2d_base", "fx2d_base_s1", "fx2d_zero_deg", "fx2d_headdim32", "fx2d_inproj", "vx2d",
                "ms_mean", "ms_weighted", "attn_dot", "no_attn_mean", "no_geoembed", "nonlinear",
-               "node_embed", "pointnet", "fx3d", "even_layers"]
+               "node_embed", "pointnet", "fx3d", "even_layers", "linear_kernelonly", "nonlinear_kernelonly", "rope", "pointnet_mean"]
 
 
 class Golden:
@@ -56,6 +56,7 @@ class Golden:
             patch_size=t["patch_size"], tf_hidden_size=t["hidden_size"], num_layers=t.get("num_layers", 3),
             num_heads=a["num_heads"], num_kv_heads=a["num_kv_heads"],
             use_conditional_norm=a.get("use_conditional_norm", False),
+            positional_embedding=t.get("positional_embedding", "absolute"),
             latent_tokens_size=self.latent_tokens_size)
 
     def csr_lists(self):

@@ -8,7 +8,9 @@ The reference hard-imports three packages that are absent here:
   * torch_scatter         -> pure-torch stand-in written below (upstream semantics:
                              empty segment -> 0, mean divides by max(count,1))
   * omegaconf             -> empty stub (only imported, never used on this path)
-  * rotary_embedding_torch-> stub that raises if constructed (rope is non-default)
+  * rotary_embedding_torch-> stand-in restating the published RotaryEmbedding(dim) defaults (freqs_for='lang', theta=1e4,
+                             learned_freq=False: `freqs` is a frozen nn.Parameter; rotate_queries_or_keys rotates the
+                             interleaved pairs (2i, 2i+1) by position * freqs[i]); used by the `rope` case only
 The stand-ins are written to a temp dir, never into the repo tree.
 
 Usage:  python tests/golden/make_golden.py            (writes tests/golden/*.npz)
@@ -62,6 +64,26 @@ SCATTER_STANDIN = textwrap.dedent('''
 ''')
 
 
+ROTARY_STANDIN = textwrap.dedent('''
+    import torch
+    from torch import nn
+    class RotaryEmbedding(nn.Module):
+        def __init__(self, dim, theta=10000):
+            super().__init__()
+            freqs = 1. / (theta ** (torch.arange(0, dim, 2)[:(dim // 2)].float() / dim))
+            self.freqs = nn.Parameter(freqs, requires_grad=False)
+        def rotate_queries_or_keys(self, t, seq_dim=-2):
+            seq_len = t.shape[seq_dim]
+            seq = torch.arange(seq_len, device=t.device, dtype=t.dtype)
+            freqs = torch.einsum('..., f -> ... f', seq, self.freqs.to(t.dtype))
+            freqs = freqs.repeat_interleave(2, dim=-1)                     # repeat '... n -> ... (n r)', r = 2
+            x = t.reshape(*t.shape[:-1], -1, 2)
+            x1, x2 = x.unbind(dim=-1)
+            rot = torch.stack((-x2, x1), dim=-1).reshape(t.shape)          # rotate_half
+            return t * freqs.cos() + rot * freqs.sin()
+''')
+
+
 def install_standins():
     root = tempfile.mkdtemp(prefix="gaot_ref_standins_")
     for pkg in ("torch_scatter", "omegaconf", "rotary_embedding_torch"):
@@ -73,7 +95,7 @@ def install_standins():
     with open(os.path.join(root, "omegaconf", "__init__.py"), "w") as f:
         f.write("class DictConfig(dict): pass\nclass OmegaConf: pass\n")
     with open(os.path.join(root, "rotary_embedding_torch", "__init__.py"), "w") as f:
-        f.write("class RotaryEmbedding:\n    def __init__(self,*a,**k): raise RuntimeError('stand-in')\n")
+        f.write(ROTARY_STANDIN)
     sys.path.insert(0, root)
     sys.path.insert(1, REF)
 
@@ -121,6 +143,12 @@ CASES = {
     "fx3d":           ({"coord_dim": 3, "radius": 0.45, "lifting_channels": 6}, {"hidden_size": 48}, {},
                        dict(N=300, lat=[8, 8, 8], B=2, cin=3, cout=1, seed=0)),
     "even_layers":    ({}, {"num_layers": 4}, {}, dict(N=256, lat=[16, 16], B=2, cin=1, cout=1, seed=4, light=True)),
+    # round 2
+    "linear_kernelonly":    ({"transform_type": "linear_kernelonly"}, {}, {}, dict(N=256, lat=[16, 16], B=2, cin=2, cout=1, seed=5)),
+    "nonlinear_kernelonly": ({"transform_type": "nonlinear_kernelonly"}, {}, {}, dict(N=256, lat=[16, 16], B=2, cin=8, cout=1, seed=6)),
+    "rope":           ({}, {"positional_embedding": "rope"}, {"num_heads": 4, "num_kv_heads": 2},
+                       dict(N=256, lat=[16, 16], B=2, cin=1, cout=1, seed=7)),
+    "pointnet_mean":  ({"embedding_method": "pointnet", "pooling": "mean"}, {}, {}, dict(N=256, lat=[16, 16], B=2, cin=1, cout=1, seed=8, light=True)),
 }
 
 
@@ -306,7 +334,7 @@ def run_neighbor_kats():
     for d, n, mq, rad in ((2, 400, 144, 0.15), (3, 500, 125, 0.4)):
         data = torch.rand(n, d, generator=g) * 2 - 1
         q = grid([12, 12] if d == 2 else [5, 5, 5])
-        for meth in ("native", "chunked"):
+        for meth in ("native", "chunked") + (("grid",) if d == 2 else ()):
             r = NeighborSearch(meth)(data, q, rad)
             out[f"rand{d}d.{meth}.index"] = r["neighbors_index"]
             out[f"rand{d}d.{meth}.splits"] = r["neighbors_row_splits"]

@@ -12,7 +12,8 @@ from tests._golden import GOLDEN_DIR, Golden
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SEEDS = {"fx2d_base": 0, "fx2d_base_s1": 1, "attn_dot": 0, "ms_weighted": 1, "fx3d": 0, "pointnet": 0,
-         "fx2d_inproj": 3, "even_layers": 4, "nonlinear": 0, "node_embed": 0, "vx2d": 0, "no_geoembed": 0}
+         "fx2d_inproj": 3, "even_layers": 4, "nonlinear": 0, "node_embed": 0, "vx2d": 0, "no_geoembed": 0,
+         "linear_kernelonly": 5, "nonlinear_kernelonly": 6, "rope": 7, "pointnet_mean": 8}
 
 
 def _model(g):

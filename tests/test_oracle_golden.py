@@ -93,3 +93,18 @@ def test_neighbor_known_answers():
         assert sorted(idx[sp[i]:sp[i + 1]].tolist()) == sorted(gi[gs[i]:gs[i + 1]].tolist())
     # inclusive boundary: the centre of a unit lattice has itself + 4 axis neighbours at distance exactly r
     assert int(sp[1] - sp[0]) == 5
+
+
+def test_exact_difference_search_is_the_grid_backend():
+    """radius_csr(exact=True) restates the distance test of the reference's `grid` backend (what method='auto' resolves to
+    without torch_cluster): same neighbour sets per query as the KAT exported from it (the grid backend lists a row cell by
+    cell, the restatement in ascending index)."""
+    z = Golden.__new__(Golden)
+    z.raw = dict(np.load(__import__("os").path.join(__import__("tests._golden", fromlist=["x"]).GOLDEN_DIR, "neighbor_kats.npz")))
+    for name in ("lattice", "rand2d"):
+        data, q, r = z.t(f"{name}.data"), z.t(f"{name}.queries"), float(z.raw[f"{name}.radius"])
+        idx, sp = O.radius_csr(data, q, r, exact=True)
+        gi, gs = z.t(f"{name}.grid.index"), z.t(f"{name}.grid.splits")
+        assert torch.equal(sp, gs)
+        for i in range(sp.numel() - 1):
+            assert idx[sp[i]:sp[i + 1]].tolist() == sorted(gi[gs[i]:gs[i + 1]].tolist())
