@@ -110,7 +110,7 @@ class GroupQueryFlashAttention(nn.Module):
             x = self.correction(c=condition, x=x)
         qkv = ops.linear_cat(x, [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight])
         if relative_positions is not None:       # the reference only tests for None: the rotation angle is the SEQUENCE index
-            qkv = ops.rope_(qkv.contiguous(), self.num_heads + self.num_kv_heads, self.head_dim,
+            qkv = ops.rope(qkv, self.num_heads + self.num_kv_heads, self.head_dim,
                             self.rotary_emb.cos_sin(qkv.shape[-2], qkv.device))
         o = ops.attention(qkv, self.num_heads, self.num_kv_heads, self.head_dim)
         return ops.linear(o, self.o_proj.weight, residual=residual)

@@ -970,19 +970,20 @@ def cond_affine(x, scale, shift):
 
 
 class _Rope(torch.autograd.Function):
-    """rotary embedding of q and k IN PLACE on the fused projection output (attn.py:106-108); an orthogonal map, so the backward
-    is the transposed rotation of the incoming gradient."""
+    """rotary embedding of the q and k heads of the fused projection output (attn.py:106-108); an orthogonal map, so the
+    backward is the transposed rotation of the incoming gradient.  (The kernel works in place; the copy keeps the projection's
+    own output untouched -- autograd forbids in-place edits of a custom Function's view outputs.)"""
 
     @staticmethod
     def forward(ctx, qkv, n_heads, D, cos_sin):
         _dev(qkv, cos_sin)
-        assert qkv.is_contiguous() and qkv.dim() == 3
-        B, S, W = qkv.shape
-        L.check(L.load().gaot_rope_inplace(_p(qkv), B, S, W, n_heads, D, _p(cos_sin), 0, _stream()), "gaot_rope_inplace")
-        ctx.mark_dirty(qkv)
+        assert qkv.dim() == 3
+        out = qkv.contiguous().clone()
+        B, S, W = out.shape
+        L.check(L.load().gaot_rope_inplace(_p(out), B, S, W, n_heads, D, _p(cos_sin), 0, _stream()), "gaot_rope_inplace")
         ctx.args = (n_heads, D)
         ctx.save_for_backward(cos_sin)
-        return qkv
+        return out
 
     @staticmethod
     def backward(ctx, g):
@@ -994,7 +995,7 @@ class _Rope(torch.autograd.Function):
         return g, None, None, None
 
 
-def rope_(qkv, n_heads, D, cos_sin):
+def rope(qkv, n_heads, D, cos_sin):
     return _Rope.apply(qkv, n_heads, D, cos_sin)
 
 

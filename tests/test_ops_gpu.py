@@ -676,3 +676,112 @@ def test_projected_gno_transform_matches_unfused(B, n_src, Q, OC, C, rb, bias):
     for u, v, w in zip(gf, g0, gd):
         assert u.shape == w.shape
         assert rel(u, w) < 1e-5, (rel(u, w), rel(v, w))
+
+
+def test_segment_csr_wrapper_matches_reference_semantics():
+    """utils/segment_csr.py (the reference wrapper's signature, utils/segment_csr.py:14-55): sum / mean over CSR segments of
+    [E], [E,C] and [B,E,C] inputs, empty segment -> 0, gradient = broadcast of the row gradient"""
+    from gaot_amd.model.layers.utils.segment_csr import segment_csr
+    g = torch.Generator().manual_seed(4)
+    deg = torch.tensor([3, 0, 5, 1, 0, 7])
+    ip = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(deg, 0)])
+    qid = torch.repeat_interleave(torch.arange(6), deg)
+    for shape in ((16,), (16, 8), (3, 16, 8)):
+        x = torch.randn(*shape, generator=g)
+        for red in ("sum", "mean"):
+            xd = x.to(dev()).requires_grad_(True)
+            out = segment_csr(xd, ip.to(dev()), reduce=red)
+            dim = 0 if x.dim() < 3 else 1
+            ref = torch.zeros(*([6] if x.dim() == 1 else ([6, 8] if x.dim() == 2 else [3, 6, 8])), dtype=torch.float64)
+            ref.index_add_(dim, qid, x.double())
+            if red == "mean":
+                d = deg.clamp(min=1).double()
+                ref = ref / (d if x.dim() == 1 else (d[:, None] if x.dim() == 2 else d[None, :, None]))
+            assert rel(out, ref) < 1e-6 and out.shape == ref.shape
+            w = torch.randn(out.shape, generator=g)
+            (out * w.to(dev())).sum().backward()
+            gref = w.double().index_select(dim, qid)
+            if red == "mean":
+                d = (1.0 / deg.clamp(min=1).double())[qid]
+                gref = gref * (d if x.dim() == 1 else (d[:, None] if x.dim() == 2 else d[None, :, None]))
+            assert rel(xd.grad, gref) < 1e-6
+    with pytest.raises(ValueError):
+        segment_csr(torch.zeros(4, device=dev()), torch.tensor([0, 4], device=dev()), reduce="max")
+
+
+def test_glue_kernels_against_float64():
+    """dot-product edge score, segment max pool (even split among ties), multiscale mixing, conditioned-norm modulation, RoPE"""
+    from gaot_amd import ops
+    from gaot_amd.plan import GeometryPlan
+    from oracle import gaot_oracle as O
+    g = torch.Generator().manual_seed(6)
+    x, lat, enc, _ = _random_geometry(6, 700, [12, 12], 0.3)
+    plan = GeometryPlan(enc[0].to(dev()), enc[1].to(dev()), 700)
+    idx, sp = enc
+    qid, deg = O.edge_query_ids(sp)
+    E, Q = idx.numel(), 144
+    # dot score + its two node gradients
+    qn, kn = torch.randn(Q, 64, generator=g), torch.randn(700, 64, generator=g)
+    qd, kd = qn.to(dev()).requires_grad_(True), kn.to(dev()).requires_grad_(True)
+    sc = ops.edge_dot_score(qd, kd, plan, 0.125)
+    q64, k64 = qn.double().requires_grad_(True), kn.double().requires_grad_(True)
+    ref = (q64[qid] * k64[idx]).sum(-1) * 0.125
+    assert rel(sc[:E], ref) < 1e-6
+    w = torch.randn(E, generator=g)
+    (sc[:E] * w.to(dev())).sum().backward()
+    (ref * w.double()).sum().backward()
+    assert rel(qd.grad, q64.grad) < 1e-6 and rel(kd.grad, k64.grad) < 1e-6
+    # segment max with ties (ReLU zeros) -> even split, as torch.scatter_reduce(amax)
+    h = torch.relu(torch.randn(E, 16, generator=g))
+    hd = h.to(dev()).requires_grad_(True)
+    out = ops.segment_max(hd, plan)
+    h64 = h.double().requires_grad_(True)
+    ref = torch.zeros(Q, 16, dtype=torch.float64).scatter_reduce(0, qid[:, None].expand(E, 16), h64, reduce="amax", include_self=False)
+    assert torch.equal(out.cpu().double(), ref.detach())
+    w = torch.randn(Q, 16, generator=g)
+    (out * w.to(dev())).sum().backward()
+    (ref * w.double()).sum().backward()
+    assert rel(hd.grad, h64.grad) < 1e-6
+    # multiscale mixing
+    ts = [torch.randn(3, Q, 24, generator=g) for _ in range(3)]
+    wq = torch.softmax(torch.randn(Q, 3, generator=g), -1)
+    tds = [t.to(dev()).requires_grad_(True) for t in ts]
+    wd = wq.to(dev()).requires_grad_(True)
+    t64 = [t.double().requires_grad_(True) for t in ts]
+    w64 = wq.double().requires_grad_(True)
+    o1, o2 = ops.scale_mix(tds, wd), ops.scale_mix(tds, None)
+    r1 = sum(w64[None, :, i:i + 1] * t64[i] for i in range(3))
+    r2 = torch.stack(t64, 0).mean(0)
+    assert rel(o1, r1) < 1e-6 and rel(o2, r2) < 1e-6
+    gw = torch.randn(3, Q, 24, generator=g)
+    ((o1 + 0.5 * o2) * gw.to(dev())).sum().backward()
+    ((r1 + 0.5 * r2) * gw.double()).sum().backward()
+    assert rel(wd.grad, w64.grad) < 1e-5 and all(rel(a.grad, b.grad) < 1e-6 for a, b in zip(tds, t64))
+    # conditioned-norm modulation
+    xx, s_, b_ = torch.randn(3, 300, 48, generator=g), torch.randn(3, 48, generator=g), torch.randn(3, 48, generator=g)
+    ds = [t.to(dev()).requires_grad_(True) for t in (xx, s_, b_)]
+    d64 = [t.double().requires_grad_(True) for t in (xx, s_, b_)]
+    y = ops.cond_affine(*ds)
+    yr = d64[0] * d64[1][:, None, :] + d64[2][:, None, :]
+    assert rel(y, yr) < 1e-6
+    gy = torch.randn(3, 300, 48, generator=g)
+    (y * gy.to(dev())).sum().backward()
+    (yr * gy.double()).sum().backward()
+    assert all(rel(a.grad, b.grad) < 2e-6 for a, b in zip(ds, d64))
+    # RoPE: in place on the q|k part of a fused projection output; backward = transposed rotation
+    B, S, H, Hkv, D = 2, 37, 4, 2, 16
+    qkv = torch.randn(B, S, (H + 2 * Hkv) * D, generator=g)
+    freqs = 1.0 / (10000.0 ** (torch.arange(0, D, 2).float() / D))
+    ang = torch.arange(S, dtype=torch.float32)[:, None] * freqs[None, :]
+    cs = torch.stack([ang.cos(), ang.sin()], -1).contiguous().to(dev())
+    base = qkv.to(dev()).requires_grad_(True)
+    out = ops.rope(base, H + Hkv, D, cs)
+    q64 = qkv.double().requires_grad_(True)
+    heads = q64.reshape(B, S, H + 2 * Hkv, D)
+    rot = O.rotate_queries_or_keys(heads[:, :, :H + Hkv].transpose(1, 2), freqs.double()).transpose(1, 2)
+    ref = torch.cat([rot, heads[:, :, H + Hkv:]], dim=2).reshape(B, S, -1)
+    assert rel(out, ref) < 1e-6
+    gq = torch.randn(B, S, (H + 2 * Hkv) * D, generator=g)
+    (out * gq.to(dev())).sum().backward()
+    (ref * gq.double()).sum().backward()
+    assert rel(base.grad, q64.grad) < 1e-6
