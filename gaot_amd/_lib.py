@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgaot_hip.so")
+# GAOT_HIP_LIB: another build of the same ABI (same-box A/B runs of a kernel change: tools/ only)
+LIB_PATH = os.environ.get("GAOT_HIP_LIB") or os.path.join(_HERE, "lib", "libgaot_hip.so")
 
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD, ACT_RELU_BWD, ACT_SWIGLU_BWD, ACT_SWIGLU = 0, 1, 2, 3, 4, 5, 6
 
