@@ -49,12 +49,13 @@ PROTOTYPES = {
     "gaot_segment_softmax_fwd": (C.c_int, [_f, _i, C.c_int32, _f, _s]),
     "gaot_segment_softmax_bwd": (C.c_int, [_f, _f, _i, C.c_int32, _f, _s]),
     "gaot_edge_features": (C.c_int, [_f, _f, C.c_int32, _i, _i, C.c_int32, _f, _i, _s]),
-    "gaot_geo_stats": (C.c_int, [_f, _f, C.c_int32, _i, _i, C.c_int32, _f, C.c_void_p, _i, _s]),
+    "gaot_geo_stats": (C.c_int, [_f, _f, C.c_int32, _i, _i, C.c_int32, _f, C.c_void_p, _i, C.c_int32, _s]),
+    "gaot_concat_offset": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, _i, _s]),
     "gaot_cells_build": (C.c_int, [_f, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_float, C.POINTER(C.c_int32), _i, _i, _i, _s]),
-    "gaot_radius_count": (C.c_int, [_f, C.c_int32, _f, C.c_int32, C.c_float, C.POINTER(C.c_float), C.c_float, C.POINTER(C.c_int32),
+    "gaot_radius_count": (C.c_int, [_f, C.c_int32, _f, C.c_int32, C.c_int32, C.c_float, C.POINTER(C.c_float), C.c_float, C.POINTER(C.c_int32),
                                     _i, _i, _i, _i, C.c_int32, C.c_int32, _s]),
-    "gaot_radius_fill": (C.c_int, [_f, C.c_int32, _f, C.c_int32, C.c_float, C.POINTER(C.c_float), C.c_float, C.POINTER(C.c_int32),
-                                   _i, _i, _i, _i, C.c_int32, C.c_int32, _s]),
+    "gaot_radius_fill": (C.c_int, [_f, C.c_int32, _f, C.c_int32, C.c_int32, C.c_float, C.POINTER(C.c_float), C.c_float, C.POINTER(C.c_int32),
+                                   _i, _i, _i, _i, _i, C.c_int32, C.c_int32, _s]),
     "gaot_gno_gather_reduce": (C.c_int, [_f, _f, C.c_int32, C.c_int32, C.c_int32, _i, _i, _i, C.c_int32, _f, _f, _s]),
     "gaot_gno_edge_grad": (C.c_int, [_f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i, _i, C.c_int32, _f, _f, _s]),
     "gaot_gno_segment_sum": (C.c_int, [_f, C.c_int32, C.c_int32, C.c_int32, _i, C.c_int32, _f, _f, _s]),

@@ -5,6 +5,7 @@
 // and workgroups of one batch sample are pinned to one XCD so the sample's feature matrix (N*C*4 B,
 // 4 MiB at the 16k-node config) stays resident in that XCD's private L2.
 #include "common.h"
+#include "segsort.h"
 
 namespace gaot {
 
@@ -17,16 +18,18 @@ __global__ void csr_prepare_kernel(const int64_t* __restrict__ idx64, const int6
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid <= Q) {
         const int64_t s = sp64[gid];
-        sp32[gid] = (int)s;
+        // a broken list is FLAGGED (the host raises, at once or one step later when validation is lazy); what is stored is
+        // clamped so that the kernels that may run before the flag is read stay inside their arrays
+        sp32[gid] = (int)(s < 0 ? 0 : (s > E ? E : s));
         if (s < 0 || s > E || (gid > 0 && sp64[gid - 1] > s) || (gid == Q && s != E) || (gid == 0 && s != 0))
             atomicOr(flag, 1);
     }
     if (gid < E) {
         const int64_t j = idx64[gid];
         if (j < 0 || j >= n_src) atomicOr(flag, 2);
-        idx32[gid] = (int)j;
+        idx32[gid] = (int)(j < 0 ? 0 : (j >= n_src ? n_src - 1 : j));
         // upper_bound(splits, gid) - 1
-        int lo = 0, hi = Q;  // invariant: sp[lo] <= gid < sp[hi]  (hi == Q holds since sp[Q] == E > gid)
+        int lo = 0, hi = Q;  // invariant: sp[lo] <= gid < sp[hi]  (hi == Q holds since sp[Q] == E > gid); any list: 0 <= lo < Q
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
             if (sp64[mid] <= gid) lo = mid; else hi = mid;
@@ -75,16 +78,15 @@ __global__ void fill_kernel(const int* __restrict__ idx, int E, const int* __res
         tedge[tsp[j] + slot] = e;
     }
 }
-__global__ void sort_segments_kernel(const int* __restrict__ tsp, int n, int* __restrict__ tedge) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const int b = tsp[j], e = tsp[j + 1];
-    for (int i = b + 1; i < e; ++i) {  // insertion sort; segments are short
-        const int v = tedge[i];
-        int k = i - 1;
-        while (k >= b && tedge[k] > v) { tedge[k + 1] = tedge[k]; --k; }
-        tedge[k + 1] = v;
-    }
+// concatenation of per-sample int arrays with a per-part offset (block-diagonal union of per-sample CSR plans): out = [parts[0] +
+// off[0], parts[1] + off[1], ...].  Up to 64 parts per launch (kernel-argument struct: no device-side pointer table to upload).
+struct ConcatParts { const int* ptr[64]; int len[64]; int off[64]; int begin[64]; int n; };
+__global__ void concat_offset_kernel(ConcatParts p, int total, int* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int lo = 0, hi = p.n;                       // part of element i: begin[lo] <= i < begin[lo + 1]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (p.begin[mid] <= i) lo = mid; else hi = mid; }
+    out[i] = p.ptr[lo][i - p.begin[lo]] + p.off[lo];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -240,11 +242,15 @@ __global__ void geo_stats_raw_kernel(const float* __restrict__ geom, const float
     o[0] = (float)n; o[1] = (float)mean; o[2] = (float)var;
     for (int d = 0; d < DIM; ++d) { o[3 + d] = (float)(cen[d] - x[d]); o[3 + DIM + d] = (float)ev[d]; }
 }
-// column sums (pass 0: sum x -> acc[f]; pass 1: sum (x-mean)^2 -> acc[F+f]) in fp64 via block reduce + atomics
+// column sums (pass 0: sum x -> acc[f]; pass 1: sum (x-mean)^2 -> acc[F+f]) in fp64 via block reduce + atomics.
+// Rows come in `groups` equal groups of Q rows (vx mode: one group per sample of the block-diagonal union), each standardised
+// on its own (gemb.py:164-169 runs per sample there): blockIdx.y = group, acc = [group][2 * F].
 __global__ __launch_bounds__(256) void geo_colstat_kernel(const float* __restrict__ raw, int Q, int F, int pass,
-                                                          double* __restrict__ acc, const int* __restrict__ guard) {
+                                                          double* __restrict__ acc_all, const int* __restrict__ guard) {
     __shared__ double red[4];
     if (guard && *guard == 0) return;
+    raw += (long)blockIdx.y * Q * F;
+    double* acc = acc_all + (long)blockIdx.y * 2 * F;
     for (int f = 0; f < F; ++f) {
         const double mean = pass ? acc[f] / Q : 0.0;
         double s = 0.0;
@@ -263,12 +269,13 @@ __global__ void zero_f64_kernel(double* p, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0.0;
 }
-__global__ void geo_standardise_kernel(float* __restrict__ raw, int Q, int F, const double* __restrict__ acc,
-                                       const int* __restrict__ guard) {
+__global__ void geo_standardise_kernel(float* __restrict__ raw, int Q, int F, const double* __restrict__ acc_all,
+                                       const int* __restrict__ guard, int groups) {
     if (guard && *guard == 0) return;
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (long)Q * F) return;
+    if (gid >= (long)groups * Q * F) return;
     const int f = (int)(gid % F);
+    const double* acc = acc_all + (gid / ((long)Q * F)) * 2 * F;
     const double mean = acc[f] / Q;
     // torch.std: unbiased; cast to fp32 before the 1e-6 test like the reference's fp32 tensor (gemb.py:165-166)
     float sd = (float)sqrt(acc[F + f] / (double)(Q - 1));
@@ -418,13 +425,13 @@ extern "C" int gaot_csr_prepare(const int64_t* index_i64, const int64_t* splits_
 
 extern "C" int gaot_csr_transpose(const int32_t* index32, int32_t E, int32_t n_src, int32_t* t_splits, int32_t* t_edge,
                                   int32_t* scratch, gaot_stream_t stream) {
-    GAOT_REQUIRE(t_splits && scratch && n_src > 0 && E >= 0, "csr_transpose: bad arguments");
+    GAOT_REQUIRE(t_splits && scratch && n_src > 0 && E >= 0, "csr_transpose: bad arguments (scratch: n_src + 1 + E int32)");
     hipLaunchKernelGGL(zero_i32_kernel, dim3(cdiv(n_src + 1, 256)), dim3(256), 0, ST(stream), scratch, n_src + 1);
     if (E > 0) hipLaunchKernelGGL(count_kernel, dim3(cdiv(E, 256)), dim3(256), 0, ST(stream), index32, E, scratch);
     hipLaunchKernelGGL(exscan_kernel, dim3(1), dim3(1024), 0, ST(stream), scratch, n_src, t_splits);
     if (E > 0) {
         hipLaunchKernelGGL(fill_kernel, dim3(cdiv(E, 256)), dim3(256), 0, ST(stream), index32, E, t_splits, scratch, t_edge);
-        hipLaunchKernelGGL(sort_segments_kernel, dim3(cdiv(n_src, 256)), dim3(256), 0, ST(stream), t_splits, n_src, t_edge);
+        sort_segments<int, int>(t_splits, n_src, t_edge, scratch + n_src + 1, ST(stream));     // ascending edge ids: deterministic backward
     }
     GAOT_CHECK_LAUNCH("gaot_csr_transpose");
     return GAOT_OK;
@@ -473,20 +480,46 @@ extern "C" int gaot_edge_features(const float* src, const float* qry, int32_t di
 
 extern "C" int gaot_geo_stats(const float* geom, const float* qry, int32_t dim, const int32_t* index32,
                               const int32_t* splits32, int32_t Q, float* stats, double* scratch, const int32_t* guard,
-                              gaot_stream_t stream) {
+                              int32_t groups, gaot_stream_t stream) {
     GAOT_REQUIRE(dim == 2 || dim == 3, "geo_stats: coord dim must be 2 or 3 (got %d)", dim);
-    GAOT_REQUIRE(geom && qry && splits32 && stats && scratch && Q > 0, "geo_stats: bad arguments");
+    GAOT_REQUIRE(geom && qry && splits32 && stats && scratch && Q > 0 && groups >= 1 && Q % groups == 0,
+                 "geo_stats: bad arguments (Q must be a multiple of groups)");
     const int F = 3 + 2 * dim;
+    const int Qg = Q / groups;
     if (dim == 2)
         hipLaunchKernelGGL(geo_stats_raw_kernel<2>, dim3(cdiv(Q, 128)), dim3(128), 0, ST(stream), geom, qry, index32, splits32, Q, stats, guard);
     else
         hipLaunchKernelGGL(geo_stats_raw_kernel<3>, dim3(cdiv(Q, 128)), dim3(128), 0, ST(stream), geom, qry, index32, splits32, Q, stats, guard);
-    hipLaunchKernelGGL(zero_f64_kernel, dim3(1), dim3(64), 0, ST(stream), scratch, 2 * F);
-    int nb = cdiv(Q, 256); if (nb > 256) nb = 256;
-    hipLaunchKernelGGL(geo_colstat_kernel, dim3(nb), dim3(256), 0, ST(stream), stats, Q, F, 0, scratch, guard);
-    hipLaunchKernelGGL(geo_colstat_kernel, dim3(nb), dim3(256), 0, ST(stream), stats, Q, F, 1, scratch, guard);
-    hipLaunchKernelGGL(geo_standardise_kernel, dim3(cdiv((long)Q * F, 256)), dim3(256), 0, ST(stream), stats, Q, F, scratch, guard);
+    hipLaunchKernelGGL(zero_f64_kernel, dim3(cdiv(2 * F * groups, 64)), dim3(64), 0, ST(stream), scratch, 2 * F * groups);
+    int nb = cdiv(Qg, 256); if (nb > 256) nb = 256;
+    hipLaunchKernelGGL(geo_colstat_kernel, dim3(nb, groups), dim3(256), 0, ST(stream), stats, Qg, F, 0, scratch, guard);
+    hipLaunchKernelGGL(geo_colstat_kernel, dim3(nb, groups), dim3(256), 0, ST(stream), stats, Qg, F, 1, scratch, guard);
+    hipLaunchKernelGGL(geo_standardise_kernel, dim3(cdiv((long)Q * F, 256)), dim3(256), 0, ST(stream), stats, Qg, F, scratch, guard, groups);
     GAOT_CHECK_LAUNCH("gaot_geo_stats");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_concat_offset(const int32_t* const* parts, const int32_t* lens, const int32_t* offsets, int32_t n_parts, int32_t* out,
+                                  gaot_stream_t stream) {
+    GAOT_REQUIRE(parts && lens && offsets && out && n_parts >= 1, "concat_offset: bad arguments");
+    long done = 0;
+    for (int base = 0; base < n_parts; base += 64) {
+        ConcatParts p;
+        p.n = n_parts - base < 64 ? n_parts - base : 64;
+        int total = 0;
+        for (int i = 0; i < 64; ++i) {
+            const bool live = i < p.n;
+            p.ptr[i] = live ? parts[base + i] : nullptr;
+            p.len[i] = live ? lens[base + i] : 0;
+            p.off[i] = live ? offsets[base + i] : 0;
+            p.begin[i] = total;
+            GAOT_REQUIRE(!live || p.len[i] == 0 || p.ptr[i], "concat_offset: null part %d", base + i);
+            total += p.len[i];
+        }
+        if (total > 0) hipLaunchKernelGGL(concat_offset_kernel, dim3(cdiv(total, 256)), dim3(256), 0, ST(stream), p, total, out + done);
+        done += total;
+    }
+    GAOT_CHECK_LAUNCH("gaot_concat_offset");
     return GAOT_OK;
 }
 

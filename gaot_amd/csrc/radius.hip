@@ -2,6 +2,7 @@
 // inclusive `dist <= r`, unbounded degree, neighbours of a query in ascending data index like the `native` backend).
 // Replaces the O(Q*N) distance matrix of torch.cdist with O(Q * points-in-27-cells).  Once per geometry.
 #include "common.h"
+#include "segsort.h"
 
 namespace gaot {
 
@@ -56,17 +57,6 @@ __global__ void cell_fill_kernel(const int* __restrict__ cell_id, int n, const i
     if (i >= n) return;
     const int c = cell_id[i];
     pts[start[c] + atomicSub(&cnt[c], 1) - 1] = i;
-}
-__global__ void sort_int_segments_kernel(const int* __restrict__ start, int nseg, int* __restrict__ v) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= nseg) return;
-    const int b = start[s], e = start[s + 1];
-    for (int i = b + 1; i < e; ++i) {
-        const int x = v[i];
-        int k = i - 1;
-        while (k >= b && v[k] > x) { v[k + 1] = v[k]; --k; }
-        v[k + 1] = x;
-    }
 }
 __global__ void zero_i32(int* p, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -157,6 +147,51 @@ __global__ void radius_query_kernel(const float* __restrict__ qry, int m, const 
     }
 }
 
+// One WAVE per query (few queries against many, unevenly spread points: the encoder side of an airfoil-like cloud has cells of
+// ~1000 points around the body; a single thread walking 9 such cells serialises thousands of distance tests).  Lanes stride
+// over the points of a cell; hits are counted with a ballot and, in the fill pass, placed by the lane's rank among the hits
+// (deterministic); the row is sorted afterwards (sort_segments).  Uncapped, inclusive `dist <= r` semantics only.
+template <bool FILL>
+__global__ __launch_bounds__(256) void radius_query_wave_kernel(const float* __restrict__ qry, int m, const float* __restrict__ data,
+                                                                CellGrid g, float r, const int* __restrict__ start,
+                                                                const int* __restrict__ pts, int* __restrict__ deg,
+                                                                const int64_t* __restrict__ splits, int64_t* __restrict__ index) {
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (q >= m) return;
+    const float* x = qry + (long)q * g.dim;
+    int lo[3], hi[3];
+    const float o[3] = {g.ox, g.oy, g.oz};
+    const int nn[3] = {g.nx, g.ny, g.nz};
+    bool empty = false;
+    for (int k = 0; k < 3; ++k) {
+        if (k >= g.dim) { lo[k] = hi[k] = 0; continue; }
+        const int c = (int)floorf((x[k] - o[k]) * g.inv_cell);
+        lo[k] = max(c - 1, 0);
+        hi[k] = min(c + 1, nn[k] - 1);
+        if (lo[k] > hi[k]) empty = true;
+    }
+    int count = 0;
+    const int64_t base = FILL ? splits[q] : 0;
+    if (!empty)
+        for (int cz = lo[2]; cz <= hi[2]; ++cz)
+            for (int cy = lo[1]; cy <= hi[1]; ++cy)
+                for (int cx = lo[0]; cx <= hi[0]; ++cx) {
+                    const int c = (cz * g.ny + cy) * g.nx + cx;
+                    const int t0 = start[c], t1 = start[c + 1];
+                    for (int t = t0; t < t1; t += 64) {
+                        const int tt = t + lane;
+                        int j = -1;
+                        bool hit = false;
+                        if (tt < t1) { j = pts[tt]; hit = within(x, data + (long)j * g.dim, g.dim, r); }
+                        const unsigned long long mask = __ballot(hit);
+                        if (FILL && hit) index[base + count + __popcll(mask & ((1ull << lane) - 1ull))] = j;
+                        count += __popcll(mask);
+                    }
+                }
+    if (!FILL && lane == 0) deg[q] = count;
+}
+
 }  // namespace gaot
 
 using namespace gaot;
@@ -171,7 +206,7 @@ static int make_grid(CellGrid& g, int dim, const float* origin, float cell, cons
 }
 
 // cell list of the data points.  origin[dim], dims[dim] are HOST arrays (the bounding box is computed by the caller);
-// cell >= radius.  Device outputs: cell_start[ncell+1], cell_points[n]; scratch: n + ncell + 1 int32.
+// cell >= radius.  Device outputs: cell_start[ncell+1], cell_points[n]; scratch: 2 * n + ncell + 1 int32.
 extern "C" int gaot_cells_build(const float* data, int32_t n, int32_t dim, const float* origin, float cell, const int32_t* dims,
                                 int32_t* cell_start, int32_t* cell_points, int32_t* scratch, gaot_stream_t stream) {
     GAOT_REQUIRE(data && origin && dims && cell_start && cell_points && scratch, "cells_build: null pointer");
@@ -186,13 +221,16 @@ extern "C" int gaot_cells_build(const float* data, int32_t n, int32_t dim, const
     hipLaunchKernelGGL(cell_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ST(stream), data, n, g, cell_id, cnt);
     hipLaunchKernelGGL(exscan_i32_kernel, dim3(1), dim3(1024), 0, ST(stream), cnt, (int)ncell, cell_start, (int64_t*)nullptr);
     hipLaunchKernelGGL(cell_fill_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ST(stream), cell_id, n, cell_start, cnt, cell_points);
-    hipLaunchKernelGGL(sort_int_segments_kernel, dim3(cdiv(ncell, 256)), dim3(256), 0, ST(stream), cell_start, (int)ncell, cell_points);
+    sort_segments<int, int>(cell_start, (int)ncell, cell_points, scratch + n + ncell + 1, ST(stream));   // ascending point ids per cell
     GAOT_CHECK_LAUNCH("gaot_cells_build");
     return GAOT_OK;
 }
 
+// a wave per query pays when queries are few and their neighbourhoods can be large: more data points than queries
+static inline bool wave_per_query(int m, int n_data, int cap) { return cap == 0 && n_data >= m && (long)m * 64 <= (1L << 27); }
+
 // degree per query + row splits (int64, [m+1]).  The caller reads splits[m] to size the index array.
-extern "C" int gaot_radius_count(const float* queries, int32_t m, const float* data, int32_t dim, float radius,
+extern "C" int gaot_radius_count(const float* queries, int32_t m, const float* data, int32_t n_data, int32_t dim, float radius,
                                  const float* origin, float cell, const int32_t* dims, const int32_t* cell_start,
                                  const int32_t* cell_points, int32_t* deg, int64_t* splits, int32_t max_neighbors, int32_t strict,
                                  gaot_stream_t stream) {
@@ -200,22 +238,33 @@ extern "C" int gaot_radius_count(const float* queries, int32_t m, const float* d
     GAOT_REQUIRE(m > 0 && radius >= 0.f && cell >= radius && max_neighbors >= 0, "radius_count: need cell >= radius, max_neighbors >= 0");
     CellGrid g;
     make_grid(g, dim, origin, cell, dims);
-    hipLaunchKernelGGL(radius_query_kernel<false>, dim3(cdiv(m, 128)), dim3(128), 0, ST(stream), queries, m, data, g, radius,
-                       cell_start, cell_points, deg, (const int64_t*)nullptr, (int64_t*)nullptr, (int)max_neighbors, (int)strict);
+    if (wave_per_query(m, n_data, max_neighbors) && !strict)
+        hipLaunchKernelGGL(radius_query_wave_kernel<false>, dim3(cdiv(m, 4)), dim3(256), 0, ST(stream), queries, m, data, g, radius,
+                           cell_start, cell_points, deg, (const int64_t*)nullptr, (int64_t*)nullptr);
+    else
+        hipLaunchKernelGGL(radius_query_kernel<false>, dim3(cdiv(m, 128)), dim3(128), 0, ST(stream), queries, m, data, g, radius,
+                           cell_start, cell_points, deg, (const int64_t*)nullptr, (int64_t*)nullptr, (int)max_neighbors, (int)strict);
     hipLaunchKernelGGL(exscan_i32_kernel, dim3(1), dim3(1024), 0, ST(stream), deg, m, (int*)nullptr, splits);
     GAOT_CHECK_LAUNCH("gaot_radius_count");
     return GAOT_OK;
 }
 
-extern "C" int gaot_radius_fill(const float* queries, int32_t m, const float* data, int32_t dim, float radius,
+// scratch: E int64 (only rows longer than 4096 neighbours use it; may be NULL when the caller knows the maximum degree is smaller)
+extern "C" int gaot_radius_fill(const float* queries, int32_t m, const float* data, int32_t n_data, int32_t dim, float radius,
                                 const float* origin, float cell, const int32_t* dims, const int32_t* cell_start,
-                                const int32_t* cell_points, const int64_t* splits, int64_t* index, int32_t max_neighbors,
-                                int32_t strict, gaot_stream_t stream) {
+                                const int32_t* cell_points, const int64_t* splits, int64_t* index, int64_t* scratch,
+                                int32_t max_neighbors, int32_t strict, gaot_stream_t stream) {
     GAOT_REQUIRE(queries && data && origin && dims && cell_start && cell_points && splits && max_neighbors >= 0, "radius_fill: bad arguments");
     CellGrid g;
     make_grid(g, dim, origin, cell, dims);
-    hipLaunchKernelGGL(radius_query_kernel<true>, dim3(cdiv(m, 128)), dim3(128), 0, ST(stream), queries, m, data, g, radius,
-                       cell_start, cell_points, (int*)nullptr, splits, index, (int)max_neighbors, (int)strict);
+    if (wave_per_query(m, n_data, max_neighbors) && !strict) {
+        hipLaunchKernelGGL(radius_query_wave_kernel<true>, dim3(cdiv(m, 4)), dim3(256), 0, ST(stream), queries, m, data, g, radius,
+                           cell_start, cell_points, (int*)nullptr, splits, index);
+        sort_segments<int64_t, int64_t>(splits, m, index, scratch, ST(stream));       // ascending data index inside every row
+    } else {
+        hipLaunchKernelGGL(radius_query_kernel<true>, dim3(cdiv(m, 128)), dim3(128), 0, ST(stream), queries, m, data, g, radius,
+                           cell_start, cell_points, (int*)nullptr, splits, index, (int)max_neighbors, (int)strict);
+    }
     GAOT_CHECK_LAUNCH("gaot_radius_fill");
     return GAOT_OK;
 }

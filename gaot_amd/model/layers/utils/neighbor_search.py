@@ -63,18 +63,20 @@ def _hip_cell_list(data: torch.Tensor, queries: torch.Tensor, radius: float, cap
     cdims = (C.c_int32 * dim)(*dims)
     cell_start = torch.empty(ncell + 1, dtype=torch.int32, device=dev)
     cell_points = torch.empty(n, dtype=torch.int32, device=dev)
-    scratch = torch.empty(n + ncell + 1, dtype=torch.int32, device=dev)
+    scratch = torch.empty(2 * n + ncell + 1, dtype=torch.int32, device=dev)
     L.check(lib.gaot_cells_build(_p(data), n, dim, origin, cell, cdims, _p(cell_start), _p(cell_points), _p(scratch), _stream()),
             "gaot_cells_build")
     deg = torch.empty(m, dtype=torch.int32, device=dev)
     splits = torch.empty(m + 1, dtype=torch.long, device=dev)
-    L.check(lib.gaot_radius_count(_p(queries), m, _p(data), dim, float(radius), origin, cell, cdims, _p(cell_start),
+    L.check(lib.gaot_radius_count(_p(queries), m, _p(data), n, dim, float(radius), origin, cell, cdims, _p(cell_start),
                                   _p(cell_points), _p(deg), _p(splits), int(cap), int(strict), _stream()), "gaot_radius_count")
     E = int(splits[-1].item())
     index = torch.empty(E, dtype=torch.long, device=dev)
     if E > 0:
-        L.check(lib.gaot_radius_fill(_p(queries), m, _p(data), dim, float(radius), origin, cell, cdims, _p(cell_start),
-                                     _p(cell_points), _p(splits), _p(index), int(cap), int(strict), _stream()), "gaot_radius_fill")
+        sort_scratch = torch.empty(E, dtype=torch.long, device=dev)
+        L.check(lib.gaot_radius_fill(_p(queries), m, _p(data), n, dim, float(radius), origin, cell, cdims, _p(cell_start),
+                                     _p(cell_points), _p(splits), _p(index), _p(sort_scratch), int(cap), int(strict), _stream()),
+                "gaot_radius_fill")
     return {'neighbors_index': index, 'neighbors_row_splits': splits}
 
 

@@ -17,8 +17,28 @@ from .ops import _p, _stream
 _PLAN_KEY = "_gaot_amd_plan"
 
 
+_PENDING: list = []          # (device flag, event) of plans built with validate="lazy"
+
+
+def _raise_if_bad(bad: int):
+    if bad:
+        raise ValueError(f"invalid CSR neighbour list (flag {bad}: 1 = row_splits not monotone 0..E, 2 = index outside [0, n_src))")
+
+
+def _check_pending(block: bool = False):
+    keep = []
+    for flag, ev in _PENDING:
+        if block or ev.query():
+            _raise_if_bad(int(flag.item()))
+        else:
+            keep.append((flag, ev))
+    _PENDING[:] = keep
+
+
 class GeometryPlan:
-    def __init__(self, index_i64: torch.Tensor, splits_i64: torch.Tensor, n_src: int, validate: bool = True):
+    def __init__(self, index_i64: torch.Tensor, splits_i64: torch.Tensor, n_src: int, validate=True):
+        if index_i64 is None:          # assembled by GeometryPlan.compose()
+            return
         if not index_i64.is_cuda or not splits_i64.is_cuda:
             raise RuntimeError("GeometryPlan needs the CSR on the GPU (gaot_amd has no CPU path)")
         lib = L.load()
@@ -35,14 +55,21 @@ class GeometryPlan:
         flag = torch.zeros(1, dtype=torch.int32, device=dev)
         L.check(lib.gaot_csr_prepare(_p(index_i64), _p(splits_i64), self.Q, self.E, self.n_src, _p(self.index),
                                      _p(self.splits), _p(self.edge_query), _p(flag), _stream()), "gaot_csr_prepare")
+        # the CSR contract is checked on device.  validate=True: one host sync per geometry, BEFORE anything is derived from the
+        # list; "lazy": the flag is read when a later plan is built (per-step geometries of a vx batch: no sync on the step that
+        # uploads them, the error surfaces one step on; csr_prepare clamps what it stores so the kernels in between stay in bounds)
+        _check_pending()
+        if validate == "lazy":
+            ev = torch.cuda.Event()
+            ev.record()
+            _PENDING.append((flag, ev))
+        elif validate:
+            _raise_if_bad(int(flag.item()))
         self.t_splits = torch.empty(self.n_src + 1, dtype=torch.int32, device=dev)
         self.t_edge = torch.empty(E1, dtype=torch.int32, device=dev)
-        scratch = torch.empty(self.n_src + 1, dtype=torch.int32, device=dev)
+        scratch = torch.empty(self.n_src + 1 + E1, dtype=torch.int32, device=dev)
         L.check(lib.gaot_csr_transpose(_p(self.index), self.E, self.n_src, _p(self.t_splits), _p(self.t_edge), _p(scratch),
                                        _stream()), "gaot_csr_transpose")
-        bad = int(flag.item()) if validate else 0     # one sync per geometry: the CSR contract is checked on device
-        if bad:
-            raise ValueError(f"invalid CSR neighbour list (flag {bad}: 1 = row_splits not monotone 0..E, 2 = index outside [0, n_src))")
         deg = (splits_i64[1:] - splits_i64[:-1])
         self.deg = deg
         self._inv_deg_edge: Optional[torch.Tensor] = None
@@ -60,6 +87,8 @@ class GeometryPlan:
 
     @property
     def index_long(self) -> torch.Tensor:
+        if self._index_long is None:
+            self._index_long = self.index[:self.E].long()
         return self._index_long
 
     @property
@@ -123,22 +152,25 @@ class GeometryPlan:
                                                         _p(attn), _p(guard), _stream()), "gaot_edge_attention_cosine")
         return self._cached("cos", (src, qry), alloc, compute)
 
-    def geo_stats(self, geom: torch.Tensor, qry: torch.Tensor) -> torch.Tensor:
+    def geo_stats(self, geom: torch.Tensor, qry: torch.Tensor, groups: int = 1) -> torch.Tensor:
+        """`groups`: the query rows are that many equal groups, each standardised on its own (vx mode: one per sample)"""
         def alloc(ts):
             F = 3 + 2 * ts[0].shape[1]
             stats = torch.empty(self.Q, F, device=ts[0].device, dtype=torch.float32)
-            return (stats, torch.empty(4 * F, device=ts[0].device, dtype=torch.float64)), stats
+            return (stats, torch.empty(2 * F * groups, device=ts[0].device, dtype=torch.float64)), stats
 
         def compute(full, ts, guard):
             stats, scratch = full
             L.check(L.load().gaot_geo_stats(_p(ts[0]), _p(ts[1]), ts[0].shape[1], _p(self.index), _p(self.splits), self.Q, _p(stats),
-                                            _p(scratch), _p(guard), _stream()), "gaot_geo_stats")
-        return self._cached("stats", (geom, qry), alloc, compute)
+                                            _p(scratch), _p(guard), groups, _stream()), "gaot_geo_stats")
+        return self._cached(f"stats{groups}", (geom, qry), alloc, compute)
 
 
 def plan_for(neighbors: dict, n_src: int) -> GeometryPlan:
     """Plan attached to (and cached on) a reference-style neighbour dict."""
     plan = neighbors.get(_PLAN_KEY)
+    if plan is not None and plan._src_id is None:          # the union of a MergedGeometry: owned by it, nothing to re-derive
+        return plan
     idx = neighbors["neighbors_index"]
     if plan is None or plan._src_id != (id(idx), idx._version) or plan.n_src != n_src:
         plan = GeometryPlan(idx, neighbors["neighbors_row_splits"], n_src)
@@ -147,45 +179,103 @@ def plan_for(neighbors: dict, n_src: int) -> GeometryPlan:
     return plan
 
 
+def _i32_array(vals):
+    arr = (C.c_int32 * len(vals))()
+    for i, v in enumerate(vals):
+        arr[i] = int(v)
+    return arr
+
+
+def _concat_offset(tensors, lens, offsets, out):
+    ptrs = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        ptrs[i] = t.data_ptr()
+    L.check(L.load().gaot_concat_offset(ptrs, _i32_array(lens), _i32_array(offsets), len(tensors), _p(out), _stream()), "gaot_concat_offset")
+
+
+def compose_plans(plans) -> GeometryPlan:
+    """Block-diagonal union of already built per-sample plans WITHOUT re-deriving anything: sources and queries of the samples
+    are stacked, so every int32 array of the union is the concatenation of the per-sample arrays plus a per-sample offset --
+    including the transposed CSR (a source belongs to exactly one sample, so its edge list is unchanged up to the edge offset,
+    and stays sorted).  Five small launches instead of a count / scan / fill / sort pipeline over the union."""
+    dev = plans[0].splits.device
+    m = GeometryPlan(None, None, 0)
+    m.Q, m.E, m.n_src = sum(p.Q for p in plans), sum(p.E for p in plans), sum(p.n_src for p in plans)
+    E1 = max(m.E, 1)
+    e_off, q_off, s_off = [0], [0], [0]
+    for p in plans:
+        e_off.append(e_off[-1] + p.E); q_off.append(q_off[-1] + p.Q); s_off.append(s_off[-1] + p.n_src)
+    m.index = torch.empty(E1, dtype=torch.int32, device=dev)
+    m.edge_query = torch.empty(E1, dtype=torch.int32, device=dev)
+    m.t_edge = torch.empty(E1, dtype=torch.int32, device=dev)
+    m.splits = torch.empty(m.Q + 1, dtype=torch.int32, device=dev)
+    m.t_splits = torch.empty(m.n_src + 1, dtype=torch.int32, device=dev)
+    Es = [p.E for p in plans]
+    if m.E > 0:
+        _concat_offset([p.index for p in plans], Es, s_off[:-1], m.index)
+        _concat_offset([p.edge_query for p in plans], Es, q_off[:-1], m.edge_query)
+        _concat_offset([p.t_edge for p in plans], Es, e_off[:-1], m.t_edge)
+    # row splits: every part contributes its Q (n_src) leading entries; the last part also its closing entry
+    last = len(plans) - 1
+    _concat_offset([p.splits for p in plans], [p.Q + (1 if i == last else 0) for i, p in enumerate(plans)], e_off[:-1], m.splits)
+    _concat_offset([p.t_splits for p in plans], [p.n_src + (1 if i == last else 0) for i, p in enumerate(plans)], e_off[:-1], m.t_splits)
+    m.deg = torch.cat([p.deg for p in plans])
+    m._inv_deg_edge = m._edge_query_long = None
+    m._index_long = None
+    m._coord_cache = {}
+    m.epoch = 0
+    return m
+
+
 class MergedGeometry:
     """Block-diagonal union of per-sample geometries (vx mode, reference magno.py:356-413 / 694-751 loops over
     samples in Python): sources and queries of all samples are concatenated, CSR indices are offset per sample, so
     the whole minibatch goes through ONE launch of each GNO kernel with a batch dimension of 1.
 
-    Per-sample quantities that the reference normalises per geometry (the geometry statistics' global
-    standardisation, gemb.py:164-169) are computed per sample and concatenated."""
+    Two ways to get the union's plan:
+      * every per-sample neighbour dict already carries a plan (dicts kept on the device across steps, any batch order):
+        `compose_plans` -- concatenation with offsets, no counting sort, no per-row sort, no host synchronisation;
+      * otherwise (a loader that uploads fresh dicts every step): one plan over the concatenated CSR, validated lazily.
+    Per-sample quantities that the reference normalises per geometry (the geometry statistics' global standardisation,
+    gemb.py:164-169) are standardised per sample group inside one launch."""
 
-    def __init__(self, nbr_dicts, src_coords, dst_coords):
-        idx, sp, self.n_src_each, self.n_dst_each = [], [], [], []
-        e_off = s_off = 0
-        dev = nbr_dicts[0]["neighbors_row_splits"].device
-        for nb, sc, dc in zip(nbr_dicts, src_coords, dst_coords):
-            i, s_ = nb["neighbors_index"], nb["neighbors_row_splits"]
-            idx.append(i + s_off)
-            sp.append(s_[:-1] + e_off)
-            e_off += int(i.numel())
-            s_off += int(sc.shape[0])
-            self.n_src_each.append(int(sc.shape[0]))
-            self.n_dst_each.append(int(dc.shape[0]))
-        sp.append(torch.tensor([e_off], dtype=torch.long, device=dev))
-        self.neighbors = {"neighbors_index": torch.cat(idx), "neighbors_row_splits": torch.cat(sp)}
+    def __init__(self, nbr_dicts, src_coords, dst_coords, build_parts: bool = False):
+        B = len(nbr_dicts)
+        self.B = B
+        self.n_src_each = [int(c.shape[0]) for c in src_coords]
+        self.n_dst_each = [int(c.shape[0]) for c in dst_coords]
         self.src = torch.cat(list(src_coords), dim=0).contiguous()
         self.dst = torch.cat(list(dst_coords), dim=0).contiguous()
-        for nb, sc in zip(nbr_dicts, src_coords):          # validates each part once (cached on the per-sample dict)
-            plan_for(nb, sc.shape[0])
-        plan = GeometryPlan(self.neighbors["neighbors_index"], self.neighbors["neighbors_row_splits"], self.src.shape[0],
-                            validate=False)                # parts are valid => the offset union is valid: no host sync
-        plan._src_id = (id(self.neighbors["neighbors_index"]), self.neighbors["neighbors_index"]._version)
-        self.neighbors[_PLAN_KEY] = plan
+        if build_parts:
+            for nb, n in zip(nbr_dicts, self.n_src_each):
+                plan_for(nb, n)
+        parts = [nb.get(_PLAN_KEY) for nb in nbr_dicts]
+        ok = all(p is not None and p.n_src == n and p._src_id == (id(nb["neighbors_index"]), nb["neighbors_index"]._version)
+                 for p, n, nb in zip(parts, self.n_src_each, nbr_dicts))
+        if ok:
+            plan = compose_plans(parts)
+            self.composed = True
+        else:
+            dev = nbr_dicts[0]["neighbors_row_splits"].device
+            Es = [int(nb["neighbors_index"].numel()) for nb in nbr_dicts]
+            s_off = torch.tensor([sum(self.n_src_each[:b]) for b in range(B)], dtype=torch.long).to(dev, non_blocking=True)
+            e_off = torch.tensor([sum(Es[:b]) for b in range(B)], dtype=torch.long).to(dev, non_blocking=True)
+            rep = torch.tensor(Es, dtype=torch.long).to(dev, non_blocking=True)
+            idx = torch.cat([nb["neighbors_index"] for nb in nbr_dicts]) + torch.repeat_interleave(s_off, rep, output_size=sum(Es))
+            nd = torch.tensor(self.n_dst_each, dtype=torch.long).to(dev, non_blocking=True)
+            sp = torch.cat([nb["neighbors_row_splits"][:-1] for nb in nbr_dicts]) + torch.repeat_interleave(e_off, nd, output_size=sum(self.n_dst_each))
+            sp = torch.cat([sp, torch.full((1,), sum(Es), dtype=torch.long, device=dev)])
+            plan = GeometryPlan(idx, sp, self.src.shape[0], validate="lazy")
+            self.composed = False
+        self.neighbors = {"neighbors_index": None, "neighbors_row_splits": None, _PLAN_KEY: plan}
+        plan._src_id = None
         self.plan = plan
-        self._parts = (list(nbr_dicts), list(src_coords), list(dst_coords))
-        self._stats = None
+        self._equal = len(set(self.n_dst_each)) == 1
 
     def geo_stats(self) -> torch.Tensor:
-        if self._stats is None:
-            nbs, scs, dcs = self._parts
-            self._stats = torch.cat([plan_for(nb, sc.shape[0]).geo_stats(sc, dc) for nb, sc, dc in zip(nbs, scs, dcs)], dim=0)
-        return self._stats
+        if not self._equal:
+            raise ValueError("vx mode needs the same number of query points in every sample of a batch")
+        return self.plan.geo_stats(self.src, self.dst, groups=self.B)
 
 
 _MERGE_CACHE = {}
@@ -193,12 +283,17 @@ _MERGE_CACHE = {}
 
 def merged_geometry(nbr_dicts, src_coords, dst_coords, parents=()) -> MergedGeometry:
     """Cached on the identity of the per-sample neighbour dicts and of the PARENT coordinate tensors (per-sample
-    slices are new objects on every call).  A re-shuffled batch is a new combination and is merged afresh."""
+    slices are new objects on every call).  A re-shuffled batch is a new combination: composed from the per-sample plans
+    when the dicts carry them (their first use builds and caches them), else planned afresh over the union."""
     key = tuple(id(n) for n in nbr_dicts) + tuple((id(c), c._version) for c in parents)
     hit = _MERGE_CACHE.get(key)
-    if hit is None or any(a is not b for a, b in zip(hit[1], parents)):
+    if hit is None or any(a is not b for a, b in zip(hit[1], parents)) or any(a is not b for a, b in zip(hit[2], nbr_dicts)):
         if len(_MERGE_CACHE) > 64:
             _MERGE_CACHE.clear()
-        hit = (MergedGeometry(nbr_dicts, src_coords, dst_coords), tuple(parents), list(nbr_dicts))   # hold refs: ids stay unique
+        # a dict seen before (it carries a marker) is worth a plan of its own: the next batch that contains it composes
+        seen = all(n.get("_gaot_amd_seen") for n in nbr_dicts)
+        for n in nbr_dicts:
+            n["_gaot_amd_seen"] = True
+        hit = (MergedGeometry(nbr_dicts, src_coords, dst_coords, build_parts=seen), tuple(parents), list(nbr_dicts))   # hold refs: ids stay unique
         _MERGE_CACHE[key] = hit
     return hit[0]

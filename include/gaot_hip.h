@@ -95,8 +95,13 @@ int gaot_debug_set_gemm_glds(int on);
 int gaot_csr_prepare(const int64_t* index_i64, const int64_t* splits_i64, int32_t Q, int32_t E, int32_t n_src,
                      int32_t* index32, int32_t* splits32, int32_t* edge_query, int32_t* status_flag,
                      gaot_stream_t stream);
-/* transposed (by-source) CSR: t_splits[n_src+1], t_edge[E] (edge ids ascending inside a source).
- * scratch: n_src+1 int32. */
+/* transposed (by-source) CSR: t_splits[n_src+1], t_edge[E] (edge ids ascending inside a source: counting sort by source, then a
+ * per-row sort -- thread-level for short rows, a workgroup-level rank sort for the long rows of skewed meshes).
+ * scratch: n_src + 1 + E int32. */
+/* out = [parts[0] + offsets[0] | parts[1] + offsets[1] | ...]: block-diagonal union of per-sample CSR plans (vx mode) without
+ * re-deriving them.  parts / lens / offsets are HOST arrays of n_parts entries (device pointers inside parts). */
+int gaot_concat_offset(const int32_t* const* parts, const int32_t* lens, const int32_t* offsets, int32_t n_parts, int32_t* out,
+                       gaot_stream_t stream);
 int gaot_csr_transpose(const int32_t* index32, int32_t E, int32_t n_src,
                        int32_t* t_splits, int32_t* t_edge, int32_t* scratch, gaot_stream_t stream);
 /* Content guard of the per-geometry caches.  The reference trainer uploads the (unchanged) coordinates anew every step
@@ -124,32 +129,34 @@ int gaot_segment_softmax_bwd(const float* attn, const float* dattn, const int32_
 int gaot_edge_features(const float* src, const float* qry, int32_t dim,
                        const int32_t* index32, const int32_t* edge_query, int32_t E,
                        float* feat, const int32_t* guard, gaot_stream_t stream);
-/* GeometricEmbedding statistics, standardised (gemb.py:83-171): stats[Q, 3+2*dim], dim in {2,3}.
- * scratch: 4*(3+2*dim) doubles. */
+/* GeometricEmbedding statistics, standardised (gemb.py:83-171): stats[Q, 3+2*dim], dim in {2,3}.  The Q rows form `groups`
+ * equal groups (vx mode: one per sample of a block-diagonal union), each standardised on its own as the reference does per
+ * sample.  scratch: 2*(3+2*dim)*groups doubles. */
 int gaot_geo_stats(const float* geom, const float* qry, int32_t dim,
                    const int32_t* index32, const int32_t* splits32, int32_t Q,
-                   float* stats, double* scratch, const int32_t* guard, gaot_stream_t stream);
+                   float* stats, double* scratch, const int32_t* guard, int32_t groups, gaot_stream_t stream);
 
 /* radius graph by cell list (replaces NeighborSearch backends, neighbor_search.py:65-335; `dist <= r` inclusive,
  * unbounded degree, ascending data index per query like `_native_neighbor_search`).  origin[dim] / dims[dim] are HOST
  * arrays describing a uniform grid with cell size `cell` >= radius that covers the data points.
- *   1. gaot_cells_build : cell_start[ncell+1], cell_points[n]           (scratch: n + ncell + 1 int32)
+ *   1. gaot_cells_build : cell_start[ncell+1], cell_points[n]           (scratch: 2 * n + ncell + 1 int32)
  *   2. gaot_radius_count: deg[m], splits[m+1] (int64; caller reads splits[m] = E to size the index array)
- *   3. gaot_radius_fill : index[E] (int64)
+ *   3. gaot_radius_fill : index[E] (int64)      (scratch: E int64, used by rows of more than 4096 neighbours; n_data = number of
+ *      data points: with more data points than queries a wave works per query -- dense cells of a skewed cloud -- else a thread)
  * max_neighbors > 0 with strict = 1 reproduces the `torch_cluster` backend (neighbor_search.py:148-175: torch_cluster.radius
  * with its default max_num_neighbors = 32): squared distance strictly below r^2, and of a query's neighbours only the
  * max_neighbors with the SMALLEST data indices (its kernel scans the data in index order and stops at the cap).
  * max_neighbors = 0, strict = 0: the in-repo backends (native / chunked / grid). */
 int gaot_cells_build(const float* data, int32_t n, int32_t dim, const float* origin, float cell, const int32_t* dims,
                      int32_t* cell_start, int32_t* cell_points, int32_t* scratch, gaot_stream_t stream);
-int gaot_radius_count(const float* queries, int32_t m, const float* data, int32_t dim, float radius,
+int gaot_radius_count(const float* queries, int32_t m, const float* data, int32_t n_data, int32_t dim, float radius,
                       const float* origin, float cell, const int32_t* dims, const int32_t* cell_start,
                       const int32_t* cell_points, int32_t* deg, int64_t* splits, int32_t max_neighbors, int32_t strict,
                       gaot_stream_t stream);
-int gaot_radius_fill(const float* queries, int32_t m, const float* data, int32_t dim, float radius,
+int gaot_radius_fill(const float* queries, int32_t m, const float* data, int32_t n_data, int32_t dim, float radius,
                      const float* origin, float cell, const int32_t* dims, const int32_t* cell_start,
-                     const int32_t* cell_points, const int64_t* splits, int64_t* index, int32_t max_neighbors, int32_t strict,
-                     gaot_stream_t stream);
+                     const int32_t* cell_points, const int64_t* splits, int64_t* index, int64_t* scratch, int32_t max_neighbors,
+                     int32_t strict, gaot_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * GNO integral transform = gather / per-edge weight / CSR segment reduce (agno.py:198,245-271).

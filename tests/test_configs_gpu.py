@@ -446,7 +446,7 @@ def test_geometry_caches_hit_by_content_not_identity():
     nb = list(model.encoder.neighbor_cache.values())[0][0]
     plan = plan_for(nb, 2000)
     ptrs = {k: v["val"].data_ptr() for k, v in plan._coord_cache.items()}
-    assert set(ptrs) == {"feat", "cos", "stats"}
+    assert set(ptrs) == {"feat", "cos", "stats1"}
     y2 = model(latent_tokens_coord=lat.to(dev()), xcoord=x.to(dev()), pndata=p)           # fresh uploads, same bytes
     assert torch.equal(y1, y2)
     assert {k: v["val"].data_ptr() for k, v in plan._coord_cache.items()} == ptrs and plan_for(nb, 2000) is plan
@@ -456,7 +456,7 @@ def test_geometry_caches_hit_by_content_not_identity():
     feat = plan.edge_features(xs, ls)
     cos = plan.cosine_attention(xs, ls)
     st = plan.geo_stats(xs, ls)
-    assert feat.data_ptr() == ptrs["feat"] and st.data_ptr() == ptrs["stats"]
+    assert feat.data_ptr() == ptrs["feat"] and st.data_ptr() == ptrs["stats1"]
     idx, sp = nb["neighbors_index"].cpu(), nb["neighbors_row_splits"].cpu()
     qid, _ = O.edge_query_ids(sp)
     assert torch.equal(feat.cpu(), torch.cat([x2[idx], lat[qid]], dim=1))
@@ -470,3 +470,48 @@ def test_geometry_caches_hit_by_content_not_identity():
         e_new = model.encode(x2.to(dev()), p, lat.to(dev()), None)
         e_new2 = model.encode(x2.to(dev()), p, lat.to(dev()), None)
     assert rel_l2(e_new.cpu(), e_old.cpu()) > 1e-4 and torch.equal(e_new, e_new2)
+
+
+def test_vx_union_composed_from_per_sample_plans_equals_union_planned_afresh():
+    """vx mode re-planning (reference magno.py:356-413 loops over samples): the block-diagonal union of a batch is either planned
+    over the concatenated CSR (fresh dicts) or COMPOSED from per-sample plans by concatenation with offsets (dicts seen before,
+    any batch order).  Both must give the same int32 CSR, transposed CSR (edge ids ascending per source -- also for the
+    350-edge rows of these skewed meshes), per-sample standardised statistics, edge features and attention weights."""
+    from gaot_amd.plan import MergedGeometry, merged_geometry
+    from gaot_amd.model.layers.utils.neighbor_search import NeighborSearch
+    g = torch.Generator().manual_seed(31)
+    B, N = 5, 4096
+    lat = grid([64, 64]).to(dev())
+    xs = [naca_points(N, g, 0.12).to(dev()) for _ in range(B)]
+    ns = NeighborSearch("native")
+    for src_of, dst_of in ((lambda b: xs[b], lambda b: lat), (lambda b: lat, lambda b: xs[b])):      # encoder- and decoder-shaped
+        dicts = [ns(src_of(b), dst_of(b), 0.033) for b in range(B)]
+        order = [3, 0, 4, 1, 2]
+        fresh = MergedGeometry([dicts[i] for i in order], [src_of(i) for i in order], [dst_of(i) for i in order])
+        comp = MergedGeometry([dicts[i] for i in order], [src_of(i) for i in order], [dst_of(i) for i in order], build_parts=True)
+        assert not fresh.composed and comp.composed
+        a, b = fresh.plan, comp.plan
+        assert (a.Q, a.E, a.n_src) == (b.Q, b.E, b.n_src)
+        for name in ("index", "splits", "edge_query", "t_splits", "t_edge"):
+            assert torch.equal(getattr(a, name)[:a.E if name in ("index", "edge_query", "t_edge") else None], getattr(b, name)[:a.E if name in ("index", "edge_query", "t_edge") else None]), name
+        assert torch.equal(a.deg, b.deg)
+        te, ts_ = b.t_edge[:b.E].cpu(), b.t_splits.cpu()
+        long_rows = 0
+        for j in torch.nonzero((ts_[1:] - ts_[:-1]) > 64).flatten().tolist()[:50]:      # the long rows went through the rank sort
+            seg = te[ts_[j]:ts_[j + 1]]
+            assert bool((seg[1:] > seg[:-1]).all())
+            long_rows += 1
+        assert torch.equal(fresh.geo_stats(), comp.geo_stats())
+        assert torch.equal(a.edge_features(fresh.src, fresh.dst), b.edge_features(comp.src, comp.dst))
+        assert torch.equal(a.cosine_attention(fresh.src, fresh.dst), b.cosine_attention(comp.src, comp.dst))
+        # per-sample statistics inside the union == statistics of each sample alone
+        from gaot_amd.plan import plan_for
+        alone = torch.cat([plan_for(dicts[i], src_of(i).shape[0]).geo_stats(src_of(i), dst_of(i)) for i in order])
+        assert rel_l2(comp.geo_stats().cpu(), alone.cpu()) < 1e-6
+    # the cache: first sight of a batch plans the union afresh, a later batch of the same dicts (other order) composes
+    dicts = [ns(xs[b], lat, 0.033) for b in range(B)]
+    x_all = torch.stack(xs)
+    m1 = merged_geometry(dicts, xs, [lat] * B, parents=(x_all, lat))
+    perm = [4, 2, 0, 1, 3]
+    m2 = merged_geometry([dicts[i] for i in perm], [xs[i] for i in perm], [lat] * B, parents=(x_all[perm], lat))
+    assert not m1.composed and m2.composed
