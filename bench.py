@@ -74,8 +74,10 @@ def gemm_roofline(ts):
 
     # the HBM regime: the fused gather / segment-reduce / edge-gradient kernels of the integral transforms (csrc/gno.hip)
     gno = []
-    GNO_CALLS = {"gaot_gno_lift_gather_reduce": "encoder fwd", "gaot_gno_lift_edge_grad": "encoder bwd",
-                 "gaot_gno_proj_gather_reduce": "decoder fwd", "gaot_gno_proj_backward": "decoder bwd",
+    GNO_CALLS = {"gaot_gno_lift_gather_reduce": "encoder fwd", "gaot_gno_lift_gather_reduce_ep": "encoder fwd",
+                 "gaot_gno_lift_edge_grad": "encoder bwd",
+                 "gaot_gno_proj_gather_reduce": "decoder fwd", "gaot_gno_proj_gather_reduce_bin": "decoder fwd",
+                 "gaot_gno_proj_backward": "decoder bwd", "gaot_gno_proj_gather_t_ep": "decoder bwd",
                  "gaot_gno_gather_reduce": "unfused transform", "gaot_gno_edge_grad": "unfused edge grad"}
     saved = {}
     for name in GNO_CALLS:

@@ -87,6 +87,11 @@ PROTOTYPES = {
     "gaot_mse_loss_bwd": (C.c_int, [_f, _f, C.c_int64, _f, _f, _s]),
     "gaot_adamw_step": (C.c_int, [_f, _f, _f, _f, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _f, _s]),
     "gaot_adamw_step_dev": (C.c_int, [_f, _f, _f, _f, C.c_int64, _f, _f, _s]),
+    "gaot_debug_set_ep_chunk": (C.c_int, [C.c_int]),
+    "gaot_gno_ep_workspace": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "gaot_gno_lift_gather_reduce_ep": (C.c_int, [_f, _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i, _i, _i, C.c_int32, C.c_int32, _f, _f, _f, _s]),
+    "gaot_gno_proj_gather_t_ep": (C.c_int, [_f, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i, _i, C.c_int32, _i, _i, _f, _f, _f, _s]),
+    "gaot_gno_proj_gather_reduce_bin": (C.c_int, [_f, _f, _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i, _i, C.c_int32, _f, _f, _s]),
     "gaot_rope_inplace": (C.c_int, [_f, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _f, C.c_int32, _s]),
     "gaot_edge_dot_score": (C.c_int, [_f, _f, C.c_int32, _i, _i, C.c_int32, C.c_float, _f, _s]),
     "gaot_edge_rowdot_scale": (C.c_int, [_f, _f, _f, C.c_int32, C.c_int32, _f, _s]),

@@ -99,6 +99,15 @@ def gemm(M: int, N: int, K: int, A, lda, a_kmajor, B, ldb, b_kmajor, out, ldc, *
 # + the split-bf16 tiles where the heuristic picks them; 1 = fp32 MFMA tiles only); the split-K choice below follows it
 _FUSED_KERNEL_MLP = os.environ.get("GAOT_FUSED_KERNEL_MLP", "1") != "0"     # A/B switch for tools; the chain path is also HIP
 _GEMM_MODE = int(os.environ.get("GAOT_GEMM_MODE", "4"))
+# integral-transform kernel choice: 2 (default) = edge-partitioned kernels on degree-skewed plans + batch-inside decoder forward,
+# 1 = edge-partitioned everywhere, 0 = the row-parallel kernels of round 1 (A/B switch for tools and tests)
+_GNO_EP = int(os.environ.get("GAOT_GNO_EP", "2"))
+
+
+def set_gno_ep(mode: int) -> int:
+    global _GNO_EP
+    old, _GNO_EP = _GNO_EP, int(mode)
+    return old
 if _GEMM_MODE != 4:
     L.load().gaot_debug_set_gemm_glds(_GEMM_MODE)
 if os.environ.get("GAOT_ATTN_SPLIT", "1") != "1":          # A/B switch: argument of gaot_debug_set_attention_split (0 = fp32 MFMA)
@@ -617,9 +626,17 @@ class _GNOLiftTransform(torch.autograd.Function):
         Cc = k.shape[1]
         w2 = wl.reshape(Cc, ci).contiguous()
         out = torch.empty(B, plan.Q, Cc, device=k.device, dtype=torch.float32)
-        L.check(L.load().gaot_gno_lift_gather_reduce(_p(k), _p(pn), _p(w2), _p(bl), B, n_src, ci, Cc, _p(plan.splits),
-                                                     _p(plan.index), plan.Q, _p(escale), _p(out), _stream()),
-                "gaot_gno_lift_gather_reduce")
+        lib = L.load()
+        if _GNO_EP == 1 or (_GNO_EP == 2 and plan.rows_skewed and Cc <= 256):
+            # degree-skewed rows: edge-partitioned kernel with segmented reductions (csrc/gno_ep.hip)
+            ws = torch.empty(int(lib.gaot_gno_ep_workspace(plan.E, Cc, B)), device=k.device, dtype=torch.float32)
+            L.check(lib.gaot_gno_lift_gather_reduce_ep(_p(k), _p(pn), _p(w2), _p(bl), B, n_src, ci, Cc, _p(plan.splits), _p(plan.index),
+                                                       _p(plan.edge_query), plan.Q, plan.E, _p(escale), _p(out), _p(ws), _stream()),
+                    "gaot_gno_lift_gather_reduce_ep")
+        else:
+            L.check(lib.gaot_gno_lift_gather_reduce(_p(k), _p(pn), _p(w2), _p(bl), B, n_src, ci, Cc, _p(plan.splits),
+                                                    _p(plan.index), plan.Q, _p(escale), _p(out), _stream()),
+                    "gaot_gno_lift_gather_reduce")
         ctx.plan = plan
         ctx.save_for_backward(k, pn, w2, bl if bl is not None else k.new_empty(0), escale if escale is not None else k.new_empty(0))
         ctx.meta = (wl.shape, bl is not None, escale is not None, _claim(wl), _claim(bl))
@@ -666,9 +683,14 @@ class _GNOProjTransform(torch.autograd.Function):
         OC = weff.shape[0]
         rb = rowb.contiguous() if rowb is not None else None
         y = torch.empty(B, plan.Q, OC, device=k.device, dtype=torch.float32)
-        L.check(L.load().gaot_gno_proj_gather_reduce(_p(k), _p(f), _p(weff), _p(rb), _p(bias), B, n_src, Cc, OC, _p(plan.splits),
-                                                     _p(plan.index), plan.Q, _p(escale), _p(y), _stream()),
-                "gaot_gno_proj_gather_reduce")
+        if _GNO_EP != 0 and B > 1:      # batch inside the lane group: every kernel-value row is read once per 4 samples
+            L.check(L.load().gaot_gno_proj_gather_reduce_bin(_p(k), _p(f), _p(weff), _p(rb), _p(bias), B, n_src, Cc, OC, _p(plan.splits),
+                                                             _p(plan.index), plan.Q, _p(escale), _p(y), _stream()),
+                    "gaot_gno_proj_gather_reduce_bin")
+        else:
+            L.check(L.load().gaot_gno_proj_gather_reduce(_p(k), _p(f), _p(weff), _p(rb), _p(bias), B, n_src, Cc, OC, _p(plan.splits),
+                                                         _p(plan.index), plan.Q, _p(escale), _p(y), _stream()),
+                    "gaot_gno_proj_gather_reduce")
         ctx.plan = plan
         ctx.save_for_backward(k, f, weff, escale if escale is not None else k.new_empty(0))
         ctx.meta = (escale is not None, rowb.shape if rowb is not None else None, bias is not None)
@@ -695,10 +717,16 @@ class _GNOProjTransform(torch.autograd.Function):
         else:
             nparts = int(lib.gaot_gno_lift_edge_grad_parts(plan.E, Cc))
             part = torch.empty(nparts, OC * Cc, device=k.device, dtype=torch.float32)
+            ep = df is not None and (_GNO_EP == 1 or (_GNO_EP == 2 and plan.t_rows_skewed))
             L.check(lib.gaot_gno_proj_backward(_p(dy), _p(k), _p(f), _p(weff), B, plan.Q, n_src, Cc, OC, _p(plan.index),
                                                _p(plan.edge_query), plan.E, _p(plan.t_splits), _p(plan.t_edge),
-                                               _p(esc) if has_e else None, _p(dk), _p(part), _p(df), _stream()),
+                                               _p(esc) if has_e else None, _p(dk), _p(part), None if ep else _p(df), _stream()),
                     "gaot_gno_proj_backward")
+            if ep:      # dF over the (skewed) transposed CSR: edge-partitioned, segmented
+                ws = torch.empty(int(lib.gaot_gno_ep_workspace(plan.E, Cc, B)), device=k.device, dtype=torch.float32)
+                L.check(lib.gaot_gno_proj_gather_t_ep(_p(k), _p(dy), _p(weff), B, plan.Q, n_src, Cc, OC, _p(plan.index), _p(plan.edge_query),
+                                                      plan.E, _p(plan.t_splits), _p(plan.t_edge), _p(esc) if has_e else None, _p(df), _p(ws),
+                                                      _stream()), "gaot_gno_proj_gather_t_ep")
             dweff = colsum(part).reshape(OC, Cc)
         if rb_shape is not None and need[3]:
             drowb = batchsum(dy.reshape(B, -1), B).reshape(rb_shape)

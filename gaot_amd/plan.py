@@ -72,11 +72,29 @@ class GeometryPlan:
                                        _stream()), "gaot_csr_transpose")
         deg = (splits_i64[1:] - splits_i64[:-1])
         self.deg = deg
+        # degree skew decides between the row-parallel and the edge-partitioned transform kernels (ops.py).  A plan built with a
+        # host sync anyway (validate=True) reads the two maxima now; a lazily validated one does not wait for them and is
+        # treated as skewed (the edge-partitioned kernels are right for any distribution)
+        self.max_deg = self.max_t_deg = (0 if self.E == 0 else None)
+        if validate is True and self.E > 0:
+            td = self.t_splits[1:] - self.t_splits[:-1]
+            m = torch.stack([deg.max().to(torch.int64), td.max().to(torch.int64)]).cpu()
+            self.max_deg, self.max_t_deg = int(m[0]), int(m[1])
         self._inv_deg_edge: Optional[torch.Tensor] = None
         self._edge_query_long: Optional[torch.Tensor] = None
         self._index_long = index_i64
         self._coord_cache: Dict[str, dict] = {}
         self.epoch = 0                # bumped whenever a coordinate-derived array may have been refreshed in place
+
+    SKEW_DEGREE = 48      # rows longer than this (or unknown) go to the edge-partitioned kernels
+
+    @property
+    def rows_skewed(self) -> bool:
+        return self.max_deg is None or self.max_deg > self.SKEW_DEGREE
+
+    @property
+    def t_rows_skewed(self) -> bool:
+        return self.max_t_deg is None or self.max_t_deg > self.SKEW_DEGREE
 
     # ---- lazily derived
     @property
@@ -220,6 +238,8 @@ def compose_plans(plans) -> GeometryPlan:
     _concat_offset([p.splits for p in plans], [p.Q + (1 if i == last else 0) for i, p in enumerate(plans)], e_off[:-1], m.splits)
     _concat_offset([p.t_splits for p in plans], [p.n_src + (1 if i == last else 0) for i, p in enumerate(plans)], e_off[:-1], m.t_splits)
     m.deg = torch.cat([p.deg for p in plans])
+    m.max_deg = None if any(p.max_deg is None for p in plans) else max(p.max_deg for p in plans)
+    m.max_t_deg = None if any(p.max_t_deg is None for p in plans) else max(p.max_t_deg for p in plans)
     m._inv_deg_edge = m._edge_query_long = None
     m._index_long = None
     m._coord_cache = {}

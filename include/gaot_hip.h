@@ -280,6 +280,30 @@ int gaot_patchify(const float* in, int32_t B, int32_t H, int32_t W, int32_t Dz, 
                   float* out, int32_t inverse, gaot_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Edge-partitioned forms of the fused integral-transform kernels (csrc/gno_ep.hip): the edge list is cut into equal chunks, a
+ * lane group walks one chunk with a running (segmented) sum per sample, rows that span chunks are completed from carry slots
+ * by a second small kernel in chunk order.  Same results as the row-parallel forms up to summation order inside a row;
+ * the work per lane group no longer depends on the degree distribution (BASELINE config 3: rows of 350+ edges next to empty
+ * rows).  ws: gaot_gno_ep_workspace(E, C, B) floats.
+ *   gaot_gno_lift_gather_reduce_ep : as gaot_gno_lift_gather_reduce (+ edge_query[E])
+ *   gaot_gno_proj_gather_t_ep      : the dF product of gaot_gno_proj_backward over the transposed CSR
+ *   gaot_gno_proj_gather_reduce_bin: gaot_gno_proj_gather_reduce with the batch INSIDE the lane group (each kernel-value row is
+ *                                    read once for 4 samples instead of once per sample)
+ * ------------------------------------------------------------------------------------------ */
+int64_t gaot_gno_ep_workspace(int32_t E, int32_t C, int32_t B);
+int gaot_debug_set_ep_chunk(int edges_per_chunk);      /* tuning only: 0 = default (32) */
+int gaot_gno_lift_gather_reduce_ep(const float* k, const float* pn, const float* wl, const float* bl, int32_t B, int32_t n_src,
+                                   int32_t c_in, int32_t C, const int32_t* splits, const int32_t* cols, const int32_t* edge_query,
+                                   int32_t Q, int32_t E, const float* escale, float* out, float* ws, gaot_stream_t stream);
+int gaot_gno_proj_gather_t_ep(const float* k, const float* dy, const float* weff, int32_t B, int32_t Q, int32_t n_src, int32_t C,
+                              int32_t out_channels, const int32_t* index32, const int32_t* edge_query, int32_t E,
+                              const int32_t* t_splits, const int32_t* t_edge, const float* escale, float* df, float* ws,
+                              gaot_stream_t stream);
+int gaot_gno_proj_gather_reduce_bin(const float* k, const float* f, const float* weff, const float* rowbias, const float* bias,
+                                    int32_t B, int32_t n_src, int32_t C, int32_t out_channels, const int32_t* splits,
+                                    const int32_t* cols, int32_t Q, const float* escale, float* y, gaot_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Operator variants off the default configuration (csrc/glue.hip).
  * ------------------------------------------------------------------------------------------ */
 /* RoPE on queries and keys (attn.py:106-108; rotary_embedding_torch.RotaryEmbedding(dim=head_dim).rotate_queries_or_keys: the
