@@ -1,0 +1,223 @@
+"""hipGraph replay of GAOT's training forward and backward INSIDE an unchanged eager training loop.
+
+The reference trainer (optimizers.py:247-257 around static_trainer.py:160-178) drives the model eagerly: per step it uploads
+the batch and the coordinates, calls `model(...)`, `loss_fn`, `loss.backward()`, `optimizer.step()`.  Run that way the HIP path
+is host-bound in places (a few hundred kernel launches through Python per step) and every upload from pageable memory drains
+the stream.  `trainer.TrainStep` avoids all of it, but it is another API.  This module keeps the reference loop as it is:
+
+    GAOT.forward (training mode, fixed shapes, fx coordinates)  ->  _GraphedStep.apply(pndata, *parameters)
+        forward : copy pndata into a static buffer, replay the captured forward graph, hand back a copy of its output
+        backward: copy the incoming gradient into a static buffer, replay the captured backward graph, return parameter
+                  gradients as views of ONE static flat gradient buffer (the weight-gradient GEMMs wrote them there directly:
+                  ops._claim) -- AccumulateGrad adopts them without a copy after the usual optimizer.zero_grad().
+
+Geometry: the model owns static coordinate buffers.  When the caller hands over NEW coordinate tensors (the reference trainer
+uploads them every step) two small kernels compare their bytes with the static buffers and raise a device flag, the buffers are
+overwritten, and the captured forward graph BEGINS with the plans' refresh kernels (kernel-MLP rows, cosine attention, geometry
+statistics) guarded by that flag: they recompute in place only if the bytes changed, and the graph's last node clears the
+flag.  No host synchronisation, four extra launches per step.  Weights are read through their storage pointers: in-place optimizers (torch.optim.*) keep them; if a
+parameter's storage moves (or a shape, the batch size, the training flag changes) the step is captured again.
+
+Not eligible (the eager HIP path runs as before): evaluation / no_grad, vx coordinates, caller-supplied neighbour lists,
+neighbour sub-sampling, node_embedding, pndata that requires grad, host tensors, or `model.auto_graph = False` /
+GAOT_AUTO_GRAPH=0.  trainer.TrainStep switches it off for its model (it captures the whole step itself).
+"""
+import os
+from typing import Optional
+
+import torch
+
+from . import ops
+
+ENABLED = os.environ.get("GAOT_AUTO_GRAPH", "1") != "0"
+MAX_ENTRIES = 3          # distinct (shape, mode) keys kept captured per model
+
+
+class _Entry:
+    pass
+
+
+def eligible(model, latent, xcoord, pndata, query_coord, encoder_nbrs, decoder_nbrs, condition) -> bool:
+    if not (ENABLED and getattr(model, "auto_graph", True) and model.training and torch.is_grad_enabled()):
+        return False
+    if getattr(model, "_auto_graph_bypass", False):
+        return False
+    if encoder_nbrs is not None or decoder_nbrs is not None or query_coord is not None:
+        return False
+    if not (pndata.is_cuda and xcoord.is_cuda and latent.is_cuda) or pndata.requires_grad or xcoord.dim() != 2:
+        return False
+    if condition is not None and not (torch.is_tensor(condition) and condition.is_cuda and not condition.requires_grad):
+        return False
+    if torch.cuda.is_current_stream_capturing():
+        return False
+    for side in (model.encoder, model.decoder):
+        if side.sampling_strategy is not None or side.node_embedding or side.precompute_edges:
+            return False
+    return True
+
+
+def _key(model, latent, xcoord, pndata, condition):
+    return (tuple(pndata.shape), pndata.dtype, tuple(xcoord.shape), tuple(latent.shape),
+            None if condition is None else tuple(condition.shape), pndata.device.index,
+            tuple(p.data_ptr() for p in model.parameters()))
+
+
+class _GraphedStep(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, entry, pndata, condition, *params):
+        entry.p.copy_(pndata, non_blocking=True)
+        if condition is not None:
+            entry.c.copy_(condition, non_blocking=True)
+        entry.g_fwd.replay()
+        ctx.entry = entry
+        return entry.y.clone()
+
+    @staticmethod
+    def backward(ctx, gy):
+        e = ctx.entry
+        e.gy.copy_(gy, non_blocking=True)
+        # gradient accumulation (a caller that did not zero .grad): the .grad tensors may be the views of the static buffer handed
+        # out last time, which the replay is about to overwrite -- keep their values, hand out copies of the new gradients
+        accumulate = any(p.grad is not None for p in e.params)
+        prev = e.flat_g.clone() if accumulate else None
+        e.g_bwd.replay()
+        src = e.flat_g
+        if accumulate:
+            src = e.flat_g.clone()
+            e.flat_g.copy_(prev)
+        grads = []
+        for p, (o, n, live) in zip(e.params, e.slices):
+            grads.append(src[o:o + n].view_as(p) if live else None)
+        return (None, None, None, *grads)
+
+
+def _static_coordinates(model, latent, xcoord):
+    """per model and coordinate shapes: static buffers (lat, x) + the device flag 'their bytes just changed'"""
+    store = model.__dict__.setdefault("_auto_graph_coords", {})
+    key = (tuple(latent.shape), tuple(xcoord.shape), latent.device.index)
+    if key not in store:
+        store[key] = (latent.detach().clone(), xcoord.detach().clone(), torch.zeros(1, dtype=torch.int32, device=latent.device))
+    return store[key]
+
+
+def _plans(model, lat, x):
+    from .plan import plan_for
+    for side, src, dst in ((model.encoder, x, lat), (model.decoder, lat, x)):
+        for nb in side._compute_neighbors(src, dst, 'fx'):
+            yield plan_for(nb, src.shape[0]), (src, dst)
+
+
+def _capture(model, latent, xcoord, pndata, condition) -> _Entry:
+    from . import plan as P
+    from . import _lib as L
+    e = _Entry()
+    dev = pndata.device
+    params = [p for p in model.parameters()]
+    e.params = params
+    e.lat, e.x, e.flag = _static_coordinates(model, latent, xcoord)
+    e.lat.copy_(latent)
+    e.x.copy_(xcoord)
+    e.p = pndata.detach().clone()
+    e.c = None if condition is None else condition.detach().clone()
+    # one flat static gradient buffer; every trainable parameter gets a 256-byte aligned slice (the weight-gradient GEMMs write
+    # straight into it: ops._claim)
+    off, slices = 0, []
+    for p in params:
+        off = -(-off // 64) * 64
+        slices.append([off, p.numel(), p.requires_grad])
+        off += p.numel()
+    e.flat_g = torch.zeros(max(off, 1), device=dev, dtype=torch.float32)
+    e.slices = slices
+    # The captured autograd graph gets its OWN leaves: detached aliases of the parameters (same storage).  The module's
+    # parameters keep AccumulateGrad nodes tied to the stream they were first used on; letting a capture touch those draws
+    # the default stream into the capture (hipStreamEndCapture then fails on the unjoined fork).
+    names = [n for n, _ in model.named_parameters()]
+    leaves = {n: p.detach().requires_grad_(p.requires_grad) for n, p in zip(names, params)}
+    train = [leaves[n] for n, p in zip(names, params) if p.requires_grad]
+    views = [e.flat_g[o:o + n].view_as(p) for p, (o, n, live) in zip(params, slices) if live]
+
+    def fwd():
+        model._auto_graph_bypass = True
+        try:
+            return torch.func.functional_call(model, leaves, (), dict(latent_tokens_coord=e.lat, xcoord=e.x, pndata=e.p, condition=e.c))
+        finally:
+            model._auto_graph_bypass = False
+
+    def fwd_bwd(gy):
+        ops.register_grad_slots(train, views)
+        ops.release_grad_slots()
+        y = fwd()
+        gs = torch.autograd.grad(y, train, gy, allow_unused=True)
+        return y, gs
+
+    def settle(gs):
+        """gradients that did not land in their slice (no claim: tiny vectors, parameters used twice) are copied there"""
+        for v, g in zip(views, gs):
+            if g is None:
+                v.zero_()
+            elif g.data_ptr() != v.data_ptr():
+                v.copy_(g)
+
+    saved_slots = dict(ops._GRAD_SLOTS)
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            y = fwd()                               # plans see the static coordinate buffers (content guard: same bytes)
+            for plan, pair in _plans(model, e.lat, e.x):
+                P.adopt_static_coordinates(plan, pair)
+            e.gy = torch.zeros_like(y)
+            P.FORCE_GUARD[0] = e.flag               # from here on the plans' refresh kernels are launched, guarded by the flag
+            for _ in range(2):
+                _, gs = fwd_bwd(e.gy)
+                settle(gs)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        pool = torch.cuda.graph_pool_handle()
+        e.g_fwd = torch.cuda.CUDAGraph()
+        ops.register_grad_slots(train, views)
+        ops.release_grad_slots()
+        with torch.cuda.graph(e.g_fwd, pool=pool, stream=side, capture_error_mode="thread_local"):
+            e.y = fwd()
+            L.check(L.load().gaot_guard_begin(ops._p(e.flag), ops._stream()), "gaot_guard_begin")      # last node: flag = 0
+        P.FORCE_GUARD[0] = None
+        e.g_bwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(e.g_bwd, pool=pool, stream=side, capture_error_mode="thread_local"):
+            gs = torch.autograd.grad(e.y, train, e.gy, allow_unused=True)
+            settle(gs)
+    finally:
+        P.FORCE_GUARD[0] = None
+        ops._GRAD_SLOTS.clear()
+        ops._GRAD_SLOTS.update(saved_slots)
+    return e
+
+
+def run(model, latent, xcoord, pndata, condition) -> Optional[torch.Tensor]:
+    """the training forward through captured graphs, or None when the step cannot be (or could not be) captured"""
+    cache = model.__dict__.setdefault("_auto_graph_cache", {})
+    key = _key(model, latent, xcoord, pndata, condition)
+    e = cache.get(key)
+    if e is None:
+        if len(cache) >= MAX_ENTRIES:
+            cache.pop(next(iter(cache)))
+        # the first call with this key runs eagerly (it also builds the neighbour lists and plans, which synchronise);
+        # the second one captures
+        if key not in model.__dict__.setdefault("_auto_graph_seen", set()):
+            model._auto_graph_seen.add(key)
+            if len(model._auto_graph_seen) > 16:
+                model._auto_graph_seen.clear()
+            return None
+        e = _capture(model, latent, xcoord, pndata, condition)
+        cache[key] = e
+    # geometry: new coordinate tensors (a trainer that uploads them every step): compare with the static buffers (flag |= differ),
+    # overwrite the buffers; the captured forward starts with the flag-guarded refresh of the plans' arrays and ends by clearing it
+    if xcoord is not e.__dict__.get("last_x") or latent is not e.__dict__.get("last_lat"):
+        from . import _lib as L
+        lib = L.load()
+        for new, kept in ((xcoord, e.x), (latent, e.lat)):
+            new = new.contiguous()
+            L.check(lib.gaot_guard_compare(ops._p(new), ops._p(kept), kept.numel() * kept.element_size(), ops._p(e.flag), ops._stream()),
+                    "gaot_guard_compare")
+            kept.copy_(new, non_blocking=True)
+        e.last_x, e.last_lat = xcoord, latent
+    return _GraphedStep.apply(e, pndata, condition, *e.params)

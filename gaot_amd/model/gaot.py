@@ -8,7 +8,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import autograph, ops
 from .layers.attn import Transformer
 from .layers.magno import MAGNODecoder, MAGNOEncoder
 
@@ -104,6 +104,15 @@ class GAOT(nn.Module):
     def forward(self, latent_tokens_coord: torch.Tensor, xcoord: torch.Tensor, pndata: torch.Tensor,
                 query_coord: Optional[torch.Tensor] = None, encoder_nbrs: Optional[list] = None,
                 decoder_nbrs: Optional[list] = None, condition: Optional[float] = None) -> torch.Tensor:
+        # an unchanged eager training loop (the reference trainer's) on fixed shapes: forward and backward as hipGraph replays
+        if autograph.eligible(self, latent_tokens_coord, xcoord, pndata, query_coord, encoder_nbrs, decoder_nbrs, condition):
+            out = autograph.run(self, latent_tokens_coord, xcoord, pndata, condition)
+            if out is not None:
+                return out
+        return self._forward_eager(latent_tokens_coord, xcoord, pndata, query_coord, encoder_nbrs, decoder_nbrs, condition)
+
+    def _forward_eager(self, latent_tokens_coord, xcoord, pndata, query_coord=None, encoder_nbrs=None, decoder_nbrs=None,
+                       condition=None) -> torch.Tensor:
         rn = self.encode(x_coord=xcoord, pndata=pndata, latent_tokens_coord=latent_tokens_coord, encoder_nbrs=encoder_nbrs)
         rn = ops.cut(rn)                      # staged backward (data-parallel training): encoder gradients complete last
         rn = self.process(rndata=rn, condition=condition)

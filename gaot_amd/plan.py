@@ -18,6 +18,21 @@ _PLAN_KEY = "_gaot_amd_plan"
 
 
 _PENDING: list = []          # (device flag, event) of plans built with validate="lazy"
+FORCE_GUARD = [None]         # set by autograph.py while it captures: a device flag that guards re-computation inside the graph
+
+
+def adopt_static_coordinates(plan: "GeometryPlan", tensors) -> None:
+    """autograph.py: `tensors` (src, dst) are static coordinate buffers that it keeps current.  The plan's arrays derived from a
+    coordinate pair of these shapes take them as THE kept copy, so the eager content guard and the captured refresh agree on
+    what the arrays hold."""
+    gkey = tuple((tuple(t.shape), t.dtype, t.device) for t in tensors)
+    grp = plan._groups.get(gkey)
+    if grp is None:
+        return
+    key = tuple((id(t), t._version) for t in tensors)
+    grp["kept"], grp["key"], grp["hold"] = list(tensors), key, tuple(tensors)
+    for entry in grp["arrays"].values():
+        entry["key"] = key
 
 
 def _raise_if_bad(bad: int):
@@ -84,6 +99,7 @@ class GeometryPlan:
         self._edge_query_long: Optional[torch.Tensor] = None
         self._index_long = index_i64
         self._coord_cache: Dict[str, dict] = {}
+        self._groups: Dict[tuple, dict] = {}          # per coordinate pair (by shapes): kept bytes + the arrays derived from them
         self.epoch = 0                # bumped whenever a coordinate-derived array may have been refreshed in place
 
     SKEW_DEGREE = 48      # rows longer than this (or unknown) go to the edge-partitioned kernels
@@ -120,34 +136,52 @@ class GeometryPlan:
     def _cached(self, name: str, tensors, alloc, compute):
         """geometry-only array `name` derived from coordinate tensors.
           * same tensor objects (and versions) as last time            -> the cached array, no launch;
-          * NEW objects of the same shape (a trainer that re-uploads the coordinates every step,
+          * NEW objects of the same shapes (a trainer that re-uploads the coordinates every step,
             static_trainer.py:167-170)                                  -> device-side content guard: the bytes are compared
-            with the kept copy and the array is recomputed IN PLACE only if they differ -- no host synchronisation;
+            with the kept copy ONCE for all arrays derived from that coordinate pair, and those arrays are recomputed IN PLACE
+            only if they differ -- no host synchronisation;
           * otherwise                                                   -> fresh allocation and computation."""
         key = tuple((id(t), t._version) for t in tensors)
         hit = self._coord_cache.get(name)
         if hit is not None and hit["key"] == key:
+            if FORCE_GUARD[0] is not None:
+                # autograph.py is capturing: the refresh of this array becomes part of the captured forward, guarded by a flag
+                # the caller raises when it finds new coordinate bytes (the tensors here are its static coordinate buffers)
+                compute(hit["full"], [t.contiguous() for t in tensors], FORCE_GUARD[0])
             return hit["val"]
-        lib = L.load()
-        if hit is not None and all(t.shape == k.shape and t.dtype == k.dtype and t.device == k.device for t, k in zip(tensors, hit["kept"])):
-            flag = hit["flag"]
-            cur = [t.contiguous() for t in tensors]
-            L.check(lib.gaot_guard_begin(_p(flag), _stream()), "gaot_guard_begin")
-            for t, k in zip(cur, hit["kept"]):
-                L.check(lib.gaot_guard_compare(_p(t), _p(k), t.numel() * t.element_size(), _p(flag), _stream()), "gaot_guard_compare")
-            for t, k in zip(cur, hit["kept"]):
-                L.check(lib.gaot_guard_update(_p(t), _p(k), t.numel() * t.element_size(), _p(flag), _stream()), "gaot_guard_update")
-            compute(hit["full"], cur, flag)
-            hit["key"], hit["hold"] = key, tuple(tensors)
-            self.epoch += 1           # dependants cached on the host (inference-time kernel values, row bias) must re-derive
-            return hit["val"]
+        gkey = tuple((tuple(t.shape), t.dtype, t.device) for t in tensors)
+        grp = self._groups.get(gkey)
         cur = [t.contiguous() for t in tensors]
+        if grp is not None and grp["key"] != key:
+            self._refresh_group(grp, key, tensors, cur)
+        if hit is not None and hit.get("group") is grp and grp is not None:
+            return hit["val"]
         full, val = alloc(cur)
         compute(full, cur, None)
-        self._coord_cache[name] = {"key": key, "hold": tuple(tensors), "val": val, "full": full,
-                                   "kept": [t.clone() for t in cur],
-                                   "flag": torch.zeros(1, dtype=torch.int32, device=cur[0].device)}
+        if grp is None:
+            grp = {"key": key, "hold": tuple(tensors), "kept": [t.clone() for t in cur], "arrays": {},
+                   "flag": torch.zeros(1, dtype=torch.int32, device=cur[0].device)}
+            self._groups[gkey] = grp
+        entry = {"key": key, "val": val, "full": full, "compute": compute, "group": grp}
+        grp["arrays"][name] = entry
+        self._coord_cache[name] = entry
         return val
+
+    def _refresh_group(self, grp, key, tensors, cur):
+        """new tensor objects for a coordinate pair the plan already holds arrays for: compare, update the kept copy, recompute
+        every array of the pair under the guard flag (all of them: they must stay consistent with the kept bytes)"""
+        lib = L.load()
+        flag = grp["flag"]
+        L.check(lib.gaot_guard_begin(_p(flag), _stream()), "gaot_guard_begin")
+        for t, k in zip(cur, grp["kept"]):
+            L.check(lib.gaot_guard_compare(_p(t), _p(k), t.numel() * t.element_size(), _p(flag), _stream()), "gaot_guard_compare")
+        for t, k in zip(cur, grp["kept"]):
+            L.check(lib.gaot_guard_update(_p(t), _p(k), t.numel() * t.element_size(), _p(flag), _stream()), "gaot_guard_update")
+        for entry in grp["arrays"].values():
+            entry["compute"](entry["full"], cur, flag)
+            entry["key"] = key
+        grp["key"], grp["hold"] = key, tuple(tensors)
+        self.epoch += 1               # dependants cached on the host (inference-time kernel values, row bias) must re-derive
 
     def edge_features(self, src: torch.Tensor, qry: torch.Tensor) -> torch.Tensor:
         """[y_j, x_i] rows of the kernel MLP (agno.py:229)."""
@@ -243,6 +277,7 @@ def compose_plans(plans) -> GeometryPlan:
     m._inv_deg_edge = m._edge_query_long = None
     m._index_long = None
     m._coord_cache = {}
+    m._groups = {}
     m.epoch = 0
     return m
 

@@ -289,6 +289,7 @@ class TrainStep:
         """`staged`: split the backward at the model's cut points and reduce each phase's gradient slice while the next phase
         runs (default: whenever there is more than one rank and the model offers `backward_phases()`)."""
         self.model = model
+        model.auto_graph = False          # this harness captures the whole step itself (autograph.py serves plain eager loops)
         self.group = group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         broadcast_parameters(model, 0, group)

@@ -515,3 +515,54 @@ def test_vx_union_composed_from_per_sample_plans_equals_union_planned_afresh():
     perm = [4, 2, 0, 1, 3]
     m2 = merged_geometry([dicts[i] for i in perm], [xs[i] for i in perm], [lat] * B, parents=(x_all[perm], lat))
     assert not m1.composed and m2.composed
+
+
+def test_auto_graph_reference_loop_equals_eager_loop():
+    """autograph.py: the reference trainer's loop, unchanged (per-step uploads of batch and coordinates, zero_grad, eager call,
+    nn.MSELoss, backward, torch.optim.AdamW), runs forward and backward as hipGraph replays from its third step on.  It must give
+    what the plain eager HIP path gives: same losses, same weights -- also when the coordinates' CONTENT changes under the same
+    shape mid-run (the captured kernels read geometry arrays that the device-side content guard refreshes in place), across an
+    evaluation in between, and with gradient accumulation (no zero_grad)."""
+    from gaot_amd.model.gaot import GAOT
+    model, sd, _ = make_model(2, 1, [32, 32], C=32, hidden=128, heads=4, radius=0.08, precompute=False, seed=41)
+    g = torch.Generator().manual_seed(41)
+    lat = grid([32, 32])
+    x1 = uniform_points(1800, 2, g)
+    x2 = (x1 + 0.002 * torch.randn(x1.shape, generator=g)).clamp(-1, 1)          # same shape, other bytes (steps 5..)
+    data = [(torch.randn(3, 1800, 2, generator=g), torch.randn(3, 1800, 1, generator=g)) for _ in range(8)]
+    runs = {}
+    for auto in (True, False):
+        m = GAOT(2, 1, model_cfg(model))
+        m.load_state_dict(sd)
+        m.to(dev()).train()
+        m.auto_graph = auto
+        opt = torch.optim.AdamW(m.parameters(), lr=2e-3, weight_decay=1e-4)
+        lossf = torch.nn.MSELoss()
+        losses, evals = [], []
+        for i, (p, t) in enumerate(data):
+            xc = x1 if i < 5 else x2
+            xb, yb, latd, coord = p.to(dev()), t.to(dev()), lat.to(dev()), xc.to(dev())       # fresh device tensors every step
+            opt.zero_grad()
+            loss = lossf(m(latent_tokens_coord=latd, xcoord=coord, pndata=xb), yb)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+            if i == 3:
+                m.eval()
+                with torch.no_grad():
+                    evals.append(m(latent_tokens_coord=latd, xcoord=coord, pndata=xb).cpu())
+                m.train()
+        if auto:
+            assert len(m._auto_graph_cache) == 1                                             # it did capture
+        # gradient accumulation: two backward passes without zero_grad
+        opt.zero_grad()
+        for p, t in data[:2]:
+            lossf(m(latent_tokens_coord=lat.to(dev()), xcoord=x2.to(dev()), pndata=p.to(dev())), t.to(dev())).backward()
+        acc = torch.cat([q.grad.detach().reshape(-1) for q in m.parameters()]).cpu()
+        runs[auto] = (losses, torch.cat([q.detach().reshape(-1) for q in m.parameters()]).cpu(), evals[0], acc)
+    la, wa, ea, ga = runs[True]
+    lb, wb, eb, gb = runs[False]
+    assert max(abs(a - b) / abs(b) for a, b in zip(la, lb)) < 1e-5, (la, lb)
+    assert float((wa - wb).abs().max()) < 2e-5
+    assert rel_l2(ea, eb) < 1e-5
+    assert rel_l2(ga, gb) < 1e-4
