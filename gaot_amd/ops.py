@@ -102,6 +102,7 @@ _GEMM_MODE = int(os.environ.get("GAOT_GEMM_MODE", "4"))
 # integral-transform kernel choice: 2 (default) = edge-partitioned kernels on degree-skewed plans + batch-inside decoder forward,
 # 1 = edge-partitioned everywhere, 0 = the row-parallel kernels of round 1 (A/B switch for tools and tests)
 _GNO_EP = int(os.environ.get("GAOT_GNO_EP", "2"))
+_NARROW_SPLIT = int(os.environ.get("GAOT_NARROW_SPLIT", "1"))        # A/B switch: split-K for narrow-output activation products
 
 
 def set_gno_ep(mode: int) -> int:
@@ -152,6 +153,16 @@ def linear_nt(x2: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = N
     return gemm(M, N, K, x2, lda, 1, w, ldb, 1, out, out.stride(0) if M > 1 else N, **epi)
 
 
+def _split_for_narrow_output(Mo: int, No: int, K: int) -> int:
+    """activation-side products whose output is only two 128-wide tiles across (N = 256) with a long reduction (K >= 2048,
+    du @ [w1;w3]): 128 output tiles leave half the CUs idle; two K halves on the split-bf16 tiles + one reduce measured
+    78 -> 61 us at 8192 x 256 x 2048 (tools/gemm_n256_sweep.py)"""
+    if _GEMM_MODE < 4 or _NARROW_SPLIT == 0 or K < 2048 or K % 64 or Mo % 4 or No % 4:
+        return 1
+    t128 = ((Mo + 127) // 128) * ((No + 127) // 128)
+    return 2 if 100 <= t128 < 200 else 1
+
+
 def matmul_nn(g: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, **epi) -> torch.Tensor:
     """out[M,K] = g[M,N] @ w[N,K]   (input gradient of a Linear with weight w)."""
     g, lda = _rowmajor(g)
@@ -161,6 +172,8 @@ def matmul_nn(g: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = No
     assert w.shape[0] == N
     if out is None:
         out = torch.empty(M, K, device=g.device, dtype=torch.float32)
+    if "split_k" not in epi:
+        epi["split_k"] = _split_for_narrow_output(M, K, N)
     return gemm(M, K, N, g, lda, 1, w, ldb, 0, out, out.stride(0) if M > 1 else K, **epi)
 
 
