@@ -253,6 +253,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-loop", action="store_true")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32 (default, the parity path).  bf16: GEMM operands rounded to bf16 wherever the tile kernels apply (one "
+                         "MFMA piece product instead of six, fp32 accumulation); attention, integral transforms, norms and the "
+                         "optimizer stay fp32.  A separately reported variant (BASELINE configs[1]), never the headline.")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -275,6 +279,10 @@ def main():
             dist.init_process_group(backend=backend)
 
     from gaot_amd.trainer import TrainStep
+    if args.dtype == "bf16":
+        from gaot_amd import ops, _lib
+        ops.set_gemm_mode(5)                  # split-tile kernels wherever eligible ...
+        _lib.load().gaot_debug_set_gemm_pieces(1)      # ... with ONE bf16 piece per operand
     torch.manual_seed(0)                      # identical weights on every rank (and broadcast from rank 0 anyway)
     model = build_model().to(dev).train()
     lat, x, p, t = synthetic(1234 + rank, dev)
@@ -341,7 +349,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.dtype == "f32" else "bf16 GEMM operands (RNE), fp32 accumulation; everything else f32 -- NOT the parity path",
             "data": "synthetic (uniform-random 16384-point 2-D mesh in [-1,1]^2, N(0,1) fields, random-init weights)",
             "config": {"workload": "BASELINE configs[1]: Poisson-Gauss-shaped 2D, 16384 nodes/mesh, batch 8 per GPU, fx mode; "
                                    "example model latent 64x64, C=64, patch 2, transformer 256x3, 8 heads",

@@ -40,6 +40,7 @@ PROTOTYPES = {
     "gaot_debug_set_gemm_ablate": (C.c_int, [C.c_int]),
     "gaot_debug_last_gemm_path": (C.c_int, []),
     "gaot_debug_set_gemm_glds": (C.c_int, [C.c_int]),
+    "gaot_debug_set_gemm_pieces": (C.c_int, [C.c_int]),
     "gaot_csr_prepare": (C.c_int, [_i, _i, C.c_int32, C.c_int32, C.c_int32, _i, _i, _i, _i, _s]),
     "gaot_csr_transpose": (C.c_int, [_i, C.c_int32, C.c_int32, _i, _i, _i, _s]),
     "gaot_guard_begin": (C.c_int, [_i, _s]),
@@ -107,6 +108,8 @@ PROTOTYPES = {
     "gaot_cond_affine_fwd": (C.c_int, [_f, _f, _f, C.c_int32, C.c_int64, C.c_int32, _f, _s]),
     "gaot_cond_affine_bwd_chunks": (C.c_int32, [C.c_int64]),
     "gaot_cond_affine_bwd": (C.c_int, [_f, _f, _f, C.c_int32, C.c_int64, C.c_int32, _f, _f, _s]),
+    "gaot_rollout_input": (C.c_int, [_f, C.c_int32, _f, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_int64, _f, _s]),
+    "gaot_rollout_update": (C.c_int, [_f, _f, C.c_int32, _f, _f, _f, _f, C.c_float, C.c_int32, C.c_int64, _f, _s]),
     "gaot_patchify": (C.c_int, [_f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f, C.c_int32, _s]),
 }
 

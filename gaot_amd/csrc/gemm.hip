@@ -341,6 +341,8 @@ extern "C" int gaot_debug_set_gemm_glds(int on) {
     gaot::set_glds_stages(on == 3 ? 3 : 2);
     return old;
 }
+static int g_split_pieces = 3;   // 3: fp32-level products (default); 1: operands rounded to bf16, one piece product (bench `--dtype bf16` only)
+extern "C" int gaot_debug_set_gemm_pieces(int n) { const int old = g_split_pieces; g_split_pieces = (n == 1) ? 1 : 3; return old; }
 static int g_ablate = 0;
 extern "C" int gaot_debug_set_gemm_ablate(int bits) { const int old = g_ablate; g_ablate = bits; return old; }
 static int g_tile_override = 0;   // tuning hook: 0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 128x32
@@ -403,7 +405,7 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
         if (g_use_split == 2 || (g_use_split && nb128 >= 256)) {
             g_last_path = 3;
             const bool big = a.M >= 256 && (g_split_bm256 == 2 || (g_split_bm256 == 1 && nb128 >= 500));
-            launch_split(a, ak, bk, st, big ? 256 : 128);
+            launch_split(a, ak, bk, st, big && g_split_pieces == 3 ? 256 : 128, g_split_pieces);
         }
         else { g_last_path = 1; launch_glds(a, ak, bk, nb128 >= 512 ? 1 : ((long)cdiv(a.M, 128) * cdiv(a.N, 64) >= 512 ? 2 : 3), st); }
         GAOT_CHECK_LAUNCH("gaot_gemm_f32(swiglu)");
@@ -432,7 +434,7 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
         g_last_path = 3;
         // 256x128 (8-wave) tiles: measured +3-7 % on the NT / TN products that still give ~200 workgroups, -2 % on NN
         const bool big = split128 && a.M >= 512 && (g_split_bm256 == 2 || (g_split_bm256 == 1 && ak == bk && blocks(256, 128) >= 190));
-        launch_split(a, ak, bk, st, split64 ? 64 : (big ? 256 : 128));
+        launch_split(a, ak, bk, st, split64 ? 64 : (big && g_split_pieces == 3 ? 256 : 128), g_split_pieces);
     }
     else if (glds_ok && g_tile_override >= 0 && g_tile_override <= 3) {
         int tile = g_tile_override;

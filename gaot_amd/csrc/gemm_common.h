@@ -215,6 +215,6 @@ bool launch_skinny(const GemmArgs& a, bool a_kmajor, bool b_kmajor, hipStream_t 
 void launch_glds(GemmArgs& a, bool a_kmajor, bool b_kmajor, int tile, hipStream_t st);
 
 // split-bf16 kernel (gemm_split.hip): fp32 product from six bf16 MFMA piece products, 128x128 tiles
-void launch_split(GemmArgs& a, bool a_kmajor, bool b_kmajor, hipStream_t st, int bm = 128);
+void launch_split(GemmArgs& a, bool a_kmajor, bool b_kmajor, hipStream_t st, int bm = 128, int pieces = 3);
 
 }  // namespace gaot

@@ -22,6 +22,19 @@ constexpr int S_BM = 128, S_BN = 128;
 constexpr int S_PLANE = 128 * 48;       // bytes per plane (k-contiguous layout is the larger one)
 constexpr int S_STAGE = 6 * S_PLANE;    // 3 planes x 2 operands
 
+// two fp32 values rounded to nearest-even bf16, packed (element 0 in the low half)
+__device__ __forceinline__ unsigned rne_pair(float x0, float x1) {
+    unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+    u0 += 0x7fffu + ((u0 >> 16) & 1u);
+    u1 += 0x7fffu + ((u1 >> 16) & 1u);
+    return __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+}
+template <int NP, int ABL>
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& ph, unsigned& pm, unsigned& pl) {
+    if (NP == 1) { ph = rne_pair(x0, x1); pm = pl = 0u; }
+    else split3_pair<ABL>(x0, x1, ph, pm, pl);
+}
+
 template <int ABL>
 __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
     if (ABL & 2) { c[0] += __builtin_bit_cast(u32x4, a)[0] * 1e-30f + __builtin_bit_cast(u32x4, b)[1] * 1e-30f; return c; }
@@ -29,10 +42,13 @@ __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
 }
 
 // ABL (tuning builds only, tools/split_bench.hip): 1 = no split arithmetic (raw words to LDS), 2 = no MFMA, 4 = no
-// epilogue stores, 8 = no LDS fragment reads, 16 = no global loads in the loop
+// epilogue stores, 8 = no LDS fragment reads, 16 = no global loads in the loop, 32 = no LDS plane writes, 64 = no barrier per k-tile
 // BM = 128 (4 waves of 64x64) or 64 (4 waves of 32x64: twice the workgroups for outputs only two tiles wide, N = 256)
 // BM = 256: 8 waves (4 x 2) of 64x64, one workgroup per CU: a quarter less split work and LDS write traffic per MFMA
-template <bool AK, bool BKM, int BM = 128, int ABL = 0>
+// NP = 3: the fp32-level product (three pieces per operand, six piece products).  NP = 1: a plain bf16 GEMM on the same skeleton
+// (operands ROUNDED to nearest-even bf16, one piece product, fp32 accumulation) -- the separately reported `--dtype bf16` bench
+// variant (BASELINE configs[1] names bf16); never used by the fp32 parity path.
+template <bool AK, bool BKM, int BM = 128, int ABL = 0, int NP = 3>
 __global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 1 : 2) void gemm_split_kernel(const GemmArgs p) {
     constexpr int BN = S_BN, NW = BM == 256 ? 8 : 4, NT = 64 * NW, WAVES_N = 2, WM = BM / (NW / 2), WN = 64, TM = WM / 32, TN = 2;
     constexpr int ABYTES = BM * 4;       // row stride of a row-contiguous A plane ([k pair][BM rows] of packed dwords; BM = 64 only)
@@ -126,48 +142,45 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 1 : 2) void gemm
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         unsigned a_, b_, c_;
-                        split3_pair<ABL>(r[q][2 * e], r[q][2 * e + 1], a_, b_, c_);
+                        split_pair<NP, ABL>(r[q][2 * e], r[q][2 * e + 1], a_, b_, c_);
                         h[2 * q + e] = a_; m[2 * q + e] = b_; l[2 * q + e] = c_;
                     }
                 unsigned char* dst = base + (tid >> 1) * 48 + (tid & 1) * 16;
                 *reinterpret_cast<u32x4*>(dst) = h;
-                *reinterpret_cast<u32x4*>(dst + plane) = m;
-                *reinterpret_cast<u32x4*>(dst + 2 * plane) = l;
+                if (NP == 3) { *reinterpret_cast<u32x4*>(dst + plane) = m; *reinterpret_cast<u32x4*>(dst + 2 * plane) = l; }
             } else {
                 u32x2 h, m, l;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     unsigned a_, b_, c_;
-                    split3_pair<ABL>(r[0][2 * e], r[0][2 * e + 1], a_, b_, c_);
+                    split_pair<NP, ABL>(r[0][2 * e], r[0][2 * e + 1], a_, b_, c_);
                     h[e] = a_; m[e] = b_; l[e] = c_;
                 }
                 unsigned char* dst = base + (tid >> 2) * 48 + (tid & 3) * 8;
                 *reinterpret_cast<u32x2*>(dst) = h;
-                *reinterpret_cast<u32x2*>(dst + plane) = m;
-                *reinterpret_cast<u32x2*>(dst + 2 * plane) = l;
+                if (NP == 3) { *reinterpret_cast<u32x2*>(dst + plane) = m; *reinterpret_cast<u32x2*>(dst + 2 * plane) = l; }
             }
         } else {
             if (!full && tid >= half_threads) return;
             u32x4 h, m, l;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { unsigned a_, b_, c_; split3_pair<ABL>(r[0][e], r[1][e], a_, b_, c_); h[e] = a_; m[e] = b_; l[e] = c_; }
+            for (int e = 0; e < 4; ++e) { unsigned a_, b_, c_; split_pair<NP, ABL>(r[0][e], r[1][e], a_, b_, c_); h[e] = a_; m[e] = b_; l[e] = c_; }
             if (!legacy64) {
                 unsigned char* dst = base + (tid >> 3) * 4 * 48 + (tid & 7) * 4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     *reinterpret_cast<unsigned*>(dst + e * 48) = h[e];
-                    *reinterpret_cast<unsigned*>(dst + e * 48 + plane) = m[e];
-                    *reinterpret_cast<unsigned*>(dst + e * 48 + 2 * plane) = l[e];
+                    if (NP == 3) { *reinterpret_cast<unsigned*>(dst + e * 48 + plane) = m[e]; *reinterpret_cast<unsigned*>(dst + e * 48 + 2 * plane) = l[e]; }
                 }
             } else {
                 unsigned char* dst = base + (tid >> 4) * 256 + (tid & 15) * 16;
                 *reinterpret_cast<u32x4*>(dst) = h;
-                *reinterpret_cast<u32x4*>(dst + plane) = m;
-                *reinterpret_cast<u32x4*>(dst + 2 * plane) = l;
+                if (NP == 3) { *reinterpret_cast<u32x4*>(dst + plane) = m; *reinterpret_cast<u32x4*>(dst + 2 * plane) = l; }
             }
         }
     };
     auto sstore = [&](int stage, const f32x4 (&xa)[2], const f32x4 (&xb)[2], bool live) {
+        if (ABL & 32) { asm volatile("" :: "v"(xa[0][0]), "v"(xb[0][0]), "v"(xa[1][3]), "v"(xb[1][3])); return; }     // tuning: no LDS plane writes
         unsigned char* sa = smem_raw + stage * STAGE;
         stage_store(sa, xa, AK, A_FULL, PA, 128, BM == 64);
         stage_store(sa + 3 * PA, xb, BKM, B_FULL, PB, 256, false);
@@ -201,11 +214,17 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 1 : 2) void gemm
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) a[i][pl] = frag(sa + pl * PA, wm * WM + i * 32 + li, AK || BM != 64, ABYTES);
+            for (int pl = 0; pl < NP; ++pl) a[i][pl] = frag(sa + pl * PA, wm * WM + i * 32 + li, AK || BM != 64, ABYTES);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) b[j][pl] = frag(sb + pl * PB, wn * WN + j * 32 + li, true, 512);
+            for (int pl = 0; pl < NP; ++pl) b[j][pl] = frag(sb + pl * PB, wn * WN + j * 32 + li, true, 512);
+        if (NP == 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = mfma<ABL>(a[i][0], b[j][0], acc[i][j]);
+        } else {
         // small terms first
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -228,16 +247,17 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 1 : 2) void gemm
                 acc[i][j] = mfma<ABL>(a[i][0], b[j][1], acc[i][j]);
                 acc[i][j] = mfma<ABL>(a[i][0], b[j][0], acc[i][j]);
             }
+        }
         sstore(stage ^ 1, xa, xb, kt + 1 < kt_end);
         // interleave: one MFMA, a few VALU ops of the split, now and then one of its LDS writes
         __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);       // the prefetch loads go first: a whole k-tile to land
 #pragma unroll
-        for (int g = 0; g < TM * TN * 6; ++g) {
+        for (int g = 0; g < TM * TN * (NP == 3 ? 6 : 1); ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
         }
-        __syncthreads();
+        if (!(ABL & 64)) __syncthreads();                  // tuning: 64 = no barrier per k-tile (results garbage)
     };
 
     gload(kt_begin, ra[0], rb[0]);
@@ -268,22 +288,26 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 1 : 2) void gemm
     else epilogue_vec<TM, TN, WM, WN>(p, reinterpret_cast<float*>(smem_raw), acc, m0, n0, wm, wn, wave, lane);
 }
 
-template <int BM>
+template <int BM, int NP>
 static void launch_split_bm(GemmArgs& a, bool ak, bool bk, hipStream_t st) {
     a.tiles_m = cdiv(a.M, BM);
     a.tiles_n = cdiv(a.N, S_BN);
     dim3 grid(a.tiles_m * a.tiles_n, 1, a.split_k > 1 ? a.split_k : 1);
     dim3 block(BM == 256 ? 512 : 256);
-    if (ak && bk)        hipLaunchKernelGGL((gemm_split_kernel<true, true, BM>), grid, block, 0, st, a);
-    else if (ak && !bk)  hipLaunchKernelGGL((gemm_split_kernel<true, false, BM>), grid, block, 0, st, a);
-    else if (!ak && !bk) hipLaunchKernelGGL((gemm_split_kernel<false, false, BM>), grid, block, 0, st, a);
-    else                 hipLaunchKernelGGL((gemm_split_kernel<false, true, BM>), grid, block, 0, st, a);
+    if (ak && bk)        hipLaunchKernelGGL((gemm_split_kernel<true, true, BM, 0, NP>), grid, block, 0, st, a);
+    else if (ak && !bk)  hipLaunchKernelGGL((gemm_split_kernel<true, false, BM, 0, NP>), grid, block, 0, st, a);
+    else if (!ak && !bk) hipLaunchKernelGGL((gemm_split_kernel<false, false, BM, 0, NP>), grid, block, 0, st, a);
+    else                 hipLaunchKernelGGL((gemm_split_kernel<false, true, BM, 0, NP>), grid, block, 0, st, a);
 }
 
-void launch_split(GemmArgs& a, bool ak, bool bk, hipStream_t st, int bm) {
-    if (bm == 64)       launch_split_bm<64>(a, ak, bk, st);
-    else if (bm == 256) launch_split_bm<256>(a, ak, bk, st);
-    else                launch_split_bm<128>(a, ak, bk, st);
+void launch_split(GemmArgs& a, bool ak, bool bk, hipStream_t st, int bm, int pieces) {
+    if (pieces == 1) {           // plain bf16 operands (bench variant): 128- and 64-row tiles
+        if (bm == 64) launch_split_bm<64, 1>(a, ak, bk, st); else launch_split_bm<128, 1>(a, ak, bk, st);
+        return;
+    }
+    if (bm == 64)       launch_split_bm<64, 3>(a, ak, bk, st);
+    else if (bm == 256) launch_split_bm<256, 3>(a, ak, bk, st);
+    else                launch_split_bm<128, 3>(a, ak, bk, st);
 }
 
 }  // namespace gaot

@@ -454,3 +454,62 @@ extern "C" int gaot_edge_rowdot_scale(float* T, const float* k, const float* a, 
     GAOT_CHECK_LAUNCH("gaot_edge_rowdot_scale");
     return GAOT_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// autoregressive rollout glue (gaot.py:371-388 input assembly, 432 re-normalisation, 436-476 stepper modes), one pass each:
+//   rollout_input : pn[b,n,:] = [state[b,n,:U], static[b,n,:S], t0n, (dtn)]         (n_time = 1 drops the dt column: cond-norm models)
+//   rollout_update: den = stepper(pred, state) de-normalised;  state <- (den - u_mean) / u_std
+// The arithmetic is the reference's sequence of separately rounded fp32 operations (no contraction into FMAs).
+// ---------------------------------------------------------------------------------------------
+namespace gaot {
+__global__ __launch_bounds__(256) void rollout_input_kernel(const float* __restrict__ state, int U, const float* __restrict__ stat, int S,
+                                                            float t0n, float dtn, int n_time, long rows, float* __restrict__ pn) {
+    const int W = U + S + n_time;
+    const long total = rows * W;
+    for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(gid % W);
+        const long r = gid / W;
+        pn[gid] = c < U ? state[r * U + c] : (c < U + S ? stat[r * S + (c - U)] : (c == U + S ? t0n : dtn));
+    }
+}
+__global__ __launch_bounds__(256) void rollout_update_kernel(const float* __restrict__ pred, float* __restrict__ state, int U,
+                                                             const float* __restrict__ u_mean, const float* __restrict__ u_std,
+                                                             const float* __restrict__ a_mean, const float* __restrict__ a_std, float dt,
+                                                             int mode, long rows, float* __restrict__ den_out) {
+    const long total = rows * U;
+    for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(gid % U);
+        const float um = u_mean[c], us = u_std[c], p = pred[gid];
+        float den;
+        if (mode == 0) {
+            den = __fadd_rn(__fmul_rn(p, us), um);
+        } else {
+            const float cur = __fadd_rn(__fmul_rn(state[gid], us), um);
+            float inc = __fadd_rn(__fmul_rn(p, a_std[c]), a_mean[c]);
+            if (mode == 2) inc = __fmul_rn(dt, inc);
+            den = __fadd_rn(cur, inc);
+        }
+        den_out[gid] = den;
+        state[gid] = __fdiv_rn(__fsub_rn(den, um), us);
+    }
+}
+}  // namespace gaot
+
+extern "C" int gaot_rollout_input(const float* state, int32_t U, const float* stat, int32_t S, float t0n, float dtn, int32_t n_time,
+                                  int64_t rows, float* pn, gaot_stream_t stream) {
+    GAOT_REQUIRE(state && pn && U > 0 && S >= 0 && (S == 0 || stat) && (n_time == 1 || n_time == 2) && rows > 0, "rollout_input: bad arguments");
+    hipLaunchKernelGGL(gaot::rollout_input_kernel, dim3(cap_blocks(rows * (U + S + n_time), 256, 4096)), dim3(256), 0, ST(stream), state, U, stat, S,
+                       t0n, dtn, n_time, (long)rows, pn);
+    GAOT_CHECK_LAUNCH("gaot_rollout_input");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_rollout_update(const float* pred, float* state, int32_t U, const float* u_mean, const float* u_std, const float* a_mean,
+                                   const float* a_std, float dt, int32_t mode, int64_t rows, float* den_out, gaot_stream_t stream) {
+    GAOT_REQUIRE(pred && state && u_mean && u_std && den_out && U > 0 && rows > 0 && mode >= 0 && mode <= 2 && (mode == 0 || (a_mean && a_std)),
+                 "rollout_update: bad arguments (mode 0 output, 1 residual, 2 time_der)");
+    hipLaunchKernelGGL(gaot::rollout_update_kernel, dim3(cap_blocks(rows * U, 256, 4096)), dim3(256), 0, ST(stream), pred, state, U, u_mean, u_std,
+                       a_mean, a_std, dt, mode, (long)rows, den_out);
+    GAOT_CHECK_LAUNCH("gaot_rollout_update");
+    return GAOT_OK;
+}

@@ -152,8 +152,12 @@ class GAOT(nn.Module):
         graphs = dict(encoder_nbrs=encoder_nbrs, decoder_nbrs=decoder_nbrs) \
             if (encoder_nbrs is not None and decoder_nbrs is not None) else {}
         aux = {k: (stats[k]["mean"].to(dev), stats[k]["std"].to(dev)) for k in ("res", "der") if k in stats}
-        preds = []
         runner = _RolloutRunner(self, latent_tokens_coord, fixed_coord, graphs, use_conditional_norm) if x_batch.is_cuda else None
+        n_steps = len(time_indices) - 1
+        if runner is not None and dt_ == torch.float32 and n_steps > 0:
+            return self._rollout_device(runner, state, static, u_mean, u_std, aux, stats, time_indices, t_values, stepper_mode,
+                                        use_conditional_norm)
+        preds = []
         with torch.no_grad():
             for i in range(1, len(time_indices)):
                 t0 = t_values[time_indices[i - 1]]
@@ -164,15 +168,11 @@ class GAOT(nn.Module):
                 cols += [torch.full((B, N, 1), float(t0n), dtype=dt_, device=dev),
                          torch.full((B, N, 1), float(dtn), dtype=dt_, device=dev)]
                 xin = torch.cat(cols, dim=-1)
-                if use_conditional_norm:          # last column (dt) becomes the conditioning scalar
+                if use_conditional_norm:          # the dt column is dropped, the time enters through `condition`
                     pn, cond = xin[..., :-1].contiguous(), xin[..., 0, -2:-1].contiguous()
                 else:
                     pn, cond = xin, None
-                if runner is not None:
-                    pred = runner(pn, cond)
-                else:
-                    pred = self.forward(latent_tokens_coord=latent_tokens_coord, xcoord=fixed_coord, pndata=pn,
-                                        condition=cond, **graphs)
+                pred = self.forward(latent_tokens_coord=latent_tokens_coord, xcoord=fixed_coord, pndata=pn, condition=cond, **graphs)
                 if stepper_mode == "output":
                     den = pred * u_std + u_mean
                 elif stepper_mode == "residual":
@@ -182,6 +182,44 @@ class GAOT(nn.Module):
                 preds.append(den)
                 state = (den - u_mean) / u_std
         return torch.stack(preds, dim=1)
+
+
+    def _rollout_device(self, runner, state, static, u_mean, u_std, aux, stats, time_indices, t_values, stepper_mode, cond_norm):
+        """the rollout loop on the device: per step ONE launch assembles the input rows straight into the
+        captured forward's static buffer, the forward is a hipGraph replay, ONE launch applies the stepper mode, de-normalises into
+        the output slab and re-normalises the running state (gaot.py:371-388, 432, 436-476)."""
+        import ctypes as C
+        from .. import _lib as L
+        lib = L.load()
+        B, N, U = state.shape
+        S = 0 if static is None else static.shape[-1]
+        dev = state.device
+        state = state.contiguous().clone()
+        stat = None if static is None else static.contiguous()
+        n_steps = len(time_indices) - 1
+        out = torch.empty(B, n_steps, N, U, device=dev, dtype=torch.float32)
+        step_out = torch.empty(B, N, U, device=dev, dtype=torch.float32)
+        pn = torch.empty(B, N, U + S + (1 if cond_norm else 2), device=dev, dtype=torch.float32)
+        mode = {"output": 0, "residual": 1, "time_der": 2}[stepper_mode]
+        a = aux.get("res" if mode == 1 else "der") if mode else None
+        a_mean = a_std = None
+        if a is not None:
+            a_mean, a_std = a[0].contiguous().float(), a[1].contiguous().float()
+        um, us = u_mean.contiguous().float(), u_std.contiguous().float()
+        with torch.no_grad():
+            for i in range(1, len(time_indices)):
+                t0 = t_values[time_indices[i - 1]]
+                dt = t_values[time_indices[i]] - t0
+                t0n = float((t0 - stats["start_time"]["mean"]) / stats["start_time"]["std"])
+                dtn = float((dt - stats["time_diffs"]["mean"]) / stats["time_diffs"]["std"])
+                L.check(lib.gaot_rollout_input(ops._p(state), U, ops._p(stat), S, t0n, dtn, 1 if cond_norm else 2, B * N, ops._p(pn),
+                                               ops._stream()), "gaot_rollout_input")
+                cond = torch.full((B, 1), t0n, dtype=torch.float32, device=dev) if cond_norm else None
+                pred = runner(pn, cond, clone=False)
+                L.check(lib.gaot_rollout_update(ops._p(pred.contiguous()), ops._p(state), U, ops._p(um), ops._p(us), ops._p(a_mean), ops._p(a_std),
+                                                float(dt), mode, B * N, ops._p(step_out), ops._stream()), "gaot_rollout_update")
+                out[:, i - 1].copy_(step_out)
+        return out
 
 
 class _RolloutRunner:
@@ -197,7 +235,7 @@ class _RolloutRunner:
     def _versions(self):
         return tuple(p._version for p in self.model.parameters()) + (ops.weights_generation(),)
 
-    def __call__(self, pn: torch.Tensor, cond: Optional[torch.Tensor]):
+    def __call__(self, pn: torch.Tensor, cond: Optional[torch.Tensor], clone: bool = True):
         m = self.model
         key = (tuple(pn.shape), None if cond is None else tuple(cond.shape), id(self.latent), id(self.coord), self._versions())
         cache = getattr(m, "_rollout_graph", None)
@@ -220,4 +258,4 @@ class _RolloutRunner:
         if cond is not None:
             cache["c"].copy_(cond)
         cache["graph"].replay()
-        return cache["y"].clone()
+        return cache["y"].clone() if clone else cache["y"]

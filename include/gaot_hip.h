@@ -86,6 +86,9 @@ int gaot_debug_last_gemm_path(void);
  * ring, 4 = + split-bf16 tiles where the heuristic picks them (DEFAULT), 5 = split-bf16 wherever eligible, 6 = split-bf16
  * for the SwiGLU-gate product only */
 int gaot_debug_set_gemm_glds(int on);
+/* 3 (default): fp32-level products from three bf16 pieces per operand; 1: operands rounded to bf16, one piece product, fp32
+ * accumulation -- the separately reported `bench.py --dtype bf16` variant only (BASELINE configs[1]); returns the old value. */
+int gaot_debug_set_gemm_pieces(int pieces);
 
 /* ------------------------------------------------------------------------------------------
  * Geometry plan pieces (once per mesh geometry; torch_scatter / repeat_interleave call sites
@@ -354,6 +357,17 @@ int gaot_cond_affine_fwd(const float* x, const float* scale, const float* shift,
 int32_t gaot_cond_affine_bwd_chunks(int64_t S);
 int gaot_cond_affine_bwd(const float* x, const float* dy, const float* scale, int32_t B, int64_t S, int32_t D, float* dx,
                          float* part, gaot_stream_t stream);
+
+/* autoregressive rollout glue (gaot.py:371-388, 432, 436-476), one pass each over the [rows = B*N] node rows:
+ *   gaot_rollout_input : pn[r,:] = [state[r,:U], stat[r,:S], t0n, dtn]   (n_time = 2), or without the dtn column (n_time = 1:
+ *                        conditioned-norm models feed the time through `condition`)
+ *   gaot_rollout_update: den = de-normalised stepper result (mode 0 'output': pred*u_std+u_mean; 1 'residual': (state*u_std+u_mean)
+ *                        + (pred*a_std+a_mean); 2 'time_der': ... + dt*(pred*a_std+a_mean)), then state = (den - u_mean) / u_std in
+ *                        place; every operation rounded separately like the reference's tensor expression. */
+int gaot_rollout_input(const float* state, int32_t U, const float* stat, int32_t S, float t0n, float dtn, int32_t n_time,
+                       int64_t rows, float* pn, gaot_stream_t stream);
+int gaot_rollout_update(const float* pred, float* state, int32_t U, const float* u_mean, const float* u_std, const float* a_mean,
+                        const float* a_std, float dt, int32_t mode, int64_t rows, float* den_out, gaot_stream_t stream);
 
 #ifdef __cplusplus
 }

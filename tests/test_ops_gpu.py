@@ -838,3 +838,29 @@ def test_edge_partitioned_transforms_match_row_parallel_and_float64(skew, B, ci,
             ops.set_gno_ep(old)
     for a, b in zip(results[0], results[1]):
         assert float((a - b).norm() / max(float(b.norm()), 1e-30)) < 2e-6
+
+
+def test_gemm_bf16_piece_mode_is_a_plain_bf16_gemm():
+    """gaot_debug_set_gemm_pieces(1) (bench --dtype bf16 only): operands rounded to nearest-even bf16, fp32 accumulation.  Against
+    float64 products of the ROUNDED operands the error is fp32 accumulation error; against the exact operands it is bf16-level
+    (and the default 3-piece mode, re-selected afterwards, is back at fp32 level)."""
+    from gaot_amd import ops, _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(8)
+    M, N, K = 1024, 384, 256
+    x, w, gy = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(M, N, generator=g)
+    r = lambda t: t.bfloat16().double()
+    old_mode = ops.set_gemm_mode(5)
+    old = lib.gaot_debug_set_gemm_pieces(1)
+    try:
+        y = ops.linear_nt(x.to(dev()), w.to(dev()))
+        assert lib.gaot_debug_last_gemm_path() == 3
+        dx = ops.matmul_nn(gy.to(dev()), w.to(dev()))
+        dw = ops.matmul_tn(gy.to(dev()), x.to(dev()))
+        assert rel(y, r(x) @ r(w).t()) < 2e-6 and rel(dx, r(gy) @ r(w)) < 2e-6 and rel(dw, r(gy).t() @ r(x)) < 2e-6
+        assert 5e-4 < rel(y, x.double() @ w.double().t()) < 1e-2
+    finally:
+        lib.gaot_debug_set_gemm_pieces(old)
+    y3 = ops.linear_nt(x.to(dev()), w.to(dev()))
+    ops.set_gemm_mode(old_mode)
+    assert rel(y3, x.double() @ w.double().t()) < 2e-6

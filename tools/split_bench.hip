@@ -33,9 +33,11 @@ static void sweep(const char* kind, int M, int N, int K, int split) {
     a.split_k = split; a.ktiles_per_split = cdiv(cdiv(K, 32), split); a.ws = ws; a.vec_epi = 1; a.rb_period = 1;
     const double gf = 2.0 * M * N * K * 1e-6;
     float t0 = run<AK, BKM, 0>(a, 20), t1 = run<AK, BKM, 1>(a, 20), t2 = run<AK, BKM, 2>(a, 20), t4 = run<AK, BKM, 4>(a, 20),
-          t8 = run<AK, BKM, 8>(a, 20), t16 = run<AK, BKM, 16>(a, 20), t3 = run<AK, BKM, 3>(a, 20), t27 = run<AK, BKM, 27>(a, 20), t31 = run<AK, BKM, 31>(a, 20);
-    printf("%s M=%d N=%d K=%d sk=%d | full %.1fus %.0fTF | -split %.1f | -mfma %.1f | -stores %.1f | -ldsread %.1f | -gload %.1f | -split-mfma %.1f | only stores %.1f | nothing %.1f\n",
-           kind, M, N, K, split, t0, gf / t0, t1, t2, t4, t8, t16, t3, t27, t31);
+          t8 = run<AK, BKM, 8>(a, 20), t16 = run<AK, BKM, 16>(a, 20), t3 = run<AK, BKM, 3>(a, 20), t27 = run<AK, BKM, 27>(a, 20), t31 = run<AK, BKM, 31>(a, 20),
+          t63 = run<AK, BKM, 63>(a, 20), t127 = run<AK, BKM, 127>(a, 20), t15 = run<AK, BKM, 15>(a, 20), t47 = run<AK, BKM, 47>(a, 20), t6 = run<AK, BKM, 6>(a, 20);
+    printf("%s M=%d N=%d K=%d sk=%d | full %.1fus %.0fTF | -split %.1f | -mfma %.1f | -stores %.1f | -ldsread %.1f | -gload %.1f | -split-mfma %.1f | only stores %.1f | nothing %.1f"
+           " | nothing-ldswrite %.1f | nothing-ldswrite-barrier %.1f | loads only (no split/mfma/epilogue/ldsread) %.1f | loads only, no lds write %.1f | -mfma-epilogue %.1f\n",
+           kind, M, N, K, split, t0, gf / t0, t1, t2, t4, t8, t16, t3, t27, t31, t63, t127, t15, t47, t6);
     hipFree(A); hipFree(B); hipFree(C); hipFree(ws);
 }
 
