@@ -288,9 +288,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const GemmArgs p
         red[wave][lane] = v;
         __syncthreads();
         if (wave == 0 && idx < total4) {
-            const f32x4 r = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+            f32x4 r = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
             const long m = idx / n4;
             const int n = (int)(idx - m * n4) * 4;
+            if (p.residual) r += *reinterpret_cast<const f32x4*>(p.residual + m * p.ldr + n);
             *reinterpret_cast<f32x4*>(p.C + m * p.ldc + n) = r;
         }
     } else {                                     // trailing blocks: the fused column-sum slab [split_k][M]
@@ -341,6 +342,8 @@ extern "C" int gaot_debug_set_gemm_glds(int on) {
     gaot::set_glds_stages(on == 3 ? 3 : 2);
     return old;
 }
+namespace gaot { void set_split_persist(int n); }
+extern "C" int gaot_debug_set_split_persist(int n) { gaot::set_split_persist(n); return 0; }
 static int g_split_pieces = 3;   // 3: fp32-level products (default); 1: operands rounded to bf16, one piece product (bench `--dtype bf16` only)
 extern "C" int gaot_debug_set_gemm_pieces(int n) { const int old = g_split_pieces; g_split_pieces = (n == 1) ? 1 : 3; return old; }
 static int g_ablate = 0;
@@ -463,7 +466,8 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
     GAOT_CHECK_LAUNCH("gaot_gemm_f32");
     if (a.split_k > 1) {
         const long total = (long)a.M * a.N;
-        const bool plain = !a.bias && !a.rowbias && !a.rowscale && !a.aux_out && !a.residual && a.act == GAOT_ACT_NONE &&
+        const bool plain = !a.bias && !a.rowbias && !a.rowscale && !a.aux_out && a.act == GAOT_ACT_NONE &&
+                           (!a.residual || (aligned16(a.residual) && a.ldr % 4 == 0)) &&
                            a.N % 4 == 0 && a.ldc % 4 == 0 && aligned16(a.C) && aligned16(a.ws);
         if (plain) {
             const long nb = cdiv(total / 4, 64) + (a.colsum ? cdiv(a.M, 64) : 0);

@@ -67,9 +67,13 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 1 : 2) void gemm
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
     const int tiles = p.tiles_m * p.tiles_n;
+    // PERSISTENT over tiles: the grid may be smaller than the tile count (launch_split_bm caps it at the number of workgroups
+    // the chip holds at once); a workgroup then walks tiles vb = blockIdx.x, blockIdx.x + gridDim.x, ...  Workgroups that started
+    // together drift apart after their first tile, so the load phase of one overlaps the store phase of another.
+    for (int vb = blockIdx.x; vb < tiles; vb += gridDim.x) {
     int logical;
-    {   // XCD-aware tile order (as gemm.hip)
-        const int q = tiles >> 3, r = tiles & 7, x = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    {   // XCD-aware tile order (as gemm.hip); gridDim.x is a multiple of 8 whenever it is smaller than `tiles`
+        const int q = tiles >> 3, r = tiles & 7, x = vb & 7, slot = vb >> 3;
         logical = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + slot;
     }
     const int m0 = (logical / p.tiles_n) * BM;
@@ -283,16 +287,30 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 1 : 2) void gemm
         }
         __syncthreads();
     }
-    if (ABL & 4) { if (acc[0][0][0] + acc[1][1][3] + acc[0][1][5] + acc[1][0][7] == 123.456f) p.C[tid] = 1.f; return; }
+    if (ABL & 4) { if (acc[0][0][0] + acc[1][1][3] + acc[0][1][5] + acc[1][0][7] == 123.456f) p.C[tid] = 1.f; __syncthreads(); continue; }
     if (BKM && p.act == GAOT_ACT_SWIGLU) epilogue_swiglu<TM, TN, WM, WN>(p, reinterpret_cast<float*>(smem_raw), acc, m0, n0, wm, wn, wave, lane);
     else epilogue_vec<TM, TN, WM, WN>(p, reinterpret_cast<float*>(smem_raw), acc, m0, n0, wm, wn, wave, lane);
+    __syncthreads();          // the epilogue's LDS slabs alias the stages the next tile is about to fill
+    }
 }
+
+// 0: one workgroup per tile (round 1).  n > 0: grids larger than n workgroups become persistent with n (MI355X holds 512 of the
+// 128-row, 256-thread workgroups at once: 2 per CU).  Tuning hook: gaot_debug_set_split_persist.
+static int g_split_persist = 0;
+void set_split_persist(int n) { g_split_persist = n; }
 
 template <int BM, int NP>
 static void launch_split_bm(GemmArgs& a, bool ak, bool bk, hipStream_t st) {
     a.tiles_m = cdiv(a.M, BM);
     a.tiles_n = cdiv(a.N, S_BN);
-    dim3 grid(a.tiles_m * a.tiles_n, 1, a.split_k > 1 ? a.split_k : 1);
+    int gx = a.tiles_m * a.tiles_n;
+    const int z = a.split_k > 1 ? a.split_k : 1;
+    if (g_split_persist > 0 && (long)gx * z > g_split_persist) {       // persistent: at most that many workgroups in the grid
+        int cap = g_split_persist / z;
+        cap = cap < 8 ? 8 : (cap / 8) * 8;
+        if (gx > cap) gx = cap;
+    }
+    dim3 grid(gx, 1, z);
     dim3 block(BM == 256 ? 512 : 256);
     if (ak && bk)        hipLaunchKernelGGL((gemm_split_kernel<true, true, BM, 0, NP>), grid, block, 0, st, a);
     else if (ak && !bk)  hipLaunchKernelGGL((gemm_split_kernel<true, false, BM, 0, NP>), grid, block, 0, st, a);

@@ -89,6 +89,8 @@ int gaot_debug_set_gemm_glds(int on);
 /* 3 (default): fp32-level products from three bf16 pieces per operand; 1: operands rounded to bf16, one piece product, fp32
  * accumulation -- the separately reported `bench.py --dtype bf16` variant only (BASELINE configs[1]); returns the old value. */
 int gaot_debug_set_gemm_pieces(int pieces);
+/* split-bf16 tile kernels: 0 = one workgroup per tile; n > 0 = launches of more than n workgroups run persistently with n */
+int gaot_debug_set_split_persist(int n);
 
 /* ------------------------------------------------------------------------------------------
  * Geometry plan pieces (once per mesh geometry; torch_scatter / repeat_interleave call sites
