@@ -611,7 +611,7 @@ def train_step(sd: Dict[str, Tensor], cfg: OracleConfig, batch: dict, lr: float 
 # --------------------------------------------------------------------------------------
 def autoregressive_predict(sd, cfg: OracleConfig, x_batch: Tensor, time_indices, t_values, stats: dict,
                            stepper_mode: str, latent: Tensor, fixed_coord: Tensor,
-                           use_conditional_norm: bool = False) -> Tensor:
+                           use_conditional_norm: bool = False, encoder_nbrs=None, decoder_nbrs=None) -> Tensor:
     B, N, _ = x_batch.shape
     u_mean, u_std = stats["u"]["mean"], stats["u"]["std"]
     udim = u_mean.shape[0]
@@ -630,9 +630,10 @@ def autoregressive_predict(sd, cfg: OracleConfig, x_batch: Tensor, time_indices,
                      torch.full((B, N, 1), float(dtn), dtype=x_batch.dtype)]
             xin = torch.cat(cols, dim=-1)
             if use_conditional_norm:                                # gaot.py:403-408
-                pred = gaot_forward(sd, cfg, latent, fixed_coord, xin[..., :-1], condition=xin[..., 0, -2:-1])
+                pred = gaot_forward(sd, cfg, latent, fixed_coord, xin[..., :-1], condition=xin[..., 0, -2:-1],
+                                    encoder_nbrs=encoder_nbrs, decoder_nbrs=decoder_nbrs)
             else:
-                pred = gaot_forward(sd, cfg, latent, fixed_coord, xin)
+                pred = gaot_forward(sd, cfg, latent, fixed_coord, xin, encoder_nbrs=encoder_nbrs, decoder_nbrs=decoder_nbrs)
             if stepper_mode == "output":                            # gaot.py:454-472
                 den = pred * u_std + u_mean
             elif stepper_mode == "residual":

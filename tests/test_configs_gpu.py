@@ -6,7 +6,8 @@
       > 256 next to thousands of empty latent rows; also with training-time neighbour sub-sampling on
   C1  1 024-node meshes, batch 4: 43 % of the latent tokens have no neighbour
   C5  3-D surface cloud, 32^3 latent grid = 4 096 tokens of width 384, head_dim 48
-  C4  is covered by test_model_gpu.py (rollout goldens) and test_train_eval_train_eval below.
+  C4  NS-Gauss-shaped time-dependent run: 16 384 nodes, batch 4, in = u(2) + 2 time columns, out 2: a pair-training step and a
+      10-step autoregressive rollout (stepper 'time_der'; hipGraph-replayed forward, fused stepper kernels) against the oracle
 
 Tolerances (north_star: <= 1e-5 relative output error, fp32): output rel-L2 <= 1e-5, loss <= 1e-5 relative, every gradient
 tensor rel-L2 <= 1e-4 (denominator floored at 1e-3 of the largest gradient norm of the model: a tensor whose true gradient
@@ -566,3 +567,44 @@ def test_auto_graph_reference_loop_equals_eager_loop():
     assert float((wa - wb).abs().max()) < 2e-5
     assert rel_l2(ea, eb) < 1e-5
     assert rel_l2(ga, gb) < 1e-4
+
+
+def test_c4_ns_gauss_16k_pair_step_and_10_step_rollout_vs_oracle():
+    """BASELINE configs[3] at its stated single-GPU shape: fx, 16 384 nodes, batch 4, example model with in 4 / out 2."""
+    import numpy as np
+    from oracle import gaot_oracle as O
+    model, sd, ocfg = make_model(4, 2, [64, 64], precompute=False, seed=9)
+    ocfg = O.OracleConfig(**{**ocfg.__dict__, "precompute_edges": False})
+    g = torch.Generator().manual_seed(9)
+    lat, x = grid([64, 64]), uniform_points(16384, 2, g)
+    p, tgt = torch.randn(4, 16384, 4, generator=g), torch.randn(4, 16384, 2, generator=g)
+    enc, dec = [O.radius_csr(x, lat, 0.033, exact=True)], [O.radius_csr(lat, x, 0.033, exact=True)]
+    ocfg_pre = O.OracleConfig(**{**ocfg.__dict__, "precompute_edges": True})
+    loss, grads, _, _, pred = O.train_step(sd, ocfg_pre, dict(latent=lat, xcoord=x, pndata=p, target=tgt, encoder_nbrs=enc, decoder_nbrs=dec),
+                                           return_pred=True)
+    model.to(dev()).train()
+    kw = dict(latent_tokens_coord=lat.to(dev()), xcoord=x.to(dev()))
+    from gaot_amd import ops
+    model.zero_grad(set_to_none=True)
+    out = model(pndata=p.to(dev()), **kw)
+    l = ops.mse_loss(out, tgt.to(dev()))
+    l.backward()
+    assert rel_l2(out.detach().cpu(), pred) < OUT_TOL and abs(float(l.detach()) - float(loss)) < LOSS_TOL * abs(float(loss))
+    errs = grad_errors(model, grads)
+    gated = ("encoder.geoembed.mlp.0.weight", "encoder.geoembed.mlp.0.bias", "decoder.geoembed.mlp.0.weight", "decoder.geoembed.mlp.0.bias")
+    assert max(v for k, v in errs.items() if k not in gated) < GRAD_TOL
+    assert max(errs[k] for k in gated) < 1e-3          # statistics-gated tensors: the reference's own fp32 conditioning (see the C2 test)
+    # 10-step rollout, stepper 'time_der'
+    stats = {"u": {"mean": torch.tensor([0.1, -0.2]), "std": torch.tensor([1.5, 0.7])},
+             "der": {"mean": torch.tensor([-0.05, 0.03]), "std": torch.tensor([0.8, 1.1])},
+             "start_time": {"mean": 0.4, "std": 0.25}, "time_diffs": {"mean": 0.1, "std": 0.05}}
+    tv, ti = np.linspace(0.0, 1.0, 21), np.arange(0, 22, 2)[:11]
+    xb = torch.randn(4, 16384, 2, generator=g)
+    ref = O.autoregressive_predict(sd, ocfg_pre, xb, ti, tv, stats, "time_der", lat, x, encoder_nbrs=enc, decoder_nbrs=dec)
+    model.eval()
+    got = model.autoregressive_predict(x_batch=xb.to(dev()), time_indices=ti, t_values=tv, stats=stats, stepper_mode="time_der",
+                                       latent_tokens_coord=lat.to(dev()), fixed_coord=x.to(dev()))
+    assert got.shape == (4, 10, 16384, 2)
+    per_step = [rel_l2(got[:, i].cpu(), ref[:, i]) for i in range(10)]
+    print("[C4 rollout] rel-L2 per step:", " ".join(f"{e:.1e}" for e in per_step))
+    assert per_step[0] < OUT_TOL and max(per_step) < 5e-5
