@@ -289,7 +289,8 @@ def main():
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()} if want_cpu else None
     hip0 = hip_reference_pass(model, (lat, x, p, t)) if want_cpu else None
-    ts = TrainStep(model, lr=8e-4, weight_decay=1e-5, use_graph=not args.no_graph)
+    staged = {"0": False, "1": True}.get(os.environ.get("GAOT_BENCH_STAGED", ""), None)     # A/B hook; default: staged when world > 1
+    ts = TrainStep(model, lr=8e-4, weight_decay=1e-5, use_graph=not args.no_graph, staged=staged)
     ts.bind(p, t, latent_tokens_coord=lat, xcoord=x)
 
     def sync():
