@@ -42,6 +42,7 @@ PROTOTYPES = {
     "gaot_debug_set_gemm_glds": (C.c_int, [C.c_int]),
     "gaot_debug_set_gemm_pieces": (C.c_int, [C.c_int]),
     "gaot_debug_set_split_persist": (C.c_int, [C.c_int]),
+    "gaot_debug_set_gemm_gsplit": (C.c_int, [C.c_int]),
     "gaot_csr_prepare": (C.c_int, [_i, _i, C.c_int32, C.c_int32, C.c_int32, _i, _i, _i, _i, _s]),
     "gaot_csr_transpose": (C.c_int, [_i, C.c_int32, C.c_int32, _i, _i, _i, _s]),
     "gaot_guard_begin": (C.c_int, [_i, _s]),

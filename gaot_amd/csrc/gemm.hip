@@ -344,6 +344,8 @@ extern "C" int gaot_debug_set_gemm_glds(int on) {
 }
 namespace gaot { void set_split_persist(int n); }
 extern "C" int gaot_debug_set_split_persist(int n) { gaot::set_split_persist(n); return 0; }
+static int g_gsplit = 0;         // 1: split-eligible products run on gemm_gsplit.hip (LDS-direct, split in registers) instead of gemm_split.hip
+extern "C" int gaot_debug_set_gemm_gsplit(int on) { const int old = g_gsplit; g_gsplit = on; return old; }
 static int g_split_pieces = 3;   // 3: fp32-level products (default); 1: operands rounded to bf16, one piece product (bench `--dtype bf16` only)
 extern "C" int gaot_debug_set_gemm_pieces(int n) { const int old = g_split_pieces; g_split_pieces = (n == 1) ? 1 : 3; return old; }
 static int g_ablate = 0;
@@ -408,7 +410,8 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
         if (g_use_split == 2 || (g_use_split && nb128 >= 256)) {
             g_last_path = 3;
             const bool big = a.M >= 256 && (g_split_bm256 == 2 || (g_split_bm256 == 1 && nb128 >= 500));
-            launch_split(a, ak, bk, st, big && g_split_pieces == 3 ? 256 : 128, g_split_pieces);
+            if (g_gsplit) launch_gsplit(a, ak, bk, st, 128, g_split_pieces);
+            else launch_split(a, ak, bk, st, big && g_split_pieces == 3 ? 256 : 128, g_split_pieces);
         }
         else { g_last_path = 1; launch_glds(a, ak, bk, nb128 >= 512 ? 1 : ((long)cdiv(a.M, 128) * cdiv(a.N, 64) >= 512 ? 2 : 3), st); }
         GAOT_CHECK_LAUNCH("gaot_gemm_f32(swiglu)");
@@ -437,7 +440,8 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
         g_last_path = 3;
         // 256x128 (8-wave) tiles: measured +3-7 % on the NT / TN products that still give ~200 workgroups, -2 % on NN
         const bool big = split128 && a.M >= 512 && (g_split_bm256 == 2 || (g_split_bm256 == 1 && ak == bk && blocks(256, 128) >= 190));
-        launch_split(a, ak, bk, st, split64 ? 64 : (big && g_split_pieces == 3 ? 256 : 128), g_split_pieces);
+        if (g_gsplit) launch_gsplit(a, ak, bk, st, split64 ? 64 : 128, g_split_pieces);
+        else launch_split(a, ak, bk, st, split64 ? 64 : (big && g_split_pieces == 3 ? 256 : 128), g_split_pieces);
     }
     else if (glds_ok && g_tile_override >= 0 && g_tile_override <= 3) {
         int tile = g_tile_override;

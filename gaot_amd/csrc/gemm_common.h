@@ -216,5 +216,7 @@ void launch_glds(GemmArgs& a, bool a_kmajor, bool b_kmajor, int tile, hipStream_
 
 // split-bf16 kernel (gemm_split.hip): fp32 product from six bf16 MFMA piece products, 128x128 tiles
 void launch_split(GemmArgs& a, bool a_kmajor, bool b_kmajor, hipStream_t st, int bm = 128, int pieces = 3);
+// the same products with LDS-direct fp32 operand tiles and the split done in registers after the fragment reads (gemm_gsplit.hip)
+void launch_gsplit(GemmArgs& a, bool a_kmajor, bool b_kmajor, hipStream_t st, int bm = 128, int pieces = 3);
 
 }  // namespace gaot

@@ -66,6 +66,9 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 1 : 2) void gemm
     const int li = lane & 31, lh = lane >> 5;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
+    if ((ABL & 128) && (blockIdx.x & 8)) {      // tuning: de-phase half of the workgroups by ~p.ablate x 3.4 us at start
+        for (int i = 0; i < p.ablate; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     const int tiles = p.tiles_m * p.tiles_n;
     // PERSISTENT over tiles: the grid may be smaller than the tile count (launch_split_bm caps it at the number of workgroups
     // the chip holds at once); a workgroup then walks tiles vb = blockIdx.x, blockIdx.x + gridDim.x, ...  Workgroups that started

@@ -91,6 +91,9 @@ int gaot_debug_set_gemm_glds(int on);
 int gaot_debug_set_gemm_pieces(int pieces);
 /* split-bf16 tile kernels: 0 = one workgroup per tile; n > 0 = launches of more than n workgroups run persistently with n */
 int gaot_debug_set_split_persist(int n);
+/* 1: the fp32-level bf16-pipe products use the LDS-direct kernel (fp32 tiles by DMA, operands split in registers) instead of the
+ * plane kernel; 0: the plane kernel (gemm_split.hip).  Returns the old value. */
+int gaot_debug_set_gemm_gsplit(int on);
 
 /* ------------------------------------------------------------------------------------------
  * Geometry plan pieces (once per mesh geometry; torch_scatter / repeat_interleave call sites

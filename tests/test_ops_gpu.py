@@ -864,3 +864,27 @@ def test_gemm_bf16_piece_mode_is_a_plain_bf16_gemm():
     y3 = ops.linear_nt(x.to(dev()), w.to(dev()))
     ops.set_gemm_mode(old_mode)
     assert rel(y3, x.double() @ w.double().t()) < 2e-6
+
+
+def test_gemm_gsplit_alternative_kernel_matches_float64():
+    """gemm_gsplit.hip (LDS-direct fp32 tiles, operands split in registers after the fragment reads): the measured alternative
+    to the plane kernel (same speed; selected with gaot_debug_set_gemm_gsplit).  NT / NN / TN + fused column sum."""
+    from gaot_amd import ops, _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(12)
+    M, N, K = 640, 384, 224
+    x, w, gy = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(M, N, generator=g)
+    old_mode, old = ops.set_gemm_mode(5), lib.gaot_debug_set_gemm_gsplit(1)
+    try:
+        for mode in (5, 7):
+            ops.set_gemm_mode(mode)
+            y = ops.linear_nt(x.to(dev()), w.to(dev()), bias=torch.ones(N, device=dev()))
+            assert lib.gaot_debug_last_gemm_path() == 3
+            dx = ops.matmul_nn(gy.to(dev()), w.to(dev()))
+            db = torch.empty(N, device=dev())
+            dw = ops.matmul_tn(gy.to(dev()), x.to(dev()), colsum_out=db)
+            assert rel(y, x.double() @ w.double().t() + 1) < 2e-6 and rel(dx, gy.double() @ w.double()) < 2e-6
+            assert rel(dw, gy.double().t() @ x.double()) < 2e-6 and rel(db, gy.double().sum(0)) < 2e-5
+    finally:
+        lib.gaot_debug_set_gemm_gsplit(old)
+        ops.set_gemm_mode(old_mode)

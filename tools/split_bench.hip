@@ -41,7 +41,25 @@ static void sweep(const char* kind, int M, int N, int K, int split) {
     hipFree(A); hipFree(B); hipFree(C); hipFree(ws);
 }
 
+template <bool AK, bool BKM>
+static void dephase(const char* kind, int M, int N, int K) {
+    float *A, *B, *C;
+    hipMalloc(&A, (size_t)M * K * 4); hipMalloc(&B, (size_t)N * K * 4); hipMalloc(&C, (size_t)M * N * 4);
+    hipMemset(A, 0, (size_t)M * K * 4); hipMemset(B, 0, (size_t)N * K * 4);
+    GemmArgs a{}; a.M = M; a.N = N; a.K = K; a.A = A; a.lda = AK ? K : M; a.B = B; a.ldb = BKM ? K : N; a.C = C; a.ldc = N;
+    a.split_k = 1; a.ktiles_per_split = cdiv(K, 32); a.vec_epi = 1; a.rb_period = 1;
+    printf("%s M=%d N=%d K=%d de-phasing half of the workgroups at start:", kind, M, N, K);
+    printf(" none %.1fus", run<AK, BKM, 0>(a, 20));
+    for (int d = 1; d <= 8; ++d) { a.ablate = d; printf(" | %d x 3.4us -> %.1f", d, run<AK, BKM, 128>(a, 20)); }
+    printf("\n");
+    hipFree(A); hipFree(B); hipFree(C);
+}
+
 int main() {
+    dephase<true, true>("nt", 8192, 2048, 256);
+    dephase<true, true>("nt", 8192, 768, 256);
+    dephase<true, false>("nn", 8192, 1024, 256);
+    return 0;
     sweep<true, true>("nt", 4096, 4096, 4096, 1);
     sweep<true, true>("nt", 8192, 2048, 256, 1);
     sweep<true, true>("nt", 8192, 256, 1024, 1);
