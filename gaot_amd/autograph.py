@@ -59,7 +59,7 @@ def eligible(model, latent, xcoord, pndata, query_coord, encoder_nbrs, decoder_n
 def _key(model, latent, xcoord, pndata, condition):
     return (tuple(pndata.shape), pndata.dtype, tuple(xcoord.shape), tuple(latent.shape),
             None if condition is None else tuple(condition.shape), pndata.device.index,
-            tuple(p.data_ptr() for p in model.parameters()))
+            tuple(p.data_ptr() if p.requires_grad else -p.data_ptr() for p in model.parameters()))      # storage AND trainability
 
 
 class _GraphedStep(torch.autograd.Function):
