@@ -100,11 +100,17 @@ def _static_coordinates(model, latent, xcoord):
     return store[key]
 
 
-def _plans(model, lat, x):
-    from .plan import plan_for
-    for side, src, dst in ((model.encoder, x, lat), (model.decoder, lat, x)):
-        for nb in side._compute_neighbors(src, dst, 'fx'):
-            yield plan_for(nb, src.shape[0]), (src, dst)
+def _sync_coordinates(e, latent, xcoord):
+    """new coordinate tensors: flag |= (bytes differ from the static buffers), then the buffers take the new bytes.  The captured
+    forward starts with the plans' refresh kernels guarded by the flag and ends by clearing it."""
+    from . import _lib as L
+    lib = L.load()
+    for new, kept in ((xcoord, e.x), (latent, e.lat)):
+        new = new.contiguous()
+        L.check(lib.gaot_guard_compare(ops._p(new), ops._p(kept), kept.numel() * kept.element_size(), ops._p(e.flag), ops._stream()),
+                "gaot_guard_compare")
+        kept.copy_(new, non_blocking=True)
+    e.last_x, e.last_lat = xcoord, latent
 
 
 def _capture(model, latent, xcoord, pndata, condition) -> _Entry:
@@ -115,8 +121,7 @@ def _capture(model, latent, xcoord, pndata, condition) -> _Entry:
     params = [p for p in model.parameters()]
     e.params = params
     e.lat, e.x, e.flag = _static_coordinates(model, latent, xcoord)
-    e.lat.copy_(latent)
-    e.x.copy_(xcoord)
+    _sync_coordinates(e, latent, xcoord)      # buffers shared with an earlier capture may hold other bytes: raise the flag first
     e.p = pndata.detach().clone()
     e.c = None if condition is None else condition.detach().clone()
     # one flat static gradient buffer; every trainable parameter gets a 256-byte aligned slice (the weight-gradient GEMMs write
@@ -163,11 +168,11 @@ def _capture(model, latent, xcoord, pndata, condition) -> _Entry:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            y = fwd()                               # plans see the static coordinate buffers (content guard: same bytes)
-            for plan, pair in _plans(model, e.lat, e.x):
-                P.adopt_static_coordinates(plan, pair)
+            y = fwd()                               # plans see the static coordinate buffers through their content guard
             e.gy = torch.zeros_like(y)
-            P.FORCE_GUARD[0] = e.flag               # from here on the plans' refresh kernels are launched, guarded by the flag
+            # from here on the plans' refresh kernels are launched, guarded by the flag (raised above if an earlier capture left
+            # other bytes in the shared buffers: the warm-up passes then recompute the arrays before anything is captured)
+            P.FORCE_GUARD[0] = e.flag
             for _ in range(2):
                 _, gs = fwd_bwd(e.gy)
                 settle(gs)
@@ -212,12 +217,5 @@ def run(model, latent, xcoord, pndata, condition) -> Optional[torch.Tensor]:
     # geometry: new coordinate tensors (a trainer that uploads them every step): compare with the static buffers (flag |= differ),
     # overwrite the buffers; the captured forward starts with the flag-guarded refresh of the plans' arrays and ends by clearing it
     if xcoord is not e.__dict__.get("last_x") or latent is not e.__dict__.get("last_lat"):
-        from . import _lib as L
-        lib = L.load()
-        for new, kept in ((xcoord, e.x), (latent, e.lat)):
-            new = new.contiguous()
-            L.check(lib.gaot_guard_compare(ops._p(new), ops._p(kept), kept.numel() * kept.element_size(), ops._p(e.flag), ops._stream()),
-                    "gaot_guard_compare")
-            kept.copy_(new, non_blocking=True)
-        e.last_x, e.last_lat = xcoord, latent
+        _sync_coordinates(e, latent, xcoord)
     return _GraphedStep.apply(e, pndata, condition, *e.params)

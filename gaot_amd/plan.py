@@ -21,20 +21,6 @@ _PENDING: list = []          # (device flag, event) of plans built with validate
 FORCE_GUARD = [None]         # set by autograph.py while it captures: a device flag that guards re-computation inside the graph
 
 
-def adopt_static_coordinates(plan: "GeometryPlan", tensors) -> None:
-    """autograph.py: `tensors` (src, dst) are static coordinate buffers that it keeps current.  The plan's arrays derived from a
-    coordinate pair of these shapes take them as THE kept copy, so the eager content guard and the captured refresh agree on
-    what the arrays hold."""
-    gkey = tuple((tuple(t.shape), t.dtype, t.device) for t in tensors)
-    grp = plan._groups.get(gkey)
-    if grp is None:
-        return
-    key = tuple((id(t), t._version) for t in tensors)
-    grp["kept"], grp["key"], grp["hold"] = list(tensors), key, tuple(tensors)
-    for entry in grp["arrays"].values():
-        entry["key"] = key
-
-
 def _raise_if_bad(bad: int):
     if bad:
         raise ValueError(f"invalid CSR neighbour list (flag {bad}: 1 = row_splits not monotone 0..E, 2 = index outside [0, n_src))")
@@ -147,7 +133,15 @@ class GeometryPlan:
             if FORCE_GUARD[0] is not None:
                 # autograph.py is capturing: the refresh of this array becomes part of the captured forward, guarded by a flag
                 # the caller raises when it finds new coordinate bytes (the tensors here are its static coordinate buffers)
-                compute(hit["full"], [t.contiguous() for t in tensors], FORCE_GUARD[0])
+                cur = [t.contiguous() for t in tensors]
+                compute(hit["full"], cur, FORCE_GUARD[0])
+                grp = hit["group"]
+                if next(iter(grp["arrays"].values())) is hit:
+                    # ... and so does the update of the pair's kept bytes (once per pair): the eager content guard compares
+                    # against what the arrays were last derived from, whoever refreshed them
+                    for t, k in zip(cur, grp["kept"]):
+                        L.check(L.load().gaot_guard_update(_p(t), _p(k), t.numel() * t.element_size(), _p(FORCE_GUARD[0]), _stream()),
+                                "gaot_guard_update")
             return hit["val"]
         gkey = tuple((tuple(t.shape), t.dtype, t.device) for t in tensors)
         grp = self._groups.get(gkey)

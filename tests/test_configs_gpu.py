@@ -555,6 +555,13 @@ def test_auto_graph_reference_loop_equals_eager_loop():
                 m.train()
         if auto:
             assert len(m._auto_graph_cache) == 1                                             # it did capture
+        # another batch size = another captured entry sharing the static coordinate buffers, first seen with the OLD coordinates
+        for xc in (x1, x1, x1, x2):
+            opt.zero_grad()
+            loss = lossf(m(latent_tokens_coord=lat.to(dev()), xcoord=xc.to(dev()), pndata=data[0][0][:2].to(dev())), data[0][1][:2].to(dev()))
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
         # gradient accumulation: two backward passes without zero_grad
         opt.zero_grad()
         for p, t in data[:2]:
