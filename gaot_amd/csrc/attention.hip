@@ -546,6 +546,241 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_fwd_split_kerne
 }
 
 // ---------------------------------------------------------------------------------------------
+// software-pipelined forward (8 waves x 32 queries, S a multiple of 64): the loop body is ONE basic block in which
+//   S^T(t+1) = K(t+1) Q^T      (24 MFMAs, independent of everything else in the iteration)
+//   softmax(t), split of P(t)   (VALU)
+//   O^T += V(t)^T P(t)^T        (24 MFMAs)
+//   staging of V(t+1), K(t+2)   (VALU + LDS writes)
+// sit side by side, so the matrix pipe works on the next tile's scores while the vector pipe does this tile's softmax.  No
+// branch in the loop: the O rescale is unconditional (alpha == 1 exactly when the running max did not move), tiles past the
+// end are staged from clamped rows and never used.  No packed-fp32 instruction in the loop (common.h: they serialise the
+// matrix pipe with the vector stream).  Same arithmetic per tile as attn_fwd_split_kernel.
+// ABL (tools/attn_ablate.hip only): 1 no S MFMAs, 2 no PV MFMAs, 4 no P split, 8 no K/V staging, 16 no exp, 32 no barrier
+// ---------------------------------------------------------------------------------------------
+template <int ABL = 0>
+__global__ __launch_bounds__(512, 1) void attn_fwd_split_pipe_kernel(const AttnArgs p) {
+    constexpr int NW = 8, KT = 64, QB = 32 * NW;
+    constexpr int KST = 3 * AS_KPL, VST = 3 * AS_VPL;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KST + 2 * VST];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    int bh, blk;
+    xcd_group_decode(blockIdx.x, p.B * p.H, (p.S + QB - 1) / QB, bh, blk);
+    const int b = bh / p.H, h = bh % p.H, hk = h / (p.H / p.Hkv);
+    const int q0 = blk * QB + wave * 32;
+    const float c = p.scale * LOG2E;
+
+    bf16x8 qf[3][2];
+    {
+        const int qi = q0 + li;
+        const float* qrow = p.q + ((long)b * p.S + qi) * p.ldq + (long)h * 32;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const f32x4 v0 = load4(qrow, 16 * u + 8 * lh, 32, qi < p.S, true);
+            const f32x4 v1 = load4(qrow, 16 * u + 8 * lh + 4, 32, qi < p.S, true);
+            u32x4 ph, pm, pl;
+            unsigned a_, b_, c_;
+            split3_pair(v0[0], v0[1], a_, b_, c_); ph[0] = a_; pm[0] = b_; pl[0] = c_;
+            split3_pair(v0[2], v0[3], a_, b_, c_); ph[1] = a_; pm[1] = b_; pl[1] = c_;
+            split3_pair(v1[0], v1[1], a_, b_, c_); ph[2] = a_; pm[2] = b_; pl[2] = c_;
+            split3_pair(v1[2], v1[3], a_, b_, c_); ph[3] = a_; pm[3] = b_; pl[3] = c_;
+            qf[0][u] = __builtin_bit_cast(bf16x8, ph); qf[1][u] = __builtin_bit_cast(bf16x8, pm); qf[2][u] = __builtin_bit_cast(bf16x8, pl);
+        }
+    }
+    const float* kbase = p.k + (long)b * p.S * p.ldk + (long)hk * 32;
+    const float* vbase = p.v + (long)b * p.S * p.ldv + (long)hk * 32;
+    // staging roles: K item (key = tid >> 3, 4-d chunk = tid & 7) for every thread; V^T item (key pair kp = tid >> 3, chunk)
+    // for the first 256 threads
+    const bool vthread = tid < 256;
+    const int srow = tid >> 3, sch = tid & 7;
+    f32x4 rk, rv[2];
+    auto fetch_k = [&](int kt) {
+        rk = *reinterpret_cast<const f32x4*>(kbase + (long)min(kt * KT + srow, p.S - 1) * p.ldk + sch * 4);
+    };
+    auto fetch_v = [&](int kt) {
+        if (vthread) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                rv[i] = *reinterpret_cast<const f32x4*>(vbase + (long)min(kt * KT + 2 * srow + i, p.S - 1) * p.ldv + sch * 4);
+        }
+    };
+    auto stage_k = [&](int stg) {
+        u32x2 hh, mm, ll;
+        unsigned a_, b_, c_;
+        split3_pair(rk[0], rk[1], a_, b_, c_); hh[0] = a_; mm[0] = b_; ll[0] = c_;
+        split3_pair(rk[2], rk[3], a_, b_, c_); hh[1] = a_; mm[1] = b_; ll[1] = c_;
+        unsigned char* dst = smem + stg * KST + srow * AS_KROW + sch * 8;
+        *reinterpret_cast<u32x2*>(dst) = hh;
+        *reinterpret_cast<u32x2*>(dst + AS_KPL) = mm;
+        *reinterpret_cast<u32x2*>(dst + 2 * AS_KPL) = ll;
+    };
+    auto stage_v = [&](int stg) {
+        if (vthread) {
+            unsigned char* Vp = smem + 2 * KST + stg * VST;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned a_, b_, c_;
+                split3_pair(rv[0][e], rv[1][e], a_, b_, c_);
+                unsigned char* dst = Vp + (sch * 4 + e) * AS_VROW + srow * 4;
+                *reinterpret_cast<unsigned*>(dst) = a_;
+                *reinterpret_cast<unsigned*>(dst + AS_VPL) = b_;
+                *reinterpret_cast<unsigned*>(dst + 2 * AS_VPL) = c_;
+            }
+        }
+    };
+    auto scores = [&](int stg, f32x16 (&s)[2]) {
+        const unsigned char* Kp = smem + stg * KST;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const unsigned char* kr = Kp + (32 * t + li) * AS_KROW + u * 32 + lh * 16;
+                const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(kr);
+                const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(kr + AS_KPL);
+                const bf16x8 k2 = *reinterpret_cast<const bf16x8*>(kr + 2 * AS_KPL);
+                if (ABL & 1) { s[t][4 * u] += __builtin_bit_cast(f32x4, k0)[0] + __builtin_bit_cast(f32x4, k1)[1] + __builtin_bit_cast(f32x4, k2)[2]; continue; }
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k2, qf[0][u], s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[2][u], s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[1][u], s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[0][u], s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[1][u], s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[0][u], s[t], 0, 0, 0);
+            }
+        }
+    };
+
+    f32x16 oacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const int ntiles = p.S / KT;
+    // prologue: K(0), V(0) staged; S(0) computed; K(1) staged; K(2), V(1) in flight
+    fetch_k(0); fetch_v(0);
+    stage_k(0); stage_v(0);
+    fetch_k(1); fetch_v(1);
+    __syncthreads();
+    f32x16 s[2], sn[2];
+    scores(0, s);
+    stage_k(1);
+    fetch_k(2);
+    __syncthreads();
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int stg = kt & 1;
+        // ---- (0) LDS reads of the K(kt + 1) fragments, issued ahead of the region that uses them
+        bf16x8 kfr[2][2][3];
+        {
+            const unsigned char* Kp = smem + (stg ^ 1) * KST;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const unsigned char* kr = Kp + (32 * t + li) * AS_KROW + u * 32 + lh * 16;
+#pragma unroll
+                    for (int pl_ = 0; pl_ < 3; ++pl_) kfr[t][u][pl_] = *reinterpret_cast<const bf16x8*>(kr + pl_ * AS_KPL);
+                }
+        }
+        // ---- (1) floating-point region, no MFMA in it: online softmax over the 64 keys of tile kt.  (Floating-point vector
+        // instructions of one wave do not overlap with MFMAs of the other wave of the SIMD, integer ones do:
+        // tools/pipe_overlap.hip.  Both waves run this code in step, so the matrix work goes where the integer work is.)
+        float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; r += 1) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float mc = -m_new * c;
+        float ps = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float a = fmaf(s[t][r], c, mc);
+                s[t][r] = (ABL & 16) ? a : __builtin_amdgcn_exp2f(a);
+                ps = add_scalar(ps, s[t][r]);
+            }
+        ps += __shfl_xor(ps, 32, 64);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[r] = mul_scalar(oacc[r], alpha);
+        l_run = l_run * alpha + ps;
+        m_run = m_new;
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- (2) matrix + integer region: P split, O^T += V^T P^T, S^T(kt + 1) = K(kt + 1) Q^T, staging
+        const unsigned char* Vp = smem + 2 * KST + stg * VST;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sn[t][r] = 0.f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                u32x4 ph, pm, pl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    unsigned a_, b_, c_;
+                    if (ABL & 4) { a_ = __float_as_uint(s[t][8 * u + 2 * e]); b_ = __float_as_uint(s[t][8 * u + 2 * e + 1]); c_ = a_ ^ b_; }
+                    else split3_pair(s[t][8 * u + 2 * e], s[t][8 * u + 2 * e + 1], a_, b_, c_);
+                    ph[e] = a_; pm[e] = b_; pl[e] = c_;
+                }
+                const bf16x8 p0 = __builtin_bit_cast(bf16x8, ph), p1 = __builtin_bit_cast(bf16x8, pm), p2 = __builtin_bit_cast(bf16x8, pl);
+                const unsigned char* vr = Vp + li * AS_VROW + (32 * t + 16 * u + 4 * lh) * 2;
+                bf16x8 v[3];
+#pragma unroll
+                for (int pl_ = 0; pl_ < 3; ++pl_) {
+                    const u32x2 lo = *reinterpret_cast<const u32x2*>(vr + pl_ * AS_VPL);
+                    const u32x2 hi2 = *reinterpret_cast<const u32x2*>(vr + pl_ * AS_VPL + 16);
+                    v[pl_] = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi2[0], hi2[1]});
+                }
+                if (!(ABL & 2)) {
+                    oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[2], p0, oacc, 0, 0, 0);
+                    oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0], p2, oacc, 0, 0, 0);
+                    oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[1], p1, oacc, 0, 0, 0);
+                    oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[1], p0, oacc, 0, 0, 0);
+                    oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0], p1, oacc, 0, 0, 0);
+                    oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0], p0, oacc, 0, 0, 0);
+                } else {
+                    const f32x4 z = __builtin_bit_cast(f32x4, v[0]) + __builtin_bit_cast(f32x4, v[1]) + __builtin_bit_cast(f32x4, v[2]) + __builtin_bit_cast(f32x4, p0) + __builtin_bit_cast(f32x4, p1) + __builtin_bit_cast(f32x4, p2);
+                    oacc[4 * (2 * t + u)] += z[0]; oacc[4 * (2 * t + u) + 1] += z[1]; oacc[4 * (2 * t + u) + 2] += z[2]; oacc[4 * (2 * t + u) + 3] += z[3];
+                }
+                if (!(ABL & 1)) {
+                    sn[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[t][u][2], qf[0][u], sn[t], 0, 0, 0);
+                    sn[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[t][u][0], qf[2][u], sn[t], 0, 0, 0);
+                    sn[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[t][u][1], qf[1][u], sn[t], 0, 0, 0);
+                    sn[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[t][u][1], qf[0][u], sn[t], 0, 0, 0);
+                    sn[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[t][u][0], qf[1][u], sn[t], 0, 0, 0);
+                    sn[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[t][u][0], qf[0][u], sn[t], 0, 0, 0);
+                } else {
+                    sn[t][4 * u] += __builtin_bit_cast(f32x4, kfr[t][u][0])[0] + __builtin_bit_cast(f32x4, kfr[t][u][1])[1] + __builtin_bit_cast(f32x4, kfr[t][u][2])[2];
+                }
+            }
+        }
+        // staging for the iterations to come (rows clamped: tiles past the end are harmless copies of the last row)
+        if (!(ABL & 8)) {
+            stage_v(stg ^ 1);          // V(kt + 1): its slot held V(kt - 1), read before the last barrier
+            stage_k(stg);              // K(kt + 2): its slot held K(kt), read before the last barrier
+            fetch_v(kt + 2);
+            fetch_k(kt + 3);
+        }
+        if (!(ABL & 32)) __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) s[t] = sn[t];
+    }
+    const float inv_l = 1.0f / l_run;
+    float* Os = reinterpret_cast<float*>(smem) + wave * 32 * 33;          // 8 * 4224 B <= the K stages
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Os[li * 33 + crow(r, lh)] = oacc[r] * inv_l;
+    __syncthreads();
+    for (int rr = lh; rr < 32; rr += 2) {
+        const int qi = q0 + rr;
+        if (qi >= p.S) break;
+        p.o[((long)b * p.S + qi) * p.ldo + (long)h * 32 + li] = Os[rr * 33 + li];
+    }
+    if (lh == 0 && q0 + li < p.S)
+        p.lse[((long)b * p.H + h) * p.S + q0 + li] = m_run * p.scale + logf(l_run);
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward helpers
 // ---------------------------------------------------------------------------------------------
 // delta[b,h,s] = sum_d dO * O       (one thread per (b,s,h); rows are short)
@@ -1353,6 +1588,8 @@ using namespace gaot;
 
 static int g_attn_split = 1;     // head_dim 32: 1 = split-bf16 kernels (default; 8-wave forward when it fills the chip), 0 = fp32-MFMA kernels,
                                  // 2 = split with the 8-wave forward always, 3 = split with the 4-wave forward always
+static int g_attn_pipe = 1;      // software-pipelined variants (S % 64 == 0) on / off
+extern "C" int gaot_debug_set_attention_pipe(int on) { const int old = g_attn_pipe; g_attn_pipe = on; return old; }
 extern "C" int gaot_debug_set_attention_split(int on) { const int old = g_attn_split; g_attn_split = on; return old; }
 
 extern "C" int gaot_attention_fwd(const float* q, const float* k, const float* v, int64_t ldq, int64_t ldk, int64_t ldv,
@@ -1366,8 +1603,10 @@ extern "C" int gaot_attention_fwd(const float* q, const float* k, const float* v
     a.o = o; a.ldo = ldo; a.lse = lse;
     dim3 grid(cdiv(S, 128) * B * H), block(256);
     // 256-query workgroups once they still fill the chip (one per CU): half the K / V tile splits per head
-    if (head_dim == 32 && a.vec && g_attn_split && g_attn_split != 3 && (g_attn_split == 2 || (long)cdiv(S, 256) * B * H >= 256))
-        hipLaunchKernelGGL(attn_fwd_split_kernel<8>, dim3(cdiv(S, 256) * B * H), dim3(512), 0, ST(stream), a);
+    if (head_dim == 32 && a.vec && g_attn_split && g_attn_split != 3 && (g_attn_split == 2 || (long)cdiv(S, 256) * B * H >= 256)) {
+        if (S % 64 == 0 && g_attn_pipe) hipLaunchKernelGGL(attn_fwd_split_pipe_kernel<0>, dim3(cdiv(S, 256) * B * H), dim3(512), 0, ST(stream), a);
+        else hipLaunchKernelGGL(attn_fwd_split_kernel<8>, dim3(cdiv(S, 256) * B * H), dim3(512), 0, ST(stream), a);
+    }
     else if (head_dim == 32 && a.vec && g_attn_split) hipLaunchKernelGGL(attn_fwd_split_kernel<4>, grid, block, 0, ST(stream), a);
     else if (head_dim == 32 && a.vec) hipLaunchKernelGGL(attn_fwd_glds_kernel, grid, block, 0, ST(stream), a);
     else if (head_dim <= 32) hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, block, 0, ST(stream), a);

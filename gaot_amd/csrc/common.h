@@ -65,19 +65,37 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-// two elements at a time so that the residual subtractions are v_pk_add_f32; returns the three packed bf16 pairs
-// (element 0 in the low half).  Only the pieces that feed a subtraction are masked; packing is a byte permute.
+// two elements at a time; returns the three packed bf16 pairs (element 0 in the low half).  Only the pieces that feed a
+// subtraction are masked; packing is a byte permute.  The residual subtractions are SCALAR v_sub_f32 on purpose: packed-fp32
+// instructions (v_pk_add/mul/fma_f32, v_pk_mov_b32) do not overlap with MFMAs on gfx950 -- one of them per MFMA serialises the
+// matrix pipe with the whole vector stream (tools/pipe_overlap.hip: 7 fma + 1 pk_add per MFMA takes 56 ns where 8 fma take
+// 39) -- while v_sub_f32 / v_and_b32 (VOP2) issue at twice the rate of three-operand instructions.  The asm keeps the SLP
+// vectoriser from re-packing them.
+__device__ __forceinline__ float sub_scalar(float a, float b) {
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float add_scalar(float a, float b) {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float mul_scalar(float a, float b) {
+    float r;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 template <int ABL = 0>
 __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& ph, unsigned& pm, unsigned& pl) {
     if (ABL & 1) { ph = pm = pl = __float_as_uint(x0) ^ __float_as_uint(x1); return; }
-    const f32x2 x = {x0, x1};
     const unsigned h0 = __float_as_uint(x0) & 0xffff0000u, h1 = __float_as_uint(x1) & 0xffff0000u;
-    const f32x2 r = x - f32x2{__uint_as_float(h0), __uint_as_float(h1)};
-    const unsigned m0 = __float_as_uint(r[0]) & 0xffff0000u, m1 = __float_as_uint(r[1]) & 0xffff0000u;
-    const f32x2 r2 = r - f32x2{__uint_as_float(m0), __uint_as_float(m1)};      // <= 8 significant bits left: exact in bf16
+    const float r0 = sub_scalar(x0, __uint_as_float(h0)), r1 = sub_scalar(x1, __uint_as_float(h1));
+    const unsigned m0 = __float_as_uint(r0) & 0xffff0000u, m1 = __float_as_uint(r1) & 0xffff0000u;
+    const float s0 = sub_scalar(r0, __uint_as_float(m0)), s1 = sub_scalar(r1, __uint_as_float(m1));      // <= 8 significant bits left: exact in bf16
     ph = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
     pm = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
-    pl = __builtin_amdgcn_perm(__float_as_uint(r2[1]), __float_as_uint(r2[0]), 0x07060302u);
+    pl = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -265,7 +265,7 @@ def test_swiglu():
 
 @pytest.mark.parametrize("B,S,H,Hkv,D", [(2, 256, 4, 4, 32), (1, 1024, 8, 8, 32), (2, 64, 4, 4, 8), (2, 200, 4, 4, 12),
                                          (1, 130, 2, 2, 64), (2, 96, 4, 2, 16), (1, 33, 1, 1, 32), (2, 203, 4, 2, 32),
-                                         (1, 129, 2, 1, 32)])
+                                         (1, 129, 2, 1, 32), (2, 128, 4, 2, 32), (1, 64, 2, 2, 32)])
 def test_attention_fwd_bwd(B, S, H, Hkv, D):
     from gaot_amd import ops, _lib
     g = torch.Generator().manual_seed(S + D)
@@ -303,6 +303,15 @@ def test_attention_fwd_bwd(B, S, H, Hkv, D):
         finally:
             _lib.load().gaot_debug_set_attention_split(old)
         assert rel(out3, ref) < 3e-6 and rel(d3.grad, r.grad) < 1e-5
+        if S % 64 == 0:     # mode 2 ran the software-pipelined forward; the plain 8-wave forward stays covered too
+            lib = _lib.load()
+            old, oldp = lib.gaot_debug_set_attention_split(2), lib.gaot_debug_set_attention_pipe(0)
+            try:
+                with torch.no_grad():
+                    out4 = ops.attention(qkv.to(dev()), H, Hkv, D)
+            finally:
+                lib.gaot_debug_set_attention_split(old); lib.gaot_debug_set_attention_pipe(oldp)
+            assert rel(out4, ref) < 3e-6 and rel(out4, out3) < 1e-6
 
 
 def test_attention_peaked_softmax():
@@ -319,6 +328,13 @@ def test_attention_peaked_softmax():
     v = r[..., 2 * H * D:].reshape(B, S, H, D).transpose(1, 2)
     ref = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(D), -1) @ v).transpose(1, 2).reshape(B, S, H * D)
     out = ops.attention(qkv.to(dev()), H, H, D)
+    assert rel(out, ref) < 3e-6 and torch.isfinite(out).all()
+    from gaot_amd import _lib
+    old = _lib.load().gaot_debug_set_attention_split(2)      # the pipelined 8-wave forward: unconditional rescale, first tile from -inf
+    try:
+        out = ops.attention(qkv.to(dev()), H, H, D)
+    finally:
+        _lib.load().gaot_debug_set_attention_split(old)
     assert rel(out, ref) < 3e-6 and torch.isfinite(out).all()
 
 

@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
-"""head_dim-32 attention at the bench shape: fp32-MFMA kernels (mode 0) vs split-bf16 (1: 4-wave, 2: 8-wave forward)."""
+"""head_dim-32 attention at the bench shape: fp32-MFMA kernels (mode 0) vs split-bf16 (1: 4-wave, 2: 8-wave forward), and the
+software-pipelined variants of the split kernels on / off; errors against float64."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from gaot_amd import ops, _lib as L
 lib = L.load(); dev = torch.device("cuda:0")
-qkv = torch.randn(8, 1024, 768, device=dev, requires_grad=True)
-go = torch.randn(8, 1024, 256, device=dev)
+B, S, H, D = 8, int(os.environ.get("S", 1024)), 8, 32
+qkv = torch.randn(B, S, 3 * H * D, device=dev, requires_grad=True)
+go = torch.randn(B, S, H * D, device=dev)
 def timeit(fn, iters=20):
     for _ in range(5): fn()
     torch.cuda.synchronize()
@@ -15,14 +17,20 @@ def timeit(fn, iters=20):
     for _ in range(iters): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters * 1e3
-ref = None
-for mode in (0, 1, 2):
+q64 = qkv.detach().double().requires_grad_(True)
+q_, k_, v_ = (t.reshape(B, S, H, D).transpose(1, 2) for t in q64.split(H * D, dim=2))
+o64 = torch.softmax(q_ @ k_.transpose(-1, -2) / D ** 0.5, -1) @ v_
+o64 = o64.transpose(1, 2).reshape(B, S, H * D)
+g64, = torch.autograd.grad(o64, q64, go.double())
+rel = lambda a, b: float((a.double() - b).norm() / b.norm())
+for mode, pipe in ((0, 0), (1, 0), (2, 0), (2, 1)):
     lib.gaot_debug_set_attention_split(mode)
+    lib.gaot_debug_set_attention_pipe(pipe)
     with torch.no_grad():
         o = ops.attention(qkv, 8, 8, 32)
         tf = timeit(lambda: ops.attention(qkv, 8, 8, 32))
     o2 = ops.attention(qkv, 8, 8, 32)
+    g, = torch.autograd.grad(o2, qkv, go, retain_graph=True)
     tb = timeit(lambda: torch.autograd.grad(o2, qkv, go, retain_graph=True))
-    if ref is None: ref = o
-    print(f"mode {mode}: fwd {tf:.1f} us   bwd (delta + main + dq reduce) {tb:.1f} us   max |o - o_fp32| {float((o - ref).abs().max()):.2e}")
-lib.gaot_debug_set_attention_split(1)
+    print(f"mode {mode} pipe {pipe}: fwd {tf:.1f} us   bwd (delta + main + dq reduce) {tb:.1f} us   rel-L2 vs f64: out {rel(o, o64.detach()):.2e}  dqkv {rel(g, g64):.2e}")
+lib.gaot_debug_set_attention_split(1); lib.gaot_debug_set_attention_pipe(1)
