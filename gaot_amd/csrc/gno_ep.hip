@@ -20,12 +20,12 @@ static inline int ep_pow2_ceil(int v) { int p = 1; while (p < v) p <<= 1; return
 // ---------------------------------------------------------------- encoder: lifting + gather + segmented reduce
 // out[b,q,:] = bl (*) S_0[q,:] + sum_ci Wl[:,ci] (*) S_ci[b,q,:],  S_ci = sum_{e in row q} a_e pn[b,j(e),ci] k_e,  S_0 = sum_e a_e k_e
 // The lifting is applied at flush time (it is linear, so partial sums may be mixed before they are added).
-template <int CI, int BCH>
+template <int CI, int BCH, int UNR>
 __global__ __launch_bounds__(256) void lift_ep_kernel(const float* __restrict__ k, const float* __restrict__ pn, const float* __restrict__ wl,
                                                       const float* __restrict__ bl, int B, int n_src, int C, const int* __restrict__ sp,
                                                       const int* __restrict__ cols, const int* __restrict__ eq, int Q, int E,
                                                       const float* __restrict__ escale, float* __restrict__ out, float* __restrict__ ws,
-                                                      int lanes, int epc) {
+                                                      int lanes, int epc, int abl) {
     const int groups_per_block = 256 / lanes;
     const int g = blockIdx.x * groups_per_block + threadIdx.x / lanes;
     const int c = (threadIdx.x % lanes) * 4;
@@ -42,39 +42,46 @@ __global__ __launch_bounds__(256) void lift_ep_kernel(const float* __restrict__ 
 #pragma unroll
         for (int ci = 0; ci < CI; ++ci) acc[b][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
     int cur = eq[begin];
-    auto flush = [&](int row) {
-        const bool complete = sp[row] >= begin && sp[row + 1] <= end;
-        const int slot = sp[row] < begin ? 0 : 1;
+    // the rows just outside the chunk tell whether its first / last row continues across the boundary: no row_splits reads
+    // (dependent loads) on the flush path
+    const int row_before = begin > 0 ? eq[begin - 1] : -1, row_after = end < E ? eq[end] : -1;
+    bool first = true;
+    auto flush = [&](int row, bool last) {
+        const bool starts_here = !(first && row == row_before), ends_here = !(last && row == row_after);
+        const bool complete = starts_here && ends_here;
+        const int slot = starts_here ? 1 : 0;
+        first = false;
 #pragma unroll
         for (int b = 0; b < BCH; ++b) {
             if (b0 + b >= B) break;
             f32x4 o = bq * s0;
 #pragma unroll
             for (int ci = 0; ci < CI; ++ci) { o += wq[ci] * acc[b][ci]; acc[b][ci] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            if ((abl & 2) && o[0] != 123.456f) continue;
             if (complete) *reinterpret_cast<f32x4*>(out + ((long)(b0 + b) * Q + row) * C + c) = o;
             else *reinterpret_cast<f32x4*>(ws + (((long)g * 2 + slot) * B + (b0 + b)) * C + c) = o;
         }
         s0 = f32x4{0.f, 0.f, 0.f, 0.f};
     };
-    for (int t = begin; t < end; t += 4) {
-        int j[4], row[4]; f32x4 kq[4]; float pv[4][BCH][CI];
+    for (int t = begin; t < end; t += UNR) {
+        int j[UNR], row[UNR]; f32x4 kq[UNR]; float pv[UNR][BCH][CI];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int tt = min(t + u, end - 1); j[u] = cols[tt]; row[u] = eq[tt]; }
+        for (int u = 0; u < UNR; ++u) { const int tt = min(t + u, end - 1); j[u] = cols[tt]; row[u] = eq[tt]; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < UNR; ++u) {
             const int tt = min(t + u, end - 1);
-            kq[u] = *reinterpret_cast<const f32x4*>(k + (long)tt * C + c) * (escale ? escale[tt] : 1.0f);
+            kq[u] = (abl & 4) ? f32x4{1.f * tt, 2.f, 3.f, 4.f} : *reinterpret_cast<const f32x4*>(k + (long)tt * C + c) * (escale ? escale[tt] : 1.0f);
 #pragma unroll
             for (int b = 0; b < BCH; ++b) {
-                const float* pr = pn + ((long)min(b0 + b, B - 1) * n_src + j[u]) * CI;
+                const float* pr = pn + ((long)min(b0 + b, B - 1) * n_src + ((abl & 1) ? 0 : j[u])) * CI;
 #pragma unroll
                 for (int ci = 0; ci < CI; ++ci) pv[u][b][ci] = pr[ci];
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < UNR; ++u) {
             if (t + u >= end) break;
-            if (row[u] != cur) { flush(cur); cur = row[u]; }
+            if (row[u] != cur) { flush(cur, false); cur = row[u]; }
             s0 += kq[u];
 #pragma unroll
             for (int b = 0; b < BCH; ++b)
@@ -82,7 +89,7 @@ __global__ __launch_bounds__(256) void lift_ep_kernel(const float* __restrict__ 
                 for (int ci = 0; ci < CI; ++ci) acc[b][ci] += kq[u] * pv[u][b][ci];
         }
     }
-    flush(cur);
+    flush(cur, true);
 }
 
 // rows that span chunks: out[b,row,:] = carry(last slot of the chunk the row starts in) + sum of the first slots of the chunks it
@@ -125,9 +132,13 @@ __global__ __launch_bounds__(256) void proj_t_ep_kernel(const float* __restrict_
 #pragma unroll
     for (int b = 0; b < BCH; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
     int cur = idx[tedge[begin]];
-    auto flush = [&](int row) {
-        const bool complete = tsp[row] >= begin && tsp[row + 1] <= end;
-        const int slot = tsp[row] < begin ? 0 : 1;
+    const int row_before = begin > 0 ? idx[tedge[begin - 1]] : -1, row_after = end < E ? idx[tedge[end]] : -1;
+    bool first = true;
+    auto flush = [&](int row, bool last) {
+        const bool starts_here = !(first && row == row_before), ends_here = !(last && row == row_after);
+        const bool complete = starts_here && ends_here;
+        const int slot = starts_here ? 1 : 0;
+        first = false;
 #pragma unroll
         for (int b = 0; b < BCH; ++b) {
             if (b0 + b >= B) break;
@@ -156,7 +167,7 @@ __global__ __launch_bounds__(256) void proj_t_ep_kernel(const float* __restrict_
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (t + u >= end) break;
-            if (row[u] != cur) { flush(cur); cur = row[u]; }
+            if (row[u] != cur) { flush(cur, false); cur = row[u]; }
 #pragma unroll
             for (int b = 0; b < BCH; ++b) {
                 f32x4 gv = wq[0] * gy[u][b][0];
@@ -166,7 +177,7 @@ __global__ __launch_bounds__(256) void proj_t_ep_kernel(const float* __restrict_
             }
         }
     }
-    flush(cur);
+    flush(cur, true);
 }
 
 // ---------------------------------------------------------------- decoder forward with the batch inside the lane group
@@ -228,7 +239,8 @@ using namespace gaot;
 static int g_ep_chunk = 0;       // tuning hook: 0 = heuristic
 extern "C" int gaot_debug_set_ep_chunk(int n) { const int old = g_ep_chunk; g_ep_chunk = n; return old; }
 // measured (tools/gno_ep_bench.py, union of 16 skewed samples, 445 k edges): 16 / 32 / 64 / 128 edges per chunk -> 48 / 47 / 65 / 95 us
-static inline int ep_chunk(int E) { (void)E; return g_ep_chunk > 0 ? g_ep_chunk : 32; }
+static inline int ep_chunk(int E) { (void)E; return (g_ep_chunk & 0xffff) > 0 ? (g_ep_chunk & 0xffff) : 32; }
+static inline int ep_abl() { return g_ep_chunk >> 16; }      // tuning only: 1 = no pn gathers, 2 = no stores, 4 = no k_e loads
 
 extern "C" int64_t gaot_gno_ep_workspace(int32_t E, int32_t C, int32_t B) {
     const int epc = ep_chunk(E);
@@ -244,11 +256,15 @@ extern "C" int gaot_gno_lift_gather_reduce_ep(const float* k, const float* pn, c
     GAOT_REQUIRE(k && pn && wl && splits && out && ws && aligned16(k) && aligned16(out) && aligned16(ws) && (!bl || aligned16(bl)) &&
                  (E == 0 || (cols && edge_query)), "gno_lift_gather_reduce_ep: null or misaligned pointer");
     const int lanes = ep_pow2_ceil(C / 4), gpb = 256 / lanes, epc = ep_chunk(E);
-    constexpr int BCH = 2;
     if (E > 0) {
+        // one sample (the vx union of a batch): no batch blocking, eight edge rows in flight per lane group (the kernel is a stream
+        // of k_e rows; with a chunk of 32 edges a lane group lives for only 32 / UNR dependent load rounds)
+        const int BCH = B == 1 ? 1 : 2;
         dim3 grid(cdiv(cdiv(E, epc), gpb), cdiv(B, BCH)), block(256);
-#define LG(CI) hipLaunchKernelGGL((lift_ep_kernel<CI, BCH>), grid, block, 0, ST(stream), k, pn, wl, bl, B, n_src, C, splits, cols, edge_query, Q, E, \
-                                  escale, out, ws, lanes, epc)
+#define LG(CI) do { if (B == 1) hipLaunchKernelGGL((lift_ep_kernel<CI, 1, 8>), grid, block, 0, ST(stream), k, pn, wl, bl, B, n_src, C, splits, cols, edge_query, Q, E, \
+                                  escale, out, ws, lanes, epc, ep_abl()); \
+                    else hipLaunchKernelGGL((lift_ep_kernel<CI, 2, 4>), grid, block, 0, ST(stream), k, pn, wl, bl, B, n_src, C, splits, cols, edge_query, Q, E, \
+                                  escale, out, ws, lanes, epc, ep_abl()); } while (0)
         if (c_in == 1) LG(1); else if (c_in == 2) LG(2); else if (c_in == 3) LG(3); else LG(4);
 #undef LG
     }
