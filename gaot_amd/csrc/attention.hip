@@ -26,7 +26,20 @@ struct AttnArgs {
     const float *oin, *dout; float *dq, *dk, *dv; long lddq, lddk, lddv;
     float* delta; float* dq_part; int n_kblocks;
     float scale; int vec;
+    // attention dropout (attn.py:110-114, dropout_p of F.scaled_dot_product_attention in training): P is multiplied by
+    // keep(b, h, q, k) / (1 - p) after the softmax; the mask is a counter-based hash of (*drop_seed, element index), so the
+    // backward regenerates it from the same seed word
+    const unsigned long long* drop_seed; unsigned drop_thresh; float drop_scale;
 };
+
+// splitmix64 finaliser of (seed + linear index of the score): the top 32 bits against the keep threshold
+__device__ __forceinline__ float attn_drop_factor(unsigned long long seed, long idx, unsigned thresh, float scale) {
+    unsigned long long x = seed + (unsigned long long)idx;
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27; x *= 0x94d049bb133111ebull;
+    x ^= x >> 31;
+    return (unsigned)(x >> 32) < thresh ? scale : 0.f;
+}
 
 // id -> (group, member): groups are dealt to XCDs round-robin, all members of a group stay on the group's XCD.
 // With G groups of n members: XCD x = id % 8 serves groups x, x+8, ...; falls back to the plain order when G % 8 != 0.
@@ -55,7 +68,7 @@ __device__ __forceinline__ f32x4 load4(const float* __restrict__ row, int d, int
 // ---------------------------------------------------------------------------------------------
 // forward: workgroup = 4 waves x 32 queries; key/value tiles of 64 rows staged through LDS
 // ---------------------------------------------------------------------------------------------
-template <int DP>
+template <int DP, bool DROP = false>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     constexpr int ND = DP / 32;          // 32-wide d tiles
     constexpr int LDT = DP + 4;          // LDS row stride (floats)
@@ -156,6 +169,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
             for (int t = 0; t < ND; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+            if (DROP) {      // the row sum above is of the undropped probabilities (softmax first, dropout on its output)
+                const unsigned long long seed = *p.drop_seed;
+                const long base = (((long)b * p.H + h) * p.S + (q0 + li)) * p.S + kvs;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] *= attn_drop_factor(seed, base + crow(r, lh), p.drop_thresh, p.drop_scale);
+            }
             // ---- O^T[d][q] += sum_kv V[kv][d] P^T[kv][q]   (P^T registers are the B operand as they are)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -841,7 +860,7 @@ __global__ void attn_dq_reduce_kernel(const AttnArgs p, int DP) {
 // ---------------------------------------------------------------------------------------------
 // backward main: workgroup = 4 waves, each owns 32 keys (block = 128 keys); loops over query tiles of 32
 // ---------------------------------------------------------------------------------------------
-template <int DP>
+template <int DP, bool DROP = false>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs p) {
     constexpr int ND = DP / 32;
     constexpr int LDT = DP + 4;
@@ -962,8 +981,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs p) {
             const int qr = crow(r, lh);
             float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c, -lse_s[qr]));
             if (!kv_ok) pv = 0.f;
-            s[r] = pv;
-            dp[r] = pv * (dp[r] - del_s[qr]);
+            if (DROP) {      // O = (P o M) V: dV takes P o M, dS = P o (M o dP - delta); delta = rowsum(dO o O) as without dropout
+                const float m = attn_drop_factor(*p.drop_seed, (((long)b * p.H + h) * p.S + (q0 + qr)) * p.S + kv0 + li, p.drop_thresh, p.drop_scale);
+                s[r] = pv * m;
+                dp[r] = pv * (dp[r] * m - del_s[qr]);
+            } else {
+                s[r] = pv;
+                dp[r] = pv * (dp[r] - del_s[qr]);
+            }
         }
         // ---- dV^T[d][kv] += dO^T[d][q] P[q][kv] ; dK^T[d][kv] += Q^T[d][q] dS[q][kv]
 #pragma unroll
@@ -1612,6 +1637,89 @@ extern "C" int gaot_attention_fwd(const float* q, const float* k, const float* v
     else if (head_dim <= 32) hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, block, 0, ST(stream), a);
     else                hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, block, 0, ST(stream), a);
     GAOT_CHECK_LAUNCH("gaot_attention_fwd");
+    return GAOT_OK;
+}
+
+// ---- attention dropout: seed bookkeeping on the device (graph-replay safe: nothing about the seed is a launch argument)
+// state = (seed, counter).  used[0] = seed mixed with counter and salt; counter += 1.
+__global__ void attn_seed_next_kernel(unsigned long long* state, unsigned long long salt, unsigned long long* used) {
+    unsigned long long x = state[0] + 0x9e3779b97f4a7c15ull * (state[1] + 1) + salt;
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27; x *= 0x94d049bb133111ebull;
+    x ^= x >> 31;
+    used[0] = x;
+    state[1] += 1;
+}
+
+extern "C" int gaot_attention_seed_next(uint64_t* state, uint64_t salt, uint64_t* used, gaot_stream_t stream) {
+    GAOT_REQUIRE(state && used, "attention_seed_next: null pointer");
+    hipLaunchKernelGGL(attn_seed_next_kernel, dim3(1), dim3(1), 0, ST(stream), reinterpret_cast<unsigned long long*>(state),
+                       (unsigned long long)salt, reinterpret_cast<unsigned long long*>(used));
+    GAOT_CHECK_LAUNCH("gaot_attention_seed_next");
+    return GAOT_OK;
+}
+
+static int fill_dropout(AttnArgs& a, float p_drop, const uint64_t* seed) {
+    GAOT_REQUIRE(p_drop > 0.f && p_drop < 1.f && seed, "attention dropout: need 0 < p < 1 and a device seed word");
+    a.drop_seed = reinterpret_cast<const unsigned long long*>(seed);
+    const double keep = 1.0 - (double)p_drop;
+    a.drop_thresh = (unsigned)(keep * 4294967296.0 >= 4294967295.0 ? 4294967295.0 : keep * 4294967296.0);
+    a.drop_scale = (float)(1.0 / keep);
+    return GAOT_OK;
+}
+
+extern "C" int gaot_attention_fwd_dropout(const float* q, const float* k, const float* v, int64_t ldq, int64_t ldk, int64_t ldv,
+                                          int32_t B, int32_t S, int32_t H, int32_t Hkv, int32_t head_dim, float* o, int64_t ldo,
+                                          float* lse, float p_drop, const uint64_t* seed, gaot_stream_t stream) {
+    GAOT_REQUIRE(q && k && v && o && lse, "attention_fwd_dropout: null pointer");
+    GAOT_REQUIRE(B > 0 && S > 0 && H > 0 && Hkv > 0 && H % Hkv == 0, "attention_fwd_dropout: bad sizes B=%d S=%d H=%d Hkv=%d", B, S, H, Hkv);
+    GAOT_REQUIRE(head_dim > 0 && head_dim <= 64, "attention_fwd_dropout: head_dim %d not in 1..64", head_dim);
+    AttnArgs a = {};
+    fill_common(a, q, k, v, ldq, ldk, ldv, B, S, H, Hkv, head_dim);
+    a.o = o; a.ldo = ldo; a.lse = lse;
+    if (int rc = fill_dropout(a, p_drop, seed)) return rc;
+    dim3 grid(cdiv(S, 128) * B * H), block(256);
+    if (head_dim <= 32) hipLaunchKernelGGL((attn_fwd_kernel<32, true>), grid, block, 0, ST(stream), a);
+    else                hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, block, 0, ST(stream), a);
+    GAOT_CHECK_LAUNCH("gaot_attention_fwd_dropout");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_attention_bwd_dropout(const float* q, const float* k, const float* v, int64_t ldq, int64_t ldk, int64_t ldv,
+                                          const float* o, const float* dout, int64_t ldo, const float* lse, int32_t B, int32_t S,
+                                          int32_t H, int32_t Hkv, int32_t head_dim, float* dq, float* dk, float* dv, int64_t lddq,
+                                          int64_t lddk, int64_t lddv, float* workspace, float p_drop, const uint64_t* seed,
+                                          gaot_stream_t stream) {
+    GAOT_REQUIRE(q && k && v && o && dout && lse && dq && dk && dv && workspace, "attention_bwd_dropout: null pointer");
+    GAOT_REQUIRE(B > 0 && S > 0 && H > 0 && Hkv > 0 && H % Hkv == 0, "attention_bwd_dropout: bad sizes");
+    GAOT_REQUIRE(head_dim > 0 && head_dim <= 64, "attention_bwd_dropout: head_dim %d not in 1..64", head_dim);
+    AttnArgs a = {};
+    fill_common(a, q, k, v, ldq, ldk, ldv, B, S, H, Hkv, head_dim);
+    a.vec = a.vec && (ldo % 4 == 0) && aligned16(dout);
+    a.oin = o; a.dout = dout; a.ldo = ldo; a.lse = const_cast<float*>(lse);
+    a.dq = dq; a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+    a.delta = workspace;
+    a.dq_part = workspace + (int64_t)B * H * S;
+    a.n_kblocks = cdiv(S, 128);
+    if (int rc = fill_dropout(a, p_drop, seed)) return rc;
+    const int DP = head_dim <= 32 ? 32 : 64;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv((long)B * S * H, 256)), dim3(256), 0, ST(stream), a);
+    dim3 grid(a.n_kblocks * B * H), block(256);
+    if (DP == 32) {
+        hipLaunchKernelGGL((attn_bwd_kernel<32, true>), grid, block, bwd_lds_bytes<32>(), ST(stream), a);
+    } else {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)bwd_lds_bytes<64>());
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((attn_bwd_kernel<64, true>), grid, block, bwd_lds_bytes<64>(), ST(stream), a);
+    }
+    const long total = (long)B * H * S * DP;
+    int nb = cdiv(total, 256); if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(attn_dq_reduce_kernel, dim3(nb), dim3(256), 0, ST(stream), a, DP);
+    GAOT_CHECK_LAUNCH("gaot_attention_bwd_dropout");
     return GAOT_OK;
 }
 

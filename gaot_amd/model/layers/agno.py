@@ -27,8 +27,6 @@ class AGNO(nn.Module):
             raise ValueError("Either channel_mlp or channel_mlp_layers must be provided.")
         if transform_type not in _TRANSFORMS:
             raise ValueError(f"Invalid transform_type: {transform_type}")
-        if channel_mlp_non_linearity is not F.gelu:
-            raise NotImplementedError("the fused kernel MLP implements the reference default (exact-erf GELU) only")
         self.transform_type = transform_type
         self.use_attn = use_attn
         self.attention_type = attention_type
@@ -39,7 +37,7 @@ class AGNO(nn.Module):
             if attention_type not in ('cosine', 'dot_product'):
                 raise ValueError(f"Invalid attention_type: {attention_type}")
             self.coord_dim = coord_dim
-        self.channel_mlp = channel_mlp if channel_mlp is not None else LinearChannelMLP(layers=channel_mlp_layers)
+        self.channel_mlp = channel_mlp if channel_mlp is not None else LinearChannelMLP(layers=channel_mlp_layers, non_linearity=channel_mlp_non_linearity)
         if use_attn and attention_type == 'dot_product':
             self.query_proj = nn.Linear(coord_dim, 64)
             self.key_proj = nn.Linear(coord_dim, 64)

@@ -104,15 +104,15 @@ class GroupQueryFlashAttention(nn.Module):
             raise NotImplementedError("attention kernel supports head_dim <= 64")
 
     def forward(self, x, condition=None, relative_positions=None, residual=None):
-        if self.training and self.atten_dropout > 0.0:
-            raise NotImplementedError("attention dropout > 0 is not supported by the HIP attention kernel")
         if self.correction is not None:
             x = self.correction(c=condition, x=x)
         qkv = ops.linear_cat(x, [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight])
         if relative_positions is not None:       # the reference only tests for None: the rotation angle is the SEQUENCE index
             qkv = ops.rope(qkv, self.num_heads + self.num_kv_heads, self.head_dim,
                             self.rotary_emb.cos_sin(qkv.shape[-2], qkv.device))
-        o = ops.attention(qkv, self.num_heads, self.num_kv_heads, self.head_dim)
+        # attn.py:110-114: dropout on the attention weights while training
+        o = ops.attention(qkv, self.num_heads, self.num_kv_heads, self.head_dim,
+                          dropout_p=self.atten_dropout if self.training else 0.0)
         return ops.linear(o, self.o_proj.weight, residual=residual)
 
     def fused_weight_groups(self):

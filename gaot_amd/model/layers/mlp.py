@@ -11,11 +11,22 @@ import torch.nn as nn
 from ... import ops
 
 
+def activation_name(fn: Optional[Callable]) -> str:
+    """the reference passes activation CALLABLES (mlp.py:311, default F.gelu); the HIP kernels know them by name"""
+    import torch.nn.functional as F
+    if fn is None or fn is F.gelu or isinstance(fn, nn.GELU):
+        return "gelu"
+    if fn is F.relu or fn is torch.relu or isinstance(fn, nn.ReLU):
+        return "relu"
+    raise NotImplementedError(f"kernel-MLP activation {fn!r}: the HIP kernels implement exact-erf GELU (the reference default) and ReLU")
+
+
 class LinearChannelMLP(nn.Module):
-    """Kernel MLP of the integral transform (reference mlp.py:307-337): Linear + GELU(erf), last layer bare."""
+    """Kernel MLP of the integral transform (reference mlp.py:307-337): Linear + activation (default GELU(erf)), last layer bare."""
 
     def __init__(self, layers: Sequence[int], non_linearity: Optional[Callable] = None, dropout: float = 0.0):
         super().__init__()
+        self.act = activation_name(non_linearity)
         if len(layers) < 2:
             raise AssertionError("LinearChannelMLP needs at least one layer")
         if dropout and dropout > 0.0:
@@ -24,7 +35,7 @@ class LinearChannelMLP(nn.Module):
         self.fcs = nn.ModuleList(nn.Linear(layers[i], layers[i + 1]) for i in range(self.n_layers))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        acts = ["gelu"] * (self.n_layers - 1) + ["none"]
+        acts = [self.act] * (self.n_layers - 1) + ["none"]
         return ops.mlp_chain(x, [fc.weight for fc in self.fcs], [fc.bias for fc in self.fcs], acts)
 
 

@@ -1215,10 +1215,12 @@ def swiglu_ffn(x, w1, w3, w2, residual=None):
 
 
 class _Attention(torch.autograd.Function):
-    """qkv [B,S,(H + 2 Hkv) * D] fused projection output -> softmax(q k^T / sqrt(D)) v  as [B,S,H*D]."""
+    """qkv [B,S,(H + 2 Hkv) * D] fused projection output -> softmax(q k^T / sqrt(D)) v  as [B,S,H*D].
+    p_drop > 0: attention dropout (attn.py:110-114) -- the softmax output is multiplied by a keep mask / (1 - p) drawn from a
+    counter-based hash of a device-resident seed word (`dropout_state`), regenerated by the backward."""
 
     @staticmethod
-    def forward(ctx, qkv, H, Hkv, D):
+    def forward(ctx, qkv, H, Hkv, D, p_drop=0.0):
         _dev(qkv)
         qkv = qkv.contiguous()
         B, S, W = qkv.shape
@@ -1228,16 +1230,27 @@ class _Attention(torch.autograd.Function):
         q = qkv.view(-1)
         kq = q[H * D:]
         vq = q[(H + Hkv) * D:]
-        L.check(L.load().gaot_attention_fwd(_p(q), _p(kq), _p(vq), W, W, W, B, S, H, Hkv, D, _p(o), H * D, _p(lse), _stream()),
-                "gaot_attention_fwd")
-        ctx.save_for_backward(qkv, o, lse)
-        ctx.dims = (B, S, H, Hkv, D)
+        lib = L.load()
+        seed = None
+        if p_drop > 0.0:
+            if not p_drop < 1.0:
+                raise ValueError(f"attention dropout probability must be in [0, 1), got {p_drop}")
+            seed = torch.empty(1, device=qkv.device, dtype=torch.int64)
+            L.check(lib.gaot_attention_seed_next(_p(dropout_state(qkv.device)), 0, _p(seed), _stream()), "gaot_attention_seed_next")
+            L.check(lib.gaot_attention_fwd_dropout(_p(q), _p(kq), _p(vq), W, W, W, B, S, H, Hkv, D, _p(o), H * D, _p(lse), float(p_drop),
+                                                   _p(seed), _stream()), "gaot_attention_fwd_dropout")
+            _LAST_DROPOUT_SEED[0] = seed
+        else:
+            L.check(lib.gaot_attention_fwd(_p(q), _p(kq), _p(vq), W, W, W, B, S, H, Hkv, D, _p(o), H * D, _p(lse), _stream()),
+                    "gaot_attention_fwd")
+        ctx.save_for_backward(qkv, o, lse, seed if seed is not None else qkv.new_empty(0))
+        ctx.dims = (B, S, H, Hkv, D, float(p_drop))
         return o
 
     @staticmethod
     def backward(ctx, do):
-        qkv, o, lse = ctx.saved_tensors
-        B, S, H, Hkv, D = ctx.dims
+        qkv, o, lse, seed = ctx.saved_tensors
+        B, S, H, Hkv, D, p_drop = ctx.dims
         W = (H + 2 * Hkv) * D
         lib = L.load()
         do = do.contiguous()
@@ -1251,18 +1264,43 @@ class _Attention(torch.autograd.Function):
             dk_full = torch.empty(B, S, H * D, device=qkv.device, dtype=torch.float32)
             dv_full = torch.empty_like(dk_full)
             dk_t, dv_t, ldk, ldv = dk_full.view(-1), dv_full.view(-1), H * D, H * D
-        L.check(lib.gaot_attention_bwd(_p(flat), _p(flat[H * D:]), _p(flat[(H + Hkv) * D:]), W, W, W, _p(o), _p(do), H * D,
-                                       _p(lse), B, S, H, Hkv, D, _p(dflat), _p(dk_t), _p(dv_t), W, ldk, ldv, _p(ws), _stream()),
-                "gaot_attention_bwd")
+        if p_drop > 0.0:
+            L.check(lib.gaot_attention_bwd_dropout(_p(flat), _p(flat[H * D:]), _p(flat[(H + Hkv) * D:]), W, W, W, _p(o), _p(do), H * D,
+                                                   _p(lse), B, S, H, Hkv, D, _p(dflat), _p(dk_t), _p(dv_t), W, ldk, ldv, _p(ws),
+                                                   p_drop, _p(seed), _stream()), "gaot_attention_bwd_dropout")
+        else:
+            L.check(lib.gaot_attention_bwd(_p(flat), _p(flat[H * D:]), _p(flat[(H + Hkv) * D:]), W, W, W, _p(o), _p(do), H * D,
+                                           _p(lse), B, S, H, Hkv, D, _p(dflat), _p(dk_t), _p(dv_t), W, ldk, ldv, _p(ws), _stream()),
+                    "gaot_attention_bwd")
         if Hkv != H:
             r = H // Hkv
             dqkv[..., H * D:(H + Hkv) * D] = dk_full.view(B, S, Hkv, r, D).sum(3).reshape(B, S, Hkv * D)
             dqkv[..., (H + Hkv) * D:] = dv_full.view(B, S, Hkv, r, D).sum(3).reshape(B, S, Hkv * D)
-        return dqkv, None, None, None
+        return dqkv, None, None, None, None
 
 
-def attention(qkv, H, Hkv, D):
-    return _Attention.apply(qkv, H, Hkv, D)
+_DROPOUT_STATE = {}                 # per device: int64 [2] = (seed, counter) -- advanced on the device by every dropout forward
+_LAST_DROPOUT_SEED = [None]         # the seed word of the latest dropout forward (tests rebuild the mask from it)
+
+
+def dropout_state(device) -> torch.Tensor:
+    """the device-resident (seed, counter) pair of the attention-dropout generator; seeded from torch's default generator the first
+    time it is used on a device (so `torch.manual_seed` before the first step makes runs repeatable), `seed_dropout` re-seeds."""
+    key = torch.device(device).index or 0
+    st = _DROPOUT_STATE.get(key)
+    if st is None:
+        st = torch.tensor([int(torch.randint(0, 2 ** 62, (1,)).item()), 0], dtype=torch.int64).to(device)
+        _DROPOUT_STATE[key] = st
+    return st
+
+
+def seed_dropout(seed: int, device=None) -> None:
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    dropout_state(device).copy_(torch.tensor([int(seed), 0], dtype=torch.int64))
+
+
+def attention(qkv, H, Hkv, D, dropout_p: float = 0.0):
+    return _Attention.apply(qkv, H, Hkv, D, float(dropout_p))
 
 
 class _Patchify(torch.autograd.Function):

@@ -240,6 +240,21 @@ int gaot_attention_fwd(const float* q, const float* k, const float* v, int64_t l
                        int32_t B, int32_t S, int32_t H, int32_t Hkv, int32_t head_dim,
                        float* o, int64_t ldo, float* lse, gaot_stream_t stream);
 /* workspace floats needed by gaot_attention_bwd */
+/* attention dropout (attn.py:110-114: dropout_p of F.scaled_dot_product_attention while training): the softmax output is
+ * multiplied by keep(b,h,q,k) / (1 - p) before the product with V.  keep = (splitmix64(seed + ((b*H + h)*S + q)*S + k) >> 32) <
+ * (1 - p) * 2^32 with seed read from DEVICE memory, so captured graphs draw a new mask at every replay:
+ *   gaot_attention_seed_next : used[0] = mix(state[0], state[1] + 1, salt); state[1] += 1   (state = {seed, counter})
+ *   gaot_attention_fwd_dropout / _bwd_dropout : as gaot_attention_fwd / _bwd (fp32-MFMA kernels) with p_drop in (0, 1) and the
+ *   device word written by gaot_attention_seed_next; the backward regenerates the forward's mask from the same word. */
+int gaot_attention_seed_next(uint64_t* state, uint64_t salt, uint64_t* used, gaot_stream_t stream);
+int gaot_attention_fwd_dropout(const float* q, const float* k, const float* v, int64_t ldq, int64_t ldk, int64_t ldv,
+                               int32_t B, int32_t S, int32_t H, int32_t Hkv, int32_t head_dim, float* o, int64_t ldo,
+                               float* lse, float p_drop, const uint64_t* seed, gaot_stream_t stream);
+int gaot_attention_bwd_dropout(const float* q, const float* k, const float* v, int64_t ldq, int64_t ldk, int64_t ldv,
+                               const float* o, const float* dout, int64_t ldo, const float* lse, int32_t B, int32_t S,
+                               int32_t H, int32_t Hkv, int32_t head_dim, float* dq, float* dk, float* dv, int64_t lddq,
+                               int64_t lddk, int64_t lddv, float* workspace, float p_drop, const uint64_t* seed,
+                               gaot_stream_t stream);
 int64_t gaot_attention_bwd_workspace(int32_t B, int32_t S, int32_t H, int32_t head_dim);
 int gaot_attention_bwd(const float* q, const float* k, const float* v, int64_t ldq, int64_t ldk, int64_t ldv,
                        const float* o, const float* dout, int64_t ldo, const float* lse,

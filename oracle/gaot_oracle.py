@@ -474,8 +474,10 @@ def rotate_queries_or_keys(t: Tensor, freqs: Tensor) -> Tensor:
     return t * ang.cos() + rot * ang.sin()
 
 
-def attention(sd, prefix: str, cfg: OracleConfig, x: Tensor, condition) -> Tensor:
-    """GroupQueryFlashAttention.forward (attn.py:78-119), softmax attention written out."""
+def attention(sd, prefix: str, cfg: OracleConfig, x: Tensor, condition, drop_factor: Optional[Tensor] = None) -> Tensor:
+    """GroupQueryFlashAttention.forward (attn.py:78-119), softmax attention written out.
+    drop_factor [B, H, S, S] (optional): the dropout multiplier keep / (1 - p) applied to the softmax output, i.e. what
+    F.scaled_dot_product_attention(dropout_p=p) does in training (attn.py:110-114) for ONE given draw of the mask."""
     if cfg.use_conditional_norm:
         x = cond_norm(sd, f"{prefix}.correction", condition, x)
     B, S, _ = x.shape
@@ -494,6 +496,8 @@ def attention(sd, prefix: str, cfg: OracleConfig, x: Tensor, condition) -> Tenso
         q = rotate_queries_or_keys(q, sd[f"{prefix}.rotary_emb.freqs"])
         k = rotate_queries_or_keys(k, sd[f"{prefix}.rotary_emb.freqs"])
     p = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(dh), dim=-1)
+    if drop_factor is not None:
+        p = p * drop_factor
     o = (p @ v).transpose(1, 2).reshape(B, S, H * dh)
     return o @ sd[f"{prefix}.o_proj.weight"].t()
 

@@ -615,3 +615,36 @@ def test_c4_ns_gauss_16k_pair_step_and_10_step_rollout_vs_oracle():
     per_step = [rel_l2(got[:, i].cpu(), ref[:, i]) for i in range(10)]
     print("[C4 rollout] rel-L2 per step:", " ".join(f"{e:.1e}" for e in per_step))
     assert per_step[0] < OUT_TOL and max(per_step) < 5e-5
+
+
+def test_attention_dropout_in_the_model_train_vs_eval():
+    """atten_dropout > 0 (attn.py:110-114): active in training mode only, a new mask per call, also inside the captured
+    training graphs (the seed lives on the device); evaluation equals the model without dropout"""
+    from gaot_amd import ops
+    from gaot_amd.model.gaot import GAOT
+    from gaot_amd.model.layers.attn import AttentionConfig
+    model, sd, _ = make_model(2, 1, [16, 16], C=32, hidden=128, heads=4, radius=0.12, precompute=False, seed=5)
+    cfg = model_cfg(model)
+    cfg.args.transformer.attn_config = AttentionConfig(num_heads=4, num_kv_heads=4, atten_dropout=0.2)
+    drop = GAOT(2, 1, cfg); drop.load_state_dict(sd); drop.to(dev())
+    model.to(dev())
+    g = torch.Generator().manual_seed(5)
+    lat, x = grid([16, 16]).to(dev()), uniform_points(700, 2, g).to(dev())
+    p = torch.randn(2, 700, 2, generator=g).to(dev()); t = torch.randn(2, 700, 1, generator=g).to(dev())
+    model.eval(); drop.eval()
+    with torch.no_grad():
+        assert torch.equal(drop(latent_tokens_coord=lat, xcoord=x, pndata=p), model(latent_tokens_coord=lat, xcoord=x, pndata=p))
+    drop.train(); model.train()
+    ops.seed_dropout(99, dev())
+    outs, losses = [], []
+    for step in range(4):            # the third and fourth calls replay captured graphs (autograph)
+        drop.zero_grad(set_to_none=True)
+        y = drop(latent_tokens_coord=lat, xcoord=x, pndata=p)
+        loss = ops.mse_loss(y, t); loss.backward()
+        assert all(torch.isfinite(q.grad).all() for q in drop.parameters() if q.grad is not None)
+        outs.append(y.detach().clone()); losses.append(float(loss.detach()))
+    ref = model(latent_tokens_coord=lat, xcoord=x, pndata=p).detach()
+    for i in range(4):
+        assert 1e-4 < rel_l2(outs[i].cpu(), ref.cpu()) < 0.5, rel_l2(outs[i].cpu(), ref.cpu())
+        for j in range(i):
+            assert not torch.equal(outs[i], outs[j])

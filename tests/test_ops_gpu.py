@@ -314,6 +314,65 @@ def test_attention_fwd_bwd(B, S, H, Hkv, D):
             assert rel(out4, ref) < 3e-6 and rel(out4, out3) < 1e-6
 
 
+def _dropout_factor(seed: int, B, H, S, p):
+    """host restatement of attention.hip attn_drop_factor: splitmix64 finaliser of seed + ((b*H + h)*S + q)*S + k"""
+    import numpy as np
+    idx = np.arange(B * H * S * S, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        x = np.uint64(seed & (2 ** 64 - 1)) + idx
+        x ^= x >> np.uint64(30); x *= np.uint64(0xbf58476d1ce4e5b9)
+        x ^= x >> np.uint64(27); x *= np.uint64(0x94d049bb133111eb)
+        x ^= x >> np.uint64(31)
+    keep = (x >> np.uint64(32)) < np.uint64(min(int((1.0 - p) * 2 ** 32), 2 ** 32 - 1))
+    return torch.from_numpy(keep.reshape(B, H, S, S).astype(np.float64) / (1.0 - p))
+
+
+@pytest.mark.parametrize("B,S,H,Hkv,D,p", [(2, 96, 4, 4, 32, 0.1), (1, 130, 2, 1, 64, 0.25), (2, 70, 4, 2, 16, 0.5)])
+def test_attention_dropout_matches_float64_with_the_same_mask(B, S, H, Hkv, D, p):
+    """attn.py:110-114: softmax, then dropout of the attention weights, then the product with V.  The mask cannot equal torch's
+    (another generator); the kernel's own mask is rebuilt on the host from the seed word and the math is checked against float64"""
+    from gaot_amd import ops
+    g = torch.Generator().manual_seed(S + D)
+    W = (H + 2 * Hkv) * D
+    qkv = torch.randn(B, S, W, generator=g)
+    go = torch.randn(B, S, H * D, generator=g)
+    ops.seed_dropout(1234, dev())
+    d = qkv.to(dev()).requires_grad_(True)
+    out = ops.attention(d, H, Hkv, D, dropout_p=p)
+    out.backward(go.to(dev()))
+    seed = int(ops._LAST_DROPOUT_SEED[0].cpu().item())
+    fac = _dropout_factor(seed, B, H, S, p)
+    assert abs(float((fac > 0).double().mean()) - (1.0 - p)) < 0.02          # the keep rate
+    r = qkv.clone().double().requires_grad_(True)
+    q = r[..., :H * D].reshape(B, S, H, D).transpose(1, 2)
+    k = r[..., H * D:(H + Hkv) * D].reshape(B, S, Hkv, D).transpose(1, 2).repeat_interleave(H // Hkv, dim=1)
+    v = r[..., (H + Hkv) * D:].reshape(B, S, Hkv, D).transpose(1, 2).repeat_interleave(H // Hkv, dim=1)
+    pr = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(D), dim=-1) * fac
+    ref = (pr @ v).transpose(1, 2).reshape(B, S, H * D)
+    ref.backward(go.double())
+    assert rel(out, ref) < 3e-6
+    assert rel(d.grad, r.grad) < 1e-5
+    # a second call draws another mask (the counter lives on the device); re-seeding reproduces the first
+    out2 = ops.attention(d.detach(), H, Hkv, D, dropout_p=p)
+    assert rel(out2, ref) > 1e-2
+    ops.seed_dropout(1234, dev())
+    assert torch.equal(ops.attention(d.detach(), H, Hkv, D, dropout_p=p), out.detach())
+
+
+def test_attention_dropout_draws_a_new_mask_at_every_graph_replay():
+    from gaot_amd import ops
+    qkv = torch.randn(1, 64, 3 * 2 * 32, device=dev())
+    ops.seed_dropout(7, dev())
+    ops.attention(qkv, 2, 2, 32, dropout_p=0.3)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        y = ops.attention(qkv, 2, 2, 32, dropout_p=0.3)
+    gr.replay(); a = y.clone()
+    gr.replay(); b = y.clone()
+    assert not torch.equal(a, b) and torch.isfinite(a).all() and torch.isfinite(b).all()
+
+
 def test_attention_peaked_softmax():
     """one key dominates one query (running-max rescale path) -- full-tensor check against fp64"""
     from gaot_amd import ops
@@ -904,3 +963,38 @@ def test_gemm_gsplit_alternative_kernel_matches_float64():
     finally:
         lib.gaot_debug_set_gemm_gsplit(old)
         ops.set_gemm_mode(old_mode)
+
+
+def test_agno_with_relu_kernel_mlp_matches_float64():
+    """channel_mlp_non_linearity other than the default GELU (reference agno.py:71, mlp.py:311): ReLU runs on the same fused
+    kernels; anything else is refused by name"""
+    import torch.nn.functional as F
+    from gaot_amd.model.layers.agno import AGNO
+    x, lat, enc, _ = _random_geometry(11, 600, [12, 12], 0.2)
+    idx, sp = enc
+    torch.manual_seed(3)
+    layer = AGNO(channel_mlp_layers=[4, 64, 64, 64], channel_mlp_non_linearity=F.relu, transform_type="linear", use_attn=False).to(dev())
+    f = torch.randn(2, 600, 64)
+    fd = f.to(dev()).requires_grad_(True)
+    out = layer(y=x.to(dev()), x=lat.to(dev()), f_y=fd, neighbors=_dict(enc))
+    go = torch.randn(out.shape)
+    out.backward(go.to(dev()))
+    # float64: k_e = MLP_relu([y_j, x_i]); out[b,q] = mean over the row of k_e * f[b, j]
+    w = [p.detach().cpu().double() for p in layer.channel_mlp.parameters()]
+    ws = [q.clone().requires_grad_(True) for q in w]
+    qid = torch.repeat_interleave(torch.arange(sp.numel() - 1), sp[1:] - sp[:-1])
+    h = torch.cat([x[idx], lat[qid]], -1).double()
+    for i in range(0, len(ws), 2):
+        h = h @ ws[i].t() + ws[i + 1]
+        if i + 2 < len(ws):
+            h = torch.relu(h)
+    fr = f.double().requires_grad_(True)
+    contrib = h[None] * fr[:, idx]
+    ref = torch.zeros(2, sp.numel() - 1, 64, dtype=torch.float64).index_add(1, qid, contrib)
+    ref = ref / (sp[1:] - sp[:-1]).clamp(min=1)[None, :, None]
+    ref.backward(go.double())
+    assert rel(out, ref) < 3e-6 and rel(fd.grad, fr.grad) < 3e-6
+    for prm, r in zip(layer.channel_mlp.parameters(), ws):
+        assert rel(prm.grad, r.grad) < 2e-5
+    with pytest.raises(NotImplementedError):
+        AGNO(channel_mlp_layers=[4, 64, 64], channel_mlp_non_linearity=F.silu)

@@ -40,7 +40,7 @@ for name, B, npts, ci in (("C3 union of 16 skewed samples", 1, 8192, 3), ("C2 un
     bytes_e = 4.0 * (enc.E * C + B * n_src_e * ci + 3 * enc.E + B * enc.Q * C)
     bytes_t = 4.0 * (dec.E * C + B * dec.Q + 4 * dec.E + B * n_src_d * C)
     print(f"== {name}: encoder E={enc.E} Q={enc.Q}, decoder E={dec.E} Q={dec.Q}")
-    for mode, chunk in ((0, 0), (1, 16), (1, 32), (1, 64), (1, 128)):
+    for mode, chunk in ((0, 0), (1, 8), (1, 16), (1, 32), (1, 64)):
         ops.set_gno_ep(mode); lib.gaot_debug_set_ep_chunk(chunk)
         with torch.no_grad():
             us_e = timeit(lambda: ops._GNOLiftTransform.apply(k_e, pn, wl, bl, enc, a_e))
