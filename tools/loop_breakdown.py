@@ -58,6 +58,11 @@ rows.append(("eager loop, resident tensors, torch AdamW (foreach), torch MSELoss
 rows.append(("  + HIP mse_loss", timed(loop(False, False, {}, "hip"))))
 rows.append(("  + fused=True AdamW", timed(loop(False, False, {"fused": True}, "torch"))))
 rows.append(("eager loop, batch uploaded per step", timed(loop(True, False, {}, "torch"))))
+p_pag, t_pag = p_c, t_c
+p_c, t_c = p_c.pin_memory(), t_c.pin_memory()          # what the reference's DataLoader hands over (data_processor.py:357: pin_memory=True)
+rows.append(("eager loop, batch uploaded per step from PINNED memory", timed(loop(True, False, {}, "torch"))))
+rows.append(("eager loop, pinned batch AND pageable coordinates uploaded per step", timed(loop(True, True, {}, "torch"))))
+p_c, t_c = p_pag, t_pag
 rows.append(("eager loop, batch AND coordinates uploaded per step (= bench reference_loop)", timed(loop(True, True, {}, "torch"))))
 
 # host-side cost of one eager step: enqueue only (GPU parked behind a long sleep)
