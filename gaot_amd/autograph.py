@@ -56,10 +56,32 @@ def eligible(model, latent, xcoord, pndata, query_coord, encoder_nbrs, decoder_n
     return True
 
 
+# The parameter list of a model is walked once and kept until ANY module registers a parameter or a sub-module (global
+# registration hooks bump the epoch): `model.parameters()` costs ~45 us per call on the example model, on the host path between
+# the trainer's synchronising uploads and the launch of the forward graph, where the GPU sits idle.
+_REG_EPOCH = [0]
+
+
+def _bump_epoch(*_args):
+    _REG_EPOCH[0] += 1
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_bump_epoch)
+torch.nn.modules.module.register_module_module_registration_hook(_bump_epoch)
+
+
+def _param_list(model):
+    hit = model.__dict__.get("_auto_graph_plist")
+    if hit is None or hit[0] != _REG_EPOCH[0]:
+        hit = (_REG_EPOCH[0], list(model.parameters()))
+        model.__dict__["_auto_graph_plist"] = hit
+    return hit[1]
+
+
 def _key(model, latent, xcoord, pndata, condition):
     return (tuple(pndata.shape), pndata.dtype, tuple(xcoord.shape), tuple(latent.shape),
             None if condition is None else tuple(condition.shape), pndata.device.index,
-            tuple(p.data_ptr() if p.requires_grad else -p.data_ptr() for p in model.parameters()))      # storage AND trainability
+            tuple(p.data_ptr() if p.requires_grad else -p.data_ptr() for p in _param_list(model)))      # storage AND trainability
 
 
 class _GraphedStep(torch.autograd.Function):
@@ -118,7 +140,7 @@ def _capture(model, latent, xcoord, pndata, condition) -> _Entry:
     from . import _lib as L
     e = _Entry()
     dev = pndata.device
-    params = [p for p in model.parameters()]
+    params = list(_param_list(model))
     e.params = params
     e.lat, e.x, e.flag = _static_coordinates(model, latent, xcoord)
     _sync_coordinates(e, latent, xcoord)      # buffers shared with an earlier capture may hold other bytes: raise the flag first

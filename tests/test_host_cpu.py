@@ -228,3 +228,19 @@ def test_torch_cluster_capped_search_known_answers():
     # 'auto' stays uncapped and inclusive
     full = NeighborSearch("auto")(data, q, r)
     assert int((full["neighbors_row_splits"][1:] - full["neighbors_row_splits"][:-1]).max()) > 32
+
+
+def test_autograph_parameter_list_cache_follows_registrations():
+    """autograph keeps a model's parameter list between calls; any parameter / sub-module registration anywhere invalidates it"""
+    import torch.nn as nn
+    from gaot_amd import autograph as AG
+    m = nn.Sequential(nn.Linear(3, 4), nn.Linear(4, 2))
+    a = AG._param_list(m)
+    assert AG._param_list(m) is a and len(a) == 4
+    m[0].extra = nn.Parameter(torch.zeros(2))
+    b = AG._param_list(m)
+    assert b is not a and len(b) == 5 and any(p is m[0].extra for p in b)
+    m.add_module("tail", nn.Linear(2, 2))
+    assert len(AG._param_list(m)) == 7
+    m[1].weight = nn.Parameter(torch.ones(2, 4))                     # a replaced Parameter object is picked up as well
+    assert any(p is m[1].weight for p in AG._param_list(m))
