@@ -368,11 +368,17 @@ constexpr int AS_KPL = 64 * AS_KROW, AS_VPL = 32 * AS_VROW;
 constexpr int AS_STAGE = 3 * AS_KPL + 3 * AS_VPL;          // bytes
 
 // NW = 4 (128 queries per workgroup, two workgroups per CU) or 8 (256 queries, one workgroup per CU: every K / V tile is split
-// half as often per head and each thread stages half as much)
-template <int NW>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_fwd_split_kernel(const AttnArgs p) {
+// half as often per head and each thread stages half as much).
+// DH = 32, or 64 for 32 < head_dim <= 64 (p.D % 4 == 0; columns past head_dim are zero-filled on the way in and never stored):
+// four 16-wide d steps per score, two 32-row tiles of O^T; one workgroup per CU either way (108 KB of LDS).
+template <int NW, int DH = 32>
+__global__ __launch_bounds__(64 * NW, (NW == 4 && DH == 32) ? 2 : 1) void attn_fwd_split_kernel(const AttnArgs p) {
     constexpr int KT = 64, NT = 64 * NW, QB = 32 * NW;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * AS_STAGE];
+    constexpr int NU = DH / 16, NDT = DH / 32, CPR = DH / 4;            // d steps, O tiles, 4-float chunks per row
+    constexpr int KROW = DH * 2 + 16, KPL = 64 * KROW, VPL = DH * AS_VROW, STAGE = 3 * KPL + 3 * VPL;
+    static_assert(DH != 32 || (KROW == AS_KROW && KPL == AS_KPL && VPL == AS_VPL && STAGE == AS_STAGE), "head_dim 32 layout");
+    constexpr int EPI = NW * 32 * (DH + 1) * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE > EPI ? 2 * STAGE : EPI];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
@@ -380,17 +386,18 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_fwd_split_kerne
     xcd_group_decode(blockIdx.x, p.B * p.H, (p.S + QB - 1) / QB, bh, blk);
     const int b = bh / p.H, h = bh % p.H, hk = h / (p.H / p.Hkv);
     const int q0 = blk * QB + wave * 32;
+    const int D = DH == 32 ? 32 : p.D;
     const float c = p.scale * LOG2E;
 
-    // Q fragments: lane (q = li, hi) holds d = 16u + 8hi + e (e = 0..7) for u = 0, 1, as three packed bf16 planes
-    bf16x8 qf[3][2];
+    // Q fragments: lane (q = li, hi) holds d = 16u + 8hi + e (e = 0..7) for every d step u, as three packed bf16 planes
+    bf16x8 qf[3][NU];
     {
         const int qi = q0 + li;
-        const float* qrow = p.q + ((long)b * p.S + qi) * p.ldq + (long)h * 32;
+        const float* qrow = p.q + ((long)b * p.S + qi) * p.ldq + (long)h * D;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const f32x4 v0 = load4(qrow, 16 * u + 8 * lh, 32, qi < p.S, true);
-            const f32x4 v1 = load4(qrow, 16 * u + 8 * lh + 4, 32, qi < p.S, true);
+        for (int u = 0; u < NU; ++u) {
+            const f32x4 v0 = load4(qrow, 16 * u + 8 * lh, D, qi < p.S, true);
+            const f32x4 v1 = load4(qrow, 16 * u + 8 * lh + 4, D, qi < p.S, true);
             u32x4 ph, pm, pl;
             unsigned a_, b_, c_;
             split3_pair(v0[0], v0[1], a_, b_, c_); ph[0] = a_; pm[0] = b_; pl[0] = c_;
@@ -400,30 +407,36 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_fwd_split_kerne
             qf[0][u] = __builtin_bit_cast(bf16x8, ph); qf[1][u] = __builtin_bit_cast(bf16x8, pm); qf[2][u] = __builtin_bit_cast(bf16x8, pl);
         }
     }
-    // staging: K float4 (key = idx >> 3, chunk = idx & 7) x 2; V: key PAIR kp = tid >> 3, chunk = tid & 7 (two float4)
-    const float* kbase = p.k + (long)b * p.S * p.ldk + (long)hk * 32;
-    const float* vbase = p.v + (long)b * p.S * p.ldv + (long)hk * 32;
-    constexpr int NKF = 512 / NT;                 // K float4 per thread per tile (2 or 1)
-    const bool vthread = tid < 256;               // V pairs: 256 (key pair, chunk) items
-    f32x4 rk[NKF], rv[2];
+    // staging: K float4 items (key = idx / CPR, chunk = idx % CPR), NKF per thread; V: key PAIR items (kp = idx / CPR, chunk), two
+    // float4 each, for the first 32 * CPR threads
+    const float* kbase = p.k + (long)b * p.S * p.ldk + (long)hk * D;
+    const float* vbase = p.v + (long)b * p.S * p.ldv + (long)hk * D;
+    constexpr int NKF = 64 * CPR / NT;            // K float4 per thread per tile
+    constexpr int NVI = (32 * CPR + NT - 1) / NT;      // V key-pair items per thread (1; 2 for the 4-wave head_dim-64 form)
+    static_assert(NKF >= 1, "staging roles");
+    f32x4 rk[NKF], rv[NVI][2];
     auto fetch = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < NKF; ++i) {
             const int idx = tid + i * NT;
-            const int krow = min(kt * KT + (idx >> 3), p.S - 1);
-            rk[i] = *reinterpret_cast<const f32x4*>(kbase + (long)krow * p.ldk + (idx & 7) * 4);
+            const int krow = min(kt * KT + idx / CPR, p.S - 1);
+            rk[i] = load4(kbase + (long)krow * p.ldk, (idx % CPR) * 4, D, true, true);
         }
-        if (vthread) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int vrow = min(kt * KT + 2 * (tid >> 3) + i, p.S - 1);
-                rv[i] = *reinterpret_cast<const f32x4*>(vbase + (long)vrow * p.ldv + (tid & 7) * 4);
+        for (int j = 0; j < NVI; ++j) {
+            const int idx = tid + j * NT;
+            if (idx < 32 * CPR) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int vrow = min(kt * KT + 2 * (idx / CPR) + i, p.S - 1);
+                    rv[j][i] = load4(vbase + (long)vrow * p.ldv, (idx % CPR) * 4, D, true, true);
+                }
             }
         }
     };
     auto stage = [&](int stg) {
-        unsigned char* Kp = smem + stg * AS_STAGE;
-        unsigned char* Vp = Kp + 3 * AS_KPL;
+        unsigned char* Kp = smem + stg * STAGE;
+        unsigned char* Vp = Kp + 3 * KPL;
 #pragma unroll
         for (int i = 0; i < NKF; ++i) {
             const int idx = tid + i * NT;
@@ -431,29 +444,35 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_fwd_split_kerne
             unsigned a_, b_, c_;
             split3_pair(rk[i][0], rk[i][1], a_, b_, c_); h[0] = a_; m[0] = b_; l[0] = c_;
             split3_pair(rk[i][2], rk[i][3], a_, b_, c_); h[1] = a_; m[1] = b_; l[1] = c_;
-            unsigned char* dst = Kp + (idx >> 3) * AS_KROW + (idx & 7) * 8;
+            unsigned char* dst = Kp + (idx / CPR) * KROW + (idx % CPR) * 8;
             *reinterpret_cast<u32x2*>(dst) = h;
-            *reinterpret_cast<u32x2*>(dst + AS_KPL) = m;
-            *reinterpret_cast<u32x2*>(dst + 2 * AS_KPL) = l;
+            *reinterpret_cast<u32x2*>(dst + KPL) = m;
+            *reinterpret_cast<u32x2*>(dst + 2 * KPL) = l;
         }
         // V^T: (key 2kp, key 2kp+1) pairs of the thread's 4 d columns -> one dword per d row and plane
-        if (vthread) {
-            const int kp = tid >> 3, d0 = (tid & 7) * 4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                unsigned a_, b_, c_;
-                split3_pair(rv[0][e], rv[1][e], a_, b_, c_);
-                unsigned char* dst = Vp + (d0 + e) * AS_VROW + kp * 4;
-                *reinterpret_cast<unsigned*>(dst) = a_;
-                *reinterpret_cast<unsigned*>(dst + AS_VPL) = b_;
-                *reinterpret_cast<unsigned*>(dst + 2 * AS_VPL) = c_;
+        for (int j = 0; j < NVI; ++j) {
+            const int idx = tid + j * NT;
+            if (idx < 32 * CPR) {
+                const int kp = idx / CPR, d0 = (idx % CPR) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    unsigned a_, b_, c_;
+                    split3_pair(rv[j][0][e], rv[j][1][e], a_, b_, c_);
+                    unsigned char* dst = Vp + (d0 + e) * AS_VROW + kp * 4;
+                    *reinterpret_cast<unsigned*>(dst) = a_;
+                    *reinterpret_cast<unsigned*>(dst + VPL) = b_;
+                    *reinterpret_cast<unsigned*>(dst + 2 * VPL) = c_;
+                }
             }
         }
     };
 
-    f32x16 oacc;
+    f32x16 oacc[NDT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
     const int ntiles = (p.S + KT - 1) / KT;
     fetch(0);
@@ -462,20 +481,20 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_fwd_split_kerne
     __syncthreads();
     for (int kt = 0; kt < ntiles; ++kt) {
         const int stg = kt & 1;
-        const unsigned char* Kp = smem + stg * AS_STAGE;
-        const unsigned char* Vp = Kp + 3 * AS_KPL;
-        // ---- S^T for 64 keys: two 32-key fragments, d in two 16-wide steps, six piece products each
+        const unsigned char* Kp = smem + stg * STAGE;
+        const unsigned char* Vp = Kp + 3 * KPL;
+        // ---- S^T for 64 keys: two 32-key fragments, d in 16-wide steps, six piece products each
         f32x16 s[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const unsigned char* kr = Kp + (32 * t + li) * AS_KROW + u * 32 + lh * 16;
+            for (int u = 0; u < NU; ++u) {
+                const unsigned char* kr = Kp + (32 * t + li) * KROW + u * 32 + lh * 16;
                 const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(kr);
-                const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(kr + AS_KPL);
-                const bf16x8 k2 = *reinterpret_cast<const bf16x8*>(kr + 2 * AS_KPL);
+                const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(kr + KPL);
+                const bf16x8 k2 = *reinterpret_cast<const bf16x8*>(kr + 2 * KPL);
                 s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k2, qf[0][u], s[t], 0, 0, 0);
                 s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[2][u], s[t], 0, 0, 0);
                 s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[1][u], s[t], 0, 0, 0);
@@ -512,7 +531,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_fwd_split_kerne
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
             l_run *= alpha;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+            for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
             m_run = m_new;
         }
         l_run += ps;
@@ -529,21 +550,24 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_fwd_split_kerne
                     ph[e] = a_; pm[e] = b_; pl[e] = c_;
                 }
                 const bf16x8 p0 = __builtin_bit_cast(bf16x8, ph), p1 = __builtin_bit_cast(bf16x8, pm), p2 = __builtin_bit_cast(bf16x8, pl);
-                // V^T[d = li][keys 32t + 16u + 4hi + {0..3}] and [.. + 8 + {0..3}]
-                const unsigned char* vr = Vp + li * AS_VROW + (32 * t + 16 * u + 4 * lh) * 2;
-                bf16x8 v[3];
 #pragma unroll
-                for (int pl_ = 0; pl_ < 3; ++pl_) {
-                    const u32x2 lo = *reinterpret_cast<const u32x2*>(vr + pl_ * AS_VPL);
-                    const u32x2 hi2 = *reinterpret_cast<const u32x2*>(vr + pl_ * AS_VPL + 16);
-                    v[pl_] = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi2[0], hi2[1]});
+                for (int dt = 0; dt < NDT; ++dt) {
+                    // V^T[d = 32dt + li][keys 32t + 16u + 4hi + {0..3}] and [.. + 8 + {0..3}]
+                    const unsigned char* vr = Vp + (32 * dt + li) * AS_VROW + (32 * t + 16 * u + 4 * lh) * 2;
+                    bf16x8 v[3];
+#pragma unroll
+                    for (int pl_ = 0; pl_ < 3; ++pl_) {
+                        const u32x2 lo = *reinterpret_cast<const u32x2*>(vr + pl_ * VPL);
+                        const u32x2 hi2 = *reinterpret_cast<const u32x2*>(vr + pl_ * VPL + 16);
+                        v[pl_] = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi2[0], hi2[1]});
+                    }
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[2], p0, oacc[dt], 0, 0, 0);
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0], p2, oacc[dt], 0, 0, 0);
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[1], p1, oacc[dt], 0, 0, 0);
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[1], p0, oacc[dt], 0, 0, 0);
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0], p1, oacc[dt], 0, 0, 0);
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0], p0, oacc[dt], 0, 0, 0);
                 }
-                oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[2], p0, oacc, 0, 0, 0);
-                oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0], p2, oacc, 0, 0, 0);
-                oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[1], p1, oacc, 0, 0, 0);
-                oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[1], p0, oacc, 0, 0, 0);
-                oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0], p1, oacc, 0, 0, 0);
-                oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0], p0, oacc, 0, 0, 0);
             }
         // next tile: registers -> the other stage (its previous readers finished before the last barrier), prefetch the one after
         if (kt + 1 < ntiles) stage(stg ^ 1);
@@ -551,14 +575,18 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_fwd_split_kerne
         __syncthreads();
     }
     const float inv_l = 1.0f / l_run;
-    float* Os = reinterpret_cast<float*>(smem) + wave * 32 * 33;          // NW * 4224 B <= 2 stages
+    float* Os = reinterpret_cast<float*>(smem) + wave * 32 * (DH + 1);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) Os[li * 33 + crow(r, lh)] = oacc[r] * inv_l;
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Os[li * (DH + 1) + 32 * dt + crow(r, lh)] = oacc[dt][r] * inv_l;
     __syncthreads();
     for (int rr = lh; rr < 32; rr += 2) {
         const int qi = q0 + rr;
         if (qi >= p.S) break;
-        p.o[((long)b * p.S + qi) * p.ldo + (long)h * 32 + li] = Os[rr * 33 + li];
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+            if (32 * dt + li < D) p.o[((long)b * p.S + qi) * p.ldo + (long)h * D + 32 * dt + li] = Os[rr * (DH + 1) + 32 * dt + li];
     }
     if (lh == 0 && q0 + li < p.S)
         p.lse[((long)b * p.H + h) * p.S + q0 + li] = m_run * p.scale + logf(l_run);
@@ -1316,6 +1344,280 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_split_kernel(const AttnArgs p
 }
 
 // ---------------------------------------------------------------------------------------------
+// backward for 32 < head_dim <= 64 on the bf16 matrix pipe (DH = 64; head_dim % 4 == 0, columns past head_dim zero-filled):
+// the 4-wave kernel above with four 16-wide d steps per score, two 32-row tiles of dK^T / dV^T / dQ, one workgroup per CU
+// (120 KB of LDS, ~320 registers).  Same staging roles, same fixed-order dQ reduction over the wave partials.
+// ---------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256, 1) void attn_bwd_split_dh_kernel(const AttnArgs p) {
+    constexpr int NU = DH / 16, NDT = DH / 32, CPR = DH / 4;
+    constexpr int KROW = DH * 2 + 16, KPL = 32 * KROW;             // k-major planes [32 q][DH d]
+    constexpr int TPL = DH * AB_TROW;                              // transposed planes [DH d][32 q]
+    constexpr int NKI = 32 * CPR / 256;                            // k-major float4 items per thread and tensor (2)
+    constexpr int NTI = 16 * CPR / 256 * 2;                        // transposed items per thread: (Q, dO) x ... (see below)
+    static_assert(DH == 64, "attn_bwd_split_dh_kernel: DH = 64");
+    constexpr int SWF = 32 * DH > 32 * 33 ? 32 * DH : 32 * 33;     // floats per wave of the dS^T staging / dQ partial tile
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 3 * KPL + 2 * 3 * TPL + 64 * 4 + 4 * 32 * DH * 4 + 4 * SWF * 4];
+    unsigned char* Qk = smem;
+    unsigned char* Gk = Qk + 3 * KPL;
+    unsigned char* Qt = Gk + 3 * KPL;
+    unsigned char* Gt = Qt + 3 * TPL;
+    float* lse_s = reinterpret_cast<float*>(Gt + 3 * TPL);
+    float* del_s = lse_s + 32;
+    float* Kw = del_s + 32;                         // per wave fp32 K tile [32][DH] (dQ product)
+    float* Sw = Kw + 4 * 32 * DH;                   // per wave dS^T staging [32][33]; reused as the wave's dQ partial [32][DH]
+    (void)NTI;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    int bh, kblk;
+    xcd_group_decode(blockIdx.x, p.B * p.H, p.n_kblocks, bh, kblk);
+    const int b = bh / p.H, h = bh % p.H, hk = h / (p.H / p.Hkv);
+    const int kv0 = kblk * 128 + wave * 32;
+    const int D = p.D;
+    const float c = p.scale * LOG2E;
+    float* Kmine = Kw + wave * 32 * DH;
+    float* Smine = Sw + wave * SWF;
+    float* Pmine = Smine;
+
+    // K^T / V^T as split B operands: lane (kv = li, hi) holds d = 16u + 8hi + e
+    bf16x8 kf[3][NU], vf[3][NU];
+    const bool kv_ok = kv0 + li < p.S;
+    {
+        const float* krow = p.k + ((long)b * p.S + min(kv0 + li, p.S - 1)) * p.ldk + (long)hk * D;
+        const float* vrow = p.v + ((long)b * p.S + min(kv0 + li, p.S - 1)) * p.ldv + (long)hk * D;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const f32x4 a0 = load4(krow, 16 * u + 8 * lh, D, true, true), a1 = load4(krow, 16 * u + 8 * lh + 4, D, true, true);
+            const f32x4 w0 = load4(vrow, 16 * u + 8 * lh, D, true, true), w1 = load4(vrow, 16 * u + 8 * lh + 4, D, true, true);
+            u32x4 ph, pm, pl, vh, vm, vl;
+            unsigned a_, b_, c_;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                split3_pair(a0[2 * e], a0[2 * e + 1], a_, b_, c_); ph[e] = a_; pm[e] = b_; pl[e] = c_;
+                split3_pair(a1[2 * e], a1[2 * e + 1], a_, b_, c_); ph[2 + e] = a_; pm[2 + e] = b_; pl[2 + e] = c_;
+                split3_pair(w0[2 * e], w0[2 * e + 1], a_, b_, c_); vh[e] = a_; vm[e] = b_; vl[e] = c_;
+                split3_pair(w1[2 * e], w1[2 * e + 1], a_, b_, c_); vh[2 + e] = a_; vm[2 + e] = b_; vl[2 + e] = c_;
+            }
+            kf[0][u] = __builtin_bit_cast(bf16x8, ph); kf[1][u] = __builtin_bit_cast(bf16x8, pm); kf[2][u] = __builtin_bit_cast(bf16x8, pl);
+            vf[0][u] = __builtin_bit_cast(bf16x8, vh); vf[1][u] = __builtin_bit_cast(bf16x8, vm); vf[2][u] = __builtin_bit_cast(bf16x8, vl);
+        }
+        // the wave's fp32 K tile, row-major, for the dQ product
+        for (int t = lane; t < 32 * CPR; t += 64) {
+            const int row = t / CPR, d = (t % CPR) * 4;
+            const f32x4 a = load4(p.k + ((long)b * p.S + min(kv0 + row, p.S - 1)) * p.ldk + (long)hk * D, d, D, kv0 + row < p.S, true);
+            *reinterpret_cast<f32x4*>(Kmine + row * DH + d) = a;
+        }
+    }
+    f32x16 dvacc[NDT], dkacc[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dvacc[dt][r] = 0.f; dkacc[dt][r] = 0.f; }
+
+    const float* qbase = p.q + (long)b * p.S * p.ldq + (long)h * D;
+    const float* gbase = p.dout + (long)b * p.S * p.ldo + (long)h * D;
+    const float* lse_b = p.lse + ((long)b * p.H + h) * p.S;
+    const float* del_b = p.delta + ((long)b * p.H + h) * p.S;
+    // prefetch registers.  k-major pieces: item idx = tid + 256 i -> (row = idx / CPR, chunk = idx % CPR) of Q and of dO.
+    // transposed pieces: item (qp = tid / CPR, chunk = tid % CPR) -> rows (2qp, 2qp+1), of Q and of dO (every thread does both).
+    f32x4 rq[NKI], rg[NKI], rtq[2], rtg[2];
+    float rl = 0.f, rd = 0.f;
+    auto fetch = [&](int q0) {
+#pragma unroll
+        for (int i = 0; i < NKI; ++i) {
+            const int idx = tid + 256 * i, row = idx / CPR, d = (idx % CPR) * 4;
+            const bool ok = q0 + row < p.S;
+            const long r = min(q0 + row, p.S - 1);
+            rq[i] = load4(qbase + r * p.ldq, d, D, ok, true);
+            rg[i] = load4(gbase + r * p.ldo, d, D, ok, true);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = 2 * (tid / CPR) + i, d = (tid % CPR) * 4;
+            const bool ok = q0 + row < p.S;
+            const long r = min(q0 + row, p.S - 1);
+            rtq[i] = load4(qbase + r * p.ldq, d, D, ok, true);
+            rtg[i] = load4(gbase + r * p.ldo, d, D, ok, true);
+        }
+        if (tid < 32) {
+            const bool ok = q0 + tid < p.S;
+            rl = ok ? lse_b[q0 + tid] * LOG2E : INFINITY;   // +inf -> P = 0 for padded queries
+            rd = ok ? del_b[q0 + tid] : 0.f;
+        }
+    };
+    const int nq = (p.S + 31) / 32;
+    const long part_stride = (long)p.B * p.H * p.S * DH;
+    float* part = p.dq_part + (long)kblk * part_stride + ((long)b * p.H + h) * p.S * DH;
+
+    fetch(0);
+    for (int qt = 0; qt < nq; ++qt) {
+        const int q0 = qt * 32;
+        // ---- stage the tile as split planes, both orientations
+        {
+            unsigned a_, b_, c_;
+#pragma unroll
+            for (int i = 0; i < NKI; ++i) {
+                const int idx = tid + 256 * i, row = idx / CPR, ch = idx % CPR;
+                u32x2 h2, m2, l2;
+                split3_pair(rq[i][0], rq[i][1], a_, b_, c_); h2[0] = a_; m2[0] = b_; l2[0] = c_;
+                split3_pair(rq[i][2], rq[i][3], a_, b_, c_); h2[1] = a_; m2[1] = b_; l2[1] = c_;
+                unsigned char* dq_ = Qk + row * KROW + ch * 8;
+                *reinterpret_cast<u32x2*>(dq_) = h2; *reinterpret_cast<u32x2*>(dq_ + KPL) = m2; *reinterpret_cast<u32x2*>(dq_ + 2 * KPL) = l2;
+                split3_pair(rg[i][0], rg[i][1], a_, b_, c_); h2[0] = a_; m2[0] = b_; l2[0] = c_;
+                split3_pair(rg[i][2], rg[i][3], a_, b_, c_); h2[1] = a_; m2[1] = b_; l2[1] = c_;
+                unsigned char* dg_ = Gk + row * KROW + ch * 8;
+                *reinterpret_cast<u32x2*>(dg_) = h2; *reinterpret_cast<u32x2*>(dg_ + KPL) = m2; *reinterpret_cast<u32x2*>(dg_ + 2 * KPL) = l2;
+            }
+            // transposed: (q = 2qp, 2qp+1) pairs of this thread's 4 d columns, for Q and for dO
+            const int qp = tid / CPR, d0 = (tid % CPR) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                split3_pair(rtq[0][e], rtq[1][e], a_, b_, c_);
+                unsigned char* dst = Qt + (d0 + e) * AB_TROW + qp * 4;
+                *reinterpret_cast<unsigned*>(dst) = a_;
+                *reinterpret_cast<unsigned*>(dst + TPL) = b_;
+                *reinterpret_cast<unsigned*>(dst + 2 * TPL) = c_;
+                split3_pair(rtg[0][e], rtg[1][e], a_, b_, c_);
+                dst = Gt + (d0 + e) * AB_TROW + qp * 4;
+                *reinterpret_cast<unsigned*>(dst) = a_;
+                *reinterpret_cast<unsigned*>(dst + TPL) = b_;
+                *reinterpret_cast<unsigned*>(dst + 2 * TPL) = c_;
+            }
+        }
+        if (tid < 32) { lse_s[tid] = rl; del_s[tid] = rd; }
+        __syncthreads();                                    // barrier A
+        if (qt + 1 < nq) fetch(q0 + 32);
+
+        // ---- S[q][kv] and dP[q][kv]: A = Q / dO planes (lane -> query row), B = K^T / V^T register planes
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const unsigned char* qr = Qk + li * KROW + u * 32 + lh * 16;
+            const unsigned char* gr = Gk + li * KROW + u * 32 + lh * 16;
+            const bf16x8 q0_ = *reinterpret_cast<const bf16x8*>(qr), q1_ = *reinterpret_cast<const bf16x8*>(qr + KPL), q2_ = *reinterpret_cast<const bf16x8*>(qr + 2 * KPL);
+            const bf16x8 g0_ = *reinterpret_cast<const bf16x8*>(gr), g1_ = *reinterpret_cast<const bf16x8*>(gr + KPL), g2_ = *reinterpret_cast<const bf16x8*>(gr + 2 * KPL);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q2_, kf[0][u], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g2_, vf[0][u], dp, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0_, kf[2][u], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0_, vf[2][u], dp, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q1_, kf[1][u], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1_, vf[1][u], dp, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q1_, kf[0][u], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1_, vf[0][u], dp, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0_, kf[1][u], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0_, vf[1][u], dp, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0_, kf[0][u], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0_, vf[0][u], dp, 0, 0, 0);
+        }
+        // ---- P = exp(S*scale - lse), dS = P * (dP - delta)   (rows q = crow(r,lh), column kv = li)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qr = crow(r, lh);
+            float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c, -lse_s[qr]));
+            if (!kv_ok) pv = 0.f;
+            s[r] = pv;
+            dp[r] = pv * (dp[r] - del_s[qr]);
+        }
+        // ---- dV^T[d][kv] += dO^T[d][q] P[q][kv] ; dK^T[d][kv] += Q^T[d][q] dS[q][kv]: the k-slots of step u are the lane's own
+        // registers r = 8u .. 8u+7 (queries 16u + 4hi + {0..3, 8..11}); A from the transposed planes (two 8-byte reads each)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            u32x4 ph, pm, pl, sh, sm, sl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned a_, b_, c_;
+                split3_pair(s[8 * u + 2 * e], s[8 * u + 2 * e + 1], a_, b_, c_); ph[e] = a_; pm[e] = b_; pl[e] = c_;
+                split3_pair(dp[8 * u + 2 * e], dp[8 * u + 2 * e + 1], a_, b_, c_); sh[e] = a_; sm[e] = b_; sl[e] = c_;
+            }
+            const bf16x8 p0 = __builtin_bit_cast(bf16x8, ph), p1 = __builtin_bit_cast(bf16x8, pm), p2 = __builtin_bit_cast(bf16x8, pl);
+            const bf16x8 d0 = __builtin_bit_cast(bf16x8, sh), d1 = __builtin_bit_cast(bf16x8, sm), d2 = __builtin_bit_cast(bf16x8, sl);
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const unsigned char* gr = Gt + (32 * dt + li) * AB_TROW + (16 * u + 4 * lh) * 2;
+                const unsigned char* qr = Qt + (32 * dt + li) * AB_TROW + (16 * u + 4 * lh) * 2;
+                bf16x8 ga[3], qa[3];
+#pragma unroll
+                for (int pl_ = 0; pl_ < 3; ++pl_) {
+                    const u32x2 g_lo = *reinterpret_cast<const u32x2*>(gr + pl_ * TPL), g_hi = *reinterpret_cast<const u32x2*>(gr + pl_ * TPL + 16);
+                    const u32x2 q_lo = *reinterpret_cast<const u32x2*>(qr + pl_ * TPL), q_hi = *reinterpret_cast<const u32x2*>(qr + pl_ * TPL + 16);
+                    ga[pl_] = __builtin_bit_cast(bf16x8, u32x4{g_lo[0], g_lo[1], g_hi[0], g_hi[1]});
+                    qa[pl_] = __builtin_bit_cast(bf16x8, u32x4{q_lo[0], q_lo[1], q_hi[0], q_hi[1]});
+                }
+                dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[2], p0, dvacc[dt], 0, 0, 0);
+                dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[2], d0, dkacc[dt], 0, 0, 0);
+                dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p2, dvacc[dt], 0, 0, 0);
+                dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d2, dkacc[dt], 0, 0, 0);
+                dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1], p1, dvacc[dt], 0, 0, 0);
+                dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1], d1, dkacc[dt], 0, 0, 0);
+                dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1], p0, dvacc[dt], 0, 0, 0);
+                dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1], d0, dkacc[dt], 0, 0, 0);
+                dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p1, dvacc[dt], 0, 0, 0);
+                dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d1, dkacc[dt], 0, 0, 0);
+                dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p0, dvacc[dt], 0, 0, 0);
+                dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d0, dkacc[dt], 0, 0, 0);
+            }
+        }
+        // ---- dQ[q][d] partial = sum_kv dS[q][kv] K[kv][d] on the fp32 MFMA: dS through wave-private LDS to flip lanes
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Smine[crow(r, lh) * 33 + li] = dp[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        f32x16 dq[NDT];
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+        float sa[16];
+#pragma unroll
+        for (int t16 = 0; t16 < 16; ++t16) sa[t16] = Smine[li * 33 + t16 + 16 * lh];
+#pragma unroll
+        for (int t16 = 0; t16 < 16; ++t16)
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt)
+                dq[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[t16], Kmine[(t16 + 16 * lh) * DH + 32 * dt + li], dq[dt], 0, 0, 0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                     // every lane has read its dS row before the tile is overwritten
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Pmine[crow(r, lh) * DH + 32 * dt + li] = dq[dt][r];
+        __syncthreads();                                    // barrier B
+        for (int t = tid; t < 32 * DH; t += 256) {
+            const int row = t / DH;
+            if (q0 + row < p.S)
+                part[(long)(q0 + row) * DH + (t % DH)] = (Sw[t] + Sw[SWF + t]) + (Sw[2 * SWF + t] + Sw[3 * SWF + t]);
+        }
+    }
+    // ---- epilogue: dK^T, dV^T -> [kv][d] through wave-private LDS, coalesced row stores (per QUERY head h)
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 2 * NDT; ++pass) {
+        const int dt = pass >> 1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Smine[li * 33 + crow(r, lh)] = ((pass & 1) == 0 ? dkacc[dt][r] * p.scale : dvacc[dt][r]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int rr = lh; rr < 32; rr += 2) {
+            const int kv = kv0 + rr;
+            if (kv < p.S && 32 * dt + li < D) {
+                if ((pass & 1) == 0) p.dk[((long)b * p.S + kv) * p.lddk + (long)h * D + 32 * dt + li] = Smine[rr * 33 + li];
+                else                 p.dv[((long)b * p.S + kv) * p.lddv + (long)h * D + 32 * dt + li] = Smine[rr * 33 + li];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward, 8 waves x 32 keys = 256 keys per workgroup (one workgroup per CU): the Q / dO tile is staged once per 256 keys,
 // the dQ slabs halve, and with 150 KB of LDS per workgroup the dQ product moves onto the bf16 pipe as well: dS is written as
 // three bf16 planes [q][kv] (2-byte stores straight from the packed split registers), K^T planes [d][kv] are built once per
@@ -1633,6 +1935,11 @@ extern "C" int gaot_attention_fwd(const float* q, const float* k, const float* v
         else hipLaunchKernelGGL(attn_fwd_split_kernel<8>, dim3(cdiv(S, 256) * B * H), dim3(512), 0, ST(stream), a);
     }
     else if (head_dim == 32 && a.vec && g_attn_split) hipLaunchKernelGGL(attn_fwd_split_kernel<4>, grid, block, 0, ST(stream), a);
+    else if (head_dim > 32 && a.vec && g_attn_split) {      // 32 < head_dim <= 64 (a.vec: head_dim % 4 == 0): split-bf16 with four d steps
+        if (g_attn_split != 3 && (g_attn_split == 2 || (long)cdiv(S, 256) * B * H >= 256))
+            hipLaunchKernelGGL((attn_fwd_split_kernel<8, 64>), dim3(cdiv(S, 256) * B * H), dim3(512), 0, ST(stream), a);
+        else hipLaunchKernelGGL((attn_fwd_split_kernel<4, 64>), grid, block, 0, ST(stream), a);
+    }
     else if (head_dim == 32 && a.vec) hipLaunchKernelGGL(attn_fwd_glds_kernel, grid, block, 0, ST(stream), a);
     else if (head_dim <= 32) hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, block, 0, ST(stream), a);
     else                hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, block, 0, ST(stream), a);
@@ -1758,6 +2065,8 @@ extern "C" int gaot_attention_bwd(const float* q, const float* k, const float* v
         hipLaunchKernelGGL(attn_bwd_split8_kernel, dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a);
     } else if (split_ok) {
         hipLaunchKernelGGL(attn_bwd_split_kernel, grid, block, 0, ST(stream), a);
+    } else if (head_dim > 32 && a.vec && g_attn_split && aligned16(dq) && aligned16(dk) && aligned16(dv)) {
+        hipLaunchKernelGGL(attn_bwd_split_dh_kernel<64>, grid, block, 0, ST(stream), a);
     } else if (DP == 32) {
         hipLaunchKernelGGL(attn_bwd_kernel<32>, grid, block, bwd_lds_bytes<32>(), ST(stream), a);
     } else {

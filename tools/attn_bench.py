@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from gaot_amd import ops, _lib as L
 lib = L.load(); dev = torch.device("cuda:0")
-B, S, H, D = 8, int(os.environ.get("S", 1024)), 8, 32
+B, S, H, D = int(os.environ.get("B", 8)), int(os.environ.get("S", 1024)), 8, int(os.environ.get("D", 32))
 qkv = torch.randn(B, S, 3 * H * D, device=dev, requires_grad=True)
 go = torch.randn(B, S, H * D, device=dev)
 def timeit(fn, iters=20):
@@ -27,9 +27,9 @@ for mode, pipe in ((0, 0), (1, 0), (2, 0), (2, 1)):
     lib.gaot_debug_set_attention_split(mode)
     lib.gaot_debug_set_attention_pipe(pipe)
     with torch.no_grad():
-        o = ops.attention(qkv, 8, 8, 32)
-        tf = timeit(lambda: ops.attention(qkv, 8, 8, 32))
-    o2 = ops.attention(qkv, 8, 8, 32)
+        o = ops.attention(qkv, H, H, D)
+        tf = timeit(lambda: ops.attention(qkv, H, H, D))
+    o2 = ops.attention(qkv, H, H, D)
     g, = torch.autograd.grad(o2, qkv, go, retain_graph=True)
     tb = timeit(lambda: torch.autograd.grad(o2, qkv, go, retain_graph=True))
     print(f"mode {mode} pipe {pipe}: fwd {tf:.1f} us   bwd (delta + main + dq reduce) {tb:.1f} us   rel-L2 vs f64: out {rel(o, o64.detach()):.2e}  dqkv {rel(g, g64):.2e}")
