@@ -537,6 +537,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && DH == 32) ? 2 : 1) void attn_f
             m_run = m_new;
         }
         l_run += ps;
+        // the tile's product is accumulated from ZERO on the matrix pipe and added to O on the vector pipe: the bf16 MFMA does
+        // not round its accumulator to nearest, and thousands of same-signed increments into one growing accumulator (many equal
+        // tokens: P nearly uniform, V rows alike) drift by 1e-5 relative (measured on the C5 shape: 4 096 keys, 92 % equal rows)
+        f32x16 ot[NDT];
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[dt][r] = 0.f;
         // ---- O^T += V^T P^T: P split in registers; step u of tile t covers the lane's registers r = 8u .. 8u+7
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -561,14 +569,18 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && DH == 32) ? 2 : 1) void attn_f
                         const u32x2 hi2 = *reinterpret_cast<const u32x2*>(vr + pl_ * VPL + 16);
                         v[pl_] = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi2[0], hi2[1]});
                     }
-                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[2], p0, oacc[dt], 0, 0, 0);
-                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0], p2, oacc[dt], 0, 0, 0);
-                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[1], p1, oacc[dt], 0, 0, 0);
-                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[1], p0, oacc[dt], 0, 0, 0);
-                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0], p1, oacc[dt], 0, 0, 0);
-                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0], p0, oacc[dt], 0, 0, 0);
+                    ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[2], p0, ot[dt], 0, 0, 0);
+                    ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0], p2, ot[dt], 0, 0, 0);
+                    ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[1], p1, ot[dt], 0, 0, 0);
+                    ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[1], p0, ot[dt], 0, 0, 0);
+                    ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0], p1, ot[dt], 0, 0, 0);
+                    ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0], p0, ot[dt], 0, 0, 0);
                 }
             }
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[dt][r] += ot[dt][r];
         // next tile: registers -> the other stage (its previous readers finished before the last barrier), prefetch the one after
         if (kt + 1 < ntiles) stage(stg ^ 1);
         if (kt + 2 < ntiles) fetch(kt + 2);
@@ -745,17 +757,20 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_split_pipe_kernel(const AttnA
             for (int r = 0; r < 16; ++r) {
                 const float a = fmaf(s[t][r], c, mc);
                 s[t][r] = (ABL & 16) ? a : __builtin_amdgcn_exp2f(a);
-                ps = add_scalar(ps, s[t][r]);
+                ps += s[t][r];          // plain C on purpose: inline asm reading a v_exp_f32 result misses the trans-use wait state
             }
         ps += __shfl_xor(ps, 32, 64);
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[r] = mul_scalar(oacc[r], alpha);
         l_run = l_run * alpha + ps;
         m_run = m_new;
         __builtin_amdgcn_sched_barrier(0);
         // ---- (2) matrix + integer region: P split, O^T += V^T P^T, S^T(kt + 1) = K(kt + 1) Q^T, staging
         const unsigned char* Vp = smem + 2 * KST + stg * VST;
+        // the tile's P V product starts from zero and joins O on the vector pipe (attn_fwd_split_kernel: the bf16 MFMA does not
+        // round its accumulator to nearest; long same-signed accumulations drift)
+        f32x16 ot;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[r] = 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -780,15 +795,15 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_split_pipe_kernel(const AttnA
                     v[pl_] = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi2[0], hi2[1]});
                 }
                 if (!(ABL & 2)) {
-                    oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[2], p0, oacc, 0, 0, 0);
-                    oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0], p2, oacc, 0, 0, 0);
-                    oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[1], p1, oacc, 0, 0, 0);
-                    oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[1], p0, oacc, 0, 0, 0);
-                    oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0], p1, oacc, 0, 0, 0);
-                    oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0], p0, oacc, 0, 0, 0);
+                    ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[2], p0, ot, 0, 0, 0);
+                    ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0], p2, ot, 0, 0, 0);
+                    ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[1], p1, ot, 0, 0, 0);
+                    ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[1], p0, ot, 0, 0, 0);
+                    ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0], p1, ot, 0, 0, 0);
+                    ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0], p0, ot, 0, 0, 0);
                 } else {
                     const f32x4 z = __builtin_bit_cast(f32x4, v[0]) + __builtin_bit_cast(f32x4, v[1]) + __builtin_bit_cast(f32x4, v[2]) + __builtin_bit_cast(f32x4, p0) + __builtin_bit_cast(f32x4, p1) + __builtin_bit_cast(f32x4, p2);
-                    oacc[4 * (2 * t + u)] += z[0]; oacc[4 * (2 * t + u) + 1] += z[1]; oacc[4 * (2 * t + u) + 2] += z[2]; oacc[4 * (2 * t + u) + 3] += z[3];
+                    ot[4 * (2 * t + u)] += z[0]; ot[4 * (2 * t + u) + 1] += z[1]; ot[4 * (2 * t + u) + 2] += z[2]; ot[4 * (2 * t + u) + 3] += z[3];
                 }
                 if (!(ABL & 1)) {
                     sn[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[t][u][2], qf[0][u], sn[t], 0, 0, 0);
@@ -802,6 +817,8 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_split_pipe_kernel(const AttnA
                 }
             }
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[r] = oacc[r] * alpha + ot[r];      // alpha == 1 exactly when the running max did not move; plain C (hazards: see above)
         // staging for the iterations to come (rows clamped: tiles past the end are harmless copies of the last row)
         if (!(ABL & 8)) {
             stage_v(stg ^ 1);          // V(kt + 1): its slot held V(kt - 1), read before the last barrier
@@ -1260,6 +1277,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_split_kernel(const AttnArgs p
         }
         // ---- dV^T[d][kv] += dO^T[d][q] P[q][kv] ; dK^T[d][kv] += Q^T[d][q] dS[q][kv]: the k-slots of step u are the lane's own
         // registers r = 8u .. 8u+7 (queries 16u + 4hi + {0..3, 8..11}); A from the transposed planes (two 8-byte reads each)
+        // this q tile's dV^T / dK^T contributions start from zero on the matrix pipe and join the running sums on the vector pipe
+        // (the bf16 MFMA does not round its accumulator to nearest: S / 32 tiles of same-signed increments would drift)
+        f32x16 dvt, dkt;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dvt[r] = 0.f; dkt[r] = 0.f; }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             u32x4 ph, pm, pl, sh, sm, sl;
@@ -1281,19 +1303,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_split_kernel(const AttnArgs p
                 ga[pl_] = __builtin_bit_cast(bf16x8, u32x4{g_lo[0], g_lo[1], g_hi[0], g_hi[1]});
                 qa[pl_] = __builtin_bit_cast(bf16x8, u32x4{q_lo[0], q_lo[1], q_hi[0], q_hi[1]});
             }
-            dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[2], p0, dvacc, 0, 0, 0);
-            dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[2], d0, dkacc, 0, 0, 0);
-            dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p2, dvacc, 0, 0, 0);
-            dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d2, dkacc, 0, 0, 0);
-            dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1], p1, dvacc, 0, 0, 0);
-            dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1], d1, dkacc, 0, 0, 0);
-            dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1], p0, dvacc, 0, 0, 0);
-            dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1], d0, dkacc, 0, 0, 0);
-            dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p1, dvacc, 0, 0, 0);
-            dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d1, dkacc, 0, 0, 0);
-            dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p0, dvacc, 0, 0, 0);
-            dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d0, dkacc, 0, 0, 0);
+            dvt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[2], p0, dvt, 0, 0, 0);
+            dkt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[2], d0, dkt, 0, 0, 0);
+            dvt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p2, dvt, 0, 0, 0);
+            dkt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d2, dkt, 0, 0, 0);
+            dvt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1], p1, dvt, 0, 0, 0);
+            dkt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1], d1, dkt, 0, 0, 0);
+            dvt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1], p0, dvt, 0, 0, 0);
+            dkt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1], d0, dkt, 0, 0, 0);
+            dvt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p1, dvt, 0, 0, 0);
+            dkt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d1, dkt, 0, 0, 0);
+            dvt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p0, dvt, 0, 0, 0);
+            dkt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d0, dkt, 0, 0, 0);
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dvacc[r] += dvt[r]; dkacc[r] += dkt[r]; }
         // ---- dQ[q][d] partial = sum_kv dS[q][kv] K[kv][d] on the fp32 MFMA: dS through wave-private LDS to flip lanes
 #pragma unroll
         for (int r = 0; r < 16; ++r) Smine[crow(r, lh) * 33 + li] = dp[r];
@@ -1524,6 +1548,13 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_split_dh_kernel(const AttnArg
         }
         // ---- dV^T[d][kv] += dO^T[d][q] P[q][kv] ; dK^T[d][kv] += Q^T[d][q] dS[q][kv]: the k-slots of step u are the lane's own
         // registers r = 8u .. 8u+7 (queries 16u + 4hi + {0..3, 8..11}); A from the transposed planes (two 8-byte reads each)
+        // this q tile's dV^T / dK^T contributions start from zero on the matrix pipe and join the running sums on the vector pipe
+        // (the bf16 MFMA does not round its accumulator to nearest: S / 32 tiles of same-signed increments would drift)
+        f32x16 dvt[NDT], dkt[NDT];
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dvt[dt][r] = 0.f; dkt[dt][r] = 0.f; }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             u32x4 ph, pm, pl, sh, sm, sl;
@@ -1547,20 +1578,24 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_split_dh_kernel(const AttnArg
                     ga[pl_] = __builtin_bit_cast(bf16x8, u32x4{g_lo[0], g_lo[1], g_hi[0], g_hi[1]});
                     qa[pl_] = __builtin_bit_cast(bf16x8, u32x4{q_lo[0], q_lo[1], q_hi[0], q_hi[1]});
                 }
-                dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[2], p0, dvacc[dt], 0, 0, 0);
-                dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[2], d0, dkacc[dt], 0, 0, 0);
-                dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p2, dvacc[dt], 0, 0, 0);
-                dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d2, dkacc[dt], 0, 0, 0);
-                dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1], p1, dvacc[dt], 0, 0, 0);
-                dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1], d1, dkacc[dt], 0, 0, 0);
-                dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1], p0, dvacc[dt], 0, 0, 0);
-                dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1], d0, dkacc[dt], 0, 0, 0);
-                dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p1, dvacc[dt], 0, 0, 0);
-                dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d1, dkacc[dt], 0, 0, 0);
-                dvacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p0, dvacc[dt], 0, 0, 0);
-                dkacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d0, dkacc[dt], 0, 0, 0);
+                dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[2], p0, dvt[dt], 0, 0, 0);
+                dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[2], d0, dkt[dt], 0, 0, 0);
+                dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p2, dvt[dt], 0, 0, 0);
+                dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d2, dkt[dt], 0, 0, 0);
+                dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1], p1, dvt[dt], 0, 0, 0);
+                dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1], d1, dkt[dt], 0, 0, 0);
+                dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1], p0, dvt[dt], 0, 0, 0);
+                dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1], d0, dkt[dt], 0, 0, 0);
+                dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p1, dvt[dt], 0, 0, 0);
+                dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d1, dkt[dt], 0, 0, 0);
+                dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p0, dvt[dt], 0, 0, 0);
+                dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d0, dkt[dt], 0, 0, 0);
             }
         }
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dvacc[dt][r] += dvt[dt][r]; dkacc[dt][r] += dkt[dt][r]; }
         // ---- dQ[q][d] partial = sum_kv dS[q][kv] K[kv][d] on the fp32 MFMA: dS through wave-private LDS to flip lanes
 #pragma unroll
         for (int r = 0; r < 16; ++r) Smine[crow(r, lh) * 33 + li] = dp[r];
@@ -1786,6 +1821,11 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
             s[r] = pv;
             dp[r] = pv * (dp[r] - del_s[qr]);
         }
+        // this q tile's dV^T / dK^T contributions start from zero on the matrix pipe and join the running sums on the vector pipe
+        // (the bf16 MFMA does not round its accumulator to nearest: S / 32 tiles of same-signed increments would drift)
+        f32x16 dvt, dkt;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dvt[r] = 0.f; dkt[r] = 0.f; }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             u32x4 ph, pm, pl, sh, sm, sl;
@@ -1815,19 +1855,21 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
                 ga[pl_] = __builtin_bit_cast(bf16x8, u32x4{g_lo[0], g_lo[1], g_hi[0], g_hi[1]});
                 qa[pl_] = __builtin_bit_cast(bf16x8, u32x4{q_lo[0], q_lo[1], q_hi[0], q_hi[1]});
             }
-            dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[2], p0, dvacc, 0, 0, 0);
-            dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[2], d0, dkacc, 0, 0, 0);
-            dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p2, dvacc, 0, 0, 0);
-            dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d2, dkacc, 0, 0, 0);
-            dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1], p1, dvacc, 0, 0, 0);
-            dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1], d1, dkacc, 0, 0, 0);
-            dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1], p0, dvacc, 0, 0, 0);
-            dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1], d0, dkacc, 0, 0, 0);
-            dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p1, dvacc, 0, 0, 0);
-            dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d1, dkacc, 0, 0, 0);
-            dvacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p0, dvacc, 0, 0, 0);
-            dkacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d0, dkacc, 0, 0, 0);
+            dvt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[2], p0, dvt, 0, 0, 0);
+            dkt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[2], d0, dkt, 0, 0, 0);
+            dvt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p2, dvt, 0, 0, 0);
+            dkt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d2, dkt, 0, 0, 0);
+            dvt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1], p1, dvt, 0, 0, 0);
+            dkt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1], d1, dkt, 0, 0, 0);
+            dvt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1], p0, dvt, 0, 0, 0);
+            dkt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1], d0, dkt, 0, 0, 0);
+            dvt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p1, dvt, 0, 0, 0);
+            dkt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d1, dkt, 0, 0, 0);
+            dvt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p0, dvt, 0, 0, 0);
+            dkt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d0, dkt, 0, 0, 0);
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dvacc[r] += dvt[r]; dkacc[r] += dkt[r]; }
         // ---- dQ[q][d] partial = sum_kv dS[q][kv] K[kv][d]: A = dS planes (lane -> q), B = K^T planes (lane -> d), kv = 16u + 8hi + e
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1915,7 +1957,8 @@ using namespace gaot;
 
 static int g_attn_split = 1;     // head_dim 32: 1 = split-bf16 kernels (default; 8-wave forward when it fills the chip), 0 = fp32-MFMA kernels,
                                  // 2 = split with the 8-wave forward always, 3 = split with the 4-wave forward always
-static int g_attn_pipe = 1;      // software-pipelined variants (S % 64 == 0) on / off
+static int g_attn_pipe = 0;      // 1 = the software-pipelined 8-wave forward for S % 64 == 0 (same speed as the plain one since both keep the
+                                 // tile product off the running accumulator: 57.6 vs 58.0 us; kept for tools/attn_ablate.hip and as a tested variant)
 extern "C" int gaot_debug_set_attention_pipe(int on) { const int old = g_attn_pipe; g_attn_pipe = on; return old; }
 extern "C" int gaot_debug_set_attention_split(int on) { const int old = g_attn_split; g_attn_split = on; return old; }
 

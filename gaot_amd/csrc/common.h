@@ -70,20 +70,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // instructions (v_pk_add/mul/fma_f32, v_pk_mov_b32) do not overlap with MFMAs on gfx950 -- one of them per MFMA serialises the
 // matrix pipe with the whole vector stream (tools/pipe_overlap.hip: 7 fma + 1 pk_add per MFMA takes 56 ns where 8 fma take
 // 39) -- while v_sub_f32 / v_and_b32 (VOP2) issue at twice the rate of three-operand instructions.  The asm keeps the SLP
-// vectoriser from re-packing them.
+// vectoriser from re-packing them.  CAUTION with inline-asm VALU: the compiler's hazard recogniser does not look inside it.  An asm
+// instruction whose input was just written by v_exp_f32 (trans-use wait state) or by an MFMA reads garbage (seen: wrong row
+// sums in an attention kernel).  Here every input is first read by a compiler-generated v_and_b32, which takes the wait.
 __device__ __forceinline__ float sub_scalar(float a, float b) {
     float r;
     asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ float add_scalar(float a, float b) {
-    float r;
-    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ float mul_scalar(float a, float b) {
-    float r;
-    asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
 template <int ABL = 0>

@@ -428,7 +428,13 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
     auto blocks = [&](int bm, int bn) { return (long)cdiv(a.M, bm) * cdiv(a.N, bn) * z; };
     (void)z;
     const bool glds_ok = g_use_glds && vec && a.vec_epi && a.K % 32 == 0 && a.M >= 4 && a.N >= 4;
-    const bool split_ok = g_use_split && g_use_split != 3 && glds_ok && a.A2 == nullptr && g_tile_override == 0;
+    // the bf16 MFMA does not round its fp32 accumulator to nearest: same-signed increments drift (4096^3 with positive
+    // operands: 1.1e-5 relative against 8e-7 on the fp32 MFMA, tools/acc_bias.py), so one workgroup accumulates at most 1 024
+    // values of k on that pipe; longer reductions either arrive split (the slabs are summed on the vector pipe) or stay on the
+    // fp32-MFMA tiles
+    const long k_per_wg = a.split_k > 1 ? (long)a.ktiles_per_split * 32 : a.K;
+    const bool split_ok = g_use_split && g_use_split != 3 && glds_ok && a.A2 == nullptr && g_tile_override == 0 &&
+                          (k_per_wg <= 1024 || g_split_pieces == 1 || g_use_split != 1);      // forced tuning modes bypass the cap
     // measured (tools/gemm_split_test.py): the 128x128 split-bf16 tiles win once they fill the chip (>= 256 workgroups
     // counting split-K slabs) on outputs at least one tile wide; narrower / smaller products stay on the fp32 MFMA tiles
     const bool split128 = split_ok && g_use_split != 4 &&

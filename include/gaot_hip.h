@@ -233,7 +233,7 @@ int gaot_swiglu_bwd(const float* u, const float* dg, int32_t M, int32_t F, float
 /* tuning hook: head_dim 32 attention, 1 = split-bf16 MFMA kernels (default), 0 = fp32-MFMA kernels, 2 / 3 = split with the
  * 8-wave / 4-wave forward workgroup forced.  Returns the previous value. */
 int gaot_debug_set_attention_split(int on);
-/* tuning hook: 1 (default) = the software-pipelined 8-wave split forward where it applies (S % 64 == 0), 0 = the plain one.
+/* tuning hook: 1 = the software-pipelined 8-wave split forward where it applies (S % 64 == 0), 0 (default) = the plain one.
  * Returns the previous value. */
 int gaot_debug_set_attention_pipe(int on);
 int gaot_attention_fwd(const float* q, const float* k, const float* v, int64_t ldq, int64_t ldk, int64_t ldv,
