@@ -517,7 +517,10 @@ class _KernelMLP(torch.autograd.Function):
         cin = x.shape[1]
         if cin > 16 or tuple(weights[0].shape) != (64, cin):
             return False
-        return all(tuple(w.shape) == (64, 64) for w in weights[1:]) and all(tuple(b.shape) == (64,) for b in biases)
+        cout = weights[-1].shape[0]           # the last layer may be narrower (lifting_channels < 64): rows past it are staged as zeros
+        if not (4 <= cout <= 64 and cout % 4 == 0 and tuple(weights[-1].shape) == (cout, 64) and tuple(biases[-1].shape) == (cout,)):
+            return False
+        return all(tuple(w.shape) == (64, 64) for w in weights[1:-1]) and all(tuple(b.shape) == (64,) for b in biases[:-1])
 
     @staticmethod
     def _ptrs(ts):
@@ -533,8 +536,9 @@ class _KernelMLP(torch.autograd.Function):
         bs = [b.contiguous() for b in wb[n:]]
         _dev(x, *ws, *bs)
         E, cin = x.shape
-        out = torch.empty(E, 64, device=x.device, dtype=torch.float32)
-        L.check(L.load().gaot_kernel_mlp_fwd(_p(x), E, cin, n, _KernelMLP._ptrs(ws), _KernelMLP._ptrs(bs), act, _p(out), _stream()),
+        cout = ws[-1].shape[0]
+        out = torch.empty(E, cout, device=x.device, dtype=torch.float32)
+        L.check(L.load().gaot_kernel_mlp_fwd_w(_p(x), E, cin, n, _KernelMLP._ptrs(ws), _KernelMLP._ptrs(bs), act, cout, _p(out), _stream()),
                 "gaot_kernel_mlp_fwd")
         ctx.save_for_backward(x, *ws, *bs)
         ctx.n, ctx.act = n, act
@@ -551,12 +555,15 @@ class _KernelMLP(torch.autograd.Function):
         psize = (n - 1) * 4096 + 64 * cin + 64 * n
         grads = torch.empty(psize, device=x.device, dtype=torch.float32)
         wsp = torch.empty(int(lib.gaot_kernel_mlp_bwd_workspace(E, cin, n)), device=x.device, dtype=torch.float32)
-        L.check(lib.gaot_kernel_mlp_bwd(_p(x), E, cin, n, _KernelMLP._ptrs(ws), _KernelMLP._ptrs(bs), ctx.act, _p(dk), _p(grads),
-                                        _p(wsp), _stream()), "gaot_kernel_mlp_bwd")
+        cout = ws[-1].shape[0]
+        L.check(lib.gaot_kernel_mlp_bwd_w(_p(x), E, cin, n, _KernelMLP._ptrs(ws), _KernelMLP._ptrs(bs), ctx.act, cout, _p(dk), _p(grads),
+                                          _p(wsp), _stream()), "gaot_kernel_mlp_bwd")
         o = (n - 1) * 4096
         dws = [grads[o:o + 64 * cin].view(64, cin)] + [grads[m * 4096:(m + 1) * 4096].view(64, 64) for m in range(n - 1)]
+        dws[-1] = dws[-1][:cout]              # rows past the last layer's width carry zeros
         ob = o + 64 * cin
         dbs = [grads[ob + 64 * i:ob + 64 * (i + 1)] for i in range(n)]
+        dbs[-1] = dbs[-1][:cout]
         return (None, None, None, *dws, *dbs)
 
 

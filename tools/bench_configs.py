@@ -77,7 +77,7 @@ def c4():
             "rollout_10_steps_ms": dt_roll * 1e3, "rollout_ms_per_step": dt_roll * 1e3 / 10}
 
 
-def c5():
+def c5(build_only: bool = False):
     torch.manual_seed(0)
     B, N = 1, 65536
     mc = MAGNOConfig(coord_dim=3, radius=0.067, lifting_channels=48)
@@ -88,6 +88,8 @@ def c5():
     p, t = torch.randn(B, N, 3, device=dev), torch.randn(B, N, 1, device=dev)
     ts = TrainStep(model)
     ts.bind(p, t, latent_tokens_coord=lat, xcoord=x)
+    if build_only:
+        return ts
     dt = timed(ts.step, 3, 10)
     nb = list(model.encoder.neighbor_cache.values())[0][0]
     deg = nb["neighbors_row_splits"][1:] - nb["neighbors_row_splits"][:-1]
