@@ -47,11 +47,11 @@ __global__ __launch_bounds__(256) void skinny_n_kernel(const GemmArgs p, int lpr
             if (n < p.N) epilogue_store(p, m, n, acc[n]);
 }
 
-// ---- C: out[m,n] = sum_r A[r*lda + m] * B[r*ldb + n]; lanes along the WIDE output dim, J <= 8 accumulators along the
+// ---- C: out[m,n] = sum_r A[r*lda + m] * B[r*ldb + n]; lanes along the WIDE output dim, J <= JM (8 or 16) accumulators along the
 // narrow one; grid (wide tiles of 64, row chunks); 4 waves interleave rows; partials -> ws[chunk][M*N]
-template <bool WIDE_IS_M>
+template <bool WIDE_IS_M, int JM = 8>
 __global__ __launch_bounds__(256) void skinny_tn_partial_kernel(const GemmArgs p, int chunks) {
-    __shared__ float red[4][8][64];
+    __shared__ float red[4][JM][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int W = WIDE_IS_M ? p.M : p.N, J = WIDE_IS_M ? p.N : p.M;
     const int w = blockIdx.x * 64 + lane;
@@ -60,24 +60,24 @@ __global__ __launch_bounds__(256) void skinny_tn_partial_kernel(const GemmArgs p
     const float* wide = WIDE_IS_M ? p.A : p.B;
     const float* nar = WIDE_IS_M ? p.B : p.A;
     const long ldw = WIDE_IS_M ? p.lda : p.ldb, ldn = WIDE_IS_M ? p.ldb : p.lda;
-    float acc[8], cs[8];     // cs: fused column sum of the A operand (WIDE_IS_M: cs[0] per lane; else per narrow index)
+    float acc[JM], cs[JM];     // cs: fused column sum of the A operand (WIDE_IS_M: cs[0] per lane; else per narrow index)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { acc[j] = 0.f; cs[j] = 0.f; }
+    for (int j = 0; j < JM; ++j) { acc[j] = 0.f; cs[j] = 0.f; }
     if (w < W) {
         int r = r0 + wave;
         for (; r + 12 < r1; r += 16) {             // four rows in flight per wave (HBM latency, not bandwidth, limits here)
-            float v[4], nn[4][8];
+            float v[4], nn[4][JM];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 v[u] = wide[(long)(r + 4 * u) * ldw + w];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) nn[u][j] = (j < J) ? nar[(long)(r + 4 * u) * ldn + j] : 0.f;
+                for (int j = 0; j < JM; ++j) nn[u][j] = (j < J) ? nar[(long)(r + 4 * u) * ldn + j] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (WIDE_IS_M) cs[0] += v[u];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < JM; ++j) {
                     acc[j] = fmaf(v[u], nn[u][j], acc[j]);
                     if (!WIDE_IS_M) cs[j] += nn[u][j];
                 }
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void skinny_tn_partial_kernel(const GemmArgs p
             const float v0 = wide[(long)r * ldw + w];
             if (WIDE_IS_M) cs[0] += v0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < JM; ++j)
                 if (j < J) {
                     const float n0 = nar[(long)r * ldn + j];
                     acc[j] = fmaf(v0, n0, acc[j]);
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void skinny_tn_partial_kernel(const GemmArgs p
         }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) red[wave][j][lane] = acc[j];
+    for (int j = 0; j < JM; ++j) red[wave][j][lane] = acc[j];
     __syncthreads();
     if (wave == 0 && w < W)
         for (int j = 0; j < J; ++j) {
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void skinny_tn_partial_kernel(const GemmArgs p
     if (p.colsum) {             // uniform over the block
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 8; ++j) red[wave][j][lane] = cs[j];
+        for (int j = 0; j < JM; ++j) red[wave][j][lane] = cs[j];
         __syncthreads();
         float* slab = p.ws + (long)chunks * p.M * p.N + (long)blockIdx.y * p.M;
         if (WIDE_IS_M) {
@@ -165,10 +165,13 @@ __global__ __launch_bounds__(256) void skinny_tn_final_kernel(const GemmArgs p, 
 bool launch_skinny(const GemmArgs& a, bool ak, bool bk, hipStream_t st) {
     if (a.A2 != nullptr) return false;
     // C: transposed-A weight gradient with a tiny side and a long reduction (needs the split-K workspace)
-    if (!ak && !bk && a.split_k > 1 && a.ws != nullptr && (a.N <= 8 || a.M <= 8) && (long)a.M * a.N <= 4096 && a.K >= 1024) {
+    if (!ak && !bk && a.split_k > 1 && a.ws != nullptr && (a.N <= 16 || a.M <= 16) && (long)a.M * a.N <= 4096 && a.K >= 1024) {
         const int chunks = a.split_k;
-        if (a.N <= 8) hipLaunchKernelGGL(skinny_tn_partial_kernel<true>, dim3(cdiv(a.M, 64), chunks), dim3(256), 0, st, a, chunks);
-        else          hipLaunchKernelGGL(skinny_tn_partial_kernel<false>, dim3(cdiv(a.N, 64), chunks), dim3(256), 0, st, a, chunks);
+        // narrow side up to 8 (2-D geometry statistics: 7 columns) or up to 16 (3-D: 9 columns, 3-channel inputs of wide layers)
+        if (a.N <= 8)       hipLaunchKernelGGL((skinny_tn_partial_kernel<true, 8>), dim3(cdiv(a.M, 64), chunks), dim3(256), 0, st, a, chunks);
+        else if (a.M <= 8)  hipLaunchKernelGGL((skinny_tn_partial_kernel<false, 8>), dim3(cdiv(a.N, 64), chunks), dim3(256), 0, st, a, chunks);
+        else if (a.N <= 16) hipLaunchKernelGGL((skinny_tn_partial_kernel<true, 16>), dim3(cdiv(a.M, 64), chunks), dim3(256), 0, st, a, chunks);
+        else                hipLaunchKernelGGL((skinny_tn_partial_kernel<false, 16>), dim3(cdiv(a.N, 64), chunks), dim3(256), 0, st, a, chunks);
         hipLaunchKernelGGL(skinny_tn_final_kernel, dim3(cdiv((long)a.M * a.N, 64)), dim3(256), 0, st, a, chunks);
         return true;
     }

@@ -136,7 +136,7 @@ def _split_for_reduction(Mo: int, No: int, K: int) -> int:
         return int(max(1, min(512 // t128, K // 256)))
     tiles = ((Mo + 63) // 64) * ((No + 63) // 64)
     want = max(1, 1024 // max(1, tiles))          # ~1024 workgroups of 64x64 (tools/gemm_bench.py sweep)
-    if Mo * No <= 4096 and min(Mo, No) <= 8:      # skinny path: HBM-latency bound, wants many short row chunks
+    if Mo * No <= 4096 and min(Mo, No) <= 16:     # skinny path: HBM-latency bound, wants many short row chunks
         return int(max(1, min(1024, (K + 127) // 128)))
     return int(max(1, min(want, 256, (K + 255) // 256)))
 
@@ -150,6 +150,8 @@ def linear_nt(x2: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = N
     assert w.shape[1] == K, (x2.shape, w.shape)
     if out is None:
         out = torch.empty(M, N, device=x2.device, dtype=torch.float32)
+    if "split_k" not in epi and epi.get("act", L.ACT_NONE) == L.ACT_NONE and epi.get("aux_out") is None and epi.get("aux_in") is None:
+        epi["split_k"] = _split_for_narrow_output(M, N, K)
     return gemm(M, N, K, x2, lda, 1, w, ldb, 1, out, out.stride(0) if M > 1 else N, **epi)
 
 
@@ -157,10 +159,19 @@ def _split_for_narrow_output(Mo: int, No: int, K: int) -> int:
     """activation-side products whose output is only two 128-wide tiles across (N = 256) with a long reduction (K >= 2048,
     du @ [w1;w3]): 128 output tiles leave half the CUs idle; two K halves on the split-bf16 tiles + one reduce measured
     78 -> 61 us at 8192 x 256 x 2048 (tools/gemm_n256_sweep.py)"""
-    if _GEMM_MODE < 4 or _NARROW_SPLIT == 0 or K < 2048 or K % 64 or Mo % 4 or No % 4:
+    if _GEMM_MODE < 4 or _NARROW_SPLIT == 0 or K < 1024 or K % 64 or Mo % 4 or No % 4:
         return 1
     t128 = ((Mo + 127) // 128) * ((No + 127) // 128)
-    return 2 if 100 <= t128 < 200 else 1
+    if 100 <= t128 < 200:
+        return 2 if K >= 2048 else 1
+    if 48 <= t128 < 100 and Mo >= 128 and No >= 128:
+        # fewer than 100 output tiles (4 096 tokens x 384 at the 3-D configuration): on the fp32-MFMA tiles 130 us at K = 3 072;
+        # enough K slabs for ~256 workgroups on the split-bf16 tiles, each at most 1 024 deep (the accumulation cap of gemm.hip)
+        s = min(-(-256 // t128), K // 512)
+        while s > 0 and K / s > 1024 and s < K // 256:
+            s += 1
+        return max(1, s)
+    return 1
 
 
 def matmul_nn(g: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, **epi) -> torch.Tensor:

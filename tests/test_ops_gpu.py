@@ -428,7 +428,8 @@ def test_host_tensors_are_refused():
         ops.linear(torch.randn(4, 4), torch.randn(4, 4))
 
 
-@pytest.mark.parametrize("N,K,M", [(256, 256, 8192), (64, 64, 55592), (64, 1, 131072), (1, 64, 70000), (64, 7, 4096), (96, 40, 1000)])
+@pytest.mark.parametrize("N,K,M", [(256, 256, 8192), (64, 64, 55592), (64, 1, 131072), (1, 64, 70000), (64, 7, 4096), (96, 40, 1000),
+                                   (64, 9, 65536), (12, 48, 32768), (64, 16, 5000), (9, 64, 20000)])
 def test_weight_grad_with_fused_bias_grad(N, K, M):
     """dW = dY^T X with the bias gradient (column sums of dY) produced by the same kernel (MFMA and skinny paths)"""
     from gaot_amd import ops
