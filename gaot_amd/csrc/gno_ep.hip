@@ -239,7 +239,9 @@ using namespace gaot;
 static int g_ep_chunk = 0;       // tuning hook: 0 = heuristic
 extern "C" int gaot_debug_set_ep_chunk(int n) { const int old = g_ep_chunk; g_ep_chunk = n; return old; }
 // measured (tools/gno_ep_bench.py, union of 16 skewed samples, 445 k edges): 16 / 32 / 64 / 128 edges per chunk -> 48 / 47 / 65 / 95 us
-static inline int ep_chunk(int E) { (void)E; return (g_ep_chunk & 0xffff) > 0 ? (g_ep_chunk & 0xffff) : 32; }
+// chunk length: the kernels are latency-bound (a lane group lives for chunk / 4 dependent load rounds), so small edge lists want
+// more, shorter chunks (C2, 55 k edges: dF 18.9 us at 16 vs 22.0 at 32; C3, 445 k edges: 35 us at 32 vs 43 at 16)
+static inline int ep_chunk(int E) { return (g_ep_chunk & 0xffff) > 0 ? (g_ep_chunk & 0xffff) : (E < 131072 ? 16 : 32); }
 static inline int ep_abl() { return g_ep_chunk >> 16; }      // tuning only: 1 = no pn gathers, 2 = no stores, 4 = no k_e loads
 
 extern "C" int64_t gaot_gno_ep_workspace(int32_t E, int32_t C, int32_t B) {

@@ -748,7 +748,9 @@ class _GNOProjTransform(torch.autograd.Function):
         else:
             nparts = int(lib.gaot_gno_lift_edge_grad_parts(plan.E, Cc))
             part = torch.empty(nparts, OC * Cc, device=k.device, dtype=torch.float32)
-            ep = df is not None and (_GNO_EP == 1 or (_GNO_EP == 2 and plan.t_rows_skewed))
+            # the edge-partitioned dF kernel keeps four samples' sums per lane group (every k row read once per four samples): also
+            # ahead of the row-parallel form on regular plans once the batch is that large (C2: 24.6 -> 18.9 us, tools/gno_c2_kernels.py)
+            ep = df is not None and (_GNO_EP == 1 or (_GNO_EP == 2 and (plan.t_rows_skewed or B >= 4)))
             L.check(lib.gaot_gno_proj_backward(_p(dy), _p(k), _p(f), _p(weff), B, plan.Q, n_src, Cc, OC, _p(plan.index),
                                                _p(plan.edge_query), plan.E, _p(plan.t_splits), _p(plan.t_edge),
                                                _p(esc) if has_e else None, _p(dk), _p(part), None if ep else _p(df), _stream()),
