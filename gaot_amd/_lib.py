@@ -91,8 +91,8 @@ PROTOTYPES = {
     "gaot_debug_set_kernel_mlp_ablate": (C.c_int, [C.c_int]),
     "gaot_debug_set_attention_split": (C.c_int, [C.c_int]),
     "gaot_debug_set_attention_pipe": (C.c_int, [C.c_int]),
-    "gaot_kernel_mlp_fwd_w": (C.c_int, [_f, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_int32, _f, _s]),
-    "gaot_kernel_mlp_bwd_w": (C.c_int, [_f, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_int32, _f, _f, _f, _s]),
+    "gaot_kernel_mlp_fwd_w": (C.c_int, [_f, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_int32), _f, _s]),
+    "gaot_kernel_mlp_bwd_w": (C.c_int, [_f, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_int32), _f, _f, _f, _s]),
     "gaot_kernel_mlp_bwd_workspace": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "gaot_kernel_mlp_bwd": (C.c_int, [_f, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, _f, _f, _f, _s]),
     "gaot_mse_loss_fwd": (C.c_int, [_f, _f, C.c_int64, _f, _f, _s]),

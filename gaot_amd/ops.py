@@ -526,12 +526,16 @@ class _KernelMLP(torch.autograd.Function):
         if list(acts) not in (["gelu"] * (n - 1) + ["none"], ["relu"] * (n - 1) + ["none"]) or any(b is None for b in biases):
             return False
         cin = x.shape[1]
-        if cin > 16 or tuple(weights[0].shape) != (64, cin):
+        if cin > 16:
             return False
-        cout = weights[-1].shape[0]           # the last layer may be narrower (lifting_channels < 64): rows past it are staged as zeros
-        if not (4 <= cout <= 64 and cout % 4 == 0 and tuple(weights[-1].shape) == (cout, 64) and tuple(biases[-1].shape) == (cout,)):
-            return False
-        return all(tuple(w.shape) == (64, 64) for w in weights[1:-1]) and all(tuple(b.shape) == (64,) for b in biases[:-1])
+        # every layer at most 64 wide, widths multiples of 4 (narrower layers -- lifting_channels 48 at the 3-D configuration -- run
+        # zero-padded at 64 inside the kernels)
+        prev = cin
+        for w, b in zip(weights, biases):
+            if w.dim() != 2 or w.shape[1] != prev or not (4 <= w.shape[0] <= 64 and w.shape[0] % 4 == 0) or tuple(b.shape) != (w.shape[0],):
+                return False
+            prev = w.shape[0]
+        return True
 
     @staticmethod
     def _ptrs(ts):
@@ -547,9 +551,9 @@ class _KernelMLP(torch.autograd.Function):
         bs = [b.contiguous() for b in wb[n:]]
         _dev(x, *ws, *bs)
         E, cin = x.shape
-        cout = ws[-1].shape[0]
-        out = torch.empty(E, cout, device=x.device, dtype=torch.float32)
-        L.check(L.load().gaot_kernel_mlp_fwd_w(_p(x), E, cin, n, _KernelMLP._ptrs(ws), _KernelMLP._ptrs(bs), act, cout, _p(out), _stream()),
+        widths = (C.c_int32 * n)(*[int(w.shape[0]) for w in ws])
+        out = torch.empty(E, ws[-1].shape[0], device=x.device, dtype=torch.float32)
+        L.check(L.load().gaot_kernel_mlp_fwd_w(_p(x), E, cin, n, _KernelMLP._ptrs(ws), _KernelMLP._ptrs(bs), act, widths, _p(out), _stream()),
                 "gaot_kernel_mlp_fwd")
         ctx.save_for_backward(x, *ws, *bs)
         ctx.n, ctx.act = n, act
@@ -566,15 +570,18 @@ class _KernelMLP(torch.autograd.Function):
         psize = (n - 1) * 4096 + 64 * cin + 64 * n
         grads = torch.empty(psize, device=x.device, dtype=torch.float32)
         wsp = torch.empty(int(lib.gaot_kernel_mlp_bwd_workspace(E, cin, n)), device=x.device, dtype=torch.float32)
-        cout = ws[-1].shape[0]
-        L.check(lib.gaot_kernel_mlp_bwd_w(_p(x), E, cin, n, _KernelMLP._ptrs(ws), _KernelMLP._ptrs(bs), ctx.act, cout, _p(dk), _p(grads),
+        wo = [int(w.shape[0]) for w in ws]
+        widths = (C.c_int32 * n)(*wo)
+        L.check(lib.gaot_kernel_mlp_bwd_w(_p(x), E, cin, n, _KernelMLP._ptrs(ws), _KernelMLP._ptrs(bs), ctx.act, widths, _p(dk), _p(grads),
                                           _p(wsp), _stream()), "gaot_kernel_mlp_bwd")
         o = (n - 1) * 4096
-        dws = [grads[o:o + 64 * cin].view(64, cin)] + [grads[m * 4096:(m + 1) * 4096].view(64, 64) for m in range(n - 1)]
-        dws[-1] = dws[-1][:cout]              # rows past the last layer's width carry zeros
+        # 64 x 64 blocks (64 x cin for the first layer) whose leading [out, in] corner is the gradient; the padding carries zeros
+        dws = [grads[o:o + 64 * cin].view(64, cin)[:wo[0]]]
+        for m in range(n - 1):
+            blk = grads[m * 4096:(m + 1) * 4096].view(64, 64)[:wo[m + 1], :wo[m]]
+            dws.append(blk if wo[m] == 64 else blk.contiguous())
         ob = o + 64 * cin
-        dbs = [grads[ob + 64 * i:ob + 64 * (i + 1)] for i in range(n)]
-        dbs[-1] = dbs[-1][:cout]
+        dbs = [grads[ob + 64 * i:ob + 64 * i + wo[i]] for i in range(n)]
         return (None, None, None, *dws, *dbs)
 
 

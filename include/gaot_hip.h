@@ -286,12 +286,14 @@ int gaot_debug_set_kernel_mlp_ablate(int bits);
 int64_t gaot_kernel_mlp_bwd_workspace(int32_t E, int32_t c_in, int32_t n_layers);
 int gaot_kernel_mlp_bwd(const float* x, int32_t E, int32_t c_in, int32_t n_layers, const float* const* w,
                         const float* const* b, int32_t act, const float* dk, float* grads, float* workspace, gaot_stream_t stream);
-/* the same pair for a LAST layer narrower than 64 (weight [cout][64], bias [cout]; cout a multiple of 4 in 4..64, e.g. 48 lifting
- * channels): out / dk are [E, cout]; the gradient vector keeps its layout, the last layer's block holds cout meaningful rows. */
+/* the same pair for layers narrower than 64: widths[i] = output width of layer i (multiples of 4 in 4..64, e.g. 48 lifting
+ * channels); weight i is [widths[i]][widths[i-1]] row-major (layer 0: [widths[0]][cin]), out / dk are [E, widths[n-1]].  The chain
+ * runs zero-padded at width 64; the gradient vector keeps its layout of 64 x 64 blocks, of which the leading
+ * widths[i] x widths[i-1] corner is meaningful (the rest is zero). */
 int gaot_kernel_mlp_fwd_w(const float* x, int32_t E, int32_t cin, int32_t n_layers, const float* const* w, const float* const* b,
-                          int32_t act, int32_t cout, float* out, gaot_stream_t stream);
+                          int32_t act, const int32_t* widths, float* out, gaot_stream_t stream);
 int gaot_kernel_mlp_bwd_w(const float* x, int32_t E, int32_t cin, int32_t n_layers, const float* const* w, const float* const* b,
-                          int32_t act, int32_t cout, const float* dk, float* grads, float* workspace, gaot_stream_t stream);
+                          int32_t act, const int32_t* widths, const float* dk, float* grads, float* workspace, gaot_stream_t stream);
 /* nn.MSELoss() with mean reduction (the reference trainers' loss, base_trainer.py:71): loss[0] = mean((pred - target)^2) over
  * n elements through `partial` (>= 256 floats; fixed-order two-stage sum, deterministic); backward
  * dpred = 2 (pred - target) / n * grad_loss[0] with grad_loss a DEVICE scalar (so the launch replays inside a hipGraph). */

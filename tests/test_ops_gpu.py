@@ -598,16 +598,18 @@ def test_gemm_split_bf16_exactness_of_the_split():
 @pytest.mark.parametrize("E,cin,n,act,cout", [(55592, 4, 4, "gelu", 64), (1000, 4, 4, "gelu", 64), (131, 6, 4, "gelu", 64), (4097, 4, 3, "gelu", 64),
                                               (300, 12, 2, "gelu", 64), (31, 4, 4, "gelu", 64), (4096, 7, 3, "relu", 64), (16384, 7, 3, "relu", 64),
                                               (77, 9, 3, "relu", 64), (5000, 6, 4, "gelu", 48), (333, 4, 4, "gelu", 32), (1025, 6, 3, "gelu", 4),
-                                              (700, 4, 2, "relu", 60)])
+                                              (700, 4, 2, "relu", 60), (4000, 9, 3, "relu", (64, 48, 48)), (999, 6, 4, "gelu", (32, 64, 16, 8)),
+                                              (2049, 4, 3, "gelu", (48, 48, 48))])
 def test_fused_kernel_mlp_matches_chain_and_float64(E, cin, n, act, cout):
     """csrc/kernel_mlp.hip (one launch forward, one backward) against the GEMM-chain path of the same op and a float64
     torch reference: output, every weight / bias gradient (mlp.py:307-337 semantics, exact-erf GELU).  cout < 64: a last layer
-    narrower than the hidden width (lifting_channels = 48 at the 3-D configuration)."""
+    narrower than the hidden width (lifting_channels = 48 at the 3-D configuration); a tuple: every width (zero-padded to 64 inside)."""
     from gaot_amd import ops
     torch.manual_seed(E + cin + n)
     d = "cuda"
     x = torch.rand(E, cin, device=d) * 2 - 1
-    dims = [cin] + [64] * (n - 1) + [cout]
+    dims = [cin] + (list(cout) if isinstance(cout, tuple) else [64] * (n - 1) + [cout])      # a tuple: every layer's width
+    cout = dims[-1]
     ws = [(torch.randn(dims[i + 1], dims[i], device=d) / dims[i] ** 0.5).requires_grad_() for i in range(n)]
     bs = [(0.1 * torch.randn(dims[i + 1], device=d)).requires_grad_() for i in range(n)]
     acts = [act] * (n - 1) + ["none"]
