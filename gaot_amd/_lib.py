@@ -48,6 +48,7 @@ PROTOTYPES = {
     "gaot_guard_begin": (C.c_int, [_i, _s]),
     "gaot_guard_compare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _i, _s]),
     "gaot_guard_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _i, _s]),
+    "gaot_guard_sync2": (C.c_int, [_f, _f, C.c_int64, _f, _f, C.c_int64, _i, _s]),
     "gaot_edge_attention_cosine": (C.c_int, [_f, _f, C.c_int32, _i, _i, C.c_int32, _f, _i, _s]),
     "gaot_segment_softmax_fwd": (C.c_int, [_f, _i, C.c_int32, _f, _s]),
     "gaot_segment_softmax_bwd": (C.c_int, [_f, _f, _i, C.c_int32, _f, _s]),

@@ -127,11 +127,9 @@ def _sync_coordinates(e, latent, xcoord):
     forward starts with the plans' refresh kernels guarded by the flag and ends by clearing it."""
     from . import _lib as L
     lib = L.load()
-    for new, kept in ((xcoord, e.x), (latent, e.lat)):
-        new = new.contiguous()
-        L.check(lib.gaot_guard_compare(ops._p(new), ops._p(kept), kept.numel() * kept.element_size(), ops._p(e.flag), ops._stream()),
-                "gaot_guard_compare")
-        kept.copy_(new, non_blocking=True)
+    xc, lc = xcoord.contiguous(), latent.contiguous()
+    L.check(lib.gaot_guard_sync2(ops._p(xc), ops._p(e.x), e.x.numel() * e.x.element_size(), ops._p(lc), ops._p(e.lat),
+                                 e.lat.numel() * e.lat.element_size(), ops._p(e.flag), ops._stream()), "gaot_guard_sync2")
     e.last_x, e.last_lat = xcoord, latent
 
 

@@ -296,6 +296,18 @@ __global__ void guard_compare_kernel(const uint32_t* __restrict__ cur, const uin
         diff |= cur[i] != kept[i];
     if (__any(diff) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
+// compare two (current, kept) pairs and take the new bytes into the kept copies in the same pass: flag |= any word differs
+__global__ void guard_sync2_kernel(const uint32_t* __restrict__ c0, uint32_t* __restrict__ k0, long n0,
+                                   const uint32_t* __restrict__ c1, uint32_t* __restrict__ k1, long n1, int* __restrict__ flag) {
+    bool diff = false;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n0 + n1; i += (long)gridDim.x * blockDim.x) {
+        const uint32_t v = i < n0 ? c0[i] : c1[i - n0];
+        uint32_t* dst = i < n0 ? k0 + i : k1 + (i - n0);
+        diff |= v != *dst;
+        *dst = v;
+    }
+    if (__any(diff) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
 __global__ void guard_update_kernel(const uint32_t* __restrict__ cur, uint32_t* __restrict__ kept, long nwords,
                                     const int* __restrict__ flag) {
     if (*flag == 0) return;
@@ -537,6 +549,18 @@ extern "C" int gaot_guard_compare(const void* current, const void* kept, int64_t
     hipLaunchKernelGGL(guard_compare_kernel, dim3(cap_blocks(nw, 256, 512)), dim3(256), 0, ST(stream), (const uint32_t*)current,
                        (const uint32_t*)kept, nw, flag);
     GAOT_CHECK_LAUNCH("gaot_guard_compare");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_guard_sync2(const void* cur0, void* kept0, int64_t nbytes0, const void* cur1, void* kept1, int64_t nbytes1,
+                                int32_t* flag, gaot_stream_t stream) {
+    GAOT_REQUIRE(cur0 && kept0 && cur1 && kept1 && flag && nbytes0 >= 0 && nbytes1 >= 0 && nbytes0 % 4 == 0 && nbytes1 % 4 == 0,
+                 "guard_sync2: bad arguments (sizes %% 4 == 0)");
+    const long nw = (nbytes0 + nbytes1) / 4;
+    if (nw == 0) return GAOT_OK;
+    hipLaunchKernelGGL(guard_sync2_kernel, dim3(cap_blocks(nw, 256, 512)), dim3(256), 0, ST(stream), (const uint32_t*)cur0, (uint32_t*)kept0,
+                       (long)(nbytes0 / 4), (const uint32_t*)cur1, (uint32_t*)kept1, (long)(nbytes1 / 4), flag);
+    GAOT_CHECK_LAUNCH("gaot_guard_sync2");
     return GAOT_OK;
 }
 

@@ -123,6 +123,10 @@ int gaot_csr_transpose(const int32_t* index32, int32_t E, int32_t n_src,
 int gaot_guard_begin(int32_t* flag, gaot_stream_t stream);
 int gaot_guard_compare(const void* current, const void* kept, int64_t nbytes, int32_t* flag, gaot_stream_t stream);
 int gaot_guard_update(const void* current, void* kept, int64_t nbytes, const int32_t* flag, gaot_stream_t stream);
+/* two (current, kept) pairs in ONE launch: flag |= (any word differs), then kept := current (what the captured-step path of
+ * autograph.py does with the latent and physical coordinates before every replay) */
+int gaot_guard_sync2(const void* cur0, void* kept0, int64_t nbytes0, const void* cur1, void* kept1, int64_t nbytes1,
+                     int32_t* flag, gaot_stream_t stream);
 /* cosine edge attention + segment softmax (agno.py:112-146, 211-224): attn[E].
  * src [n_src,dim], qry [Q,dim] are the (possibly node_pos_encoded) kernel coordinates. */
 int gaot_edge_attention_cosine(const float* src, const float* qry, int32_t dim,
