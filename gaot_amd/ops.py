@@ -133,7 +133,8 @@ def _split_for_reduction(Mo: int, No: int, K: int) -> int:
     t128 = ((Mo + 127) // 128) * ((No + 127) // 128)
     if _GEMM_MODE >= 4 and K % 32 == 0 and Mo % 4 == 0 and No % 4 == 0 and min(Mo, No) >= 128 and t128 >= 8:
         # split-bf16 128x128 tiles (gemm_split.hip): ~512 workgroups, at least 256 reduction rows per slab
-        return int(max(1, min(512 // t128, K // 256)))
+        # ... and at most 1 024 per slab (the split tiles' accumulation cap, gemm.hip)
+        return int(max(1, min(512 // t128, K // 256), -(-K // 1024)))
     tiles = ((Mo + 63) // 64) * ((No + 63) // 64)
     want = max(1, 1024 // max(1, tiles))          # ~1024 workgroups of 64x64 (tools/gemm_bench.py sweep)
     if Mo * No <= 4096 and min(Mo, No) <= 16:     # skinny path: HBM-latency bound, wants many short row chunks
@@ -171,6 +172,11 @@ def _split_for_narrow_output(Mo: int, No: int, K: int) -> int:
         while s > 0 and K / s > 1024 and s < K // 256:
             s += 1
         return max(1, s)
+    if t128 >= 200 and K > 1024 and Mo >= 128 and No >= 128:
+        # plenty of tiles, long reduction (C3: 16 384 x 256 x 2 048): the split-bf16 tiles accumulate at most 1 024 values of k per
+        # workgroup (gemm.hip), so the reduction arrives in slabs of that depth rather than falling back to the fp32-MFMA tiles
+        # (165 vs 123 us per launch at that shape)
+        return -(-K // 1024)
     return 1
 
 
