@@ -918,7 +918,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs p) {
     float* del_s = lse_s + 32;                     // [32]
     float* Kw = del_s + 32;                        // per wave [32][DP]
     float* Sw = Kw + 4 * 32 * DP;                  // per wave dS^T staging [32][33]
-    float* Pq = Sw + 4 * 32 * 33;                  // per wave dQ partial [32][DP]
+    float* Pq = Sw + 4 * 32 * 33;                  // per wave dQ partial [32][PQW]: at most 64 columns at a time (head_dim 128: two passes)
+    constexpr int PQW = DP < 64 ? DP : 64, NCH = DP / PQW, TPC = PQW / 32;      // partial width, passes, 32-wide d tiles per pass
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -931,7 +932,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs p) {
     const float c = p.scale * LOG2E;
     float* Kmine = Kw + wave * 32 * DP;
     float* Smine = Sw + wave * 32 * 33;
-    float* Pmine = Pq + wave * 32 * DP;
+    float* Pmine = Pq + wave * 32 * PQW;
 
     // K^T / V^T operands for this lane's key (column li): K[kv][8g + 4lh + s]
     float kreg[DP / 2], vreg[DP / 2];
@@ -1066,15 +1067,19 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs p) {
                 dq[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Kmine[kvs * DP + 32 * t + li], dq[t], 0, 0, 0);
         }
 #pragma unroll
-        for (int t = 0; t < ND; ++t)
+        for (int ch = 0; ch < NCH; ++ch) {
+            if (ch > 0) __syncthreads();                    // the previous pass's partials have been summed
 #pragma unroll
-            for (int r = 0; r < 16; ++r) Pmine[crow(r, lh) * DP + 32 * t + li] = dq[t][r];
-        __syncthreads();                                    // barrier B
-        // fixed-order sum of the four waves' partials -> this key block's slice of the dQ workspace
-        for (int t = tid; t < 32 * DP; t += 256) {
-            const int row = t / DP;
-            if (q0 + row < p.S)
-                part[(long)(q0 + row) * DP + (t % DP)] = Pq[t] + Pq[32 * DP + t] + Pq[2 * 32 * DP + t] + Pq[3 * 32 * DP + t];
+            for (int t = 0; t < TPC; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Pmine[crow(r, lh) * PQW + 32 * t + li] = dq[ch * TPC + t][r];
+            __syncthreads();                                // barrier B
+            // fixed-order sum of the four waves' partials -> this key block's slice of the dQ workspace
+            for (int t = tid; t < 32 * PQW; t += 256) {
+                const int row = t / PQW;
+                if (q0 + row < p.S)
+                    part[(long)(q0 + row) * DP + ch * PQW + (t % PQW)] = Pq[t] + Pq[32 * PQW + t] + Pq[2 * 32 * PQW + t] + Pq[3 * 32 * PQW + t];
+            }
         }
     }
     // ---- epilogue: dK^T, dV^T -> [kv][d] through wave-private LDS, coalesced row stores (per QUERY head h)
@@ -1938,7 +1943,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
 }
 
 template <int DP> static size_t bwd_lds_bytes() {
-    return sizeof(float) * (2 * 32 * (DP + 4) + 64 + 4 * 32 * DP + 4 * 32 * 33 + 4 * 32 * DP);
+    return sizeof(float) * (2 * 32 * (DP + 4) + 64 + 4 * 32 * DP + 4 * 32 * 33 + 4 * 32 * (DP < 64 ? DP : 64));
 }
 
 static int fill_common(AttnArgs& a, const float* q, const float* k, const float* v, int64_t ldq, int64_t ldk, int64_t ldv,
@@ -1967,7 +1972,7 @@ extern "C" int gaot_attention_fwd(const float* q, const float* k, const float* v
                                   float* lse, gaot_stream_t stream) {
     GAOT_REQUIRE(q && k && v && o && lse, "attention_fwd: null pointer");
     GAOT_REQUIRE(B > 0 && S > 0 && H > 0 && Hkv > 0 && H % Hkv == 0, "attention_fwd: bad sizes B=%d S=%d H=%d Hkv=%d", B, S, H, Hkv);
-    GAOT_REQUIRE(head_dim > 0 && head_dim <= 64, "attention_fwd: head_dim %d not in 1..64", head_dim);
+    GAOT_REQUIRE(head_dim > 0 && head_dim <= 128, "attention_fwd: head_dim %d not in 1..128", head_dim);
     AttnArgs a = {};
     fill_common(a, q, k, v, ldq, ldk, ldv, B, S, H, Hkv, head_dim);
     a.o = o; a.ldo = ldo; a.lse = lse;
@@ -1978,14 +1983,15 @@ extern "C" int gaot_attention_fwd(const float* q, const float* k, const float* v
         else hipLaunchKernelGGL(attn_fwd_split_kernel<8>, dim3(cdiv(S, 256) * B * H), dim3(512), 0, ST(stream), a);
     }
     else if (head_dim == 32 && a.vec && g_attn_split) hipLaunchKernelGGL(attn_fwd_split_kernel<4>, grid, block, 0, ST(stream), a);
-    else if (head_dim > 32 && a.vec && g_attn_split) {      // 32 < head_dim <= 64 (a.vec: head_dim % 4 == 0): split-bf16 with four d steps
+    else if (head_dim > 32 && head_dim <= 64 && a.vec && g_attn_split) {      // (a.vec: head_dim % 4 == 0): split-bf16 with four d steps
         if (g_attn_split != 3 && (g_attn_split == 2 || (long)cdiv(S, 256) * B * H >= 256))
             hipLaunchKernelGGL((attn_fwd_split_kernel<8, 64>), dim3(cdiv(S, 256) * B * H), dim3(512), 0, ST(stream), a);
         else hipLaunchKernelGGL((attn_fwd_split_kernel<4, 64>), grid, block, 0, ST(stream), a);
     }
     else if (head_dim == 32 && a.vec) hipLaunchKernelGGL(attn_fwd_glds_kernel, grid, block, 0, ST(stream), a);
     else if (head_dim <= 32) hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, block, 0, ST(stream), a);
-    else                hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, block, 0, ST(stream), a);
+    else if (head_dim <= 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, block, 0, ST(stream), a);
+    else                     hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, block, 0, ST(stream), a);      // 64 < head_dim <= 128: fp32 MFMA, one wave per SIMD
     GAOT_CHECK_LAUNCH("gaot_attention_fwd");
     return GAOT_OK;
 }
@@ -2074,7 +2080,7 @@ extern "C" int gaot_attention_bwd_dropout(const float* q, const float* k, const 
 }
 
 extern "C" int64_t gaot_attention_bwd_workspace(int32_t B, int32_t S, int32_t H, int32_t head_dim) {
-    const int DP = head_dim <= 32 ? 32 : 64;
+    const int DP = head_dim <= 32 ? 32 : (head_dim <= 64 ? 64 : 128);
     const int64_t nkb = cdiv(S, 128);
     return (int64_t)B * H * S + nkb * B * H * S * DP;   // delta + dQ partials per key block
 }
@@ -2085,7 +2091,7 @@ extern "C" int gaot_attention_bwd(const float* q, const float* k, const float* v
                                   int64_t lddk, int64_t lddv, float* workspace, gaot_stream_t stream) {
     GAOT_REQUIRE(q && k && v && o && dout && lse && dq && dk && dv && workspace, "attention_bwd: null pointer");
     GAOT_REQUIRE(B > 0 && S > 0 && H > 0 && Hkv > 0 && H % Hkv == 0, "attention_bwd: bad sizes");
-    GAOT_REQUIRE(head_dim > 0 && head_dim <= 64, "attention_bwd: head_dim %d not in 1..64", head_dim);
+    GAOT_REQUIRE(head_dim > 0 && head_dim <= 128, "attention_bwd: head_dim %d not in 1..128", head_dim);
     AttnArgs a = {};
     fill_common(a, q, k, v, ldq, ldk, ldv, B, S, H, Hkv, head_dim);
     a.vec = a.vec && (ldo % 4 == 0) && aligned16(dout);
@@ -2094,7 +2100,7 @@ extern "C" int gaot_attention_bwd(const float* q, const float* k, const float* v
     a.delta = workspace;
     a.dq_part = workspace + (int64_t)B * H * S;
     a.n_kblocks = cdiv(S, 128);
-    const int DP = head_dim <= 32 ? 32 : 64;
+    const int DP = head_dim <= 32 ? 32 : (head_dim <= 64 ? 64 : 128);
     if (a.vec && aligned16(o)) {
         const int lpr = 8;
         hipLaunchKernelGGL(attn_delta_vec_kernel, dim3(cdiv((long)B * S * H * lpr, 256)), dim3(256), 0, ST(stream), a, lpr);
@@ -2108,11 +2114,11 @@ extern "C" int gaot_attention_bwd(const float* q, const float* k, const float* v
         hipLaunchKernelGGL(attn_bwd_split8_kernel, dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a);
     } else if (split_ok) {
         hipLaunchKernelGGL(attn_bwd_split_kernel, grid, block, 0, ST(stream), a);
-    } else if (head_dim > 32 && a.vec && g_attn_split && aligned16(dq) && aligned16(dk) && aligned16(dv)) {
+    } else if (head_dim > 32 && head_dim <= 64 && a.vec && g_attn_split && aligned16(dq) && aligned16(dk) && aligned16(dv)) {
         hipLaunchKernelGGL(attn_bwd_split_dh_kernel<64>, grid, block, 0, ST(stream), a);
     } else if (DP == 32) {
         hipLaunchKernelGGL(attn_bwd_kernel<32>, grid, block, bwd_lds_bytes<32>(), ST(stream), a);
-    } else {
+    } else if (DP == 64) {
         static bool attr_set = false;
         if (!attr_set) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2120,6 +2126,14 @@ extern "C" int gaot_attention_bwd(const float* q, const float* k, const float* v
             attr_set = true;
         }
         hipLaunchKernelGGL(attn_bwd_kernel<64>, grid, block, bwd_lds_bytes<64>(), ST(stream), a);
+    } else {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)bwd_lds_bytes<128>());
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(attn_bwd_kernel<128>, grid, block, bwd_lds_bytes<128>(), ST(stream), a);
     }
     const long total = (long)B * H * S * DP;
     int nb = cdiv(total, 256); if (nb > 4096) nb = 4096;

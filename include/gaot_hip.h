@@ -233,7 +233,7 @@ int gaot_swiglu_bwd(const float* u, const float* dg, int32_t M, int32_t F, float
 /* softmax attention, no mask, scale 1/sqrt(head_dim) (attn.py:98-116, F.scaled_dot_product_attention).
  * q/k/v are strided views: element (b,s,h,d) at ptr[(b*S+s)*ld + h*head_dim + d]; kv head = h / (H/Hkv).
  * o has the same addressing with ldo.  lse[B,H,S] (natural-log-sum-exp of scaled scores) saved for bwd.
- * head_dim <= 64, S arbitrary. */
+ * head_dim <= 128, S arbitrary (head_dim <= 64: split-bf16 kernels where they apply; above: fp32 MFMA). */
 /* tuning hook: head_dim 32 attention, 1 = split-bf16 MFMA kernels (default), 0 = fp32-MFMA kernels, 2 / 3 = split with the
  * 8-wave / 4-wave forward workgroup forced.  Returns the previous value. */
 int gaot_debug_set_attention_split(int on);

@@ -669,3 +669,19 @@ def test_attention_dropout_in_the_model_train_vs_eval():
         assert 1e-4 < rel_l2(outs[i].cpu(), ref.cpu()) < 0.5, rel_l2(outs[i].cpu(), ref.cpu())
         for j in range(i):
             assert not torch.equal(outs[i], outs[j])
+
+
+def test_head_dim_128_model_vs_oracle():
+    """hidden 256 on 2 heads: head_dim 128 (the fp32-MFMA attention kernels above 64) -- forward, loss and every gradient"""
+    from oracle import gaot_oracle as O
+    model, sd, ocfg = make_model(2, 1, [16, 16], C=32, hidden=256, heads=2, radius=0.12, seed=21)
+    g = torch.Generator().manual_seed(21)
+    lat, x = grid([16, 16]), uniform_points(900, 2, g)
+    p, tgt = torch.randn(2, 900, 2, generator=g), torch.randn(2, 900, 1, generator=g)
+    enc, dec = [O.radius_csr(x, lat, 0.12)], [O.radius_csr(lat, x, 0.12)]
+    loss, grads, _, _, pred = O.train_step(sd, ocfg, dict(latent=lat, xcoord=x, pndata=p, target=tgt, encoder_nbrs=enc, decoder_nbrs=dec),
+                                           return_pred=True)
+    model.to(dev()).train()
+    assert model.processor.blocks_in_order()[0].attn.head_dim == 128
+    kw = dict(latent_tokens_coord=lat.to(dev()), xcoord=x.to(dev()), encoder_nbrs=[csr_dict(enc[0])], decoder_nbrs=[csr_dict(dec[0])])
+    check_step(model, (loss, grads, pred), kw, p.to(dev()), tgt.to(dev()), "head_dim 128")

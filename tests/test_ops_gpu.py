@@ -266,7 +266,8 @@ def test_swiglu():
 @pytest.mark.parametrize("B,S,H,Hkv,D", [(2, 256, 4, 4, 32), (1, 1024, 8, 8, 32), (2, 64, 4, 4, 8), (2, 200, 4, 4, 12),
                                          (1, 130, 2, 2, 64), (2, 96, 4, 2, 16), (1, 33, 1, 1, 32), (2, 203, 4, 2, 32),
                                          (1, 129, 2, 1, 32), (2, 128, 4, 2, 32), (1, 64, 2, 2, 32),
-                                         (2, 200, 4, 2, 48), (1, 256, 2, 2, 64), (1, 512, 4, 4, 48), (1, 70, 2, 1, 36)])
+                                         (2, 200, 4, 2, 48), (1, 256, 2, 2, 64), (1, 512, 4, 4, 48), (1, 70, 2, 1, 36),
+                                         (1, 160, 2, 2, 128), (2, 97, 2, 1, 96), (1, 300, 1, 1, 72)])
 def test_attention_fwd_bwd(B, S, H, Hkv, D):
     from gaot_amd import ops, _lib
     g = torch.Generator().manual_seed(S + D)
@@ -285,7 +286,7 @@ def test_attention_fwd_bwd(B, S, H, Hkv, D):
     out.backward(go.to(dev()))
     assert rel(out, ref) < 3e-6
     assert rel(d.grad, r.grad) < 1e-5
-    if D >= 32 and D % 4 == 0:        # the default above is the split-bf16 pair of kernels (head_dim 32, and 36..64 in steps of 4); the fp32-MFMA kernels stay covered too
+    if 32 <= D <= 64 and D % 4 == 0:        # the default above is the split-bf16 pair of kernels (head_dim 32, and 36..64 in steps of 4); the fp32-MFMA kernels stay covered too
         old = _lib.load().gaot_debug_set_attention_split(0)
         try:
             d2 = qkv.to(dev()).requires_grad_(True)
