@@ -685,3 +685,36 @@ def test_head_dim_128_model_vs_oracle():
     assert model.processor.blocks_in_order()[0].attn.head_dim == 128
     kw = dict(latent_tokens_coord=lat.to(dev()), xcoord=x.to(dev()), encoder_nbrs=[csr_dict(enc[0])], decoder_nbrs=[csr_dict(dec[0])])
     check_step(model, (loss, grads, pred), kw, p.to(dev()), tgt.to(dev()), "head_dim 128")
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_twelve_training_steps_track_the_oracle(graph):
+    """TrainStep (eager and hipGraph replay) against the oracle's loop over 12 optimizer steps on changing batches: the loss
+    history and the final weights stay together (differences compound through AdamW's normalisation, hence the looser bars:
+    loss 1e-4 relative, weights 1e-3 of the largest update -- an element whose gradient is at the rounding level moves by lr
+    whatever its value)"""
+    from gaot_amd.model.gaot import GAOT
+    from gaot_amd.trainer import TrainStep
+    from oracle import gaot_oracle as O
+    model, sd, ocfg = make_model(2, 1, [16, 16], C=32, hidden=128, heads=4, radius=0.12, precompute=False, seed=31)
+    g = torch.Generator().manual_seed(31)
+    lat, x = grid([16, 16]), uniform_points(800, 2, g)
+    data = [(torch.randn(3, 800, 2, generator=g), torch.randn(3, 800, 1, generator=g)) for _ in range(12)]
+    enc, dec = [O.radius_csr(x, lat, 0.12, exact=True)], [O.radius_csr(lat, x, 0.12, exact=True)]
+    cur, state, ref_losses = sd, None, []
+    for p, t in data:
+        loss, _, cur, state = O.train_step(cur, ocfg, dict(latent=lat, xcoord=x, pndata=p, target=t, encoder_nbrs=enc, decoder_nbrs=dec),
+                                           lr=2e-3, weight_decay=1e-4, state=state)
+        ref_losses.append(float(loss))
+    m = GAOT(2, 1, model_cfg(model)); m.load_state_dict(sd); m.to(dev()).train()
+    ts = TrainStep(m, lr=2e-3, weight_decay=1e-4, use_graph=graph)
+    ts.bind(data[0][0].to(dev()), data[0][1].to(dev()), latent_tokens_coord=lat.to(dev()), xcoord=x.to(dev()))
+    losses = []
+    for p, t in data:
+        losses.append(float(ts.step(p.to(dev()), t.to(dev()))))
+    torch.cuda.synchronize()
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - b) < 1e-4 * abs(b), (losses, ref_losses)
+    moved = max(float((cur[k] - sd[k]).abs().max()) for k in sd)
+    worst = max(float((prm.detach().cpu() - cur[k]).abs().max()) for k, prm in m.state_dict().items())
+    assert worst < 1e-3 * moved, (worst, moved)
