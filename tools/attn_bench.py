@@ -9,7 +9,7 @@ lib = L.load(); dev = torch.device("cuda:0")
 B, S, H, D = int(os.environ.get("B", 8)), int(os.environ.get("S", 1024)), 8, int(os.environ.get("D", 32))
 qkv = torch.randn(B, S, 3 * H * D, device=dev, requires_grad=True)
 go = torch.randn(B, S, H * D, device=dev)
-def timeit(fn, iters=20):
+def timeit(fn, iters=200):
     for _ in range(5): fn()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
