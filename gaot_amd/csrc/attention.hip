@@ -1873,8 +1873,6 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
             dvt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p0, dvt, 0, 0, 0);
             dkt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d0, dkt, 0, 0, 0);
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { dvacc[r] += dvt[r]; dkacc[r] += dkt[r]; }
         // ---- dQ[q][d] partial = sum_kv dS[q][kv] K[kv][d]: A = dS planes (lane -> q), B = K^T planes (lane -> d), kv = 16u + 8hi + e
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1904,6 +1902,9 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
         for (int r = 0; r < 16; ++r) Pmine[crow(r, lh) * 32 + li] = dq[r];
+        // the tile's dV / dK join the running sums here rather than right behind their MFMAs: nothing waits for the matrix pipe (-1 %)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dvacc[r] += dvt[r]; dkacc[r] += dkt[r]; }
         __syncthreads();                                    // barrier B
         // fixed-order sum of the eight waves' partials -> this key block's slice of the dQ workspace
 #pragma unroll
