@@ -31,11 +31,19 @@ class GemmDesc(C.Structure):
     ]
 
 
-# name -> (restype, argtypes): every symbol include/gaot_hip.h declares
+class WgradItem(C.Structure):
+    """gaot_wgrad_item: out[M,N] = g[K,M]^T x[K,N] (+ colsum[m] = sum_k g[k,m])"""
+    _fields_ = [("g", _f), ("ldg", C.c_int64), ("x", _f), ("ldx", C.c_int64), ("out", _f), ("ldo", C.c_int64), ("colsum", _f),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32)]
+
+
+# name -> (restype, argtypes): every symbol include/gaot_hip.h (data path) and include/gaot_hip_debug.h (tuning hooks) declare
 PROTOTYPES = {
     "gaot_abi_version": (C.c_int, []),
     "gaot_last_error": (C.c_char_p, []),
     "gaot_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _s]),
+    "gaot_gemm_tn_grouped_workspace": (C.c_int64, [C.POINTER(WgradItem), C.c_int32, C.POINTER(C.c_int32)]),
+    "gaot_gemm_tn_grouped": (C.c_int, [C.POINTER(WgradItem), C.c_int32, _f, _i, _s]),
     "gaot_debug_set_gemm_tile": (C.c_int, [C.c_int]),
     "gaot_debug_set_gemm_ablate": (C.c_int, [C.c_int]),
     "gaot_debug_last_gemm_path": (C.c_int, []),

@@ -23,6 +23,7 @@ neighbour sub-sampling, node_embedding, pndata that requires grad, host tensors,
 GAOT_AUTO_GRAPH=0.  trainer.TrainStep switches it off for its model (it captures the whole step itself).
 """
 import os
+import weakref
 from typing import Optional
 
 import torch
@@ -44,8 +45,12 @@ def eligible(model, latent, xcoord, pndata, query_coord, encoder_nbrs, decoder_n
         return False
     if encoder_nbrs is not None or decoder_nbrs is not None or query_coord is not None:
         return False
+    if not (torch.is_tensor(pndata) and torch.is_tensor(xcoord) and torch.is_tensor(latent)):
+        return False          # e.g. pndata=None (static_trainer.py:164-167 with an empty x_batch): the model's own validation answers
     if not (pndata.is_cuda and xcoord.is_cuda and latent.is_cuda) or pndata.requires_grad or xcoord.dim() != 2:
         return False
+    if not (pndata.dtype == xcoord.dtype == latent.dtype == torch.float32):
+        return False          # the static buffers are fp32: anything else takes the eager path (which raises a clear TypeError)
     if condition is not None and not (torch.is_tensor(condition) and condition.is_cuda and not condition.requires_grad):
         return False
     if torch.cuda.is_current_stream_capturing():
@@ -92,11 +97,21 @@ class _GraphedStep(torch.autograd.Function):
             entry.c.copy_(condition, non_blocking=True)
         entry.g_fwd.replay()
         ctx.entry = entry
+        # the saved activations live INSIDE the captured graph: they belong to the latest replay.  `gen` ties this node to its
+        # replay; `pending` (a weak reference: it dies with the autograd graph) lets run() send a second forward that arrives
+        # before this node's backward to the eager path instead of overwriting what the backward still needs.
+        entry.gen += 1
+        ctx.gen = entry.gen
+        entry.pending = weakref.ref(ctx)
         return entry.y.clone()
 
     @staticmethod
     def backward(ctx, gy):
         e = ctx.entry
+        ctx._done = True
+        if ctx.gen != e.gen:
+            raise RuntimeError("gaot_amd.autograph: the captured forward was replayed again before this backward ran; its saved "
+                               "activations are gone (set model.auto_graph = False for losses that need two live forwards)")
         e.gy.copy_(gy, non_blocking=True)
         # gradient accumulation (a caller that did not zero .grad): the .grad tensors may be the views of the static buffer handed
         # out last time, which the replay is about to overwrite -- keep their values, hand out copies of the new gradients
@@ -109,7 +124,7 @@ class _GraphedStep(torch.autograd.Function):
             e.flat_g.copy_(prev)
         grads = []
         for p, (o, n, live) in zip(e.params, e.slices):
-            grads.append(src[o:o + n].view_as(p) if live else None)
+            grads.append(src[o:o + n].view_as(p) if live else None)       # live: trainable AND reached by the captured backward
         return (None, None, None, *grads)
 
 
@@ -118,8 +133,23 @@ def _static_coordinates(model, latent, xcoord):
     store = model.__dict__.setdefault("_auto_graph_coords", {})
     key = (tuple(latent.shape), tuple(xcoord.shape), latent.device.index)
     if key not in store:
-        store[key] = (latent.detach().clone(), xcoord.detach().clone(), torch.zeros(1, dtype=torch.int32, device=latent.device))
+        # [static lat, static x, flag, last] -- `last` = what the buffers were last synchronised with: (x object, x version, lat
+        # object, lat version), kept HERE (the buffers and the flag are shared by every entry of these shapes)
+        store[key] = [latent.detach().clone(), xcoord.detach().clone(), torch.zeros(1, dtype=torch.int32, device=latent.device), None]
     return store[key]
+
+
+def _plan_epochs(model):
+    """epochs of every GeometryPlan behind the model's module-owned neighbour lists: a plan whose coordinate-derived arrays were
+    refreshed in place by an EAGER call (evaluation with other coordinates of the same shapes) has moved on"""
+    from .plan import _PLAN_KEY
+    ep = []
+    for side in (model.encoder, model.decoder):
+        for nbrs in side.neighbor_cache.values():
+            for nb in nbrs:
+                plan = nb.get(_PLAN_KEY) if isinstance(nb, dict) else None
+                ep.append(-1 if plan is None else plan.epoch)
+    return tuple(ep)
 
 
 def _sync_coordinates(e, latent, xcoord):
@@ -130,7 +160,7 @@ def _sync_coordinates(e, latent, xcoord):
     xc, lc = xcoord.contiguous(), latent.contiguous()
     L.check(lib.gaot_guard_sync2(ops._p(xc), ops._p(e.x), e.x.numel() * e.x.element_size(), ops._p(lc), ops._p(e.lat),
                                  e.lat.numel() * e.lat.element_size(), ops._p(e.flag), ops._stream()), "gaot_guard_sync2")
-    e.last_x, e.last_lat = xcoord, latent
+    e.store[3] = (xcoord, xcoord._version, latent, latent._version)
 
 
 def _capture(model, latent, xcoord, pndata, condition) -> _Entry:
@@ -140,7 +170,9 @@ def _capture(model, latent, xcoord, pndata, condition) -> _Entry:
     dev = pndata.device
     params = list(_param_list(model))
     e.params = params
-    e.lat, e.x, e.flag = _static_coordinates(model, latent, xcoord)
+    e.store = _static_coordinates(model, latent, xcoord)
+    e.lat, e.x, e.flag = e.store[0], e.store[1], e.store[2]
+    e.gen, e.pending = 0, None
     _sync_coordinates(e, latent, xcoord)      # buffers shared with an earlier capture may hold other bytes: raise the flag first
     e.p = pndata.detach().clone()
     e.c = None if condition is None else condition.detach().clone()
@@ -172,7 +204,8 @@ def _capture(model, latent, xcoord, pndata, condition) -> _Entry:
         ops.register_grad_slots(train, views)
         ops.release_grad_slots()
         y = fwd()
-        gs = torch.autograd.grad(y, train, gy, allow_unused=True)
+        with ops.deferred_wgrad():
+            gs = torch.autograd.grad(y, train, gy, allow_unused=True)
         return y, gs
 
     def settle(gs):
@@ -208,8 +241,16 @@ def _capture(model, latent, xcoord, pndata, condition) -> _Entry:
         P.FORCE_GUARD[0] = None
         e.g_bwd = torch.cuda.CUDAGraph()
         with torch.cuda.graph(e.g_bwd, pool=pool, stream=side, capture_error_mode="thread_local"):
-            gs = torch.autograd.grad(e.y, train, e.gy, allow_unused=True)
+            with ops.deferred_wgrad():          # every weight gradient of the pass from one grouped launch
+                gs = torch.autograd.grad(e.y, train, e.gy, allow_unused=True)
             settle(gs)
+        # parameters the backward never reaches (an unused projection, scale_weighting without multiscale): the eager loop leaves
+        # their .grad at None and torch.optim.AdamW skips them -- hand back None as well, not a zero tensor (static per graph)
+        reached = iter([g is not None for g in gs])
+        for sl in e.slices:
+            if sl[2]:
+                sl[2] = next(reached)
+        e.epochs = _plan_epochs(model)
     finally:
         P.FORCE_GUARD[0] = None
         ops._GRAD_SLOTS.clear()
@@ -236,6 +277,16 @@ def run(model, latent, xcoord, pndata, condition) -> Optional[torch.Tensor]:
         cache[key] = e
     # geometry: new coordinate tensors (a trainer that uploads them every step): compare with the static buffers (flag |= differ),
     # overwrite the buffers; the captured forward starts with the flag-guarded refresh of the plans' arrays and ends by clearing it
-    if xcoord is not e.__dict__.get("last_x") or latent is not e.__dict__.get("last_lat"):
-        _sync_coordinates(e, latent, xcoord)
+    pend = e.pending
+    if pend is not None and pend() is not None and pend().gen == e.gen and not getattr(pend(), "_done", False):
+        return None        # a forward of this entry is still waiting for its backward: this call runs eagerly (correct, slower)
+    last = e.store[3]
+    if (last is None or xcoord is not last[0] or xcoord._version != last[1] or latent is not last[2] or latent._version != last[3]):
+        _sync_coordinates(e, latent, xcoord)      # new objects, or the same objects edited in place: compare bytes on the device
+    ep = _plan_epochs(model)
+    if ep != e.epochs:
+        # an eager call refreshed a plan's arrays in place for OTHER coordinates since the last replay: the captured forward must
+        # recompute them from the static buffers whatever the byte comparison says
+        e.flag.fill_(1)
+        e.epochs = ep
     return _GraphedStep.apply(e, pndata, condition, *e.params)

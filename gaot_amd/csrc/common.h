@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include "../../include/gaot_hip.h"
+#include "../../include/gaot_hip_debug.h"
 
 namespace gaot {
 

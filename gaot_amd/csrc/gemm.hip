@@ -491,3 +491,50 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
     }
     return GAOT_OK;
 }
+
+
+// ---- grouped weight-gradient products (kernel: gemm_split.hip)
+static int check_wgrad_items(const gaot_wgrad_item* items, int n) {
+    GAOT_REQUIRE(items != nullptr && n > 0, "gemm_tn_grouped: no items");
+    for (int i = 0; i < n; ++i) {
+        const gaot_wgrad_item& it = items[i];
+        GAOT_REQUIRE(it.g && it.x && it.out, "gemm_tn_grouped: item %d has a null operand", i);
+        GAOT_REQUIRE(it.M >= 4 && it.N >= 4 && it.K >= 32 && it.M % 4 == 0 && it.N % 4 == 0 && it.K % 32 == 0,
+                     "gemm_tn_grouped: item %d needs M, N %% 4 == 0 and K %% 32 == 0 (got %d, %d, %d)", i, it.M, it.N, it.K);
+        GAOT_REQUIRE(it.ldg % 4 == 0 && it.ldx % 4 == 0 && it.ldo % 4 == 0 && it.ldg >= it.M && it.ldx >= it.N && it.ldo >= it.N &&
+                     aligned16(it.g) && aligned16(it.x) && aligned16(it.out),
+                     "gemm_tn_grouped: item %d needs 16-byte aligned operands and leading dimensions that are multiples of 4", i);
+    }
+    return GAOT_OK;
+}
+
+extern "C" int64_t gaot_gemm_tn_grouped_workspace(const gaot_wgrad_item* items, int32_t n, int32_t* n_counters) {
+    if (check_wgrad_items(items, n) != GAOT_OK) return -1;
+    long ws = 0; int cnt = 0;
+    for (int i0 = 0; i0 < n; i0 += TN_GROUP_MAX) {          // launches of at most TN_GROUP_MAX products share the buffers: sizes add up
+        int c = 0;
+        ws += plan_tn_grouped(items + i0, n - i0 < TN_GROUP_MAX ? n - i0 : TN_GROUP_MAX, nullptr, &c, nullptr);
+        cnt += c;
+    }
+    if (n_counters) *n_counters = cnt;
+    return ws;
+}
+
+extern "C" int gaot_gemm_tn_grouped(const gaot_wgrad_item* items, int32_t n, float* workspace, int32_t* counters, gaot_stream_t stream) {
+    if (int rc = check_wgrad_items(items, n)) return rc;
+    int cnt = 0;
+    const long need = gaot_gemm_tn_grouped_workspace(items, n, &cnt);
+    GAOT_REQUIRE((need == 0 || (workspace != nullptr && aligned16(workspace))) && (cnt == 0 || counters != nullptr),
+                 "gemm_tn_grouped: needs a 16-byte aligned workspace of %ld floats and %d zeroed counters", need, cnt);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    long ws_off = 0; int cnt_off = 0;
+    for (int i0 = 0; i0 < n; i0 += TN_GROUP_MAX) {
+        const int m = n - i0 < TN_GROUP_MAX ? n - i0 : TN_GROUP_MAX;
+        int c = 0;
+        const long w = plan_tn_grouped(items + i0, m, nullptr, &c, nullptr);
+        launch_tn_grouped(items + i0, m, workspace + ws_off, counters + cnt_off, st);
+        GAOT_CHECK_LAUNCH("gaot_gemm_tn_grouped");
+        ws_off += w; cnt_off += c;
+    }
+    return GAOT_OK;
+}

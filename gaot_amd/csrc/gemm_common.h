@@ -95,8 +95,9 @@ __device__ __forceinline__ void epilogue_store_row(const GemmArgs& p, const RowC
 // The caller must have synchronised the workgroup (smem is reused) and smem must hold NW * 32 * (WN + 4) floats.
 template <int TM, int TN, int WM, int WN>
 __device__ __forceinline__ void epilogue_vec(const GemmArgs& p, float* smem, const f32x16 (&acc)[TM][TN], int m0, int n0,
-                                         int wm, int wn, int wave, int lane) {
+                                         int wm, int wn, int wave, int lane, int zs = -1) {
     const int li = lane & 31, lh = lane >> 5;
+    const int zslab = zs >= 0 ? zs : (int)blockIdx.z;          // K slab of a split-K product (grouped launches pass their own)
     // ---- vector epilogue: each wave transposes its 32-row fragment band through a private LDS slab (C-layout puts a
     // COLUMN in a lane; stores want 4 consecutive columns per lane) and then does bias / row bias / row scale /
     // activation / residual / store on 16-byte vectors: 4x fewer store instructions, 128-256 B contiguous per row.
@@ -126,7 +127,7 @@ __device__ __forceinline__ void epilogue_vec(const GemmArgs& p, float* smem, con
             if (nok && m < p.M) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(Cw + row * LDC_S + lc);
                 if (p.split_k > 1) {
-                    *reinterpret_cast<f32x4*>(p.ws + ((long)blockIdx.z * p.M + m) * p.N + n) = v;
+                    *reinterpret_cast<f32x4*>(p.ws + ((long)zslab * p.M + m) * p.N + n) = v;
                 } else {
                     v += bv;
                     if (p.rowbias) v += *reinterpret_cast<const f32x4*>(p.rowbias + (long)(m % p.rb_period) * p.ld_rb + n);
@@ -218,5 +219,11 @@ void launch_glds(GemmArgs& a, bool a_kmajor, bool b_kmajor, int tile, hipStream_
 void launch_split(GemmArgs& a, bool a_kmajor, bool b_kmajor, hipStream_t st, int bm = 128, int pieces = 3);
 // the same products with LDS-direct fp32 operand tiles and the split done in registers after the fragment reads (gemm_gsplit.hip)
 void launch_gsplit(GemmArgs& a, bool a_kmajor, bool b_kmajor, hipStream_t st, int bm = 128, int pieces = 3);
+
+// grouped weight-gradient launch (gemm_split.hip): prefix table / workspace need of n items; the launch itself
+struct TnGroupArgs;
+long plan_tn_grouped(const gaot_wgrad_item* items, int n, TnGroupArgs* args, int* n_counters, int* n_wg);
+void launch_tn_grouped(const gaot_wgrad_item* items, int n, float* ws, int* counters, hipStream_t st);
+constexpr int TN_GROUP_MAX = 24;          // products per launch (the table travels in the kernel arguments)
 
 }  // namespace gaot

@@ -48,17 +48,25 @@ __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
 // NP = 3: the fp32-level product (three pieces per operand, six piece products).  NP = 1: a plain bf16 GEMM on the same skeleton
 // (operands ROUNDED to nearest-even bf16, one piece product, fp32 accumulation) -- the separately reported `--dtype bf16` bench
 // variant (BASELINE configs[1] names bf16); never used by the fp32 parity path.
-template <bool AK, bool BKM, int BM = 128, int ABL = 0, int NP = 3>
-__global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 1 : 2) void gemm_split_kernel(const GemmArgs p) {
-    constexpr int BN = S_BN, NW = BM == 256 ? 8 : 4, NT = 64 * NW, WAVES_N = 2, WM = BM / (NW / 2), WN = 64, TM = WM / 32, TN = 2;
+template <int BM>
+struct SplitGeom {
+    static constexpr int BN = S_BN, NW = BM == 256 ? 8 : 4, NT = 64 * NW, WAVES_N = 2, WM = BM / (NW / 2), WN = 64, TM = WM / 32, TN = 2;
+    static constexpr int PA = (BM > 128 ? BM : 128) * 48, PB = 128 * 48;      // bytes per plane
+    static constexpr int STAGE = 3 * PA + 3 * PB;
+    static constexpr int EPI_BYTES = NW * 32 * (WN + 4) * 4;
+    static constexpr int SMEM_BYTES = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
+};
+
+// ONE output tile (`logical` in the XCD-aware order of the caller, K slab `zs` of p.split_k) of the product described by p.
+// Shared by the per-product kernel below and by the grouped weight-gradient kernel (one launch over many products).
+template <bool AK, bool BKM, int BM, int ABL, int NP>
+__device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* smem_raw, const int logical, const int zs) {
+    using G = SplitGeom<BM>;
+    constexpr int BN = G::BN, NW = G::NW, NT = G::NT, WAVES_N = G::WAVES_N, WM = G::WM, WN = G::WN, TM = G::TM, TN = G::TN;
     constexpr int ABYTES = BM * 4;       // row stride of a row-contiguous A plane ([k pair][BM rows] of packed dwords; BM = 64 only)
-    constexpr int PA = (BM > 128 ? BM : 128) * 48, PB = 128 * 48;      // bytes per plane
-    constexpr int STAGE = 3 * PA + 3 * PB;
+    constexpr int PA = G::PA, PB = G::PB, STAGE = G::STAGE;
     constexpr bool A_FULL = BM * 2 == NT;        // two float4 per thread (else one / half the threads)
     constexpr bool B_FULL = 128 * 2 == NT;
-    constexpr int EPI_BYTES = NW * 32 * (WN + 4) * 4;
-    constexpr int SMEM_BYTES = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -66,26 +74,13 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 1 : 2) void gemm
     const int li = lane & 31, lh = lane >> 5;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-    if ((ABL & 128) && (blockIdx.x & 8)) {      // tuning: de-phase half of the workgroups by ~p.ablate x 3.4 us at start
-        for (int i = 0; i < p.ablate; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-    const int tiles = p.tiles_m * p.tiles_n;
-    // PERSISTENT over tiles: the grid may be smaller than the tile count (launch_split_bm caps it at the number of workgroups
-    // the chip holds at once); a workgroup then walks tiles vb = blockIdx.x, blockIdx.x + gridDim.x, ...  Workgroups that started
-    // together drift apart after their first tile, so the load phase of one overlaps the store phase of another.
-    for (int vb = blockIdx.x; vb < tiles; vb += gridDim.x) {
-    int logical;
-    {   // XCD-aware tile order (as gemm.hip); gridDim.x is a multiple of 8 whenever it is smaller than `tiles`
-        const int q = tiles >> 3, r = tiles & 7, x = vb & 7, slot = vb >> 3;
-        logical = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + slot;
-    }
     const int m0 = (logical / p.tiles_n) * BM;
     const int n0 = (logical % p.tiles_n) * BN;
 
     const int nkt = p.K / SBK;
     int kt_begin = 0, kt_end = nkt;
     if (p.split_k > 1) {                     // ktiles_per_split counts 32-wide tiles
-        kt_begin = blockIdx.z * p.ktiles_per_split * 2;
+        kt_begin = zs * p.ktiles_per_split * 2;
         kt_end = min(nkt, kt_begin + p.ktiles_per_split * 2);
     }
 
@@ -285,16 +280,144 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 1 : 2) void gemm
             float s = 0.f;
 #pragma unroll
             for (int g = 0; g < 8; ++g) s += cs[g * BM + tid];
-            if (p.split_k > 1) p.ws[(long)p.split_k * p.M * p.N + (long)blockIdx.z * p.M + m0 + tid] = s;
+            if (p.split_k > 1) p.ws[(long)p.split_k * p.M * p.N + (long)zs * p.M + m0 + tid] = s;
             else p.colsum[m0 + tid] = s;
         }
         __syncthreads();
     }
-    if (ABL & 4) { if (acc[0][0][0] + acc[1][1][3] + acc[0][1][5] + acc[1][0][7] == 123.456f) p.C[tid] = 1.f; __syncthreads(); continue; }
+    if (ABL & 4) { if (acc[0][0][0] + acc[1][1][3] + acc[0][1][5] + acc[1][0][7] == 123.456f) p.C[tid] = 1.f; __syncthreads(); return; }
     if (BKM && p.act == GAOT_ACT_SWIGLU) epilogue_swiglu<TM, TN, WM, WN>(p, reinterpret_cast<float*>(smem_raw), acc, m0, n0, wm, wn, wave, lane);
-    else epilogue_vec<TM, TN, WM, WN>(p, reinterpret_cast<float*>(smem_raw), acc, m0, n0, wm, wn, wave, lane);
+    else epilogue_vec<TM, TN, WM, WN>(p, reinterpret_cast<float*>(smem_raw), acc, m0, n0, wm, wn, wave, lane, zs);
     __syncthreads();          // the epilogue's LDS slabs alias the stages the next tile is about to fill
+}
+
+template <bool AK, bool BKM, int BM = 128, int ABL = 0, int NP = 3>
+__global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 1 : 2) void gemm_split_kernel(const GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SplitGeom<BM>::SMEM_BYTES];
+    if ((ABL & 128) && (blockIdx.x & 8)) {      // tuning: de-phase half of the workgroups by ~p.ablate x 3.4 us at start
+        for (int i = 0; i < p.ablate; ++i) __builtin_amdgcn_s_sleep(127);
     }
+    const int tiles = p.tiles_m * p.tiles_n;
+    // PERSISTENT over tiles: the grid may be smaller than the tile count (launch_split_bm caps it at the number of workgroups
+    // the chip holds at once); a workgroup then walks tiles vb = blockIdx.x, blockIdx.x + gridDim.x, ...  Workgroups that started
+    // together drift apart after their first tile, so the load phase of one overlaps the store phase of another.
+    for (int vb = blockIdx.x; vb < tiles; vb += gridDim.x) {
+        // XCD-aware tile order (as gemm.hip); gridDim.x is a multiple of 8 whenever it is smaller than `tiles`
+        const int q = tiles >> 3, r = tiles & 7, x = vb & 7, slot = vb >> 3;
+        const int logical = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + slot;
+        split_tile<AK, BKM, BM, ABL, NP>(p, smem_raw, logical, blockIdx.z);
+    }
+}
+
+// ---- grouped weight-gradient products: ONE launch over many C_i[M_i,N_i] = A_i[K_i,M_i]^T B_i[K_i,N_i] (both operands row-contiguous,
+// the long reduction runs over the rows: dW = dY^T X of every Linear of a backward pass).  A workgroup finds its product in a
+// prefix table carried in the kernel arguments, computes one 128x128 tile of one K slab with split_tile<TN>, and -- when the
+// product is cut into K slabs (at most 1 024 values of k per workgroup: the bf16 MFMA accumulation cap, gemm.hip) -- the LAST
+// workgroup to finish a tile sums that tile's slabs in slab order and writes C (and the fused column sums): deterministic, no
+// atomics on data, no separate reduce launch.  Cross-workgroup visibility follows cdna_hip_programming.md guideline 16: plain
+// slab stores -> every wave drains vmcnt -> barrier -> lane 0: agent-scope release, asm vmcnt(0), relaxed agent-scope ticket ->
+// the last arriver: agent-scope acquire (invalidates this CU's L1) -> barrier -> plain loads.  The ticket counters return to
+// zero (the last arriver resets its counter), so the same zero-initialised buffer serves every launch.
+constexpr int TNG_MAX = TN_GROUP_MAX;
+struct TnProb {
+    const float* A; const float* B; float* C; float* colsum;
+    int M, N, K; int lda, ldb, ldc;
+    int tiles_m, tiles_n, split, kt_per_split;     // kt_per_split in 32-wide k-tiles (GemmArgs convention)
+    int wg_end;                                    // first workgroup index past this product
+    int cnt_off;                                   // first ticket counter of this product
+    long ws_off;                                   // float offset of this product's slabs in the workspace
+};
+struct TnGroupArgs { int n; float* ws; int* counters; TnProb p[TNG_MAX]; };
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const TnGroupArgs g) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SplitGeom<128>::SMEM_BYTES];
+    const int b = blockIdx.x;
+    int i = 0;
+    while (i + 1 < g.n && b >= g.p[i].wg_end) ++i;                  // wave-uniform scan of <= 24 entries
+    const int first = i > 0 ? g.p[i - 1].wg_end : 0;
+    const int split = g.p[i].split;
+    const int local = b - first;
+    const int tile = local / split, z = local - tile * split;       // a tile's slabs are adjacent workgroups
+    GemmArgs a;
+    a.M = g.p[i].M; a.N = g.p[i].N; a.K = g.p[i].K;
+    a.A = g.p[i].A; a.lda = g.p[i].lda; a.A2 = nullptr; a.lda2 = 0; a.k_split = 0;
+    a.B = g.p[i].B; a.ldb = g.p[i].ldb; a.C = g.p[i].C; a.ldc = g.p[i].ldc;
+    a.bias = nullptr; a.rowbias = nullptr; a.rb_period = 0; a.ld_rb = 0; a.rowscale = nullptr; a.act = GAOT_ACT_NONE;
+    a.aux_in = nullptr; a.aux_out = nullptr; a.ld_aux = 0; a.residual = nullptr; a.ldr = 0;
+    a.split_k = split; a.ktiles_per_split = g.p[i].kt_per_split; a.ws = g.ws + g.p[i].ws_off;
+    a.colsum = g.p[i].colsum; a.tiles_m = g.p[i].tiles_m; a.tiles_n = g.p[i].tiles_n; a.vec_epi = 1; a.ablate = 0;
+    split_tile<false, false, 128, 0, 3>(a, smem_raw, tile, z);
+    if (split <= 1) return;
+
+    const int tid = threadIdx.x;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this wave's slab stores have left
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(smem_raw);
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the write-back must not be overtaken by the ticket (ROCm 7.2 drops the fence's own wait)
+        int* cnt = g.counters + g.p[i].cnt_off + tile;
+        const int t = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = t == split - 1;
+        if (last) {
+            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    const int m0 = (tile / a.tiles_n) * 128, n0 = (tile % a.tiles_n) * 128;
+    const long slab = (long)a.M * a.N;
+#pragma unroll 4
+    for (int idx = tid; idx < 128 * 32; idx += 256) {
+        const int m = m0 + (idx >> 5), n = n0 + (idx & 31) * 4;
+        if (m < a.M && n < a.N) {
+            const float* src = a.ws + (long)m * a.N + n;
+            f32x4 s = *reinterpret_cast<const f32x4*>(src);
+            for (int zz = 1; zz < split; ++zz) s += *reinterpret_cast<const f32x4*>(src + zz * slab);
+            *reinterpret_cast<f32x4*>(a.C + (long)m * a.ldc + n) = s;
+        }
+    }
+    if (a.colsum != nullptr && (tile % a.tiles_n) == 0 && tid < 128 && m0 + tid < a.M) {
+        const float* src = a.ws + (long)split * slab + m0 + tid;
+        float s = src[0];
+        for (int zz = 1; zz < split; ++zz) s += src[(long)zz * a.M];
+        a.colsum[m0 + tid] = s;
+    }
+}
+
+// host side of the grouped launch: items -> prefix table; returns the workspace floats / counters it needs when `args` is null
+long plan_tn_grouped(const gaot_wgrad_item* items, int n, TnGroupArgs* args, int* n_counters, int* n_wg) {
+    long ws = 0; int cnt = 0, wg = 0;
+    for (int i = 0; i < n; ++i) {
+        const gaot_wgrad_item& it = items[i];
+        const int kt32 = it.K / 32;
+        int split = (it.K + 1023) / 1024;                            // <= 1 024 values of k per workgroup
+        int per = (kt32 + split - 1) / split;
+        split = (kt32 + per - 1) / per;
+        const int tm = cdiv(it.M, 128), tn = cdiv(it.N, 128);
+        if (args) {
+            TnProb& q = args->p[i];
+            q.A = it.g; q.B = it.x; q.C = it.out; q.colsum = it.colsum;
+            q.M = it.M; q.N = it.N; q.K = it.K; q.lda = (int)it.ldg; q.ldb = (int)it.ldx; q.ldc = (int)it.ldo;
+            q.tiles_m = tm; q.tiles_n = tn; q.split = split; q.kt_per_split = per;
+            q.wg_end = wg + tm * tn * split; q.cnt_off = cnt; q.ws_off = ws;
+        }
+        wg += tm * tn * split;
+        if (split > 1) { ws += (long)split * ((long)it.M * it.N + it.M); ws = (ws + 3) & ~3L; cnt += tm * tn; }
+    }
+    if (n_counters) *n_counters = cnt;
+    if (n_wg) *n_wg = wg;
+    return ws;
+}
+
+void launch_tn_grouped(const gaot_wgrad_item* items, int n, float* ws, int* counters, hipStream_t st) {
+    TnGroupArgs args;
+    args.n = n; args.ws = ws; args.counters = counters;
+    int wg = 0;
+    plan_tn_grouped(items, n, &args, nullptr, &wg);
+    hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(wg), dim3(256), 0, st, args);
 }
 
 // 0: one workgroup per tile (round 1).  n > 0: grids larger than n workgroups become persistent with n (MI355X holds 512 of the

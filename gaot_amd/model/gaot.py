@@ -35,6 +35,26 @@ class GAOT(nn.Module):
         self.processor = self.init_processor(self.node_latent_size, tf_cfg)
         self.decoder = self.init_decoder(output_size, self.node_latent_size, magno_cfg)
 
+    # ---- dtype contract.  The reference trainer casts the model to its configured dtype (base_trainer.py:63-68,173-179:
+    # `model.type(dtype)`, dtype float or double).  The HIP kernels compute in fp32 -- the reference's default, and the arithmetic
+    # the parity bar is stated in; there is no fp64 (or half) kernel set, and silently computing a "double" model in fp32 would
+    # be a wrong answer, not a drop-in.  So the request fails HERE, at the module, with the parameters left untouched in fp32.
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn, recurse)
+        bad = next((p.dtype for p in self.parameters() if p.is_floating_point() and p.dtype != torch.float32), None)
+        if bad is not None:
+            super()._apply(lambda t: t.float() if t.is_floating_point() else t, recurse)
+            raise TypeError(f"gaot_amd.GAOT computes in float32 only (requested {bad}): there are no {bad} kernels on the HIP path. "
+                            "Keep the trainer's dtype at float32 (the reference default); the parameters were left in float32.")
+        return out
+
+    @staticmethod
+    def _require_f32(**tensors):
+        for name, t in tensors.items():
+            if torch.is_tensor(t) and t.is_floating_point() and t.dtype != torch.float32:
+                raise TypeError(f"gaot_amd.GAOT.forward: `{name}` is {t.dtype}; the HIP path computes in float32 only "
+                                "(cast the inputs, or keep the trainer's dtype at float32)")
+
     # ---- construction (same order as the reference so a seeded build draws identical weights)
     def init_encoder(self, input_size, latent_size, config):
         return MAGNOEncoder(in_channels=input_size, out_channels=latent_size, config=config)
@@ -104,6 +124,8 @@ class GAOT(nn.Module):
     def forward(self, latent_tokens_coord: torch.Tensor, xcoord: torch.Tensor, pndata: torch.Tensor,
                 query_coord: Optional[torch.Tensor] = None, encoder_nbrs: Optional[list] = None,
                 decoder_nbrs: Optional[list] = None, condition: Optional[float] = None) -> torch.Tensor:
+        self._require_f32(latent_tokens_coord=latent_tokens_coord, xcoord=xcoord, pndata=pndata, query_coord=query_coord,
+                          condition=condition)
         # an unchanged eager training loop (the reference trainer's) on fixed shapes: forward and backward as hipGraph replays
         if autograph.eligible(self, latent_tokens_coord, xcoord, pndata, query_coord, encoder_nbrs, decoder_nbrs, condition):
             out = autograph.run(self, latent_tokens_coord, xcoord, pndata, condition)
@@ -201,11 +223,26 @@ class GAOT(nn.Module):
         step_out = torch.empty(B, N, U, device=dev, dtype=torch.float32)
         pn = torch.empty(B, N, U + S + (1 if cond_norm else 2), device=dev, dtype=torch.float32)
         mode = {"output": 0, "residual": 1, "time_der": 2}[stepper_mode]
-        a = aux.get("res" if mode == 1 else "der") if mode else None
+        if self.output_size != U:
+            raise ValueError(f"autoregressive_predict: the model predicts {self.output_size} channels but stats['u'] describes {U}")
+
+        def per_channel(t, what):
+            """[U] fp32 statistics for the fused stepper kernel (it indexes [c], c < U): scalars / [1] broadcast like the eager
+            expression `pred * std + mean` would, anything else is a shape error here rather than an out-of-bounds read there"""
+            t = t.to(device=dev, dtype=torch.float32).reshape(-1)
+            if t.numel() == 1:
+                t = t.expand(U)
+            if t.numel() != U:
+                raise ValueError(f"autoregressive_predict: stats {what} has {t.numel()} entries, expected {U} (or 1)")
+            return t.contiguous()
+
         a_mean = a_std = None
-        if a is not None:
-            a_mean, a_std = a[0].contiguous().float(), a[1].contiguous().float()
-        um, us = u_mean.contiguous().float(), u_std.contiguous().float()
+        if mode:
+            k = "res" if mode == 1 else "der"
+            if k not in aux:
+                raise KeyError(k)          # the reference indexes stats['res'] / stats['der'] directly (gaot.py:448-470)
+            a_mean, a_std = per_channel(aux[k][0], f"['{k}']['mean']"), per_channel(aux[k][1], f"['{k}']['std']")
+        um, us = per_channel(u_mean, "['u']['mean']"), per_channel(u_std, "['u']['std']")
         with torch.no_grad():
             for i in range(1, len(time_indices)):
                 t0 = t_values[time_indices[i - 1]]
@@ -216,6 +253,8 @@ class GAOT(nn.Module):
                                                ops._stream()), "gaot_rollout_input")
                 cond = torch.full((B, 1), t0n, dtype=torch.float32, device=dev) if cond_norm else None
                 pred = runner(pn, cond, clone=False)
+                if pred.shape != (B, N, U):
+                    raise ValueError(f"autoregressive_predict: forward returned {tuple(pred.shape)}, expected {(B, N, U)}")
                 L.check(lib.gaot_rollout_update(ops._p(pred.contiguous()), ops._p(state), U, ops._p(um), ops._p(us), ops._p(a_mean), ops._p(a_std),
                                                 float(dt), mode, B * N, ops._p(step_out), ops._stream()), "gaot_rollout_update")
                 out[:, i - 1].copy_(step_out)

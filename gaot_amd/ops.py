@@ -203,10 +203,90 @@ def matmul_tn(g: torch.Tensor, x2: torch.Tensor, out: Optional[torch.Tensor] = N
     M, N = g.shape
     K = x2.shape[1]
     assert x2.shape[0] == M
+    if out is not None and _WGRAD_DEPTH[0] > 0 and _wgrad_groupable(g, lda, x2, ldb, out, colsum_out, N, K, M):
+        # a caller-provided destination (the parameter's slice of the flat gradient buffer) inside a deferral scope: the product
+        # joins the grouped launch at the end of the backward pass (flush_wgrad); operands stay alive in the queue until then
+        _WGRAD_QUEUE.append((g, lda, x2, ldb, out, out.stride(0), colsum_out, N, K, M))
+        return out
     if out is None:
         out = torch.empty(N, K, device=g.device, dtype=torch.float32)
     ldc = out.stride(0) if N > 1 else K
     return gemm(N, K, M, g, lda, 0, x2, ldb, 0, out, ldc, split_k=_split_for_reduction(N, K, M), colsum=colsum_out)
+
+
+# --------------------------------------------------------------------------------------------
+# Deferred, grouped weight gradients.  Autograd reaches the Linear layers of a backward pass one by one; each weight gradient is
+# a long reduction over all tokens into a small matrix (2048 x 256 ... 256 x 256 at the example model, K = 8 192), which on its
+# own fills the chip only through 16-32 split-K slabs and a separate reduce launch.  Inside a `deferred_wgrad()` scope
+# (trainer.TrainStep, autograph: callers that own the gradient buffers, so nobody reads a gradient before the pass has ended)
+# matmul_tn only queues the product; flush_wgrad() runs ALL queued products as one launch (gaot_gemm_tn_grouped).
+# --------------------------------------------------------------------------------------------
+_WGRAD_DEPTH = [0]
+_WGRAD_QUEUE: list = []
+_WGRAD_COUNTERS: dict = {}
+_WGRAD_GROUPED = os.environ.get("GAOT_WGRAD_GROUPED", "1") != "0"        # A/B switch
+
+
+def _wgrad_groupable(g, lda, x2, ldb, out, colsum_out, Mo, No, K) -> bool:
+    if not _WGRAD_GROUPED or _GEMM_MODE < 4:
+        return False
+    if Mo % 4 or No % 4 or K % 32 or K < 1024 or min(Mo, No) < 32 or lda % 4 or ldb % 4 or out.dim() != 2 or out.stride(1) != 1 or out.stride(0) % 4:
+        return False
+    if (g.data_ptr() | x2.data_ptr() | out.data_ptr()) & 15:
+        return False
+    return g.dtype == x2.dtype == out.dtype == torch.float32 and g.is_cuda
+
+
+class deferred_wgrad:
+    """`with ops.deferred_wgrad(): loss.backward()`: weight gradients with a registered destination are computed by ONE grouped
+    launch when the outermost scope ends.  The gradient buffers must not be read inside the scope."""
+
+    def __enter__(self):
+        _WGRAD_DEPTH[0] += 1
+        return self
+
+    def __exit__(self, et, ev, tb):
+        _WGRAD_DEPTH[0] -= 1
+        if _WGRAD_DEPTH[0] == 0:
+            if et is None:
+                flush_wgrad()
+            else:
+                _WGRAD_QUEUE.clear()
+        return False
+
+
+def wgrad_launch(items) -> None:
+    """items: (g [K,M], ldg, x [K,N], ldx, out [M,N], ldo, colsum or None, M, N, K).  One gaot_gemm_tn_grouped call."""
+    lib = L.load()
+    n = len(items)
+    arr = (L.WgradItem * n)()
+    for i, (g, ldg, x2, ldx, out, ldo, cs, Mo, No, K) in enumerate(items):
+        arr[i] = L.WgradItem(g.data_ptr(), ldg, x2.data_ptr(), ldx, out.data_ptr(), ldo, None if cs is None else cs.data_ptr(), Mo, No, K)
+    cnt = C.c_int32(0)
+    need = int(lib.gaot_gemm_tn_grouped_workspace(arr, n, C.byref(cnt)))
+    if need < 0:
+        L.check(-1, "gaot_gemm_tn_grouped_workspace")
+    dev = items[0][0].device
+    ws = torch.empty(max(need, 4), device=dev, dtype=torch.float32)
+    # ticket counters: one zero-initialised buffer per device (every launch leaves it zero again).  Launches are ordered on the
+    # calling stream; grouped launches on two streams of one device at the same time would need separate buffers (the C ABI
+    # takes the buffer from the caller).  Never created inside a graph capture: its zero fill would be captured, not executed.
+    key = dev.index
+    ctr = _WGRAD_COUNTERS.get(key)
+    if ctr is None or ctr.numel() < cnt.value:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("grouped weight gradients: the ticket counters must exist before graph capture (run one eager step first)")
+        ctr = torch.zeros(max(8192, 2 * cnt.value), device=dev, dtype=torch.int32)
+        _WGRAD_COUNTERS[key] = ctr
+    L.check(lib.gaot_gemm_tn_grouped(arr, n, _p(ws), _p(ctr), _stream()), "gaot_gemm_tn_grouped")
+
+
+def flush_wgrad() -> None:
+    if not _WGRAD_QUEUE:
+        return
+    items = list(_WGRAD_QUEUE)
+    _WGRAD_QUEUE.clear()
+    wgrad_launch(items)
 
 
 def colsum(x2: torch.Tensor) -> torch.Tensor:

@@ -327,9 +327,19 @@ class TrainStep:
     def _forward_backward(self):
         """unstaged: forward, loss, the whole backward, gradients packed"""
         loss = self._forward_loss()
-        loss.backward()
+        self._backward(loss)
         self.bucket.pack()
         return loss.detach()
+
+    @staticmethod
+    def _backward(t, grad=None):
+        """backward pass with the weight-gradient products deferred to ONE grouped launch at its end (ops.deferred_wgrad)"""
+        if t.is_cuda:
+            from . import ops
+            with ops.deferred_wgrad():
+                t.backward(grad)
+        else:
+            t.backward(grad)
 
     def _phase0(self):
         """staged: forward with cut points + the backward of phase 0 (everything after the last cut)"""
@@ -342,7 +352,7 @@ class TrainStep:
             ops.set_cut_hook(None)
         if len(self._cuts.pairs) != self.bucket.n_phases - 1:
             raise RuntimeError(f"model marked {len(self._cuts.pairs)} cut points but lists {self.bucket.n_phases} backward phases")
-        loss.backward()
+        self._backward(loss)
         self._check_phase(0)
         self.bucket.pack(0)
         return loss.detach()
@@ -351,7 +361,7 @@ class TrainStep:
         t, leaf = self._cuts.pairs[-k]
         if leaf.grad is None:
             raise RuntimeError(f"cut point {len(self._cuts.pairs) - k} received no gradient")
-        t.backward(leaf.grad)
+        self._backward(t, leaf.grad)
         self._check_phase(k)
         self.bucket.pack(k)
         if k == self.bucket.n_phases - 1:

@@ -75,25 +75,23 @@ typedef struct gaot_gemm_desc {
 } gaot_gemm_desc;
 
 int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream);
-/* tuning hook (not part of the data path): force the GEMM tile; 0 = heuristic. Returns the previous value. */
-int gaot_debug_set_gemm_tile(int cfg);
-/* tuning hook: ablate parts of the GEMM kernel (results become WRONG): 1 no in-loop loads, 2 no LDS staging, 4 no stores */
-int gaot_debug_set_gemm_ablate(int bits);
-/* which kernel family served the calling thread's last gaot_gemm_f32: 1 = fp32 MFMA tiles, 2 = skinny VALU path,
- * 3 = split-bf16 MFMA tiles (fp32 operands split exactly into three bf16 pieces, six bf16 MFMAs per product, fp32-level error) */
-int gaot_debug_last_gemm_path(void);
-/* tuning hook: 0 = register-staged fp32 tiles only, 1 = + LDS-direct fp32 tiles (2-stage ring), 3 = same with a 3-stage
- * ring, 4 = + split-bf16 tiles where the heuristic picks them (DEFAULT), 5 = split-bf16 wherever eligible, 6 = split-bf16
- * for the SwiGLU-gate product only */
-int gaot_debug_set_gemm_glds(int on);
-/* 3 (default): fp32-level products from three bf16 pieces per operand; 1: operands rounded to bf16, one piece product, fp32
- * accumulation -- the separately reported `bench.py --dtype bf16` variant only (BASELINE configs[1]); returns the old value. */
-int gaot_debug_set_gemm_pieces(int pieces);
-/* split-bf16 tile kernels: 0 = one workgroup per tile; n > 0 = launches of more than n workgroups run persistently with n */
-int gaot_debug_set_split_persist(int n);
-/* 1: the fp32-level bf16-pipe products use the LDS-direct kernel (fp32 tiles by DMA, operands split in registers) instead of the
- * plane kernel; 0: the plane kernel (gemm_split.hip).  Returns the old value. */
-int gaot_debug_set_gemm_gsplit(int on);
+
+/* Grouped weight-gradient products: ONE launch over n products  out_i[M_i,N_i] = g_i[K_i,M_i]^T x_i[K_i,N_i]  (+ colsum_i[m] =
+ * sum_k g_i[k,m], the bias gradient), i.e. dW = dY^T X (and db) of every nn.Linear / Conv1d(k=1) whose backward has been
+ * reached (mlp.py:283-305, attn.py:92-117,150-156,225-227, gaot.py:208: autograd runs them one by one, each a long reduction
+ * over all tokens into a small matrix).  fp32-level products on the bf16 matrix pipe (six piece products, as gaot_gemm_f32's
+ * split tiles); K slabs of at most 1 024 rows are summed in slab order by the last workgroup to finish a tile (deterministic).
+ * Needs M, N % 4 == 0, K % 32 == 0, ld* % 4 == 0, 16-byte aligned pointers.  `workspace`: >= gaot_gemm_tn_grouped_workspace()
+ * floats; `counters`: >= *n_counters int32, ZERO before the first call (every call leaves them zero again). */
+typedef struct gaot_wgrad_item {
+    const float* g;  int64_t ldg;     /* [K, M] row-major: the output gradient dY (tokens x out_features)  */
+    const float* x;  int64_t ldx;     /* [K, N] row-major: the layer input X  (tokens x in_features)       */
+    float* out;      int64_t ldo;     /* [M, N]: dW                                                        */
+    float* colsum;                    /* optional [M]: db                                                  */
+    int32_t M, N, K;
+} gaot_wgrad_item;
+int64_t gaot_gemm_tn_grouped_workspace(const gaot_wgrad_item* items, int32_t n, int32_t* n_counters);
+int gaot_gemm_tn_grouped(const gaot_wgrad_item* items, int32_t n, float* workspace, int32_t* counters, gaot_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Geometry plan pieces (once per mesh geometry; torch_scatter / repeat_interleave call sites
@@ -234,12 +232,6 @@ int gaot_swiglu_bwd(const float* u, const float* dg, int32_t M, int32_t F, float
  * q/k/v are strided views: element (b,s,h,d) at ptr[(b*S+s)*ld + h*head_dim + d]; kv head = h / (H/Hkv).
  * o has the same addressing with ldo.  lse[B,H,S] (natural-log-sum-exp of scaled scores) saved for bwd.
  * head_dim <= 128, S arbitrary (head_dim <= 64: split-bf16 kernels where they apply; above: fp32 MFMA). */
-/* tuning hook: head_dim 32 attention, 1 = split-bf16 MFMA kernels (default), 0 = fp32-MFMA kernels, 2 / 3 = split with the
- * 8-wave / 4-wave forward workgroup forced.  Returns the previous value. */
-int gaot_debug_set_attention_split(int on);
-/* tuning hook: 1 = the software-pipelined 8-wave split forward where it applies (S % 64 == 0), 0 (default) = the plain one.
- * Returns the previous value. */
-int gaot_debug_set_attention_pipe(int on);
 int gaot_attention_fwd(const float* q, const float* k, const float* v, int64_t ldq, int64_t ldk, int64_t ldv,
                        int32_t B, int32_t S, int32_t H, int32_t Hkv, int32_t head_dim,
                        float* o, int64_t ldo, float* lse, gaot_stream_t stream);
@@ -285,8 +277,6 @@ int gaot_batchsum(const float* x, int32_t B, int64_t RN, float* out, gaot_stream
  * per-workgroup partials summed in fixed order).  x gets no gradient (edge coordinates). */
 int gaot_kernel_mlp_fwd(const float* x, int32_t E, int32_t c_in, int32_t n_layers, const float* const* w,
                         const float* const* b, int32_t act, float* out, gaot_stream_t stream);
-/* tuning hook (results become WRONG): forward kernel 1 = no stores, 2 = no GELU, 4 = no MFMA layers, 8 = no weight staging */
-int gaot_debug_set_kernel_mlp_ablate(int bits);
 int64_t gaot_kernel_mlp_bwd_workspace(int32_t E, int32_t c_in, int32_t n_layers);
 int gaot_kernel_mlp_bwd(const float* x, int32_t E, int32_t c_in, int32_t n_layers, const float* const* w,
                         const float* const* b, int32_t act, const float* dk, float* grads, float* workspace, gaot_stream_t stream);
@@ -329,7 +319,6 @@ int gaot_patchify(const float* in, int32_t B, int32_t H, int32_t W, int32_t Dz, 
  *                                    read once for 4 samples instead of once per sample)
  * ------------------------------------------------------------------------------------------ */
 int64_t gaot_gno_ep_workspace(int32_t E, int32_t C, int32_t B);
-int gaot_debug_set_ep_chunk(int edges_per_chunk);      /* tuning only: 0 = default (32) */
 int gaot_gno_lift_gather_reduce_ep(const float* k, const float* pn, const float* wl, const float* bl, int32_t B, int32_t n_src,
                                    int32_t c_in, int32_t C, const int32_t* splits, const int32_t* cols, const int32_t* edge_query,
                                    int32_t Q, int32_t E, const float* escale, float* out, float* ws, gaot_stream_t stream);

@@ -1,0 +1,48 @@
+/*
+ * gaot_hip_debug.h -- tuning / ablation hooks of libgaot_hip.so.  NOT part of the data path and NOT part of the drop-in
+ * boundary (include/gaot_hip.h): these setters change process-global kernel-selection state, so they are neither thread-safe
+ * nor re-entrant across streams.  Only tools/, bench.py's separately reported `--dtype bf16` variant and A/B tests call them;
+ * gaot_amd's modules never do.  Every setter returns the previous value.
+ */
+#ifndef GAOT_HIP_DEBUG_H
+#define GAOT_HIP_DEBUG_H
+
+#include "gaot_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* tuning hook (not part of the data path): force the GEMM tile; 0 = heuristic. Returns the previous value. */
+int gaot_debug_set_gemm_tile(int cfg);
+/* tuning hook: ablate parts of the GEMM kernel (results become WRONG): 1 no in-loop loads, 2 no LDS staging, 4 no stores */
+int gaot_debug_set_gemm_ablate(int bits);
+/* which kernel family served the calling thread's last gaot_gemm_f32: 1 = fp32 MFMA tiles, 2 = skinny VALU path,
+ * 3 = split-bf16 MFMA tiles (fp32 operands split exactly into three bf16 pieces, six bf16 MFMAs per product, fp32-level error) */
+int gaot_debug_last_gemm_path(void);
+/* tuning hook: 0 = register-staged fp32 tiles only, 1 = + LDS-direct fp32 tiles (2-stage ring), 3 = same with a 3-stage
+ * ring, 4 = + split-bf16 tiles where the heuristic picks them (DEFAULT), 5 = split-bf16 wherever eligible, 6 = split-bf16
+ * for the SwiGLU-gate product only */
+int gaot_debug_set_gemm_glds(int on);
+/* 3 (default): fp32-level products from three bf16 pieces per operand; 1: operands rounded to bf16, one piece product, fp32
+ * accumulation -- the separately reported `bench.py --dtype bf16` variant only (BASELINE configs[1]); returns the old value. */
+int gaot_debug_set_gemm_pieces(int pieces);
+/* split-bf16 tile kernels: 0 = one workgroup per tile; n > 0 = launches of more than n workgroups run persistently with n */
+int gaot_debug_set_split_persist(int n);
+/* 1: the fp32-level bf16-pipe products use the LDS-direct kernel (fp32 tiles by DMA, operands split in registers) instead of the
+ * plane kernel; 0: the plane kernel (gemm_split.hip).  Returns the old value. */
+int gaot_debug_set_gemm_gsplit(int on);
+/* tuning hook: head_dim 32 attention, 1 = split-bf16 MFMA kernels (default), 0 = fp32-MFMA kernels, 2 / 3 = split with the
+ * 8-wave / 4-wave forward workgroup forced.  Returns the previous value. */
+int gaot_debug_set_attention_split(int on);
+/* tuning hook: 1 = the software-pipelined 8-wave split forward where it applies (S % 64 == 0), 0 (default) = the plain one.
+ * Returns the previous value. */
+int gaot_debug_set_attention_pipe(int on);
+/* tuning hook (results become WRONG): forward kernel 1 = no stores, 2 = no GELU, 4 = no MFMA layers, 8 = no weight staging */
+int gaot_debug_set_kernel_mlp_ablate(int bits);
+int gaot_debug_set_ep_chunk(int edges_per_chunk);      /* tuning only: 0 = default (32) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

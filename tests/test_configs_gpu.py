@@ -232,6 +232,29 @@ def test_c3_naca_vx_degree_skew_vs_oracle():
     assert rel_l2(y2.cpu(), y[perm].cpu()) < 1e-6
 
 
+def test_c3_named_size_batch16_of_8192_nodes_vs_oracle():
+    """BASELINE configs[2] AT ITS NAMED SIZE: batch 16 of 8 192-node airfoil-like meshes (vx).  The block-diagonal union has
+    131 072 sources, 65 536 latent rows and ~445 k edges per direction: the edge-partitioned kernels' chunking, the composed plans and
+    the K slabs of the 16 384-token GEMMs all run at the size the bench reports.  The oracle loops over the samples as the
+    reference does (magno.py:356-413).  Also: TrainStep under hipGraph takes the same first step (loss) on this batch."""
+    from oracle import gaot_oracle as O
+    model, sd, ocfg, lat, x, p, tgt, enc, dec = _c3_case(B=16, N=8192)
+    E = sum(int(e[0][0].numel()) for e in enc)
+    deg = torch.cat([e[0][1][1:] - e[0][1][:-1] for e in enc])
+    assert E > 400_000 and int(deg.max()) > 256 and int((deg == 0).sum()) > 30_000, (E, int(deg.max()), int((deg == 0).sum()))
+    batch = dict(latent=lat, xcoord=x, pndata=p, target=tgt, encoder_nbrs=enc, decoder_nbrs=dec)
+    loss, grads, _, _, pred = O.train_step(sd, ocfg, batch, return_pred=True)
+    model.to(dev()).train()
+    kw = dict(latent_tokens_coord=lat.to(dev()), xcoord=x.to(dev()),
+              encoder_nbrs=[[csr_dict(c) for c in row] for row in enc], decoder_nbrs=[[csr_dict(c) for c in row] for row in dec])
+    check_step(model, (loss, grads, pred), kw, p.to(dev()), tgt.to(dev()), f"C3 vx B=16 x 8192, {E} encoder edges, max degree {int(deg.max())}")
+    from gaot_amd.trainer import TrainStep
+    ts = TrainStep(model, lr=8e-4, weight_decay=1e-5, use_graph=True)
+    ts.bind(p.to(dev()), tgt.to(dev()), **kw)
+    l0 = float(ts.step())
+    assert abs(l0 - float(loss)) < LOSS_TOL * abs(float(loss))
+
+
 @pytest.mark.parametrize("vx", [False, True])
 def test_c3_max_neighbors_sampling_on_gpu(vx, monkeypatch):
     """row A12 on the device: training-time neighbour sub-sampling (sampling_strategy='max_neighbors') runs inside the
@@ -299,15 +322,17 @@ def test_c1_poisson_1k_nodes_batch4_many_empty_tokens():
     check_step(model, (loss, grads, pred), kw, p.to(dev()), tgt.to(dev()), "C1 1k nodes B=4")
 
 
-def test_c5_3d_cloud_4096_tokens_headdim48():
-    """BASELINE configs[4] shape at a size the oracle finishes: 3-D surface cloud, 32^3 latent grid -> 4 096 tokens of width
-    8*48 = 384, 8 heads x 48 (the head_dim-64 split-bf16 attention kernels), 48 lifting channels (kernel MLP and geometry-embedding
-    chain with layers narrower than 64), 92 % empty latent rows."""
+@pytest.mark.parametrize("n_points", [16384, 65536])
+def test_c5_3d_cloud_4096_tokens_headdim48(n_points):
+    """BASELINE configs[4]: 3-D surface cloud, 32^3 latent grid -> 4 096 tokens of width 8*48 = 384, 8 heads x 48 (the head_dim-64
+    split-bf16 attention kernels), 48 lifting channels (kernel MLP and geometry-embedding chain with layers narrower than 64),
+    92 % empty latent rows.  65 536 points = the NAMED size (308 k edges per direction, encoder rows of > 600 edges); 16 384 points
+    = the same shape at a quarter of the cloud."""
     from oracle import gaot_oracle as O
     model, sd, ocfg = make_model(3, 1, [32, 32, 32], d=3, C=48, hidden=384, heads=8, radius=0.067, seed=7)
     g = torch.Generator().manual_seed(7)
-    lat, x = grid([32, 32, 32]), shell_points(16384, g)
-    p, tgt = torch.randn(1, 16384, 3, generator=g), torch.randn(1, 16384, 1, generator=g)
+    lat, x = grid([32, 32, 32]), shell_points(n_points, g)
+    p, tgt = torch.randn(1, n_points, 3, generator=g), torch.randn(1, n_points, 1, generator=g)
     enc, dec = [O.radius_csr(x, lat, 0.067)], [O.radius_csr(lat, x, 0.067)]
     batch = dict(latent=lat, xcoord=x, pndata=p, target=tgt, encoder_nbrs=enc, decoder_nbrs=dec)
     loss, grads, _, _, pred = O.train_step(sd, ocfg, batch, return_pred=True)
@@ -330,7 +355,7 @@ def test_c5_3d_cloud_4096_tokens_headdim48():
     assert abs(float(l.detach()) - float(loss)) < LOSS_TOL * abs(float(loss))
     e32, e64 = grad_errors(model, grads), grad_errors(model, grads64)
     worst = max(e32, key=lambda k: min(e32[k], e64[k]))
-    print(f"[C5 3-D 4096 tokens head_dim 48] worst gradient tensor {worst}: {e32[worst]:.2e} vs the fp32 oracle, {e64[worst]:.2e} vs its float64 evaluation; "
+    print(f"[C5 3-D {n_points} points, {int(enc[0][0].numel())} edges, 4096 tokens head_dim 48] worst gradient tensor {worst}: {e32[worst]:.2e} vs the fp32 oracle, {e64[worst]:.2e} vs its float64 evaluation; "
           + ", ".join(f"{k.split('.')[0][:3]}.{k.split('.')[-1][0]} {e32[k]:.1e}/{e64[k]:.1e}" for k in STATS_GATED))
     for k in e32:
         assert min(e32[k], e64[k]) < GRAD_TOL, (k, e32[k], e64[k])

@@ -32,10 +32,24 @@ def test_library_builds_loads_and_exports_header_symbols():
     lib = _lib.load()
     assert lib.gaot_abi_version() == 2
     header = open(os.path.join(ROOT, "include", "gaot_hip.h")).read()
+    debug = open(os.path.join(ROOT, "include", "gaot_hip_debug.h")).read()
     declared = set(re.findall(r"\b(gaot_[a-z0-9_]+)\s*\(", header))
+    hooks = set(re.findall(r"\b(gaot_[a-z0-9_]+)\s*\(", debug))
+    # the boundary header carries no process-global knob; the tuning hooks live in their own header
+    assert not any(n.startswith("gaot_debug_") for n in declared) and all(n.startswith("gaot_debug_") for n in hooks)
+    declared |= hooks
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
     for name in declared:
         assert hasattr(lib, name), name
+
+
+def test_wgrad_item_layout_matches_header():
+    from gaot_amd._lib import WgradItem
+    header = open(os.path.join(ROOT, "include", "gaot_hip.h")).read()
+    body = header[header.index("typedef struct gaot_wgrad_item {"):header.index("} gaot_wgrad_item;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = re.findall(r"(?:\*|\s)([A-Za-z_][A-Za-z0-9_]*)\s*[;,]", body)
+    assert names == [f[0] for f in WgradItem._fields_], names
 
 
 def test_gemm_desc_layout_matches_header():
@@ -244,3 +258,17 @@ def test_autograph_parameter_list_cache_follows_registrations():
     assert len(AG._param_list(m)) == 7
     m[1].weight = nn.Parameter(torch.ones(2, 4))                     # a replaced Parameter object is picked up as well
     assert any(p is m[1].weight for p in AG._param_list(m))
+
+
+def test_fp64_request_fails_at_the_module_and_leaves_fp32_parameters():
+    """base_trainer.py:63-68,173-179 allow `dtype: double` and call model.type(dtype): the HIP path is fp32 only and says so at the
+    module (TypeError), not deep inside an op; the parameters stay float32 and usable"""
+    g = Golden("fx2d_base")
+    m = _model(g)
+    for cast in (lambda: m.type(torch.float64), lambda: m.double(), lambda: m.to(torch.float64), lambda: m.half()):
+        with pytest.raises(TypeError, match="float32 only"):
+            cast()
+        assert all(p.dtype == torch.float32 for p in m.parameters())
+    assert m.type(torch.float32) is m and m.float() is m
+    with pytest.raises(TypeError, match="float32 only"):
+        m(latent_tokens_coord=g.t("in.latent"), xcoord=g.t("in.xcoord"), pndata=g.t("in.pndata").double())

@@ -789,8 +789,20 @@ def test_segment_csr_wrapper_matches_reference_semantics():
                 d = (1.0 / deg.clamp(min=1).double())[qid]
                 gref = gref * (d if x.dim() == 1 else (d[:, None] if x.dim() == 2 else d[None, :, None]))
             assert rel(xd.grad, gref) < 1e-6
+        # reduce='max' (torch_scatter's, used by the reference's segment softmax agno.py:131-133): per-segment maximum, empty -> 0
+        xd = x.to(dev())
+        out = segment_csr(xd, ip.to(dev()), reduce="max")
+        xs = x.double() if x.dim() == 3 else (x.double()[None] if x.dim() == 2 else x.double()[None, :, None])
+        ref = torch.zeros(xs.shape[0], 6, xs.shape[2], dtype=torch.float64)
+        for q in range(6):
+            if deg[q] > 0:
+                ref[:, q] = xs[:, int(ip[q]):int(ip[q + 1])].max(dim=1).values
+        ref = ref if x.dim() == 3 else (ref[0] if x.dim() == 2 else ref[0, :, 0])
+        assert out.shape == ref.shape and torch.equal(out.double().cpu(), ref)
+    with pytest.raises(ValueError):       # the reference's native branch (use_scatter=False) knows mean and sum only
+        segment_csr(torch.zeros(4, device=dev()), torch.tensor([0, 4], device=dev()), reduce="max", use_scatter=False)
     with pytest.raises(ValueError):
-        segment_csr(torch.zeros(4, device=dev()), torch.tensor([0, 4], device=dev()), reduce="max")
+        segment_csr(torch.zeros(4, device=dev()), torch.tensor([0, 4], device=dev()), reduce="prod")
 
 
 def test_glue_kernels_against_float64():
@@ -1051,3 +1063,71 @@ def test_split_gemm_same_signed_long_reduction():
     A, Bm = torch.rand(1024, 4096, generator=g) + 0.5, torch.rand(1024, 4096, generator=g) + 0.5
     out = ops.linear_nt(A.to(dev()), Bm.to(dev()))
     assert rel(out, A.double() @ Bm.double().t()) < 2e-6
+
+
+# ------------------------------------------------------------------ grouped weight-gradient products
+def _wgrad_items(shapes, seed, with_colsum=()):
+    g = torch.Generator().manual_seed(seed)
+    items, refs = [], []
+    for i, (Mo, No, K) in enumerate(shapes):
+        dy = torch.randn(K, Mo, generator=g)
+        x = torch.randn(K, No, generator=g)
+        out = torch.full((Mo, No), float("nan"), device=dev())
+        cs = torch.full((Mo,), float("nan"), device=dev()) if i in with_colsum else None
+        items.append((dy.to(dev()), Mo, x.to(dev()), No, out, No, cs, Mo, No, K))
+        refs.append((dy.double().t() @ x.double(), dy.double().sum(0)))
+    return items, refs
+
+
+def test_wgrad_grouped_matches_float64_and_is_deterministic():
+    """gaot_gemm_tn_grouped: many dW = dY^T X (+ db) in one launch; ragged tiles, one and many K slabs, > 24 products (two
+    launches), ticket counters back at zero, bitwise repeatable"""
+    from gaot_amd import ops
+    shapes = [(256, 256, 2048), (2048, 256, 4096), (132, 68, 1024), (64, 64, 8192), (256, 1024, 1024), (768, 256, 3072),
+              (36, 260, 1056), (128, 128, 32)] + [(128, 132, 2048)] * 20
+    items, refs = _wgrad_items(shapes, 11, with_colsum=(0, 2, 3, 6))
+    ops.wgrad_launch(items)
+    torch.cuda.synchronize()
+    for it, (ref, cref) in zip(items, refs):
+        assert rel(it[4], ref) < 2e-6, it[7:]
+        if it[6] is not None:
+            assert maxrel(it[6], cref) < 5e-6, it[7:]
+    assert int(ops._WGRAD_COUNTERS[dev().index].abs().sum()) == 0
+    first = [it[4].clone() for it in items]
+    for it in items:
+        it[4].fill_(float("nan"))
+    ops.wgrad_launch(items)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, it[4]) for a, it in zip(first, items))
+
+
+def test_wgrad_grouped_same_signed_long_reduction():
+    """thousands of same-signed products per output (the bf16 MFMA accumulator does not round to nearest): the grouped launch keeps
+    every matrix-pipe accumulation run at <= 1 024 values of k like the single-product path"""
+    from gaot_amd import ops
+    g = torch.Generator().manual_seed(3)
+    K, Mo, No = 8192, 128, 256
+    dy = torch.rand(K, Mo, generator=g) + 0.5
+    x = torch.rand(K, No, generator=g) + 0.5
+    out = torch.empty(Mo, No, device=dev())
+    ops.wgrad_launch([(dy.to(dev()), Mo, x.to(dev()), No, out, No, None, Mo, No, K)])
+    assert rel(out, dy.double().t() @ x.double()) < 1.5e-6
+
+
+def test_deferred_wgrad_scope_equals_immediate_products():
+    """ops.deferred_wgrad(): products with a destination are queued and computed at scope exit; ineligible ones run at once"""
+    from gaot_amd import ops
+    g = torch.Generator().manual_seed(9)
+    dy, x = torch.randn(4096, 256, generator=g).to(dev()), torch.randn(4096, 512, generator=g).to(dev())
+    small_dy, small_x = torch.randn(4096, 6, generator=g).to(dev()), torch.randn(4096, 10, generator=g).to(dev())
+    want = ops.matmul_tn(dy, x)
+    want_small = ops.matmul_tn(small_dy, small_x)
+    out, db = torch.zeros(256, 512, device=dev()), torch.zeros(256, device=dev())
+    out_small = torch.zeros(6, 10, device=dev())
+    with ops.deferred_wgrad():
+        r = ops.matmul_tn(dy, x, out=out, colsum_out=db)
+        assert r is out and len(ops._WGRAD_QUEUE) == 1
+        ops.matmul_tn(small_dy, small_x, out=out_small)          # not groupable (6 x 10): computed immediately
+        assert len(ops._WGRAD_QUEUE) == 1 and rel(out_small, want_small) < 1e-6
+    assert not ops._WGRAD_QUEUE
+    assert rel(out, want) < 2e-6 and maxrel(db, dy.double().sum(0)) < 5e-6
