@@ -37,6 +37,11 @@ class WgradItem(C.Structure):
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32)]
 
 
+class ColsumItem(C.Structure):
+    """gaot_colsum_item: out[n] = sum_m x[m * ld + n]"""
+    _fields_ = [("x", _f), ("ld", C.c_int64), ("out", _f), ("M", C.c_int32), ("N", C.c_int32)]
+
+
 # name -> (restype, argtypes): every symbol include/gaot_hip.h (data path) and include/gaot_hip_debug.h (tuning hooks) declare
 PROTOTYPES = {
     "gaot_abi_version": (C.c_int, []),
@@ -90,6 +95,7 @@ PROTOTYPES = {
                                              _f, _f, _f, C.c_int64, C.c_int64, C.c_int64, _f, C.c_float, _i, _s]),
     "gaot_colsum_scratch": (C.c_int64, [C.c_int32, C.c_int32]),
     "gaot_colsum": (C.c_int, [_f, C.c_int64, C.c_int32, C.c_int32, _f, _f, _s]),
+    "gaot_colsum_grouped": (C.c_int, [C.POINTER(ColsumItem), C.c_int32, _s]),
     "gaot_batchsum": (C.c_int, [_f, C.c_int32, C.c_int64, _f, _s]),
     "gaot_gno_lift_gather_reduce": (C.c_int, [_f, _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f, _f, C.c_int32, _f, _f, _s]),
     "gaot_gno_lift_edge_grad_parts": (C.c_int32, [C.c_int32, C.c_int32]),

@@ -261,6 +261,44 @@ __global__ __launch_bounds__(256) void colsum_small_kernel(const float* __restri
     __syncthreads();
     if (rg == 0 && n < N) *reinterpret_cast<f32x4*>(out + n) = (red[0][c4] + red[1][c4]) + (red[2][c4] + red[3][c4]);
 }
+// ---- grouped column sums: ONE launch over many small partial-row matrices (the per-workgroup partial rows of the norm-weight
+// and lifting gradients: each used to cost its own 5 us launch at the end of its backward node).  Same tiling as colsum_small_kernel
+// (16 columns per workgroup as 4 float4 lanes x 64 row groups, fixed-order LDS sum); the item table travels in the kernel arguments.
+constexpr int COLSUM_GROUP_MAX = 32;
+struct ColsumItem { const float* x; float* out; long ld; int M, N, wg_end; };
+struct ColsumGroupArgs { int n; ColsumItem it[COLSUM_GROUP_MAX]; };
+__global__ __launch_bounds__(256) void colsum_grouped_kernel(const ColsumGroupArgs g) {
+    __shared__ f32x4 red[64][4];
+    int i = 0;
+    while (i + 1 < g.n && (int)blockIdx.x >= g.it[i].wg_end) ++i;
+    const int first = i > 0 ? g.it[i - 1].wg_end : 0;
+    const float* __restrict__ x = g.it[i].x;
+    const long ld = g.it[i].ld;
+    const int M = g.it[i].M, N = g.it[i].N;
+    const int c4 = threadIdx.x & 3, rg = threadIdx.x >> 2;
+    const int n = ((int)blockIdx.x - first) * 16 + c4 * 4;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    if (n < N) {
+        int r = rg;
+        for (; r + 192 < M; r += 256) {
+            s0 += *reinterpret_cast<const f32x4*>(x + (long)r * ld + n);
+            s1 += *reinterpret_cast<const f32x4*>(x + (long)(r + 64) * ld + n);
+            s2 += *reinterpret_cast<const f32x4*>(x + (long)(r + 128) * ld + n);
+            s3 += *reinterpret_cast<const f32x4*>(x + (long)(r + 192) * ld + n);
+        }
+        for (; r < M; r += 64) s0 += *reinterpret_cast<const f32x4*>(x + (long)r * ld + n);
+    }
+    red[rg][c4] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rg < 4) {
+        f32x4 t = red[rg][c4];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) t += red[rg + 4 * q][c4];
+        red[rg][c4] = t;
+    }
+    __syncthreads();
+    if (rg == 0 && n < N) *reinterpret_cast<f32x4*>(g.it[i].out + n) = (red[0][c4] + red[1][c4]) + (red[2][c4] + red[3][c4]);
+}
 __global__ void batchsum_kernel(const float* __restrict__ x, int B, long RN, float* __restrict__ out) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < RN; i += (long)gridDim.x * blockDim.x) {
         float s = 0.f;
@@ -438,6 +476,27 @@ extern "C" int gaot_colsum(const float* x, int64_t ld, int32_t M, int32_t N, flo
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 64), P), dim3(256), 0, ST(stream), x, (long)ld, M, N, P, scratch);
     hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 64)), dim3(256), 0, ST(stream), scratch, P, N, out);
     GAOT_CHECK_LAUNCH("gaot_colsum");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_colsum_grouped(const gaot_colsum_item* items, int32_t n, gaot_stream_t stream) {
+    GAOT_REQUIRE(items != nullptr && n > 0, "colsum_grouped: no items");
+    for (int i = 0; i < n; ++i)
+        GAOT_REQUIRE(items[i].x && items[i].out && items[i].M > 0 && items[i].N > 0 && items[i].N % 4 == 0 && items[i].ld % 4 == 0 &&
+                     items[i].ld >= items[i].N && aligned16(items[i].x) && aligned16(items[i].out),
+                     "colsum_grouped: item %d needs N %% 4 == 0, ld %% 4 == 0 and 16-byte aligned pointers", i);
+    for (int i0 = 0; i0 < n; i0 += COLSUM_GROUP_MAX) {
+        ColsumGroupArgs a;
+        a.n = n - i0 < COLSUM_GROUP_MAX ? n - i0 : COLSUM_GROUP_MAX;
+        int wg = 0;
+        for (int i = 0; i < a.n; ++i) {
+            const gaot_colsum_item& it = items[i0 + i];
+            wg += cdiv(it.N, 16);
+            a.it[i] = ColsumItem{it.x, it.out, (long)it.ld, it.M, it.N, wg};
+        }
+        hipLaunchKernelGGL(colsum_grouped_kernel, dim3(wg), dim3(256), 0, ST(stream), a);
+        GAOT_CHECK_LAUNCH("gaot_colsum_grouped");
+    }
     return GAOT_OK;
 }
 

@@ -195,18 +195,24 @@ def matmul_nn(g: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = No
 
 
 def matmul_tn(g: torch.Tensor, x2: torch.Tensor, out: Optional[torch.Tensor] = None,
-              colsum_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              colsum_out: Optional[torch.Tensor] = None, final: bool = False) -> torch.Tensor:
     """out[N,K] = g[M,N]^T @ x2[M,K]   (weight gradient); split-K over the long M reduction.
-    colsum_out[N] (optional) receives sum_m g[m,:] -- the bias gradient -- from the same pass over g."""
+    colsum_out[N] (optional) receives sum_m g[m,:] -- the bias gradient -- from the same pass over g.
+    `final`: `out` (and `colsum_out`) are a PARAMETER's registered gradient slices (ops._claim): nothing reads them before the
+    backward pass has ended, so inside a deferred_wgrad() scope the product may join the grouped launch at its end."""
     g, lda = _rowmajor(g)
     x2, ldb = _rowmajor(x2)
     M, N = g.shape
     K = x2.shape[1]
     assert x2.shape[0] == M
-    if out is not None and _WGRAD_DEPTH[0] > 0 and _wgrad_groupable(g, lda, x2, ldb, out, colsum_out, N, K, M):
+    if final and out is not None and _WGRAD_DEPTH[0] > 0 and _wgrad_groupable(g, lda, x2, ldb, out, colsum_out, N, K, M):
         # a caller-provided destination (the parameter's slice of the flat gradient buffer) inside a deferral scope: the product
         # joins the grouped launch at the end of the backward pass (flush_wgrad); operands stay alive in the queue until then
-        _WGRAD_QUEUE.append((g, lda, x2, ldb, out, out.stride(0), colsum_out, N, K, M))
+        # the queue keeps ALIASES, not the tensor objects handed back to autograd (an extra reference to those makes AccumulateGrad clone)
+        _WGRAD_QUEUE.append((g, lda, x2, ldb, out.detach(), out.stride(0), None if colsum_out is None else colsum_out.detach(), N, K, M))
+        _note_deferred(out)
+        if colsum_out is not None:
+            _note_deferred(colsum_out)
         return out
     if out is None:
         out = torch.empty(N, K, device=g.device, dtype=torch.float32)
@@ -223,6 +229,7 @@ def matmul_tn(g: torch.Tensor, x2: torch.Tensor, out: Optional[torch.Tensor] = N
 # --------------------------------------------------------------------------------------------
 _WGRAD_DEPTH = [0]
 _WGRAD_QUEUE: list = []
+_COLSUM_QUEUE: list = []
 _WGRAD_COUNTERS: dict = {}
 _WGRAD_GROUPED = os.environ.get("GAOT_WGRAD_GROUPED", "1") != "0"        # A/B switch
 
@@ -252,6 +259,7 @@ class deferred_wgrad:
                 flush_wgrad()
             else:
                 _WGRAD_QUEUE.clear()
+                _COLSUM_QUEUE.clear()
         return False
 
 
@@ -282,6 +290,13 @@ def wgrad_launch(items) -> None:
 
 
 def flush_wgrad() -> None:
+    if _COLSUM_QUEUE:
+        cs = list(_COLSUM_QUEUE)
+        _COLSUM_QUEUE.clear()
+        arr = (L.ColsumItem * len(cs))()
+        for i, (x2, ld, out, M, N) in enumerate(cs):
+            arr[i] = L.ColsumItem(x2.data_ptr(), ld, out.data_ptr(), M, N)
+        L.check(L.load().gaot_colsum_grouped(arr, len(cs), _stream()), "gaot_colsum_grouped")
     if not _WGRAD_QUEUE:
         return
     items = list(_WGRAD_QUEUE)
@@ -289,11 +304,19 @@ def flush_wgrad() -> None:
     wgrad_launch(items)
 
 
-def colsum(x2: torch.Tensor) -> torch.Tensor:
+def colsum(x2: torch.Tensor, out: Optional[torch.Tensor] = None, final: bool = False) -> torch.Tensor:
+    """column sums of [M, N].  `final` (with `out` = a parameter's registered gradient slice, see matmul_tn): inside a
+    deferred_wgrad() scope the sum joins ONE grouped launch at the end of the backward pass (gaot_colsum_grouped)."""
     x2, ld = _rowmajor(x2)
     M, N = x2.shape
     lib = L.load()
-    out = torch.empty(N, device=x2.device, dtype=torch.float32)
+    if (final and out is not None and _WGRAD_DEPTH[0] > 0 and _WGRAD_GROUPED and N % 4 == 0 and ld % 4 == 0 and M <= 8192
+            and out.is_contiguous() and not ((x2.data_ptr() | out.data_ptr()) & 15)):
+        _COLSUM_QUEUE.append((x2, ld, out.detach().view(-1), M, N))
+        _note_deferred(out.view(-1))
+        return out
+    if out is None:
+        out = torch.empty(N, device=x2.device, dtype=torch.float32)
     scratch = torch.empty(int(lib.gaot_colsum_scratch(M, N)), device=x2.device, dtype=torch.float32)
     L.check(lib.gaot_colsum(_p(x2), ld, M, N, _p(out), _p(scratch), _stream()), "gaot_colsum")
     return out
@@ -329,6 +352,23 @@ def register_grad_slots(params, views):
 def release_grad_slots():
     for s in _GRAD_SLOTS.values():
         s[1] = False
+    _DEFERRED_DESTS.clear()
+
+
+# destinations (address ranges inside the flat gradient buffer) that a deferred, grouped launch writes at the END of the backward
+# pass.  AccumulateGrad may have taken a COPY of the tensor a backward node returned for such a slice (it clones instead of adopting
+# whenever it sees another reference) -- a copy of memory the product had not reached yet.  Whoever gathers gradients into the flat
+# buffer afterwards (FlatGradBucket.pack, autograph's settle) must therefore not copy such a tensor over its slice.
+_DEFERRED_DESTS: list = []
+
+
+def deferred_dest(ptr: int) -> bool:
+    return any(lo <= ptr < hi for lo, hi in _DEFERRED_DESTS)
+
+
+def _note_deferred(t: torch.Tensor) -> None:
+    lo = t.data_ptr()
+    _DEFERRED_DESTS.append((lo, lo + ((t.shape[0] - 1) * t.stride(0) + t.shape[-1]) * 4 if t.dim() == 2 else lo + t.numel() * 4))
 
 
 def _claim(w) -> Optional[torch.Tensor]:
@@ -405,9 +445,12 @@ class _Linear(torch.autograd.Function):
             dw = wslot.detach().view(N, w2d.shape[1]) if wslot is not None else torch.empty(N, w2d.shape[1], device=g.device, dtype=torch.float32)
             if want_db:      # bias gradient rides the weight-gradient product (same pass over dY)
                 db = bslot.detach() if bslot is not None else torch.empty(N, device=g.device, dtype=torch.float32)
-            matmul_tn(g, xm, out=dw[:, :K], colsum_out=db)
+            # final: both destinations are the parameters' own gradient slices (a bias gradient without its slice is read by
+            # autograd right away, so it keeps the product immediate)
+            fin = wslot is not None and (db is None or bslot is not None)
+            matmul_tn(g, xm, out=dw[:, :K], colsum_out=db, final=fin)
             if x2m is not None:
-                matmul_tn(g, x2m, out=dw[:, K:])
+                matmul_tn(g, x2m, out=dw[:, K:], final=wslot is not None)
             dw = dw.reshape(wshape)
         elif want_db:
             db = colsum(g)
@@ -493,7 +536,7 @@ class _LinearCat(torch.autograd.Function):
         dx = matmul_nn(g, W).reshape(shp) if ctx.needs_input_grad[0] else None
         dws = [None] * len(rows)
         if any(ctx.needs_input_grad[1:]):
-            dws = list(matmul_tn(g, xm, out=ctx.slot).split(rows, dim=0))
+            dws = list(matmul_tn(g, xm, out=ctx.slot, final=ctx.slot is not None).split(rows, dim=0))
         return (dx, *dws)
 
 
@@ -558,7 +601,8 @@ class _MLPChain(torch.autograd.Function):
                 if want_db:
                     db = bslot.detach() if bslot is not None else torch.empty(g.shape[1], device=g.device, dtype=torch.float32)
                 out = wslot.detach().view(g.shape[1], ins[i].shape[1]) if wslot is not None else None
-                grads[2 * i] = matmul_tn(g, ins[i], out=out, colsum_out=db).reshape(wshapes[i])
+                grads[2 * i] = matmul_tn(g, ins[i], out=out, colsum_out=db,
+                                         final=out is not None and (db is None or bslot is not None)).reshape(wshapes[i])
                 grads[2 * i + 1] = db
             elif want_db:
                 grads[2 * i + 1] = colsum(g)
@@ -783,6 +827,11 @@ class _GNOLiftTransform(torch.autograd.Function):
         L.check(lib.gaot_gno_lift_edge_grad(_p(dout), _p(k), _p(pn), _p(w2), _p(bl) if has_b else None, B, plan.Q, n_src, ci, Cc,
                                             _p(plan.index), _p(plan.edge_query), plan.E, _p(esc) if has_e else None, _p(dk),
                                             _p(part), _stream()), "gaot_gno_lift_edge_grad")
+        if ci == 1 and wslot is not None and (not has_b or bslot is not None):
+            # one input channel: dWl and dbl are the two column blocks of the partial rows -> straight into their gradient slices
+            dwl = colsum(part[:, :Cc], out=wslot.detach().view(-1), final=True).view(wshape)
+            dbl = colsum(part[:, Cc:], out=bslot.detach(), final=True) if has_b else None
+            return dk, None, dwl, dbl, None, None
         sums = colsum(part)                                  # [(ci + 1) * C] = [dWl^T | dbl]
         dwl = sums[:ci * Cc].reshape(ci, Cc).t().reshape(wshape) if ci > 1 else sums[:Cc].reshape(wshape)
         dbl = sums[ci * Cc:] if has_b else None
@@ -1169,6 +1218,7 @@ class _RMSNorm(torch.autograd.Function):
         L.check(L.load().gaot_rmsnorm_fwd(_p(xm), _p(w), M, D, float(eps), _p(y), _p(rstd), _stream()), "gaot_rmsnorm_fwd")
         ctx.save_for_backward(xm, w, rstd)
         ctx.shp = shp
+        ctx.slot = _claim(w)
         return y.reshape(shp)
 
     @staticmethod
@@ -1181,7 +1231,9 @@ class _RMSNorm(torch.autograd.Function):
         P = int(lib.gaot_rmsnorm_bwd_partials(M))
         part = torch.empty(P, D, device=xm.device, dtype=torch.float32)
         L.check(lib.gaot_rmsnorm_bwd(_p(xm), _p(w), _p(rstd), _p(g), None, M, D, _p(dx), _p(part), _stream()), "gaot_rmsnorm_bwd")
-        dw = colsum(part) if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = colsum(part, out=ctx.slot.detach() if ctx.slot is not None else None, final=ctx.slot is not None)
         return dx.reshape(ctx.shp), dw, None
 
 
@@ -1206,6 +1258,7 @@ class _RMSNormFork(torch.autograd.Function):
         L.check(L.load().gaot_rmsnorm_fwd(_p(xm), _p(w), M, D, float(eps), _p(y), _p(rstd), _stream()), "gaot_rmsnorm_fwd")
         ctx.save_for_backward(xm, w, rstd)
         ctx.shp = shp
+        ctx.slot = _claim(w)
         return x.view_as(x), y.reshape(shp)
 
     @staticmethod
@@ -1221,7 +1274,9 @@ class _RMSNormFork(torch.autograd.Function):
         P = int(lib.gaot_rmsnorm_bwd_partials(M))
         part = torch.empty(P, D, device=xm.device, dtype=torch.float32)
         L.check(lib.gaot_rmsnorm_bwd(_p(xm), _p(w), _p(rstd), _p(g), _p(add), M, D, _p(dx), _p(part), _stream()), "gaot_rmsnorm_bwd")
-        dw = colsum(part) if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = colsum(part, out=ctx.slot.detach() if ctx.slot is not None else None, final=ctx.slot is not None)
         return dx.reshape(ctx.shp), dw, None
 
 
@@ -1305,13 +1360,13 @@ class _SwiGLUFFN(torch.autograd.Function):
         du = torch.empty(M, 2 * F, device=d.device, dtype=torch.float32)
         gemm(M, F, No, d, ldd, 1, w2c, ldw2, 0, du, 2 * F, act=L.ACT_SWIGLU_BWD, aux_in=u, ld_aux=2 * F)
         slot13, slot2 = ctx.slots
-        dw2 = matmul_tn(d, g, out=slot2.detach() if slot2 is not None else None) if need[3] else None
+        dw2 = matmul_tn(d, g, out=slot2.detach() if slot2 is not None else None, final=slot2 is not None) if need[3] else None
         dx = None
         if need[0]:
             dx = (matmul_nn(du, w13, residual=d, ldr=ldd) if res_is_x else matmul_nn(du, w13)).reshape(shp)
         dw1 = dw3 = None
         if need[1] or need[2]:
-            dw13 = matmul_tn(du, xm, out=slot13)
+            dw13 = matmul_tn(du, xm, out=slot13, final=slot13 is not None)
             dw1, dw3 = dw13[:F], dw13[F:]
         dres = dy.reshape(res_shape) if (res_shape is not None and need[4]) else None
         return dx, dw1, dw3, dw2, dres, None

@@ -103,6 +103,10 @@ class FlatGradBucket:
     def pack(self, phase: Optional[int] = None):
         """gather the gradients (of one backward phase, or of all) into their views of the flat buffer"""
         srcs, dsts = [], []
+        deferred = None
+        if self.flat.is_cuda:
+            from . import ops
+            deferred = ops.deferred_dest
         for i, (p, v) in enumerate(zip(self.params, self.views)):
             if phase is not None and self.phase[i] != phase:
                 continue
@@ -112,7 +116,9 @@ class FlatGradBucket:
                     self._dirty[i] = False
             else:
                 self._dirty[i] = True
-                if p.grad.data_ptr() != v.data_ptr():
+                # a slice written by a deferred, grouped launch is already final: what autograd holds for it may be a copy taken
+                # BEFORE that launch ran (ops._DEFERRED_DESTS)
+                if p.grad.data_ptr() != v.data_ptr() and not (deferred is not None and deferred(v.data_ptr())):
                     srcs.append(p.grad)
                     dsts.append(v)
             p.grad = v

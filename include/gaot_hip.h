@@ -265,6 +265,11 @@ int gaot_attention_bwd(const float* q, const float* k, const float* v, int64_t l
 int64_t gaot_colsum_scratch(int32_t M, int32_t N);
 int gaot_colsum(const float* x, int64_t ld, int32_t M, int32_t N, float* out, float* scratch, gaot_stream_t stream);
 /* out[r,:] = sum_b x[b,r,:]   (row-periodic bias gradients; x is [B,R,N] contiguous) */
+/* Grouped column sums: out_i[n] = sum_m x_i[m*ld_i + n] for n small partial-row matrices in ONE launch (the per-workgroup partial
+ * rows behind the norm-weight gradients attn.py:161-172 and the lifting gradient magno.py:273-274, reduced at the end of a backward
+ * pass).  N % 4 == 0, ld % 4 == 0, 16-byte aligned pointers; fixed summation order (deterministic). */
+typedef struct gaot_colsum_item { const float* x; int64_t ld; float* out; int32_t M, N; } gaot_colsum_item;
+int gaot_colsum_grouped(const gaot_colsum_item* items, int32_t n, gaot_stream_t stream);
 int gaot_batchsum(const float* x, int32_t B, int64_t RN, float* out, gaot_stream_t stream);
 /* Fused row-wise MLP, every width 64: the kernel MLP of the integral transform (LinearChannelMLP, mlp.py:307-337, called per
  * edge at agno.py:229-231; act = GAOT_ACT_GELU) and the statistical geometry embedding followed by its recovery block

@@ -78,3 +78,34 @@ def rel_l2(a, b):
     b = b.double().flatten()
     den = b.norm().item()
     return (a - b).norm().item() / (den if den > 0 else 1.0)
+
+
+STATS_GATED = ("encoder.geoembed.mlp.0.weight", "encoder.geoembed.mlp.0.bias", "decoder.geoembed.mlp.0.weight", "decoder.geoembed.mlp.0.bias")
+
+
+class StatsGates:
+    """tests/golden/c2_stats_gates.npz: the REFERENCE at the bench configuration in float32 and in float64 on identical weights
+    (make_golden.run_c2_stats_gates): losses, the relative movement of the prediction and of every gradient tensor between the
+    two, and the full gradients of the four tensors behind the geometry statistics' ReLU gates in both precisions."""
+
+    def __init__(self):
+        z = np.load(os.path.join(GOLDEN_DIR, "c2_stats_gates.npz"), allow_pickle=False)
+        self.raw = {k: z[k] for k in z.files}
+        self.move = {k[5:]: float(v) for k, v in self.raw.items() if k.startswith("move.")}
+        self.top = float(self.raw["grad_norm_top"])
+        self.g32 = {k: torch.from_numpy(np.array(self.raw[f"g32.{k}"])) for k in STATS_GATED}
+        self.g64 = {k: torch.from_numpy(np.array(self.raw[f"g64.{k}"])) for k in STATS_GATED}
+
+    def same_weights(self, sd) -> bool:
+        """the seeded build drew the weights the fixture was made with (sum and norm of every tensor, in float64)"""
+        for k, v in sd.items():
+            want = self.raw[f"wsum.{k}"]
+            got = np.array([float(v.double().sum()), float(v.double().norm())])
+            if not np.allclose(got, want, rtol=1e-12, atol=1e-12):
+                return False
+        return True
+
+    def err(self, grads, ref) -> dict:
+        """per gated tensor: rel-L2 against `ref` (self.g32 or self.g64), denominator floored as in the parity tests"""
+        return {k: float((grads[k].detach().cpu().double() - ref[k].double()).norm()) / max(float(ref[k].double().norm()), 1e-3 * self.top)
+                for k in STATS_GATED}

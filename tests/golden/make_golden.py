@@ -317,6 +317,65 @@ def run_condnorm_rollout():
     print("condnorm_rollout:", tuple(out["out.rollout.output"].shape))
 
 
+
+def run_c2_stats_gates():
+    """The reference's OWN float32 -> float64 movement at the bench configuration (BASELINE configs[1]: 16 384 nodes, batch 8, the
+    example model; weights and data exactly as bench.py builds them).
+
+    Four gradient tensors sit right behind ReLU gates that read the standardised geometry statistics (gemb.py:103-171, 54-59):
+    with 16 384 x 64 gates a few pre-activations lie within fp32 rounding of zero, and which side they fall on depends on the
+    arithmetic the statistics were computed in.  This fixture pins that statement to the reference itself: the same model, weights
+    and batch are run in float32 and in float64 (`model.type(torch.float64)`, base_trainer.py:173-179).  NOTE: the reference's
+    float64 path raises at gemb.py:153 (`PCA_features = torch.zeros(...)` is float32 whatever the model dtype); it only runs with
+    torch's DEFAULT dtype switched to float64 around the call, which is what is done here -- the reference sources are untouched.
+    Stored: both losses, the relative movement of the prediction and of EVERY gradient tensor, the full float32 and float64
+    gradients of the four gated tensors, and checksums of the initial weights (the GPU test rebuilds them from the seed)."""
+    import bench
+    from src.model.gaot import GAOT
+    from src.model.layers.magno import MAGNOConfig
+    from src.model.layers.attn import TransformerConfig
+    from oracle import gaot_oracle as O
+    torch.manual_seed(0)
+    mcfg = MAGNOConfig(coord_dim=2, radius=bench.RADIUS, hidden_size=64, mlp_layers=3, lifting_channels=bench.C_LIFT,
+                       neighbor_search_method="grid", precompute_edges=True)
+    tcfg = TransformerConfig(patch_size=bench.PATCH, hidden_size=bench.HIDDEN)
+    model = GAOT(1, 1, NS(args=NS(magno=mcfg, transformer=tcfg), latent_tokens_size=bench.LATENT))
+    lat, x, p, t = bench.synthetic(1234, torch.device("cpu"))
+    enc, dec = O.radius_csr(x, lat, bench.RADIUS, exact=True), O.radius_csr(lat, x, bench.RADIUS, exact=True)      # = the `grid` backend's lists
+    nb = lambda c: {"neighbors_index": c[0], "neighbors_row_splits": c[1]}
+    out = {"meta.case": "c2_stats_gates", "meta.note": "reference GAOT at the bench configuration, float32 and float64 on identical weights"}
+    for k, v in model.state_dict().items():
+        out[f"wsum.{k}"] = np.array([float(v.double().sum()), float(v.double().norm())])
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        torch.set_default_dtype(dt)
+        try:
+            m = model.type(dt).train()
+            m.zero_grad(set_to_none=True)
+            pred = m(latent_tokens_coord=lat.to(dt), xcoord=x.to(dt), pndata=p.to(dt), encoder_nbrs=[nb(enc)], decoder_nbrs=[nb(dec)])
+            loss = torch.nn.MSELoss()(pred, t.to(dt))
+            loss.backward()
+        finally:
+            torch.set_default_dtype(torch.float32)
+        res[dt] = ({k: q.grad.detach().double().clone() for k, q in m.named_parameters()}, pred.detach().double(), float(loss.detach()))
+    (g32, p32, l32), (g64, p64, l64) = res[torch.float32], res[torch.float64]
+    top = max(float(v.norm()) for v in g64.values())
+    out["loss32"], out["loss64"] = np.float64(l32), np.float64(l64)
+    out["pred_rel_move"] = np.float64(float((p32 - p64).norm() / p64.norm()))
+    out["grad_norm_top"] = np.float64(top)
+    gated = ("encoder.geoembed.mlp.0.weight", "encoder.geoembed.mlp.0.bias", "decoder.geoembed.mlp.0.weight", "decoder.geoembed.mlp.0.bias")
+    for k in g64:
+        out[f"move.{k}"] = np.float64(float((g32[k] - g64[k]).norm()) / max(float(g64[k].norm()), 1e-3 * top))
+        out[f"gnorm64.{k}"] = np.float64(float(g64[k].norm()))
+    for k in gated:
+        out[f"g32.{k}"] = g32[k].float()
+        out[f"g64.{k}"] = g64[k]                  # float64
+    np.savez_compressed(os.path.join(HERE, "c2_stats_gates.npz"), **to_np(out))
+    worst = sorted(((float(out[f"move.{k}"]), k) for k in g64), reverse=True)[:4]
+    print("c2_stats_gates: loss32 %.9f loss64 %.9f; prediction moves %.2e; gradients: %s" % (l32, l64, float(out["pred_rel_move"]),
+          ", ".join(f"{k} {v:.2e}" for v, k in worst)))
+
+
 def run_neighbor_kats():
     """CSR known answers from the reference's in-repo backends, incl. points exactly at distance r."""
     from src.model.layers.utils.neighbor_search import NeighborSearch
@@ -356,3 +415,6 @@ if __name__ == "__main__":
         run_condnorm_rollout()
     if not only or "neighbor_kats" in only:
         run_neighbor_kats()
+    if not only or "c2_stats_gates" in only:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))      # bench.py (the bench configuration's builders) and the oracle's CSR
+        run_c2_stats_gates()

@@ -1125,9 +1125,12 @@ def test_deferred_wgrad_scope_equals_immediate_products():
     out, db = torch.zeros(256, 512, device=dev()), torch.zeros(256, device=dev())
     out_small = torch.zeros(6, 10, device=dev())
     with ops.deferred_wgrad():
-        r = ops.matmul_tn(dy, x, out=out, colsum_out=db)
+        r = ops.matmul_tn(dy, x, out=out, colsum_out=db, final=True)
         assert r is out and len(ops._WGRAD_QUEUE) == 1
-        ops.matmul_tn(small_dy, small_x, out=out_small)          # not groupable (6 x 10): computed immediately
+        ops.matmul_tn(small_dy, small_x, out=out_small, final=True)          # not groupable (6 x 10): computed immediately
         assert len(ops._WGRAD_QUEUE) == 1 and rel(out_small, want_small) < 1e-6
+        tmp = torch.zeros(256, 512, device=dev())
+        ops.matmul_tn(dy, x, out=tmp)                            # a destination somebody may read at once (not `final`): immediate
+        assert len(ops._WGRAD_QUEUE) == 1 and rel(tmp, want) < 2e-6
     assert not ops._WGRAD_QUEUE
     assert rel(out, want) < 2e-6 and maxrel(db, dy.double().sum(0)) < 5e-6

@@ -23,7 +23,7 @@ def single():
 def grouped():
     with ops.deferred_wgrad():
         for dy, x, out in ops_in:
-            ops.matmul_tn(dy, x, out=out)
+            ops.matmul_tn(dy, x, out=out, final=True)
 
 
 def timed(fn, n=30):
