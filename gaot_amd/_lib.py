@@ -39,7 +39,7 @@ class WgradItem(C.Structure):
 
 class ColsumItem(C.Structure):
     """gaot_colsum_item: out[n] = sum_m x[m * ld + n]"""
-    _fields_ = [("x", _f), ("ld", C.c_int64), ("out", _f), ("M", C.c_int32), ("N", C.c_int32)]
+    _fields_ = [("x", _f), ("ld", C.c_int64), ("out", _f), ("M", C.c_int32), ("N", C.c_int32), ("out_cols", C.c_int32), ("out_ld", C.c_int64)]
 
 
 # name -> (restype, argtypes): every symbol include/gaot_hip.h (data path) and include/gaot_hip_debug.h (tuning hooks) declare
@@ -56,6 +56,7 @@ PROTOTYPES = {
     "gaot_debug_set_gemm_pieces": (C.c_int, [C.c_int]),
     "gaot_debug_set_split_persist": (C.c_int, [C.c_int]),
     "gaot_debug_set_gemm_gsplit": (C.c_int, [C.c_int]),
+    "gaot_debug_set_wgrad_kslab": (C.c_int, [C.c_int]),
     "gaot_csr_prepare": (C.c_int, [_i, _i, C.c_int32, C.c_int32, C.c_int32, _i, _i, _i, _i, _s]),
     "gaot_csr_transpose": (C.c_int, [_i, C.c_int32, C.c_int32, _i, _i, _i, _s]),
     "gaot_guard_begin": (C.c_int, [_i, _s]),
@@ -106,9 +107,13 @@ PROTOTYPES = {
     "gaot_debug_set_kernel_mlp_ablate": (C.c_int, [C.c_int]),
     "gaot_debug_set_attention_split": (C.c_int, [C.c_int]),
     "gaot_debug_set_attention_pipe": (C.c_int, [C.c_int]),
-    "gaot_kernel_mlp_fwd_w": (C.c_int, [_f, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_int32), _f, _s]),
-    "gaot_kernel_mlp_bwd_w": (C.c_int, [_f, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_int32), _f, _f, _f, _s]),
+    "gaot_debug_set_attention_p_pieces": (C.c_int, [C.c_int]),
+    "gaot_kernel_mlp_fwd_w": (C.c_int, [_f, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_int32),
+                                        C.POINTER(C.c_int32), _f, _s]),
+    "gaot_kernel_mlp_bwd_w": (C.c_int, [_f, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_int32),
+                                        C.POINTER(C.c_int32), _f, _f, _f, _s]),
     "gaot_kernel_mlp_bwd_workspace": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "gaot_kernel_mlp_bwd_rows": (C.c_int32, [C.c_int32]),
     "gaot_kernel_mlp_bwd": (C.c_int, [_f, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, _f, _f, _f, _s]),
     "gaot_mse_loss_fwd": (C.c_int, [_f, _f, C.c_int64, _f, _f, _s]),
     "gaot_mse_loss_bwd": (C.c_int, [_f, _f, C.c_int64, _f, _f, _s]),

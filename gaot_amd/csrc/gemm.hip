@@ -494,6 +494,8 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
 
 
 // ---- grouped weight-gradient products (kernel: gemm_split.hip)
+namespace gaot { void set_tn_kslab(int k); }
+extern "C" int gaot_debug_set_wgrad_kslab(int k) { gaot::set_tn_kslab(k); return 0; }
 static int check_wgrad_items(const gaot_wgrad_item* items, int n) {
     GAOT_REQUIRE(items != nullptr && n > 0, "gemm_tn_grouped: no items");
     for (int i = 0; i < n; ++i) {

@@ -59,7 +59,10 @@ struct SplitGeom {
 
 // ONE output tile (`logical` in the XCD-aware order of the caller, K slab `zs` of p.split_k) of the product described by p.
 // Shared by the per-product kernel below and by the grouped weight-gradient kernel (one launch over many products).
-template <bool AK, bool BKM, int BM, int ABL, int NP>
+// FLUSH > 0: every FLUSH k-tiles (16 k each) the MFMA accumulators are added to running sums on the VECTOR pipe and restart from
+// zero: the bf16 MFMA does not round its accumulator to nearest, so one matrix-pipe accumulation run stays at FLUSH * 16 <= 1 024
+// values of k however long the workgroup's reduction is (costs TM * TN * 16 more registers: the grouped TN kernel has them)
+template <bool AK, bool BKM, int BM, int ABL, int NP, int FLUSH = 0>
 __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* smem_raw, const int logical, const int zs) {
     using G = SplitGeom<BM>;
     constexpr int BN = G::BN, NW = G::NW, NT = G::NT, WAVES_N = G::WAVES_N, WM = G::WM, WN = G::WN, TM = G::TM, TN = G::TN;
@@ -266,9 +269,40 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
     sstore(0, ra[0], rb[0], kt_begin < kt_end);
     gload(kt_begin + 1, ra[1], rb[1]);
     __syncthreads();
+    if (FLUSH > 0) {
+        f32x16 tot[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
+        int since = 0;
+        for (int kt = kt_begin; kt < kt_end; kt += 2) {
+            step(kt, 0, ra[1], rb[1], ra[0], rb[0]);
+            if (kt + 1 < kt_end) step(kt + 1, 1, ra[0], rb[0], ra[1], rb[1]);
+            since += 2;
+            if (since >= FLUSH) {          // wave-uniform
+                since = 0;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { tot[i][j][r] += acc[i][j][r]; acc[i][j][r] = 0.f; }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += tot[i][j][r];
+    } else {
     for (int kt = kt_begin; kt < kt_end; kt += 2) {
         step(kt, 0, ra[1], rb[1], ra[0], rb[0]);
         if (kt + 1 < kt_end) step(kt + 1, 1, ra[0], rb[0], ra[1], rb[1]);
+    }
     }
 
     if (!AK && do_colsum) {          // reduce the 8 k-pair groups through LDS (the stages are free now)
@@ -346,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const TnGroupAr
     a.aux_in = nullptr; a.aux_out = nullptr; a.ld_aux = 0; a.residual = nullptr; a.ldr = 0;
     a.split_k = split; a.ktiles_per_split = g.p[i].kt_per_split; a.ws = g.ws + g.p[i].ws_off;
     a.colsum = g.p[i].colsum; a.tiles_m = g.p[i].tiles_m; a.tiles_n = g.p[i].tiles_n; a.vec_epi = 1; a.ablate = 0;
-    split_tile<false, false, 128, 0, 3>(a, smem_raw, tile, z);
+    split_tile<false, false, 128, 0, 3, 64>(a, smem_raw, tile, z);
     if (split <= 1) return;
 
     const int tid = threadIdx.x;
@@ -387,13 +421,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const TnGroupAr
     }
 }
 
+static int g_tn_kslab = 2048;
+void set_tn_kslab(int k) { g_tn_kslab = k < 256 ? 256 : (k / 32) * 32; }
 // host side of the grouped launch: items -> prefix table; returns the workspace floats / counters it needs when `args` is null
 long plan_tn_grouped(const gaot_wgrad_item* items, int n, TnGroupArgs* args, int* n_counters, int* n_wg) {
     long ws = 0; int cnt = 0, wg = 0;
     for (int i = 0; i < n; ++i) {
         const gaot_wgrad_item& it = items[i];
         const int kt32 = it.K / 32;
-        int split = (it.K + 1023) / 1024;                            // <= 1 024 values of k per workgroup
+        // K slab per workgroup: the accumulators are flushed to the vector pipe every 1 024 values of k inside the kernel, so the
+        // slab length is a load-balance / slab-traffic choice (g_tn_kslab, default 2 048: half the slab traffic of 1 024)
+        int split = (it.K + g_tn_kslab - 1) / g_tn_kslab;
         int per = (kt32 + split - 1) / split;
         split = (kt32 + per - 1) / per;
         const int tm = cdiv(it.M, 128), tn = cdiv(it.N, 128);

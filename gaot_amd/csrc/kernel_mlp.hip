@@ -35,6 +35,7 @@ struct KMArgs {
     int ntiles;            // 128-edge tiles
     int abl;               // tuning only (gaot_debug_set_kernel_mlp_ablate): forward 1 = no stores, 2 = no GELU, 4 = no MFMA layers, 8 = no weight staging
     int cout;              // width of the LAST layer (<= 64, multiple of 4): only the first cout columns are stored / read
+    int ldw[4];            // row stride of layer i's weight matrix (>= its input width: a column block of a wider matrix is fine)
     int wo[4];             // output width of layer i (<= 64, multiples of 4; layer i + 1 reads that many inputs): weights are [wo[i]][wo[i-1]]
                            // row-major; rows / columns past the widths are staged as ZEROS, so the chain runs at width 64 throughout
                            // (act(0) = 0 for GELU and ReLU: padded features carry nothing forward, and their gradients come out zero)
@@ -68,10 +69,10 @@ __device__ __forceinline__ void km_stage_weights(const KMArgs& p, float* Ws, flo
         for (int i = tid; i < 64 * 16; i += 256) {          // 16 float4 per row
             const int r = i >> 4, c4 = (i & 15) * 4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (r < p.wo[m + 1] && c4 < p.wo[m]) v = *reinterpret_cast<const f32x4*>(p.w[m] + r * p.wo[m] + c4);
+            if (r < p.wo[m + 1] && c4 < p.wo[m]) v = *reinterpret_cast<const f32x4*>(p.w[m] + r * p.ldw[m + 1] + c4);
             *reinterpret_cast<f32x4*>(Ws + m * 64 * KM_WLD + r * KM_WLD + c4) = v;
         }
-    for (int i = tid; i < 64 * CM; i += 256) { const int f = i / CM, c = i % CM; W1s[i] = (c < p.cin && f < p.wo[0]) ? p.w1[f * p.cin + c] : 0.f; }   // rows padded to CM
+    for (int i = tid; i < 64 * CM; i += 256) { const int f = i / CM, c = i % CM; W1s[i] = (c < p.cin && f < p.wo[0]) ? p.w1[f * p.ldw[0] + c] : 0.f; }   // rows padded to CM
     if (tid < 64) {
         Bs[tid] = tid < p.wo[0] ? p.b1[tid] : 0.f;
 #pragma unroll
@@ -366,9 +367,11 @@ static int km_check(const float* x, int E, int cin, int n_layers, const float* c
 }
 
 static int g_km_abl = 0;
-static void km_fill(KMArgs& a, const float* x, int E, int cin, int n_layers, const float* const* w, const float* const* b, const int* widths) {
+static void km_fill(KMArgs& a, const float* x, int E, int cin, int n_layers, const float* const* w, const float* const* b, const int* widths,
+                    const int* ldw = nullptr) {
     a.x = x; a.cin = cin; a.E = E; a.w1 = w[0]; a.b1 = b[0]; a.cout = widths[n_layers - 1];
     for (int i = 0; i < 4; ++i) a.wo[i] = i < n_layers ? widths[i] : 64;
+    for (int i = 0; i < 4; ++i) a.ldw[i] = (ldw && i < n_layers && ldw[i] > 0) ? ldw[i] : (i == 0 ? cin : a.wo[i - 1]);
     for (int m = 0; m < 3; ++m) { a.w[m] = m + 1 < n_layers ? w[m + 1] : nullptr; a.b[m] = m + 1 < n_layers ? b[m + 1] : nullptr; }
     a.ntiles = cdiv(E, 128);
     a.abl = g_km_abl;
@@ -390,19 +393,30 @@ static int km_widths_ok(const int32_t* widths, int n_layers) {
 static const int32_t KM_W64[4] = {64, 64, 64, 64};
 
 extern "C" int gaot_kernel_mlp_fwd_w(const float* x, int32_t E, int32_t cin, int32_t n_layers, const float* const* w,
-                                     const float* const* b, int32_t act, const int32_t* widths, float* out, gaot_stream_t stream);
+                                     const float* const* b, int32_t act, const int32_t* widths, const int32_t* ldw, float* out, gaot_stream_t stream);
 extern "C" int gaot_kernel_mlp_fwd(const float* x, int32_t E, int32_t cin, int32_t n_layers, const float* const* w,
                                    const float* const* b, int32_t act, float* out, gaot_stream_t stream) {
-    return gaot_kernel_mlp_fwd_w(x, E, cin, n_layers, w, b, act, KM_W64, out, stream);
+    return gaot_kernel_mlp_fwd_w(x, E, cin, n_layers, w, b, act, KM_W64, nullptr, out, stream);
+}
+
+static int km_ldw_ok(const int32_t* ldw, const int32_t* widths, int cin, int n_layers) {
+    if (!ldw) return GAOT_OK;
+    for (int i = 0; i < n_layers; ++i) {
+        const int in_w = i == 0 ? cin : widths[i - 1];
+        GAOT_REQUIRE(ldw[i] == 0 || (ldw[i] >= in_w && (i == 0 || ldw[i] % 4 == 0)), "kernel_mlp: ldw[%d] = %d must be 0 (dense) or >= %d%s", i, ldw[i], in_w,
+                     i ? " and a multiple of 4" : "");
+    }
+    return GAOT_OK;
 }
 
 extern "C" int gaot_kernel_mlp_fwd_w(const float* x, int32_t E, int32_t cin, int32_t n_layers, const float* const* w,
-                                     const float* const* b, int32_t act, const int32_t* widths, float* out, gaot_stream_t stream) {
+                                     const float* const* b, int32_t act, const int32_t* widths, const int32_t* ldw, float* out, gaot_stream_t stream) {
     if (int rc = km_check(x, E, cin, n_layers, w, b)) return rc;
     if (int rc = km_widths_ok(widths, n_layers)) return rc;
+    if (int rc = km_ldw_ok(ldw, widths, cin, n_layers)) return rc;
     GAOT_REQUIRE(act == GAOT_ACT_GELU || act == GAOT_ACT_RELU, "kernel_mlp: hidden activation must be GAOT_ACT_GELU or GAOT_ACT_RELU (got %d)", act);
     GAOT_REQUIRE(out && aligned16(out), "kernel_mlp_fwd: out must be non-null and 16-byte aligned");
-    KMArgs a{}; km_fill(a, x, E, cin, n_layers, w, b, widths); a.out = out;
+    KMArgs a{}; km_fill(a, x, E, cin, n_layers, w, b, widths, ldw); a.out = out;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid(a.ntiles), block(256);
 #define KM_FWD2(NL, A) do { if (cin == 4) hipLaunchKernelGGL((kernel_mlp_fwd_kernel<NL, 4, A>), grid, block, 0, st, a); \
@@ -423,22 +437,23 @@ extern "C" int64_t gaot_kernel_mlp_bwd_workspace(int32_t E, int32_t cin, int32_t
 }
 
 extern "C" int gaot_kernel_mlp_bwd_w(const float* x, int32_t E, int32_t cin, int32_t n_layers, const float* const* w,
-                                     const float* const* b, int32_t act, const int32_t* widths, const float* dk, float* grads,
+                                     const float* const* b, int32_t act, const int32_t* widths, const int32_t* ldw, const float* dk, float* grads,
                                      float* workspace, gaot_stream_t stream);
 extern "C" int gaot_kernel_mlp_bwd(const float* x, int32_t E, int32_t cin, int32_t n_layers, const float* const* w,
                                    const float* const* b, int32_t act, const float* dk, float* grads, float* workspace,
                                    gaot_stream_t stream) {
-    return gaot_kernel_mlp_bwd_w(x, E, cin, n_layers, w, b, act, KM_W64, dk, grads, workspace, stream);
+    return gaot_kernel_mlp_bwd_w(x, E, cin, n_layers, w, b, act, KM_W64, nullptr, dk, grads, workspace, stream);
 }
 
 extern "C" int gaot_kernel_mlp_bwd_w(const float* x, int32_t E, int32_t cin, int32_t n_layers, const float* const* w,
-                                     const float* const* b, int32_t act, const int32_t* widths, const float* dk, float* grads,
+                                     const float* const* b, int32_t act, const int32_t* widths, const int32_t* ldw, const float* dk, float* grads,
                                      float* workspace, gaot_stream_t stream) {
     if (int rc = km_check(x, E, cin, n_layers, w, b)) return rc;
     if (int rc = km_widths_ok(widths, n_layers)) return rc;
+    if (int rc = km_ldw_ok(ldw, widths, cin, n_layers)) return rc;
     GAOT_REQUIRE(act == GAOT_ACT_GELU || act == GAOT_ACT_RELU, "kernel_mlp: hidden activation must be GAOT_ACT_GELU or GAOT_ACT_RELU (got %d)", act);
     GAOT_REQUIRE(dk && grads && workspace && aligned16(dk), "kernel_mlp_bwd: dk (16-byte aligned), grads, workspace must be non-null");
-    KMArgs a{}; km_fill(a, x, E, cin, n_layers, w, b, widths); a.dk = dk; a.ws = workspace;
+    KMArgs a{}; km_fill(a, x, E, cin, n_layers, w, b, widths, ldw); a.dk = dk; a.ws = workspace;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int grid = a.ntiles > 256 ? 256 : a.ntiles;
 #define KM_BWD2(NL, A) do { if (cin == 4) hipLaunchKernelGGL((kernel_mlp_bwd_kernel<NL, 4, A>), dim3(grid), dim3(256), 0, st, a); \
@@ -448,8 +463,13 @@ extern "C" int gaot_kernel_mlp_bwd_w(const float* x, int32_t E, int32_t cin, int
     if (n_layers == 2) KM_BWD(1); else if (n_layers == 3) KM_BWD(2); else KM_BWD(3);
 #undef KM_BWD
 #undef KM_BWD2
-    // fixed-order sum of the per-workgroup partial rows: the short-matrix column sum of pointwise.hip (<= 256 rows)
-    if (int rc = gaot_colsum(workspace, a.psize, grid, a.psize, grads, workspace, stream)) return rc;
     GAOT_CHECK_LAUNCH("gaot_kernel_mlp_bwd");
+    // fixed-order sum of the per-workgroup partial rows: the short-matrix column sum of pointwise.hip (<= 256 rows).
+    // grads == workspace: the caller sums the rows itself (gaot_colsum_grouped over parameter-sized column blocks, at the end of
+    // the backward pass): rows = gaot_kernel_mlp_bwd_rows(E), row stride = the parameter block size.
+    if (grads != workspace)
+        if (int rc = gaot_colsum(workspace, a.psize, grid, a.psize, grads, workspace, stream)) return rc;
     return GAOT_OK;
 }
+
+extern "C" int32_t gaot_kernel_mlp_bwd_rows(int32_t E) { int grid = cdiv(E, 128); return grid > 256 ? 256 : grid; }

@@ -264,8 +264,8 @@ __global__ __launch_bounds__(256) void colsum_small_kernel(const float* __restri
 // ---- grouped column sums: ONE launch over many small partial-row matrices (the per-workgroup partial rows of the norm-weight
 // and lifting gradients: each used to cost its own 5 us launch at the end of its backward node).  Same tiling as colsum_small_kernel
 // (16 columns per workgroup as 4 float4 lanes x 64 row groups, fixed-order LDS sum); the item table travels in the kernel arguments.
-constexpr int COLSUM_GROUP_MAX = 32;
-struct ColsumItem { const float* x; float* out; long ld; int M, N, wg_end; };
+constexpr int COLSUM_GROUP_MAX = 64;       // 64 x 56 B of table in the kernel arguments
+struct ColsumItem { const float* x; float* out; long ld; int M, N, wg_end, out_cols; long out_ld; };
 struct ColsumGroupArgs { int n; ColsumItem it[COLSUM_GROUP_MAX]; };
 __global__ __launch_bounds__(256) void colsum_grouped_kernel(const ColsumGroupArgs g) {
     __shared__ f32x4 red[64][4];
@@ -297,7 +297,11 @@ __global__ __launch_bounds__(256) void colsum_grouped_kernel(const ColsumGroupAr
         red[rg][c4] = t;
     }
     __syncthreads();
-    if (rg == 0 && n < N) *reinterpret_cast<f32x4*>(g.it[i].out + n) = (red[0][c4] + red[1][c4]) + (red[2][c4] + red[3][c4]);
+    if (rg == 0 && n < N) {
+        const int oc = g.it[i].out_cols;          // the sums form an [N / oc, oc] matrix stored with row stride out_ld (oc = N: one row)
+        float* dst = g.it[i].out + (long)(n / oc) * g.it[i].out_ld + (n % oc);
+        *reinterpret_cast<f32x4*>(dst) = (red[0][c4] + red[1][c4]) + (red[2][c4] + red[3][c4]);
+    }
 }
 __global__ void batchsum_kernel(const float* __restrict__ x, int B, long RN, float* __restrict__ out) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < RN; i += (long)gridDim.x * blockDim.x) {
@@ -483,8 +487,10 @@ extern "C" int gaot_colsum_grouped(const gaot_colsum_item* items, int32_t n, gao
     GAOT_REQUIRE(items != nullptr && n > 0, "colsum_grouped: no items");
     for (int i = 0; i < n; ++i)
         GAOT_REQUIRE(items[i].x && items[i].out && items[i].M > 0 && items[i].N > 0 && items[i].N % 4 == 0 && items[i].ld % 4 == 0 &&
-                     items[i].ld >= items[i].N && aligned16(items[i].x) && aligned16(items[i].out),
-                     "colsum_grouped: item %d needs N %% 4 == 0, ld %% 4 == 0 and 16-byte aligned pointers", i);
+                     items[i].ld >= items[i].N && aligned16(items[i].x) && aligned16(items[i].out) &&
+                     (items[i].out_cols == 0 || (items[i].out_cols % 4 == 0 && items[i].N % items[i].out_cols == 0 && items[i].out_ld % 4 == 0 &&
+                                                 items[i].out_ld >= items[i].out_cols)),
+                     "colsum_grouped: item %d needs N %% 4 == 0, ld %% 4 == 0, 16-byte aligned pointers (and out_cols | N, out_cols, out_ld %% 4 == 0)", i);
     for (int i0 = 0; i0 < n; i0 += COLSUM_GROUP_MAX) {
         ColsumGroupArgs a;
         a.n = n - i0 < COLSUM_GROUP_MAX ? n - i0 : COLSUM_GROUP_MAX;
@@ -492,7 +498,7 @@ extern "C" int gaot_colsum_grouped(const gaot_colsum_item* items, int32_t n, gao
         for (int i = 0; i < a.n; ++i) {
             const gaot_colsum_item& it = items[i0 + i];
             wg += cdiv(it.N, 16);
-            a.it[i] = ColsumItem{it.x, it.out, (long)it.ld, it.M, it.N, wg};
+            a.it[i] = ColsumItem{it.x, it.out, (long)it.ld, it.M, it.N, wg, it.out_cols > 0 ? it.out_cols : it.N, it.out_cols > 0 ? (long)it.out_ld : (long)it.N};
         }
         hipLaunchKernelGGL(colsum_grouped_kernel, dim3(wg), dim3(256), 0, ST(stream), a);
         GAOT_CHECK_LAUNCH("gaot_colsum_grouped");

@@ -143,7 +143,9 @@ class _MAGNOBase(nn.Module):
         if self.use_geoembed:
             w = self.recovery.fcs[0].weight.squeeze(-1)                                             # [C, 2C]
             C = w.shape[0]
-            w_agno, w_geo = ops.split_cols(w, C)      # one gradient assembly instead of two slice-backward chains
+            # one gradient assembly instead of two slice-backward chains; with a registered gradient slice the two halves are
+            # written in place by the layers that use them
+            w_agno, w_geo = ops.split_cols(w, C, param=self.recovery.fcs[0].weight)
             key = None
             if not torch.is_grad_enabled() and nb is neighbors:
                 # inference (autoregressive rollouts): geometry and weights are fixed across steps -> keep the row bias
@@ -161,7 +163,7 @@ class _MAGNOBase(nn.Module):
                     self._infer_cache["rowb"] = (key, nb, rowb, (src_coord, dst_coord))      # hold the tensors: ids stay unique
             if head is not None:
                 hw, hb = head
-                proj = (ops.linear(hw, w_agno.t()),              # [out, C] = W @ Wr1   (tiny)
+                proj = (ops.matmul(hw, w_agno),                  # [out, C] = W @ Wr1   (tiny; operands read in place)
                         ops.linear(rowb, hw, hb), None)          # [n_dst, out]
         elif head is not None:
             proj = (head[0], None, head[1])

@@ -294,8 +294,8 @@ def flush_wgrad() -> None:
         cs = list(_COLSUM_QUEUE)
         _COLSUM_QUEUE.clear()
         arr = (L.ColsumItem * len(cs))()
-        for i, (x2, ld, out, M, N) in enumerate(cs):
-            arr[i] = L.ColsumItem(x2.data_ptr(), ld, out.data_ptr(), M, N)
+        for i, (x2, ld, out, M, N, oc, old_) in enumerate(cs):
+            arr[i] = L.ColsumItem(x2.data_ptr(), ld, out.data_ptr(), M, N, oc, old_)
         L.check(L.load().gaot_colsum_grouped(arr, len(cs), _stream()), "gaot_colsum_grouped")
     if not _WGRAD_QUEUE:
         return
@@ -311,10 +311,16 @@ def colsum(x2: torch.Tensor, out: Optional[torch.Tensor] = None, final: bool = F
     M, N = x2.shape
     lib = L.load()
     if (final and out is not None and _WGRAD_DEPTH[0] > 0 and _WGRAD_GROUPED and N % 4 == 0 and ld % 4 == 0 and M <= 8192
-            and out.is_contiguous() and not ((x2.data_ptr() | out.data_ptr()) & 15)):
-        _COLSUM_QUEUE.append((x2, ld, out.detach().view(-1), M, N))
-        _note_deferred(out.view(-1))
-        return out
+            and not ((x2.data_ptr() | out.data_ptr()) & 15)):
+        if out.is_contiguous():
+            _COLSUM_QUEUE.append((x2, ld, out.detach(), M, N, 0, 0))
+            _note_deferred(out.view(-1))
+            return out
+        if out.dim() == 2 and out.stride(1) == 1 and out.numel() == N and out.shape[1] % 4 == 0 and out.stride(0) % 4 == 0:
+            # a column block of a wider gradient matrix (a slice handed out by split_cols)
+            _COLSUM_QUEUE.append((x2, ld, out.detach(), M, N, out.shape[1], out.stride(0)))
+            _note_deferred(out)
+            return out
     if out is None:
         out = torch.empty(N, device=x2.device, dtype=torch.float32)
     scratch = torch.empty(int(lib.gaot_colsum_scratch(M, N)), device=x2.device, dtype=torch.float32)
@@ -350,6 +356,9 @@ def register_grad_slots(params, views):
 
 
 def release_grad_slots():
+    for k in _TEMP_SLOT_IDS:          # slices inherited by temporaries of the last forward pass (split_cols)
+        _GRAD_SLOTS.pop(k, None)
+    _TEMP_SLOT_IDS.clear()
     for s in _GRAD_SLOTS.values():
         s[1] = False
     _DEFERRED_DESTS.clear()
@@ -468,28 +477,86 @@ def linear(x, w, b=None, residual=None, rowbias=None, x2=None):
     return _Linear.apply(x, w, b, residual, rowbias, x2)
 
 
+class _MatMul(torch.autograd.Function):
+    """y[M,N] = a[M,K] @ b[K,N] with both operands as they lie in memory (no transposed copy of either): the folded
+    projection o recovery weight of the decoder, W_proj @ W_rec[:, :C] (magno.py:640-641 after 345-350)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _dev(a, b)
+        a2, lda = _rowmajor(a)
+        b2, ldb = _rowmajor(b)
+        M, K = a2.shape
+        N = b2.shape[1]
+        assert b2.shape[0] == K, (a.shape, b.shape)
+        out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+        gemm(M, N, K, a2, lda, 1, b2, ldb, 0, out, N)
+        ctx.save_for_backward(a2, b2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a2, b2 = ctx.saved_tensors
+        g, _ = _rowmajor(g)
+        da = linear_nt(g, b2) if ctx.needs_input_grad[0] else None          # g [M,N] @ b[K,N]^T
+        db = matmul_tn(a2, g) if ctx.needs_input_grad[1] else None          # a[M,K]^T @ g [M,N]
+        return da, db
+
+
+def matmul(a, b):
+    return _MatMul.apply(a, b)
+
+
 class _SplitCols(torch.autograd.Function):
     """w [N, K] -> (w[:, :c], w[:, c:]) as views; the backward writes both column blocks into ONE gradient (autograd's
     own slice nodes would zero-fill two full-size gradients, copy a block into each and add them)."""
 
     @staticmethod
-    def forward(ctx, w, c):
-        ctx.c, ctx.shape = c, w.shape
+    def forward(ctx, w, c, slot):
+        ctx.c, ctx.shape, ctx.slot = c, w.shape, slot
         return w[:, :c], w[:, c:]
 
     @staticmethod
     def backward(ctx, g1, g2):
         N, K = ctx.shape
+        s_ = ctx.slot
+        if s_ is not None:
+            # the views carried the parameter's own slice: a block whose consumer wrote its gradient in place (possibly by a
+            # deferred launch that has not run yet -- never READ such a block here) is final; any other block is copied in
+            for g_, blk in ((g1, s_[:, :ctx.c]), (g2, s_[:, ctx.c:])):
+                if g_ is None:
+                    blk.zero_()
+                elif not (g_.data_ptr() == blk.data_ptr() and g_.stride(0) == K):
+                    blk.copy_(g_)
+            return s_.detach(), None, None
         ref = g1 if g1 is not None else g2
         if g1 is None:
             g1 = ref.new_zeros(N, ctx.c)
         if g2 is None:
             g2 = ref.new_zeros(N, K - ctx.c)
-        return torch.cat([g1, g2], dim=1), None
+        return torch.cat([g1, g2], dim=1), None, None
 
 
-def split_cols(w, c: int):
-    return _SplitCols.apply(w, c)
+_TEMP_SLOT_IDS: list = []
+
+
+def split_cols(w, c: int, param=None):
+    """(w[:, :c], w[:, c:]).  `param`: the nn.Parameter w is a reshaped view of (a Conv1d weight with its trailing singleton
+    dimension squeezed).  When that parameter's gradient slice is registered, the two views inherit its column blocks as THEIR
+    gradient slices: the layers that consume the views write their weight gradients straight into the parameter's slice and the
+    backward of the split hands that slice on (no concatenation, no copy into the flat buffer)."""
+    owner = w if param is None else param
+    slot = _claim(owner) if torch.is_grad_enabled() else None
+    s2 = slot.detach().view(w.shape[0], -1) if (slot is not None and w.dim() == 2 and slot.numel() == w.numel()
+                                                 and c % 4 == 0 and (w.shape[1] - c) % 4 == 0) else None
+    if slot is not None and s2 is None:
+        _GRAD_SLOTS[id(owner)][1] = False         # not forwarded: give the claim back
+    a, b = _SplitCols.apply(w, c, s2)
+    if s2 is not None:
+        for v, blk in ((a, s2[:, :c]), (b, s2[:, c:])):
+            _GRAD_SLOTS[id(v)] = [blk, False, v]
+            _TEMP_SLOT_IDS.append(id(v))
+    return a, b
 
 
 def adjacent_rows(ws: Sequence[torch.Tensor]) -> Optional[torch.Tensor]:
@@ -677,16 +744,21 @@ class _KernelMLP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, n, act, *wb):
         x = x.contiguous()
-        ws = [w.contiguous() for w in wb[:n]]
+        # a weight that is a column block of a wider matrix (the geoembed half of the recovery weight: split_cols) is read in
+        # place through its row stride; anything else non-contiguous is copied
+        ws = [w if (w.dim() == 2 and w.stride(1) == 1 and w.stride(0) >= w.shape[1] and w.stride(0) % 4 == 0 and not (w.data_ptr() & 15))
+              else w.contiguous() for w in wb[:n]]
         bs = [b.contiguous() for b in wb[n:]]
         _dev(x, *ws, *bs)
         E, cin = x.shape
         widths = (C.c_int32 * n)(*[int(w.shape[0]) for w in ws])
+        ldw = (C.c_int32 * n)(*[int(w.stride(0)) if w.shape[0] > 1 else 0 for w in ws])
         out = torch.empty(E, ws[-1].shape[0], device=x.device, dtype=torch.float32)
-        L.check(L.load().gaot_kernel_mlp_fwd_w(_p(x), E, cin, n, _KernelMLP._ptrs(ws), _KernelMLP._ptrs(bs), act, widths, _p(out), _stream()),
+        L.check(L.load().gaot_kernel_mlp_fwd_w(_p(x), E, cin, n, _KernelMLP._ptrs(ws), _KernelMLP._ptrs(bs), act, widths, ldw, _p(out), _stream()),
                 "gaot_kernel_mlp_fwd")
         ctx.save_for_backward(x, *ws, *bs)
         ctx.n, ctx.act = n, act
+        ctx.slots = [_claim(t) for t in wb]        # the parameters' slices of the flat gradient buffer (weights, then biases)
         return out
 
     @staticmethod
@@ -702,9 +774,27 @@ class _KernelMLP(torch.autograd.Function):
         wsp = torch.empty(int(lib.gaot_kernel_mlp_bwd_workspace(E, cin, n)), device=x.device, dtype=torch.float32)
         wo = [int(w.shape[0]) for w in ws]
         widths = (C.c_int32 * n)(*wo)
-        L.check(lib.gaot_kernel_mlp_bwd_w(_p(x), E, cin, n, _KernelMLP._ptrs(ws), _KernelMLP._ptrs(bs), ctx.act, widths, _p(dk), _p(grads),
-                                          _p(wsp), _stream()), "gaot_kernel_mlp_bwd")
+        ldw = (C.c_int32 * n)(*[int(w.stride(0)) if w.shape[0] > 1 else 0 for w in ws])
         o = (n - 1) * 4096
+        slots = ctx.slots
+        if (_WGRAD_DEPTH[0] > 0 and _WGRAD_GROUPED and all(s_ is not None for s_ in slots) and all(v == 64 for v in wo)
+                and (64 * cin) % 4 == 0 and all(ctx.needs_input_grad[3:])):
+            # every parameter has its slice and every layer is 64 wide (the blocks of the partial rows ARE the parameters' layouts):
+            # the per-workgroup partial rows are summed per parameter, straight into the slices, by the grouped column-sum launch
+            # at the end of the backward pass -- no row sum here, no packed gradient buffer, no copy into the flat buffer later
+            L.check(lib.gaot_kernel_mlp_bwd_w(_p(x), E, cin, n, _KernelMLP._ptrs(ws), _KernelMLP._ptrs(bs), ctx.act, widths, ldw, _p(dk), _p(wsp),
+                                              _p(wsp), _stream()), "gaot_kernel_mlp_bwd")
+            rows = int(lib.gaot_kernel_mlp_bwd_rows(E))
+            part = wsp[:rows * psize].view(rows, psize)
+            blocks = [(o, 64 * cin)] + [(m * 4096, 4096) for m in range(n - 1)] + [(o + 64 * cin + 64 * i, 64) for i in range(n)]
+            outs = []
+            for (off, width), slot in zip(blocks, slots):
+                dst = slot.detach()
+                outs.append(colsum(part[:, off:off + width], out=dst if (dst.dim() == 2 and not dst.is_contiguous()) else dst.view(-1),
+                                   final=True).view(slot.shape))
+            return (None, None, None, *outs)
+        L.check(lib.gaot_kernel_mlp_bwd_w(_p(x), E, cin, n, _KernelMLP._ptrs(ws), _KernelMLP._ptrs(bs), ctx.act, widths, ldw, _p(dk), _p(grads),
+                                          _p(wsp), _stream()), "gaot_kernel_mlp_bwd")
         # 64 x 64 blocks (64 x cin for the first layer) whose leading [out, in] corner is the gradient; the padding carries zeros
         dws = [grads[o:o + 64 * cin].view(64, cin)[:wo[0]]]
         for m in range(n - 1):

@@ -320,6 +320,7 @@ class TrainStep:
         self._kwargs: Dict = {}
         self._cuts: Optional[_Cuts] = None
         self._checked_phases = False
+        self.comm_enabled = True      # False: skip the gradient exchange (bench.py measures the exposed communication as the difference)
 
     # ---- the eager pieces
     def _forward_loss(self):
@@ -342,10 +343,18 @@ class TrainStep:
         """backward pass with the weight-gradient products deferred to ONE grouped launch at its end (ops.deferred_wgrad)"""
         if t.is_cuda:
             from . import ops
+            if grad is None and t.dim() == 0:
+                # the seed gradient of the loss: a kept 1.0 instead of the ones_like() fill autograd would launch every step
+                one = TrainStep._ONES.get(t.device)
+                if one is None:
+                    one = TrainStep._ONES[t.device] = torch.ones((), device=t.device, dtype=t.dtype)
+                grad = one
             with ops.deferred_wgrad():
                 t.backward(grad)
         else:
             t.backward(grad)
+
+    _ONES: Dict = {}
 
     def _phase0(self):
         """staged: forward with cut points + the backward of phase 0 (everything after the last cut)"""
@@ -447,14 +456,16 @@ class TrainStep:
         self.opt.sync_hyper()                    # a scheduler may have moved lr since the last step (device buffer, no re-capture)
         if not self.staged:
             self._graphs[0].replay()
-            self.bucket.all_reduce_mean(self.group)      # one flat RCCL all-reduce between the two graphs
+            if self.comm_enabled:
+                self.bucket.all_reduce_mean(self.group)      # one flat RCCL all-reduce between the two graphs
         else:
             # everything below is enqueued without a host wait: phase k's slice is reduced on RCCL's stream while the main
             # stream replays the backward of phase k+1
             works = []
             for k, g in enumerate(self._graphs):
                 g.replay()
-                works.append(self.bucket.all_reduce_mean(self.group, k, async_op=True))
+                if self.comm_enabled:
+                    works.append(self.bucket.all_reduce_mean(self.group, k, async_op=True))
             for w in works:
                 if w is not None:
                     w.wait()

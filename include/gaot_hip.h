@@ -268,7 +268,11 @@ int gaot_colsum(const float* x, int64_t ld, int32_t M, int32_t N, float* out, fl
 /* Grouped column sums: out_i[n] = sum_m x_i[m*ld_i + n] for n small partial-row matrices in ONE launch (the per-workgroup partial
  * rows behind the norm-weight gradients attn.py:161-172 and the lifting gradient magno.py:273-274, reduced at the end of a backward
  * pass).  N % 4 == 0, ld % 4 == 0, 16-byte aligned pointers; fixed summation order (deterministic). */
-typedef struct gaot_colsum_item { const float* x; int64_t ld; float* out; int32_t M, N; } gaot_colsum_item;
+typedef struct gaot_colsum_item {
+    const float* x; int64_t ld; float* out; int32_t M, N;
+    int32_t out_cols; int64_t out_ld;   /* 0, 0: out is N contiguous floats; else the N sums are an [N / out_cols, out_cols] matrix stored with
+                                           row stride out_ld (a column block of a wider gradient matrix); out_cols % 4 == 0 */
+} gaot_colsum_item;
 int gaot_colsum_grouped(const gaot_colsum_item* items, int32_t n, gaot_stream_t stream);
 int gaot_batchsum(const float* x, int32_t B, int64_t RN, float* out, gaot_stream_t stream);
 /* Fused row-wise MLP, every width 64: the kernel MLP of the integral transform (LinearChannelMLP, mlp.py:307-337, called per
@@ -283,16 +287,22 @@ int gaot_batchsum(const float* x, int32_t B, int64_t RN, float* out, gaot_stream
 int gaot_kernel_mlp_fwd(const float* x, int32_t E, int32_t c_in, int32_t n_layers, const float* const* w,
                         const float* const* b, int32_t act, float* out, gaot_stream_t stream);
 int64_t gaot_kernel_mlp_bwd_workspace(int32_t E, int32_t c_in, int32_t n_layers);
+/* rows of per-workgroup partial gradients the backward leaves in `workspace` (row stride = the parameter block size); passing
+ * grads == workspace skips the final row sum: the caller reduces column blocks itself (gaot_colsum_grouped). */
+int32_t gaot_kernel_mlp_bwd_rows(int32_t E);
 int gaot_kernel_mlp_bwd(const float* x, int32_t E, int32_t c_in, int32_t n_layers, const float* const* w,
                         const float* const* b, int32_t act, const float* dk, float* grads, float* workspace, gaot_stream_t stream);
 /* the same pair for layers narrower than 64: widths[i] = output width of layer i (multiples of 4 in 4..64, e.g. 48 lifting
  * channels); weight i is [widths[i]][widths[i-1]] row-major (layer 0: [widths[0]][cin]), out / dk are [E, widths[n-1]].  The chain
  * runs zero-padded at width 64; the gradient vector keeps its layout of 64 x 64 blocks, of which the leading
- * widths[i] x widths[i-1] corner is meaningful (the rest is zero). */
+ * widths[i] x widths[i-1] corner is meaningful (the rest is zero).
+ * ldw (optional, NULL = dense): ldw[i] = row stride of weight i in floats (0 = dense; a column block of a wider matrix -- the
+ * geoembed half of the recovery weight, magno.py:345-350 -- is read in place). */
 int gaot_kernel_mlp_fwd_w(const float* x, int32_t E, int32_t cin, int32_t n_layers, const float* const* w, const float* const* b,
-                          int32_t act, const int32_t* widths, float* out, gaot_stream_t stream);
+                          int32_t act, const int32_t* widths, const int32_t* ldw, float* out, gaot_stream_t stream);
 int gaot_kernel_mlp_bwd_w(const float* x, int32_t E, int32_t cin, int32_t n_layers, const float* const* w, const float* const* b,
-                          int32_t act, const int32_t* widths, const float* dk, float* grads, float* workspace, gaot_stream_t stream);
+                          int32_t act, const int32_t* widths, const int32_t* ldw, const float* dk, float* grads, float* workspace,
+                          gaot_stream_t stream);
 /* nn.MSELoss() with mean reduction (the reference trainers' loss, base_trainer.py:71): loss[0] = mean((pred - target)^2) over
  * n elements through `partial` (>= 256 floats; fixed-order two-stage sum, deterministic); backward
  * dpred = 2 (pred - target) / n * grad_loss[0] with grad_loss a DEVICE scalar (so the launch replays inside a hipGraph). */

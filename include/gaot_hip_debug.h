@@ -32,9 +32,15 @@ int gaot_debug_set_split_persist(int n);
 /* 1: the fp32-level bf16-pipe products use the LDS-direct kernel (fp32 tiles by DMA, operands split in registers) instead of the
  * plane kernel; 0: the plane kernel (gemm_split.hip).  Returns the old value. */
 int gaot_debug_set_gemm_gsplit(int on);
+/* grouped weight gradients: values of k per workgroup (K slab length; multiple of 32, default 2048) */
+int gaot_debug_set_wgrad_kslab(int k);
 /* tuning hook: head_dim 32 attention, 1 = split-bf16 MFMA kernels (default), 0 = fp32-MFMA kernels, 2 / 3 = split with the
  * 8-wave / 4-wave forward workgroup forced.  Returns the previous value. */
 int gaot_debug_set_attention_split(int on);
+/* head_dim-32 split attention: pieces of P in the forward and of P / dS in the backward products, as 10 * forward + backward:
+ * 32 (default) = exact three-way split forward, two rounded pieces (five piece products instead of six) backward; 33, 22, 23 for
+ * A/B runs.  Returns the previous value. */
+int gaot_debug_set_attention_p_pieces(int n);
 /* tuning hook: 1 = the software-pipelined 8-wave split forward where it applies (S % 64 == 0), 0 (default) = the plain one.
  * Returns the previous value. */
 int gaot_debug_set_attention_pipe(int on);

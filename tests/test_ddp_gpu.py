@@ -47,11 +47,16 @@ def _flat(model):
     return torch.cat([p.detach().reshape(-1) for p in model.parameters()])
 
 
-def _worker(rank, world, port, out, graph, staged):
+def _worker(rank, world, port, out, graph, staged, backend="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # gloo: every rank on cuda:0 (one-GPU boxes);  nccl (= RCCL): one device per rank
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from gaot_amd.trainer import TrainStep, shard_indices
-    dev = torch.device("cuda:0")
     model = _build(seed=300 + rank).to(dev).train()           # ranks start DIFFERENT (reference: seed + rank); rank 0 is broadcast
     lat, x, p, t = _data()
     idx = shard_indices(4, rank, world, shuffle=False)
@@ -71,12 +76,11 @@ def _worker(rank, world, port, out, graph, staged):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("graph,staged", [(True, None), (False, None), (True, False)])
-def test_gaot_two_ranks_one_gpu_equals_single_process_global_batch(graph, staged):
+def _two_ranks(graph, staged, backend):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, graph, staged)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, graph, staged, backend)) for r in range(2)]
     for p in procs:
         p.start()
     p0, p1, losses = q.get(timeout=600)
@@ -97,6 +101,49 @@ def test_gaot_two_ranks_one_gpu_equals_single_process_global_batch(graph, staged
     ref = _flat(model).cpu()
     # 3 AdamW steps of 2e-3 each: the weights moved by ~6e-3 per entry; agreement to 2e-5 absolute = gradients agree
     assert float((p0 - ref).abs().max()) < 2e-5, float((p0 - ref).abs().max())
+
+
+@pytest.mark.parametrize("graph,staged", [(True, None), (False, None), (True, False)])
+def test_gaot_two_ranks_one_gpu_equals_single_process_global_batch(graph, staged):
+    _two_ranks(graph, staged, "gloo")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
+@pytest.mark.parametrize("graph,staged", [(True, None), (False, None)])
+def test_gaot_two_ranks_two_gpus_over_rccl(graph, staged):
+    """the same check with one device per rank and the gradient exchange on RCCL (ReduceOp.AVG, async per phase slice): ranks end
+    bit-identical and equal to single-process training on the global batch.  Skipped on one-GPU boxes."""
+    _two_ranks(graph, staged, "nccl")
+
+
+def _bench_line_two_ranks(env_extra):
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env={**os.environ, **env_extra})
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_two_ranks_on_one_gpu_over_gloo_line():
+    """bench.py's N = 2 code path as the driver launches it (torch.distributed.run, two ranks), with both ranks on cuda:0 over gloo
+    (bench.py's test hooks; RCCL needs one device per rank): staged backward, per-phase exchange, MAX-over-ranks timing, `comm`"""
+    line = _bench_line_two_ranks({"GAOT_BENCH_FORCE_DEVICE": "0", "GAOT_BENCH_BACKEND": "gloo"})
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 16 and line["value"] > 0
+    assert len(line["comm"]["slices"]) == line["config"]["staged_backward_phases"] == 4
+    assert sum(s["bytes"] for s in line["comm"]["slices"]) >= 4 * line["config"]["params"]
+    assert line["comm"]["ms_per_step_without_exchange"] > 0
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_bench_two_gpus_rccl_line():
+    """bench.py exactly as the driver launches it for N = 2: one JSON line with n_gpus 2, weak scaling, and the `comm` object
+    (per-slice all-reduce times, exposed communication)"""
+    line = _bench_line_two_ranks({})
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 16 and line["value"] > 0
+    assert len(line["comm"]["slices"]) == line["config"]["staged_backward_phases"] == 4
+    assert sum(s["bytes"] for s in line["comm"]["slices"]) >= 4 * line["config"]["params"]
 
 
 def test_staged_single_rank_equals_unstaged():

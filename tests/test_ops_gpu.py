@@ -1134,3 +1134,28 @@ def test_deferred_wgrad_scope_equals_immediate_products():
         assert len(ops._WGRAD_QUEUE) == 1 and rel(tmp, want) < 2e-6
     assert not ops._WGRAD_QUEUE
     assert rel(out, want) < 2e-6 and maxrel(db, dy.double().sum(0)) < 5e-6
+
+
+def test_colsum_grouped_contiguous_and_column_block_outputs():
+    """gaot_colsum_grouped through ops.colsum(final=True) inside a deferral scope: many small partial-row matrices, strided inputs
+    (column blocks of one workspace), outputs that are contiguous vectors or column blocks of a wider matrix"""
+    from gaot_amd import ops
+    g = torch.Generator().manual_seed(21)
+    ws = torch.randn(200, 12800, generator=g).to(dev())
+    wide = torch.zeros(64, 128, device=dev())
+    outs, refs = [], []
+    with ops.deferred_wgrad():
+        for off, width in ((0, 4096), (4096, 256), (12288, 64), (8192, 4096)):
+            o = torch.zeros(width, device=dev())
+            assert ops.colsum(ws[:, off:off + width], out=o, final=True) is o
+            outs.append(o); refs.append(ws[:, off:off + width].double().sum(0))
+        blk = wide[:, 64:]
+        assert ops.colsum(ws[:, 4352:4352 + 4096], out=blk, final=True) is blk
+        small = torch.randn(37, 256, generator=g).to(dev())
+        o2 = torch.zeros(256, device=dev())
+        ops.colsum(small, out=o2, final=True)
+        assert len(ops._COLSUM_QUEUE) == 6 and float(o2.abs().sum()) == 0.0          # nothing computed yet
+    for o, r in zip(outs, refs):
+        assert maxrel(o, r) < 2e-6
+    assert maxrel(wide[:, 64:], ws[:, 4352:4352 + 4096].double().sum(0).view(64, 64)) < 2e-6 and float(wide[:, :64].abs().sum()) == 0.0
+    assert maxrel(o2, small.double().sum(0)) < 2e-6

@@ -54,7 +54,9 @@ ref = [o.clone() for _, _, o in ops_in]
 grouped()
 torch.cuda.synchronize()
 err = max(float((o.double() - r.double()).norm() / r.double().norm()) for (_, _, o), r in zip(ops_in, ref))
-for rep in range(2):
-    us_s, us_g = timed(single), timed(grouped)
-    print(f"single launches {us_s:8.1f} us ({flops / us_s / 1e6:6.1f} TF/s)   grouped {us_g:8.1f} us ({flops / us_g / 1e6:6.1f} TF/s)   "
+from gaot_amd import _lib
+for rep, kslab in enumerate((1024, 2048, 4096, 1024, 2048, 4096)):
+    _lib.load().gaot_debug_set_wgrad_kslab(kslab)
+    us_s, us_g = (timed(single) if rep == 0 else us_s), timed(grouped)
+    print(f"kslab {kslab}: single launches {us_s:8.1f} us ({flops / us_s / 1e6:6.1f} TF/s)   grouped {us_g:8.1f} us ({flops / us_g / 1e6:6.1f} TF/s)   "
           f"max rel diff {err:.2e}", flush=True)
