@@ -348,6 +348,8 @@ static int g_gsplit = 0;         // 1: split-eligible products run on gemm_gspli
 extern "C" int gaot_debug_set_gemm_gsplit(int on) { const int old = g_gsplit; g_gsplit = on; return old; }
 static int g_split_pieces = 3;   // 3: fp32-level products (default); 1: operands rounded to bf16, one piece product (bench `--dtype bf16` only)
 extern "C" int gaot_debug_set_gemm_pieces(int n) { const int old = g_split_pieces; g_split_pieces = (n == 1) ? 1 : 3; return old; }
+static int g_use_planes = 1;     // 0: ignore gaot_gemm_desc.b_planes (A/B switch)
+extern "C" int gaot_debug_set_gemm_planes(int on) { const int old = g_use_planes; g_use_planes = on; return old; }
 static int g_ablate = 0;
 extern "C" int gaot_debug_set_gemm_ablate(int bits) { const int old = g_ablate; g_ablate = bits; return old; }
 static int g_tile_override = 0;   // tuning hook: 0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 128x32
@@ -390,6 +392,10 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
     a.split_k = split; a.ktiles_per_split = cdiv(nkt, split); a.ws = d->workspace;
     a.colsum = d->colsum;
     a.ablate = g_ablate;
+    // B pre-split into bf16 planes (weights): only the split-bf16 tile kernels read them; every other path uses B itself
+    a.Bpl = nullptr; a.ld_bpl = 0; a.bpl_stride = 0;
+    const bool planes_ok = d->b_planes != nullptr && g_use_planes && g_split_pieces == 3 && !g_gsplit && aligned16(d->b_planes) &&
+                           d->ld_bplanes % 8 == 0 && d->b_plane_stride % 8 == 0 && d->K % 16 == 0;
     {
         auto ok4 = [](const void* ptr, long ld) { return ptr == nullptr || (aligned16(ptr) && ld % 4 == 0); };
         a.vec_epi = (a.N % 4 == 0) && aligned16(a.C) && (a.ldc % 4 == 0) && ok4(a.bias, 4) && ok4(a.rowbias, a.ld_rb) &&
@@ -410,6 +416,7 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
         if (g_use_split == 2 || (g_use_split && nb128 >= 256)) {
             g_last_path = 3;
             const bool big = a.M >= 256 && (g_split_bm256 == 2 || (g_split_bm256 == 1 && nb128 >= 500));
+            if (planes_ok) { a.Bpl = reinterpret_cast<const unsigned short*>(d->b_planes); a.ld_bpl = d->ld_bplanes; a.bpl_stride = d->b_plane_stride; }
             if (g_gsplit) launch_gsplit(a, ak, bk, st, 128, g_split_pieces);
             else launch_split(a, ak, bk, st, big && g_split_pieces == 3 ? 256 : 128, g_split_pieces);
         }
@@ -440,10 +447,12 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
     const bool split128 = split_ok && g_use_split != 4 &&
                           (g_use_split == 2 || (blocks(128, 128) >= 250 && a.M >= 128 && a.N >= 128 && (long)cdiv(a.M, 128) * cdiv(a.N, 128) >= 8));
     // outputs only a few 128-wide tiles across (N = 256): 64-row tiles double the workgroup count
+    // (with pre-split B planes an NN product stages B exactly like an NT one)
     const bool split64 = split_ok && !split128 && g_use_split != 5 && g_use_split != 2 &&
-                         (g_use_split == 4 || ((ak && (bk || g_use_split == 6)) && blocks(64, 128) >= 250 && a.M >= 64 && a.N >= 128 && a.split_k <= 1));   // measured: NT +6-14 %, NN +-0
+                         (g_use_split == 4 || ((ak && (bk || planes_ok || g_use_split == 6)) && blocks(64, 128) >= 250 && a.M >= 64 && a.N >= 128 && a.split_k <= 1));   // measured: NT +6-14 %, NN +-0
     if (split128 || split64) {
         g_last_path = 3;
+        if (planes_ok) { a.Bpl = reinterpret_cast<const unsigned short*>(d->b_planes); a.ld_bpl = d->ld_bplanes; a.bpl_stride = d->b_plane_stride; }
         // 256x128 (8-wave) tiles: measured +3-7 % on the NT / TN products that still give ~200 workgroups, -2 % on NN
         const bool big = split128 && a.M >= 512 && (g_split_bm256 == 2 || (g_split_bm256 == 1 && ak == bk && blocks(256, 128) >= 190));
         if (g_gsplit) launch_gsplit(a, ak, bk, st, split64 ? 64 : 128, g_split_pieces);

@@ -15,6 +15,7 @@ struct GemmArgs {
     int split_k; int ktiles_per_split; float* ws;
     float* colsum;          // optional (A m-major only): colsum[m] = sum_k Aop[m,k]  (bias gradient fused into dW = dY^T X)
     int tiles_m, tiles_n;
+    const unsigned short* Bpl; long ld_bpl; long bpl_stride;   // optional: B pre-split into three k-contiguous bf16 planes (gemm_split.hip BPL)
     int vec_epi;            // 1: N, ldc and every epilogue operand allow 16-byte accesses -> LDS-transposed vector epilogue
     int ablate;             // tuning only (gaot_debug_set_gemm_ablate): 1 = no in-loop global loads, 2 = no LDS staging/barriers, 4 = no stores
 };

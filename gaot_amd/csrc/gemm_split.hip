@@ -62,7 +62,12 @@ struct SplitGeom {
 // FLUSH > 0: every FLUSH k-tiles (16 k each) the MFMA accumulators are added to running sums on the VECTOR pipe and restart from
 // zero: the bf16 MFMA does not round its accumulator to nearest, so one matrix-pipe accumulation run stays at FLUSH * 16 <= 1 024
 // values of k however long the workgroup's reduction is (costs TM * TN * 16 more registers: the grouped TN kernel has them)
-template <bool AK, bool BKM, int BM, int ABL, int NP, int FLUSH = 0>
+// BPL: the B operand arrives ALREADY split (p.Bpl: three bf16 planes of B^T-or-B laid out k-contiguous, element (n, k) of plane q
+// at q * bpl_stride + n * ld_bpl + k -- weights, split once per optimizer step by gaot_split_planes_grouped): its tiles go from the
+// global-load registers to LDS as they are (no split arithmetic, half of the tile's vector work); bit-identical products, since the
+// planes are what split3_pair would have produced here.  Requires BKM (the planes are k-contiguous whatever B's own layout).
+struct BRegs { f32x4 f[2]; u32x4 pl[3]; };
+template <bool AK, bool BKM, int BM, int ABL, int NP, int FLUSH = 0, bool BPL = false>
 __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* smem_raw, const int logical, const int zs) {
     using G = SplitGeom<BM>;
     constexpr int BN = G::BN, NW = G::NW, NT = G::NT, WAVES_N = G::WAVES_N, WM = G::WM, WN = G::WN, TM = G::TM, TN = G::TN;
@@ -92,7 +97,9 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
     // row-contiguous (128-row tiles): kp = tid & 7 (k pair), r4 = tid >> 3 (4 rows); q = which k of the pair.  The packed
     // (k, k+1) dwords are written TRANSPOSED into the k-contiguous plane layout (4 x ds_write_b32 per plane), so every
     // operand is read back with ds_read_b128 whatever its layout in memory
+    static_assert(!BPL || (BKM && NP == 3), "pre-split B planes are k-contiguous three-piece planes");
     const float* a_src[2]; const float* b_src[2];
+    const unsigned short* bp_src = nullptr;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         if (AK) {
@@ -111,13 +118,15 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
                 nrow = (within / (WN / 2)) * F + min(gcol, F - 1);
             }
             b_src[q] = B_FULL ? p.B + (long)nrow * p.ldb + (tid & 1) * 8 + q * 4 : p.B + (long)nrow * p.ldb + (tid & 3) * 4;
+            if (BPL) bp_src = B_FULL ? p.Bpl + (long)nrow * p.ld_bpl + (tid & 1) * 8 : p.Bpl + (long)nrow * p.ld_bpl + (tid & 3) * 4;
         } else {      // 128 rows: (k pair = tid & 7, row quad = tid >> 3) for the first 256 threads
             b_src[q] = p.B + (long)(2 * (tid & 7) + q) * p.ldb + min(n0 + ((tid >> 3) & 31) * 4, p.N - 4);
         }
     }
     // two register sets: tile j lives in set j & 1 (loads run two k-tiles ahead of the MFMAs, the split one ahead)
-    f32x4 ra[2][2], rb[2][2];
-    auto gload = [&](int kt, f32x4 (&xa)[2], f32x4 (&xb)[2]) {
+    f32x4 ra[2][2];
+    BRegs rb[2];
+    auto gload = [&](int kt, f32x4 (&xa)[2], BRegs& xb) {
         const long k0 = (long)min(kt, kt_end - 1) * SBK;      // past the end: re-load the last tile (never consumed)
         if ((ABL & 16) && kt > kt_begin + 1) return;
 #pragma unroll
@@ -126,8 +135,17 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
             const bool b_live = B_FULL || (BKM ? q == 0 : tid < 256);
             if (a_live) xa[q] = *reinterpret_cast<const f32x4*>(AK ? a_src[q] + k0 : a_src[q] + k0 * p.lda);
             else xa[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (b_live) xb[q] = *reinterpret_cast<const f32x4*>(BKM ? b_src[q] + k0 : b_src[q] + k0 * p.ldb);
-            else xb[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!BPL) {
+                if (b_live) xb.f[q] = *reinterpret_cast<const f32x4*>(BKM ? b_src[q] + k0 : b_src[q] + k0 * p.ldb);
+                else xb.f[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        if (BPL) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                if (B_FULL) xb.pl[pl] = *reinterpret_cast<const u32x4*>(bp_src + pl * p.bpl_stride + k0);
+                else { const u32x2 v = *reinterpret_cast<const u32x2*>(bp_src + pl * p.bpl_stride + k0); xb.pl[pl] = u32x4{v[0], v[1], 0u, 0u}; }
+            }
         }
     };
 
@@ -184,11 +202,23 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
             }
         }
     };
-    auto sstore = [&](int stage, const f32x4 (&xa)[2], const f32x4 (&xb)[2], bool live) {
-        if (ABL & 32) { asm volatile("" :: "v"(xa[0][0]), "v"(xb[0][0]), "v"(xa[1][3]), "v"(xb[1][3])); return; }     // tuning: no LDS plane writes
+    auto sstore = [&](int stage, const f32x4 (&xa)[2], const BRegs& xb, bool live) {
+        if (ABL & 32) { asm volatile("" :: "v"(xa[0][0]), "v"(xb.f[0][0]), "v"(xa[1][3]), "v"(xb.f[1][3])); return; }     // tuning: no LDS plane writes
         unsigned char* sa = smem_raw + stage * STAGE;
         stage_store(sa, xa, AK, A_FULL, PA, 128, BM == 64);
-        stage_store(sa + 3 * PA, xb, BKM, B_FULL, PB, 256, false);
+        if (BPL) {
+            unsigned char* sb = sa + 3 * PA;
+            if (B_FULL) {
+                unsigned char* dst = sb + (tid >> 1) * 48 + (tid & 1) * 16;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * PB) = xb.pl[pl];
+            } else {
+                unsigned char* dst = sb + (tid >> 2) * 48 + (tid & 3) * 8;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x2*>(dst + pl * PB) = u32x2{xb.pl[pl][0], xb.pl[pl][1]};
+            }
+        } else
+        stage_store(sa + 3 * PA, xb.f, BKM, B_FULL, PB, 256, false);
         if (!AK) { const float w = (do_colsum && live && (A_FULL || tid < 128)) ? 1.f : 0.f; csum += (xa[0] + xa[1]) * w; }   // branch-free: keeps the k-loop one block
     };
 
@@ -211,7 +241,7 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
 
     // one k-tile: MFMAs on `stage` while the NEXT tile (registers xa/xb) is split into the other stage and the tile
     // after that is fetched into (ya/yb).  Branch-free, so the scheduler can interleave the three streams.
-    auto step = [&](int kt, int stage, f32x4 (&xa)[2], f32x4 (&xb)[2], f32x4 (&ya)[2], f32x4 (&yb)[2]) {
+    auto step = [&](int kt, int stage, f32x4 (&xa)[2], BRegs& xb, f32x4 (&ya)[2], BRegs& yb) {
         gload(kt + 2, ya, yb);
         const unsigned char* sa = smem_raw + stage * STAGE;
         const unsigned char* sb = sa + 3 * PA;
@@ -325,7 +355,7 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
     __syncthreads();          // the epilogue's LDS slabs alias the stages the next tile is about to fill
 }
 
-template <bool AK, bool BKM, int BM = 128, int ABL = 0, int NP = 3>
+template <bool AK, bool BKM, int BM = 128, int ABL = 0, int NP = 3, bool BPL = false>
 __global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 1 : 2) void gemm_split_kernel(const GemmArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SplitGeom<BM>::SMEM_BYTES];
     if ((ABL & 128) && (blockIdx.x & 8)) {      // tuning: de-phase half of the workgroups by ~p.ablate x 3.4 us at start
@@ -339,7 +369,7 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 1 : 2) void gemm
         // XCD-aware tile order (as gemm.hip); gridDim.x is a multiple of 8 whenever it is smaller than `tiles`
         const int q = tiles >> 3, r = tiles & 7, x = vb & 7, slot = vb >> 3;
         const int logical = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + slot;
-        split_tile<AK, BKM, BM, ABL, NP>(p, smem_raw, logical, blockIdx.z);
+        split_tile<AK, BKM, BM, ABL, NP, 0, BPL>(p, smem_raw, logical, blockIdx.z);
     }
 }
 
@@ -363,6 +393,11 @@ struct TnProb {
 };
 struct TnGroupArgs { int n; float* ws; int* counters; TnProb p[TNG_MAX]; };
 
+// ABL: tuning builds only (the ablation bits of split_tile).  Measured on the 15 products of the bench step (K = 8 192, K slabs of
+// 4 096, 364 us): without the split arithmetic 345, without MFMAs 269, without LDS fragment reads 297, without in-loop global loads
+// 304, without LDS plane writes 282, without the barrier 351 -- every part costs 20-100 us and the parts ADD UP (the k-loop's
+// load -> split -> plane write -> barrier -> fragment read -> MFMA chain is not overlapped across the two resident workgroups of a CU).
+template <int ABL = 0>
 __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const TnGroupArgs g) {
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SplitGeom<128>::SMEM_BYTES];
     const int b = blockIdx.x;
@@ -380,7 +415,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const TnGroupAr
     a.aux_in = nullptr; a.aux_out = nullptr; a.ld_aux = 0; a.residual = nullptr; a.ldr = 0;
     a.split_k = split; a.ktiles_per_split = g.p[i].kt_per_split; a.ws = g.ws + g.p[i].ws_off;
     a.colsum = g.p[i].colsum; a.tiles_m = g.p[i].tiles_m; a.tiles_n = g.p[i].tiles_n; a.vec_epi = 1; a.ablate = 0;
-    split_tile<false, false, 128, 0, 3, 64>(a, smem_raw, tile, z);
+    a.Bpl = nullptr; a.ld_bpl = 0; a.bpl_stride = 0;
+    split_tile<false, false, 128, ABL, 3, 64>(a, smem_raw, tile, z);
     if (split <= 1) return;
 
     const int tid = threadIdx.x;
@@ -421,7 +457,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const TnGroupAr
     }
 }
 
-static int g_tn_kslab = 2048;
+static int g_tn_kslab = 4096;
 void set_tn_kslab(int k) { g_tn_kslab = k < 256 ? 256 : (k / 32) * 32; }
 // host side of the grouped launch: items -> prefix table; returns the workspace floats / counters it needs when `args` is null
 long plan_tn_grouped(const gaot_wgrad_item* items, int n, TnGroupArgs* args, int* n_counters, int* n_wg) {
@@ -430,7 +466,7 @@ long plan_tn_grouped(const gaot_wgrad_item* items, int n, TnGroupArgs* args, int
         const gaot_wgrad_item& it = items[i];
         const int kt32 = it.K / 32;
         // K slab per workgroup: the accumulators are flushed to the vector pipe every 1 024 values of k inside the kernel, so the
-        // slab length is a load-balance / slab-traffic choice (g_tn_kslab, default 2 048: half the slab traffic of 1 024)
+        // slab length is a load-balance / slab-traffic choice (g_tn_kslab; measured on the 15 products of the bench step: 448 / 396 / 366 us at 1 024 / 2 048 / 4 096)
         int split = (it.K + g_tn_kslab - 1) / g_tn_kslab;
         int per = (kt32 + split - 1) / split;
         split = (kt32 + per - 1) / per;
@@ -455,7 +491,7 @@ void launch_tn_grouped(const gaot_wgrad_item* items, int n, float* ws, int* coun
     args.n = n; args.ws = ws; args.counters = counters;
     int wg = 0;
     plan_tn_grouped(items, n, &args, nullptr, &wg);
-    hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(wg), dim3(256), 0, st, args);
+    hipLaunchKernelGGL(gemm_tn_grouped_kernel<0>, dim3(wg), dim3(256), 0, st, args);
 }
 
 // 0: one workgroup per tile (round 1).  n > 0: grids larger than n workgroups become persistent with n (MI355X holds 512 of the
@@ -476,7 +512,11 @@ static void launch_split_bm(GemmArgs& a, bool ak, bool bk, hipStream_t st) {
     }
     dim3 grid(gx, 1, z);
     dim3 block(BM == 256 ? 512 : 256);
-    if (ak && bk)        hipLaunchKernelGGL((gemm_split_kernel<true, true, BM, 0, NP>), grid, block, 0, st, a);
+    if (NP == 3 && a.Bpl != nullptr) {          // pre-split B (weights): the planes are k-contiguous whatever B's own layout
+        if (ak) hipLaunchKernelGGL((gemm_split_kernel<true, true, BM, 0, 3, true>), grid, block, 0, st, a);
+        else    hipLaunchKernelGGL((gemm_split_kernel<false, true, BM, 0, 3, true>), grid, block, 0, st, a);
+    }
+    else if (ak && bk)   hipLaunchKernelGGL((gemm_split_kernel<true, true, BM, 0, NP>), grid, block, 0, st, a);
     else if (ak && !bk)  hipLaunchKernelGGL((gemm_split_kernel<true, false, BM, 0, NP>), grid, block, 0, st, a);
     else if (!ak && !bk) hipLaunchKernelGGL((gemm_split_kernel<false, false, BM, 0, NP>), grid, block, 0, st, a);
     else                 hipLaunchKernelGGL((gemm_split_kernel<false, true, BM, 0, NP>), grid, block, 0, st, a);

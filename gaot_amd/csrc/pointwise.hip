@@ -28,7 +28,7 @@ constexpr int RMS_MAX_D = 2048;
 // dx = r*(w*dy) - x*r^3*mean(w*dy*x) (+dx_add) ; dw partial per block = sum_rows dy*x*r
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ rstd, const float* __restrict__ dy,
-                                                          const float* __restrict__ dx_add, int M, int D,
+                                                          const float* __restrict__ dx_add, const float* __restrict__ dx_add2, int M, int D,
                                                           float* __restrict__ dx, float* __restrict__ dwp) {
     __shared__ float red[4][RMS_MAX_D];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
         const float coef = r * r * r * dot / (float)D;
         float* or_ = dx + (long)row * D;
         const float* ar = dx_add ? dx_add + (long)row * D : nullptr;
+        const float* ar2 = dx_add2 ? dx_add2 + (long)row * D : nullptr;
 #pragma unroll
         for (int i = 0; i < RMS_MAX_D / 64; ++i) {
             const int d = lane + i * 64;
@@ -55,6 +56,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
                 const float xv = xr[d], gv = gr[d];
                 float v = r * w[d] * gv - xv * coef;
                 if (ar) v += ar[d];
+                if (ar2) v += ar2[d];
                 or_[d] = v;
                 dwacc[i] += gv * xv * r;
             }
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_vec_kernel(const float* __res
 template <int NV>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ rstd, const float* __restrict__ dy,
-                                                              const float* __restrict__ dx_add, int M,
+                                                              const float* __restrict__ dx_add, const float* __restrict__ dx_add2, int M,
                                                               float* __restrict__ dx, float* __restrict__ dwp) {
     constexpr int D = 256 * NV;
     __shared__ f32x4 red[4][NV][64];
@@ -128,6 +130,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_vec_kernel(const float* __res
         for (int v = 0; v < NV; ++v) {
             f32x4 o = wv[v] * gv[v] * r - xv[v] * coef;
             if (dx_add) o += *reinterpret_cast<const f32x4*>(dx_add + (long)row * D + v * 256 + lane * 4);
+            if (dx_add2) o += *reinterpret_cast<const f32x4*>(dx_add2 + (long)row * D + v * 256 + lane * 4);
             *reinterpret_cast<f32x4*>(dx + (long)row * D + v * 256 + lane * 4) = o;
             dwacc[v] += gv[v] * xv[v] * r;
         }
@@ -303,6 +306,51 @@ __global__ __launch_bounds__(256) void colsum_grouped_kernel(const ColsumGroupAr
         *reinterpret_cast<f32x4*>(dst) = (red[0][c4] + red[1][c4]) + (red[2][c4] + red[3][c4]);
     }
 }
+// ---- exact three-way bf16 split of fp32 matrices into planes (gaot_gemm_desc.b_planes), many matrices per launch.  64 x 64 tiles
+// through LDS so that both the plain and the transposed planes are written in whole 128-byte rows.
+constexpr int SPLIT_GROUP_MAX = 48;
+struct SplitItem { const float* src; unsigned short* planes; long ld, ld_out, plane_stride; int rows, cols, transpose, tiles_c, wg_end; };
+struct SplitGroupArgs { int n; SplitItem it[SPLIT_GROUP_MAX]; };
+__global__ __launch_bounds__(256) void split_planes_grouped_kernel(const SplitGroupArgs g) {
+    __shared__ float tile[64][65];
+    int i = 0;
+    while (i + 1 < g.n && (int)blockIdx.x >= g.it[i].wg_end) ++i;
+    const int local = (int)blockIdx.x - (i > 0 ? g.it[i - 1].wg_end : 0);
+    const int r0 = (local / g.it[i].tiles_c) * 64, c0 = (local % g.it[i].tiles_c) * 64;
+    const int rows = g.it[i].rows, cols = g.it[i].cols;
+    const float* __restrict__ src = g.it[i].src;
+    const long ld = g.it[i].ld;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 64 * 64; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        tile[r][c] = (r0 + r < rows && c0 + c < cols) ? src[(long)(r0 + r) * ld + c0 + c] : 0.f;
+    }
+    __syncthreads();
+    const bool tr = g.it[i].transpose != 0;
+    const int orows = tr ? cols : rows, ocols = tr ? rows : cols;          // extents in the output orientation
+    const int or0 = tr ? c0 : r0, oc0 = tr ? r0 : c0;
+    unsigned short* __restrict__ out = g.it[i].planes;
+    const long ldo = g.it[i].ld_out, ps = g.it[i].plane_stride;
+    const int pp = tid & 31;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int orow = (tid >> 5) + 8 * k;
+        const float x0 = tr ? tile[2 * pp][orow] : tile[orow][2 * pp];
+        const float x1 = tr ? tile[2 * pp + 1][orow] : tile[orow][2 * pp + 1];
+        unsigned a, b, c;
+        split3_pair<0>(x0, x1, a, b, c);
+        if (or0 + orow < orows && oc0 + 2 * pp < ocols) {
+            unsigned short* d = out + (long)(or0 + orow) * ldo + oc0 + 2 * pp;
+            if (oc0 + 2 * pp + 1 < ocols) {
+                *reinterpret_cast<unsigned*>(d) = a;
+                *reinterpret_cast<unsigned*>(d + ps) = b;
+                *reinterpret_cast<unsigned*>(d + 2 * ps) = c;
+            } else {
+                d[0] = (unsigned short)(a & 0xffffu); d[ps] = (unsigned short)(b & 0xffffu); d[2 * ps] = (unsigned short)(c & 0xffffu);
+            }
+        }
+    }
+}
 __global__ void batchsum_kernel(const float* __restrict__ x, int B, long RN, float* __restrict__ out) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < RN; i += (long)gridDim.x * blockDim.x) {
         float s = 0.f;
@@ -439,14 +487,15 @@ extern "C" int gaot_rmsnorm_fwd(const float* x, const float* w, int32_t M, int32
 extern "C" int gaot_rmsnorm_bwd_partials(int32_t M) { return cdiv(M, RMS_ROWS_PER_BLOCK); }
 
 extern "C" int gaot_rmsnorm_bwd(const float* x, const float* w, const float* rstd, const float* dy, const float* dx_add,
-                                int32_t M, int32_t D, float* dx, float* dw_partial, gaot_stream_t stream) {
+                                const float* dx_add2, int32_t M, int32_t D, float* dx, float* dw_partial, gaot_stream_t stream) {
     GAOT_REQUIRE(x && w && rstd && dy && dx && dw_partial && M > 0 && D > 0, "rmsnorm_bwd: bad arguments");
     GAOT_REQUIRE(D <= RMS_MAX_D, "rmsnorm_bwd: D=%d exceeds %d", D, RMS_MAX_D);
-    const bool v16 = aligned16(x) && aligned16(w) && aligned16(dy) && aligned16(dx) && aligned16(dw_partial) && (!dx_add || aligned16(dx_add));
+    const bool v16 = aligned16(x) && aligned16(w) && aligned16(dy) && aligned16(dx) && aligned16(dw_partial) && (!dx_add || aligned16(dx_add)) &&
+                     (!dx_add2 || aligned16(dx_add2));
     const dim3 grid(cdiv(M, RMS_ROWS_PER_BLOCK));
-    if (v16 && D == 256)      hipLaunchKernelGGL(rmsnorm_bwd_vec_kernel<1>, grid, dim3(256), 0, ST(stream), x, w, rstd, dy, dx_add, M, dx, dw_partial);
-    else if (v16 && D == 512) hipLaunchKernelGGL(rmsnorm_bwd_vec_kernel<2>, grid, dim3(256), 0, ST(stream), x, w, rstd, dy, dx_add, M, dx, dw_partial);
-    else hipLaunchKernelGGL(rmsnorm_bwd_kernel, grid, dim3(256), 0, ST(stream), x, w, rstd, dy, dx_add, M, D, dx, dw_partial);
+    if (v16 && D == 256)      hipLaunchKernelGGL(rmsnorm_bwd_vec_kernel<1>, grid, dim3(256), 0, ST(stream), x, w, rstd, dy, dx_add, dx_add2, M, dx, dw_partial);
+    else if (v16 && D == 512) hipLaunchKernelGGL(rmsnorm_bwd_vec_kernel<2>, grid, dim3(256), 0, ST(stream), x, w, rstd, dy, dx_add, dx_add2, M, dx, dw_partial);
+    else hipLaunchKernelGGL(rmsnorm_bwd_kernel, grid, dim3(256), 0, ST(stream), x, w, rstd, dy, dx_add, dx_add2, M, D, dx, dw_partial);
     GAOT_CHECK_LAUNCH("gaot_rmsnorm_bwd");
     return GAOT_OK;
 }
@@ -502,6 +551,31 @@ extern "C" int gaot_colsum_grouped(const gaot_colsum_item* items, int32_t n, gao
         }
         hipLaunchKernelGGL(colsum_grouped_kernel, dim3(wg), dim3(256), 0, ST(stream), a);
         GAOT_CHECK_LAUNCH("gaot_colsum_grouped");
+    }
+    return GAOT_OK;
+}
+
+extern "C" int gaot_split_planes_grouped(const gaot_split_item* items, int32_t n, gaot_stream_t stream) {
+    GAOT_REQUIRE(items != nullptr && n > 0, "split_planes_grouped: no items");
+    for (int i = 0; i < n; ++i) {
+        const gaot_split_item& it = items[i];
+        GAOT_REQUIRE(it.src && it.planes && it.rows > 0 && it.cols > 0 && it.ld >= it.cols && it.ld_out % 2 == 0 && it.plane_stride % 2 == 0 &&
+                     it.ld_out >= (it.transpose ? it.rows : it.cols) && (reinterpret_cast<uintptr_t>(it.planes) & 3u) == 0,
+                     "split_planes_grouped: item %d: bad shape / leading dimension / alignment", i);
+    }
+    for (int i0 = 0; i0 < n; i0 += SPLIT_GROUP_MAX) {
+        SplitGroupArgs a;
+        a.n = n - i0 < SPLIT_GROUP_MAX ? n - i0 : SPLIT_GROUP_MAX;
+        int wg = 0;
+        for (int i = 0; i < a.n; ++i) {
+            const gaot_split_item& it = items[i0 + i];
+            const int tc = cdiv(it.cols, 64);
+            wg += cdiv(it.rows, 64) * tc;
+            a.it[i] = SplitItem{it.src, reinterpret_cast<unsigned short*>(it.planes), (long)it.ld, (long)it.ld_out, (long)it.plane_stride,
+                                it.rows, it.cols, it.transpose, tc, wg};
+        }
+        hipLaunchKernelGGL(split_planes_grouped_kernel, dim3(wg), dim3(256), 0, ST(stream), a);
+        GAOT_CHECK_LAUNCH("gaot_split_planes_grouped");
     }
     return GAOT_OK;
 }

@@ -165,16 +165,22 @@ class TransformerBlock(nn.Module):
         if skip_connection:
             self.skip_proj = nn.Linear(input_size * 2, input_size)
 
-    def forward(self, x, condition=None, relative_positions=None, skip=None):
+    def forward(self, x, condition=None, relative_positions=None, skip=None, want_input_alias: bool = False):
+        """want_input_alias: also return an alias of the block's INPUT taken from the pre-norm fork (Transformer keeps it as the
+        long-range skip): the skip's gradient then joins the stream's inside the norm-gradient kernel instead of by an add launch."""
         if self.skip_connection and skip is not None:          # cat([x, skip]) @ W^T + b as a split-K-operand GEMM
             x = ops.linear(x, self.skip_proj.weight, self.skip_proj.bias, x2=skip)
+        alias = x
         if self.attn_norm is None:
             h = x
+        elif want_input_alias:
+            x, h, alias = ops.rms_norm_fork(x, self.attn_norm.weight, self.attn_norm.eps, with_skip_alias=True)
         else:       # (x, norm(x)) from one node: the residual's gradient is added inside the norm-gradient kernel
             x, h = ops.rms_norm_fork(x, self.attn_norm.weight, self.attn_norm.eps)
         h = self.attn(h, condition=condition, relative_positions=relative_positions, residual=x)   # x + attn(h)
         h = h if self.ffn_norm is None else self.ffn_norm(h)
-        return self.ffn(h, condition=condition, residual=h)    # residual on the NORMALISED stream (attn.py:231-232)
+        out = self.ffn(h, condition=condition, residual=h)     # residual on the NORMALISED stream (attn.py:231-232)
+        return (out, alias) if want_input_alias else out
 
 
 class Transformer(nn.Module):
@@ -203,18 +209,29 @@ class Transformer(nn.Module):
             x = ops.linear(x, self.input_proj.weight, self.input_proj.bias)
         skips = []
         left = len(self.blocks_in_order())          # a cut point (staged backward, trainer.TrainStep) after every block but the last
-        for blk in self.encoder_layers:
-            x = blk(x, condition=condition, relative_positions=relative_positions)
-            left -= 1
-            x = ops.cut(x) if left else x
-            skips.append(x)
-        if self.middle_layer is not None:
-            x = self.middle_layer(x, condition=condition, relative_positions=relative_positions)
-            left -= 1
-            x = ops.cut(x) if left else x
-        for blk in self.decoder_layers:
-            s = skips.pop() if self.use_long_range_skip else None
-            x = blk(x, condition=condition, relative_positions=relative_positions, skip=s)
+        # the output of encoder layer i is the long-range skip of a decoder layer AND the input of the next block: the skip is taken
+        # as an alias handed out by that next block's pre-norm fork (same values; its gradient is added inside the norm-gradient kernel)
+        blocks = self.blocks_in_order()
+        n_enc = len(self.encoder_layers)
+        pending_skip = False                         # the previous block's output is owed to `skips`
+        # (a staged backward cuts the graph between blocks: an alias handed out by the NEXT block's node would be reached from two
+        # separate backward passes, so with cut points active the skip is the block output itself, as in the reference)
+        via_fork = ops._CUT_HOOK[0] is None
+        for bi, blk in enumerate(blocks):
+            is_dec = bi >= len(blocks) - len(self.decoder_layers)
+            if pending_skip and is_dec:              # no block in between: the first decoder layer's skip is its own input
+                skips.append(x)
+                pending_skip = False
+            s = skips.pop() if (is_dec and self.use_long_range_skip) else None
+            if pending_skip and not via_fork:
+                skips.append(x)
+                pending_skip = False
+            if pending_skip:                         # this block forks its input first thing: take the skip alias from the fork
+                x, alias = blk(x, condition=condition, relative_positions=relative_positions, skip=s, want_input_alias=True)
+                skips.append(alias)
+            else:
+                x = blk(x, condition=condition, relative_positions=relative_positions, skip=s)
+            pending_skip = bi < n_enc
             left -= 1
             x = ops.cut(x) if left else x
         if isinstance(self.output_proj, nn.Linear):

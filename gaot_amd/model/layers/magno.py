@@ -163,8 +163,8 @@ class _MAGNOBase(nn.Module):
                     self._infer_cache["rowb"] = (key, nb, rowb, (src_coord, dst_coord))      # hold the tensors: ids stay unique
             if head is not None:
                 hw, hb = head
-                proj = (ops.matmul(hw, w_agno),                  # [out, C] = W @ Wr1   (tiny; operands read in place)
-                        ops.linear(rowb, hw, hb), None)          # [n_dst, out]
+                weff, rproj = ops.proj_fold(hw, hb, w_agno, rowb)      # [out, C] = W @ Wr1 and [n_dst, out] = rowb @ W^T + b (tiny)
+                proj = (weff, rproj, None)
         elif head is not None:
             proj = (head[0], None, head[1])
         # with few output channels the folded map is applied INSIDE the transform kernels (AGNO decides: `applied_proj`)

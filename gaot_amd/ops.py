@@ -88,11 +88,46 @@ def gemm(M: int, N: int, K: int, A, lda, a_kmajor, B, ldb, b_kmajor, out, ldc, *
     ws = None
     if split_k > 1:
         ws = torch.empty(split_k * (M * N + M), device=out.device, dtype=torch.float32)
+    bp, bp_ld, bp_stride = (None, 0, 0)
+    if _PLANES_ACTIVE[0] and A2 is None:
+        bp, bp_ld, bp_stride = _weight_planes(B, N, K, ldb, bool(b_kmajor))
     d = L.GemmDesc(M, N, K, _p(A), lda, int(a_kmajor), _p(A2), lda2, k_split, _p(B), ldb, int(b_kmajor),
                    _p(out), ldc, _p(bias), _p(rowbias), rowbias_period, ld_rowbias, _p(rowscale), act,
-                   _p(aux_in), _p(aux_out), ld_aux, _p(residual), ldr, split_k, _p(ws), _p(colsum))
+                   _p(aux_in), _p(aux_out), ld_aux, _p(residual), ldr, split_k, _p(ws), _p(colsum),
+                   bp, bp_ld, bp_stride)
     L.check(L.load().gaot_gemm_f32(C.byref(d), _stream()), "gaot_gemm_f32")
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# Pre-split weight planes (gaot_gemm_desc.b_planes).  The split-bf16 tile kernels form three bf16 pieces of every fp32 operand
+# element on its way into LDS -- once per workgroup per k-tile, so a weight matrix is re-split by every row tile of the
+# activations (64 times at 8 192 tokens).  trainer.TrainStep keeps the pieces of every Linear weight in two flat plane buffers
+# (as stored, and transposed for the input-gradient products), refreshed by ONE launch after each optimizer step; while a
+# TrainStep.step() is running (`_PLANES_ACTIVE`) every GEMM whose B operand is such a weight hands the kernel its planes.
+# Bit-identical results (the planes are exactly what the kernel would have computed); outside TrainStep nothing changes.
+# --------------------------------------------------------------------------------------------
+_PLANES_ACTIVE = [False]
+_WEIGHT_PLANES: dict = {}     # weight data_ptr -> (rows_avail, cols, k_ptr, k_ld, k_stride, t_ptr, t_ld, t_stride)
+
+
+def register_weight_planes(table: dict) -> None:
+    _WEIGHT_PLANES.clear()
+    _WEIGHT_PLANES.update(table)
+
+
+def _weight_planes(B, N: int, K: int, ldb: int, b_kmajor: bool):
+    e = _WEIGHT_PLANES.get(B.data_ptr())
+    if e is None:
+        return None, 0, 0
+    rows, cols, k_ptr, k_ld, k_stride, t_ptr, t_ld, t_stride = e
+    if b_kmajor:              # B = W [N, K] as stored: rows of W are the GEMM's n, columns its k
+        if N <= rows and K == cols and ldb == cols:
+            return C.c_void_p(k_ptr), k_ld, k_stride
+    else:                     # B = W [K', N'] used as Bop[k'][n']: the planes of W^T (n' = W's column, k' = W's row)
+        if K <= rows and N <= cols and ldb == cols:
+            return C.c_void_p(t_ptr), t_ld, t_stride
+    return None, 0, 0
 
 
 # tuning switch (tools / A-B runs only): GAOT_GEMM_MODE = argument of gaot_debug_set_gemm_glds (default 4: fp32 MFMA tiles
@@ -390,6 +425,23 @@ def _claim(w) -> Optional[torch.Tensor]:
     return s[0]
 
 
+def _claim_view(t) -> Optional[torch.Tensor]:
+    """the gradient slice of the PARAMETER that `t` is a reshaped view of (a Conv1d weight with its trailing singleton dimension
+    squeezed): same storage address and element count"""
+    if t is None or not t.requires_grad:
+        return None
+    s = _GRAD_SLOTS.get(id(t))
+    if s is not None:
+        return _claim(t)
+    ptr, n = t.data_ptr(), t.numel()
+    for s in _GRAD_SLOTS.values():
+        p = s[2]
+        if (not s[1]) and p.data_ptr() == ptr and p.numel() == n and s[0].device == t.device and t.is_contiguous():
+            s[1] = True
+            return s[0]
+    return None
+
+
 class _Linear(torch.autograd.Function):
     """y = x @ w[:, :K]^T (+ x2 @ w[:, K:]^T) + b + rowbias[m % P] + residual"""
 
@@ -505,6 +557,53 @@ class _MatMul(torch.autograd.Function):
 
 def matmul(a, b):
     return _MatMul.apply(a, b)
+
+
+class _ProjFold(torch.autograd.Function):
+    """The decoder's output projection folded into the recovery block (magno.py:345-350 then 640-641; both linear, nothing in
+    between):   weff = W @ Wr_a  [OC, C]   and   rproj = rowb @ W^T + b  [Q, OC],   so that  y = agno @ weff^T + rproj.
+    ONE node for both uses of the projection weight W: its two gradient contributions are summed inside the second product
+    (residual operand) and land in W's own gradient slice; Wr_a's gradient goes straight into the column block of the recovery
+    weight's slice that split_cols handed out."""
+
+    @staticmethod
+    def forward(ctx, hw, hb, w_a, rowb):
+        _dev(hw, w_a, rowb)
+        hw2, ldh = _rowmajor(hw)
+        wa2, lda = _rowmajor(w_a)
+        rb2, _ = _rowmajor(rowb)
+        OC, Cc = hw2.shape
+        weff = torch.empty(OC, wa2.shape[1], device=hw.device, dtype=torch.float32)
+        gemm(OC, wa2.shape[1], Cc, hw2, ldh, 1, wa2, lda, 0, weff, wa2.shape[1])
+        rproj = linear_nt(rb2, hw2, bias=hb)
+        ctx.save_for_backward(hw2, wa2, rb2)
+        ctx.slots = (_claim_view(hw), _claim(hb), _claim(w_a))
+        ctx.has_b = hb is not None
+        return weff, rproj
+
+    @staticmethod
+    def backward(ctx, g_weff, g_rproj):
+        hw2, wa2, rb2 = ctx.saved_tensors
+        s_w, s_b, s_a = ctx.slots
+        need = ctx.needs_input_grad
+        g1, _ = _rowmajor(g_weff)
+        g2, _ = _rowmajor(g_rproj)
+        dhw = dhb = dwa = drowb = None
+        if need[0]:
+            part = matmul_tn(g2, rb2)                                              # g_rproj^T @ rowb   [OC, C]
+            out = s_w.detach().view(hw2.shape) if s_w is not None else None
+            dhw = linear_nt(g1, wa2, out=out, residual=part, ldr=part.stride(0) if part.shape[0] > 1 else part.shape[1])   # + g_weff @ Wr_a^T
+        if ctx.has_b and need[1]:
+            dhb = colsum(g2, out=s_b.detach() if s_b is not None else None)
+        if need[2]:
+            dwa = matmul_tn(hw2, g1, out=s_a.detach() if s_a is not None else None)   # W^T @ g_weff   [C, C]
+        if need[3]:
+            drowb = matmul_nn(g2, hw2)                                             # g_rproj @ W       [Q, C]
+        return dhw, dhb, dwa, drowb
+
+
+def proj_fold(hw, hb, w_a, rowb):
+    return _ProjFold.apply(hw, hb, w_a, rowb)
 
 
 class _SplitCols(torch.autograd.Function):
@@ -1320,7 +1419,7 @@ class _RMSNorm(torch.autograd.Function):
         dx = torch.empty_like(xm)
         P = int(lib.gaot_rmsnorm_bwd_partials(M))
         part = torch.empty(P, D, device=xm.device, dtype=torch.float32)
-        L.check(lib.gaot_rmsnorm_bwd(_p(xm), _p(w), _p(rstd), _p(g), None, M, D, _p(dx), _p(part), _stream()), "gaot_rmsnorm_bwd")
+        L.check(lib.gaot_rmsnorm_bwd(_p(xm), _p(w), _p(rstd), _p(g), None, None, M, D, _p(dx), _p(part), _stream()), "gaot_rmsnorm_bwd")
         dw = None
         if ctx.needs_input_grad[1]:
             dw = colsum(part, out=ctx.slot.detach() if ctx.slot is not None else None, final=ctx.slot is not None)
@@ -1332,12 +1431,14 @@ def rms_norm(x, w, eps):
 
 
 class _RMSNormFork(torch.autograd.Function):
-    """(x, rmsnorm(x)): the pre-norm residual fork.  Handing the untouched stream back through the SAME node lets the
+    """(x, rmsnorm(x)[, x]): the pre-norm residual fork.  Handing the untouched stream back through the SAME node lets the
     backward add the residual branch's gradient inside the norm-gradient kernel (dx_add) instead of autograd launching
-    a separate elementwise add per fork."""
+    a separate elementwise add per fork.  `n_alias` = 2 hands out a second alias of the stream (the long-range skip of the
+    U-shaped processor, attn.py:281-299): its gradient is added in the same kernel (dx_add2)."""
 
     @staticmethod
-    def forward(ctx, x, w, eps):
+    def forward(ctx, x, w, eps, n_alias=1):
+        ctx.set_materialize_grads(False)      # an output nobody differentiated stays None (no zero tensors, no kernel reading them)
         _dev(x, w)
         shp = x.shape
         D = shp[-1]
@@ -1349,30 +1450,35 @@ class _RMSNormFork(torch.autograd.Function):
         ctx.save_for_backward(xm, w, rstd)
         ctx.shp = shp
         ctx.slot = _claim(w)
+        if n_alias == 2:
+            return x.view_as(x), y.reshape(shp), x.view_as(x)
         return x.view_as(x), y.reshape(shp)
 
     @staticmethod
-    def backward(ctx, dres, dy):
+    def backward(ctx, dres, dy, dskip=None):
         xm, w, rstd = ctx.saved_tensors
         M, D = xm.shape
         if dy is None:
-            return dres, None, None
+            tot = dres if dskip is None else (dskip if dres is None else dres + dskip)
+            return tot, None, None, None
         lib = L.load()
         g = dy.reshape(M, D).contiguous()
         add = dres.reshape(M, D).contiguous() if dres is not None else None
+        add2 = dskip.reshape(M, D).contiguous() if dskip is not None else None
         dx = torch.empty_like(xm)
         P = int(lib.gaot_rmsnorm_bwd_partials(M))
         part = torch.empty(P, D, device=xm.device, dtype=torch.float32)
-        L.check(lib.gaot_rmsnorm_bwd(_p(xm), _p(w), _p(rstd), _p(g), _p(add), M, D, _p(dx), _p(part), _stream()), "gaot_rmsnorm_bwd")
+        L.check(lib.gaot_rmsnorm_bwd(_p(xm), _p(w), _p(rstd), _p(g), _p(add), _p(add2), M, D, _p(dx), _p(part), _stream()), "gaot_rmsnorm_bwd")
         dw = None
         if ctx.needs_input_grad[1]:
             dw = colsum(part, out=ctx.slot.detach() if ctx.slot is not None else None, final=ctx.slot is not None)
-        return dx.reshape(ctx.shp), dw, None
+        return dx.reshape(ctx.shp), dw, None, None
 
 
-def rms_norm_fork(x, w, eps):
-    """returns (x, rmsnorm(x)); use the returned x for the residual branch."""
-    return _RMSNormFork.apply(x, w, eps)
+def rms_norm_fork(x, w, eps, with_skip_alias: bool = False):
+    """returns (x, rmsnorm(x)); use the returned x for the residual branch.  with_skip_alias: (x, rmsnorm(x), x_skip) -- a second
+    alias of the stream for the long-range skip connection."""
+    return _RMSNormFork.apply(x, w, eps, 2 if with_skip_alias else 1)
 
 
 class _SwiGLU(torch.autograd.Function):

@@ -72,6 +72,11 @@ typedef struct gaot_gemm_desc {
     const float* residual; int64_t ldr;
     int32_t split_k; float* workspace;
     float* colsum;   /* optional, a_kmajor = 0 only: colsum[m] = sum_k Aop[m,k] (bias gradient fused into dW = dY^T X) */
+    /* optional: Bop PRE-SPLIT into the three bf16 pieces the split-bf16 tile kernels form from every fp32 operand (weights: split
+     * once per optimizer step by gaot_split_planes_grouped instead of once per workgroup per k-tile).  Piece q of Bop[k,n] is the
+     * 16-bit word b_planes[q * b_plane_stride + n * ld_bplanes + k] (k-contiguous whatever b_kmajor says).  Products are bit-identical
+     * with and without; kernels that do not take planes ignore the field.  ld_bplanes, b_plane_stride multiples of 8. */
+    const void* b_planes; int64_t ld_bplanes; int64_t b_plane_stride;
 } gaot_gemm_desc;
 
 int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream);
@@ -92,6 +97,16 @@ typedef struct gaot_wgrad_item {
 } gaot_wgrad_item;
 int64_t gaot_gemm_tn_grouped_workspace(const gaot_wgrad_item* items, int32_t n, int32_t* n_counters);
 int gaot_gemm_tn_grouped(const gaot_wgrad_item* items, int32_t n, float* workspace, int32_t* counters, gaot_stream_t stream);
+
+/* Exact three-way bf16 split of fp32 matrices into planes for gaot_gemm_desc.b_planes, n matrices per launch: item i reads
+ * src[r * ld + c] (rows x cols) and writes piece q of element (r, c) to planes[q * plane_stride + r * ld_out + c], or -- transpose
+ * != 0 -- to planes[q * plane_stride + c * ld_out + r] (the planes of the TRANSPOSED matrix: what the input-gradient product
+ * dX = dY W reads as its k-contiguous B operand).  x = p0 + p1 + p2 exactly (8 + 8 + 8 significant bits, truncation). */
+typedef struct gaot_split_item {
+    const float* src; int64_t ld; int32_t rows, cols;
+    void* planes; int64_t ld_out; int64_t plane_stride; int32_t transpose;
+} gaot_split_item;
+int gaot_split_planes_grouped(const gaot_split_item* items, int32_t n, gaot_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Geometry plan pieces (once per mesh geometry; torch_scatter / repeat_interleave call sites
@@ -220,10 +235,12 @@ int gaot_gno_segment_sum(const float* x, int32_t B, int32_t E, int32_t C, const 
 /* RMSNorm attn.py:161-172.  y = x * rstd * w ; rstd[M] saved for backward. */
 int gaot_rmsnorm_fwd(const float* x, const float* w, int32_t M, int32_t D, float eps,
                      float* y, float* rstd, gaot_stream_t stream);
-/* dx = rstd*(w*dy - x*rstd^2*mean(w*dy*x)) (+ dx_add) ; dw_partial[P,D] column partials (P returned rows =
- * gaot_rmsnorm_bwd_partials(M)); caller sums them. */
+/* dx = rstd*(w*dy - x*rstd^2*mean(w*dy*x)) (+ dx_add) (+ dx_add2) ; dw_partial[P,D] column partials (P returned rows =
+ * gaot_rmsnorm_bwd_partials(M)); caller sums them.  dx_add / dx_add2 (optional): gradients reaching the SAME tensor by other
+ * routes -- the block's residual branch (attn.py:228-233) and the long-range skip (attn.py:281-299) -- added here instead of by
+ * separate elementwise launches. */
 int gaot_rmsnorm_bwd_partials(int32_t M);
-int gaot_rmsnorm_bwd(const float* x, const float* w, const float* rstd, const float* dy, const float* dx_add,
+int gaot_rmsnorm_bwd(const float* x, const float* w, const float* rstd, const float* dy, const float* dx_add, const float* dx_add2,
                      int32_t M, int32_t D, float* dx, float* dw_partial, gaot_stream_t stream);
 /* SwiGLU gate attn.py:151: u = [u1 | u3] ([M,2F]); g = silu(u1)*u3 ; bwd writes du [M,2F]. */
 int gaot_swiglu_fwd(const float* u, int32_t M, int32_t F, float* g, gaot_stream_t stream);

@@ -1159,3 +1159,75 @@ def test_colsum_grouped_contiguous_and_column_block_outputs():
         assert maxrel(o, r) < 2e-6
     assert maxrel(wide[:, 64:], ws[:, 4352:4352 + 4096].double().sum(0).view(64, 64)) < 2e-6 and float(wide[:, :64].abs().sum()) == 0.0
     assert maxrel(o2, small.double().sum(0)) < 2e-6
+
+
+# ------------------------------------------------------------------ pre-split weight planes
+def _planes_for(W):
+    """(k planes [3, N, K], t planes [3, K, N]) of W [N, K] through gaot_split_planes_grouped + the registry entry ops expects"""
+    import ctypes as C
+    from gaot_amd import _lib as L
+    N, K = W.shape
+    pk = torch.zeros(3, N * K, dtype=torch.int16, device=W.device)
+    pt = torch.zeros(3, N * K, dtype=torch.int16, device=W.device)
+    items = (L.SplitItem * 2)(L.SplitItem(W.data_ptr(), K, N, K, pk.data_ptr(), K, N * K, 0),
+                              L.SplitItem(W.data_ptr(), K, N, K, pt.data_ptr(), N, N * K, 1))
+    L.check(L.load().gaot_split_planes_grouped(items, 2, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "split")
+    return pk, pt, {W.data_ptr(): (N, K, pk.data_ptr(), K, N * K, pt.data_ptr(), N, N * K)}
+
+
+def test_split_planes_are_the_exact_three_way_split():
+    g = torch.Generator().manual_seed(31)
+    W = (torch.randn(200, 136, generator=g) * torch.logspace(-6, 3, 136)[None, :]).to(dev())
+    pk, pt, _ = _planes_for(W)
+    as_f32 = lambda p: (p.to(torch.int32) << 16).view(torch.float32)
+    parts = as_f32(pk).view(3, 200, 136).double()
+    assert torch.equal(parts.sum(0), W.double().cpu().to(dev()))                       # x = p0 + p1 + p2 exactly
+    assert torch.equal(as_f32(pt).view(3, 136, 200), as_f32(pk).view(3, 200, 136).transpose(1, 2))   # planes of W^T
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 256, 256), (8192, 768, 256), (8192, 256, 1024), (4096, 1024, 256)])
+def test_gemm_with_presplit_weight_planes_is_bit_identical(M, N, K):
+    """forward (x W^T) and input-gradient (g W) products with gaot_gemm_desc.b_planes vs the in-kernel split of the same weight"""
+    from gaot_amd import ops, _lib as L
+    g = torch.Generator().manual_seed(M + N + K)
+    x, W, gy = torch.randn(M, K, generator=g).to(dev()), (torch.randn(N, K, generator=g) / 8).to(dev()), torch.randn(M, N, generator=g).to(dev())
+    old = ops.set_gemm_mode(5)          # split-bf16 tiles wherever eligible: the same kernel family with and without the planes
+    try:
+        y0, dx0 = ops.linear_nt(x, W), ops.matmul_nn(gy, W)
+        assert L.load().gaot_debug_last_gemm_path() == 3
+        pk, pt, table = _planes_for(W)
+        ops.register_weight_planes(table)
+        ops._PLANES_ACTIVE[0] = True
+        y1, dx1 = ops.linear_nt(x, W), ops.matmul_nn(gy, W)
+    finally:
+        ops._PLANES_ACTIVE[0] = False
+        ops.register_weight_planes({})
+        ops.set_gemm_mode(old)
+    assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
+    assert rel(y1, x.double() @ W.double().t()) < 2e-6 and rel(dx1, gy.double() @ W.double()) < 2e-6
+
+
+def test_trainstep_with_weight_planes_equals_without(monkeypatch):
+    """three TrainStep updates with the pre-split weight planes (GAOT_WEIGHT_PLANES=1; off by default: measured slower) and
+    without: the same weights to fp32 rounding (the planes are exactly what the kernels would have formed; the tile heuristics may
+    pick another kernel for an input-gradient product), bit-identical between eager and hipGraph; load_state_dict between steps is noticed"""
+    from tests.test_ddp_gpu import _build, _data, _flat
+    from gaot_amd.trainer import TrainStep
+    lat, x, p, t = _data()
+    res = {}
+    for planes in ("1", "0"):
+        monkeypatch.setenv("GAOT_WEIGHT_PLANES", planes)
+        for graph in (False, True):
+            model = _build(seed=9).to(dev()).train()
+            ts = TrainStep(model, lr=2e-3, weight_decay=1e-4, use_graph=graph)
+            assert (getattr(ts.opt, "_planes_table", None) is not None and len(ts.opt._planes_table) > 10) == (planes == "1")
+            ts.bind(p.to(dev()), t.to(dev()), latent_tokens_coord=lat.to(dev()), xcoord=x.to(dev()))
+            for _ in range(2):
+                ts.step()
+            sd = {k: v.detach().clone() * 1.01 for k, v in model.state_dict().items()}
+            model.load_state_dict(sd)                     # weights change behind the planes' back: the next step must re-split
+            ts.step()
+            torch.cuda.synchronize()
+            res[(planes, graph)] = _flat(model).cpu()
+    assert float((res[("1", False)] - res[("0", False)]).abs().max()) < 2e-5 and float((res[("1", True)] - res[("0", True)]).abs().max()) < 2e-5
+    assert torch.equal(res[("1", False)], res[("1", True)]) and torch.equal(res[("0", False)], res[("0", True)])
