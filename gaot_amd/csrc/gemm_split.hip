@@ -400,13 +400,21 @@ struct TnGroupArgs { int n; float* ws; int* counters; TnProb p[TNG_MAX]; };
 template <int ABL = 0>
 __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const TnGroupArgs g) {
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SplitGeom<128>::SMEM_BYTES];
-    const int b = blockIdx.x;
+    // XCD-aware order (workgroup b runs on XCD b % 8): every XCD takes a CONTIGUOUS range of the logical work list, and inside
+    // a product the list runs K slab by K slab, tile row by tile row -- so the workgroups an XCD's L2 serves at the same time
+    // share the A panel of one (tile row, K slab) and walk the B panels of neighbouring tile columns
+    int b;
+    {
+        const int total = gridDim.x, q = total >> 3, r = total & 7, x = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        b = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + slot;
+    }
     int i = 0;
     while (i + 1 < g.n && b >= g.p[i].wg_end) ++i;                  // wave-uniform scan of <= 24 entries
     const int first = i > 0 ? g.p[i - 1].wg_end : 0;
     const int split = g.p[i].split;
     const int local = b - first;
-    const int tile = local / split, z = local - tile * split;       // a tile's slabs are adjacent workgroups
+    const int ntile = g.p[i].tiles_m * g.p[i].tiles_n;
+    const int z = local / ntile, tile = local - z * ntile;
     GemmArgs a;
     a.M = g.p[i].M; a.N = g.p[i].N; a.K = g.p[i].K;
     a.A = g.p[i].A; a.lda = g.p[i].lda; a.A2 = nullptr; a.lda2 = 0; a.k_split = 0;

@@ -11,14 +11,30 @@ import torch.nn as nn
 from ... import ops
 
 
-def activation_name(fn: Optional[Callable]) -> str:
-    """the reference passes activation CALLABLES (mlp.py:311, default F.gelu); the HIP kernels know them by name"""
+def activation_name(fn: Optional[Callable]) -> Optional[str]:
+    """the reference passes activation CALLABLES (mlp.py:253,311, default F.gelu); the fused HIP kernels know exact-erf GELU and ReLU
+    by name.  Any other callable returns None: the layers then run one HIP GEMM each with the caller's own callable in between."""
     import torch.nn.functional as F
-    if fn is None or fn is F.gelu or isinstance(fn, nn.GELU):
+    if fn is None or fn is F.gelu or (isinstance(fn, nn.GELU) and getattr(fn, "approximate", "none") == "none"):
         return "gelu"
     if fn is F.relu or fn is torch.relu or isinstance(fn, nn.ReLU):
         return "relu"
-    raise NotImplementedError(f"kernel-MLP activation {fn!r}: the HIP kernels implement exact-erf GELU (the reference default) and ReLU")
+    return None
+
+
+def _generic_chain(x, fcs, non_linearity, drops):
+    """mlp.py:283-298,329-337 for an arbitrary activation callable and / or dropout: every Linear / Conv1d(k=1) is a HIP GEMM
+    (ops.linear, channels last), the caller's callable and nn.Dropout run between them as what they are"""
+    import torch.nn.functional as F
+    act = F.gelu if non_linearity is None else non_linearity
+    n = len(fcs)
+    for i, fc in enumerate(fcs):
+        x = ops.linear(x, fc.weight, fc.bias)
+        if i < n - 1:
+            x = act(x)
+        if drops is not None:
+            x = drops[i](x)
+    return x
 
 
 class LinearChannelMLP(nn.Module):
@@ -26,15 +42,20 @@ class LinearChannelMLP(nn.Module):
 
     def __init__(self, layers: Sequence[int], non_linearity: Optional[Callable] = None, dropout: float = 0.0):
         super().__init__()
+        self.non_linearity = non_linearity
         self.act = activation_name(non_linearity)
         if len(layers) < 2:
             raise AssertionError("LinearChannelMLP needs at least one layer")
-        if dropout and dropout > 0.0:
-            raise NotImplementedError("dropout inside the kernel MLP is not part of the GAOT path")
         self.n_layers = len(layers) - 1
-        self.fcs = nn.ModuleList(nn.Linear(layers[i], layers[i + 1]) for i in range(self.n_layers))
+        self.fcs = nn.ModuleList()
+        # same registration order as the reference (fcs, then dropout: mlp.py:318-327) -- dropout holds no parameters
+        self.dropout = nn.ModuleList([nn.Dropout(dropout) for _ in range(self.n_layers)]) if dropout and dropout > 0.0 else None
+        for i in range(self.n_layers):
+            self.fcs.append(nn.Linear(layers[i], layers[i + 1]))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.act is None or self.dropout is not None:
+            return _generic_chain(x, self.fcs, self.non_linearity, self.dropout)
         acts = [self.act] * (self.n_layers - 1) + ["none"]
         return ops.mlp_chain(x, [fc.weight for fc in self.fcs], [fc.bias for fc in self.fcs], acts)
 
@@ -51,15 +72,19 @@ class ChannelMLP(nn.Module):
         self.in_channels = in_channels
         self.out_channels = in_channels if out_channels is None else out_channels
         self.hidden_channels = in_channels if hidden_channels is None else hidden_channels
-        if dropout and dropout > 0.0:
-            raise NotImplementedError("ChannelMLP dropout is not part of the GAOT path")
+        self.non_linearity = non_linearity
+        self.act = activation_name(non_linearity)
+        self.dropout = nn.ModuleList([nn.Dropout(dropout) for _ in range(n_layers)]) if dropout and dropout > 0.0 else None
         widths = [self.in_channels] + [self.hidden_channels] * (n_layers - 1) + [self.out_channels]
         self.fcs = nn.ModuleList(nn.Conv1d(widths[i], widths[i + 1], 1) for i in range(n_layers))
 
     def forward_channels_last(self, x: torch.Tensor, rowbias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if self.dropout is not None or (self.n_layers > 1 and self.act is None):
+            y = _generic_chain(x, self.fcs, self.non_linearity, self.dropout)
+            return y if rowbias is None else y + rowbias
         if self.n_layers == 1:
             return ops.linear(x, self.fcs[0].weight, self.fcs[0].bias, rowbias=rowbias)
-        acts = ["gelu"] * (self.n_layers - 1) + ["none"]
+        acts = [self.act] * (self.n_layers - 1) + ["none"]
         return ops.mlp_chain(x, [fc.weight for fc in self.fcs], [fc.bias for fc in self.fcs], acts)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:          # [B, c_in, n] -> [B, c_out, n]

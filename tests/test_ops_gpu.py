@@ -1017,8 +1017,40 @@ def test_agno_with_relu_kernel_mlp_matches_float64():
     assert rel(out, ref) < 3e-6 and rel(fd.grad, fr.grad) < 3e-6
     for prm, r in zip(layer.channel_mlp.parameters(), ws):
         assert rel(prm.grad, r.grad) < 2e-5
-    with pytest.raises(NotImplementedError):
-        AGNO(channel_mlp_layers=[4, 64, 64], channel_mlp_non_linearity=F.silu)
+    # any OTHER activation callable (mlp.py:311) -- and dropout (mlp.py:318-322) -- is served as well: one HIP GEMM per layer with the
+    # caller's callable in between
+    torch.manual_seed(3)
+    layer2 = AGNO(channel_mlp_layers=[4, 32, 64], channel_mlp_non_linearity=F.silu, use_attn=False, coord_dim=2).to(dev())
+    out2 = layer2(y=x.to(dev()), x=lat.to(dev()), f_y=f.to(dev()), neighbors=_dict(enc))
+    w2 = [p.detach().cpu().double() for p in layer2.channel_mlp.parameters()]
+    h2 = torch.cat([x[idx], lat[qid]], -1).double()
+    h2 = F.silu(h2 @ w2[0].t() + w2[1]) @ w2[2].t() + w2[3]
+    ref2 = torch.zeros(2, sp.numel() - 1, 64, dtype=torch.float64).index_add(1, qid, h2[None] * f.double()[:, idx])
+    ref2 = ref2 / (sp[1:] - sp[:-1]).clamp(min=1)[None, :, None]
+    assert rel(out2, ref2) < 3e-6
+
+
+def test_channel_mlp_arbitrary_activation_and_dropout():
+    """ChannelMLP / LinearChannelMLP with a non-default `non_linearity` callable and dropout (mlp.py:253-298, 311-337): the
+    Linear / Conv1d(k=1) layers stay HIP GEMMs; in eval mode dropout is the identity, in training mode it is torch's"""
+    import torch.nn.functional as F
+    from gaot_amd.model.layers.mlp import ChannelMLP, LinearChannelMLP
+    torch.manual_seed(0)
+    x = torch.randn(3, 500, 12)
+    for mod in (LinearChannelMLP([12, 40, 24], non_linearity=F.tanh, dropout=0.25), ChannelMLP(12, 24, 40, n_layers=3, non_linearity=F.silu, dropout=0.1)):
+        mod = mod.to(dev()).eval()
+        ws = [p.detach().cpu().double().reshape(p.shape[0], -1) if p.dim() > 1 else p.detach().cpu().double() for p in mod.parameters()]
+        act = mod.non_linearity
+        h = x.double()
+        for i in range(0, len(ws), 2):
+            h = h @ ws[i].t() + ws[i + 1]
+            if i + 2 < len(ws):
+                h = act(h)
+        y = mod(x.to(dev())) if isinstance(mod, LinearChannelMLP) else mod.forward_channels_last(x.to(dev()))
+        assert rel(y, h) < 3e-6
+        mod.train()
+        yt = mod(x.to(dev())) if isinstance(mod, LinearChannelMLP) else mod.forward_channels_last(x.to(dev()))
+        assert yt.shape == y.shape and float((yt == 0).float().mean()) > 0.05          # dropout zeroed its share of the outputs
 
 
 def test_attention_many_equal_tokens_long_sequence():
