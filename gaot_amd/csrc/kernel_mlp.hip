@@ -55,6 +55,10 @@ template <int ACT> __device__ __forceinline__ void act_both(float z, float& h, f
     else gelu_both(z, h, d);
 }
 
+// crow(r, hi) = crow0(r) + 4 hi: addressing through (base + 4 hi) [crow0(r) * stride] keeps ONE address register and constant offsets
+// (written as crow(r, hi) the compiler turns the sum into an OR it cannot fold and hoists one address per r out of the tile loop)
+__device__ __forceinline__ constexpr int crow0(int r) { return (r & 3) + 8 * (r >> 2); }
+
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -87,9 +91,9 @@ __device__ __forceinline__ void km_layer0(const float* W1s, const float* Bs, con
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            const int f = kt * 32 + crow(t, hi);
-            float v = Bs[f];
-            const float* wr = W1s + f * CM;              // zero-padded row: whole 16-byte chunks, no per-column predicate
+            const int f0 = kt * 32 + crow0(t);           // feature f0 + 4 hi: one address register, constant offsets
+            float v = (Bs + 4 * hi)[f0];
+            const float* wr = (W1s + 4 * hi * CM) + f0 * CM;      // zero-padded row: whole 16-byte chunks, no per-column predicate
 #pragma unroll
             for (int c4 = 0; c4 < CM / 4; ++c4) {
                 const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + 4 * c4);
@@ -358,6 +362,335 @@ __global__ __launch_bounds__(256, 1) void kernel_mlp_bwd_kernel(const KMArgs p) 
     for (int i = tid; i < nsmall; i += 256) dst[NL * 4096 + i] = R[i];
 }
 
+// =========================================================================================== bf16-split variants (default)
+// The same two kernels with the 64-wide layers of the forward chain, of the recompute and of the input-gradient chain on
+// v_mfma_f32_32x32x16_bf16: each fp32 operand is split exactly into three bf16 pieces (common.h), six piece products per k-step give
+// the fp32-level product at 3 / 8 of the matrix-pipe time of the fp32 MFMA (6 x 8 passes per 16 k against 8 x 16 passes).  The
+// orientation trick of the fp32 kernels carries over unchanged: k-slot e of half-wave hi in k-step j is feature
+// 16 j + 8 (e >> 2) + 4 hi + (e & 3), i.e. fragment registers 8 (j & 1) .. + 7 of tile j >> 1, so the B operand is split straight out
+// of the previous layer's result registers.  Weights sit in LDS as three bf16 planes [64][64] per layer (split once per workgroup);
+// the A operand is two 8-byte reads per plane (forward) or two TRANSPOSING reads (ds_read_b64_tr_b16: a lane supplies the address of 4
+// consecutive columns of one row and receives 4 consecutive rows of one column; tools/probe/tr_read.hip prints the lane map) for W^T
+// in the input-gradient chain.  The weight gradient stays on the fp32 MFMA with fp32 [feature][edge] tiles: it reduces over the
+// EDGES, with cancellation, so its operands need all 24 bits, and six bf16 planes of a 128-edge tile do not fit next to the weight
+// planes (two ROUNDED pieces per operand did fit, were 12 % faster and cost 7.6e-6 of relative error on every dW: not taken).
+constexpr int KS_LDB = 136;                   // bytes per row of a 64-column bf16 plane (+8: conflict-free 8-byte row reads and edge-row stores)
+constexpr int KS_PLANE = 64 * KS_LDB;         // one weight plane
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ u32x2 lds_tr(const unsigned char* p) {
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p)));
+}
+__device__ __forceinline__ u32x4 join8(u32x2 lo, u32x2 hi) { return u32x4{lo[0], lo[1], hi[0], hi[1]}; }
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// the six piece products, smallest terms first
+__device__ __forceinline__ f32x16 mfma_split6(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x16 c) {
+    c = mfma_bf16(a[2], b[0], c);
+    c = mfma_bf16(a[0], b[2], c);
+    c = mfma_bf16(a[1], b[1], c);
+    c = mfma_bf16(a[1], b[0], c);
+    c = mfma_bf16(a[0], b[1], c);
+    return mfma_bf16(a[0], b[0], c);
+}
+template <int NL, int CM>
+__device__ __forceinline__ void km_stage_weights_split(const KMArgs& p, unsigned char* Wp, float* W1s, float* Bs, int tid) {
+#pragma unroll
+    for (int m = 0; m < NL; ++m)
+        for (int i = tid; i < 64 * 16; i += 256) {
+            const int r = i >> 4, c4 = (i & 15) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (r < p.wo[m + 1] && c4 < p.wo[m]) v = *reinterpret_cast<const f32x4*>(p.w[m] + r * p.ldw[m + 1] + c4);
+            unsigned h0, m0, l0, h1, m1, l1;
+            split3_pair(v[0], v[1], h0, m0, l0);
+            split3_pair(v[2], v[3], h1, m1, l1);
+            unsigned char* d = Wp + m * 3 * KS_PLANE + r * KS_LDB + c4 * 2;
+            *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(d + KS_PLANE) = u32x2{m0, m1};
+            *reinterpret_cast<u32x2*>(d + 2 * KS_PLANE) = u32x2{l0, l1};
+        }
+    for (int i = tid; i < 64 * CM; i += 256) { const int f = i / CM, c = i % CM; W1s[i] = (c < p.cin && f < p.wo[0]) ? p.w1[f * p.ldw[0] + c] : 0.f; }
+    if (tid < 64) {
+        Bs[tid] = tid < p.wo[0] ? p.b1[tid] : 0.f;
+#pragma unroll
+        for (int m = 0; m < NL; ++m) Bs[64 * (m + 1) + tid] = tid < p.wo[m + 1] ? p.b[m][tid] : 0.f;
+    }
+}
+
+// one layer: acc[io] = b + W h, W as three planes at Wp
+__device__ __forceinline__ void km_layer_split(const unsigned char* Wp, const float* bias, const f32x16 (&h)[2], int li, int hi, f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int io = 0; io < 2; ++io)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[io][r] = (bias + 4 * hi)[io * 32 + crow0(r)];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int kt = j >> 1, r0 = 8 * (j & 1);
+        unsigned q0[4], q1[4], q2[4];
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) split3_pair(h[kt][r0 + 2 * e2], h[kt][r0 + 2 * e2 + 1], q0[e2], q1[e2], q2[e2]);
+        const u32x4 b[3] = {u32x4{q0[0], q0[1], q0[2], q0[3]}, u32x4{q1[0], q1[1], q1[2], q1[3]}, u32x4{q2[0], q2[1], q2[2], q2[3]}};
+#pragma unroll
+        for (int io = 0; io < 2; ++io) {
+            const unsigned char* ap = Wp + (io * 32 + li) * KS_LDB + (16 * j + 4 * hi) * 2;
+            u32x4 a[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                a[pl] = join8(*reinterpret_cast<const u32x2*>(ap + pl * KS_PLANE), *reinterpret_cast<const u32x2*>(ap + pl * KS_PLANE + 16));
+            acc[io] = mfma_split6(a, b, acc[io]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// (two workgroups per CU: 9 planes + the first layer's [64][CM] weights + biases are 80 384 B at c_in <= 4, and 256 registers)
+template <int NL, int CM, int ACT>
+__global__ __launch_bounds__(256, 2) void kernel_mlp_fwd_split_kernel(const KMArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char Wp[NL * 3 * KS_PLANE];
+    __shared__ __attribute__((aligned(16))) float W1s[64 * CM];
+    __shared__ float Bs[64 * (NL + 1)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, hi = lane >> 5;
+    km_stage_weights_split<NL, CM>(p, Wp, W1s, Bs, tid);
+    __syncthreads();
+    const int e0 = (blockIdx.x * 4 + wave) * 32;
+    if (e0 >= p.E) return;
+    const int e = min(e0 + li, p.E - 1);
+    float xr[CM];
+    km_load_x<CM>(p, e, xr);
+    f32x16 z[2], h[2];
+    km_layer0<CM>(W1s, Bs, xr, p.cin, hi, z);
+#pragma unroll
+    for (int m = 0; m < NL; ++m) {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) h[kt][t] = act_f<ACT>(z[kt][t]);
+        km_layer_split(Wp + m * 3 * KS_PLANE, Bs + 64 * (m + 1), h, li, hi, z);
+    }
+    if (e0 + li < p.E) {
+        float* dst = p.out + (long)(e0 + li) * p.cout;
+#pragma unroll
+        for (int io = 0; io < 2; ++io)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (io * 32 + 8 * q + 4 * hi < p.cout)
+                    *reinterpret_cast<f32x4*>(dst + io * 32 + 8 * q + 4 * hi) = f32x4{z[io][4 * q], z[io][4 * q + 1], z[io][4 * q + 2], z[io][4 * q + 3]};
+    }
+}
+
+template <int NL, int CM, int ACT>
+__global__ __launch_bounds__(256, 1) void kernel_mlp_bwd_split_kernel(const KMArgs p) {
+    constexpr int TILE = 64 * KM_TLD128;
+    __shared__ __attribute__((aligned(16))) unsigned char Wp[NL * 3 * KS_PLANE];
+    __shared__ __attribute__((aligned(16))) float W1s[64 * KM_MAXC];
+    __shared__ float Bs[64 * (NL + 1)];
+    __shared__ __attribute__((aligned(16))) float Gt[TILE];
+    __shared__ __attribute__((aligned(16))) float Ht[TILE];
+    __shared__ __attribute__((aligned(16))) float Xt[128 * KM_MAXC];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, hi = lane >> 5;
+    const int io_w = wave >> 1, kt_w = wave & 1;
+    const int cin = p.cin;
+    // transposing read: lane t of 16-lane group g addresses row 4 (g >> 1) + (t >> 2), columns 16 (g & 1) + 4 (t & 3) .. + 3 of a
+    // [16 rows][32 columns] block and receives rows 4 (g >> 1) .. + 3 of column 16 (g & 1) + t = li: k-slots 0..3 of half-wave hi = g >> 1
+    // (k-slots 4..7: the same, eight rows further down)
+    const int tr_off = (4 * (lane >> 5) + ((lane & 15) >> 2)) * KS_LDB + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    km_stage_weights_split<NL, CM>(p, Wp, W1s, Bs, tid);
+    __syncthreads();
+
+    f32x16 dW[NL];
+#pragma unroll
+    for (int m = 0; m < NL; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dW[m][r] = 0.f;
+    float db[NL + 1];
+    float dw1[CM];
+#pragma unroll
+    for (int m = 0; m <= NL; ++m) db[m] = 0.f;
+#pragma unroll
+    for (int c = 0; c < CM; ++c) dw1[c] = 0.f;
+
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        asm volatile("" ::: "memory");
+        const int e0 = tile * 128 + wave * 32;
+        const bool valid = e0 + li < p.E;
+        const int e = min(e0 + li, p.E - 1);
+        float xr[CM];
+        km_load_x<CM>(p, e, xr);
+        // upstream gradient: requested now, consumed after the recompute (one wave per SIMD: nothing else hides the HBM latency)
+        f32x16 g[2];
+        {
+            const float* src = p.dk + (long)e * p.cout;
+#pragma unroll
+            for (int io = 0; io < 2; ++io)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (valid && io * 32 + 8 * q + 4 * hi < p.cout) v = *reinterpret_cast<const f32x4*>(src + io * 32 + 8 * q + 4 * hi);
+                    g[io][4 * q] = v[0]; g[io][4 * q + 1] = v[1]; g[io][4 * q + 2] = v[2]; g[io][4 * q + 3] = v[3];
+                }
+        }
+        if (hi == 0) {
+#pragma unroll
+            for (int c = 0; c < CM; ++c) Xt[(wave * 32 + li) * KM_MAXC + c] = valid ? xr[c] : 0.f;
+        }
+        // recompute the chain; every hidden activation is evaluated ONCE, together with its derivative: z[m] becomes act'(z[m]),
+        // hk[m] = act(z[m]).  The LAST hidden activation is not needed by the recompute: it is evaluated inside its layer's
+        // backward, eight values at a time.
+        // (KEEP_H: with three MFMA layers the two kept activation fragments push the kernel past 512 registers, and the spills cost
+        // more than evaluating those activations a second time)
+        constexpr bool KEEP_H = true;
+        f32x16 z[NL][2], hk[KEEP_H && NL > 1 ? NL - 1 : 1][2];
+        km_layer0<CM>(W1s, Bs, xr, cin, hi, z[0]);
+#pragma unroll
+        for (int m = 0; m + 1 < NL; ++m) {
+            if (KEEP_H) {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        float hv, dv;
+                        act_both<ACT>(z[m][kt][t], hv, dv);
+                        hk[m][kt][t] = hv; z[m][kt][t] = dv;
+                    }
+                km_layer_split(Wp + m * 3 * KS_PLANE, Bs + 64 * (m + 1), hk[m], li, hi, z[m + 1]);
+            } else {
+                f32x16 h[2];
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) h[kt][t] = act_f<ACT>(z[m][kt][t]);
+                km_layer_split(Wp + m * 3 * KS_PLANE, Bs + 64 * (m + 1), h, li, hi, z[m + 1]);
+            }
+        }
+        // The bf16 MFMA does not round its accumulator to nearest: every result carries a small bias of ONE sign, whatever the sign
+        // of the value (measured: db_1 = sum over edges of G_0 was 2.8e-6 off at 5.6e4 edges and 8.8e-6 at 4e5, growing like sqrt(E),
+        // where the fp32 MFMA gives 3e-7).  Odd edges therefore run the input-gradient chain on -G: their bias comes back with the
+        // opposite sign and cancels in every sum over edges (the sign is undone in the act' multiply below; G itself goes to the
+        // tiles unflipped).
+        const unsigned sbit = (unsigned)(li & 1) << 31;
+        auto flip = [sbit](float v) { return __uint_as_float(__float_as_uint(v) ^ sbit); };
+        float* gcol = Gt + (4 * hi) * KM_TLD128 + wave * 32 + li;       // this lane's edge column, feature row 4 hi
+        float* hcol = Ht + (4 * hi) * KM_TLD128 + wave * 32 + li;
+#pragma unroll
+        for (int m = NL; m >= 1; --m) {
+            // dH_{m-1} = W_m^T G_m on the bf16 pipe (W^T fragments by transposing reads, G split out of the registers), G_m and
+            // H_{m-1} to the workgroup's fp32 [feature][edge] tiles on the way; then dW_m quadrant on the fp32 MFMA (its operands
+            // are summed over ~10^5 edges with cancellation: two-piece operands there cost 7e-6 of relative error, measured)
+            const unsigned char* W = Wp + (m - 1) * 3 * KS_PLANE;
+            f32x16 dh[2];
+#pragma unroll
+            for (int io = 0; io < 2; ++io)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dh[io][r] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kt = j >> 1, r0 = 8 * (j & 1);
+                u32x4 a[2][3];
+#pragma unroll
+                for (int io = 0; io < 2; ++io) {
+                    const unsigned char* ap = W + (16 * j) * KS_LDB + (io * 32) * 2 + tr_off;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) a[io][pl] = join8(lds_tr(ap + pl * KS_PLANE), lds_tr(ap + pl * KS_PLANE + 8 * KS_LDB));
+                }
+                unsigned q0[4], q1[4], q2[4];
+#pragma unroll
+                for (int e2 = 0; e2 < 4; ++e2) split3_pair(flip(g[kt][r0 + 2 * e2]), flip(g[kt][r0 + 2 * e2 + 1]), q0[e2], q1[e2], q2[e2]);
+                const u32x4 b[3] = {u32x4{q0[0], q0[1], q0[2], q0[3]}, u32x4{q1[0], q1[1], q1[2], q1[3]}, u32x4{q2[0], q2[1], q2[2], q2[3]}};
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    float hv;
+                    if (m == NL || !KEEP_H) { float dv; act_both<ACT>(z[m - 1][kt][r0 + u], hv, dv); z[m - 1][kt][r0 + u] = dv; }
+                    else hv = hk[m == NL ? 0 : m - 1][kt][r0 + u];
+                    gcol[(kt * 32 + crow0(r0 + u)) * KM_TLD128] = g[kt][r0 + u];
+                    hcol[(kt * 32 + crow0(r0 + u)) * KM_TLD128] = hv;
+                }
+#pragma unroll
+                for (int io = 0; io < 2; ++io) dh[io] = mfma_split6(a[io], b, dh[io]);
+                __builtin_amdgcn_sched_barrier(0);          // one k-step at a time: left alone, the scheduler hoists fragment reads until it spills
+            }
+            __syncthreads();
+            {
+                const float* ga = Gt + (io_w * 32 + li) * KM_TLD128 + 4 * hi;
+                const float* hb = Ht + (kt_w * 32 + li) * KM_TLD128 + 4 * hi;
+                float dsum = 0.f;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(ga + 8 * q);
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(hb + 8 * q);
+                    dsum += (av[0] + av[1]) + (av[2] + av[3]);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) dW[m - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], dW[m - 1], 0, 0, 0);
+                }
+                db[m] += dsum;
+            }
+#pragma unroll
+            for (int io = 0; io < 2; ++io)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) g[io][r] = dh[io][r] * flip(z[m - 1][io][r]);
+            __syncthreads();
+        }
+        // first layer: dW_1 = G_0 x^T, db_1 on the VALU
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) gcol[(kt * 32 + crow0(t)) * KM_TLD128] = g[kt][t];
+        __syncthreads();
+        {
+            const float* ga = Gt + (io_w * 32 + li) * KM_TLD128 + kt_w * 64 + 4 * hi;
+            float dsum = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(ga + 8 * q);
+                dsum += (av[0] + av[1]) + (av[2] + av[3]);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float* xe = Xt + (kt_w * 64 + 8 * q + 4 * hi + s) * KM_MAXC;
+#pragma unroll
+                    for (int c4 = 0; c4 < CM / 4; ++c4) {
+                        const f32x4 xv = *reinterpret_cast<const f32x4*>(xe + 4 * c4);
+                        dw1[4 * c4] += av[s] * xv[0]; dw1[4 * c4 + 1] += av[s] * xv[1]; dw1[4 * c4 + 2] += av[s] * xv[2]; dw1[4 * c4 + 3] += av[s] * xv[3];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            db[0] += dsum;
+        }
+        __syncthreads();
+    }
+
+    float* dst = p.ws + (long)blockIdx.x * p.psize;
+#pragma unroll
+    for (int m = 0; m < NL; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[m * 4096 + (io_w * 32 + crow(r, hi)) * 64 + kt_w * 32 + li] = dW[m][r];
+    float* R = Gt;
+    const int off_b = 64 * cin, nsmall = 64 * cin + 64 * (NL + 1);
+#pragma unroll
+    for (int c = 0; c < CM; ++c) dw1[c] += __shfl_xor(dw1[c], 32, 64);
+#pragma unroll
+    for (int m = 0; m <= NL; ++m) db[m] += __shfl_xor(db[m], 32, 64);
+    for (int pass = 0; pass < 2; ++pass) {
+        if (kt_w == pass && hi == 0) {
+#pragma unroll
+            for (int c = 0; c < CM; ++c)
+                if (c < cin) { float* d = R + (io_w * 32 + li) * cin + c; *d = pass == 0 ? dw1[c] : *d + dw1[c]; }
+            float* d0 = R + off_b + io_w * 32 + li;
+            *d0 = pass == 0 ? db[0] : *d0 + db[0];
+            if (pass == 0) {
+#pragma unroll
+                for (int m = 1; m <= NL; ++m) R[off_b + m * 64 + io_w * 32 + li] = db[m];
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < nsmall; i += 256) dst[NL * 4096 + i] = R[i];
+}
+
 static int km_check(const float* x, int E, int cin, int n_layers, const float* const* w, const float* const* b) {
     GAOT_REQUIRE(x && E > 0 && cin >= 1 && cin <= KM_MAXC, "kernel_mlp: need x, E > 0 and 1 <= c_in <= %d (got %d)", KM_MAXC, cin);
     GAOT_REQUIRE(n_layers >= 2 && n_layers <= 4, "kernel_mlp: 2..4 layers (got %d)", n_layers);
@@ -367,6 +700,7 @@ static int km_check(const float* x, int E, int cin, int n_layers, const float* c
 }
 
 static int g_km_abl = 0;
+static int g_km_split = 1;      // 1: bf16-split kernels (default), 0: the fp32-MFMA kernels (gaot_debug_set_kernel_mlp_split)
 static void km_fill(KMArgs& a, const float* x, int E, int cin, int n_layers, const float* const* w, const float* const* b, const int* widths,
                     const int* ldw = nullptr) {
     a.x = x; a.cin = cin; a.E = E; a.w1 = w[0]; a.b1 = b[0]; a.cout = widths[n_layers - 1];
@@ -383,6 +717,7 @@ static void km_fill(KMArgs& a, const float* x, int E, int cin, int n_layers, con
 using namespace gaot;
 
 extern "C" int gaot_debug_set_kernel_mlp_ablate(int bits) { const int old = g_km_abl; g_km_abl = bits; return old; }
+extern "C" int gaot_debug_set_kernel_mlp_split(int on) { const int old = g_km_split; g_km_split = on ? 1 : 0; return old; }
 
 static int km_widths_ok(const int32_t* widths, int n_layers) {
     GAOT_REQUIRE(widths, "kernel_mlp: widths must be non-null");
@@ -419,13 +754,15 @@ extern "C" int gaot_kernel_mlp_fwd_w(const float* x, int32_t E, int32_t cin, int
     KMArgs a{}; km_fill(a, x, E, cin, n_layers, w, b, widths, ldw); a.out = out;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid(a.ntiles), block(256);
-#define KM_FWD2(NL, A) do { if (cin == 4) hipLaunchKernelGGL((kernel_mlp_fwd_kernel<NL, 4, A>), grid, block, 0, st, a); \
-                            else if (cin <= 8) hipLaunchKernelGGL((kernel_mlp_fwd_kernel<NL, 8, A>), grid, block, 0, st, a); \
-                            else hipLaunchKernelGGL((kernel_mlp_fwd_kernel<NL, KM_MAXC, A>), grid, block, 0, st, a); } while (0)
+#define KM_FWD3(K, NL, A) do { if (cin == 4) hipLaunchKernelGGL((K<NL, 4, A>), grid, block, 0, st, a); \
+                               else if (cin <= 8) hipLaunchKernelGGL((K<NL, 8, A>), grid, block, 0, st, a); \
+                               else hipLaunchKernelGGL((K<NL, KM_MAXC, A>), grid, block, 0, st, a); } while (0)
+#define KM_FWD2(NL, A) do { if (g_km_split && !a.abl) KM_FWD3(kernel_mlp_fwd_split_kernel, NL, A); else KM_FWD3(kernel_mlp_fwd_kernel, NL, A); } while (0)
 #define KM_FWD(NL) do { if (act == GAOT_ACT_RELU) KM_FWD2(NL, GAOT_ACT_RELU); else KM_FWD2(NL, GAOT_ACT_GELU); } while (0)
     if (n_layers == 2) KM_FWD(1); else if (n_layers == 3) KM_FWD(2); else KM_FWD(3);
 #undef KM_FWD
 #undef KM_FWD2
+#undef KM_FWD3
     GAOT_CHECK_LAUNCH("gaot_kernel_mlp_fwd");
     return GAOT_OK;
 }
@@ -456,13 +793,15 @@ extern "C" int gaot_kernel_mlp_bwd_w(const float* x, int32_t E, int32_t cin, int
     KMArgs a{}; km_fill(a, x, E, cin, n_layers, w, b, widths, ldw); a.dk = dk; a.ws = workspace;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int grid = a.ntiles > 256 ? 256 : a.ntiles;
-#define KM_BWD2(NL, A) do { if (cin == 4) hipLaunchKernelGGL((kernel_mlp_bwd_kernel<NL, 4, A>), dim3(grid), dim3(256), 0, st, a); \
-                            else if (cin <= 8) hipLaunchKernelGGL((kernel_mlp_bwd_kernel<NL, 8, A>), dim3(grid), dim3(256), 0, st, a); \
-                            else hipLaunchKernelGGL((kernel_mlp_bwd_kernel<NL, KM_MAXC, A>), dim3(grid), dim3(256), 0, st, a); } while (0)
+#define KM_BWD3(K, NL, A) do { if (cin == 4) hipLaunchKernelGGL((K<NL, 4, A>), dim3(grid), dim3(256), 0, st, a); \
+                               else if (cin <= 8) hipLaunchKernelGGL((K<NL, 8, A>), dim3(grid), dim3(256), 0, st, a); \
+                               else hipLaunchKernelGGL((K<NL, KM_MAXC, A>), dim3(grid), dim3(256), 0, st, a); } while (0)
+#define KM_BWD2(NL, A) do { if (g_km_split) KM_BWD3(kernel_mlp_bwd_split_kernel, NL, A); else KM_BWD3(kernel_mlp_bwd_kernel, NL, A); } while (0)
 #define KM_BWD(NL) do { if (act == GAOT_ACT_RELU) KM_BWD2(NL, GAOT_ACT_RELU); else KM_BWD2(NL, GAOT_ACT_GELU); } while (0)
     if (n_layers == 2) KM_BWD(1); else if (n_layers == 3) KM_BWD(2); else KM_BWD(3);
 #undef KM_BWD
 #undef KM_BWD2
+#undef KM_BWD3
     GAOT_CHECK_LAUNCH("gaot_kernel_mlp_bwd");
     // fixed-order sum of the per-workgroup partial rows: the short-matrix column sum of pointwise.hip (<= 256 rows).
     // grads == workspace: the caller sums the rows itself (gaot_colsum_grouped over parameter-sized column blocks, at the end of

@@ -48,6 +48,9 @@ int gaot_debug_set_attention_p_pieces(int n);
 int gaot_debug_set_attention_pipe(int on);
 /* tuning hook (results become WRONG): forward kernel 1 = no stores, 2 = no GELU, 4 = no MFMA layers, 8 = no weight staging */
 int gaot_debug_set_kernel_mlp_ablate(int bits);
+/* A/B hook: 1 (default) = the bf16-split kernel-MLP kernels (fp32-level products on v_mfma_f32_32x32x16_bf16), 0 = the fp32-MFMA
+ * kernels.  Same results to fp32 rounding either way.  Returns the previous value. */
+int gaot_debug_set_kernel_mlp_split(int on);
 int gaot_debug_set_ep_chunk(int edges_per_chunk);      /* tuning only: 0 = default (32) */
 
 #ifdef __cplusplus

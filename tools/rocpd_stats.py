@@ -13,6 +13,9 @@ for n, s, e in rows:
     a = agg[n]; d = e - s
     a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
 tot = sum(v[1] for v in agg.values())
+if steps is None or steps <= 0:          # one optimizer launch per step: count them instead of trusting the caller
+    n_opt = [v[0] for k, v in agg.items() if 'adamw_kernel' in k]
+    steps = float(n_opt[0]) if n_opt else None
 def demangle(n):
     n = re.sub(r'\.kd$', '', n)
     m = re.match(r'_ZN4gaot(\d+)([A-Za-z_0-9]+)', n)
