@@ -200,12 +200,29 @@ def cpu_baseline(sd, tensors, hip, steps: int = 3):
     # behind ReLU gates on those statistics and move by ~2e-4 when the ORACLE ITSELF switches their arithmetic
     cfg64 = O.OracleConfig(**{**cfg.__dict__, "stats_dtype": "float64"})
     _, grads64, _, _ = O.train_step(sd, cfg64, batch, state=None)
+    dbl = lambda v: v.double() if v.is_floating_point() else v
+    batch64 = {k: (dbl(v) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    _, gradsd, _, _, predd = O.train_step({k: dbl(v) for k, v in sd.items()}, cfg, batch64, state=None, return_pred=True)   # float64 end to end
     loss0, grads0, sd, state, pred0 = O.train_step(sd, cfg, batch, state=None, return_pred=True)      # warm-up + parity reference
     top = max(float(g.double().norm()) for g in grads0.values())
     rel = lambda ref: {k: float((hip["grads"][k].double() - g.double()).norm()) / max(float(g.double().norm()), 1e-3 * top) for k, g in ref.items()}
     gerr, gerr64 = rel(grads0), rel(grads64)
     worst, worst64 = max(gerr, key=gerr.get), max(gerr64, key=gerr64.get)
+    # and against the SAME oracle evaluated in float64 throughout (weights, batch, every intermediate): the fp32 oracle's own rounding
+    # leaves the comparison, what remains is the kernels' (tools/grad_errors.py prints the per-tensor table)
+    topd = max(float(g.norm()) for g in gradsd.values())
+    reld = lambda a, b: float((a.double() - b).norm()) / max(float(b.norm()), 1e-3 * topd)
+    gerrd = {k: reld(hip["grads"][k], g) for k, g in gradsd.items()}
+    gerrd_oracle = {k: reld(grads0[k], g) for k, g in gradsd.items()}
+    worstd = max(gerrd, key=gerrd.get)
+    vs64 = {"output": float((hip["pred"].double() - predd).norm() / predd.norm()),
+            "grad_worst_tensor": gerrd[worstd], "grad_worst_name": worstd,
+            "fp32_oracle_output": float((pred0.double() - predd).norm() / predd.norm()),
+            "fp32_oracle_grad_worst_tensor": max(gerrd_oracle.values()),
+            "what": "the same comparison against the oracle evaluated in float64 end to end; fp32_oracle_*: the fp32 oracle "
+                    "(= the reference's arithmetic) against it, i.e. the reference's own rounding on this batch"}
     parity = {"output": float((hip["pred"].double() - pred0.double()).norm() / pred0.double().norm()),
+              "vs_float64_oracle": vs64,
               "loss": abs(hip["loss"] - float(loss0)) / abs(float(loss0)),
               "grad_worst_tensor": gerr[worst], "grad_worst_name": worst,
               "grad_worst_tensor_vs_oracle_with_f64_statistics": gerr64[worst64], "grad_worst_name_f64_statistics": worst64,

@@ -1978,13 +1978,15 @@ using namespace gaot;
 
 static int g_attn_split = 1;     // head_dim 32: 1 = split-bf16 kernels (default; 8-wave forward when it fills the chip), 0 = fp32-MFMA kernels,
                                  // 2 = split with the 8-wave forward always, 3 = split with the 4-wave forward always
-// pieces of P (forward) and of P / dS (backward) in the head_dim-32 split kernels, as 10 * forward + backward: 32 (default) = exact
-// three-way split in the forward (the output bar is 1e-5 and the two-piece forward costs 1e-6 of it per layer), two rounded pieces
-// in the backward (gradient bar 1e-4; measured 1.3e-6); 33 / 22 / 23: A/B and tests
-static int g_attn_pp = 32;
+// pieces of P (forward) and of P / dS (backward) in the head_dim-32 split kernels, as 10 * forward + backward: 22 (default) = two ROUNDED
+// pieces everywhere (five piece products per P V / dS K product instead of six).  Measured at the bench configuration against the
+// oracle evaluated in float64 (tools/grad_errors.py): output 1.25e-7 with either forward, worst gradient tensor 7.6e-7 (q_proj of the
+// middle layer) with either; the kernel alone is 2.2e-6 off float64 instead of 2.4e-7 on random data -- a rounding error of the
+// probabilities, which sum to one and average out over the keys.  33 / 32 / 23: A/B and tests.
+static int g_attn_pp = 22;
 extern "C" int gaot_debug_set_attention_p_pieces(int n) {
     const int old = g_attn_pp;
-    g_attn_pp = (n == 33 || n == 22 || n == 23 || n == 32) ? n : (n == 3 ? 33 : (n == 2 ? 22 : 32));
+    g_attn_pp = (n == 33 || n == 22 || n == 23 || n == 32) ? n : (n == 3 ? 33 : 22);
     return old;
 }
 static int g_attn_pipe = 0;      // 1 = the software-pipelined 8-wave forward for S % 64 == 0 (same speed as the plain one since both keep the

@@ -40,8 +40,8 @@ int gaot_debug_set_wgrad_kslab(int k);
  * 8-wave / 4-wave forward workgroup forced.  Returns the previous value. */
 int gaot_debug_set_attention_split(int on);
 /* head_dim-32 split attention: pieces of P in the forward and of P / dS in the backward products, as 10 * forward + backward:
- * 32 (default) = exact three-way split forward, two rounded pieces (five piece products instead of six) backward; 33, 22, 23 for
- * A/B runs.  Returns the previous value. */
+ * 22 (default) = two rounded pieces (five piece products instead of six) in both; 33 = exact three-way splits; 32, 23 for A/B runs.
+ * Returns the previous value. */
 int gaot_debug_set_attention_p_pieces(int n);
 /* tuning hook: 1 = the software-pipelined 8-wave split forward where it applies (S % 64 == 0), 0 (default) = the plain one.
  * Returns the previous value. */

@@ -295,7 +295,16 @@ def test_attention_fwd_bwd(B, S, H, Hkv, D):
         finally:
             _lib.load().gaot_debug_set_attention_split(old)
         assert rel(out2, ref) < 3e-6 and rel(d2.grad, r.grad) < 1e-5
-        assert rel(out, ref) < 2 * rel(out2, ref) + 1e-7 and rel(d.grad, r.grad) < 2 * rel(d2.grad, r.grad) + 1e-7     # as accurate as fp32 MFMA
+        # head_dim 32 defaults to two ROUNDED pieces of P / dS (the bars above); with exact three-way splits (33) the split kernels are
+        # as accurate as the fp32 MFMA
+        old = _lib.load().gaot_debug_set_attention_p_pieces(33)
+        try:
+            d3 = qkv.to(dev()).requires_grad_(True)
+            out3 = ops.attention(d3, H, Hkv, D)
+            out3.backward(go.to(dev()))
+        finally:
+            _lib.load().gaot_debug_set_attention_p_pieces(old)
+        assert rel(out3, ref) < 2 * rel(out2, ref) + 1e-7 and rel(d3.grad, r.grad) < 2 * rel(d2.grad, r.grad) + 1e-7
         # the 256-query / 256-key workgroup variants (picked by the heuristic only when they fill the chip) forced on
         old = _lib.load().gaot_debug_set_attention_split(2)
         try:
@@ -313,7 +322,7 @@ def test_attention_fwd_bwd(B, S, H, Hkv, D):
                     out4 = ops.attention(qkv.to(dev()), H, Hkv, D)
             finally:
                 lib.gaot_debug_set_attention_split(old); lib.gaot_debug_set_attention_pipe(oldp)
-            assert rel(out4, ref) < 3e-6 and rel(out4, out3) < 1e-6
+            assert rel(out4, ref) < 3e-6 and rel(out4, out3) < 3e-6      # (the pipelined variant splits P three ways, the default two)
 
 
 def _dropout_factor(seed: int, B, H, S, p):

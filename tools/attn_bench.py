@@ -34,4 +34,4 @@ for mode, pipe, pp in ((0, 0, 33), (2, 0, 33), (2, 0, 22), (2, 0, 33), (2, 0, 22
     g, = torch.autograd.grad(o2, qkv, go, retain_graph=True)
     tb = timeit(lambda: torch.autograd.grad(o2, qkv, go, retain_graph=True))
     print(f"mode {mode} pipe {pipe} P pieces {pp}: fwd {tf:.1f} us   bwd (delta + main + dq reduce) {tb:.1f} us   rel-L2 vs f64: out {rel(o, o64.detach()):.2e}  dqkv {rel(g, g64):.2e}")
-lib.gaot_debug_set_attention_split(1); lib.gaot_debug_set_attention_pipe(0); lib.gaot_debug_set_attention_p_pieces(32)
+lib.gaot_debug_set_attention_split(1); lib.gaot_debug_set_attention_pipe(0); lib.gaot_debug_set_attention_p_pieces(22)
