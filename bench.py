@@ -439,19 +439,18 @@ def secondary_configs(dev, which=("C3", "C4", "C5"), steps: int = 20, warmup: in
     return out
 
 
-def hip_reference_pass(model, tensors):
-    """prediction, loss and every gradient of the HIP path at the INITIAL weights (eager, before TrainStep touches them)"""
-    from gaot_amd import ops
+def hip_reference_pass(ts, model, tensors):
+    """prediction, loss and every gradient of the HIP path at the INITIAL weights, through the TRAINING path itself: TrainStep's eager
+    forward + backward (the same launches the captured step replays, including the grouped weight-gradient launch), before any update"""
     lat, x, p, t = tensors
-    model.zero_grad(set_to_none=True)
-    pred = model(latent_tokens_coord=lat, xcoord=x, pndata=p)
-    loss = ops.mse_loss(pred, t)
-    loss.backward()
+    with torch.no_grad():
+        pred = model(latent_tokens_coord=lat, xcoord=x, pndata=p)
+    loss = ts._forward_backward()
     torch.cuda.synchronize()
     csr = lambda m: tuple(list(m.neighbor_cache.values())[0][0][k].cpu() for k in ("neighbors_index", "neighbors_row_splits"))
-    out = {"pred": pred.detach().cpu(), "loss": float(loss.detach()), "grads": {k: q.grad.detach().cpu().clone() for k, q in model.named_parameters()},
+    out = {"pred": pred.detach().cpu(), "loss": float(loss), "grads": {k: q.grad.detach().cpu().clone() for k, q in model.named_parameters()},
            "enc_csr": csr(model.encoder), "dec_csr": csr(model.decoder)}
-    model.zero_grad(set_to_none=True)
+    ts.bucket.clear()
     return out
 
 
@@ -499,10 +498,10 @@ def main():
     lat, x, p, t = synthetic(1234 + rank, dev)
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()} if want_cpu else None
-    hip0 = hip_reference_pass(model, (lat, x, p, t)) if want_cpu else None
     staged = {"0": False, "1": True}.get(os.environ.get("GAOT_BENCH_STAGED", ""), None)     # A/B hook; default: staged when world > 1
     ts = TrainStep(model, lr=8e-4, weight_decay=1e-5, use_graph=not args.no_graph, staged=staged)
     ts.bind(p, t, latent_tokens_coord=lat, xcoord=x)
+    hip0 = hip_reference_pass(ts, model, (lat, x, p, t)) if want_cpu else None
 
     def sync():
         torch.cuda.synchronize()

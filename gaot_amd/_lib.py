@@ -29,6 +29,7 @@ class GemmDesc(C.Structure):
         ("split_k", C.c_int32), ("workspace", _f),
         ("colsum", _f),
         ("b_planes", C.c_void_p), ("ld_bplanes", C.c_int64), ("b_plane_stride", C.c_int64),
+        ("pieces", C.c_int32),
     ]
 
 
@@ -55,7 +56,7 @@ PROTOTYPES = {
     "gaot_last_error": (C.c_char_p, []),
     "gaot_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _s]),
     "gaot_gemm_tn_grouped_workspace": (C.c_int64, [C.POINTER(WgradItem), C.c_int32, C.POINTER(C.c_int32)]),
-    "gaot_gemm_tn_grouped": (C.c_int, [C.POINTER(WgradItem), C.c_int32, _f, _i, _s]),
+    "gaot_gemm_tn_grouped": (C.c_int, [C.POINTER(WgradItem), C.c_int32, C.c_int32, _f, _i, _s]),
     "gaot_debug_set_gemm_tile": (C.c_int, [C.c_int]),
     "gaot_debug_set_gemm_ablate": (C.c_int, [C.c_int]),
     "gaot_debug_last_gemm_path": (C.c_int, []),

@@ -346,8 +346,15 @@ namespace gaot { void set_split_persist(int n); }
 extern "C" int gaot_debug_set_split_persist(int n) { gaot::set_split_persist(n); return 0; }
 static int g_gsplit = 0;         // 1: split-eligible products run on gemm_gsplit.hip (LDS-direct, split in registers) instead of gemm_split.hip
 extern "C" int gaot_debug_set_gemm_gsplit(int on) { const int old = g_gsplit; g_gsplit = on; return old; }
-static int g_split_pieces = 3;   // 3: fp32-level products (default); 1: operands rounded to bf16, one piece product (bench `--dtype bf16` only)
-extern "C" int gaot_debug_set_gemm_pieces(int n) { const int old = g_split_pieces; g_split_pieces = (n == 1) ? 1 : 3; return old; }
+// precision override of the split tiles: 0 (default) = every call's own gaot_gemm_desc.pieces; 1 = operands rounded to bf16, one piece
+// product (bench `--dtype bf16` only); 2 / 3 = forced for A/B runs
+static int g_split_pieces = 3, g_split_pieces_forced = 0;
+extern "C" int gaot_debug_set_gemm_pieces(int n) {
+    const int old = g_split_pieces_forced ? g_split_pieces : 0;
+    g_split_pieces_forced = (n == 1 || n == 2 || n == 3); g_split_pieces = g_split_pieces_forced ? n : 3;
+    return old;
+}
+int gaot_forced_pieces() { return g_split_pieces_forced ? g_split_pieces : 0; }
 static int g_use_planes = 1;     // 0: ignore gaot_gemm_desc.b_planes (A/B switch)
 extern "C" int gaot_debug_set_gemm_planes(int on) { const int old = g_use_planes; g_use_planes = on; return old; }
 static int g_ablate = 0;
@@ -382,6 +389,10 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
     if (split > 1) GAOT_REQUIRE(d->workspace != nullptr, "gemm: split_k > 1 needs a workspace");
     if (d->colsum) GAOT_REQUIRE(d->a_kmajor == 0 && d->A2 == nullptr, "gemm: colsum needs an m-major A operand (a_kmajor = 0)");
 
+    GAOT_REQUIRE(d->pieces == 0 || d->pieces == 2 || d->pieces == 3, "gemm: pieces must be 0 / 3 (exact) or 2 (two rounded pieces), got %d", d->pieces);
+    // the debug override (1: `--dtype bf16` bench variant; 2 / 3 forced for A/B runs) wins over the call's own precision
+    const int pieces = g_split_pieces_forced ? g_split_pieces : (d->pieces == 2 ? 2 : 3);
+
     GemmArgs a;
     a.M = d->M; a.N = d->N; a.K = d->K;
     a.A = d->A; a.lda = d->lda; a.A2 = d->A2; a.lda2 = d->lda2; a.k_split = d->k_split;
@@ -394,7 +405,7 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
     a.ablate = g_ablate;
     // B pre-split into bf16 planes (weights): only the split-bf16 tile kernels read them; every other path uses B itself
     a.Bpl = nullptr; a.ld_bpl = 0; a.bpl_stride = 0;
-    const bool planes_ok = d->b_planes != nullptr && g_use_planes && g_split_pieces == 3 && !g_gsplit && aligned16(d->b_planes) &&
+    const bool planes_ok = d->b_planes != nullptr && g_use_planes && pieces == 3 && !g_gsplit && aligned16(d->b_planes) &&
                            d->ld_bplanes % 8 == 0 && d->b_plane_stride % 8 == 0 && d->K % 16 == 0;
     {
         auto ok4 = [](const void* ptr, long ld) { return ptr == nullptr || (aligned16(ptr) && ld % 4 == 0); };
@@ -417,8 +428,8 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
             g_last_path = 3;
             const bool big = a.M >= 256 && (g_split_bm256 == 2 || (g_split_bm256 == 1 && nb128 >= 500));
             if (planes_ok) { a.Bpl = reinterpret_cast<const unsigned short*>(d->b_planes); a.ld_bpl = d->ld_bplanes; a.bpl_stride = d->b_plane_stride; }
-            if (g_gsplit) launch_gsplit(a, ak, bk, st, 128, g_split_pieces);
-            else launch_split(a, ak, bk, st, big && g_split_pieces == 3 ? 256 : 128, g_split_pieces);
+            if (g_gsplit) launch_gsplit(a, ak, bk, st, 128, pieces);
+            else launch_split(a, ak, bk, st, big && pieces == 3 ? 256 : 128, pieces);
         }
         else { g_last_path = 1; launch_glds(a, ak, bk, nb128 >= 512 ? 1 : ((long)cdiv(a.M, 128) * cdiv(a.N, 64) >= 512 ? 2 : 3), st); }
         GAOT_CHECK_LAUNCH("gaot_gemm_f32(swiglu)");
@@ -441,22 +452,23 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
     // fp32-MFMA tiles
     const long k_per_wg = a.split_k > 1 ? (long)a.ktiles_per_split * 32 : a.K;
     const bool split_ok = g_use_split && g_use_split != 3 && glds_ok && a.A2 == nullptr && g_tile_override == 0 &&
-                          (k_per_wg <= 1024 || g_split_pieces == 1 || g_use_split != 1);      // forced tuning modes bypass the cap
+                          (k_per_wg <= 1024 || pieces == 1 || g_use_split != 1);      // forced tuning modes bypass the cap
     // measured (tools/gemm_split_test.py): the 128x128 split-bf16 tiles win once they fill the chip (>= 256 workgroups
     // counting split-K slabs) on outputs at least one tile wide; narrower / smaller products stay on the fp32 MFMA tiles
     const bool split128 = split_ok && g_use_split != 4 &&
                           (g_use_split == 2 || (blocks(128, 128) >= 250 && a.M >= 128 && a.N >= 128 && (long)cdiv(a.M, 128) * cdiv(a.N, 128) >= 8));
     // outputs only a few 128-wide tiles across (N = 256): 64-row tiles double the workgroup count
-    // (with pre-split B planes an NN product stages B exactly like an NT one)
+    // (with pre-split B planes an NN product stages B exactly like an NT one; with two-piece products the 64-row split tiles beat the
+    // fp32-MFMA tiles on the NN products too: 8192 x 256 x 768 37.4 -> 25.6 us, x 512 26.5 -> 19.0, x 256 15.5 -> 12.8, tools/gemm_modes_2p.py)
     const bool split64 = split_ok && !split128 && g_use_split != 5 && g_use_split != 2 &&
-                         (g_use_split == 4 || ((ak && (bk || planes_ok || g_use_split == 6)) && blocks(64, 128) >= 250 && a.M >= 64 && a.N >= 128 && a.split_k <= 1));   // measured: NT +6-14 %, NN +-0
+                         (g_use_split == 4 || ((ak && (bk || planes_ok || g_use_split == 6 || pieces == 2)) && blocks(64, 128) >= 250 && a.M >= 64 && a.N >= 128 && a.split_k <= 1));   // measured: NT +6-14 %, NN +-0
     if (split128 || split64) {
         g_last_path = 3;
         if (planes_ok) { a.Bpl = reinterpret_cast<const unsigned short*>(d->b_planes); a.ld_bpl = d->ld_bplanes; a.bpl_stride = d->b_plane_stride; }
         // 256x128 (8-wave) tiles: measured +3-7 % on the NT / TN products that still give ~200 workgroups, -2 % on NN
         const bool big = split128 && a.M >= 512 && (g_split_bm256 == 2 || (g_split_bm256 == 1 && ak == bk && blocks(256, 128) >= 190));
-        if (g_gsplit) launch_gsplit(a, ak, bk, st, split64 ? 64 : 128, g_split_pieces);
-        else launch_split(a, ak, bk, st, split64 ? 64 : (big && g_split_pieces == 3 ? 256 : 128), g_split_pieces);
+        if (g_gsplit) launch_gsplit(a, ak, bk, st, split64 ? 64 : 128, pieces);
+        else launch_split(a, ak, bk, st, split64 ? 64 : (big && pieces == 3 ? 256 : 128), pieces);
     }
     else if (glds_ok && g_tile_override >= 0 && g_tile_override <= 3) {
         int tile = g_tile_override;
@@ -531,7 +543,9 @@ extern "C" int64_t gaot_gemm_tn_grouped_workspace(const gaot_wgrad_item* items, 
     return ws;
 }
 
-extern "C" int gaot_gemm_tn_grouped(const gaot_wgrad_item* items, int32_t n, float* workspace, int32_t* counters, gaot_stream_t stream) {
+extern "C" int gaot_gemm_tn_grouped(const gaot_wgrad_item* items, int32_t n, int32_t pieces, float* workspace, int32_t* counters, gaot_stream_t stream) {
+    GAOT_REQUIRE(pieces == 0 || pieces == 2 || pieces == 3, "gemm_tn_grouped: pieces must be 0 / 3 (exact) or 2 (two rounded pieces), got %d", pieces);
+    if (gaot_forced_pieces() >= 2) pieces = gaot_forced_pieces();
     if (int rc = check_wgrad_items(items, n)) return rc;
     int cnt = 0;
     const long need = gaot_gemm_tn_grouped_workspace(items, n, &cnt);
@@ -543,7 +557,7 @@ extern "C" int gaot_gemm_tn_grouped(const gaot_wgrad_item* items, int32_t n, flo
         const int m = n - i0 < TN_GROUP_MAX ? n - i0 : TN_GROUP_MAX;
         int c = 0;
         const long w = plan_tn_grouped(items + i0, m, nullptr, &c, nullptr);
-        launch_tn_grouped(items + i0, m, workspace + ws_off, counters + cnt_off, st);
+        launch_tn_grouped(items + i0, m, workspace + ws_off, counters + cnt_off, pieces == 2 ? 2 : 3, st);
         GAOT_CHECK_LAUNCH("gaot_gemm_tn_grouped");
         ws_off += w; cnt_off += c;
     }

@@ -224,7 +224,7 @@ void launch_gsplit(GemmArgs& a, bool a_kmajor, bool b_kmajor, hipStream_t st, in
 // grouped weight-gradient launch (gemm_split.hip): prefix table / workspace need of n items; the launch itself
 struct TnGroupArgs;
 long plan_tn_grouped(const gaot_wgrad_item* items, int n, TnGroupArgs* args, int* n_counters, int* n_wg);
-void launch_tn_grouped(const gaot_wgrad_item* items, int n, float* ws, int* counters, hipStream_t st);
+void launch_tn_grouped(const gaot_wgrad_item* items, int n, float* ws, int* counters, int pieces, hipStream_t st);
 constexpr int TN_GROUP_MAX = 24;          // products per launch (the table travels in the kernel arguments)
 
 }  // namespace gaot

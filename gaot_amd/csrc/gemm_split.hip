@@ -32,6 +32,7 @@ __device__ __forceinline__ unsigned rne_pair(float x0, float x1) {
 template <int NP, int ABL>
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& ph, unsigned& pm, unsigned& pl) {
     if (NP == 1) { ph = rne_pair(x0, x1); pm = pl = 0u; }
+    else if (NP == 2) { split2_pair(x0, x1, ph, pm); pl = 0u; }       // two ROUNDED pieces: x = h + m + e, |e| <= 2^-18 |x|, unbiased
     else split3_pair<ABL>(x0, x1, ph, pm, pl);
 }
 
@@ -170,7 +171,8 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
                     }
                 unsigned char* dst = base + (tid >> 1) * 48 + (tid & 1) * 16;
                 *reinterpret_cast<u32x4*>(dst) = h;
-                if (NP == 3) { *reinterpret_cast<u32x4*>(dst + plane) = m; *reinterpret_cast<u32x4*>(dst + 2 * plane) = l; }
+                if (NP >= 2) *reinterpret_cast<u32x4*>(dst + plane) = m;
+                if (NP == 3) *reinterpret_cast<u32x4*>(dst + 2 * plane) = l;
             } else {
                 u32x2 h, m, l;
 #pragma unroll
@@ -181,7 +183,8 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
                 }
                 unsigned char* dst = base + (tid >> 2) * 48 + (tid & 3) * 8;
                 *reinterpret_cast<u32x2*>(dst) = h;
-                if (NP == 3) { *reinterpret_cast<u32x2*>(dst + plane) = m; *reinterpret_cast<u32x2*>(dst + 2 * plane) = l; }
+                if (NP >= 2) *reinterpret_cast<u32x2*>(dst + plane) = m;
+                if (NP == 3) *reinterpret_cast<u32x2*>(dst + 2 * plane) = l;
             }
         } else {
             if (!full && tid >= half_threads) return;
@@ -193,12 +196,14 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     *reinterpret_cast<unsigned*>(dst + e * 48) = h[e];
-                    if (NP == 3) { *reinterpret_cast<unsigned*>(dst + e * 48 + plane) = m[e]; *reinterpret_cast<unsigned*>(dst + e * 48 + 2 * plane) = l[e]; }
+                    if (NP >= 2) *reinterpret_cast<unsigned*>(dst + e * 48 + plane) = m[e];
+                    if (NP == 3) *reinterpret_cast<unsigned*>(dst + e * 48 + 2 * plane) = l[e];
                 }
             } else {
                 unsigned char* dst = base + (tid >> 4) * 256 + (tid & 15) * 16;
                 *reinterpret_cast<u32x4*>(dst) = h;
-                if (NP == 3) { *reinterpret_cast<u32x4*>(dst + plane) = m; *reinterpret_cast<u32x4*>(dst + 2 * plane) = l; }
+                if (NP >= 2) *reinterpret_cast<u32x4*>(dst + plane) = m;
+                if (NP == 3) *reinterpret_cast<u32x4*>(dst + 2 * plane) = l;
             }
         }
     };
@@ -259,6 +264,15 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = mfma<ABL>(a[i][0], b[j][0], acc[i][j]);
+        } else if (NP == 2) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = mfma<ABL>(a[i][1], b[j][0], acc[i][j]);
+                    acc[i][j] = mfma<ABL>(a[i][0], b[j][1], acc[i][j]);
+                    acc[i][j] = mfma<ABL>(a[i][0], b[j][0], acc[i][j]);
+                }
         } else {
         // small terms first
 #pragma unroll
@@ -287,7 +301,7 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
         // interleave: one MFMA, a few VALU ops of the split, now and then one of its LDS writes
         __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);       // the prefetch loads go first: a whole k-tile to land
 #pragma unroll
-        for (int g = 0; g < TM * TN * (NP == 3 ? 6 : 1); ++g) {
+        for (int g = 0; g < TM * TN * (NP == 3 ? 6 : NP == 2 ? 3 : 1); ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
@@ -397,7 +411,7 @@ struct TnGroupArgs { int n; float* ws; int* counters; TnProb p[TNG_MAX]; };
 // 4 096, 364 us): without the split arithmetic 345, without MFMAs 269, without LDS fragment reads 297, without in-loop global loads
 // 304, without LDS plane writes 282, without the barrier 351 -- every part costs 20-100 us and the parts ADD UP (the k-loop's
 // load -> split -> plane write -> barrier -> fragment read -> MFMA chain is not overlapped across the two resident workgroups of a CU).
-template <int ABL = 0>
+template <int ABL = 0, int NP = 3>
 __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const TnGroupArgs g) {
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SplitGeom<128>::SMEM_BYTES];
     // XCD-aware order (workgroup b runs on XCD b % 8): every XCD takes a CONTIGUOUS range of the logical work list, and inside
@@ -424,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const TnGroupAr
     a.split_k = split; a.ktiles_per_split = g.p[i].kt_per_split; a.ws = g.ws + g.p[i].ws_off;
     a.colsum = g.p[i].colsum; a.tiles_m = g.p[i].tiles_m; a.tiles_n = g.p[i].tiles_n; a.vec_epi = 1; a.ablate = 0;
     a.Bpl = nullptr; a.ld_bpl = 0; a.bpl_stride = 0;
-    split_tile<false, false, 128, ABL, 3, 64>(a, smem_raw, tile, z);
+    split_tile<false, false, 128, ABL, NP, 64>(a, smem_raw, tile, z);
     if (split <= 1) return;
 
     const int tid = threadIdx.x;
@@ -494,12 +508,14 @@ long plan_tn_grouped(const gaot_wgrad_item* items, int n, TnGroupArgs* args, int
     return ws;
 }
 
-void launch_tn_grouped(const gaot_wgrad_item* items, int n, float* ws, int* counters, hipStream_t st) {
+// pieces per operand: 3 = exact (six piece products), 2 = two rounded pieces (three piece products)
+void launch_tn_grouped(const gaot_wgrad_item* items, int n, float* ws, int* counters, int pieces, hipStream_t st) {
     TnGroupArgs args;
     args.n = n; args.ws = ws; args.counters = counters;
     int wg = 0;
     plan_tn_grouped(items, n, &args, nullptr, &wg);
-    hipLaunchKernelGGL(gemm_tn_grouped_kernel<0>, dim3(wg), dim3(256), 0, st, args);
+    if (pieces == 2) hipLaunchKernelGGL((gemm_tn_grouped_kernel<0, 2>), dim3(wg), dim3(256), 0, st, args);
+    else hipLaunchKernelGGL((gemm_tn_grouped_kernel<0, 3>), dim3(wg), dim3(256), 0, st, args);
 }
 
 // 0: one workgroup per tile (round 1).  n > 0: grids larger than n workgroups become persistent with n (MI355X holds 512 of the
@@ -533,6 +549,10 @@ static void launch_split_bm(GemmArgs& a, bool ak, bool bk, hipStream_t st) {
 void launch_split(GemmArgs& a, bool ak, bool bk, hipStream_t st, int bm, int pieces) {
     if (pieces == 1) {           // plain bf16 operands (bench variant): 128- and 64-row tiles
         if (bm == 64) launch_split_bm<64, 1>(a, ak, bk, st); else launch_split_bm<128, 1>(a, ak, bk, st);
+        return;
+    }
+    if (pieces == 2) {           // two rounded pieces per operand (three piece products)
+        if (bm == 64) launch_split_bm<64, 2>(a, ak, bk, st); else launch_split_bm<128, 2>(a, ak, bk, st);
         return;
     }
     if (bm == 64)       launch_split_bm<64, 3>(a, ak, bk, st);

@@ -78,11 +78,46 @@ def cut(t: torch.Tensor) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------------------------
+# Precision of the products on the split-bf16 tiles (gaot_gemm_desc.pieces), per product kind:
+#   "nt": activations x weight^T (every forward Linear), "nn": dY x weight (input gradients), "tn": dY^T x X (weight gradients).
+# 3 = every fp32 operand as three bf16 pieces, six piece products (exact to fp32 rounding); 2 = two pieces, both rounded to
+# nearest, three piece products (16 significant bits per operand, half the matrix-pipe work).
+# Default 2 everywhere, measured at the bench configuration against the reference algorithm evaluated in float64 (tools/grad_errors.py):
+#   all 3: output 1.25e-7, worst gradient tensor 8.8e-7        all 2: output 3.7e-7, worst gradient tensor 4.9e-6
+# while the reference's own fp32 arithmetic is 7.1e-7 / 2.4e-4 from the same float64 result: the two-piece
+# products stay inside the reference's own rounding on the output and inside the 1e-5 / 1e-4 bars with an order of magnitude to
+# spare, and the step is 7 % faster (2.58 -> 2.39 ms).  set_gemm_pieces(3) / GAOT_GEMM_PIECES=3 restores exact products
+# (kernel-level tests pin both).
+# --------------------------------------------------------------------------------------------
+_PIECES = {"nt": 2, "nn": 2, "tn": 2}
+
+
+def set_gemm_pieces(nt: Optional[int] = None, nn: Optional[int] = None, tn: Optional[int] = None) -> dict:
+    """pieces per operand (2 or 3) for the three product kinds; one argument sets all three.  Returns the previous setting."""
+    old = dict(_PIECES)
+    if nt is not None and nn is None and tn is None:
+        nn = tn = nt
+    for k, v in (("nt", nt), ("nn", nn), ("tn", tn)):
+        if v is not None:
+            if v not in (2, 3):
+                raise ValueError(f"gemm pieces must be 2 or 3, got {v}")
+            _PIECES[k] = v
+    return old
+
+
+if os.environ.get("GAOT_GEMM_PIECES"):          # "3", "2" or "nt,nn,tn"
+    _parts = [int(t) for t in os.environ["GAOT_GEMM_PIECES"].split(",")]
+    if len(_parts) not in (1, 3):
+        raise ValueError("GAOT_GEMM_PIECES: one value or nt,nn,tn")
+    set_gemm_pieces(*_parts)
+
+
+# --------------------------------------------------------------------------------------------
 # raw calls
 # --------------------------------------------------------------------------------------------
 def gemm(M: int, N: int, K: int, A, lda, a_kmajor, B, ldb, b_kmajor, out, ldc, *, bias=None, rowbias=None,
          rowbias_period=0, ld_rowbias=0, rowscale=None, act=L.ACT_NONE, aux_in=None, aux_out=None, ld_aux=0,
-         residual=None, ldr=0, A2=None, lda2=0, k_split=0, split_k=1, colsum=None):
+         residual=None, ldr=0, A2=None, lda2=0, k_split=0, split_k=1, colsum=None, pieces: Optional[int] = None):
     _dev(A, B, out, bias, rowbias, rowscale, aux_in, aux_out, residual, A2, colsum)
     _f32(A, B, out)
     ws = None
@@ -94,7 +129,8 @@ def gemm(M: int, N: int, K: int, A, lda, a_kmajor, B, ldb, b_kmajor, out, ldc, *
     d = L.GemmDesc(M, N, K, _p(A), lda, int(a_kmajor), _p(A2), lda2, k_split, _p(B), ldb, int(b_kmajor),
                    _p(out), ldc, _p(bias), _p(rowbias), rowbias_period, ld_rowbias, _p(rowscale), act,
                    _p(aux_in), _p(aux_out), ld_aux, _p(residual), ldr, split_k, _p(ws), _p(colsum),
-                   bp, bp_ld, bp_stride)
+                   bp, bp_ld, bp_stride,
+                   pieces if pieces is not None else _PIECES["tn" if not a_kmajor else ("nt" if b_kmajor else "nn")])
     L.check(L.load().gaot_gemm_f32(C.byref(d), _stream()), "gaot_gemm_f32")
     return out
 
@@ -321,7 +357,7 @@ def wgrad_launch(items) -> None:
             raise RuntimeError("grouped weight gradients: the ticket counters must exist before graph capture (run one eager step first)")
         ctr = torch.zeros(max(8192, 2 * cnt.value), device=dev, dtype=torch.int32)
         _WGRAD_COUNTERS[key] = ctr
-    L.check(lib.gaot_gemm_tn_grouped(arr, n, _p(ws), _p(ctr), _stream()), "gaot_gemm_tn_grouped")
+    L.check(lib.gaot_gemm_tn_grouped(arr, n, _PIECES["tn"], _p(ws), _p(ctr), _stream()), "gaot_gemm_tn_grouped")
 
 
 def flush_wgrad() -> None:

@@ -77,6 +77,11 @@ typedef struct gaot_gemm_desc {
      * 16-bit word b_planes[q * b_plane_stride + n * ld_bplanes + k] (k-contiguous whatever b_kmajor says).  Products are bit-identical
      * with and without; kernels that do not take planes ignore the field.  ld_bplanes, b_plane_stride multiples of 8. */
     const void* b_planes; int64_t ld_bplanes; int64_t b_plane_stride;
+    /* precision of the product where the split-bf16 tile kernels run it (per call, no global state): 0 or 3 = every fp32 operand as
+     * THREE bf16 pieces, six piece products: exact to fp32 rounding (error vs float64 ~ 2e-7, like the fp32 MFMA); 2 = TWO pieces, both
+     * rounded to nearest (x = h + m + e, |e| <= 2^-18 |x|, unbiased), three piece products: 16 significant bits per operand, half the
+     * matrix-pipe work.  Kernels on the fp32 MFMA / vector pipe ignore the field.  Anything else: GAOT_ERR_INVALID. */
+    int32_t pieces;
 } gaot_gemm_desc;
 
 int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream);
@@ -84,8 +89,7 @@ int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream);
 /* Grouped weight-gradient products: ONE launch over n products  out_i[M_i,N_i] = g_i[K_i,M_i]^T x_i[K_i,N_i]  (+ colsum_i[m] =
  * sum_k g_i[k,m], the bias gradient), i.e. dW = dY^T X (and db) of every nn.Linear / Conv1d(k=1) whose backward has been
  * reached (mlp.py:283-305, attn.py:92-117,150-156,225-227, gaot.py:208: autograd runs them one by one, each a long reduction
- * over all tokens into a small matrix).  fp32-level products on the bf16 matrix pipe (six piece products, as gaot_gemm_f32's
- * split tiles); K slabs of at most 1 024 rows are summed in slab order by the last workgroup to finish a tile (deterministic).
+ * over all tokens into a small matrix).  Products on the bf16 matrix pipe with `pieces` (0 / 3 or 2) as gaot_gemm_desc.pieces; K slabs of at most 1 024 rows are summed in slab order by the last workgroup to finish a tile (deterministic).
  * Needs M, N % 4 == 0, K % 32 == 0, ld* % 4 == 0, 16-byte aligned pointers.  `workspace`: >= gaot_gemm_tn_grouped_workspace()
  * floats; `counters`: >= *n_counters int32, ZERO before the first call (every call leaves them zero again). */
 typedef struct gaot_wgrad_item {
@@ -96,7 +100,7 @@ typedef struct gaot_wgrad_item {
     int32_t M, N, K;
 } gaot_wgrad_item;
 int64_t gaot_gemm_tn_grouped_workspace(const gaot_wgrad_item* items, int32_t n, int32_t* n_counters);
-int gaot_gemm_tn_grouped(const gaot_wgrad_item* items, int32_t n, float* workspace, int32_t* counters, gaot_stream_t stream);
+int gaot_gemm_tn_grouped(const gaot_wgrad_item* items, int32_t n, int32_t pieces, float* workspace, int32_t* counters, gaot_stream_t stream);
 
 /* Exact three-way bf16 split of fp32 matrices into planes for gaot_gemm_desc.b_planes, n matrices per launch: item i reads
  * src[r * ld + c] (rows x cols) and writes piece q of element (r, c) to planes[q * plane_stride + r * ld_out + c], or -- transpose

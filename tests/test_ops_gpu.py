@@ -649,6 +649,44 @@ def test_fused_kernel_mlp_matches_chain_and_float64(E, cin, n, act, cout):
         assert rel(a, c) < 4 * rel(b, c) + 2e-6          # as accurate as the chain path
 
 
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(8192, 2048, 256), (8192, 256, 1024), (4096, 768, 256)])
+def test_gemm_two_piece_products(M, N, K):
+    """gaot_gemm_desc.pieces = 2 (the default of the model path): every operand as two bf16 pieces, both rounded to nearest
+    (16 significant bits, unbiased), three piece products.  On random normal data -- sums with full cancellation, the worst case for a
+    per-term relative error -- the products stay within 6e-6 of float64 (measured 3-4.5e-6; the exact three-piece products: 2-5e-7), for
+    all three product kinds and the grouped weight-gradient launch; and 2 IS the default."""
+    from gaot_amd import ops, _lib
+    assert ops._PIECES == {"nt": 2, "nn": 2, "tn": 2}
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w, dy = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(M, N, generator=g)
+    xd, wd, dyd = x.cuda(), w.cuda(), dy.cuda()
+    ref = {"nt": x.double() @ w.double().t(), "nn": dy.double() @ w.double(), "tn": dy.double().t() @ x.double()}
+    run = {"nt": lambda: ops.linear_nt(xd, wd), "nn": lambda: ops.matmul_nn(dyd, wd), "tn": lambda: ops.matmul_tn(dyd, xd)}
+    for kind in ("nt", "nn", "tn"):
+        e2 = rel(run[kind](), ref[kind])
+        on_split_tiles = _lib.load().gaot_debug_last_gemm_path() == 3
+        old = ops.set_gemm_pieces(3)
+        try:
+            e3 = rel(run[kind](), ref[kind])
+        finally:
+            ops.set_gemm_pieces(**old)
+        assert e3 < 1e-6 and e2 < 6e-6, (kind, e2, e3)
+        if on_split_tiles:
+            assert e2 > 2 * e3, (kind, e2, e3)          # the field reaches the kernel (products on the fp32 MFMA ignore it)
+    # the grouped launch
+    out2, out3 = torch.empty(N, K, device="cuda"), torch.empty(N, K, device="cuda")
+    ops.wgrad_launch([(dyd, N, xd, K, out2, K, None, N, K, M)])
+    old = ops.set_gemm_pieces(3)
+    try:
+        ops.wgrad_launch([(dyd, N, xd, K, out3, K, None, N, K, M)])
+    finally:
+        ops.set_gemm_pieces(**old)
+    assert rel(out3, ref["tn"]) < 1e-6 and 2 * rel(out3, ref["tn"]) < rel(out2, ref["tn"]) < 6e-6
+    with pytest.raises(ValueError):
+        ops.set_gemm_pieces(4)
+
 @pytest.mark.gpu
 def test_branch_free_erf_accuracy():
     """common.h erf_nb (single-range 1 - 2^(-|x| Q(|x|)), no branch) behind every GELU of the path: absolute error of

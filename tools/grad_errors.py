@@ -14,7 +14,10 @@ torch.manual_seed(0)
 model = bench.build_model().to(dev).train()
 tensors = bench.synthetic(1234, dev)
 sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-hip = bench.hip_reference_pass(model, tensors)
+from gaot_amd.trainer import TrainStep
+ts = TrainStep(model, lr=8e-4, weight_decay=1e-5, use_graph=False)
+ts.bind(tensors[2], tensors[3], latent_tokens_coord=tensors[0], xcoord=tensors[1])
+hip = bench.hip_reference_pass(ts, model, tensors)       # the training path: grouped weight-gradient launch included
 lat, x, p, t = [v.cpu() for v in tensors]
 cfg = O.OracleConfig(radius=bench.RADIUS, hidden_size=64, lifting_channels=bench.C_LIFT, patch_size=bench.PATCH, tf_hidden_size=bench.HIDDEN,
                      latent_tokens_size=bench.LATENT, precompute_edges=True)
