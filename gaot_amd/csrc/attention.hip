@@ -363,6 +363,12 @@ __global__ __launch_bounds__(256) void attn_fwd_glds_kernel(const AttnArgs p) {
 //                 A = V^T planes from LDS ([d][64 keys] bf16, row stride 136 B: two conflict-free ds_read_b64 per plane / step).
 // K / V tiles (64 keys) are split by all 256 threads on the way from the prefetch registers into one of two LDS stages.
 // ---------------------------------------------------------------------------------------------
+// pieces of an operand pair: OP = 3 exact (split3_pair), OP = 2 two rounded pieces (split2_pair; third piece zero, never stored or multiplied)
+template <int OP>
+__device__ __forceinline__ void split_op(float x0, float x1, unsigned& a, unsigned& b, unsigned& c) {
+    if (OP == 3) split3_pair(x0, x1, a, b, c);
+    else { split2_pair(x0, x1, a, b); c = 0u; }
+}
 constexpr int AS_KROW = 80, AS_VROW = 136;
 constexpr int AS_KPL = 64 * AS_KROW, AS_VPL = 32 * AS_VROW;
 constexpr int AS_STAGE = 3 * AS_KPL + 3 * AS_VPL;          // bytes
@@ -374,7 +380,7 @@ constexpr int AS_STAGE = 3 * AS_KPL + 3 * AS_VPL;          // bytes
 // PP = pieces of P in the P V product: 3 = exact split; 2 = two pieces (common.h split2_pair: the second one rounded to nearest),
 // five piece products instead of six -- P is a softmax output in [0, 1] carrying ~1e-7 of relative noise from exp2 alone, the
 // dropped part is <= 2^-17 of each probability and unbiased
-template <int NW, int DH = 32, int PP = 3>
+template <int NW, int DH = 32, int PP = 3, int OP = 3>
 __global__ __launch_bounds__(64 * NW, (NW == 4 && DH == 32) ? 2 : 1) void attn_fwd_split_kernel(const AttnArgs p) {
     constexpr int KT = 64, NT = 64 * NW, QB = 32 * NW;
     constexpr int NU = DH / 16, NDT = DH / 32, CPR = DH / 4;            // d steps, O tiles, 4-float chunks per row
@@ -403,10 +409,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && DH == 32) ? 2 : 1) void attn_f
             const f32x4 v1 = load4(qrow, 16 * u + 8 * lh + 4, D, qi < p.S, true);
             u32x4 ph, pm, pl;
             unsigned a_, b_, c_;
-            split3_pair(v0[0], v0[1], a_, b_, c_); ph[0] = a_; pm[0] = b_; pl[0] = c_;
-            split3_pair(v0[2], v0[3], a_, b_, c_); ph[1] = a_; pm[1] = b_; pl[1] = c_;
-            split3_pair(v1[0], v1[1], a_, b_, c_); ph[2] = a_; pm[2] = b_; pl[2] = c_;
-            split3_pair(v1[2], v1[3], a_, b_, c_); ph[3] = a_; pm[3] = b_; pl[3] = c_;
+            split_op<OP>(v0[0], v0[1], a_, b_, c_); ph[0] = a_; pm[0] = b_; pl[0] = c_;
+            split_op<OP>(v0[2], v0[3], a_, b_, c_); ph[1] = a_; pm[1] = b_; pl[1] = c_;
+            split_op<OP>(v1[0], v1[1], a_, b_, c_); ph[2] = a_; pm[2] = b_; pl[2] = c_;
+            split_op<OP>(v1[2], v1[3], a_, b_, c_); ph[3] = a_; pm[3] = b_; pl[3] = c_;
             qf[0][u] = __builtin_bit_cast(bf16x8, ph); qf[1][u] = __builtin_bit_cast(bf16x8, pm); qf[2][u] = __builtin_bit_cast(bf16x8, pl);
         }
     }
@@ -445,12 +451,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && DH == 32) ? 2 : 1) void attn_f
             const int idx = tid + i * NT;
             u32x2 h, m, l;
             unsigned a_, b_, c_;
-            split3_pair(rk[i][0], rk[i][1], a_, b_, c_); h[0] = a_; m[0] = b_; l[0] = c_;
-            split3_pair(rk[i][2], rk[i][3], a_, b_, c_); h[1] = a_; m[1] = b_; l[1] = c_;
+            split_op<OP>(rk[i][0], rk[i][1], a_, b_, c_); h[0] = a_; m[0] = b_; l[0] = c_;
+            split_op<OP>(rk[i][2], rk[i][3], a_, b_, c_); h[1] = a_; m[1] = b_; l[1] = c_;
             unsigned char* dst = Kp + (idx / CPR) * KROW + (idx % CPR) * 8;
             *reinterpret_cast<u32x2*>(dst) = h;
             *reinterpret_cast<u32x2*>(dst + KPL) = m;
-            *reinterpret_cast<u32x2*>(dst + 2 * KPL) = l;
+            if (OP == 3) *reinterpret_cast<u32x2*>(dst + 2 * KPL) = l;
         }
         // V^T: (key 2kp, key 2kp+1) pairs of the thread's 4 d columns -> one dword per d row and plane
 #pragma unroll
@@ -461,11 +467,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && DH == 32) ? 2 : 1) void attn_f
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     unsigned a_, b_, c_;
-                    split3_pair(rv[j][0][e], rv[j][1][e], a_, b_, c_);
+                    split_op<OP>(rv[j][0][e], rv[j][1][e], a_, b_, c_);
                     unsigned char* dst = Vp + (d0 + e) * AS_VROW + kp * 4;
                     *reinterpret_cast<unsigned*>(dst) = a_;
                     *reinterpret_cast<unsigned*>(dst + VPL) = b_;
-                    *reinterpret_cast<unsigned*>(dst + 2 * VPL) = c_;
+                    if (OP == 3) *reinterpret_cast<unsigned*>(dst + 2 * VPL) = c_;
                 }
             }
         }
@@ -497,10 +503,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && DH == 32) ? 2 : 1) void attn_f
                 const unsigned char* kr = Kp + (32 * t + li) * KROW + u * 32 + lh * 16;
                 const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(kr);
                 const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(kr + KPL);
-                const bf16x8 k2 = *reinterpret_cast<const bf16x8*>(kr + 2 * KPL);
-                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k2, qf[0][u], s[t], 0, 0, 0);
-                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[2][u], s[t], 0, 0, 0);
-                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[1][u], s[t], 0, 0, 0);
+                if (OP == 3) {
+                    const bf16x8 k2 = *reinterpret_cast<const bf16x8*>(kr + 2 * KPL);
+                    s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k2, qf[0][u], s[t], 0, 0, 0);
+                    s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[2][u], s[t], 0, 0, 0);
+                    s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[1][u], s[t], 0, 0, 0);
+                }
                 s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[0][u], s[t], 0, 0, 0);
                 s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[1][u], s[t], 0, 0, 0);
                 s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[0][u], s[t], 0, 0, 0);
@@ -568,14 +576,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && DH == 32) ? 2 : 1) void attn_f
                     const unsigned char* vr = Vp + (32 * dt + li) * AS_VROW + (32 * t + 16 * u + 4 * lh) * 2;
                     bf16x8 v[3];
 #pragma unroll
-                    for (int pl_ = 0; pl_ < 3; ++pl_) {
+                    for (int pl_ = 0; pl_ < OP; ++pl_) {
                         const u32x2 lo = *reinterpret_cast<const u32x2*>(vr + pl_ * VPL);
                         const u32x2 hi2 = *reinterpret_cast<const u32x2*>(vr + pl_ * VPL + 16);
                         v[pl_] = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi2[0], hi2[1]});
                     }
-                    ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[2], p0, ot[dt], 0, 0, 0);
+                    if (OP == 3) ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[2], p0, ot[dt], 0, 0, 0);
                     if (PP == 3) ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0], p2, ot[dt], 0, 0, 0);
-                    ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[1], p1, ot[dt], 0, 0, 0);
+                    if (OP == 3 || PP == 3) ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[1], p1, ot[dt], 0, 0, 0);   // second x second piece: <= 2^-18 of the term
                     ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[1], p0, ot[dt], 0, 0, 0);
                     ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0], p1, ot[dt], 0, 0, 0);
                     ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0], p0, ot[dt], 0, 0, 0);
@@ -1672,7 +1680,7 @@ constexpr int AB8_WAVE = 2 * 3 * AB_KPL;                                        
 constexpr int AB8_LDS = AB8_SHARED + 8 * AB8_WAVE;
 
 // PP = pieces of P and of dS = P (dP - delta) in the dV, dK and dQ products (3: exact split, 2: split2_pair, see the forward)
-template <int PP = 3>
+template <int PP = 3, int OP = 3>
 __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs p) {
     constexpr int DP = 32, NW = 8;
     __shared__ __attribute__((aligned(16))) unsigned char smem[AB8_LDS];
@@ -1708,10 +1716,10 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
             unsigned a_, b_, c_;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                split3_pair(a0[2 * e], a0[2 * e + 1], a_, b_, c_); ph[e] = a_; pm[e] = b_; pl[e] = c_;
-                split3_pair(a1[2 * e], a1[2 * e + 1], a_, b_, c_); ph[2 + e] = a_; pm[2 + e] = b_; pl[2 + e] = c_;
-                split3_pair(w0[2 * e], w0[2 * e + 1], a_, b_, c_); vh[e] = a_; vm[e] = b_; vl[e] = c_;
-                split3_pair(w1[2 * e], w1[2 * e + 1], a_, b_, c_); vh[2 + e] = a_; vm[2 + e] = b_; vl[2 + e] = c_;
+                split_op<OP>(a0[2 * e], a0[2 * e + 1], a_, b_, c_); ph[e] = a_; pm[e] = b_; pl[e] = c_;
+                split_op<OP>(a1[2 * e], a1[2 * e + 1], a_, b_, c_); ph[2 + e] = a_; pm[2 + e] = b_; pl[2 + e] = c_;
+                split_op<OP>(w0[2 * e], w0[2 * e + 1], a_, b_, c_); vh[e] = a_; vm[e] = b_; vl[e] = c_;
+                split_op<OP>(w1[2 * e], w1[2 * e + 1], a_, b_, c_); vh[2 + e] = a_; vm[2 + e] = b_; vl[2 + e] = c_;
             }
             kf[0][u] = __builtin_bit_cast(bf16x8, ph); kf[1][u] = __builtin_bit_cast(bf16x8, pm); kf[2][u] = __builtin_bit_cast(bf16x8, pl);
             vf[0][u] = __builtin_bit_cast(bf16x8, vh); vf[1][u] = __builtin_bit_cast(bf16x8, vm); vf[2][u] = __builtin_bit_cast(bf16x8, vl);
@@ -1726,11 +1734,11 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 unsigned a_, b_, c_;
-                split3_pair(r0[e], r1[e], a_, b_, c_);
+                split_op<OP>(r0[e], r1[e], a_, b_, c_);
                 unsigned char* dst = Ktp + (d0 + e) * AB_KROW + kp * 4;
                 *reinterpret_cast<unsigned*>(dst) = a_;
                 *reinterpret_cast<unsigned*>(dst + AB_KPL) = b_;
-                *reinterpret_cast<unsigned*>(dst + 2 * AB_KPL) = c_;
+                if (OP == 3) *reinterpret_cast<unsigned*>(dst + 2 * AB_KPL) = c_;
             }
         }
     }
@@ -1781,20 +1789,21 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
             const int row = t8 >> 3, ch = tid & 7;
             u32x2 h2, m2, l2;
             unsigned a_, b_, c_;
-            split3_pair(rk1[0], rk1[1], a_, b_, c_); h2[0] = a_; m2[0] = b_; l2[0] = c_;
-            split3_pair(rk1[2], rk1[3], a_, b_, c_); h2[1] = a_; m2[1] = b_; l2[1] = c_;
+            split_op<OP>(rk1[0], rk1[1], a_, b_, c_); h2[0] = a_; m2[0] = b_; l2[0] = c_;
+            split_op<OP>(rk1[2], rk1[3], a_, b_, c_); h2[1] = a_; m2[1] = b_; l2[1] = c_;
             unsigned char* dk_ = (kind == 0 ? Qk : Gk) + row * AB_KROW + ch * 8;
-            *reinterpret_cast<u32x2*>(dk_) = h2; *reinterpret_cast<u32x2*>(dk_ + AB_KPL) = m2; *reinterpret_cast<u32x2*>(dk_ + 2 * AB_KPL) = l2;
+            *reinterpret_cast<u32x2*>(dk_) = h2; *reinterpret_cast<u32x2*>(dk_ + AB_KPL) = m2;
+            if (OP == 3) *reinterpret_cast<u32x2*>(dk_ + 2 * AB_KPL) = l2;
             if (tthread) {
                 const int qp = t8 >> 3, d0 = ch * 4;
                 unsigned char* tb = (kind == 0 ? Qt : Gt) + qp * 4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    split3_pair(rt[0][e], rt[1][e], a_, b_, c_);
+                    split_op<OP>(rt[0][e], rt[1][e], a_, b_, c_);
                     unsigned char* dst = tb + (d0 + e) * AB_TROW;
                     *reinterpret_cast<unsigned*>(dst) = a_;
                     *reinterpret_cast<unsigned*>(dst + AB_TPL) = b_;
-                    *reinterpret_cast<unsigned*>(dst + 2 * AB_TPL) = c_;
+                    if (OP == 3) *reinterpret_cast<unsigned*>(dst + 2 * AB_TPL) = c_;
                 }
             }
         }
@@ -1809,14 +1818,17 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
         for (int u = 0; u < 2; ++u) {
             const unsigned char* qr = Qk + li * AB_KROW + u * 32 + lh * 16;
             const unsigned char* gr = Gk + li * AB_KROW + u * 32 + lh * 16;
-            const bf16x8 q0_ = *reinterpret_cast<const bf16x8*>(qr), q1_ = *reinterpret_cast<const bf16x8*>(qr + AB_KPL), q2_ = *reinterpret_cast<const bf16x8*>(qr + 2 * AB_KPL);
-            const bf16x8 g0_ = *reinterpret_cast<const bf16x8*>(gr), g1_ = *reinterpret_cast<const bf16x8*>(gr + AB_KPL), g2_ = *reinterpret_cast<const bf16x8*>(gr + 2 * AB_KPL);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q2_, kf[0][u], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g2_, vf[0][u], dp, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0_, kf[2][u], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0_, vf[2][u], dp, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q1_, kf[1][u], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1_, vf[1][u], dp, 0, 0, 0);
+            const bf16x8 q0_ = *reinterpret_cast<const bf16x8*>(qr), q1_ = *reinterpret_cast<const bf16x8*>(qr + AB_KPL);
+            const bf16x8 g0_ = *reinterpret_cast<const bf16x8*>(gr), g1_ = *reinterpret_cast<const bf16x8*>(gr + AB_KPL);
+            if (OP == 3) {
+                const bf16x8 q2_ = *reinterpret_cast<const bf16x8*>(qr + 2 * AB_KPL), g2_ = *reinterpret_cast<const bf16x8*>(gr + 2 * AB_KPL);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q2_, kf[0][u], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g2_, vf[0][u], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0_, kf[2][u], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0_, vf[2][u], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q1_, kf[1][u], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1_, vf[1][u], dp, 0, 0, 0);
+            }
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q1_, kf[0][u], s, 0, 0, 0);
             dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1_, vf[0][u], dp, 0, 0, 0);
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0_, kf[1][u], s, 0, 0, 0);
@@ -1866,20 +1878,24 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
             const unsigned char* qr = Qt + li * AB_TROW + (16 * u + 4 * lh) * 2;
             bf16x8 ga[3], qa[3];
 #pragma unroll
-            for (int pl_ = 0; pl_ < 3; ++pl_) {
+            for (int pl_ = 0; pl_ < OP; ++pl_) {
                 const u32x2 g_lo = *reinterpret_cast<const u32x2*>(gr + pl_ * AB_TPL), g_hi = *reinterpret_cast<const u32x2*>(gr + pl_ * AB_TPL + 16);
                 const u32x2 q_lo = *reinterpret_cast<const u32x2*>(qr + pl_ * AB_TPL), q_hi = *reinterpret_cast<const u32x2*>(qr + pl_ * AB_TPL + 16);
                 ga[pl_] = __builtin_bit_cast(bf16x8, u32x4{g_lo[0], g_lo[1], g_hi[0], g_hi[1]});
                 qa[pl_] = __builtin_bit_cast(bf16x8, u32x4{q_lo[0], q_lo[1], q_hi[0], q_hi[1]});
             }
-            dvt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[2], p0, dvt, 0, 0, 0);
-            dkt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[2], d0, dkt, 0, 0, 0);
+            if (OP == 3) {
+                dvt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[2], p0, dvt, 0, 0, 0);
+                dkt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[2], d0, dkt, 0, 0, 0);
+            }
             if (PP == 3) {
                 dvt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p2, dvt, 0, 0, 0);
                 dkt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d2, dkt, 0, 0, 0);
             }
-            dvt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1], p1, dvt, 0, 0, 0);
-            dkt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1], d1, dkt, 0, 0, 0);
+            if (OP == 3 || PP == 3) {
+                dvt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1], p1, dvt, 0, 0, 0);
+                dkt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1], d1, dkt, 0, 0, 0);
+            }
             dvt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1], p0, dvt, 0, 0, 0);
             dkt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1], d0, dkt, 0, 0, 0);
             dvt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p1, dvt, 0, 0, 0);
@@ -1901,13 +1917,14 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
             for (int pl_ = 0; pl_ < 3; ++pl_) {
                 if (pl_ < PP) da[u][pl_] = *reinterpret_cast<const bf16x8*>(dSp + pl_ * AB_KPL + li * AB_KROW + u * 32 + lh * 16);
                 else da[u][pl_] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                kb[u][pl_] = *reinterpret_cast<const bf16x8*>(Ktp + pl_ * AB_KPL + li * AB_KROW + u * 32 + lh * 16);
+                if (pl_ < OP) kb[u][pl_] = *reinterpret_cast<const bf16x8*>(Ktp + pl_ * AB_KPL + li * AB_KROW + u * 32 + lh * 16);
+                else kb[u][pl_] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
             }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if (PP == 3) dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[u][2], kb[u][0], dq, 0, 0, 0);
-            dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[u][0], kb[u][2], dq, 0, 0, 0);
-            dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[u][1], kb[u][1], dq, 0, 0, 0);
+            if (OP == 3) dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[u][0], kb[u][2], dq, 0, 0, 0);
+            if (OP == 3 || PP == 3) dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[u][1], kb[u][1], dq, 0, 0, 0);
             dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[u][1], kb[u][0], dq, 0, 0, 0);
             dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[u][0], kb[u][1], dq, 0, 0, 0);
             dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[u][0], kb[u][0], dq, 0, 0, 0);
@@ -1989,6 +2006,10 @@ extern "C" int gaot_debug_set_attention_p_pieces(int n) {
     g_attn_pp = (n == 33 || n == 22 || n == 23 || n == 32) ? n : (n == 3 ? 33 : 22);
     return old;
 }
+// pieces of the Q / K / V / dO operands in the same kernels (with two-piece P / dS only): 2 (default) = two rounded pieces, three piece
+// products per k-step in every product of the kernel (forward 11 -> 6 MFMAs per k-step pair, backward 27 -> 15); 3 = exact three-way splits
+static int g_attn_op = 2;
+extern "C" int gaot_debug_set_attention_operand_pieces(int n) { const int old = g_attn_op; g_attn_op = n == 3 ? 3 : 2; return old; }
 static int g_attn_pipe = 0;      // 1 = the software-pipelined 8-wave forward for S % 64 == 0 (same speed as the plain one since both keep the
                                  // tile product off the running accumulator: 57.6 vs 58.0 us; kept for tools/attn_ablate.hip and as a tested variant)
 extern "C" int gaot_debug_set_attention_pipe(int on) { const int old = g_attn_pipe; g_attn_pipe = on; return old; }
@@ -2008,11 +2029,13 @@ extern "C" int gaot_attention_fwd(const float* q, const float* k, const float* v
     if (head_dim == 32 && a.vec && g_attn_split && g_attn_split != 3 && (g_attn_split == 2 || (long)cdiv(S, 256) * B * H >= 256)) {
         if (S % 64 == 0 && g_attn_pipe) hipLaunchKernelGGL(attn_fwd_split_pipe_kernel<0>, dim3(cdiv(S, 256) * B * H), dim3(512), 0, ST(stream), a);
         else if (g_attn_pp / 10 == 3) hipLaunchKernelGGL((attn_fwd_split_kernel<8, 32, 3>), dim3(cdiv(S, 256) * B * H), dim3(512), 0, ST(stream), a);
-        else hipLaunchKernelGGL((attn_fwd_split_kernel<8, 32, 2>), dim3(cdiv(S, 256) * B * H), dim3(512), 0, ST(stream), a);
+        else if (g_attn_op == 3) hipLaunchKernelGGL((attn_fwd_split_kernel<8, 32, 2>), dim3(cdiv(S, 256) * B * H), dim3(512), 0, ST(stream), a);
+        else hipLaunchKernelGGL((attn_fwd_split_kernel<8, 32, 2, 2>), dim3(cdiv(S, 256) * B * H), dim3(512), 0, ST(stream), a);
     }
     else if (head_dim == 32 && a.vec && g_attn_split) {
         if (g_attn_pp / 10 == 3) hipLaunchKernelGGL((attn_fwd_split_kernel<4, 32, 3>), grid, block, 0, ST(stream), a);
-        else hipLaunchKernelGGL((attn_fwd_split_kernel<4, 32, 2>), grid, block, 0, ST(stream), a);
+        else if (g_attn_op == 3) hipLaunchKernelGGL((attn_fwd_split_kernel<4, 32, 2>), grid, block, 0, ST(stream), a);
+        else hipLaunchKernelGGL((attn_fwd_split_kernel<4, 32, 2, 2>), grid, block, 0, ST(stream), a);
     }
     else if (head_dim > 32 && head_dim <= 64 && a.vec && g_attn_split) {      // (a.vec: head_dim % 4 == 0): split-bf16 with four d steps
         if (g_attn_split != 3 && (g_attn_split == 2 || (long)cdiv(S, 256) * B * H >= 256))
@@ -2143,7 +2166,8 @@ extern "C" int gaot_attention_bwd(const float* q, const float* k, const float* v
     if (split_ok && g_attn_split != 3 && (g_attn_split == 2 || (long)cdiv(S, 256) * B * H >= 256)) {
         a.n_kblocks = cdiv(S, 256);          // 256 keys per workgroup: half the dQ slabs (the workspace is sized for 128)
         if (g_attn_pp % 10 == 3) hipLaunchKernelGGL(attn_bwd_split8_kernel<3>, dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a);
-        else hipLaunchKernelGGL(attn_bwd_split8_kernel<2>, dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a);
+        else if (g_attn_op == 3) hipLaunchKernelGGL(attn_bwd_split8_kernel<2>, dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a);
+        else hipLaunchKernelGGL((attn_bwd_split8_kernel<2, 2>), dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a);
     } else if (split_ok) {
         hipLaunchKernelGGL(attn_bwd_split_kernel, grid, block, 0, ST(stream), a);
     } else if (head_dim > 32 && head_dim <= 64 && a.vec && g_attn_split && aligned16(dq) && aligned16(dk) && aligned16(dv)) {

@@ -687,6 +687,36 @@ def test_gemm_two_piece_products(M, N, K):
     with pytest.raises(ValueError):
         ops.set_gemm_pieces(4)
 
+
+@pytest.mark.gpu
+def test_attention_two_piece_default():
+    """the shipped head_dim-32 attention: P / dS and the Q / K / V / dO operands as two rounded bf16 pieces (three piece products per
+    k-step in all seven products).  Random normal data (the worst case for a per-term relative error): output within 1e-5 and
+    gradients within 1.5e-5 of float64 (measured 6.6e-6 / 7.9e-6; exact splits: 2.5e-7 / 4.8e-7); many equal tokens (same-signed
+    accumulation): no drift; and (22, 2) IS the default."""
+    from gaot_amd import ops, _lib
+    lib = _lib.load()
+    assert lib.gaot_debug_set_attention_p_pieces(22) == 22 and lib.gaot_debug_set_attention_operand_pieces(2) == 2
+    def run(qkv, go, H, D):
+        B, S, _ = qkv.shape
+        r = qkv.clone().double().requires_grad_(True)
+        q, k, v = [r[..., i * H * D:(i + 1) * H * D].reshape(B, S, H, D).transpose(1, 2) for i in range(3)]
+        ref = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(D), -1) @ v).transpose(1, 2).reshape(B, S, H * D)
+        ref.backward(go.double())
+        d = qkv.to(dev()).requires_grad_(True)
+        out = ops.attention(d, H, H, D)
+        out.backward(go.to(dev()))
+        return rel(out, ref), rel(d.grad, r.grad)
+    g = torch.Generator().manual_seed(7)
+    B, S, H, D = 8, 1024, 8, 32                           # the bench shape
+    eo, eg = run(torch.randn(B, S, 3 * H * D, generator=g), torch.randn(B, S, H * D, generator=g), H, D)
+    assert 1e-6 < eo < 1e-5 and 1e-6 < eg < 1.5e-5, (eo, eg)
+    base = (torch.randn(1, 1, 3 * H * D, generator=g) * 0.6).repeat(1, 2048, 1)
+    idx = torch.randperm(2048, generator=g)[:200]
+    base[0, idx] = torch.randn(200, 3 * H * D, generator=g) * 0.6
+    eo, eg = run(base + 1e-3 * torch.randn(1, 2048, 3 * H * D, generator=g), torch.randn(1, 2048, H * D, generator=g), H, D)
+    assert eo < 1e-5 and eg < 5e-5, (eo, eg)
+
 @pytest.mark.gpu
 def test_branch_free_erf_accuracy():
     """common.h erf_nb (single-range 1 - 2^(-|x| Q(|x|)), no branch) behind every GELU of the path: absolute error of

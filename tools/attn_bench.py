@@ -23,15 +23,16 @@ o64 = torch.softmax(q_ @ k_.transpose(-1, -2) / D ** 0.5, -1) @ v_
 o64 = o64.transpose(1, 2).reshape(B, S, H * D)
 g64, = torch.autograd.grad(o64, q64, go.double())
 rel = lambda a, b: float((a.double() - b).norm() / b.norm())
-for mode, pipe, pp in ((0, 0, 33), (2, 0, 33), (2, 0, 22), (2, 0, 33), (2, 0, 22), (2, 0, 32)):
+for mode, pipe, pp, op in ((0, 0, 33, 3), (2, 0, 33, 3), (2, 0, 22, 3), (2, 0, 22, 2), (2, 0, 33, 3), (2, 0, 22, 3), (2, 0, 22, 2)):
     lib.gaot_debug_set_attention_split(mode)
     lib.gaot_debug_set_attention_pipe(pipe)
     lib.gaot_debug_set_attention_p_pieces(pp)
+    lib.gaot_debug_set_attention_operand_pieces(op)
     with torch.no_grad():
         o = ops.attention(qkv, H, H, D)
         tf = timeit(lambda: ops.attention(qkv, H, H, D))
     o2 = ops.attention(qkv, H, H, D)
     g, = torch.autograd.grad(o2, qkv, go, retain_graph=True)
     tb = timeit(lambda: torch.autograd.grad(o2, qkv, go, retain_graph=True))
-    print(f"mode {mode} pipe {pipe} P pieces {pp}: fwd {tf:.1f} us   bwd (delta + main + dq reduce) {tb:.1f} us   rel-L2 vs f64: out {rel(o, o64.detach()):.2e}  dqkv {rel(g, g64):.2e}")
-lib.gaot_debug_set_attention_split(1); lib.gaot_debug_set_attention_pipe(0); lib.gaot_debug_set_attention_p_pieces(22)
+    print(f"mode {mode} pipe {pipe} P pieces {pp} operand pieces {op}: fwd {tf:.1f} us   bwd (delta + main + dq reduce) {tb:.1f} us   rel-L2 vs f64: out {rel(o, o64.detach()):.2e}  dqkv {rel(g, g64):.2e}")
+lib.gaot_debug_set_attention_split(1); lib.gaot_debug_set_attention_pipe(0); lib.gaot_debug_set_attention_p_pieces(22); lib.gaot_debug_set_attention_operand_pieces(2)
