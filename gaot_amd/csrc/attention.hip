@@ -1389,7 +1389,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_split_kernel(const AttnArgs p
 // the 4-wave kernel above with four 16-wide d steps per score, two 32-row tiles of dK^T / dV^T / dQ, one workgroup per CU
 // (120 KB of LDS, ~320 registers).  Same staging roles, same fixed-order dQ reduction over the wave partials.
 // ---------------------------------------------------------------------------------------------
-template <int DH>
+// PP / OP: pieces of P / dS and of the Q / K / V / dO operands, as in attn_bwd_split8_kernel (the dQ product stays on the fp32 MFMA)
+template <int DH, int PP = 3, int OP = 3>
 __global__ __launch_bounds__(256, 1) void attn_bwd_split_dh_kernel(const AttnArgs p) {
     constexpr int NU = DH / 16, NDT = DH / 32, CPR = DH / 4;
     constexpr int KROW = DH * 2 + 16, KPL = 32 * KROW;             // k-major planes [32 q][DH d]
@@ -1436,10 +1437,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_split_dh_kernel(const AttnArg
             unsigned a_, b_, c_;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                split3_pair(a0[2 * e], a0[2 * e + 1], a_, b_, c_); ph[e] = a_; pm[e] = b_; pl[e] = c_;
-                split3_pair(a1[2 * e], a1[2 * e + 1], a_, b_, c_); ph[2 + e] = a_; pm[2 + e] = b_; pl[2 + e] = c_;
-                split3_pair(w0[2 * e], w0[2 * e + 1], a_, b_, c_); vh[e] = a_; vm[e] = b_; vl[e] = c_;
-                split3_pair(w1[2 * e], w1[2 * e + 1], a_, b_, c_); vh[2 + e] = a_; vm[2 + e] = b_; vl[2 + e] = c_;
+                split_op<OP>(a0[2 * e], a0[2 * e + 1], a_, b_, c_); ph[e] = a_; pm[e] = b_; pl[e] = c_;
+                split_op<OP>(a1[2 * e], a1[2 * e + 1], a_, b_, c_); ph[2 + e] = a_; pm[2 + e] = b_; pl[2 + e] = c_;
+                split_op<OP>(w0[2 * e], w0[2 * e + 1], a_, b_, c_); vh[e] = a_; vm[e] = b_; vl[e] = c_;
+                split_op<OP>(w1[2 * e], w1[2 * e + 1], a_, b_, c_); vh[2 + e] = a_; vm[2 + e] = b_; vl[2 + e] = c_;
             }
             kf[0][u] = __builtin_bit_cast(bf16x8, ph); kf[1][u] = __builtin_bit_cast(bf16x8, pm); kf[2][u] = __builtin_bit_cast(bf16x8, pl);
             vf[0][u] = __builtin_bit_cast(bf16x8, vh); vf[1][u] = __builtin_bit_cast(bf16x8, vm); vf[2][u] = __builtin_bit_cast(bf16x8, vl);
@@ -1502,29 +1503,31 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_split_dh_kernel(const AttnArg
             for (int i = 0; i < NKI; ++i) {
                 const int idx = tid + 256 * i, row = idx / CPR, ch = idx % CPR;
                 u32x2 h2, m2, l2;
-                split3_pair(rq[i][0], rq[i][1], a_, b_, c_); h2[0] = a_; m2[0] = b_; l2[0] = c_;
-                split3_pair(rq[i][2], rq[i][3], a_, b_, c_); h2[1] = a_; m2[1] = b_; l2[1] = c_;
+                split_op<OP>(rq[i][0], rq[i][1], a_, b_, c_); h2[0] = a_; m2[0] = b_; l2[0] = c_;
+                split_op<OP>(rq[i][2], rq[i][3], a_, b_, c_); h2[1] = a_; m2[1] = b_; l2[1] = c_;
                 unsigned char* dq_ = Qk + row * KROW + ch * 8;
-                *reinterpret_cast<u32x2*>(dq_) = h2; *reinterpret_cast<u32x2*>(dq_ + KPL) = m2; *reinterpret_cast<u32x2*>(dq_ + 2 * KPL) = l2;
-                split3_pair(rg[i][0], rg[i][1], a_, b_, c_); h2[0] = a_; m2[0] = b_; l2[0] = c_;
-                split3_pair(rg[i][2], rg[i][3], a_, b_, c_); h2[1] = a_; m2[1] = b_; l2[1] = c_;
+                *reinterpret_cast<u32x2*>(dq_) = h2; *reinterpret_cast<u32x2*>(dq_ + KPL) = m2;
+                if (OP == 3) *reinterpret_cast<u32x2*>(dq_ + 2 * KPL) = l2;
+                split_op<OP>(rg[i][0], rg[i][1], a_, b_, c_); h2[0] = a_; m2[0] = b_; l2[0] = c_;
+                split_op<OP>(rg[i][2], rg[i][3], a_, b_, c_); h2[1] = a_; m2[1] = b_; l2[1] = c_;
                 unsigned char* dg_ = Gk + row * KROW + ch * 8;
-                *reinterpret_cast<u32x2*>(dg_) = h2; *reinterpret_cast<u32x2*>(dg_ + KPL) = m2; *reinterpret_cast<u32x2*>(dg_ + 2 * KPL) = l2;
+                *reinterpret_cast<u32x2*>(dg_) = h2; *reinterpret_cast<u32x2*>(dg_ + KPL) = m2;
+                if (OP == 3) *reinterpret_cast<u32x2*>(dg_ + 2 * KPL) = l2;
             }
             // transposed: (q = 2qp, 2qp+1) pairs of this thread's 4 d columns, for Q and for dO
             const int qp = tid / CPR, d0 = (tid % CPR) * 4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                split3_pair(rtq[0][e], rtq[1][e], a_, b_, c_);
+                split_op<OP>(rtq[0][e], rtq[1][e], a_, b_, c_);
                 unsigned char* dst = Qt + (d0 + e) * AB_TROW + qp * 4;
                 *reinterpret_cast<unsigned*>(dst) = a_;
                 *reinterpret_cast<unsigned*>(dst + TPL) = b_;
-                *reinterpret_cast<unsigned*>(dst + 2 * TPL) = c_;
-                split3_pair(rtg[0][e], rtg[1][e], a_, b_, c_);
+                if (OP == 3) *reinterpret_cast<unsigned*>(dst + 2 * TPL) = c_;
+                split_op<OP>(rtg[0][e], rtg[1][e], a_, b_, c_);
                 dst = Gt + (d0 + e) * AB_TROW + qp * 4;
                 *reinterpret_cast<unsigned*>(dst) = a_;
                 *reinterpret_cast<unsigned*>(dst + TPL) = b_;
-                *reinterpret_cast<unsigned*>(dst + 2 * TPL) = c_;
+                if (OP == 3) *reinterpret_cast<unsigned*>(dst + 2 * TPL) = c_;
             }
         }
         if (tid < 32) { lse_s[tid] = rl; del_s[tid] = rd; }
@@ -1539,14 +1542,17 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_split_dh_kernel(const AttnArg
         for (int u = 0; u < NU; ++u) {
             const unsigned char* qr = Qk + li * KROW + u * 32 + lh * 16;
             const unsigned char* gr = Gk + li * KROW + u * 32 + lh * 16;
-            const bf16x8 q0_ = *reinterpret_cast<const bf16x8*>(qr), q1_ = *reinterpret_cast<const bf16x8*>(qr + KPL), q2_ = *reinterpret_cast<const bf16x8*>(qr + 2 * KPL);
-            const bf16x8 g0_ = *reinterpret_cast<const bf16x8*>(gr), g1_ = *reinterpret_cast<const bf16x8*>(gr + KPL), g2_ = *reinterpret_cast<const bf16x8*>(gr + 2 * KPL);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q2_, kf[0][u], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g2_, vf[0][u], dp, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0_, kf[2][u], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0_, vf[2][u], dp, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q1_, kf[1][u], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1_, vf[1][u], dp, 0, 0, 0);
+            const bf16x8 q0_ = *reinterpret_cast<const bf16x8*>(qr), q1_ = *reinterpret_cast<const bf16x8*>(qr + KPL);
+            const bf16x8 g0_ = *reinterpret_cast<const bf16x8*>(gr), g1_ = *reinterpret_cast<const bf16x8*>(gr + KPL);
+            if (OP == 3) {
+                const bf16x8 q2_ = *reinterpret_cast<const bf16x8*>(qr + 2 * KPL), g2_ = *reinterpret_cast<const bf16x8*>(gr + 2 * KPL);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q2_, kf[0][u], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g2_, vf[0][u], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0_, kf[2][u], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0_, vf[2][u], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q1_, kf[1][u], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1_, vf[1][u], dp, 0, 0, 0);
+            }
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q1_, kf[0][u], s, 0, 0, 0);
             dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1_, vf[0][u], dp, 0, 0, 0);
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0_, kf[1][u], s, 0, 0, 0);
@@ -1578,8 +1584,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_split_dh_kernel(const AttnArg
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 unsigned a_, b_, c_;
-                split3_pair(s[8 * u + 2 * e], s[8 * u + 2 * e + 1], a_, b_, c_); ph[e] = a_; pm[e] = b_; pl[e] = c_;
-                split3_pair(dp[8 * u + 2 * e], dp[8 * u + 2 * e + 1], a_, b_, c_); sh[e] = a_; sm[e] = b_; sl[e] = c_;
+                split_op<PP>(s[8 * u + 2 * e], s[8 * u + 2 * e + 1], a_, b_, c_); ph[e] = a_; pm[e] = b_; pl[e] = c_;
+                split_op<PP>(dp[8 * u + 2 * e], dp[8 * u + 2 * e + 1], a_, b_, c_); sh[e] = a_; sm[e] = b_; sl[e] = c_;
             }
             const bf16x8 p0 = __builtin_bit_cast(bf16x8, ph), p1 = __builtin_bit_cast(bf16x8, pm), p2 = __builtin_bit_cast(bf16x8, pl);
             const bf16x8 d0 = __builtin_bit_cast(bf16x8, sh), d1 = __builtin_bit_cast(bf16x8, sm), d2 = __builtin_bit_cast(bf16x8, sl);
@@ -1589,18 +1595,24 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_split_dh_kernel(const AttnArg
                 const unsigned char* qr = Qt + (32 * dt + li) * AB_TROW + (16 * u + 4 * lh) * 2;
                 bf16x8 ga[3], qa[3];
 #pragma unroll
-                for (int pl_ = 0; pl_ < 3; ++pl_) {
+                for (int pl_ = 0; pl_ < OP; ++pl_) {
                     const u32x2 g_lo = *reinterpret_cast<const u32x2*>(gr + pl_ * TPL), g_hi = *reinterpret_cast<const u32x2*>(gr + pl_ * TPL + 16);
                     const u32x2 q_lo = *reinterpret_cast<const u32x2*>(qr + pl_ * TPL), q_hi = *reinterpret_cast<const u32x2*>(qr + pl_ * TPL + 16);
                     ga[pl_] = __builtin_bit_cast(bf16x8, u32x4{g_lo[0], g_lo[1], g_hi[0], g_hi[1]});
                     qa[pl_] = __builtin_bit_cast(bf16x8, u32x4{q_lo[0], q_lo[1], q_hi[0], q_hi[1]});
                 }
-                dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[2], p0, dvt[dt], 0, 0, 0);
-                dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[2], d0, dkt[dt], 0, 0, 0);
-                dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p2, dvt[dt], 0, 0, 0);
-                dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d2, dkt[dt], 0, 0, 0);
-                dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1], p1, dvt[dt], 0, 0, 0);
-                dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1], d1, dkt[dt], 0, 0, 0);
+                if (OP == 3) {
+                    dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[2], p0, dvt[dt], 0, 0, 0);
+                    dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[2], d0, dkt[dt], 0, 0, 0);
+                }
+                if (PP == 3) {
+                    dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p2, dvt[dt], 0, 0, 0);
+                    dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d2, dkt[dt], 0, 0, 0);
+                }
+                if (OP == 3 || PP == 3) {
+                    dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1], p1, dvt[dt], 0, 0, 0);
+                    dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1], d1, dkt[dt], 0, 0, 0);
+                }
                 dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1], p0, dvt[dt], 0, 0, 0);
                 dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1], d0, dkt[dt], 0, 0, 0);
                 dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p1, dvt[dt], 0, 0, 0);
@@ -2038,8 +2050,11 @@ extern "C" int gaot_attention_fwd(const float* q, const float* k, const float* v
         else hipLaunchKernelGGL((attn_fwd_split_kernel<4, 32, 2, 2>), grid, block, 0, ST(stream), a);
     }
     else if (head_dim > 32 && head_dim <= 64 && a.vec && g_attn_split) {      // (a.vec: head_dim % 4 == 0): split-bf16 with four d steps
+        const bool two64 = g_attn_pp / 10 == 2 && g_attn_op == 2;             // two rounded pieces of everything, or exact splits
         if (g_attn_split != 3 && (g_attn_split == 2 || (long)cdiv(S, 256) * B * H >= 256))
-            hipLaunchKernelGGL((attn_fwd_split_kernel<8, 64>), dim3(cdiv(S, 256) * B * H), dim3(512), 0, ST(stream), a);
+            { if (two64) hipLaunchKernelGGL((attn_fwd_split_kernel<8, 64, 2, 2>), dim3(cdiv(S, 256) * B * H), dim3(512), 0, ST(stream), a);
+              else hipLaunchKernelGGL((attn_fwd_split_kernel<8, 64>), dim3(cdiv(S, 256) * B * H), dim3(512), 0, ST(stream), a); }
+        else if (two64) hipLaunchKernelGGL((attn_fwd_split_kernel<4, 64, 2, 2>), grid, block, 0, ST(stream), a);
         else hipLaunchKernelGGL((attn_fwd_split_kernel<4, 64>), grid, block, 0, ST(stream), a);
     }
     else if (head_dim == 32 && a.vec) hipLaunchKernelGGL(attn_fwd_glds_kernel, grid, block, 0, ST(stream), a);
@@ -2171,7 +2186,8 @@ extern "C" int gaot_attention_bwd(const float* q, const float* k, const float* v
     } else if (split_ok) {
         hipLaunchKernelGGL(attn_bwd_split_kernel, grid, block, 0, ST(stream), a);
     } else if (head_dim > 32 && head_dim <= 64 && a.vec && g_attn_split && aligned16(dq) && aligned16(dk) && aligned16(dv)) {
-        hipLaunchKernelGGL(attn_bwd_split_dh_kernel<64>, grid, block, 0, ST(stream), a);
+        if (g_attn_pp % 10 == 2 && g_attn_op == 2) hipLaunchKernelGGL((attn_bwd_split_dh_kernel<64, 2, 2>), grid, block, 0, ST(stream), a);
+        else hipLaunchKernelGGL((attn_bwd_split_dh_kernel<64>), grid, block, 0, ST(stream), a);
     } else if (DP == 32) {
         hipLaunchKernelGGL(attn_bwd_kernel<32>, grid, block, bwd_lds_bytes<32>(), ST(stream), a);
     } else if (DP == 64) {
