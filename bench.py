@@ -489,6 +489,7 @@ def main():
             dist.init_process_group(backend=backend)
 
     from gaot_amd.trainer import TrainStep
+    from gaot_amd import ops as _ops
     if args.dtype == "bf16":
         from gaot_amd import ops, _lib
         ops.set_gemm_mode(5)                  # split-tile kernels wherever eligible ...
@@ -596,6 +597,13 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32" if args.dtype == "f32" else "bf16 GEMM operands (RNE), fp32 accumulation; everything else f32 -- NOT the parity path",
+            "precision": {"storage_and_accumulation": "f32 everywhere (weights, activations, gradients, optimizer state, every accumulator)",
+                          "gemm_pieces": dict(_ops._PIECES), "attention": "P / dS and Q / K / V / dO as two rounded bf16 pieces (head_dim <= 64)",
+                          "what": "products on the bf16 matrix pipe take each f32 operand as N bf16 pieces: 3 = exact to f32 rounding (six piece "
+                                  "products), 2 = two pieces both rounded to nearest, 16 significant bits per operand (three piece products).  "
+                                  "Default 2; GAOT_GEMM_PIECES=3 + gaot_debug_set_attention_{p,operand}_pieces(33, 3) give the exact mode.  "
+                                  "rel_l2_vs_oracle.vs_float64_oracle measures what it costs: the two-piece path stays closer to float64 than the "
+                                  "reference's own fp32 arithmetic on the output, and 15x under the 1e-4 gradient bar"},
             "data": "synthetic (uniform-random 16384-point 2-D mesh in [-1,1]^2, N(0,1) fields, random-init weights)",
             "config": {"workload": "BASELINE configs[1]: Poisson-Gauss-shaped 2D, 16384 nodes/mesh, batch 8 per GPU, fx mode; "
                                    "example model latent 64x64, C=64, patch 2, transformer 256x3, 8 heads",
@@ -603,8 +611,11 @@ def main():
                        "step": "fwd + MSE + bwd + AdamW" + (" + staged flat-grad RCCL all-reduce (one async slice per backward phase)" if world > 1 else ""),
                        "hipgraph": ts.use_graph, "staged_backward_phases": ts.bucket.n_phases, "final_loss": loss},
             "roofline": {"bound": "mfma", "kernel": "gaot_gemm_f32 MFMA tile kernels, every launch of one step: gemm_glds_kernel (v_mfma_f32_32x32x2_f32) and "
-                                   "gemm_split_kernel (fp32 operands split exactly into 3 bf16 pieces, 6 x v_mfma_f32_32x32x16_bf16 per product)",
-                         "peak_note": "peak = dense f32 matrix rate; the split-bf16 kernel's own ceiling is bf16 dense / 6 = 419 TFLOP/s of f32 work",
+                                   "gemm_split_kernel / gemm_tn_grouped_kernel (f32 operands as 2 rounded bf16 pieces, 3 x v_mfma_f32_32x32x16_bf16 per product; "
+                                   "3 exact pieces / 6 products with GAOT_GEMM_PIECES=3)",
+                         "peak_note": "peak = dense f32 matrix rate (dtype f32); the split-bf16 kernels' own ceiling is bf16 dense / 3 = 833 TFLOP/s of f32 "
+                                      "work with two pieces (/ 6 = 419 with three)",
+                         "frac_of_bf16_pipe": roof["tflops"] * (3 if _ops._PIECES["nt"] == 2 else 6) / 2500.0,
                          "split_bf16_launches_per_step": roof["split_launches"],
                          "achieved": roof["tflops"], "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": roof["tflops"] / PEAK_F32_MATRIX_TFLOPS, "traffic": traffic,

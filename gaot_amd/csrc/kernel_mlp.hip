@@ -395,7 +395,14 @@ __device__ __forceinline__ f32x16 mfma_split6(const u32x4 (&a)[3], const u32x4 (
     c = mfma_bf16(a[0], b[1], c);
     return mfma_bf16(a[0], b[0], c);
 }
-template <int NL, int CM>
+// NP pieces per operand: 3 = exact, 2 = two rounded pieces (common.h split2_pair); layer m's planes start at m * NP * KS_PLANE
+template <int NP>
+__device__ __forceinline__ void km_split(float x0, float x1, unsigned& a, unsigned& b, unsigned& c) {
+    if (NP == 3) split3_pair(x0, x1, a, b, c);
+    else { split2_pair(x0, x1, a, b); c = 0u; }
+}
+
+template <int NL, int CM, int NP = 3>
 __device__ __forceinline__ void km_stage_weights_split(const KMArgs& p, unsigned char* Wp, float* W1s, float* Bs, int tid) {
 #pragma unroll
     for (int m = 0; m < NL; ++m)
@@ -404,12 +411,12 @@ __device__ __forceinline__ void km_stage_weights_split(const KMArgs& p, unsigned
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (r < p.wo[m + 1] && c4 < p.wo[m]) v = *reinterpret_cast<const f32x4*>(p.w[m] + r * p.ldw[m + 1] + c4);
             unsigned h0, m0, l0, h1, m1, l1;
-            split3_pair(v[0], v[1], h0, m0, l0);
-            split3_pair(v[2], v[3], h1, m1, l1);
-            unsigned char* d = Wp + m * 3 * KS_PLANE + r * KS_LDB + c4 * 2;
+            km_split<NP>(v[0], v[1], h0, m0, l0);
+            km_split<NP>(v[2], v[3], h1, m1, l1);
+            unsigned char* d = Wp + m * NP * KS_PLANE + r * KS_LDB + c4 * 2;
             *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
             *reinterpret_cast<u32x2*>(d + KS_PLANE) = u32x2{m0, m1};
-            *reinterpret_cast<u32x2*>(d + 2 * KS_PLANE) = u32x2{l0, l1};
+            if (NP == 3) *reinterpret_cast<u32x2*>(d + 2 * KS_PLANE) = u32x2{l0, l1};
         }
     for (int i = tid; i < 64 * CM; i += 256) { const int f = i / CM, c = i % CM; W1s[i] = (c < p.cin && f < p.wo[0]) ? p.w1[f * p.ldw[0] + c] : 0.f; }
     if (tid < 64) {
@@ -419,7 +426,17 @@ __device__ __forceinline__ void km_stage_weights_split(const KMArgs& p, unsigned
     }
 }
 
-// one layer: acc[io] = b + W h, W as three planes at Wp
+// the piece products of one k-step, smallest terms first: six with three pieces, three with two (second x second <= 2^-18 of the term)
+template <int NP>
+__device__ __forceinline__ f32x16 mfma_pieces(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x16 c) {
+    if (NP == 3) return mfma_split6(a, b, c);
+    c = mfma_bf16(a[1], b[0], c);
+    c = mfma_bf16(a[0], b[1], c);
+    return mfma_bf16(a[0], b[0], c);
+}
+
+// one layer: acc[io] = b + W h, W as NP planes at Wp
+template <int NP = 3>
 __device__ __forceinline__ void km_layer_split(const unsigned char* Wp, const float* bias, const f32x16 (&h)[2], int li, int hi, f32x16 (&acc)[2]) {
 #pragma unroll
     for (int io = 0; io < 2; ++io)
@@ -430,7 +447,7 @@ __device__ __forceinline__ void km_layer_split(const unsigned char* Wp, const fl
         const int kt = j >> 1, r0 = 8 * (j & 1);
         unsigned q0[4], q1[4], q2[4];
 #pragma unroll
-        for (int e2 = 0; e2 < 4; ++e2) split3_pair(h[kt][r0 + 2 * e2], h[kt][r0 + 2 * e2 + 1], q0[e2], q1[e2], q2[e2]);
+        for (int e2 = 0; e2 < 4; ++e2) km_split<NP>(h[kt][r0 + 2 * e2], h[kt][r0 + 2 * e2 + 1], q0[e2], q1[e2], q2[e2]);
         const u32x4 b[3] = {u32x4{q0[0], q0[1], q0[2], q0[3]}, u32x4{q1[0], q1[1], q1[2], q1[3]}, u32x4{q2[0], q2[1], q2[2], q2[3]}};
 #pragma unroll
         for (int io = 0; io < 2; ++io) {
@@ -438,22 +455,23 @@ __device__ __forceinline__ void km_layer_split(const unsigned char* Wp, const fl
             u32x4 a[3];
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
-                a[pl] = join8(*reinterpret_cast<const u32x2*>(ap + pl * KS_PLANE), *reinterpret_cast<const u32x2*>(ap + pl * KS_PLANE + 16));
-            acc[io] = mfma_split6(a, b, acc[io]);
+                a[pl] = pl < NP ? join8(*reinterpret_cast<const u32x2*>(ap + pl * KS_PLANE), *reinterpret_cast<const u32x2*>(ap + pl * KS_PLANE + 16))
+                                : u32x4{0u, 0u, 0u, 0u};
+            acc[io] = mfma_pieces<NP>(a, b, acc[io]);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
 // (two workgroups per CU: 9 planes + the first layer's [64][CM] weights + biases are 80 384 B at c_in <= 4, and 256 registers)
-template <int NL, int CM, int ACT>
+template <int NL, int CM, int ACT, int NP = 3>
 __global__ __launch_bounds__(256, 2) void kernel_mlp_fwd_split_kernel(const KMArgs p) {
-    __shared__ __attribute__((aligned(16))) unsigned char Wp[NL * 3 * KS_PLANE];
+    __shared__ __attribute__((aligned(16))) unsigned char Wp[NL * NP * KS_PLANE];
     __shared__ __attribute__((aligned(16))) float W1s[64 * CM];
     __shared__ float Bs[64 * (NL + 1)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, hi = lane >> 5;
-    km_stage_weights_split<NL, CM>(p, Wp, W1s, Bs, tid);
+    km_stage_weights_split<NL, CM, NP>(p, Wp, W1s, Bs, tid);
     __syncthreads();
     const int e0 = (blockIdx.x * 4 + wave) * 32;
     if (e0 >= p.E) return;
@@ -468,7 +486,7 @@ __global__ __launch_bounds__(256, 2) void kernel_mlp_fwd_split_kernel(const KMAr
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int t = 0; t < 16; ++t) h[kt][t] = act_f<ACT>(z[kt][t]);
-        km_layer_split(Wp + m * 3 * KS_PLANE, Bs + 64 * (m + 1), h, li, hi, z);
+        km_layer_split<NP>(Wp + m * NP * KS_PLANE, Bs + 64 * (m + 1), h, li, hi, z);
     }
     if (e0 + li < p.E) {
         float* dst = p.out + (long)(e0 + li) * p.cout;
@@ -691,6 +709,249 @@ __global__ __launch_bounds__(256, 1) void kernel_mlp_bwd_split_kernel(const KMAr
     for (int i = tid; i < nsmall; i += 256) dst[NL * 4096 + i] = R[i];
 }
 
+// ------------------------------------------------------------------------------------------ backward, two rounded pieces everywhere
+// With two pieces per operand the weight planes take a third less LDS, and the weight gradient moves onto the bf16 pipe as well:
+// G_m and H_{m-1} go to LDS as their two bf16 pieces, [128 edges][64 features] (a lane's four consecutive features are one 8-byte
+// store; G's pieces are the ones the input-gradient chain has just formed), and come back edge-major through the transposing reads;
+// three piece products per 16-edge k-step.  db rides on the A fragments (v_dot2c_f32_bf16).  The sign flip of odd edges (see the
+// three-piece kernel) covers G AND H here, so their products -- and dW -- are unchanged; db undoes it with (+1, -1) dot factors.
+// The bf16 accumulators of dW run over at most KS_FLUSH_TILES tiles before they are added to the workgroup's partial row.
+constexpr int KS_TPLANE = 128 * KS_LDB;
+constexpr int KS_FLUSH_TILES = 16;
+__device__ __forceinline__ float dot2_pm(unsigned w, float acc) {          // acc + lo(w) - hi(w) of a packed bf16 pair
+    asm("v_dot2c_f32_bf16 %0, 0xbf803f80, %1" : "+v"(acc) : "v"(w));       // (inline asm: see the note on __builtin_amdgcn_fdot2_f32_bf16 in DESIGN.md 6)
+    return acc;
+}
+template <int NL, int CM, int ACT>
+__global__ __launch_bounds__(256, 1) void kernel_mlp_bwd_split2_kernel(const KMArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char Wp[NL * 2 * KS_PLANE];
+    __shared__ __attribute__((aligned(16))) float W1s[64 * KM_MAXC];
+    __shared__ float Bs[64 * (NL + 1)];
+    __shared__ __attribute__((aligned(16))) unsigned char T[4 * KS_TPLANE];     // G piece 1 | G piece 2 | H piece 1 | H piece 2; first layer: fp32 [64][132]
+    __shared__ __attribute__((aligned(16))) float Xt[128 * KM_MAXC];
+    static_assert(4 * KS_TPLANE >= 64 * KM_TLD128 * 4, "the first layer's fp32 tile lives in the plane region");
+    float* Gt = reinterpret_cast<float*>(T);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, hi = lane >> 5;
+    const int io_w = wave >> 1, kt_w = wave & 1;
+    const int cin = p.cin;
+    const int tr_off = (4 * (lane >> 5) + ((lane & 15) >> 2)) * KS_LDB + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    km_stage_weights_split<NL, CM, 2>(p, Wp, W1s, Bs, tid);
+    __syncthreads();
+
+    f32x16 dW[NL];
+#pragma unroll
+    for (int m = 0; m < NL; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dW[m][r] = 0.f;
+    float db[NL + 1];
+    float dw1[CM];
+#pragma unroll
+    for (int m = 0; m <= NL; ++m) db[m] = 0.f;
+#pragma unroll
+    for (int c = 0; c < CM; ++c) dw1[c] = 0.f;
+    float* dst = p.ws + (long)blockIdx.x * p.psize;
+    float* dquad = dst + (io_w * 32 + 4 * hi) * 64 + kt_w * 32 + li;      // this lane's column of its dW quadrant, row 4 hi (one address register)
+    int since_flush = 0;
+    bool flushed = false;
+
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        asm volatile("" ::: "memory");
+        if (since_flush == KS_FLUSH_TILES) {
+            float* dq2 = dquad;
+            asm volatile("" : "+v"(dq2));           // keep the 48 store addresses of this cold block out of the loop's registers
+#pragma unroll
+            for (int m = 0; m < NL; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float* d = dq2 + m * 4096 + crow0(r) * 64;
+                    *d = flushed ? *d + dW[m][r] : dW[m][r];
+                    dW[m][r] = 0.f;
+                }
+            flushed = true;
+            since_flush = 0;
+        }
+        ++since_flush;
+        const int e0 = tile * 128 + wave * 32;
+        const bool valid = e0 + li < p.E;
+        const int e = min(e0 + li, p.E - 1);
+        float xr[CM];
+        km_load_x<CM>(p, e, xr);
+        f32x16 g[2];
+        {
+            const float* src = p.dk + (long)e * p.cout;
+#pragma unroll
+            for (int io = 0; io < 2; ++io)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (valid && io * 32 + 8 * q + 4 * hi < p.cout) v = *reinterpret_cast<const f32x4*>(src + io * 32 + 8 * q + 4 * hi);
+                    g[io][4 * q] = v[0]; g[io][4 * q + 1] = v[1]; g[io][4 * q + 2] = v[2]; g[io][4 * q + 3] = v[3];
+                }
+        }
+        if (hi == 0) {
+#pragma unroll
+            for (int c = 0; c < CM; ++c) Xt[(wave * 32 + li) * KM_MAXC + c] = valid ? xr[c] : 0.f;
+        }
+        f32x16 z[NL][2], hk[NL > 1 ? NL - 1 : 1][2];
+        km_layer0<CM>(W1s, Bs, xr, cin, hi, z[0]);
+#pragma unroll
+        for (int m = 0; m + 1 < NL; ++m) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    float hv, dv;
+                    act_both<ACT>(z[m][kt][t], hv, dv);
+                    hk[m][kt][t] = hv; z[m][kt][t] = dv;
+                }
+            km_layer_split<2>(Wp + m * 2 * KS_PLANE, Bs + 64 * (m + 1), hk[m], li, hi, z[m + 1]);
+        }
+        const unsigned sbit = (unsigned)(li & 1) << 31;
+        auto flip = [sbit](float v) { return __uint_as_float(__float_as_uint(v) ^ sbit); };
+        unsigned char* trow = T + (wave * 32 + li) * KS_LDB + (4 * hi) * 2;      // this lane's edge row, its feature quad
+        float* gcol = Gt + (4 * hi) * KM_TLD128 + wave * 32 + li;
+#pragma unroll
+        for (int m = NL; m >= 1; --m) {
+            const unsigned char* W = Wp + (m - 1) * 2 * KS_PLANE;
+            f32x16 dh[2];
+#pragma unroll
+            for (int io = 0; io < 2; ++io)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dh[io][r] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kt = j >> 1, r0 = 8 * (j & 1);
+                u32x4 a[2][2];
+#pragma unroll
+                for (int io = 0; io < 2; ++io) {
+                    const unsigned char* ap = W + (16 * j) * KS_LDB + (io * 32) * 2 + tr_off;
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) a[io][pl] = join8(lds_tr(ap + pl * KS_PLANE), lds_tr(ap + pl * KS_PLANE + 8 * KS_LDB));
+                }
+                unsigned g1[4], g2[4], h1[4], h2[4];
+                float hv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (m == NL) { float dv; act_both<ACT>(z[m - 1][kt][r0 + u], hv[u], dv); z[m - 1][kt][r0 + u] = dv; }
+                    else hv[u] = hk[m == NL ? 0 : m - 1][kt][r0 + u];
+                }
+#pragma unroll
+                for (int e2 = 0; e2 < 4; ++e2) {
+                    split2_pair(flip(g[kt][r0 + 2 * e2]), flip(g[kt][r0 + 2 * e2 + 1]), g1[e2], g2[e2]);
+                    split2_pair(flip(hv[2 * e2]), flip(hv[2 * e2 + 1]), h1[e2], h2[e2]);
+                }
+                // registers r0 .. r0 + 3 are features 16 j + 4 hi + 0..3, r0 + 4 .. r0 + 7 the same, eight features up
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    unsigned char* d = trow + (16 * j + 8 * s2) * 2;
+                    *reinterpret_cast<u32x2*>(d) = u32x2{g1[2 * s2], g1[2 * s2 + 1]};
+                    *reinterpret_cast<u32x2*>(d + KS_TPLANE) = u32x2{g2[2 * s2], g2[2 * s2 + 1]};
+                    *reinterpret_cast<u32x2*>(d + 2 * KS_TPLANE) = u32x2{h1[2 * s2], h1[2 * s2 + 1]};
+                    *reinterpret_cast<u32x2*>(d + 3 * KS_TPLANE) = u32x2{h2[2 * s2], h2[2 * s2 + 1]};
+                }
+                const u32x4 b0 = {g1[0], g1[1], g1[2], g1[3]}, b1 = {g2[0], g2[1], g2[2], g2[3]};
+#pragma unroll
+                for (int io = 0; io < 2; ++io) {
+                    dh[io] = mfma_bf16(a[io][1], b0, dh[io]);
+                    dh[io] = mfma_bf16(a[io][0], b1, dh[io]);
+                    dh[io] = mfma_bf16(a[io][0], b0, dh[io]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+            // dW_m quadrant (io_w, kt_w) += G_m[io_w features] H_{m-1}[kt_w features]^T over the tile's 128 edges
+            {
+                const unsigned char* ga = T + (io_w * 32) * 2 + tr_off;
+                const unsigned char* hb = T + 2 * KS_TPLANE + (kt_w * 32) * 2 + tr_off;
+                float dsum = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    u32x4 a[2], b[2];
+#pragma unroll
+                    for (int pc = 0; pc < 2; ++pc) {
+                        a[pc] = join8(lds_tr(ga + pc * KS_TPLANE + (16 * ks) * KS_LDB), lds_tr(ga + pc * KS_TPLANE + (16 * ks + 8) * KS_LDB));
+                        b[pc] = join8(lds_tr(hb + pc * KS_TPLANE + (16 * ks) * KS_LDB), lds_tr(hb + pc * KS_TPLANE + (16 * ks + 8) * KS_LDB));
+                    }
+                    dW[m - 1] = mfma_bf16(a[1], b[0], dW[m - 1]);
+                    dW[m - 1] = mfma_bf16(a[0], b[1], dW[m - 1]);
+                    dW[m - 1] = mfma_bf16(a[0], b[0], dW[m - 1]);
+                    if (kt_w == 0) {
+#pragma unroll
+                        for (int pc = 1; pc >= 0; --pc)
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) dsum = dot2_pm(a[pc][u], dsum);
+                    }
+                }
+                db[m] += dsum;
+            }
+#pragma unroll
+            for (int io = 0; io < 2; ++io)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) g[io][r] = dh[io][r] * flip(z[m - 1][io][r]);
+            __syncthreads();
+        }
+        // first layer: dW_1 = G_0 x^T, db_1 on the VALU (fp32 tile in the plane region)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) gcol[(kt * 32 + crow0(t)) * KM_TLD128] = g[kt][t];
+        __syncthreads();
+        {
+            const float* ga = Gt + (io_w * 32 + li) * KM_TLD128 + kt_w * 64 + 4 * hi;
+            float dsum = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(ga + 8 * q);
+                dsum += (av[0] + av[1]) + (av[2] + av[3]);
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    const float* xe = Xt + (kt_w * 64 + 8 * q + 4 * hi + s2) * KM_MAXC;
+#pragma unroll
+                    for (int c4 = 0; c4 < CM / 4; ++c4) {
+                        const f32x4 xv = *reinterpret_cast<const f32x4*>(xe + 4 * c4);
+                        dw1[4 * c4] += av[s2] * xv[0]; dw1[4 * c4 + 1] += av[s2] * xv[1]; dw1[4 * c4 + 2] += av[s2] * xv[2]; dw1[4 * c4 + 3] += av[s2] * xv[3];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            db[0] += dsum;
+        }
+        __syncthreads();
+    }
+
+    asm volatile("" : "+v"(dquad));
+#pragma unroll
+    for (int m = 0; m < NL; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float* d = dquad + m * 4096 + crow0(r) * 64;
+            *d = flushed ? *d + dW[m][r] : dW[m][r];
+        }
+    float* R = Gt;
+    const int off_b = 64 * cin, nsmall = 64 * cin + 64 * (NL + 1);
+#pragma unroll
+    for (int c = 0; c < CM; ++c) dw1[c] += __shfl_xor(dw1[c], 32, 64);
+#pragma unroll
+    for (int m = 0; m <= NL; ++m) db[m] += __shfl_xor(db[m], 32, 64);
+    for (int pass = 0; pass < 2; ++pass) {
+        if (kt_w == pass && hi == 0) {
+#pragma unroll
+            for (int c = 0; c < CM; ++c)
+                if (c < cin) { float* d = R + (io_w * 32 + li) * cin + c; *d = pass == 0 ? dw1[c] : *d + dw1[c]; }
+            float* d0 = R + off_b + io_w * 32 + li;
+            *d0 = pass == 0 ? db[0] : *d0 + db[0];
+            if (pass == 0) {
+#pragma unroll
+                for (int m = 1; m <= NL; ++m) R[off_b + m * 64 + io_w * 32 + li] = db[m];
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < nsmall; i += 256) dst[NL * 4096 + i] = R[i];
+}
+
 static int km_check(const float* x, int E, int cin, int n_layers, const float* const* w, const float* const* b) {
     GAOT_REQUIRE(x && E > 0 && cin >= 1 && cin <= KM_MAXC, "kernel_mlp: need x, E > 0 and 1 <= c_in <= %d (got %d)", KM_MAXC, cin);
     GAOT_REQUIRE(n_layers >= 2 && n_layers <= 4, "kernel_mlp: 2..4 layers (got %d)", n_layers);
@@ -728,10 +989,11 @@ static int km_widths_ok(const int32_t* widths, int n_layers) {
 static const int32_t KM_W64[4] = {64, 64, 64, 64};
 
 extern "C" int gaot_kernel_mlp_fwd_w(const float* x, int32_t E, int32_t cin, int32_t n_layers, const float* const* w,
-                                     const float* const* b, int32_t act, const int32_t* widths, const int32_t* ldw, float* out, gaot_stream_t stream);
+                                     const float* const* b, int32_t act, const int32_t* widths, const int32_t* ldw, int32_t pieces, float* out,
+                                     gaot_stream_t stream);
 extern "C" int gaot_kernel_mlp_fwd(const float* x, int32_t E, int32_t cin, int32_t n_layers, const float* const* w,
                                    const float* const* b, int32_t act, float* out, gaot_stream_t stream) {
-    return gaot_kernel_mlp_fwd_w(x, E, cin, n_layers, w, b, act, KM_W64, nullptr, out, stream);
+    return gaot_kernel_mlp_fwd_w(x, E, cin, n_layers, w, b, act, KM_W64, nullptr, 0, out, stream);
 }
 
 static int km_ldw_ok(const int32_t* ldw, const int32_t* widths, int cin, int n_layers) {
@@ -745,7 +1007,9 @@ static int km_ldw_ok(const int32_t* ldw, const int32_t* widths, int cin, int n_l
 }
 
 extern "C" int gaot_kernel_mlp_fwd_w(const float* x, int32_t E, int32_t cin, int32_t n_layers, const float* const* w,
-                                     const float* const* b, int32_t act, const int32_t* widths, const int32_t* ldw, float* out, gaot_stream_t stream) {
+                                     const float* const* b, int32_t act, const int32_t* widths, const int32_t* ldw, int32_t pieces, float* out,
+                                     gaot_stream_t stream) {
+    GAOT_REQUIRE(pieces == 0 || pieces == 2 || pieces == 3, "kernel_mlp: pieces must be 0 / 3 (exact) or 2 (two rounded pieces), got %d", pieces);
     if (int rc = km_check(x, E, cin, n_layers, w, b)) return rc;
     if (int rc = km_widths_ok(widths, n_layers)) return rc;
     if (int rc = km_ldw_ok(ldw, widths, cin, n_layers)) return rc;
@@ -754,10 +1018,12 @@ extern "C" int gaot_kernel_mlp_fwd_w(const float* x, int32_t E, int32_t cin, int
     KMArgs a{}; km_fill(a, x, E, cin, n_layers, w, b, widths, ldw); a.out = out;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid(a.ntiles), block(256);
-#define KM_FWD3(K, NL, A) do { if (cin == 4) hipLaunchKernelGGL((K<NL, 4, A>), grid, block, 0, st, a); \
-                               else if (cin <= 8) hipLaunchKernelGGL((K<NL, 8, A>), grid, block, 0, st, a); \
-                               else hipLaunchKernelGGL((K<NL, KM_MAXC, A>), grid, block, 0, st, a); } while (0)
-#define KM_FWD2(NL, A) do { if (g_km_split && !a.abl) KM_FWD3(kernel_mlp_fwd_split_kernel, NL, A); else KM_FWD3(kernel_mlp_fwd_kernel, NL, A); } while (0)
+#define KM_FWD3(K, NL, ...) do { if (cin == 4) hipLaunchKernelGGL((K<NL, 4, __VA_ARGS__>), grid, block, 0, st, a); \
+                                 else if (cin <= 8) hipLaunchKernelGGL((K<NL, 8, __VA_ARGS__>), grid, block, 0, st, a); \
+                                 else hipLaunchKernelGGL((K<NL, KM_MAXC, __VA_ARGS__>), grid, block, 0, st, a); } while (0)
+#define KM_FWD2(NL, A) do { if (g_km_split && !a.abl) { if (pieces == 2) KM_FWD3(kernel_mlp_fwd_split_kernel, NL, A, 2); \
+                                                        else KM_FWD3(kernel_mlp_fwd_split_kernel, NL, A, 3); } \
+                            else KM_FWD3(kernel_mlp_fwd_kernel, NL, A); } while (0)
 #define KM_FWD(NL) do { if (act == GAOT_ACT_RELU) KM_FWD2(NL, GAOT_ACT_RELU); else KM_FWD2(NL, GAOT_ACT_GELU); } while (0)
     if (n_layers == 2) KM_FWD(1); else if (n_layers == 3) KM_FWD(2); else KM_FWD(3);
 #undef KM_FWD
@@ -774,17 +1040,18 @@ extern "C" int64_t gaot_kernel_mlp_bwd_workspace(int32_t E, int32_t cin, int32_t
 }
 
 extern "C" int gaot_kernel_mlp_bwd_w(const float* x, int32_t E, int32_t cin, int32_t n_layers, const float* const* w,
-                                     const float* const* b, int32_t act, const int32_t* widths, const int32_t* ldw, const float* dk, float* grads,
-                                     float* workspace, gaot_stream_t stream);
+                                     const float* const* b, int32_t act, const int32_t* widths, const int32_t* ldw, int32_t pieces, const float* dk,
+                                     float* grads, float* workspace, gaot_stream_t stream);
 extern "C" int gaot_kernel_mlp_bwd(const float* x, int32_t E, int32_t cin, int32_t n_layers, const float* const* w,
                                    const float* const* b, int32_t act, const float* dk, float* grads, float* workspace,
                                    gaot_stream_t stream) {
-    return gaot_kernel_mlp_bwd_w(x, E, cin, n_layers, w, b, act, KM_W64, nullptr, dk, grads, workspace, stream);
+    return gaot_kernel_mlp_bwd_w(x, E, cin, n_layers, w, b, act, KM_W64, nullptr, 0, dk, grads, workspace, stream);
 }
 
 extern "C" int gaot_kernel_mlp_bwd_w(const float* x, int32_t E, int32_t cin, int32_t n_layers, const float* const* w,
-                                     const float* const* b, int32_t act, const int32_t* widths, const int32_t* ldw, const float* dk, float* grads,
-                                     float* workspace, gaot_stream_t stream) {
+                                     const float* const* b, int32_t act, const int32_t* widths, const int32_t* ldw, int32_t pieces, const float* dk,
+                                     float* grads, float* workspace, gaot_stream_t stream) {
+    GAOT_REQUIRE(pieces == 0 || pieces == 2 || pieces == 3, "kernel_mlp: pieces must be 0 / 3 (exact) or 2 (two rounded pieces), got %d", pieces);
     if (int rc = km_check(x, E, cin, n_layers, w, b)) return rc;
     if (int rc = km_widths_ok(widths, n_layers)) return rc;
     if (int rc = km_ldw_ok(ldw, widths, cin, n_layers)) return rc;
@@ -796,7 +1063,8 @@ extern "C" int gaot_kernel_mlp_bwd_w(const float* x, int32_t E, int32_t cin, int
 #define KM_BWD3(K, NL, A) do { if (cin == 4) hipLaunchKernelGGL((K<NL, 4, A>), dim3(grid), dim3(256), 0, st, a); \
                                else if (cin <= 8) hipLaunchKernelGGL((K<NL, 8, A>), dim3(grid), dim3(256), 0, st, a); \
                                else hipLaunchKernelGGL((K<NL, KM_MAXC, A>), dim3(grid), dim3(256), 0, st, a); } while (0)
-#define KM_BWD2(NL, A) do { if (g_km_split) KM_BWD3(kernel_mlp_bwd_split_kernel, NL, A); else KM_BWD3(kernel_mlp_bwd_kernel, NL, A); } while (0)
+#define KM_BWD2(NL, A) do { if (g_km_split && pieces == 2) KM_BWD3(kernel_mlp_bwd_split2_kernel, NL, A); \
+                            else if (g_km_split) KM_BWD3(kernel_mlp_bwd_split_kernel, NL, A); else KM_BWD3(kernel_mlp_bwd_kernel, NL, A); } while (0)
 #define KM_BWD(NL) do { if (act == GAOT_ACT_RELU) KM_BWD2(NL, GAOT_ACT_RELU); else KM_BWD2(NL, GAOT_ACT_GELU); } while (0)
     if (n_layers == 2) KM_BWD(1); else if (n_layers == 3) KM_BWD(2); else KM_BWD(3);
 #undef KM_BWD

@@ -89,7 +89,7 @@ def cut(t: torch.Tensor) -> torch.Tensor:
 # spare, and the step is 7 % faster (2.58 -> 2.39 ms).  set_gemm_pieces(3) / GAOT_GEMM_PIECES=3 restores exact products
 # (kernel-level tests pin both).
 # --------------------------------------------------------------------------------------------
-_PIECES = {"nt": 2, "nn": 2, "tn": 2}
+_PIECES = {"nt": 2, "nn": 2, "tn": 2}          # the fused row-wise MLP kernels (kernel_mlp.hip) follow "nt"
 
 
 def set_gemm_pieces(nt: Optional[int] = None, nn: Optional[int] = None, tn: Optional[int] = None) -> dict:
@@ -877,6 +877,13 @@ class _KernelMLP(torch.autograd.Function):
         return arr
 
     @staticmethod
+    def _pieces(act) -> int:
+        """two rounded pieces per operand (the "nt" setting) behind a smooth activation; EXACT products behind ReLU: a ReLU chain's
+        gradient is discontinuous in its pre-activations -- at 5e-6 of relative error a few of 10^6 gates flip and the first layers'
+        gradients move by 2e-3 (measured, tools/kmlp_ab.py), where the exact products move them by 3e-7"""
+        return _PIECES["nt"] if act == L.ACT_GELU else 3
+
+    @staticmethod
     def forward(ctx, x, n, act, *wb):
         x = x.contiguous()
         # a weight that is a column block of a wider matrix (the geoembed half of the recovery weight: split_cols) is read in
@@ -889,7 +896,7 @@ class _KernelMLP(torch.autograd.Function):
         widths = (C.c_int32 * n)(*[int(w.shape[0]) for w in ws])
         ldw = (C.c_int32 * n)(*[int(w.stride(0)) if w.shape[0] > 1 else 0 for w in ws])
         out = torch.empty(E, ws[-1].shape[0], device=x.device, dtype=torch.float32)
-        L.check(L.load().gaot_kernel_mlp_fwd_w(_p(x), E, cin, n, _KernelMLP._ptrs(ws), _KernelMLP._ptrs(bs), act, widths, ldw, _p(out), _stream()),
+        L.check(L.load().gaot_kernel_mlp_fwd_w(_p(x), E, cin, n, _KernelMLP._ptrs(ws), _KernelMLP._ptrs(bs), act, widths, ldw, _KernelMLP._pieces(act), _p(out), _stream()),
                 "gaot_kernel_mlp_fwd")
         ctx.save_for_backward(x, *ws, *bs)
         ctx.n, ctx.act = n, act
@@ -917,7 +924,7 @@ class _KernelMLP(torch.autograd.Function):
             # every parameter has its slice and every layer is 64 wide (the blocks of the partial rows ARE the parameters' layouts):
             # the per-workgroup partial rows are summed per parameter, straight into the slices, by the grouped column-sum launch
             # at the end of the backward pass -- no row sum here, no packed gradient buffer, no copy into the flat buffer later
-            L.check(lib.gaot_kernel_mlp_bwd_w(_p(x), E, cin, n, _KernelMLP._ptrs(ws), _KernelMLP._ptrs(bs), ctx.act, widths, ldw, _p(dk), _p(wsp),
+            L.check(lib.gaot_kernel_mlp_bwd_w(_p(x), E, cin, n, _KernelMLP._ptrs(ws), _KernelMLP._ptrs(bs), ctx.act, widths, ldw, _KernelMLP._pieces(ctx.act), _p(dk), _p(wsp),
                                               _p(wsp), _stream()), "gaot_kernel_mlp_bwd")
             rows = int(lib.gaot_kernel_mlp_bwd_rows(E))
             part = wsp[:rows * psize].view(rows, psize)
@@ -928,7 +935,7 @@ class _KernelMLP(torch.autograd.Function):
                 outs.append(colsum(part[:, off:off + width], out=dst if (dst.dim() == 2 and not dst.is_contiguous()) else dst.view(-1),
                                    final=True).view(slot.shape))
             return (None, None, None, *outs)
-        L.check(lib.gaot_kernel_mlp_bwd_w(_p(x), E, cin, n, _KernelMLP._ptrs(ws), _KernelMLP._ptrs(bs), ctx.act, widths, ldw, _p(dk), _p(grads),
+        L.check(lib.gaot_kernel_mlp_bwd_w(_p(x), E, cin, n, _KernelMLP._ptrs(ws), _KernelMLP._ptrs(bs), ctx.act, widths, ldw, _KernelMLP._pieces(ctx.act), _p(dk), _p(grads),
                                           _p(wsp), _stream()), "gaot_kernel_mlp_bwd")
         # 64 x 64 blocks (64 x cin for the first layer) whose leading [out, in] corner is the gradient; the padding carries zeros
         dws = [grads[o:o + 64 * cin].view(64, cin)[:wo[0]]]

@@ -318,12 +318,14 @@ int gaot_kernel_mlp_bwd(const float* x, int32_t E, int32_t c_in, int32_t n_layer
  * runs zero-padded at width 64; the gradient vector keeps its layout of 64 x 64 blocks, of which the leading
  * widths[i] x widths[i-1] corner is meaningful (the rest is zero).
  * ldw (optional, NULL = dense): ldw[i] = row stride of weight i in floats (0 = dense; a column block of a wider matrix -- the
- * geoembed half of the recovery weight, magno.py:345-350 -- is read in place). */
+ * geoembed half of the recovery weight, magno.py:345-350 -- is read in place).
+ * pieces: precision of the 64-wide layers' products, as gaot_gemm_desc.pieces (0 / 3 = exact three-piece products, with the weight
+ * gradient on the fp32 MFMA; 2 = two rounded pieces per operand everywhere, the weight gradient on the bf16 pipe as well). */
 int gaot_kernel_mlp_fwd_w(const float* x, int32_t E, int32_t cin, int32_t n_layers, const float* const* w, const float* const* b,
-                          int32_t act, const int32_t* widths, const int32_t* ldw, float* out, gaot_stream_t stream);
+                          int32_t act, const int32_t* widths, const int32_t* ldw, int32_t pieces, float* out, gaot_stream_t stream);
 int gaot_kernel_mlp_bwd_w(const float* x, int32_t E, int32_t cin, int32_t n_layers, const float* const* w, const float* const* b,
-                          int32_t act, const int32_t* widths, const int32_t* ldw, const float* dk, float* grads, float* workspace,
-                          gaot_stream_t stream);
+                          int32_t act, const int32_t* widths, const int32_t* ldw, int32_t pieces, const float* dk, float* grads,
+                          float* workspace, gaot_stream_t stream);
 /* nn.MSELoss() with mean reduction (the reference trainers' loss, base_trainer.py:71): loss[0] = mean((pred - target)^2) over
  * n elements through `partial` (>= 256 floats; fixed-order two-stage sum, deterministic); backward
  * dpred = 2 (pred - target) / n * grad_loss[0] with grad_loss a DEVICE scalar (so the launch replays inside a hipGraph). */

@@ -27,7 +27,7 @@ def _exact_gemm_products_in_kernel_level_tests(request):
     """tests/test_ops_gpu.py pins the kernels against float64 math at fp32-rounding bars: it runs the tile GEMMs with exact
     three-piece products (ops.set_gemm_pieces(3)) and the head_dim-32 attention with exact three-way splits.  The shipped default --
     two rounded pieces per operand -- is what every model-level file (test_model_gpu, test_configs_gpu, test_ddp_gpu, ...) runs, and
-    test_gemm_two_piece_products / test_attention_two_piece_default pin its own bars."""
+    test_gemm_two_piece_products / test_attention_two_piece_default / test_kernel_mlp_two_piece_default pin its own bars."""
     if request.node.fspath.basename != "test_ops_gpu.py" or "two_piece" in request.node.name:
         yield
         return

@@ -717,6 +717,48 @@ def test_attention_two_piece_default():
     eo, eg = run(base + 1e-3 * torch.randn(1, 2048, 3 * H * D, generator=g), torch.randn(1, 2048, H * D, generator=g), H, D)
     assert eo < 1e-5 and eg < 5e-5, (eo, eg)
 
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("E,cin,n", [(55592, 4, 4), (5000, 6, 3), (400000, 4, 4)])
+def test_kernel_mlp_two_piece_default(E, cin, n):
+    """the shipped kernel MLP behind GELU: two rounded bf16 pieces per operand in the forward chain, the recompute, the
+    input-gradient chain and (through bf16 planes in LDS) the weight gradient.  Random data: output within 1e-5, every parameter
+    gradient within 1.5e-5 of float64 (measured 5.6e-6 / 7.6e-6 .. 9.8e-6 at 4e5 edges).  Behind ReLU the products stay EXACT
+    (gates): same bars as the three-piece test."""
+    from gaot_amd import ops
+    assert ops._PIECES["nt"] == 2
+    torch.manual_seed(E + n)
+    d = "cuda"
+    x = torch.rand(E, cin, device=d) * 2 - 1
+    dims = [cin] + [64] * n
+    for act, bar_out, bar_grad in (("gelu", 1e-5, 1.5e-5), ("relu", 2e-6, 2e-6)):
+        ws = [(torch.randn(dims[i + 1], dims[i], device=d) / dims[i] ** 0.5).requires_grad_() for i in range(n)]
+        bs = [(0.1 * torch.randn(64, device=d)).requires_grad_() for _ in range(n)]
+        acts = [act] * (n - 1) + ["none"]
+        dk = torch.randn(E, 64, device=d)
+        y = ops.mlp_chain(x, ws, bs, acts)
+        g = torch.autograd.grad(y, ws + bs, dk)
+        h = x.double()
+        wd = [w.detach().double().requires_grad_() for w in ws]
+        bd = [b.detach().double().requires_grad_() for b in bs]
+        for i in range(n):
+            h = h @ wd[i].t() + bd[i]
+            if i < n - 1:
+                h = torch.nn.functional.gelu(h) if act == "gelu" else torch.relu(h)
+        gd = torch.autograd.grad(h, wd + bd, dk.double())
+        errs = [rel(a, b) for a, b in zip(g, gd)]
+        if act == "gelu":
+            assert rel(y, h) < bar_out and max(errs) < bar_grad, (act, rel(y, h), errs)
+            assert rel(y, h) > 1e-6          # the two-piece kernels did run
+        else:                                # exact products whatever the setting: bit-identical to the three-piece mode
+            old = ops.set_gemm_pieces(3)
+            try:
+                y3 = ops.mlp_chain(x, ws, bs, acts)
+                g3 = torch.autograd.grad(y3, ws + bs, dk)
+            finally:
+                ops.set_gemm_pieces(**old)
+            assert rel(y, h) < bar_out and torch.equal(y, y3) and all(torch.equal(a, b) for a, b in zip(g, g3))
+
 @pytest.mark.gpu
 def test_branch_free_erf_accuracy():
     """common.h erf_nb (single-range 1 - 2^(-|x| Q(|x|)), no branch) behind every GELU of the path: absolute error of

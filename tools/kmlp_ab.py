@@ -29,8 +29,8 @@ for E, cin, n, act in [(55592, 4, 4, "gelu"), (55592, 7, 3, "relu"), (400000, 4,
         h = h @ wd[i].t() + bd[i]
         if i < n - 1: h = torch.nn.functional.gelu(h) if act == "gelu" else torch.relu(h)
     gd = torch.autograd.grad(h, wd + bd, dk.double())
-    for split in (0, 1):
-        lib.gaot_debug_set_kernel_mlp_split(split)
+    for split in (0, 1, 2):
+        lib.gaot_debug_set_kernel_mlp_split(1 if split else 0); ops.set_gemm_pieces(2 if split == 2 else 3)
         def fwd():
             with torch.no_grad(): return ops.mlp_chain(x, ws, bs, acts)
         y = ops.mlp_chain(x, ws, bs, acts)
