@@ -455,13 +455,17 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
                           (k_per_wg <= 1024 || pieces == 1 || g_use_split != 1);      // forced tuning modes bypass the cap
     // measured (tools/gemm_split_test.py): the 128x128 split-bf16 tiles win once they fill the chip (>= 256 workgroups
     // counting split-K slabs) on outputs at least one tile wide; narrower / smaller products stay on the fp32 MFMA tiles
-    const bool split128 = split_ok && g_use_split != 4 &&
+    // two-piece products, outputs at most six 128-wide tiles across (N <= 768): the 64-row tiles win although the 128-row ones would
+    // fill the chip (8192 x 768 x 256 NT: 21.7 vs 24.2 us, NN x 512 x 256: 18.6 vs 19.5; N >= 1 024: the other way round)
+    const bool prefer64 = split_ok && g_use_split == 1 && pieces == 2 && ak && cdiv(a.N, 128) <= 6 && blocks(64, 128) >= 250 && a.M >= 64 &&
+                          a.N >= 128 && a.split_k <= 1;
+    const bool split128 = split_ok && g_use_split != 4 && !prefer64 &&
                           (g_use_split == 2 || (blocks(128, 128) >= 250 && a.M >= 128 && a.N >= 128 && (long)cdiv(a.M, 128) * cdiv(a.N, 128) >= 8));
     // outputs only a few 128-wide tiles across (N = 256): 64-row tiles double the workgroup count
     // (with pre-split B planes an NN product stages B exactly like an NT one; with two-piece products the 64-row split tiles beat the
     // fp32-MFMA tiles on the NN products too: 8192 x 256 x 768 37.4 -> 25.6 us, x 512 26.5 -> 19.0, x 256 15.5 -> 12.8, tools/gemm_modes_2p.py)
     const bool split64 = split_ok && !split128 && g_use_split != 5 && g_use_split != 2 &&
-                         (g_use_split == 4 || ((ak && (bk || planes_ok || g_use_split == 6 || pieces == 2)) && blocks(64, 128) >= 250 && a.M >= 64 && a.N >= 128 && a.split_k <= 1));   // measured: NT +6-14 %, NN +-0
+                         (g_use_split == 4 || prefer64 || ((ak && (bk || planes_ok || g_use_split == 6 || pieces == 2)) && blocks(64, 128) >= 250 && a.M >= 64 && a.N >= 128 && a.split_k <= 1));   // measured: NT +6-14 %, NN +-0
     if (split128 || split64) {
         g_last_path = 3;
         if (planes_ok) { a.Bpl = reinterpret_cast<const unsigned short*>(d->b_planes); a.ld_bpl = d->ld_bplanes; a.bpl_stride = d->b_plane_stride; }

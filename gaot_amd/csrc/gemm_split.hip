@@ -49,11 +49,15 @@ __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
 // NP = 3: the fp32-level product (three pieces per operand, six piece products).  NP = 1: a plain bf16 GEMM on the same skeleton
 // (operands ROUNDED to nearest-even bf16, one piece product, fp32 accumulation) -- the separately reported `--dtype bf16` bench
 // variant (BASELINE configs[1] names bf16); never used by the fp32 parity path.
-template <int BM>
+#ifndef GAOT_SPLIT2_WG_PER_CU
+#define GAOT_SPLIT2_WG_PER_CU 3        // two-piece tiles: workgroups per CU the kernels are compiled for (A/B builds: 2)
+#endif
+template <int BM, int NP = 3>
 struct SplitGeom {
+    static constexpr int NPL = NP == 2 ? 2 : 3;            // planes per operand in a stage (two-piece tiles: 48 KB, three workgroups per CU)
     static constexpr int BN = S_BN, NW = BM == 256 ? 8 : 4, NT = 64 * NW, WAVES_N = 2, WM = BM / (NW / 2), WN = 64, TM = WM / 32, TN = 2;
     static constexpr int PA = (BM > 128 ? BM : 128) * 48, PB = 128 * 48;      // bytes per plane
-    static constexpr int STAGE = 3 * PA + 3 * PB;
+    static constexpr int STAGE = NPL * PA + NPL * PB;
     static constexpr int EPI_BYTES = NW * 32 * (WN + 4) * 4;
     static constexpr int SMEM_BYTES = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
 };
@@ -70,7 +74,8 @@ struct SplitGeom {
 struct BRegs { f32x4 f[2]; u32x4 pl[3]; };
 template <bool AK, bool BKM, int BM, int ABL, int NP, int FLUSH = 0, bool BPL = false>
 __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* smem_raw, const int logical, const int zs) {
-    using G = SplitGeom<BM>;
+    using G = SplitGeom<BM, NP>;
+    constexpr int NPL = G::NPL;
     constexpr int BN = G::BN, NW = G::NW, NT = G::NT, WAVES_N = G::WAVES_N, WM = G::WM, WN = G::WN, TM = G::TM, TN = G::TN;
     constexpr int ABYTES = BM * 4;       // row stride of a row-contiguous A plane ([k pair][BM rows] of packed dwords; BM = 64 only)
     constexpr int PA = G::PA, PB = G::PB, STAGE = G::STAGE;
@@ -212,7 +217,7 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
         unsigned char* sa = smem_raw + stage * STAGE;
         stage_store(sa, xa, AK, A_FULL, PA, 128, BM == 64);
         if (BPL) {
-            unsigned char* sb = sa + 3 * PA;
+            unsigned char* sb = sa + NPL * PA;
             if (B_FULL) {
                 unsigned char* dst = sb + (tid >> 1) * 48 + (tid & 1) * 16;
 #pragma unroll
@@ -223,7 +228,7 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
                 for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x2*>(dst + pl * PB) = u32x2{xb.pl[pl][0], xb.pl[pl][1]};
             }
         } else
-        stage_store(sa + 3 * PA, xb.f, BKM, B_FULL, PB, 256, false);
+        stage_store(sa + NPL * PA, xb.f, BKM, B_FULL, PB, 256, false);
         if (!AK) { const float w = (do_colsum && live && (A_FULL || tid < 128)) ? 1.f : 0.f; csum += (xa[0] + xa[1]) * w; }   // branch-free: keeps the k-loop one block
     };
 
@@ -249,7 +254,7 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
     auto step = [&](int kt, int stage, f32x4 (&xa)[2], BRegs& xb, f32x4 (&ya)[2], BRegs& yb) {
         gload(kt + 2, ya, yb);
         const unsigned char* sa = smem_raw + stage * STAGE;
-        const unsigned char* sb = sa + 3 * PA;
+        const unsigned char* sb = sa + NPL * PA;
         bf16x8 a[TM][3], b[TN][3];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -370,8 +375,8 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
 }
 
 template <bool AK, bool BKM, int BM = 128, int ABL = 0, int NP = 3, bool BPL = false>
-__global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 1 : 2) void gemm_split_kernel(const GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SplitGeom<BM>::SMEM_BYTES];
+__global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 1 : (NP == 2 ? GAOT_SPLIT2_WG_PER_CU : 2)) void gemm_split_kernel(const GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SplitGeom<BM, NP>::SMEM_BYTES];
     if ((ABL & 128) && (blockIdx.x & 8)) {      // tuning: de-phase half of the workgroups by ~p.ablate x 3.4 us at start
         for (int i = 0; i < p.ablate; ++i) __builtin_amdgcn_s_sleep(127);
     }
@@ -413,7 +418,7 @@ struct TnGroupArgs { int n; float* ws; int* counters; TnProb p[TNG_MAX]; };
 // load -> split -> plane write -> barrier -> fragment read -> MFMA chain is not overlapped across the two resident workgroups of a CU).
 template <int ABL = 0, int NP = 3>
 __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const TnGroupArgs g) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SplitGeom<128>::SMEM_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SplitGeom<128, NP>::SMEM_BYTES];
     // XCD-aware order (workgroup b runs on XCD b % 8): every XCD takes a CONTIGUOUS range of the logical work list, and inside
     // a product the list runs K slab by K slab, tile row by tile row -- so the workgroups an XCD's L2 serves at the same time
     // share the A panel of one (tile row, K slab) and walk the B panels of neighbouring tile columns
