@@ -120,6 +120,7 @@ PROTOTYPES = {
     "gaot_debug_set_attention_pipe": (C.c_int, [C.c_int]),
     "gaot_debug_set_attention_p_pieces": (C.c_int, [C.c_int]),
     "gaot_debug_set_attention_operand_pieces": (C.c_int, [C.c_int]),
+    "gaot_debug_set_attention_tr": (C.c_int, [C.c_int]),
     "gaot_kernel_mlp_fwd_w": (C.c_int, [_f, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_int32),
                                         C.POINTER(C.c_int32), C.c_int32, _f, _s]),
     "gaot_kernel_mlp_bwd_w": (C.c_int, [_f, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_int32),

@@ -1692,7 +1692,11 @@ constexpr int AB8_WAVE = 2 * 3 * AB_KPL;                                        
 constexpr int AB8_LDS = AB8_SHARED + 8 * AB8_WAVE;
 
 // PP = pieces of P and of dS = P (dP - delta) in the dV, dK and dQ products (3: exact split, 2: split2_pair, see the forward)
-template <int PP = 3, int OP = 3>
+// TR: the dO^T / Q^T operands of dV / dK and the dS operand of dQ come through TRANSPOSING LDS reads (common.h lds_tr) instead of
+// separately staged transposed planes: no second (transposed) copy of the Q / dO tile is loaded, split and written per q tile, and dS goes
+// to LDS as [kv][q] with 8-byte stores (a lane's four consecutive queries) instead of [q][kv] with 2-byte ones (8 stores per tile and
+// wave instead of 64)
+template <int PP = 3, int OP = 3, bool TR = false>
 __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs p) {
     constexpr int DP = 32, NW = 8;
     __shared__ __attribute__((aligned(16))) unsigned char smem[AB8_LDS];
@@ -1714,6 +1718,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
     unsigned char* Ktp = smem + AB8_SHARED + wave * AB8_WAVE;        // 3 planes [d][32 kv]
     unsigned char* dSp = Ktp + 3 * AB_KPL;                           // 3 planes [q][32 kv]
     float* Pmine = reinterpret_cast<float*>(dSp);                    // [32 q][32 d] fp32 after the dQ MFMAs
+    const int tr_off = lds_tr_lane_offset(lane, AB_KROW);
 
     bf16x8 kf[3][2], vf[3][2];
     const bool kv_ok = kv0 + li < p.S;
@@ -1776,7 +1781,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
             rk1 = *reinterpret_cast<const f32x4*>(sbase + (long)min(q0 + row, p.S - 1) * sld + d);
             if (q0 + row >= p.S) rk1 = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if (tthread) {
+        if (!TR && tthread) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int row = 2 * (t8 >> 3) + i, d = (tid & 7) * 4;
@@ -1806,7 +1811,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
             unsigned char* dk_ = (kind == 0 ? Qk : Gk) + row * AB_KROW + ch * 8;
             *reinterpret_cast<u32x2*>(dk_) = h2; *reinterpret_cast<u32x2*>(dk_ + AB_KPL) = m2;
             if (OP == 3) *reinterpret_cast<u32x2*>(dk_ + 2 * AB_KPL) = l2;
-            if (tthread) {
+            if (!TR && tthread) {
                 const int qp = t8 >> 3, d0 = ch * 4;
                 unsigned char* tb = (kind == 0 ? Qt : Gt) + qp * 4;
 #pragma unroll
@@ -1873,6 +1878,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
                 if (PP == 3) split3_pair(dp[8 * u + 2 * e], dp[8 * u + 2 * e + 1], a_, b_, c_);
                 else split2_pair(dp[8 * u + 2 * e], dp[8 * u + 2 * e + 1], a_, b_);
                 sh[e] = a_; sm[e] = b_; sl[e] = c_;
+                if (!TR) {
                 // dS pieces for the dQ product: rows q = crow(8u + 2e, hi) and q + 1, column kv = li, 2-byte stores
                 unsigned char* dst = dSp + crow(8 * u + 2 * e, lh) * AB_KROW + li * 2;
                 *reinterpret_cast<unsigned short*>(dst) = (unsigned short)(a_ & 0xffffu);
@@ -1883,6 +1889,19 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
                     *reinterpret_cast<unsigned short*>(dst + 2 * AB_KPL) = (unsigned short)(c_ & 0xffffu);
                     *reinterpret_cast<unsigned short*>(dst + 2 * AB_KPL + AB_KROW) = (unsigned short)(c_ >> 16);
                 }
+                }
+            }
+            if (TR) {
+                // dS^T pieces [kv = li][q]: registers 8u .. 8u + 3 are queries 16u + 4hi + 0..3, 8u + 4 .. 8u + 7 the same, eight up
+                unsigned char* dst = dSp + li * AB_KROW + (16 * u + 4 * lh) * 2;
+                *reinterpret_cast<u32x2*>(dst) = u32x2{sh[0], sh[1]};
+                *reinterpret_cast<u32x2*>(dst + 16) = u32x2{sh[2], sh[3]};
+                *reinterpret_cast<u32x2*>(dst + AB_KPL) = u32x2{sm[0], sm[1]};
+                *reinterpret_cast<u32x2*>(dst + AB_KPL + 16) = u32x2{sm[2], sm[3]};
+                if (PP == 3) {
+                    *reinterpret_cast<u32x2*>(dst + 2 * AB_KPL) = u32x2{sl[0], sl[1]};
+                    *reinterpret_cast<u32x2*>(dst + 2 * AB_KPL + 16) = u32x2{sl[2], sl[3]};
+                }
             }
             const bf16x8 p0 = __builtin_bit_cast(bf16x8, ph), p1 = __builtin_bit_cast(bf16x8, pm), p2 = __builtin_bit_cast(bf16x8, pl);
             const bf16x8 d0 = __builtin_bit_cast(bf16x8, sh), d1 = __builtin_bit_cast(bf16x8, sm), d2 = __builtin_bit_cast(bf16x8, sl);
@@ -1891,10 +1910,15 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
             bf16x8 ga[3], qa[3];
 #pragma unroll
             for (int pl_ = 0; pl_ < OP; ++pl_) {
+                if (TR) {         // dO^T / Q^T fragments straight from the k-major planes [q][d]: column d = li, rows q = 16u + 4hi + 0..3 and + 8
+                    ga[pl_] = __builtin_bit_cast(bf16x8, join8(lds_tr(Gk + pl_ * AB_KPL + (16 * u) * AB_KROW + tr_off), lds_tr(Gk + pl_ * AB_KPL + (16 * u + 8) * AB_KROW + tr_off)));
+                    qa[pl_] = __builtin_bit_cast(bf16x8, join8(lds_tr(Qk + pl_ * AB_KPL + (16 * u) * AB_KROW + tr_off), lds_tr(Qk + pl_ * AB_KPL + (16 * u + 8) * AB_KROW + tr_off)));
+                } else {
                 const u32x2 g_lo = *reinterpret_cast<const u32x2*>(gr + pl_ * AB_TPL), g_hi = *reinterpret_cast<const u32x2*>(gr + pl_ * AB_TPL + 16);
                 const u32x2 q_lo = *reinterpret_cast<const u32x2*>(qr + pl_ * AB_TPL), q_hi = *reinterpret_cast<const u32x2*>(qr + pl_ * AB_TPL + 16);
                 ga[pl_] = __builtin_bit_cast(bf16x8, u32x4{g_lo[0], g_lo[1], g_hi[0], g_hi[1]});
                 qa[pl_] = __builtin_bit_cast(bf16x8, u32x4{q_lo[0], q_lo[1], q_hi[0], q_hi[1]});
+                }
             }
             if (OP == 3) {
                 dvt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[2], p0, dvt, 0, 0, 0);
@@ -1927,10 +1951,18 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int pl_ = 0; pl_ < 3; ++pl_) {
+                if (TR) {         // k-slot e = key 16u + 8 (e >> 2) + 4 hi + (e & 3) in both operands
+                    if (pl_ < PP) da[u][pl_] = __builtin_bit_cast(bf16x8, join8(lds_tr(dSp + pl_ * AB_KPL + (16 * u) * AB_KROW + tr_off), lds_tr(dSp + pl_ * AB_KPL + (16 * u + 8) * AB_KROW + tr_off)));
+                    else da[u][pl_] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    const unsigned char* kr = Ktp + pl_ * AB_KPL + li * AB_KROW + (16 * u + 4 * lh) * 2;
+                    if (pl_ < OP) kb[u][pl_] = __builtin_bit_cast(bf16x8, join8(*reinterpret_cast<const u32x2*>(kr), *reinterpret_cast<const u32x2*>(kr + 16)));
+                    else kb[u][pl_] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                } else {
                 if (pl_ < PP) da[u][pl_] = *reinterpret_cast<const bf16x8*>(dSp + pl_ * AB_KPL + li * AB_KROW + u * 32 + lh * 16);
                 else da[u][pl_] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
                 if (pl_ < OP) kb[u][pl_] = *reinterpret_cast<const bf16x8*>(Ktp + pl_ * AB_KPL + li * AB_KROW + u * 32 + lh * 16);
                 else kb[u][pl_] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                }
             }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -2022,6 +2054,8 @@ extern "C" int gaot_debug_set_attention_p_pieces(int n) {
 // products per k-step in every product of the kernel (forward 11 -> 6 MFMAs per k-step pair, backward 27 -> 15); 3 = exact three-way splits
 static int g_attn_op = 2;
 extern "C" int gaot_debug_set_attention_operand_pieces(int n) { const int old = g_attn_op; g_attn_op = n == 3 ? 3 : 2; return old; }
+static int g_attn_tr = 1;        // 1 (default): the two-piece 8-wave backward takes its transposed operands through transposing LDS reads
+extern "C" int gaot_debug_set_attention_tr(int on) { const int old = g_attn_tr; g_attn_tr = on ? 1 : 0; return old; }
 static int g_attn_pipe = 0;      // 1 = the software-pipelined 8-wave forward for S % 64 == 0 (same speed as the plain one since both keep the
                                  // tile product off the running accumulator: 57.6 vs 58.0 us; kept for tools/attn_ablate.hip and as a tested variant)
 extern "C" int gaot_debug_set_attention_pipe(int on) { const int old = g_attn_pipe; g_attn_pipe = on; return old; }
@@ -2182,6 +2216,7 @@ extern "C" int gaot_attention_bwd(const float* q, const float* k, const float* v
         a.n_kblocks = cdiv(S, 256);          // 256 keys per workgroup: half the dQ slabs (the workspace is sized for 128)
         if (g_attn_pp % 10 == 3) hipLaunchKernelGGL(attn_bwd_split8_kernel<3>, dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a);
         else if (g_attn_op == 3) hipLaunchKernelGGL(attn_bwd_split8_kernel<2>, dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a);
+        else if (g_attn_tr) hipLaunchKernelGGL((attn_bwd_split8_kernel<2, 2, true>), dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a);
         else hipLaunchKernelGGL((attn_bwd_split8_kernel<2, 2>), dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a);
     } else if (split_ok) {
         hipLaunchKernelGGL(attn_bwd_split_kernel, grid, block, 0, ST(stream), a);

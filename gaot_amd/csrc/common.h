@@ -103,6 +103,23 @@ __device__ __forceinline__ void split2_pair(float x0, float x1, unsigned& ph, un
     pm = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
 }
 
+// transposing LDS read (gfx950 ds_read_b64_tr_b16): within each 16-lane group, lane t supplies the address of 4 consecutive 16-bit
+// COLUMNS of one row and receives 4 consecutive ROWS of one column: with lane t addressing row rbase + (t >> 2), columns
+// cbase + 4 (t & 3) .. + 3 it gets rows rbase .. rbase + 3 of column cbase + t (tools/probe/tr_read.hip prints the map).  Two of them
+// give an MFMA A / B fragment (8 k-slots) of a matrix stored with k as its ROW index.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ u32x2 lds_tr(const unsigned char* p) {
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p)));
+}
+__device__ __forceinline__ u32x4 join8(u32x2 lo, u32x2 hi) { return u32x4{lo[0], lo[1], hi[0], hi[1]}; }
+// byte offset of a lane inside a [16 rows][32 columns] bf16 block read as an MFMA fragment by two lds_tr (rows + 0 and + 8): lane
+// (li = lane & 31, hi = lane >> 5) receives column li, rows 4 hi .. + 3
+__device__ __forceinline__ int lds_tr_lane_offset(int lane, int row_bytes) {
+    return (4 * (lane >> 5) + ((lane & 15) >> 2)) * row_bytes + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -376,13 +376,6 @@ __global__ __launch_bounds__(256, 1) void kernel_mlp_bwd_kernel(const KMArgs p) 
 // planes (two ROUNDED pieces per operand did fit, were 12 % faster and cost 7.6e-6 of relative error on every dW: not taken).
 constexpr int KS_LDB = 136;                   // bytes per row of a 64-column bf16 plane (+8: conflict-free 8-byte row reads and edge-row stores)
 constexpr int KS_PLANE = 64 * KS_LDB;         // one weight plane
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-
-__device__ __forceinline__ u32x2 lds_tr(const unsigned char* p) {
-    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p)));
-}
-__device__ __forceinline__ u32x4 join8(u32x2 lo, u32x2 hi) { return u32x4{lo[0], lo[1], hi[0], hi[1]}; }
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }

@@ -46,6 +46,9 @@ int gaot_debug_set_attention_p_pieces(int n);
 /* head_dim-32 split attention: pieces of the Q / K / V / dO operands: 2 (default) = two rounded pieces (with two-piece P / dS: three
  * piece products everywhere), 3 = exact three-way splits.  Returns the previous value. */
 int gaot_debug_set_attention_operand_pieces(int n);
+/* A/B hook: 1 (default) = the two-piece head_dim-32 backward reads dO^T / Q^T / dS through transposing LDS reads, 0 = separately staged
+ * transposed planes.  Same results.  Returns the previous value. */
+int gaot_debug_set_attention_tr(int on);
 /* tuning hook: 1 = the software-pipelined 8-wave split forward where it applies (S % 64 == 0), 0 (default) = the plain one.
  * Returns the previous value. */
 int gaot_debug_set_attention_pipe(int on);

@@ -711,6 +711,8 @@ def test_attention_two_piece_default():
     B, S, H, D = 8, 1024, 8, 32                           # the bench shape
     eo, eg = run(torch.randn(B, S, 3 * H * D, generator=g), torch.randn(B, S, H * D, generator=g), H, D)
     assert 1e-6 < eo < 1e-5 and 1e-6 < eg < 1.5e-5, (eo, eg)
+    eo, eg = run(torch.randn(1, 512, 3 * 4 * 48, generator=g), torch.randn(1, 512, 4 * 48, generator=g), 4, 48)      # head_dim 48: the DH = 64 kernels
+    assert 1e-6 < eo < 1e-5 and 1e-6 < eg < 1.5e-5, (eo, eg)
     base = (torch.randn(1, 1, 3 * H * D, generator=g) * 0.6).repeat(1, 2048, 1)
     idx = torch.randperm(2048, generator=g)[:200]
     base[0, idx] = torch.randn(200, 3 * H * D, generator=g) * 0.6
@@ -719,7 +721,7 @@ def test_attention_two_piece_default():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("E,cin,n", [(55592, 4, 4), (5000, 6, 3), (400000, 4, 4)])
+@pytest.mark.parametrize("E,cin,n", [(55592, 4, 4), (5000, 6, 3), (400000, 4, 4), (600000, 4, 3)])      # 6e5 edges: more than 16 tiles per workgroup (accumulator flush)
 def test_kernel_mlp_two_piece_default(E, cin, n):
     """the shipped kernel MLP behind GELU: two rounded bf16 pieces per operand in the forward chain, the recompute, the
     input-gradient chain and (through bf16 planes in LDS) the weight gradient.  Random data: output within 1e-5, every parameter
