@@ -1399,15 +1399,20 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_split_dh_kernel(const AttnArg
     constexpr int NTI = 16 * CPR / 256 * 2;                        // transposed items per thread: (Q, dO) x ... (see below)
     static_assert(DH == 64, "attn_bwd_split_dh_kernel: DH = 64");
     constexpr int SWF = 32 * DH > 32 * 33 ? 32 * DH : 32 * 33;     // floats per wave of the dS^T staging / dQ partial tile
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 3 * KPL + 2 * 3 * TPL + 64 * 4 + 4 * 32 * DH * 4 + 4 * SWF * 4];
+    // two-piece mode: the dQ product runs on the bf16 pipe too -- the wave's K rows as two bf16 planes [32 kv][DH] (row stride KPROW) in
+    // place of the fp32 tile, dS^T as two planes [kv][32 q] in the staging region, both read through transposing LDS reads
+    constexpr bool DQ16 = PP == 2 && OP == 2;
+    constexpr int KPROW = DH * 2 + 16, KPPL = 32 * KPROW;
+    constexpr int KWB = DQ16 ? (2 * KPPL > 32 * DH * 4 ? 2 * KPPL : 32 * DH * 4) : 32 * DH * 4;      // bytes per wave
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 3 * KPL + 2 * 3 * TPL + 64 * 4 + 4 * KWB + 4 * SWF * 4];
     unsigned char* Qk = smem;
     unsigned char* Gk = Qk + 3 * KPL;
     unsigned char* Qt = Gk + 3 * KPL;
     unsigned char* Gt = Qt + 3 * TPL;
     float* lse_s = reinterpret_cast<float*>(Gt + 3 * TPL);
     float* del_s = lse_s + 32;
-    float* Kw = del_s + 32;                         // per wave fp32 K tile [32][DH] (dQ product)
-    float* Sw = Kw + 4 * 32 * DH;                   // per wave dS^T staging [32][33]; reused as the wave's dQ partial [32][DH]
+    float* Kw = del_s + 32;                         // per wave fp32 K tile [32][DH] (dQ product), or its two bf16 planes
+    float* Sw = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(Kw) + 4 * KWB);   // per wave dS^T staging; reused as the wave's dQ partial [32][DH]
     (void)NTI;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1419,7 +1424,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_split_dh_kernel(const AttnArg
     const int kv0 = kblk * 128 + wave * 32;
     const int D = p.D;
     const float c = p.scale * LOG2E;
-    float* Kmine = Kw + wave * 32 * DH;
+    float* Kmine = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(Kw) + wave * KWB);
+    unsigned char* Kpl = reinterpret_cast<unsigned char*>(Kmine);
     float* Smine = Sw + wave * SWF;
     float* Pmine = Smine;
 
@@ -1445,11 +1451,17 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_split_dh_kernel(const AttnArg
             kf[0][u] = __builtin_bit_cast(bf16x8, ph); kf[1][u] = __builtin_bit_cast(bf16x8, pm); kf[2][u] = __builtin_bit_cast(bf16x8, pl);
             vf[0][u] = __builtin_bit_cast(bf16x8, vh); vf[1][u] = __builtin_bit_cast(bf16x8, vm); vf[2][u] = __builtin_bit_cast(bf16x8, vl);
         }
-        // the wave's fp32 K tile, row-major, for the dQ product
+        // the wave's K tile, row-major, for the dQ product: fp32, or two rounded bf16 planes
         for (int t = lane; t < 32 * CPR; t += 64) {
             const int row = t / CPR, d = (t % CPR) * 4;
             const f32x4 a = load4(p.k + ((long)b * p.S + min(kv0 + row, p.S - 1)) * p.ldk + (long)hk * D, d, D, kv0 + row < p.S, true);
-            *reinterpret_cast<f32x4*>(Kmine + row * DH + d) = a;
+            if (DQ16) {
+                unsigned h0, m0, h1, m1;
+                split2_pair(a[0], a[1], h0, m0);
+                split2_pair(a[2], a[3], h1, m1);
+                *reinterpret_cast<u32x2*>(Kpl + row * KPROW + d * 2) = u32x2{h0, h1};
+                *reinterpret_cast<u32x2*>(Kpl + KPPL + row * KPROW + d * 2) = u32x2{m0, m1};
+            } else *reinterpret_cast<f32x4*>(Kmine + row * DH + d) = a;
         }
     }
     f32x16 dvacc[NDT], dkacc[NDT];
@@ -1625,17 +1637,55 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_split_dh_kernel(const AttnArg
         for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { dvacc[dt][r] += dvt[dt][r]; dkacc[dt][r] += dkt[dt][r]; }
-        // ---- dQ[q][d] partial = sum_kv dS[q][kv] K[kv][d] on the fp32 MFMA: dS through wave-private LDS to flip lanes
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Smine[crow(r, lh) * 33 + li] = dp[r];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- dQ[q][d] partial = sum_kv dS[q][kv] K[kv][d]: dS through wave-private LDS to flip lanes
         f32x16 dq[NDT];
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+        if (DQ16) {
+            // dS^T pieces [kv = li][q] (the pieces the dK product has just formed are gone: re-split, 8 pairs), 8-byte stores; both operands come
+            // back through transposing reads: k-slot e = key 16u + 8 (e >> 2) + 4 hi + (e & 3)
+            unsigned char* dSp = reinterpret_cast<unsigned char*>(Smine);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                unsigned h_[4], m_[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split2_pair(dp[8 * u + 2 * e], dp[8 * u + 2 * e + 1], h_[e], m_[e]);
+                unsigned char* dst = dSp + li * AB_KROW + (16 * u + 4 * lh) * 2;
+                *reinterpret_cast<u32x2*>(dst) = u32x2{h_[0], h_[1]};
+                *reinterpret_cast<u32x2*>(dst + 16) = u32x2{h_[2], h_[3]};
+                *reinterpret_cast<u32x2*>(dst + AB_KPL) = u32x2{m_[0], m_[1]};
+                *reinterpret_cast<u32x2*>(dst + AB_KPL + 16) = u32x2{m_[2], m_[3]};
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int tr_s = lds_tr_lane_offset(lane, AB_KROW), tr_k = lds_tr_lane_offset(lane, KPROW);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                bf16x8 da[2];
+#pragma unroll
+                for (int pl_ = 0; pl_ < 2; ++pl_)
+                    da[pl_] = __builtin_bit_cast(bf16x8, join8(lds_tr(dSp + pl_ * AB_KPL + (16 * u) * AB_KROW + tr_s), lds_tr(dSp + pl_ * AB_KPL + (16 * u + 8) * AB_KROW + tr_s)));
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) {
+                    bf16x8 kb[2];
+#pragma unroll
+                    for (int pl_ = 0; pl_ < 2; ++pl_)
+                        kb[pl_] = __builtin_bit_cast(bf16x8, join8(lds_tr(Kpl + pl_ * KPPL + (16 * u) * KPROW + 32 * dt * 2 + tr_k),
+                                                                   lds_tr(Kpl + pl_ * KPPL + (16 * u + 8) * KPROW + 32 * dt * 2 + tr_k)));
+                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[1], kb[0], dq[dt], 0, 0, 0);
+                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[0], kb[1], dq[dt], 0, 0, 0);
+                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[0], kb[0], dq[dt], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Smine[crow(r, lh) * 33 + li] = dp[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         float sa[16];
 #pragma unroll
         for (int t16 = 0; t16 < 16; ++t16) sa[t16] = Smine[li * 33 + t16 + 16 * lh];
@@ -1644,6 +1694,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_split_dh_kernel(const AttnArg
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt)
                 dq[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[t16], Kmine[(t16 + 16 * lh) * DH + 32 * dt + li], dq[dt], 0, 0, 0);
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();                     // every lane has read its dS row before the tile is overwritten
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
