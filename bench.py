@@ -492,8 +492,7 @@ def main():
     from gaot_amd import ops as _ops
     if args.dtype == "bf16":
         from gaot_amd import ops, _lib
-        ops.set_gemm_mode(5)                  # split-tile kernels wherever eligible ...
-        _lib.load().gaot_debug_set_gemm_pieces(1)      # ... with ONE bf16 piece per operand
+        _lib.load().gaot_debug_set_gemm_pieces(1)      # the tile kernels the heuristic picks, with ONE bf16 piece per operand
     torch.manual_seed(0)                      # identical weights on every rank (and broadcast from rank 0 anyway)
     model = build_model().to(dev).train()
     lat, x, p, t = synthetic(1234 + rank, dev)

@@ -429,7 +429,7 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
             const bool big = a.M >= 256 && (g_split_bm256 == 2 || (g_split_bm256 == 1 && nb128 >= 500));
             if (planes_ok) { a.Bpl = reinterpret_cast<const unsigned short*>(d->b_planes); a.ld_bpl = d->ld_bplanes; a.bpl_stride = d->b_plane_stride; }
             if (g_gsplit) launch_gsplit(a, ak, bk, st, 128, pieces);
-            else launch_split(a, ak, bk, st, big && pieces == 3 ? 256 : 128, pieces);
+            else launch_split(a, ak, bk, st, big && pieces != 1 ? 256 : 128, pieces);
         }
         else { g_last_path = 1; launch_glds(a, ak, bk, nb128 >= 512 ? 1 : ((long)cdiv(a.M, 128) * cdiv(a.N, 64) >= 512 ? 2 : 3), st); }
         GAOT_CHECK_LAUNCH("gaot_gemm_f32(swiglu)");
@@ -472,7 +472,7 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
         // 256x128 (8-wave) tiles: measured +3-7 % on the NT / TN products that still give ~200 workgroups, -2 % on NN
         const bool big = split128 && a.M >= 512 && (g_split_bm256 == 2 || (g_split_bm256 == 1 && ak == bk && blocks(256, 128) >= 190));
         if (g_gsplit) launch_gsplit(a, ak, bk, st, split64 ? 64 : 128, pieces);
-        else launch_split(a, ak, bk, st, split64 ? 64 : (big && pieces == 3 ? 256 : 128), pieces);
+        else launch_split(a, ak, bk, st, split64 ? 64 : (big && pieces != 1 ? 256 : 128), pieces);
     }
     else if (glds_ok && g_tile_override >= 0 && g_tile_override <= 3) {
         int tile = g_tile_override;

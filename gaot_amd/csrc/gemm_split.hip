@@ -557,7 +557,9 @@ void launch_split(GemmArgs& a, bool ak, bool bk, hipStream_t st, int bm, int pie
         return;
     }
     if (pieces == 2) {           // two rounded pieces per operand (three piece products)
-        if (bm == 64) launch_split_bm<64, 2>(a, ak, bk, st); else launch_split_bm<128, 2>(a, ak, bk, st);
+        if (bm == 64) launch_split_bm<64, 2>(a, ak, bk, st);
+        else if (bm == 256) launch_split_bm<256, 2>(a, ak, bk, st);
+        else launch_split_bm<128, 2>(a, ak, bk, st);
         return;
     }
     if (bm == 64)       launch_split_bm<64, 3>(a, ak, bk, st);
