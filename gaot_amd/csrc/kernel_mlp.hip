@@ -464,13 +464,14 @@ __global__ __launch_bounds__(256, 2) void kernel_mlp_fwd_split_kernel(const KMAr
     __shared__ float Bs[64 * (NL + 1)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, hi = lane >> 5;
-    km_stage_weights_split<NL, CM, NP>(p, Wp, W1s, Bs, tid);
-    __syncthreads();
+    // the edge coordinates are requested before the weights are staged: their latency hides behind the staging
     const int e0 = (blockIdx.x * 4 + wave) * 32;
-    if (e0 >= p.E) return;
     const int e = min(e0 + li, p.E - 1);
     float xr[CM];
     km_load_x<CM>(p, e, xr);
+    km_stage_weights_split<NL, CM, NP>(p, Wp, W1s, Bs, tid);
+    __syncthreads();
+    if (e0 >= p.E) return;
     f32x16 z[2], h[2];
     km_layer0<CM>(W1s, Bs, xr, p.cin, hi, z);
 #pragma unroll
@@ -730,6 +731,10 @@ __global__ __launch_bounds__(256, 1) void kernel_mlp_bwd_split2_kernel(const KMA
     const int io_w = wave >> 1, kt_w = wave & 1;
     const int cin = p.cin;
     const int tr_off = (4 * (lane >> 5) + ((lane & 15) >> 2)) * KS_LDB + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    // edge coordinates run one tile ahead (the first request goes out before the weights are staged): with one wave per SIMD nothing
+    // else hides the latency of the load the whole tile starts with
+    float xn[CM];
+    km_load_x<CM>(p, min((int)blockIdx.x * 128 + wave * 32 + li, p.E - 1), xn);
     km_stage_weights_split<NL, CM, 2>(p, Wp, W1s, Bs, tid);
     __syncthreads();
 
@@ -770,7 +775,9 @@ __global__ __launch_bounds__(256, 1) void kernel_mlp_bwd_split2_kernel(const KMA
         const bool valid = e0 + li < p.E;
         const int e = min(e0 + li, p.E - 1);
         float xr[CM];
-        km_load_x<CM>(p, e, xr);
+#pragma unroll
+        for (int c = 0; c < CM; ++c) xr[c] = xn[c];
+        if (tile + (int)gridDim.x < p.ntiles) km_load_x<CM>(p, min((tile + (int)gridDim.x) * 128 + wave * 32 + li, p.E - 1), xn);
         f32x16 g[2];
         {
             const float* src = p.dk + (long)e * p.cout;

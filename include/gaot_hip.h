@@ -89,7 +89,8 @@ int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream);
 /* Grouped weight-gradient products: ONE launch over n products  out_i[M_i,N_i] = g_i[K_i,M_i]^T x_i[K_i,N_i]  (+ colsum_i[m] =
  * sum_k g_i[k,m], the bias gradient), i.e. dW = dY^T X (and db) of every nn.Linear / Conv1d(k=1) whose backward has been
  * reached (mlp.py:283-305, attn.py:92-117,150-156,225-227, gaot.py:208: autograd runs them one by one, each a long reduction
- * over all tokens into a small matrix).  Products on the bf16 matrix pipe with `pieces` (0 / 3 or 2) as gaot_gemm_desc.pieces; K slabs of at most 1 024 rows are summed in slab order by the last workgroup to finish a tile (deterministic).
+ * over all tokens into a small matrix).  Products on the bf16 matrix pipe with `pieces` (0 / 3 or 2) as gaot_gemm_desc.pieces; K slabs (4 096 rows; the matrix pipe accumulates runs of 1 024, the running sums live in registers) are summed in slab order by
+ * the last workgroup to finish a tile (deterministic, no atomics on data).
  * Needs M, N % 4 == 0, K % 32 == 0, ld* % 4 == 0, 16-byte aligned pointers.  `workspace`: >= gaot_gemm_tn_grouped_workspace()
  * floats; `counters`: >= *n_counters int32, ZERO before the first call (every call leaves them zero again). */
 typedef struct gaot_wgrad_item {
