@@ -23,8 +23,8 @@ def timed(fn, n=40):
     return a.elapsed_time(b) / n * 1e3
 for rep in range(2):
     for pieces in (3, 2):
-        lib.gaot_debug_set_wgrad_pieces(pieces)
+        ops.set_gemm_pieces(pieces)
         grouped(); torch.cuda.synchronize()
         errs = [float((o.double() - r).norm() / r.norm()) for (_, _, o), r in zip(ops_in, ref)]
         print(f"pieces {pieces}: {timed(grouped):.1f} us   error vs float64: max {max(errs):.2e}  mean {sum(errs)/len(errs):.2e}", flush=True)
-lib.gaot_debug_set_wgrad_pieces(3)
+ops.set_gemm_pieces(2)
