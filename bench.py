@@ -560,7 +560,8 @@ def main():
         # exposed communication = the same K steps WITHOUT the gradient exchange (ranks drift apart: timing only, after the headline)
         # subtracted from the headline; plus every phase slice's all-reduce timed on its own (RCCL over xGMI, HIP events)
         slices = []
-        for k, (lo, hi) in enumerate(ts.bucket.segments):
+        for k, ks in enumerate(ts.stage_groups if ts.staged else [list(range(ts.bucket.n_phases))]):
+            lo, hi = ts.bucket.segments[ks[0]][0], ts.bucket.segments[ks[-1]][1]
             buf = ts.bucket.flat[lo:hi]
             for _ in range(3):
                 dist.all_reduce(buf, op=dist.ReduceOp.AVG if dist.get_backend() == "nccl" else dist.ReduceOp.SUM)
@@ -571,7 +572,7 @@ def main():
                 dist.all_reduce(buf, op=dist.ReduceOp.AVG if dist.get_backend() == "nccl" else dist.ReduceOp.SUM)
             b.record()
             torch.cuda.synchronize()
-            slices.append({"phase": k, "bytes": 4 * (hi - lo), "allreduce_us_alone": 1e3 * a.elapsed_time(b) / 10})
+            slices.append({"stage_group": k, "backward_phases": list(ks), "bytes": 4 * (hi - lo), "allreduce_us_alone": 1e3 * a.elapsed_time(b) / 10})
         ts.comm_enabled = False
         for _ in range(3):
             ts.step()
@@ -588,8 +589,9 @@ def main():
         comm = {"backend": dist.get_backend() + (" (RCCL over xGMI)" if dist.get_backend() == "nccl" else ""), "slices": slices,
                 "ms_per_step_without_exchange": 1e3 * no_comm / args.steps,
                 "exposed_ms_per_step": 1e3 * (elapsed - no_comm) / args.steps,
-                "what": "per backward phase one asynchronous all-reduce (ReduceOp.AVG) of that phase's slice of the flat gradient buffer, "
-                        "issued while the next phase's backward graph replays; exposed = headline step - the same step without the exchange"}
+                "what": "per stage group (a run of backward phases sharing one graph and one grouped weight-gradient launch) one asynchronous all-reduce "
+                        "(ReduceOp.AVG) of its slice of the flat gradient buffer, issued while the next group's backward graph replays; exposed = "
+                        "headline step - the same step without the exchange"}
 
     roof = gemm_roofline(ts)
     if rank == 0:
@@ -640,8 +642,8 @@ def main():
             "config": {"workload": "BASELINE configs[1]: Poisson-Gauss-shaped 2D, 16384 nodes/mesh, batch 8 per GPU, fx mode; "
                                    "example model latent 64x64, C=64, patch 2, transformer 256x3, 8 heads",
                        "params": n_params, "global_batch": BATCH * world, "parallelism": f"dp{world}",
-                       "step": "fwd + MSE + bwd + AdamW" + (" + staged flat-grad RCCL all-reduce (one async slice per backward phase)" if world > 1 else ""),
-                       "hipgraph": ts.use_graph, "staged_backward_phases": ts.bucket.n_phases, "final_loss": loss},
+                       "step": "fwd + MSE + bwd + AdamW" + (" + staged flat-grad RCCL all-reduce (one async slice per stage group)" if world > 1 else ""),
+                       "hipgraph": ts.use_graph, "staged_backward_phases": ts.bucket.n_phases, "stage_groups": ts.stage_groups, "final_loss": loss},
             "roofline": {"bound": "mfma", "kernel": "gaot_gemm_f32 MFMA tile kernels, every launch of one step: gemm_glds_kernel (v_mfma_f32_32x32x2_f32) and "
                                    "gemm_split_kernel / gemm_tn_grouped_kernel (f32 operands as 2 rounded bf16 pieces, 3 x v_mfma_f32_32x32x16_bf16 per product; "
                                    "3 exact pieces / 6 products with GAOT_GEMM_PIECES=3)",

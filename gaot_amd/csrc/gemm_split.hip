@@ -484,17 +484,31 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const TnGroupAr
     }
 }
 
-static int g_tn_kslab = 4096;
-void set_tn_kslab(int k) { g_tn_kslab = k < 256 ? 256 : (k / 32) * 32; }
+static int g_tn_kslab = 0;           // 0 = automatic (below); otherwise a fixed K slab (tuning hook)
+void set_tn_kslab(int k) { g_tn_kslab = k <= 0 ? 0 : (k < 256 ? 256 : (k / 32) * 32); }
 // host side of the grouped launch: items -> prefix table; returns the workspace floats / counters it needs when `args` is null
 long plan_tn_grouped(const gaot_wgrad_item* items, int n, TnGroupArgs* args, int* n_counters, int* n_wg) {
     long ws = 0; int cnt = 0, wg = 0;
+    // K slab per workgroup: the accumulators are flushed to the vector pipe every 1 024 values of k inside the kernel, so the slab
+    // length is a load-balance / slab-traffic choice.  A launch lasts as long as one workgroup's K loop, whatever the number of work
+    // items, until the items outnumber the workgroups the chip holds: so the slab count is what brings tiles x slabs to a bit more
+    // than one workgroup per CU (272).  Measured (tools/wgrad_kslab_sweep.py, K = 8 192): the 14-15 products of a whole backward pass
+    // (204 tiles): 314 / 340 / 387 us at slabs of 4 096 / 2 048 / 1 024 -> 2 slabs; the 4 products of ONE phase of a staged backward
+    // (68 tiles): 160 / 108 / 123 us -> 4 slabs.
+    long tiles_total = 0;
+    for (int i = 0; i < n; ++i) tiles_total += (long)cdiv(items[i].M, 128) * cdiv(items[i].N, 128);
+    const int want = (int)((272 + tiles_total - 1) / (tiles_total > 0 ? tiles_total : 1));
     for (int i = 0; i < n; ++i) {
         const gaot_wgrad_item& it = items[i];
         const int kt32 = it.K / 32;
-        // K slab per workgroup: the accumulators are flushed to the vector pipe every 1 024 values of k inside the kernel, so the
-        // slab length is a load-balance / slab-traffic choice (g_tn_kslab; measured on the 15 products of the bench step: 448 / 396 / 366 us at 1 024 / 2 048 / 4 096)
-        int split = (it.K + g_tn_kslab - 1) / g_tn_kslab;
+        int kslab = g_tn_kslab;
+        if (kslab == 0) {
+            int s_auto = want < 1 ? 1 : (want > 16 ? 16 : want);      // the last workgroup of a tile sums the slabs alone: keep them few
+            if (s_auto > it.K / 512) s_auto = it.K / 512 > 0 ? it.K / 512 : 1;      // slabs of at least 512
+            kslab = (it.K + s_auto - 1) / s_auto;
+            if (kslab > 4096) kslab = 4096;             // products with a much longer reduction than the rest (node-level layers: K = batch x nodes)
+        }
+        int split = (it.K + kslab - 1) / kslab;
         int per = (kt32 + split - 1) / split;
         split = (kt32 + per - 1) / per;
         const int tm = cdiv(it.M, 128), tn = cdiv(it.N, 128);

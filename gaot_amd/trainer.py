@@ -130,7 +130,12 @@ class FlatGradBucket:
         (`_force`: issue the collective even in a one-rank group -- tests of the RCCL branch on one-GPU boxes)"""
         if not (dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or _force)):
             return None
-        buf = self.flat if phase is None else self.flat[self.segments[phase][0]:self.segments[phase][1]]
+        if phase is None:
+            buf = self.flat
+        elif isinstance(phase, (tuple, list)):          # a run of consecutive phases: one slice (the layout is phase by phase)
+            buf = self.flat[self.segments[phase[0]][0]:self.segments[phase[-1]][1]]
+        else:
+            buf = self.flat[self.segments[phase][0]:self.segments[phase][1]]
         if buf.numel() == 0:
             return None
         if dist.get_backend(group) == "nccl":       # RCCL averages in the collective: no separate scaling pass
@@ -346,7 +351,7 @@ class TrainStep:
     """One reference-trainer step on fixed shapes.  `static` holds everything forward() needs except pndata."""
 
     def __init__(self, model: torch.nn.Module, lr: float = 8e-4, weight_decay: float = 1e-5, use_graph: bool = True,
-                 group=None, staged: Optional[bool] = None):
+                 group=None, staged: Optional[bool] = None, stage_groups=None):
         """`staged`: split the backward at the model's cut points and reduce each phase's gradient slice while the next phase
         runs (default: whenever there is more than one rank and the model offers `backward_phases()`)."""
         self.model = model
@@ -360,6 +365,27 @@ class TrainStep:
             staged = self.world > 1
         self.staged = bool(staged and phases is not None and len(phases) > 1)
         self.bucket = FlatGradBucket(list(model.parameters()), groups, phases if self.staged else None)
+        # Stage groups: runs of consecutive backward phases that share ONE hipGraph, ONE grouped weight-gradient launch and ONE
+        # all-reduce.  A grouped launch lasts as long as one workgroup's K loop however few products it holds, so a launch per
+        # phase costs 4 x 140 us where the whole pass takes 265 (measured, bench configuration); the default is therefore two groups:
+        # [every phase but the last] and [the last: the encoder], i.e. one all-reduce of the decoder's and the processor's gradients
+        # (13.5 of 13.6 MB) that runs while the encoder's backward computes, and a small exposed one.  GAOT_STAGE_GROUPS=each gives
+        # one group per phase (round 2's schedule), =pairs two phases per group.
+        n_ph = self.bucket.n_phases
+        import os as _os
+        mode = _os.environ.get("GAOT_STAGE_GROUPS", "default") if stage_groups is None else stage_groups
+        if not self.staged:
+            self.stage_groups = [[0]]
+        elif isinstance(mode, (list, tuple)):
+            self.stage_groups = [list(g) for g in mode]
+        elif mode == "each":
+            self.stage_groups = [[k] for k in range(n_ph)]
+        elif mode == "pairs":
+            self.stage_groups = [list(range(k, min(k + 2, n_ph))) for k in range(0, n_ph, 2)]
+        else:
+            self.stage_groups = [list(range(n_ph - 1)), [n_ph - 1]] if n_ph > 1 else [[0]]
+        if [k for g in self.stage_groups for k in g] != list(range(n_ph if self.staged else 1)):
+            raise ValueError(f"stage_groups must list the phases 0..{n_ph - 1} in order, got {self.stage_groups}")
         dev = self.bucket.flat.device
         on_gpu = dev.type == "cuda"
         if on_gpu:
@@ -443,6 +469,23 @@ class TrainStep:
         if k == self.bucket.n_phases - 1:
             self._cuts = None
 
+    def _run_group(self, gi: int):
+        """the phases of one stage group back to back, their weight-gradient products in ONE grouped launch at the group's end"""
+        loss = None
+        if self.bucket.flat.is_cuda:
+            from . import ops
+            scope = ops.deferred_wgrad()
+        else:
+            import contextlib
+            scope = contextlib.nullcontext()
+        with scope:
+            for k in self.stage_groups[gi]:
+                if k == 0:
+                    loss = self._phase0()
+                else:
+                    self._phase(k)
+        return loss
+
     def _check_phase(self, k: int):
         """first eager pass only: after phase k no parameter of a LATER phase may hold a gradient yet (the slices reduced
         so far are final) -- guards a model whose backward_phases() and cut points disagree"""
@@ -459,11 +502,11 @@ class TrainStep:
             loss = self._forward_backward()
             self.bucket.all_reduce_mean(self.group)
         else:
-            loss = self._phase0()
-            works = [self.bucket.all_reduce_mean(self.group, 0, async_op=True)]
-            for k in range(1, self.bucket.n_phases):
-                self._phase(k)
-                works.append(self.bucket.all_reduce_mean(self.group, k, async_op=True))
+            works, loss = [], None
+            for gi, ks in enumerate(self.stage_groups):
+                out = self._run_group(gi)
+                loss = out if out is not None else loss
+                works.append(self.bucket.all_reduce_mean(self.group, ks, async_op=True))
             for w in works:
                 if w is not None:
                     w.wait()
@@ -492,12 +535,12 @@ class TrainStep:
         self._graphs = []
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
-            self._loss = self._phase0() if self.staged else self._forward_backward()
+            self._loss = self._run_group(0) if self.staged else self._forward_backward()
         self._graphs.append(g)
-        for k in range(1, self.bucket.n_phases if self.staged else 1):
+        for gi in range(1, len(self.stage_groups) if self.staged else 1):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
-                self._phase(k)
+                self._run_group(gi)
             self._graphs.append(g)
         self._g_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g_opt, pool=pool, capture_error_mode="thread_local"):
@@ -542,13 +585,13 @@ class TrainStep:
             if self.comm_enabled:
                 self.bucket.all_reduce_mean(self.group)      # one flat RCCL all-reduce between the two graphs
         else:
-            # everything below is enqueued without a host wait: phase k's slice is reduced on RCCL's stream while the main
-            # stream replays the backward of phase k+1
+            # everything below is enqueued without a host wait: a stage group's slice is reduced on RCCL's stream while the main
+            # stream replays the backward of the next group
             works = []
-            for k, g in enumerate(self._graphs):
+            for gi, g in enumerate(self._graphs):
                 g.replay()
                 if self.comm_enabled:
-                    works.append(self.bucket.all_reduce_mean(self.group, k, async_op=True))
+                    works.append(self.bucket.all_reduce_mean(self.group, self.stage_groups[gi], async_op=True))
             for w in works:
                 if w is not None:
                     w.wait()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A few training steps of a BASELINE configuration for the profiler.  usage: eager_steps.py c2|c3 N [graph]
+"""A few training steps of a BASELINE configuration for the profiler.  usage: eager_steps.py c2|c3 N [graph] [staged]
 c2 = the bench configuration; c3 = NACA-shaped skewed meshes, vx mode, batch 16, 8192 nodes (tests/_workloads.naca_points)."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -34,7 +34,7 @@ else:
     dec = [[ns(lat, x[b], 0.033)] for b in range(B)]
     p, t = torch.randn(B, N, 3, device=dev), torch.randn(B, N, 1, device=dev)
     kw = dict(latent_tokens_coord=lat, xcoord=x, encoder_nbrs=enc, decoder_nbrs=dec)
-ts = TrainStep(model, use_graph=graph)
+ts = TrainStep(model, use_graph=graph, staged=("staged" in sys.argv) or None)
 ts.bind(p, t, **kw)
 for _ in range(3):
     ts.step()
