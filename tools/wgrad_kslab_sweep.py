@@ -3,7 +3,7 @@ sys.path.insert(0, "/root/repo")
 import torch
 from gaot_amd import ops, _lib
 lib = _lib.load(); dev = torch.device("cuda:0")
-T = 8192
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 shapes = [(2048, 256), (256, 1024), (256, 256), (768, 256)] * 3 + [(256, 256), (256, 512)]
 g = torch.Generator().manual_seed(0)
 ops_in = [(torch.randn(T, Mo, generator=g).to(dev), torch.randn(T, No, generator=g).to(dev), torch.empty(Mo, No, device=dev)) for Mo, No in shapes]
