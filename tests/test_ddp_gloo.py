@@ -169,3 +169,45 @@ def test_staged_backward_equals_plain_backward_single_process():
             ts.step()
         out.append(torch.cat([p.detach().reshape(-1) for p in m.parameters()]))
     assert torch.equal(out[0], out[1])
+
+
+class ThreePhaseOperator(torch.nn.Module):
+    """three backward phases (two cut points): exercises stage groups that merge phases"""
+
+    def __init__(self, seed):
+        super().__init__()
+        torch.manual_seed(seed)
+        self.a, self.b, self.c = torch.nn.Linear(3, 8), torch.nn.Linear(8, 8), torch.nn.Linear(8, 2)
+
+    def forward(self, pndata):
+        from gaot_amd import ops
+        h = ops.cut(torch.tanh(self.a(pndata)))
+        h = ops.cut(torch.tanh(self.b(h)))
+        return self.c(h)
+
+    def backward_phases(self):
+        return [list(self.c.parameters()), list(self.b.parameters()), list(self.a.parameters())]
+
+
+@pytest.mark.parametrize("groups,expect", [(None, [[0, 1], [2]]), ("each", [[0], [1], [2]]), ("pairs", [[0, 1], [2]]), ([[0], [1, 2]], [[0], [1, 2]])])
+def test_stage_groups_merge_phases_without_changing_the_update(groups, expect):
+    """TrainStep(stage_groups=...): runs of consecutive phases share one backward scope and one all-reduce slice; every grouping
+    gives the update of the plain backward.  Default: every phase but the last | the last."""
+    xs, ys = torch.randn(4, 5, 3), torch.randn(4, 5, 2)
+    ref = ThreePhaseOperator(7)
+    t0 = TrainStep(ref, lr=1e-2, weight_decay=1e-3, staged=False)
+    t0.bind(xs, ys)
+    m = ThreePhaseOperator(7)
+    ts = TrainStep(m, lr=1e-2, weight_decay=1e-3, staged=True, stage_groups=groups)
+    assert ts.stage_groups == expect and ts.bucket.n_phases == 3
+    ts.bind(xs, ys)
+    for _ in range(2):
+        t0.step()
+        ts.step()
+    assert all(torch.equal(p, q) for p, q in zip(ref.parameters(), m.parameters()))
+    # a group's slice is the contiguous range of its phases
+    for g in ts.stage_groups:
+        lo, hi = ts.bucket.segments[g[0]][0], ts.bucket.segments[g[-1]][1]
+        assert 0 <= lo < hi <= ts.bucket.numel
+    with pytest.raises(ValueError):
+        TrainStep(ThreePhaseOperator(7), staged=True, stage_groups=[[0, 2], [1]])
