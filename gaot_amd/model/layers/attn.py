@@ -108,6 +108,8 @@ class GroupQueryFlashAttention(nn.Module):
     def forward(self, x, condition=None, relative_positions=None, residual=None):
         if self.correction is not None:
             x = self.correction(c=condition, x=x)
+        if x.is_cuda:
+            ops.adopt_adjacent_storage([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight])
         qkv = ops.linear_cat(x, [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight])
         if relative_positions is not None:       # the reference only tests for None: the rotation angle is the SEQUENCE index
             qkv = ops.rope(qkv, self.num_heads + self.num_kv_heads, self.head_dim,
@@ -142,6 +144,8 @@ class FFN(nn.Module):
         return [[self.w1.weight, self.w3.weight]]
 
     def forward(self, x, condition=None, residual=None):
+        if x.is_cuda:
+            ops.adopt_adjacent_storage([self.w1.weight, self.w3.weight])
         if self.correction is None:
             return ops.swiglu_ffn(x, self.w1.weight, self.w3.weight, self.w2.weight, residual=residual)
         y = self.correction(c=condition, x=ops.swiglu_ffn(x, self.w1.weight, self.w3.weight, self.w2.weight))

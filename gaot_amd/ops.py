@@ -714,6 +714,29 @@ def adjacent_rows(ws: Sequence[torch.Tensor]) -> Optional[torch.Tensor]:
     return base.as_strided((rows, K), (K, 1), off)
 
 
+def adopt_adjacent_storage(params: Sequence[torch.nn.Parameter]) -> bool:
+    """Re-home the weights a fused GEMM reads as ONE matrix (q|k|v, w1|w3) into one storage, back to back, once: `param.data`
+    becomes a view of it (names, shapes, values, state_dict and the optimizer's references are untouched; in-place updates keep the
+    views).  trainer.FlatAdamW does this for its whole flat buffer; this is for plain loops (the reference trainer's own, with
+    torch.optim.AdamW): without it every forward concatenates the group again -- six torch.cat launches per step at the example model.
+    Returns True if the group is (now) adjacent.  Called by the owning modules at the top of their forward; a no-op pointer check
+    once adopted, and again after anything that re-creates the storages (`.to()`, `.cuda()`)."""
+    if adjacent_rows(params) is not None:
+        return True
+    K = params[0].shape[-1]
+    if torch.cuda.is_current_stream_capturing() or not all(
+            isinstance(p_, torch.nn.Parameter) and p_.is_cuda and p_.dtype == torch.float32 and p_.dim() == 2 and p_.shape[1] == K for p_ in params):
+        return False
+    with torch.no_grad():
+        buf = torch.cat([p_.detach() for p_ in params], dim=0)
+        r = 0
+        for p_ in params:
+            p_.data = buf[r:r + p_.shape[0]]
+            r += p_.shape[0]
+    bump_weights_generation()
+    return True
+
+
 def stacked_rows(ws: Sequence[torch.Tensor]) -> torch.Tensor:
     v = adjacent_rows(ws)
     return v if v is not None else torch.cat([w.detach() for w in ws], dim=0)
