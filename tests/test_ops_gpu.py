@@ -684,6 +684,9 @@ def test_gemm_two_piece_products(M, N, K):
     finally:
         ops.set_gemm_pieces(**old)
     assert rel(out3, ref["tn"]) < 1e-6 and 2 * rel(out3, ref["tn"]) < rel(out2, ref["tn"]) < 6e-6
+    again = torch.empty_like(out2)
+    ops.wgrad_launch([(dyd, N, xd, K, again, K, None, N, K, M)])
+    assert torch.equal(again, out2)                      # deterministic (fixed-order slab sums)
     with pytest.raises(ValueError):
         ops.set_gemm_pieces(4)
 
@@ -706,6 +709,10 @@ def test_attention_two_piece_default():
         d = qkv.to(dev()).requires_grad_(True)
         out = ops.attention(d, H, H, D)
         out.backward(go.to(dev()))
+        d2 = qkv.to(dev()).requires_grad_(True)
+        out2 = ops.attention(d2, H, H, D)
+        out2.backward(go.to(dev()))
+        assert torch.equal(out, out2) and torch.equal(d.grad, d2.grad)           # deterministic
         return rel(out, ref), rel(d.grad, r.grad)
     g = torch.Generator().manual_seed(7)
     B, S, H, D = 8, 1024, 8, 32                           # the bench shape
@@ -752,6 +759,8 @@ def test_kernel_mlp_two_piece_default(E, cin, n):
         if act == "gelu":
             assert rel(y, h) < bar_out and max(errs) < bar_grad, (act, rel(y, h), errs)
             assert rel(y, h) > 1e-6          # the two-piece kernels did run
+            g_again = torch.autograd.grad(ops.mlp_chain(x, ws, bs, acts), ws + bs, dk)
+            assert all(torch.equal(a, b) for a, b in zip(g, g_again))         # deterministic (per-workgroup partial rows, fixed-order sums)
         else:                                # exact products whatever the setting: bit-identical to the three-piece mode
             old = ops.set_gemm_pieces(3)
             try:
