@@ -2070,6 +2070,253 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// backward for 32 < head_dim <= 64 with two rounded pieces of everything, 8 waves x 32 keys = 256 keys per workgroup (one workgroup
+// per CU, two waves per SIMD -- the 4-wave kernel above runs one; half the Q / dO tile staging per key and half the dQ slabs).
+// Everything a wave keeps per key lives in LDS except V: K as two bf16 planes [32 kv][64 d] (B operand of S through 16-byte row
+// reads, B operand of dQ through transposing reads), dS^T planes; the Q / dO tile is staged k-major only and read row-wise (S, dP)
+// and through transposing reads (dK, dV).  158 KB of LDS.
+// ---------------------------------------------------------------------------------------------
+constexpr int AD8_KROW = 64 * 2 + 16, AD8_KPL = 32 * AD8_KROW;                     // a [32 rows][64 d] bf16 plane
+constexpr int AD8_SHARED = 2 * 2 * AD8_KPL + 64 * 4;                                // Q and dO, two pieces each + lse / delta
+constexpr int AD8_WAVE = 2 * AD8_KPL + 32 * 64 * 4;                                 // K planes + (dS^T planes | dQ partial [32][64] fp32)
+constexpr int AD8_LDS = AD8_SHARED + 8 * AD8_WAVE;
+__global__ __launch_bounds__(512, 1) void attn_bwd_split8_dh_kernel(const AttnArgs p) {
+    constexpr int DH = 64, NU = 4, NDT = 2, CPR = 16, NW = 8;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[AD8_LDS];
+    unsigned char* Qk = smem;
+    unsigned char* Gk = Qk + 2 * AD8_KPL;
+    float* lse_s = reinterpret_cast<float*>(Gk + 2 * AD8_KPL);
+    float* del_s = lse_s + 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    int bh, kblk;
+    xcd_group_decode(blockIdx.x, p.B * p.H, p.n_kblocks, bh, kblk);
+    const int b = bh / p.H, h = bh % p.H, hk = h / (p.H / p.Hkv);
+    const int kv0 = kblk * 256 + wave * 32;
+    const int D = p.D;
+    const float c = p.scale * LOG2E;
+    unsigned char* Kpl = smem + AD8_SHARED + wave * AD8_WAVE;         // two planes [32 kv][64 d]
+    unsigned char* dSp = Kpl + 2 * AD8_KPL;                            // two planes [32 kv][32 q] (row stride AB_KROW); dQ partial after the MFMAs
+    float* Pmine = reinterpret_cast<float*>(dSp);
+    const int tr_k = lds_tr_lane_offset(lane, AD8_KROW), tr_s = lds_tr_lane_offset(lane, AB_KROW);
+
+    // V^T as the split B operand of dP: lane (kv = li, hi) holds d = 16u + 8hi + e; K goes to the wave's planes
+    bf16x8 vf[2][NU];
+    const bool kv_ok = kv0 + li < p.S;
+    {
+        const float* vrow = p.v + ((long)b * p.S + min(kv0 + li, p.S - 1)) * p.ldv + (long)hk * D;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const f32x4 w0 = load4(vrow, 16 * u + 8 * lh, D, true, true), w1 = load4(vrow, 16 * u + 8 * lh + 4, D, true, true);
+            u32x4 vh, vm;
+            unsigned a_, b_;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                split2_pair(w0[2 * e], w0[2 * e + 1], a_, b_); vh[e] = a_; vm[e] = b_;
+                split2_pair(w1[2 * e], w1[2 * e + 1], a_, b_); vh[2 + e] = a_; vm[2 + e] = b_;
+            }
+            vf[0][u] = __builtin_bit_cast(bf16x8, vh); vf[1][u] = __builtin_bit_cast(bf16x8, vm);
+        }
+        for (int t = lane; t < 32 * CPR; t += 64) {
+            const int row = t / CPR, d = (t % CPR) * 4;
+            const f32x4 a = load4(p.k + ((long)b * p.S + min(kv0 + row, p.S - 1)) * p.ldk + (long)hk * D, d, D, kv0 + row < p.S, true);
+            unsigned h0, m0, h1, m1;
+            split2_pair(a[0], a[1], h0, m0);
+            split2_pair(a[2], a[3], h1, m1);
+            *reinterpret_cast<u32x2*>(Kpl + row * AD8_KROW + d * 2) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(Kpl + AD8_KPL + row * AD8_KROW + d * 2) = u32x2{m0, m1};
+        }
+    }
+    f32x16 dvacc[NDT], dkacc[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dvacc[dt][r] = 0.f; dkacc[dt][r] = 0.f; }
+
+    const float* qbase = p.q + (long)b * p.S * p.ldq + (long)h * D;
+    const float* gbase = p.dout + (long)b * p.S * p.ldo + (long)h * D;
+    const float* lse_b = p.lse + ((long)b * p.H + h) * p.S;
+    const float* del_b = p.delta + ((long)b * p.H + h) * p.S;
+    // staging: one float4 of Q and one of dO per thread (row = tid >> 4, chunk = tid & 15)
+    f32x4 rq, rg;
+    float rl = 0.f, rd = 0.f;
+    auto fetch = [&](int q0) {
+        const int row = tid >> 4, d = (tid & 15) * 4;
+        const bool ok = q0 + row < p.S;
+        const long r = min(q0 + row, p.S - 1);
+        rq = load4(qbase + r * p.ldq, d, D, ok, true);
+        rg = load4(gbase + r * p.ldo, d, D, ok, true);
+        if (tid < 32) {
+            const bool okq = q0 + tid < p.S;
+            rl = okq ? lse_b[q0 + tid] * LOG2E : INFINITY;
+            rd = okq ? del_b[q0 + tid] : 0.f;
+        }
+    };
+    const int nq = (p.S + 31) / 32;
+    const long part_stride = (long)p.B * p.H * p.S * DH;
+    float* part = p.dq_part + (long)kblk * part_stride + ((long)b * p.H + h) * p.S * DH;
+
+    fetch(0);
+    for (int qt = 0; qt < nq; ++qt) {
+        const int q0 = qt * 32;
+        {
+            const int row = tid >> 4, ch = tid & 15;
+            unsigned h0, m0, h1, m1;
+            split2_pair(rq[0], rq[1], h0, m0);
+            split2_pair(rq[2], rq[3], h1, m1);
+            *reinterpret_cast<u32x2*>(Qk + row * AD8_KROW + ch * 8) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(Qk + AD8_KPL + row * AD8_KROW + ch * 8) = u32x2{m0, m1};
+            split2_pair(rg[0], rg[1], h0, m0);
+            split2_pair(rg[2], rg[3], h1, m1);
+            *reinterpret_cast<u32x2*>(Gk + row * AD8_KROW + ch * 8) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(Gk + AD8_KPL + row * AD8_KROW + ch * 8) = u32x2{m0, m1};
+        }
+        if (tid < 32) { lse_s[tid] = rl; del_s[tid] = rd; }
+        __syncthreads();                                    // barrier A
+        if (qt + 1 < nq) fetch(q0 + 32);
+
+        // ---- S[q][kv] and dP[q][kv]: A = Q / dO planes (lane -> query row), B = K planes (LDS) / V^T (registers)
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const unsigned char* qr = Qk + li * AD8_KROW + u * 32 + lh * 16;
+            const unsigned char* gr = Gk + li * AD8_KROW + u * 32 + lh * 16;
+            const unsigned char* kr = Kpl + li * AD8_KROW + u * 32 + lh * 16;
+            const bf16x8 q0_ = *reinterpret_cast<const bf16x8*>(qr), q1_ = *reinterpret_cast<const bf16x8*>(qr + AD8_KPL);
+            const bf16x8 g0_ = *reinterpret_cast<const bf16x8*>(gr), g1_ = *reinterpret_cast<const bf16x8*>(gr + AD8_KPL);
+            const bf16x8 k0_ = *reinterpret_cast<const bf16x8*>(kr), k1_ = *reinterpret_cast<const bf16x8*>(kr + AD8_KPL);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q1_, k0_, s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1_, vf[0][u], dp, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0_, k1_, s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0_, vf[1][u], dp, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0_, k0_, s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0_, vf[0][u], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qr = crow(r, lh);
+            float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c, -lse_s[qr]));
+            if (!kv_ok) pv = 0.f;
+            s[r] = pv;
+            dp[r] = pv * (dp[r] - del_s[qr]);
+        }
+        // ---- dV^T / dK^T: the tile's contributions start from zero on the matrix pipe and join the running sums on the vector pipe
+        f32x16 dvt[NDT], dkt[NDT];
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dvt[dt][r] = 0.f; dkt[dt][r] = 0.f; }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            u32x4 ph, pm, sh, sm;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned a_, b_;
+                split2_pair(s[8 * u + 2 * e], s[8 * u + 2 * e + 1], a_, b_); ph[e] = a_; pm[e] = b_;
+                split2_pair(dp[8 * u + 2 * e], dp[8 * u + 2 * e + 1], a_, b_); sh[e] = a_; sm[e] = b_;
+            }
+            // dS^T pieces [kv = li][q]: registers 8u .. 8u + 3 are queries 16u + 4hi + 0..3, 8u + 4 .. 8u + 7 the same, eight up
+            unsigned char* dst = dSp + li * AB_KROW + (16 * u + 4 * lh) * 2;
+            *reinterpret_cast<u32x2*>(dst) = u32x2{sh[0], sh[1]};
+            *reinterpret_cast<u32x2*>(dst + 16) = u32x2{sh[2], sh[3]};
+            *reinterpret_cast<u32x2*>(dst + AB_KPL) = u32x2{sm[0], sm[1]};
+            *reinterpret_cast<u32x2*>(dst + AB_KPL + 16) = u32x2{sm[2], sm[3]};
+            const bf16x8 p0 = __builtin_bit_cast(bf16x8, ph), p1 = __builtin_bit_cast(bf16x8, pm);
+            const bf16x8 d0 = __builtin_bit_cast(bf16x8, sh), d1 = __builtin_bit_cast(bf16x8, sm);
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                // dO^T / Q^T fragments from the k-major planes: column d = 32dt + li, rows q = 16u + 4hi + 0..3 and + 8
+                const unsigned char* gb = Gk + (16 * u) * AD8_KROW + 32 * dt * 2 + tr_k;
+                const unsigned char* qb = Qk + (16 * u) * AD8_KROW + 32 * dt * 2 + tr_k;
+                const bf16x8 ga0 = __builtin_bit_cast(bf16x8, join8(lds_tr(gb), lds_tr(gb + 8 * AD8_KROW)));
+                const bf16x8 ga1 = __builtin_bit_cast(bf16x8, join8(lds_tr(gb + AD8_KPL), lds_tr(gb + AD8_KPL + 8 * AD8_KROW)));
+                const bf16x8 qa0 = __builtin_bit_cast(bf16x8, join8(lds_tr(qb), lds_tr(qb + 8 * AD8_KROW)));
+                const bf16x8 qa1 = __builtin_bit_cast(bf16x8, join8(lds_tr(qb + AD8_KPL), lds_tr(qb + AD8_KPL + 8 * AD8_KROW)));
+                dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga1, p0, dvt[dt], 0, 0, 0);
+                dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa1, d0, dkt[dt], 0, 0, 0);
+                dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga0, p1, dvt[dt], 0, 0, 0);
+                dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa0, d1, dkt[dt], 0, 0, 0);
+                dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga0, p0, dvt[dt], 0, 0, 0);
+                dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa0, d0, dkt[dt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dvacc[dt][r] += dvt[dt][r]; dkacc[dt][r] += dkt[dt][r]; }
+        // ---- dQ[q][d] partial = sum_kv dS[q][kv] K[kv][d]: both operands through transposing reads (k-slot e = key 16u + 8 (e >> 2) + 4 hi + (e & 3))
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        f32x16 dq[NDT];
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const bf16x8 da0 = __builtin_bit_cast(bf16x8, join8(lds_tr(dSp + (16 * u) * AB_KROW + tr_s), lds_tr(dSp + (16 * u + 8) * AB_KROW + tr_s)));
+            const bf16x8 da1 = __builtin_bit_cast(bf16x8, join8(lds_tr(dSp + AB_KPL + (16 * u) * AB_KROW + tr_s), lds_tr(dSp + AB_KPL + (16 * u + 8) * AB_KROW + tr_s)));
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const unsigned char* kb = Kpl + (16 * u) * AD8_KROW + 32 * dt * 2 + tr_k;
+                const bf16x8 kb0 = __builtin_bit_cast(bf16x8, join8(lds_tr(kb), lds_tr(kb + 8 * AD8_KROW)));
+                const bf16x8 kb1 = __builtin_bit_cast(bf16x8, join8(lds_tr(kb + AD8_KPL), lds_tr(kb + AD8_KPL + 8 * AD8_KROW)));
+                dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1, kb0, dq[dt], 0, 0, 0);
+                dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da0, kb1, dq[dt], 0, 0, 0);
+                dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da0, kb0, dq[dt], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                     // every lane holds its dS fragments: the planes may be overwritten
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Pmine[crow(r, lh) * DH + 32 * dt + li] = dq[dt][r];
+        __syncthreads();                                    // barrier B
+        // fixed-order sum of the eight waves' partials -> this key block's slice of the dQ workspace
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int t = tid + i * 512;
+            const int row = t / DH;
+            if (q0 + row < p.S) {
+                float acc = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w)
+                    acc += reinterpret_cast<const float*>(smem + AD8_SHARED + w * AD8_WAVE + 2 * AD8_KPL)[t];
+                part[(long)(q0 + row) * DH + (t % DH)] = acc;
+            }
+        }
+    }
+    // ---- epilogue: dK^T, dV^T -> [kv][d] through the wave's (now free) dS region, coalesced row stores
+    __syncthreads();
+    float* Smine = reinterpret_cast<float*>(dSp);            // [32][33] floats
+#pragma unroll
+    for (int pass = 0; pass < 2 * NDT; ++pass) {
+        const int dt = pass >> 1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Smine[li * 33 + crow(r, lh)] = ((pass & 1) == 0 ? dkacc[dt][r] * p.scale : dvacc[dt][r]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int rr = lh; rr < 32; rr += 2) {
+            const int kv = kv0 + rr;
+            if (kv < p.S && 32 * dt + li < D) {
+                if ((pass & 1) == 0) p.dk[((long)b * p.S + kv) * p.lddk + (long)h * D + 32 * dt + li] = Smine[rr * 33 + li];
+                else                 p.dv[((long)b * p.S + kv) * p.lddv + (long)h * D + 32 * dt + li] = Smine[rr * 33 + li];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 template <int DP> static size_t bwd_lds_bytes() {
     return sizeof(float) * (2 * 32 * (DP + 4) + 64 + 4 * 32 * DP + 4 * 32 * 33 + 4 * 32 * (DP < 64 ? DP : 64));
 }
@@ -2272,7 +2519,11 @@ extern "C" int gaot_attention_bwd(const float* q, const float* k, const float* v
     } else if (split_ok) {
         hipLaunchKernelGGL(attn_bwd_split_kernel, grid, block, 0, ST(stream), a);
     } else if (head_dim > 32 && head_dim <= 64 && a.vec && g_attn_split && aligned16(dq) && aligned16(dk) && aligned16(dv)) {
-        if (g_attn_pp % 10 == 2 && g_attn_op == 2) hipLaunchKernelGGL((attn_bwd_split_dh_kernel<64, 2, 2>), grid, block, 0, ST(stream), a);
+        if (g_attn_pp % 10 == 2 && g_attn_op == 2 && g_attn_tr && g_attn_split != 3 && (g_attn_split == 2 || (long)cdiv(S, 256) * B * H >= 256)) {      // (C5: 128 such workgroups: stays on the 4-wave kernel, 800 vs 822 us)
+            a.n_kblocks = cdiv(S, 256);          // 256 keys per workgroup: half the dQ slabs (the workspace is sized for 128)
+            hipLaunchKernelGGL(attn_bwd_split8_dh_kernel, dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a);
+        }
+        else if (g_attn_pp % 10 == 2 && g_attn_op == 2) hipLaunchKernelGGL((attn_bwd_split_dh_kernel<64, 2, 2>), grid, block, 0, ST(stream), a);
         else hipLaunchKernelGGL((attn_bwd_split_dh_kernel<64>), grid, block, 0, ST(stream), a);
     } else if (DP == 32) {
         hipLaunchKernelGGL(attn_bwd_kernel<32>, grid, block, bwd_lds_bytes<32>(), ST(stream), a);

@@ -720,6 +720,12 @@ def test_attention_two_piece_default():
     assert 1e-6 < eo < 1e-5 and 1e-6 < eg < 1.5e-5, (eo, eg)
     eo, eg = run(torch.randn(1, 512, 3 * 4 * 48, generator=g), torch.randn(1, 512, 4 * 48, generator=g), 4, 48)      # head_dim 48: the DH = 64 kernels
     assert 1e-6 < eo < 1e-5 and 1e-6 < eg < 1.5e-5, (eo, eg)
+    old = lib.gaot_debug_set_attention_split(2)           # ... and their 8-wave / 256-key backward (picked when it fills the chip), ragged S
+    try:
+        eo, eg = run(torch.randn(2, 333, 3 * 4 * 36, generator=g), torch.randn(2, 333, 4 * 36, generator=g), 4, 36)
+    finally:
+        lib.gaot_debug_set_attention_split(old)
+    assert 1e-6 < eo < 1e-5 and 1e-6 < eg < 1.5e-5, (eo, eg)
     base = (torch.randn(1, 1, 3 * H * D, generator=g) * 0.6).repeat(1, 2048, 1)
     idx = torch.randperm(2048, generator=g)[:200]
     base[0, idx] = torch.randn(200, 3 * H * D, generator=g) * 0.6
