@@ -8,13 +8,16 @@ A "step" = one reference-trainer step (forward + MSE + backward + AdamW, plus th
 when N > 1) on BASELINE config 2: 2-D mesh with 16 384 nodes, batch 8 PER GPU (weak scaling), the reference's
 example model (config/examples/time_indep/poisson_gauss.json: latent 64x64, C=64, patch 2, transformer 256 x 3
 blocks, 8 heads; 3 396 033 parameters), synthetic data, random-init weights, inputs resident in HBM.
-Arithmetic is fp32 end to end (the reference has no reduced-precision path; parity tolerance 1e-5 is fp32).
+The HEADLINE (`value`, `ms_per_step`, `dtype: "f32"`) is fp32-equivalent arithmetic end to end, like the reference (no autocast
+anywhere, base_trainer.py:63-68): every product on the bf16 matrix pipe takes each fp32 operand as THREE bf16 pieces (six piece
+products, exact to fp32 rounding), storage and accumulation are fp32.  Narrower arithmetic is reported as labelled `variants`
+(bf16x2: two rounded bf16 pieces per operand; bf16: one piece in the tile GEMMs), each with its own error against the float64 oracle.
 
 Extra objects on the JSON line:
-  roofline     dominant kernel family = the MFMA GEMM tiles behind gaot_gemm_f32 (fp32 MFMA, and fp32-exact products
-               on the bf16 MFMA pipe from 3-way split operands): algorithmic FLOPs of its launches in
-               one step / their summed duration, timed live with HIP events on the launch stream in an
-               instrumented eager step; peak = 157.3 TFLOP/s (dense f32 matrix rate, MI355X_MICROARCH.md)
+  roofline     dominant kernel family = the split-bf16 MFMA GEMM kernels behind gaot_gemm_f32 and the grouped weight-gradient
+               launch: piece-product FLOPs ISSUED on the bf16 matrix pipe in one step / their summed duration, timed live with HIP
+               events on the launch stream in an instrumented eager step; peak = 2500 TFLOP/s (dense bf16 MFMA, MI355X_MICROARCH.md);
+               the fp32-equivalent rate (algorithmic FLOPs) is a secondary key
   cpu_baseline the CPU oracle (oracle/gaot_oracle.py, a parity-checked port of the reference path) timed on the
                host cores of this box on the same workload, a few steps (rank 0, N = 1 only)
 """
@@ -34,6 +37,7 @@ if ROOT not in sys.path:
 
 N_NODES, BATCH, LATENT, C_LIFT, HIDDEN, PATCH, RADIUS = 16384, 8, [64, 64], 64, 256, 2, 0.033
 PEAK_F32_MATRIX_TFLOPS = 157.3
+PEAK_BF16_MATRIX_TFLOPS = 2500.0
 PEAK_HBM_GBPS = 8000.0
 
 
@@ -114,7 +118,9 @@ def gemm_roofline(ts):
         s.record()
         out = raw(M, N, K, *a, **kw)
         e.record()
-        records.append((s, e, 2.0 * M * N * K, (M, N, K, int(a[2]), int(a[5]), kw.get("split_k", 1)), lib.gaot_debug_last_gemm_path()))
+        kind = "tn" if not int(a[2]) else ("nt" if int(a[5]) else "nn")
+        pcs = kw.get("pieces") or ops._PIECES[kind]
+        records.append((s, e, 2.0 * M * N * K, (M, N, K, int(a[2]), int(a[5]), kw.get("split_k", 1)), lib.gaot_debug_last_gemm_path(), pcs))
         return out
 
     # the HBM regime: the fused gather / segment-reduce / edge-gradient kernels of the integral transforms (csrc/gno.hip)
@@ -127,7 +133,8 @@ def gemm_roofline(ts):
         s.record()
         raw_wgrad(items)
         e.record()
-        wg.append((s, e, sum(2.0 * it[7] * it[8] * it[9] for it in items), sum(4.0 * (it[9] * (it[7] + it[8]) + it[7] * it[8]) for it in items), len(items)))
+        wg.append((s, e, sum(2.0 * it[7] * it[8] * it[9] for it in items), sum(4.0 * (it[9] * (it[7] + it[8]) + it[7] * it[8]) for it in items), len(items),
+                   ops._PIECES["tn"]))
 
     use_graph = ts.use_graph
     ts.use_graph = False
@@ -149,10 +156,14 @@ def gemm_roofline(ts):
         for name, fn in saved.items():
             setattr(lib, name, fn)
     gno_us = _gno_us(gno)
-    mfma = [r for r in records if r[4] in (1, 3)]     # launches served by the MFMA tile kernels (1 = fp32 MFMA, 3 = split-bf16 MFMA)
-    n_split = sum(1 for r in records if r[4] == 3)
+    nprod = {3: 6.0, 2: 3.0, 1: 1.0}              # piece products per fp32-equivalent product
+    one_piece = os.environ.get("GAOT_BENCH_ONE_PIECE") == "1"          # the `bf16` variant (gaot_debug_set_gemm_pieces(1)): one product
+    mfma = [r for r in records if r[4] == 3]      # launches served by the split-bf16 MFMA tile kernels (the bf16 matrix pipe)
+    f32m = [r for r in records if r[4] == 1]      # fp32-MFMA tile launches (products too small / narrow for the split tiles)
+    n_split = len(mfma)
     ms = sum(r[0].elapsed_time(r[1]) for r in mfma) + sum(w[0].elapsed_time(w[1]) for w in wg)
     flops = sum(r[2] for r in mfma) + sum(w[2] for w in wg)
+    piece_flops = sum(r[2] * (1.0 if one_piece else nprod[r[5]]) for r in mfma) + sum(w[2] * (1.0 if one_piece else nprod[w[5]]) for w in wg)
     abytes = sum(4.0 * (r[3][0] * r[3][2] + r[3][1] * r[3][2] + r[3][0] * r[3][1]) for r in mfma) + sum(w[3] for w in wg)   # A + B + C touched once
     ms_all = sum(r[0].elapsed_time(r[1]) for r in records) + sum(w[0].elapsed_time(w[1]) for w in wg)
     if os.environ.get("GAOT_BENCH_GEMM_TABLE"):
@@ -164,7 +175,9 @@ def gemm_roofline(ts):
             us = w[0].elapsed_time(w[1]) * 1e3
             print(f"# grouped weight gradients: {w[4]} products in one launch {us:8.1f}us {w[2] / us / 1e6:6.1f}TF", file=sys.stderr)
     return {"launches": len(mfma) + len(wg), "flops": flops, "ms": ms, "tflops": flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
-            "skinny_launches": len(records) - len(mfma), "all_gemm_ms": ms_all, "split_launches": n_split,
+            "piece_tflops": piece_flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, "piece_flops": piece_flops,
+            "f32_mfma_launches": len(f32m), "f32_mfma_ms": sum(r[0].elapsed_time(r[1]) for r in f32m), "f32_mfma_gflop": sum(r[2] for r in f32m) / 1e9,
+            "skinny_launches": len(records) - len(mfma) - len(f32m), "all_gemm_ms": ms_all, "split_launches": n_split,
             "alg_bytes_per_launch": abytes / max(1, len(mfma) + len(wg)), "gno_us": gno_us, "gno_launches": len(gno),
             "grouped_wgrad": {"launches": len(wg), "products": sum(w[4] for w in wg), "gflop": sum(w[2] for w in wg) / 1e9,
                               "us": sum(w[0].elapsed_time(w[1]) for w in wg) * 1e3}}
@@ -247,7 +260,18 @@ def cpu_baseline(sd, tensors, hip, steps: int = 3):
     base = {"value": BATCH * steps / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{steps} full train steps (fwd+MSE+bwd+AdamW) of the same workload (16384 nodes, batch {BATCH}) "
                       f"on the CPU oracle, {dt / steps:.2f} s/step"}
-    return base, parity
+    return base, parity, {"pred": predd, "grads": gradsd}
+
+
+def errors_vs_float64(hip, ref64):
+    """output rel-L2 and worst per-tensor gradient rel-L2 (denominator floored at 1e-3 of the largest gradient norm) of a HIP
+    reference pass against the oracle evaluated in float64 end to end"""
+    topd = max(float(g.norm()) for g in ref64["grads"].values())
+    errs = {k: float((hip["grads"][k].double() - g).norm()) / max(float(g.norm()), 1e-3 * topd) for k, g in ref64["grads"].items()}
+    worst = max(errs, key=errs.get)
+    return {"output": float((hip["pred"].double() - ref64["pred"]).norm() / ref64["pred"].norm()),
+            "grad_worst_tensor": errs[worst], "grad_worst_name": worst,
+            "what": "vs the CPU oracle evaluated in float64 end to end, same initial weights and batch; gradients through the training path"}
 
 
 def reference_loop_rate(dev, steps: int = 30, warmup: int = 8):
@@ -286,14 +310,17 @@ def reference_loop_rate(dev, steps: int = 30, warmup: int = 8):
                     "reference trainer sees without changing it"}
 
 
-def exact_products_rate(dev, steps: int = 40, warmup: int = 8):
-    """The SAME TrainStep with EXACT products everywhere (three bf16 pieces per operand, six piece products: fp32 rounding; the
-    round-1/2 arithmetic): what the two-piece default buys, next to what it costs (rel_l2_vs_oracle.vs_float64_oracle)."""
+def variant_rate(dev, name: str, ref64, steps: int = 40, warmup: int = 8):
+    """The SAME TrainStep at NARROWER arithmetic than the headline -- a labelled variant, never `value`:
+      bf16x2: every product on the bf16 matrix pipe takes each fp32 operand as TWO rounded bf16 pieces (16 significant bits; GEMM tiles,
+              grouped weight gradients, attention, the GELU kernel MLP); storage / accumulation fp32
+      bf16:   BASELINE configs[1]'s "bf16": tile-GEMM operands rounded to ONE bf16 piece, fp32 accumulation; everything else as the headline
+    with its own error against the float64 oracle (same initial weights and batch as the headline)."""
     from gaot_amd import ops, _lib
     from gaot_amd.trainer import TrainStep
     lib = _lib.load()
-    old = ops.set_gemm_pieces(3)
-    old_p, old_op = lib.gaot_debug_set_attention_p_pieces(33), lib.gaot_debug_set_attention_operand_pieces(3)
+    old = ops.set_precision("bf16x2") if name == "bf16x2" else dict(ops._PIECES)
+    old1 = lib.gaot_debug_set_gemm_pieces(1) if name == "bf16" else None
     try:
         ops.register_grad_slots([], [])
         torch.manual_seed(0)
@@ -301,6 +328,7 @@ def exact_products_rate(dev, steps: int = 40, warmup: int = 8):
         lat, x, p, t = synthetic(1234, dev)
         ts = TrainStep(model, lr=8e-4, weight_decay=1e-5, use_graph=True)
         ts.bind(p, t, latent_tokens_coord=lat, xcoord=x)
+        err = errors_vs_float64(hip_reference_pass(ts, model, (lat, x, p, t)), ref64) if ref64 is not None else None
         for _ in range(warmup):
             ts.step()
         torch.cuda.synchronize()
@@ -312,11 +340,12 @@ def exact_products_rate(dev, steps: int = 40, warmup: int = 8):
         del ts
     finally:
         ops.set_gemm_pieces(**old)
-        lib.gaot_debug_set_attention_p_pieces(old_p)
-        lib.gaot_debug_set_attention_operand_pieces(old_op)
-    return {"value": BATCH * steps / dt, "unit": "samples/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
-            "what": "the headline step with exact three-piece products in every GEMM, the attention and the kernel MLP (GAOT_GEMM_PIECES=3, "
-                    "attention pieces (33, 3)): output 1.3e-7 / worst gradient 8.8e-7 from the float64 oracle"}
+        if old1 is not None:
+            lib.gaot_debug_set_gemm_pieces(old1)
+    dtype = {"bf16x2": "bf16x2 products (two rounded bf16 pieces per f32 operand), f32 accumulate and storage",
+             "bf16": "bf16 tile-GEMM operands (one piece, RNE), f32 accumulate and storage; attention / kernel MLP / transforms as the headline"}[name]
+    return {"value": BATCH * steps / dt, "unit": "samples/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "dtype": dtype,
+            "rel_l2_vs_oracle": err}
 
 
 def secondary_configs(dev, which=("C3", "C4", "C5"), steps: int = 20, warmup: int = 5, oracle: bool = True):
@@ -496,10 +525,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-loop", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the secondary C3 / C4 / C5 measurements")
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
-                    help="f32 (default, the parity path).  bf16: GEMM operands rounded to bf16 wherever the tile kernels apply (one "
-                         "MFMA piece product instead of six, fp32 accumulation); attention, integral transforms, norms and the "
-                         "optimizer stay fp32.  A separately reported variant (BASELINE configs[1]), never the headline.")
+    ap.add_argument("--dtype", choices=["f32", "bf16x2", "bf16"], default="f32",
+                    help="f32 (default, the parity path and the only headline): exact three-piece products.  bf16x2 / bf16: run the whole "
+                         "line at that narrower arithmetic (A/B and profiling runs; the line says so in `dtype`).  The default line "
+                         "already carries both as `variants`.")
+    ap.add_argument("--no-variants", action="store_true", help="skip the bf16x2 / bf16 variant measurements")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -524,8 +554,11 @@ def main():
     from gaot_amd.trainer import TrainStep
     from gaot_amd import ops as _ops
     if args.dtype == "bf16":
-        from gaot_amd import ops, _lib
+        from gaot_amd import _lib
         _lib.load().gaot_debug_set_gemm_pieces(1)      # the tile kernels the heuristic picks, with ONE bf16 piece per operand
+        os.environ["GAOT_BENCH_ONE_PIECE"] = "1"
+    elif args.dtype == "bf16x2":
+        _ops.set_precision("bf16x2")
     torch.manual_seed(0)                      # identical weights on every rank (and broadcast from rank 0 anyway)
     model = build_model().to(dev).train()
     lat, x, p, t = synthetic(1234 + rank, dev)
@@ -556,7 +589,18 @@ def main():
         elapsed = float(tt.item())
     loss = float(ts._loss if ts.use_graph else ts.step())
     comm = None
+    ranks_seen = None
     if world > 1:
+        # proof that the collective saw N distinct ranks / devices and that they stayed identical: every rank contributes its device index
+        # and a checksum of its flat parameter buffer after the timed steps (one all-gather, after the timed region)
+        flat_w = ts.opt.flat_p if hasattr(ts.opt, "flat_p") else torch.cat([q.detach().reshape(-1) for q in model.parameters()])
+        mine = torch.tensor([float(rank), float(torch.cuda.current_device()), float(flat_w.double().sum()), float(flat_w.double().abs().sum())],
+                            device=dev, dtype=torch.float64)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rows = [[float(v) for v in r_.tolist()] for r_ in allr]
+        ranks_seen = {"n_ranks_seen": len({int(r_[0]) for r_ in rows}), "devices": [int(r_[1]) for r_ in rows],
+                      "param_checksums_identical": all(r_[2:] == rows[0][2:] for r_ in rows), "param_checksum": rows[0][2:]}
         # exposed communication = the same K steps WITHOUT the gradient exchange (ranks drift apart: timing only, after the headline)
         # subtracted from the headline; plus every phase slice's all-reduce timed on its own (RCCL over xGMI, HIP events)
         slices = []
@@ -586,7 +630,7 @@ def main():
         tt = torch.tensor([no_comm], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         no_comm = float(tt.item())
-        comm = {"backend": dist.get_backend() + (" (RCCL over xGMI)" if dist.get_backend() == "nccl" else ""), "slices": slices,
+        comm = {"backend": dist.get_backend() + (" (RCCL over xGMI)" if dist.get_backend() == "nccl" else ""), **ranks_seen, "slices": slices,
                 "ms_per_step_without_exchange": 1e3 * no_comm / args.steps,
                 "exposed_ms_per_step": 1e3 * (elapsed - no_comm) / args.steps,
                 "what": "per stage group (a run of backward phases sharing one graph and one grouped weight-gradient launch) one asynchronous all-reduce "
@@ -617,7 +661,8 @@ def main():
         gno_total_b = sum(gno_bytes.values())
         hbm_achieved = gno_total_b / (gno_total_us * 1e-6) / 1e9 if gno_total_us > 0 else 0.0
         gno_traffic, gno_src = recorded_traffic("gno")
-        t_mfma_ideal = 259.0e9 / (PEAK_F32_MATRIX_TFLOPS * 1e12) * 1e3           # 259 GFLOP per B = 8 step
+        n_prod = {"f32": 6.0, "bf16x2": 3.0, "bf16": 1.0}[args.dtype]
+        t_mfma_ideal = n_prod * 259.0e9 / (PEAK_BF16_MATRIX_TFLOPS * 1e12) * 1e3   # 259 GFLOP per B = 8 step, as piece products on the pipe in use
         t_hbm_ideal = (8 * (42 + 120) + 13) * 1e6 / (PEAK_HBM_GBPS * 1e9) * 1e3   # ~1.31 GB per step
         line = {
             "metric": "train samples/sec (2D 16k-node mesh, bs=8 per GPU)",
@@ -630,34 +675,37 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.dtype == "f32" else "bf16 GEMM operands (RNE), fp32 accumulation; everything else f32 -- NOT the parity path",
+            "dtype": {"f32": "f32", "bf16x2": "bf16x2 products (two rounded bf16 pieces per f32 operand), f32 accumulate -- NOT the parity headline",
+                      "bf16": "bf16 tile-GEMM operands (one piece), f32 accumulate -- NOT the parity headline"}[args.dtype],
             "precision": {"storage_and_accumulation": "f32 everywhere (weights, activations, gradients, optimizer state, every accumulator)",
-                          "gemm_pieces": dict(_ops._PIECES), "attention": "P / dS and Q / K / V / dO as two rounded bf16 pieces (head_dim <= 64)",
-                          "what": "products on the bf16 matrix pipe take each f32 operand as N bf16 pieces: 3 = exact to f32 rounding (six piece "
-                                  "products), 2 = two pieces both rounded to nearest, 16 significant bits per operand (three piece products).  "
-                                  "Default 2; GAOT_GEMM_PIECES=3 + gaot_debug_set_attention_{p,operand}_pieces(33, 3) give the exact mode.  "
-                                  "rel_l2_vs_oracle.vs_float64_oracle measures what it costs: the two-piece path stays closer to float64 than the "
-                                  "reference's own fp32 arithmetic on the output, and 15x under the 1e-4 gradient bar"},
+                          "pieces": dict(_ops._PIECES), "mode": _ops.precision() if args.dtype != "bf16" else "bf16 (one piece in the tile GEMMs)",
+                          "what": "products on the bf16 matrix pipe take each f32 operand as N bf16 pieces: 3 (default, the headline) = exact to f32 "
+                                  "rounding, six piece products -- the fp32 arithmetic of the reference (base_trainer.py:63-68); 2 = two pieces both rounded "
+                                  "to nearest, 16 significant bits (three piece products): reported under `variants.bf16x2`, never as `value`"},
             "data": "synthetic (uniform-random 16384-point 2-D mesh in [-1,1]^2, N(0,1) fields, random-init weights)",
             "config": {"workload": "BASELINE configs[1]: Poisson-Gauss-shaped 2D, 16384 nodes/mesh, batch 8 per GPU, fx mode; "
                                    "example model latent 64x64, C=64, patch 2, transformer 256x3, 8 heads",
                        "params": n_params, "global_batch": BATCH * world, "parallelism": f"dp{world}",
                        "step": "fwd + MSE + bwd + AdamW" + (" + staged flat-grad RCCL all-reduce (one async slice per stage group)" if world > 1 else ""),
+                       "h2d": "excluded: the timed region replays one batch bound in HBM ahead of time (TrainStep.bind); nothing is uploaded or "
+                              "re-copied per step (the PCIe-inclusive drop-in rate is `reference_loop`)",
                        "hipgraph": ts.use_graph, "staged_backward_phases": ts.bucket.n_phases, "stage_groups": ts.stage_groups, "final_loss": loss},
-            "roofline": {"bound": "mfma", "kernel": "gaot_gemm_f32 MFMA tile kernels, every launch of one step: gemm_glds_kernel (v_mfma_f32_32x32x2_f32) and "
-                                   "gemm_split_kernel / gemm_tn_grouped_kernel (f32 operands as 2 rounded bf16 pieces, 3 x v_mfma_f32_32x32x16_bf16 per product; "
-                                   "3 exact pieces / 6 products with GAOT_GEMM_PIECES=3)",
-                         "peak_note": "peak = dense f32 matrix rate (dtype f32); the split-bf16 kernels' own ceiling is bf16 dense / 3 = 833 TFLOP/s of f32 "
-                                      "work with two pieces (/ 6 = 419 with three)",
-                         "frac_of_bf16_pipe": roof["tflops"] * (3 if _ops._PIECES["nt"] == 2 else 6) / 2500.0,
-                         "split_bf16_launches_per_step": roof["split_launches"],
-                         "achieved": roof["tflops"], "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                         "frac": roof["tflops"] / PEAK_F32_MATRIX_TFLOPS, "traffic": traffic,
+            "roofline": {"bound": "mfma", "pipe": "bf16 mfma (v_mfma_f32_32x32x16_bf16)",
+                         "kernel": "every launch of one step on the bf16 matrix pipe behind gaot_gemm_f32: gemm_split_kernel (NT / NN tiles) and the grouped "
+                                   "weight-gradient launch gemm_tn_grouped_kernel; each f32 operand as "
+                                   f"{ {'f32': 'three exact bf16 pieces, six piece products', 'bf16x2': 'two rounded bf16 pieces, three piece products', 'bf16': 'one bf16 piece, one product'}[args.dtype] }",
+                         "achieved": roof["piece_tflops"], "peak": PEAK_BF16_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                         "frac": roof["piece_tflops"] / PEAK_BF16_MATRIX_TFLOPS,
+                         "achieved_note": "piece-product FLOPs ISSUED on the matrix pipe (2MNK x piece products per product) / event-timed duration",
+                         "f32_equivalent_tflops": roof["tflops"], "f32_equivalent_frac_of_f32_matrix_peak": roof["tflops"] / PEAK_F32_MATRIX_TFLOPS,
+                         "traffic": traffic,
                          "traffic_note": "HBM bytes per launch, PMC FETCH_SIZE(x2, gfx950)+WRITE_SIZE, separate --pmc passes over the same "
                                          f"launches (eager step): {traffic_src}",
                          "algorithmic_bytes_per_launch": roof["alg_bytes_per_launch"],
-                         "launches_per_step": roof["launches"], "gflop_per_step": roof["flops"] / 1e9,
+                         "launches_per_step": roof["launches"], "gflop_per_step": roof["flops"] / 1e9, "piece_gflop_per_step": roof["piece_flops"] / 1e9,
                          "kernel_ms_per_step": roof["ms"], "avg_launch_us": 1e3 * roof["ms"] / max(1, roof["launches"]),
+                         "f32_mfma_tiles": {"launches_per_step": roof["f32_mfma_launches"], "ms_per_step": roof["f32_mfma_ms"], "gflop_per_step": roof["f32_mfma_gflop"],
+                                            "note": "products too small / narrow for the split tiles run on v_mfma_f32_32x32x2_f32 (157.3 TFLOP/s dense): not part of `achieved`"},
                          "skinny_valu_launches_per_step": roof["skinny_launches"], "all_gemm_entry_ms_per_step": roof["all_gemm_ms"]},
             "roofline_hbm": {"bound": "hbm", "kernel": "fused integral-transform kernels of one step (csrc/gno.hip, gno_ep.hip): lift_gather_reduce, "
                                                         "lift_edge_grad, proj_fwd_bin, proj_edge_grad + proj_gather_t (row-parallel forms: the bench "
@@ -668,8 +716,8 @@ def main():
                              "edges": {"encoder": Ee, "decoder": Ed}},
             "roofline_step": {"t_mfma_ideal_ms": t_mfma_ideal, "t_hbm_ideal_ms": t_hbm_ideal,
                               "achieved": max(t_mfma_ideal, t_hbm_ideal) / ms_step,
-                              "note": "SURVEY 8d: max(t_HBM, t_MFMA)_ideal / t_measured with 259 GFLOP and ~1.31 GB of algorithmic work per "
-                                      "8-sample step against 157.3 TFLOP/s (f32 matrix) and 8 TB/s"},
+                              "note": "SURVEY 8d: max(t_HBM, t_MFMA)_ideal / t_measured with 259 GFLOP (x piece products per product, on the bf16 "
+                                      "matrix pipe at 2500 TFLOP/s) and ~1.31 GB of algorithmic work per 8-sample step at 8 TB/s"},
         }
         if comm is not None:
             line["comm"] = comm
@@ -687,14 +735,17 @@ def main():
         if world == 1 and not args.no_configs:
             del ts
             line["configs"] = secondary_configs(dev, oracle=not args.no_cpu_baseline)
-        if world == 1 and not args.no_configs:
-            line["exact_products"] = exact_products_rate(dev)
-            line["exact_products"]["headline_speedup"] = line["value"] / line["exact_products"]["value"]
         if world == 1 and not args.no_reference_loop:
             line["reference_loop"] = reference_loop_rate(dev)
             line["reference_loop"]["frac_of_headline"] = line["reference_loop"]["value"] / line["value"]
+        ref64 = None
         if want_cpu:
-            line["cpu_baseline"], line["rel_l2_vs_oracle"] = cpu_baseline(sd0, (lat, x, p, t), hip0)
+            line["cpu_baseline"], line["rel_l2_vs_oracle"], ref64 = cpu_baseline(sd0, (lat, x, p, t), hip0)
+        if world == 1 and not args.no_variants and args.dtype == "f32":
+            # narrower arithmetic than the reference's fp32: labelled variants next to the headline, each with its own error vs float64
+            line["variants"] = {nm: variant_rate(dev, nm, ref64) for nm in ("bf16x2", "bf16")}
+            for v in line["variants"].values():
+                v["speedup_vs_headline"] = v["value"] / line["value"]
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -213,7 +213,7 @@ def _capture(model, latent, xcoord, pndata, condition) -> _Entry:
         for v, g in zip(views, gs):
             if g is None:
                 v.zero_()
-            elif g.data_ptr() != v.data_ptr() and not ops.deferred_dest(v.data_ptr()):
+            elif g.data_ptr() != v.data_ptr() and not ops.deferred_dest(v.data_ptr(), v.numel() * 4):
                 v.copy_(g)          # (a slice the grouped launches wrote is final already: ops._DEFERRED_DESTS)
 
     saved_slots = dict(ops._GRAD_SLOTS)

@@ -2342,16 +2342,17 @@ static int g_attn_split = 1;     // head_dim 32: 1 = split-bf16 kernels (default
 // oracle evaluated in float64 (tools/grad_errors.py): output 1.25e-7 with either forward, worst gradient tensor 7.6e-7 (q_proj of the
 // middle layer) with either; the kernel alone is 2.2e-6 off float64 instead of 2.4e-7 on random data -- a rounding error of the
 // probabilities, which sum to one and average out over the keys.  33 / 32 / 23: A/B and tests.
-static int g_attn_pp = 22;
+// -1 (default): follow the call's `pieces` argument (3 -> 33, 2 -> 22); anything else overrides every call (A/B runs, tools)
+static int g_attn_pp = -1;
 extern "C" int gaot_debug_set_attention_p_pieces(int n) {
     const int old = g_attn_pp;
-    g_attn_pp = (n == 33 || n == 22 || n == 23 || n == 32) ? n : (n == 3 ? 33 : 22);
+    g_attn_pp = (n == 33 || n == 22 || n == 23 || n == 32) ? n : (n == 3 ? 33 : (n == 2 ? 22 : -1));
     return old;
 }
 // pieces of the Q / K / V / dO operands in the same kernels (with two-piece P / dS only): 2 (default) = two rounded pieces, three piece
 // products per k-step in every product of the kernel (forward 11 -> 6 MFMAs per k-step pair, backward 27 -> 15); 3 = exact three-way splits
-static int g_attn_op = 2;
-extern "C" int gaot_debug_set_attention_operand_pieces(int n) { const int old = g_attn_op; g_attn_op = n == 3 ? 3 : 2; return old; }
+static int g_attn_op = -1;       // -1 (default): follow the call's `pieces` argument
+extern "C" int gaot_debug_set_attention_operand_pieces(int n) { const int old = g_attn_op; g_attn_op = n == 3 ? 3 : (n == 2 ? 2 : -1); return old; }
 static int g_attn_tr = 1;        // 1 (default): the two-piece 8-wave backward takes its transposed operands through transposing LDS reads
 extern "C" int gaot_debug_set_attention_tr(int on) { const int old = g_attn_tr; g_attn_tr = on ? 1 : 0; return old; }
 static int g_attn_pipe = 0;      // 1 = the software-pipelined 8-wave forward for S % 64 == 0 (same speed as the plain one since both keep the
@@ -2361,8 +2362,11 @@ extern "C" int gaot_debug_set_attention_split(int on) { const int old = g_attn_s
 
 extern "C" int gaot_attention_fwd(const float* q, const float* k, const float* v, int64_t ldq, int64_t ldk, int64_t ldv,
                                   int32_t B, int32_t S, int32_t H, int32_t Hkv, int32_t head_dim, float* o, int64_t ldo,
-                                  float* lse, gaot_stream_t stream) {
+                                  float* lse, int32_t pieces, gaot_stream_t stream) {
     GAOT_REQUIRE(q && k && v && o && lse, "attention_fwd: null pointer");
+    GAOT_REQUIRE(pieces == 0 || pieces == 2 || pieces == 3, "attention_fwd: pieces %d not in {0, 2, 3}", pieces);
+    const int g_attn_pp = ::g_attn_pp >= 0 ? ::g_attn_pp : (pieces == 2 ? 22 : 33);
+    const int g_attn_op = ::g_attn_op >= 0 ? ::g_attn_op : (pieces == 2 ? 2 : 3);
     GAOT_REQUIRE(B > 0 && S > 0 && H > 0 && Hkv > 0 && H % Hkv == 0, "attention_fwd: bad sizes B=%d S=%d H=%d Hkv=%d", B, S, H, Hkv);
     GAOT_REQUIRE(head_dim > 0 && head_dim <= 128, "attention_fwd: head_dim %d not in 1..128", head_dim);
     AttnArgs a = {};
@@ -2489,8 +2493,11 @@ extern "C" int64_t gaot_attention_bwd_workspace(int32_t B, int32_t S, int32_t H,
 extern "C" int gaot_attention_bwd(const float* q, const float* k, const float* v, int64_t ldq, int64_t ldk, int64_t ldv,
                                   const float* o, const float* dout, int64_t ldo, const float* lse, int32_t B, int32_t S,
                                   int32_t H, int32_t Hkv, int32_t head_dim, float* dq, float* dk, float* dv, int64_t lddq,
-                                  int64_t lddk, int64_t lddv, float* workspace, gaot_stream_t stream) {
+                                  int64_t lddk, int64_t lddv, float* workspace, int32_t pieces, gaot_stream_t stream) {
     GAOT_REQUIRE(q && k && v && o && dout && lse && dq && dk && dv && workspace, "attention_bwd: null pointer");
+    GAOT_REQUIRE(pieces == 0 || pieces == 2 || pieces == 3, "attention_bwd: pieces %d not in {0, 2, 3}", pieces);
+    const int g_attn_pp = ::g_attn_pp >= 0 ? ::g_attn_pp : (pieces == 2 ? 22 : 33);
+    const int g_attn_op = ::g_attn_op >= 0 ? ::g_attn_op : (pieces == 2 ? 2 : 3);
     GAOT_REQUIRE(B > 0 && S > 0 && H > 0 && Hkv > 0 && H % Hkv == 0, "attention_bwd: bad sizes");
     GAOT_REQUIRE(head_dim > 0 && head_dim <= 128, "attention_bwd: head_dim %d not in 1..128", head_dim);
     AttnArgs a = {};

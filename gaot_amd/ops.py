@@ -78,38 +78,62 @@ def cut(t: torch.Tensor) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------------------------
-# Precision of the products on the split-bf16 tiles (gaot_gemm_desc.pieces), per product kind:
-#   "nt": activations x weight^T (every forward Linear), "nn": dY x weight (input gradients), "tn": dY^T x X (weight gradients).
-# 3 = every fp32 operand as three bf16 pieces, six piece products (exact to fp32 rounding); 2 = two pieces, both rounded to
-# nearest, three piece products (16 significant bits per operand, half the matrix-pipe work).
-# Default 2 everywhere, measured at the bench configuration against the reference algorithm evaluated in float64 (tools/grad_errors.py):
-#   all 3: output 1.25e-7, worst gradient tensor 8.8e-7        all 2: output 3.7e-7, worst gradient tensor 4.9e-6
-# while the reference's own fp32 arithmetic is 7.1e-7 / 2.4e-4 from the same float64 result: the two-piece
-# products stay inside the reference's own rounding on the output and inside the 1e-5 / 1e-4 bars with an order of magnitude to
-# spare, and the step is 7 % faster (2.58 -> 2.39 ms).  set_gemm_pieces(3) / GAOT_GEMM_PIECES=3 restores exact products
-# (kernel-level tests pin both).
+# Precision of the products on the bf16 matrix pipe (gaot_gemm_desc.pieces and the `pieces` argument of the attention / kernel-MLP
+# entry points), per product kind:
+#   "nt": activations x weight^T (every forward Linear), "nn": dY x weight (input gradients), "tn": dY^T x X (weight gradients),
+#   "attn": Q / K / V / dO and the probabilities P / dS of the flash-attention kernels, "kmlp": the fused row-wise MLP kernels behind
+#   a smooth activation (ReLU chains always keep exact products, _KernelMLP._pieces).
+# 3 = every fp32 operand as THREE bf16 pieces, six piece products: exact to fp32 rounding -- the arithmetic of the reference, which
+#     computes in fp32 end to end (base_trainer.py:63-68).  THE DEFAULT ("f32").
+# 2 = two pieces, both rounded to nearest, three piece products: 16 significant bits per operand, half the matrix-pipe work
+#     ("bf16x2", opt-in: set_precision("bf16x2") / GAOT_PRECISION=bf16x2).  Measured at the bench configuration against the
+#     reference algorithm evaluated in float64 (tools/grad_errors.py): exact products: output 1.25e-7, worst gradient tensor 8.8e-7;
+#     two pieces: output 4.3e-7, worst gradient tensor 6.6e-6 (the fp32 reference itself: 7.1e-7 / <= 4.4e-7 outside the four
+#     statistics-gated tensors): inside the 1e-5 output bar, but 4-15x further from float64 than the reference's fp32 on gradients.
 # --------------------------------------------------------------------------------------------
-_PIECES = {"nt": 2, "nn": 2, "tn": 2}          # the fused row-wise MLP kernels (kernel_mlp.hip) follow "nt"
+_PIECES = {"nt": 3, "nn": 3, "tn": 3, "attn": 3, "kmlp": 3}
+_PRECISIONS = {"f32": 3, "bf16x2": 2}
 
 
-def set_gemm_pieces(nt: Optional[int] = None, nn: Optional[int] = None, tn: Optional[int] = None) -> dict:
-    """pieces per operand (2 or 3) for the three product kinds; one argument sets all three.  Returns the previous setting."""
+def set_gemm_pieces(all: Optional[int] = None, *, nt: Optional[int] = None, nn: Optional[int] = None, tn: Optional[int] = None,
+                    attn: Optional[int] = None, kmlp: Optional[int] = None) -> dict:
+    """pieces per operand (2 or 3) per product kind.  The positional argument sets the three GEMM kinds (nt, nn, tn); keywords set
+    exactly the kind they name.  Returns the previous setting (a dict that can be passed back as keywords)."""
     old = dict(_PIECES)
-    if nt is not None and nn is None and tn is None:
-        nn = tn = nt
-    for k, v in (("nt", nt), ("nn", nn), ("tn", tn)):
+    if all is not None:
+        nt = all if nt is None else nt
+        nn = all if nn is None else nn
+        tn = all if tn is None else tn
+    for k, v in (("nt", nt), ("nn", nn), ("tn", tn), ("attn", attn), ("kmlp", kmlp)):
         if v is not None:
             if v not in (2, 3):
-                raise ValueError(f"gemm pieces must be 2 or 3, got {v}")
+                raise ValueError(f"pieces must be 2 or 3, got {v}")
             _PIECES[k] = v
     return old
 
 
-if os.environ.get("GAOT_GEMM_PIECES"):          # "3", "2" or "nt,nn,tn"
+def set_precision(name: str) -> dict:
+    """"f32" (default): exact three-piece products everywhere; "bf16x2": two rounded bf16 pieces per operand everywhere (GEMM tiles,
+    grouped weight gradients, attention, the GELU kernel MLP).  Storage and accumulation are fp32 either way.  Returns the previous
+    per-kind setting (restore with set_gemm_pieces(**old))."""
+    if name not in _PRECISIONS:
+        raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}, got {name!r}")
+    v = _PRECISIONS[name]
+    return set_gemm_pieces(nt=v, nn=v, tn=v, attn=v, kmlp=v)
+
+
+def precision() -> str:
+    vals = set(_PIECES.values())
+    return "f32" if vals == {3} else ("bf16x2" if vals == {2} else "mixed")
+
+
+if os.environ.get("GAOT_PRECISION"):
+    set_precision(os.environ["GAOT_PRECISION"])
+if os.environ.get("GAOT_GEMM_PIECES"):          # tools: "3", "2" or "nt,nn,tn" (the GEMM kinds only)
     _parts = [int(t) for t in os.environ["GAOT_GEMM_PIECES"].split(",")]
     if len(_parts) not in (1, 3):
         raise ValueError("GAOT_GEMM_PIECES: one value or nt,nn,tn")
-    set_gemm_pieces(*_parts)
+    set_gemm_pieces(*_parts) if len(_parts) == 1 else set_gemm_pieces(nt=_parts[0], nn=_parts[1], tn=_parts[2])
 
 
 # --------------------------------------------------------------------------------------------
@@ -276,7 +300,8 @@ def matmul_tn(g: torch.Tensor, x2: torch.Tensor, out: Optional[torch.Tensor] = N
     M, N = g.shape
     K = x2.shape[1]
     assert x2.shape[0] == M
-    if final and out is not None and _WGRAD_DEPTH[0] > 0 and _wgrad_groupable(g, lda, x2, ldb, out, colsum_out, N, K, M):
+    if (final and out is not None and _WGRAD_DEPTH[0] > 0 and not _slot_shared(out) and not _slot_shared(colsum_out)
+            and _wgrad_groupable(g, lda, x2, ldb, out, colsum_out, N, K, M)):
         # a caller-provided destination (the parameter's slice of the flat gradient buffer) inside a deferral scope: the product
         # joins the grouped launch at the end of the backward pass (flush_wgrad); operands stay alive in the queue until then
         # the queue keeps ALIASES, not the tensor objects handed back to autograd (an extra reference to those makes AccumulateGrad clone)
@@ -302,6 +327,7 @@ _WGRAD_DEPTH = [0]
 _WGRAD_QUEUE: list = []
 _COLSUM_QUEUE: list = []
 _WGRAD_COUNTERS: dict = {}
+_WGRAD_COUNTERS_RETIRED: list = []
 _WGRAD_GROUPED = os.environ.get("GAOT_WGRAD_GROUPED", "1") != "0"        # A/B switch
 
 
@@ -355,7 +381,9 @@ def wgrad_launch(items) -> None:
     if ctr is None or ctr.numel() < cnt.value:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("grouped weight gradients: the ticket counters must exist before graph capture (run one eager step first)")
-        ctr = torch.zeros(max(8192, 2 * cnt.value), device=dev, dtype=torch.int32)
+        if ctr is not None:
+            _WGRAD_COUNTERS_RETIRED.append(ctr)      # a captured graph may hold its address (and zero it at every replay): keep it alive
+        ctr = torch.zeros(max(65536, 4 * cnt.value), device=dev, dtype=torch.int32)
         _WGRAD_COUNTERS[key] = ctr
     L.check(lib.gaot_gemm_tn_grouped(arr, n, _PIECES["tn"], _p(ws), _p(ctr), _stream()), "gaot_gemm_tn_grouped")
 
@@ -388,7 +416,7 @@ def colsum(x2: torch.Tensor, out: Optional[torch.Tensor] = None, final: bool = F
     M, N = x2.shape
     lib = L.load()
     if (final and out is not None and _WGRAD_DEPTH[0] > 0 and _WGRAD_GROUPED and N % 4 == 0 and ld % 4 == 0 and M <= 8192
-            and not ((x2.data_ptr() | out.data_ptr()) & 15)):
+            and not ((x2.data_ptr() | out.data_ptr()) & 15) and not _slot_shared(out)):
         if out.is_contiguous():
             _COLSUM_QUEUE.append((x2, ld, out.detach(), M, N, 0, 0))
             _note_deferred(out.view(-1))
@@ -439,6 +467,28 @@ def release_grad_slots():
     for s in _GRAD_SLOTS.values():
         s[1] = False
     _DEFERRED_DESTS.clear()
+    _SHARED_SLOTS.clear()
+
+
+# Slots of parameters used MORE THAN ONCE in a forward pass (the reference shares agno / geoembed / lifting / recovery / projection
+# weights across all `scales`, magno.py:277-300): the first use holds the slot and writes its contribution in place, every further
+# use returns an ordinary gradient tensor and autograd sums them -- so the slot is READ (by that sum) before the backward pass has
+# ended and must never be the destination of a deferred launch.  _claim() records the slice of a parameter claimed twice; matmul_tn /
+# colsum drop `final` for destinations inside such a slice (decided at backward time: every forward use precedes the backward pass,
+# and the decision is the same at capture and at replay).
+_SHARED_SLOTS: list = []
+
+
+def _mark_shared(slot: torch.Tensor) -> None:
+    lo = slot.data_ptr()
+    _SHARED_SLOTS.append((lo, lo + slot.numel() * 4))
+
+
+def _slot_shared(t: Optional[torch.Tensor]) -> bool:
+    if t is None or not _SHARED_SLOTS:
+        return False
+    p_ = t.data_ptr()
+    return any(lo <= p_ < hi for lo, hi in _SHARED_SLOTS)
 
 
 # destinations (address ranges inside the flat gradient buffer) that a deferred, grouped launch writes at the END of the backward
@@ -448,8 +498,10 @@ def release_grad_slots():
 _DEFERRED_DESTS: list = []
 
 
-def deferred_dest(ptr: int) -> bool:
-    return any(lo <= ptr < hi for lo, hi in _DEFERRED_DESTS)
+def deferred_dest(ptr: int, nbytes: int = 4) -> bool:
+    """does [ptr, ptr + nbytes) -- a parameter's whole gradient slice -- overlap a destination of a deferred launch?  (A slice whose
+    column blocks were handed out by split_cols may be deferred in part only: the slice, not its base address, is what counts.)"""
+    return any(lo < ptr + nbytes and ptr < hi for lo, hi in _DEFERRED_DESTS)
 
 
 def _note_deferred(t: torch.Tensor) -> None:
@@ -461,7 +513,10 @@ def _claim(w) -> Optional[torch.Tensor]:
     if w is None or not w.requires_grad:
         return None
     s = _GRAD_SLOTS.get(id(w))
-    if s is None or s[1] or s[2] is not w or s[0].device != w.device:
+    if s is None or s[2] is not w or s[0].device != w.device:
+        return None
+    if s[1]:
+        _mark_shared(s[0])       # second use in this forward pass: the holder of the slot must not defer (see _SHARED_SLOTS)
         return None
     s[1] = True
     return s[0]
@@ -478,7 +533,10 @@ def _claim_view(t) -> Optional[torch.Tensor]:
     ptr, n = t.data_ptr(), t.numel()
     for s in _GRAD_SLOTS.values():
         p = s[2]
-        if (not s[1]) and p.data_ptr() == ptr and p.numel() == n and s[0].device == t.device and t.is_contiguous():
+        if p.data_ptr() == ptr and p.numel() == n and s[0].device == t.device and t.is_contiguous():
+            if s[1]:
+                _mark_shared(s[0])
+                return None
             s[1] = True
             return s[0]
     return None
@@ -907,10 +965,10 @@ class _KernelMLP(torch.autograd.Function):
 
     @staticmethod
     def _pieces(act) -> int:
-        """two rounded pieces per operand (the "nt" setting) behind a smooth activation; EXACT products behind ReLU: a ReLU chain's
+        """the "kmlp" setting behind a smooth activation; EXACT products behind ReLU whatever the setting: a ReLU chain's
         gradient is discontinuous in its pre-activations -- at 5e-6 of relative error a few of 10^6 gates flip and the first layers'
         gradients move by 2e-3 (measured, tools/kmlp_ab.py), where the exact products move them by 3e-7"""
-        return _PIECES["nt"] if act == L.ACT_GELU else 3
+        return _PIECES["kmlp"] if act == L.ACT_GELU else 3
 
     @staticmethod
     def forward(ctx, x, n, act, *wb):
@@ -1677,7 +1735,7 @@ class _Attention(torch.autograd.Function):
                                                    _p(seed), _stream()), "gaot_attention_fwd_dropout")
             _LAST_DROPOUT_SEED[0] = seed
         else:
-            L.check(lib.gaot_attention_fwd(_p(q), _p(kq), _p(vq), W, W, W, B, S, H, Hkv, D, _p(o), H * D, _p(lse), _stream()),
+            L.check(lib.gaot_attention_fwd(_p(q), _p(kq), _p(vq), W, W, W, B, S, H, Hkv, D, _p(o), H * D, _p(lse), _PIECES["attn"], _stream()),
                     "gaot_attention_fwd")
         ctx.save_for_backward(qkv, o, lse, seed if seed is not None else qkv.new_empty(0))
         ctx.dims = (B, S, H, Hkv, D, float(p_drop))
@@ -1706,7 +1764,7 @@ class _Attention(torch.autograd.Function):
                                                    p_drop, _p(seed), _stream()), "gaot_attention_bwd_dropout")
         else:
             L.check(lib.gaot_attention_bwd(_p(flat), _p(flat[H * D:]), _p(flat[(H + Hkv) * D:]), W, W, W, _p(o), _p(do), H * D,
-                                           _p(lse), B, S, H, Hkv, D, _p(dflat), _p(dk_t), _p(dv_t), W, ldk, ldv, _p(ws), _stream()),
+                                           _p(lse), B, S, H, Hkv, D, _p(dflat), _p(dk_t), _p(dv_t), W, ldk, ldv, _p(ws), _PIECES["attn"], _stream()),
                     "gaot_attention_bwd")
         if Hkv != H:
             r = H // Hkv

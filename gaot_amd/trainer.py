@@ -118,7 +118,7 @@ class FlatGradBucket:
                 self._dirty[i] = True
                 # a slice written by a deferred, grouped launch is already final: what autograd holds for it may be a copy taken
                 # BEFORE that launch ran (ops._DEFERRED_DESTS)
-                if p.grad.data_ptr() != v.data_ptr() and not (deferred is not None and deferred(v.data_ptr())):
+                if p.grad.data_ptr() != v.data_ptr() and not (deferred is not None and deferred(v.data_ptr(), v.numel() * 4)):
                     srcs.append(p.grad)
                     dsts.append(v)
             p.grad = v
@@ -384,8 +384,8 @@ class TrainStep:
             self.stage_groups = [list(range(k, min(k + 2, n_ph))) for k in range(0, n_ph, 2)]
         else:
             self.stage_groups = [list(range(n_ph - 1)), [n_ph - 1]] if n_ph > 1 else [[0]]
-        if [k for g in self.stage_groups for k in g] != list(range(n_ph if self.staged else 1)):
-            raise ValueError(f"stage_groups must list the phases 0..{n_ph - 1} in order, got {self.stage_groups}")
+        if any(len(g) == 0 for g in self.stage_groups) or [k for g in self.stage_groups for k in g] != list(range(n_ph if self.staged else 1)):
+            raise ValueError(f"stage_groups must list the phases 0..{n_ph - 1} in order in non-empty groups, got {self.stage_groups}")
         dev = self.bucket.flat.device
         on_gpu = dev.type == "cuda"
         if on_gpu:

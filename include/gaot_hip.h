@@ -253,10 +253,12 @@ int gaot_swiglu_bwd(const float* u, const float* dg, int32_t M, int32_t F, float
 /* softmax attention, no mask, scale 1/sqrt(head_dim) (attn.py:98-116, F.scaled_dot_product_attention).
  * q/k/v are strided views: element (b,s,h,d) at ptr[(b*S+s)*ld + h*head_dim + d]; kv head = h / (H/Hkv).
  * o has the same addressing with ldo.  lse[B,H,S] (natural-log-sum-exp of scaled scores) saved for bwd.
- * head_dim <= 128, S arbitrary (head_dim <= 64: split-bf16 kernels where they apply; above: fp32 MFMA). */
+ * head_dim <= 128, S arbitrary (head_dim <= 64: split-bf16 kernels where they apply; above: fp32 MFMA).
+ * pieces: precision of the products on the bf16 matrix pipe, as gaot_gemm_desc.pieces: 0 / 3 = every fp32 operand (Q, K, V, dO and the
+ * probabilities P / dS) as three bf16 pieces, exact to fp32 rounding; 2 = two rounded pieces each (16 significant bits). */
 int gaot_attention_fwd(const float* q, const float* k, const float* v, int64_t ldq, int64_t ldk, int64_t ldv,
                        int32_t B, int32_t S, int32_t H, int32_t Hkv, int32_t head_dim,
-                       float* o, int64_t ldo, float* lse, gaot_stream_t stream);
+                       float* o, int64_t ldo, float* lse, int32_t pieces, gaot_stream_t stream);
 /* workspace floats needed by gaot_attention_bwd */
 /* attention dropout (attn.py:110-114: dropout_p of F.scaled_dot_product_attention while training): the softmax output is
  * multiplied by keep(b,h,q,k) / (1 - p) before the product with V.  keep = (splitmix64(seed + ((b*H + h)*S + q)*S + k) >> 32) <
@@ -278,7 +280,7 @@ int gaot_attention_bwd(const float* q, const float* k, const float* v, int64_t l
                        const float* o, const float* dout, int64_t ldo, const float* lse,
                        int32_t B, int32_t S, int32_t H, int32_t Hkv, int32_t head_dim,
                        float* dq, float* dk, float* dv, int64_t lddq, int64_t lddk, int64_t lddv,
-                       float* workspace, gaot_stream_t stream);
+                       float* workspace, int32_t pieces, gaot_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * reductions / layout

@@ -102,8 +102,12 @@ def c2():
     # the same step with the geometry statistics evaluated in float64 (test instrument, see OracleConfig.stats_dtype)
     ocfg64 = O.OracleConfig(**{**ocfg.__dict__, "stats_dtype": "float64"})
     loss64, grads64, new_sd64, _, pred64 = O.train_step(sd, ocfg64, batch, lr=8e-4, weight_decay=1e-5, return_pred=True)
+    # ... and the oracle evaluated in float64 END TO END (weights, batch, every intermediate): the measuring stick that separates the
+    # kernels' rounding from the fp32 reference's own
+    dbl = lambda v: v.double() if torch.is_tensor(v) and v.is_floating_point() else v
+    _, gradsd, _, _, predd = O.train_step({k: dbl(v) for k, v in sd.items()}, ocfg, {k: dbl(v) for k, v in batch.items()}, return_pred=True)
     return NS(sd=sd, lat=lat, x=x, p=p, t=t, enc=enc, dec=dec, loss=loss, grads=grads, new_sd=new_sd, pred=pred,
-              loss64=loss64, grads64=grads64, new_sd64=new_sd64, pred64=pred64)
+              loss64=loss64, grads64=grads64, new_sd64=new_sd64, pred64=pred64, gradsd=gradsd, predd=predd)
 
 
 def _c2_model(c2):
@@ -167,6 +171,58 @@ def test_c2_bench_config_forward_loss_grads_vs_oracle(c2, mode):
             ops.set_gemm_mode(old_g)
         if old_a is not None:
             ops.set_attention_split(old_a)
+
+
+def test_c2_default_gradients_stay_within_the_reference_fp32_rounding(c2):
+    """What "gradient parity" means for the shipped default, derived from the reference instead of a free 1e-4: measured against the
+    oracle in float64 end to end, EVERY gradient tensor of the default path (exact three-piece products) is at most 3x as far from
+    float64 as the reference's own fp32 arithmetic (the fp32 oracle) is on that tensor, plus 1e-6 (tensors the fp32 oracle happens to
+    hit exactly); the output within 2e-6.  Through the TRAINING path (TrainStep: grouped weight gradients, deferred column sums).
+    The opt-in bf16x2 precision does NOT meet this bar (4-15x the reference's distance, see test_c2_bf16x2_variant_error_budget)."""
+    from gaot_amd import ops
+    from gaot_amd.trainer import TrainStep
+    assert ops.precision() == "f32"
+    m = _c2_model(c2)
+    ts = TrainStep(m, lr=8e-4, weight_decay=1e-5, use_graph=False)
+    ts.bind(c2.p.to(dev()), c2.t.to(dev()), latent_tokens_coord=c2.lat.to(dev()), xcoord=c2.x.to(dev()))
+    with torch.no_grad():
+        pred = m(pndata=c2.p.to(dev()), latent_tokens_coord=c2.lat.to(dev()), xcoord=c2.x.to(dev()))
+    ts._forward_backward()
+    torch.cuda.synchronize()
+    hip = grad_errors(m, c2.gradsd)
+    topd = max(float(g.norm()) for g in c2.gradsd.values())
+    own = {k: float((c2.grads[k].double() - g).norm()) / max(float(g.norm()), 1e-3 * topd) for k, g in c2.gradsd.items()}
+    e_out = float((pred.detach().cpu().double() - c2.predd).norm() / c2.predd.norm())
+    ratio = {k: hip[k] / (3 * own[k] + 1e-6) for k in hip}
+    worst = max(ratio, key=ratio.get)
+    wk = max(hip, key=hip.get)
+    print(f"[C2 default vs float64 oracle] out {e_out:.2e}; worst gradient tensor {hip[wk]:.2e} ({wk}; fp32 oracle there {own[wk]:.2e}); "
+          f"tightest tensor {worst}: {hip[worst]:.2e} against a bar of {3 * own[worst] + 1e-6:.2e}")
+    assert e_out < 2e-6, e_out
+    assert ratio[worst] <= 1.0, (worst, hip[worst], own[worst])
+    ts.bucket.clear()
+
+
+def test_c2_bf16x2_variant_error_budget(c2, bf16x2):
+    """the opt-in two-piece precision at the bench configuration, against the float64 oracle: output within the 1e-5 bar of north_star
+    (measured 4.3e-7), every gradient tensor within 2e-5 (measured 6.6e-6) -- and it is NOT at the fp32 level: its worst tensor is more
+    than 2e-6 off (the default: < 1e-6).  bench.py reports it as `variants.bf16x2` with these numbers, never as the headline."""
+    from gaot_amd import ops
+    from gaot_amd.trainer import TrainStep
+    assert ops.precision() == "bf16x2"
+    m = _c2_model(c2)
+    ts = TrainStep(m, lr=8e-4, weight_decay=1e-5, use_graph=False)
+    ts.bind(c2.p.to(dev()), c2.t.to(dev()), latent_tokens_coord=c2.lat.to(dev()), xcoord=c2.x.to(dev()))
+    with torch.no_grad():
+        pred = m(pndata=c2.p.to(dev()), latent_tokens_coord=c2.lat.to(dev()), xcoord=c2.x.to(dev()))
+    ts._forward_backward()
+    torch.cuda.synchronize()
+    hip = grad_errors(m, c2.gradsd)
+    wk = max(hip, key=hip.get)
+    e_out = float((pred.detach().cpu().double() - c2.predd).norm() / c2.predd.norm())
+    print(f"[C2 bf16x2 vs float64 oracle] out {e_out:.2e}; worst gradient tensor {hip[wk]:.2e} ({wk})")
+    assert e_out < OUT_TOL and 2e-6 < hip[wk] < 2e-5, (e_out, wk, hip[wk])
+    ts.bucket.clear()
 
 
 def test_c2_radius_graph_backends_differ_only_at_the_boundary(c2):
@@ -634,6 +690,60 @@ def test_auto_graph_reference_loop_equals_eager_loop():
     assert float((wa - wb).abs().max()) < 2e-5
     assert rel_l2(ea, eb) < 1e-5
     assert rel_l2(ga, gb) < 1e-4
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_multiscale_shared_weights_with_deferred_gradients(weighted):
+    """scales = [1, 2]: the reference shares the agno / geoembed / lifting / recovery / projection weights across scales
+    (magno.py:277-300), so every such parameter is used TWICE in a forward pass.  Inside a deferral scope (TrainStep eager and graph,
+    autograph from its second step) only a parameter used exactly once may have its gradient slice written by the deferred, grouped
+    launches (ops._SHARED_SLOTS): gradients of TrainStep and of the auto-graphed plain loop must equal the plain eager backward, and
+    the multiscale forward itself is pinned by the golden cases ms_mean / ms_weighted."""
+    from gaot_amd import ops
+    from gaot_amd.model.gaot import GAOT
+    from gaot_amd.trainer import TrainStep
+    model, sd, _ = make_model(2, 1, [32, 32], C=32, hidden=128, heads=4, radius=0.08, precompute=False, seed=43, scales=[1.0, 2.0],
+                              use_scale_weights=weighted)
+    g = torch.Generator().manual_seed(43)
+    lat, x = grid([32, 32]), uniform_points(2400, 2, g)
+    p, t = torch.randn(4, 2400, 2, generator=g), torch.randn(4, 2400, 1, generator=g)
+    kw = dict(latent_tokens_coord=lat.to(dev()), xcoord=x.to(dev()))
+
+    def fresh(auto=False):
+        m = GAOT(2, 1, model_cfg(model))
+        m.load_state_dict(sd)
+        m.to(dev()).train()
+        m.auto_graph = auto
+        return m
+
+    ops.register_grad_slots([], [])
+    m0 = fresh()
+    ops.mse_loss(m0(pndata=p.to(dev()), **kw), t.to(dev())).backward()           # plain eager: no slots, no deferral
+    ref = {k: q.grad.detach().clone() for k, q in m0.named_parameters()}
+    top = max(float(v.norm()) for v in ref.values())
+    err = lambda got: max(float((got[k] - ref[k]).norm()) / max(float(ref[k].norm()), 1e-3 * top) for k in ref)
+    for graph in (False, True):
+        m = fresh()
+        ts = TrainStep(m, lr=0.0, weight_decay=0.0, use_graph=graph)
+        ts.bind(p.to(dev()), t.to(dev()), **kw)
+        if graph:
+            ts.step(); ts.step()                                               # lr = 0: weights stay; the replay's gradients land in the flat buffer
+        else:
+            ts._forward_backward()
+        torch.cuda.synchronize()
+        view_of = {id(q_): v for q_, v in zip(ts.bucket.params, ts.bucket.views)}
+        got = {k: view_of[id(q)].detach().clone() for k, q in m.named_parameters()}
+        assert err(got) < 2e-6, ("TrainStep", graph, err(got))
+        ts.bucket.clear()
+        ops.register_grad_slots([], [])
+    m = fresh(auto=True)                                                          # the reference's own loop, auto-graphed from step 2 on
+    opt = torch.optim.SGD(m.parameters(), lr=0.0)
+    for i in range(4):
+        opt.zero_grad()
+        torch.nn.functional.mse_loss(m(pndata=p.to(dev()), **kw), t.to(dev())).backward()
+        got = {k: q.grad.detach().clone() for k, q in m.named_parameters()}
+        assert err(got) < 2e-6, ("autograph", i, err(got))
+    assert len(m._auto_graph_cache) == 1
 
 
 def test_c4_ns_gauss_16k_pair_step_and_10_step_rollout_vs_oracle():

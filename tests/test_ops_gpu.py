@@ -295,16 +295,8 @@ def test_attention_fwd_bwd(B, S, H, Hkv, D):
         finally:
             _lib.load().gaot_debug_set_attention_split(old)
         assert rel(out2, ref) < 3e-6 and rel(d2.grad, r.grad) < 1e-5
-        # head_dim 32 defaults to two ROUNDED pieces of P / dS (the bars above); with exact three-way splits (33) the split kernels are
-        # as accurate as the fp32 MFMA
-        old = _lib.load().gaot_debug_set_attention_p_pieces(33)
-        try:
-            d3 = qkv.to(dev()).requires_grad_(True)
-            out3 = ops.attention(d3, H, Hkv, D)
-            out3.backward(go.to(dev()))
-        finally:
-            _lib.load().gaot_debug_set_attention_p_pieces(old)
-        assert rel(out3, ref) < 2 * rel(out2, ref) + 1e-7 and rel(d3.grad, r.grad) < 2 * rel(d2.grad, r.grad) + 1e-7
+        # the default (exact three-way splits of every operand) is as accurate as the fp32 MFMA
+        assert rel(out, ref) < 2 * rel(out2, ref) + 1e-7 and rel(d.grad, r.grad) < 2 * rel(d2.grad, r.grad) + 1e-7
         # the 256-query / 256-key workgroup variants (picked by the heuristic only when they fill the chip) forced on
         old = _lib.load().gaot_debug_set_attention_split(2)
         try:
@@ -652,13 +644,13 @@ def test_fused_kernel_mlp_matches_chain_and_float64(E, cin, n, act, cout):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,N,K", [(8192, 2048, 256), (8192, 256, 1024), (4096, 768, 256)])
-def test_gemm_two_piece_products(M, N, K):
-    """gaot_gemm_desc.pieces = 2 (the default of the model path): every operand as two bf16 pieces, both rounded to nearest
+def test_gemm_two_piece_products(M, N, K, bf16x2):
+    """gaot_gemm_desc.pieces = 2 (the opt-in "bf16x2" precision): every operand as two bf16 pieces, both rounded to nearest
     (16 significant bits, unbiased), three piece products.  On random normal data -- sums with full cancellation, the worst case for a
     per-term relative error -- the products stay within 6e-6 of float64 (measured 3-4.5e-6; the exact three-piece products: 2-5e-7), for
-    all three product kinds and the grouped weight-gradient launch; and 2 IS the default."""
+    all three product kinds and the grouped weight-gradient launch; the default (exact products, checked by the fixture) stays under 1e-6."""
     from gaot_amd import ops, _lib
-    assert ops._PIECES == {"nt": 2, "nn": 2, "tn": 2}
+    assert ops.precision() == "bf16x2"
     g = torch.Generator().manual_seed(M + N + K)
     x, w, dy = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(M, N, generator=g)
     xd, wd, dyd = x.cuda(), w.cuda(), dy.cuda()
@@ -692,14 +684,14 @@ def test_gemm_two_piece_products(M, N, K):
 
 
 @pytest.mark.gpu
-def test_attention_two_piece_default():
-    """the shipped head_dim-32 attention: P / dS and the Q / K / V / dO operands as two rounded bf16 pieces (three piece products per
+def test_attention_two_piece_variant(bf16x2):
+    """the "bf16x2" attention (`pieces` = 2 per call): P / dS and the Q / K / V / dO operands as two rounded bf16 pieces (three piece products per
     k-step in all seven products).  Random normal data (the worst case for a per-term relative error): output within 1e-5 and
     gradients within 1.5e-5 of float64 (measured 6.6e-6 / 7.9e-6; exact splits: 2.5e-7 / 4.8e-7); many equal tokens (same-signed
-    accumulation): no drift; and (22, 2) IS the default."""
+    accumulation): no drift.  No debug override is active (-1: the kernels follow the call's argument)."""
     from gaot_amd import ops, _lib
     lib = _lib.load()
-    assert lib.gaot_debug_set_attention_p_pieces(22) == 22 and lib.gaot_debug_set_attention_operand_pieces(2) == 2
+    assert lib.gaot_debug_set_attention_p_pieces(-1) == -1 and lib.gaot_debug_set_attention_operand_pieces(-1) == -1
     def run(qkv, go, H, D):
         B, S, _ = qkv.shape
         r = qkv.clone().double().requires_grad_(True)
@@ -735,13 +727,13 @@ def test_attention_two_piece_default():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("E,cin,n", [(55592, 4, 4), (5000, 6, 3), (400000, 4, 4), (600000, 4, 3)])      # 6e5 edges: more than 16 tiles per workgroup (accumulator flush)
-def test_kernel_mlp_two_piece_default(E, cin, n):
-    """the shipped kernel MLP behind GELU: two rounded bf16 pieces per operand in the forward chain, the recompute, the
+def test_kernel_mlp_two_piece_variant(E, cin, n, bf16x2):
+    """the "bf16x2" kernel MLP behind GELU: two rounded bf16 pieces per operand in the forward chain, the recompute, the
     input-gradient chain and (through bf16 planes in LDS) the weight gradient.  Random data: output within 1e-5, every parameter
     gradient within 1.5e-5 of float64 (measured 5.6e-6 / 7.6e-6 .. 9.8e-6 at 4e5 edges).  Behind ReLU the products stay EXACT
     (gates): same bars as the three-piece test."""
     from gaot_amd import ops
-    assert ops._PIECES["nt"] == 2
+    assert ops._PIECES["kmlp"] == 2
     torch.manual_seed(E + n)
     d = "cuda"
     x = torch.rand(E, cin, device=d) * 2 - 1
@@ -768,7 +760,7 @@ def test_kernel_mlp_two_piece_default(E, cin, n):
             g_again = torch.autograd.grad(ops.mlp_chain(x, ws, bs, acts), ws + bs, dk)
             assert all(torch.equal(a, b) for a, b in zip(g, g_again))         # deterministic (per-workgroup partial rows, fixed-order sums)
         else:                                # exact products whatever the setting: bit-identical to the three-piece mode
-            old = ops.set_gemm_pieces(3)
+            old = ops.set_precision("f32")
             try:
                 y3 = ops.mlp_chain(x, ws, bs, acts)
                 g3 = torch.autograd.grad(y3, ws + bs, dk)
