@@ -28,21 +28,20 @@ class GemmDesc(C.Structure):
         ("residual", _f), ("ldr", C.c_int64),
         ("split_k", C.c_int32), ("workspace", _f),
         ("colsum", _f),
-        ("b_planes", C.c_void_p), ("ld_bplanes", C.c_int64), ("b_plane_stride", C.c_int64),
         ("pieces", C.c_int32),
+        ("a_absmax", _f), ("b_absmax", _f), ("c_absmax", _f),
     ]
 
 
 class WgradItem(C.Structure):
     """gaot_wgrad_item: out[M,N] = g[K,M]^T x[K,N] (+ colsum[m] = sum_k g[k,m])"""
     _fields_ = [("g", _f), ("ldg", C.c_int64), ("x", _f), ("ldx", C.c_int64), ("out", _f), ("ldo", C.c_int64), ("colsum", _f),
-                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32)]
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("g_absmax", _f), ("x_absmax", _f)]
 
 
-class SplitItem(C.Structure):
-    """gaot_split_item: fp32 matrix -> three bf16 planes (optionally of its transpose)"""
-    _fields_ = [("src", _f), ("ld", C.c_int64), ("rows", C.c_int32), ("cols", C.c_int32), ("planes", C.c_void_p), ("ld_out", C.c_int64),
-                ("plane_stride", C.c_int64), ("transpose", C.c_int32)]
+class AbsmaxItem(C.Structure):
+    """gaot_absmax_item: out[0] = max(out[0], max |x[r * ld + c]|)"""
+    _fields_ = [("x", _f), ("ld", C.c_int64), ("rows", C.c_int32), ("cols", C.c_int32), ("out", _f)]
 
 
 class ColsumItem(C.Structure):
@@ -62,10 +61,8 @@ PROTOTYPES = {
     "gaot_debug_last_gemm_path": (C.c_int, []),
     "gaot_debug_set_gemm_glds": (C.c_int, [C.c_int]),
     "gaot_debug_set_gemm_pieces": (C.c_int, [C.c_int]),
-    "gaot_debug_set_split_persist": (C.c_int, [C.c_int]),
-    "gaot_debug_set_gemm_gsplit": (C.c_int, [C.c_int]),
-    "gaot_debug_set_gemm_planes": (C.c_int, [C.c_int]),
-    "gaot_split_planes_grouped": (C.c_int, [C.POINTER(SplitItem), C.c_int32, _s]),
+    "gaot_gemm_path": (C.c_int, [C.POINTER(GemmDesc)]),
+    "gaot_absmax_grouped": (C.c_int, [C.POINTER(AbsmaxItem), C.c_int32, _s]),
     "gaot_debug_set_wgrad_kslab": (C.c_int, [C.c_int]),
     "gaot_csr_prepare": (C.c_int, [_i, _i, C.c_int32, C.c_int32, C.c_int32, _i, _i, _i, _i, _s]),
     "gaot_csr_transpose": (C.c_int, [_i, C.c_int32, C.c_int32, _i, _i, _i, _s]),

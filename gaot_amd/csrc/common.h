@@ -103,6 +103,27 @@ __device__ __forceinline__ void split2_pair(float x0, float x1, unsigned& ph, un
     pm = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
 }
 
+// TWO fp16 pieces of sc * x, both rounded to nearest even (v_cvt_pk_f16_f32): h = rn16(sc x), r = sc x - h (exact in fp32), m = rn16(r).
+// An fp32 value has 24 significant bits, h takes 11 of them and |r| <= half an ulp of h, so r has at most 13 significant bits of which
+// m keeps 11: sc x = h + m + e with |e| <= 2^-24 |sc x| (ONE fp32 rounding; e = 0 for three values in four) -- as long as m stays a
+// NORMAL fp16 number, i.e. |sc x| >= 2^-2; below that m is subnormal and the error is absolute, <= 2^-25.  With sc = the power of two
+// that puts the operand's largest magnitude into [2^13, 2^14), every element within 2^-16 of the largest keeps full fp32 precision
+// and smaller ones are off by at most 2^-39 of the largest -- and nothing overflows (fp16 max 65 504).
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float mul_scalar(float a, float b) {
+    float r;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void split2h_pair(float x0, float x1, float sc, unsigned& ph, unsigned& pm) {
+    const f32x2 x = {mul_scalar(x0, sc), mul_scalar(x1, sc)};
+    const f16x2_t h = __builtin_convertvector(x, f16x2_t);
+    ph = __builtin_bit_cast(unsigned, h);
+    const f32x2 r = {sub_scalar(x[0], (float)h[0]), sub_scalar(x[1], (float)h[1])};
+    pm = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2_t));
+}
+
 // transposing LDS read (gfx950 ds_read_b64_tr_b16): within each 16-lane group, lane t supplies the address of 4 consecutive 16-bit
 // COLUMNS of one row and receives 4 consecutive ROWS of one column: with lane t addressing row rbase + (t >> 2), columns
 // cbase + 4 (t & 3) .. + 3 it gets rows rbase .. rbase + 3 of column cbase + t (tools/probe/tr_read.hip prints the map).  Two of them
@@ -118,6 +139,33 @@ __device__ __forceinline__ u32x4 join8(u32x2 lo, u32x2 hi) { return u32x4{lo[0],
 // (li = lane & 31, hi = lane >> 5) receives column li, rows 4 hi .. + 3
 __device__ __forceinline__ int lds_tr_lane_offset(int lane, int row_bytes) {
     return (4 * (lane >> 5) + ((lane & 15) >> 2)) * row_bytes + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+}
+
+// ---- per-tensor magnitude words for the fp16-piece products.  A "word" is GAOT_AMAX_SLOTS = 64 floats: thousands of waves of a
+// producer publish max |x| of what they stored by an atomic max on a float's bit pattern (non-negative floats order like unsigned
+// integers), each into the slot its workgroup index selects -- one address would serialise them (measured: +13 us on a 1 024-workgroup
+// launch) -- and a consumer takes the maximum of the 64 slots.  The slots are zero before the pass (ops._amax_words).
+__device__ __forceinline__ void amax_publish(float* word, float v, int lane, int slot) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    unsigned* w = reinterpret_cast<unsigned*>(word) + (slot & (GAOT_AMAX_SLOTS - 1));
+    // look first (a relaxed agent-scope load; a stale, smaller value only costs the atomic): once a slot holds a large value almost
+    // every later wave leaves without an atomic
+    if (lane == 0 && v > 0.f && __float_as_uint(v) > __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(w, __float_as_uint(v));
+}
+// (scale, 1 / scale) for an operand whose largest magnitude is the maximum of the word's slots: scale = 2^(13 - floor(log2 amax)),
+// exponent clamped to +-126 (amax = 0 or denormal: the clamp; the operand is zero or flushes to it).  NaN / inf magnitudes give a finite
+// scale: the product's NaNs come from the data itself.  Every lane of the wave must call it (cross-lane maximum).
+__device__ __forceinline__ void amax_scale(const float* word, float& sc, float& inv) {
+    unsigned b = __float_as_uint(word[threadIdx.x & (GAOT_AMAX_SLOTS - 1)]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const unsigned o = __shfl_xor(b, off, 64); b = o > b ? o : b; }
+    const int e = (int)((b >> 23) & 0xffu);                               // biased exponent of amax
+    int se = 140 - e;                                                     // 13 - (e - 127)
+    se = se > 126 ? 126 : (se < -126 ? -126 : se);
+    sc = __uint_as_float((unsigned)(127 + se) << 23);
+    inv = __uint_as_float((unsigned)(127 - se) << 23);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -342,27 +342,23 @@ extern "C" int gaot_debug_set_gemm_glds(int on) {
     gaot::set_glds_stages(on == 3 ? 3 : 2);
     return old;
 }
-namespace gaot { void set_split_persist(int n); }
-extern "C" int gaot_debug_set_split_persist(int n) { gaot::set_split_persist(n); return 0; }
-static int g_gsplit = 0;         // 1: split-eligible products run on gemm_gsplit.hip (LDS-direct, split in registers) instead of gemm_split.hip
-extern "C" int gaot_debug_set_gemm_gsplit(int on) { const int old = g_gsplit; g_gsplit = on; return old; }
 // precision override of the split tiles: 0 (default) = every call's own gaot_gemm_desc.pieces; 1 = operands rounded to bf16, one piece
 // product (bench `--dtype bf16` only); 2 / 3 = forced for A/B runs
 static int g_split_pieces = 3, g_split_pieces_forced = 0;
 extern "C" int gaot_debug_set_gemm_pieces(int n) {
     const int old = g_split_pieces_forced ? g_split_pieces : 0;
-    g_split_pieces_forced = (n == 1 || n == 2 || n == 3); g_split_pieces = g_split_pieces_forced ? n : 3;
+    g_split_pieces_forced = (n >= 1 && n <= 5); g_split_pieces = g_split_pieces_forced ? n : 3;
     return old;
 }
 int gaot_forced_pieces() { return g_split_pieces_forced ? g_split_pieces : 0; }
-static int g_use_planes = 1;     // 0: ignore gaot_gemm_desc.b_planes (A/B switch)
-extern "C" int gaot_debug_set_gemm_planes(int on) { const int old = g_use_planes; g_use_planes = on; return old; }
+
 static int g_ablate = 0;
 extern "C" int gaot_debug_set_gemm_ablate(int bits) { const int old = g_ablate; g_ablate = bits; return old; }
 static int g_tile_override = 0;   // tuning hook: 0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 128x32
 extern "C" int gaot_debug_set_gemm_tile(int cfg) { const int old = g_tile_override; g_tile_override = cfg; return old; }
 
-extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
+// dry: only decide which kernel family would serve the product (g_last_path), launch nothing
+static int gemm_run(const gaot_gemm_desc* d, gaot_stream_t stream, const bool dry) {
     GAOT_REQUIRE(d != nullptr, "gemm: null descriptor");
     GAOT_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm: M,N,K must be positive (got %d,%d,%d)", d->M, d->N, d->K);
     GAOT_REQUIRE(d->A && d->B && d->C, "gemm: A, B, C must be non-null");
@@ -389,9 +385,11 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
     if (split > 1) GAOT_REQUIRE(d->workspace != nullptr, "gemm: split_k > 1 needs a workspace");
     if (d->colsum) GAOT_REQUIRE(d->a_kmajor == 0 && d->A2 == nullptr, "gemm: colsum needs an m-major A operand (a_kmajor = 0)");
 
-    GAOT_REQUIRE(d->pieces == 0 || d->pieces == 2 || d->pieces == 3, "gemm: pieces must be 0 / 3 (exact) or 2 (two rounded pieces), got %d", d->pieces);
+    GAOT_REQUIRE(d->pieces == 0 || (d->pieces >= 2 && d->pieces <= 4), "gemm: pieces must be 0 / 3 (three bf16 pieces), 4 (two fp16 pieces) or 2 (two bf16 pieces), got %d", d->pieces);
+    GAOT_REQUIRE(d->pieces != 4 || (d->a_absmax && d->b_absmax), "gemm: pieces = 4 (fp16 pieces) needs a_absmax and b_absmax");
     // the debug override (1: `--dtype bf16` bench variant; 2 / 3 forced for A/B runs) wins over the call's own precision
-    const int pieces = g_split_pieces_forced ? g_split_pieces : (d->pieces == 2 ? 2 : 3);
+    int pieces = g_split_pieces_forced ? g_split_pieces : (d->pieces == 2 ? 2 : (d->pieces == 4 ? 4 : 3));
+    if (pieces >= 4 && !(d->a_absmax && d->b_absmax)) pieces = 3;
 
     GemmArgs a;
     a.M = d->M; a.N = d->N; a.K = d->K;
@@ -403,10 +401,7 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
     a.split_k = split; a.ktiles_per_split = cdiv(nkt, split); a.ws = d->workspace;
     a.colsum = d->colsum;
     a.ablate = g_ablate;
-    // B pre-split into bf16 planes (weights): only the split-bf16 tile kernels read them; every other path uses B itself
-    a.Bpl = nullptr; a.ld_bpl = 0; a.bpl_stride = 0;
-    const bool planes_ok = d->b_planes != nullptr && g_use_planes && pieces == 3 && !g_gsplit && aligned16(d->b_planes) &&
-                           d->ld_bplanes % 8 == 0 && d->b_plane_stride % 8 == 0 && d->K % 16 == 0;
+    a.a_amax = pieces >= 4 ? d->a_absmax : nullptr; a.b_amax = pieces >= 4 ? d->b_absmax : nullptr; a.c_amax = d->c_absmax;
     {
         auto ok4 = [](const void* ptr, long ld) { return ptr == nullptr || (aligned16(ptr) && ld % 4 == 0); };
         a.vec_epi = (a.N % 4 == 0) && aligned16(a.C) && (a.ldc % 4 == 0) && ok4(a.bias, 4) && ok4(a.rowbias, a.ld_rb) &&
@@ -426,16 +421,16 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
         a.vec_epi = 1;
         if (g_use_split == 2 || (g_use_split && nb128 >= 256)) {
             g_last_path = 3;
+            if (dry) return GAOT_OK;
             const bool big = a.M >= 256 && (g_split_bm256 == 2 || (g_split_bm256 == 1 && nb128 >= 500));
-            if (planes_ok) { a.Bpl = reinterpret_cast<const unsigned short*>(d->b_planes); a.ld_bpl = d->ld_bplanes; a.bpl_stride = d->b_plane_stride; }
-            if (g_gsplit) launch_gsplit(a, ak, bk, st, 128, pieces);
-            else launch_split(a, ak, bk, st, big && pieces != 1 ? 256 : 128, pieces);
+            launch_split(a, ak, bk, st, big && pieces != 1 ? 256 : 128, pieces);
         }
-        else { g_last_path = 1; launch_glds(a, ak, bk, nb128 >= 512 ? 1 : ((long)cdiv(a.M, 128) * cdiv(a.N, 64) >= 512 ? 2 : 3), st); }
+        else { g_last_path = 1; if (dry) return GAOT_OK; launch_glds(a, ak, bk, nb128 >= 512 ? 1 : ((long)cdiv(a.M, 128) * cdiv(a.N, 64) >= 512 ? 2 : 3), st); }
         GAOT_CHECK_LAUNCH("gaot_gemm_f32(swiglu)");
         return GAOT_OK;
     }
-    if (g_tile_override == 0 && launch_skinny(a, ak, bk, st)) {
+    if (g_tile_override == 0 && dry && skinny_would(a, ak, bk)) { g_last_path = 2; return GAOT_OK; }
+    if (g_tile_override == 0 && !dry && launch_skinny(a, ak, bk, st)) {
         g_last_path = 2;
         GAOT_CHECK_LAUNCH("gaot_gemm_f32(skinny)");
         return GAOT_OK;
@@ -457,7 +452,8 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
     // counting split-K slabs) on outputs at least one tile wide; narrower / smaller products stay on the fp32 MFMA tiles
     // two-piece products, outputs at most six 128-wide tiles across (N <= 768): the 64-row tiles win although the 128-row ones would
     // fill the chip (8192 x 768 x 256 NT: 21.7 vs 24.2 us, NN x 512 x 256: 18.6 vs 19.5; N >= 1 024: the other way round)
-    const bool prefer64 = split_ok && g_use_split == 1 && pieces == 2 && ak && cdiv(a.N, 128) <= 6 && blocks(64, 128) >= 250 && a.M >= 64 &&
+    const bool two_pl = pieces == 2 || pieces >= 4;       // two planes per operand in LDS
+    const bool prefer64 = split_ok && g_use_split == 1 && two_pl && ak && cdiv(a.N, 128) <= 6 && blocks(64, 128) >= 250 && a.M >= 64 &&
                           a.N >= 128 && a.split_k <= 1;
     const bool split128 = split_ok && g_use_split != 4 && !prefer64 &&
                           (g_use_split == 2 || (blocks(128, 128) >= 250 && a.M >= 128 && a.N >= 128 && (long)cdiv(a.M, 128) * cdiv(a.N, 128) >= 8));
@@ -465,14 +461,13 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
     // (with pre-split B planes an NN product stages B exactly like an NT one; with two-piece products the 64-row split tiles beat the
     // fp32-MFMA tiles on the NN products too: 8192 x 256 x 768 37.4 -> 25.6 us, x 512 26.5 -> 19.0, x 256 15.5 -> 12.8, tools/gemm_modes_2p.py)
     const bool split64 = split_ok && !split128 && g_use_split != 5 && g_use_split != 2 &&
-                         (g_use_split == 4 || prefer64 || ((ak && (bk || planes_ok || g_use_split == 6 || pieces == 2)) && blocks(64, 128) >= 250 && a.M >= 64 && a.N >= 128 && a.split_k <= 1));   // measured: NT +6-14 %, NN +-0
+                         (g_use_split == 4 || prefer64 || ((ak && (bk || g_use_split == 6 || two_pl)) && blocks(64, 128) >= 250 && a.M >= 64 && a.N >= 128 && a.split_k <= 1));   // measured: NT +6-14 %, NN +-0
+    if (dry) { g_last_path = (split128 || split64) ? 3 : 1; return GAOT_OK; }
     if (split128 || split64) {
         g_last_path = 3;
-        if (planes_ok) { a.Bpl = reinterpret_cast<const unsigned short*>(d->b_planes); a.ld_bpl = d->ld_bplanes; a.bpl_stride = d->b_plane_stride; }
         // 256x128 (8-wave) tiles: measured +3-7 % on the NT / TN products that still give ~200 workgroups, -2 % on NN
         const bool big = split128 && a.M >= 512 && (g_split_bm256 == 2 || (g_split_bm256 == 1 && ak == bk && blocks(256, 128) >= 190));
-        if (g_gsplit) launch_gsplit(a, ak, bk, st, split64 ? 64 : 128, pieces);
-        else launch_split(a, ak, bk, st, split64 ? 64 : (big && pieces != 1 ? 256 : 128), pieces);
+        launch_split(a, ak, bk, st, split64 ? 64 : (big && pieces != 1 ? 256 : 128), pieces);
     }
     else if (glds_ok && g_tile_override >= 0 && g_tile_override <= 3) {
         int tile = g_tile_override;
@@ -518,6 +513,17 @@ extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) {
 }
 
 
+extern "C" int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream) { return gemm_run(d, stream, false); }
+// which kernel family WOULD serve this product (as gaot_debug_last_gemm_path: 1 fp32-MFMA tiles, 2 skinny, 3 split tiles on the
+// bf16 / fp16 matrix pipe); launches nothing.  Callers use it to decide whether the fp16-piece operands' absmax words are needed.
+extern "C" int gaot_gemm_path(const gaot_gemm_desc* d) {
+    const int keep = g_last_path;
+    const int rc = gemm_run(d, nullptr, true);
+    const int path = rc == GAOT_OK ? g_last_path : -1;
+    g_last_path = keep;
+    return path;
+}
+
 // ---- grouped weight-gradient products (kernel: gemm_split.hip)
 namespace gaot { void set_tn_kslab(int k); }
 extern "C" int gaot_debug_set_wgrad_kslab(int k) { gaot::set_tn_kslab(k); return 0; }
@@ -548,9 +554,10 @@ extern "C" int64_t gaot_gemm_tn_grouped_workspace(const gaot_wgrad_item* items, 
 }
 
 extern "C" int gaot_gemm_tn_grouped(const gaot_wgrad_item* items, int32_t n, int32_t pieces, float* workspace, int32_t* counters, gaot_stream_t stream) {
-    GAOT_REQUIRE(pieces == 0 || pieces == 2 || pieces == 3, "gemm_tn_grouped: pieces must be 0 / 3 (exact) or 2 (two rounded pieces), got %d", pieces);
+    GAOT_REQUIRE(pieces == 0 || (pieces >= 2 && pieces <= 4), "gemm_tn_grouped: pieces must be 0 / 3, 4 (two fp16 pieces) or 2, got %d", pieces);
     if (gaot_forced_pieces() >= 2) pieces = gaot_forced_pieces();
     if (int rc = check_wgrad_items(items, n)) return rc;
+    if (pieces >= 4) for (int i = 0; i < n; ++i) if (!items[i].g_absmax || !items[i].x_absmax) { pieces = 3; break; }
     int cnt = 0;
     const long need = gaot_gemm_tn_grouped_workspace(items, n, &cnt);
     GAOT_REQUIRE((need == 0 || (workspace != nullptr && aligned16(workspace))) && (cnt == 0 || counters != nullptr),
@@ -561,7 +568,7 @@ extern "C" int gaot_gemm_tn_grouped(const gaot_wgrad_item* items, int32_t n, int
         const int m = n - i0 < TN_GROUP_MAX ? n - i0 : TN_GROUP_MAX;
         int c = 0;
         const long w = plan_tn_grouped(items + i0, m, nullptr, &c, nullptr);
-        launch_tn_grouped(items + i0, m, workspace + ws_off, counters + cnt_off, pieces == 2 ? 2 : 3, st);
+        launch_tn_grouped(items + i0, m, workspace + ws_off, counters + cnt_off, pieces >= 4 ? 4 : (pieces == 2 ? 2 : 3), st);
         GAOT_CHECK_LAUNCH("gaot_gemm_tn_grouped");
         ws_off += w; cnt_off += c;
     }

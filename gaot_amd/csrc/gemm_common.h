@@ -15,8 +15,9 @@ struct GemmArgs {
     int split_k; int ktiles_per_split; float* ws;
     float* colsum;          // optional (A m-major only): colsum[m] = sum_k Aop[m,k]  (bias gradient fused into dW = dY^T X)
     int tiles_m, tiles_n;
-    const unsigned short* Bpl; long ld_bpl; long bpl_stride;   // optional: B pre-split into three k-contiguous bf16 planes (gemm_split.hip BPL)
     int vec_epi;            // 1: N, ldc and every epilogue operand allow 16-byte accesses -> LDS-transposed vector epilogue
+    const float* a_amax; const float* b_amax;   // fp16-piece products (gemm_split.hip NP = 4): device words holding max |A|, max |B| (or a bound)
+    float* c_amax;          // optional: max |C| as stored, accumulated by atomic max on the float's bit pattern (zero before the launch)
     int ablate;             // tuning only (gaot_debug_set_gemm_ablate): 1 = no in-loop global loads, 2 = no LDS staging/barriers, 4 = no stores
 };
 
@@ -96,7 +97,8 @@ __device__ __forceinline__ void epilogue_store_row(const GemmArgs& p, const RowC
 // The caller must have synchronised the workgroup (smem is reused) and smem must hold NW * 32 * (WN + 4) floats.
 template <int TM, int TN, int WM, int WN>
 __device__ __forceinline__ void epilogue_vec(const GemmArgs& p, float* smem, const f32x16 (&acc)[TM][TN], int m0, int n0,
-                                         int wm, int wn, int wave, int lane, int zs = -1) {
+                                         int wm, int wn, int wave, int lane, int zs = -1, float so1 = 1.f, float so2 = 1.f) {
+    float amax = 0.f;
     const int li = lane & 31, lh = lane >> 5;
     const int zslab = zs >= 0 ? zs : (int)blockIdx.z;          // K slab of a split-K product (grouped launches pass their own)
     // ---- vector epilogue: each wave transposes its 32-row fragment band through a private LDS slab (C-layout puts a
@@ -126,7 +128,7 @@ __device__ __forceinline__ void epilogue_vec(const GemmArgs& p, float* smem, con
             const int row = ps * RPP + lr;
             const int m = m0 + wm * WM + i * 32 + row;
             if (nok && m < p.M) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(Cw + row * LDC_S + lc);
+                f32x4 v = *reinterpret_cast<const f32x4*>(Cw + row * LDC_S + lc) * so1 * so2;
                 if (p.split_k > 1) {
                     *reinterpret_cast<f32x4*>(p.ws + ((long)zslab * p.M + m) * p.N + n) = v;
                 } else {
@@ -152,9 +154,11 @@ __device__ __forceinline__ void epilogue_vec(const GemmArgs& p, float* smem, con
 #pragma unroll
                         for (int q = 0; q < 4; ++q) { float d1, d3q; swiglu_grad_f(v[q], u1[q], u3[q], d1, d3q); v[q] = d1; d3[q] = d3q; }
                         *reinterpret_cast<f32x4*>(p.C + (long)m * p.ldc + p.N + n) = d3;
+                        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(d3[0]), fabsf(d3[1])), fmaxf(fabsf(d3[2]), fabsf(d3[3]))));
                     }
                     if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (long)m * p.ldr + n);
                     *reinterpret_cast<f32x4*>(p.C + (long)m * p.ldc + n) = v;
+                    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
                 }
             }
         }
@@ -162,6 +166,7 @@ __device__ __forceinline__ void epilogue_vec(const GemmArgs& p, float* smem, con
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    if (p.c_amax != nullptr && p.split_k <= 1) amax_publish(p.c_amax, amax, lane, (int)blockIdx.x * 4 + wave);
 }
 
 // SwiGLU forward epilogue (GAOT_ACT_SWIGLU): the kernel staged the B rows so that every wave's WN-column band holds
@@ -169,7 +174,8 @@ __device__ __forceinline__ void epilogue_vec(const GemmArgs& p, float* smem, con
 // LDS slab, so u is written once (for the backward pass) and never read back.
 template <int TM, int TN, int WM, int WN>
 __device__ __forceinline__ void epilogue_swiglu(const GemmArgs& p, float* smem, const f32x16 (&acc)[TM][TN], int m0, int n0,
-                                            int wm, int wn, int wave, int lane) {
+                                            int wm, int wn, int wave, int lane, float so1 = 1.f, float so2 = 1.f) {
+    float amax = 0.f;
     const int li = lane & 31, lh = lane >> 5;
     constexpr int LDC_S = WN + 4;
     constexpr int HW = WN / 2;                         // gate columns per band
@@ -193,8 +199,8 @@ __device__ __forceinline__ void epilogue_swiglu(const GemmArgs& p, float* smem, 
             const int row = ps * RPP + lr;
             const int m = m0 + wm * WM + i * 32 + row;
             if (nok && m < p.M) {
-                const f32x4 u1 = *reinterpret_cast<const f32x4*>(Cw + row * LDC_S + lc);
-                const f32x4 u3 = *reinterpret_cast<const f32x4*>(Cw + row * LDC_S + HW + lc);
+                const f32x4 u1 = *reinterpret_cast<const f32x4*>(Cw + row * LDC_S + lc) * so1 * so2;
+                const f32x4 u3 = *reinterpret_cast<const f32x4*>(Cw + row * LDC_S + HW + lc) * so1 * so2;
                 if (p.aux_out) {
                     *reinterpret_cast<f32x4*>(p.aux_out + (long)m * p.ld_aux + gcol) = u1;
                     *reinterpret_cast<f32x4*>(p.aux_out + (long)m * p.ld_aux + F + gcol) = u3;
@@ -203,24 +209,24 @@ __device__ __forceinline__ void epilogue_swiglu(const GemmArgs& p, float* smem, 
 #pragma unroll
                 for (int q = 0; q < 4; ++q) o[q] = swiglu_f(u1[q], u3[q]);
                 *reinterpret_cast<f32x4*>(p.C + (long)m * p.ldc + gcol) = o;
+                amax = fmaxf(amax, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    if (p.c_amax != nullptr) amax_publish(p.c_amax, amax, lane, (int)blockIdx.x * 4 + wave);
 }
 
 // skinny VALU paths (skinny.hip); return true if they handled the product
 bool launch_skinny(const GemmArgs& a, bool a_kmajor, bool b_kmajor, hipStream_t st);
+bool skinny_would(const GemmArgs& a, bool a_kmajor, bool b_kmajor);
 // LDS-direct (global_load_lds) tile kernels (gemm_glds.hip); tile: 1 = 128x128 (8 waves), 2 = 128x64, 3 = 64x64
 void launch_glds(GemmArgs& a, bool a_kmajor, bool b_kmajor, int tile, hipStream_t st);
 
 // split-bf16 kernel (gemm_split.hip): fp32 product from six bf16 MFMA piece products, 128x128 tiles
 void launch_split(GemmArgs& a, bool a_kmajor, bool b_kmajor, hipStream_t st, int bm = 128, int pieces = 3);
-// the same products with LDS-direct fp32 operand tiles and the split done in registers after the fragment reads (gemm_gsplit.hip)
-void launch_gsplit(GemmArgs& a, bool a_kmajor, bool b_kmajor, hipStream_t st, int bm = 128, int pieces = 3);
-
 // grouped weight-gradient launch (gemm_split.hip): prefix table / workspace need of n items; the launch itself
 struct TnGroupArgs;
 long plan_tn_grouped(const gaot_wgrad_item* items, int n, TnGroupArgs* args, int* n_counters, int* n_wg);

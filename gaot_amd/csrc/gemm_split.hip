@@ -29,16 +29,20 @@ __device__ __forceinline__ unsigned rne_pair(float x0, float x1) {
     u1 += 0x7fffu + ((u1 >> 16) & 1u);
     return __builtin_amdgcn_perm(u1, u0, 0x07060302u);
 }
+// NP = 4 / 5: two fp16 pieces of sc * x (sc a power of two that brings the operand's largest magnitude to ~2^14, see split2h_pair):
+// three (4) or four (5) piece products on v_mfma_f32_32x32x16_f16
 template <int NP, int ABL>
-__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& ph, unsigned& pm, unsigned& pl) {
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& ph, unsigned& pm, unsigned& pl, float sc = 1.f) {
     if (NP == 1) { ph = rne_pair(x0, x1); pm = pl = 0u; }
     else if (NP == 2) { split2_pair(x0, x1, ph, pm); pl = 0u; }       // two ROUNDED pieces: x = h + m + e, |e| <= 2^-18 |x|, unbiased
+    else if (NP >= 4) { split2h_pair(x0, x1, sc, ph, pm); pl = 0u; }
     else split3_pair<ABL>(x0, x1, ph, pm, pl);
 }
 
-template <int ABL>
+template <int ABL, bool F16 = false>
 __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
     if (ABL & 2) { c[0] += __builtin_bit_cast(u32x4, a)[0] * 1e-30f + __builtin_bit_cast(u32x4, b)[1] * 1e-30f; return c; }
+    if (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
@@ -54,7 +58,7 @@ __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
 #endif
 template <int BM, int NP = 3>
 struct SplitGeom {
-    static constexpr int NPL = NP == 2 ? 2 : 3;            // planes per operand in a stage (two-piece tiles: 48 KB, three workgroups per CU)
+    static constexpr int NPL = (NP == 2 || NP >= 4) ? 2 : 3;            // planes per operand in a stage (two-piece tiles: 48 KB, three workgroups per CU)
     static constexpr int BN = S_BN, NW = BM == 256 ? 8 : 4, NT = 64 * NW, WAVES_N = 2, WM = BM / (NW / 2), WN = 64, TM = WM / 32, TN = 2;
     static constexpr int PA = (BM > 128 ? BM : 128) * 48, PB = 128 * 48;      // bytes per plane
     static constexpr int STAGE = NPL * PA + NPL * PB;
@@ -67,12 +71,8 @@ struct SplitGeom {
 // FLUSH > 0: every FLUSH k-tiles (16 k each) the MFMA accumulators are added to running sums on the VECTOR pipe and restart from
 // zero: the bf16 MFMA does not round its accumulator to nearest, so one matrix-pipe accumulation run stays at FLUSH * 16 <= 1 024
 // values of k however long the workgroup's reduction is (costs TM * TN * 16 more registers: the grouped TN kernel has them)
-// BPL: the B operand arrives ALREADY split (p.Bpl: three bf16 planes of B^T-or-B laid out k-contiguous, element (n, k) of plane q
-// at q * bpl_stride + n * ld_bpl + k -- weights, split once per optimizer step by gaot_split_planes_grouped): its tiles go from the
-// global-load registers to LDS as they are (no split arithmetic, half of the tile's vector work); bit-identical products, since the
-// planes are what split3_pair would have produced here.  Requires BKM (the planes are k-contiguous whatever B's own layout).
-struct BRegs { f32x4 f[2]; u32x4 pl[3]; };
-template <bool AK, bool BKM, int BM, int ABL, int NP, int FLUSH = 0, bool BPL = false>
+struct BRegs { f32x4 f[2]; };
+template <bool AK, bool BKM, int BM, int ABL, int NP, int FLUSH = 0>
 __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* smem_raw, const int logical, const int zs) {
     using G = SplitGeom<BM, NP>;
     constexpr int NPL = G::NPL;
@@ -103,9 +103,11 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
     // row-contiguous (128-row tiles): kp = tid & 7 (k pair), r4 = tid >> 3 (4 rows); q = which k of the pair.  The packed
     // (k, k+1) dwords are written TRANSPOSED into the k-contiguous plane layout (4 x ds_write_b32 per plane), so every
     // operand is read back with ds_read_b128 whatever its layout in memory
-    static_assert(!BPL || (BKM && NP == 3), "pre-split B planes are k-contiguous three-piece planes");
+    constexpr bool F16 = NP >= 4;
+    // fp16 pieces: power-of-two operand scales from the operands' magnitude words (uniform: two scalar loads per workgroup)
+    float sc_a = 1.f, sc_b = 1.f, so_a = 1.f, so_b = 1.f;
+    if (F16) { amax_scale(p.a_amax, sc_a, so_a); amax_scale(p.b_amax, sc_b, so_b); }
     const float* a_src[2]; const float* b_src[2];
-    const unsigned short* bp_src = nullptr;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         if (AK) {
@@ -124,7 +126,6 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
                 nrow = (within / (WN / 2)) * F + min(gcol, F - 1);
             }
             b_src[q] = B_FULL ? p.B + (long)nrow * p.ldb + (tid & 1) * 8 + q * 4 : p.B + (long)nrow * p.ldb + (tid & 3) * 4;
-            if (BPL) bp_src = B_FULL ? p.Bpl + (long)nrow * p.ld_bpl + (tid & 1) * 8 : p.Bpl + (long)nrow * p.ld_bpl + (tid & 3) * 4;
         } else {      // 128 rows: (k pair = tid & 7, row quad = tid >> 3) for the first 256 threads
             b_src[q] = p.B + (long)(2 * (tid & 7) + q) * p.ldb + min(n0 + ((tid >> 3) & 31) * 4, p.N - 4);
         }
@@ -141,17 +142,8 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
             const bool b_live = B_FULL || (BKM ? q == 0 : tid < 256);
             if (a_live) xa[q] = *reinterpret_cast<const f32x4*>(AK ? a_src[q] + k0 : a_src[q] + k0 * p.lda);
             else xa[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (!BPL) {
-                if (b_live) xb.f[q] = *reinterpret_cast<const f32x4*>(BKM ? b_src[q] + k0 : b_src[q] + k0 * p.ldb);
-                else xb.f[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        }
-        if (BPL) {
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                if (B_FULL) xb.pl[pl] = *reinterpret_cast<const u32x4*>(bp_src + pl * p.bpl_stride + k0);
-                else { const u32x2 v = *reinterpret_cast<const u32x2*>(bp_src + pl * p.bpl_stride + k0); xb.pl[pl] = u32x4{v[0], v[1], 0u, 0u}; }
-            }
+            if (b_live) xb.f[q] = *reinterpret_cast<const f32x4*>(BKM ? b_src[q] + k0 : b_src[q] + k0 * p.ldb);
+            else xb.f[q] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
 
@@ -162,7 +154,7 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
     // split + store one operand's registers into its three planes of `plane` bytes.  full: two float4 per thread; else one
     // float4 (k-contiguous) or the first `half_threads` threads with two (row-contiguous).  Row-contiguous operands are written
     // TRANSPOSED into the k-contiguous layout, except the 64-row A tile (legacy [k pair][row] layout, not picked by the heuristic).
-    auto stage_store = [&](unsigned char* base, const f32x4 (&r)[2], bool kmajor, bool full, int plane, int half_threads, bool legacy64) {
+    auto stage_store = [&](unsigned char* base, const f32x4 (&r)[2], bool kmajor, bool full, int plane, int half_threads, bool legacy64, float sc) {
         if (kmajor) {
             if (full) {
                 u32x4 h, m, l;
@@ -171,7 +163,7 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         unsigned a_, b_, c_;
-                        split_pair<NP, ABL>(r[q][2 * e], r[q][2 * e + 1], a_, b_, c_);
+                        split_pair<NP, ABL>(r[q][2 * e], r[q][2 * e + 1], a_, b_, c_, sc);
                         h[2 * q + e] = a_; m[2 * q + e] = b_; l[2 * q + e] = c_;
                     }
                 unsigned char* dst = base + (tid >> 1) * 48 + (tid & 1) * 16;
@@ -183,7 +175,7 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     unsigned a_, b_, c_;
-                    split_pair<NP, ABL>(r[0][2 * e], r[0][2 * e + 1], a_, b_, c_);
+                    split_pair<NP, ABL>(r[0][2 * e], r[0][2 * e + 1], a_, b_, c_, sc);
                     h[e] = a_; m[e] = b_; l[e] = c_;
                 }
                 unsigned char* dst = base + (tid >> 2) * 48 + (tid & 3) * 8;
@@ -195,7 +187,7 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
             if (!full && tid >= half_threads) return;
             u32x4 h, m, l;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { unsigned a_, b_, c_; split_pair<NP, ABL>(r[0][e], r[1][e], a_, b_, c_); h[e] = a_; m[e] = b_; l[e] = c_; }
+            for (int e = 0; e < 4; ++e) { unsigned a_, b_, c_; split_pair<NP, ABL>(r[0][e], r[1][e], a_, b_, c_, sc); h[e] = a_; m[e] = b_; l[e] = c_; }
             if (!legacy64) {
                 unsigned char* dst = base + (tid >> 3) * 4 * 48 + (tid & 7) * 4;
 #pragma unroll
@@ -215,20 +207,8 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
     auto sstore = [&](int stage, const f32x4 (&xa)[2], const BRegs& xb, bool live) {
         if (ABL & 32) { asm volatile("" :: "v"(xa[0][0]), "v"(xb.f[0][0]), "v"(xa[1][3]), "v"(xb.f[1][3])); return; }     // tuning: no LDS plane writes
         unsigned char* sa = smem_raw + stage * STAGE;
-        stage_store(sa, xa, AK, A_FULL, PA, 128, BM == 64);
-        if (BPL) {
-            unsigned char* sb = sa + NPL * PA;
-            if (B_FULL) {
-                unsigned char* dst = sb + (tid >> 1) * 48 + (tid & 1) * 16;
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * PB) = xb.pl[pl];
-            } else {
-                unsigned char* dst = sb + (tid >> 2) * 48 + (tid & 3) * 8;
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x2*>(dst + pl * PB) = u32x2{xb.pl[pl][0], xb.pl[pl][1]};
-            }
-        } else
-        stage_store(sa + NPL * PA, xb.f, BKM, B_FULL, PB, 256, false);
+        stage_store(sa, xa, AK, A_FULL, PA, 128, BM == 64, sc_a);
+        stage_store(sa + NPL * PA, xb.f, BKM, B_FULL, PB, 256, false, sc_b);
         if (!AK) { const float w = (do_colsum && live && (A_FULL || tid < 128)) ? 1.f : 0.f; csum += (xa[0] + xa[1]) * w; }   // branch-free: keeps the k-loop one block
     };
 
@@ -259,24 +239,25 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int pl = 0; pl < NP; ++pl) a[i][pl] = frag(sa + pl * PA, wm * WM + i * 32 + li, AK || BM != 64, ABYTES);
+            for (int pl = 0; pl < NPL; ++pl) a[i][pl] = frag(sa + pl * PA, wm * WM + i * 32 + li, AK || BM != 64, ABYTES);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int pl = 0; pl < NP; ++pl) b[j][pl] = frag(sb + pl * PB, wn * WN + j * 32 + li, true, 512);
+            for (int pl = 0; pl < NPL; ++pl) b[j][pl] = frag(sb + pl * PB, wn * WN + j * 32 + li, true, 512);
         if (NP == 1) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = mfma<ABL>(a[i][0], b[j][0], acc[i][j]);
-        } else if (NP == 2) {
+        } else if (NP == 2 || NP >= 4) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = mfma<ABL>(a[i][1], b[j][0], acc[i][j]);
-                    acc[i][j] = mfma<ABL>(a[i][0], b[j][1], acc[i][j]);
-                    acc[i][j] = mfma<ABL>(a[i][0], b[j][0], acc[i][j]);
+                    if (NP == 5) acc[i][j] = mfma<ABL, F16>(a[i][1], b[j][1], acc[i][j]);
+                    acc[i][j] = mfma<ABL, F16>(a[i][1], b[j][0], acc[i][j]);
+                    acc[i][j] = mfma<ABL, F16>(a[i][0], b[j][1], acc[i][j]);
+                    acc[i][j] = mfma<ABL, F16>(a[i][0], b[j][0], acc[i][j]);
                 }
         } else {
         // small terms first
@@ -306,7 +287,7 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
         // interleave: one MFMA, a few VALU ops of the split, now and then one of its LDS writes
         __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);       // the prefetch loads go first: a whole k-tile to land
 #pragma unroll
-        for (int g = 0; g < TM * TN * (NP == 3 ? 6 : NP == 2 ? 3 : 1); ++g) {
+        for (int g = 0; g < TM * TN * (NP == 3 ? 6 : NP == 5 ? 4 : (NP == 2 || NP == 4) ? 3 : 1); ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
@@ -369,26 +350,24 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
         __syncthreads();
     }
     if (ABL & 4) { if (acc[0][0][0] + acc[1][1][3] + acc[0][1][5] + acc[1][0][7] == 123.456f) p.C[tid] = 1.f; __syncthreads(); return; }
-    if (BKM && p.act == GAOT_ACT_SWIGLU) epilogue_swiglu<TM, TN, WM, WN>(p, reinterpret_cast<float*>(smem_raw), acc, m0, n0, wm, wn, wave, lane);
-    else epilogue_vec<TM, TN, WM, WN>(p, reinterpret_cast<float*>(smem_raw), acc, m0, n0, wm, wn, wave, lane, zs);
+    if (BKM && p.act == GAOT_ACT_SWIGLU) epilogue_swiglu<TM, TN, WM, WN>(p, reinterpret_cast<float*>(smem_raw), acc, m0, n0, wm, wn, wave, lane, so_a, so_b);
+    else epilogue_vec<TM, TN, WM, WN>(p, reinterpret_cast<float*>(smem_raw), acc, m0, n0, wm, wn, wave, lane, zs, so_a, so_b);
     __syncthreads();          // the epilogue's LDS slabs alias the stages the next tile is about to fill
 }
 
-template <bool AK, bool BKM, int BM = 128, int ABL = 0, int NP = 3, bool BPL = false>
-__global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 1 : (NP == 2 ? GAOT_SPLIT2_WG_PER_CU : 2)) void gemm_split_kernel(const GemmArgs p) {
+template <bool AK, bool BKM, int BM = 128, int ABL = 0, int NP = 3>
+__global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 1 : ((NP == 2 || NP >= 4) ? GAOT_SPLIT2_WG_PER_CU : 2)) void gemm_split_kernel(const GemmArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SplitGeom<BM, NP>::SMEM_BYTES];
     if ((ABL & 128) && (blockIdx.x & 8)) {      // tuning: de-phase half of the workgroups by ~p.ablate x 3.4 us at start
         for (int i = 0; i < p.ablate; ++i) __builtin_amdgcn_s_sleep(127);
     }
     const int tiles = p.tiles_m * p.tiles_n;
-    // PERSISTENT over tiles: the grid may be smaller than the tile count (launch_split_bm caps it at the number of workgroups
-    // the chip holds at once); a workgroup then walks tiles vb = blockIdx.x, blockIdx.x + gridDim.x, ...  Workgroups that started
-    // together drift apart after their first tile, so the load phase of one overlaps the store phase of another.
-    for (int vb = blockIdx.x; vb < tiles; vb += gridDim.x) {
-        // XCD-aware tile order (as gemm.hip); gridDim.x is a multiple of 8 whenever it is smaller than `tiles`
+    {
+        const int vb = blockIdx.x;
+        // XCD-aware tile order (as gemm.hip)
         const int q = tiles >> 3, r = tiles & 7, x = vb & 7, slot = vb >> 3;
         const int logical = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + slot;
-        split_tile<AK, BKM, BM, ABL, NP, 0, BPL>(p, smem_raw, logical, blockIdx.z);
+        split_tile<AK, BKM, BM, ABL, NP, 0>(p, smem_raw, logical, blockIdx.z);
     }
 }
 
@@ -409,6 +388,7 @@ struct TnProb {
     int wg_end;                                    // first workgroup index past this product
     int cnt_off;                                   // first ticket counter of this product
     long ws_off;                                   // float offset of this product's slabs in the workspace
+    const float* a_amax; const float* b_amax;      // fp16 pieces (NP = 4): the operands' magnitude words
 };
 struct TnGroupArgs { int n; float* ws; int* counters; TnProb p[TNG_MAX]; };
 
@@ -442,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const TnGroupAr
     a.aux_in = nullptr; a.aux_out = nullptr; a.ld_aux = 0; a.residual = nullptr; a.ldr = 0;
     a.split_k = split; a.ktiles_per_split = g.p[i].kt_per_split; a.ws = g.ws + g.p[i].ws_off;
     a.colsum = g.p[i].colsum; a.tiles_m = g.p[i].tiles_m; a.tiles_n = g.p[i].tiles_n; a.vec_epi = 1; a.ablate = 0;
-    a.Bpl = nullptr; a.ld_bpl = 0; a.bpl_stride = 0;
+    a.a_amax = g.p[i].a_amax; a.b_amax = g.p[i].b_amax; a.c_amax = nullptr;
     split_tile<false, false, 128, ABL, NP, 64>(a, smem_raw, tile, z);
     if (split <= 1) return;
 
@@ -518,6 +498,7 @@ long plan_tn_grouped(const gaot_wgrad_item* items, int n, TnGroupArgs* args, int
             q.M = it.M; q.N = it.N; q.K = it.K; q.lda = (int)it.ldg; q.ldb = (int)it.ldx; q.ldc = (int)it.ldo;
             q.tiles_m = tm; q.tiles_n = tn; q.split = split; q.kt_per_split = per;
             q.wg_end = wg + tm * tn * split; q.cnt_off = cnt; q.ws_off = ws;
+            q.a_amax = it.g_absmax; q.b_amax = it.x_absmax;
         }
         wg += tm * tn * split;
         if (split > 1) { ws += (long)split * ((long)it.M * it.N + it.M); ws = (ws + 3) & ~3L; cnt += tm * tn; }
@@ -533,33 +514,21 @@ void launch_tn_grouped(const gaot_wgrad_item* items, int n, float* ws, int* coun
     args.n = n; args.ws = ws; args.counters = counters;
     int wg = 0;
     plan_tn_grouped(items, n, &args, nullptr, &wg);
-    if (pieces == 2) hipLaunchKernelGGL((gemm_tn_grouped_kernel<0, 2>), dim3(wg), dim3(256), 0, st, args);
+    if (pieces == 4) hipLaunchKernelGGL((gemm_tn_grouped_kernel<0, 4>), dim3(wg), dim3(256), 0, st, args);
+    else if (pieces == 5) hipLaunchKernelGGL((gemm_tn_grouped_kernel<0, 5>), dim3(wg), dim3(256), 0, st, args);
+    else if (pieces == 2) hipLaunchKernelGGL((gemm_tn_grouped_kernel<0, 2>), dim3(wg), dim3(256), 0, st, args);
     else hipLaunchKernelGGL((gemm_tn_grouped_kernel<0, 3>), dim3(wg), dim3(256), 0, st, args);
 }
-
-// 0: one workgroup per tile (round 1).  n > 0: grids larger than n workgroups become persistent with n (MI355X holds 512 of the
-// 128-row, 256-thread workgroups at once: 2 per CU).  Tuning hook: gaot_debug_set_split_persist.
-static int g_split_persist = 0;
-void set_split_persist(int n) { g_split_persist = n; }
 
 template <int BM, int NP>
 static void launch_split_bm(GemmArgs& a, bool ak, bool bk, hipStream_t st) {
     a.tiles_m = cdiv(a.M, BM);
     a.tiles_n = cdiv(a.N, S_BN);
-    int gx = a.tiles_m * a.tiles_n;
+    const int gx = a.tiles_m * a.tiles_n;
     const int z = a.split_k > 1 ? a.split_k : 1;
-    if (g_split_persist > 0 && (long)gx * z > g_split_persist) {       // persistent: at most that many workgroups in the grid
-        int cap = g_split_persist / z;
-        cap = cap < 8 ? 8 : (cap / 8) * 8;
-        if (gx > cap) gx = cap;
-    }
     dim3 grid(gx, 1, z);
     dim3 block(BM == 256 ? 512 : 256);
-    if (NP == 3 && a.Bpl != nullptr) {          // pre-split B (weights): the planes are k-contiguous whatever B's own layout
-        if (ak) hipLaunchKernelGGL((gemm_split_kernel<true, true, BM, 0, 3, true>), grid, block, 0, st, a);
-        else    hipLaunchKernelGGL((gemm_split_kernel<false, true, BM, 0, 3, true>), grid, block, 0, st, a);
-    }
-    else if (ak && bk)   hipLaunchKernelGGL((gemm_split_kernel<true, true, BM, 0, NP>), grid, block, 0, st, a);
+    if (ak && bk)   hipLaunchKernelGGL((gemm_split_kernel<true, true, BM, 0, NP>), grid, block, 0, st, a);
     else if (ak && !bk)  hipLaunchKernelGGL((gemm_split_kernel<true, false, BM, 0, NP>), grid, block, 0, st, a);
     else if (!ak && !bk) hipLaunchKernelGGL((gemm_split_kernel<false, false, BM, 0, NP>), grid, block, 0, st, a);
     else                 hipLaunchKernelGGL((gemm_split_kernel<false, true, BM, 0, NP>), grid, block, 0, st, a);
@@ -568,6 +537,11 @@ static void launch_split_bm(GemmArgs& a, bool ak, bool bk, hipStream_t st) {
 void launch_split(GemmArgs& a, bool ak, bool bk, hipStream_t st, int bm, int pieces) {
     if (pieces == 1) {           // plain bf16 operands (bench variant): 128- and 64-row tiles
         if (bm == 64) launch_split_bm<64, 1>(a, ak, bk, st); else launch_split_bm<128, 1>(a, ak, bk, st);
+        return;
+    }
+    if (pieces == 4 || pieces == 5) {      // two fp16 pieces per operand (three / four piece products on the f16 MFMA)
+        if (pieces == 4) { if (bm == 64) launch_split_bm<64, 4>(a, ak, bk, st); else if (bm == 256) launch_split_bm<256, 4>(a, ak, bk, st); else launch_split_bm<128, 4>(a, ak, bk, st); }
+        else { if (bm == 64) launch_split_bm<64, 5>(a, ak, bk, st); else if (bm == 256) launch_split_bm<256, 5>(a, ak, bk, st); else launch_split_bm<128, 5>(a, ak, bk, st); }
         return;
     }
     if (pieces == 2) {           // two rounded pieces per operand (three piece products)

@@ -306,51 +306,6 @@ __global__ __launch_bounds__(256) void colsum_grouped_kernel(const ColsumGroupAr
         *reinterpret_cast<f32x4*>(dst) = (red[0][c4] + red[1][c4]) + (red[2][c4] + red[3][c4]);
     }
 }
-// ---- exact three-way bf16 split of fp32 matrices into planes (gaot_gemm_desc.b_planes), many matrices per launch.  64 x 64 tiles
-// through LDS so that both the plain and the transposed planes are written in whole 128-byte rows.
-constexpr int SPLIT_GROUP_MAX = 48;
-struct SplitItem { const float* src; unsigned short* planes; long ld, ld_out, plane_stride; int rows, cols, transpose, tiles_c, wg_end; };
-struct SplitGroupArgs { int n; SplitItem it[SPLIT_GROUP_MAX]; };
-__global__ __launch_bounds__(256) void split_planes_grouped_kernel(const SplitGroupArgs g) {
-    __shared__ float tile[64][65];
-    int i = 0;
-    while (i + 1 < g.n && (int)blockIdx.x >= g.it[i].wg_end) ++i;
-    const int local = (int)blockIdx.x - (i > 0 ? g.it[i - 1].wg_end : 0);
-    const int r0 = (local / g.it[i].tiles_c) * 64, c0 = (local % g.it[i].tiles_c) * 64;
-    const int rows = g.it[i].rows, cols = g.it[i].cols;
-    const float* __restrict__ src = g.it[i].src;
-    const long ld = g.it[i].ld;
-    const int tid = threadIdx.x;
-    for (int e = tid; e < 64 * 64; e += 256) {
-        const int r = e >> 6, c = e & 63;
-        tile[r][c] = (r0 + r < rows && c0 + c < cols) ? src[(long)(r0 + r) * ld + c0 + c] : 0.f;
-    }
-    __syncthreads();
-    const bool tr = g.it[i].transpose != 0;
-    const int orows = tr ? cols : rows, ocols = tr ? rows : cols;          // extents in the output orientation
-    const int or0 = tr ? c0 : r0, oc0 = tr ? r0 : c0;
-    unsigned short* __restrict__ out = g.it[i].planes;
-    const long ldo = g.it[i].ld_out, ps = g.it[i].plane_stride;
-    const int pp = tid & 31;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int orow = (tid >> 5) + 8 * k;
-        const float x0 = tr ? tile[2 * pp][orow] : tile[orow][2 * pp];
-        const float x1 = tr ? tile[2 * pp + 1][orow] : tile[orow][2 * pp + 1];
-        unsigned a, b, c;
-        split3_pair<0>(x0, x1, a, b, c);
-        if (or0 + orow < orows && oc0 + 2 * pp < ocols) {
-            unsigned short* d = out + (long)(or0 + orow) * ldo + oc0 + 2 * pp;
-            if (oc0 + 2 * pp + 1 < ocols) {
-                *reinterpret_cast<unsigned*>(d) = a;
-                *reinterpret_cast<unsigned*>(d + ps) = b;
-                *reinterpret_cast<unsigned*>(d + 2 * ps) = c;
-            } else {
-                d[0] = (unsigned short)(a & 0xffffu); d[ps] = (unsigned short)(b & 0xffffu); d[2 * ps] = (unsigned short)(c & 0xffffu);
-            }
-        }
-    }
-}
 __global__ void batchsum_kernel(const float* __restrict__ x, int B, long RN, float* __restrict__ out) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < RN; i += (long)gridDim.x * blockDim.x) {
         float s = 0.f;
@@ -555,27 +510,68 @@ extern "C" int gaot_colsum_grouped(const gaot_colsum_item* items, int32_t n, gao
     return GAOT_OK;
 }
 
-extern "C" int gaot_split_planes_grouped(const gaot_split_item* items, int32_t n, gaot_stream_t stream) {
-    GAOT_REQUIRE(items != nullptr && n > 0, "split_planes_grouped: no items");
-    for (int i = 0; i < n; ++i) {
-        const gaot_split_item& it = items[i];
-        GAOT_REQUIRE(it.src && it.planes && it.rows > 0 && it.cols > 0 && it.ld >= it.cols && it.ld_out % 2 == 0 && it.plane_stride % 2 == 0 &&
-                     it.ld_out >= (it.transpose ? it.rows : it.cols) && (reinterpret_cast<uintptr_t>(it.planes) & 3u) == 0,
-                     "split_planes_grouped: item %d: bad shape / leading dimension / alignment", i);
+// ---- grouped absmax: the magnitude words of the fp16-piece products (gaot_gemm_desc.a_absmax ...), n matrices per launch.  A workgroup
+// streams its share of one matrix (float4 loads when the rows allow, no per-element division), wave-reduces and publishes one atomic
+// max per wave into the word's slot.
+constexpr int ABSMAX_GROUP_MAX = 96;
+struct AbsmaxItem { const float* x; float* out; long ld; int rows, cols, wg_end; };
+struct AbsmaxGroupArgs { int n; AbsmaxItem it[ABSMAX_GROUP_MAX]; };
+__global__ __launch_bounds__(256) void absmax_grouped_kernel(const AbsmaxGroupArgs g) {
+    int i = 0;
+    while (i + 1 < g.n && (int)blockIdx.x >= g.it[i].wg_end) ++i;
+    const int first = i > 0 ? g.it[i - 1].wg_end : 0, nwg = g.it[i].wg_end - first, b = (int)blockIdx.x - first;
+    const float* __restrict__ x = g.it[i].x;
+    const long ld = g.it[i].ld;
+    const int rows = g.it[i].rows, cols = g.it[i].cols;
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+    const bool vec = (cols & 3) == 0 && (ld & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0);
+    if (vec && ld == cols) {                     // contiguous: one flat stream of float4, four in flight per thread
+        const long total = (long)rows * (cols >> 2), step = (long)nwg * 256;
+        const f32x4* __restrict__ x4 = reinterpret_cast<const f32x4*>(x);
+        long idx = (long)b * 256 + threadIdx.x;
+        for (; idx + 3 * step < total; idx += 4 * step) {
+            const f32x4 v0 = x4[idx], v1 = x4[idx + step], v2 = x4[idx + 2 * step], v3 = x4[idx + 3 * step];
+            m0 = fmaxf(m0, fmaxf(fmaxf(fabsf(v0[0]), fabsf(v0[1])), fmaxf(fabsf(v0[2]), fabsf(v0[3]))));
+            m1 = fmaxf(m1, fmaxf(fmaxf(fabsf(v1[0]), fabsf(v1[1])), fmaxf(fabsf(v1[2]), fabsf(v1[3]))));
+            m2 = fmaxf(m2, fmaxf(fmaxf(fabsf(v2[0]), fabsf(v2[1])), fmaxf(fabsf(v2[2]), fabsf(v2[3]))));
+            m3 = fmaxf(m3, fmaxf(fmaxf(fabsf(v3[0]), fabsf(v3[1])), fmaxf(fabsf(v3[2]), fabsf(v3[3]))));
+        }
+        for (; idx < total; idx += step) {
+            const f32x4 v0 = x4[idx];
+            m0 = fmaxf(m0, fmaxf(fmaxf(fabsf(v0[0]), fabsf(v0[1])), fmaxf(fabsf(v0[2]), fabsf(v0[3]))));
+        }
+    } else if (vec) {                            // strided rows: a wave per row
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        for (long r = (long)b * 4 + wave; r < rows; r += (long)nwg * 4)
+            for (int c = lane * 4; c < cols; c += 256) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + r * ld + c);
+                m0 = fmaxf(m0, fmaxf(fmaxf(fabsf(v0[0]), fabsf(v0[1])), fmaxf(fabsf(v0[2]), fabsf(v0[3]))));
+            }
+    } else {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        for (long r = (long)b * 4 + wave; r < rows; r += (long)nwg * 4)
+            for (int c = lane; c < cols; c += 64) m0 = fmaxf(m0, fabsf(x[r * ld + c]));
     }
-    for (int i0 = 0; i0 < n; i0 += SPLIT_GROUP_MAX) {
-        SplitGroupArgs a;
-        a.n = n - i0 < SPLIT_GROUP_MAX ? n - i0 : SPLIT_GROUP_MAX;
+    amax_publish(g.it[i].out, fmaxf(fmaxf(m0, m1), fmaxf(m2, m3)), threadIdx.x & 63, (int)blockIdx.x * 4 + (threadIdx.x >> 6));
+}
+
+extern "C" int gaot_absmax_grouped(const gaot_absmax_item* items, int32_t n, gaot_stream_t stream) {
+    GAOT_REQUIRE(items != nullptr && n > 0, "absmax_grouped: no items");
+    for (int i = 0; i < n; ++i)
+        GAOT_REQUIRE(items[i].x && items[i].out && items[i].rows > 0 && items[i].cols > 0 && items[i].ld >= items[i].cols,
+                     "absmax_grouped: item %d needs x, out, rows, cols > 0 and ld >= cols", i);
+    for (int i0 = 0; i0 < n; i0 += ABSMAX_GROUP_MAX) {
+        AbsmaxGroupArgs a;
+        a.n = n - i0 < ABSMAX_GROUP_MAX ? n - i0 : ABSMAX_GROUP_MAX;
         int wg = 0;
         for (int i = 0; i < a.n; ++i) {
-            const gaot_split_item& it = items[i0 + i];
-            const int tc = cdiv(it.cols, 64);
-            wg += cdiv(it.rows, 64) * tc;
-            a.it[i] = SplitItem{it.src, reinterpret_cast<unsigned short*>(it.planes), (long)it.ld, (long)it.ld_out, (long)it.plane_stride,
-                                it.rows, it.cols, it.transpose, tc, wg};
+            const gaot_absmax_item& it = items[i0 + i];
+            long w = ((long)it.rows * it.cols + 8191) / 8192;          // >= 32 KB of floats per workgroup
+            wg += (int)(w > 1024 ? 1024 : (w < 1 ? 1 : w));
+            a.it[i] = AbsmaxItem{it.x, it.out, (long)it.ld, it.rows, it.cols, wg};
         }
-        hipLaunchKernelGGL(split_planes_grouped_kernel, dim3(wg), dim3(256), 0, ST(stream), a);
-        GAOT_CHECK_LAUNCH("gaot_split_planes_grouped");
+        hipLaunchKernelGGL(absmax_grouped_kernel, dim3(wg), dim3(256), 0, ST(stream), a);
+        GAOT_CHECK_LAUNCH("gaot_absmax_grouped");
     }
     return GAOT_OK;
 }

@@ -162,6 +162,14 @@ __global__ __launch_bounds__(256) void skinny_tn_final_kernel(const GemmArgs p, 
     }
 }
 
+// the same decision without a launch (gaot_gemm_path)
+bool skinny_would(const GemmArgs& a, bool ak, bool bk) {
+    if (a.A2 != nullptr) return false;
+    if (!ak && !bk && a.split_k > 1 && a.ws != nullptr && (a.N <= 16 || a.M <= 16) && (long)a.M * a.N <= 4096 && a.K >= 1024) return true;
+    if (!ak || a.split_k > 1 || a.colsum != nullptr) return false;
+    return a.K <= 16 || a.N <= 4;
+}
+
 bool launch_skinny(const GemmArgs& a, bool ak, bool bk, hipStream_t st) {
     if (a.A2 != nullptr) return false;
     // C: transposed-A weight gradient with a tiny side and a long reduction (needs the split-K workspace)

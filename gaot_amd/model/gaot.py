@@ -135,6 +135,13 @@ class GAOT(nn.Module):
 
     def _forward_eager(self, latent_tokens_coord, xcoord, pndata, query_coord=None, encoder_nbrs=None, decoder_nbrs=None,
                        condition=None) -> torch.Tensor:
+        if pndata.is_cuda and ops.wants_amax():
+            # magnitude words of the fp16-piece products: a fresh arena for this pass, every weight's word in one launch
+            ops.begin_pass()
+            if getattr(self, "_amax_lists", None) is None:
+                self._amax_lists = (list(self.parameters()),
+                                    [g for m in self.modules() if hasattr(m, "fused_weight_groups") for g in m.fused_weight_groups()])
+            ops.refresh_weight_amax(*self._amax_lists)
         rn = self.encode(x_coord=xcoord, pndata=pndata, latent_tokens_coord=latent_tokens_coord, encoder_nbrs=encoder_nbrs)
         rn = ops.cut(rn)                      # staged backward (data-parallel training): encoder gradients complete last
         rn = self.process(rndata=rn, condition=condition)

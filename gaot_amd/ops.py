@@ -137,57 +137,198 @@ if os.environ.get("GAOT_GEMM_PIECES"):          # tools: "3", "2" or "nt,nn,tn" 
 
 
 # --------------------------------------------------------------------------------------------
+# Magnitude words: the fp16-piece products (gaot_gemm_desc.pieces = 4, the way the "f32" precision runs on the split tiles) scale each
+# operand by the power of two that brings its largest magnitude to ~2^14 before splitting it into two fp16 pieces; the kernels read
+# that magnitude from DEVICE memory (one float per tensor, so captured launches follow the data).  A word is
+#   * published by the kernel that produced the tensor (GEMM epilogues: gaot_gemm_desc.c_absmax), or
+#   * computed by gaot_absmax_grouped (weights: one launch per forward pass over every parameter, refresh_weight_amax; any other
+#     tensor: on first use, amax_for),
+# and travels as the attribute `_gaot_amax` = (word, tensor._version) of the tensor OBJECT (lost by reshapes / saved_tensors: the
+# autograd Functions below carry the words of saved operands in their ctx).  Words live in a zeroed arena that is replaced, never
+# reset, at the start of every forward pass (begin_pass), so a captured graph re-zeroes its own words at every replay.
+# --------------------------------------------------------------------------------------------
+_F16_PIECES = [os.environ.get("GAOT_F32_PIECES", "fp16x2") != "bf16x3"]      # False: the "f32" precision runs three bf16 pieces everywhere (A/B)
+
+
+def set_f32_pieces(name: str) -> str:
+    """how the "f32" precision forms its products on the split tiles: "fp16x2" (default: two fp16 pieces of the scaled operand, three
+    piece products) or "bf16x3" (three bf16 pieces, six piece products).  Both carry every operand to fp32 rounding.  Returns the old name."""
+    if name not in ("fp16x2", "bf16x3"):
+        raise ValueError(f"f32 pieces must be 'fp16x2' or 'bf16x3', got {name!r}")
+    old = "fp16x2" if _F16_PIECES[0] else "bf16x3"
+    _F16_PIECES[0] = name == "fp16x2"
+    return old
+
+
+class _Arena:
+    __slots__ = ("buf", "used", "n")
+
+    def __init__(self, device, n=512):
+        self.buf = torch.zeros(n * AMAX_SLOTS, device=device, dtype=torch.float32)       # n words of AMAX_SLOTS floats (256 bytes each)
+        self.n = n
+        self.used = 0
+
+
+AMAX_SLOTS = 64                # include/gaot_hip.h GAOT_AMAX_SLOTS
+_ARENA = [None]
+_WEIGHT_AMAX: list = []        # (lo, hi, word) of the current pass: every parameter and every fused weight group
+
+
+def begin_pass() -> None:
+    """top of a forward pass: magnitude words of the previous pass are not reused (their arena lives on while a ctx still holds it)"""
+    _ARENA[0] = None
+    _WEIGHT_AMAX.clear()
+
+
+def _amax_words(n: int, device) -> List[torch.Tensor]:
+    a = _ARENA[0]
+    if a is None or a.buf.device != device or a.used + n > a.n:
+        a = _Arena(device, max(512, n))
+        _ARENA[0] = a
+    out = [a.buf[(a.used + i) * AMAX_SLOTS:(a.used + i + 1) * AMAX_SLOTS] for i in range(n)]
+    a.used += n
+    return out
+
+
+def _absmax_launch(pairs) -> None:
+    """pairs: (2-D tensor with unit inner stride, word): ONE gaot_absmax_grouped launch"""
+    arr = (L.AbsmaxItem * len(pairs))()
+    for i, (t, w) in enumerate(pairs):
+        arr[i] = L.AbsmaxItem(t.data_ptr(), t.stride(0) if t.shape[0] > 1 else t.shape[1], t.shape[0], t.shape[1], w.data_ptr())
+    L.check(L.load().gaot_absmax_grouped(arr, len(pairs), _stream()), "gaot_absmax_grouped")
+
+
+def _amax_get(*objs):
+    for o in objs:
+        a = getattr(o, "_gaot_amax", None)
+        if a is not None and a[1] == o._version and a[0].device == o.device:
+            return a[0]
+    return None
+
+
+def _amax_set(word, *objs) -> None:
+    for o in objs:
+        if o is not None:
+            o._gaot_amax = (word, o._version)
+
+
+def amax_for(t2d: torch.Tensor, *aliases) -> torch.Tensor:
+    """the magnitude word of a 2-D operand (unit inner stride): the one its producer published / an earlier use computed (carried by
+    the tensor object or one of `aliases`, the objects it is a reshape of), else one absmax launch; remembered on all of them"""
+    w = _amax_get(t2d, *aliases)
+    if w is None:
+        w = _amax_words(1, t2d.device)[0]
+        _absmax_launch([(t2d, w)])
+    _amax_set(w, t2d, *aliases)
+    return w
+
+
+def _publish(word, *objs) -> None:
+    """hand the word a kernel published for its output to the tensor objects that carry that output"""
+    if word is not None:
+        _amax_set(word, *objs)
+
+
+def wants_amax() -> bool:
+    """does the current precision run fp16-piece products (i.e. are magnitude words of any use)?"""
+    return _F16_PIECES[0] and 3 in _PIECES.values()
+
+
+def refresh_weight_amax(params, groups=()) -> None:
+    """magnitude words of every parameter (and of every fused weight group read as one matrix) in ONE launch; the model calls it at
+    the top of a forward pass, the products of that pass and of its backward look their weight operands up by address.  An entry is
+    trusted while its parameter is alive and unchanged (weak reference, Parameter._version, weights_generation())."""
+    import weakref
+    items, owners = [], []
+    for g in groups:
+        g = list(g)
+        v = adjacent_rows(g)
+        if v is not None and v.is_cuda and v.dtype == torch.float32:
+            items.append(v)
+            owners.append(g)
+    for q in params:
+        if q.is_cuda and q.dtype == torch.float32 and q.dim() >= 1 and q.numel() > 0 and q.is_contiguous():
+            items.append(q.detach().reshape(q.shape[0], -1))
+            owners.append([q])
+    if not items:
+        return
+    words = _amax_words(len(items), items[0].device)
+    _absmax_launch(list(zip(items, words)))
+    gen = weights_generation()
+    for t, w, own in zip(items, words, owners):
+        lo = t.data_ptr()
+        _WEIGHT_AMAX.append((lo, lo + t.numel() * 4, w, [weakref.ref(q) for q in own], [q._version for q in own], gen))
+
+
+def weight_amax(w2d: torch.Tensor) -> torch.Tensor:
+    """magnitude word of a weight operand: the smallest registered parameter / fused group that contains the view (a bound over a
+    superset is as good), else as amax_for"""
+    lo = w2d.data_ptr()
+    hi = lo + ((w2d.shape[0] - 1) * w2d.stride(0) + w2d.shape[1]) * 4 if w2d.shape[0] > 1 else lo + w2d.shape[1] * 4
+    best = None
+    gen = weights_generation()
+    for a, b, w, refs, vers, g_ in _WEIGHT_AMAX:
+        if a <= lo and hi <= b and (best is None or b - a < best[0]) and w.device == w2d.device and g_ == gen:
+            if all((q := r()) is not None and q._version == v for r, v in zip(refs, vers)):
+                best = (b - a, w)
+    return best[1] if best is not None else amax_for(w2d)
+
+
+_PATH_CACHE: dict = {}
+
+
+def _gemm_path(d, key) -> int:
+    p_ = _PATH_CACHE.get(key)
+    if p_ is None:
+        p_ = int(L.load().gaot_gemm_path(C.byref(d)))
+        if p_ < 0:
+            L.check(-1, "gaot_gemm_path")
+        _PATH_CACHE[key] = p_
+    return p_
+
+
+# --------------------------------------------------------------------------------------------
 # raw calls
 # --------------------------------------------------------------------------------------------
 def gemm(M: int, N: int, K: int, A, lda, a_kmajor, B, ldb, b_kmajor, out, ldc, *, bias=None, rowbias=None,
          rowbias_period=0, ld_rowbias=0, rowscale=None, act=L.ACT_NONE, aux_in=None, aux_out=None, ld_aux=0,
-         residual=None, ldr=0, A2=None, lda2=0, k_split=0, split_k=1, colsum=None, pieces: Optional[int] = None):
+         residual=None, ldr=0, A2=None, lda2=0, k_split=0, split_k=0, colsum=None, pieces: Optional[int] = None,
+         a_amax=None, b_amax=None, b_is_weight: Optional[bool] = None):
+    """`a_amax` / `b_amax`: magnitude words of the operands where the caller has them (fp16-piece products); missing ones are looked up /
+    computed here.  `b_is_weight` (default: every product but the transposed-A one): B is a parameter (or a view of one).
+    The output's own word, when the kernel published it, is left in `gemm.last_c_amax` (None otherwise)."""
     _dev(A, B, out, bias, rowbias, rowscale, aux_in, aux_out, residual, A2, colsum)
     _f32(A, B, out)
+    split_k = max(1, split_k)
     ws = None
     if split_k > 1:
         ws = torch.empty(split_k * (M * N + M), device=out.device, dtype=torch.float32)
-    bp, bp_ld, bp_stride = (None, 0, 0)
-    if _PLANES_ACTIVE[0] and A2 is None:
-        bp, bp_ld, bp_stride = _weight_planes(B, N, K, ldb, bool(b_kmajor))
+    kind = "tn" if not a_kmajor else ("nt" if b_kmajor else "nn")
+    pc = pieces if pieces is not None else _PIECES[kind]
     d = L.GemmDesc(M, N, K, _p(A), lda, int(a_kmajor), _p(A2), lda2, k_split, _p(B), ldb, int(b_kmajor),
                    _p(out), ldc, _p(bias), _p(rowbias), rowbias_period, ld_rowbias, _p(rowscale), act,
                    _p(aux_in), _p(aux_out), ld_aux, _p(residual), ldr, split_k, _p(ws), _p(colsum),
-                   bp, bp_ld, bp_stride,
-                   pieces if pieces is not None else _PIECES["tn" if not a_kmajor else ("nt" if b_kmajor else "nn")])
+                   pc, None, None, None)
+    gemm.last_c_amax = None
+    if pc == 3 and _F16_PIECES[0] and A2 is None:
+        key = (M, N, K, int(a_kmajor), int(b_kmajor), act, split_k, colsum is None, bias is None, rowbias is None, rowscale is None,
+               aux_in is None, aux_out is None, residual is None, lda % 4, ldb % 4, ldc % 4, ld_aux % 4, ldr % 4,
+               (A.data_ptr() | B.data_ptr() | out.data_ptr()) & 15, _GEMM_MODE)
+        if _gemm_path(d, key) == 3:
+            if a_amax is None:
+                a_amax = amax_for(A)
+            if b_amax is None:
+                b_amax = weight_amax(B) if (b_is_weight if b_is_weight is not None else kind != "tn") else amax_for(B)
+            d.pieces, d.a_absmax, d.b_absmax = 4, a_amax.data_ptr(), b_amax.data_ptr()
+            if split_k <= 1 and colsum is None:
+                cw = _amax_words(1, out.device)[0]
+                d.c_absmax = cw.data_ptr()
+                gemm.last_c_amax = cw
     L.check(L.load().gaot_gemm_f32(C.byref(d), _stream()), "gaot_gemm_f32")
     return out
 
 
-# --------------------------------------------------------------------------------------------
-# Pre-split weight planes (gaot_gemm_desc.b_planes).  The split-bf16 tile kernels form three bf16 pieces of every fp32 operand
-# element on its way into LDS -- once per workgroup per k-tile, so a weight matrix is re-split by every row tile of the
-# activations (64 times at 8 192 tokens).  trainer.TrainStep keeps the pieces of every Linear weight in two flat plane buffers
-# (as stored, and transposed for the input-gradient products), refreshed by ONE launch after each optimizer step; while a
-# TrainStep.step() is running (`_PLANES_ACTIVE`) every GEMM whose B operand is such a weight hands the kernel its planes.
-# Bit-identical results (the planes are exactly what the kernel would have computed); outside TrainStep nothing changes.
-# --------------------------------------------------------------------------------------------
-_PLANES_ACTIVE = [False]
-_WEIGHT_PLANES: dict = {}     # weight data_ptr -> (rows_avail, cols, k_ptr, k_ld, k_stride, t_ptr, t_ld, t_stride)
-
-
-def register_weight_planes(table: dict) -> None:
-    _WEIGHT_PLANES.clear()
-    _WEIGHT_PLANES.update(table)
-
-
-def _weight_planes(B, N: int, K: int, ldb: int, b_kmajor: bool):
-    e = _WEIGHT_PLANES.get(B.data_ptr())
-    if e is None:
-        return None, 0, 0
-    rows, cols, k_ptr, k_ld, k_stride, t_ptr, t_ld, t_stride = e
-    if b_kmajor:              # B = W [N, K] as stored: rows of W are the GEMM's n, columns its k
-        if N <= rows and K == cols and ldb == cols:
-            return C.c_void_p(k_ptr), k_ld, k_stride
-    else:                     # B = W [K', N'] used as Bop[k'][n']: the planes of W^T (n' = W's column, k' = W's row)
-        if K <= rows and N <= cols and ldb == cols:
-            return C.c_void_p(t_ptr), t_ld, t_stride
-    return None, 0, 0
+gemm.last_c_amax = None
 
 
 # tuning switch (tools / A-B runs only): GAOT_GEMM_MODE = argument of gaot_debug_set_gemm_glds (default 4: fp32 MFMA tiles
@@ -290,7 +431,7 @@ def matmul_nn(g: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = No
 
 
 def matmul_tn(g: torch.Tensor, x2: torch.Tensor, out: Optional[torch.Tensor] = None,
-              colsum_out: Optional[torch.Tensor] = None, final: bool = False) -> torch.Tensor:
+              colsum_out: Optional[torch.Tensor] = None, final: bool = False, g_amax=None, x_amax=None) -> torch.Tensor:
     """out[N,K] = g[M,N]^T @ x2[M,K]   (weight gradient); split-K over the long M reduction.
     colsum_out[N] (optional) receives sum_m g[m,:] -- the bias gradient -- from the same pass over g.
     `final`: `out` (and `colsum_out`) are a PARAMETER's registered gradient slices (ops._claim): nothing reads them before the
@@ -305,7 +446,10 @@ def matmul_tn(g: torch.Tensor, x2: torch.Tensor, out: Optional[torch.Tensor] = N
         # a caller-provided destination (the parameter's slice of the flat gradient buffer) inside a deferral scope: the product
         # joins the grouped launch at the end of the backward pass (flush_wgrad); operands stay alive in the queue until then
         # the queue keeps ALIASES, not the tensor objects handed back to autograd (an extra reference to those makes AccumulateGrad clone)
-        _WGRAD_QUEUE.append((g, lda, x2, ldb, out.detach(), out.stride(0), None if colsum_out is None else colsum_out.detach(), N, K, M))
+        if _PIECES["tn"] == 3 and _F16_PIECES[0]:      # the operands' magnitude words, now (the tensors' producers may have published them)
+            g_amax = g_amax if g_amax is not None else amax_for(g)
+            x_amax = x_amax if x_amax is not None else amax_for(x2)
+        _WGRAD_QUEUE.append((g, lda, x2, ldb, out.detach(), out.stride(0), None if colsum_out is None else colsum_out.detach(), N, K, M, g_amax, x_amax))
         _note_deferred(out)
         if colsum_out is not None:
             _note_deferred(colsum_out)
@@ -313,7 +457,7 @@ def matmul_tn(g: torch.Tensor, x2: torch.Tensor, out: Optional[torch.Tensor] = N
     if out is None:
         out = torch.empty(N, K, device=g.device, dtype=torch.float32)
     ldc = out.stride(0) if N > 1 else K
-    return gemm(N, K, M, g, lda, 0, x2, ldb, 0, out, ldc, split_k=_split_for_reduction(N, K, M), colsum=colsum_out)
+    return gemm(N, K, M, g, lda, 0, x2, ldb, 0, out, ldc, split_k=_split_for_reduction(N, K, M), colsum=colsum_out, a_amax=g_amax, b_amax=x_amax)
 
 
 # --------------------------------------------------------------------------------------------
@@ -361,12 +505,19 @@ class deferred_wgrad:
 
 
 def wgrad_launch(items) -> None:
-    """items: (g [K,M], ldg, x [K,N], ldx, out [M,N], ldo, colsum or None, M, N, K).  One gaot_gemm_tn_grouped call."""
+    """items: (g [K,M], ldg, x [K,N], ldx, out [M,N], ldo, colsum or None, M, N, K[, g_amax, x_amax]).  One gaot_gemm_tn_grouped call."""
     lib = L.load()
     n = len(items)
     arr = (L.WgradItem * n)()
-    for i, (g, ldg, x2, ldx, out, ldo, cs, Mo, No, K) in enumerate(items):
-        arr[i] = L.WgradItem(g.data_ptr(), ldg, x2.data_ptr(), ldx, out.data_ptr(), ldo, None if cs is None else cs.data_ptr(), Mo, No, K)
+    f16 = _PIECES["tn"] == 3 and _F16_PIECES[0]
+    for i, it in enumerate(items):
+        g, ldg, x2, ldx, out, ldo, cs, Mo, No, K = it[:10]
+        ga, xa = (it[10], it[11]) if len(it) > 10 else (None, None)
+        if f16:
+            ga = ga if ga is not None else amax_for(g)
+            xa = xa if xa is not None else amax_for(x2)
+        arr[i] = L.WgradItem(g.data_ptr(), ldg, x2.data_ptr(), ldx, out.data_ptr(), ldo, None if cs is None else cs.data_ptr(), Mo, No, K,
+                             None if ga is None else ga.data_ptr(), None if xa is None else xa.data_ptr())
     cnt = C.c_int32(0)
     need = int(lib.gaot_gemm_tn_grouped_workspace(arr, n, C.byref(cnt)))
     if need < 0:
@@ -385,7 +536,7 @@ def wgrad_launch(items) -> None:
             _WGRAD_COUNTERS_RETIRED.append(ctr)      # a captured graph may hold its address (and zero it at every replay): keep it alive
         ctr = torch.zeros(max(65536, 4 * cnt.value), device=dev, dtype=torch.int32)
         _WGRAD_COUNTERS[key] = ctr
-    L.check(lib.gaot_gemm_tn_grouped(arr, n, _PIECES["tn"], _p(ws), _p(ctr), _stream()), "gaot_gemm_tn_grouped")
+    L.check(lib.gaot_gemm_tn_grouped(arr, n, 4 if f16 else _PIECES["tn"], _p(ws), _p(ctr), _stream()), "gaot_gemm_tn_grouped")
 
 
 def flush_wgrad() -> None:
@@ -402,9 +553,9 @@ def flush_wgrad() -> None:
     _WGRAD_QUEUE.clear()
     # a grouped launch lasts as long as one workgroup's K loop: a queue of one or two small products (the encoder's stage group of a
     # staged backward: ONE 64 x 64 product over 32 768 rows, 113 us as a grouped launch) runs faster as plain split-K products
-    if sum(((Mo + 127) // 128) * ((No + 127) // 128) for *_, Mo, No, K in items) <= 4:
-        for g, ldg, x2, ldx, out, ldo, cs, Mo, No, K in items:
-            gemm(Mo, No, K, g, ldg, 0, x2, ldx, 0, out, ldo, split_k=_split_for_reduction(Mo, No, K), colsum=cs)
+    if sum(((it[7] + 127) // 128) * ((it[8] + 127) // 128) for it in items) <= 4:
+        for g, ldg, x2, ldx, out, ldo, cs, Mo, No, K, ga, xa in items:
+            gemm(Mo, No, K, g, ldg, 0, x2, ldx, 0, out, ldo, split_k=_split_for_reduction(Mo, No, K), colsum=cs, a_amax=ga, b_amax=xa)
         return
     wgrad_launch(items)
 
@@ -562,9 +713,11 @@ class _Linear(torch.autograd.Function):
         if rowbias is not None:
             rb, ldrb = _rowmajor(rowbias.reshape(-1, N))
             epi.update(rowbias=rb, rowbias_period=rb.shape[0], ld_rowbias=ldrb)
+        cw = None
         if x2 is None:
             assert w2d.shape[1] == K
-            y = linear_nt(xm, w2d, **epi)
+            y = linear_nt(xm, w2d, a_amax=_amax_get(x, xm), **epi)
+            cw = gemm.last_c_amax
             x2m = None
         else:
             K2 = x2.shape[-1]
@@ -580,11 +733,15 @@ class _Linear(torch.autograd.Function):
                 linear_nt(xm_, wc[:, :K], out=y, **epi)
                 linear_nt(x2m_, wc[:, K:], out=y, residual=y, ldr=N)
         ctx.save_for_backward(xm, x2m, w2d)
+        ctx.amax_x = _amax_get(xm, x)          # the input's magnitude word, for the weight-gradient product (saved_tensors are new objects)
+        _publish(ctx.amax_x, x)
         ctx.slots = (_claim(w), _claim(b))
         ctx.meta = (shp, x2.shape if x2 is not None else None, w.shape, b is not None,
                     residual.shape if residual is not None else None,
                     rowbias.shape if rowbias is not None else None)
-        return y.reshape(*shp[:-1], N)
+        yr = y.reshape(*shp[:-1], N)
+        _publish(cw, y, yr)
+        return yr
 
     @staticmethod
     def backward(ctx, dy):
@@ -597,7 +754,9 @@ class _Linear(torch.autograd.Function):
         need = ctx.needs_input_grad
         dx = dw = db = dres = drb = dx2 = None
         if need[0]:
-            dx = matmul_nn(g, w2d[:, :K]).reshape(shp)
+            dx2d = matmul_nn(g, w2d[:, :K], a_amax=_amax_get(g, dy))
+            dx = dx2d.reshape(shp)
+            _publish(gemm.last_c_amax, dx2d, dx)
         if need[5] and x2m is not None:
             dx2 = matmul_nn(g, w2d[:, K:]).reshape(shp2)
         want_db = has_b and need[2]
@@ -609,7 +768,7 @@ class _Linear(torch.autograd.Function):
             # final: both destinations are the parameters' own gradient slices (a bias gradient without its slice is read by
             # autograd right away, so it keeps the product immediate)
             fin = wslot is not None and (db is None or bslot is not None)
-            matmul_tn(g, xm, out=dw[:, :K], colsum_out=db, final=fin)
+            matmul_tn(g, xm, out=dw[:, :K], colsum_out=db, final=fin, g_amax=_amax_get(g, dy), x_amax=ctx.amax_x)
             if x2m is not None:
                 matmul_tn(g, x2m, out=dw[:, K:], final=wslot is not None)
             dw = dw.reshape(wshape)
@@ -810,22 +969,31 @@ class _LinearCat(torch.autograd.Function):
         shp = x.shape
         xm = x.reshape(-1, shp[-1])
         W = stacked_rows(ws)
-        y = linear_nt(xm, W)
+        y = linear_nt(xm, W, a_amax=_amax_get(x, xm))
+        cw = gemm.last_c_amax
         ctx.save_for_backward(xm, W)
+        ctx.amax_x = _amax_get(xm, x)
+        _publish(ctx.amax_x, x)
         slots = [_claim(w) for w in ws]
         ctx.slot = adjacent_rows(slots) if all(s_ is not None for s_ in slots) else None
         ctx.meta = (shp, [w.shape[0] for w in ws])
-        return y.reshape(*shp[:-1], W.shape[0])
+        yr = y.reshape(*shp[:-1], W.shape[0])
+        _publish(cw, y, yr)
+        return yr
 
     @staticmethod
     def backward(ctx, dy):
         xm, W = ctx.saved_tensors
         shp, rows = ctx.meta
         g, _ = _rowmajor(dy.reshape(-1, W.shape[0]))
-        dx = matmul_nn(g, W).reshape(shp) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx2d = matmul_nn(g, W, a_amax=_amax_get(g, dy))
+            dx = dx2d.reshape(shp)
+            _publish(gemm.last_c_amax, dx2d, dx)
         dws = [None] * len(rows)
         if any(ctx.needs_input_grad[1:]):
-            dws = list(matmul_tn(g, xm, out=ctx.slot, final=ctx.slot is not None).split(rows, dim=0))
+            dws = list(matmul_tn(g, xm, out=ctx.slot, final=ctx.slot is not None, g_amax=_amax_get(g, dy), x_amax=ctx.amax_x).split(rows, dim=0))
         return (dx, *dws)
 
 
@@ -1662,17 +1830,23 @@ class _SwiGLUFFN(torch.autograd.Function):
             residual = x
         u = torch.empty(M, 2 * F, device=x.device, dtype=torch.float32)
         g = torch.empty(M, F, device=x.device, dtype=torch.float32)
-        gemm(M, 2 * F, K, xm, lda, 1, w13, K, 1, g, F, act=L.ACT_SWIGLU, aux_out=u, ld_aux=2 * F)
+        gemm(M, 2 * F, K, xm, lda, 1, w13, K, 1, g, F, act=L.ACT_SWIGLU, aux_out=u, ld_aux=2 * F, a_amax=_amax_get(x, xm))
+        _publish(gemm.last_c_amax, g)
         epi = {}
         if residual is not None:
             res2, ldr = _rowmajor(residual.reshape(M, No))
             epi.update(residual=res2, ldr=ldr)
         y = linear_nt(g, w2, **epi)
+        cw = gemm.last_c_amax
+        ctx.amax = (_amax_get(xm, x), _amax_get(g))
+        _publish(ctx.amax[0], x)
         ctx.save_for_backward(xm, u, g, w13, w2)
         s1, s3, s2 = _claim(w1), _claim(w3), _claim(w2)
         ctx.slots = (adjacent_rows([s1, s3]) if (s1 is not None and s3 is not None) else None, s2)
         ctx.meta = (shp, residual.shape if (residual is not None and not res_is_x) else None, bool(res_is_x))
-        return y.reshape(*shp[:-1], No)
+        yr = y.reshape(*shp[:-1], No)
+        _publish(cw, y, yr)
+        return yr
 
     @staticmethod
     def backward(ctx, dy):
@@ -1684,15 +1858,19 @@ class _SwiGLUFFN(torch.autograd.Function):
         need = ctx.needs_input_grad
         w2c, ldw2 = _rowmajor(w2)
         du = torch.empty(M, 2 * F, device=d.device, dtype=torch.float32)
-        gemm(M, F, No, d, ldd, 1, w2c, ldw2, 0, du, 2 * F, act=L.ACT_SWIGLU_BWD, aux_in=u, ld_aux=2 * F)
+        ax, ag = ctx.amax
+        gemm(M, F, No, d, ldd, 1, w2c, ldw2, 0, du, 2 * F, act=L.ACT_SWIGLU_BWD, aux_in=u, ld_aux=2 * F, a_amax=_amax_get(d, dy))
+        _publish(gemm.last_c_amax, du)
         slot13, slot2 = ctx.slots
-        dw2 = matmul_tn(d, g, out=slot2.detach() if slot2 is not None else None, final=slot2 is not None) if need[3] else None
+        dw2 = matmul_tn(d, g, out=slot2.detach() if slot2 is not None else None, final=slot2 is not None, g_amax=_amax_get(d, dy), x_amax=ag) if need[3] else None
         dx = None
         if need[0]:
-            dx = (matmul_nn(du, w13, residual=d, ldr=ldd) if res_is_x else matmul_nn(du, w13)).reshape(shp)
+            dx2d = matmul_nn(du, w13, residual=d, ldr=ldd) if res_is_x else matmul_nn(du, w13)
+            dx = dx2d.reshape(shp)
+            _publish(gemm.last_c_amax, dx2d, dx)
         dw1 = dw3 = None
         if need[1] or need[2]:
-            dw13 = matmul_tn(du, xm, out=slot13, final=slot13 is not None)
+            dw13 = matmul_tn(du, xm, out=slot13, final=slot13 is not None, g_amax=_amax_get(du), x_amax=ax)
             dw1, dw3 = dw13[:F], dw13[F:]
         dres = dy.reshape(res_shape) if (res_shape is not None and need[4]) else None
         return dx, dw1, dw3, dw2, dres, None

@@ -254,59 +254,6 @@ class FlatAdamW(torch.optim.Optimizer):
     def zero_grad(self, set_to_none: bool = True):
         self.bucket.clear()
 
-    # ---- pre-split weight planes (ops._WEIGHT_PLANES): the three bf16 pieces the split-bf16 GEMM kernels form from every fp32
-    # operand, kept for every Linear weight as stored and transposed, refreshed by one launch after each update
-    def build_planes(self, groups):
-        """groups: lists of parameters stored back to back that fused GEMMs read as one matrix (fused_weight_groups())"""
-        import ctypes as C
-        from . import _lib as L
-        off = {id(p): o for p, o in zip(self.bucket.params, self.bucket.offsets)}
-        in_group = {}
-        mats = []                                   # (first offset, rows_total, cols, [(param, row offset)])
-        for g in groups or []:
-            if all(id(p) in off for p in g) and all(p.dim() >= 2 for p in g):
-                cols = g[0].numel() // g[0].shape[0]
-                rows, members, o0, ok = 0, [], off[id(g[0])], True
-                for p in g:
-                    ok = ok and p.numel() // p.shape[0] == cols and off[id(p)] == o0 + rows * cols
-                    members.append((p, rows))
-                    rows += p.shape[0]
-                if ok:
-                    mats.append((o0, rows, cols, members))
-                    in_group.update({id(p): True for p in g})
-        for p in self.bucket.params:
-            if id(p) not in in_group and p.dim() >= 2 and p.shape[0] > 1:
-                mats.append((off[id(p)], p.shape[0], p.numel() // p.shape[0], [(p, 0)]))
-        mats = [m for m in mats if m[1] % 8 == 0 and m[2] % 8 == 0 and m[1] >= 32 and m[2] >= 32]
-        n = self.flat_p.numel()
-        self.planes_k = torch.zeros(3, n, dtype=torch.int16, device=self.flat_p.device)
-        self.planes_t = torch.zeros(3, n, dtype=torch.int16, device=self.flat_p.device)
-        items, table = [], {}
-        base_p, base_k, base_t = self.flat_p.data_ptr(), self.planes_k.data_ptr(), self.planes_t.data_ptr()
-        for o0, rows, cols, members in mats:
-            items.append(L.SplitItem(base_p + 4 * o0, cols, rows, cols, base_k + 2 * o0, cols, n, 0))
-            items.append(L.SplitItem(base_p + 4 * o0, cols, rows, cols, base_t + 2 * o0, rows, n, 1))
-            for prm, r_off in members:
-                # rows available from this member on, W's column count, planes as stored (row r_off on), planes of W^T (column r_off on)
-                table[prm.data_ptr()] = (rows - r_off, cols, base_k + 2 * (o0 + r_off * cols), cols, n, base_t + 2 * (o0 + r_off), rows, n)
-        self._split_items = (L.SplitItem * len(items))(*items) if items else None
-        self._planes_table = table
-        self._plane_versions = None
-        self.refresh_planes()
-
-    def refresh_planes(self):
-        """(re)compute every plane from the current weights: one launch (capturable)"""
-        if getattr(self, "_split_items", None) is None:
-            return
-        from . import _lib as L
-        from .ops import _stream
-        L.check(L.load().gaot_split_planes_grouped(self._split_items, len(self._split_items), _stream()), "gaot_split_planes_grouped")
-        self._plane_versions = tuple(p._version for p in self.bucket.params)
-
-    def planes_current(self) -> bool:
-        """no parameter was written through torch since the planes were last computed (raw-pointer updates by step() refresh them itself)"""
-        return self._plane_versions == tuple(p._version for p in self.bucket.params)
-
     def step(self, closure=None, _sync: bool = True):
         from . import _lib as L
         from . import ops
@@ -316,8 +263,6 @@ class FlatAdamW(torch.optim.Optimizer):
         L.check(L.load().gaot_adamw_step_dev(_p(self.flat_p), _p(self.bucket.flat), _p(self.m), _p(self.v), self.flat_p.numel(),
                                              _p(self.hyper), _p(self.step_count), _stream()), "gaot_adamw_step_dev")
         ops.bump_weights_generation()      # the kernel writes through raw pointers: Parameter._version does not move
-        if getattr(self, "_split_items", None) is not None:
-            self.refresh_planes()          # the pieces of the NEW weights, for the next step's GEMMs (part of the captured update)
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None):
@@ -390,12 +335,6 @@ class TrainStep:
         on_gpu = dev.type == "cuda"
         if on_gpu:
             self.opt = FlatAdamW(self.bucket, lr=lr, weight_decay=weight_decay)
-            import os
-            # pre-split weight planes: measured NEGATIVE on the bench step (2.74 vs 2.62 ms, same box, alternating runs): the tile
-            # kernels are not bound by the split arithmetic, and three 16-byte plane loads per thread and k-tile cost more than
-            # two fp32 ones.  Kept as a tested option (bit-identical results), off by default.
-            if os.environ.get("GAOT_WEIGHT_PLANES", "0") == "1":
-                self.opt.build_planes(groups)
         else:           # CPU (gloo tests of the data-parallel plumbing): torch's own AdamW, parameters in MODEL order
             self.opt = torch.optim.AdamW(self.bucket.model_order, lr=lr, weight_decay=weight_decay)
         # per-step random neighbour sub-sampling (MAGNOConfig.sampling_strategy) draws masks and syncs: not capturable
@@ -547,32 +486,13 @@ class TrainStep:
             self.opt.step(_sync=False)
         for dst, src in zip((self.opt.flat_p, self.opt.m, self.opt.v, self.opt.step_count), snap):
             dst.copy_(src)
-        self.opt.refresh_planes()          # the planes followed the warm-up updates: back to the restored weights
-
-    def _planes_on(self):
-        """hand the GEMMs of this step the pre-split weight planes (ops._weight_planes) -- after making sure they describe the
-        current weights: anything that wrote a parameter through torch since the last refresh (load_state_dict, a manual edit)
-        moved its _version"""
-        opt = self.opt
-        if getattr(opt, "_planes_table", None):
-            from . import ops
-            if not opt.planes_current():
-                opt.refresh_planes()
-            ops.register_weight_planes(opt._planes_table)
-            ops._PLANES_ACTIVE[0] = True
 
     def step(self, pndata: Optional[torch.Tensor] = None, target: Optional[torch.Tensor] = None) -> torch.Tensor:
         if pndata is not None:
             self._x.copy_(pndata, non_blocking=True)
         if target is not None:
             self._y.copy_(target, non_blocking=True)
-        self._planes_on()
-        try:
-            return self._step()
-        finally:
-            if self.bucket.flat.is_cuda:
-                from . import ops
-                ops._PLANES_ACTIVE[0] = False
+        return self._step()
 
     def _step(self) -> torch.Tensor:
         if not self.use_graph:

@@ -44,6 +44,10 @@ enum gaot_act {
 int gaot_abi_version(void);
 const char* gaot_last_error(void);
 
+/* A "magnitude word" (gaot_gemm_desc.a_absmax ..., gaot_absmax_grouped) is GAOT_AMAX_SLOTS floats, 256-byte aligned: producers publish
+ * max |x| into the slot their workgroup index selects (atomic max on the float bit pattern), consumers take the maximum of the slots. */
+#define GAOT_AMAX_SLOTS 64
+
 /* ------------------------------------------------------------------------------------------
  * fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32), fused prologue/epilogue.
  * Replaces every nn.Linear / Conv1d(k=1) on the path and their backward products:
@@ -72,24 +76,38 @@ typedef struct gaot_gemm_desc {
     const float* residual; int64_t ldr;
     int32_t split_k; float* workspace;
     float* colsum;   /* optional, a_kmajor = 0 only: colsum[m] = sum_k Aop[m,k] (bias gradient fused into dW = dY^T X) */
-    /* optional: Bop PRE-SPLIT into the three bf16 pieces the split-bf16 tile kernels form from every fp32 operand (weights: split
-     * once per optimizer step by gaot_split_planes_grouped instead of once per workgroup per k-tile).  Piece q of Bop[k,n] is the
-     * 16-bit word b_planes[q * b_plane_stride + n * ld_bplanes + k] (k-contiguous whatever b_kmajor says).  Products are bit-identical
-     * with and without; kernels that do not take planes ignore the field.  ld_bplanes, b_plane_stride multiples of 8. */
-    const void* b_planes; int64_t ld_bplanes; int64_t b_plane_stride;
     /* precision of the product where the split-bf16 tile kernels run it (per call, no global state): 0 or 3 = every fp32 operand as
      * THREE bf16 pieces, six piece products: exact to fp32 rounding (error vs float64 ~ 2e-7, like the fp32 MFMA); 2 = TWO pieces, both
      * rounded to nearest (x = h + m + e, |e| <= 2^-18 |x|, unbiased), three piece products: 16 significant bits per operand, half the
-     * matrix-pipe work.  Kernels on the fp32 MFMA / vector pipe ignore the field.  Anything else: GAOT_ERR_INVALID. */
+     * matrix-pipe work.  4 = TWO fp16 pieces of the SCALED operand, both rounded to nearest, three piece products on
+     * v_mfma_f32_32x32x16_f16: with s = the power of two that puts the operand's largest magnitude into [2^13, 2^14), s x = h + m + e,
+     * |e| <= 2^-24 |s x| (one fp32 rounding; zero for three values in four) for every element within 2^-16 of the largest, an absolute
+     * 2^-39 of the largest below that: fp32-level products (measured error vs float64 at or below the three-piece products') at the
+     * matrix-pipe work of the two-piece ones.  Needs a_absmax / b_absmax; without them, and on kernels off the split tiles, it means 3.
+     * Kernels on the fp32 MFMA / vector pipe ignore the field.  Anything else: GAOT_ERR_INVALID. */
     int32_t pieces;
+    /* pieces = 4: device magnitude words (GAOT_AMAX_SLOTS floats each) holding max |Aop| and max |Bop| (an upper bound is as good: one
+     * binade of slack costs nothing), read by the kernel -- no host value, so a captured launch follows the data.  gaot_absmax_grouped
+     * computes them; producers publish them. */
+    const float* a_absmax; const float* b_absmax;
+    /* optional (any pieces): the magnitude word of C as this launch stores it (atomic max per slot): the word must be ZERO (or hold a
+     * running maximum of the same tensor) before the launch.  Not with split_k > 1.  The next product's a_absmax. */
+    float* c_absmax;
 } gaot_gemm_desc;
 
 int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream);
+/* which kernel family gaot_gemm_f32 WOULD run this product on: 1 = fp32-MFMA tiles, 2 = skinny vector kernels, 3 = split tiles on the
+ * bf16 / fp16 matrix pipe (the only ones that read pieces / *_absmax); launches nothing; < 0 on a bad descriptor */
+int gaot_gemm_path(const gaot_gemm_desc* d);
+/* magnitude words for pieces = 4: max over the slots of out_i = max(that, max |x_i[r * ld + c]|) over rows x cols, n matrices in ONE
+ * launch (atomic max per slot: zero the words first, or let them accumulate over pieces of one tensor).  NaNs are ignored. */
+typedef struct gaot_absmax_item { const float* x; int64_t ld; int32_t rows, cols; float* out; } gaot_absmax_item;
+int gaot_absmax_grouped(const gaot_absmax_item* items, int32_t n, gaot_stream_t stream);
 
 /* Grouped weight-gradient products: ONE launch over n products  out_i[M_i,N_i] = g_i[K_i,M_i]^T x_i[K_i,N_i]  (+ colsum_i[m] =
  * sum_k g_i[k,m], the bias gradient), i.e. dW = dY^T X (and db) of every nn.Linear / Conv1d(k=1) whose backward has been
  * reached (mlp.py:283-305, attn.py:92-117,150-156,225-227, gaot.py:208: autograd runs them one by one, each a long reduction
- * over all tokens into a small matrix).  Products on the bf16 matrix pipe with `pieces` (0 / 3 or 2) as gaot_gemm_desc.pieces; K slabs (4 096 rows; the matrix pipe accumulates runs of 1 024, the running sums live in registers) are summed in slab order by
+ * over all tokens into a small matrix).  Products on the bf16 / fp16 matrix pipe with `pieces` (0 / 3, 4 or 2) as gaot_gemm_desc.pieces (4 falls back to 3 unless every item carries its magnitude words); K slabs (4 096 rows; the matrix pipe accumulates runs of 1 024, the running sums live in registers) are summed in slab order by
  * the last workgroup to finish a tile (deterministic, no atomics on data).
  * Needs M, N % 4 == 0, K % 32 == 0, ld* % 4 == 0, 16-byte aligned pointers.  `workspace`: >= gaot_gemm_tn_grouped_workspace()
  * floats; `counters`: >= *n_counters int32, ZERO before the first call (every call leaves them zero again). */
@@ -99,19 +117,10 @@ typedef struct gaot_wgrad_item {
     float* out;      int64_t ldo;     /* [M, N]: dW                                                        */
     float* colsum;                    /* optional [M]: db                                                  */
     int32_t M, N, K;
+    const float* g_absmax; const float* x_absmax;   /* pieces = 4: magnitude words of g and x (as gaot_gemm_desc.a_absmax); else may be NULL */
 } gaot_wgrad_item;
 int64_t gaot_gemm_tn_grouped_workspace(const gaot_wgrad_item* items, int32_t n, int32_t* n_counters);
 int gaot_gemm_tn_grouped(const gaot_wgrad_item* items, int32_t n, int32_t pieces, float* workspace, int32_t* counters, gaot_stream_t stream);
-
-/* Exact three-way bf16 split of fp32 matrices into planes for gaot_gemm_desc.b_planes, n matrices per launch: item i reads
- * src[r * ld + c] (rows x cols) and writes piece q of element (r, c) to planes[q * plane_stride + r * ld_out + c], or -- transpose
- * != 0 -- to planes[q * plane_stride + c * ld_out + r] (the planes of the TRANSPOSED matrix: what the input-gradient product
- * dX = dY W reads as its k-contiguous B operand).  x = p0 + p1 + p2 exactly (8 + 8 + 8 significant bits, truncation). */
-typedef struct gaot_split_item {
-    const float* src; int64_t ld; int32_t rows, cols;
-    void* planes; int64_t ld_out; int64_t plane_stride; int32_t transpose;
-} gaot_split_item;
-int gaot_split_planes_grouped(const gaot_split_item* items, int32_t n, gaot_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Geometry plan pieces (once per mesh geometry; torch_scatter / repeat_interleave call sites

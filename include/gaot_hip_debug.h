@@ -27,13 +27,6 @@ int gaot_debug_set_gemm_glds(int on);
 /* 3 (default): fp32-level products from three bf16 pieces per operand; 1: operands rounded to bf16, one piece product, fp32
  * accumulation -- the separately reported `bench.py --dtype bf16` variant only (BASELINE configs[1]); returns the old value. */
 int gaot_debug_set_gemm_pieces(int pieces);
-/* split-bf16 tile kernels: 0 = one workgroup per tile; n > 0 = launches of more than n workgroups run persistently with n */
-int gaot_debug_set_split_persist(int n);
-/* 1: the fp32-level bf16-pipe products use the LDS-direct kernel (fp32 tiles by DMA, operands split in registers) instead of the
- * plane kernel; 0: the plane kernel (gemm_split.hip).  Returns the old value. */
-int gaot_debug_set_gemm_gsplit(int on);
-/* 0: ignore gaot_gemm_desc.b_planes (same-box A/B of the pre-split weight planes); returns the old value */
-int gaot_debug_set_gemm_planes(int on);
 /* grouped weight gradients: values of k per workgroup (K slab length; multiple of 32, default 4096) */
 int gaot_debug_set_wgrad_kslab(int k);
 /* tuning hook: head_dim 32 attention, 1 = split-bf16 MFMA kernels (default), 0 = fp32-MFMA kernels, 2 / 3 = split with the

@@ -531,13 +531,15 @@ def test_swiglu_ffn_fused_matches_unfused(M, K, F):
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", [5, 7, 11])
 @pytest.mark.parametrize("M,N,K", [(200, 132, 64), (520, 260, 96), (1000, 64, 256), (4096, 512, 1024)])
-def test_gemm_split_bf16_kernel(M, N, K, mode):
+def test_gemm_split_bf16_kernel(M, N, K, mode, request):
     """gemm_split.hip: fp32 operands split exactly into three bf16 pieces, six bf16 MFMAs per product.  Forced on
     (mode 5) for every layout / epilogue it serves; must be as accurate as the fp32 MFMA kernel (float64 reference),
     including operands whose rows differ by orders of magnitude.  mode 5 = 128x128 tiles, 7 = 64-row tiles, 11 = 256-row (8-wave)
-    tiles wherever M >= 512."""
+    tiles wherever M >= 512.  Runs with ops.set_f32_pieces("bf16x3"): the three-piece kernels are what serves operands without magnitude
+    words and the A/B of the default fp16-piece products (test_gemm_fp16_piece_products pins those, incl. their own dynamic-range bound)."""
     from gaot_amd import ops, _lib
     lib = _lib.load()
+    request.addfinalizer(lambda old=ops.set_f32_pieces("bf16x3"): ops.set_f32_pieces(old))
     g = torch.Generator().manual_seed(M + N + K)
     x = torch.randn(M, K, generator=g) * torch.exp(3 * torch.randn(M, 1, generator=g))
     w, gy = torch.randn(N, K, generator=g), torch.randn(M, N, generator=g)
@@ -575,6 +577,71 @@ def test_gemm_split_bf16_kernel(M, N, K, mode):
     # element-wise: error relative to sum |a||b| stays at the fp32 rounding level (no lost low-order pieces)
     scale = xd.abs() @ wd.abs().t()
     assert float(((z.double().cpu() - z_ref).abs() / (scale + 1)).max()) < 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(8192, 2048, 256), (8192, 256, 1024), (4096, 768, 256), (520, 260, 96)])
+def test_gemm_fp16_piece_products(M, N, K):
+    """gaot_gemm_desc.pieces = 4, the way the default "f32" precision runs on the split tiles: every operand scaled by the power of two
+    that puts its largest magnitude (a device word: published by its producer or computed by gaot_absmax_grouped) into [2^13, 2^14) and
+    split into TWO fp16 pieces, both rounded to nearest (s x = h + m + e, |e| <= 2^-24 |s x|), three piece products on the f16 MFMA.
+      * random normal operands at magnitudes from 1e-9 to 1e+9: all three product kinds and the grouped launch are AT LEAST as close to
+        float64 as the three-piece bf16 products (fewer accumulation steps on the matrix pipe), < 6e-7;
+      * the words follow the data: the same tensor objects refilled with 1e6 x larger values (in place, through torch) give the same
+        relative error -- no stale scale, no overflow;
+      * dynamic range INSIDE an operand (the documented bound): rows 1e-4 below the largest keep fp32 accuracy; rows 1e-7 below it are
+        carried with an absolute error of 2^-39 of the operand's largest magnitude (relative 1e-4 for such a row: the three-piece
+        products, which need no scale, keep 2.4e-7 there -- set_f32_pieces("bf16x3") selects them)."""
+    from gaot_amd import ops, _lib
+    lib = _lib.load()
+    assert ops.precision() == "f32" and ops._F16_PIECES[0]
+    g = torch.Generator().manual_seed(M + N + K)
+    Mk = M - M % 32
+    for mag_a, mag_b in ((1.0, 0.06), (1e-9, 30.0), (1e9, 1e-3)):
+        x, w, dy = torch.randn(M, K, generator=g) * mag_a, torch.randn(N, K, generator=g) * mag_b, torch.randn(M, N, generator=g) * mag_a
+        xd, wd, dyd = x.cuda(), w.cuda(), dy.cuda()
+        ref = {"nt": x.double() @ w.double().t(), "nn": dy.double() @ w.double(), "tn": dy[:Mk].double().t() @ x[:Mk].double()}
+        run = {"nt": lambda: ops.linear_nt(xd, wd), "nn": lambda: ops.matmul_nn(dyd, wd), "tn": lambda: ops.matmul_tn(dyd[:Mk], xd[:Mk])}
+        for kind in ("nt", "nn", "tn"):
+            e4 = rel(run[kind](), ref[kind])
+            split = lib.gaot_debug_last_gemm_path() == 3
+            old = ops.set_f32_pieces("bf16x3")
+            try:
+                e3 = rel(run[kind](), ref[kind])
+            finally:
+                ops.set_f32_pieces(old)
+            assert e4 < 6e-7 and e3 < 1e-6 and (not split or e4 < 1.05 * e3), (kind, mag_a, mag_b, e4, e3)
+        if N % 4 == 0 and K % 4 == 0 and Mk >= 1024:
+            out4, out3 = torch.empty(N, K, device="cuda"), torch.empty(N, K, device="cuda")
+            ops.wgrad_launch([(dyd[:Mk], N, xd[:Mk], K, out4, K, None, N, K, Mk)])
+            old = ops.set_f32_pieces("bf16x3")
+            try:
+                ops.wgrad_launch([(dyd[:Mk], N, xd[:Mk], K, out3, K, None, N, K, Mk)])
+            finally:
+                ops.set_f32_pieces(old)
+            assert rel(out4, ref["tn"]) < 6e-7 and rel(out4, ref["tn"]) < 1.05 * rel(out3, ref["tn"])
+            again = torch.empty_like(out4)
+            ops.wgrad_launch([(dyd[:Mk], N, xd[:Mk], K, again, K, None, N, K, Mk)])
+            assert torch.equal(again, out4)                      # deterministic
+    # the words follow the data: refill the SAME tensor objects (torch ops bump their version: the cached words are dropped)
+    e0 = rel(ops.linear_nt(xd, wd), ref["nt"])
+    xd.mul_(2.0 ** 20); wd.mul_(2.0 ** -3)
+    e1 = rel(ops.linear_nt(xd, wd), ref["nt"] * 2.0 ** 17)
+    assert abs(e1 - e0) < 1e-9, (e0, e1)                          # power-of-two rescaling: bit-identical up to the scale
+    # dynamic range inside an operand
+    x = torch.randn(M, K, generator=g)
+    x[1::4] *= 1e-4
+    x[2::4] *= 1e-7
+    y = ops.linear_nt(x.cuda(), w.cuda())
+    if lib.gaot_debug_last_gemm_path() == 3:
+        r = x.double() @ w.double().t()
+        assert rel(y[0::4], r[0::4]) < 6e-7 and rel(y[1::4], r[1::4]) < 6e-7
+        assert rel(y[2::4], r[2::4]) < 3e-4
+        old = ops.set_f32_pieces("bf16x3")
+        try:
+            assert rel(ops.linear_nt(x.cuda(), w.cuda())[2::4], r[2::4]) < 6e-7
+        finally:
+            ops.set_f32_pieces(old)
 
 
 @pytest.mark.gpu
@@ -1090,30 +1157,6 @@ def test_gemm_bf16_piece_mode_is_a_plain_bf16_gemm():
     assert rel(y3, x.double() @ w.double().t()) < 2e-6
 
 
-def test_gemm_gsplit_alternative_kernel_matches_float64():
-    """gemm_gsplit.hip (LDS-direct fp32 tiles, operands split in registers after the fragment reads): the measured alternative
-    to the plane kernel (same speed; selected with gaot_debug_set_gemm_gsplit).  NT / NN / TN + fused column sum."""
-    from gaot_amd import ops, _lib as L
-    lib = L.load()
-    g = torch.Generator().manual_seed(12)
-    M, N, K = 640, 384, 224
-    x, w, gy = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(M, N, generator=g)
-    old_mode, old = ops.set_gemm_mode(5), lib.gaot_debug_set_gemm_gsplit(1)
-    try:
-        for mode in (5, 7):
-            ops.set_gemm_mode(mode)
-            y = ops.linear_nt(x.to(dev()), w.to(dev()), bias=torch.ones(N, device=dev()))
-            assert lib.gaot_debug_last_gemm_path() == 3
-            dx = ops.matmul_nn(gy.to(dev()), w.to(dev()))
-            db = torch.empty(N, device=dev())
-            dw = ops.matmul_tn(gy.to(dev()), x.to(dev()), colsum_out=db)
-            assert rel(y, x.double() @ w.double().t() + 1) < 2e-6 and rel(dx, gy.double() @ w.double()) < 2e-6
-            assert rel(dw, gy.double().t() @ x.double()) < 2e-6 and rel(db, gy.double().sum(0)) < 2e-5
-    finally:
-        lib.gaot_debug_set_gemm_gsplit(old)
-        ops.set_gemm_mode(old_mode)
-
-
 def test_agno_with_relu_kernel_mlp_matches_float64():
     """channel_mlp_non_linearity other than the default GELU (reference agno.py:71, mlp.py:311): ReLU runs on the same fused
     kernels; anything else is refused by name"""
@@ -1319,75 +1362,3 @@ def test_colsum_grouped_contiguous_and_column_block_outputs():
         assert maxrel(o, r) < 2e-6
     assert maxrel(wide[:, 64:], ws[:, 4352:4352 + 4096].double().sum(0).view(64, 64)) < 2e-6 and float(wide[:, :64].abs().sum()) == 0.0
     assert maxrel(o2, small.double().sum(0)) < 2e-6
-
-
-# ------------------------------------------------------------------ pre-split weight planes
-def _planes_for(W):
-    """(k planes [3, N, K], t planes [3, K, N]) of W [N, K] through gaot_split_planes_grouped + the registry entry ops expects"""
-    import ctypes as C
-    from gaot_amd import _lib as L
-    N, K = W.shape
-    pk = torch.zeros(3, N * K, dtype=torch.int16, device=W.device)
-    pt = torch.zeros(3, N * K, dtype=torch.int16, device=W.device)
-    items = (L.SplitItem * 2)(L.SplitItem(W.data_ptr(), K, N, K, pk.data_ptr(), K, N * K, 0),
-                              L.SplitItem(W.data_ptr(), K, N, K, pt.data_ptr(), N, N * K, 1))
-    L.check(L.load().gaot_split_planes_grouped(items, 2, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "split")
-    return pk, pt, {W.data_ptr(): (N, K, pk.data_ptr(), K, N * K, pt.data_ptr(), N, N * K)}
-
-
-def test_split_planes_are_the_exact_three_way_split():
-    g = torch.Generator().manual_seed(31)
-    W = (torch.randn(200, 136, generator=g) * torch.logspace(-6, 3, 136)[None, :]).to(dev())
-    pk, pt, _ = _planes_for(W)
-    as_f32 = lambda p: (p.to(torch.int32) << 16).view(torch.float32)
-    parts = as_f32(pk).view(3, 200, 136).double()
-    assert torch.equal(parts.sum(0), W.double().cpu().to(dev()))                       # x = p0 + p1 + p2 exactly
-    assert torch.equal(as_f32(pt).view(3, 136, 200), as_f32(pk).view(3, 200, 136).transpose(1, 2))   # planes of W^T
-
-
-@pytest.mark.parametrize("M,N,K", [(8192, 256, 256), (8192, 768, 256), (8192, 256, 1024), (4096, 1024, 256)])
-def test_gemm_with_presplit_weight_planes_is_bit_identical(M, N, K):
-    """forward (x W^T) and input-gradient (g W) products with gaot_gemm_desc.b_planes vs the in-kernel split of the same weight"""
-    from gaot_amd import ops, _lib as L
-    g = torch.Generator().manual_seed(M + N + K)
-    x, W, gy = torch.randn(M, K, generator=g).to(dev()), (torch.randn(N, K, generator=g) / 8).to(dev()), torch.randn(M, N, generator=g).to(dev())
-    old = ops.set_gemm_mode(5)          # split-bf16 tiles wherever eligible: the same kernel family with and without the planes
-    try:
-        y0, dx0 = ops.linear_nt(x, W), ops.matmul_nn(gy, W)
-        assert L.load().gaot_debug_last_gemm_path() == 3
-        pk, pt, table = _planes_for(W)
-        ops.register_weight_planes(table)
-        ops._PLANES_ACTIVE[0] = True
-        y1, dx1 = ops.linear_nt(x, W), ops.matmul_nn(gy, W)
-    finally:
-        ops._PLANES_ACTIVE[0] = False
-        ops.register_weight_planes({})
-        ops.set_gemm_mode(old)
-    assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
-    assert rel(y1, x.double() @ W.double().t()) < 2e-6 and rel(dx1, gy.double() @ W.double()) < 2e-6
-
-
-def test_trainstep_with_weight_planes_equals_without(monkeypatch):
-    """three TrainStep updates with the pre-split weight planes (GAOT_WEIGHT_PLANES=1; off by default: measured slower) and
-    without: the same weights to fp32 rounding (the planes are exactly what the kernels would have formed; the tile heuristics may
-    pick another kernel for an input-gradient product), bit-identical between eager and hipGraph; load_state_dict between steps is noticed"""
-    from tests.test_ddp_gpu import _build, _data, _flat
-    from gaot_amd.trainer import TrainStep
-    lat, x, p, t = _data()
-    res = {}
-    for planes in ("1", "0"):
-        monkeypatch.setenv("GAOT_WEIGHT_PLANES", planes)
-        for graph in (False, True):
-            model = _build(seed=9).to(dev()).train()
-            ts = TrainStep(model, lr=2e-3, weight_decay=1e-4, use_graph=graph)
-            assert (getattr(ts.opt, "_planes_table", None) is not None and len(ts.opt._planes_table) > 10) == (planes == "1")
-            ts.bind(p.to(dev()), t.to(dev()), latent_tokens_coord=lat.to(dev()), xcoord=x.to(dev()))
-            for _ in range(2):
-                ts.step()
-            sd = {k: v.detach().clone() * 1.01 for k, v in model.state_dict().items()}
-            model.load_state_dict(sd)                     # weights change behind the planes' back: the next step must re-split
-            ts.step()
-            torch.cuda.synchronize()
-            res[(planes, graph)] = _flat(model).cpu()
-    assert float((res[("1", False)] - res[("0", False)]).abs().max()) < 2e-5 and float((res[("1", True)] - res[("0", True)]).abs().max()) < 2e-5
-    assert torch.equal(res[("1", False)], res[("1", True)]) and torch.equal(res[("0", False)], res[("0", True)])

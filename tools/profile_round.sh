@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $ROOT
 P="timeout -s KILL 300 rocprofv3"
-$P --kernel-trace -d $OUT/trace -o bench -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-reference-loop --no-configs > $OUT/bench_line.json 2> $OUT/bench.err
+$P --kernel-trace -d $OUT/trace -o bench -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-reference-loop --no-configs --no-variants > $OUT/bench_line.json 2> $OUT/bench.err
 python tools/rocpd_stats.py $(ls $OUT/trace/*.db | head -1) 0 > $OUT/kernel_stats.txt 2>> $OUT/bench.err
 # the launches of ONE hipGraph-replayed step, in order (dispatch count, per-kernel durations, gaps)
 timeout -s KILL 300 rocprofv3 --kernel-trace -d $OUT/trace_seq -o seq -- python tools/eager_steps.py c2 6 graph > /dev/null 2>> $OUT/bench.err
