@@ -84,9 +84,9 @@ PROTOTYPES = {
     "gaot_gno_gather_reduce": (C.c_int, [_f, _f, C.c_int32, C.c_int32, C.c_int32, _i, _i, _i, C.c_int32, _f, _f, _s]),
     "gaot_gno_edge_grad": (C.c_int, [_f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i, _i, C.c_int32, _f, _f, _s]),
     "gaot_gno_segment_sum": (C.c_int, [_f, C.c_int32, C.c_int32, C.c_int32, _i, C.c_int32, _f, _f, _s]),
-    "gaot_rmsnorm_fwd": (C.c_int, [_f, _f, C.c_int32, C.c_int32, C.c_float, _f, _f, _s]),
+    "gaot_rmsnorm_fwd": (C.c_int, [_f, _f, C.c_int32, C.c_int32, C.c_float, _f, _f, _f, _s]),
     "gaot_rmsnorm_bwd_partials": (C.c_int, [C.c_int32]),
-    "gaot_rmsnorm_bwd": (C.c_int, [_f, _f, _f, _f, _f, _f, C.c_int32, C.c_int32, _f, _f, _s]),
+    "gaot_rmsnorm_bwd": (C.c_int, [_f, _f, _f, _f, _f, _f, C.c_int32, C.c_int32, _f, _f, _f, _s]),
     "gaot_swiglu_fwd": (C.c_int, [_f, C.c_int32, C.c_int32, _f, _s]),
     "gaot_swiglu_bwd": (C.c_int, [_f, _f, C.c_int32, C.c_int32, _f, _s]),
     "gaot_attention_fwd": (C.c_int, [_f, _f, _f, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32,

@@ -141,24 +141,24 @@ __device__ __forceinline__ int lds_tr_lane_offset(int lane, int row_bytes) {
     return (4 * (lane >> 5) + ((lane & 15) >> 2)) * row_bytes + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
 }
 
-// ---- per-tensor magnitude words for the fp16-piece products.  A "word" is GAOT_AMAX_SLOTS = 64 floats: thousands of waves of a
-// producer publish max |x| of what they stored by an atomic max on a float's bit pattern (non-negative floats order like unsigned
-// integers), each into the slot its workgroup index selects -- one address would serialise them (measured: +13 us on a 1 024-workgroup
-// launch) -- and a consumer takes the maximum of the 64 slots.  The slots are zero before the pass (ops._amax_words).
+// ---- per-tensor magnitude words for the fp16-piece products.  A "word" is GAOT_AMAX_SLOTS = 32 slots, one float at the head of each
+// 128-byte line (GAOT_AMAX_STRIDE = 32 floats): thousands of waves of a producer publish max |x| of what they stored by an atomic max
+// on a float's bit pattern (non-negative floats order like unsigned integers), each into the slot its wave index selects.  Device-scope
+// atomics on ONE cache line serialise at ~11 ns each (4 096 waves on one word: +30 us per launch, measured; on two lines: +11 us), so
+// the slots sit on separate lines; a consumer takes the maximum of the 32 slots.  The slots are zero before the pass (ops._amax_words).
 __device__ __forceinline__ void amax_publish(float* word, float v, int lane, int slot) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    unsigned* w = reinterpret_cast<unsigned*>(word) + (slot & (GAOT_AMAX_SLOTS - 1));
-    // look first (a relaxed agent-scope load; a stale, smaller value only costs the atomic): once a slot holds a large value almost
-    // every later wave leaves without an atomic
-    if (lane == 0 && v > 0.f && __float_as_uint(v) > __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-        atomicMax(w, __float_as_uint(v));
+    unsigned* w = reinterpret_cast<unsigned*>(word) + (slot & (GAOT_AMAX_SLOTS - 1)) * GAOT_AMAX_STRIDE;
+    // fire and forget: a non-returning atomic (nothing waits for it; a look-before-you-leap load would put its round trip at the end of
+    // every workgroup's life: measured +20 us on a 1 024-workgroup launch)
+    if (lane == 0 && v > 0.f) (void)__hip_atomic_fetch_max(w, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // (scale, 1 / scale) for an operand whose largest magnitude is the maximum of the word's slots: scale = 2^(13 - floor(log2 amax)),
 // exponent clamped to +-126 (amax = 0 or denormal: the clamp; the operand is zero or flushes to it).  NaN / inf magnitudes give a finite
 // scale: the product's NaNs come from the data itself.  Every lane of the wave must call it (cross-lane maximum).
 __device__ __forceinline__ void amax_scale(const float* word, float& sc, float& inv) {
-    unsigned b = __float_as_uint(word[threadIdx.x & (GAOT_AMAX_SLOTS - 1)]);
+    unsigned b = __float_as_uint(word[(threadIdx.x & (GAOT_AMAX_SLOTS - 1)) * GAOT_AMAX_STRIDE]);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { const unsigned o = __shfl_xor(b, off, 64); b = o > b ? o : b; }
     const int e = (int)((b >> 23) & 0xffu);                               // biased exponent of amax

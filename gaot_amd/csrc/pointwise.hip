@@ -8,7 +8,7 @@ namespace gaot {
 // ---------------------------------------------------------------- RMSNorm (attn.py:161-172)
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           int M, int D, float eps, float* __restrict__ y,
-                                                          float* __restrict__ rstd) {
+                                                          float* __restrict__ rstd, float* __restrict__ y_amax) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= M) return;
@@ -19,7 +19,9 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
     const float r = rsqrtf(ss / (float)D + eps);
     if (lane == 0) rstd[row] = r;
     float* yr = y + (long)row * D;
-    for (int d = lane; d < D; d += 64) yr[d] = xr[d] * r * w[d];
+    float am = 0.f;
+    for (int d = lane; d < D; d += 64) { const float o = xr[d] * r * w[d]; yr[d] = o; am = fmaxf(am, fabsf(o)); }
+    if (y_amax) amax_publish(y_amax, am, lane, row);
 }
 
 constexpr int RMS_ROWS_PER_BLOCK = 8;
@@ -29,9 +31,10 @@ constexpr int RMS_MAX_D = 2048;
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ rstd, const float* __restrict__ dy,
                                                           const float* __restrict__ dx_add, const float* __restrict__ dx_add2, int M, int D,
-                                                          float* __restrict__ dx, float* __restrict__ dwp) {
+                                                          float* __restrict__ dx, float* __restrict__ dwp, float* __restrict__ dx_amax) {
     __shared__ float red[4][RMS_MAX_D];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float am = 0.f;
     float dwacc[RMS_MAX_D / 64];
 #pragma unroll
     for (int i = 0; i < RMS_MAX_D / 64; ++i) dwacc[i] = 0.f;
@@ -58,10 +61,12 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
                 if (ar) v += ar[d];
                 if (ar2) v += ar2[d];
                 or_[d] = v;
+                am = fmaxf(am, fabsf(v));
                 dwacc[i] += gv * xv * r;
             }
         }
     }
+    if (dx_amax) amax_publish(dx_amax, am, lane, (int)blockIdx.x * 4 + wave);
 #pragma unroll
     for (int i = 0; i < RMS_MAX_D / 64; ++i) {
         const int d = lane + i * 64;
@@ -75,7 +80,8 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
 // 16-byte variants for D = 256 * NV: a lane owns float4 columns lane*4 + 256*v; one pass over x / dy.
 template <int NV>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ w, int M,
-                                                              float eps, float* __restrict__ y, float* __restrict__ rstd) {
+                                                              float eps, float* __restrict__ y, float* __restrict__ rstd,
+                                                              float* __restrict__ y_amax) {
     constexpr int D = 256 * NV;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -90,20 +96,25 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_vec_kernel(const float* __res
     ss = wave_sum(ss);
     const float r = rsqrtf(ss / (float)D + eps);
     if (lane == 0) rstd[row] = r;
+    float am = 0.f;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         const f32x4 wv = *reinterpret_cast<const f32x4*>(w + v * 256 + lane * 4);
-        *reinterpret_cast<f32x4*>(y + (long)row * D + v * 256 + lane * 4) = xv[v] * r * wv;
+        const f32x4 o = xv[v] * r * wv;
+        *reinterpret_cast<f32x4*>(y + (long)row * D + v * 256 + lane * 4) = o;
+        am = fmaxf(am, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
     }
+    if (y_amax) amax_publish(y_amax, am, lane, row);
 }
 template <int NV>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ rstd, const float* __restrict__ dy,
                                                               const float* __restrict__ dx_add, const float* __restrict__ dx_add2, int M,
-                                                              float* __restrict__ dx, float* __restrict__ dwp) {
+                                                              float* __restrict__ dx, float* __restrict__ dwp, float* __restrict__ dx_amax) {
     constexpr int D = 256 * NV;
     __shared__ f32x4 red[4][NV][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float am = 0.f;
     f32x4 wv[NV], dwacc[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
@@ -132,9 +143,11 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_vec_kernel(const float* __res
             if (dx_add) o += *reinterpret_cast<const f32x4*>(dx_add + (long)row * D + v * 256 + lane * 4);
             if (dx_add2) o += *reinterpret_cast<const f32x4*>(dx_add2 + (long)row * D + v * 256 + lane * 4);
             *reinterpret_cast<f32x4*>(dx + (long)row * D + v * 256 + lane * 4) = o;
+            am = fmaxf(am, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
             dwacc[v] += gv[v] * xv[v] * r;
         }
     }
+    if (dx_amax) amax_publish(dx_amax, am, lane, (int)blockIdx.x * 4 + wave);
 #pragma unroll
     for (int v = 0; v < NV; ++v) red[wave][v][lane] = dwacc[v];
     __syncthreads();
@@ -428,13 +441,13 @@ __global__ void patchify_vec_kernel(const float* __restrict__ in, float* __restr
 using namespace gaot;
 #define ST(s) reinterpret_cast<hipStream_t>(s)
 
-extern "C" int gaot_rmsnorm_fwd(const float* x, const float* w, int32_t M, int32_t D, float eps, float* y, float* rstd,
+extern "C" int gaot_rmsnorm_fwd(const float* x, const float* w, int32_t M, int32_t D, float eps, float* y, float* rstd, float* y_absmax,
                                 gaot_stream_t stream) {
     GAOT_REQUIRE(x && w && y && rstd && M > 0 && D > 0, "rmsnorm_fwd: bad arguments");
     const bool v16 = aligned16(x) && aligned16(w) && aligned16(y);
-    if (v16 && D == 256)      hipLaunchKernelGGL(rmsnorm_fwd_vec_kernel<1>, dim3(cdiv(M, 4)), dim3(256), 0, ST(stream), x, w, M, eps, y, rstd);
-    else if (v16 && D == 512) hipLaunchKernelGGL(rmsnorm_fwd_vec_kernel<2>, dim3(cdiv(M, 4)), dim3(256), 0, ST(stream), x, w, M, eps, y, rstd);
-    else hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, ST(stream), x, w, M, D, eps, y, rstd);
+    if (v16 && D == 256)      hipLaunchKernelGGL(rmsnorm_fwd_vec_kernel<1>, dim3(cdiv(M, 4)), dim3(256), 0, ST(stream), x, w, M, eps, y, rstd, y_absmax);
+    else if (v16 && D == 512) hipLaunchKernelGGL(rmsnorm_fwd_vec_kernel<2>, dim3(cdiv(M, 4)), dim3(256), 0, ST(stream), x, w, M, eps, y, rstd, y_absmax);
+    else hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, ST(stream), x, w, M, D, eps, y, rstd, y_absmax);
     GAOT_CHECK_LAUNCH("gaot_rmsnorm_fwd");
     return GAOT_OK;
 }
@@ -442,15 +455,16 @@ extern "C" int gaot_rmsnorm_fwd(const float* x, const float* w, int32_t M, int32
 extern "C" int gaot_rmsnorm_bwd_partials(int32_t M) { return cdiv(M, RMS_ROWS_PER_BLOCK); }
 
 extern "C" int gaot_rmsnorm_bwd(const float* x, const float* w, const float* rstd, const float* dy, const float* dx_add,
-                                const float* dx_add2, int32_t M, int32_t D, float* dx, float* dw_partial, gaot_stream_t stream) {
+                                const float* dx_add2, int32_t M, int32_t D, float* dx, float* dw_partial, float* dx_absmax,
+                                gaot_stream_t stream) {
     GAOT_REQUIRE(x && w && rstd && dy && dx && dw_partial && M > 0 && D > 0, "rmsnorm_bwd: bad arguments");
     GAOT_REQUIRE(D <= RMS_MAX_D, "rmsnorm_bwd: D=%d exceeds %d", D, RMS_MAX_D);
     const bool v16 = aligned16(x) && aligned16(w) && aligned16(dy) && aligned16(dx) && aligned16(dw_partial) && (!dx_add || aligned16(dx_add)) &&
                      (!dx_add2 || aligned16(dx_add2));
     const dim3 grid(cdiv(M, RMS_ROWS_PER_BLOCK));
-    if (v16 && D == 256)      hipLaunchKernelGGL(rmsnorm_bwd_vec_kernel<1>, grid, dim3(256), 0, ST(stream), x, w, rstd, dy, dx_add, dx_add2, M, dx, dw_partial);
-    else if (v16 && D == 512) hipLaunchKernelGGL(rmsnorm_bwd_vec_kernel<2>, grid, dim3(256), 0, ST(stream), x, w, rstd, dy, dx_add, dx_add2, M, dx, dw_partial);
-    else hipLaunchKernelGGL(rmsnorm_bwd_kernel, grid, dim3(256), 0, ST(stream), x, w, rstd, dy, dx_add, dx_add2, M, D, dx, dw_partial);
+    if (v16 && D == 256)      hipLaunchKernelGGL(rmsnorm_bwd_vec_kernel<1>, grid, dim3(256), 0, ST(stream), x, w, rstd, dy, dx_add, dx_add2, M, dx, dw_partial, dx_absmax);
+    else if (v16 && D == 512) hipLaunchKernelGGL(rmsnorm_bwd_vec_kernel<2>, grid, dim3(256), 0, ST(stream), x, w, rstd, dy, dx_add, dx_add2, M, dx, dw_partial, dx_absmax);
+    else hipLaunchKernelGGL(rmsnorm_bwd_kernel, grid, dim3(256), 0, ST(stream), x, w, rstd, dy, dx_add, dx_add2, M, D, dx, dw_partial, dx_absmax);
     GAOT_CHECK_LAUNCH("gaot_rmsnorm_bwd");
     return GAOT_OK;
 }

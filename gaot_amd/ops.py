@@ -163,13 +163,13 @@ def set_f32_pieces(name: str) -> str:
 class _Arena:
     __slots__ = ("buf", "used", "n")
 
-    def __init__(self, device, n=512):
-        self.buf = torch.zeros(n * AMAX_SLOTS, device=device, dtype=torch.float32)       # n words of AMAX_SLOTS floats (256 bytes each)
+    def __init__(self, device, n=256):
+        self.buf = torch.zeros(n * AMAX_SLOTS, device=device, dtype=torch.float32)       # n words of AMAX_SLOTS floats
         self.n = n
         self.used = 0
 
 
-AMAX_SLOTS = 64                # include/gaot_hip.h GAOT_AMAX_SLOTS
+AMAX_SLOTS = 32 * 32           # floats per magnitude word: include/gaot_hip.h GAOT_AMAX_SLOTS * GAOT_AMAX_STRIDE (4 KB)
 _ARENA = [None]
 _WEIGHT_AMAX: list = []        # (lo, hi, word) of the current pass: every parameter and every fused weight group
 
@@ -183,7 +183,7 @@ def begin_pass() -> None:
 def _amax_words(n: int, device) -> List[torch.Tensor]:
     a = _ARENA[0]
     if a is None or a.buf.device != device or a.used + n > a.n:
-        a = _Arena(device, max(512, n))
+        a = _Arena(device, max(256, n))
         _ARENA[0] = a
     out = [a.buf[(a.used + i) * AMAX_SLOTS:(a.used + i + 1) * AMAX_SLOTS] for i in range(n)]
     a.used += n
@@ -221,6 +221,11 @@ def amax_for(t2d: torch.Tensor, *aliases) -> torch.Tensor:
         _absmax_launch([(t2d, w)])
     _amax_set(w, t2d, *aliases)
     return w
+
+
+def _want_word(device):
+    """a fresh (zero) magnitude word for a producer kernel to publish into, or None when no fp16-piece product will ask for it"""
+    return _amax_words(1, device)[0] if wants_amax() else None
 
 
 def _publish(word, *objs) -> None:
@@ -275,6 +280,7 @@ def weight_amax(w2d: torch.Tensor) -> torch.Tensor:
 
 
 _PATH_CACHE: dict = {}
+_PUBLISH_C = os.environ.get("GAOT_NO_CAMAX", "0") != "1"       # A/B switch (tools): GEMM epilogues publish the output's magnitude word
 
 
 def _gemm_path(d, key) -> int:
@@ -314,13 +320,16 @@ def gemm(M: int, N: int, K: int, A, lda, a_kmajor, B, ldb, b_kmajor, out, ldc, *
         key = (M, N, K, int(a_kmajor), int(b_kmajor), act, split_k, colsum is None, bias is None, rowbias is None, rowscale is None,
                aux_in is None, aux_out is None, residual is None, lda % 4, ldb % 4, ldc % 4, ld_aux % 4, ldr % 4,
                (A.data_ptr() | B.data_ptr() | out.data_ptr()) & 15, _GEMM_MODE)
-        if _gemm_path(d, key) == 3:
+        d.pieces, d.a_absmax, d.b_absmax = 4, A.data_ptr(), B.data_ptr()      # (placeholders: the dry run reads no memory)
+        path = _gemm_path(d, key)
+        d.pieces, d.a_absmax, d.b_absmax = 3, None, None
+        if path == 3:
             if a_amax is None:
                 a_amax = amax_for(A)
             if b_amax is None:
                 b_amax = weight_amax(B) if (b_is_weight if b_is_weight is not None else kind != "tn") else amax_for(B)
             d.pieces, d.a_absmax, d.b_absmax = 4, a_amax.data_ptr(), b_amax.data_ptr()
-            if split_k <= 1 and colsum is None:
+            if split_k <= 1 and colsum is None and _PUBLISH_C:
                 cw = _amax_words(1, out.device)[0]
                 d.c_absmax = cw.data_ptr()
                 gemm.last_c_amax = cw
@@ -1702,11 +1711,14 @@ class _RMSNorm(torch.autograd.Function):
         M = xm.shape[0]
         y = torch.empty_like(xm)
         rstd = torch.empty(M, device=x.device, dtype=torch.float32)
-        L.check(L.load().gaot_rmsnorm_fwd(_p(xm), _p(w), M, D, float(eps), _p(y), _p(rstd), _stream()), "gaot_rmsnorm_fwd")
+        yw = _want_word(x.device)
+        L.check(L.load().gaot_rmsnorm_fwd(_p(xm), _p(w), M, D, float(eps), _p(y), _p(rstd), _p(yw), _stream()), "gaot_rmsnorm_fwd")
         ctx.save_for_backward(xm, w, rstd)
         ctx.shp = shp
         ctx.slot = _claim(w)
-        return y.reshape(shp)
+        yr = y.reshape(shp)
+        _publish(yw, y, yr)
+        return yr
 
     @staticmethod
     def backward(ctx, dy):
@@ -1717,11 +1729,14 @@ class _RMSNorm(torch.autograd.Function):
         dx = torch.empty_like(xm)
         P = int(lib.gaot_rmsnorm_bwd_partials(M))
         part = torch.empty(P, D, device=xm.device, dtype=torch.float32)
-        L.check(lib.gaot_rmsnorm_bwd(_p(xm), _p(w), _p(rstd), _p(g), None, None, M, D, _p(dx), _p(part), _stream()), "gaot_rmsnorm_bwd")
+        dxw = _want_word(xm.device)
+        L.check(lib.gaot_rmsnorm_bwd(_p(xm), _p(w), _p(rstd), _p(g), None, None, M, D, _p(dx), _p(part), _p(dxw), _stream()), "gaot_rmsnorm_bwd")
         dw = None
         if ctx.needs_input_grad[1]:
             dw = colsum(part, out=ctx.slot.detach() if ctx.slot is not None else None, final=ctx.slot is not None)
-        return dx.reshape(ctx.shp), dw, None
+        dxr = dx.reshape(ctx.shp)
+        _publish(dxw, dx, dxr)
+        return dxr, dw, None
 
 
 def rms_norm(x, w, eps):
@@ -1744,13 +1759,16 @@ class _RMSNormFork(torch.autograd.Function):
         M = xm.shape[0]
         y = torch.empty_like(xm)
         rstd = torch.empty(M, device=x.device, dtype=torch.float32)
-        L.check(L.load().gaot_rmsnorm_fwd(_p(xm), _p(w), M, D, float(eps), _p(y), _p(rstd), _stream()), "gaot_rmsnorm_fwd")
+        yw = _want_word(x.device)
+        L.check(L.load().gaot_rmsnorm_fwd(_p(xm), _p(w), M, D, float(eps), _p(y), _p(rstd), _p(yw), _stream()), "gaot_rmsnorm_fwd")
         ctx.save_for_backward(xm, w, rstd)
         ctx.shp = shp
         ctx.slot = _claim(w)
+        yr = y.reshape(shp)
+        _publish(yw, y, yr)
         if n_alias == 2:
-            return x.view_as(x), y.reshape(shp), x.view_as(x)
-        return x.view_as(x), y.reshape(shp)
+            return x.view_as(x), yr, x.view_as(x)
+        return x.view_as(x), yr
 
     @staticmethod
     def backward(ctx, dres, dy, dskip=None):
@@ -1766,11 +1784,14 @@ class _RMSNormFork(torch.autograd.Function):
         dx = torch.empty_like(xm)
         P = int(lib.gaot_rmsnorm_bwd_partials(M))
         part = torch.empty(P, D, device=xm.device, dtype=torch.float32)
-        L.check(lib.gaot_rmsnorm_bwd(_p(xm), _p(w), _p(rstd), _p(g), _p(add), _p(add2), M, D, _p(dx), _p(part), _stream()), "gaot_rmsnorm_bwd")
+        dxw = _want_word(xm.device)
+        L.check(lib.gaot_rmsnorm_bwd(_p(xm), _p(w), _p(rstd), _p(g), _p(add), _p(add2), M, D, _p(dx), _p(part), _p(dxw), _stream()), "gaot_rmsnorm_bwd")
         dw = None
         if ctx.needs_input_grad[1]:
             dw = colsum(part, out=ctx.slot.detach() if ctx.slot is not None else None, final=ctx.slot is not None)
-        return dx.reshape(ctx.shp), dw, None, None
+        dxr = dx.reshape(ctx.shp)
+        _publish(dxw, dx, dxr)
+        return dxr, dw, None, None
 
 
 def rms_norm_fork(x, w, eps, with_skip_alias: bool = False):
@@ -1894,6 +1915,7 @@ class _Attention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, H, Hkv, D, p_drop=0.0):
         _dev(qkv)
+        qkv_in = qkv
         qkv = qkv.contiguous()
         B, S, W = qkv.shape
         assert W == (H + 2 * Hkv) * D
@@ -1917,6 +1939,8 @@ class _Attention(torch.autograd.Function):
                     "gaot_attention_fwd")
         ctx.save_for_backward(qkv, o, lse, seed if seed is not None else qkv.new_empty(0))
         ctx.dims = (B, S, H, Hkv, D, float(p_drop))
+        if p_drop == 0.0:      # every output row is a convex combination of V rows: max |o| <= max |v| <= max |qkv| (a bound is as good as the maximum)
+            _publish(_amax_get(qkv, qkv_in), o)
         return o
 
     @staticmethod

@@ -44,9 +44,11 @@ enum gaot_act {
 int gaot_abi_version(void);
 const char* gaot_last_error(void);
 
-/* A "magnitude word" (gaot_gemm_desc.a_absmax ..., gaot_absmax_grouped) is GAOT_AMAX_SLOTS floats, 256-byte aligned: producers publish
- * max |x| into the slot their workgroup index selects (atomic max on the float bit pattern), consumers take the maximum of the slots. */
-#define GAOT_AMAX_SLOTS 64
+/* A "magnitude word" (gaot_gemm_desc.a_absmax ..., gaot_absmax_grouped) is GAOT_AMAX_SLOTS slots, one float at the head of each
+ * 128-byte line (GAOT_AMAX_SLOTS * GAOT_AMAX_STRIDE floats in all, 128-byte aligned): producers publish max |x| into the slot their wave
+ * index selects (atomic max on the float bit pattern), consumers take the maximum of the slots. */
+#define GAOT_AMAX_SLOTS 32
+#define GAOT_AMAX_STRIDE 32
 
 /* ------------------------------------------------------------------------------------------
  * fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32), fused prologue/epilogue.
@@ -86,7 +88,7 @@ typedef struct gaot_gemm_desc {
      * matrix-pipe work of the two-piece ones.  Needs a_absmax / b_absmax; without them, and on kernels off the split tiles, it means 3.
      * Kernels on the fp32 MFMA / vector pipe ignore the field.  Anything else: GAOT_ERR_INVALID. */
     int32_t pieces;
-    /* pieces = 4: device magnitude words (GAOT_AMAX_SLOTS floats each) holding max |Aop| and max |Bop| (an upper bound is as good: one
+    /* pieces = 4: device magnitude words (above) holding max |Aop| and max |Bop| (an upper bound is as good: one
      * binade of slack costs nothing), read by the kernel -- no host value, so a captured launch follows the data.  gaot_absmax_grouped
      * computes them; producers publish them. */
     const float* a_absmax; const float* b_absmax;
@@ -246,16 +248,17 @@ int gaot_gno_segment_sum(const float* x, int32_t B, int32_t E, int32_t C, const 
 /* ------------------------------------------------------------------------------------------
  * processor pieces (attn.py)
  * ------------------------------------------------------------------------------------------ */
-/* RMSNorm attn.py:161-172.  y = x * rstd * w ; rstd[M] saved for backward. */
+/* RMSNorm attn.py:161-172.  y = x * rstd * w ; rstd[M] saved for backward.  y_absmax (optional): the magnitude word of y
+ * (gaot_gemm_desc.c_absmax conventions: zero before the launch) -- y is the A operand of the q|k|v / w1|w3 products. */
 int gaot_rmsnorm_fwd(const float* x, const float* w, int32_t M, int32_t D, float eps,
-                     float* y, float* rstd, gaot_stream_t stream);
+                     float* y, float* rstd, float* y_absmax, gaot_stream_t stream);
 /* dx = rstd*(w*dy - x*rstd^2*mean(w*dy*x)) (+ dx_add) (+ dx_add2) ; dw_partial[P,D] column partials (P returned rows =
  * gaot_rmsnorm_bwd_partials(M)); caller sums them.  dx_add / dx_add2 (optional): gradients reaching the SAME tensor by other
  * routes -- the block's residual branch (attn.py:228-233) and the long-range skip (attn.py:281-299) -- added here instead of by
  * separate elementwise launches. */
 int gaot_rmsnorm_bwd_partials(int32_t M);
 int gaot_rmsnorm_bwd(const float* x, const float* w, const float* rstd, const float* dy, const float* dx_add, const float* dx_add2,
-                     int32_t M, int32_t D, float* dx, float* dw_partial, gaot_stream_t stream);
+                     int32_t M, int32_t D, float* dx, float* dw_partial, float* dx_absmax /* optional, as y_absmax */, gaot_stream_t stream);
 /* SwiGLU gate attn.py:151: u = [u1 | u3] ([M,2F]); g = silu(u1)*u3 ; bwd writes du [M,2F]. */
 int gaot_swiglu_fwd(const float* u, int32_t M, int32_t F, float* g, gaot_stream_t stream);
 int gaot_swiglu_bwd(const float* u, const float* dg, int32_t M, int32_t F, float* du, gaot_stream_t stream);
