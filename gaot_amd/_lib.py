@@ -90,11 +90,11 @@ PROTOTYPES = {
     "gaot_swiglu_fwd": (C.c_int, [_f, C.c_int32, C.c_int32, _f, _s]),
     "gaot_swiglu_bwd": (C.c_int, [_f, _f, C.c_int32, C.c_int32, _f, _s]),
     "gaot_attention_fwd": (C.c_int, [_f, _f, _f, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
-                                     C.c_int32, C.c_int32, _f, C.c_int64, _f, C.c_int32, _s]),
+                                     C.c_int32, C.c_int32, _f, C.c_int64, _f, C.c_int32, _f, _s]),
     "gaot_attention_bwd_workspace": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "gaot_attention_bwd": (C.c_int, [_f, _f, _f, C.c_int64, C.c_int64, C.c_int64, _f, _f, C.c_int64, _f,
                                      C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                                     _f, _f, _f, C.c_int64, C.c_int64, C.c_int64, _f, C.c_int32, _s]),
+                                     _f, _f, _f, C.c_int64, C.c_int64, C.c_int64, _f, C.c_int32, _f, _f, _s]),
     "gaot_attention_seed_next": (C.c_int, [_i, C.c_uint64, _i, _s]),
     "gaot_attention_fwd_dropout": (C.c_int, [_f, _f, _f, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                              C.c_int32, C.c_int32, _f, C.c_int64, _f, C.c_float, _i, _s]),

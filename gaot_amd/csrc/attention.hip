@@ -30,6 +30,8 @@ struct AttnArgs {
     // keep(b, h, q, k) / (1 - p) after the softmax; the mask is a counter-based hash of (*drop_seed, element index), so the
     // backward regenerates it from the same seed word
     const unsigned long long* drop_seed; unsigned drop_thresh; float drop_scale;
+    // fp16-piece kernels (pieces = 4): magnitude words of the q | k | v operands (one word: they are one tensor) and of dO
+    const float* qkv_amax; const float* dout_amax;
 };
 
 // splitmix64 finaliser of (seed + linear index of the score): the top 32 bits against the keep threshold
@@ -364,11 +366,29 @@ __global__ __launch_bounds__(256) void attn_fwd_glds_kernel(const AttnArgs p) {
 // K / V tiles (64 keys) are split by all 256 threads on the way from the prefetch registers into one of two LDS stages.
 // ---------------------------------------------------------------------------------------------
 // pieces of an operand pair: OP = 3 exact (split3_pair), OP = 2 two rounded pieces (split2_pair; third piece zero, never stored or multiplied)
-template <int OP>
-__device__ __forceinline__ void split_op(float x0, float x1, unsigned& a, unsigned& b, unsigned& c) {
-    if (OP == 3) split3_pair(x0, x1, a, b, c);
+// F16: two fp16 pieces of sc * x (common.h split2h_pair: x carried to fp32 rounding once sc puts the operand's largest magnitude at ~2^14)
+template <int OP, bool F16 = false>
+__device__ __forceinline__ void split_op(float x0, float x1, unsigned& a, unsigned& b, unsigned& c, float sc = 1.f) {
+    if (F16) { split2h_pair(x0, x1, sc, a, b); c = 0u; }
+    else if (OP == 3) split3_pair(x0, x1, a, b, c);
     else { split2_pair(x0, x1, a, b); c = 0u; }
 }
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
+    if (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// power-of-two scale (and inverse) that puts a wave-uniform magnitude at ~2^14: the per-tile scale of dS in the fp16-piece backward
+__device__ __forceinline__ void pow2_scale(float amax, float& sc, float& inv) {
+    int se = 140 - (int)((__float_as_uint(amax) >> 23) & 0xffu);
+    se = se > 126 ? 126 : (se < -126 ? -126 : se);
+    sc = __uint_as_float((unsigned)(127 + se) << 23);
+    inv = __uint_as_float((unsigned)(127 - se) << 23);
+}
+// probabilities live in [0, 1]: static scale 2^13 -- not 2^15: with scores of ~1e7 (fp32 ulp ~1 in the exponent) a recomputed
+// exp2(s c - lse) comes out as 2 or 4 instead of <= 1, and 4 x 2^15 is past fp16's 65 504 (inf -> NaN where the three-piece kernels
+// merely return the same garbage the reference does); every P >= 2^-15 keeps full precision, smaller ones an absolute 2^-38
+constexpr float P_SCALE = 8192.f, P_INV = 1.f / 8192.f;
 constexpr int AS_KROW = 80, AS_VROW = 136;
 constexpr int AS_KPL = 64 * AS_KROW, AS_VPL = 32 * AS_VROW;
 constexpr int AS_STAGE = 3 * AS_KPL + 3 * AS_VPL;          // bytes
@@ -380,7 +400,9 @@ constexpr int AS_STAGE = 3 * AS_KPL + 3 * AS_VPL;          // bytes
 // PP = pieces of P in the P V product: 3 = exact split; 2 = two pieces (common.h split2_pair: the second one rounded to nearest),
 // five piece products instead of six -- P is a softmax output in [0, 1] carrying ~1e-7 of relative noise from exp2 alone, the
 // dropped part is <= 2^-17 of each probability and unbiased
-template <int NW, int DH = 32, int PP = 3, int OP = 3>
+// F16 (with PP = OP = 2): two fp16 pieces of the scaled operands (Q, K, V by the power of two from their magnitude word, P by 2^15), three
+// piece products per k-step on the f16 MFMA: fp32-level products at the two-piece kernels' cost.
+template <int NW, int DH = 32, int PP = 3, int OP = 3, bool F16 = false>
 __global__ __launch_bounds__(64 * NW, (NW == 4 && DH == 32) ? 2 : 1) void attn_fwd_split_kernel(const AttnArgs p) {
     constexpr int KT = 64, NT = 64 * NW, QB = 32 * NW;
     constexpr int NU = DH / 16, NDT = DH / 32, CPR = DH / 4;            // d steps, O tiles, 4-float chunks per row
@@ -396,7 +418,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && DH == 32) ? 2 : 1) void attn_f
     const int b = bh / p.H, h = bh % p.H, hk = h / (p.H / p.Hkv);
     const int q0 = blk * QB + wave * 32;
     const int D = DH == 32 ? 32 : p.D;
-    const float c = p.scale * LOG2E;
+    static_assert(!F16 || (PP == 2 && OP == 2), "fp16 pieces come in twos");
+    float sc_in = 1.f, so_in = 1.f;
+    if (F16) amax_scale(p.qkv_amax, sc_in, so_in);
+    const float sm_scale = p.scale * so_in * so_in;          // scores arrive scaled by sc_in^2
+    const float c = sm_scale * LOG2E;
+    const float o_inv = F16 ? so_in * P_INV : 1.f;             // the tile's V^T P^T arrives scaled by sc_in * 2^15
 
     // Q fragments: lane (q = li, hi) holds d = 16u + 8hi + e (e = 0..7) for every d step u, as three packed bf16 planes
     bf16x8 qf[3][NU];
@@ -409,10 +436,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && DH == 32) ? 2 : 1) void attn_f
             const f32x4 v1 = load4(qrow, 16 * u + 8 * lh + 4, D, qi < p.S, true);
             u32x4 ph, pm, pl;
             unsigned a_, b_, c_;
-            split_op<OP>(v0[0], v0[1], a_, b_, c_); ph[0] = a_; pm[0] = b_; pl[0] = c_;
-            split_op<OP>(v0[2], v0[3], a_, b_, c_); ph[1] = a_; pm[1] = b_; pl[1] = c_;
-            split_op<OP>(v1[0], v1[1], a_, b_, c_); ph[2] = a_; pm[2] = b_; pl[2] = c_;
-            split_op<OP>(v1[2], v1[3], a_, b_, c_); ph[3] = a_; pm[3] = b_; pl[3] = c_;
+            split_op<OP, F16>(v0[0], v0[1], a_, b_, c_, sc_in); ph[0] = a_; pm[0] = b_; pl[0] = c_;
+            split_op<OP, F16>(v0[2], v0[3], a_, b_, c_, sc_in); ph[1] = a_; pm[1] = b_; pl[1] = c_;
+            split_op<OP, F16>(v1[0], v1[1], a_, b_, c_, sc_in); ph[2] = a_; pm[2] = b_; pl[2] = c_;
+            split_op<OP, F16>(v1[2], v1[3], a_, b_, c_, sc_in); ph[3] = a_; pm[3] = b_; pl[3] = c_;
             qf[0][u] = __builtin_bit_cast(bf16x8, ph); qf[1][u] = __builtin_bit_cast(bf16x8, pm); qf[2][u] = __builtin_bit_cast(bf16x8, pl);
         }
     }
@@ -451,8 +478,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && DH == 32) ? 2 : 1) void attn_f
             const int idx = tid + i * NT;
             u32x2 h, m, l;
             unsigned a_, b_, c_;
-            split_op<OP>(rk[i][0], rk[i][1], a_, b_, c_); h[0] = a_; m[0] = b_; l[0] = c_;
-            split_op<OP>(rk[i][2], rk[i][3], a_, b_, c_); h[1] = a_; m[1] = b_; l[1] = c_;
+            split_op<OP, F16>(rk[i][0], rk[i][1], a_, b_, c_, sc_in); h[0] = a_; m[0] = b_; l[0] = c_;
+            split_op<OP, F16>(rk[i][2], rk[i][3], a_, b_, c_, sc_in); h[1] = a_; m[1] = b_; l[1] = c_;
             unsigned char* dst = Kp + (idx / CPR) * KROW + (idx % CPR) * 8;
             *reinterpret_cast<u32x2*>(dst) = h;
             *reinterpret_cast<u32x2*>(dst + KPL) = m;
@@ -467,7 +494,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && DH == 32) ? 2 : 1) void attn_f
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     unsigned a_, b_, c_;
-                    split_op<OP>(rv[j][0][e], rv[j][1][e], a_, b_, c_);
+                    split_op<OP, F16>(rv[j][0][e], rv[j][1][e], a_, b_, c_, sc_in);
                     unsigned char* dst = Vp + (d0 + e) * AS_VROW + kp * 4;
                     *reinterpret_cast<unsigned*>(dst) = a_;
                     *reinterpret_cast<unsigned*>(dst + VPL) = b_;
@@ -505,13 +532,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && DH == 32) ? 2 : 1) void attn_f
                 const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(kr + KPL);
                 if (OP == 3) {
                     const bf16x8 k2 = *reinterpret_cast<const bf16x8*>(kr + 2 * KPL);
-                    s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k2, qf[0][u], s[t], 0, 0, 0);
-                    s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[2][u], s[t], 0, 0, 0);
-                    s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[1][u], s[t], 0, 0, 0);
+                    s[t] = mfma16<F16>(k2, qf[0][u], s[t]);
+                    s[t] = mfma16<F16>(k0, qf[2][u], s[t]);
+                    s[t] = mfma16<F16>(k1, qf[1][u], s[t]);
                 }
-                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[0][u], s[t], 0, 0, 0);
-                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[1][u], s[t], 0, 0, 0);
-                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[0][u], s[t], 0, 0, 0);
+                s[t] = mfma16<F16>(k1, qf[0][u], s[t]);
+                s[t] = mfma16<F16>(k0, qf[1][u], s[t]);
+                s[t] = mfma16<F16>(k0, qf[0][u], s[t]);
             }
         }
         // ---- online softmax over the 64 keys (fp32)
@@ -566,6 +593,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && DH == 32) ? 2 : 1) void attn_f
                 for (int e = 0; e < 4; ++e) {
                     unsigned a_, b_, c_ = 0u;
                     if (PP == 3) split3_pair(s[t][8 * u + 2 * e], s[t][8 * u + 2 * e + 1], a_, b_, c_);
+                    else if (F16) split2h_pair(s[t][8 * u + 2 * e], s[t][8 * u + 2 * e + 1], P_SCALE, a_, b_);
                     else split2_pair(s[t][8 * u + 2 * e], s[t][8 * u + 2 * e + 1], a_, b_);
                     ph[e] = a_; pm[e] = b_; pl[e] = c_;
                 }
@@ -581,18 +609,18 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && DH == 32) ? 2 : 1) void attn_f
                         const u32x2 hi2 = *reinterpret_cast<const u32x2*>(vr + pl_ * VPL + 16);
                         v[pl_] = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi2[0], hi2[1]});
                     }
-                    if (OP == 3) ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[2], p0, ot[dt], 0, 0, 0);
-                    if (PP == 3) ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0], p2, ot[dt], 0, 0, 0);
-                    if (OP == 3 || PP == 3) ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[1], p1, ot[dt], 0, 0, 0);   // second x second piece: <= 2^-18 of the term
-                    ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[1], p0, ot[dt], 0, 0, 0);
-                    ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0], p1, ot[dt], 0, 0, 0);
-                    ot[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0], p0, ot[dt], 0, 0, 0);
+                    if (OP == 3) ot[dt] = mfma16<F16>(v[2], p0, ot[dt]);
+                    if (PP == 3) ot[dt] = mfma16<F16>(v[0], p2, ot[dt]);
+                    if (OP == 3 || PP == 3) ot[dt] = mfma16<F16>(v[1], p1, ot[dt]);   // second x second piece: <= 2^-18 of the term
+                    ot[dt] = mfma16<F16>(v[1], p0, ot[dt]);
+                    ot[dt] = mfma16<F16>(v[0], p1, ot[dt]);
+                    ot[dt] = mfma16<F16>(v[0], p0, ot[dt]);
                 }
             }
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[dt][r] += ot[dt][r];
+            for (int r = 0; r < 16; ++r) oacc[dt][r] = F16 ? fmaf(ot[dt][r], o_inv, oacc[dt][r]) : oacc[dt][r] + ot[dt][r];
         // next tile: registers -> the other stage (its previous readers finished before the last barrier), prefetch the one after
         if (kt + 1 < ntiles) stage(stg ^ 1);
         if (kt + 2 < ntiles) fetch(kt + 2);
@@ -613,7 +641,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && DH == 32) ? 2 : 1) void attn_f
             if (32 * dt + li < D) p.o[((long)b * p.S + qi) * p.ldo + (long)h * D + 32 * dt + li] = Os[rr * (DH + 1) + 32 * dt + li];
     }
     if (lh == 0 && q0 + li < p.S)
-        p.lse[((long)b * p.H + h) * p.S + q0 + li] = m_run * p.scale + logf(l_run);
+        p.lse[((long)b * p.H + h) * p.S + q0 + li] = m_run * sm_scale + logf(l_run);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1747,7 +1775,10 @@ constexpr int AB8_LDS = AB8_SHARED + 8 * AB8_WAVE;
 // separately staged transposed planes: no second (transposed) copy of the Q / dO tile is loaded, split and written per q tile, and dS goes
 // to LDS as [kv][q] with 8-byte stores (a lane's four consecutive queries) instead of [q][kv] with 2-byte ones (8 stores per tile and
 // wave instead of 64)
-template <int PP = 3, int OP = 3, bool TR = false>
+// F16 (with PP = OP = 2, TR): two fp16 pieces of the scaled operands -- Q, K, V by the power of two from the qkv magnitude word, dO by its
+// own word, P by 2^15, dS by a per-tile power of two from the wave's own maximum (the tile products join the running sums on the vector
+// pipe anyway: the inverse scales ride that fused multiply-add) -- three piece products per k-step on the f16 MFMA.  (P by 2^13, see P_SCALE.)
+template <int PP = 3, int OP = 3, bool TR = false, bool F16 = false>
 __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs p) {
     constexpr int DP = 32, NW = 8;
     __shared__ __attribute__((aligned(16))) unsigned char smem[AB8_LDS];
@@ -1765,7 +1796,12 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
     xcd_group_decode(blockIdx.x, p.B * p.H, p.n_kblocks, bh, kblk);
     const int b = bh / p.H, h = bh % p.H, hk = h / (p.H / p.Hkv);
     const int kv0 = kblk * 256 + wave * 32;
-    const float c = p.scale * LOG2E;
+    static_assert(!F16 || (PP == 2 && OP == 2), "fp16 pieces come in twos");
+    float sc_in = 1.f, so_in = 1.f, sc_g = 1.f, so_g = 1.f;
+    if (F16) { amax_scale(p.qkv_amax, sc_in, so_in); amax_scale(p.dout_amax, sc_g, so_g); }
+    const float c = p.scale * LOG2E * so_in * so_in;         // scores arrive scaled by sc_in^2
+    const float dp_inv = so_g * so_in;                       // dO V^T arrives scaled by sc_g * sc_in
+    const float dv_inv = F16 ? so_g * P_INV : 1.f;           // dO^T P by sc_g * 2^15
     unsigned char* Ktp = smem + AB8_SHARED + wave * AB8_WAVE;        // 3 planes [d][32 kv]
     unsigned char* dSp = Ktp + 3 * AB_KPL;                           // 3 planes [q][32 kv]
     float* Pmine = reinterpret_cast<float*>(dSp);                    // [32 q][32 d] fp32 after the dQ MFMAs
@@ -1784,10 +1820,10 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
             unsigned a_, b_, c_;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                split_op<OP>(a0[2 * e], a0[2 * e + 1], a_, b_, c_); ph[e] = a_; pm[e] = b_; pl[e] = c_;
-                split_op<OP>(a1[2 * e], a1[2 * e + 1], a_, b_, c_); ph[2 + e] = a_; pm[2 + e] = b_; pl[2 + e] = c_;
-                split_op<OP>(w0[2 * e], w0[2 * e + 1], a_, b_, c_); vh[e] = a_; vm[e] = b_; vl[e] = c_;
-                split_op<OP>(w1[2 * e], w1[2 * e + 1], a_, b_, c_); vh[2 + e] = a_; vm[2 + e] = b_; vl[2 + e] = c_;
+                split_op<OP, F16>(a0[2 * e], a0[2 * e + 1], a_, b_, c_, sc_in); ph[e] = a_; pm[e] = b_; pl[e] = c_;
+                split_op<OP, F16>(a1[2 * e], a1[2 * e + 1], a_, b_, c_, sc_in); ph[2 + e] = a_; pm[2 + e] = b_; pl[2 + e] = c_;
+                split_op<OP, F16>(w0[2 * e], w0[2 * e + 1], a_, b_, c_, sc_in); vh[e] = a_; vm[e] = b_; vl[e] = c_;
+                split_op<OP, F16>(w1[2 * e], w1[2 * e + 1], a_, b_, c_, sc_in); vh[2 + e] = a_; vm[2 + e] = b_; vl[2 + e] = c_;
             }
             kf[0][u] = __builtin_bit_cast(bf16x8, ph); kf[1][u] = __builtin_bit_cast(bf16x8, pm); kf[2][u] = __builtin_bit_cast(bf16x8, pl);
             vf[0][u] = __builtin_bit_cast(bf16x8, vh); vf[1][u] = __builtin_bit_cast(bf16x8, vm); vf[2][u] = __builtin_bit_cast(bf16x8, vl);
@@ -1802,7 +1838,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 unsigned a_, b_, c_;
-                split_op<OP>(r0[e], r1[e], a_, b_, c_);
+                split_op<OP, F16>(r0[e], r1[e], a_, b_, c_, sc_in);
                 unsigned char* dst = Ktp + (d0 + e) * AB_KROW + kp * 4;
                 *reinterpret_cast<unsigned*>(dst) = a_;
                 *reinterpret_cast<unsigned*>(dst + AB_KPL) = b_;
@@ -1857,8 +1893,9 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
             const int row = t8 >> 3, ch = tid & 7;
             u32x2 h2, m2, l2;
             unsigned a_, b_, c_;
-            split_op<OP>(rk1[0], rk1[1], a_, b_, c_); h2[0] = a_; m2[0] = b_; l2[0] = c_;
-            split_op<OP>(rk1[2], rk1[3], a_, b_, c_); h2[1] = a_; m2[1] = b_; l2[1] = c_;
+            const float sc_st = kind == 0 ? sc_in : sc_g;
+            split_op<OP, F16>(rk1[0], rk1[1], a_, b_, c_, sc_st); h2[0] = a_; m2[0] = b_; l2[0] = c_;
+            split_op<OP, F16>(rk1[2], rk1[3], a_, b_, c_, sc_st); h2[1] = a_; m2[1] = b_; l2[1] = c_;
             unsigned char* dk_ = (kind == 0 ? Qk : Gk) + row * AB_KROW + ch * 8;
             *reinterpret_cast<u32x2*>(dk_) = h2; *reinterpret_cast<u32x2*>(dk_ + AB_KPL) = m2;
             if (OP == 3) *reinterpret_cast<u32x2*>(dk_ + 2 * AB_KPL) = l2;
@@ -1867,7 +1904,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
                 unsigned char* tb = (kind == 0 ? Qt : Gt) + qp * 4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    split_op<OP>(rt[0][e], rt[1][e], a_, b_, c_);
+                    split_op<OP, F16>(rt[0][e], rt[1][e], a_, b_, c_, sc_st);
                     unsigned char* dst = tb + (d0 + e) * AB_TROW;
                     *reinterpret_cast<unsigned*>(dst) = a_;
                     *reinterpret_cast<unsigned*>(dst + AB_TPL) = b_;
@@ -1890,19 +1927,19 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
             const bf16x8 g0_ = *reinterpret_cast<const bf16x8*>(gr), g1_ = *reinterpret_cast<const bf16x8*>(gr + AB_KPL);
             if (OP == 3) {
                 const bf16x8 q2_ = *reinterpret_cast<const bf16x8*>(qr + 2 * AB_KPL), g2_ = *reinterpret_cast<const bf16x8*>(gr + 2 * AB_KPL);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q2_, kf[0][u], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g2_, vf[0][u], dp, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0_, kf[2][u], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0_, vf[2][u], dp, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q1_, kf[1][u], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1_, vf[1][u], dp, 0, 0, 0);
+                s = mfma16<F16>(q2_, kf[0][u], s);
+                dp = mfma16<F16>(g2_, vf[0][u], dp);
+                s = mfma16<F16>(q0_, kf[2][u], s);
+                dp = mfma16<F16>(g0_, vf[2][u], dp);
+                s = mfma16<F16>(q1_, kf[1][u], s);
+                dp = mfma16<F16>(g1_, vf[1][u], dp);
             }
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q1_, kf[0][u], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1_, vf[0][u], dp, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0_, kf[1][u], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0_, vf[1][u], dp, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0_, kf[0][u], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0_, vf[0][u], dp, 0, 0, 0);
+            s = mfma16<F16>(q1_, kf[0][u], s);
+            dp = mfma16<F16>(g1_, vf[0][u], dp);
+            s = mfma16<F16>(q0_, kf[1][u], s);
+            dp = mfma16<F16>(g0_, vf[1][u], dp);
+            s = mfma16<F16>(q0_, kf[0][u], s);
+            dp = mfma16<F16>(g0_, vf[0][u], dp);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -1910,8 +1947,20 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
             float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c, -lse_s[qr]));
             if (!kv_ok) pv = 0.f;
             s[r] = pv;
-            dp[r] = pv * (dp[r] - del_s[qr]);
+            dp[r] = F16 ? pv * fmaf(dp[r], dp_inv, -del_s[qr]) : pv * (dp[r] - del_s[qr]);
         }
+        // fp16 pieces: this tile's dS gets its own power-of-two scale from the wave's maximum (dS = P (dP - delta) spans many binades
+        // below any bound known in advance); wave-uniform, undone where the tile's products join the running sums
+        float sc_ds = 1.f, ds_inv = 1.f;
+        if (F16) {
+            float mx = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(dp[r]));
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+            pow2_scale(mx, sc_ds, ds_inv);
+        }
+        const float dk_inv = ds_inv * so_in, dq_inv = ds_inv * so_in;          // Q^T dS by sc_in * sc_ds; dS K likewise
         // this q tile's dV^T / dK^T contributions start from zero on the matrix pipe and join the running sums on the vector pipe
         // (the bf16 MFMA does not round its accumulator to nearest: S / 32 tiles of same-signed increments would drift)
         f32x16 dvt, dkt;
@@ -1924,9 +1973,11 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
             for (int e = 0; e < 4; ++e) {
                 unsigned a_, b_, c_ = 0u;
                 if (PP == 3) split3_pair(s[8 * u + 2 * e], s[8 * u + 2 * e + 1], a_, b_, c_);
+                else if (F16) split2h_pair(s[8 * u + 2 * e], s[8 * u + 2 * e + 1], P_SCALE, a_, b_);
                 else split2_pair(s[8 * u + 2 * e], s[8 * u + 2 * e + 1], a_, b_);
                 ph[e] = a_; pm[e] = b_; pl[e] = c_;
                 if (PP == 3) split3_pair(dp[8 * u + 2 * e], dp[8 * u + 2 * e + 1], a_, b_, c_);
+                else if (F16) split2h_pair(dp[8 * u + 2 * e], dp[8 * u + 2 * e + 1], sc_ds, a_, b_);
                 else split2_pair(dp[8 * u + 2 * e], dp[8 * u + 2 * e + 1], a_, b_);
                 sh[e] = a_; sm[e] = b_; sl[e] = c_;
                 if (!TR) {
@@ -1972,23 +2023,23 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
                 }
             }
             if (OP == 3) {
-                dvt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[2], p0, dvt, 0, 0, 0);
-                dkt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[2], d0, dkt, 0, 0, 0);
+                dvt = mfma16<F16>(ga[2], p0, dvt);
+                dkt = mfma16<F16>(qa[2], d0, dkt);
             }
             if (PP == 3) {
-                dvt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p2, dvt, 0, 0, 0);
-                dkt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d2, dkt, 0, 0, 0);
+                dvt = mfma16<F16>(ga[0], p2, dvt);
+                dkt = mfma16<F16>(qa[0], d2, dkt);
             }
             if (OP == 3 || PP == 3) {
-                dvt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1], p1, dvt, 0, 0, 0);
-                dkt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1], d1, dkt, 0, 0, 0);
+                dvt = mfma16<F16>(ga[1], p1, dvt);
+                dkt = mfma16<F16>(qa[1], d1, dkt);
             }
-            dvt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1], p0, dvt, 0, 0, 0);
-            dkt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1], d0, dkt, 0, 0, 0);
-            dvt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p1, dvt, 0, 0, 0);
-            dkt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d1, dkt, 0, 0, 0);
-            dvt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p0, dvt, 0, 0, 0);
-            dkt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d0, dkt, 0, 0, 0);
+            dvt = mfma16<F16>(ga[1], p0, dvt);
+            dkt = mfma16<F16>(qa[1], d0, dkt);
+            dvt = mfma16<F16>(ga[0], p1, dvt);
+            dkt = mfma16<F16>(qa[0], d1, dkt);
+            dvt = mfma16<F16>(ga[0], p0, dvt);
+            dkt = mfma16<F16>(qa[0], d0, dkt);
         }
         // ---- dQ[q][d] partial = sum_kv dS[q][kv] K[kv][d]: A = dS planes (lane -> q), B = K^T planes (lane -> d), kv = 16u + 8hi + e
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -2017,21 +2068,24 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
             }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            if (PP == 3) dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[u][2], kb[u][0], dq, 0, 0, 0);
-            if (OP == 3) dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[u][0], kb[u][2], dq, 0, 0, 0);
-            if (OP == 3 || PP == 3) dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[u][1], kb[u][1], dq, 0, 0, 0);
-            dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[u][1], kb[u][0], dq, 0, 0, 0);
-            dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[u][0], kb[u][1], dq, 0, 0, 0);
-            dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[u][0], kb[u][0], dq, 0, 0, 0);
+            if (PP == 3) dq = mfma16<F16>(da[u][2], kb[u][0], dq);
+            if (OP == 3) dq = mfma16<F16>(da[u][0], kb[u][2], dq);
+            if (OP == 3 || PP == 3) dq = mfma16<F16>(da[u][1], kb[u][1], dq);
+            dq = mfma16<F16>(da[u][1], kb[u][0], dq);
+            dq = mfma16<F16>(da[u][0], kb[u][1], dq);
+            dq = mfma16<F16>(da[u][0], kb[u][0], dq);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();                     // every lane holds its dS fragments: the planes may be overwritten
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Pmine[crow(r, lh) * 32 + li] = dq[r];
+        for (int r = 0; r < 16; ++r) Pmine[crow(r, lh) * 32 + li] = F16 ? dq[r] * dq_inv : dq[r];
         // the tile's dV / dK join the running sums here rather than right behind their MFMAs: nothing waits for the matrix pipe (-1 %)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { dvacc[r] += dvt[r]; dkacc[r] += dkt[r]; }
+        for (int r = 0; r < 16; ++r) {
+            dvacc[r] = F16 ? fmaf(dvt[r], dv_inv, dvacc[r]) : dvacc[r] + dvt[r];
+            dkacc[r] = F16 ? fmaf(dkt[r], dk_inv, dkacc[r]) : dkacc[r] + dkt[r];
+        }
         __syncthreads();                                    // barrier B
         // fixed-order sum of the eight waves' partials -> this key block's slice of the dQ workspace
 #pragma unroll
@@ -2362,26 +2416,29 @@ extern "C" int gaot_debug_set_attention_split(int on) { const int old = g_attn_s
 
 extern "C" int gaot_attention_fwd(const float* q, const float* k, const float* v, int64_t ldq, int64_t ldk, int64_t ldv,
                                   int32_t B, int32_t S, int32_t H, int32_t Hkv, int32_t head_dim, float* o, int64_t ldo,
-                                  float* lse, int32_t pieces, gaot_stream_t stream) {
+                                  float* lse, int32_t pieces, const float* qkv_absmax, gaot_stream_t stream) {
     GAOT_REQUIRE(q && k && v && o && lse, "attention_fwd: null pointer");
-    GAOT_REQUIRE(pieces == 0 || pieces == 2 || pieces == 3, "attention_fwd: pieces %d not in {0, 2, 3}", pieces);
+    GAOT_REQUIRE(pieces == 0 || (pieces >= 2 && pieces <= 4), "attention_fwd: pieces %d not in {0, 2, 3, 4}", pieces);
+    const bool f16 = pieces == 4 && qkv_absmax != nullptr && ::g_attn_pp < 0 && ::g_attn_op < 0;      // fp16 pieces where a kernel takes them; else exact
     const int g_attn_pp = ::g_attn_pp >= 0 ? ::g_attn_pp : (pieces == 2 ? 22 : 33);
     const int g_attn_op = ::g_attn_op >= 0 ? ::g_attn_op : (pieces == 2 ? 2 : 3);
     GAOT_REQUIRE(B > 0 && S > 0 && H > 0 && Hkv > 0 && H % Hkv == 0, "attention_fwd: bad sizes B=%d S=%d H=%d Hkv=%d", B, S, H, Hkv);
     GAOT_REQUIRE(head_dim > 0 && head_dim <= 128, "attention_fwd: head_dim %d not in 1..128", head_dim);
     AttnArgs a = {};
     fill_common(a, q, k, v, ldq, ldk, ldv, B, S, H, Hkv, head_dim);
-    a.o = o; a.ldo = ldo; a.lse = lse;
+    a.o = o; a.ldo = ldo; a.lse = lse; a.qkv_amax = qkv_absmax;
     dim3 grid(cdiv(S, 128) * B * H), block(256);
     // 256-query workgroups once they still fill the chip (one per CU): half the K / V tile splits per head
     if (head_dim == 32 && a.vec && g_attn_split && g_attn_split != 3 && (g_attn_split == 2 || (long)cdiv(S, 256) * B * H >= 256)) {
-        if (S % 64 == 0 && g_attn_pipe) hipLaunchKernelGGL(attn_fwd_split_pipe_kernel<0>, dim3(cdiv(S, 256) * B * H), dim3(512), 0, ST(stream), a);
+        if (f16) hipLaunchKernelGGL((attn_fwd_split_kernel<8, 32, 2, 2, true>), dim3(cdiv(S, 256) * B * H), dim3(512), 0, ST(stream), a);
+        else if (S % 64 == 0 && g_attn_pipe) hipLaunchKernelGGL(attn_fwd_split_pipe_kernel<0>, dim3(cdiv(S, 256) * B * H), dim3(512), 0, ST(stream), a);
         else if (g_attn_pp / 10 == 3) hipLaunchKernelGGL((attn_fwd_split_kernel<8, 32, 3>), dim3(cdiv(S, 256) * B * H), dim3(512), 0, ST(stream), a);
         else if (g_attn_op == 3) hipLaunchKernelGGL((attn_fwd_split_kernel<8, 32, 2>), dim3(cdiv(S, 256) * B * H), dim3(512), 0, ST(stream), a);
         else hipLaunchKernelGGL((attn_fwd_split_kernel<8, 32, 2, 2>), dim3(cdiv(S, 256) * B * H), dim3(512), 0, ST(stream), a);
     }
     else if (head_dim == 32 && a.vec && g_attn_split) {
-        if (g_attn_pp / 10 == 3) hipLaunchKernelGGL((attn_fwd_split_kernel<4, 32, 3>), grid, block, 0, ST(stream), a);
+        if (f16) hipLaunchKernelGGL((attn_fwd_split_kernel<4, 32, 2, 2, true>), grid, block, 0, ST(stream), a);
+        else if (g_attn_pp / 10 == 3) hipLaunchKernelGGL((attn_fwd_split_kernel<4, 32, 3>), grid, block, 0, ST(stream), a);
         else if (g_attn_op == 3) hipLaunchKernelGGL((attn_fwd_split_kernel<4, 32, 2>), grid, block, 0, ST(stream), a);
         else hipLaunchKernelGGL((attn_fwd_split_kernel<4, 32, 2, 2>), grid, block, 0, ST(stream), a);
     }
@@ -2493,9 +2550,11 @@ extern "C" int64_t gaot_attention_bwd_workspace(int32_t B, int32_t S, int32_t H,
 extern "C" int gaot_attention_bwd(const float* q, const float* k, const float* v, int64_t ldq, int64_t ldk, int64_t ldv,
                                   const float* o, const float* dout, int64_t ldo, const float* lse, int32_t B, int32_t S,
                                   int32_t H, int32_t Hkv, int32_t head_dim, float* dq, float* dk, float* dv, int64_t lddq,
-                                  int64_t lddk, int64_t lddv, float* workspace, int32_t pieces, gaot_stream_t stream) {
+                                  int64_t lddk, int64_t lddv, float* workspace, int32_t pieces, const float* qkv_absmax,
+                                  const float* dout_absmax, gaot_stream_t stream) {
     GAOT_REQUIRE(q && k && v && o && dout && lse && dq && dk && dv && workspace, "attention_bwd: null pointer");
-    GAOT_REQUIRE(pieces == 0 || pieces == 2 || pieces == 3, "attention_bwd: pieces %d not in {0, 2, 3}", pieces);
+    GAOT_REQUIRE(pieces == 0 || (pieces >= 2 && pieces <= 4), "attention_bwd: pieces %d not in {0, 2, 3, 4}", pieces);
+    const bool f16 = pieces == 4 && qkv_absmax != nullptr && dout_absmax != nullptr && ::g_attn_pp < 0 && ::g_attn_op < 0;
     const int g_attn_pp = ::g_attn_pp >= 0 ? ::g_attn_pp : (pieces == 2 ? 22 : 33);
     const int g_attn_op = ::g_attn_op >= 0 ? ::g_attn_op : (pieces == 2 ? 2 : 3);
     GAOT_REQUIRE(B > 0 && S > 0 && H > 0 && Hkv > 0 && H % Hkv == 0, "attention_bwd: bad sizes");
@@ -2508,6 +2567,7 @@ extern "C" int gaot_attention_bwd(const float* q, const float* k, const float* v
     a.delta = workspace;
     a.dq_part = workspace + (int64_t)B * H * S;
     a.n_kblocks = cdiv(S, 128);
+    a.qkv_amax = qkv_absmax; a.dout_amax = dout_absmax;
     const int DP = head_dim <= 32 ? 32 : (head_dim <= 64 ? 64 : 128);
     if (a.vec && aligned16(o)) {
         const int lpr = 8;
@@ -2519,7 +2579,8 @@ extern "C" int gaot_attention_bwd(const float* q, const float* k, const float* v
     const bool split_ok = head_dim == 32 && a.vec && g_attn_split && aligned16(dq) && aligned16(dk) && aligned16(dv);
     if (split_ok && g_attn_split != 3 && (g_attn_split == 2 || (long)cdiv(S, 256) * B * H >= 256)) {
         a.n_kblocks = cdiv(S, 256);          // 256 keys per workgroup: half the dQ slabs (the workspace is sized for 128)
-        if (g_attn_pp % 10 == 3) hipLaunchKernelGGL(attn_bwd_split8_kernel<3>, dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a);
+        if (f16) hipLaunchKernelGGL((attn_bwd_split8_kernel<2, 2, true, true>), dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a);
+        else if (g_attn_pp % 10 == 3) hipLaunchKernelGGL(attn_bwd_split8_kernel<3>, dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a);
         else if (g_attn_op == 3) hipLaunchKernelGGL(attn_bwd_split8_kernel<2>, dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a);
         else if (g_attn_tr) hipLaunchKernelGGL((attn_bwd_split8_kernel<2, 2, true>), dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a);
         else hipLaunchKernelGGL((attn_bwd_split8_kernel<2, 2>), dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a);

@@ -1935,10 +1935,17 @@ class _Attention(torch.autograd.Function):
                                                    _p(seed), _stream()), "gaot_attention_fwd_dropout")
             _LAST_DROPOUT_SEED[0] = seed
         else:
-            L.check(lib.gaot_attention_fwd(_p(q), _p(kq), _p(vq), W, W, W, B, S, H, Hkv, D, _p(o), H * D, _p(lse), _PIECES["attn"], _stream()),
+            pc, qw = _PIECES["attn"], None
+            if pc == 3 and _F16_PIECES[0] and D == 32:       # fp16 pieces: the operands' magnitude word (published by the projection's epilogue)
+                qw = amax_for(qkv.view(B * S, W), qkv, qkv_in)
+                pc = 4
+            L.check(lib.gaot_attention_fwd(_p(q), _p(kq), _p(vq), W, W, W, B, S, H, Hkv, D, _p(o), H * D, _p(lse), pc, _p(qw), _stream()),
                     "gaot_attention_fwd")
+            ctx.qkv_amax = qw
         ctx.save_for_backward(qkv, o, lse, seed if seed is not None else qkv.new_empty(0))
         ctx.dims = (B, S, H, Hkv, D, float(p_drop))
+        if p_drop > 0.0:
+            ctx.qkv_amax = None
         if p_drop == 0.0:      # every output row is a convex combination of V rows: max |o| <= max |v| <= max |qkv| (a bound is as good as the maximum)
             _publish(_amax_get(qkv, qkv_in), o)
         return o
@@ -1949,6 +1956,7 @@ class _Attention(torch.autograd.Function):
         B, S, H, Hkv, D, p_drop = ctx.dims
         W = (H + 2 * Hkv) * D
         lib = L.load()
+        do_in = do
         do = do.contiguous()
         dqkv = torch.empty_like(qkv)
         ws = torch.empty(int(lib.gaot_attention_bwd_workspace(B, S, H, D)), device=qkv.device, dtype=torch.float32)
@@ -1965,8 +1973,14 @@ class _Attention(torch.autograd.Function):
                                                    _p(lse), B, S, H, Hkv, D, _p(dflat), _p(dk_t), _p(dv_t), W, ldk, ldv, _p(ws),
                                                    p_drop, _p(seed), _stream()), "gaot_attention_bwd_dropout")
         else:
+            pc, qw, gw = _PIECES["attn"], ctx.qkv_amax, None
+            if pc == 3 and _F16_PIECES[0] and D == 32:
+                if qw is None:
+                    qw = amax_for(qkv.view(B * S, W), qkv)
+                gw = amax_for(do.view(B * S, H * D), do, do_in)
+                pc = 4
             L.check(lib.gaot_attention_bwd(_p(flat), _p(flat[H * D:]), _p(flat[(H + Hkv) * D:]), W, W, W, _p(o), _p(do), H * D,
-                                           _p(lse), B, S, H, Hkv, D, _p(dflat), _p(dk_t), _p(dv_t), W, ldk, ldv, _p(ws), _PIECES["attn"], _stream()),
+                                           _p(lse), B, S, H, Hkv, D, _p(dflat), _p(dk_t), _p(dv_t), W, ldk, ldv, _p(ws), pc, _p(qw), _p(gw), _stream()),
                     "gaot_attention_bwd")
         if Hkv != H:
             r = H // Hkv

@@ -266,11 +266,14 @@ int gaot_swiglu_bwd(const float* u, const float* dg, int32_t M, int32_t F, float
  * q/k/v are strided views: element (b,s,h,d) at ptr[(b*S+s)*ld + h*head_dim + d]; kv head = h / (H/Hkv).
  * o has the same addressing with ldo.  lse[B,H,S] (natural-log-sum-exp of scaled scores) saved for bwd.
  * head_dim <= 128, S arbitrary (head_dim <= 64: split-bf16 kernels where they apply; above: fp32 MFMA).
- * pieces: precision of the products on the bf16 matrix pipe, as gaot_gemm_desc.pieces: 0 / 3 = every fp32 operand (Q, K, V, dO and the
- * probabilities P / dS) as three bf16 pieces, exact to fp32 rounding; 2 = two rounded pieces each (16 significant bits). */
+ * pieces: precision of the products on the matrix pipe, as gaot_gemm_desc.pieces: 0 / 3 = every fp32 operand (Q, K, V, dO and the
+ * probabilities P / dS) as three bf16 pieces, exact to fp32 rounding; 2 = two rounded bf16 pieces each (16 significant bits); 4 = two
+ * fp16 pieces of the scaled operand (head_dim 32; elsewhere, and without the words, it means 3): Q / K / V scaled through
+ * qkv_absmax -- ONE magnitude word for the three of them (they are column blocks of one projection output; any bound works) --
+ * dO through dout_absmax, P by 2^13, dS per 32 x 32 tile by the tile's own maximum. */
 int gaot_attention_fwd(const float* q, const float* k, const float* v, int64_t ldq, int64_t ldk, int64_t ldv,
                        int32_t B, int32_t S, int32_t H, int32_t Hkv, int32_t head_dim,
-                       float* o, int64_t ldo, float* lse, int32_t pieces, gaot_stream_t stream);
+                       float* o, int64_t ldo, float* lse, int32_t pieces, const float* qkv_absmax, gaot_stream_t stream);
 /* workspace floats needed by gaot_attention_bwd */
 /* attention dropout (attn.py:110-114: dropout_p of F.scaled_dot_product_attention while training): the softmax output is
  * multiplied by keep(b,h,q,k) / (1 - p) before the product with V.  keep = (splitmix64(seed + ((b*H + h)*S + q)*S + k) >> 32) <
@@ -292,7 +295,7 @@ int gaot_attention_bwd(const float* q, const float* k, const float* v, int64_t l
                        const float* o, const float* dout, int64_t ldo, const float* lse,
                        int32_t B, int32_t S, int32_t H, int32_t Hkv, int32_t head_dim,
                        float* dq, float* dk, float* dv, int64_t lddq, int64_t lddk, int64_t lddv,
-                       float* workspace, int32_t pieces, gaot_stream_t stream);
+                       float* workspace, int32_t pieces, const float* qkv_absmax, const float* dout_absmax, gaot_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * reductions / layout

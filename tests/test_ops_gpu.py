@@ -751,6 +751,52 @@ def test_gemm_two_piece_products(M, N, K, bf16x2):
 
 
 @pytest.mark.gpu
+def test_attention_fp16_piece_products():
+    """the default head_dim-32 attention (`pieces` = 4): Q / K / V as two fp16 pieces scaled through ONE magnitude word, dO through its
+    own, P by 2^13, dS per 32 x 32 tile by the tile's own maximum; three piece products per k-step on the f16 MFMA.
+      * random normal data at the bench shape (8-wave kernels) and at a small one (4-wave forward): output and gradients as close to
+        float64 as the three-piece bf16 kernels (within 1.5x run to run; < 6e-7 / 1.2e-6);
+      * operands 1e-3 / gradients 1e-9 times smaller, or 3 / 1e+6 times larger: errors at the same level (the words follow the data);
+      * many equal tokens (same-signed accumulation): no drift; deterministic."""
+    from gaot_amd import ops, _lib
+    assert ops.precision() == "f32" and ops._F16_PIECES[0]
+
+    def run(qkv, go, H, D):
+        B, S, _ = qkv.shape
+        r = qkv.clone().double().requires_grad_(True)
+        q, k, v = [r[..., i * H * D:(i + 1) * H * D].reshape(B, S, H, D).transpose(1, 2) for i in range(3)]
+        ref = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(D), -1) @ v).transpose(1, 2).reshape(B, S, H * D)
+        ref.backward(go.double())
+        outs = []
+        for mode in ("fp16x2", "fp16x2", "bf16x3"):
+            old = ops.set_f32_pieces(mode)
+            try:
+                d = qkv.to(dev()).requires_grad_(True)
+                out = ops.attention(d, H, H, D)
+                out.backward(go.to(dev()))
+            finally:
+                ops.set_f32_pieces(old)
+            outs.append((out.detach(), d.grad))
+        assert all(bool(torch.isfinite(t).all()) for o in outs for t in o), [bool(torch.isfinite(t).all()) for o in outs for t in o]
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (rel(outs[0][0], outs[1][0].double().cpu()), rel(outs[0][1], outs[1][1].double().cpu()))           # deterministic
+        return (rel(outs[0][0], ref), rel(outs[0][1], r.grad)), (rel(outs[2][0], ref), rel(outs[2][1], r.grad))
+
+    g = torch.Generator().manual_seed(11)
+    for (B, S, H, D) in ((8, 1024, 8, 32), (2, 333, 4, 32)):
+        qkv, go = torch.randn(B, S, 3 * H * D, generator=g), torch.randn(B, S, H * D, generator=g)
+        base = None
+        for sq, sg in ((1.0, 1.0), (1e-3, 1e-9), (3.0, 1e6)):
+            (eo, eg), (eo3, eg3) = run(qkv * sq if sq == 1.0 else qkv * sq, go * sg, H, D)
+            assert eo < 1.5 * eo3 + 2e-8 and eg < 1.5 * eg3 + 2e-8, (B, S, sq, sg, eo, eg, eo3, eg3)
+            assert sq > 1.0 or (eo < 6e-7 and eg < 1.2e-6), (B, S, sq, sg, eo, eg)      # (3 x larger q, k: a 9 x sharper softmax amplifies every kernel's rounding)
+    base = (torch.randn(1, 1, 3 * 8 * 32, generator=g) * 0.6).repeat(1, 2048, 1)
+    idx = torch.randperm(2048, generator=g)[:200]
+    base[0, idx] = torch.randn(200, 3 * 8 * 32, generator=g) * 0.6
+    (eo, eg), _ = run(base + 1e-3 * torch.randn(1, 2048, 3 * 8 * 32, generator=g), torch.randn(1, 2048, 8 * 32, generator=g), 8, 32)
+    assert eo < 2e-6 and eg < 1e-5, (eo, eg)
+
+
+@pytest.mark.gpu
 def test_attention_two_piece_variant(bf16x2):
     """the "bf16x2" attention (`pieces` = 2 per call): P / dS and the Q / K / V / dO operands as two rounded bf16 pieces (three piece products per
     k-step in all seven products).  Random normal data (the worst case for a per-term relative error): output within 1e-5 and
