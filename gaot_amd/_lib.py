@@ -94,7 +94,7 @@ PROTOTYPES = {
     "gaot_attention_bwd_workspace": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "gaot_attention_bwd": (C.c_int, [_f, _f, _f, C.c_int64, C.c_int64, C.c_int64, _f, _f, C.c_int64, _f,
                                      C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                                     _f, _f, _f, C.c_int64, C.c_int64, C.c_int64, _f, C.c_int32, _f, _f, _s]),
+                                     _f, _f, _f, C.c_int64, C.c_int64, C.c_int64, _f, C.c_int32, _f, _f, _f, _s]),
     "gaot_attention_seed_next": (C.c_int, [_i, C.c_uint64, _i, _s]),
     "gaot_attention_fwd_dropout": (C.c_int, [_f, _f, _f, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                              C.c_int32, C.c_int32, _f, C.c_int64, _f, C.c_float, _i, _s]),
@@ -151,7 +151,7 @@ PROTOTYPES = {
     "gaot_cond_affine_bwd": (C.c_int, [_f, _f, _f, C.c_int32, C.c_int64, C.c_int32, _f, _f, _s]),
     "gaot_rollout_input": (C.c_int, [_f, C.c_int32, _f, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_int64, _f, _s]),
     "gaot_rollout_update": (C.c_int, [_f, _f, C.c_int32, _f, _f, _f, _f, C.c_float, C.c_int32, C.c_int64, _f, _s]),
-    "gaot_patchify": (C.c_int, [_f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f, C.c_int32, _s]),
+    "gaot_patchify": (C.c_int, [_f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f, C.c_int32, _f, _s]),
 }
 
 _lib = None

@@ -32,6 +32,7 @@ struct AttnArgs {
     const unsigned long long* drop_seed; unsigned drop_thresh; float drop_scale;
     // fp16-piece kernels (pieces = 4): magnitude words of the q | k | v operands (one word: they are one tensor) and of dO
     const float* qkv_amax; const float* dout_amax;
+    float* dqkv_amax;          // optional: published magnitude word of dq | dk | dv
 };
 
 // splitmix64 finaliser of (seed + linear index of the score): the top 32 bits against the keep threshold
@@ -929,6 +930,7 @@ __global__ void attn_delta_vec_kernel(const AttnArgs p, int lpr) {
 // dq[b,s,h,:] = scale * sum_kb part[kb][b,h,s,:]
 __global__ void attn_dq_reduce_kernel(const AttnArgs p, int DP) {
     const long total = (long)p.B * p.H * p.S * DP;
+    float am = 0.f;
     for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long)gridDim.x * blockDim.x) {
         const int d = (int)(gid % DP);
         if (d >= p.D) continue;
@@ -939,7 +941,9 @@ __global__ void attn_dq_reduce_kernel(const AttnArgs p, int DP) {
         float acc = 0.f;
         for (int kb = 0; kb < p.n_kblocks; ++kb) acc += p.dq_part[(long)kb * total + gid];
         p.dq[((long)b * p.S + s) * p.lddq + (long)h * p.D + d] = acc * p.scale;
+        am = fmaxf(am, fabsf(acc * p.scale));
     }
+    if (p.dqkv_amax) amax_publish(p.dqkv_amax, am, threadIdx.x & 63, (int)blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2104,6 +2108,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
     // ---- epilogue: dK^T, dV^T -> [kv][d] through the wave's (now free) dS region, coalesced row stores
     __syncthreads();
     float* Smine = reinterpret_cast<float*>(dSp);            // [32][33] floats = 4224 B <= 7680
+    float am = 0.f;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
@@ -2114,14 +2119,17 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
         for (int rr = lh; rr < 32; rr += 2) {
             const int kv = kv0 + rr;
             if (kv < p.S) {
-                if (pass == 0) p.dk[((long)b * p.S + kv) * p.lddk + (long)h * 32 + li] = Smine[rr * 33 + li];
-                else           p.dv[((long)b * p.S + kv) * p.lddv + (long)h * 32 + li] = Smine[rr * 33 + li];
+                const float val = Smine[rr * 33 + li];
+                if (pass == 0) p.dk[((long)b * p.S + kv) * p.lddk + (long)h * 32 + li] = val;
+                else           p.dv[((long)b * p.S + kv) * p.lddv + (long)h * 32 + li] = val;
+                am = fmaxf(am, fabsf(val));
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    if (F16 && p.dqkv_amax) { __syncthreads(); amax_publish_block<8>(p.dqkv_amax, am, reinterpret_cast<float*>(smem)); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2551,7 +2559,7 @@ extern "C" int gaot_attention_bwd(const float* q, const float* k, const float* v
                                   const float* o, const float* dout, int64_t ldo, const float* lse, int32_t B, int32_t S,
                                   int32_t H, int32_t Hkv, int32_t head_dim, float* dq, float* dk, float* dv, int64_t lddq,
                                   int64_t lddk, int64_t lddv, float* workspace, int32_t pieces, const float* qkv_absmax,
-                                  const float* dout_absmax, gaot_stream_t stream) {
+                                  const float* dout_absmax, float* dqkv_absmax, gaot_stream_t stream) {
     GAOT_REQUIRE(q && k && v && o && dout && lse && dq && dk && dv && workspace, "attention_bwd: null pointer");
     GAOT_REQUIRE(pieces == 0 || (pieces >= 2 && pieces <= 4), "attention_bwd: pieces %d not in {0, 2, 3, 4}", pieces);
     const bool f16 = pieces == 4 && qkv_absmax != nullptr && dout_absmax != nullptr && ::g_attn_pp < 0 && ::g_attn_op < 0;
@@ -2567,7 +2575,8 @@ extern "C" int gaot_attention_bwd(const float* q, const float* k, const float* v
     a.delta = workspace;
     a.dq_part = workspace + (int64_t)B * H * S;
     a.n_kblocks = cdiv(S, 128);
-    a.qkv_amax = qkv_absmax; a.dout_amax = dout_absmax;
+    a.qkv_amax = qkv_absmax; a.dout_amax = dout_absmax; a.dqkv_amax = dqkv_absmax;
+    bool dkdv_published = false;
     const int DP = head_dim <= 32 ? 32 : (head_dim <= 64 ? 64 : 128);
     if (a.vec && aligned16(o)) {
         const int lpr = 8;
@@ -2579,7 +2588,7 @@ extern "C" int gaot_attention_bwd(const float* q, const float* k, const float* v
     const bool split_ok = head_dim == 32 && a.vec && g_attn_split && aligned16(dq) && aligned16(dk) && aligned16(dv);
     if (split_ok && g_attn_split != 3 && (g_attn_split == 2 || (long)cdiv(S, 256) * B * H >= 256)) {
         a.n_kblocks = cdiv(S, 256);          // 256 keys per workgroup: half the dQ slabs (the workspace is sized for 128)
-        if (f16) hipLaunchKernelGGL((attn_bwd_split8_kernel<2, 2, true, true>), dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a);
+        if (f16) { hipLaunchKernelGGL((attn_bwd_split8_kernel<2, 2, true, true>), dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a); dkdv_published = true; }
         else if (g_attn_pp % 10 == 3) hipLaunchKernelGGL(attn_bwd_split8_kernel<3>, dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a);
         else if (g_attn_op == 3) hipLaunchKernelGGL(attn_bwd_split8_kernel<2>, dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a);
         else if (g_attn_tr) hipLaunchKernelGGL((attn_bwd_split8_kernel<2, 2, true>), dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a);
@@ -2616,5 +2625,9 @@ extern "C" int gaot_attention_bwd(const float* q, const float* k, const float* v
     int nb = cdiv(total, 256); if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(attn_dq_reduce_kernel, dim3(nb), dim3(256), 0, ST(stream), a, DP);
     GAOT_CHECK_LAUNCH("gaot_attention_bwd");
+    if (dqkv_absmax && !dkdv_published) {        // main kernels that do not publish: one grouped-absmax launch over dK and dV
+        gaot_absmax_item it[2] = {{dk, lddk, B * S, H * head_dim, dqkv_absmax}, {dv, lddv, B * S, H * head_dim, dqkv_absmax}};
+        if (int rc = gaot_absmax_grouped(it, 2, stream)) return rc;
+    }
     return GAOT_OK;
 }

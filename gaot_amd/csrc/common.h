@@ -154,6 +154,22 @@ __device__ __forceinline__ void amax_publish(float* word, float v, int lane, int
     // every workgroup's life: measured +20 us on a 1 024-workgroup launch)
     if (lane == 0 && v > 0.f) (void)__hip_atomic_fetch_max(w, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// the same with ONE atomic per workgroup (kernels whose workgroups all finish together: thousands of per-wave atomics at the very end of
+// a launch cost microseconds, 8 x fewer do not): every thread of the workgroup must call it; `red` = NW floats of LDS
+template <int NW>
+__device__ __forceinline__ void amax_publish_block(float* word, float v, float* red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = red[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) m = fmaxf(m, red[w]);
+        if (m > 0.f) (void)__hip_atomic_fetch_max(reinterpret_cast<unsigned*>(word) + ((int)blockIdx.x & (GAOT_AMAX_SLOTS - 1)) * GAOT_AMAX_STRIDE,
+                                                  __float_as_uint(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 // (scale, 1 / scale) for an operand whose largest magnitude is the maximum of the word's slots: scale = 2^(13 - floor(log2 amax)),
 // exponent clamped to +-126 (amax = 0 or denormal: the clamp; the operand is zero or flushes to it).  NaN / inf magnitudes give a finite
 // scale: the product's NaNs come from the data itself.  Every lane of the wave must call it (cross-lane maximum).

@@ -83,9 +83,11 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_vec_kernel(const float* __res
                                                               float eps, float* __restrict__ y, float* __restrict__ rstd,
                                                               float* __restrict__ y_amax) {
     constexpr int D = 256 * NV;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ float amred[4];
+    const int row_ = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (row >= M) return;
+    const bool live = row_ < M;
+    const int row = live ? row_ : M - 1;             // past the end: recompute the last row, store nothing (the block-wide publish needs every wave)
     f32x4 xv[NV];
     float ss = 0.f;
 #pragma unroll
@@ -95,16 +97,16 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_vec_kernel(const float* __res
     }
     ss = wave_sum(ss);
     const float r = rsqrtf(ss / (float)D + eps);
-    if (lane == 0) rstd[row] = r;
+    if (lane == 0 && live) rstd[row] = r;
     float am = 0.f;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         const f32x4 wv = *reinterpret_cast<const f32x4*>(w + v * 256 + lane * 4);
         const f32x4 o = xv[v] * r * wv;
-        *reinterpret_cast<f32x4*>(y + (long)row * D + v * 256 + lane * 4) = o;
+        if (live) *reinterpret_cast<f32x4*>(y + (long)row * D + v * 256 + lane * 4) = o;
         am = fmaxf(am, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
     }
-    if (y_amax) amax_publish(y_amax, am, lane, row);
+    if (y_amax) amax_publish_block<4>(y_amax, am, amred);
 }
 template <int NV>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ w,
@@ -113,6 +115,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_vec_kernel(const float* __res
                                                               float* __restrict__ dx, float* __restrict__ dwp, float* __restrict__ dx_amax) {
     constexpr int D = 256 * NV;
     __shared__ f32x4 red[4][NV][64];
+    __shared__ float amred[4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float am = 0.f;
     f32x4 wv[NV], dwacc[NV];
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_vec_kernel(const float* __res
             dwacc[v] += gv[v] * xv[v] * r;
         }
     }
-    if (dx_amax) amax_publish(dx_amax, am, lane, (int)blockIdx.x * 4 + wave);
+    if (dx_amax) amax_publish_block<4>(dx_amax, am, amred);
 #pragma unroll
     for (int v = 0; v < NV; ++v) red[wave][v][lane] = dwacc[v];
     __syncthreads();
@@ -404,7 +407,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 
 // 16-byte patchify: one thread per 4 channels of a grid node (C % 4 == 0); a node's C channels stay contiguous on both sides
 __global__ void patchify_vec_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int Dz, int P,
-                                    int C, int inverse) {
+                                    int C, int inverse, float* __restrict__ out_amax) {
+    float am = 0.f;
     const int dim = Dz > 0 ? 3 : 2;
     const int D1 = Dz > 0 ? Dz : 1;
     const int C4 = C / 4;
@@ -431,9 +435,11 @@ __global__ void patchify_vec_kernel(const float* __restrict__ in, float* __restr
         }
         const long tok = (b * (nodes / pvol) + s) * ((long)pvol * C) + k;
         const long g = (b * nodes + node) * C + c;
-        if (inverse) *reinterpret_cast<f32x4*>(out + g) = *reinterpret_cast<const f32x4*>(in + tok);
-        else *reinterpret_cast<f32x4*>(out + tok) = *reinterpret_cast<const f32x4*>(in + g);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(inverse ? in + tok : in + g);
+        *reinterpret_cast<f32x4*>(inverse ? out + g : out + tok) = v;
+        am = fmaxf(am, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
     }
+    if (out_amax) amax_publish(out_amax, am, threadIdx.x & 63, (int)blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 
 }  // namespace gaot
@@ -598,14 +604,20 @@ extern "C" int gaot_batchsum(const float* x, int32_t B, int64_t RN, float* out, 
 }
 
 extern "C" int gaot_patchify(const float* in, int32_t B, int32_t H, int32_t W, int32_t Dz, int32_t P, int32_t C,
-                             float* out, int32_t inverse, gaot_stream_t stream) {
+                             float* out, int32_t inverse, float* out_absmax, gaot_stream_t stream) {
     GAOT_REQUIRE(in && out && B > 0 && H > 0 && W > 0 && Dz >= 0 && P > 0 && C > 0, "patchify: bad arguments");
     GAOT_REQUIRE(H % P == 0 && W % P == 0 && (Dz == 0 || Dz % P == 0), "patchify: grid %dx%dx%d not divisible by patch %d", H, W, Dz, P);
     const long total = (long)B * H * W * (Dz > 0 ? Dz : 1) * C;
     if (C % 4 == 0 && aligned16(in) && aligned16(out))
-        hipLaunchKernelGGL(patchify_vec_kernel, dim3(cap_blocks(total / 4, 256, 8192)), dim3(256), 0, ST(stream), in, out, B, H, W, Dz, P, C, inverse);
-    else
+        hipLaunchKernelGGL(patchify_vec_kernel, dim3(cap_blocks(total / 4, 256, 8192)), dim3(256), 0, ST(stream), in, out, B, H, W, Dz, P, C, inverse, out_absmax);
+    else {
         hipLaunchKernelGGL(patchify_kernel, dim3(cap_blocks(total, 256, 8192)), dim3(256), 0, ST(stream), in, out, B, H, W, Dz, P, C, inverse);
+        if (out_absmax) {           // the scalar kernel does not publish: one grouped-absmax launch over the output
+            const int32_t cols = inverse ? C : C * (Dz > 0 ? P * P * P : P * P);
+            gaot_absmax_item it = {out, (int64_t)cols, (int32_t)(total / cols), cols, out_absmax};
+            if (int rc = gaot_absmax_grouped(&it, 1, stream)) return rc;
+        }
+    }
     GAOT_CHECK_LAUNCH("gaot_patchify");
     return GAOT_OK;
 }

@@ -192,6 +192,10 @@ def _amax_words(n: int, device) -> List[torch.Tensor]:
 
 def _absmax_launch(pairs) -> None:
     """pairs: (2-D tensor with unit inner stride, word): ONE gaot_absmax_grouped launch"""
+    if _AMAX_TRACE:
+        import traceback
+        fr = [f"{f.name}:{f.lineno}" for f in traceback.extract_stack()[-7:-1]]
+        print(f"[absmax] {[tuple(t.shape) for t, _ in pairs][:4]}{'...' if len(pairs) > 4 else ''} <- {' < '.join(reversed(fr))}", flush=True)
     arr = (L.AbsmaxItem * len(pairs))()
     for i, (t, w) in enumerate(pairs):
         arr[i] = L.AbsmaxItem(t.data_ptr(), t.stride(0) if t.shape[0] > 1 else t.shape[1], t.shape[0], t.shape[1], w.data_ptr())
@@ -279,6 +283,7 @@ def weight_amax(w2d: torch.Tensor) -> torch.Tensor:
     return best[1] if best is not None else amax_for(w2d)
 
 
+_AMAX_TRACE = os.environ.get("GAOT_AMAX_TRACE", "0") == "1"      # tools: print every fallback absmax launch with its call site
 _PATH_CACHE: dict = {}
 _PUBLISH_C = os.environ.get("GAOT_NO_CAMAX", "0") != "1"       # A/B switch (tools): GEMM epilogues publish the output's magnitude word
 
@@ -1979,9 +1984,11 @@ class _Attention(torch.autograd.Function):
                     qw = amax_for(qkv.view(B * S, W), qkv)
                 gw = amax_for(do.view(B * S, H * D), do, do_in)
                 pc = 4
+            dw_ = _want_word(qkv.device) if Hkv == H else None          # dq | dk | dv feed the q|k|v input-gradient and weight-gradient products
             L.check(lib.gaot_attention_bwd(_p(flat), _p(flat[H * D:]), _p(flat[(H + Hkv) * D:]), W, W, W, _p(o), _p(do), H * D,
-                                           _p(lse), B, S, H, Hkv, D, _p(dflat), _p(dk_t), _p(dv_t), W, ldk, ldv, _p(ws), pc, _p(qw), _p(gw), _stream()),
+                                           _p(lse), B, S, H, Hkv, D, _p(dflat), _p(dk_t), _p(dv_t), W, ldk, ldv, _p(ws), pc, _p(qw), _p(gw), _p(dw_), _stream()),
                     "gaot_attention_bwd")
+            _publish(dw_, dqkv)
         if Hkv != H:
             r = H // Hkv
             dqkv[..., H * D:(H + Hkv) * D] = dk_full.view(B, S, Hkv, r, D).sum(3).reshape(B, S, Hkv * D)
@@ -2030,8 +2037,10 @@ class _Patchify(torch.autograd.Function):
         else:
             Cc = x.shape[2]
             out = torch.empty(B, nodes // pvol, pvol * Cc, device=x.device, dtype=torch.float32)
-        L.check(L.load().gaot_patchify(_p(x), B, H, W, Dz, P, Cc, _p(out), int(inverse), _stream()), "gaot_patchify")
+        ow = _want_word(x.device)
+        L.check(L.load().gaot_patchify(_p(x), B, H, W, Dz, P, Cc, _p(out), int(inverse), _p(ow), _stream()), "gaot_patchify")
         ctx.args = (tuple(sizes), P, inverse)
+        _publish(ow, out)
         return out
 
     @staticmethod

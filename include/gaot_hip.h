@@ -295,7 +295,9 @@ int gaot_attention_bwd(const float* q, const float* k, const float* v, int64_t l
                        const float* o, const float* dout, int64_t ldo, const float* lse,
                        int32_t B, int32_t S, int32_t H, int32_t Hkv, int32_t head_dim,
                        float* dq, float* dk, float* dv, int64_t lddq, int64_t lddk, int64_t lddv,
-                       float* workspace, int32_t pieces, const float* qkv_absmax, const float* dout_absmax, gaot_stream_t stream);
+                       float* workspace, int32_t pieces, const float* qkv_absmax, const float* dout_absmax,
+                       float* dqkv_absmax /* optional: ONE magnitude word (zero before) for everything stored to dq, dk and dv */,
+                       gaot_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * reductions / layout
@@ -361,7 +363,7 @@ int gaot_adamw_step_dev(float* p, const float* g, float* m, float* v, int64_t n,
 /* patchify gaot.py:182-185,202-205 and its inverse gaot.py:224-231.  Latent grid H x W (x Dz; Dz = 0 for 2-D).
  * inverse = 0: in = grid[b, (h,w[,z]), c]  -> out = tokens[b, s, (p..., c)];  inverse = 1: the other way. */
 int gaot_patchify(const float* in, int32_t B, int32_t H, int32_t W, int32_t Dz, int32_t P, int32_t C,
-                  float* out, int32_t inverse, gaot_stream_t stream);
+                  float* out, int32_t inverse, float* out_absmax /* optional: magnitude word of `out` (zero before) */, gaot_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Edge-partitioned forms of the fused integral-transform kernels (csrc/gno_ep.hip): the edge list is cut into equal chunks, a

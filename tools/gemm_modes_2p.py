@@ -18,8 +18,11 @@ def timeit(fn, iters=30):
 M = 8192
 shapes = [("nt", 2048, 256), ("nt", 256, 1024), ("nt", 768, 256), ("nt", 256, 256), ("nt", 256, 512),
           ("nn", 256, 2048), ("nn", 1024, 256), ("nn", 256, 768), ("nn", 256, 256), ("nn", 256, 512), ("nn", 512, 256)]
-for pieces in (2, 3):
-    ops.set_gemm_pieces(pieces)
+if len(sys.argv) > 1:
+    shapes = [s_ for s_ in shapes if s_[0] in sys.argv[1:]]
+for pieces in ("fp16x2", "bf16x3", "bf16x2"):
+    if pieces == "bf16x2": ops.set_precision("bf16x2")
+    else: ops.set_precision("f32"); ops.set_f32_pieces(pieces)
     print(f"pieces {pieces}:   kind     N     K |  heuristic(path)   split128   split64   fp32-MFMA   [us]")
     for kind, N, K in shapes:
         out = torch.empty(M, N, device=dev)
