@@ -347,6 +347,7 @@ class TrainStep:
         self._cuts: Optional[_Cuts] = None
         self._checked_phases = False
         self.comm_enabled = True      # False: skip the gradient exchange (bench.py measures the exposed communication as the difference)
+        self.force_comm = False       # True: issue the collectives even in a one-rank group (tests of the RCCL path on one-GPU boxes)
 
     # ---- the eager pieces
     def _forward_loss(self):
@@ -439,13 +440,13 @@ class TrainStep:
     def _eager_step(self):
         if not self.staged:
             loss = self._forward_backward()
-            self.bucket.all_reduce_mean(self.group)
+            self.bucket.all_reduce_mean(self.group, _force=self.force_comm)
         else:
             works, loss = [], None
             for gi, ks in enumerate(self.stage_groups):
                 out = self._run_group(gi)
                 loss = out if out is not None else loss
-                works.append(self.bucket.all_reduce_mean(self.group, ks, async_op=True))
+                works.append(self.bucket.all_reduce_mean(self.group, ks, async_op=True, _force=self.force_comm))
             for w in works:
                 if w is not None:
                     w.wait()
@@ -503,7 +504,7 @@ class TrainStep:
         if not self.staged:
             self._graphs[0].replay()
             if self.comm_enabled:
-                self.bucket.all_reduce_mean(self.group)      # one flat RCCL all-reduce between the two graphs
+                self.bucket.all_reduce_mean(self.group, _force=self.force_comm)      # one flat RCCL all-reduce between the two graphs
         else:
             # everything below is enqueued without a host wait: a stage group's slice is reduced on RCCL's stream while the main
             # stream replays the backward of the next group
@@ -511,7 +512,7 @@ class TrainStep:
             for gi, g in enumerate(self._graphs):
                 g.replay()
                 if self.comm_enabled:
-                    works.append(self.bucket.all_reduce_mean(self.group, self.stage_groups[gi], async_op=True))
+                    works.append(self.bucket.all_reduce_mean(self.group, self.stage_groups[gi], async_op=True, _force=self.force_comm))
             for w in works:
                 if w is not None:
                     w.wait()

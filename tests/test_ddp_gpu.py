@@ -173,6 +173,36 @@ def test_staged_single_rank_equals_unstaged():
         assert float((r - res[0]).norm() / res[0].norm()) < 2e-6
 
 
+@pytest.mark.parametrize("graph", [True, False])
+def test_whole_staged_trainstep_on_rccl_one_rank_group(graph):
+    """the WHOLE staged TrainStep as every rank of an N-GPU job runs it, on RCCL: stage-group hipGraph replays interleaved with
+    all_reduce(async_op=True, ReduceOp.AVG) of each group's slice on RCCL's own stream, wait(), optimizer graph -- with a one-rank
+    `nccl` group (all a one-GPU box can host) and the exchange forced on (TrainStep.force_comm).  The mean over one rank is the
+    identity, so twelve steps must leave the weights BIT-IDENTICAL to the same staged step without any communication: any missing
+    stream dependency between a replay and its all-reduce, or an all-reduce reading a slice a later replay is still writing, shows."""
+    from gaot_amd.trainer import TrainStep
+    port = _free_port()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    dev = torch.device("cuda:0")
+    lat, x, p, t = _data()
+    res = {}
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        for comm in (True, False):
+            model = _build(seed=5).to(dev).train()
+            ts = TrainStep(model, lr=2e-3, weight_decay=1e-4, use_graph=graph, staged=True)
+            assert ts.staged and len(ts.stage_groups) == 2
+            ts.force_comm, ts.comm_enabled = comm, comm
+            ts.bind(p.to(dev), t.to(dev), latent_tokens_coord=lat.to(dev), xcoord=x.to(dev))
+            losses = [float(ts.step()) for _ in range(12)]
+            torch.cuda.synchronize()
+            res[comm] = (_flat(model).cpu(), losses)
+    finally:
+        dist.destroy_process_group()
+    assert torch.equal(res[True][0], res[False][0]) and res[True][1] == res[False][1]
+    assert res[True][1][-1] < res[True][1][0]                    # and it trains
+
+
 def test_rccl_avg_all_reduce_on_flat_bucket_one_rank():
     """the `nccl` (= RCCL) branch of FlatGradBucket.all_reduce_mean: ReduceOp.AVG on the flat buffer and on a phase slice,
     synchronous and async_op, with a one-rank group (all this box can host)."""
