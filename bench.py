@@ -156,7 +156,9 @@ def gemm_roofline(ts):
         for name, fn in saved.items():
             setattr(lib, name, fn)
     gno_us = _gno_us(gno)
-    nprod = {3: 6.0, 2: 3.0, 1: 1.0}              # piece products per fp32-equivalent product
+    # piece products per fp32-equivalent product: three bf16 pieces -> 6; two bf16 pieces -> 3; the default "f32" precision on the split
+    # tiles = two fp16 pieces of the scaled operand -> 3 (ops._F16_PIECES; 6 with GAOT_F32_PIECES=bf16x3)
+    nprod = {3: 3.0 if ops._F16_PIECES[0] else 6.0, 2: 3.0, 1: 1.0}
     one_piece = os.environ.get("GAOT_BENCH_ONE_PIECE") == "1"          # the `bf16` variant (gaot_debug_set_gemm_pieces(1)): one product
     mfma = [r for r in records if r[4] == 3]      # launches served by the split-bf16 MFMA tile kernels (the bf16 matrix pipe)
     f32m = [r for r in records if r[4] == 1]      # fp32-MFMA tile launches (products too small / narrow for the split tiles)
@@ -661,7 +663,7 @@ def main():
         gno_total_b = sum(gno_bytes.values())
         hbm_achieved = gno_total_b / (gno_total_us * 1e-6) / 1e9 if gno_total_us > 0 else 0.0
         gno_traffic, gno_src = recorded_traffic("gno")
-        n_prod = {"f32": 6.0, "bf16x2": 3.0, "bf16": 1.0}[args.dtype]
+        n_prod = {"f32": 3.0 if _ops._F16_PIECES[0] else 6.0, "bf16x2": 3.0, "bf16": 1.0}[args.dtype]
         t_mfma_ideal = n_prod * 259.0e9 / (PEAK_BF16_MATRIX_TFLOPS * 1e12) * 1e3   # 259 GFLOP per B = 8 step, as piece products on the pipe in use
         t_hbm_ideal = (8 * (42 + 120) + 13) * 1e6 / (PEAK_HBM_GBPS * 1e9) * 1e3   # ~1.31 GB per step
         line = {
@@ -690,10 +692,10 @@ def main():
                        "h2d": "excluded: the timed region replays one batch bound in HBM ahead of time (TrainStep.bind); nothing is uploaded or "
                               "re-copied per step (the PCIe-inclusive drop-in rate is `reference_loop`)",
                        "hipgraph": ts.use_graph, "staged_backward_phases": ts.bucket.n_phases, "stage_groups": ts.stage_groups, "final_loss": loss},
-            "roofline": {"bound": "mfma", "pipe": "bf16 mfma (v_mfma_f32_32x32x16_bf16)",
+            "roofline": {"bound": "mfma", "pipe": "f16 / bf16 mfma (v_mfma_f32_32x32x16_f16 / _bf16: the same 2.5 PFLOP/s dense rate)",
                          "kernel": "every launch of one step on the bf16 matrix pipe behind gaot_gemm_f32: gemm_split_kernel (NT / NN tiles) and the grouped "
                                    "weight-gradient launch gemm_tn_grouped_kernel; each f32 operand as "
-                                   f"{ {'f32': 'three exact bf16 pieces, six piece products', 'bf16x2': 'two rounded bf16 pieces, three piece products', 'bf16': 'one bf16 piece, one product'}[args.dtype] }",
+                                   f"{ {'f32': 'two fp16 pieces of the power-of-two scaled operand (carried to fp32 rounding), three piece products on v_mfma_f32_32x32x16_f16' if _ops._F16_PIECES[0] else 'three exact bf16 pieces, six piece products', 'bf16x2': 'two rounded bf16 pieces, three piece products', 'bf16': 'one bf16 piece, one product'}[args.dtype] }",
                          "achieved": roof["piece_tflops"], "peak": PEAK_BF16_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": roof["piece_tflops"] / PEAK_BF16_MATRIX_TFLOPS,
                          "achieved_note": "piece-product FLOPs ISSUED on the matrix pipe (2MNK x piece products per product) / event-timed duration",

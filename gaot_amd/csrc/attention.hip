@@ -1422,7 +1422,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_split_kernel(const AttnArgs p
 // (120 KB of LDS, ~320 registers).  Same staging roles, same fixed-order dQ reduction over the wave partials.
 // ---------------------------------------------------------------------------------------------
 // PP / OP: pieces of P / dS and of the Q / K / V / dO operands, as in attn_bwd_split8_kernel (the dQ product stays on the fp32 MFMA)
-template <int DH, int PP = 3, int OP = 3>
+// F16 (with PP = OP = 2): fp16 pieces of the scaled operands, as attn_bwd_split8_kernel
+template <int DH, int PP = 3, int OP = 3, bool F16 = false>
 __global__ __launch_bounds__(256, 1) void attn_bwd_split_dh_kernel(const AttnArgs p) {
     constexpr int NU = DH / 16, NDT = DH / 32, CPR = DH / 4;
     constexpr int KROW = DH * 2 + 16, KPL = 32 * KROW;             // k-major planes [32 q][DH d]
@@ -1455,7 +1456,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_split_dh_kernel(const AttnArg
     const int b = bh / p.H, h = bh % p.H, hk = h / (p.H / p.Hkv);
     const int kv0 = kblk * 128 + wave * 32;
     const int D = p.D;
-    const float c = p.scale * LOG2E;
+    static_assert(!F16 || (PP == 2 && OP == 2), "fp16 pieces come in twos");
+    float sc_in = 1.f, so_in = 1.f, sc_g = 1.f, so_g = 1.f;
+    if (F16) { amax_scale(p.qkv_amax, sc_in, so_in); amax_scale(p.dout_amax, sc_g, so_g); }
+    const float c = p.scale * LOG2E * so_in * so_in;
+    const float dp_inv = so_g * so_in, dv_inv = F16 ? so_g * P_INV : 1.f;
     float* Kmine = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(Kw) + wave * KWB);
     unsigned char* Kpl = reinterpret_cast<unsigned char*>(Kmine);
     float* Smine = Sw + wave * SWF;
@@ -1475,10 +1480,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_split_dh_kernel(const AttnArg
             unsigned a_, b_, c_;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                split_op<OP>(a0[2 * e], a0[2 * e + 1], a_, b_, c_); ph[e] = a_; pm[e] = b_; pl[e] = c_;
-                split_op<OP>(a1[2 * e], a1[2 * e + 1], a_, b_, c_); ph[2 + e] = a_; pm[2 + e] = b_; pl[2 + e] = c_;
-                split_op<OP>(w0[2 * e], w0[2 * e + 1], a_, b_, c_); vh[e] = a_; vm[e] = b_; vl[e] = c_;
-                split_op<OP>(w1[2 * e], w1[2 * e + 1], a_, b_, c_); vh[2 + e] = a_; vm[2 + e] = b_; vl[2 + e] = c_;
+                split_op<OP, F16>(a0[2 * e], a0[2 * e + 1], a_, b_, c_, sc_in); ph[e] = a_; pm[e] = b_; pl[e] = c_;
+                split_op<OP, F16>(a1[2 * e], a1[2 * e + 1], a_, b_, c_, sc_in); ph[2 + e] = a_; pm[2 + e] = b_; pl[2 + e] = c_;
+                split_op<OP, F16>(w0[2 * e], w0[2 * e + 1], a_, b_, c_, sc_in); vh[e] = a_; vm[e] = b_; vl[e] = c_;
+                split_op<OP, F16>(w1[2 * e], w1[2 * e + 1], a_, b_, c_, sc_in); vh[2 + e] = a_; vm[2 + e] = b_; vl[2 + e] = c_;
             }
             kf[0][u] = __builtin_bit_cast(bf16x8, ph); kf[1][u] = __builtin_bit_cast(bf16x8, pm); kf[2][u] = __builtin_bit_cast(bf16x8, pl);
             vf[0][u] = __builtin_bit_cast(bf16x8, vh); vf[1][u] = __builtin_bit_cast(bf16x8, vm); vf[2][u] = __builtin_bit_cast(bf16x8, vl);
@@ -1489,8 +1494,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_split_dh_kernel(const AttnArg
             const f32x4 a = load4(p.k + ((long)b * p.S + min(kv0 + row, p.S - 1)) * p.ldk + (long)hk * D, d, D, kv0 + row < p.S, true);
             if (DQ16) {
                 unsigned h0, m0, h1, m1;
-                split2_pair(a[0], a[1], h0, m0);
-                split2_pair(a[2], a[3], h1, m1);
+                if (F16) { split2h_pair(a[0], a[1], sc_in, h0, m0); split2h_pair(a[2], a[3], sc_in, h1, m1); }
+                else { split2_pair(a[0], a[1], h0, m0); split2_pair(a[2], a[3], h1, m1); }
                 *reinterpret_cast<u32x2*>(Kpl + row * KPROW + d * 2) = u32x2{h0, h1};
                 *reinterpret_cast<u32x2*>(Kpl + KPPL + row * KPROW + d * 2) = u32x2{m0, m1};
             } else *reinterpret_cast<f32x4*>(Kmine + row * DH + d) = a;
@@ -1547,13 +1552,13 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_split_dh_kernel(const AttnArg
             for (int i = 0; i < NKI; ++i) {
                 const int idx = tid + 256 * i, row = idx / CPR, ch = idx % CPR;
                 u32x2 h2, m2, l2;
-                split_op<OP>(rq[i][0], rq[i][1], a_, b_, c_); h2[0] = a_; m2[0] = b_; l2[0] = c_;
-                split_op<OP>(rq[i][2], rq[i][3], a_, b_, c_); h2[1] = a_; m2[1] = b_; l2[1] = c_;
+                split_op<OP, F16>(rq[i][0], rq[i][1], a_, b_, c_, sc_in); h2[0] = a_; m2[0] = b_; l2[0] = c_;
+                split_op<OP, F16>(rq[i][2], rq[i][3], a_, b_, c_, sc_in); h2[1] = a_; m2[1] = b_; l2[1] = c_;
                 unsigned char* dq_ = Qk + row * KROW + ch * 8;
                 *reinterpret_cast<u32x2*>(dq_) = h2; *reinterpret_cast<u32x2*>(dq_ + KPL) = m2;
                 if (OP == 3) *reinterpret_cast<u32x2*>(dq_ + 2 * KPL) = l2;
-                split_op<OP>(rg[i][0], rg[i][1], a_, b_, c_); h2[0] = a_; m2[0] = b_; l2[0] = c_;
-                split_op<OP>(rg[i][2], rg[i][3], a_, b_, c_); h2[1] = a_; m2[1] = b_; l2[1] = c_;
+                split_op<OP, F16>(rg[i][0], rg[i][1], a_, b_, c_, sc_g); h2[0] = a_; m2[0] = b_; l2[0] = c_;
+                split_op<OP, F16>(rg[i][2], rg[i][3], a_, b_, c_, sc_g); h2[1] = a_; m2[1] = b_; l2[1] = c_;
                 unsigned char* dg_ = Gk + row * KROW + ch * 8;
                 *reinterpret_cast<u32x2*>(dg_) = h2; *reinterpret_cast<u32x2*>(dg_ + KPL) = m2;
                 if (OP == 3) *reinterpret_cast<u32x2*>(dg_ + 2 * KPL) = l2;
@@ -1562,12 +1567,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_split_dh_kernel(const AttnArg
             const int qp = tid / CPR, d0 = (tid % CPR) * 4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                split_op<OP>(rtq[0][e], rtq[1][e], a_, b_, c_);
+                split_op<OP, F16>(rtq[0][e], rtq[1][e], a_, b_, c_, sc_in);
                 unsigned char* dst = Qt + (d0 + e) * AB_TROW + qp * 4;
                 *reinterpret_cast<unsigned*>(dst) = a_;
                 *reinterpret_cast<unsigned*>(dst + TPL) = b_;
                 if (OP == 3) *reinterpret_cast<unsigned*>(dst + 2 * TPL) = c_;
-                split_op<OP>(rtg[0][e], rtg[1][e], a_, b_, c_);
+                split_op<OP, F16>(rtg[0][e], rtg[1][e], a_, b_, c_, sc_g);
                 dst = Gt + (d0 + e) * AB_TROW + qp * 4;
                 *reinterpret_cast<unsigned*>(dst) = a_;
                 *reinterpret_cast<unsigned*>(dst + TPL) = b_;
@@ -1590,19 +1595,19 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_split_dh_kernel(const AttnArg
             const bf16x8 g0_ = *reinterpret_cast<const bf16x8*>(gr), g1_ = *reinterpret_cast<const bf16x8*>(gr + KPL);
             if (OP == 3) {
                 const bf16x8 q2_ = *reinterpret_cast<const bf16x8*>(qr + 2 * KPL), g2_ = *reinterpret_cast<const bf16x8*>(gr + 2 * KPL);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q2_, kf[0][u], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g2_, vf[0][u], dp, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0_, kf[2][u], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0_, vf[2][u], dp, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q1_, kf[1][u], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1_, vf[1][u], dp, 0, 0, 0);
+                s = mfma16<F16>(q2_, kf[0][u], s);
+                dp = mfma16<F16>(g2_, vf[0][u], dp);
+                s = mfma16<F16>(q0_, kf[2][u], s);
+                dp = mfma16<F16>(g0_, vf[2][u], dp);
+                s = mfma16<F16>(q1_, kf[1][u], s);
+                dp = mfma16<F16>(g1_, vf[1][u], dp);
             }
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q1_, kf[0][u], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1_, vf[0][u], dp, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0_, kf[1][u], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0_, vf[1][u], dp, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0_, kf[0][u], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0_, vf[0][u], dp, 0, 0, 0);
+            s = mfma16<F16>(q1_, kf[0][u], s);
+            dp = mfma16<F16>(g1_, vf[0][u], dp);
+            s = mfma16<F16>(q0_, kf[1][u], s);
+            dp = mfma16<F16>(g0_, vf[1][u], dp);
+            s = mfma16<F16>(q0_, kf[0][u], s);
+            dp = mfma16<F16>(g0_, vf[0][u], dp);
         }
         // ---- P = exp(S*scale - lse), dS = P * (dP - delta)   (rows q = crow(r,lh), column kv = li)
 #pragma unroll
@@ -1611,8 +1616,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_split_dh_kernel(const AttnArg
             float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c, -lse_s[qr]));
             if (!kv_ok) pv = 0.f;
             s[r] = pv;
-            dp[r] = pv * (dp[r] - del_s[qr]);
+            dp[r] = F16 ? pv * fmaf(dp[r], dp_inv, -del_s[qr]) : pv * (dp[r] - del_s[qr]);
         }
+        float sc_ds = 1.f, ds_inv = 1.f;          // fp16 pieces: the tile's own power-of-two scale for dS (attn_bwd_split8_kernel)
+        if (F16) {
+            float mx = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(dp[r]));
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+            pow2_scale(mx, sc_ds, ds_inv);
+        }
+        const float dk_inv = ds_inv * so_in;
         // ---- dV^T[d][kv] += dO^T[d][q] P[q][kv] ; dK^T[d][kv] += Q^T[d][q] dS[q][kv]: the k-slots of step u are the lane's own
         // registers r = 8u .. 8u+7 (queries 16u + 4hi + {0..3, 8..11}); A from the transposed planes (two 8-byte reads each)
         // this q tile's dV^T / dK^T contributions start from zero on the matrix pipe and join the running sums on the vector pipe
@@ -1628,8 +1643,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_split_dh_kernel(const AttnArg
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 unsigned a_, b_, c_;
-                split_op<PP>(s[8 * u + 2 * e], s[8 * u + 2 * e + 1], a_, b_, c_); ph[e] = a_; pm[e] = b_; pl[e] = c_;
-                split_op<PP>(dp[8 * u + 2 * e], dp[8 * u + 2 * e + 1], a_, b_, c_); sh[e] = a_; sm[e] = b_; sl[e] = c_;
+                split_op<PP, F16>(s[8 * u + 2 * e], s[8 * u + 2 * e + 1], a_, b_, c_, P_SCALE); ph[e] = a_; pm[e] = b_; pl[e] = c_;
+                split_op<PP, F16>(dp[8 * u + 2 * e], dp[8 * u + 2 * e + 1], a_, b_, c_, sc_ds); sh[e] = a_; sm[e] = b_; sl[e] = c_;
             }
             const bf16x8 p0 = __builtin_bit_cast(bf16x8, ph), p1 = __builtin_bit_cast(bf16x8, pm), p2 = __builtin_bit_cast(bf16x8, pl);
             const bf16x8 d0 = __builtin_bit_cast(bf16x8, sh), d1 = __builtin_bit_cast(bf16x8, sm), d2 = __builtin_bit_cast(bf16x8, sl);
@@ -1646,29 +1661,32 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_split_dh_kernel(const AttnArg
                     qa[pl_] = __builtin_bit_cast(bf16x8, u32x4{q_lo[0], q_lo[1], q_hi[0], q_hi[1]});
                 }
                 if (OP == 3) {
-                    dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[2], p0, dvt[dt], 0, 0, 0);
-                    dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[2], d0, dkt[dt], 0, 0, 0);
+                    dvt[dt] = mfma16<F16>(ga[2], p0, dvt[dt]);
+                    dkt[dt] = mfma16<F16>(qa[2], d0, dkt[dt]);
                 }
                 if (PP == 3) {
-                    dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p2, dvt[dt], 0, 0, 0);
-                    dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d2, dkt[dt], 0, 0, 0);
+                    dvt[dt] = mfma16<F16>(ga[0], p2, dvt[dt]);
+                    dkt[dt] = mfma16<F16>(qa[0], d2, dkt[dt]);
                 }
                 if (OP == 3 || PP == 3) {
-                    dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1], p1, dvt[dt], 0, 0, 0);
-                    dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1], d1, dkt[dt], 0, 0, 0);
+                    dvt[dt] = mfma16<F16>(ga[1], p1, dvt[dt]);
+                    dkt[dt] = mfma16<F16>(qa[1], d1, dkt[dt]);
                 }
-                dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1], p0, dvt[dt], 0, 0, 0);
-                dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1], d0, dkt[dt], 0, 0, 0);
-                dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p1, dvt[dt], 0, 0, 0);
-                dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d1, dkt[dt], 0, 0, 0);
-                dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], p0, dvt[dt], 0, 0, 0);
-                dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], d0, dkt[dt], 0, 0, 0);
+                dvt[dt] = mfma16<F16>(ga[1], p0, dvt[dt]);
+                dkt[dt] = mfma16<F16>(qa[1], d0, dkt[dt]);
+                dvt[dt] = mfma16<F16>(ga[0], p1, dvt[dt]);
+                dkt[dt] = mfma16<F16>(qa[0], d1, dkt[dt]);
+                dvt[dt] = mfma16<F16>(ga[0], p0, dvt[dt]);
+                dkt[dt] = mfma16<F16>(qa[0], d0, dkt[dt]);
             }
         }
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { dvacc[dt][r] += dvt[dt][r]; dkacc[dt][r] += dkt[dt][r]; }
+            for (int r = 0; r < 16; ++r) {
+                dvacc[dt][r] = F16 ? fmaf(dvt[dt][r], dv_inv, dvacc[dt][r]) : dvacc[dt][r] + dvt[dt][r];
+                dkacc[dt][r] = F16 ? fmaf(dkt[dt][r], dk_inv, dkacc[dt][r]) : dkacc[dt][r] + dkt[dt][r];
+            }
         // ---- dQ[q][d] partial = sum_kv dS[q][kv] K[kv][d]: dS through wave-private LDS to flip lanes
         f32x16 dq[NDT];
 #pragma unroll
@@ -1683,7 +1701,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_split_dh_kernel(const AttnArg
             for (int u = 0; u < 2; ++u) {
                 unsigned h_[4], m_[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) split2_pair(dp[8 * u + 2 * e], dp[8 * u + 2 * e + 1], h_[e], m_[e]);
+                for (int e = 0; e < 4; ++e) {
+                    if (F16) split2h_pair(dp[8 * u + 2 * e], dp[8 * u + 2 * e + 1], sc_ds, h_[e], m_[e]);
+                    else split2_pair(dp[8 * u + 2 * e], dp[8 * u + 2 * e + 1], h_[e], m_[e]);
+                }
                 unsigned char* dst = dSp + li * AB_KROW + (16 * u + 4 * lh) * 2;
                 *reinterpret_cast<u32x2*>(dst) = u32x2{h_[0], h_[1]};
                 *reinterpret_cast<u32x2*>(dst + 16) = u32x2{h_[2], h_[3]};
@@ -1707,9 +1728,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_split_dh_kernel(const AttnArg
                     for (int pl_ = 0; pl_ < 2; ++pl_)
                         kb[pl_] = __builtin_bit_cast(bf16x8, join8(lds_tr(Kpl + pl_ * KPPL + (16 * u) * KPROW + 32 * dt * 2 + tr_k),
                                                                    lds_tr(Kpl + pl_ * KPPL + (16 * u + 8) * KPROW + 32 * dt * 2 + tr_k)));
-                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[1], kb[0], dq[dt], 0, 0, 0);
-                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[0], kb[1], dq[dt], 0, 0, 0);
-                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[0], kb[0], dq[dt], 0, 0, 0);
+                    dq[dt] = mfma16<F16>(da[1], kb[0], dq[dt]);
+                    dq[dt] = mfma16<F16>(da[0], kb[1], dq[dt]);
+                    dq[dt] = mfma16<F16>(da[0], kb[0], dq[dt]);
                 }
             }
         } else {
@@ -1733,7 +1754,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_split_dh_kernel(const AttnArg
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) Pmine[crow(r, lh) * DH + 32 * dt + li] = dq[dt][r];
+            for (int r = 0; r < 16; ++r) Pmine[crow(r, lh) * DH + 32 * dt + li] = F16 ? dq[dt][r] * dk_inv : dq[dt][r];
         __syncthreads();                                    // barrier B
         for (int t = tid; t < 32 * DH; t += 256) {
             const int row = t / DH;
@@ -1864,13 +1885,17 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
     const bool tthread = t8 < 128;
     const float* sbase = kind == 0 ? qbase : gbase;
     const long sld = kind == 0 ? p.ldq : p.ldo;
-    f32x4 rk1, rt[2];
+    f32x4 rk1, rt[2], ro = {0.f, 0.f, 0.f, 0.f};
     float rl = 0.f, rd = 0.f;
+    // F16: delta[q] = sum_d dO[q][d] O[q][d] is formed HERE from the dO tile the kind-1 threads stage anyway (+ the matching O chunk): no
+    // separate delta launch, no delta array
+    const float* obase = p.oin + (long)b * p.S * p.ldo + (long)h * 32;
     auto fetch = [&](int q0) {
         {
             const int row = t8 >> 3, d = (tid & 7) * 4;
             rk1 = *reinterpret_cast<const f32x4*>(sbase + (long)min(q0 + row, p.S - 1) * sld + d);
             if (q0 + row >= p.S) rk1 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (F16 && kind == 1) ro = *reinterpret_cast<const f32x4*>(obase + (long)min(q0 + row, p.S - 1) * p.ldo + d);
         }
         if (!TR && tthread) {
 #pragma unroll
@@ -1883,7 +1908,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
         if (tid < 32) {
             const bool ok = q0 + tid < p.S;
             rl = ok ? lse_b[q0 + tid] * LOG2E : INFINITY;
-            rd = ok ? del_b[q0 + tid] : 0.f;
+            rd = (ok && !F16) ? del_b[q0 + tid] : 0.f;
         }
     };
     const int nq = (p.S + 31) / 32;
@@ -1916,7 +1941,12 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
                 }
             }
         }
-        if (tid < 32) { lse_s[tid] = rl; del_s[tid] = rd; }
+        if (tid < 32) { lse_s[tid] = rl; if (!F16) del_s[tid] = rd; }
+        if (F16 && kind == 1) {          // rows of the dO tile: eight consecutive lanes hold one row's 32 d
+            float dsum = (rk1[0] * ro[0] + rk1[1] * ro[1]) + (rk1[2] * ro[2] + rk1[3] * ro[3]);
+            dsum += __shfl_xor(dsum, 1, 64); dsum += __shfl_xor(dsum, 2, 64); dsum += __shfl_xor(dsum, 4, 64);
+            if ((tid & 7) == 0) del_s[t8 >> 3] = dsum;
+        }
         __syncthreads();                                    // barrier A
         if (qt + 1 < nq) fetch(q0 + 32);
 
@@ -2452,7 +2482,10 @@ extern "C" int gaot_attention_fwd(const float* q, const float* k, const float* v
     }
     else if (head_dim > 32 && head_dim <= 64 && a.vec && g_attn_split) {      // (a.vec: head_dim % 4 == 0): split-bf16 with four d steps
         const bool two64 = g_attn_pp / 10 == 2 && g_attn_op == 2;             // two rounded pieces of everything, or exact splits
-        if (g_attn_split != 3 && (g_attn_split == 2 || (long)cdiv(S, 256) * B * H >= 256))
+        if (f16 && g_attn_split != 3 && (g_attn_split == 2 || (long)cdiv(S, 256) * B * H >= 256))
+            hipLaunchKernelGGL((attn_fwd_split_kernel<8, 64, 2, 2, true>), dim3(cdiv(S, 256) * B * H), dim3(512), 0, ST(stream), a);
+        else if (f16) hipLaunchKernelGGL((attn_fwd_split_kernel<4, 64, 2, 2, true>), grid, block, 0, ST(stream), a);
+        else if (g_attn_split != 3 && (g_attn_split == 2 || (long)cdiv(S, 256) * B * H >= 256))
             { if (two64) hipLaunchKernelGGL((attn_fwd_split_kernel<8, 64, 2, 2>), dim3(cdiv(S, 256) * B * H), dim3(512), 0, ST(stream), a);
               else hipLaunchKernelGGL((attn_fwd_split_kernel<8, 64>), dim3(cdiv(S, 256) * B * H), dim3(512), 0, ST(stream), a); }
         else if (two64) hipLaunchKernelGGL((attn_fwd_split_kernel<4, 64, 2, 2>), grid, block, 0, ST(stream), a);
@@ -2578,17 +2611,19 @@ extern "C" int gaot_attention_bwd(const float* q, const float* k, const float* v
     a.qkv_amax = qkv_absmax; a.dout_amax = dout_absmax; a.dqkv_amax = dqkv_absmax;
     bool dkdv_published = false;
     const int DP = head_dim <= 32 ? 32 : (head_dim <= 64 ? 64 : 128);
-    if (a.vec && aligned16(o)) {
+    const bool split_ok = head_dim == 32 && a.vec && g_attn_split && aligned16(dq) && aligned16(dk) && aligned16(dv);
+    const bool fused_delta = f16 && split_ok && aligned16(o) && g_attn_split != 3 && (g_attn_split == 2 || (long)cdiv(S, 256) * B * H >= 256);   // the fp16 8-wave kernel forms delta itself
+    if (fused_delta) {
+    } else if (a.vec && aligned16(o)) {
         const int lpr = 8;
         hipLaunchKernelGGL(attn_delta_vec_kernel, dim3(cdiv((long)B * S * H * lpr, 256)), dim3(256), 0, ST(stream), a, lpr);
     } else {
         hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv((long)B * S * H, 256)), dim3(256), 0, ST(stream), a);
     }
     dim3 grid(a.n_kblocks * B * H), block(256);
-    const bool split_ok = head_dim == 32 && a.vec && g_attn_split && aligned16(dq) && aligned16(dk) && aligned16(dv);
     if (split_ok && g_attn_split != 3 && (g_attn_split == 2 || (long)cdiv(S, 256) * B * H >= 256)) {
         a.n_kblocks = cdiv(S, 256);          // 256 keys per workgroup: half the dQ slabs (the workspace is sized for 128)
-        if (f16) { hipLaunchKernelGGL((attn_bwd_split8_kernel<2, 2, true, true>), dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a); dkdv_published = true; }
+        if (f16 && fused_delta) { hipLaunchKernelGGL((attn_bwd_split8_kernel<2, 2, true, true>), dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a); dkdv_published = true; }
         else if (g_attn_pp % 10 == 3) hipLaunchKernelGGL(attn_bwd_split8_kernel<3>, dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a);
         else if (g_attn_op == 3) hipLaunchKernelGGL(attn_bwd_split8_kernel<2>, dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a);
         else if (g_attn_tr) hipLaunchKernelGGL((attn_bwd_split8_kernel<2, 2, true>), dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a);
@@ -2600,6 +2635,7 @@ extern "C" int gaot_attention_bwd(const float* q, const float* k, const float* v
             a.n_kblocks = cdiv(S, 256);          // 256 keys per workgroup: half the dQ slabs (the workspace is sized for 128)
             hipLaunchKernelGGL(attn_bwd_split8_dh_kernel, dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a);
         }
+        else if (f16) hipLaunchKernelGGL((attn_bwd_split_dh_kernel<64, 2, 2, true>), grid, block, 0, ST(stream), a);
         else if (g_attn_pp % 10 == 2 && g_attn_op == 2) hipLaunchKernelGGL((attn_bwd_split_dh_kernel<64, 2, 2>), grid, block, 0, ST(stream), a);
         else hipLaunchKernelGGL((attn_bwd_split_dh_kernel<64>), grid, block, 0, ST(stream), a);
     } else if (DP == 32) {

@@ -1941,7 +1941,7 @@ class _Attention(torch.autograd.Function):
             _LAST_DROPOUT_SEED[0] = seed
         else:
             pc, qw = _PIECES["attn"], None
-            if pc == 3 and _F16_PIECES[0] and D == 32:       # fp16 pieces: the operands' magnitude word (published by the projection's epilogue)
+            if pc == 3 and _F16_PIECES[0] and 32 <= D <= 64 and D % 4 == 0:       # fp16 pieces: the operands' magnitude word (published by the projection's epilogue)
                 qw = amax_for(qkv.view(B * S, W), qkv, qkv_in)
                 pc = 4
             L.check(lib.gaot_attention_fwd(_p(q), _p(kq), _p(vq), W, W, W, B, S, H, Hkv, D, _p(o), H * D, _p(lse), pc, _p(qw), _stream()),
@@ -1979,7 +1979,7 @@ class _Attention(torch.autograd.Function):
                                                    p_drop, _p(seed), _stream()), "gaot_attention_bwd_dropout")
         else:
             pc, qw, gw = _PIECES["attn"], ctx.qkv_amax, None
-            if pc == 3 and _F16_PIECES[0] and D == 32:
+            if pc == 3 and _F16_PIECES[0] and 32 <= D <= 64 and D % 4 == 0:
                 if qw is None:
                     qw = amax_for(qkv.view(B * S, W), qkv)
                 gw = amax_for(do.view(B * S, H * D), do, do_in)

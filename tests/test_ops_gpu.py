@@ -752,7 +752,7 @@ def test_gemm_two_piece_products(M, N, K, bf16x2):
 
 @pytest.mark.gpu
 def test_attention_fp16_piece_products():
-    """the default head_dim-32 attention (`pieces` = 4): Q / K / V as two fp16 pieces scaled through ONE magnitude word, dO through its
+    """the default attention for head_dim 32..64 (`pieces` = 4): Q / K / V as two fp16 pieces scaled through ONE magnitude word, dO through its
     own, P by 2^13, dS per 32 x 32 tile by the tile's own maximum; three piece products per k-step on the f16 MFMA.
       * random normal data at the bench shape (8-wave kernels) and at a small one (4-wave forward): output and gradients as close to
         float64 as the three-piece bf16 kernels (within 1.5x run to run; < 6e-7 / 1.2e-6);
@@ -782,7 +782,7 @@ def test_attention_fp16_piece_products():
         return (rel(outs[0][0], ref), rel(outs[0][1], r.grad)), (rel(outs[2][0], ref), rel(outs[2][1], r.grad))
 
     g = torch.Generator().manual_seed(11)
-    for (B, S, H, D) in ((8, 1024, 8, 32), (2, 333, 4, 32)):
+    for (B, S, H, D) in ((8, 1024, 8, 32), (2, 333, 4, 32), (1, 1024, 8, 48), (2, 333, 4, 36), (4, 2048, 8, 64)):      # head_dim 33..64: the DH = 64 kernels
         qkv, go = torch.randn(B, S, 3 * H * D, generator=g), torch.randn(B, S, H * D, generator=g)
         base = None
         for sq, sg in ((1.0, 1.0), (1e-3, 1e-9), (3.0, 1e6)):
