@@ -9,9 +9,12 @@ when N > 1) on BASELINE config 2: 2-D mesh with 16 384 nodes, batch 8 PER GPU (w
 example model (config/examples/time_indep/poisson_gauss.json: latent 64x64, C=64, patch 2, transformer 256 x 3
 blocks, 8 heads; 3 396 033 parameters), synthetic data, random-init weights, inputs resident in HBM.
 The HEADLINE (`value`, `ms_per_step`, `dtype: "f32"`) is fp32-equivalent arithmetic end to end, like the reference (no autocast
-anywhere, base_trainer.py:63-68): every product on the bf16 matrix pipe takes each fp32 operand as THREE bf16 pieces (six piece
-products, exact to fp32 rounding), storage and accumulation are fp32.  Narrower arithmetic is reported as labelled `variants`
-(bf16x2: two rounded bf16 pieces per operand; bf16: one piece in the tile GEMMs), each with its own error against the float64 oracle.
+anywhere, base_trainer.py:63-68): storage and accumulation are fp32, and every product on the matrix pipe carries each fp32 operand
+to fp32 rounding -- as TWO fp16 pieces of the operand scaled by a power of two read from a device-resident magnitude word (24
+significant bits: |s x - h - m| <= 2^-24 |s x|; three piece products), or, where no word is available, as THREE bf16 pieces (six
+piece products).  Its error against the float64 oracle is in `rel_l2_vs_oracle.vs_float64_oracle` next to the fp32 reference's own.
+Other arithmetic is reported as labelled `variants` (bf16x3: the three-piece products everywhere, equally fp32-level; bf16x2: two
+rounded bf16 pieces, 16 bits; bf16: one piece in the tile GEMMs), each with its own error against the float64 oracle.
 
 Extra objects on the JSON line:
   roofline     dominant kernel family = the split-bf16 MFMA GEMM kernels behind gaot_gemm_f32 and the grouped weight-gradient
@@ -313,7 +316,8 @@ def reference_loop_rate(dev, steps: int = 30, warmup: int = 8):
 
 
 def variant_rate(dev, name: str, ref64, steps: int = 40, warmup: int = 8):
-    """The SAME TrainStep at NARROWER arithmetic than the headline -- a labelled variant, never `value`:
+    """The SAME TrainStep in another arithmetic -- a labelled variant, never `value`:
+      bf16x3: fp32-level like the headline, by three bf16 pieces per operand and six piece products instead of two fp16 pieces and three
       bf16x2: every product on the bf16 matrix pipe takes each fp32 operand as TWO rounded bf16 pieces (16 significant bits; GEMM tiles,
               grouped weight gradients, attention, the GELU kernel MLP); storage / accumulation fp32
       bf16:   BASELINE configs[1]'s "bf16": tile-GEMM operands rounded to ONE bf16 piece, fp32 accumulation; everything else as the headline
@@ -323,6 +327,7 @@ def variant_rate(dev, name: str, ref64, steps: int = 40, warmup: int = 8):
     lib = _lib.load()
     old = ops.set_precision("bf16x2") if name == "bf16x2" else dict(ops._PIECES)
     old1 = lib.gaot_debug_set_gemm_pieces(1) if name == "bf16" else None
+    old3 = ops.set_f32_pieces("bf16x3") if name == "bf16x3" else None
     try:
         ops.register_grad_slots([], [])
         torch.manual_seed(0)
@@ -344,7 +349,11 @@ def variant_rate(dev, name: str, ref64, steps: int = 40, warmup: int = 8):
         ops.set_gemm_pieces(**old)
         if old1 is not None:
             lib.gaot_debug_set_gemm_pieces(old1)
-    dtype = {"bf16x2": "bf16x2 products (two rounded bf16 pieces per f32 operand), f32 accumulate and storage",
+        if old3 is not None:
+            ops.set_f32_pieces(old3)
+    dtype = {"bf16x3": "f32 through THREE bf16 pieces per operand, six piece products (rounds 1-3's exact mode; GAOT_F32_PIECES=bf16x3): the same "
+                       "fp32-level arithmetic as the headline by other means, for comparison of speed and of error",
+             "bf16x2": "bf16x2 products (two rounded bf16 pieces per f32 operand), f32 accumulate and storage",
              "bf16": "bf16 tile-GEMM operands (one piece, RNE), f32 accumulate and storage; attention / kernel MLP / transforms as the headline"}[name]
     return {"value": BATCH * steps / dt, "unit": "samples/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "dtype": dtype,
             "rel_l2_vs_oracle": err}
@@ -681,9 +690,15 @@ def main():
                       "bf16": "bf16 tile-GEMM operands (one piece), f32 accumulate -- NOT the parity headline"}[args.dtype],
             "precision": {"storage_and_accumulation": "f32 everywhere (weights, activations, gradients, optimizer state, every accumulator)",
                           "pieces": dict(_ops._PIECES), "mode": _ops.precision() if args.dtype != "bf16" else "bf16 (one piece in the tile GEMMs)",
-                          "what": "products on the bf16 matrix pipe take each f32 operand as N bf16 pieces: 3 (default, the headline) = exact to f32 "
-                                  "rounding, six piece products -- the fp32 arithmetic of the reference (base_trainer.py:63-68); 2 = two pieces both rounded "
-                                  "to nearest, 16 significant bits (three piece products): reported under `variants.bf16x2`, never as `value`"},
+                          "f32_pieces": "fp16x2" if _ops._F16_PIECES[0] else "bf16x3",
+                          "what": "`pieces` 3 = the f32 precision (the headline): every operand of a matrix-pipe product is carried to fp32 rounding -- "
+                                  "f32_pieces fp16x2: as two fp16 pieces h + m of the operand scaled by a power of two from its device-resident magnitude "
+                                  "word (|s x - h - m| <= 2^-24 |s x|: 24 significant bits; three piece products h h + h m + m h) in the GEMM tiles, the "
+                                  "grouped weight gradients and the attention for head_dim <= 64; as three bf16 pieces (8 + 8 + 8 bits exactly, six piece "
+                                  "products) in the kernel MLP, wherever a product has no magnitude word, and everywhere with GAOT_F32_PIECES=bf16x3 "
+                                  "(`variants.bf16x3`).  Measured against float64 the fp16x2 products are at or below the bf16x3 ones (tests/test_ops_gpu.py "
+                                  "test_gemm_fp16_piece_products, test_attention_fp16_piece_products; `rel_l2_vs_oracle.vs_float64_oracle` here).  `pieces` 2 = two "
+                                  "rounded bf16 pieces, 16 significant bits: `variants.bf16x2`, never `value`"},
             "data": "synthetic (uniform-random 16384-point 2-D mesh in [-1,1]^2, N(0,1) fields, random-init weights)",
             "config": {"workload": "BASELINE configs[1]: Poisson-Gauss-shaped 2D, 16384 nodes/mesh, batch 8 per GPU, fx mode; "
                                    "example model latent 64x64, C=64, patch 2, transformer 256x3, 8 heads",
@@ -745,7 +760,7 @@ def main():
             line["cpu_baseline"], line["rel_l2_vs_oracle"], ref64 = cpu_baseline(sd0, (lat, x, p, t), hip0)
         if world == 1 and not args.no_variants and args.dtype == "f32":
             # narrower arithmetic than the reference's fp32: labelled variants next to the headline, each with its own error vs float64
-            line["variants"] = {nm: variant_rate(dev, nm, ref64) for nm in ("bf16x2", "bf16")}
+            line["variants"] = {nm: variant_rate(dev, nm, ref64) for nm in ("bf16x3", "bf16x2", "bf16")}
             for v in line["variants"].values():
                 v["speedup_vs_headline"] = v["value"] / line["value"]
         print(json.dumps(line), flush=True)

@@ -347,7 +347,7 @@ extern "C" int gaot_debug_set_gemm_glds(int on) {
 static int g_split_pieces = 3, g_split_pieces_forced = 0;
 extern "C" int gaot_debug_set_gemm_pieces(int n) {
     const int old = g_split_pieces_forced ? g_split_pieces : 0;
-    g_split_pieces_forced = (n >= 1 && n <= 5); g_split_pieces = g_split_pieces_forced ? n : 3;
+    g_split_pieces_forced = (n >= 1 && n <= 3); g_split_pieces = g_split_pieces_forced ? n : 3;
     return old;
 }
 int gaot_forced_pieces() { return g_split_pieces_forced ? g_split_pieces : 0; }

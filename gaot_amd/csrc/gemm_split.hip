@@ -29,8 +29,9 @@ __device__ __forceinline__ unsigned rne_pair(float x0, float x1) {
     u1 += 0x7fffu + ((u1 >> 16) & 1u);
     return __builtin_amdgcn_perm(u1, u0, 0x07060302u);
 }
-// NP = 4 / 5: two fp16 pieces of sc * x (sc a power of two that brings the operand's largest magnitude to ~2^14, see split2h_pair):
-// three (4) or four (5) piece products on v_mfma_f32_32x32x16_f16
+// NP = 4: two fp16 pieces of sc * x (sc a power of two that brings the operand's largest magnitude to ~2^14, see split2h_pair): three
+// piece products h h + h m + m h on v_mfma_f32_32x32x16_f16 (the fourth, m m <= 2^-22 of the term, was measured: 1.87e-7 instead of
+// 1.90e-7 against float64 on random data -- the fp32 accumulation dominates -- at +7 % time: not taken)
 template <int NP, int ABL>
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& ph, unsigned& pm, unsigned& pl, float sc = 1.f) {
     if (NP == 1) { ph = rne_pair(x0, x1); pm = pl = 0u; }
@@ -254,7 +255,6 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    if (NP == 5) acc[i][j] = mfma<ABL, F16>(a[i][1], b[j][1], acc[i][j]);
                     acc[i][j] = mfma<ABL, F16>(a[i][1], b[j][0], acc[i][j]);
                     acc[i][j] = mfma<ABL, F16>(a[i][0], b[j][1], acc[i][j]);
                     acc[i][j] = mfma<ABL, F16>(a[i][0], b[j][0], acc[i][j]);
@@ -287,7 +287,7 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
         // interleave: one MFMA, a few VALU ops of the split, now and then one of its LDS writes
         __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);       // the prefetch loads go first: a whole k-tile to land
 #pragma unroll
-        for (int g = 0; g < TM * TN * (NP == 3 ? 6 : NP == 5 ? 4 : (NP == 2 || NP == 4) ? 3 : 1); ++g) {
+        for (int g = 0; g < TM * TN * (NP == 3 ? 6 : (NP == 2 || NP == 4) ? 3 : 1); ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
@@ -397,7 +397,7 @@ struct TnGroupArgs { int n; float* ws; int* counters; TnProb p[TNG_MAX]; };
 // 304, without LDS plane writes 282, without the barrier 351 -- every part costs 20-100 us and the parts ADD UP (the k-loop's
 // load -> split -> plane write -> barrier -> fragment read -> MFMA chain is not overlapped across the two resident workgroups of a CU).
 template <int ABL = 0, int NP = 3>
-__global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const TnGroupArgs g) {
+__global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const TnGroupArgs g) {      // (three per CU: 168 registers, 94 spilled)
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SplitGeom<128, NP>::SMEM_BYTES];
     // XCD-aware order (workgroup b runs on XCD b % 8): every XCD takes a CONTIGUOUS range of the logical work list, and inside
     // a product the list runs K slab by K slab, tile row by tile row -- so the workgroups an XCD's L2 serves at the same time
@@ -515,7 +515,6 @@ void launch_tn_grouped(const gaot_wgrad_item* items, int n, float* ws, int* coun
     int wg = 0;
     plan_tn_grouped(items, n, &args, nullptr, &wg);
     if (pieces == 4) hipLaunchKernelGGL((gemm_tn_grouped_kernel<0, 4>), dim3(wg), dim3(256), 0, st, args);
-    else if (pieces == 5) hipLaunchKernelGGL((gemm_tn_grouped_kernel<0, 5>), dim3(wg), dim3(256), 0, st, args);
     else if (pieces == 2) hipLaunchKernelGGL((gemm_tn_grouped_kernel<0, 2>), dim3(wg), dim3(256), 0, st, args);
     else hipLaunchKernelGGL((gemm_tn_grouped_kernel<0, 3>), dim3(wg), dim3(256), 0, st, args);
 }
@@ -539,9 +538,8 @@ void launch_split(GemmArgs& a, bool ak, bool bk, hipStream_t st, int bm, int pie
         if (bm == 64) launch_split_bm<64, 1>(a, ak, bk, st); else launch_split_bm<128, 1>(a, ak, bk, st);
         return;
     }
-    if (pieces == 4 || pieces == 5) {      // two fp16 pieces per operand (three / four piece products on the f16 MFMA)
-        if (pieces == 4) { if (bm == 64) launch_split_bm<64, 4>(a, ak, bk, st); else if (bm == 256) launch_split_bm<256, 4>(a, ak, bk, st); else launch_split_bm<128, 4>(a, ak, bk, st); }
-        else { if (bm == 64) launch_split_bm<64, 5>(a, ak, bk, st); else if (bm == 256) launch_split_bm<256, 5>(a, ak, bk, st); else launch_split_bm<128, 5>(a, ak, bk, st); }
+    if (pieces == 4) {           // two fp16 pieces per scaled operand (three piece products on the f16 MFMA)
+        if (bm == 64) launch_split_bm<64, 4>(a, ak, bk, st); else if (bm == 256) launch_split_bm<256, 4>(a, ak, bk, st); else launch_split_bm<128, 4>(a, ak, bk, st);
         return;
     }
     if (pieces == 2) {           // two rounded pieces per operand (three piece products)
