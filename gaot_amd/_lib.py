@@ -89,6 +89,7 @@ PROTOTYPES = {
     "gaot_rmsnorm_bwd": (C.c_int, [_f, _f, _f, _f, _f, _f, C.c_int32, C.c_int32, _f, _f, _f, _s]),
     "gaot_swiglu_fwd": (C.c_int, [_f, C.c_int32, C.c_int32, _f, _s]),
     "gaot_swiglu_bwd": (C.c_int, [_f, _f, C.c_int32, C.c_int32, _f, _s]),
+    "gaot_act_bwd": (C.c_int, [_f, _f, C.c_int64, C.c_int32, _f, _s]),
     "gaot_attention_fwd": (C.c_int, [_f, _f, _f, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_int32, _f, C.c_int64, _f, C.c_int32, _f, _s]),
     "gaot_attention_bwd_workspace": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

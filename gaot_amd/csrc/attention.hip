@@ -2532,14 +2532,15 @@ extern "C" int gaot_attention_fwd_dropout(const float* q, const float* k, const 
                                           float* lse, float p_drop, const uint64_t* seed, gaot_stream_t stream) {
     GAOT_REQUIRE(q && k && v && o && lse, "attention_fwd_dropout: null pointer");
     GAOT_REQUIRE(B > 0 && S > 0 && H > 0 && Hkv > 0 && H % Hkv == 0, "attention_fwd_dropout: bad sizes B=%d S=%d H=%d Hkv=%d", B, S, H, Hkv);
-    GAOT_REQUIRE(head_dim > 0 && head_dim <= 64, "attention_fwd_dropout: head_dim %d not in 1..64", head_dim);
+    GAOT_REQUIRE(head_dim > 0 && head_dim <= 128, "attention_fwd_dropout: head_dim %d not in 1..128", head_dim);
     AttnArgs a = {};
     fill_common(a, q, k, v, ldq, ldk, ldv, B, S, H, Hkv, head_dim);
     a.o = o; a.ldo = ldo; a.lse = lse;
     if (int rc = fill_dropout(a, p_drop, seed)) return rc;
     dim3 grid(cdiv(S, 128) * B * H), block(256);
-    if (head_dim <= 32) hipLaunchKernelGGL((attn_fwd_kernel<32, true>), grid, block, 0, ST(stream), a);
-    else                hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, block, 0, ST(stream), a);
+    if (head_dim <= 32)      hipLaunchKernelGGL((attn_fwd_kernel<32, true>), grid, block, 0, ST(stream), a);
+    else if (head_dim <= 64) hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, block, 0, ST(stream), a);
+    else                     hipLaunchKernelGGL((attn_fwd_kernel<128, true>), grid, block, 0, ST(stream), a);
     GAOT_CHECK_LAUNCH("gaot_attention_fwd_dropout");
     return GAOT_OK;
 }
@@ -2551,7 +2552,7 @@ extern "C" int gaot_attention_bwd_dropout(const float* q, const float* k, const 
                                           gaot_stream_t stream) {
     GAOT_REQUIRE(q && k && v && o && dout && lse && dq && dk && dv && workspace, "attention_bwd_dropout: null pointer");
     GAOT_REQUIRE(B > 0 && S > 0 && H > 0 && Hkv > 0 && H % Hkv == 0, "attention_bwd_dropout: bad sizes");
-    GAOT_REQUIRE(head_dim > 0 && head_dim <= 64, "attention_bwd_dropout: head_dim %d not in 1..64", head_dim);
+    GAOT_REQUIRE(head_dim > 0 && head_dim <= 128, "attention_bwd_dropout: head_dim %d not in 1..128", head_dim);
     AttnArgs a = {};
     fill_common(a, q, k, v, ldq, ldk, ldv, B, S, H, Hkv, head_dim);
     a.vec = a.vec && (ldo % 4 == 0) && aligned16(dout);
@@ -2561,11 +2562,19 @@ extern "C" int gaot_attention_bwd_dropout(const float* q, const float* k, const 
     a.dq_part = workspace + (int64_t)B * H * S;
     a.n_kblocks = cdiv(S, 128);
     if (int rc = fill_dropout(a, p_drop, seed)) return rc;
-    const int DP = head_dim <= 32 ? 32 : 64;
+    const int DP = head_dim <= 32 ? 32 : (head_dim <= 64 ? 64 : 128);
     hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv((long)B * S * H, 256)), dim3(256), 0, ST(stream), a);
     dim3 grid(a.n_kblocks * B * H), block(256);
     if (DP == 32) {
         hipLaunchKernelGGL((attn_bwd_kernel<32, true>), grid, block, bwd_lds_bytes<32>(), ST(stream), a);
+    } else if (DP == 128) {
+        static bool attr_set128 = false;
+        if (!attr_set128) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)bwd_lds_bytes<128>());
+            attr_set128 = true;
+        }
+        hipLaunchKernelGGL((attn_bwd_kernel<128, true>), grid, block, bwd_lds_bytes<128>(), ST(stream), a);
     } else {
         static bool attr_set = false;
         if (!attr_set) {

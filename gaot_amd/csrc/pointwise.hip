@@ -482,6 +482,19 @@ extern "C" int gaot_swiglu_fwd(const float* u, int32_t M, int32_t F, float* g, g
     return GAOT_OK;
 }
 
+// out[i] = g[i] * act'(z[i]): the derivative of a chain's LAST activation (no following product to fuse it into)
+__global__ void act_bwd_kernel(const float* __restrict__ g, const float* __restrict__ z, long n, int act, float* __restrict__ out) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float zv = z[i];
+        out[i] = act == GAOT_ACT_GELU ? g[i] * gelu_grad_f(zv) : (zv > 0.f ? g[i] : 0.f);
+    }
+}
+extern "C" int gaot_act_bwd(const float* g, const float* z, int64_t n, int32_t act, float* out, gaot_stream_t stream) {
+    GAOT_REQUIRE(g && z && out && n > 0 && (act == GAOT_ACT_GELU || act == GAOT_ACT_RELU), "act_bwd: bad arguments");
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(cap_blocks(n, 256, 4096)), dim3(256), 0, ST(stream), g, z, (long)n, act, out);
+    GAOT_CHECK_LAUNCH("gaot_act_bwd");
+    return GAOT_OK;
+}
 extern "C" int gaot_swiglu_bwd(const float* u, const float* dg, int32_t M, int32_t F, float* du, gaot_stream_t stream) {
     GAOT_REQUIRE(u && dg && du && M > 0 && F > 0 && F % 4 == 0 && aligned16(u) && aligned16(dg) && aligned16(du),
                  "swiglu_bwd: bad arguments (F %% 4 == 0, 16B aligned)");

@@ -102,8 +102,6 @@ class GroupQueryFlashAttention(nn.Module):
             self.rotary_emb = RotaryEmbedding(dim=self.head_dim)
         if self.head_dim > 128:
             raise NotImplementedError("the attention kernels support head_dim <= 128")
-        if self.head_dim > 64 and self.atten_dropout > 0.0:
-            raise NotImplementedError("attention dropout is built for head_dim <= 64")
 
     def forward(self, x, condition=None, relative_positions=None, residual=None):
         if self.correction is not None:

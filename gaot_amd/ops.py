@@ -1059,10 +1059,10 @@ class _MLPChain(torch.autograd.Function):
         g = dy.reshape(-1, ws[-1].shape[0])
         g, _ = _rowmajor(g)
         last_act = ACT[ctx.acts[-1]]
-        if last_act == L.ACT_RELU:      # derivative of the final activation (not fusable: no following GEMM)
-            g = torch.ops.aten.threshold_backward(g, auxs[-1], 0.0)
-        elif last_act == L.ACT_GELU:
-            raise NotImplementedError("final GELU in an MLP chain")
+        if last_act in (L.ACT_RELU, L.ACT_GELU):      # derivative of the final activation (not fusable: no following GEMM)
+            g2 = torch.empty_like(g)
+            L.check(L.load().gaot_act_bwd(_p(g), _p(auxs[-1].contiguous()), g.numel(), last_act, _p(g2), _stream()), "gaot_act_bwd")
+            g = g2
         grads: List[Optional[torch.Tensor]] = [None] * (2 * n)
         for i in range(n - 1, -1, -1):
             want_db = has_b[i] and ctx.needs_input_grad[3 + 2 * i]

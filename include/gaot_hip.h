@@ -262,6 +262,9 @@ int gaot_rmsnorm_bwd(const float* x, const float* w, const float* rstd, const fl
 /* SwiGLU gate attn.py:151: u = [u1 | u3] ([M,2F]); g = silu(u1)*u3 ; bwd writes du [M,2F]. */
 int gaot_swiglu_fwd(const float* u, int32_t M, int32_t F, float* g, gaot_stream_t stream);
 int gaot_swiglu_bwd(const float* u, const float* dg, int32_t M, int32_t F, float* du, gaot_stream_t stream);
+/* out[i] = g[i] * act'(z[i]), act = GAOT_ACT_GELU (z = the saved pre-activation) or GAOT_ACT_RELU (z = the saved output): the derivative of
+ * the LAST activation of an MLP chain (mlp.py:283-305 with a non-default final non-linearity), which has no following product to ride on */
+int gaot_act_bwd(const float* g, const float* z, int64_t n, int32_t act, float* out, gaot_stream_t stream);
 /* softmax attention, no mask, scale 1/sqrt(head_dim) (attn.py:98-116, F.scaled_dot_product_attention).
  * q/k/v are strided views: element (b,s,h,d) at ptr[(b*S+s)*ld + h*head_dim + d]; kv head = h / (H/Hkv).
  * o has the same addressing with ldo.  lse[B,H,S] (natural-log-sum-exp of scaled scores) saved for bwd.
@@ -279,7 +282,7 @@ int gaot_attention_fwd(const float* q, const float* k, const float* v, int64_t l
  * multiplied by keep(b,h,q,k) / (1 - p) before the product with V.  keep = (splitmix64(seed + ((b*H + h)*S + q)*S + k) >> 32) <
  * (1 - p) * 2^32 with seed read from DEVICE memory, so captured graphs draw a new mask at every replay:
  *   gaot_attention_seed_next : used[0] = mix(state[0], state[1] + 1, salt); state[1] += 1   (state = {seed, counter})
- *   gaot_attention_fwd_dropout / _bwd_dropout : as gaot_attention_fwd / _bwd (fp32-MFMA kernels) with p_drop in (0, 1) and the
+ *   gaot_attention_fwd_dropout / _bwd_dropout : as gaot_attention_fwd / _bwd (fp32-MFMA kernels, head_dim <= 128) with p_drop in (0, 1) and the
  *   device word written by gaot_attention_seed_next; the backward regenerates the forward's mask from the same word. */
 int gaot_attention_seed_next(uint64_t* state, uint64_t salt, uint64_t* used, gaot_stream_t stream);
 int gaot_attention_fwd_dropout(const float* q, const float* k, const float* v, int64_t ldq, int64_t ldk, int64_t ldv,

@@ -330,7 +330,7 @@ def _dropout_factor(seed: int, B, H, S, p):
     return torch.from_numpy(keep.reshape(B, H, S, S).astype(np.float64) / (1.0 - p))
 
 
-@pytest.mark.parametrize("B,S,H,Hkv,D,p", [(2, 96, 4, 4, 32, 0.1), (1, 130, 2, 1, 64, 0.25), (2, 70, 4, 2, 16, 0.5)])
+@pytest.mark.parametrize("B,S,H,Hkv,D,p", [(2, 96, 4, 4, 32, 0.1), (1, 130, 2, 1, 64, 0.25), (2, 70, 4, 2, 16, 0.5), (1, 150, 2, 2, 96, 0.2), (1, 64, 1, 1, 128, 0.3)])
 def test_attention_dropout_matches_float64_with_the_same_mask(B, S, H, Hkv, D, p):
     """attn.py:110-114: softmax, then dropout of the attention weights, then the product with V.  The mask cannot equal torch's
     (another generator); the kernel's own mask is rebuilt on the host from the seed word and the math is checked against float64"""
@@ -1245,6 +1245,32 @@ def test_agno_with_relu_kernel_mlp_matches_float64():
     ref2 = torch.zeros(2, sp.numel() - 1, 64, dtype=torch.float64).index_add(1, qid, h2[None] * f.double()[:, idx])
     ref2 = ref2 / (sp[1:] - sp[:-1]).clamp(min=1)[None, :, None]
     assert rel(out2, ref2) < 3e-6
+
+
+def test_mlp_chain_with_a_final_activation():
+    """an MLP chain whose LAST layer carries GELU / ReLU too (ops.mlp_chain acts = [..., 'gelu']): the derivative of the final
+    activation has no following product to ride on and runs as its own kernel (gaot_act_bwd); against float64"""
+    from gaot_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for act in ("gelu", "relu"):
+        x = torch.randn(700, 24, generator=g)
+        ws = [torch.randn(40, 24, generator=g) / 5, torch.randn(12, 40, generator=g) / 6]
+        bs = [torch.randn(40, generator=g) / 3, torch.randn(12, generator=g) / 3]
+        go = torch.randn(700, 12, generator=g)
+        f = (lambda t: torch.nn.functional.gelu(t)) if act == "gelu" else torch.relu
+        xd = x.double().requires_grad_()
+        wd = [w.double().requires_grad_() for w in ws]
+        bd = [b.double().requires_grad_() for b in bs]
+        ref = f(f(xd @ wd[0].t() + bd[0]) @ wd[1].t() + bd[1])
+        gref = torch.autograd.grad(ref, [xd] + wd + bd, go.double())
+        xg = x.to(dev()).requires_grad_()
+        wg = [w.to(dev()).requires_grad_() for w in ws]
+        bg = [b.to(dev()).requires_grad_() for b in bs]
+        y = ops.mlp_chain(xg, wg, bg, [act, act])
+        got = torch.autograd.grad(y, [xg] + wg + bg, go.to(dev()))
+        assert rel(y, ref) < 2e-6
+        for a, b in zip(got, gref):
+            assert rel(a, b) < 5e-6, (act, rel(a, b))
 
 
 def test_channel_mlp_arbitrary_activation_and_dropout():
