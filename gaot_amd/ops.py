@@ -414,7 +414,9 @@ def _split_for_narrow_output(Mo: int, No: int, K: int) -> int:
         return 1
     t128 = ((Mo + 127) // 128) * ((No + 127) // 128)
     if 100 <= t128 < 200:
-        return 2 if K >= 2048 else 1
+        # fp16 / two-piece tiles (tools/gemm_splitk_sweep.py, product + reduce): K = 2048: 76 / 51 / 47 us at 1 / 2 / 4 slabs on the
+        # 128-row tiles (64-row tiles without slabs: 66); K = 1024: 34 (64-row, no slabs) / 31.5 (two slabs)
+        return 4 if K >= 2048 else 2
     if 48 <= t128 < 100 and Mo >= 128 and No >= 128:
         # fewer than 100 output tiles (4 096 tokens x 384 at the 3-D configuration): on the fp32-MFMA tiles 130 us at K = 3 072;
         # enough K slabs for ~256 workgroups on the split-bf16 tiles, each at most 1 024 deep (the accumulation cap of gemm.hip)
