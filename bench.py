@@ -10,8 +10,9 @@ example model (config/examples/time_indep/poisson_gauss.json: latent 64x64, C=64
 blocks, 8 heads; 3 396 033 parameters), synthetic data, random-init weights, inputs resident in HBM.
 The HEADLINE (`value`, `ms_per_step`, `dtype: "f32"`) is fp32-equivalent arithmetic end to end, like the reference (no autocast
 anywhere, base_trainer.py:63-68): storage and accumulation are fp32, and every product on the matrix pipe carries each fp32 operand
-to fp32 rounding -- as TWO fp16 pieces of the operand scaled by a power of two read from a device-resident magnitude word (24
-significant bits: |s x - h - m| <= 2^-24 |s x|; three piece products), or, where no word is available, as THREE bf16 pieces (six
+at fp32 width -- as TWO fp16 pieces of the operand scaled by a power of two read from a device-resident magnitude word (24
+significant bits up to the operand's last one: |s x - h - m| <= 2^-23 |s x|, zero for three values in four; three piece products), or,
+where no word is available, as THREE bf16 pieces (six
 piece products).  Its error against the float64 oracle is in `rel_l2_vs_oracle.vs_float64_oracle` next to the fp32 reference's own.
 Other arithmetic is reported as labelled `variants` (bf16x3: the three-piece products everywhere, equally fp32-level; bf16x2: two
 rounded bf16 pieces, 16 bits; bf16: one piece in the tile GEMMs), each with its own error against the float64 oracle.
@@ -691,9 +692,9 @@ def main():
             "precision": {"storage_and_accumulation": "f32 everywhere (weights, activations, gradients, optimizer state, every accumulator)",
                           "pieces": dict(_ops._PIECES), "mode": _ops.precision() if args.dtype != "bf16" else "bf16 (one piece in the tile GEMMs)",
                           "f32_pieces": "fp16x2" if _ops._F16_PIECES[0] else "bf16x3",
-                          "what": "`pieces` 3 = the f32 precision (the headline): every operand of a matrix-pipe product is carried to fp32 rounding -- "
+                          "what": "`pieces` 3 = the f32 precision (the headline): every operand of a matrix-pipe product is carried at fp32 width -- "
                                   "f32_pieces fp16x2: as two fp16 pieces h + m of the operand scaled by a power of two from its device-resident magnitude "
-                                  "word (|s x - h - m| <= 2^-24 |s x|: 24 significant bits; three piece products h h + h m + m h) in the GEMM tiles, the "
+                                  "word (|s x - h - m| <= 2^-23 |s x|: at most the operand's last bit, zero for three values in four; three piece products h h + h m + m h) in the GEMM tiles, the "
                                   "grouped weight gradients and the attention for head_dim <= 64; as three bf16 pieces (8 + 8 + 8 bits exactly, six piece "
                                   "products) in the kernel MLP, wherever a product has no magnitude word, and everywhere with GAOT_F32_PIECES=bf16x3 "
                                   "(`variants.bf16x3`).  Measured against float64 the fp16x2 products are at or below the bf16x3 ones (tests/test_ops_gpu.py "
@@ -710,7 +711,7 @@ def main():
             "roofline": {"bound": "mfma", "pipe": "f16 / bf16 mfma (v_mfma_f32_32x32x16_f16 / _bf16: the same 2.5 PFLOP/s dense rate)",
                          "kernel": "every launch of one step on the bf16 matrix pipe behind gaot_gemm_f32: gemm_split_kernel (NT / NN tiles) and the grouped "
                                    "weight-gradient launch gemm_tn_grouped_kernel; each f32 operand as "
-                                   f"{ {'f32': 'two fp16 pieces of the power-of-two scaled operand (carried to fp32 rounding), three piece products on v_mfma_f32_32x32x16_f16' if _ops._F16_PIECES[0] else 'three exact bf16 pieces, six piece products', 'bf16x2': 'two rounded bf16 pieces, three piece products', 'bf16': 'one bf16 piece, one product'}[args.dtype] }",
+                                   f"{ {'f32': 'two fp16 pieces of the power-of-two scaled operand (24 significant bits up to its last one), three piece products on v_mfma_f32_32x32x16_f16' if _ops._F16_PIECES[0] else 'three exact bf16 pieces, six piece products', 'bf16x2': 'two rounded bf16 pieces, three piece products', 'bf16': 'one bf16 piece, one product'}[args.dtype] }",
                          "achieved": roof["piece_tflops"], "peak": PEAK_BF16_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": roof["piece_tflops"] / PEAK_BF16_MATRIX_TFLOPS,
                          "achieved_note": "piece-product FLOPs ISSUED on the matrix pipe (2MNK x piece products per product) / event-timed duration",

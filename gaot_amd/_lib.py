@@ -29,7 +29,9 @@ class GemmDesc(C.Structure):
         ("split_k", C.c_int32), ("workspace", _f),
         ("colsum", _f),
         ("pieces", C.c_int32),
-        ("a_absmax", _f), ("b_absmax", _f), ("c_absmax", _f),
+        ("a_absmax", _f), ("b_absmax", _f),
+        ("b_planes", C.c_void_p), ("ld_bplanes", C.c_int64), ("b_plane_stride", C.c_int64),
+        ("c_absmax", _f),
     ]
 
 
@@ -42,6 +44,11 @@ class WgradItem(C.Structure):
 class AbsmaxItem(C.Structure):
     """gaot_absmax_item: out[0] = max(out[0], max |x[r * ld + c]|)"""
     _fields_ = [("x", _f), ("ld", C.c_int64), ("rows", C.c_int32), ("cols", C.c_int32), ("out", _f)]
+
+
+class F16PlanesItem(C.Structure):
+    """gaot_f16_planes_item: weight matrix -> two fp16 planes of the scaled weight, as stored and transposed"""
+    _fields_ = [("src", _f), ("ld", C.c_int64), ("rows", C.c_int32), ("cols", C.c_int32), ("absmax", _f), ("planes_k", C.c_void_p), ("planes_t", C.c_void_p)]
 
 
 class ColsumItem(C.Structure):
@@ -63,6 +70,8 @@ PROTOTYPES = {
     "gaot_debug_set_gemm_pieces": (C.c_int, [C.c_int]),
     "gaot_gemm_path": (C.c_int, [C.POINTER(GemmDesc)]),
     "gaot_absmax_grouped": (C.c_int, [C.POINTER(AbsmaxItem), C.c_int32, _s]),
+    "gaot_split_f16_planes_grouped": (C.c_int, [C.POINTER(F16PlanesItem), C.c_int32, _s]),
+    "gaot_debug_set_gemm_planes": (C.c_int, [C.c_int]),
     "gaot_debug_set_wgrad_kslab": (C.c_int, [C.c_int]),
     "gaot_csr_prepare": (C.c_int, [_i, _i, C.c_int32, C.c_int32, C.c_int32, _i, _i, _i, _i, _s]),
     "gaot_csr_transpose": (C.c_int, [_i, C.c_int32, C.c_int32, _i, _i, _i, _s]),

@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void attn_fwd_glds_kernel(const AttnArgs p) {
 // K / V tiles (64 keys) are split by all 256 threads on the way from the prefetch registers into one of two LDS stages.
 // ---------------------------------------------------------------------------------------------
 // pieces of an operand pair: OP = 3 exact (split3_pair), OP = 2 two rounded pieces (split2_pair; third piece zero, never stored or multiplied)
-// F16: two fp16 pieces of sc * x (common.h split2h_pair: x carried to fp32 rounding once sc puts the operand's largest magnitude at ~2^14)
+// F16: two fp16 pieces of sc * x (common.h split2h_pair: x carried up to its last bit once sc puts the operand's largest magnitude at ~2^14)
 template <int OP, bool F16 = false>
 __device__ __forceinline__ void split_op(float x0, float x1, unsigned& a, unsigned& b, unsigned& c, float sc = 1.f) {
     if (F16) { split2h_pair(x0, x1, sc, a, b); c = 0u; }

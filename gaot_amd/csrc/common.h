@@ -104,11 +104,14 @@ __device__ __forceinline__ void split2_pair(float x0, float x1, unsigned& ph, un
 }
 
 // TWO fp16 pieces of sc * x, both rounded to nearest even (v_cvt_pk_f16_f32): h = rn16(sc x), r = sc x - h (exact in fp32), m = rn16(r).
-// An fp32 value has 24 significant bits, h takes 11 of them and |r| <= half an ulp of h, so r has at most 13 significant bits of which
-// m keeps 11: sc x = h + m + e with |e| <= 2^-24 |sc x| (ONE fp32 rounding; e = 0 for three values in four) -- as long as m stays a
-// NORMAL fp16 number, i.e. |sc x| >= 2^-2; below that m is subnormal and the error is absolute, <= 2^-25.  With sc = the power of two
-// that puts the operand's largest magnitude into [2^13, 2^14), every element within 2^-16 of the largest keeps full fp32 precision
-// and smaller ones are off by at most 2^-39 of the largest -- and nothing overflows (fp16 max 65 504).
+// An fp32 value has 24 significant bits; h takes 11 of them and |r| <= half an ulp of h, so r has at most 13 significant bits of which
+// m keeps 11: sc x = h + m + e where e is AT MOST THE OPERAND'S LAST BIT -- |e| <= 2^-23 |sc x|, and e = 0 for three values in four
+// (r fits m exactly unless it sits in the upper half of its range AND x's last bit is set; rms 0.4 x 2^-23: below one fp32 rounding of
+// the product).  That holds while m stays a NORMAL fp16 number, i.e. |sc x| >= 2^-2; below that m is subnormal and the error is
+// absolute, <= 2^-25.  With sc = the power of two that puts the operand's largest magnitude into [2^13, 2^14), every element within
+// 2^-16 of the largest keeps that precision and smaller ones are off by at most 2^-39 of the largest -- and nothing overflows (fp16
+// max 65 504).  Measured against float64 the three piece products h h + h m + m h are at or below the six-product three-piece bf16
+// form on every product kind (tests/test_ops_gpu.py test_gemm_fp16_piece_products): fewer accumulation steps on the matrix pipe.
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ float mul_scalar(float a, float b) {

@@ -352,6 +352,8 @@ extern "C" int gaot_debug_set_gemm_pieces(int n) {
 }
 int gaot_forced_pieces() { return g_split_pieces_forced ? g_split_pieces : 0; }
 
+static int g_use_planes = 1;     // 0: ignore gaot_gemm_desc.b_planes (A/B switch)
+extern "C" int gaot_debug_set_gemm_planes(int on) { const int old = g_use_planes; g_use_planes = on; return old; }
 static int g_ablate = 0;
 extern "C" int gaot_debug_set_gemm_ablate(int bits) { const int old = g_ablate; g_ablate = bits; return old; }
 static int g_tile_override = 0;   // tuning hook: 0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 128x32
@@ -402,6 +404,12 @@ static int gemm_run(const gaot_gemm_desc* d, gaot_stream_t stream, const bool dr
     a.colsum = d->colsum;
     a.ablate = g_ablate;
     a.a_amax = pieces >= 4 ? d->a_absmax : nullptr; a.b_amax = pieces >= 4 ? d->b_absmax : nullptr; a.c_amax = d->c_absmax;
+    // B pre-split into fp16 planes (weights, once per pass): only the split tiles with fp16 pieces read them
+    a.Bpl = nullptr; a.ld_bpl = 0; a.bpl_stride = 0;
+    if (pieces >= 4 && d->b_planes != nullptr && g_use_planes && aligned16(d->b_planes) && d->ld_bplanes % 8 == 0 && d->b_plane_stride % 8 == 0 &&
+        d->K % 16 == 0 && d->A2 == nullptr) {
+        a.Bpl = reinterpret_cast<const unsigned short*>(d->b_planes); a.ld_bpl = d->ld_bplanes; a.bpl_stride = d->b_plane_stride;
+    }
     {
         auto ok4 = [](const void* ptr, long ld) { return ptr == nullptr || (aligned16(ptr) && ld % 4 == 0); };
         a.vec_epi = (a.N % 4 == 0) && aligned16(a.C) && (a.ldc % 4 == 0) && ok4(a.bias, 4) && ok4(a.rowbias, a.ld_rb) &&
@@ -461,7 +469,7 @@ static int gemm_run(const gaot_gemm_desc* d, gaot_stream_t stream, const bool dr
     // (with pre-split B planes an NN product stages B exactly like an NT one; with two-piece products the 64-row split tiles beat the
     // fp32-MFMA tiles on the NN products too: 8192 x 256 x 768 37.4 -> 25.6 us, x 512 26.5 -> 19.0, x 256 15.5 -> 12.8, tools/gemm_modes_2p.py)
     const bool split64 = split_ok && !split128 && g_use_split != 5 && g_use_split != 2 &&
-                         (g_use_split == 4 || prefer64 || ((ak && (bk || g_use_split == 6 || two_pl)) && blocks(64, 128) >= 250 && a.M >= 64 && a.N >= 128 && a.split_k <= 1));   // measured: NT +6-14 %, NN +-0
+                         (g_use_split == 4 || prefer64 || ((ak && (bk || a.Bpl != nullptr || g_use_split == 6 || two_pl)) && blocks(64, 128) >= 250 && a.M >= 64 && a.N >= 128 && a.split_k <= 1));   // measured: NT +6-14 %, NN +-0
     if (dry) { g_last_path = (split128 || split64) ? 3 : 1; return GAOT_OK; }
     if (split128 || split64) {
         g_last_path = 3;

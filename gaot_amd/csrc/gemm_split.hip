@@ -72,8 +72,12 @@ struct SplitGeom {
 // FLUSH > 0: every FLUSH k-tiles (16 k each) the MFMA accumulators are added to running sums on the VECTOR pipe and restart from
 // zero: the bf16 MFMA does not round its accumulator to nearest, so one matrix-pipe accumulation run stays at FLUSH * 16 <= 1 024
 // values of k however long the workgroup's reduction is (costs TM * TN * 16 more registers: the grouped TN kernel has them)
-struct BRegs { f32x4 f[2]; };
-template <bool AK, bool BKM, int BM, int ABL, int NP, int FLUSH = 0>
+// BPL (NP = 4, B staged k-contiguous): the B operand arrives ALREADY split -- two fp16 planes of the scaled weight, k-contiguous,
+// element (n, k) of piece q at Bpl[q * bpl_stride + n * ld_bpl + k], built once per pass from the same magnitude word the kernel
+// reads its inverse scale from (gaot_split_f16_planes_grouped): B tiles go from the load registers to LDS as they are -- no
+// vector arithmetic for B at all (half of the k-loop's split work), same number of loads and LDS writes, bit-identical products.
+struct BRegs { f32x4 f[2]; u32x4 pl[2]; };
+template <bool AK, bool BKM, int BM, int ABL, int NP, int FLUSH = 0, bool BPL = false>
 __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* smem_raw, const int logical, const int zs) {
     using G = SplitGeom<BM, NP>;
     constexpr int NPL = G::NPL;
@@ -105,10 +109,12 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
     // (k, k+1) dwords are written TRANSPOSED into the k-contiguous plane layout (4 x ds_write_b32 per plane), so every
     // operand is read back with ds_read_b128 whatever its layout in memory
     constexpr bool F16 = NP >= 4;
+    static_assert(!BPL || (BKM && NP == 4), "pre-split B planes: fp16 pieces, k-contiguous");
     // fp16 pieces: power-of-two operand scales from the operands' magnitude words (uniform: two scalar loads per workgroup)
     float sc_a = 1.f, sc_b = 1.f, so_a = 1.f, so_b = 1.f;
     if (F16) { amax_scale(p.a_amax, sc_a, so_a); amax_scale(p.b_amax, sc_b, so_b); }
     const float* a_src[2]; const float* b_src[2];
+    const unsigned short* bp_src = nullptr;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         if (AK) {
@@ -127,6 +133,7 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
                 nrow = (within / (WN / 2)) * F + min(gcol, F - 1);
             }
             b_src[q] = B_FULL ? p.B + (long)nrow * p.ldb + (tid & 1) * 8 + q * 4 : p.B + (long)nrow * p.ldb + (tid & 3) * 4;
+            if (BPL) bp_src = B_FULL ? p.Bpl + (long)nrow * p.ld_bpl + (tid & 1) * 8 : p.Bpl + (long)nrow * p.ld_bpl + (tid & 3) * 4;
         } else {      // 128 rows: (k pair = tid & 7, row quad = tid >> 3) for the first 256 threads
             b_src[q] = p.B + (long)(2 * (tid & 7) + q) * p.ldb + min(n0 + ((tid >> 3) & 31) * 4, p.N - 4);
         }
@@ -143,8 +150,17 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
             const bool b_live = B_FULL || (BKM ? q == 0 : tid < 256);
             if (a_live) xa[q] = *reinterpret_cast<const f32x4*>(AK ? a_src[q] + k0 : a_src[q] + k0 * p.lda);
             else xa[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (b_live) xb.f[q] = *reinterpret_cast<const f32x4*>(BKM ? b_src[q] + k0 : b_src[q] + k0 * p.ldb);
-            else xb.f[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!BPL) {
+                if (b_live) xb.f[q] = *reinterpret_cast<const f32x4*>(BKM ? b_src[q] + k0 : b_src[q] + k0 * p.ldb);
+                else xb.f[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        if (BPL) {
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                if (B_FULL) xb.pl[pl] = *reinterpret_cast<const u32x4*>(bp_src + pl * p.bpl_stride + k0);
+                else { const u32x2 v = *reinterpret_cast<const u32x2*>(bp_src + pl * p.bpl_stride + k0); xb.pl[pl] = u32x4{v[0], v[1], 0u, 0u}; }
+            }
         }
     };
 
@@ -209,6 +225,18 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
         if (ABL & 32) { asm volatile("" :: "v"(xa[0][0]), "v"(xb.f[0][0]), "v"(xa[1][3]), "v"(xb.f[1][3])); return; }     // tuning: no LDS plane writes
         unsigned char* sa = smem_raw + stage * STAGE;
         stage_store(sa, xa, AK, A_FULL, PA, 128, BM == 64, sc_a);
+        if (BPL) {
+            unsigned char* sb = sa + NPL * PA;
+            if (B_FULL) {
+                unsigned char* dst = sb + (tid >> 1) * 48 + (tid & 1) * 16;
+                *reinterpret_cast<u32x4*>(dst) = xb.pl[0];
+                *reinterpret_cast<u32x4*>(dst + PB) = xb.pl[1];
+            } else {
+                unsigned char* dst = sb + (tid >> 2) * 48 + (tid & 3) * 8;
+                *reinterpret_cast<u32x2*>(dst) = u32x2{xb.pl[0][0], xb.pl[0][1]};
+                *reinterpret_cast<u32x2*>(dst + PB) = u32x2{xb.pl[1][0], xb.pl[1][1]};
+            }
+        } else
         stage_store(sa + NPL * PA, xb.f, BKM, B_FULL, PB, 256, false, sc_b);
         if (!AK) { const float w = (do_colsum && live && (A_FULL || tid < 128)) ? 1.f : 0.f; csum += (xa[0] + xa[1]) * w; }   // branch-free: keeps the k-loop one block
     };
@@ -355,7 +383,7 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
     __syncthreads();          // the epilogue's LDS slabs alias the stages the next tile is about to fill
 }
 
-template <bool AK, bool BKM, int BM = 128, int ABL = 0, int NP = 3>
+template <bool AK, bool BKM, int BM = 128, int ABL = 0, int NP = 3, bool BPL = false>
 __global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 1 : ((NP == 2 || NP >= 4) ? GAOT_SPLIT2_WG_PER_CU : 2)) void gemm_split_kernel(const GemmArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SplitGeom<BM, NP>::SMEM_BYTES];
     if ((ABL & 128) && (blockIdx.x & 8)) {      // tuning: de-phase half of the workgroups by ~p.ablate x 3.4 us at start
@@ -367,7 +395,7 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 1 : ((NP == 2 ||
         // XCD-aware tile order (as gemm.hip)
         const int q = tiles >> 3, r = tiles & 7, x = vb & 7, slot = vb >> 3;
         const int logical = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + slot;
-        split_tile<AK, BKM, BM, ABL, NP, 0>(p, smem_raw, logical, blockIdx.z);
+        split_tile<AK, BKM, BM, ABL, NP, 0, BPL>(p, smem_raw, logical, blockIdx.z);
     }
 }
 
@@ -423,6 +451,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const TnGroupAr
     a.split_k = split; a.ktiles_per_split = g.p[i].kt_per_split; a.ws = g.ws + g.p[i].ws_off;
     a.colsum = g.p[i].colsum; a.tiles_m = g.p[i].tiles_m; a.tiles_n = g.p[i].tiles_n; a.vec_epi = 1; a.ablate = 0;
     a.a_amax = g.p[i].a_amax; a.b_amax = g.p[i].b_amax; a.c_amax = nullptr;
+    a.Bpl = nullptr; a.ld_bpl = 0; a.bpl_stride = 0;
     split_tile<false, false, 128, ABL, NP, 64>(a, smem_raw, tile, z);
     if (split <= 1) return;
 
@@ -527,7 +556,11 @@ static void launch_split_bm(GemmArgs& a, bool ak, bool bk, hipStream_t st) {
     const int z = a.split_k > 1 ? a.split_k : 1;
     dim3 grid(gx, 1, z);
     dim3 block(BM == 256 ? 512 : 256);
-    if (ak && bk)   hipLaunchKernelGGL((gemm_split_kernel<true, true, BM, 0, NP>), grid, block, 0, st, a);
+    if (NP == 4 && a.Bpl != nullptr) {          // pre-split B (weights): the planes are k-contiguous whatever B's own layout
+        if (ak) hipLaunchKernelGGL((gemm_split_kernel<true, true, BM, 0, 4, true>), grid, block, 0, st, a);
+        else    hipLaunchKernelGGL((gemm_split_kernel<false, true, BM, 0, 4, true>), grid, block, 0, st, a);
+    }
+    else if (ak && bk)   hipLaunchKernelGGL((gemm_split_kernel<true, true, BM, 0, NP>), grid, block, 0, st, a);
     else if (ak && !bk)  hipLaunchKernelGGL((gemm_split_kernel<true, false, BM, 0, NP>), grid, block, 0, st, a);
     else if (!ak && !bk) hipLaunchKernelGGL((gemm_split_kernel<false, false, BM, 0, NP>), grid, block, 0, st, a);
     else                 hipLaunchKernelGGL((gemm_split_kernel<false, true, BM, 0, NP>), grid, block, 0, st, a);

@@ -543,6 +543,52 @@ extern "C" int gaot_colsum_grouped(const gaot_colsum_item* items, int32_t n, gao
     return GAOT_OK;
 }
 
+// ---- fp16 planes of weight matrices (gaot_gemm_desc.b_planes), many matrices per launch.  64 x 64 tiles through LDS so that both the
+// plain and the transposed planes are written in whole 128-byte rows.
+constexpr int F16PL_GROUP_MAX = 64;
+struct F16PlItem { const float* src; const float* amax; unsigned short* pk; unsigned short* pt; long ld; int rows, cols, tiles_c, wg_end; };
+struct F16PlGroupArgs { int n; F16PlItem it[F16PL_GROUP_MAX]; };
+__global__ __launch_bounds__(256) void split_f16_planes_kernel(const F16PlGroupArgs g) {
+    __shared__ float tile[64][65];
+    int i = 0;
+    while (i + 1 < g.n && (int)blockIdx.x >= g.it[i].wg_end) ++i;
+    const int local = (int)blockIdx.x - (i > 0 ? g.it[i - 1].wg_end : 0);
+    const int r0 = (local / g.it[i].tiles_c) * 64, c0 = (local % g.it[i].tiles_c) * 64;
+    const int rows = g.it[i].rows, cols = g.it[i].cols;
+    const float* __restrict__ src = g.it[i].src;
+    const long ld = g.it[i].ld;
+    const int tid = threadIdx.x;
+    float sc, inv;
+    amax_scale(g.it[i].amax, sc, inv);
+    for (int e = tid; e < 64 * 64; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        tile[r][c] = (r0 + r < rows && c0 + c < cols) ? src[(long)(r0 + r) * ld + c0 + c] : 0.f;
+    }
+    __syncthreads();
+    const long plane = (long)rows * cols;
+    const int pp = tid & 31;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {          // 0: as stored [rows][cols]; 1: transposed [cols][rows]
+        unsigned short* __restrict__ out = pass == 0 ? g.it[i].pk : g.it[i].pt;
+        if (out == nullptr) continue;
+        const bool tr = pass == 1;
+        const int orows = tr ? cols : rows, ocols = tr ? rows : cols, or0 = tr ? c0 : r0, oc0 = tr ? r0 : c0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int orow = (tid >> 5) + 8 * k;
+            const float x0 = tr ? tile[2 * pp][orow] : tile[orow][2 * pp];
+            const float x1 = tr ? tile[2 * pp + 1][orow] : tile[orow][2 * pp + 1];
+            unsigned h, m;
+            split2h_pair(x0, x1, sc, h, m);
+            if (or0 + orow < orows && oc0 + 2 * pp + 1 < ocols) {          // rows, cols even (checked on the host): pairs are in or out
+                unsigned short* d = out + (long)(or0 + orow) * ocols + oc0 + 2 * pp;
+                *reinterpret_cast<unsigned*>(d) = h;
+                *reinterpret_cast<unsigned*>(d + plane) = m;
+            }
+        }
+    }
+}
+
 // ---- grouped absmax: the magnitude words of the fp16-piece products (gaot_gemm_desc.a_absmax ...), n matrices per launch.  A workgroup
 // streams its share of one matrix (float4 loads when the rows allow, no per-element division), wave-reduces and publishes one atomic
 // max per wave into the word's slot.
@@ -586,6 +632,31 @@ __global__ __launch_bounds__(256) void absmax_grouped_kernel(const AbsmaxGroupAr
             for (int c = lane; c < cols; c += 64) m0 = fmaxf(m0, fabsf(x[r * ld + c]));
     }
     amax_publish(g.it[i].out, fmaxf(fmaxf(m0, m1), fmaxf(m2, m3)), threadIdx.x & 63, (int)blockIdx.x * 4 + (threadIdx.x >> 6));
+}
+
+extern "C" int gaot_split_f16_planes_grouped(const gaot_f16_planes_item* items, int32_t n, gaot_stream_t stream) {
+    GAOT_REQUIRE(items != nullptr && n > 0, "split_f16_planes_grouped: no items");
+    for (int i = 0; i < n; ++i) {
+        const gaot_f16_planes_item& it = items[i];
+        GAOT_REQUIRE(it.src && it.absmax && (it.planes_k || it.planes_t) && it.rows > 0 && it.cols > 0 && it.rows % 8 == 0 && it.cols % 8 == 0 &&
+                     it.ld >= it.cols && (reinterpret_cast<uintptr_t>(it.planes_k) & 15u) == 0 && (reinterpret_cast<uintptr_t>(it.planes_t) & 15u) == 0,
+                     "split_f16_planes_grouped: item %d: rows, cols multiples of 8, 16-byte aligned planes", i);
+    }
+    for (int i0 = 0; i0 < n; i0 += F16PL_GROUP_MAX) {
+        F16PlGroupArgs a;
+        a.n = n - i0 < F16PL_GROUP_MAX ? n - i0 : F16PL_GROUP_MAX;
+        int wg = 0;
+        for (int i = 0; i < a.n; ++i) {
+            const gaot_f16_planes_item& it = items[i0 + i];
+            const int tc = cdiv(it.cols, 64);
+            wg += cdiv(it.rows, 64) * tc;
+            a.it[i] = F16PlItem{it.src, it.absmax, reinterpret_cast<unsigned short*>(it.planes_k), reinterpret_cast<unsigned short*>(it.planes_t),
+                                (long)it.ld, it.rows, it.cols, tc, wg};
+        }
+        hipLaunchKernelGGL(split_f16_planes_kernel, dim3(wg), dim3(256), 0, ST(stream), a);
+        GAOT_CHECK_LAUNCH("gaot_split_f16_planes_grouped");
+    }
+    return GAOT_OK;
 }
 
 extern "C" int gaot_absmax_grouped(const gaot_absmax_item* items, int32_t n, gaot_stream_t stream) {

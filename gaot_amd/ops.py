@@ -152,7 +152,7 @@ _F16_PIECES = [os.environ.get("GAOT_F32_PIECES", "fp16x2") != "bf16x3"]      # F
 
 def set_f32_pieces(name: str) -> str:
     """how the "f32" precision forms its products on the split tiles: "fp16x2" (default: two fp16 pieces of the scaled operand, three
-    piece products) or "bf16x3" (three bf16 pieces, six piece products).  Both carry every operand to fp32 rounding.  Returns the old name."""
+    piece products) or "bf16x3" (three bf16 pieces, six piece products).  Both carry every operand at fp32 width (bf16x3 exactly; fp16x2 up to the operand's last bit, common.h split2h_pair).  Returns the old name."""
     if name not in ("fp16x2", "bf16x3"):
         raise ValueError(f"f32 pieces must be 'fp16x2' or 'bf16x3', got {name!r}")
     old = "fp16x2" if _F16_PIECES[0] else "bf16x3"
@@ -243,10 +243,16 @@ def wants_amax() -> bool:
     return _F16_PIECES[0] and 3 in _PIECES.values()
 
 
+_PLANE_CACHE: dict = {}        # (address, rows, cols, device) -> (planes_k, planes_t): persistent fp16 plane buffers of a weight matrix
+_USE_PLANES = os.environ.get("GAOT_WEIGHT_PLANES", "1") != "0"        # A/B switch (bit-identical results either way)
+
+
 def refresh_weight_amax(params, groups=()) -> None:
-    """magnitude words of every parameter (and of every fused weight group read as one matrix) in ONE launch; the model calls it at
-    the top of a forward pass, the products of that pass and of its backward look their weight operands up by address.  An entry is
-    trusted while its parameter is alive and unchanged (weak reference, Parameter._version, weights_generation())."""
+    """magnitude words of every parameter (and of every fused weight group read as one matrix) in ONE launch, and -- second launch --
+    the two fp16 planes of every weight MATRIX scaled through its word, as stored and transposed (gaot_gemm_desc.b_planes: the tile
+    kernels then stage their B operand without any split arithmetic).  The model calls it at the top of a forward pass; the products
+    of that pass and of its backward look their weight operands up by address.  An entry is trusted while its parameter is alive and
+    unchanged (weak reference, Parameter._version, weights_generation())."""
     import weakref
     items, owners = [], []
     for g in groups:
@@ -255,6 +261,7 @@ def refresh_weight_amax(params, groups=()) -> None:
         if v is not None and v.is_cuda and v.dtype == torch.float32:
             items.append(v)
             owners.append(g)
+    grouped = {id(q) for own in owners for q in own}
     for q in params:
         if q.is_cuda and q.dtype == torch.float32 and q.dim() >= 1 and q.numel() > 0 and q.is_contiguous():
             items.append(q.detach().reshape(q.shape[0], -1))
@@ -264,23 +271,67 @@ def refresh_weight_amax(params, groups=()) -> None:
     words = _amax_words(len(items), items[0].device)
     _absmax_launch(list(zip(items, words)))
     gen = weights_generation()
+    pl_items = []
     for t, w, own in zip(items, words, owners):
         lo = t.data_ptr()
-        _WEIGHT_AMAX.append((lo, lo + t.numel() * 4, w, [weakref.ref(q) for q in own], [q._version for q in own], gen))
+        rows, cols = t.shape
+        pk = pt = None
+        # planes for matrices the tile kernels can read as B: once per storage (a parameter inside a fused group is covered by the group)
+        if (_USE_PLANES and rows % 8 == 0 and cols % 8 == 0 and min(rows, cols) >= 32 and not (len(own) == 1 and id(own[0]) in grouped)
+                and not (lo & 15)):
+            key = (lo, rows, cols, t.device.index)
+            buf = _PLANE_CACHE.get(key)
+            if buf is None:
+                if len(_PLANE_CACHE) > 512:
+                    _PLANE_CACHE.clear()
+                buf = (torch.empty(2 * rows * cols, device=t.device, dtype=torch.int16), torch.empty(2 * rows * cols, device=t.device, dtype=torch.int16))
+                _PLANE_CACHE[key] = buf
+            pk, pt = buf
+            pl_items.append(L.F16PlanesItem(lo, cols, rows, cols, w.data_ptr(), pk.data_ptr(), pt.data_ptr()))
+        _WEIGHT_AMAX.append((lo, lo + t.numel() * 4, w, [weakref.ref(q) for q in own], [q._version for q in own], gen, rows, cols, pk, pt))
+    if pl_items:
+        arr = (L.F16PlanesItem * len(pl_items))(*pl_items)
+        L.check(L.load().gaot_split_f16_planes_grouped(arr, len(pl_items), _stream()), "gaot_split_f16_planes_grouped")
+
+
+def _weight_entry(w2d: torch.Tensor):
+    lo = w2d.data_ptr()
+    hi = lo + ((w2d.shape[0] - 1) * w2d.stride(0) + w2d.shape[1]) * 4 if w2d.shape[0] > 1 else lo + w2d.shape[1] * 4
+    best = None
+    gen = weights_generation()
+    for e in _WEIGHT_AMAX:
+        a, b, w, refs, vers, g_ = e[:6]
+        if a <= lo and hi <= b and (best is None or b - a < best[1] - best[0]) and w.device == w2d.device and g_ == gen:
+            if all((q := r()) is not None and q._version == v for r, v in zip(refs, vers)):
+                best = e
+    return best
 
 
 def weight_amax(w2d: torch.Tensor) -> torch.Tensor:
     """magnitude word of a weight operand: the smallest registered parameter / fused group that contains the view (a bound over a
     superset is as good), else as amax_for"""
-    lo = w2d.data_ptr()
-    hi = lo + ((w2d.shape[0] - 1) * w2d.stride(0) + w2d.shape[1]) * 4 if w2d.shape[0] > 1 else lo + w2d.shape[1] * 4
-    best = None
-    gen = weights_generation()
-    for a, b, w, refs, vers, g_ in _WEIGHT_AMAX:
-        if a <= lo and hi <= b and (best is None or b - a < best[0]) and w.device == w2d.device and g_ == gen:
-            if all((q := r()) is not None and q._version == v for r, v in zip(refs, vers)):
-                best = (b - a, w)
-    return best[1] if best is not None else amax_for(w2d)
+    e = _weight_entry(w2d)
+    return e[2] if e is not None else amax_for(w2d)
+
+
+def weight_operand(w2d: torch.Tensor, b_kmajor: bool):
+    """(magnitude word, planes pointer or None, ld, plane stride) of a weight B operand: the pre-split fp16 planes of the registered
+    matrix that contains the view -- as stored for x W^T (b_kmajor), transposed for dY W"""
+    e = _weight_entry(w2d)
+    if e is None:
+        return amax_for(w2d), None, 0, 0
+    lo, _, word, _, _, _, rows, cols, pk, pt = e
+    if pk is None or (w2d.shape[0] > 1 and w2d.stride(0) != cols):
+        return word, None, 0, 0
+    off = (w2d.data_ptr() - lo) // 4
+    r0, c0 = off // cols, off % cols
+    if b_kmajor:
+        ptr, ld = pk.data_ptr() + 2 * (r0 * cols + c0), cols
+    else:
+        ptr, ld = pt.data_ptr() + 2 * (c0 * rows + r0), rows
+    if ptr & 15:
+        return word, None, 0, 0
+    return word, ptr, ld, rows * cols
 
 
 _AMAX_TRACE = os.environ.get("GAOT_AMAX_TRACE", "0") == "1"      # tools: print every fallback absmax launch with its call site
@@ -319,7 +370,7 @@ def gemm(M: int, N: int, K: int, A, lda, a_kmajor, B, ldb, b_kmajor, out, ldc, *
     d = L.GemmDesc(M, N, K, _p(A), lda, int(a_kmajor), _p(A2), lda2, k_split, _p(B), ldb, int(b_kmajor),
                    _p(out), ldc, _p(bias), _p(rowbias), rowbias_period, ld_rowbias, _p(rowscale), act,
                    _p(aux_in), _p(aux_out), ld_aux, _p(residual), ldr, split_k, _p(ws), _p(colsum),
-                   pc, None, None, None)
+                   pc, None, None, None, 0, 0, None)
     gemm.last_c_amax = None
     if pc == 3 and _F16_PIECES[0] and A2 is None:
         key = (M, N, K, int(a_kmajor), int(b_kmajor), act, split_k, colsum is None, bias is None, rowbias is None, rowscale is None,
@@ -331,8 +382,14 @@ def gemm(M: int, N: int, K: int, A, lda, a_kmajor, B, ldb, b_kmajor, out, ldc, *
         if path == 3:
             if a_amax is None:
                 a_amax = amax_for(A)
-            if b_amax is None:
-                b_amax = weight_amax(B) if (b_is_weight if b_is_weight is not None else kind != "tn") else amax_for(B)
+            if b_is_weight if b_is_weight is not None else kind != "tn":
+                wword, pl, pl_ld, pl_stride = weight_operand(B, bool(b_kmajor))
+                if b_amax is None:
+                    b_amax = wword
+                if pl is not None and b_amax is wword:
+                    d.b_planes, d.ld_bplanes, d.b_plane_stride = pl, pl_ld, pl_stride
+            elif b_amax is None:
+                b_amax = amax_for(B)
             d.pieces, d.a_absmax, d.b_absmax = 4, a_amax.data_ptr(), b_amax.data_ptr()
             if split_k <= 1 and colsum is None and _PUBLISH_C:
                 cw = _amax_words(1, out.device)[0]

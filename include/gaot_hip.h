@@ -83,7 +83,7 @@ typedef struct gaot_gemm_desc {
      * rounded to nearest (x = h + m + e, |e| <= 2^-18 |x|, unbiased), three piece products: 16 significant bits per operand, half the
      * matrix-pipe work.  4 = TWO fp16 pieces of the SCALED operand, both rounded to nearest, three piece products on
      * v_mfma_f32_32x32x16_f16: with s = the power of two that puts the operand's largest magnitude into [2^13, 2^14), s x = h + m + e,
-     * |e| <= 2^-24 |s x| (one fp32 rounding; zero for three values in four) for every element within 2^-16 of the largest, an absolute
+     * |e| <= 2^-23 |s x| (at most the operand's last bit; zero for three values in four) for every element within 2^-16 of the largest, an absolute
      * 2^-39 of the largest below that: fp32-level products (measured error vs float64 at or below the three-piece products') at the
      * matrix-pipe work of the two-piece ones.  Needs a_absmax / b_absmax; without them, and on kernels off the split tiles, it means 3.
      * Kernels on the fp32 MFMA / vector pipe ignore the field.  Anything else: GAOT_ERR_INVALID. */
@@ -92,6 +92,11 @@ typedef struct gaot_gemm_desc {
      * binade of slack costs nothing), read by the kernel -- no host value, so a captured launch follows the data.  gaot_absmax_grouped
      * computes them; producers publish them. */
     const float* a_absmax; const float* b_absmax;
+    /* optional (pieces = 4): Bop ALREADY split into the two fp16 planes the kernel would form from it (weights: once per pass by
+     * gaot_split_f16_planes_grouped from the SAME b_absmax word, instead of once per workgroup per k-tile).  Piece q of Bop[k,n] is the
+     * 16-bit word b_planes[q * b_plane_stride + n * ld_bplanes + k] (k-contiguous whatever b_kmajor says).  Bit-identical products;
+     * kernels that do not take planes ignore the field.  ld_bplanes, b_plane_stride multiples of 8, 16-byte aligned. */
+    const void* b_planes; int64_t ld_bplanes; int64_t b_plane_stride;
     /* optional (any pieces): the magnitude word of C as this launch stores it (atomic max per slot): the word must be ZERO (or hold a
      * running maximum of the same tensor) before the launch.  Not with split_k > 1.  The next product's a_absmax. */
     float* c_absmax;
@@ -101,6 +106,14 @@ int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream);
 /* which kernel family gaot_gemm_f32 WOULD run this product on: 1 = fp32-MFMA tiles, 2 = skinny vector kernels, 3 = split tiles on the
  * bf16 / fp16 matrix pipe (the only ones that read pieces / *_absmax); launches nothing; < 0 on a bad descriptor */
 int gaot_gemm_path(const gaot_gemm_desc* d);
+/* fp16 planes of weight matrices for gaot_gemm_desc.b_planes, n matrices per launch: item i reads src[r * ld + c] (rows x cols), scales
+ * by the power of two its magnitude word `absmax` selects, and writes piece q (0: h = rn16(s x), 1: m = rn16(s x - h)) of element (r, c)
+ * to planes_k[q * rows * cols + r * cols + c] (as stored: the k-contiguous B operand of x W^T) and to planes_t[q * rows * cols + c * rows + r]
+ * (transposed: the k-contiguous B operand of the input-gradient product dY W); either may be NULL.  rows, cols multiples of 8. */
+typedef struct gaot_f16_planes_item {
+    const float* src; int64_t ld; int32_t rows, cols; const float* absmax; void* planes_k; void* planes_t;
+} gaot_f16_planes_item;
+int gaot_split_f16_planes_grouped(const gaot_f16_planes_item* items, int32_t n, gaot_stream_t stream);
 /* magnitude words for pieces = 4: max over the slots of out_i = max(that, max |x_i[r * ld + c]|) over rows x cols, n matrices in ONE
  * launch (atomic max per slot: zero the words first, or let them accumulate over pieces of one tensor).  NaNs are ignored. */
 typedef struct gaot_absmax_item { const float* x; int64_t ld; int32_t rows, cols; float* out; } gaot_absmax_item;

@@ -27,6 +27,8 @@ int gaot_debug_set_gemm_glds(int on);
 /* 3 (default): fp32-level products from three bf16 pieces per operand; 1: operands rounded to bf16, one piece product, fp32
  * accumulation -- the separately reported `bench.py --dtype bf16` variant only (BASELINE configs[1]); returns the old value. */
 int gaot_debug_set_gemm_pieces(int pieces);
+/* 0: ignore gaot_gemm_desc.b_planes (same-box A/B of the pre-split weight planes; bit-identical results); returns the old value */
+int gaot_debug_set_gemm_planes(int on);
 /* grouped weight gradients: values of k per workgroup (K slab length; multiple of 32, default 4096) */
 int gaot_debug_set_wgrad_kslab(int k);
 /* tuning hook: head_dim 32 attention, 1 = split-bf16 MFMA kernels (default), 0 = fp32-MFMA kernels, 2 / 3 = split with the

@@ -584,7 +584,8 @@ def test_gemm_split_bf16_kernel(M, N, K, mode, request):
 def test_gemm_fp16_piece_products(M, N, K):
     """gaot_gemm_desc.pieces = 4, the way the default "f32" precision runs on the split tiles: every operand scaled by the power of two
     that puts its largest magnitude (a device word: published by its producer or computed by gaot_absmax_grouped) into [2^13, 2^14) and
-    split into TWO fp16 pieces, both rounded to nearest (s x = h + m + e, |e| <= 2^-24 |s x|), three piece products on the f16 MFMA.
+    split into TWO fp16 pieces, both rounded to nearest (s x = h + m + e, |e| <= 2^-23 |s x|: at most the operand's last bit, zero for
+    three values in four), three piece products on the f16 MFMA.
       * random normal operands at magnitudes from 1e-9 to 1e+9: all three product kinds and the grouped launch are AT LEAST as close to
         float64 as the three-piece bf16 products (fewer accumulation steps on the matrix pipe), < 6e-7;
       * the words follow the data: the same tensor objects refilled with 1e6 x larger values (in place, through torch) give the same
@@ -1434,3 +1435,62 @@ def test_colsum_grouped_contiguous_and_column_block_outputs():
         assert maxrel(o, r) < 2e-6
     assert maxrel(wide[:, 64:], ws[:, 4352:4352 + 4096].double().sum(0).view(64, 64)) < 2e-6 and float(wide[:, :64].abs().sum()) == 0.0
     assert maxrel(o2, small.double().sum(0)) < 2e-6
+
+
+# ------------------------------------------------------------------ pre-split fp16 weight planes
+@pytest.mark.parametrize("M,N,K", [(8192, 2048, 256), (8192, 256, 1024), (4096, 768, 256)])
+def test_gemm_with_presplit_f16_weight_planes_is_bit_identical(M, N, K):
+    """gaot_gemm_desc.b_planes: the two fp16 planes of a weight matrix, built once per pass by gaot_split_f16_planes_grouped from the same
+    magnitude word the kernel takes its inverse scale from, are exactly what the tile kernel would have formed itself: forward (x W^T)
+    and input-gradient (g W) products are BIT-IDENTICAL with and without them -- also for a row block / column block of a registered
+    matrix (fused q|k|v weights, the split recovery weight) -- and the planes are really in use (the debug switch changes the kernel)."""
+    from gaot_amd import ops, _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    x, gy = torch.randn(M, K, generator=g).cuda(), torch.randn(M, N, generator=g).cuda()
+    W = torch.nn.Parameter((torch.randn(N, K, generator=g) * 0.07).cuda())
+    ops.begin_pass()
+    ops.refresh_weight_amax([W])
+    word, pl, ld, stride = ops.weight_operand(W.detach(), True)
+    assert pl is not None and ld == K and stride == N * K
+    # the planes themselves: h + m reproduces s * w up to its last bit (|e| <= 2^-23 |s w|, zero for three values in four) for every
+    # element within 2^-16 of the largest, to 2^-25 absolute below that
+    pk = ops._PLANE_CACHE[(W.data_ptr(), N, K, 0)][0].view(torch.float16).view(2, N, K).double()
+    amax = float(word.max())
+    sc = 2.0 ** (13 - math.floor(math.log2(amax)))
+    big = W.detach().abs().double() * sc >= 0.25
+    err = ((pk[0] + pk[1]) - W.detach().double() * sc).abs() / (W.detach().abs().double() * sc).clamp_min(1e-300)
+    assert float(err[big].max()) <= 2.0 ** -23 and float((err[big] == 0).double().mean()) > 0.70
+    assert float((pk[0] + pk[1] - W.detach().double() * sc)[~big].abs().max()) <= 2.0 ** -25
+    res = {}
+    for on in (1, 0):
+        old = lib.gaot_debug_set_gemm_planes(on)
+        try:
+            res[on] = (ops.linear_nt(x, W.detach()), ops.matmul_nn(gy, W.detach()), ops.linear_nt(x, W.detach()[N // 4:N // 2]), ops.matmul_nn(gy[:, :N // 2].contiguous(), W.detach()[:N // 2]),
+                       ops.matmul_nn(gy, W.detach()[:, K // 2:]))
+        finally:
+            lib.gaot_debug_set_gemm_planes(old)
+    for a, b in zip(res[1], res[0]):
+        assert torch.equal(a, b)
+    assert rel(res[1][0], x.double().cpu() @ W.detach().double().cpu().t()) < 6e-7
+
+
+def test_trainstep_with_f16_weight_planes_equals_without(monkeypatch):
+    """three TrainStep updates (eager and hipGraph) with the pre-split planes (default) and without: the same weights bit for bit"""
+    import importlib
+    from gaot_amd import ops
+    from gaot_amd.trainer import TrainStep
+    from tests.test_ddp_gpu import _build, _data, _flat
+    lat, x, p, t = _data()
+    res = {}
+    for planes in (True, False):
+        monkeypatch.setattr(ops, "_USE_PLANES", planes)
+        for graph in (False, True):
+            model = _build(seed=5).to(dev()).train()
+            ts = TrainStep(model, lr=2e-3, weight_decay=1e-4, use_graph=graph)
+            ts.bind(p.to(dev()), t.to(dev()), latent_tokens_coord=lat.to(dev()), xcoord=x.to(dev()))
+            for _ in range(3):
+                ts.step()
+            torch.cuda.synchronize()
+            res[(planes, graph)] = _flat(model).cpu()
+    assert torch.equal(res[(True, False)], res[(True, True)]) and torch.equal(res[(True, False)], res[(False, False)]) and torch.equal(res[(False, False)], res[(False, True)])
