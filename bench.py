@@ -449,6 +449,37 @@ def secondary_configs(dev, which=("C3", "C4", "C5"), steps: int = 20, warmup: in
                 f"BASELINE configs[2]: NACA0012-shaped 2D meshes (density ~ exp(-dist to the contour / 0.15)), vx mode, {N} nodes, batch {B}, "
                 f"3 input channels; {Ee} encoder edges over the batch, encoder degree max {int(deg.max())}, {int((deg == 0).sum())} empty latent rows",
                 (Ee, Ed, B * Q, B * N, C_LIFT, 1, 3, 1))
+        # the reference's variable-coordinate loop (static_trainer.py:180-202 inside optimizers.py:247-257), unchanged -- per-step upload of
+        # the fields from host memory, zero_grad, eager call with coordinates and per-sample graphs, nn.MSELoss, backward, torch.optim.AdamW --
+        # with the dataset's graphs and coordinates kept on the device (the same dict objects every epoch): autograph replays the batch
+        # composition from its third sight on
+        from gaot_amd import ops as _o
+        _o.register_grad_slots([], [])
+        torch.manual_seed(0)
+        m2 = GAOT(3, 1, NS(args=NS(magno=mc, transformer=TransformerConfig(patch_size=PATCH, hidden_size=HIDDEN)), latent_tokens_size=LATENT)).to(dev).train()
+        opt = torch.optim.AdamW(m2.parameters(), lr=8e-4, weight_decay=1e-5)
+        lossf = torch.nn.MSELoss()
+
+        def one():
+            xb, yb = p.to(dev), t.to(dev)
+            opt.zero_grad()
+            out_ = m2(latent_tokens_coord=latd, xcoord=xd, pndata=xb, encoder_nbrs=enc, decoder_nbrs=dec)
+            lossf(out_, yb).backward()
+            opt.step()
+            return type(out_.grad_fn).__name__ == "_GraphedStepBackward"
+        for _ in range(6):
+            one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        graphed = sum(one() for _ in range(steps))
+        torch.cuda.synchronize()
+        dtl = (time.perf_counter() - t0) / steps
+        out["C3"]["reference_loop_vx"] = {"value": B / dtl, "unit": "samples/s", "ms_per_step": 1e3 * dtl, "steps": steps, "graphed_steps": int(graphed),
+                                          "frac_of_trainstep": (B / dtl) / out["C3"]["samples_per_s"],
+                                          "what": "the reference's vx loop unchanged (host->device upload of the fields per step, zero_grad, eager call, nn.MSELoss, "
+                                                  "torch.optim.AdamW) with the per-sample graphs and coordinates resident on the device: a repeated batch "
+                                                  "composition replays as hipGraphs (autograph.py); graphs uploaded anew every step run eagerly"}
+        del m2, opt
     if "C4" in which:
         torch.manual_seed(0)
         B, N = 4, N_NODES

@@ -18,9 +18,16 @@ statistics) guarded by that flag: they recompute in place only if the bytes chan
 flag.  No host synchronisation, four extra launches per step.  Weights are read through their storage pointers: in-place optimizers (torch.optim.*) keep them; if a
 parameter's storage moves (or a shape, the batch size, the training flag changes) the step is captured again.
 
-Not eligible (the eager HIP path runs as before): evaluation / no_grad, vx coordinates, caller-supplied neighbour lists,
-neighbour sub-sampling, node_embedding, pndata that requires grad, host tensors, or `model.auto_graph = False` /
-GAOT_AUTO_GRAPH=0.  trainer.TrainStep switches it off for its model (it captures the whole step itself).
+vx (a different mesh per sample, caller-supplied neighbour lists: static_trainer.py:180-202).  A batch is replayed when it is the
+SAME COMPOSITION as a captured one: the same per-sample neighbour dict OBJECTS in the same order (a dataset kept on the device hands
+out the same dicts every epoch) and coordinates with the same content -- the same tensor object, or one whose bytes equal the captured
+ones (checked with one torch.equal, i.e. one host synchronisation per step; the reference loop synchronises at every upload anyway).
+The captured graphs read the block-diagonal union plan that was composed for that batch; any other composition runs eagerly (its
+first repeat captures it).  Dicts uploaded anew every step (the reference's default CPU-side dataset) are new objects: eager.
+
+Not eligible (the eager HIP path runs as before): evaluation / no_grad, neighbour sub-sampling, node_embedding, fx coordinates with
+caller-supplied neighbour lists, pndata that requires grad, host tensors, or `model.auto_graph = False` / GAOT_AUTO_GRAPH=0.
+trainer.TrainStep switches it off for its model (it captures the whole step itself).
 """
 import os
 import weakref
@@ -43,11 +50,14 @@ def eligible(model, latent, xcoord, pndata, query_coord, encoder_nbrs, decoder_n
         return False
     if getattr(model, "_auto_graph_bypass", False):
         return False
-    if encoder_nbrs is not None or decoder_nbrs is not None or query_coord is not None:
+    if query_coord is not None:
         return False
     if not (torch.is_tensor(pndata) and torch.is_tensor(xcoord) and torch.is_tensor(latent)):
         return False          # e.g. pndata=None (static_trainer.py:164-167 with an empty x_batch): the model's own validation answers
-    if not (pndata.is_cuda and xcoord.is_cuda and latent.is_cuda) or pndata.requires_grad or xcoord.dim() != 2:
+    vx = encoder_nbrs is not None or decoder_nbrs is not None
+    if vx and not (_vx_lists_ok(encoder_nbrs, pndata) and _vx_lists_ok(decoder_nbrs, pndata) and xcoord.dim() == 3):
+        return False
+    if not (pndata.is_cuda and xcoord.is_cuda and latent.is_cuda) or pndata.requires_grad or (not vx and xcoord.dim() != 2):
         return False
     if not (pndata.dtype == xcoord.dtype == latent.dtype == torch.float32):
         return False          # the static buffers are fp32: anything else takes the eager path (which raises a clear TypeError)
@@ -56,8 +66,22 @@ def eligible(model, latent, xcoord, pndata, query_coord, encoder_nbrs, decoder_n
     if torch.cuda.is_current_stream_capturing():
         return False
     for side in (model.encoder, model.decoder):
-        if side.sampling_strategy is not None or side.node_embedding or side.precompute_edges:
+        if side.sampling_strategy is not None or side.node_embedding or bool(side.precompute_edges) != vx:
             return False
+    return True
+
+
+def _vx_lists_ok(nbrs, pndata) -> bool:
+    """per-sample lists of per-scale neighbour dicts with device tensors: [[{neighbors_index, neighbors_row_splits}, ...] x B]"""
+    if not isinstance(nbrs, (list, tuple)) or len(nbrs) != pndata.shape[0]:
+        return False
+    for row in nbrs:
+        if not isinstance(row, (list, tuple)) or not row:
+            return False
+        for d in row:
+            if not (isinstance(d, dict) and torch.is_tensor(d.get("neighbors_index")) and d["neighbors_index"].is_cuda
+                    and torch.is_tensor(d.get("neighbors_row_splits")) and d["neighbors_row_splits"].is_cuda):
+                return False
     return True
 
 
@@ -83,9 +107,10 @@ def _param_list(model):
     return hit[1]
 
 
-def _key(model, latent, xcoord, pndata, condition):
+def _key(model, latent, xcoord, pndata, condition, enc=None, dec=None):
+    comp = None if enc is None else (tuple(id(d) for row in enc for d in row), tuple(id(d) for row in dec for d in row))      # vx: the batch composition
     return (tuple(pndata.shape), pndata.dtype, tuple(xcoord.shape), tuple(latent.shape),
-            None if condition is None else tuple(condition.shape), pndata.device.index,
+            None if condition is None else tuple(condition.shape), pndata.device.index, comp,
             tuple(p.data_ptr() if p.requires_grad else -p.data_ptr() for p in _param_list(model)))      # storage AND trainability
 
 
@@ -163,17 +188,28 @@ def _sync_coordinates(e, latent, xcoord):
     e.store[3] = (xcoord, xcoord._version, latent, latent._version)
 
 
-def _capture(model, latent, xcoord, pndata, condition) -> _Entry:
+def _capture(model, latent, xcoord, pndata, condition, enc=None, dec=None) -> _Entry:
     from . import plan as P
     from . import _lib as L
     e = _Entry()
     dev = pndata.device
     params = list(_param_list(model))
     e.params = params
-    e.store = _static_coordinates(model, latent, xcoord)
-    e.lat, e.x, e.flag = e.store[0], e.store[1], e.store[2]
+    e.vx = enc is not None
     e.gen, e.pending = 0, None
-    _sync_coordinates(e, latent, xcoord)      # buffers shared with an earlier capture may hold other bytes: raise the flag first
+    if e.vx:
+        # private coordinate buffers (the union plan composed for THIS batch holds its own copy of the coordinates: nothing in the
+        # captured graphs follows later edits, so run() replays only for byte-identical coordinates) and the dict lists themselves
+        # (held: their ids are the key)
+        e.store = [latent.detach().clone(), xcoord.detach().clone(), torch.zeros(1, dtype=torch.int32, device=dev),
+                   (xcoord, xcoord._version, latent, latent._version)]
+        e.enc, e.dec = [list(r) for r in enc], [list(r) for r in dec]
+        e.lat, e.x, e.flag = e.store[0], e.store[1], e.store[2]
+    else:
+        e.enc = e.dec = None
+        e.store = _static_coordinates(model, latent, xcoord)
+        e.lat, e.x, e.flag = e.store[0], e.store[1], e.store[2]
+        _sync_coordinates(e, latent, xcoord)      # buffers shared with an earlier capture may hold other bytes: raise the flag first
     e.p = pndata.detach().clone()
     e.c = None if condition is None else condition.detach().clone()
     # one flat static gradient buffer; every trainable parameter gets a 256-byte aligned slice (the weight-gradient GEMMs write
@@ -196,7 +232,8 @@ def _capture(model, latent, xcoord, pndata, condition) -> _Entry:
     def fwd():
         model._auto_graph_bypass = True
         try:
-            return torch.func.functional_call(model, leaves, (), dict(latent_tokens_coord=e.lat, xcoord=e.x, pndata=e.p, condition=e.c))
+            return torch.func.functional_call(model, leaves, (), dict(latent_tokens_coord=e.lat, xcoord=e.x, pndata=e.p, condition=e.c,
+                                                                      encoder_nbrs=e.enc, decoder_nbrs=e.dec))
         finally:
             model._auto_graph_bypass = False
 
@@ -225,7 +262,7 @@ def _capture(model, latent, xcoord, pndata, condition) -> _Entry:
             e.gy = torch.zeros_like(y)
             # from here on the plans' refresh kernels are launched, guarded by the flag (raised above if an earlier capture left
             # other bytes in the shared buffers: the warm-up passes then recompute the arrays before anything is captured)
-            P.FORCE_GUARD[0] = e.flag
+            P.FORCE_GUARD[0] = None if e.vx else e.flag
             for _ in range(2):
                 _, gs = fwd_bwd(e.gy)
                 settle(gs)
@@ -258,10 +295,10 @@ def _capture(model, latent, xcoord, pndata, condition) -> _Entry:
     return e
 
 
-def run(model, latent, xcoord, pndata, condition) -> Optional[torch.Tensor]:
+def run(model, latent, xcoord, pndata, condition, enc=None, dec=None) -> Optional[torch.Tensor]:
     """the training forward through captured graphs, or None when the step cannot be (or could not be) captured"""
     cache = model.__dict__.setdefault("_auto_graph_cache", {})
-    key = _key(model, latent, xcoord, pndata, condition)
+    key = _key(model, latent, xcoord, pndata, condition, enc, dec)
     e = cache.get(key)
     if e is None:
         if len(cache) >= MAX_ENTRIES:
@@ -273,7 +310,7 @@ def run(model, latent, xcoord, pndata, condition) -> Optional[torch.Tensor]:
             if len(model._auto_graph_seen) > 16:
                 model._auto_graph_seen.clear()
             return None
-        e = _capture(model, latent, xcoord, pndata, condition)
+        e = _capture(model, latent, xcoord, pndata, condition, enc, dec)
         cache[key] = e
     # geometry: new coordinate tensors (a trainer that uploads them every step): compare with the static buffers (flag |= differ),
     # overwrite the buffers; the captured forward starts with the flag-guarded refresh of the plans' arrays and ends by clearing it
@@ -281,6 +318,13 @@ def run(model, latent, xcoord, pndata, condition) -> Optional[torch.Tensor]:
     if pend is not None and pend() is not None and pend().gen == e.gen and not getattr(pend(), "_done", False):
         return None        # a forward of this entry is still waiting for its backward: this call runs eagerly (correct, slower)
     last = e.store[3]
+    if e.vx:
+        if xcoord is not last[0] or xcoord._version != last[1] or latent is not last[2] or latent._version != last[3]:
+            # new coordinate tensors for the same dicts: replay only if their bytes are the captured ones (one host synchronisation)
+            if not (torch.equal(xcoord, e.x) and torch.equal(latent, e.lat)):
+                return None
+            e.store[3] = (xcoord, xcoord._version, latent, latent._version)
+        return _GraphedStep.apply(e, pndata, condition, *e.params)
     if (last is None or xcoord is not last[0] or xcoord._version != last[1] or latent is not last[2] or latent._version != last[3]):
         _sync_coordinates(e, latent, xcoord)      # new objects, or the same objects edited in place: compare bytes on the device
     ep = _plan_epochs(model)

@@ -128,7 +128,7 @@ class GAOT(nn.Module):
                           condition=condition)
         # an unchanged eager training loop (the reference trainer's) on fixed shapes: forward and backward as hipGraph replays
         if autograph.eligible(self, latent_tokens_coord, xcoord, pndata, query_coord, encoder_nbrs, decoder_nbrs, condition):
-            out = autograph.run(self, latent_tokens_coord, xcoord, pndata, condition)
+            out = autograph.run(self, latent_tokens_coord, xcoord, pndata, condition, encoder_nbrs, decoder_nbrs)
             if out is not None:
                 return out
         return self._forward_eager(latent_tokens_coord, xcoord, pndata, query_coord, encoder_nbrs, decoder_nbrs, condition)
