@@ -254,6 +254,7 @@ def refresh_weight_amax(params, groups=()) -> None:
     of that pass and of its backward look their weight operands up by address.  An entry is trusted while its parameter is alive and
     unchanged (weak reference, Parameter._version, weights_generation())."""
     import weakref
+    need_t = torch.is_grad_enabled()
     items, owners = [], []
     for g in groups:
         g = list(g)
@@ -287,7 +288,9 @@ def refresh_weight_amax(params, groups=()) -> None:
                 buf = (torch.empty(2 * rows * cols, device=t.device, dtype=torch.int16), torch.empty(2 * rows * cols, device=t.device, dtype=torch.int16))
                 _PLANE_CACHE[key] = buf
             pk, pt = buf
-            pl_items.append(L.F16PlanesItem(lo, cols, rows, cols, w.data_ptr(), pk.data_ptr(), pt.data_ptr()))
+            if not need_t:
+                pt = None          # inference (rollouts): no input-gradient products, only the planes as stored are read
+            pl_items.append(L.F16PlanesItem(lo, cols, rows, cols, w.data_ptr(), pk.data_ptr(), None if pt is None else pt.data_ptr()))
         _WEIGHT_AMAX.append((lo, lo + t.numel() * 4, w, [weakref.ref(q) for q in own], [q._version for q in own], gen, rows, cols, pk, pt))
     if pl_items:
         arr = (L.F16PlanesItem * len(pl_items))(*pl_items)
@@ -327,6 +330,8 @@ def weight_operand(w2d: torch.Tensor, b_kmajor: bool):
     r0, c0 = off // cols, off % cols
     if b_kmajor:
         ptr, ld = pk.data_ptr() + 2 * (r0 * cols + c0), cols
+    elif pt is None:
+        return word, None, 0, 0
     else:
         ptr, ld = pt.data_ptr() + 2 * (c0 * rows + r0), rows
     if ptr & 15:
