@@ -408,6 +408,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 // 16-byte patchify: one thread per 4 channels of a grid node (C % 4 == 0); a node's C channels stay contiguous on both sides
 __global__ void patchify_vec_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int Dz, int P,
                                     int C, int inverse, float* __restrict__ out_amax) {
+    __shared__ float amred[4];
     float am = 0.f;
     const int dim = Dz > 0 ? 3 : 2;
     const int D1 = Dz > 0 ? Dz : 1;
@@ -439,7 +440,7 @@ __global__ void patchify_vec_kernel(const float* __restrict__ in, float* __restr
         *reinterpret_cast<f32x4*>(inverse ? out + g : out + tok) = v;
         am = fmaxf(am, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
     }
-    if (out_amax) amax_publish(out_amax, am, threadIdx.x & 63, (int)blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (out_amax) amax_publish_block<4>(out_amax, am, amred);
 }
 
 }  // namespace gaot
@@ -596,8 +597,12 @@ constexpr int ABSMAX_GROUP_MAX = 96;
 struct AbsmaxItem { const float* x; float* out; long ld; int rows, cols, wg_end; };
 struct AbsmaxGroupArgs { int n; AbsmaxItem it[ABSMAX_GROUP_MAX]; };
 __global__ __launch_bounds__(256) void absmax_grouped_kernel(const AbsmaxGroupArgs g) {
-    int i = 0;
-    while (i + 1 < g.n && (int)blockIdx.x >= g.it[i].wg_end) ++i;
+    int lo_ = 0, hi_ = g.n - 1;                      // first item whose wg_end exceeds this workgroup's index (binary search: the table
+    while (lo_ < hi_) {                              // sits in the kernel arguments, a linear scan is ~90 dependent scalar loads)
+        const int mid = (lo_ + hi_) >> 1;
+        if ((int)blockIdx.x >= g.it[mid].wg_end) lo_ = mid + 1; else hi_ = mid;
+    }
+    const int i = lo_;
     const int first = i > 0 ? g.it[i - 1].wg_end : 0, nwg = g.it[i].wg_end - first, b = (int)blockIdx.x - first;
     const float* __restrict__ x = g.it[i].x;
     const long ld = g.it[i].ld;

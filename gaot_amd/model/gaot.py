@@ -136,12 +136,18 @@ class GAOT(nn.Module):
     def _forward_eager(self, latent_tokens_coord, xcoord, pndata, query_coord=None, encoder_nbrs=None, decoder_nbrs=None,
                        condition=None) -> torch.Tensor:
         if pndata.is_cuda and ops.wants_amax():
-            # magnitude words of the fp16-piece products: a fresh arena for this pass, every weight's word in one launch
-            ops.begin_pass()
+            # magnitude words of the fp16-piece products: a fresh arena for this pass, every weight's word (and planes) in two launches.
+            # Inference over unchanged weights (validation loops, the steps of an autoregressive rollout) keeps the previous pass's table.
             if getattr(self, "_amax_lists", None) is None:
                 self._amax_lists = (list(self.parameters()),
                                     [g for m in self.modules() if hasattr(m, "fused_weight_groups") for g in m.fused_weight_groups()])
-            ops.refresh_weight_amax(*self._amax_lists)
+            if not torch.is_grad_enabled() and ops.weights_current(self._amax_lists[0]):
+                ops.begin_pass(keep_weights=True)
+                if torch.cuda.is_current_stream_capturing():
+                    ops.pin_weight_table()
+            else:
+                ops.begin_pass()
+                ops.refresh_weight_amax(*self._amax_lists)
         rn = self.encode(x_coord=xcoord, pndata=pndata, latent_tokens_coord=latent_tokens_coord, encoder_nbrs=encoder_nbrs)
         rn = ops.cut(rn)                      # staged backward (data-parallel training): encoder gradients complete last
         rn = self.process(rndata=rn, condition=condition)

@@ -174,10 +174,36 @@ _ARENA = [None]
 _WEIGHT_AMAX: list = []        # (lo, hi, word) of the current pass: every parameter and every fused weight group
 
 
-def begin_pass() -> None:
-    """top of a forward pass: magnitude words of the previous pass are not reused (their arena lives on while a ctx still holds it)"""
+def begin_pass(keep_weights: bool = False) -> None:
+    """top of a forward pass: magnitude words of the previous pass are not reused (their arena lives on while a ctx still holds it).
+    keep_weights: the weight table (words + planes) of the previous pass stays (inference over unchanged weights, weights_current())."""
     _ARENA[0] = None
-    _WEIGHT_AMAX.clear()
+    if not keep_weights:
+        _WEIGHT_AMAX.clear()
+        _WEIGHT_TABLE_FOR[0] = None
+
+
+_WEIGHT_TABLE_FOR = [None]        # id of the parameter list the table was built for
+_PINNED_TABLES: list = []         # tables a captured inference graph reads without refreshing them itself: kept alive for good
+
+
+def weights_current(params) -> bool:
+    """is the weight table the one of exactly these parameters as they are now?  (every owner alive, same Parameter._version, same
+    weights_generation(): nothing wrote a weight since refresh_weight_amax built it)"""
+    if not _WEIGHT_AMAX or _WEIGHT_TABLE_FOR[0] != id(params):
+        return False
+    gen = weights_generation()
+    for e in _WEIGHT_AMAX:
+        if e[5] != gen or not all((q := r()) is not None and q._version == v for r, v in zip(e[3], e[4])):
+            return False
+    return True
+
+
+def pin_weight_table() -> None:
+    """a graph being captured will read the current table's words and planes at every replay: never free them"""
+    _PINNED_TABLES.append(list(_WEIGHT_AMAX))
+    if len(_PINNED_TABLES) > 64:
+        del _PINNED_TABLES[0]
 
 
 def _amax_words(n: int, device) -> List[torch.Tensor]:
@@ -264,6 +290,8 @@ def refresh_weight_amax(params, groups=()) -> None:
             owners.append(g)
     grouped = {id(q) for own in owners for q in own}
     for q in params:
+        if id(q) in grouped:
+            continue          # a member of a fused group is found through the group's entry (address containment)
         if q.is_cuda and q.dtype == torch.float32 and q.dim() >= 1 and q.numel() > 0 and q.is_contiguous():
             items.append(q.detach().reshape(q.shape[0], -1))
             owners.append([q])
@@ -295,6 +323,7 @@ def refresh_weight_amax(params, groups=()) -> None:
     if pl_items:
         arr = (L.F16PlanesItem * len(pl_items))(*pl_items)
         L.check(L.load().gaot_split_f16_planes_grouped(arr, len(pl_items), _stream()), "gaot_split_f16_planes_grouped")
+    _WEIGHT_TABLE_FOR[0] = id(params)
 
 
 def _weight_entry(w2d: torch.Tensor):
