@@ -1,4 +1,6 @@
-// fp32 GEMM on the bf16 matrix pipe: every fp32 operand is split EXACTLY into three bf16 pieces
+// fp32 GEMM on the f16 / bf16 matrix pipe.  Default (NP = 4, round 4): two fp16 pieces of the power-of-two scaled operand, three piece
+// products on v_mfma_f32_32x32x16_f16 (common.h split2h_pair has the error argument; the scales come from device-resident magnitude
+// words).  The original form, still what runs without magnitude words (NP = 3): every fp32 operand is split EXACTLY into three bf16 pieces
 //     x = x1 + x2 + x3        (8 + 8 + 8 significant bits, by truncation: h = x & 0xffff0000, r = x - h, ...)
 // and the product is accumulated in fp32 from the six piece products whose weight is >= 2^-16:
 //     x*y ~= x1y1 + (x1y2 + x2y1) + (x1y3 + x2y2 + x3y1)          (dropped: x2y3 + x3y2 + x3y3 <= 2^-23 |x||y|)

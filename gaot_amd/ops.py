@@ -83,8 +83,11 @@ def cut(t: torch.Tensor) -> torch.Tensor:
 #   "nt": activations x weight^T (every forward Linear), "nn": dY x weight (input gradients), "tn": dY^T x X (weight gradients),
 #   "attn": Q / K / V / dO and the probabilities P / dS of the flash-attention kernels, "kmlp": the fused row-wise MLP kernels behind
 #   a smooth activation (ReLU chains always keep exact products, _KernelMLP._pieces).
-# 3 = every fp32 operand as THREE bf16 pieces, six piece products: exact to fp32 rounding -- the arithmetic of the reference, which
-#     computes in fp32 end to end (base_trainer.py:63-68).  THE DEFAULT ("f32").
+# 3 = THE DEFAULT ("f32"): every fp32 operand carried at fp32 width -- the arithmetic of the reference, which computes in fp32 end to
+#     end (base_trainer.py:63-68).  Formed as two fp16 pieces of the power-of-two scaled operand wherever a product has its operands'
+#     magnitude words (`pieces` = 4 on the C side: tile GEMMs, grouped weight gradients, attention for head_dim <= 64; the section
+#     "Magnitude words" below), else as THREE bf16 pieces, six piece products (exact; the kernel MLP; everything with
+#     GAOT_F32_PIECES=bf16x3).
 # 2 = two pieces, both rounded to nearest, three piece products: 16 significant bits per operand, half the matrix-pipe work
 #     ("bf16x2", opt-in: set_precision("bf16x2") / GAOT_PRECISION=bf16x2).  Measured at the bench configuration against the
 #     reference algorithm evaluated in float64 (tools/grad_errors.py): exact products: output 1.25e-7, worst gradient tensor 8.8e-7;

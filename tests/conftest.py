@@ -25,7 +25,8 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture
 def bf16x2():
     """the opt-in two-piece precision (ops.set_precision("bf16x2")) for the tests that pin that variant; everything else -- kernel-level
-    and model-level files alike -- runs the shipped default: exact three-piece products ("f32")."""
+    and model-level files alike -- runs the shipped default, the "f32" precision: fp32-level products (two fp16 pieces of the scaled operand
+    where magnitude words exist, three bf16 pieces elsewhere)."""
     from gaot_amd import ops
     assert ops.precision() == "f32" and set(ops._PIECES.values()) == {3}            # exact products ARE the default
     old = ops.set_precision("bf16x2")

@@ -175,7 +175,7 @@ def test_c2_bench_config_forward_loss_grads_vs_oracle(c2, mode):
 
 def test_c2_default_gradients_stay_within_the_reference_fp32_rounding(c2):
     """What "gradient parity" means for the shipped default, derived from the reference instead of a free 1e-4: measured against the
-    oracle in float64 end to end, EVERY gradient tensor of the default path (exact three-piece products) is at most 3x as far from
+    oracle in float64 end to end, EVERY gradient tensor of the default path (the fp32-level "f32" precision) is at most 3x as far from
     float64 as the reference's own fp32 arithmetic (the fp32 oracle) is on that tensor, plus 1e-6 (tensors the fp32 oracle happens to
     hit exactly); the output within 2e-6.  Through the TRAINING path (TrainStep: grouped weight gradients, deferred column sums).
     The opt-in bf16x2 precision does NOT meet this bar (4-15x the reference's distance, see test_c2_bf16x2_variant_error_budget)."""
