@@ -55,7 +55,7 @@ grouped()
 torch.cuda.synchronize()
 err = max(float((o.double() - r.double()).norm() / r.double().norm()) for (_, _, o), r in zip(ops_in, ref))
 from gaot_amd import _lib
-for rep, kslab in enumerate((2048, 4096, 8192, 2048, 4096, 8192)):
+for rep, kslab in enumerate((2048, 2752, 4096, 8192, 2048, 2752, 4096, 8192)):
     _lib.load().gaot_debug_set_wgrad_kslab(kslab)
     us_s, us_g = (timed(single) if rep == 0 else us_s), timed(grouped)
     print(f"kslab {kslab}: single launches {us_s:8.1f} us ({flops / us_s / 1e6:6.1f} TF/s)   grouped {us_g:8.1f} us ({flops / us_g / 1e6:6.1f} TF/s)   "
