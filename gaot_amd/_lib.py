@@ -32,6 +32,7 @@ class GemmDesc(C.Structure):
         ("a_absmax", _f), ("b_absmax", _f),
         ("b_planes", C.c_void_p), ("ld_bplanes", C.c_int64), ("b_plane_stride", C.c_int64),
         ("c_absmax", _f),
+        ("a2_absmax", _f),
     ]
 
 
@@ -115,7 +116,7 @@ PROTOTYPES = {
     "gaot_colsum": (C.c_int, [_f, C.c_int64, C.c_int32, C.c_int32, _f, _f, _s]),
     "gaot_colsum_grouped": (C.c_int, [C.POINTER(ColsumItem), C.c_int32, _s]),
     "gaot_batchsum": (C.c_int, [_f, C.c_int32, C.c_int64, _f, _s]),
-    "gaot_gno_lift_gather_reduce": (C.c_int, [_f, _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f, _f, C.c_int32, _f, _f, _s]),
+    "gaot_gno_lift_gather_reduce": (C.c_int, [_f, _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f, _f, C.c_int32, _f, _f, _f, _s]),
     "gaot_gno_lift_edge_grad_parts": (C.c_int32, [C.c_int32, C.c_int32]),
     "gaot_gno_lift_edge_grad": (C.c_int, [_f, _f, _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f, _f, C.c_int32, _f, _f, _f, _s]),
     "gaot_gno_proj_gather_reduce": (C.c_int, [_f, _f, _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f, _f, C.c_int32, _f, _f, _s]),
@@ -137,8 +138,10 @@ PROTOTYPES = {
     "gaot_kernel_mlp_bwd": (C.c_int, [_f, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, _f, _f, _f, _s]),
     "gaot_mse_loss_fwd": (C.c_int, [_f, _f, C.c_int64, _f, _f, _s]),
     "gaot_mse_loss_bwd": (C.c_int, [_f, _f, C.c_int64, _f, _f, _s]),
+    "gaot_mse_loss_fwd_bwd": (C.c_int, [_f, _f, C.c_int64, _f, C.c_void_p, _f, _f, _f, _s]),
     "gaot_adamw_step": (C.c_int, [_f, _f, _f, _f, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _f, _s]),
     "gaot_adamw_step_dev": (C.c_int, [_f, _f, _f, _f, C.c_int64, _f, _f, _s]),
+    "gaot_adamw_apply_dev": (C.c_int, [_f, _f, _f, _f, C.c_int64, _f, _f, _s]),
     "gaot_debug_set_ep_chunk": (C.c_int, [C.c_int]),
     "gaot_gno_ep_workspace": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "gaot_gno_lift_gather_reduce_ep": (C.c_int, [_f, _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i, _i, _i, C.c_int32, C.c_int32, _f, _f, _f, _s]),

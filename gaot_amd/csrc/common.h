@@ -176,8 +176,10 @@ __device__ __forceinline__ void amax_publish_block(float* word, float v, float* 
 // (scale, 1 / scale) for an operand whose largest magnitude is the maximum of the word's slots: scale = 2^(13 - floor(log2 amax)),
 // exponent clamped to +-126 (amax = 0 or denormal: the clamp; the operand is zero or flushes to it).  NaN / inf magnitudes give a finite
 // scale: the product's NaNs come from the data itself.  Every lane of the wave must call it (cross-lane maximum).
-__device__ __forceinline__ void amax_scale(const float* word, float& sc, float& inv) {
+// word2 (optional): a second word whose tensor shares the scale (the two A operands of a concatenated-input product)
+__device__ __forceinline__ void amax_scale(const float* word, float& sc, float& inv, const float* word2 = nullptr) {
     unsigned b = __float_as_uint(word[(threadIdx.x & (GAOT_AMAX_SLOTS - 1)) * GAOT_AMAX_STRIDE]);
+    if (word2 != nullptr) { const unsigned b2 = __float_as_uint(word2[(threadIdx.x & (GAOT_AMAX_SLOTS - 1)) * GAOT_AMAX_STRIDE]); b = b2 > b ? b2 : b; }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { const unsigned o = __shfl_xor(b, off, 64); b = o > b ? o : b; }
     const int e = (int)((b >> 23) & 0xffu);                               // biased exponent of amax

@@ -243,11 +243,19 @@ __global__ __launch_bounds__(64 * NW) void gemm_kernel(const GemmArgs p) {
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     const long total = (long)p.M * p.N;
+    float amax = 0.f;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         float v = 0.f;
         for (int z = 0; z < p.split_k; ++z) v += p.ws[(long)z * total + idx];
-        epilogue_store(p, (int)(idx / p.N), (int)(idx % p.N), v);
+        const int m = (int)(idx / p.N), n = (int)(idx % p.N);
+        epilogue_store(p, m, n, v);
+        if (p.c_amax != nullptr) {          // the output's magnitude word: over C as stored (both halves of a SwiGLU gradient)
+            amax = fmaxf(amax, fabsf(p.C[(long)m * p.ldc + n]));
+            if (p.act == GAOT_ACT_SWIGLU_BWD) amax = fmaxf(amax, fabsf(p.C[(long)m * p.ldc + p.N + n]));
+        }
     }
+    __shared__ float red_amax[4];
+    if (p.c_amax != nullptr) amax_publish_block<4>(p.c_amax, amax, red_amax);
     if (p.colsum) {
         const float* cs = p.ws + (long)p.split_k * total;
         for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < p.M; m += (long)gridDim.x * blockDim.x) {
@@ -287,12 +295,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const GemmArgs p
         if (idx < total4) v = zsum(reinterpret_cast<const f32x4*>(p.ws) + idx, total4, p.split_k, wave);
         red[wave][lane] = v;
         __syncthreads();
-        if (wave == 0 && idx < total4) {
-            f32x4 r = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
-            const long m = idx / n4;
-            const int n = (int)(idx - m * n4) * 4;
-            if (p.residual) r += *reinterpret_cast<const f32x4*>(p.residual + m * p.ldr + n);
-            *reinterpret_cast<f32x4*>(p.C + m * p.ldc + n) = r;
+        if (wave == 0) {
+            float av = 0.f;
+            if (idx < total4) {
+                f32x4 r = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+                const long m = idx / n4;
+                const int n = (int)(idx - m * n4) * 4;
+                if (p.residual) r += *reinterpret_cast<const f32x4*>(p.residual + m * p.ldr + n);
+                *reinterpret_cast<f32x4*>(p.C + m * p.ldc + n) = r;
+                av = fmaxf(fmaxf(fabsf(r[0]), fabsf(r[1])), fmaxf(fabsf(r[2]), fabsf(r[3])));
+            }
+            if (p.c_amax != nullptr) amax_publish(p.c_amax, av, lane, (int)blockIdx.x);      // the output's magnitude word
         }
     } else {                                     // trailing blocks: the fused column-sum slab [split_k][M]
         float* redf = reinterpret_cast<float*>(&red[0][0]);
@@ -388,7 +401,7 @@ static int gemm_run(const gaot_gemm_desc* d, gaot_stream_t stream, const bool dr
     if (d->colsum) GAOT_REQUIRE(d->a_kmajor == 0 && d->A2 == nullptr, "gemm: colsum needs an m-major A operand (a_kmajor = 0)");
 
     GAOT_REQUIRE(d->pieces == 0 || (d->pieces >= 2 && d->pieces <= 4), "gemm: pieces must be 0 / 3 (three bf16 pieces), 4 (two fp16 pieces) or 2 (two bf16 pieces), got %d", d->pieces);
-    GAOT_REQUIRE(d->pieces != 4 || (d->a_absmax && d->b_absmax), "gemm: pieces = 4 (fp16 pieces) needs a_absmax and b_absmax");
+    GAOT_REQUIRE(d->pieces != 4 || (d->a_absmax && d->b_absmax && (!d->A2 || d->a2_absmax)), "gemm: pieces = 4 (fp16 pieces) needs a_absmax and b_absmax (and a2_absmax with A2)");
     // the debug override (1: `--dtype bf16` bench variant; 2 / 3 forced for A/B runs) wins over the call's own precision
     int pieces = g_split_pieces_forced ? g_split_pieces : (d->pieces == 2 ? 2 : (d->pieces == 4 ? 4 : 3));
     if (pieces >= 4 && !(d->a_absmax && d->b_absmax)) pieces = 3;
@@ -404,10 +417,11 @@ static int gemm_run(const gaot_gemm_desc* d, gaot_stream_t stream, const bool dr
     a.colsum = d->colsum;
     a.ablate = g_ablate;
     a.a_amax = pieces >= 4 ? d->a_absmax : nullptr; a.b_amax = pieces >= 4 ? d->b_absmax : nullptr; a.c_amax = d->c_absmax;
+    a.a2_amax = pieces >= 4 ? d->a2_absmax : nullptr;
     // B pre-split into fp16 planes (weights, once per pass): only the split tiles with fp16 pieces read them
     a.Bpl = nullptr; a.ld_bpl = 0; a.bpl_stride = 0;
     if (pieces >= 4 && d->b_planes != nullptr && g_use_planes && aligned16(d->b_planes) && d->ld_bplanes % 8 == 0 && d->b_plane_stride % 8 == 0 &&
-        d->K % 16 == 0 && d->A2 == nullptr) {
+        d->K % 16 == 0) {
         a.Bpl = reinterpret_cast<const unsigned short*>(d->b_planes); a.ld_bpl = d->ld_bplanes; a.bpl_stride = d->b_plane_stride;
     }
     {
@@ -438,10 +452,17 @@ static int gemm_run(const gaot_gemm_desc* d, gaot_stream_t stream, const bool dr
         return GAOT_OK;
     }
     if (g_tile_override == 0 && dry && skinny_would(a, ak, bk)) { g_last_path = 2; return GAOT_OK; }
+    // kernels without the vector epilogue do not publish C's magnitude word themselves: one absmax launch over C as stored
+    auto publish_after = [&]() -> int {
+        if (d->c_absmax == nullptr) return GAOT_OK;
+        const int32_t cols = a.act == GAOT_ACT_SWIGLU_BWD ? 2 * a.N : a.N;
+        gaot_absmax_item it = {a.C, (int64_t)a.ldc, a.M, cols, d->c_absmax};
+        return gaot_absmax_grouped(&it, 1, stream);
+    };
     if (g_tile_override == 0 && !dry && launch_skinny(a, ak, bk, st)) {
         g_last_path = 2;
         GAOT_CHECK_LAUNCH("gaot_gemm_f32(skinny)");
-        return GAOT_OK;
+        return publish_after();
     }
     g_last_path = 1;
     // tile choice: the largest tile that still gives every CU (256) a workgroup; skinny N gets a 128x32 tile
@@ -454,7 +475,7 @@ static int gemm_run(const gaot_gemm_desc* d, gaot_stream_t stream, const bool dr
     // values of k on that pipe; longer reductions either arrive split (the slabs are summed on the vector pipe) or stay on the
     // fp32-MFMA tiles
     const long k_per_wg = a.split_k > 1 ? (long)a.ktiles_per_split * 32 : a.K;
-    const bool split_ok = g_use_split && g_use_split != 3 && glds_ok && a.A2 == nullptr && g_tile_override == 0 &&
+    const bool split_ok = g_use_split && g_use_split != 3 && glds_ok && (a.A2 == nullptr || (ak && a.k_split % 16 == 0)) && g_tile_override == 0 &&
                           (k_per_wg <= 1024 || pieces == 1 || g_use_split != 1);      // forced tuning modes bypass the cap
     // measured (tools/gemm_split_test.py): the 128x128 split-bf16 tiles win once they fill the chip (>= 256 workgroups
     // counting split-K slabs) on outputs at least one tile wide; narrower / smaller products stay on the fp32 MFMA tiles
@@ -517,6 +538,7 @@ static int gemm_run(const gaot_gemm_desc* d, gaot_stream_t stream, const bool dr
         }
         GAOT_CHECK_LAUNCH("gaot_gemm_f32(split-k reduce)");
     }
+    else if (!a.vec_epi) return publish_after();
     return GAOT_OK;
 }
 

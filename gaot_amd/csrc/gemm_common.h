@@ -16,6 +16,7 @@ struct GemmArgs {
     float* colsum;          // optional (A m-major only): colsum[m] = sum_k Aop[m,k]  (bias gradient fused into dW = dY^T X)
     int tiles_m, tiles_n;
     int vec_epi;            // 1: N, ldc and every epilogue operand allow 16-byte accesses -> LDS-transposed vector epilogue
+    const float* a2_amax;   // with A2: max |A2| (the kernel scales both A operands by the larger of the two words)
     const float* a_amax; const float* b_amax;   // fp16-piece products (gemm_split.hip NP = 4): device words holding max |A|, max |B| (or a bound)
     const unsigned short* Bpl; long ld_bpl; long bpl_stride;   // optional (NP = 4): B pre-split into two k-contiguous fp16 planes of the scaled weight
     float* c_amax;          // optional: max |C| as stored, accumulated by atomic max on the float's bit pattern (zero before the launch)

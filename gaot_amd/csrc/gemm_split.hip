@@ -114,8 +114,14 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
     static_assert(!BPL || (BKM && NP == 4), "pre-split B planes: fp16 pieces, k-contiguous");
     // fp16 pieces: power-of-two operand scales from the operands' magnitude words (uniform: two scalar loads per workgroup)
     float sc_a = 1.f, sc_b = 1.f, so_a = 1.f, so_b = 1.f;
-    if (F16) { amax_scale(p.a_amax, sc_a, so_a); amax_scale(p.b_amax, sc_b, so_b); }
+    if (F16) { amax_scale(p.a_amax, sc_a, so_a, p.A2 != nullptr ? p.a2_amax : nullptr); amax_scale(p.b_amax, sc_b, so_b); }
     const float* a_src[2]; const float* b_src[2];
+    // concatenated input (k-contiguous A only): columns k >= k_split come from A2 -- as an element offset from this thread's A row
+    long a2_delta = 0;
+    if (AK && p.A2 != nullptr) {
+        const long row = min(m0 + (A_FULL ? tid >> 1 : tid >> 2), p.M - 1);
+        a2_delta = (reinterpret_cast<long>(p.A2) - reinterpret_cast<long>(p.A)) / 4 + row * (p.lda2 - p.lda) - p.k_split;
+    }
     const unsigned short* bp_src = nullptr;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -150,7 +156,7 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
         for (int q = 0; q < 2; ++q) {
             const bool a_live = A_FULL || (AK ? q == 0 : tid < 128);
             const bool b_live = B_FULL || (BKM ? q == 0 : tid < 256);
-            if (a_live) xa[q] = *reinterpret_cast<const f32x4*>(AK ? a_src[q] + k0 : a_src[q] + k0 * p.lda);
+            if (a_live) xa[q] = *reinterpret_cast<const f32x4*>(AK ? a_src[q] + k0 + ((p.A2 != nullptr && k0 >= p.k_split) ? a2_delta : 0L) : a_src[q] + k0 * p.lda);
             else xa[q] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (!BPL) {
                 if (b_live) xb.f[q] = *reinterpret_cast<const f32x4*>(BKM ? b_src[q] + k0 : b_src[q] + k0 * p.ldb);
@@ -452,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const TnGroupAr
     a.aux_in = nullptr; a.aux_out = nullptr; a.ld_aux = 0; a.residual = nullptr; a.ldr = 0;
     a.split_k = split; a.ktiles_per_split = g.p[i].kt_per_split; a.ws = g.ws + g.p[i].ws_off;
     a.colsum = g.p[i].colsum; a.tiles_m = g.p[i].tiles_m; a.tiles_n = g.p[i].tiles_n; a.vec_epi = 1; a.ablate = 0;
-    a.a_amax = g.p[i].a_amax; a.b_amax = g.p[i].b_amax; a.c_amax = nullptr;
+    a.a_amax = g.p[i].a_amax; a.b_amax = g.p[i].b_amax; a.c_amax = nullptr; a.a2_amax = nullptr;
     a.Bpl = nullptr; a.ld_bpl = 0; a.bpl_stride = 0;
     split_tile<false, false, 128, ABL, NP, 64>(a, smem_raw, tile, z);
     if (split <= 1) return;

@@ -628,12 +628,14 @@ __global__ __launch_bounds__(256) void lift_gather_reduce_kernel(const float* __
                                                                  const float* __restrict__ wl, const float* __restrict__ bl,
                                                                  int B, int n_src, int C, const int* __restrict__ sp,
                                                                  const int* __restrict__ cols, int Q, const float* __restrict__ escale,
-                                                                 float* __restrict__ out, int lanes_per_row, int rows_per_block) {
+                                                                 float* __restrict__ out, int lanes_per_row, int rows_per_block,
+                                                                 float* __restrict__ out_amax) {
+    __shared__ float amred[4];
     const int r = blockIdx.x * rows_per_block + threadIdx.x / lanes_per_row;
     const int c = (threadIdx.x % lanes_per_row) * 4;
     const int b0 = blockIdx.y * BCH;
-    if (r >= Q || c >= C) return;
-    const int t0 = sp[r], t1 = sp[r + 1];
+    const bool live = r < Q && c < C;            // (idle threads run an empty segment: the workgroup publishes the output's magnitude together)
+    const int t0 = live ? sp[r] : 0, t1 = live ? sp[r + 1] : 0;
     f32x4 acc[BCH][CI], s0 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int b = 0; b < BCH; ++b)
@@ -666,18 +668,23 @@ __global__ __launch_bounds__(256) void lift_gather_reduce_kernel(const float* __
                 for (int ci = 0; ci < CI; ++ci) acc[b][ci] += kq[u] * pv[u][b][ci];
         }
     }
-    f32x4 wq[CI];
+    float am = 0.f;
+    if (live) {
+        f32x4 wq[CI];
 #pragma unroll
-    for (int ci = 0; ci < CI; ++ci) wq[ci] = f32x4{wl[(c + 0) * CI + ci], wl[(c + 1) * CI + ci], wl[(c + 2) * CI + ci], wl[(c + 3) * CI + ci]};
-    const f32x4 bq = bl ? *reinterpret_cast<const f32x4*>(bl + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ci = 0; ci < CI; ++ci) wq[ci] = f32x4{wl[(c + 0) * CI + ci], wl[(c + 1) * CI + ci], wl[(c + 2) * CI + ci], wl[(c + 3) * CI + ci]};
+        const f32x4 bq = bl ? *reinterpret_cast<const f32x4*>(bl + c) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int b = 0; b < BCH; ++b) {
-        if (b0 + b >= B) break;
-        f32x4 o = bq * s0;
+        for (int b = 0; b < BCH; ++b) {
+            if (b0 + b >= B) break;
+            f32x4 o = bq * s0;
 #pragma unroll
-        for (int ci = 0; ci < CI; ++ci) o += wq[ci] * acc[b][ci];
-        *reinterpret_cast<f32x4*>(out + ((long)(b0 + b) * Q + r) * C + c) = o;
+            for (int ci = 0; ci < CI; ++ci) o += wq[ci] * acc[b][ci];
+            *reinterpret_cast<f32x4*>(out + ((long)(b0 + b) * Q + r) * C + c) = o;
+            am = fmaxf(am, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+        }
     }
+    if (out_amax != nullptr) amax_publish_block<4>(out_amax, am, amred);      // the input word of the Linear that follows (its weight gradient)
 }
 
 // backward of the above for one edge row and channel quad: t_ci = sum_b dOut[b,q,:] pn[b,j,ci], u = sum_b dOut[b,q,:]
@@ -878,7 +885,7 @@ __global__ __launch_bounds__(256) void proj_gather_t_kernel(const float* __restr
 
 extern "C" int gaot_gno_lift_gather_reduce(const float* k, const float* pn, const float* wl, const float* bl, int32_t B,
                                            int32_t n_src, int32_t c_in, int32_t C, const int32_t* splits, const int32_t* cols,
-                                           int32_t Q, const float* escale, float* out, gaot_stream_t stream) {
+                                           int32_t Q, const float* escale, float* out, float* out_absmax, gaot_stream_t stream) {
     GAOT_REQUIRE(B > 0 && n_src > 0 && Q >= 0 && c_in >= 1 && c_in <= 4 && C > 0 && C % 4 == 0 && C <= 1024,
                  "gno_lift_gather_reduce: need 1 <= c_in <= 4 and C %% 4 == 0 (got c_in %d, C %d)", c_in, C);
     if (Q == 0) return GAOT_OK;
@@ -888,7 +895,7 @@ extern "C" int gaot_gno_lift_gather_reduce(const float* k, const float* pn, cons
     constexpr int BCH = 2;
     dim3 grid(cdiv(Q, rpb), cdiv(B, BCH)), block(256);
 #define LG(CI) hipLaunchKernelGGL((lift_gather_reduce_kernel<CI, BCH>), grid, block, 0, ST(stream), k, pn, wl, bl, B, n_src, C, splits, \
-                                  cols, Q, escale, out, lpr, rpb)
+                                  cols, Q, escale, out, lpr, rpb, out_absmax)
     if (c_in == 1) LG(1); else if (c_in == 2) LG(2); else if (c_in == 3) LG(3); else LG(4);
 #undef LG
     GAOT_CHECK_LAUNCH("gaot_gno_lift_gather_reduce");

@@ -743,6 +743,54 @@ __global__ void mse_bwd_kernel(const float* __restrict__ p, const float* __restr
     }
     if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) dp[n4 * 4 + threadIdx.x] = (p[n4 * 4 + threadIdx.x] - y[n4 * 4 + threadIdx.x]) * c;
 }
+// forward AND the gradient for a unit seed in ONE launch (trainer.TrainStep: the loss of a training step is differentiated with
+// d loss = 1): every workgroup writes its slice of dpred = 2 (p - y) / n and its partial sum; the LAST one to finish (ticket) adds the
+// partials in the order mse_final_kernel would -- the same bits -- and, optionally, advances an optimizer's device-resident step
+// counter (the 1-thread tick launch of gaot_adamw_step*, folded in here).  The ticket returns to zero.
+__global__ __launch_bounds__(256) void mse_fused_kernel(const float* __restrict__ p, const float* __restrict__ y, long n, float* __restrict__ part,
+                                                        int* __restrict__ ticket, float inv_n, float* __restrict__ loss, float* __restrict__ dp,
+                                                        float* __restrict__ tick) {
+    __shared__ float red[4];
+    __shared__ int last_s;
+    float s = 0.f;
+    const float c = 2.0f * inv_n;
+    const long n4 = n / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(p)[i], b = reinterpret_cast<const f32x4*>(y)[i];
+        const f32x4 d = a - b;
+        reinterpret_cast<f32x4*>(dp)[i] = d * c;
+        s += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) {
+        const float d = p[n4 * 4 + threadIdx.x] - y[n4 * 4 + threadIdx.x];
+        dp[n4 * 4 + threadIdx.x] = d * c;
+        s += d * d;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = t == (int)gridDim.x - 1;
+        if (last) {
+            __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        last_s = last;
+    }
+    __syncthreads();
+    if (!last_s || threadIdx.x >= 64) return;
+    float tot = 0.f;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 64) tot += __builtin_nontemporal_load(part + i);
+    tot = wave_sum(tot);
+    if (threadIdx.x == 0) {
+        loss[0] = tot * inv_n;
+        if (tick) tick[0] += 1.0f;
+    }
+}
 static int mse_blocks(int64_t n) { long b = (n / 4 + 1023) / 1024; return (int)(b < 1 ? 1 : (b > 256 ? 256 : b)); }
 
 extern "C" int gaot_mse_loss_fwd(const float* pred, const float* target, int64_t n, float* partial, float* loss, gaot_stream_t stream) {
@@ -757,6 +805,16 @@ extern "C" int gaot_mse_loss_bwd(const float* pred, const float* target, int64_t
     GAOT_REQUIRE(pred && target && grad_loss && dpred && n > 0 && aligned16(pred) && aligned16(target) && aligned16(dpred), "mse_loss_bwd: bad arguments");
     hipLaunchKernelGGL(mse_bwd_kernel, dim3(cap_blocks(n / 4 + 1, 256, 1024)), dim3(256), 0, ST(stream), pred, target, (long)n, grad_loss, 2.0f / (float)n, dpred);
     GAOT_CHECK_LAUNCH("gaot_mse_loss_bwd");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_mse_loss_fwd_bwd(const float* pred, const float* target, int64_t n, float* partial, int32_t* ticket, float* loss, float* dpred,
+                                     float* tick, gaot_stream_t stream) {
+    GAOT_REQUIRE(pred && target && partial && ticket && loss && dpred && n > 0 && aligned16(pred) && aligned16(target) && aligned16(dpred),
+                 "mse_loss_fwd_bwd: bad arguments (16-byte aligned inputs, partial[256], a zero ticket)");
+    hipLaunchKernelGGL(mse_fused_kernel, dim3(mse_blocks(n)), dim3(256), 0, ST(stream), pred, target, (long)n, partial, ticket, 1.0f / (float)n, loss,
+                       dpred, tick);
+    GAOT_CHECK_LAUNCH("gaot_mse_loss_fwd_bwd");
     return GAOT_OK;
 }
 
@@ -776,8 +834,15 @@ extern "C" int gaot_adamw_step_dev(float* p, const float* g, float* m, float* v,
     GAOT_REQUIRE(p && g && m && v && step && hyper && n > 0, "adamw_step_dev: bad arguments");
     GAOT_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), "adamw_step_dev: flat buffers must be 16-byte aligned");
     hipLaunchKernelGGL(adamw_tick_kernel, dim3(1), dim3(1), 0, ST(stream), step);
+    return gaot_adamw_apply_dev(p, g, m, v, n, hyper, step, stream);
+}
+
+extern "C" int gaot_adamw_apply_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, const float* step,
+                                    gaot_stream_t stream) {
+    GAOT_REQUIRE(p && g && m && v && step && hyper && n > 0, "adamw_apply_dev: bad arguments");
+    GAOT_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), "adamw_apply_dev: flat buffers must be 16-byte aligned");
     hipLaunchKernelGGL(adamw_kernel, dim3(cap_blocks(n / 4 + 1, 256, 2048)), dim3(256), 0, ST(stream), p, g, m, v, (long)n, 0.f, 0.f,
                        0.f, 0.f, 0.f, step, hyper);
-    GAOT_CHECK_LAUNCH("gaot_adamw_step_dev");
+    GAOT_CHECK_LAUNCH("gaot_adamw_apply_dev");
     return GAOT_OK;
 }

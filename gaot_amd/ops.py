@@ -392,7 +392,7 @@ def _gemm_path(d, key) -> int:
 def gemm(M: int, N: int, K: int, A, lda, a_kmajor, B, ldb, b_kmajor, out, ldc, *, bias=None, rowbias=None,
          rowbias_period=0, ld_rowbias=0, rowscale=None, act=L.ACT_NONE, aux_in=None, aux_out=None, ld_aux=0,
          residual=None, ldr=0, A2=None, lda2=0, k_split=0, split_k=0, colsum=None, pieces: Optional[int] = None,
-         a_amax=None, b_amax=None, b_is_weight: Optional[bool] = None):
+         a_amax=None, b_amax=None, b_is_weight: Optional[bool] = None, a2_amax=None):
     """`a_amax` / `b_amax`: magnitude words of the operands where the caller has them (fp16-piece products); missing ones are looked up /
     computed here.  `b_is_weight` (default: every product but the transposed-A one): B is a parameter (or a view of one).
     The output's own word, when the kernel published it, is left in `gemm.last_c_amax` (None otherwise)."""
@@ -407,18 +407,22 @@ def gemm(M: int, N: int, K: int, A, lda, a_kmajor, B, ldb, b_kmajor, out, ldc, *
     d = L.GemmDesc(M, N, K, _p(A), lda, int(a_kmajor), _p(A2), lda2, k_split, _p(B), ldb, int(b_kmajor),
                    _p(out), ldc, _p(bias), _p(rowbias), rowbias_period, ld_rowbias, _p(rowscale), act,
                    _p(aux_in), _p(aux_out), ld_aux, _p(residual), ldr, split_k, _p(ws), _p(colsum),
-                   pc, None, None, None, 0, 0, None)
+                   pc, None, None, None, 0, 0, None, None)
     gemm.last_c_amax = None
-    if pc == 3 and _F16_PIECES[0] and A2 is None:
+    if pc == 3 and _F16_PIECES[0]:
         key = (M, N, K, int(a_kmajor), int(b_kmajor), act, split_k, colsum is None, bias is None, rowbias is None, rowscale is None,
                aux_in is None, aux_out is None, residual is None, lda % 4, ldb % 4, ldc % 4, ld_aux % 4, ldr % 4,
-               (A.data_ptr() | B.data_ptr() | out.data_ptr()) & 15, _GEMM_MODE)
+               (A.data_ptr() | B.data_ptr() | out.data_ptr()) & 15, _GEMM_MODE,
+               None if A2 is None else (k_split, lda2 % 4, A2.data_ptr() & 15))
         d.pieces, d.a_absmax, d.b_absmax = 4, A.data_ptr(), B.data_ptr()      # (placeholders: the dry run reads no memory)
+        d.a2_absmax = None if A2 is None else A2.data_ptr()
         path = _gemm_path(d, key)
-        d.pieces, d.a_absmax, d.b_absmax = 3, None, None
+        d.pieces, d.a_absmax, d.b_absmax, d.a2_absmax = 3, None, None, None
         if path == 3:
             if a_amax is None:
                 a_amax = amax_for(A)
+            if A2 is not None:
+                d.a2_absmax = (a2_amax if a2_amax is not None else amax_for(A2)).data_ptr()
             if b_is_weight if b_is_weight is not None else kind != "tn":
                 wword, pl, pl_ld, pl_stride = weight_operand(B, bool(b_kmajor))
                 if b_amax is None:
@@ -428,7 +432,7 @@ def gemm(M: int, N: int, K: int, A, lda, a_kmajor, B, ldb, b_kmajor, out, ldc, *
             elif b_amax is None:
                 b_amax = amax_for(B)
             d.pieces, d.a_absmax, d.b_absmax = 4, a_amax.data_ptr(), b_amax.data_ptr()
-            if split_k <= 1 and colsum is None and _PUBLISH_C:
+            if colsum is None and _PUBLISH_C:          # (split-K products: the reduce launch publishes it)
                 cw = _amax_words(1, out.device)[0]
                 d.c_absmax = cw.data_ptr()
                 gemm.last_c_amax = cw
@@ -838,13 +842,17 @@ class _Linear(torch.autograd.Function):
             wc, ldb = _rowmajor(w2d)
             y = torch.empty(M, N, device=x.device, dtype=torch.float32)
             if K % 32 == 0:
-                gemm(M, N, K + K2, xm_, lda, 1, wc, ldb, 1, y, N, A2=x2m_, lda2=lda2, k_split=K, **epi)
+                gemm(M, N, K + K2, xm_, lda, 1, wc, ldb, 1, y, N, A2=x2m_, lda2=lda2, k_split=K, a_amax=_amax_get(xm_, xm, x),
+                     a2_amax=_amax_get(x2m_, x2m, x2), **epi)
+                cw = gemm.last_c_amax
             else:
                 linear_nt(xm_, wc[:, :K], out=y, **epi)
                 linear_nt(x2m_, wc[:, K:], out=y, residual=y, ldr=N)
         ctx.save_for_backward(xm, x2m, w2d)
         ctx.amax_x = _amax_get(xm, x)          # the input's magnitude word, for the weight-gradient product (saved_tensors are new objects)
+        ctx.amax_x2 = _amax_get(x2m, x2) if x2 is not None else None
         _publish(ctx.amax_x, x)
+        _publish(ctx.amax_x2, x2)
         ctx.slots = (_claim(w), _claim(b))
         ctx.meta = (shp, x2.shape if x2 is not None else None, w.shape, b is not None,
                     residual.shape if residual is not None else None,
@@ -863,12 +871,15 @@ class _Linear(torch.autograd.Function):
         K = xm.shape[1]
         need = ctx.needs_input_grad
         dx = dw = db = dres = drb = dx2 = None
+        # dY's magnitude word: its producer's, or the one the first product that needs it computes (it stays on `g` for the others)
         if need[0]:
             dx2d = matmul_nn(g, w2d[:, :K], a_amax=_amax_get(g, dy))
             dx = dx2d.reshape(shp)
             _publish(gemm.last_c_amax, dx2d, dx)
         if need[5] and x2m is not None:
-            dx2 = matmul_nn(g, w2d[:, K:]).reshape(shp2)
+            dx2d_ = matmul_nn(g, w2d[:, K:], a_amax=_amax_get(g, dy))
+            dx2 = dx2d_.reshape(shp2)
+            _publish(gemm.last_c_amax, dx2d_, dx2)
         want_db = has_b and need[2]
         wslot, bslot = ctx.slots
         if need[1]:
@@ -880,7 +891,7 @@ class _Linear(torch.autograd.Function):
             fin = wslot is not None and (db is None or bslot is not None)
             matmul_tn(g, xm, out=dw[:, :K], colsum_out=db, final=fin, g_amax=_amax_get(g, dy), x_amax=ctx.amax_x)
             if x2m is not None:
-                matmul_tn(g, x2m, out=dw[:, K:], final=wslot is not None)
+                matmul_tn(g, x2m, out=dw[:, K:], final=wslot is not None, g_amax=_amax_get(g, dy), x_amax=ctx.amax_x2)
             dw = dw.reshape(wshape)
         elif want_db:
             db = colsum(g)
@@ -1211,6 +1222,27 @@ def mse_loss(pred, target):
     return _MSELoss.apply(pred, target)
 
 
+_MSE_WS: dict = {}        # (device, stream) -> (partials [256] float, ticket [1] int32): scratch of the one-launch form
+
+
+def mse_loss_and_grad(pred, target, tick: Optional[torch.Tensor] = None):
+    """(loss, d loss / d pred) of nn.MSELoss() for a unit seed in ONE launch (trainer.TrainStep: `pred.backward(dpred)` continues
+    the backward pass; the loss carries no graph).  Same bits as mse_loss().  `tick`: an optimizer's device-resident step counter,
+    advanced by the same launch (FlatAdamW.step(ticked=True) then skips its own 1-thread tick launch)."""
+    _dev(pred, target)
+    p, t = pred.detach().contiguous(), target.contiguous()
+    assert p.shape == t.shape, (p.shape, t.shape)
+    key = (p.device, torch.cuda.current_stream(p.device).cuda_stream)
+    ws = _MSE_WS.get(key)
+    if ws is None:
+        ws = _MSE_WS[key] = (torch.empty(256, device=p.device, dtype=torch.float32), torch.zeros(1, device=p.device, dtype=torch.int32))
+    loss = torch.empty((), device=p.device, dtype=torch.float32)
+    dp = torch.empty_like(p)
+    L.check(L.load().gaot_mse_loss_fwd_bwd(_p(p), _p(t), p.numel(), _p(ws[0]), _p(ws[1]), _p(loss), _p(dp), _p(tick), _stream()),
+            "gaot_mse_loss_fwd_bwd")
+    return loss, dp.view_as(pred)
+
+
 class _KernelMLP(torch.autograd.Function):
     """Fused kernel MLP over edge rows (csrc/kernel_mlp.hip): x [E, c_in <= 16] -> 64 -> ... -> 64, GELU between layers.
     One launch forward; backward recomputes the chain and returns every parameter gradient from one launch (+ reduce)."""
@@ -1399,9 +1431,11 @@ class _GNOLiftTransform(torch.autograd.Function):
                                                        _p(plan.edge_query), plan.Q, plan.E, _p(escale), _p(out), _p(ws), _stream()),
                     "gaot_gno_lift_gather_reduce_ep")
         else:
+            ow = _want_word(k.device)
             L.check(lib.gaot_gno_lift_gather_reduce(_p(k), _p(pn), _p(w2), _p(bl), B, n_src, ci, Cc, _p(plan.splits),
-                                                    _p(plan.index), plan.Q, _p(escale), _p(out), _stream()),
+                                                    _p(plan.index), plan.Q, _p(escale), _p(out), _p(ow), _stream()),
                     "gaot_gno_lift_gather_reduce")
+            _publish(ow, out)
         ctx.plan = plan
         ctx.save_for_backward(k, pn, w2, bl if bl is not None else k.new_empty(0), escale if escale is not None else k.new_empty(0))
         ctx.meta = (wl.shape, bl is not None, escale is not None, _claim(wl), _claim(bl))
@@ -1867,9 +1901,14 @@ class _RMSNormFork(torch.autograd.Function):
         ctx.slot = _claim(w)
         yr = y.reshape(shp)
         _publish(yw, y, yr)
+        xw = _amax_get(x, xm)            # the aliases of the stream carry the stream's word on
+        a1 = x.view_as(x)
+        _publish(xw, a1)
         if n_alias == 2:
-            return x.view_as(x), yr, x.view_as(x)
-        return x.view_as(x), yr
+            a2 = x.view_as(x)
+            _publish(xw, a2)
+            return a1, yr, a2
+        return a1, yr
 
     @staticmethod
     def backward(ctx, dres, dy, dskip=None):

@@ -254,14 +254,16 @@ class FlatAdamW(torch.optim.Optimizer):
     def zero_grad(self, set_to_none: bool = True):
         self.bucket.clear()
 
-    def step(self, closure=None, _sync: bool = True):
+    def step(self, closure=None, _sync: bool = True, ticked: bool = False):
+        """`ticked`: the step counter has already been advanced for this update (ops.mse_loss_and_grad(tick=self.step_count))"""
         from . import _lib as L
         from . import ops
         from .ops import _p, _stream
         if _sync:
             self.sync_hyper()
-        L.check(L.load().gaot_adamw_step_dev(_p(self.flat_p), _p(self.bucket.flat), _p(self.m), _p(self.v), self.flat_p.numel(),
-                                             _p(self.hyper), _p(self.step_count), _stream()), "gaot_adamw_step_dev")
+        fn = L.load().gaot_adamw_apply_dev if ticked else L.load().gaot_adamw_step_dev
+        L.check(fn(_p(self.flat_p), _p(self.bucket.flat), _p(self.m), _p(self.v), self.flat_p.numel(),
+                   _p(self.hyper), _p(self.step_count), _stream()), "gaot_adamw_step_dev")
         ops.bump_weights_generation()      # the kernel writes through raw pointers: Parameter._version does not move
 
 
@@ -346,22 +348,39 @@ class TrainStep:
         self._kwargs: Dict = {}
         self._cuts: Optional[_Cuts] = None
         self._checked_phases = False
+        self._seed = None
+        self._ticked = False
+        self.fused_loss = True        # loss + its gradient + the optimizer tick in one launch (False: ops.mse_loss through autograd)
         self.comm_enabled = True      # False: skip the gradient exchange (bench.py measures the exposed communication as the difference)
         self.force_comm = False       # True: issue the collectives even in a one-rank group (tests of the RCCL path on one-GPU boxes)
 
     # ---- the eager pieces
     def _forward_loss(self):
+        """forward + loss.  On the GPU the loss, its gradient (unit seed) and the optimizer's tick come from ONE launch; the pair
+        (pred, dpred) waits in self._seed for _backward_loss()."""
         self.bucket.clear()
         pred = self.model(pndata=self._x, **self._kwargs)
         if pred.is_cuda:
             from . import ops
+            if self.fused_loss and pred.requires_grad:
+                loss, dpred = ops.mse_loss_and_grad(pred, self._y, tick=self.opt.step_count)
+                self._seed = (pred, dpred)
+                self._ticked = True
+                return loss
             return ops.mse_loss(pred, self._y)
         return torch.nn.functional.mse_loss(pred, self._y)          # CPU: gloo tests of the data-parallel plumbing
+
+    def _backward_loss(self, loss):
+        seed, self._seed = self._seed, None
+        if seed is not None:
+            self._backward(*seed)
+        else:
+            self._backward(loss)
 
     def _forward_backward(self):
         """unstaged: forward, loss, the whole backward, gradients packed"""
         loss = self._forward_loss()
-        self._backward(loss)
+        self._backward_loss(loss)
         self.bucket.pack()
         return loss.detach()
 
@@ -394,7 +413,7 @@ class TrainStep:
             ops.set_cut_hook(None)
         if len(self._cuts.pairs) != self.bucket.n_phases - 1:
             raise RuntimeError(f"model marked {len(self._cuts.pairs)} cut points but lists {self.bucket.n_phases} backward phases")
-        self._backward(loss)
+        self._backward_loss(loss)
         self._check_phase(0)
         self.bucket.pack(0)
         return loss.detach()
@@ -438,6 +457,7 @@ class TrainStep:
             self._checked_phases = True
 
     def _eager_step(self):
+        self._ticked = False          # set by _forward_loss when the loss launch advanced the optimizer's step counter
         if not self.staged:
             loss = self._forward_backward()
             self.bucket.all_reduce_mean(self.group, _force=self.force_comm)
@@ -450,7 +470,10 @@ class TrainStep:
             for w in works:
                 if w is not None:
                     w.wait()
-        self.opt.step()
+        if self._ticked:
+            self.opt.step(ticked=True)
+        else:
+            self.opt.step()
         return loss
 
     def bind(self, pndata: torch.Tensor, target: torch.Tensor, **forward_kwargs):
@@ -473,6 +496,7 @@ class TrainStep:
         # thread_local: the RCCL watchdog thread's event queries must not invalidate the capture
         pool = torch.cuda.graph_pool_handle()
         self._graphs = []
+        self._ticked = False
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
             self._loss = self._run_group(0) if self.staged else self._forward_backward()
@@ -484,7 +508,7 @@ class TrainStep:
             self._graphs.append(g)
         self._g_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g_opt, pool=pool, capture_error_mode="thread_local"):
-            self.opt.step(_sync=False)
+            self.opt.step(_sync=False, ticked=self._ticked)          # (graphs exist on the GPU only: FlatAdamW)
         for dst, src in zip((self.opt.flat_p, self.opt.m, self.opt.v, self.opt.step_count), snap):
             dst.copy_(src)
 

@@ -97,9 +97,12 @@ typedef struct gaot_gemm_desc {
      * 16-bit word b_planes[q * b_plane_stride + n * ld_bplanes + k] (k-contiguous whatever b_kmajor says).  Bit-identical products;
      * kernels that do not take planes ignore the field.  ld_bplanes, b_plane_stride multiples of 8, 16-byte aligned. */
     const void* b_planes; int64_t ld_bplanes; int64_t b_plane_stride;
-    /* optional (any pieces): the magnitude word of C as this launch stores it (atomic max per slot): the word must be ZERO (or hold a
-     * running maximum of the same tensor) before the launch.  Not with split_k > 1.  The next product's a_absmax. */
+    /* optional (any pieces): the magnitude word of C as this call stores it (atomic max per slot): the word must be ZERO (or hold a
+     * running maximum of the same tensor) before the call.  The next product's a_absmax.  Published from the tile kernels' vector
+     * epilogue, from the split-K reduce launch, or -- skinny / scalar-epilogue kernels -- by one gaot_absmax_grouped launch over C. */
     float* c_absmax;
+    /* pieces = 4 with A2: the magnitude word of A2 (the kernel scales both halves of the concatenated operand by the larger word) */
+    const float* a2_absmax;
 } gaot_gemm_desc;
 
 int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream);
@@ -228,10 +231,11 @@ int gaot_gno_gather_reduce(const float* w, const float* src, int32_t B, int32_t 
  *   out[b,q,:] = sum_ci Wl[:,ci] * (sum_e a_e pn[b,j(e),ci] k_e) + bl * (sum_e a_e k_e)
  * -- identical to gaot_gno_gather_reduce(k, f) on the lifted f, which is never materialised.  pn [B,n_src,c_in], wl [C,c_in].
  * Backward: dk [E,C] plus gaot_gno_lift_edge_grad_parts(E,C) partial rows [(c_in+1)*C] = [dWl^T (c_in x C) | dbl (C)]
- * that the caller sums (gaot_colsum); pn gets no gradient (raw input data). */
+ * that the caller sums (gaot_colsum); pn gets no gradient (raw input data).  out_absmax (optional): out's magnitude word
+ * (gaot_gemm_desc.c_absmax conventions: zero before the launch). */
 int gaot_gno_lift_gather_reduce(const float* k, const float* pn, const float* wl, const float* bl, int32_t B, int32_t n_src,
                                 int32_t c_in, int32_t C, const int32_t* splits, const int32_t* cols, int32_t Q,
-                                const float* escale, float* out, gaot_stream_t stream);
+                                const float* escale, float* out, float* out_absmax, gaot_stream_t stream);
 int32_t gaot_gno_lift_edge_grad_parts(int32_t E, int32_t C);
 int gaot_gno_lift_edge_grad(const float* dout, const float* k, const float* pn, const float* wl, const float* bl, int32_t B,
                             int32_t Q, int32_t n_src, int32_t c_in, int32_t C, const int32_t* index32,
@@ -367,6 +371,12 @@ int gaot_kernel_mlp_bwd_w(const float* x, int32_t E, int32_t cin, int32_t n_laye
  * dpred = 2 (pred - target) / n * grad_loss[0] with grad_loss a DEVICE scalar (so the launch replays inside a hipGraph). */
 int gaot_mse_loss_fwd(const float* pred, const float* target, int64_t n, float* partial, float* loss, gaot_stream_t stream);
 int gaot_mse_loss_bwd(const float* pred, const float* target, int64_t n, const float* grad_loss, float* dpred, gaot_stream_t stream);
+/* forward and the gradient for a unit seed (d loss = 1) in ONE launch: loss[0] = mean (pred - target)^2 with the bits gaot_mse_loss_fwd
+ * gives, dpred = 2 (pred - target) / n.  partial: 256 floats of scratch; ticket: one int32, ZERO before the first call (the kernel
+ * returns it to zero); tick (optional): a device-resident optimizer step counter advanced by one by this launch (the tick of
+ * gaot_adamw_step_dev, folded in: follow with gaot_adamw_apply_dev). */
+int gaot_mse_loss_fwd_bwd(const float* pred, const float* target, int64_t n, float* partial, int32_t* ticket, float* loss, float* dpred,
+                          float* tick, gaot_stream_t stream);
 /* One AdamW update over flat fp32 buffers with torch.optim.AdamW semantics (the reference's optimizer, optimizers.py:196;
  * defaults beta = (0.9, 0.999), eps = 1e-8).  step[1] is a DEVICE counter (float) advanced by the call itself, so the launch
  * replays inside a hipGraph. */
@@ -376,6 +386,9 @@ int gaot_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, flo
  * A captured launch therefore follows the reference's per-epoch LR schedulers (optimizers.py:199-245) without re-capture. */
 int gaot_adamw_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, float* step,
                         gaot_stream_t stream);
+/* The update alone, for a step counter something else has already advanced (gaot_mse_loss_fwd_bwd's `tick`): step is only read. */
+int gaot_adamw_apply_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, const float* step,
+                         gaot_stream_t stream);
 /* patchify gaot.py:182-185,202-205 and its inverse gaot.py:224-231.  Latent grid H x W (x Dz; Dz = 0 for 2-D).
  * inverse = 0: in = grid[b, (h,w[,z]), c]  -> out = tokens[b, s, (p..., c)];  inverse = 1: the other way. */
 int gaot_patchify(const float* in, int32_t B, int32_t H, int32_t W, int32_t Dz, int32_t P, int32_t C,

@@ -919,3 +919,27 @@ def test_twelve_training_steps_track_the_oracle(graph):
     moved = max(float((cur[k] - sd[k]).abs().max()) for k in sd)
     worst = max(float((prm.detach().cpu() - cur[k]).abs().max()) for k, prm in m.state_dict().items())
     assert worst < 1e-3 * moved, (worst, moved)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_trainstep_one_launch_loss_equals_the_autograd_loss(graph):
+    """TrainStep's loss / seed gradient / optimizer tick come from one launch (ops.mse_loss_and_grad, FlatAdamW.step(ticked=True));
+    `fused_loss = False` keeps the three launches + the 1-thread tick.  Same losses, same weights, same step counter, bit for bit."""
+    from gaot_amd.trainer import TrainStep
+    from gaot_amd.model.gaot import GAOT
+    model, sd, ocfg = make_model(2, 1, [16, 16], C=32, hidden=128, heads=4, radius=0.12, precompute=False, seed=32)
+    g = torch.Generator().manual_seed(32)
+    lat, x = grid([16, 16]), uniform_points(800, 2, g)
+    data = [(torch.randn(3, 800, 2, generator=g), torch.randn(3, 800, 1, generator=g)) for _ in range(5)]
+    out = []
+    for fused in (True, False):
+        m = GAOT(2, 1, model_cfg(model)); m.load_state_dict(sd); m.to(dev()).train()
+        ts = TrainStep(m, lr=2e-3, weight_decay=1e-4, use_graph=graph)
+        ts.fused_loss = fused
+        ts.bind(data[0][0].to(dev()), data[0][1].to(dev()), latent_tokens_coord=lat.to(dev()), xcoord=x.to(dev()))
+        losses = [ts.step(p.to(dev()), t.to(dev())).clone() for p, t in data]
+        torch.cuda.synchronize()
+        out.append((losses, [q.detach().clone() for q in m.parameters()], float(ts.opt.step_count)))
+    assert out[0][2] == out[1][2] == 5.0
+    assert all(torch.equal(a, b) for a, b in zip(out[0][0], out[1][0]))
+    assert all(torch.equal(a, b) for a, b in zip(out[0][1], out[1][1]))

@@ -1494,3 +1494,76 @@ def test_trainstep_with_f16_weight_planes_equals_without(monkeypatch):
             torch.cuda.synchronize()
             res[(planes, graph)] = _flat(model).cpu()
     assert torch.equal(res[(True, False)], res[(True, True)]) and torch.equal(res[(True, False)], res[(False, False)]) and torch.equal(res[(False, False)], res[(False, True)])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,K2", [(8192, 256, 256, 256), (4096, 384, 128, 64), (300, 256, 64, 32)])
+def test_linear_over_a_concatenated_input_on_the_split_tiles(M, N, K, K2):
+    """y = [x | x2] W^T without forming the concatenation (the long skip connections of the processor, attn.py): with fp16 pieces the
+    product runs on the split tiles like any other -- columns k >= K come from the second operand, both halves are scaled through
+    the LARGER of their two magnitude words.  fp32-level against float64 whatever the two operands' magnitudes, words of x and x2 carried
+    into the weight-gradient products, and the same results with three bf16 pieces."""
+    from gaot_amd import ops, _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + K2)
+    for ma, mb in ((1.0, 1.0), (1e-3, 50.0), (2e4, 1e-2)):
+        x, x2 = torch.randn(M, K, generator=g) * ma, torch.randn(M, K2, generator=g) * mb
+        w, b = torch.randn(N, K + K2, generator=g) * 0.05, torch.randn(N, generator=g)
+        dy = torch.randn(M, N, generator=g)
+        xd, x2d, wd, bd = (t.cuda().requires_grad_(True) for t in (x, x2, w, b))
+        ops.begin_pass()
+        y = ops.linear(xd, wd, bd, x2=x2d)
+        on_split = lib.gaot_debug_last_gemm_path() == 3
+        y.backward(dy.cuda())
+        X = torch.cat([x, x2], 1).double()
+        ref = X @ w.double().t() + b.double()
+        # the bound of two-piece operands is relative to the LARGER half's magnitude: compare with the product's own scale
+        assert rel(y, ref) < 6e-7, (ma, mb, rel(y, ref))
+        assert rel(wd.grad, dy.double().t() @ X) < 1e-6
+        assert rel(xd.grad, dy.double() @ w.double()[:, :K]) < 6e-7 and rel(x2d.grad, dy.double() @ w.double()[:, K:]) < 6e-7
+        if M >= 8192 and N % 128 == 0:
+            assert on_split, "the concatenated-input product should be on the split tiles at this size"
+        old = ops.set_f32_pieces("bf16x3")
+        try:
+            y3 = ops.linear(xd.detach(), wd.detach(), bd.detach(), x2=x2d.detach())
+        finally:
+            ops.set_f32_pieces(old)
+        assert rel(y3, ref) < 6e-7 and rel(y, y3) < 6e-7
+
+
+@pytest.mark.gpu
+def test_split_k_products_publish_their_output_word():
+    """gaot_gemm_desc.c_absmax with split_k > 1: the reduce launch publishes max |C| (the residual stream a long skip connection
+    re-reads is the output of a split-K product: without the word its consumers would each pay an absmax launch)"""
+    from gaot_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x, w, r = torch.randn(8192, 1024, generator=g).cuda(), (torch.randn(256, 1024, generator=g) * 0.03).cuda(), torch.randn(8192, 256, generator=g).cuda()
+    ops.begin_pass()
+    y = ops.linear_nt(x, w, residual=r, ldr=256)
+    word = ops.gemm.last_c_amax
+    assert ops._split_for_narrow_output(8192, 256, 1024) > 1 and word is not None
+    assert float(word.max()) == float(y.abs().max())
+    assert rel(y, x.double().cpu() @ w.double().cpu().t() + r.double().cpu()) < 6e-7
+
+
+@pytest.mark.gpu
+def test_one_launch_mse_loss_and_gradient():
+    """ops.mse_loss_and_grad: loss and d loss / d pred for a unit seed from ONE launch -- the same bits as the autograd form
+    (mse_loss + backward), the optional optimizer tick advanced by exactly one, the ticket back at zero (repeatable)."""
+    from gaot_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for n in (8 * 16384, 1000003, 7):
+        p, y = torch.randn(n, generator=g).cuda().requires_grad_(True), torch.randn(n, generator=g).cuda()
+        if n % 4 == 0:
+            p2 = p.detach().view(8, -1, 1).requires_grad_(True)
+            y2 = y.view(8, -1, 1)
+        else:
+            p2, y2 = p, y
+        l0 = ops.mse_loss(p2, y2)
+        l0.backward()
+        tick = torch.full((1,), 41.0, device="cuda")
+        for _ in range(2):
+            l1, dp = ops.mse_loss_and_grad(p2.detach(), y2, tick=tick)
+            assert torch.equal(l1, l0.detach()) and torch.equal(dp, p2.grad) and dp.shape == p2.shape
+        assert float(tick) == 43.0
+        assert rel(l1, ((p.detach().double() - y.double()) ** 2).mean()) < 1e-6
