@@ -33,6 +33,7 @@ class GemmDesc(C.Structure):
         ("b_planes", C.c_void_p), ("ld_bplanes", C.c_int64), ("b_plane_stride", C.c_int64),
         ("c_absmax", _f),
         ("a2_absmax", _f),
+        ("raw_slabs", C.c_int32),
     ]
 
 
@@ -70,6 +71,7 @@ PROTOTYPES = {
     "gaot_debug_set_gemm_glds": (C.c_int, [C.c_int]),
     "gaot_debug_set_gemm_pieces": (C.c_int, [C.c_int]),
     "gaot_gemm_path": (C.c_int, [C.POINTER(GemmDesc)]),
+    "gaot_gemm_slab_count": (C.c_int32, [C.c_int32, C.c_int32]),
     "gaot_absmax_grouped": (C.c_int, [C.POINTER(AbsmaxItem), C.c_int32, _s]),
     "gaot_split_f16_planes_grouped": (C.c_int, [C.POINTER(F16PlanesItem), C.c_int32, _s]),
     "gaot_debug_set_gemm_planes": (C.c_int, [C.c_int]),
@@ -97,6 +99,7 @@ PROTOTYPES = {
     "gaot_rmsnorm_fwd": (C.c_int, [_f, _f, C.c_int32, C.c_int32, C.c_float, _f, _f, _f, _s]),
     "gaot_rmsnorm_bwd_partials": (C.c_int, [C.c_int32]),
     "gaot_rmsnorm_bwd": (C.c_int, [_f, _f, _f, _f, _f, _f, C.c_int32, C.c_int32, _f, _f, _f, _s]),
+    "gaot_rmsnorm_bwd_slabs": (C.c_int, [_f, _f, _f, _f, C.c_int32, C.c_int64, _f, _f, _f, C.c_int32, C.c_int32, _f, _f, _f, _s]),
     "gaot_swiglu_fwd": (C.c_int, [_f, C.c_int32, C.c_int32, _f, _s]),
     "gaot_swiglu_bwd": (C.c_int, [_f, _f, C.c_int32, C.c_int32, _f, _s]),
     "gaot_act_bwd": (C.c_int, [_f, _f, C.c_int64, C.c_int32, _f, _s]),

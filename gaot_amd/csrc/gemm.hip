@@ -376,7 +376,11 @@ extern "C" int gaot_debug_set_gemm_tile(int cfg) { const int old = g_tile_overri
 static int gemm_run(const gaot_gemm_desc* d, gaot_stream_t stream, const bool dry) {
     GAOT_REQUIRE(d != nullptr, "gemm: null descriptor");
     GAOT_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm: M,N,K must be positive (got %d,%d,%d)", d->M, d->N, d->K);
-    GAOT_REQUIRE(d->A && d->B && d->C, "gemm: A, B, C must be non-null");
+    GAOT_REQUIRE(d->A && d->B && (d->C || d->raw_slabs), "gemm: A, B, C must be non-null");
+    if (d->raw_slabs)
+        GAOT_REQUIRE(d->split_k > 1 && d->workspace && !d->bias && !d->rowbias && !d->rowscale && d->act == GAOT_ACT_NONE && !d->aux_in && !d->aux_out &&
+                     !d->residual && !d->colsum && d->N % 4 == 0 && aligned16(d->workspace),
+                     "gemm: raw_slabs needs split_k > 1, a 16-byte aligned workspace, N %% 4 == 0 and no epilogue operand");
     GAOT_REQUIRE(d->act >= GAOT_ACT_NONE && d->act <= GAOT_ACT_SWIGLU, "gemm: bad act %d", d->act);
     if (d->act == GAOT_ACT_GELU_BWD || d->act == GAOT_ACT_RELU_BWD || d->act == GAOT_ACT_SWIGLU_BWD)
         GAOT_REQUIRE(d->aux_in != nullptr, "gemm: *_BWD activation needs aux_in");
@@ -430,6 +434,12 @@ static int gemm_run(const gaot_gemm_desc* d, gaot_stream_t stream, const bool dr
                     ok4(a.aux_in, a.ld_aux) && ok4(a.aux_out, a.ld_aux) && ok4(a.residual, a.ldr) && ok4(a.ws, 4);
     }
     a.split_k = cdiv(nkt, a.ktiles_per_split);  // no empty splits
+    const bool raw = d->raw_slabs != 0;
+    if (raw) {
+        a.c_amax = nullptr;
+        if (a.split_k <= 1) { a.C = a.ws; a.ldc = a.N; a.vec_epi = 1; }      // a reduction too short to cut: the product itself is slab 0
+        else if (a.C == nullptr) a.C = a.ws;                                  // (never written)
+    }
 
     const bool ak = d->a_kmajor != 0, bk = d->b_kmajor != 0;
     // 16-byte vector path: contiguous extents and leading dims multiples of 4 floats, bases 16B aligned
@@ -451,7 +461,7 @@ static int gemm_run(const gaot_gemm_desc* d, gaot_stream_t stream, const bool dr
         GAOT_CHECK_LAUNCH("gaot_gemm_f32(swiglu)");
         return GAOT_OK;
     }
-    if (g_tile_override == 0 && dry && skinny_would(a, ak, bk)) { g_last_path = 2; return GAOT_OK; }
+    if (g_tile_override == 0 && !raw && dry && skinny_would(a, ak, bk)) { g_last_path = 2; return GAOT_OK; }
     // kernels without the vector epilogue do not publish C's magnitude word themselves: one absmax launch over C as stored
     auto publish_after = [&]() -> int {
         if (d->c_absmax == nullptr) return GAOT_OK;
@@ -459,7 +469,7 @@ static int gemm_run(const gaot_gemm_desc* d, gaot_stream_t stream, const bool dr
         gaot_absmax_item it = {a.C, (int64_t)a.ldc, a.M, cols, d->c_absmax};
         return gaot_absmax_grouped(&it, 1, stream);
     };
-    if (g_tile_override == 0 && !dry && launch_skinny(a, ak, bk, st)) {
+    if (g_tile_override == 0 && !raw && !dry && launch_skinny(a, ak, bk, st)) {
         g_last_path = 2;
         GAOT_CHECK_LAUNCH("gaot_gemm_f32(skinny)");
         return publish_after();
@@ -523,7 +533,7 @@ static int gemm_run(const gaot_gemm_desc* d, gaot_stream_t stream, const bool dr
     else if (blocks(128, 64) <= 3072)   launch_cfg<128, 64, 2>(a, ak, bk, vec, st);
     else                                launch_cfg<128, 128, 2>(a, ak, bk, vec, st);
     GAOT_CHECK_LAUNCH("gaot_gemm_f32");
-    if (a.split_k > 1) {
+    if (a.split_k > 1 && !raw) {
         const long total = (long)a.M * a.N;
         const bool plain = !a.bias && !a.rowbias && !a.rowscale && !a.aux_out && a.act == GAOT_ACT_NONE &&
                            (!a.residual || (aligned16(a.residual) && a.ldr % 4 == 0)) &&
@@ -538,8 +548,15 @@ static int gemm_run(const gaot_gemm_desc* d, gaot_stream_t stream, const bool dr
         }
         GAOT_CHECK_LAUNCH("gaot_gemm_f32(split-k reduce)");
     }
-    else if (!a.vec_epi) return publish_after();
+    else if (!a.vec_epi && !raw) return publish_after();
     return GAOT_OK;
+}
+
+extern "C" int32_t gaot_gemm_slab_count(int32_t K, int32_t split_k) {
+    const int nkt = cdiv(K > 0 ? K : 1, BK);
+    int split = split_k > 1 ? split_k : 1;
+    if (split > nkt) split = nkt;
+    return cdiv(nkt, cdiv(nkt, split));
 }
 
 

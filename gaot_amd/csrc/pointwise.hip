@@ -112,7 +112,10 @@ template <int NV>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ rstd, const float* __restrict__ dy,
                                                               const float* __restrict__ dx_add, const float* __restrict__ dx_add2, int M,
-                                                              float* __restrict__ dx, float* __restrict__ dwp, float* __restrict__ dx_amax) {
+                                                              float* __restrict__ dx, float* __restrict__ dwp, float* __restrict__ dx_amax,
+                                                              int nz, long zstride, const float* __restrict__ dy_add) {
+    // nz > 1: dy arrives as the K slabs of the split-K product that computed it (zstride apart; gaot_gemm_desc.raw_slabs), summed here in
+    // slab order instead of by a reduce launch of its own; dy_add: a further addend of dy (that product's fused residual)
     constexpr int D = 256 * NV;
     __shared__ f32x4 red[4][NV][64];
     __shared__ float amred[4];
@@ -134,6 +137,8 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_vec_kernel(const float* __res
         for (int v = 0; v < NV; ++v) {
             xv[v] = *reinterpret_cast<const f32x4*>(x + (long)row * D + v * 256 + lane * 4);
             gv[v] = *reinterpret_cast<const f32x4*>(dy + (long)row * D + v * 256 + lane * 4);
+            for (int z = 1; z < nz; ++z) gv[v] += *reinterpret_cast<const f32x4*>(dy + z * zstride + (long)row * D + v * 256 + lane * 4);
+            if (dy_add) gv[v] += *reinterpret_cast<const f32x4*>(dy_add + (long)row * D + v * 256 + lane * 4);
             const f32x4 t = wv[v] * gv[v] * xv[v];
             dot += t[0] + t[1] + t[2] + t[3];
         }
@@ -469,10 +474,25 @@ extern "C" int gaot_rmsnorm_bwd(const float* x, const float* w, const float* rst
     const bool v16 = aligned16(x) && aligned16(w) && aligned16(dy) && aligned16(dx) && aligned16(dw_partial) && (!dx_add || aligned16(dx_add)) &&
                      (!dx_add2 || aligned16(dx_add2));
     const dim3 grid(cdiv(M, RMS_ROWS_PER_BLOCK));
-    if (v16 && D == 256)      hipLaunchKernelGGL(rmsnorm_bwd_vec_kernel<1>, grid, dim3(256), 0, ST(stream), x, w, rstd, dy, dx_add, dx_add2, M, dx, dw_partial, dx_absmax);
-    else if (v16 && D == 512) hipLaunchKernelGGL(rmsnorm_bwd_vec_kernel<2>, grid, dim3(256), 0, ST(stream), x, w, rstd, dy, dx_add, dx_add2, M, dx, dw_partial, dx_absmax);
+    if (v16 && D == 256)      hipLaunchKernelGGL(rmsnorm_bwd_vec_kernel<1>, grid, dim3(256), 0, ST(stream), x, w, rstd, dy, dx_add, dx_add2, M, dx, dw_partial, dx_absmax, 1, 0L, (const float*)nullptr);
+    else if (v16 && D == 512) hipLaunchKernelGGL(rmsnorm_bwd_vec_kernel<2>, grid, dim3(256), 0, ST(stream), x, w, rstd, dy, dx_add, dx_add2, M, dx, dw_partial, dx_absmax, 1, 0L, (const float*)nullptr);
     else hipLaunchKernelGGL(rmsnorm_bwd_kernel, grid, dim3(256), 0, ST(stream), x, w, rstd, dy, dx_add, dx_add2, M, D, dx, dw_partial, dx_absmax);
     GAOT_CHECK_LAUNCH("gaot_rmsnorm_bwd");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_rmsnorm_bwd_slabs(const float* x, const float* w, const float* rstd, const float* dy_slabs, int32_t n_slabs, int64_t slab_stride,
+                                      const float* dy_add, const float* dx_add, const float* dx_add2, int32_t M, int32_t D, float* dx,
+                                      float* dw_partial, float* dx_absmax, gaot_stream_t stream) {
+    GAOT_REQUIRE(x && w && rstd && dy_slabs && dx && dw_partial && M > 0 && n_slabs >= 1 && (n_slabs == 1 || slab_stride >= (int64_t)M * D),
+                 "rmsnorm_bwd_slabs: bad arguments");
+    GAOT_REQUIRE((D == 256 || D == 512) && slab_stride % 4 == 0 && aligned16(x) && aligned16(w) && aligned16(dy_slabs) && aligned16(dx) && aligned16(dw_partial) &&
+                 (!dy_add || aligned16(dy_add)) && (!dx_add || aligned16(dx_add)) && (!dx_add2 || aligned16(dx_add2)),
+                 "rmsnorm_bwd_slabs: D must be 256 or 512 (got %d) and every pointer 16-byte aligned", D);
+    const dim3 grid(cdiv(M, RMS_ROWS_PER_BLOCK));
+    if (D == 256) hipLaunchKernelGGL(rmsnorm_bwd_vec_kernel<1>, grid, dim3(256), 0, ST(stream), x, w, rstd, dy_slabs, dx_add, dx_add2, M, dx, dw_partial, dx_absmax, n_slabs, (long)slab_stride, dy_add);
+    else          hipLaunchKernelGGL(rmsnorm_bwd_vec_kernel<2>, grid, dim3(256), 0, ST(stream), x, w, rstd, dy_slabs, dx_add, dx_add2, M, dx, dw_partial, dx_absmax, n_slabs, (long)slab_stride, dy_add);
+    GAOT_CHECK_LAUNCH("gaot_rmsnorm_bwd_slabs");
     return GAOT_OK;
 }
 

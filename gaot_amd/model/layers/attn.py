@@ -141,6 +141,14 @@ class FFN(nn.Module):
     def fused_weight_groups(self):
         return [[self.w1.weight, self.w3.weight]]
 
+    def forward_normed(self, x, norm):
+        """norm(x) + ffn(norm(x)) as ONE autograd node (ops._NormedSwiGLUFFN: the norm's gradient kernel sums the K slabs of the
+        input-gradient product itself), or None where that form does not apply (conditional norms, CPU, odd shapes)."""
+        if self.correction is not None or not x.is_cuda or type(norm) is not RMSNorm:
+            return None
+        ops.adopt_adjacent_storage([self.w1.weight, self.w3.weight])
+        return ops.normed_swiglu_ffn(x, norm.weight, norm.eps, self.w1.weight, self.w3.weight, self.w2.weight)
+
     def forward(self, x, condition=None, residual=None):
         if x.is_cuda:
             ops.adopt_adjacent_storage([self.w1.weight, self.w3.weight])
@@ -180,8 +188,10 @@ class TransformerBlock(nn.Module):
         else:       # (x, norm(x)) from one node: the residual's gradient is added inside the norm-gradient kernel
             x, h = ops.rms_norm_fork(x, self.attn_norm.weight, self.attn_norm.eps)
         h = self.attn(h, condition=condition, relative_positions=relative_positions, residual=x)   # x + attn(h)
-        h = h if self.ffn_norm is None else self.ffn_norm(h)
-        out = self.ffn(h, condition=condition, residual=h)     # residual on the NORMALISED stream (attn.py:231-232)
+        out = self.ffn.forward_normed(h, self.ffn_norm) if self.ffn_norm is not None else None
+        if out is None:
+            h = h if self.ffn_norm is None else self.ffn_norm(h)
+            out = self.ffn(h, condition=condition, residual=h)     # residual on the NORMALISED stream (attn.py:231-232)
         return (out, alias) if want_input_alias else out
 
 

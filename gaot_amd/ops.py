@@ -392,28 +392,32 @@ def _gemm_path(d, key) -> int:
 def gemm(M: int, N: int, K: int, A, lda, a_kmajor, B, ldb, b_kmajor, out, ldc, *, bias=None, rowbias=None,
          rowbias_period=0, ld_rowbias=0, rowscale=None, act=L.ACT_NONE, aux_in=None, aux_out=None, ld_aux=0,
          residual=None, ldr=0, A2=None, lda2=0, k_split=0, split_k=0, colsum=None, pieces: Optional[int] = None,
-         a_amax=None, b_amax=None, b_is_weight: Optional[bool] = None, a2_amax=None):
+         a_amax=None, b_amax=None, b_is_weight: Optional[bool] = None, a2_amax=None, raw_slabs: bool = False):
     """`a_amax` / `b_amax`: magnitude words of the operands where the caller has them (fp16-piece products); missing ones are looked up /
     computed here.  `b_is_weight` (default: every product but the transposed-A one): B is a parameter (or a view of one).
-    The output's own word, when the kernel published it, is left in `gemm.last_c_amax` (None otherwise)."""
+    The output's own word, when the kernel published it, is left in `gemm.last_c_amax` (None otherwise).
+    `raw_slabs` (with split_k > 1, `out` may be None): no reduce launch; returns (workspace, n_slabs): the product is the sum of the
+    [M, N] slabs workspace[z * M * N:], z < n_slabs, for a consumer that adds them itself (gaot_rmsnorm_bwd_slabs)."""
     _dev(A, B, out, bias, rowbias, rowscale, aux_in, aux_out, residual, A2, colsum)
-    _f32(A, B, out)
+    _f32(A, B) if out is None else _f32(A, B, out)
     split_k = max(1, split_k)
+    if raw_slabs and split_k <= 1:
+        raise ValueError("gemm: raw_slabs needs split_k > 1")
     ws = None
     if split_k > 1:
-        ws = torch.empty(split_k * (M * N + M), device=out.device, dtype=torch.float32)
+        ws = torch.empty(split_k * (M * N + M), device=A.device, dtype=torch.float32)
     kind = "tn" if not a_kmajor else ("nt" if b_kmajor else "nn")
     pc = pieces if pieces is not None else _PIECES[kind]
     d = L.GemmDesc(M, N, K, _p(A), lda, int(a_kmajor), _p(A2), lda2, k_split, _p(B), ldb, int(b_kmajor),
                    _p(out), ldc, _p(bias), _p(rowbias), rowbias_period, ld_rowbias, _p(rowscale), act,
                    _p(aux_in), _p(aux_out), ld_aux, _p(residual), ldr, split_k, _p(ws), _p(colsum),
-                   pc, None, None, None, 0, 0, None, None)
+                   pc, None, None, None, 0, 0, None, None, int(raw_slabs))
     gemm.last_c_amax = None
     if pc == 3 and _F16_PIECES[0]:
         key = (M, N, K, int(a_kmajor), int(b_kmajor), act, split_k, colsum is None, bias is None, rowbias is None, rowscale is None,
                aux_in is None, aux_out is None, residual is None, lda % 4, ldb % 4, ldc % 4, ld_aux % 4, ldr % 4,
-               (A.data_ptr() | B.data_ptr() | out.data_ptr()) & 15, _GEMM_MODE,
-               None if A2 is None else (k_split, lda2 % 4, A2.data_ptr() & 15))
+               (A.data_ptr() | B.data_ptr() | (0 if out is None else out.data_ptr())) & 15, _GEMM_MODE,
+               None if A2 is None else (k_split, lda2 % 4, A2.data_ptr() & 15), raw_slabs)
         d.pieces, d.a_absmax, d.b_absmax = 4, A.data_ptr(), B.data_ptr()      # (placeholders: the dry run reads no memory)
         d.a2_absmax = None if A2 is None else A2.data_ptr()
         path = _gemm_path(d, key)
@@ -432,11 +436,13 @@ def gemm(M: int, N: int, K: int, A, lda, a_kmajor, B, ldb, b_kmajor, out, ldc, *
             elif b_amax is None:
                 b_amax = amax_for(B)
             d.pieces, d.a_absmax, d.b_absmax = 4, a_amax.data_ptr(), b_amax.data_ptr()
-            if colsum is None and _PUBLISH_C:          # (split-K products: the reduce launch publishes it)
+            if colsum is None and _PUBLISH_C and not raw_slabs:          # (split-K products: the reduce launch publishes it)
                 cw = _amax_words(1, out.device)[0]
                 d.c_absmax = cw.data_ptr()
                 gemm.last_c_amax = cw
     L.check(L.load().gaot_gemm_f32(C.byref(d), _stream()), "gaot_gemm_f32")
+    if raw_slabs:
+        return ws, int(L.load().gaot_gemm_slab_count(K, split_k))
     return out
 
 
@@ -1222,7 +1228,7 @@ def mse_loss(pred, target):
     return _MSELoss.apply(pred, target)
 
 
-_MSE_WS: dict = {}        # (device, stream) -> (partials [256] float, ticket [1] int32): scratch of the one-launch form
+_MSE_WS: dict = {}        # device -> (partials [256] float, ticket [1] int32): scratch of the one-launch form (one loss at a time per device)
 
 
 def mse_loss_and_grad(pred, target, tick: Optional[torch.Tensor] = None):
@@ -1232,10 +1238,11 @@ def mse_loss_and_grad(pred, target, tick: Optional[torch.Tensor] = None):
     _dev(pred, target)
     p, t = pred.detach().contiguous(), target.contiguous()
     assert p.shape == t.shape, (p.shape, t.shape)
-    key = (p.device, torch.cuda.current_stream(p.device).cuda_stream)
-    ws = _MSE_WS.get(key)
+    ws = _MSE_WS.get(p.device)
     if ws is None:
-        ws = _MSE_WS[key] = (torch.empty(256, device=p.device, dtype=torch.float32), torch.zeros(1, device=p.device, dtype=torch.int32))
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("mse_loss_and_grad: run once outside graph capture first (its ticket is zeroed when it is allocated)")
+        ws = _MSE_WS[p.device] = (torch.empty(256, device=p.device, dtype=torch.float32), torch.zeros(1, device=p.device, dtype=torch.int32))
     loss = torch.empty((), device=p.device, dtype=torch.float32)
     dp = torch.empty_like(p)
     L.check(L.load().gaot_mse_loss_fwd_bwd(_p(p), _p(t), p.numel(), _p(ws[0]), _p(ws[1]), _p(loss), _p(dp), _p(tick), _stream()),
@@ -2035,6 +2042,95 @@ class _SwiGLUFFN(torch.autograd.Function):
             dw1, dw3 = dw13[:F], dw13[F:]
         dres = dy.reshape(res_shape) if (res_shape is not None and need[4]) else None
         return dx, dw1, dw3, dw2, dres, None
+
+
+class _NormedSwiGLUFFN(torch.autograd.Function):
+    """h = rmsnorm(x) * wn;  y = h + w2 (silu(w1 h) * w3 h): the FFN half of a transformer block (attn.py:229-233: the FFN's residual
+    is its own NORMALISED input) as one node.  Forward: the three launches of rms_norm + _SwiGLUFFN.  Backward: dY w2^T with the gate's
+    derivative in its epilogue, then du [w1; w3] as a split-K product whose K slabs are never reduced on their own: the norm-gradient
+    kernel sums them (+ dY, the residual route) while it forms dx -- one launch instead of reduce + norm gradient."""
+
+    @staticmethod
+    def forward(ctx, x, wn, eps, w1, w3, w2):
+        _dev(x, wn, w1, w3, w2)
+        shp = x.shape
+        K = shp[-1]
+        xm = x.reshape(-1, K).contiguous()
+        M, F = xm.shape[0], w1.shape[0]
+        lib = L.load()
+        h = torch.empty_like(xm)
+        rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+        hw = _want_word(x.device)
+        L.check(lib.gaot_rmsnorm_fwd(_p(xm), _p(wn), M, K, float(eps), _p(h), _p(rstd), _p(hw), _stream()), "gaot_rmsnorm_fwd")
+        w13 = stacked_rows([w1, w3])
+        u = torch.empty(M, 2 * F, device=x.device, dtype=torch.float32)
+        g = torch.empty(M, F, device=x.device, dtype=torch.float32)
+        gemm(M, 2 * F, K, h, K, 1, w13, K, 1, g, F, act=L.ACT_SWIGLU, aux_out=u, ld_aux=2 * F, a_amax=hw)
+        gw = gemm.last_c_amax
+        y = linear_nt(g, w2, residual=h, ldr=K, a_amax=gw)
+        cw = gemm.last_c_amax
+        ctx.amax = (hw, gw)
+        ctx.save_for_backward(xm, wn, rstd, h, u, g, w13, w2)
+        s1, s3, s2 = _claim(w1), _claim(w3), _claim(w2)
+        ctx.slots = (adjacent_rows([s1, s3]) if (s1 is not None and s3 is not None) else None, s2, _claim(wn))
+        ctx.shp = shp
+        yr = y.reshape(shp)
+        _publish(cw, y, yr)
+        return yr
+
+    @staticmethod
+    def backward(ctx, dy):
+        xm, wn, rstd, h, u, g, w13, w2 = ctx.saved_tensors
+        M, F = g.shape
+        K = xm.shape[1]
+        lib = L.load()
+        d, ldd = _rowmajor(dy.reshape(M, K))
+        need = ctx.needs_input_grad
+        w2c, ldw2 = _rowmajor(w2)
+        du = torch.empty(M, 2 * F, device=d.device, dtype=torch.float32)
+        hw, gw = ctx.amax
+        dword = _amax_get(d, dy)
+        gemm(M, F, K, d, ldd, 1, w2c, ldw2, 0, du, 2 * F, act=L.ACT_SWIGLU_BWD, aux_in=u, ld_aux=2 * F, a_amax=dword)
+        duw = gemm.last_c_amax
+        _publish(duw, du)
+        slot13, slot2, slotn = ctx.slots
+        dw2 = matmul_tn(d, g, out=slot2.detach() if slot2 is not None else None, final=slot2 is not None, g_amax=_amax_get(d, dy), x_amax=gw) if need[5] else None
+        dx = dwn = None
+        if need[0] or need[1]:
+            dxm = torch.empty_like(xm)
+            P = int(lib.gaot_rmsnorm_bwd_partials(M))
+            part = torch.empty(P, K, device=xm.device, dtype=torch.float32)
+            dxw = _want_word(xm.device)
+            split = _split_for_narrow_output(M, K, 2 * F)
+            dd = d if ldd == K else d.contiguous()
+            if split > 1 and K in (256, 512):
+                w13c, ldw13 = _rowmajor(w13)
+                ws, nz = gemm(M, K, 2 * F, du, 2 * F, 1, w13c, ldw13, 0, None, K, split_k=split, raw_slabs=True, a_amax=duw)
+                L.check(lib.gaot_rmsnorm_bwd_slabs(_p(xm), _p(wn), _p(rstd), _p(ws), nz, M * K, _p(dd), None, None, M, K, _p(dxm), _p(part), _p(dxw),
+                                                   _stream()), "gaot_rmsnorm_bwd_slabs")
+            else:
+                dh = matmul_nn(du, w13, residual=d, ldr=ldd)
+                L.check(lib.gaot_rmsnorm_bwd(_p(xm), _p(wn), _p(rstd), _p(dh), None, None, M, K, _p(dxm), _p(part), _p(dxw), _stream()), "gaot_rmsnorm_bwd")
+            if need[1]:
+                dwn = colsum(part, out=slotn.detach() if slotn is not None else None, final=slotn is not None)
+            dx = dxm.reshape(ctx.shp)
+            _publish(dxw, dxm, dx)
+        dw1 = dw3 = None
+        if need[3] or need[4]:
+            dw13 = matmul_tn(du, h, out=slot13, final=slot13 is not None, g_amax=_amax_get(du), x_amax=hw)
+            dw1, dw3 = dw13[:F], dw13[F:]
+        return dx, dwn, None, dw1, dw3, dw2
+
+
+_NORMED_FFN = os.environ.get("GAOT_NORMED_FFN", "1") != "0"          # A/B switch (tools): 0 = rms_norm and swiglu_ffn as separate nodes
+
+
+def normed_swiglu_ffn(x, wn, eps, w1, w3, w2):
+    """rmsnorm(x) + SwiGLU feed-forward of it, the residual on the normalised stream (one autograd node; see _NormedSwiGLUFFN);
+    None when the fused epilogues' shape rules do not hold (the caller composes rms_norm and swiglu_ffn instead)."""
+    if _NORMED_FFN and x.is_cuda and _SwiGLUFFN.fusable(x.shape[-1], w1.shape[0]) and w2.shape[0] == x.shape[-1]:
+        return _NormedSwiGLUFFN.apply(x, wn, eps, w1, w3, w2)
+    return None
 
 
 def swiglu_ffn(x, w1, w3, w2, residual=None):

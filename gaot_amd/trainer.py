@@ -350,6 +350,7 @@ class TrainStep:
         self._checked_phases = False
         self._seed = None
         self._ticked = False
+        self._merged = False
         self.fused_loss = True        # loss + its gradient + the optimizer tick in one launch (False: ops.mse_loss through autograd)
         self.comm_enabled = True      # False: skip the gradient exchange (bench.py measures the exposed communication as the difference)
         self.force_comm = False       # True: issue the collectives even in a one-rank group (tests of the RCCL path on one-GPU boxes)
@@ -497,18 +498,24 @@ class TrainStep:
         pool = torch.cuda.graph_pool_handle()
         self._graphs = []
         self._ticked = False
+        # one rank, nothing to exchange between backward and update: the optimizer joins the step's graph (one replay per step)
+        self._merged = self.world == 1 and not self.force_comm and not self.staged
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
             self._loss = self._run_group(0) if self.staged else self._forward_backward()
+            if self._merged:
+                self.opt.step(_sync=False, ticked=self._ticked)
         self._graphs.append(g)
         for gi in range(1, len(self.stage_groups) if self.staged else 1):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
                 self._run_group(gi)
             self._graphs.append(g)
-        self._g_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_opt, pool=pool, capture_error_mode="thread_local"):
-            self.opt.step(_sync=False, ticked=self._ticked)          # (graphs exist on the GPU only: FlatAdamW)
+        self._g_opt = None
+        if not self._merged:
+            self._g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g_opt, pool=pool, capture_error_mode="thread_local"):
+                self.opt.step(_sync=False, ticked=self._ticked)          # (graphs exist on the GPU only: FlatAdamW)
         for dst, src in zip((self.opt.flat_p, self.opt.m, self.opt.v, self.opt.step_count), snap):
             dst.copy_(src)
 
@@ -522,6 +529,8 @@ class TrainStep:
     def _step(self) -> torch.Tensor:
         if not self.use_graph:
             return self._eager_step()
+        if self._graphs is not None and self._merged and self.force_comm:
+            self._graphs = None                  # the exchange was switched on after a one-graph capture: split the step again
         if self._graphs is None:
             self._capture()
         self.opt.sync_hyper()                    # a scheduler may have moved lr since the last step (device buffer, no re-capture)
@@ -540,7 +549,8 @@ class TrainStep:
             for w in works:
                 if w is not None:
                     w.wait()
-        self._g_opt.replay()
+        if self._g_opt is not None:
+            self._g_opt.replay()
         from . import ops
         ops.bump_weights_generation()
         return self._loss

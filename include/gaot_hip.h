@@ -103,7 +103,14 @@ typedef struct gaot_gemm_desc {
     float* c_absmax;
     /* pieces = 4 with A2: the magnitude word of A2 (the kernel scales both halves of the concatenated operand by the larger word) */
     const float* a2_absmax;
+    /* 1 (with split_k > 1 and no epilogue operand: bias / row bias / row scale / activation / aux / residual / colsum): leave the
+     * product as its K slabs -- workspace[z * M * N + m * N + n], z < gaot_gemm_slab_count(K, split_k) -- and launch no reduce; the
+     * consumer sums them (gaot_rmsnorm_bwd_slabs).  C is not written and may be null; c_absmax is ignored. */
+    int32_t raw_slabs;
 } gaot_gemm_desc;
+
+/* the number of K slabs gaot_gemm_f32 cuts a reduction of K into when asked for split_k (32-wide k-tiles, no empty slab) */
+int32_t gaot_gemm_slab_count(int32_t K, int32_t split_k);
 
 int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream);
 /* which kernel family gaot_gemm_f32 WOULD run this product on: 1 = fp32-MFMA tiles, 2 = skinny vector kernels, 3 = split tiles on the
@@ -276,6 +283,13 @@ int gaot_rmsnorm_fwd(const float* x, const float* w, int32_t M, int32_t D, float
 int gaot_rmsnorm_bwd_partials(int32_t M);
 int gaot_rmsnorm_bwd(const float* x, const float* w, const float* rstd, const float* dy, const float* dx_add, const float* dx_add2,
                      int32_t M, int32_t D, float* dx, float* dw_partial, float* dx_absmax /* optional, as y_absmax */, gaot_stream_t stream);
+/* The same with dy = dy_slabs[0] + ... + dy_slabs[n_slabs - 1] (slab_stride floats apart) (+ dy_add): dy is the output of a split-K
+ * product left as raw K slabs (gaot_gemm_desc.raw_slabs) and of its fused residual -- the slab sum happens here, in slab order,
+ * instead of in a reduce launch of its own.  D = 256 or 512, 16-byte aligned pointers (else GAOT_ERR_INVALID: reduce, then
+ * gaot_rmsnorm_bwd). */
+int gaot_rmsnorm_bwd_slabs(const float* x, const float* w, const float* rstd, const float* dy_slabs, int32_t n_slabs, int64_t slab_stride,
+                           const float* dy_add, const float* dx_add, const float* dx_add2, int32_t M, int32_t D, float* dx,
+                           float* dw_partial, float* dx_absmax, gaot_stream_t stream);
 /* SwiGLU gate attn.py:151: u = [u1 | u3] ([M,2F]); g = silu(u1)*u3 ; bwd writes du [M,2F]. */
 int gaot_swiglu_fwd(const float* u, int32_t M, int32_t F, float* g, gaot_stream_t stream);
 int gaot_swiglu_bwd(const float* u, const float* dg, int32_t M, int32_t F, float* du, gaot_stream_t stream);

@@ -1567,3 +1567,44 @@ def test_one_launch_mse_loss_and_gradient():
             assert torch.equal(l1, l0.detach()) and torch.equal(dp, p2.grad) and dp.shape == p2.shape
         assert float(tick) == 43.0
         assert rel(l1, ((p.detach().double() - y.double()) ** 2).mean()) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,F", [(8192, 256, 1024), (2048, 512, 1024), (1000, 256, 512)])
+def test_normed_swiglu_ffn_is_the_composition_of_its_parts(M, K, F):
+    """ops.normed_swiglu_ffn (one node: the norm-gradient kernel sums the K slabs of du [w1; w3] itself, gaot_gemm_desc.raw_slabs +
+    gaot_rmsnorm_bwd_slabs) against rms_norm followed by swiglu_ffn with the residual on the normalised stream: the same forward
+    bits; the same gradients (bit for bit while the slab sums run in the same order, i.e. up to four slabs) and fp32-level against
+    float64."""
+    from gaot_amd import ops
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(4, M // 4, K, generator=g)
+    wn = 1.0 + 0.1 * torch.randn(K, generator=g)
+    w1, w3, w2 = (torch.randn(F, K, generator=g) * 0.06, torch.randn(F, K, generator=g) * 0.06, torch.randn(K, F, generator=g) * 0.03)
+    dy = torch.randn(4, M // 4, K, generator=g)
+    outs = []
+    for fused in (True, False):
+        xd, wnd, w1d, w3d, w2d = (t.cuda().requires_grad_(True) for t in (x, wn, w1, w3, w2))
+        ops.begin_pass()
+        if fused:
+            y = ops.normed_swiglu_ffn(xd, wnd, 1e-6, w1d, w3d, w2d)
+            assert y is not None
+        else:
+            h = ops.rms_norm(xd, wnd, 1e-6)
+            y = ops.swiglu_ffn(h, w1d, w3d, w2d, residual=h)
+        y.backward(dy.cuda())
+        outs.append([y.detach()] + [t.grad for t in (xd, wnd, w1d, w3d, w2d)])
+    assert torch.equal(outs[0][0], outs[1][0])
+    nz = ops._split_for_narrow_output(M, K, 2 * F)
+    for a, b, name in zip(outs[0][1:], outs[1][1:], ("dx", "dwn", "dw1", "dw3", "dw2")):
+        if nz <= 4:
+            assert torch.equal(a, b), name
+        assert rel(a, b) < 2e-6, (name, rel(a, b))
+    # float64
+    X, Wn, W1, W3, W2 = (t.double().requires_grad_(True) for t in (x, wn, w1, w3, w2))
+    hh = X * torch.rsqrt((X * X).mean(-1, keepdim=True) + 1e-6) * Wn
+    yy = hh + (torch.nn.functional.silu(hh @ W1.t()) * (hh @ W3.t())) @ W2.t()
+    yy.backward(dy.double())
+    assert rel(outs[0][0], yy.detach()) < 6e-7
+    for a, r, name in zip(outs[0][1:], (X, Wn, W1, W3, W2), ("dx", "dwn", "dw1", "dw3", "dw2")):
+        assert rel(a, r.grad) < 2e-6, (name, rel(a, r.grad))
