@@ -946,21 +946,29 @@ __global__ void attn_dq_reduce_kernel(const AttnArgs p, int DP) {
     if (p.dqkv_amax) amax_publish(p.dqkv_amax, am, threadIdx.x & 63, (int)blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 
-// 16-byte form for head_dim = DP = 32 (aligned dq): a thread sums one float4 over the slabs; one atomic per workgroup for the word
+// 16-byte form (head_dim % 4 == 0, aligned dq): a thread sums one float4 over the slabs, four slabs in flight; one atomic per workgroup
+// for the word.  DP4 = padded head_dim / 4 (8: head_dim 32; 16 / 32: head_dim <= 64 / <= 128, whose padding columns are skipped).
+template <int DP4>
 __global__ __launch_bounds__(256) void attn_dq_reduce_vec_kernel(const AttnArgs p) {
     __shared__ float amred[4];
-    const int total4 = p.B * p.H * p.S * 8;                   // float4 items (checked on the host: fits an int)
+    const int total4 = p.B * p.H * p.S * DP4;                 // float4 items (checked on the host: fits an int)
     const long slab4 = (long)total4;
     float am = 0.f;
     for (int gid = blockIdx.x * 256 + threadIdx.x; gid < total4; gid += gridDim.x * 256) {
-        const int d4 = gid & 7, bhs = gid >> 3;
+        const int d4 = gid % DP4, bhs = gid / DP4;
+        if (DP4 != 8 && d4 * 4 >= p.D) continue;
         const int s_ = bhs % p.S, bh = bhs / p.S;
         const int h = bh % p.H, b = bh / p.H;
         const f32x4* src = reinterpret_cast<const f32x4*>(p.dq_part) + gid;
         f32x4 acc = src[0];
-        for (int kb = 1; kb < p.n_kblocks; ++kb) acc += src[(long)kb * slab4];
+        int kb = 1;
+        for (; kb + 3 < p.n_kblocks; kb += 4) {
+            const f32x4 t0 = src[(long)kb * slab4], t1 = src[(long)(kb + 1) * slab4], t2 = src[(long)(kb + 2) * slab4], t3 = src[(long)(kb + 3) * slab4];
+            acc += t0; acc += t1; acc += t2; acc += t3;
+        }
+        for (; kb < p.n_kblocks; ++kb) acc += src[(long)kb * slab4];
         acc *= p.scale;
-        *reinterpret_cast<f32x4*>(p.dq + ((long)b * p.S + s_) * p.lddq + h * 32 + d4 * 4) = acc;
+        *reinterpret_cast<f32x4*>(p.dq + ((long)b * p.S + s_) * p.lddq + h * p.D + d4 * 4) = acc;
         am = fmaxf(am, fmaxf(fmaxf(fabsf(acc[0]), fabsf(acc[1])), fmaxf(fabsf(acc[2]), fabsf(acc[3]))));
     }
     if (p.dqkv_amax) amax_publish_block<4>(p.dqkv_amax, am, amred);
@@ -2688,8 +2696,13 @@ extern "C" int gaot_attention_bwd(const float* q, const float* k, const float* v
     }
     const long total = (long)B * H * S * DP;
     int nb = cdiv(total, 256); if (nb > 4096) nb = 4096;
-    if (DP == 32 && head_dim == 32 && aligned16(dq) && lddq % 4 == 0 && total < (1L << 31))
-        hipLaunchKernelGGL(attn_dq_reduce_vec_kernel, dim3(cap_blocks(total / 4, 256, 1024)), dim3(256), 0, ST(stream), a);
+    const bool vec_ok = head_dim % 4 == 0 && aligned16(dq) && lddq % 4 == 0 && total < (1L << 31);
+    if (vec_ok && DP == 32 && head_dim == 32)
+        hipLaunchKernelGGL(attn_dq_reduce_vec_kernel<8>, dim3(cap_blocks(total / 4, 256, 1024)), dim3(256), 0, ST(stream), a);
+    else if (vec_ok && DP == 64)
+        hipLaunchKernelGGL(attn_dq_reduce_vec_kernel<16>, dim3(cap_blocks(total / 4, 256, 2048)), dim3(256), 0, ST(stream), a);
+    else if (vec_ok && DP == 128)
+        hipLaunchKernelGGL(attn_dq_reduce_vec_kernel<32>, dim3(cap_blocks(total / 4, 256, 2048)), dim3(256), 0, ST(stream), a);
     else
         hipLaunchKernelGGL(attn_dq_reduce_kernel, dim3(nb), dim3(256), 0, ST(stream), a, DP);
     GAOT_CHECK_LAUNCH("gaot_attention_bwd");
