@@ -424,7 +424,7 @@ static int gemm_run(const gaot_gemm_desc* d, gaot_stream_t stream, const bool dr
     a.a2_amax = pieces >= 4 ? d->a2_absmax : nullptr;
     // B pre-split into fp16 planes (weights, once per pass): only the split tiles with fp16 pieces read them
     a.Bpl = nullptr; a.ld_bpl = 0; a.bpl_stride = 0;
-    if (pieces >= 4 && d->b_planes != nullptr && g_use_planes && aligned16(d->b_planes) && d->ld_bplanes % 8 == 0 && d->b_plane_stride % 8 == 0 &&
+    if (pieces >= 4 && d->b_planes != nullptr && g_use_planes && aligned16(d->b_planes) && d->ld_bplanes % 8 == 0 && d->b_plane_stride == 16 &&
         d->K % 16 == 0) {
         a.Bpl = reinterpret_cast<const unsigned short*>(d->b_planes); a.ld_bpl = d->ld_bplanes; a.bpl_stride = d->b_plane_stride;
     }

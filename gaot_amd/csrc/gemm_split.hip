@@ -74,8 +74,8 @@ struct SplitGeom {
 // FLUSH > 0: every FLUSH k-tiles (16 k each) the MFMA accumulators are added to running sums on the VECTOR pipe and restart from
 // zero: the bf16 MFMA does not round its accumulator to nearest, so one matrix-pipe accumulation run stays at FLUSH * 16 <= 1 024
 // values of k however long the workgroup's reduction is (costs TM * TN * 16 more registers: the grouped TN kernel has them)
-// BPL (NP = 4, B staged k-contiguous): the B operand arrives ALREADY split -- two fp16 planes of the scaled weight, k-contiguous,
-// element (n, k) of piece q at Bpl[q * bpl_stride + n * ld_bpl + k], built once per pass from the same magnitude word the kernel
+// BPL (NP = 4, B staged k-contiguous): the B operand arrives ALREADY split -- the two fp16 pieces of the scaled weight, k-contiguous in
+// groups of 16: element (n, k) of piece q at Bpl[n * ld_bpl + (k / 16) * 32 + q * 16 + k % 16], built once per pass from the same magnitude word the kernel
 // reads its inverse scale from (gaot_split_f16_planes_grouped): B tiles go from the load registers to LDS as they are -- no
 // vector arithmetic for B at all (half of the k-loop's split work), same number of loads and LDS writes, bit-identical products.
 struct BRegs { f32x4 f[2]; u32x4 pl[2]; };
@@ -166,8 +166,8 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
         if (BPL) {
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) {
-                if (B_FULL) xb.pl[pl] = *reinterpret_cast<const u32x4*>(bp_src + pl * p.bpl_stride + k0);
-                else { const u32x2 v = *reinterpret_cast<const u32x2*>(bp_src + pl * p.bpl_stride + k0); xb.pl[pl] = u32x4{v[0], v[1], 0u, 0u}; }
+                if (B_FULL) xb.pl[pl] = *reinterpret_cast<const u32x4*>(bp_src + pl * 16 + k0 * 2);
+                else { const u32x2 v = *reinterpret_cast<const u32x2*>(bp_src + pl * 16 + k0 * 2); xb.pl[pl] = u32x4{v[0], v[1], 0u, 0u}; }
             }
         }
     };

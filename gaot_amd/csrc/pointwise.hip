@@ -564,8 +564,10 @@ extern "C" int gaot_colsum_grouped(const gaot_colsum_item* items, int32_t n, gao
     return GAOT_OK;
 }
 
-// ---- fp16 planes of weight matrices (gaot_gemm_desc.b_planes), many matrices per launch.  64 x 64 tiles through LDS so that both the
-// plain and the transposed planes are written in whole 128-byte rows.
+// ---- fp16 pieces of weight matrices (gaot_gemm_desc.b_planes), many matrices per launch.  64 x 64 tiles through LDS so that both the
+// plain and the transposed form are written from coalesced reads.  Layout [row][k / 16][piece][k % 16]: the tile kernels fetch the two
+// pieces of a row's 16-wide k group as ONE 64-byte segment (two separate planes were two 32-byte requests: the L2 saw three requests
+// per row and k group where one and a half now do -- tools/pmc_cache.sh: its request rate is what the k-loops run into).
 constexpr int F16PL_GROUP_MAX = 64;
 struct F16PlItem { const float* src; const float* amax; unsigned short* pk; unsigned short* pt; long ld; int rows, cols, tiles_c, wg_end; };
 struct F16PlGroupArgs { int n; F16PlItem it[F16PL_GROUP_MAX]; };
@@ -586,7 +588,6 @@ __global__ __launch_bounds__(256) void split_f16_planes_kernel(const F16PlGroupA
         tile[r][c] = (r0 + r < rows && c0 + c < cols) ? src[(long)(r0 + r) * ld + c0 + c] : 0.f;
     }
     __syncthreads();
-    const long plane = (long)rows * cols;
     const int pp = tid & 31;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {          // 0: as stored [rows][cols]; 1: transposed [cols][rows]
@@ -601,10 +602,12 @@ __global__ __launch_bounds__(256) void split_f16_planes_kernel(const F16PlGroupA
             const float x1 = tr ? tile[2 * pp + 1][orow] : tile[orow][2 * pp + 1];
             unsigned h, m;
             split2h_pair(x0, x1, sc, h, m);
-            if (or0 + orow < orows && oc0 + 2 * pp + 1 < ocols) {          // rows, cols even (checked on the host): pairs are in or out
-                unsigned short* d = out + (long)(or0 + orow) * ocols + oc0 + 2 * pp;
+            if (or0 + orow < orows && oc0 + 2 * pp + 1 < ocols) {          // rows, cols multiples of 16 (checked on the host): pairs are in or out
+                // the two pieces of a 16-wide k group sit side by side: [row][k / 16][piece][k % 16] -- one 64-byte segment per row and group
+                const int oc = oc0 + 2 * pp;
+                unsigned short* d = out + (long)(or0 + orow) * (2 * ocols) + (oc >> 4) * 32 + (oc & 15);
                 *reinterpret_cast<unsigned*>(d) = h;
-                *reinterpret_cast<unsigned*>(d + plane) = m;
+                *reinterpret_cast<unsigned*>(d + 16) = m;
             }
         }
     }
@@ -663,9 +666,9 @@ extern "C" int gaot_split_f16_planes_grouped(const gaot_f16_planes_item* items, 
     GAOT_REQUIRE(items != nullptr && n > 0, "split_f16_planes_grouped: no items");
     for (int i = 0; i < n; ++i) {
         const gaot_f16_planes_item& it = items[i];
-        GAOT_REQUIRE(it.src && it.absmax && (it.planes_k || it.planes_t) && it.rows > 0 && it.cols > 0 && it.rows % 8 == 0 && it.cols % 8 == 0 &&
+        GAOT_REQUIRE(it.src && it.absmax && (it.planes_k || it.planes_t) && it.rows > 0 && it.cols > 0 && it.rows % 16 == 0 && it.cols % 16 == 0 &&
                      it.ld >= it.cols && (reinterpret_cast<uintptr_t>(it.planes_k) & 15u) == 0 && (reinterpret_cast<uintptr_t>(it.planes_t) & 15u) == 0,
-                     "split_f16_planes_grouped: item %d: rows, cols multiples of 8, 16-byte aligned planes", i);
+                     "split_f16_planes_grouped: item %d: rows, cols multiples of 16, 16-byte aligned planes", i);
     }
     for (int i0 = 0; i0 < n; i0 += F16PL_GROUP_MAX) {
         F16PlGroupArgs a;

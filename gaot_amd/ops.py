@@ -309,7 +309,7 @@ def refresh_weight_amax(params, groups=()) -> None:
         rows, cols = t.shape
         pk = pt = None
         # planes for matrices the tile kernels can read as B: once per storage (a parameter inside a fused group is covered by the group)
-        if (_USE_PLANES and rows % 8 == 0 and cols % 8 == 0 and min(rows, cols) >= 32 and not (len(own) == 1 and id(own[0]) in grouped)
+        if (_USE_PLANES and rows % 16 == 0 and cols % 16 == 0 and min(rows, cols) >= 32 and not (len(own) == 1 and id(own[0]) in grouped)
                 and not (lo & 15)):
             key = (lo, rows, cols, t.device.index)
             buf = _PLANE_CACHE.get(key)
@@ -360,15 +360,18 @@ def weight_operand(w2d: torch.Tensor, b_kmajor: bool):
         return word, None, 0, 0
     off = (w2d.data_ptr() - lo) // 4
     r0, c0 = off // cols, off % cols
+    # pieces [row][k / 16][piece][k % 16] (include/gaot_hip.h): a view must start on a 16-wide k group
     if b_kmajor:
-        ptr, ld = pk.data_ptr() + 2 * (r0 * cols + c0), cols
-    elif pt is None:
+        if c0 % 16:
+            return word, None, 0, 0
+        ptr, ld = pk.data_ptr() + 2 * (r0 * 2 * cols + 2 * c0), 2 * cols
+    elif pt is None or r0 % 16:
         return word, None, 0, 0
     else:
-        ptr, ld = pt.data_ptr() + 2 * (c0 * rows + r0), rows
+        ptr, ld = pt.data_ptr() + 2 * (c0 * 2 * rows + 2 * r0), 2 * rows
     if ptr & 15:
         return word, None, 0, 0
-    return word, ptr, ld, rows * cols
+    return word, ptr, ld, 16
 
 
 _AMAX_TRACE = os.environ.get("GAOT_AMAX_TRACE", "0") == "1"      # tools: print every fallback absmax launch with its call site

@@ -92,10 +92,11 @@ typedef struct gaot_gemm_desc {
      * binade of slack costs nothing), read by the kernel -- no host value, so a captured launch follows the data.  gaot_absmax_grouped
      * computes them; producers publish them. */
     const float* a_absmax; const float* b_absmax;
-    /* optional (pieces = 4): Bop ALREADY split into the two fp16 planes the kernel would form from it (weights: once per pass by
+    /* optional (pieces = 4): Bop ALREADY split into the two fp16 pieces the kernel would form from it (weights: once per pass by
      * gaot_split_f16_planes_grouped from the SAME b_absmax word, instead of once per workgroup per k-tile).  Piece q of Bop[k,n] is the
-     * 16-bit word b_planes[q * b_plane_stride + n * ld_bplanes + k] (k-contiguous whatever b_kmajor says).  Bit-identical products;
-     * kernels that do not take planes ignore the field.  ld_bplanes, b_plane_stride multiples of 8, 16-byte aligned. */
+     * 16-bit word b_planes[n * ld_bplanes + (k / 16) * 32 + q * 16 + k % 16] (k-contiguous in groups of 16 whatever b_kmajor says: the
+     * two pieces of a group are one 64-byte segment).  b_plane_stride must be 16.  Bit-identical products; kernels that do not take
+     * the pieces ignore the field.  ld_bplanes a multiple of 8, 16-byte aligned. */
     const void* b_planes; int64_t ld_bplanes; int64_t b_plane_stride;
     /* optional (any pieces): the magnitude word of C as this call stores it (atomic max per slot): the word must be ZERO (or hold a
      * running maximum of the same tensor) before the call.  The next product's a_absmax.  Published from the tile kernels' vector
@@ -116,10 +117,11 @@ int gaot_gemm_f32(const gaot_gemm_desc* d, gaot_stream_t stream);
 /* which kernel family gaot_gemm_f32 WOULD run this product on: 1 = fp32-MFMA tiles, 2 = skinny vector kernels, 3 = split tiles on the
  * bf16 / fp16 matrix pipe (the only ones that read pieces / *_absmax); launches nothing; < 0 on a bad descriptor */
 int gaot_gemm_path(const gaot_gemm_desc* d);
-/* fp16 planes of weight matrices for gaot_gemm_desc.b_planes, n matrices per launch: item i reads src[r * ld + c] (rows x cols), scales
+/* fp16 pieces of weight matrices for gaot_gemm_desc.b_planes, n matrices per launch: item i reads src[r * ld + c] (rows x cols), scales
  * by the power of two its magnitude word `absmax` selects, and writes piece q (0: h = rn16(s x), 1: m = rn16(s x - h)) of element (r, c)
- * to planes_k[q * rows * cols + r * cols + c] (as stored: the k-contiguous B operand of x W^T) and to planes_t[q * rows * cols + c * rows + r]
- * (transposed: the k-contiguous B operand of the input-gradient product dY W); either may be NULL.  rows, cols multiples of 8. */
+ * to planes_k[r * 2 cols + (c / 16) * 32 + q * 16 + c % 16] (as stored: the k-contiguous B operand of x W^T, ld_bplanes = 2 cols) and to
+ * planes_t[c * 2 rows + (r / 16) * 32 + q * 16 + r % 16] (transposed: the k-contiguous B operand of the input-gradient product dY W,
+ * ld_bplanes = 2 rows); either may be NULL.  2 rows cols 16-bit words each; rows, cols multiples of 16. */
 typedef struct gaot_f16_planes_item {
     const float* src; int64_t ld; int32_t rows, cols; const float* absmax; void* planes_k; void* planes_t;
 } gaot_f16_planes_item;

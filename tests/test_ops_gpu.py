@@ -1440,7 +1440,7 @@ def test_colsum_grouped_contiguous_and_column_block_outputs():
 # ------------------------------------------------------------------ pre-split fp16 weight planes
 @pytest.mark.parametrize("M,N,K", [(8192, 2048, 256), (8192, 256, 1024), (4096, 768, 256)])
 def test_gemm_with_presplit_f16_weight_planes_is_bit_identical(M, N, K):
-    """gaot_gemm_desc.b_planes: the two fp16 planes of a weight matrix, built once per pass by gaot_split_f16_planes_grouped from the same
+    """gaot_gemm_desc.b_planes: the two fp16 pieces of a weight matrix (interleaved per 16-wide k group), built once per pass by gaot_split_f16_planes_grouped from the same
     magnitude word the kernel takes its inverse scale from, are exactly what the tile kernel would have formed itself: forward (x W^T)
     and input-gradient (g W) products are BIT-IDENTICAL with and without them -- also for a row block / column block of a registered
     matrix (fused q|k|v weights, the split recovery weight) -- and the planes are really in use (the debug switch changes the kernel)."""
@@ -1452,10 +1452,11 @@ def test_gemm_with_presplit_f16_weight_planes_is_bit_identical(M, N, K):
     ops.begin_pass()
     ops.refresh_weight_amax([W])
     word, pl, ld, stride = ops.weight_operand(W.detach(), True)
-    assert pl is not None and ld == K and stride == N * K
+    assert pl is not None and ld == 2 * K and stride == 16
     # the planes themselves: h + m reproduces s * w up to its last bit (|e| <= 2^-23 |s w|, zero for three values in four) for every
     # element within 2^-16 of the largest, to 2^-25 absolute below that
-    pk = ops._PLANE_CACHE[(W.data_ptr(), N, K, 0)][0].view(torch.float16).view(2, N, K).double()
+    # layout [row][k / 16][piece][k % 16]: the two pieces of a 16-wide k group are one 64-byte segment
+    pk = ops._PLANE_CACHE[(W.data_ptr(), N, K, 0)][0].view(torch.float16).view(N, K // 16, 2, 16).permute(2, 0, 1, 3).reshape(2, N, K).double()
     amax = float(word.max())
     sc = 2.0 ** (13 - math.floor(math.log2(amax)))
     big = W.detach().abs().double() * sc >= 0.25

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Run ONE GEMM shape a few times (for rocprofv3 --pmc).  usage: one_gemm.py nt|nn|tn M N K [tile]"""
+"""Run ONE GEMM shape a few times (for rocprofv3 --pmc).  usage: one_gemm.py nt|nn|tn M N K [tile]
+ONE_GEMM_WEIGHT=1: B is registered as a parameter first (magnitude word + pre-split fp16 planes, as in the model)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -18,6 +19,10 @@ elif kind == "nn":
 else:
     A, B = torch.randn(K, M, device=dev), torch.randn(K, N, device=dev)
     f = lambda: ops.gemm(M, N, K, A, M, 0, B, N, 0, out, N, split_k=ops._split_for_reduction(M, N, K))
+if os.environ.get("ONE_GEMM_WEIGHT") == "1" and kind != "tn":
+    prm = torch.nn.Parameter(B)
+    ops.begin_pass()
+    ops.refresh_weight_amax([prm])
 for _ in range(10):
     f()
 torch.cuda.synchronize()
