@@ -800,7 +800,7 @@ __global__ __launch_bounds__(256) void proj_edge_grad_kernel(const float* __rest
                                                              int Q, int n_src, int C, const int* __restrict__ idx,
                                                              const int* __restrict__ eq, int E, const float* __restrict__ escale,
                                                              float* __restrict__ dk, float* __restrict__ part, int lanes_per_row,
-                                                             int rows_per_block) {
+                                                             int rows_per_block, const int* __restrict__ order) {
     extern __shared__ __attribute__((aligned(16))) float red[];      // [rows_per_block][OC * C]
     const int row = threadIdx.x / lanes_per_row;
     const int c = (threadIdx.x % lanes_per_row) * 4;
@@ -811,7 +811,19 @@ __global__ __launch_bounds__(256) void proj_edge_grad_kernel(const float* __rest
         pw[o] = f32x4{0.f, 0.f, 0.f, 0.f};
         wq[o] = cok ? *reinterpret_cast<const f32x4*>(weff + (long)o * C + c) : pw[o];
     }
-    for (int e = blockIdx.x * rows_per_block + row; e < E && cok; e += gridDim.x * rows_per_block) {
+    // The edges are walked in the order of the TRANSPOSED CSR (`order` = its edge list: sorted by source row j), a contiguous stretch per
+    // workgroup and a contiguous range of stretches per XCD (workgroup b runs on XCD b % 8): the B gathered feature rows f[b,j,:] of
+    // consecutive edges are the same rows, and an XCD's L2 sees one eighth of f.  In CSR order (rows = mesh points in the caller's order,
+    // i.e. spatially random) every edge pulled its B rows through the fabric again: 99 MB per launch for 8 MB of features (PMC).
+    int lb;
+    {
+        const int nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, x = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        lb = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + slot;
+    }
+    const int per = ((E + (int)gridDim.x * rows_per_block - 1) / ((int)gridDim.x * rows_per_block)) * rows_per_block;     // positions per workgroup
+    const int i_end = min(E, (lb + 1) * per);
+    for (int i = lb * per + row; i < i_end && cok; i += rows_per_block) {
+        const int e = order ? order[i] : i;
         const int q = eq[e], j = idx[e];
         f32x4 t[OC];
 #pragma unroll
@@ -963,7 +975,7 @@ extern "C" int gaot_gno_proj_backward(const float* dy, const float* k, const flo
     const size_t lds = sizeof(float) * (size_t)rpb * out_channels * C;
     GAOT_REQUIRE(lds <= 64 * 1024, "gno_proj_backward: C = %d too wide for the workgroup reduction", C);
 #define PE(OC) hipLaunchKernelGGL((proj_edge_grad_kernel<OC>), dim3(nb), dim3(256), lds, ST(stream), dy, k, f, weff, B, Q, n_src, C, index32, \
-                                  edge_query, E, escale, dk, dweff_partial, lpr, rpb)
+                                  edge_query, E, escale, dk, dweff_partial, lpr, rpb, t_edge)
     if (out_channels == 1) PE(1); else if (out_channels == 2) PE(2); else if (out_channels == 3) PE(3); else PE(4);
 #undef PE
     if (df) {

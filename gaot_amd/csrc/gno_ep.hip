@@ -189,9 +189,19 @@ template <int OC, int BCH>
 __global__ __launch_bounds__(256) void proj_fwd_bin_kernel(const float* __restrict__ k, const float* __restrict__ f, const float* __restrict__ weff,
                                                            const float* __restrict__ rowb, const float* __restrict__ bias, int B, int n_src,
                                                            int C, const int* __restrict__ sp, const int* __restrict__ cols, int Q,
-                                                           const float* __restrict__ escale, float* __restrict__ y, int lanes) {
+                                                           const float* __restrict__ escale, float* __restrict__ y, int lanes,
+                                                           const int* __restrict__ order) {
     const int rows_per_block = 256 / lanes;
-    const int r = blockIdx.x * rows_per_block + threadIdx.x / lanes;
+    // `order` (optional): the rows sorted by their first source row, walked in contiguous ranges per XCD (workgroup b runs on XCD b % 8):
+    // mesh points arrive in the caller's order, i.e. spatially random, and every row then pulled its gathered feature rows f[b,j,:]
+    // through the fabric again (91 MB per launch for 8 MB of features, PMC); rows that share latent neighbours now share workgroups
+    int r;
+    {
+        const int nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, x = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int lb = order ? (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + slot : (int)blockIdx.x;
+        const int pos = lb * rows_per_block + threadIdx.x / lanes;
+        r = (order && pos < Q) ? order[pos] : pos;
+    }
     const int lr = threadIdx.x % lanes;
     const int c = lr * 4;
     const int b0 = blockIdx.y * BCH;
@@ -299,7 +309,8 @@ extern "C" int gaot_gno_proj_gather_t_ep(const float* k, const float* dy, const 
 
 extern "C" int gaot_gno_proj_gather_reduce_bin(const float* k, const float* f, const float* weff, const float* rowbias, const float* bias,
                                                int32_t B, int32_t n_src, int32_t C, int32_t out_channels, const int32_t* splits,
-                                               const int32_t* cols, int32_t Q, const float* escale, float* y, gaot_stream_t stream) {
+                                               const int32_t* cols, int32_t Q, const float* escale, float* y, const int32_t* row_order,
+                                               gaot_stream_t stream) {
     GAOT_REQUIRE(B > 0 && out_channels >= 1 && out_channels <= 4 && C > 0 && C % 4 == 0 && C <= 256,
                  "gno_proj_gather_reduce_bin: need 1 <= out_channels <= 4, C %% 4 == 0, C <= 256");
     if (Q == 0) return GAOT_OK;
@@ -308,7 +319,7 @@ extern "C" int gaot_gno_proj_gather_reduce_bin(const float* k, const float* f, c
     constexpr int BCH = 4;
     dim3 grid(cdiv(Q, rpb), cdiv(B, BCH)), block(256);
 #define PG(OC) hipLaunchKernelGGL((proj_fwd_bin_kernel<OC, BCH>), grid, block, 0, ST(stream), k, f, weff, rowbias, bias, B, n_src, C, splits, cols, Q, \
-                                  escale, y, lanes)
+                                  escale, y, lanes, row_order)
     if (out_channels == 1) PG(1); else if (out_channels == 2) PG(2); else if (out_channels == 3) PG(3); else PG(4);
 #undef PG
     GAOT_CHECK_LAUNCH("gaot_gno_proj_gather_reduce_bin");

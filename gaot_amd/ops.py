@@ -1499,7 +1499,7 @@ class _GNOProjTransform(torch.autograd.Function):
         y = torch.empty(B, plan.Q, OC, device=k.device, dtype=torch.float32)
         if _GNO_EP != 0 and B > 1:      # batch inside the lane group: every kernel-value row is read once per 4 samples
             L.check(L.load().gaot_gno_proj_gather_reduce_bin(_p(k), _p(f), _p(weff), _p(rb), _p(bias), B, n_src, Cc, OC, _p(plan.splits),
-                                                             _p(plan.index), plan.Q, _p(escale), _p(y), _stream()),
+                                                             _p(plan.index), plan.Q, _p(escale), _p(y), _p(plan.row_order), _stream()),
                     "gaot_gno_proj_gather_reduce_bin")
         else:
             L.check(L.load().gaot_gno_proj_gather_reduce(_p(k), _p(f), _p(weff), _p(rb), _p(bias), B, n_src, Cc, OC, _p(plan.splits),

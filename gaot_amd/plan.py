@@ -100,6 +100,18 @@ class GeometryPlan:
 
     # ---- lazily derived
     @property
+    def row_order(self) -> Optional[torch.Tensor]:
+        """the rows sorted by their first source row (int32 [Q]; empty rows last), for kernels that gather source-row features per
+        row: rows that share neighbours then share workgroups and L2s (csrc/gno_ep.hip proj_fwd_bin_kernel).  Only for plans that
+        live across steps (built with a host sync: the dict-cached geometries of fx mode) and are worth it; None otherwise."""
+        ro = getattr(self, "_row_order", None)
+        if ro is None and getattr(self, "_src_id", None) is not None and getattr(self, "max_deg", None) is not None and self.E > 0 and self.Q >= 2048 and not torch.cuda.is_current_stream_capturing():
+            first = self.index_long[self.splits[:-1].long().clamp(max=self.E - 1)]
+            key = torch.where(self.deg > 0, first, torch.full_like(first, self.n_src))
+            ro = self._row_order = torch.argsort(key, stable=True).to(torch.int32)
+        return ro
+
+    @property
     def edge_query_long(self) -> torch.Tensor:
         if self._edge_query_long is None:
             self._edge_query_long = self.edge_query[:self.E].long()

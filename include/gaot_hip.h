@@ -419,7 +419,10 @@ int gaot_patchify(const float* in, int32_t B, int32_t H, int32_t W, int32_t Dz, 
  *   gaot_gno_lift_gather_reduce_ep : as gaot_gno_lift_gather_reduce (+ edge_query[E])
  *   gaot_gno_proj_gather_t_ep      : the dF product of gaot_gno_proj_backward over the transposed CSR
  *   gaot_gno_proj_gather_reduce_bin: gaot_gno_proj_gather_reduce with the batch INSIDE the lane group (each kernel-value row is
- *                                    read once for 4 samples instead of once per sample)
+ *                                    read once for 4 samples instead of once per sample).  row_order (optional, [Q]): a permutation
+ *                                    of the rows that puts rows with common source rows next to each other (e.g. sorted by first
+ *                                    neighbour): the rows are walked in that order, a contiguous range per XCD -- same results,
+ *                                    the gathered feature rows stay in the L2 that first fetched them
  * ------------------------------------------------------------------------------------------ */
 int64_t gaot_gno_ep_workspace(int32_t E, int32_t C, int32_t B);
 int gaot_gno_lift_gather_reduce_ep(const float* k, const float* pn, const float* wl, const float* bl, int32_t B, int32_t n_src,
@@ -431,7 +434,8 @@ int gaot_gno_proj_gather_t_ep(const float* k, const float* dy, const float* weff
                               gaot_stream_t stream);
 int gaot_gno_proj_gather_reduce_bin(const float* k, const float* f, const float* weff, const float* rowbias, const float* bias,
                                     int32_t B, int32_t n_src, int32_t C, int32_t out_channels, const int32_t* splits,
-                                    const int32_t* cols, int32_t Q, const float* escale, float* y, gaot_stream_t stream);
+                                    const int32_t* cols, int32_t Q, const float* escale, float* y, const int32_t* row_order,
+                                    gaot_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Operator variants off the default configuration (csrc/glue.hip).

@@ -1004,6 +1004,55 @@ def test_projected_gno_transform_matches_unfused(B, n_src, Q, OC, C, rb, bias):
         assert rel(u, w) < 1e-5, (rel(u, w), rel(v, w))
 
 
+@pytest.mark.parametrize("B,OC", [(8, 1), (5, 2)])
+def test_projected_gno_transform_walks_rows_in_neighbour_order(B, OC):
+    """a dict-cached plan (fx geometries) carries `row_order` (rows sorted by first source row): the batch-inside decoder forward walks
+    its rows in that order, the edge-gradient kernel its edges in the transposed CSR's order, both in contiguous ranges per XCD -- the
+    gathered feature rows stay in cache.  Per row / per edge the arithmetic is unchanged: y and dk are bit-identical to a walk in the
+    caller's order, dF too; dweff (workgroup partials cut differently) to fp32 rounding; everything against float64."""
+    from gaot_amd import ops
+    from gaot_amd.plan import plan_for
+    Q, n_src, C = 6000, 1024, 64
+    g = torch.Generator().manual_seed(B + OC)
+    deg = torch.randint(0, 7, (Q,), generator=g)
+    deg[::7] = 0
+    splits = torch.cat([torch.zeros(1, dtype=torch.long), deg.cumsum(0)])
+    E = int(splits[-1])
+    index = torch.randint(0, n_src, (E,), generator=g)
+    d = "cuda"
+    nb = {"neighbors_index": index.to(d), "neighbors_row_splits": splits.to(d)}
+    plan = plan_for(nb, n_src)
+    order = plan.row_order
+    assert order is not None and sorted(order.tolist()) == list(range(Q))
+    first = index[splits[:-1].clamp(max=E - 1)][order.cpu().long()]
+    nonempty = int((deg > 0).sum())
+    assert bool((first[:nonempty][1:] >= first[:nonempty][:-1]).all()) and bool((deg[order.cpu().long()][nonempty:] == 0).all())
+    k = torch.randn(E, C, generator=g).to(d).requires_grad_()
+    f = torch.randn(B, n_src, C, generator=g).to(d).requires_grad_()
+    weff = (torch.randn(OC, C, generator=g) * 0.3).to(d).requires_grad_()
+    rowb = torch.randn(Q, OC, generator=g).to(d).requires_grad_()
+    a = torch.rand(E, generator=g).to(d)
+    dy = torch.randn(B, Q, OC, generator=g).to(d)
+    params = [k, f, weff, rowb]
+    res = []
+    for ident in (False, True):
+        plan._row_order = torch.arange(Q, device=d, dtype=torch.int32) if ident else order
+        y = ops.gno_proj_transform(k, f, weff, rowb, None, plan, a)
+        res.append((y.detach(), torch.autograd.grad(y, params, dy)))
+    plan._row_order = order
+    assert torch.equal(res[0][0], res[1][0])
+    for u, v, name in zip(res[0][1], res[1][1], ("dk", "df", "dweff", "drowb")):
+        assert torch.equal(u, v), name
+    pd = [p.detach().double().cpu().requires_grad_() for p in params]
+    eq = torch.repeat_interleave(torch.arange(Q), deg)
+    A = torch.zeros(B, Q, C, dtype=torch.float64).index_add_(1, eq, a.double().cpu()[None, :, None] * pd[0][None] * pd[1][:, index, :])
+    yd = A @ pd[2].t() + pd[3][None]
+    gd = torch.autograd.grad(yd, pd, dy.double().cpu())
+    assert rel(res[0][0], yd) < 2e-6
+    for u, w in zip(res[0][1], gd):
+        assert rel(u, w) < 1e-5
+
+
 def test_segment_csr_wrapper_matches_reference_semantics():
     """utils/segment_csr.py (the reference wrapper's signature, utils/segment_csr.py:14-55): sum / mean over CSR segments of
     [E], [E,C] and [B,E,C] inputs, empty segment -> 0, gradient = broadcast of the row gradient"""
