@@ -709,7 +709,16 @@ __global__ __launch_bounds__(256) void lift_edge_grad_kernel(const float* __rest
         wq[ci] = cok ? f32x4{wl[(c + 0) * CI + ci], wl[(c + 1) * CI + ci], wl[(c + 2) * CI + ci], wl[(c + 3) * CI + ci]} : pb;
     }
     if (cok && bl) bq = *reinterpret_cast<const f32x4*>(bl + c);
-    for (int e = blockIdx.x * rows_per_block + row; e < E && cok; e += gridDim.x * rows_per_block) {
+    // a contiguous stretch of the edge list per workgroup, a contiguous range of stretches per XCD (workgroup b runs on XCD b % 8): the
+    // edges are sorted by query row, so an XCD's L2 sees one eighth of the gradient rows dOut[b,q,:] (as proj_edge_grad_kernel)
+    int lb;
+    {
+        const int nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, x = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        lb = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + slot;
+    }
+    const int per = ((E + (int)gridDim.x * rows_per_block - 1) / ((int)gridDim.x * rows_per_block)) * rows_per_block;
+    const int e_end = min(E, (lb + 1) * per);
+    for (int e = lb * per + row; e < e_end && cok; e += rows_per_block) {
         const int q = eq[e], j = idx[e];
         f32x4 t[CI], u = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
