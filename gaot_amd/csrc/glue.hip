@@ -493,7 +493,223 @@ __global__ __launch_bounds__(256) void rollout_update_kernel(const float* __rest
         state[gid] = __fdiv_rn(__fsub_rn(den, um), us);
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// The decoder's output projection folded into the recovery block (ops._ProjFold; magno.py:345-350 then 640-641: two linear maps with
+// nothing in between):  weff = W Wr_a [OC, Cout],  rproj = rowb W^T + b [Q, OC]  and their gradients.  The operands are tiny (OC <= 4
+// output channels, C = Cout = 64) except the row bias [Q, C]: as seven library products and reductions the backward was seven launches of
+// 5-8 us each; here it is one pass over rowb / g_rproj whose last workgroup (ticket) finishes the small matrices.  Fixed summation
+// orders throughout (deterministic).
+// ---------------------------------------------------------------------------------------------
+template <int OC>
+__global__ __launch_bounds__(256) void proj_fold_fwd_kernel(const float* __restrict__ hw, long ldh, const float* __restrict__ hb,
+                                                            const float* __restrict__ wa, long lda, const float* __restrict__ rowb, long ldr,
+                                                            int Q, int C, int Cout, float* __restrict__ weff, float* __restrict__ rproj, int lanes) {
+    const int rpb = 256 / lanes, row = threadIdx.x / lanes, lr = threadIdx.x % lanes, c = lr * 4;
+    const bool cok = c < C;
+    f32x4 wq[OC];
+#pragma unroll
+    for (int o = 0; o < OC; ++o) wq[o] = cok ? *reinterpret_cast<const f32x4*>(hw + o * ldh + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int r0 = blockIdx.x * rpb; r0 < Q; r0 += gridDim.x * rpb) {        // (every lane of a group runs the shuffles)
+        const int r = r0 + row;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (cok && r < Q) v = *reinterpret_cast<const f32x4*>(rowb + (long)r * ldr + c);
+#pragma unroll
+        for (int o = 0; o < OC; ++o) {
+            float d = (v[0] * wq[o][0] + v[1] * wq[o][1]) + (v[2] * wq[o][2] + v[3] * wq[o][3]);
+            for (int off = lanes >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
+            if (lr == 0 && r < Q) rproj[(long)r * OC + o] = d + (hb ? hb[o] : 0.f);
+        }
+    }
+    // weff = W Wr_a by the LAST workgroup of the grid (the first ones carry the most rows): every output's C-term sum is cut into
+    // `segs` stretches over as many threads (a lone thread walking 64 dependent-latency loads took 25 us), joined in stretch order
+    if (blockIdx.x == gridDim.x - 1) {
+        __shared__ float part[256];
+        const int items = OC * Cout;
+        const int segs = items >= 256 ? 1 : 256 / items, per = (C + segs - 1) / segs;
+        for (int i0 = 0; i0 < items; i0 += 256 / segs) {
+            const int i = i0 + (int)threadIdx.x % (256 / segs), sg = (int)threadIdx.x / (256 / segs);
+            float acc = 0.f;
+            if (i < items && sg < segs) {
+                const int o = i / Cout, j = i % Cout;
+                const int c1 = min(C, (sg + 1) * per);
+#pragma unroll 8
+                for (int cc = sg * per; cc < c1; ++cc) acc += hw[o * ldh + cc] * wa[cc * lda + j];
+            }
+            __syncthreads();
+            part[threadIdx.x] = acc;
+            __syncthreads();
+            if (sg == 0 && i < items) {
+                float t = part[threadIdx.x];
+                for (int q = 1; q < segs; ++q) t += part[threadIdx.x + q * (256 / segs)];
+                weff[i] = t;
+            }
+        }
+    }
+}
+
+template <int OC>
+__global__ __launch_bounds__(256) void proj_fold_bwd_kernel(const float* __restrict__ g_weff, const float* __restrict__ g_rproj,
+                                                            const float* __restrict__ hw, long ldh, const float* __restrict__ wa, long lda,
+                                                            const float* __restrict__ rowb, long ldr, int Q, int C, int Cout,
+                                                            float* __restrict__ drowb, float* __restrict__ dhw, long ld_dhw, float* __restrict__ dhb,
+                                                            float* __restrict__ dwa, long ld_dwa, float* __restrict__ ws, int* __restrict__ ticket,
+                                                            int lanes) {
+    extern __shared__ __attribute__((aligned(16))) float red[];      // [rows_per_block][OC * C + OC], later the final sums [OC * C + OC]
+    __shared__ int last_s;
+    const int rpb = 256 / lanes, row = threadIdx.x / lanes, lr = threadIdx.x % lanes, c = lr * 4;
+    const bool cok = c < C;
+    const int W = OC * C + OC;
+    f32x4 wq[OC], pw[OC];
+    float ps[OC];
+#pragma unroll
+    for (int o = 0; o < OC; ++o) {
+        wq[o] = cok ? *reinterpret_cast<const f32x4*>(hw + o * ldh + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        pw[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ps[o] = 0.f;
+    }
+    for (int r = blockIdx.x * rpb + row; r < Q && cok; r += gridDim.x * rpb) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(rowb + (long)r * ldr + c);
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int o = 0; o < OC; ++o) {
+            const float g = g_rproj[(long)r * OC + o];
+            d += wq[o] * g;          // d rowb = g_rproj W
+            pw[o] += v * g;          // g_rproj^T rowb
+            ps[o] += g;              // column sums of g_rproj (bias gradient)
+        }
+        if (drowb) *reinterpret_cast<f32x4*>(drowb + (long)r * C + c) = d;
+    }
+    if (cok) {
+#pragma unroll
+        for (int o = 0; o < OC; ++o) *reinterpret_cast<f32x4*>(red + row * W + o * C + c) = pw[o];
+        if (lr == 0) {
+#pragma unroll
+            for (int o = 0; o < OC; ++o) red[row * W + OC * C + o] = ps[o];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < W; i += 256) {
+        float acc = 0.f;
+        for (int rr = 0; rr < rpb; ++rr) acc += red[rr * W + i];
+        ws[(long)blockIdx.x * W + i] = acc;
+    }
+    // the last workgroup to get here adds the partial rows in workgroup order and finishes the small matrices
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = t == (int)gridDim.x - 1;
+        if (last) {
+            __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        last_s = last;
+    }
+    __syncthreads();
+    if (!last_s) return;
+    // (sums cut into stretches over several threads and joined in stretch order, as the forward's: fixed order, short latency chains)
+    const int nb = gridDim.x;
+    __shared__ float part[256];
+    {
+        const int segs = W >= 256 ? 1 : 256 / W, cols = 256 / segs, per = (nb + segs - 1) / segs;
+        for (int i0 = 0; i0 < W; i0 += cols) {
+            const int i = i0 + (int)threadIdx.x % cols, sg = (int)threadIdx.x / cols;
+            float acc = 0.f;
+            if (i < W && sg < segs) {
+                const int b1 = min(nb, (sg + 1) * per);
+#pragma unroll 8
+                for (int b = sg * per; b < b1; ++b) acc += __builtin_nontemporal_load(ws + (long)b * W + i);
+            }
+            __syncthreads();
+            part[threadIdx.x] = acc;
+            __syncthreads();
+            if (sg == 0 && i < W) {
+                float t = part[threadIdx.x];
+                for (int q = 1; q < segs; ++q) t += part[threadIdx.x + q * cols];
+                red[i] = t;
+            }
+        }
+    }
+    __syncthreads();
+    if (dhw) {
+        const int items = OC * C;
+        const int segs = items >= 256 ? 1 : 256 / items, cols = 256 / segs, per = (Cout + segs - 1) / segs;
+        for (int i0 = 0; i0 < items; i0 += cols) {
+            const int i = i0 + (int)threadIdx.x % cols, sg = (int)threadIdx.x / cols;
+            float acc = 0.f;
+            if (i < items && sg < segs) {
+                const int o = i / C, cc = i % C;
+                const int j1 = min(Cout, (sg + 1) * per);
+#pragma unroll 8
+                for (int j = sg * per; j < j1; ++j) acc += g_weff[(long)o * Cout + j] * wa[cc * lda + j];      // g_weff Wr_a^T
+            }
+            __syncthreads();
+            part[threadIdx.x] = acc;
+            __syncthreads();
+            if (sg == 0 && i < items) {
+                float t = red[i];                                 // (g_rproj^T rowb)[o, c]
+                for (int q = 0; q < segs; ++q) t += part[threadIdx.x + q * cols];
+                dhw[(i / C) * ld_dhw + (i % C)] = t;
+            }
+        }
+    }
+    if (dhb && threadIdx.x < OC) dhb[threadIdx.x] = red[OC * C + threadIdx.x];
+    if (dwa)
+        for (int i = threadIdx.x; i < C * Cout; i += 256) {
+            const int cc = i / Cout, j = i % Cout;
+            float acc = 0.f;
+#pragma unroll
+            for (int o = 0; o < OC; ++o) acc += hw[o * ldh + cc] * g_weff[(long)o * Cout + j];       // W^T g_weff
+            dwa[cc * ld_dwa + j] = acc;
+        }
+}
 }  // namespace gaot
+
+static inline int pf_pow2_ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+static inline int pf_blocks(int Q, int rpb) { int nb = (Q + rpb - 1) / rpb; return nb > 256 ? 256 : (nb < 1 ? 1 : nb); }
+extern "C" int32_t gaot_proj_fold_workspace(int32_t Q, int32_t C, int32_t out_channels) {
+    const int lanes = pf_pow2_ceil(C / 4 > 0 ? C / 4 : 1), rpb = 256 / (lanes < 256 ? lanes : 256);
+    return pf_blocks(Q, rpb > 0 ? rpb : 1) * (out_channels * C + out_channels);
+}
+static int pf_check(const char* who, int32_t Q, int32_t C, int32_t Cout, int32_t OC, const float* hw, int64_t ldh, const float* wa, const float* rowb, int64_t ldr) {
+    GAOT_REQUIRE(Q > 0 && C > 0 && C % 4 == 0 && C <= 256 && Cout > 0 && Cout <= 1024 && OC >= 1 && OC <= 4, "%s: need Q > 0, C %% 4 == 0, C <= 256, 1 <= out_channels <= 4", who);
+    GAOT_REQUIRE(hw && wa && rowb && aligned16(hw) && aligned16(rowb) && ldh % 4 == 0 && ldr % 4 == 0, "%s: null or misaligned operand (hw, rowb: 16 bytes, leading dims %% 4)", who);
+    return GAOT_OK;
+}
+
+extern "C" int gaot_proj_fold_fwd(const float* hw, int64_t ldh, const float* hb, const float* wa, int64_t lda, const float* rowb, int64_t ldr,
+                                  int32_t Q, int32_t C, int32_t Cout, int32_t out_channels, float* weff, float* rproj, gaot_stream_t stream) {
+    if (int rc = pf_check("proj_fold_fwd", Q, C, Cout, out_channels, hw, ldh, wa, rowb, ldr)) return rc;
+    GAOT_REQUIRE(weff && rproj, "proj_fold_fwd: null output");
+    const int lanes = pf_pow2_ceil(C / 4), rpb = 256 / lanes;
+    int nb = (Q + rpb - 1) / rpb; if (nb > 2048) nb = 2048;
+#define PF(OC) hipLaunchKernelGGL((gaot::proj_fold_fwd_kernel<OC>), dim3(nb), dim3(256), 0, ST(stream), hw, (long)ldh, hb, wa, (long)lda, rowb, (long)ldr, Q, C, Cout, weff, rproj, lanes)
+    if (out_channels == 1) PF(1); else if (out_channels == 2) PF(2); else if (out_channels == 3) PF(3); else PF(4);
+#undef PF
+    GAOT_CHECK_LAUNCH("gaot_proj_fold_fwd");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_proj_fold_bwd(const float* g_weff, const float* g_rproj, const float* hw, int64_t ldh, const float* wa, int64_t lda,
+                                  const float* rowb, int64_t ldr, int32_t Q, int32_t C, int32_t Cout, int32_t out_channels, float* drowb,
+                                  float* dhw, int64_t ld_dhw, float* dhb, float* dwa, int64_t ld_dwa, float* workspace, int32_t* ticket,
+                                  gaot_stream_t stream) {
+    if (int rc = pf_check("proj_fold_bwd", Q, C, Cout, out_channels, hw, ldh, wa, rowb, ldr)) return rc;
+    GAOT_REQUIRE(g_weff && g_rproj && workspace && ticket && (!drowb || aligned16(drowb)), "proj_fold_bwd: null gradient / workspace / ticket or misaligned drowb");
+    const int lanes = pf_pow2_ceil(C / 4), rpb = 256 / lanes;
+    const int nb = pf_blocks(Q, rpb);
+    const size_t lds = sizeof(float) * (size_t)rpb * (out_channels * C + out_channels);
+    GAOT_REQUIRE(lds <= 60 * 1024, "proj_fold_bwd: C = %d too wide for the workgroup reduction", C);
+#define PF(OC) hipLaunchKernelGGL((gaot::proj_fold_bwd_kernel<OC>), dim3(nb), dim3(256), lds, ST(stream), g_weff, g_rproj, hw, (long)ldh, wa, (long)lda, rowb, (long)ldr, \
+                                  Q, C, Cout, drowb, dhw, (long)ld_dhw, dhb, dwa, (long)ld_dwa, workspace, ticket, lanes)
+    if (out_channels == 1) PF(1); else if (out_channels == 2) PF(2); else if (out_channels == 3) PF(3); else PF(4);
+#undef PF
+    GAOT_CHECK_LAUNCH("gaot_proj_fold_bwd");
+    return GAOT_OK;
+}
 
 extern "C" int gaot_rollout_input(const float* state, int32_t U, const float* stat, int32_t S, float t0n, float dtn, int32_t n_time,
                                   int64_t rows, float* pn, gaot_stream_t stream) {

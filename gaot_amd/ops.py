@@ -956,15 +956,28 @@ class _ProjFold(torch.autograd.Function):
     weight's slice that split_cols handed out."""
 
     @staticmethod
+    def fusable(hw2, ldh, wa2, rb2, ldr) -> bool:
+        OC, Cc = hw2.shape
+        return (_FUSED_PROJ_FOLD and 1 <= OC <= 4 and Cc % 4 == 0 and Cc <= 256 and wa2.shape[1] <= 1024 and ldh % 4 == 0 and ldr % 4 == 0
+                and not ((hw2.data_ptr() | rb2.data_ptr()) & 15))
+
+    @staticmethod
     def forward(ctx, hw, hb, w_a, rowb):
         _dev(hw, w_a, rowb)
         hw2, ldh = _rowmajor(hw)
         wa2, lda = _rowmajor(w_a)
-        rb2, _ = _rowmajor(rowb)
+        rb2, ldr = _rowmajor(rowb)
         OC, Cc = hw2.shape
-        weff = torch.empty(OC, wa2.shape[1], device=hw.device, dtype=torch.float32)
-        gemm(OC, wa2.shape[1], Cc, hw2, ldh, 1, wa2, lda, 0, weff, wa2.shape[1])
-        rproj = linear_nt(rb2, hw2, bias=hb)
+        Q, Cout = rb2.shape[0], wa2.shape[1]
+        weff = torch.empty(OC, Cout, device=hw.device, dtype=torch.float32)
+        ctx.fused = _ProjFold.fusable(hw2, ldh, wa2, rb2, ldr)
+        if ctx.fused:          # one launch: the row-bias product and the tiny weight product
+            rproj = torch.empty(Q, OC, device=hw.device, dtype=torch.float32)
+            L.check(L.load().gaot_proj_fold_fwd(_p(hw2), ldh, _p(hb), _p(wa2), lda, _p(rb2), ldr, Q, Cc, Cout, OC, _p(weff), _p(rproj), _stream()),
+                    "gaot_proj_fold_fwd")
+        else:
+            gemm(OC, Cout, Cc, hw2, ldh, 1, wa2, lda, 0, weff, Cout)
+            rproj = linear_nt(rb2, hw2, bias=hb)
         ctx.save_for_backward(hw2, wa2, rb2)
         ctx.slots = (_claim_view(hw), _claim(hb), _claim(w_a))
         ctx.has_b = hb is not None
@@ -975,9 +988,36 @@ class _ProjFold(torch.autograd.Function):
         hw2, wa2, rb2 = ctx.saved_tensors
         s_w, s_b, s_a = ctx.slots
         need = ctx.needs_input_grad
+        dhw = dhb = dwa = drowb = None
+        if ctx.fused and g_weff is not None and g_rproj is not None:
+            # every gradient of the node from ONE pass over rowb / g_rproj (the last workgroup finishes the small matrices)
+            lib = L.load()
+            OC, Cc = hw2.shape
+            Q, Cout = rb2.shape[0], wa2.shape[1]
+            g1, g2 = g_weff.contiguous(), g_rproj.contiguous()
+            dev_ = hw2.device
+            if need[0]:
+                dhw = s_w.detach().view(hw2.shape) if s_w is not None else torch.empty(OC, Cc, device=dev_, dtype=torch.float32)
+            if ctx.has_b and need[1]:
+                dhb = s_b.detach() if s_b is not None else torch.empty(OC, device=dev_, dtype=torch.float32)
+            if need[2]:
+                dwa = s_a.detach() if s_a is not None else torch.empty(Cc, Cout, device=dev_, dtype=torch.float32)
+                if dwa.dim() != 2 or dwa.stride(1) != 1:
+                    dwa = torch.empty(Cc, Cout, device=dev_, dtype=torch.float32)
+            if need[3]:
+                drowb = torch.empty(Q, Cc, device=dev_, dtype=torch.float32)
+            tk = _TICKETS.get(dev_)
+            if tk is None:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("_ProjFold.backward: run once outside graph capture first (its ticket is zeroed when it is allocated)")
+                tk = _TICKETS[dev_] = torch.zeros(1, device=dev_, dtype=torch.int32)
+            ws = torch.empty(int(lib.gaot_proj_fold_workspace(Q, Cc, OC)), device=dev_, dtype=torch.float32)
+            L.check(lib.gaot_proj_fold_bwd(_p(g1), _p(g2), _p(hw2), hw2.stride(0) if OC > 1 else Cc, _p(wa2), wa2.stride(0), _p(rb2), rb2.stride(0),
+                                           Q, Cc, Cout, OC, _p(drowb), _p(dhw), (dhw.stride(0) if OC > 1 else Cc) if dhw is not None else 0, _p(dhb),
+                                           _p(dwa), dwa.stride(0) if dwa is not None else 0, _p(ws), _p(tk), _stream()), "gaot_proj_fold_bwd")
+            return dhw, dhb, dwa, drowb
         g1, _ = _rowmajor(g_weff)
         g2, _ = _rowmajor(g_rproj)
-        dhw = dhb = dwa = drowb = None
         if need[0]:
             part = matmul_tn(g2, rb2)                                              # g_rproj^T @ rowb   [OC, C]
             out = s_w.detach().view(hw2.shape) if s_w is not None else None
@@ -989,6 +1029,10 @@ class _ProjFold(torch.autograd.Function):
         if need[3]:
             drowb = matmul_nn(g2, hw2)                                             # g_rproj @ W       [Q, C]
         return dhw, dhb, dwa, drowb
+
+
+_FUSED_PROJ_FOLD = os.environ.get("GAOT_FUSED_PROJ_FOLD", "1") != "0"        # A/B switch (tools): 0 = the node as library products
+_TICKETS: dict = {}          # device -> one zero int32: the last-workgroup ticket of single-launch reductions (they return it to zero)
 
 
 def proj_fold(hw, hb, w_a, rowb):

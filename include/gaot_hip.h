@@ -437,6 +437,19 @@ int gaot_gno_proj_gather_reduce_bin(const float* k, const float* f, const float*
                                     const int32_t* cols, int32_t Q, const float* escale, float* y, const int32_t* row_order,
                                     gaot_stream_t stream);
 
+/* The decoder's output projection folded into the recovery block (magno.py:345-350 then 640-641: two linear maps, nothing in between):
+ *   weff[OC, Cout] = W[OC, C] Wr_a[C, Cout],   rproj[Q, OC] = rowb[Q, C] W^T + b        (the transform kernels above apply them)
+ * and, in ONE launch, every gradient of that node: drowb = g_rproj W, dW = g_rproj^T rowb + g_weff Wr_a^T, db = column sums of g_rproj,
+ * dWr_a = W^T g_weff (any output may be NULL).  OC <= 4, C % 4 == 0, C <= 256.  workspace: gaot_proj_fold_workspace(Q, C, OC) floats;
+ * ticket: one int32, ZERO before the first call (the kernel returns it to zero).  Fixed summation orders (deterministic). */
+int32_t gaot_proj_fold_workspace(int32_t Q, int32_t C, int32_t out_channels);
+int gaot_proj_fold_fwd(const float* hw, int64_t ldh, const float* hb, const float* wa, int64_t lda, const float* rowb, int64_t ldr,
+                       int32_t Q, int32_t C, int32_t Cout, int32_t out_channels, float* weff, float* rproj, gaot_stream_t stream);
+int gaot_proj_fold_bwd(const float* g_weff, const float* g_rproj, const float* hw, int64_t ldh, const float* wa, int64_t lda,
+                       const float* rowb, int64_t ldr, int32_t Q, int32_t C, int32_t Cout, int32_t out_channels, float* drowb,
+                       float* dhw, int64_t ld_dhw, float* dhb, float* dwa, int64_t ld_dwa, float* workspace, int32_t* ticket,
+                       gaot_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Operator variants off the default configuration (csrc/glue.hip).
  * ------------------------------------------------------------------------------------------ */

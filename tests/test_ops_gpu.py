@@ -1658,3 +1658,45 @@ def test_normed_swiglu_ffn_is_the_composition_of_its_parts(M, K, F):
     assert rel(outs[0][0], yy.detach()) < 6e-7
     for a, r, name in zip(outs[0][1:], (X, Wn, W1, W3, W2), ("dx", "dwn", "dw1", "dw3", "dw2")):
         assert rel(a, r.grad) < 2e-6, (name, rel(a, r.grad))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Q,C,Cout,OC,bias", [(16384, 64, 64, 1, True), (5000, 64, 128, 3, False), (300, 32, 64, 4, True)])
+def test_proj_fold_single_launch_node(Q, C, Cout, OC, bias, monkeypatch):
+    """ops.proj_fold (the decoder's output projection folded into the recovery block) as ONE launch each way (gaot_proj_fold_fwd / _bwd:
+    one pass over the [Q, C] row bias, the last workgroup finishes the small matrices) against the same node as library products and
+    against float64; the recovery weight's column block arrives as a strided view, exactly as the model hands it over."""
+    from gaot_amd import ops
+    g = torch.Generator().manual_seed(Q + OC)
+    hw = (torch.randn(OC, C, generator=g) * 0.3)
+    hb = torch.randn(OC, generator=g) if bias else None
+    wr = torch.randn(C, Cout + 32, generator=g) * 0.2            # the recovery weight; its first Cout columns are Wr_a
+    rowb = torch.randn(Q, C, generator=g)
+    gw, gr = torch.randn(OC, Cout, generator=g), torch.randn(Q, OC, generator=g)
+    outs = []
+    for fused in (True, False):
+        monkeypatch.setattr(ops, "_FUSED_PROJ_FOLD", fused)
+        hwd, wrd, rbd = (t.cuda().requires_grad_(True) for t in (hw, wr, rowb))
+        hbd = hb.cuda().requires_grad_(True) if bias else None
+        weff, rproj = ops.proj_fold(hwd, hbd, wrd[:, :Cout], rbd)
+        torch.autograd.backward([weff, rproj], [gw.cuda(), gr.cuda()])
+        outs.append([weff.detach(), rproj.detach(), hwd.grad, wrd.grad, rbd.grad] + ([hbd.grad] if bias else []))
+    HW, WR, RB = (t.double().requires_grad_(True) for t in (hw, wr, rowb))
+    HB = hb.double().requires_grad_(True) if bias else None
+    weff64 = HW @ WR[:, :Cout]
+    rproj64 = RB @ HW.t() + (HB if bias else 0.0)
+    torch.autograd.backward([weff64, rproj64], [gw.double(), gr.double()])
+    refs = [weff64.detach(), rproj64.detach(), HW.grad, WR.grad, RB.grad] + ([HB.grad] if bias else [])
+    for a, b, r, name in zip(outs[0], outs[1], refs, ("weff", "rproj", "dW", "dWr", "drowb", "db")):
+        assert a.shape == r.shape, name
+        assert rel(a, r) < 2e-6 and rel(b, r) < 2e-6, (name, rel(a, r), rel(b, r))
+    # deterministic
+    monkeypatch.setattr(ops, "_FUSED_PROJ_FOLD", True)
+    hwd, wrd, rbd = (t.cuda().requires_grad_(True) for t in (hw, wr, rowb))
+    weff, rproj = ops.proj_fold(hwd, None, wrd[:, :Cout], rbd)
+    torch.autograd.backward([weff, rproj], [gw.cuda(), gr.cuda()])
+    again = [hwd.grad.clone(), wrd.grad.clone()]
+    hwd.grad = wrd.grad = rbd.grad = None
+    weff, rproj = ops.proj_fold(hwd, None, wrd[:, :Cout], rbd)
+    torch.autograd.backward([weff, rproj], [gw.cuda(), gr.cuda()])
+    assert torch.equal(again[0], hwd.grad) and torch.equal(again[1], wrd.grad)
