@@ -21,7 +21,9 @@ for seed in (0, 1):
     steps.append(ts)
 torch.cuda.synchronize()
 def replay(ts):
-    ts._graphs[0].replay(); ts._g_opt.replay()
+    ts._graphs[0].replay()
+    if ts._g_opt is not None:          # (one rank: the optimizer is inside the step's graph)
+        ts._g_opt.replay()
 N = 100
 t0 = time.perf_counter()
 for _ in range(N):
