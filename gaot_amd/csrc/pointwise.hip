@@ -588,7 +588,7 @@ __global__ __launch_bounds__(256) void split_f16_planes_kernel(const F16PlGroupA
         tile[r][c] = (r0 + r < rows && c0 + c < cols) ? src[(long)(r0 + r) * ld + c0 + c] : 0.f;
     }
     __syncthreads();
-    const int pp = tid & 31;
+    const int pp = tid & 15;                        // four consecutive output columns per thread: 8-byte stores of h and of m
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {          // 0: as stored [rows][cols]; 1: transposed [cols][rows]
         unsigned short* __restrict__ out = pass == 0 ? g.it[i].pk : g.it[i].pt;
@@ -596,18 +596,21 @@ __global__ __launch_bounds__(256) void split_f16_planes_kernel(const F16PlGroupA
         const bool tr = pass == 1;
         const int orows = tr ? cols : rows, ocols = tr ? rows : cols, or0 = tr ? c0 : r0, oc0 = tr ? r0 : c0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int orow = (tid >> 5) + 8 * k;
-            const float x0 = tr ? tile[2 * pp][orow] : tile[orow][2 * pp];
-            const float x1 = tr ? tile[2 * pp + 1][orow] : tile[orow][2 * pp + 1];
-            unsigned h, m;
-            split2h_pair(x0, x1, sc, h, m);
-            if (or0 + orow < orows && oc0 + 2 * pp + 1 < ocols) {          // rows, cols multiples of 16 (checked on the host): pairs are in or out
+        for (int k = 0; k < 4; ++k) {
+            const int orow = (tid >> 4) + 16 * k;
+            float x[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = tr ? tile[4 * pp + e][orow] : tile[orow][4 * pp + e];
+            u32x2 h, m;
+            unsigned a_, b_;
+            split2h_pair(x[0], x[1], sc, a_, b_); h[0] = a_; m[0] = b_;
+            split2h_pair(x[2], x[3], sc, a_, b_); h[1] = a_; m[1] = b_;
+            if (or0 + orow < orows && oc0 + 4 * pp + 3 < ocols) {          // rows, cols multiples of 16 (checked on the host): quads are in or out
                 // the two pieces of a 16-wide k group sit side by side: [row][k / 16][piece][k % 16] -- one 64-byte segment per row and group
-                const int oc = oc0 + 2 * pp;
+                const int oc = oc0 + 4 * pp;
                 unsigned short* d = out + (long)(or0 + orow) * (2 * ocols) + (oc >> 4) * 32 + (oc & 15);
-                *reinterpret_cast<unsigned*>(d) = h;
-                *reinterpret_cast<unsigned*>(d + 16) = m;
+                *reinterpret_cast<u32x2*>(d) = h;
+                *reinterpret_cast<u32x2*>(d + 16) = m;
             }
         }
     }
