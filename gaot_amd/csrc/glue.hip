@@ -568,17 +568,32 @@ __global__ __launch_bounds__(256) void proj_fold_bwd_kernel(const float* __restr
         pw[o] = f32x4{0.f, 0.f, 0.f, 0.f};
         ps[o] = 0.f;
     }
-    for (int r = blockIdx.x * rpb + row; r < Q && cok; r += gridDim.x * rpb) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(rowb + (long)r * ldr + c);
-        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+    // four rows in flight per lane group (a workgroup of a large Q walks dozens of rows: one dependent load round each was 45 us at
+    // 131 k rows); the running sums take the rows in the same order whatever the unrolling
+    const int stride = gridDim.x * rpb;
+    for (int r0 = blockIdx.x * rpb + row; r0 < Q && cok; r0 += 4 * stride) {
+        f32x4 v[4]; float g[4][OC];
 #pragma unroll
-        for (int o = 0; o < OC; ++o) {
-            const float g = g_rproj[(long)r * OC + o];
-            d += wq[o] * g;          // d rowb = g_rproj W
-            pw[o] += v * g;          // g_rproj^T rowb
-            ps[o] += g;              // column sums of g_rproj (bias gradient)
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + u * stride;
+            const bool ok = r < Q;
+            v[u] = ok ? *reinterpret_cast<const f32x4*>(rowb + (long)r * ldr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int o = 0; o < OC; ++o) g[u][o] = ok ? g_rproj[(long)r * OC + o] : 0.f;
         }
-        if (drowb) *reinterpret_cast<f32x4*>(drowb + (long)r * C + c) = d;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + u * stride;
+            if (r >= Q) break;
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int o = 0; o < OC; ++o) {
+                d += wq[o] * g[u][o];          // d rowb = g_rproj W
+                pw[o] += v[u] * g[u][o];       // g_rproj^T rowb
+                ps[o] += g[u][o];              // column sums of g_rproj (bias gradient)
+            }
+            if (drowb) *reinterpret_cast<f32x4*>(drowb + (long)r * C + c) = d;
+        }
     }
     if (cok) {
 #pragma unroll
