@@ -19,7 +19,7 @@ dump("gemm", {"kernel_family": f"matrix-pipe GEMM kernels (gemm_split_kernel til
               "launches": n, "hbm_bytes_per_launch": sum(v["hbm_bytes_per_launch"] * v["launches_seen"] for v in gk.values()) / max(n, 1),
               "source": f"{src} (FETCH_SIZE KiB x2 + WRITE_SIZE KiB per launch, launch-weighted mean)"})
 # integral-transform kernels: the family's launches of ONE step
-nk = {k: v for k, v in d.items() if k.startswith(("lift_", "proj_", "ep_fixup", "gno_"))}
+nk = {k: v for k, v in d.items() if k.startswith(("lift_", "proj_", "ep_fixup", "gno_")) and not k.startswith("proj_fold")}      # (proj_fold_*: the projection fold, not a transform)
 dump("gno", {"kernel_family": "integral-transform kernels of one step: " + ", ".join(sorted(nk)),
              "hbm_bytes_per_launch": sum(v["hbm_bytes_per_launch"] * v["launches_seen"] / min(w["launches_seen"] for w in nk.values()) for v in nk.values()),
              "note": "sum over the family's launches of ONE step", "source": src})
