@@ -559,6 +559,24 @@ def hip_reference_pass(ts, model, tensors):
     return out
 
 
+def self_launch(n: int) -> None:
+    """re-run this command line under `python -m torch.distributed.run --nnodes=1 --nproc-per-node n` on a free loopback port and pass
+    its stdout / exit status through (stderr of the ranks goes to ours)"""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on these hosts (RCCL / tensor sharing across processes)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    r = subprocess.run(cmd, env=env)
+    if r.returncode != 0:
+        sys.exit(r.returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -578,9 +596,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N` (no launcher): start the N ranks ourselves, one process per GPU, exactly as the documented
+        # launch line does; rank 0's single JSON line is the only thing the children print to stdout
+        return self_launch(args.gpus)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs a torch.distributed.run launch with --nproc-per-node {args.gpus}")
+        sys.exit(f"--gpus {args.gpus} disagrees with WORLD_SIZE={world} (launch with --nproc-per-node {args.gpus}, or run without a launcher)")
     # test hooks (1-GPU boxes only): run the N > 1 code path with every rank on device 0 over gloo
     if os.environ.get("GAOT_BENCH_FORCE_DEVICE") is not None:
         local = int(os.environ["GAOT_BENCH_FORCE_DEVICE"])

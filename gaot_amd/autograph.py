@@ -254,6 +254,9 @@ def _capture(model, latent, xcoord, pndata, condition, enc=None, dec=None) -> _E
                 v.copy_(g)          # (a slice the grouped launches wrote is final already: ops._DEFERRED_DESTS)
 
     saved_slots = dict(ops._GRAD_SLOTS)
+    e.scratch = {}            # this entry's own tickets / counters (ops.scratch_owner): its replays may overlap another owner's launches
+    owner = ops.scratch_owner(e.scratch)
+    owner.__enter__()
     try:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -289,6 +292,7 @@ def _capture(model, latent, xcoord, pndata, condition, enc=None, dec=None) -> _E
                 sl[2] = next(reached)
         e.epochs = _plan_epochs(model)
     finally:
+        owner.__exit__(None, None, None)
         P.FORCE_GUARD[0] = None
         ops._GRAD_SLOTS.clear()
         ops._GRAD_SLOTS.update(saved_slots)

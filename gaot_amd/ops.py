@@ -146,7 +146,7 @@ if os.environ.get("GAOT_GEMM_PIECES"):          # tools: "3", "2" or "nt,nn,tn" 
 #   * published by the kernel that produced the tensor (GEMM epilogues: gaot_gemm_desc.c_absmax), or
 #   * computed by gaot_absmax_grouped (weights: one launch per forward pass over every parameter, refresh_weight_amax; any other
 #     tensor: on first use, amax_for),
-# and travels as the attribute `_gaot_amax` = (word, tensor._version) of the tensor OBJECT (lost by reshapes / saved_tensors: the
+# and travels as the attribute `_gaot_amax` = (word, tensor._version, pass id) of the tensor OBJECT (lost by reshapes / saved_tensors: the
 # autograd Functions below carry the words of saved operands in their ctx).  Words live in a zeroed arena that is replaced, never
 # reset, at the start of every forward pass (begin_pass), so a captured graph re-zeroes its own words at every replay.
 # --------------------------------------------------------------------------------------------
@@ -177,10 +177,17 @@ _ARENA = [None]
 _WEIGHT_AMAX: list = []        # (lo, hi, word) of the current pass: every parameter and every fused weight group
 
 
+_PASS_ID = [0]                 # serial number of the forward pass in progress: words cached on tensor objects are only trusted within it
+
+
 def begin_pass(keep_weights: bool = False) -> None:
-    """top of a forward pass: magnitude words of the previous pass are not reused (their arena lives on while a ctx still holds it).
+    """top of a forward pass: magnitude words of the previous pass are not reused (their arena lives on while a ctx still holds it),
+    and words remembered on tensor OBJECTS by an earlier pass are ignored (a persistent input -- TrainStep / autograph / rollout static
+    buffers -- keeps its object and, between in-place copies, even its `_version` across the eager warm-up and the capture that follows:
+    a hit there would leave the captured graph without its absmax launch, scaling every replay by the warm-up batch's magnitude).
     keep_weights: the weight table (words + planes) of the previous pass stays (inference over unchanged weights, weights_current())."""
     _ARENA[0] = None
+    _PASS_ID[0] += 1
     if not keep_weights:
         _WEIGHT_AMAX.clear()
         _WEIGHT_TABLE_FOR[0] = None
@@ -192,7 +199,9 @@ _PINNED_TABLES: list = []         # tables a captured inference graph reads with
 
 def weights_current(params) -> bool:
     """is the weight table the one of exactly these parameters as they are now?  (every owner alive, same Parameter._version, same
-    weights_generation(): nothing wrote a weight since refresh_weight_amax built it)"""
+    weights_generation(): nothing wrote a weight since refresh_weight_amax built it).  Writes that bypass both counters -- `p.data.copy_(ema)`,
+    raw-pointer kernels -- must be followed by ops.bump_weights_generation() (trainer.FlatAdamW does; load_state_dict moves Parameter._version): the table
+    holds the B operand itself (fp16 planes), not just a cache key."""
     if not _WEIGHT_AMAX or _WEIGHT_TABLE_FOR[0] != id(params):
         return False
     gen = weights_generation()
@@ -204,9 +213,8 @@ def weights_current(params) -> bool:
 
 def pin_weight_table() -> None:
     """a graph being captured will read the current table's words and planes at every replay: never free them"""
-    _PINNED_TABLES.append(list(_WEIGHT_AMAX))
-    if len(_PINNED_TABLES) > 64:
-        del _PINNED_TABLES[0]
+    _PINNED_TABLES.append(list(_WEIGHT_AMAX))          # (never trimmed: a graph that reads a table may be replayed for as long as the process lives)
+    _PLANES_IN_GRAPHS[0] = True
 
 
 def _amax_words(n: int, device) -> List[torch.Tensor]:
@@ -231,18 +239,29 @@ def _absmax_launch(pairs) -> None:
     L.check(L.load().gaot_absmax_grouped(arr, len(pairs), _stream()), "gaot_absmax_grouped")
 
 
+def _version_of(o) -> int:
+    """Tensor._version, or -1 for inference tensors (torch.inference_mode(): they have no version counter and cannot be written in
+    place after the mode ends, so a constant stands in)"""
+    try:
+        return o._version
+    except RuntimeError:
+        return -1
+
+
 def _amax_get(*objs):
+    pid = _PASS_ID[0]
     for o in objs:
         a = getattr(o, "_gaot_amax", None)
-        if a is not None and a[1] == o._version and a[0].device == o.device:
+        if a is not None and a[2] == pid and a[1] == _version_of(o) and a[0].device == o.device:
             return a[0]
     return None
 
 
 def _amax_set(word, *objs) -> None:
+    pid = _PASS_ID[0]
     for o in objs:
         if o is not None:
-            o._gaot_amax = (word, o._version)
+            o._gaot_amax = (word, _version_of(o), pid)
 
 
 def amax_for(t2d: torch.Tensor, *aliases) -> torch.Tensor:
@@ -273,6 +292,7 @@ def wants_amax() -> bool:
 
 
 _PLANE_CACHE: dict = {}        # (address, rows, cols, device) -> (planes_k, planes_t): persistent fp16 plane buffers of a weight matrix
+_PLANES_IN_GRAPHS = [False]    # a hipGraph was captured over the plane buffers (refresh_weight_amax / pin_weight_table): never evict again
 _USE_PLANES = os.environ.get("GAOT_WEIGHT_PLANES", "1") != "0"        # A/B switch (bit-identical results either way)
 
 
@@ -284,6 +304,8 @@ def refresh_weight_amax(params, groups=()) -> None:
     unchanged (weak reference, Parameter._version, weights_generation())."""
     import weakref
     need_t = torch.is_grad_enabled()
+    if torch.cuda.is_current_stream_capturing():
+        _PLANES_IN_GRAPHS[0] = True       # the graph being captured writes (and its products read) the plane buffers by address at every replay
     items, owners = [], []
     for g in groups:
         g = list(g)
@@ -314,8 +336,8 @@ def refresh_weight_amax(params, groups=()) -> None:
             key = (lo, rows, cols, t.device.index)
             buf = _PLANE_CACHE.get(key)
             if buf is None:
-                if len(_PLANE_CACHE) > 512:
-                    _PLANE_CACHE.clear()
+                if len(_PLANE_CACHE) > 512 and not _PLANES_IN_GRAPHS[0]:
+                    _PLANE_CACHE.clear()          # (only while no captured graph holds plane addresses: those buffers must outlive it)
                 buf = (torch.empty(2 * rows * cols, device=t.device, dtype=torch.int16), torch.empty(2 * rows * cols, device=t.device, dtype=torch.int16))
                 _PLANE_CACHE[key] = buf
             pk, pt = buf
@@ -590,10 +612,43 @@ def matmul_tn(g: torch.Tensor, x2: torch.Tensor, out: Optional[torch.Tensor] = N
 # (trainer.TrainStep, autograph: callers that own the gradient buffers, so nobody reads a gradient before the pass has ended)
 # matmul_tn only queues the product; flush_wgrad() runs ALL queued products as one launch (gaot_gemm_tn_grouped).
 # --------------------------------------------------------------------------------------------
+# Zero-initialised scratch that single-launch reductions leave zero again (last-workgroup tickets, the MSE partials): one set per
+# OWNER.  Launches of one owner are ordered on one stream; two owners in flight at once (an autograph replay overlapping a TrainStep, two
+# steps on two streams) must not share a ticket, so TrainStep / autograph entries / rollout runners run their launches inside
+# `with ops.scratch_owner(their dict)`; everything else shares the per-device default set (one stream at a time per device).
+_SCRATCH_DEFAULT: dict = {}
+_SCRATCH_STACK: list = []
+
+
+class scratch_owner:
+    def __init__(self, store: dict):
+        self.store = store
+
+    def __enter__(self):
+        _SCRATCH_STACK.append(self.store)
+        return self
+
+    def __exit__(self, et, ev, tb):
+        _SCRATCH_STACK.pop()
+        return False
+
+
+def _scratch(kind: str, device, make, what: str):
+    """the current owner's scratch of `kind` on `device`, created (and zero-filled) on first use -- which must not happen inside a graph
+    capture: the fill would be captured, not executed"""
+    store = _SCRATCH_STACK[-1] if _SCRATCH_STACK else _SCRATCH_DEFAULT
+    key = (kind, device.index if device.type == "cuda" else -1)
+    v = store.get(key)
+    if v is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError(f"{what}: run once outside graph capture first (its scratch is zeroed when it is allocated)")
+        v = store[key] = make()
+    return v
+
+
 _WGRAD_DEPTH = [0]
 _WGRAD_QUEUE: list = []
 _COLSUM_QUEUE: list = []
-_WGRAD_COUNTERS: dict = {}
 _WGRAD_COUNTERS_RETIRED: list = []
 _WGRAD_GROUPED = os.environ.get("GAOT_WGRAD_GROUPED", "1") != "0"        # A/B switch
 
@@ -647,18 +702,18 @@ def wgrad_launch(items) -> None:
         L.check(-1, "gaot_gemm_tn_grouped_workspace")
     dev = items[0][0].device
     ws = torch.empty(max(need, 4), device=dev, dtype=torch.float32)
-    # ticket counters: one zero-initialised buffer per device (every launch leaves it zero again).  Launches are ordered on the
-    # calling stream; grouped launches on two streams of one device at the same time would need separate buffers (the C ABI
-    # takes the buffer from the caller).  Never created inside a graph capture: its zero fill would be captured, not executed.
-    key = dev.index
-    ctr = _WGRAD_COUNTERS.get(key)
+    # ticket counters: one zero-initialised buffer per scratch owner and device (every launch leaves it zero again).  Never created
+    # inside a graph capture: its zero fill would be captured, not executed.  A buffer that has become too small is retired, not freed
+    # (a captured graph may hold its address).
+    store = _SCRATCH_STACK[-1] if _SCRATCH_STACK else _SCRATCH_DEFAULT
+    key = ("wgrad_counters", dev.index)
+    ctr = store.get(key)
     if ctr is None or ctr.numel() < cnt.value:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("grouped weight gradients: the ticket counters must exist before graph capture (run one eager step first)")
         if ctr is not None:
-            _WGRAD_COUNTERS_RETIRED.append(ctr)      # a captured graph may hold its address (and zero it at every replay): keep it alive
-        ctr = torch.zeros(max(65536, 4 * cnt.value), device=dev, dtype=torch.int32)
-        _WGRAD_COUNTERS[key] = ctr
+            _WGRAD_COUNTERS_RETIRED.append(ctr)
+        ctr = store[key] = torch.zeros(max(65536, 4 * cnt.value), device=dev, dtype=torch.int32)
     L.check(lib.gaot_gemm_tn_grouped(arr, n, 4 if f16 else _PIECES["tn"], _p(ws), _p(ctr), _stream()), "gaot_gemm_tn_grouped")
 
 
@@ -1006,11 +1061,7 @@ class _ProjFold(torch.autograd.Function):
                     dwa = torch.empty(Cc, Cout, device=dev_, dtype=torch.float32)
             if need[3]:
                 drowb = torch.empty(Q, Cc, device=dev_, dtype=torch.float32)
-            tk = _TICKETS.get(dev_)
-            if tk is None:
-                if torch.cuda.is_current_stream_capturing():
-                    raise RuntimeError("_ProjFold.backward: run once outside graph capture first (its ticket is zeroed when it is allocated)")
-                tk = _TICKETS[dev_] = torch.zeros(1, device=dev_, dtype=torch.int32)
+            tk = _scratch("ticket", dev_, lambda: torch.zeros(1, device=dev_, dtype=torch.int32), "_ProjFold.backward")
             ws = torch.empty(int(lib.gaot_proj_fold_workspace(Q, Cc, OC)), device=dev_, dtype=torch.float32)
             L.check(lib.gaot_proj_fold_bwd(_p(g1), _p(g2), _p(hw2), hw2.stride(0) if OC > 1 else Cc, _p(wa2), wa2.stride(0), _p(rb2), rb2.stride(0),
                                            Q, Cc, Cout, OC, _p(drowb), _p(dhw), (dhw.stride(0) if OC > 1 else Cc) if dhw is not None else 0, _p(dhb),
@@ -1032,7 +1083,6 @@ class _ProjFold(torch.autograd.Function):
 
 
 _FUSED_PROJ_FOLD = os.environ.get("GAOT_FUSED_PROJ_FOLD", "1") != "0"        # A/B switch (tools): 0 = the node as library products
-_TICKETS: dict = {}          # device -> one zero int32: the last-workgroup ticket of single-launch reductions (they return it to zero)
 
 
 def proj_fold(hw, hb, w_a, rowb):
@@ -1275,7 +1325,6 @@ def mse_loss(pred, target):
     return _MSELoss.apply(pred, target)
 
 
-_MSE_WS: dict = {}        # device -> (partials [256] float, ticket [1] int32): scratch of the one-launch form (one loss at a time per device)
 
 
 def mse_loss_and_grad(pred, target, tick: Optional[torch.Tensor] = None):
@@ -1285,11 +1334,8 @@ def mse_loss_and_grad(pred, target, tick: Optional[torch.Tensor] = None):
     _dev(pred, target)
     p, t = pred.detach().contiguous(), target.contiguous()
     assert p.shape == t.shape, (p.shape, t.shape)
-    ws = _MSE_WS.get(p.device)
-    if ws is None:
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("mse_loss_and_grad: run once outside graph capture first (its ticket is zeroed when it is allocated)")
-        ws = _MSE_WS[p.device] = (torch.empty(256, device=p.device, dtype=torch.float32), torch.zeros(1, device=p.device, dtype=torch.int32))
+    ws = _scratch("mse", p.device, lambda: (torch.empty(256, device=p.device, dtype=torch.float32), torch.zeros(1, device=p.device, dtype=torch.int32)),
+                  "mse_loss_and_grad")
     loss = torch.empty((), device=p.device, dtype=torch.float32)
     dp = torch.empty_like(p)
     L.check(L.load().gaot_mse_loss_fwd_bwd(_p(p), _p(t), p.numel(), _p(ws[0]), _p(ws[1]), _p(loss), _p(dp), _p(tick), _stream()),

@@ -351,6 +351,7 @@ class TrainStep:
         self._seed = None
         self._ticked = False
         self._merged = False
+        self._scratch: Dict = {}      # this step's own tickets / counters / loss partials (ops.scratch_owner)
         self.fused_loss = True        # loss + its gradient + the optimizer tick in one launch (False: ops.mse_loss through autograd)
         self.comm_enabled = True      # False: skip the gradient exchange (bench.py measures the exposed communication as the difference)
         self.force_comm = False       # True: issue the collectives even in a one-rank group (tests of the RCCL path on one-GPU boxes)
@@ -458,6 +459,13 @@ class TrainStep:
             self._checked_phases = True
 
     def _eager_step(self):
+        if self.bucket.flat.is_cuda:
+            from . import ops
+            with ops.scratch_owner(self._scratch):
+                return self._eager_step_inner()
+        return self._eager_step_inner()
+
+    def _eager_step_inner(self):
         self._ticked = False          # set by _forward_loss when the loss launch advanced the optimizer's step counter
         if not self.staged:
             loss = self._forward_backward()
@@ -485,6 +493,11 @@ class TrainStep:
         self._graphs = self._g_opt = None
 
     def _capture(self):
+        from . import ops
+        with ops.scratch_owner(self._scratch):
+            self._capture_inner()
+
+    def _capture_inner(self):
         # warm-up iterations must not advance training: snapshot weights + optimizer state, restore after capture
         snap = [t.clone() for t in (self.opt.flat_p, self.opt.m, self.opt.v, self.opt.step_count)]
         side = torch.cuda.Stream()

@@ -318,6 +318,58 @@ def run_condnorm_rollout():
 
 
 
+def run_condnorm_train():
+    """Sequential model with cond-norm, ONE TRAINING STEP the way the reference's sequential trainer takes it
+    (sequential_trainer.py:182-204: pndata = x_batch[..., :-1], condition = x_batch[..., 0, -2:-1]; MSE -> backward -> AdamW,
+    optimizers.py:247-257): loss, every parameter gradient -- the `correction.mlp_{scale,bias}` parameters of every attention and
+    FFN block included (mlp.py:74-124, attn.py:89-90,150-156) -- and the weights after the update.  Same model and data recipe
+    as run_condnorm_rollout (seed 77 / generator 5) plus a seeded target."""
+    from src.model.gaot import GAOT
+    from src.model.layers.magno import MAGNOConfig
+    from src.model.layers.attn import TransformerConfig, AttentionConfig
+    torch.manual_seed(77)
+    m = dict(BASE_M)
+    t = dict(BASE_T)
+    a = dict(BASE_A, use_conditional_norm=True)
+    cfg = NS(args=NS(magno=MAGNOConfig(**m), transformer=TransformerConfig(attn_config=AttentionConfig(**a), **t)),
+             latent_tokens_size=[16, 16])
+    udim, cdim = 2, 1
+    model = GAOT(udim + cdim + 1, udim, cfg)
+    g = torch.Generator().manual_seed(5)
+    lat = grid([16, 16])
+    N, B = 220, 2
+    x = torch.rand(N, 2, generator=g) * 2 - 1
+    xb = torch.randn(B, N, udim + cdim + 2, generator=g)
+    tgt = torch.randn(B, N, udim, generator=torch.Generator().manual_seed(6))
+    out = {"meta.case": "condnorm_train", "meta.magno": repr(m), "meta.transformer": repr(t), "meta.attn": repr(a),
+           "in.latent": lat, "in.xcoord": x, "in.x_batch": xb, "in.target": tgt}
+    for k, v in model.state_dict().items():
+        out[f"w.{k}"] = v.clone()
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=8e-4, weight_decay=1e-5)
+    for step in range(2):          # two steps: the second runs on weights whose correction MLPs have moved
+        opt.zero_grad()
+        pred = model(latent_tokens_coord=lat, xcoord=x, pndata=xb[..., :-1], condition=xb[..., 0, -2:-1])
+        loss = torch.nn.MSELoss()(pred, tgt)
+        loss.backward()
+        if step == 0:
+            out["out.pred"] = pred.detach().clone()
+        out[f"out.loss{step}"] = loss.detach().clone()
+        for k, prm in model.named_parameters():
+            out[f"g{step}.{k}"] = (prm.grad if prm.grad is not None else torch.zeros_like(prm)).clone()
+        opt.step()
+        for k, prm in model.named_parameters():
+            out[f"w{step + 1}.{k}"] = prm.detach().clone()
+    encn = list(model.encoder.neighbor_cache.values())[0]
+    decn = list(model.decoder.neighbor_cache.values())[0]
+    out["csr.enc.s0.index"], out["csr.enc.s0.splits"] = encn[0]["neighbors_index"], encn[0]["neighbors_row_splits"]
+    out["csr.dec.s0.index"], out["csr.dec.s0.splits"] = decn[0]["neighbors_index"], decn[0]["neighbors_row_splits"]
+    np.savez_compressed(os.path.join(HERE, "condnorm_train.npz"), **to_np(out))
+    corr = [k for k in out if k.startswith("g0.") and "correction" in k]
+    print(f"condnorm_train: loss {float(out['out.loss0']):.6f} -> {float(out['out.loss1']):.6f}; {len(corr)} correction gradient tensors, "
+          f"largest {max(float(out[k].abs().max()) for k in corr):.3e}")
+
+
 def run_c2_stats_gates():
     """The reference's OWN float32 -> float64 movement at the bench configuration (BASELINE configs[1]: 16 384 nodes, batch 8, the
     example model; weights and data exactly as bench.py builds them).
@@ -413,6 +465,8 @@ if __name__ == "__main__":
             run_case(c)
     if not only or "condnorm_rollout" in only:
         run_condnorm_rollout()
+    if not only or "condnorm_train" in only:
+        run_condnorm_train()
     if not only or "neighbor_kats" in only:
         run_neighbor_kats()
     if not only or "c2_stats_gates" in only:

@@ -373,6 +373,72 @@ def test_c3_max_neighbors_sampling_on_gpu(vx, monkeypatch):
     assert TrainStep(model, use_graph=True).use_graph is False
 
 
+@pytest.mark.parametrize("vx", [False, True])
+def test_c3_ratio_sampling_on_gpu(vx, monkeypatch):
+    """row A12, the other strategy (edge_drop.py:54-68 of the reference): sampling_strategy='ratio' keeps each edge with probability
+    sample_ratio, drawn on the device inside the model.  The drawn CSR lists are recorded and handed to the oracle, which must agree on
+    output, loss and gradients; the draw itself must be a sub-sequence of every row (order kept), keep about the stated share, differ
+    between two forward passes, and be skipped in eval mode."""
+    from gaot_amd.model.layers import magno as M
+    from oracle import gaot_oracle as O
+    B, N, ratio = 2, 4096, 0.6
+    model, sd, ocfg, lat, x, p, tgt, enc, dec = _c3_case(B=B, N=N, spread=0.2, seed=4, sampling_strategy="ratio", sample_ratio=ratio)
+    if not vx:
+        x = x[0]
+        enc, dec = [enc[0][0]], [dec[0][0]]
+    drawn = []
+    real = M.apply_edge_drop_csr
+
+    def recording(nb, *a, **k):
+        out = real(nb, *a, **k)
+        drawn.append((out["neighbors_index"].cpu(), out["neighbors_row_splits"].cpu()))
+        return out
+
+    monkeypatch.setattr(M, "apply_edge_drop_csr", recording)
+    model.to(dev()).train()
+    todev = (lambda rows: [[csr_dict(c) for c in row] for row in rows]) if vx else (lambda rows: [csr_dict(c) for c in rows])
+    kw = dict(latent_tokens_coord=lat.to(dev()), xcoord=x.to(dev()), encoder_nbrs=todev(enc), decoder_nbrs=todev(dec))
+    from gaot_amd import ops
+    pred = model(pndata=p.to(dev()), **kw)
+    loss = ops.mse_loss(pred, tgt.to(dev()))
+    loss.backward()
+    n_graphs = 2 * B if vx else 2
+    assert len(drawn) == n_graphs
+    if vx:
+        enc_d, dec_d = [[c] for c in drawn[:B]], [[c] for c in drawn[B:]]
+        full_graphs = [e[0] for e in enc] + [d[0] for d in dec]
+    else:
+        enc_d, dec_d = [drawn[0]], [drawn[1]]
+        full_graphs = [enc[0], dec[0]]
+    for (fi, fs), (ki, ks) in zip(full_graphs, drawn):
+        E, Ek = int(fi.numel()), int(ki.numel())
+        assert abs(Ek / E - ratio) < 0.03, (Ek, E)                        # ~55 k draws per graph: 3 sigma is 0.006
+        assert int(ks[-1]) == Ek and ks.numel() == fs.numel() and bool(((ks[1:] - ks[:-1]) <= (fs[1:] - fs[:-1])).all())
+        for q in (0, 17, int(fs.numel()) // 2, int(fs.numel()) - 2):     # kept neighbours: a sub-sequence of the row, order preserved
+            row, sub = fi[fs[q]:fs[q + 1]].tolist(), ki[ks[q]:ks[q + 1]].tolist()
+            it = iter(row)
+            assert all(v in it for v in sub), (q, row, sub)
+    batch = dict(latent=lat, xcoord=x, pndata=p, target=tgt, encoder_nbrs=enc_d, decoder_nbrs=dec_d)
+    loss_ref, grads_ref, _, _, pred_ref = O.train_step(sd, ocfg, batch, return_pred=True)
+    assert rel_l2(pred.detach().cpu(), pred_ref) < OUT_TOL
+    assert abs(float(loss) - float(loss_ref)) < LOSS_TOL * abs(float(loss_ref))
+    errs = grad_errors(model, grads_ref)
+    assert max(errs.values()) < GRAD_TOL, max(errs, key=errs.get)
+    # a second pass draws another subset; eval mode draws none (the full graph: edge_drop.py `if not training`)
+    with torch.no_grad():
+        model(pndata=p.to(dev()), **kw)
+    assert len(drawn) == 2 * n_graphs and not torch.equal(drawn[0][1], drawn[n_graphs][1])
+    model.eval()
+    with torch.no_grad():
+        y_eval = model(pndata=p.to(dev()), **kw)
+    assert all(torch.equal(d[0], f[0]) and torch.equal(d[1], f[1]) for d, f in zip(drawn[2 * n_graphs:], full_graphs)) or len(drawn) == 2 * n_graphs
+    pred_full = O.gaot_forward(sd, ocfg, lat, x, p, encoder_nbrs=enc, decoder_nbrs=dec)
+    assert rel_l2(y_eval.cpu(), pred_full) < OUT_TOL
+    from gaot_amd.trainer import TrainStep
+    model.train()
+    assert TrainStep(model, use_graph=True).use_graph is False
+
+
 # ------------------------------------------------------------------------------------------------ C1 and C5
 def test_c1_poisson_1k_nodes_batch4_many_empty_tokens():
     """BASELINE configs[0] at its stated shape: 1 024 nodes, batch 4, example model; ~43 % of the 4 096 latent tokens have

@@ -138,6 +138,23 @@ def test_bench_two_ranks_on_one_gpu_over_gloo_line():
     assert line["comm"]["ms_per_step_without_exchange"] > 0
 
 
+def test_bench_plain_command_self_launches_two_ranks():
+    """`python bench.py --gpus 2` WITHOUT any launcher (WORLD_SIZE unset): bench.py starts the two ranks itself under
+    torch.distributed.run and prints exactly one JSON line, from rank 0, whose `comm` proves that two ranks took part"""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update({"GAOT_BENCH_FORCE_DEVICE": "0", "GAOT_BENCH_BACKEND": "gloo"})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2"],
+                       capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 16 and line["value"] > 0
+    assert line["comm"]["n_ranks_seen"] == 2 and line["comm"]["param_checksums_identical"] is True
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
 def test_bench_two_gpus_rccl_line():
     """bench.py exactly as the driver launches it for N = 2: one JSON line with n_gpus 2, weak scaling, and the `comm` object

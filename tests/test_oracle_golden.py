@@ -77,6 +77,29 @@ def test_condnorm_pair_forward_and_rollouts():
         assert rel_l2(r, g.t(f"out.rollout.{mode}")) < 1e-5, mode
 
 
+def test_condnorm_train_steps():
+    """two sequential-trainer steps of the cond-norm model (sequential_trainer.py:182-204): loss, EVERY gradient -- the
+    correction.mlp_{scale,bias} parameters of each attention and FFN block without any floor on the denominator -- and the weights
+    after each AdamW update, against vectors exported from the reference (make_golden.run_condnorm_train)"""
+    g = Golden("condnorm_train")
+    cfg = g.oracle_config()
+    xb = g.t("in.x_batch")
+    batch = {"latent": g.t("in.latent"), "xcoord": g.t("in.xcoord"), "pndata": xb[..., :-1], "target": g.t("in.target"),
+             "condition": xb[..., 0, -2:-1]}
+    sd, state = g.state_dict, None
+    assert sum("correction" in k for k in sd) == 24
+    for step in range(2):
+        loss, grads, sd, state = O.train_step(sd, cfg, batch, lr=8e-4, weight_decay=1e-5, state=state)
+        assert abs(float(loss) - float(g.t(f"out.loss{step}"))) < 1e-6
+        for k, ref in g.group(f"g{step}.").items():
+            if "correction" in k:
+                assert rel_l2(grads[k], ref) < 5e-5, (step, k, rel_l2(grads[k], ref))
+            else:
+                assert (grads[k] - ref).abs().max().item() / max(ref.abs().max().item(), 1e-4) < GRAD_TOL, (step, k)
+        for k, ref in g.group(f"w{step + 1}.").items():
+            assert (sd[k] - ref).abs().max().item() < 2e-6, (step, k)
+
+
 def test_neighbor_known_answers():
     z = Golden.__new__(Golden)
     z.raw = dict(np.load(__import__("os").path.join(__import__("tests._golden", fromlist=["x"]).GOLDEN_DIR, "neighbor_kats.npz")))
