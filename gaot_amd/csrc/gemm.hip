@@ -366,6 +366,7 @@ extern "C" int gaot_debug_set_gemm_pieces(int n) {
 int gaot_forced_pieces() { return g_split_pieces_forced ? g_split_pieces : 0; }
 
 static int g_use_planes = 1;     // 0: ignore gaot_gemm_desc.b_planes (A/B switch)
+extern "C" unsigned gaot_debug_split_redo_count(int reset) { return gaot::split_redo_count(reset != 0); }
 extern "C" int gaot_debug_set_gemm_planes(int on) { const int old = g_use_planes; g_use_planes = on; return old; }
 static int g_ablate = 0;
 extern "C" int gaot_debug_set_gemm_ablate(int bits) { const int old = g_ablate; g_ablate = bits; return old; }
@@ -423,7 +424,7 @@ static int gemm_run(const gaot_gemm_desc* d, gaot_stream_t stream, const bool dr
     a.a_amax = pieces >= 4 ? d->a_absmax : nullptr; a.b_amax = pieces >= 4 ? d->b_absmax : nullptr; a.c_amax = d->c_absmax;
     a.a2_amax = pieces >= 4 ? d->a2_absmax : nullptr;
     // B pre-split into fp16 planes (weights, once per pass): only the split tiles with fp16 pieces read them
-    a.Bpl = nullptr; a.ld_bpl = 0; a.bpl_stride = 0;
+    a.Bpl = nullptr; a.ld_bpl = 0; a.bpl_stride = 0; a.bpl_flag = 0;
     if (pieces >= 4 && d->b_planes != nullptr && g_use_planes && aligned16(d->b_planes) && d->ld_bplanes % 8 == 0 && d->b_plane_stride == 16 &&
         d->K % 16 == 0) {
         a.Bpl = reinterpret_cast<const unsigned short*>(d->b_planes); a.ld_bpl = d->ld_bplanes; a.bpl_stride = d->b_plane_stride;

@@ -19,6 +19,7 @@ struct GemmArgs {
     const float* a2_amax;   // with A2: max |A2| (the kernel scales both A operands by the larger of the two words)
     const float* a_amax; const float* b_amax;   // fp16-piece products (gemm_split.hip NP = 4): device words holding max |A|, max |B| (or a bound)
     const unsigned short* Bpl; long ld_bpl; long bpl_stride;   // optional (NP = 4): B pre-split into two k-contiguous fp16 planes of the scaled weight
+    int bpl_flag;           // with Bpl: which float of b_amax's first line holds the planes' range verdict (1: along rows, 2: along columns of W as stored)
     float* c_amax;          // optional: max |C| as stored, accumulated by atomic max on the float's bit pattern (zero before the launch)
     int ablate;             // tuning only (gaot_debug_set_gemm_ablate): 1 = no in-loop global loads, 2 = no LDS staging/barriers, 4 = no stores
 };
@@ -229,6 +230,7 @@ void launch_glds(GemmArgs& a, bool a_kmajor, bool b_kmajor, int tile, hipStream_
 
 // split-bf16 kernel (gemm_split.hip): fp32 product from six bf16 MFMA piece products, 128x128 tiles
 void launch_split(GemmArgs& a, bool a_kmajor, bool b_kmajor, hipStream_t st, int bm = 128, int pieces = 3);
+unsigned split_redo_count(bool reset);      // tiles that took the fp16 pieces' second (three-piece) pass: a device counter for tests / tools
 // grouped weight-gradient launch (gemm_split.hip): prefix table / workspace need of n items; the launch itself
 struct TnGroupArgs;
 long plan_tn_grouped(const gaot_wgrad_item* items, int n, TnGroupArgs* args, int* n_counters, int* n_wg);

@@ -69,6 +69,25 @@ struct SplitGeom {
     static constexpr int SMEM_BYTES = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
 };
 
+// ---- Dynamic range of the fp16 pieces (NP = 4).  One power of two per TENSOR brings the operand's largest magnitude to [2^13, 2^14);
+// an element v of the scaled operand is carried as h + m with |v - h - m| <= max(2^-23 |v|, 2^-25): m goes subnormal below |v| ~ 2^-3, so
+// elements more than ~2^16 below the tensor's largest carry an ABSOLUTE error F = 2^-25 / scale instead of a relative one.  For one
+// output y = sum_i a_i b_i the floors add  F_a sum |b_i| + F_b sum |a_i|  to the error 2^-22 sum |a_i b_i| that fp32-level products
+// carry anyway; with t_a, t_b the typical magnitudes of the row of A and the row of B being contracted, the floors stay below that
+// as long as   (max_a / t_a) x (max_b / t_b) <= ~2^16.5   (max = the TENSOR's largest magnitude, which sets the scale).
+// Normalised activations, weights and gradients sit at 2^3 .. 2^10 per operand (measured on the bench step: tools/redo_count.py); what
+// breaks the bound is the "massive activation" pattern -- one token or one channel 10^4 .. 10^6 times larger than the rest, or rows /
+// channels that much smaller -- where every ordinary row sits 2^20 below the tensor's maximum.
+// So every workgroup watches what it stages: per thread and k-tile the largest magnitude of its 8 elements (8 consecutive k of one
+// row, or 2 k x 4 rows), and over its k range the SUM OF THE EXPONENTS of the non-zero group maxima (their geometric mean: the "typical"
+// magnitude of the thread's row, robust against the outliers themselves) -- five vector instructions per operand and k-tile.  At the end
+// L = log2(scaled tensor maximum / that mean), the largest L over the workgroup's threads per operand, and if L_a + L_b exceeds 17 -- or
+// a mean sits ABOVE the tensor's claimed maximum: a stale word -- the workgroup computes its tile AGAIN on the fp32 MFMA, straight from
+// the fp32 operands (no pieces, no scales: exact for any spread; one LDS stage, a plain loop: slow, and rare).  Exact zeros are exempt (empty latent tokens, ReLU outputs).  Pre-split weight planes
+// carry their L in the weight's magnitude word (gaot_split_f16_planes_grouped: float 1 = along the rows, float 2 = along the columns of
+// the matrix as stored).
+__device__ unsigned g_split_redo_tiles = 0;          // tiles that took the second pass since the last gaot_debug_split_redo_count(1)
+
 // ONE output tile (`logical` in the XCD-aware order of the caller, K slab `zs` of p.split_k) of the product described by p.
 // Shared by the per-product kernel below and by the grouped weight-gradient kernel (one launch over many products).
 // FLUSH > 0: every FLUSH k-tiles (16 k each) the MFMA accumulators are added to running sums on the VECTOR pipe and restart from
@@ -79,9 +98,20 @@ struct SplitGeom {
 // reads its inverse scale from (gaot_split_f16_planes_grouped): B tiles go from the load registers to LDS as they are -- no
 // vector arithmetic for B at all (half of the k-loop's split work), same number of loads and LDS writes, bit-identical products.
 struct BRegs { f32x4 f[2]; u32x4 pl[2]; };
-template <bool AK, bool BKM, int BM, int ABL, int NP, int FLUSH = 0, bool BPL = false>
+// NP = 4 watches the operands' range while it stages them and, when the tile needs it, computes it a second time on the fp32 MFMA (above).
+// BREAL (with BPL, where BKM describes the PLANES and is true): is B itself k-contiguous in memory?  (NT: yes, the planes of W as stored;
+// NN: no, the planes of W^T) -- what the second pass reads
+template <bool AK, bool BKM, int BM, int ABL, int NP, int FLUSH = 0, bool BPL = false, bool BREAL = BKM>
 __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* smem_raw, const int logical, const int zs) {
     using G = SplitGeom<BM, NP>;
+#ifndef GAOT_NO_DETECT
+    constexpr bool DETECT = NP == 4 && ABL == 0;
+#else
+    constexpr bool DETECT = false;          // A/B builds: without the range tracking (and without the second pass)
+#endif
+    // per operand ONE register: sum of the biased exponents of this thread's non-zero group maxima (low 20 bits: < 4 096 k-tiles x 255)
+    // and their count (high 12 bits)
+    unsigned ec_a = 0u, ec_b = 0u;
     constexpr int NPL = G::NPL;
     constexpr int BN = G::BN, NW = G::NW, NT = G::NT, WAVES_N = G::WAVES_N, WM = G::WM, WN = G::WN, TM = G::TM, TN = G::TN;
     constexpr int ABYTES = BM * 4;       // row stride of a row-contiguous A plane ([k pair][BM rows] of packed dwords; BM = 64 only)
@@ -229,9 +259,19 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
             }
         }
     };
+    auto track = [&](unsigned& ec, const f32x4 (&r)[2]) {
+        const float t = fmaxf(fmaxf(fmaxf(fabsf(r[0][0]), fabsf(r[0][1])), fmaxf(fabsf(r[0][2]), fabsf(r[0][3]))),
+                              fmaxf(fmaxf(fabsf(r[1][0]), fabsf(r[1][1])), fmaxf(fabsf(r[1][2]), fabsf(r[1][3]))));
+        const unsigned e = __float_as_uint(t) >> 23;          // 0 for a zero (or denormal) group: exempt
+        ec += e + (e != 0u ? (1u << 20) : 0u);
+    };
     auto sstore = [&](int stage, const f32x4 (&xa)[2], const BRegs& xb, bool live) {
         if (ABL & 32) { asm volatile("" :: "v"(xa[0][0]), "v"(xb.f[0][0]), "v"(xa[1][3]), "v"(xb.f[1][3])); return; }     // tuning: no LDS plane writes
         unsigned char* sa = smem_raw + stage * STAGE;
+        if (DETECT) {
+            track(ec_a, xa);
+            if (!BPL) track(ec_b, xb.f);
+        }
         stage_store(sa, xa, AK, A_FULL, PA, 128, BM == 64, sc_a);
         if (BPL) {
             unsigned char* sb = sa + NPL * PA;
@@ -268,8 +308,7 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
 
     // one k-tile: MFMAs on `stage` while the NEXT tile (registers xa/xb) is split into the other stage and the tile
     // after that is fetched into (ya/yb).  Branch-free, so the scheduler can interleave the three streams.
-    auto step = [&](int kt, int stage, f32x4 (&xa)[2], BRegs& xb, f32x4 (&ya)[2], BRegs& yb) {
-        gload(kt + 2, ya, yb);
+    auto compute = [&](int stage) {
         const unsigned char* sa = smem_raw + stage * STAGE;
         const unsigned char* sb = sa + NPL * PA;
         bf16x8 a[TM][3], b[TN][3];
@@ -319,6 +358,10 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
                 acc[i][j] = mfma<ABL>(a[i][0], b[j][0], acc[i][j]);
             }
         }
+    };
+    auto step = [&](int kt, int stage, f32x4 (&xa)[2], BRegs& xb, f32x4 (&ya)[2], BRegs& yb) {
+        gload(kt + 2, ya, yb);
+        compute(stage);
         sstore(stage ^ 1, xa, xb, kt + 1 < kt_end);
         // interleave: one MFMA, a few VALU ops of the split, now and then one of its LDS writes
         __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);       // the prefetch loads go first: a whole k-tile to land
@@ -371,6 +414,115 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
     }
     }
 
+    if (DETECT) {
+        // L = log2(scaled tensor maximum, taken as 2^13.5) - mean scaled exponent of the thread's group maxima, in 1/16 steps (>= 0 for a
+        // word that bounds the data); the workgroup's largest per operand through LDS (the stages are free now)
+        auto spread = [&](unsigned ec, float sc) -> int {
+            const unsigned es = ec & 0xfffffu, cn = ec >> 20;
+            if (cn == 0u) return 0;
+            const float mean_e = (float)es / (float)cn - 127.f + (float)((int)(__float_as_uint(sc) >> 23) - 127);
+            return (int)((13.5f - mean_e) * 16.f);
+        };
+        const int la = spread(ec_a, sc_a);
+        int bad;
+        if (BPL) {          // the weight's L is uniform: every thread judges its own rows, one barrier
+            const int lb_w = (int)(__uint_as_float(reinterpret_cast<const unsigned*>(p.b_amax)[p.bpl_flag]) * 16.f);
+            bad = (la + lb_w > 17 * 16 || la < -24) ? 1 : 0;          // (la < -24: a mean 1.5 binades above the claimed maximum -- a stale word)
+        } else {            // both operands tracked here: the workgroup's largest L per operand through LDS (the stages are free now)
+            int* red = reinterpret_cast<int*>(smem_raw);
+            if (tid < 2) red[tid] = -(1 << 20);
+            __syncthreads();
+            const int lb = spread(ec_b, sc_b);
+            atomicMax(&red[0], la);
+            atomicMax(&red[1], lb);
+            __syncthreads();
+            bad = (red[0] + red[1] > 17 * 16 || la < -24 || lb < -24) ? 1 : 0;
+        }
+        const int stale = (kt_end - kt_begin >= 4096) ? 1 : 0;          // (a k range too long for the packed counters: play safe)
+        if (__builtin_expect(__syncthreads_or(bad | stale), 0)) {
+            // ---- the second pass: the operands as they are, fp32, through ONE LDS stage ([row][16 k], row stride 20 floats) into the
+            // fp32 MFMA (v_mfma_f32_32x32x2_f32: the arithmetic of the fp32-MFMA tiles, gemm.hip) -- no pieces, no scales, nothing that
+            // depends on the operands' range.  A plain loop (load -> store -> barrier -> MFMAs -> barrier); it shares the accumulators,
+            // the column sums (already complete: they come from the raw values) and the epilogue with the first pass.  1/16 of the f16
+            // pipe's rate, and rare.
+            if (tid == 0) atomicAdd(&g_split_redo_tiles, 1u);
+            constexpr int LDS_S = 20;
+            static_assert((BM + BN) * LDS_S * 4 <= G::SMEM_BYTES, "second pass: one fp32 stage");
+            float* As = reinterpret_cast<float*>(smem_raw);
+            float* Bs = As + BM * LDS_S;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            // B as it lies in memory (with planes, the first pass never read it): k-contiguous rows (b_src has them, SwiGLU band map
+            // included) or row-contiguous (k pair = tid & 7, row quad = tid >> 3)
+            const float* bf0 = nullptr; const float* bf1 = nullptr;
+            if (BREAL) { bf0 = b_src[0]; bf1 = b_src[1]; }
+            else {
+                bf0 = p.B + (long)(2 * (tid & 7)) * p.ldb + min(n0 + ((tid >> 3) & 31) * 4, p.N - 4);
+                bf1 = bf0 + p.ldb;
+            }
+            for (int kt = kt_begin; kt < kt_end; ++kt) {
+                const long k0 = (long)kt * SBK;
+                f32x4 xa0 = {0.f, 0.f, 0.f, 0.f}, xa1 = xa0, xb0 = xa0, xb1 = xa0;
+                if (AK) {
+                    const long d = (p.A2 != nullptr && k0 >= p.k_split) ? a2_delta : 0L;
+                    xa0 = *reinterpret_cast<const f32x4*>(a_src[0] + k0 + d);
+                    if (A_FULL) xa1 = *reinterpret_cast<const f32x4*>(a_src[1] + k0 + d);
+                } else if (A_FULL || tid < 128) {
+                    xa0 = *reinterpret_cast<const f32x4*>(a_src[0] + k0 * p.lda);
+                    xa1 = *reinterpret_cast<const f32x4*>(a_src[1] + k0 * p.lda);
+                }
+                if (BREAL) {
+                    xb0 = *reinterpret_cast<const f32x4*>(bf0 + k0);
+                    if (B_FULL) xb1 = *reinterpret_cast<const f32x4*>(bf1 + k0);
+                } else if (tid < 256) {
+                    xb0 = *reinterpret_cast<const f32x4*>(bf0 + k0 * p.ldb);
+                    xb1 = *reinterpret_cast<const f32x4*>(bf1 + k0 * p.ldb);
+                }
+                if (AK) {
+                    if (A_FULL) {
+                        *reinterpret_cast<f32x4*>(As + (tid >> 1) * LDS_S + (tid & 1) * 8) = xa0;
+                        *reinterpret_cast<f32x4*>(As + (tid >> 1) * LDS_S + (tid & 1) * 8 + 4) = xa1;
+                    } else *reinterpret_cast<f32x4*>(As + (tid >> 2) * LDS_S + (tid & 3) * 4) = xa0;
+                } else if (A_FULL || tid < 128) {
+                    const int kp = A_FULL ? (tid & 7) : ((tid >> 4) & 7), r0 = A_FULL ? (tid >> 3) * 4 : (tid & 15) * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) *reinterpret_cast<f32x2*>(As + (r0 + e) * LDS_S + 2 * kp) = f32x2{xa0[e], xa1[e]};
+                }
+                if (BREAL) {
+                    if (B_FULL) {
+                        *reinterpret_cast<f32x4*>(Bs + (tid >> 1) * LDS_S + (tid & 1) * 8) = xb0;
+                        *reinterpret_cast<f32x4*>(Bs + (tid >> 1) * LDS_S + (tid & 1) * 8 + 4) = xb1;
+                    } else *reinterpret_cast<f32x4*>(Bs + (tid >> 2) * LDS_S + (tid & 3) * 4) = xb0;
+                } else if (tid < 256) {
+                    const int kp = tid & 7, r0 = ((tid >> 3) & 31) * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) *reinterpret_cast<f32x2*>(Bs + (r0 + e) * LDS_S + 2 * kp) = f32x2{xb0[e], xb1[e]};
+                }
+                __syncthreads();
+#pragma unroll
+                for (int g8 = 0; g8 < 2; ++g8) {
+                    f32x4 a[TM], b[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(As + (wm * WM + i * 32 + li) * LDS_S + 8 * g8 + 4 * lh);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bs + (wn * WN + j * 32 + li) * LDS_S + 8 * g8 + 4 * lh);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
+                }
+                __syncthreads();
+            }
+            so_a = 1.f; so_b = 1.f;
+        }
+    }
+
     if (!AK && do_colsum) {          // reduce the 8 k-pair groups through LDS (the stages are free now)
         float* cs = reinterpret_cast<float*>(smem_raw);
         if (A_FULL) *reinterpret_cast<f32x4*>(cs + (tid & 7) * BM + (tid >> 3) * 4) = csum;
@@ -391,7 +543,7 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
     __syncthreads();          // the epilogue's LDS slabs alias the stages the next tile is about to fill
 }
 
-template <bool AK, bool BKM, int BM = 128, int ABL = 0, int NP = 3, bool BPL = false>
+template <bool AK, bool BKM, int BM = 128, int ABL = 0, int NP = 3, bool BPL = false, bool BREAL = BKM>
 __global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 1 : ((NP == 2 || NP >= 4) ? GAOT_SPLIT2_WG_PER_CU : 2)) void gemm_split_kernel(const GemmArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SplitGeom<BM, NP>::SMEM_BYTES];
     if ((ABL & 128) && (blockIdx.x & 8)) {      // tuning: de-phase half of the workgroups by ~p.ablate x 3.4 us at start
@@ -403,7 +555,7 @@ __global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 1 : ((NP == 2 ||
         // XCD-aware tile order (as gemm.hip)
         const int q = tiles >> 3, r = tiles & 7, x = vb & 7, slot = vb >> 3;
         const int logical = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + slot;
-        split_tile<AK, BKM, BM, ABL, NP, 0, BPL>(p, smem_raw, logical, blockIdx.z);
+        split_tile<AK, BKM, BM, ABL, NP, 0, BPL, BREAL>(p, smem_raw, logical, blockIdx.z);
     }
 }
 
@@ -460,7 +612,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const TnGroupAr
     a.colsum = g.p[i].colsum; a.tiles_m = g.p[i].tiles_m; a.tiles_n = g.p[i].tiles_n; a.vec_epi = 1; a.ablate = 0;
     a.a_amax = g.p[i].a_amax; a.b_amax = g.p[i].b_amax; a.c_amax = nullptr; a.a2_amax = nullptr;
     a.Bpl = nullptr; a.ld_bpl = 0; a.bpl_stride = 0;
-    split_tile<false, false, 128, ABL, NP, 64>(a, smem_raw, tile, z);
+    a.bpl_flag = 0;
+    split_tile<false, false, 128, ABL, NP, 64, false>(a, smem_raw, tile, z);
     if (split <= 1) return;
 
     const int tid = threadIdx.x;
@@ -564,14 +717,24 @@ static void launch_split_bm(GemmArgs& a, bool ak, bool bk, hipStream_t st) {
     const int z = a.split_k > 1 ? a.split_k : 1;
     dim3 grid(gx, 1, z);
     dim3 block(BM == 256 ? 512 : 256);
+    a.bpl_flag = bk ? 1 : 2;                    // the weight word's verdict on groups along the rows (NT) / columns (NN) of the matrix as stored
     if (NP == 4 && a.Bpl != nullptr) {          // pre-split B (weights): the planes are k-contiguous whatever B's own layout
-        if (ak) hipLaunchKernelGGL((gemm_split_kernel<true, true, BM, 0, 4, true>), grid, block, 0, st, a);
-        else    hipLaunchKernelGGL((gemm_split_kernel<false, true, BM, 0, 4, true>), grid, block, 0, st, a);
+        if (ak && bk)       hipLaunchKernelGGL((gemm_split_kernel<true, true, BM, 0, 4, true, true>), grid, block, 0, st, a);
+        else if (ak)        hipLaunchKernelGGL((gemm_split_kernel<true, true, BM, 0, 4, true, false>), grid, block, 0, st, a);
+        else if (bk)        hipLaunchKernelGGL((gemm_split_kernel<false, true, BM, 0, 4, true, true>), grid, block, 0, st, a);
+        else                hipLaunchKernelGGL((gemm_split_kernel<false, true, BM, 0, 4, true, false>), grid, block, 0, st, a);
     }
     else if (ak && bk)   hipLaunchKernelGGL((gemm_split_kernel<true, true, BM, 0, NP>), grid, block, 0, st, a);
     else if (ak && !bk)  hipLaunchKernelGGL((gemm_split_kernel<true, false, BM, 0, NP>), grid, block, 0, st, a);
     else if (!ak && !bk) hipLaunchKernelGGL((gemm_split_kernel<false, false, BM, 0, NP>), grid, block, 0, st, a);
     else                 hipLaunchKernelGGL((gemm_split_kernel<false, true, BM, 0, NP>), grid, block, 0, st, a);
+}
+
+unsigned split_redo_count(bool reset) {
+    unsigned v = 0;
+    hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_split_redo_tiles), sizeof(v));
+    if (reset) { const unsigned z = 0; hipMemcpyToSymbol(HIP_SYMBOL(g_split_redo_tiles), &z, sizeof(z)); }
+    return v;
 }
 
 void launch_split(GemmArgs& a, bool ak, bool bk, hipStream_t st, int bm, int pieces) {

@@ -588,6 +588,29 @@ __global__ __launch_bounds__(256) void split_f16_planes_kernel(const F16PlGroupA
         tile[r][c] = (r0 + r < rows && c0 + c < cols) ? src[(long)(r0 + r) * ld + c0 + c] : 0.f;
     }
     __syncthreads();
+    // the matrix's spread for the consumers (gemm_split.hip, "Dynamic range of the fp16 pieces"): L = log2(scaled tensor maximum / geometric
+    // mean of the non-zero maxima of the aligned groups of 8) along each row stretch (float 1 of the word's first line) and along each column
+    // stretch (float 2) of this tile, the largest over the matrix by an atomic max on the float's bits (L >= 0; zero with every new arena)
+    if (tid < 128) {
+        const bool along_row = tid < 64;
+        const int t = tid & 63;
+        unsigned es = 0u, cn = 0u;
+#pragma unroll
+        for (int grp = 0; grp < 8; ++grp) {
+            float mx = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(along_row ? tile[t][8 * grp + j] : tile[8 * grp + j][t]));
+            const unsigned e = __float_as_uint(mx) >> 23;
+            es += e;
+            cn += e != 0u ? 1u : 0u;
+        }
+        float L = 0.f;
+        if (cn > 0u) L = fmaxf(0.f, 13.5f - ((float)es / (float)cn - 127.f + (float)((int)(__float_as_uint(sc) >> 23) - 127)));
+        // wave 0 holds the rows, wave 1 the columns: one atomic per wave (atomics of many workgroups on one line serialise)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) L = fmaxf(L, __shfl_xor(L, off, 64));
+        if (t == 0 && L > 0.f) atomicMax(reinterpret_cast<unsigned*>(const_cast<float*>(g.it[i].amax)) + (along_row ? 1 : 2), __float_as_uint(L));
+    }
     const int pp = tid & 15;                        // four consecutive output columns per thread: 8-byte stores of h and of m
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {          // 0: as stored [rows][cols]; 1: transposed [cols][rows]

@@ -29,6 +29,10 @@ int gaot_debug_set_gemm_glds(int on);
 int gaot_debug_set_gemm_pieces(int pieces);
 /* 0: ignore gaot_gemm_desc.b_planes (same-box A/B of the pre-split weight planes; bit-identical results); returns the old value */
 int gaot_debug_set_gemm_planes(int on);
+/* fp16-piece products: output tiles (of the split tile kernels and the grouped weight-gradient launch) that took the per-row second pass
+ * since the counter was last reset -- a tile whose operand rows span more than 2^13 in magnitude is recomputed with one power-of-two
+ * scale per row (gemm_split.hip).  Synchronises the device.  reset != 0: zero the counter after reading it. */
+unsigned gaot_debug_split_redo_count(int reset);
 /* grouped weight gradients: values of k per workgroup (K slab length; multiple of 32, default 4096) */
 int gaot_debug_set_wgrad_kslab(int k);
 /* tuning hook: head_dim 32 attention, 1 = split-bf16 MFMA kernels (default), 0 = fp32-MFMA kernels, 2 / 3 = split with the

@@ -439,6 +439,82 @@ def test_c3_ratio_sampling_on_gpu(vx, monkeypatch):
     assert TrainStep(model, use_graph=True).use_graph is False
 
 
+@pytest.mark.parametrize("stress", ["token_1e4", "token_1e6", "channel_1e4", "channel_1e6", "weight_row_1e-6", "all"])
+def test_c2_processor_dynamic_range_stress(stress):
+    """Model-level dynamic range of the default (fp16-piece) products -- the pattern trained transformers show ("massive activations":
+    one token / one channel 1e3-1e6 times larger than the rest on the un-normed operands) and every parity test with N(0, 1) fields
+    misses.  The C2 processor (patchify -> patch_linear + positions -> 3 blocks -> unpatchify; 8 x 1 024 tokens of 256) is fed a
+    latent field with ONE token (the four latent nodes of one patch of one sample) and / or ONE channel scaled by 1e4 / 1e6, and / or
+    carries weight rows scaled by 1e-6 (patch_linear, w1, q_proj, o_proj); loss = MSE against a random target.  Against the oracle in
+    float64 end to end, the HIP path's output and EVERY gradient (all processor weights AND the input field) must be within 3x the
+    fp32 oracle's own distance + 1e-6 -- the bar of test_c2_default_gradients_stay_within_the_reference_fp32_rounding -- which it meets
+    because tiles whose operand rows span more than 2^13 take the per-row second pass (the counter must show it did)."""
+    from gaot_amd import ops, _lib
+    from oracle import gaot_oracle as O
+    lib = _lib.load()
+    assert ops.precision() == "f32"
+    model, sd, ocfg = make_model(1, 1, [64, 64], seed=11)
+    g = torch.Generator().manual_seed(11)
+    B = 8                 # (8 192 tokens, as C2: at 4 096 the N = 256 products run on the fp32-MFMA tiles, which need no scales)
+    rn = torch.randn(B, 4096, 64, generator=g)
+    tgt = torch.randn(B, 4096, 64, generator=g)
+    kinds = stress.split("_")
+    scale = float(stress.rsplit("_", 1)[1]) if stress != "all" else 1e6
+    if kinds[0] in ("token", "all"):
+        rn[1, [130, 131, 194, 195]] *= scale               # patch (1, 1) of sample 1: latent nodes (2..3, 2..3) of the 64 x 64 grid
+    if kinds[0] in ("channel", "all"):
+        rn[:, :, 17] *= (scale if stress != "all" else 1e4)
+    if kinds[0] in ("weight", "all"):
+        for k, rows in (("patch_linear.weight", [7]), ("processor.encoder_layers.0.ffn.w1.weight", [5, 600]),
+                        ("processor.middle_layer.attn.q_proj.weight", [33]), ("processor.decoder_layers.0.attn.o_proj.weight", [2])):
+            sd[k] = sd[k].clone()
+            sd[k][rows] *= 1e-6
+    names = [k for k in sd if k.startswith("processor.") or k.startswith("patch_linear.")]
+
+    def oracle(dtype):
+        ps = {k: sd[k].to(dtype).clone().requires_grad_(True) for k in names}
+        x = rn.to(dtype).clone().requires_grad_(True)
+        out = O.process(ps, ocfg, x)
+        loss = torch.mean((out - tgt.to(dtype)) ** 2)
+        gs = torch.autograd.grad(loss, [x] + [ps[k] for k in names])
+        return out.detach(), {"input": gs[0], **{k: v for k, v in zip(names, gs[1:])}}
+
+    out64, g64 = oracle(torch.float64)
+    out32, g32 = oracle(torch.float32)
+    model.load_state_dict(sd)
+    model.to(dev()).train()
+    x = rn.to(dev()).requires_grad_(True)
+    lib.gaot_debug_split_redo_count(1)
+    # the TRAINING path's launches: gradient slots + every weight gradient from the grouped launch at the end of the pass
+    from gaot_amd.trainer import FlatGradBucket
+    groups = [gr for m_ in model.modules() if hasattr(m_, "fused_weight_groups") for gr in m_.fused_weight_groups()]
+    bucket = FlatGradBucket(list(model.parameters()), groups)
+    bucket.clear()
+    ops.begin_pass()
+    ops.refresh_weight_amax(list(model.parameters()), groups)
+    out = model.process(rndata=x)
+    loss = ops.mse_loss(out, tgt.to(dev()))
+    with ops.deferred_wgrad():
+        loss.backward()
+    bucket.pack()
+    torch.cuda.synchronize()
+    redone = int(lib.gaot_debug_split_redo_count(1))
+    got = {"input": x.grad, **{k: q.grad for k, q in model.named_parameters() if k in names}}
+    top = max(float(v.norm()) for v in g64.values())
+    err = lambda a, ref: float((a.detach().cpu().double() - ref).norm()) / max(float(ref.norm()), 1e-3 * top)
+    hip = {k: err(got[k], g64[k]) for k in g64}
+    own = {k: err(g32[k], g64[k]) for k in g64}
+    e_out, o_out = rel_l2(out.detach().cpu(), out64), rel_l2(out32, out64)
+    tight = max(hip, key=lambda k: hip[k] / (3 * own[k] + 1e-6))
+    print(f"[C2 processor, {stress}] tiles through the per-row pass: {redone}; out {e_out:.2e} (fp32 oracle {o_out:.2e}); tightest gradient {tight}: "
+          f"{hip[tight]:.2e} against 3 x {own[tight]:.2e} + 1e-6; worst {max(hip.values()):.2e}")
+    assert redone > 0 or not (stress.endswith("1e6") or stress == "all"), redone        # (1e4 = 2^13.3: the edge of the tensor-wide scale's range)
+    bucket.clear()
+    ops.register_grad_slots([], [])
+    assert e_out <= 3 * o_out + 1e-6, (e_out, o_out)
+    assert hip[tight] <= 3 * own[tight] + 1e-6, (tight, hip[tight], own[tight])
+
+
 # ------------------------------------------------------------------------------------------------ C1 and C5
 def test_c1_poisson_1k_nodes_batch4_many_empty_tokens():
     """BASELINE configs[0] at its stated shape: 1 024 nodes, batch 4, example model; ~43 % of the 4 096 latent tokens have

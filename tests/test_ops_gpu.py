@@ -590,9 +590,8 @@ def test_gemm_fp16_piece_products(M, N, K):
         float64 as the three-piece bf16 products (fewer accumulation steps on the matrix pipe), < 6e-7;
       * the words follow the data: the same tensor objects refilled with 1e6 x larger values (in place, through torch) give the same
         relative error -- no stale scale, no overflow;
-      * dynamic range INSIDE an operand (the documented bound): rows 1e-4 below the largest keep fp32 accuracy; rows 1e-7 below it are
-        carried with an absolute error of 2^-39 of the operand's largest magnitude (relative 1e-4 for such a row: the three-piece
-        products, which need no scale, keep 2.4e-7 there -- set_f32_pieces("bf16x3") selects them)."""
+      * dynamic range INSIDE an operand: rows 1e-4 and rows 1e-7 below the largest keep fp32 accuracy (the latter through the per-row
+        second pass of their tiles, round 5)."""
     from gaot_amd import ops, _lib
     lib = _lib.load()
     assert ops.precision() == "f32" and ops._F16_PIECES[0]
@@ -637,12 +636,119 @@ def test_gemm_fp16_piece_products(M, N, K):
     if lib.gaot_debug_last_gemm_path() == 3:
         r = x.double() @ w.double().t()
         assert rel(y[0::4], r[0::4]) < 6e-7 and rel(y[1::4], r[1::4]) < 6e-7
-        assert rel(y[2::4], r[2::4]) < 3e-4
-        old = ops.set_f32_pieces("bf16x3")
-        try:
-            assert rel(ops.linear_nt(x.cuda(), w.cuda())[2::4], r[2::4]) < 6e-7
-        finally:
-            ops.set_f32_pieces(old)
+        # round 5: rows more than 2^13 below the tensor's largest magnitude send their tile through the per-row second pass
+        # (test_gemm_fp16_pieces_rows_of_any_magnitude): fp32 level there too (round 4 carried them to ~1e-4)
+        assert rel(y[2::4], r[2::4]) < 6e-7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(8192, 256, 256), (4096, 768, 256), (8192, 1024, 512), (520, 260, 96)])
+def test_gemm_fp16_pieces_rows_of_any_magnitude(M, N, K):
+    """The fp16 pieces scale an operand by ONE power of two per tensor; a row of the operand (a token of the activations, an output
+    feature of the weights, a channel in the weight-gradient products: the index that survives into the output) more than 2^13 below
+    the tensor's largest magnitude would lose relative precision.  Every workgroup tracks its operand rows' maxima while staging and
+    recomputes such a tile with one power of two PER ROW (gemm_split.hip "Dynamic range of the fp16 pieces"); pre-split weight planes
+    carry their verdict in the weight's magnitude word.  Here: one row / column of an operand 1e4 and 1e6 times larger (the "massive
+    activation" pattern of trained transformers) or rows 1e-6 smaller -- every OTHER row / column of the result must stay at fp32 level
+    against float64, in all three product kinds, the grouped weight-gradient launch and with pre-split planes; benign data must not
+    take the second pass at all."""
+    from gaot_amd import ops, _lib
+    lib = _lib.load()
+    assert ops.precision() == "f32" and ops._F16_PIECES[0]
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    Mk = M - M % 32
+    x, w, dy = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.06, torch.randn(M, N, generator=g)
+    TOL = 6e-7
+
+    def others(t, dim, idx):
+        keep = torch.ones(t.shape[dim], dtype=torch.bool)
+        keep[idx] = False
+        return t[keep] if dim == 0 else t[:, keep]
+
+    def products(x, w, dy, planes):
+        xd, dyd = x.cuda(), dy.cuda()
+        wd = torch.nn.Parameter(w.cuda()) if planes else w.cuda()
+        ops.begin_pass()
+        if planes:
+            ops.refresh_weight_amax([wd])
+        lib.gaot_debug_split_redo_count(1)
+        out = {}
+        with torch.no_grad():
+            out["nt"] = ops.linear_nt(xd, wd.detach() if planes else wd)
+            split = lib.gaot_debug_last_gemm_path() == 3
+            out["nn"] = ops.matmul_nn(dyd, wd.detach() if planes else wd)
+            out["tn"] = ops.matmul_tn(dyd[:Mk], xd[:Mk])
+            if N % 4 == 0 and K % 4 == 0 and Mk >= 1024:
+                out["tng"] = torch.empty(N, K, device="cuda")
+                ops.wgrad_launch([(dyd[:Mk], N, xd[:Mk], K, out["tng"], K, None, N, K, Mk)])
+        torch.cuda.synchronize()
+        return out, split, int(lib.gaot_debug_split_redo_count(1))
+
+    def refs(x, w, dy):
+        return {"nt": x.double() @ w.double().t(), "nn": dy.double() @ w.double(), "tn": dy[:Mk].double().t() @ x[:Mk].double()}
+
+    # benign data: no tile takes the second pass
+    for planes in (False, True):
+        out, split, redone = products(x, w, dy, planes)
+        r = refs(x, w, dy)
+        assert redone == 0, (planes, redone)
+        for k, v in out.items():
+            assert rel(v, r["tn" if k == "tng" else k]) < TOL, (k, planes)
+    if not split:
+        return
+    for scale in (1e4, 1e6, 1e-6):
+        TOL = 1e-6          # fp32 level: tiles that took the second pass carry plain fp32-MFMA accumulation (the fp32 tiles' own bar), the others
+                            # at most the floor terms the L_a + L_b bar admits
+        # (a) one token of the activations and of the incoming gradient (rows of A in NT / NN; a term of every sum in TN)
+        xa, dya = x.clone(), dy.clone()
+        xa[5] *= scale; dya[7] *= scale
+        for planes in (False, True):
+            out, _, redone = products(xa, w, dya, planes)
+            r = refs(xa, w, dya)
+            assert redone > 0 or scale == 1e4          # (1e4 = 2^13.3 sits at the edge of the tensor-wide scale's range: either pass will do)
+            assert rel(others(out["nt"].cpu(), 0, 5), others(r["nt"], 0, 5)) < TOL and rel(out["nt"][5], r["nt"][5]) < TOL, (scale, planes)
+            assert rel(others(out["nn"].cpu(), 0, 7), others(r["nn"], 0, 7)) < TOL and rel(out["nn"][7], r["nn"][7]) < TOL, (scale, planes)
+            for k in ("tn", "tng"):
+                if k in out:
+                    assert rel(out[k], r["tn"]) < TOL, (k, scale, planes)
+        # (b) one CHANNEL of the activations / of the gradient (a term of every sum in NT / NN; a row / column of the weight gradient)
+        xb, dyb = x.clone(), dy.clone()
+        xb[:, 9] *= scale; dyb[:, 11] *= scale
+        out, _, redone = products(xb, w, dyb, True)
+        r = refs(xb, w, dyb)
+        assert rel(out["nt"], r["nt"]) < TOL and rel(others(out["nn"].cpu(), 0, []), r["nn"]) < TOL, scale
+        for k in ("tn", "tng"):
+            if k in out:
+                o, rr = out[k].cpu(), r["tn"]
+                assert rel(others(others(o, 0, 11), 1, 9), others(others(rr, 0, 11), 1, 9)) < TOL, (k, scale)      # every ordinary entry
+                # the scaled row and column without their crossing, and the crossing itself -- ONE sum of 8 192 terms of both signs, so
+                # measured against the size of its terms (a relative bar on a single cancelling sum is a lottery in any arithmetic)
+                # (a single channel 10^6 times SMALLER than its three neighbours in a row-contiguous operand's group of four is the one
+                # pattern the tracking does not see: that row of the weight gradient keeps the absolute floor, 2^-39 of the tensor's largest)
+                tol_small = TOL if scale > 1 else 2e-5
+                assert rel(others(o[11], 0, 9), others(rr[11], 0, 9)) < tol_small and rel(others(o[:, 9], 0, 11), others(rr[:, 9], 0, 11)) < tol_small, (k, scale)
+                cross = float(dyb[:Mk, 11].double().norm() * xb[:Mk, 9].double().norm())
+                assert abs(float(o[11, 9]) - float(rr[11, 9])) < (3e-8 if scale > 1 else 1e-6) * cross, (k, scale)
+        # (c) one output feature (row) and one input feature (column) of the WEIGHT
+        wc = w.clone()
+        wc[3] *= scale; wc[:, 13] *= scale
+        for planes in (False, True):
+            out, _, redone = products(x, wc, dy, planes)
+            r = refs(x, wc, dy)
+            assert redone > 0 or scale == 1e4          # (1e4 = 2^13.3 sits at the edge of the tensor-wide scale's range: either pass will do)
+            assert rel(others(out["nt"].cpu(), 1, 3), others(r["nt"], 1, 3)) < TOL and rel(out["nt"][:, 3], r["nt"][:, 3]) < TOL, (scale, planes)
+            # (without planes B is staged row-contiguous here, 2 k x 4 output columns per thread: ONE column 10^6 times smaller than its three
+            # neighbours is the pattern the tracking does not see -- that column keeps the absolute floor; with planes the word's verdict sees it)
+            tol_col = TOL if (scale > 1 or planes) else 2e-5
+            assert rel(others(out["nn"].cpu(), 1, 13), others(r["nn"], 1, 13)) < TOL and rel(out["nn"][:, 13], r["nn"][:, 13]) < tol_col, (scale, planes)
+    # a stale word (10^4 x too small: the pieces would overflow fp16) is caught by the same tracking
+    xd, wd = x.cuda(), w.cuda()
+    ops.begin_pass()
+    word = ops.amax_for(xd)
+    big = (x * 1e4).cuda()
+    big._gaot_amax = (word, big._version, ops._PASS_ID[0])
+    y = ops.linear_nt(big, wd)
+    assert torch.isfinite(y).all() and rel(y, (x.double() * 1e4) @ w.double().t()) < TOL
 
 
 @pytest.mark.gpu
@@ -1545,7 +1651,7 @@ def test_gemm_with_presplit_f16_weight_planes_is_bit_identical(M, N, K):
     # element within 2^-16 of the largest, to 2^-25 absolute below that
     # layout [row][k / 16][piece][k % 16]: the two pieces of a 16-wide k group are one 64-byte segment
     pk = ops._PLANE_CACHE[(W.data_ptr(), N, K, 0)][0].view(torch.float16).view(N, K // 16, 2, 16).permute(2, 0, 1, 3).reshape(2, N, K).double()
-    amax = float(word.max())
+    amax = float(word.view(32, 32)[:, 0].max())          # the 32 slots (heads of the lines; floats 1 / 2 of the first line carry the planes' spread L)
     sc = 2.0 ** (13 - math.floor(math.log2(amax)))
     big = W.detach().abs().double() * sc >= 0.25
     err = ((pk[0] + pk[1]) - W.detach().double() * sc).abs() / (W.detach().abs().double() * sc).clamp_min(1e-300)
