@@ -53,6 +53,13 @@ class F16PlanesItem(C.Structure):
     _fields_ = [("src", _f), ("ld", C.c_int64), ("rows", C.c_int32), ("cols", C.c_int32), ("absmax", _f), ("planes_k", C.c_void_p), ("planes_t", C.c_void_p)]
 
 
+class KmlpDesc(C.Structure):
+    """gaot_kmlp_desc: one chain of gaot_kernel_mlp_fwd_pair / _bwd_pair"""
+    _fields_ = [("x", _f), ("E", C.c_int32), ("cin", C.c_int32), ("n_layers", C.c_int32), ("w", C.POINTER(C.c_void_p)), ("b", C.POINTER(C.c_void_p)),
+                ("act", C.c_int32), ("widths", C.POINTER(C.c_int32)), ("ldw", C.POINTER(C.c_int32)), ("pieces", C.c_int32), ("out", _f),
+                ("dk", _f), ("grads", _f), ("workspace", _f)]
+
+
 class ColsumItem(C.Structure):
     """gaot_colsum_item: out[n] = sum_m x[m * ld + n]"""
     _fields_ = [("x", _f), ("ld", C.c_int64), ("out", _f), ("M", C.c_int32), ("N", C.c_int32), ("out_cols", C.c_int32), ("out_ld", C.c_int64)]
@@ -137,6 +144,8 @@ PROTOTYPES = {
                                         C.POINTER(C.c_int32), C.c_int32, _f, _s]),
     "gaot_kernel_mlp_bwd_w": (C.c_int, [_f, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_int32),
                                         C.POINTER(C.c_int32), C.c_int32, _f, _f, _f, _s]),
+    "gaot_kernel_mlp_fwd_pair": (C.c_int, [C.POINTER(KmlpDesc), C.POINTER(KmlpDesc), _s]),
+    "gaot_kernel_mlp_bwd_pair": (C.c_int, [C.POINTER(KmlpDesc), C.POINTER(KmlpDesc), _s]),
     "gaot_kernel_mlp_bwd_workspace": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "gaot_kernel_mlp_bwd_rows": (C.c_int32, [C.c_int32]),
     "gaot_kernel_mlp_bwd": (C.c_int, [_f, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, _f, _f, _f, _s]),

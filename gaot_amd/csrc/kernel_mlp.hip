@@ -457,15 +457,23 @@ __device__ __forceinline__ void km_layer_split(const unsigned char* Wp, const fl
 }
 
 // (two workgroups per CU: 9 planes + the first layer's [64][CM] weights + biases are 80 384 B at c_in <= 4, and 256 registers)
+// The body takes its workgroup index and its LDS from the caller: the single-problem kernel and the PAIR kernel below (two chains in one
+// launch, the workgroups of the second behind those of the first) share it.
+template <int NL, int CM, int NP>
+struct KmFwdSmem {
+    static constexpr int WP = NL * NP * KS_PLANE, W1 = 64 * CM * 4, BS = 64 * (NL + 1) * 4;
+    static constexpr int BYTES = WP + W1 + BS;
+};
 template <int NL, int CM, int ACT, int NP = 3>
-__global__ __launch_bounds__(256, 2) void kernel_mlp_fwd_split_kernel(const KMArgs p) {
-    __shared__ __attribute__((aligned(16))) unsigned char Wp[NL * NP * KS_PLANE];
-    __shared__ __attribute__((aligned(16))) float W1s[64 * CM];
-    __shared__ float Bs[64 * (NL + 1)];
+__device__ __forceinline__ void km_fwd_split_body(const KMArgs& p, const int block, unsigned char* smem) {
+    using S = KmFwdSmem<NL, CM, NP>;
+    unsigned char* Wp = smem;
+    float* W1s = reinterpret_cast<float*>(smem + S::WP);
+    float* Bs = reinterpret_cast<float*>(smem + S::WP + S::W1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, hi = lane >> 5;
     // the edge coordinates are requested before the weights are staged: their latency hides behind the staging
-    const int e0 = (blockIdx.x * 4 + wave) * 32;
+    const int e0 = (block * 4 + wave) * 32;
     const int e = min(e0 + li, p.E - 1);
     float xr[CM];
     km_load_x<CM>(p, e, xr);
@@ -492,16 +500,38 @@ __global__ __launch_bounds__(256, 2) void kernel_mlp_fwd_split_kernel(const KMAr
                     *reinterpret_cast<f32x4*>(dst + io * 32 + 8 * q + 4 * hi) = f32x4{z[io][4 * q], z[io][4 * q + 1], z[io][4 * q + 2], z[io][4 * q + 3]};
     }
 }
+template <int NL, int CM, int ACT, int NP = 3>
+__global__ __launch_bounds__(256, 2) void kernel_mlp_fwd_split_kernel(const KMArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[KmFwdSmem<NL, CM, NP>::BYTES];
+    km_fwd_split_body<NL, CM, ACT, NP>(p, blockIdx.x, smem);
+}
+// TWO chains in one launch (exact products): the kernel MLP of an integral transform (GELU, over the E edge rows: 435 workgroups at the
+// bench configuration) and the geometry-embedding chain of the same transform (ReLU, over the Q query rows: 32 .. 128 workgroups) --
+// neither depends on the other, and alone the second is a 12-14 us launch of a few dozen workgroups on 256 CUs.
+template <int NLA, int CMA, int NLB, int CMB>
+__global__ __launch_bounds__(256, 2) void kernel_mlp_fwd_pair_kernel(const KMArgs a, const KMArgs b) {
+    constexpr int BYTES = KmFwdSmem<NLA, CMA, 3>::BYTES > KmFwdSmem<NLB, CMB, 3>::BYTES ? KmFwdSmem<NLA, CMA, 3>::BYTES : KmFwdSmem<NLB, CMB, 3>::BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[BYTES];
+    if ((int)blockIdx.x < a.ntiles) km_fwd_split_body<NLA, CMA, GAOT_ACT_GELU, 3>(a, blockIdx.x, smem);
+    else km_fwd_split_body<NLB, CMB, GAOT_ACT_RELU, 3>(b, (int)blockIdx.x - a.ntiles, smem);
+}
 
+template <int NL>
+struct KmBwdSmem {
+    static constexpr int TILE = 64 * KM_TLD128;
+    static constexpr int WP = NL * 3 * KS_PLANE, W1 = 64 * KM_MAXC * 4, BS = 64 * (NL + 1) * 4, GT = TILE * 4, XT = 128 * KM_MAXC * 4;
+    static constexpr int BYTES = WP + W1 + BS + 2 * GT + XT;
+};
+// (body: workgroup `block` of `nblocks` walks the tiles block, block + nblocks, ...; see km_fwd_split_body)
 template <int NL, int CM, int ACT>
-__global__ __launch_bounds__(256, 1) void kernel_mlp_bwd_split_kernel(const KMArgs p) {
-    constexpr int TILE = 64 * KM_TLD128;
-    __shared__ __attribute__((aligned(16))) unsigned char Wp[NL * 3 * KS_PLANE];
-    __shared__ __attribute__((aligned(16))) float W1s[64 * KM_MAXC];
-    __shared__ float Bs[64 * (NL + 1)];
-    __shared__ __attribute__((aligned(16))) float Gt[TILE];
-    __shared__ __attribute__((aligned(16))) float Ht[TILE];
-    __shared__ __attribute__((aligned(16))) float Xt[128 * KM_MAXC];
+__device__ __forceinline__ void km_bwd_split_body(const KMArgs& p, const int block, const int nblocks, unsigned char* smem) {
+    using S = KmBwdSmem<NL>;
+    unsigned char* Wp = smem;
+    float* W1s = reinterpret_cast<float*>(smem + S::WP);
+    float* Bs = reinterpret_cast<float*>(smem + S::WP + S::W1);
+    float* Gt = reinterpret_cast<float*>(smem + S::WP + S::W1 + S::BS);
+    float* Ht = Gt + S::TILE;
+    float* Xt = Ht + S::TILE;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, hi = lane >> 5;
@@ -526,7 +556,7 @@ __global__ __launch_bounds__(256, 1) void kernel_mlp_bwd_split_kernel(const KMAr
 #pragma unroll
     for (int c = 0; c < CM; ++c) dw1[c] = 0.f;
 
-    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    for (int tile = block; tile < p.ntiles; tile += nblocks) {
         asm volatile("" ::: "memory");
         const int e0 = tile * 128 + wave * 32;
         const bool valid = e0 + li < p.E;
@@ -675,7 +705,7 @@ __global__ __launch_bounds__(256, 1) void kernel_mlp_bwd_split_kernel(const KMAr
         __syncthreads();
     }
 
-    float* dst = p.ws + (long)blockIdx.x * p.psize;
+    float* dst = p.ws + (long)block * p.psize;
 #pragma unroll
     for (int m = 0; m < NL; ++m)
 #pragma unroll
@@ -701,6 +731,21 @@ __global__ __launch_bounds__(256, 1) void kernel_mlp_bwd_split_kernel(const KMAr
         __syncthreads();
     }
     for (int i = tid; i < nsmall; i += 256) dst[NL * 4096 + i] = R[i];
+}
+
+template <int NL, int CM, int ACT>
+__global__ __launch_bounds__(256, 1) void kernel_mlp_bwd_split_kernel(const KMArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[KmBwdSmem<NL>::BYTES];
+    km_bwd_split_body<NL, CM, ACT>(p, blockIdx.x, gridDim.x, smem);
+}
+// the backward of the two chains of kernel_mlp_fwd_pair_kernel in one launch: one workgroup per CU, so the second chain's few workgroups
+// start as the first ones of chain A retire (its 435 tiles over 256 workgroups leave a third of the CUs idle during their second round)
+template <int NLA, int CMA, int NLB, int CMB>
+__global__ __launch_bounds__(256, 1) void kernel_mlp_bwd_pair_kernel(const KMArgs a, const KMArgs b, const int na, const int nb) {
+    constexpr int BYTES = KmBwdSmem<NLA>::BYTES > KmBwdSmem<NLB>::BYTES ? KmBwdSmem<NLA>::BYTES : KmBwdSmem<NLB>::BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[BYTES];
+    if ((int)blockIdx.x < na) km_bwd_split_body<NLA, CMA, GAOT_ACT_GELU>(a, blockIdx.x, na, smem);
+    else km_bwd_split_body<NLB, CMB, GAOT_ACT_RELU>(b, (int)blockIdx.x - na, nb, smem);
 }
 
 // ------------------------------------------------------------------------------------------ backward, two rounded pieces everywhere
@@ -1080,3 +1125,62 @@ extern "C" int gaot_kernel_mlp_bwd_w(const float* x, int32_t E, int32_t cin, int
 }
 
 extern "C" int32_t gaot_kernel_mlp_bwd_rows(int32_t E) { int grid = cdiv(E, 128); return grid > 256 ? 256 : grid; }
+
+// ---- two chains, one launch (gaot_kernel_mlp_fwd_pair / _bwd_pair): chain A = a GELU chain of 4 layers (the kernel MLP of the integral
+// transform), chain B = a ReLU chain of 3 layers (the geometry-embedding chain incl. its half of the recovery block), exact products.
+// Any other pair -- or the fp32-MFMA / two-piece modes -- runs as the two single launches.
+static bool km_pair_ok(const gaot_kmlp_desc* a, const gaot_kmlp_desc* b) {
+    return g_km_split && !g_km_abl && a->n_layers == 4 && b->n_layers == 3 && a->act == GAOT_ACT_GELU && b->act == GAOT_ACT_RELU &&
+           (a->pieces == 0 || a->pieces == 3) && a->cin <= 8 && b->cin > 4 && a->E > 0 && b->E > 0;
+}
+static int km_desc_fill(KMArgs& k, const gaot_kmlp_desc* d, bool bwd) {
+    if (int rc = km_check(d->x, d->E, d->cin, d->n_layers, d->w, d->b)) return rc;
+    if (int rc = km_widths_ok(d->widths, d->n_layers)) return rc;
+    if (int rc = km_ldw_ok(d->ldw, d->widths, d->cin, d->n_layers)) return rc;
+    km_fill(k, d->x, d->E, d->cin, d->n_layers, d->w, d->b, d->widths, d->ldw);
+    if (!bwd) { GAOT_REQUIRE(d->out && aligned16(d->out), "kernel_mlp_fwd_pair: out must be non-null and 16-byte aligned"); k.out = d->out; }
+    else { GAOT_REQUIRE(d->dk && d->grads && d->workspace && aligned16(d->dk), "kernel_mlp_bwd_pair: dk (16-byte aligned), grads, workspace must be non-null");
+           k.dk = d->dk; k.ws = d->workspace; }
+    return GAOT_OK;
+}
+
+extern "C" int gaot_kernel_mlp_fwd_pair(const gaot_kmlp_desc* a, const gaot_kmlp_desc* b, gaot_stream_t stream) {
+    GAOT_REQUIRE(a && b, "kernel_mlp_fwd_pair: null descriptor");
+    if (!km_pair_ok(a, b)) {
+        if (int rc = gaot_kernel_mlp_fwd_w(a->x, a->E, a->cin, a->n_layers, a->w, a->b, a->act, a->widths, a->ldw, a->pieces, a->out, stream)) return rc;
+        return gaot_kernel_mlp_fwd_w(b->x, b->E, b->cin, b->n_layers, b->w, b->b, b->act, b->widths, b->ldw, b->pieces, b->out, stream);
+    }
+    KMArgs ka{}, kb{};
+    if (int rc = km_desc_fill(ka, a, false)) return rc;
+    if (int rc = km_desc_fill(kb, b, false)) return rc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid(ka.ntiles + kb.ntiles), block(256);
+#define KM_PAIR(CA, CB) hipLaunchKernelGGL((kernel_mlp_fwd_pair_kernel<3, CA, 2, CB>), grid, block, 0, st, ka, kb)
+    if (a->cin == 4) { if (b->cin <= 8) KM_PAIR(4, 8); else KM_PAIR(4, KM_MAXC); }
+    else             { if (b->cin <= 8) KM_PAIR(8, 8); else KM_PAIR(8, KM_MAXC); }
+#undef KM_PAIR
+    GAOT_CHECK_LAUNCH("gaot_kernel_mlp_fwd_pair");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_kernel_mlp_bwd_pair(const gaot_kmlp_desc* a, const gaot_kmlp_desc* b, gaot_stream_t stream) {
+    GAOT_REQUIRE(a && b, "kernel_mlp_bwd_pair: null descriptor");
+    if (!km_pair_ok(a, b)) {
+        if (int rc = gaot_kernel_mlp_bwd_w(a->x, a->E, a->cin, a->n_layers, a->w, a->b, a->act, a->widths, a->ldw, a->pieces, a->dk, a->grads, a->workspace, stream)) return rc;
+        return gaot_kernel_mlp_bwd_w(b->x, b->E, b->cin, b->n_layers, b->w, b->b, b->act, b->widths, b->ldw, b->pieces, b->dk, b->grads, b->workspace, stream);
+    }
+    KMArgs ka{}, kb{};
+    if (int rc = km_desc_fill(ka, a, true)) return rc;
+    if (int rc = km_desc_fill(kb, b, true)) return rc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int na = ka.ntiles > 256 ? 256 : ka.ntiles, nb = kb.ntiles > 256 ? 256 : kb.ntiles;
+#define KM_PAIR(CA, CB) hipLaunchKernelGGL((kernel_mlp_bwd_pair_kernel<3, CA, 2, CB>), dim3(na + nb), dim3(256), 0, st, ka, kb, na, nb)
+    if (a->cin == 4) { if (b->cin <= 8) KM_PAIR(4, 8); else KM_PAIR(4, KM_MAXC); }
+    else             { if (b->cin <= 8) KM_PAIR(8, 8); else KM_PAIR(8, KM_MAXC); }
+#undef KM_PAIR
+    GAOT_CHECK_LAUNCH("gaot_kernel_mlp_bwd_pair");
+    // the per-workgroup partial rows: summed here unless the caller does it (grads == workspace, see gaot_kernel_mlp_bwd_w)
+    if (a->grads != a->workspace) if (int rc = gaot_colsum(a->workspace, ka.psize, na, ka.psize, a->grads, a->workspace, stream)) return rc;
+    if (b->grads != b->workspace) if (int rc = gaot_colsum(b->workspace, kb.psize, nb, kb.psize, b->grads, b->workspace, stream)) return rc;
+    return GAOT_OK;
+}

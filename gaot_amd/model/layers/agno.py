@@ -66,10 +66,28 @@ class AGNO(nn.Module):
             a = plan.inv_deg_edge                      # 'mean' reduction (agno.py:264)
         return a
 
+    def kernel_chain_args(self, y: torch.Tensor, neighbors: Dict[str, torch.Tensor], x: Optional[torch.Tensor] = None):
+        """(edge rows, weights, biases, acts) of the kernel MLP as forward() would run it for the batch-independent kernels (`linear`
+        transforms), or None: the caller may compute k_e together with another chain (ops.mlp_chain_pair) and hand it back as
+        `kernel_values`"""
+        from .mlp import LinearChannelMLP
+        mlp = self.channel_mlp
+        if (self.transform_type not in ("linear", "linear_kernelonly") or type(mlp) is not LinearChannelMLP or mlp.act is None
+                or mlp.dropout is not None):
+            return None
+        if x is None:
+            x = y
+        plan = plan_for(neighbors, y.shape[0])
+        if plan.E == 0:
+            return None
+        acts = [mlp.act] * (mlp.n_layers - 1) + ["none"]
+        return (plan.edge_features(y, x), [fc.weight for fc in mlp.fcs], [fc.bias for fc in mlp.fcs], acts)
+
     def forward(self, y: torch.Tensor, neighbors: Dict[str, torch.Tensor], x: Optional[torch.Tensor] = None,
-                f_y: Optional[torch.Tensor] = None, weights: Optional[torch.Tensor] = None, lift=None, proj=None):
+                f_y: Optional[torch.Tensor] = None, weights: Optional[torch.Tensor] = None, lift=None, proj=None, kernel_values=None):
         """`lift` = (pn [B,n,c_in], W [C,c_in(,1)], b [C] or None): f_y is the point-wise LINEAR map W pn + b of raw node data
-        (the encoder's lifting, magno.py:334).  When the fused kernels apply, f_y is never formed; otherwise it is computed here."""
+        (the encoder's lifting, magno.py:334).  When the fused kernels apply, f_y is never formed; otherwise it is computed here.
+        `kernel_values` = k_e [E, C] already computed by the caller from kernel_chain_args() (`linear` transforms only)."""
         if x is None:
             x = y
         self.applied_proj = False           # set when `proj` = (weff [OC,C], rowbias [Q,OC] | None, bias [OC] | None) was folded in
@@ -93,8 +111,8 @@ class AGNO(nn.Module):
             k = self.channel_mlp(ops.edge_cat(feat, f3, plan))                # [B, E, C]: rows [y_j, x_i, f(y_j)] per sample
             out = ops.nonlinear_transform(k, f3, plan, a, self.transform_type == "nonlinear")
         else:
-            k = None
-            if not torch.is_grad_enabled():      # rollouts: k_e depends on geometry + weights only -> reuse across steps
+            k = kernel_values
+            if k is None and not torch.is_grad_enabled():      # rollouts: k_e depends on geometry + weights only -> reuse across steps
                 key = (id(feat), plan.epoch, tuple(p._version for p in self.channel_mlp.parameters()), ops.weights_generation())
                 hit = getattr(self, "_infer_k", None)
                 if hit is not None and hit[0] == key and hit[1] is feat:

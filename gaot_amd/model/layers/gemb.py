@@ -34,6 +34,15 @@ class GeometricEmbedding(nn.Module):
         else:
             raise ValueError(f"Unknown method: {self.method}")
 
+    def chain_args(self, input_geom, latent_queries, spatial_nbrs, stats=None, head=None):
+        """(x, weights, biases, acts) of the statistical branch with its `head` as ONE row-wise chain (what forward() hands to
+        ops.mlp_chain), or None for the other branches: the caller may pair it with another chain in one launch (ops.mlp_chain_pair)"""
+        if self.method != 'statistical' or head is None:
+            return None
+        if stats is None:
+            stats = plan_for(spatial_nbrs, input_geom.shape[0]).geo_stats(input_geom, latent_queries)
+        return (stats, [self.mlp[0].weight, self.mlp[2].weight, head[0]], [self.mlp[0].bias, self.mlp[2].bias, head[1]], ["relu", "relu", "none"])
+
     def forward(self, input_geom, latent_queries, spatial_nbrs, stats=None, head=None):
         """`head` = (W [C_out, output_dim], b [C_out]): a Linear applied to the embedding by the caller (the geoembed half of
         the recovery block, magno.py:345-350); with it the statistical branch is ONE chain relu, relu, none that the fused

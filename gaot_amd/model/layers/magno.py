@@ -139,7 +139,7 @@ class _MAGNOBase(nn.Module):
         nb = neighbors
         if drop:
             nb = apply_edge_drop_csr(neighbors, self.sampling_strategy, self.max_neighbors, self.sample_ratio, self.training)
-        proj = rowb = w_agno = None
+        proj = rowb = w_agno = kvals = None
         if self.use_geoembed:
             w = self.recovery.fcs[0].weight.squeeze(-1)                                             # [C, 2C]
             C = w.shape[0]
@@ -156,9 +156,17 @@ class _MAGNOBase(nn.Module):
                 if hit is not None and hit[0] == key and hit[1] is nb:
                     rowb = hit[2]
             if rowb is None:
-                # embedding MLP and the geoembed half of the recovery block as one chain: [n_dst, C]
-                rowb = self.geoembed(input_geom=src_coord, latent_queries=dst_coord, spatial_nbrs=nb,
-                                     stats=stats if nb is neighbors else None, head=(w_geo, self.recovery.fcs[0].bias))
+                # embedding MLP and the geoembed half of the recovery block as one chain: [n_dst, C] -- in training together with the kernel
+                # MLP of this transform, ONE launch each way (ops.mlp_chain_pair: the chain alone is a few dozen workgroups on 256 CUs)
+                geo = kern = None
+                if torch.is_grad_enabled() and src_coord.is_cuda:
+                    geo = self.geoembed.chain_args(src_coord, dst_coord, nb, stats if nb is neighbors else None, (w_geo, self.recovery.fcs[0].bias))
+                    kern = self.agno.kernel_chain_args(self._kcoord(src_coord), nb, self._kcoord(dst_coord)) if geo is not None else None
+                if geo is not None and kern is not None:
+                    kvals, rowb = ops.mlp_chain_pair(*kern, *geo)
+                else:
+                    rowb = self.geoembed(input_geom=src_coord, latent_queries=dst_coord, spatial_nbrs=nb,
+                                         stats=stats if nb is neighbors else None, head=(w_geo, self.recovery.fcs[0].bias))
                 if key is not None:
                     self._infer_cache["rowb"] = (key, nb, rowb, (src_coord, dst_coord))      # hold the tensors: ids stay unique
             if head is not None:
@@ -168,7 +176,7 @@ class _MAGNOBase(nn.Module):
         elif head is not None:
             proj = (head[0], None, head[1])
         # with few output channels the folded map is applied INSIDE the transform kernels (AGNO decides: `applied_proj`)
-        out = self.agno(y=self._kcoord(src_coord), x=self._kcoord(dst_coord), f_y=feats, neighbors=nb, lift=lift, proj=proj)
+        out = self.agno(y=self._kcoord(src_coord), x=self._kcoord(dst_coord), f_y=feats, neighbors=nb, lift=lift, proj=proj, kernel_values=kvals)
         if proj is not None:
             return out if self.agno.applied_proj else ops.linear(out, proj[0], proj[2], rowbias=proj[1])
         if self.use_geoembed:

@@ -1444,6 +1444,119 @@ class _KernelMLP(torch.autograd.Function):
         return (None, None, None, *dws, *dbs)
 
 
+class _KernelMLPPair(torch.autograd.Function):
+    """Two fused row-wise MLP chains in ONE launch each way (gaot_kernel_mlp_fwd_pair / _bwd_pair): chain A = the kernel MLP of an integral
+    transform over the E edge rows, chain B = the geometry-embedding chain of the same transform over the Q query rows.  Neither reads the
+    other; alone chain B is a launch of a few dozen workgroups.  Arithmetic, gradient slots and deferred column sums per chain exactly as
+    _KernelMLP (whose pieces this reuses)."""
+
+    @staticmethod
+    def _desc(x, ws, bs, act, keep, out=None, dk=None, grads=None, wsp=None):
+        n = len(ws)
+        w_arr, b_arr = _KernelMLP._ptrs(ws), _KernelMLP._ptrs(bs)
+        widths = (C.c_int32 * n)(*[int(w.shape[0]) for w in ws])
+        ldw = (C.c_int32 * n)(*[int(w.stride(0)) if w.shape[0] > 1 else 0 for w in ws])
+        keep += [w_arr, b_arr, widths, ldw]
+        return L.KmlpDesc(x.data_ptr(), x.shape[0], x.shape[1], n, w_arr, b_arr, act, widths, ldw, _KernelMLP._pieces(act),
+                          None if out is None else out.data_ptr(), None if dk is None else dk.data_ptr(),
+                          None if grads is None else grads.data_ptr(), None if wsp is None else wsp.data_ptr())
+
+    @staticmethod
+    def _norm(x, n, wb):
+        x = x.contiguous()
+        ws = [w if (w.dim() == 2 and w.stride(1) == 1 and w.stride(0) >= w.shape[1] and w.stride(0) % 4 == 0 and not (w.data_ptr() & 15))
+              else w.contiguous() for w in wb[:n]]
+        bs = [b.contiguous() for b in wb[n:]]
+        _dev(x, *ws, *bs)
+        return x, ws, bs
+
+    @staticmethod
+    def forward(ctx, xa, na, acta, xb, nb, actb, *wb):
+        wba, wbb = wb[:2 * na], wb[2 * na:]
+        xa, wsa, bsa = _KernelMLPPair._norm(xa, na, wba)
+        xb, wsb, bsb = _KernelMLPPair._norm(xb, nb, wbb)
+        outa = torch.empty(xa.shape[0], wsa[-1].shape[0], device=xa.device, dtype=torch.float32)
+        outb = torch.empty(xb.shape[0], wsb[-1].shape[0], device=xb.device, dtype=torch.float32)
+        keep = []
+        da = _KernelMLPPair._desc(xa, wsa, bsa, acta, keep, out=outa)
+        db = _KernelMLPPair._desc(xb, wsb, bsb, actb, keep, out=outb)
+        L.check(L.load().gaot_kernel_mlp_fwd_pair(C.byref(da), C.byref(db), _stream()), "gaot_kernel_mlp_fwd_pair")
+        ctx.save_for_backward(xa, xb, *wsa, *bsa, *wsb, *bsb)
+        ctx.meta = (na, acta, nb, actb)
+        ctx.slots_a = [_claim(t) for t in wba]
+        ctx.slots_b = [_claim(t) for t in wbb]
+        return outa, outb
+
+    @staticmethod
+    def _finish(lib, x, ws, n, slots, wsp, grads, need_all):
+        """the parameter gradients of one chain from the kernel's output: per-workgroup partial rows summed into the parameters' slices by
+        the grouped column sum at the end of the pass (wsp is grads), or the packed gradient vector cut into its blocks"""
+        E, cin = x.shape
+        wo = [int(w.shape[0]) for w in ws]
+        o = (n - 1) * 4096
+        psize = o + 64 * cin + 64 * n
+        if grads is None:
+            rows = int(lib.gaot_kernel_mlp_bwd_rows(E))
+            part = wsp[:rows * psize].view(rows, psize)
+            blocks = [(o, 64 * cin)] + [(m * 4096, 4096) for m in range(n - 1)] + [(o + 64 * cin + 64 * i, 64) for i in range(n)]
+            outs = []
+            for (off, width), slot in zip(blocks, slots):
+                dst = slot.detach()
+                outs.append(colsum(part[:, off:off + width], out=dst if (dst.dim() == 2 and not dst.is_contiguous()) else dst.view(-1),
+                                   final=True).view(slot.shape))
+            return outs
+        dws = [grads[o:o + 64 * cin].view(64, cin)[:wo[0]]]
+        for m in range(n - 1):
+            blk = grads[m * 4096:(m + 1) * 4096].view(64, 64)[:wo[m + 1], :wo[m]]
+            dws.append(blk if wo[m] == 64 else blk.contiguous())
+        ob = o + 64 * cin
+        return dws + [grads[ob + 64 * i:ob + 64 * i + wo[i]] for i in range(n)]
+
+    @staticmethod
+    def _direct(slots, ws, x, needs):
+        return (_WGRAD_DEPTH[0] > 0 and _WGRAD_GROUPED and all(s_ is not None for s_ in slots) and all(int(w.shape[0]) == 64 for w in ws)
+                and (64 * x.shape[1]) % 4 == 0 and all(needs))
+
+    @staticmethod
+    def backward(ctx, dka, dkb):
+        na, acta, nb, actb = ctx.meta
+        sv = ctx.saved_tensors
+        xa, xb = sv[0], sv[1]
+        wsa, bsa = list(sv[2:2 + na]), list(sv[2 + na:2 + 2 * na])
+        wsb, bsb = list(sv[2 + 2 * na:2 + 2 * na + nb]), list(sv[2 + 2 * na + nb:])
+        lib = L.load()
+        dka = (dka if dka is not None else torch.zeros(xa.shape[0], wsa[-1].shape[0], device=xa.device)).contiguous()
+        dkb = (dkb if dkb is not None else torch.zeros(xb.shape[0], wsb[-1].shape[0], device=xb.device)).contiguous()
+        keep, res = [], []
+        for x, ws, n in ((xa, wsa, na), (xb, wsb, nb)):
+            psize = (n - 1) * 4096 + 64 * x.shape[1] + 64 * n
+            wsp = torch.empty(int(lib.gaot_kernel_mlp_bwd_workspace(x.shape[0], x.shape[1], n)), device=x.device, dtype=torch.float32)
+            res.append([wsp, psize])
+        need = ctx.needs_input_grad
+        direct_a = _KernelMLPPair._direct(ctx.slots_a, wsa, xa, need[6:6 + 2 * na])
+        direct_b = _KernelMLPPair._direct(ctx.slots_b, wsb, xb, need[6 + 2 * na:])
+        ga = None if direct_a else torch.empty(res[0][1], device=xa.device, dtype=torch.float32)
+        gb = None if direct_b else torch.empty(res[1][1], device=xb.device, dtype=torch.float32)
+        da = _KernelMLPPair._desc(xa, wsa, bsa, acta, keep, dk=dka, grads=res[0][0] if direct_a else ga, wsp=res[0][0])
+        db = _KernelMLPPair._desc(xb, wsb, bsb, actb, keep, dk=dkb, grads=res[1][0] if direct_b else gb, wsp=res[1][0])
+        L.check(lib.gaot_kernel_mlp_bwd_pair(C.byref(da), C.byref(db), _stream()), "gaot_kernel_mlp_bwd_pair")
+        outs_a = _KernelMLPPair._finish(lib, xa, wsa, na, ctx.slots_a, res[0][0], ga, True)
+        outs_b = _KernelMLPPair._finish(lib, xb, wsb, nb, ctx.slots_b, res[1][0], gb, True)
+        return (None, None, None, None, None, None, *outs_a, *outs_b)
+
+
+_MLP_PAIR = os.environ.get("GAOT_MLP_PAIR", "1") != "0"        # A/B switch (tools): 0 = the two chains as two launches
+
+
+def mlp_chain_pair(xa, weights_a, biases_a, acts_a, xb, weights_b, biases_b, acts_b):
+    """(chain_a(xa), chain_b(xb)): both through ONE launch each way when both are fused-kernel chains (see _KernelMLPPair), else one by one"""
+    if (_FUSED_KERNEL_MLP and _MLP_PAIR and _KernelMLP.eligible(xa, weights_a, biases_a, acts_a) and _KernelMLP.eligible(xb, weights_b, biases_b, acts_b)
+            and xa.device == xb.device):
+        return _KernelMLPPair.apply(xa, len(weights_a), ACT[acts_a[0]], xb, len(weights_b), ACT[acts_b[0]],
+                                    *weights_a, *biases_a, *weights_b, *biases_b)
+    return mlp_chain(xa, weights_a, biases_a, acts_a), mlp_chain(xb, weights_b, biases_b, acts_b)
+
+
 def mlp_chain(x, weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]], acts: Sequence[str]):
     if _FUSED_KERNEL_MLP and _KernelMLP.eligible(x, weights, biases, acts):
         return _KernelMLP.apply(x, len(weights), ACT[acts[0]], *weights, *biases)

@@ -382,6 +382,21 @@ int gaot_kernel_mlp_fwd_w(const float* x, int32_t E, int32_t cin, int32_t n_laye
 int gaot_kernel_mlp_bwd_w(const float* x, int32_t E, int32_t cin, int32_t n_layers, const float* const* w, const float* const* b,
                           int32_t act, const int32_t* widths, const int32_t* ldw, int32_t pieces, const float* dk, float* grads,
                           float* workspace, gaot_stream_t stream);
+/* TWO chains in ONE launch each way: chain `a` = the kernel MLP of an integral transform (agno.py:229-231 -> mlp.py:307-337: 4 layers,
+ * GELU, over the E edge rows), chain `b` = the geometry-embedding chain of the same transform with its half of the recovery block
+ * (gemb.py:54-59 + magno.py:345-350: 3 layers, ReLU, over the Q query rows).  Neither reads the other's result, and on its own chain b is
+ * a launch of 32 .. 128 workgroups on 256 CUs.  Arguments per chain as gaot_kernel_mlp_fwd_w / _bwd_w (forward: `out`; backward: `dk`,
+ * `grads`, `workspace`, with grads == workspace leaving the per-workgroup partial rows to the caller).  Pairs the fused kernels do not cover
+ * (other depths / activations / precisions) run as the two single launches: same results either way. */
+typedef struct gaot_kmlp_desc {
+    const float* x; int32_t E; int32_t cin; int32_t n_layers;
+    const float* const* w; const float* const* b;
+    int32_t act; const int32_t* widths; const int32_t* ldw; int32_t pieces;
+    float* out;
+    const float* dk; float* grads; float* workspace;
+} gaot_kmlp_desc;
+int gaot_kernel_mlp_fwd_pair(const gaot_kmlp_desc* a, const gaot_kmlp_desc* b, gaot_stream_t stream);
+int gaot_kernel_mlp_bwd_pair(const gaot_kmlp_desc* a, const gaot_kmlp_desc* b, gaot_stream_t stream);
 /* nn.MSELoss() with mean reduction (the reference trainers' loss, base_trainer.py:71): loss[0] = mean((pred - target)^2) over
  * n elements through `partial` (>= 256 floats; fixed-order two-stage sum, deterministic); backward
  * dpred = 2 (pred - target) / n * grad_loss[0] with grad_loss a DEVICE scalar (so the launch replays inside a hipGraph). */
