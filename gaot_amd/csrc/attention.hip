@@ -420,21 +420,29 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && DH == 32) ? 2 : 1) void attn_f
     const int q0 = blk * QB + wave * 32;
     const int D = DH == 32 ? 32 : p.D;
     static_assert(!F16 || (PP == 2 && OP == 2), "fp16 pieces come in twos");
-    float sc_in = 1.f, so_in = 1.f;
-    if (F16) amax_scale(p.qkv_amax, sc_in, so_in);
-    const float sm_scale = p.scale * so_in * so_in;          // scores arrive scaled by sc_in^2
-    const float c = sm_scale * LOG2E;
-    const float o_inv = F16 ? so_in * P_INV : 1.f;             // the tile's V^T P^T arrives scaled by sc_in * 2^15
-
-    // Q fragments: lane (q = li, hi) holds d = 16u + 8hi + e (e = 0..7) for every d step u, as three packed bf16 planes
+    // Q fragments: lane (q = li, hi) holds d = 16u + 8hi + e (e = 0..7) for every d step u, as three packed bf16 planes.  The rows are
+    // requested BEFORE the magnitude word is read: one round trip instead of two at the head of the workgroup's life.
     bf16x8 qf[3][NU];
+    f32x4 qraw[NU][2];
     {
         const int qi = q0 + li;
         const float* qrow = p.q + ((long)b * p.S + qi) * p.ldq + (long)h * D;
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
-            const f32x4 v0 = load4(qrow, 16 * u + 8 * lh, D, qi < p.S, true);
-            const f32x4 v1 = load4(qrow, 16 * u + 8 * lh + 4, D, qi < p.S, true);
+            qraw[u][0] = load4(qrow, 16 * u + 8 * lh, D, qi < p.S, true);
+            qraw[u][1] = load4(qrow, 16 * u + 8 * lh + 4, D, qi < p.S, true);
+        }
+    }
+    float sc_in = 1.f, so_in = 1.f;
+    if (F16) amax_scale(p.qkv_amax, sc_in, so_in);
+    const float sm_scale = p.scale * so_in * so_in;          // scores arrive scaled by sc_in^2
+    const float c = sm_scale * LOG2E;
+    const float o_inv = F16 ? so_in * P_INV : 1.f;             // the tile's V^T P^T arrives scaled by sc_in * 2^15
+    {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const f32x4 v0 = qraw[u][0];
+            const f32x4 v1 = qraw[u][1];
             u32x4 ph, pm, pl;
             unsigned a_, b_, c_;
             split_op<OP, F16>(v0[0], v0[1], a_, b_, c_, sc_in); ph[0] = a_; pm[0] = b_; pl[0] = c_;
@@ -1850,8 +1858,24 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
     const int b = bh / p.H, h = bh % p.H, hk = h / (p.H / p.Hkv);
     const int kv0 = kblk * 256 + wave * 32;
     static_assert(!F16 || (PP == 2 && OP == 2), "fp16 pieces come in twos");
+    // this wave's K / V rows are requested first, then both magnitude words, and only then does anything wait: one round trip at the head of
+    // the workgroup's life instead of three
+    f32x4 kraw[2][2], vraw[2][2];
+    {
+        const float* krow = p.k + ((long)b * p.S + min(kv0 + li, p.S - 1)) * p.ldk + (long)hk * 32;
+        const float* vrow = p.v + ((long)b * p.S + min(kv0 + li, p.S - 1)) * p.ldv + (long)hk * 32;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            kraw[u][0] = *reinterpret_cast<const f32x4*>(krow + 16 * u + 8 * lh); kraw[u][1] = *reinterpret_cast<const f32x4*>(krow + 16 * u + 8 * lh + 4);
+            vraw[u][0] = *reinterpret_cast<const f32x4*>(vrow + 16 * u + 8 * lh); vraw[u][1] = *reinterpret_cast<const f32x4*>(vrow + 16 * u + 8 * lh + 4);
+        }
+    }
     float sc_in = 1.f, so_in = 1.f, sc_g = 1.f, so_g = 1.f;
-    if (F16) { amax_scale(p.qkv_amax, sc_in, so_in); amax_scale(p.dout_amax, sc_g, so_g); }
+    if (F16) {
+        const unsigned w_in = amax_peek(p.qkv_amax), w_g = amax_peek(p.dout_amax);
+        amax_finish(w_in, sc_in, so_in);
+        amax_finish(w_g, sc_g, so_g);
+    }
     const float c = p.scale * LOG2E * so_in * so_in;         // scores arrive scaled by sc_in^2
     const float dp_inv = so_g * so_in;                       // dO V^T arrives scaled by sc_g * sc_in
     const float dv_inv = F16 ? so_g * P_INV : 1.f;           // dO^T P by sc_g * 2^15
@@ -1863,12 +1887,10 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
     bf16x8 kf[3][2], vf[3][2];
     const bool kv_ok = kv0 + li < p.S;
     {
-        const float* krow = p.k + ((long)b * p.S + min(kv0 + li, p.S - 1)) * p.ldk + (long)hk * 32;
-        const float* vrow = p.v + ((long)b * p.S + min(kv0 + li, p.S - 1)) * p.ldv + (long)hk * 32;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(krow + 16 * u + 8 * lh), a1 = *reinterpret_cast<const f32x4*>(krow + 16 * u + 8 * lh + 4);
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(vrow + 16 * u + 8 * lh), w1 = *reinterpret_cast<const f32x4*>(vrow + 16 * u + 8 * lh + 4);
+            const f32x4 a0 = kraw[u][0], a1 = kraw[u][1];
+            const f32x4 w0 = vraw[u][0], w1 = vraw[u][1];
             u32x4 ph, pm, pl, vh, vm, vl;
             unsigned a_, b_, c_;
 #pragma unroll

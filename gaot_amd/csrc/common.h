@@ -189,6 +189,21 @@ __device__ __forceinline__ void amax_scale(const float* word, float& sc, float& 
     inv = __uint_as_float((unsigned)(127 - se) << 23);
 }
 
+// the same in two halves, for kernels that want their first operand loads in flight before they wait for the word: amax_peek() issues
+// the word's load (one slot per lane), amax_finish() does the cross-lane maximum and forms the scales
+__device__ __forceinline__ unsigned amax_peek(const float* word) {
+    return __float_as_uint(word[(threadIdx.x & (GAOT_AMAX_SLOTS - 1)) * GAOT_AMAX_STRIDE]);
+}
+__device__ __forceinline__ void amax_finish(unsigned b, float& sc, float& inv) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const unsigned o = __shfl_xor(b, off, 64); b = o > b ? o : b; }
+    const int e = (int)((b >> 23) & 0xffu);
+    int se = 140 - e;
+    se = se > 126 ? 126 : (se < -126 ? -126 : se);
+    sc = __uint_as_float((unsigned)(127 + se) << 23);
+    inv = __uint_as_float((unsigned)(127 - se) << 23);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

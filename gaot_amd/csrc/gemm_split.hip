@@ -144,7 +144,8 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
     static_assert(!BPL || (BKM && NP == 4), "pre-split B planes: fp16 pieces, k-contiguous");
     // fp16 pieces: power-of-two operand scales from the operands' magnitude words (uniform: two scalar loads per workgroup)
     float sc_a = 1.f, sc_b = 1.f, so_a = 1.f, so_b = 1.f;
-    if (F16) { amax_scale(p.a_amax, sc_a, so_a, p.A2 != nullptr ? p.a2_amax : nullptr); amax_scale(p.b_amax, sc_b, so_b); }
+    // (the words are read AFTER the first two tiles' loads have been issued, below: one round trip instead of two at the head of every
+    // workgroup's life -- at K = 256 a workgroup lives for sixteen k-tiles)
     const float* a_src[2]; const float* b_src[2];
     // concatenated input (k-contiguous A only): columns k >= k_split come from A2 -- as an element offset from this thread's A row
     long a2_delta = 0;
@@ -375,8 +376,9 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
     };
 
     gload(kt_begin, ra[0], rb[0]);
-    sstore(0, ra[0], rb[0], kt_begin < kt_end);
     gload(kt_begin + 1, ra[1], rb[1]);
+    if (F16) { amax_scale(p.a_amax, sc_a, so_a, p.A2 != nullptr ? p.a2_amax : nullptr); amax_scale(p.b_amax, sc_b, so_b); }
+    sstore(0, ra[0], rb[0], kt_begin < kt_end);
     __syncthreads();
     if (FLUSH > 0) {
         f32x16 tot[TM][TN];
