@@ -479,6 +479,31 @@ def secondary_configs(dev, which=("C3", "C4", "C5"), steps: int = 20, warmup: in
                                           "what": "the reference's vx loop unchanged (host->device upload of the fields per step, zero_grad, eager call, nn.MSELoss, "
                                                   "torch.optim.AdamW) with the per-sample graphs and coordinates resident on the device: a repeated batch "
                                                   "composition replays as hipGraphs (autograph.py); graphs uploaded anew every step run eagerly"}
+        # ... and with a SHUFFLING loader (the reference's default, data_utils.py:272-294): every step a new composition of the same resident
+        # per-sample graphs.  The union plan is composed on the device from the cached per-sample plans (plan.compose_plans); a composition seen
+        # for the first time runs eagerly (a captured graph holds one union's arrays), so this is the eager HIP path inside the unchanged loop.
+        gsh = torch.Generator().manual_seed(7)
+        xall, pall, tall = xd, p, t
+
+        def one_shuffled():
+            perm = torch.randperm(B, generator=gsh).tolist()
+            xb, yb = pall[perm].to(dev), tall[perm].to(dev)
+            opt.zero_grad()
+            out_ = m2(latent_tokens_coord=latd, xcoord=xall[perm], pndata=xb, encoder_nbrs=[enc[i] for i in perm], decoder_nbrs=[dec[i] for i in perm])
+            lossf(out_, yb).backward()
+            opt.step()
+            return type(out_.grad_fn).__name__ == "_GraphedStepBackward"
+        for _ in range(4):
+            one_shuffled()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        graphed = sum(one_shuffled() for _ in range(steps))
+        torch.cuda.synchronize()
+        dts = (time.perf_counter() - t0) / steps
+        out["C3"]["reference_loop_vx_shuffled"] = {"value": B / dts, "unit": "samples/s", "ms_per_step": 1e3 * dts, "steps": steps, "graphed_steps": int(graphed),
+                                                   "frac_of_trainstep": (B / dts) / out["C3"]["samples_per_s"],
+                                                   "what": "the same loop with the batch re-shuffled every step (a new composition of the resident per-sample graphs each "
+                                                           "time): union plan composed on the device from the cached per-sample plans, eager HIP path (no replay)"}
         del m2, opt
     if "C4" in which:
         torch.manual_seed(0)

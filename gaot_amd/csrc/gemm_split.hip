@@ -81,7 +81,7 @@ struct SplitGeom {
 // So every workgroup watches what it stages: per thread and k-tile the largest magnitude of its 8 elements (8 consecutive k of one
 // row, or 2 k x 4 rows), and over its k range the SUM OF THE EXPONENTS of the non-zero group maxima (their geometric mean: the "typical"
 // magnitude of the thread's row, robust against the outliers themselves) -- five vector instructions per operand and k-tile.  At the end
-// L = log2(scaled tensor maximum / that mean), the largest L over the workgroup's threads per operand, and if L_a + L_b exceeds 17 -- or
+// L = log2(scaled tensor maximum / that mean) per thread, and if L_a + L_b exceeds 17 for an eighth of the workgroup's threads -- or
 // a mean sits ABOVE the tensor's claimed maximum: a stale word -- the workgroup computes its tile AGAIN on the fp32 MFMA, straight from
 // the fp32 operands (no pieces, no scales: exact for any spread; one LDS stage, a plain loop: slow, and rare).  Exact zeros are exempt (empty latent tokens, ReLU outputs).  Pre-split weight planes
 // carry their L in the weight's magnitude word (gaot_split_f16_planes_grouped: float 1 = along the rows, float 2 = along the columns of
@@ -426,22 +426,23 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
             return (int)((13.5f - mean_e) * 16.f);
         };
         const int la = spread(ec_a, sc_a);
-        int bad;
-        if (BPL) {          // the weight's L is uniform: every thread judges its own rows, one barrier
+        int bad, stale;
+        if (BPL) {          // the weight's L is uniform: every thread judges its own rows
             const int lb_w = (int)(__uint_as_float(reinterpret_cast<const unsigned*>(p.b_amax)[p.bpl_flag]) * 16.f);
-            bad = (la + lb_w > 17 * 16 || la < -24) ? 1 : 0;          // (la < -24: a mean 1.5 binades above the claimed maximum -- a stale word)
-        } else {            // both operands tracked here: the workgroup's largest L per operand through LDS (the stages are free now)
-            int* red = reinterpret_cast<int*>(smem_raw);
-            if (tid < 2) red[tid] = -(1 << 20);
-            __syncthreads();
+            bad = la + lb_w > 17 * 16 ? 1 : 0;
+            stale = la < -24 ? 1 : 0;          // a mean 1.5 binades above the claimed maximum: a stale word
+        } else {            // both operands tracked here
             const int lb = spread(ec_b, sc_b);
-            atomicMax(&red[0], la);
-            atomicMax(&red[1], lb);
-            __syncthreads();
-            bad = (red[0] + red[1] > 17 * 16 || la < -24 || lb < -24) ? 1 : 0;
+            bad = la + lb > 17 * 16 ? 1 : 0;          // each thread stages one row stream of A and one of B: it votes on its own pair
+            stale = (la < -24 || lb < -24) ? 1 : 0;
         }
-        const int stale = (kt_end - kt_begin >= 4096) ? 1 : 0;          // (a k range too long for the packed counters: play safe)
-        if (__builtin_expect(__syncthreads_or(bad | stale), 0)) {
+        if (kt_end - kt_begin >= 4096) stale = 1;          // (a k range too long for the packed counters: play safe)
+        // A VOTE, not a veto: the tile is redone when an eighth of its threads (16 of 128 rows) see the spread.  The patterns that matter
+        // -- a massive token or channel, a quarter of the rows tiny -- raise (nearly) every thread; a few tiny rows among ordinary ones
+        // (tokens of an almost empty latent patch: thousands per step on the skewed NACA meshes) do not: those rows keep the absolute
+        // floor, 2^-39 of the tensor's largest magnitude, which only their own (tiny) outputs see.
+        const int votes = __syncthreads_count(bad);
+        if (__builtin_expect(__syncthreads_or(stale) || votes * 8 >= NT, 0)) {
             // ---- the second pass: the operands as they are, fp32, through ONE LDS stage ([row][16 k], row stride 20 floats) into the
             // fp32 MFMA (v_mfma_f32_32x32x2_f32: the arithmetic of the fp32-MFMA tiles, gemm.hip) -- no pieces, no scales, nothing that
             // depends on the operands' range.  A plain loop (load -> store -> barrier -> MFMAs -> barrier); it shares the accumulators,

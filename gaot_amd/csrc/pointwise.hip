@@ -606,10 +606,16 @@ __global__ __launch_bounds__(256) void split_f16_planes_kernel(const F16PlGroupA
         }
         float L = 0.f;
         if (cn > 0u) L = fmaxf(0.f, 13.5f - ((float)es / (float)cn - 127.f + (float)((int)(__float_as_uint(sc) >> 23) - 127)));
-        // wave 0 holds the rows, wave 1 the columns: one atomic per wave (atomics of many workgroups on one line serialise)
+        // wave 0 holds the 64 row stretches, wave 1 the 64 column stretches of this tile.  What is published is the tile's EIGHTH-largest L
+        // (to a binade): a vote, as in the consumers -- one dead output feature among 64 does not send every product of the weight through
+        // the slow pass, a row 10^6 times larger than the rest (63 of 64 stretches far below it) does.  One atomic per wave.
+        float Lq = 0.f;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) L = fmaxf(L, __shfl_xor(L, off, 64));
-        if (t == 0 && L > 0.f) atomicMax(reinterpret_cast<unsigned*>(const_cast<float*>(g.it[i].amax)) + (along_row ? 1 : 2), __float_as_uint(L));
+        for (int cand = 4; cand <= 40; cand += 2) {
+            const int n = __builtin_popcountll(__ballot(L >= (float)cand));
+            if (n >= 8) Lq = (float)(cand + 1);          // (the eighth-largest lies in [cand, cand + 2))
+        }
+        if (t == 0 && Lq > 0.f) atomicMax(reinterpret_cast<unsigned*>(const_cast<float*>(g.it[i].amax)) + (along_row ? 1 : 2), __float_as_uint(Lq));
     }
     const int pp = tid & 15;                        // four consecutive output columns per thread: 8-byte stores of h and of m
 #pragma unroll
