@@ -83,9 +83,12 @@ struct SplitGeom {
 // magnitude of the thread's row, robust against the outliers themselves) -- five vector instructions per operand and k-tile.  At the end
 // L = log2(scaled tensor maximum / that mean) per thread, and if L_a + L_b exceeds 17 for an eighth of the workgroup's threads -- or
 // a mean sits ABOVE the tensor's claimed maximum: a stale word -- the workgroup computes its tile AGAIN on the fp32 MFMA, straight from
-// the fp32 operands (no pieces, no scales: exact for any spread; one LDS stage, a plain loop: slow, and rare).  Exact zeros are exempt (empty latent tokens, ReLU outputs).  Pre-split weight planes
-// carry their L in the weight's magnitude word (gaot_split_f16_planes_grouped: float 1 = along the rows, float 2 = along the columns of
-// the matrix as stored).
+// the fp32 operands (no pieces, no scales: exact for any spread; one LDS stage, a plain loop: slow, and rare).  Exact zeros are exempt
+// (empty latent tokens, ReLU outputs).  Pre-split weight planes carry their L in the weight's magnitude word
+// (gaot_split_f16_planes_grouped: float 1 = along the rows, float 2 = along the columns of the matrix as stored).
+// Where a workgroup stages BOTH operands in the same layout (the weight gradients dY^T X; x W^T without planes) a thread's groups of A
+// and of B cover the same contraction indices, and it evaluates the bound itself instead of the two means: sum over its slices of
+// max(g_a g_b, floor_a g_b, floor_b g_a) against 4 sum g_a g_b (`PAIRED` below) -- a slice counts with the weight it has in the output.
 __device__ unsigned g_split_redo_tiles = 0;          // tiles that took the second pass since the last gaot_debug_split_redo_count(1)
 
 // ONE output tile (`logical` in the XCD-aware order of the caller, K slab `zs` of p.split_k) of the product described by p.
@@ -112,6 +115,15 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
     // per operand ONE register: sum of the biased exponents of this thread's non-zero group maxima (low 20 bits: < 4 096 k-tiles x 255)
     // and their count (high 12 bits)
     unsigned ec_a = 0u, ec_b = 0u;
+    // PAIRED tracking (both operands staged here AND laid out alike, so that a thread's group of A and its group of B hold the SAME
+    // contraction indices: the weight-gradient products dY^T X, and x W^T without planes): per k-tile the slice's weight w = g_a g_b (the
+    // groups' largest magnitudes) and its error in units of 2^-22 w: max(1, floor_a / g_a, floor_b / g_b), floor = 2^-3 / scale (below it
+    // the second piece goes subnormal).  The tile is suspect when the floors add up to more than four times the rounding the
+    // products carry anyway: sum max(w, floor_a g_b, floor_b g_a) > 4 sum w.  A tiny gradient row that meets an ordinary activation
+    // row weighs nothing in either sum (thousands of empty latent tokens on the 3-D cloud: 230 tiles per step were redone before this
+    // form); a tiny gradient row that meets a MASSIVE activation row -- what RMSNorm's backward makes of a massive token -- does.
+    constexpr bool PAIRED = !BPL && AK == BKM;
+    float trk_w = 0.f, trk_r = 0.f, trk_m = 0.f, thr_a = 0.f, thr_b = 0.f;          // (trk_m: largest scaled magnitude -- a stale word)
     constexpr int NPL = G::NPL;
     constexpr int BN = G::BN, NW = G::NW, NT = G::NT, WAVES_N = G::WAVES_N, WM = G::WM, WN = G::WN, TM = G::TM, TN = G::TN;
     constexpr int ABYTES = BM * 4;       // row stride of a row-contiguous A plane ([k pair][BM rows] of packed dwords; BM = 64 only)
@@ -260,9 +272,12 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
             }
         }
     };
+    auto gmax8 = [](const f32x4 (&r)[2]) -> float {
+        return fmaxf(fmaxf(fmaxf(fabsf(r[0][0]), fabsf(r[0][1])), fmaxf(fabsf(r[0][2]), fabsf(r[0][3]))),
+                     fmaxf(fmaxf(fabsf(r[1][0]), fabsf(r[1][1])), fmaxf(fabsf(r[1][2]), fabsf(r[1][3]))));
+    };
     auto track = [&](unsigned& ec, const f32x4 (&r)[2]) {
-        const float t = fmaxf(fmaxf(fmaxf(fabsf(r[0][0]), fabsf(r[0][1])), fmaxf(fabsf(r[0][2]), fabsf(r[0][3]))),
-                              fmaxf(fmaxf(fabsf(r[1][0]), fabsf(r[1][1])), fmaxf(fabsf(r[1][2]), fabsf(r[1][3]))));
+        const float t = gmax8(r);
         const unsigned e = __float_as_uint(t) >> 23;          // 0 for a zero (or denormal) group: exempt
         ec += e + (e != 0u ? (1u << 20) : 0u);
     };
@@ -270,8 +285,16 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
         if (ABL & 32) { asm volatile("" :: "v"(xa[0][0]), "v"(xb.f[0][0]), "v"(xa[1][3]), "v"(xb.f[1][3])); return; }     // tuning: no LDS plane writes
         unsigned char* sa = smem_raw + stage * STAGE;
         if (DETECT) {
-            track(ec_a, xa);
-            if (!BPL) track(ec_b, xb.f);
+            if (PAIRED) {
+                const float ga = gmax8(xa), gb = gmax8(xb.f);
+                const float w = ga * gb;
+                trk_w += w;
+                trk_m = fmaxf(trk_m, fmaxf(ga * sc_a, gb * sc_b));
+                trk_r += w > 0.f ? fmaxf(fmaxf(w, thr_a * gb), thr_b * ga) : 0.f;
+            } else {
+                track(ec_a, xa);
+                if (!BPL) track(ec_b, xb.f);
+            }
         }
         stage_store(sa, xa, AK, A_FULL, PA, 128, BM == 64, sc_a);
         if (BPL) {
@@ -378,6 +401,7 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
     gload(kt_begin, ra[0], rb[0]);
     gload(kt_begin + 1, ra[1], rb[1]);
     if (F16) { amax_scale(p.a_amax, sc_a, so_a, p.A2 != nullptr ? p.a2_amax : nullptr); amax_scale(p.b_amax, sc_b, so_b); }
+    thr_a = 0.125f * so_a; thr_b = 0.125f * so_b;
     sstore(0, ra[0], rb[0], kt_begin < kt_end);
     __syncthreads();
     if (FLUSH > 0) {
@@ -431,9 +455,13 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
             const int lb_w = (int)(__uint_as_float(reinterpret_cast<const unsigned*>(p.b_amax)[p.bpl_flag]) * 16.f);
             bad = la + lb_w > 17 * 16 ? 1 : 0;
             stale = la < -24 ? 1 : 0;          // a mean 1.5 binades above the claimed maximum: a stale word
-        } else {            // both operands tracked here
+        } else if (PAIRED) {
+            bad = trk_r > 4.f * trk_w ? 1 : 0;
+            stale = !(trk_w < 3.0e38f && trk_m < 32768.f) ? 1 : 0;          // a word 2x too small or more (fresh ones scale the maximum
+                                                                            // into [2^13, 2^14)): the first piece would leave fp16; inf / NaN operands
+        } else {            // both operands tracked here, laid out differently: each thread votes on its own pair of streams
             const int lb = spread(ec_b, sc_b);
-            bad = la + lb > 17 * 16 ? 1 : 0;          // each thread stages one row stream of A and one of B: it votes on its own pair
+            bad = la + lb > 17 * 16 ? 1 : 0;
             stale = (la < -24 || lb < -24) ? 1 : 0;
         }
         if (kt_end - kt_begin >= 4096) stale = 1;          // (a k range too long for the packed counters: play safe)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Which products of a C2 training step send tiles through the fp16 pieces' second (three-piece) pass?  (gemm_split.hip "Dynamic range
-of the fp16 pieces"; the device counter gaot_debug_split_redo_count).  usage: redo_count.py [steps]"""
+"""Which products of a training step (C2, or `c5`) send tiles through the fp16 pieces' second pass?  (gemm_split.hip "Dynamic range of the
+fp16 pieces"; the device counter gaot_debug_split_redo_count), and how far below their tensor's maximum do the operands' rows and groups sit?
+usage: redo_count.py [c5]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,11 +12,16 @@ from gaot_amd.trainer import TrainStep
 lib = _lib.load()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-model = bench.build_model().to(dev).train()
-lat, x, p, t = bench.synthetic(1234, dev)
-ts = TrainStep(model, use_graph=False)
-ts.bind(p, t, latent_tokens_coord=lat, xcoord=x)
-for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 2):
+if len(sys.argv) > 1 and sys.argv[1] == "c5":
+    import tools.bench_configs as bc
+    ts = bc.c5(build_only=True)
+    ts.use_graph = False
+else:
+    model = bench.build_model().to(dev).train()
+    lat, x, p, t = bench.synthetic(1234, dev)
+    ts = TrainStep(model, use_graph=False)
+    ts.bind(p, t, latent_tokens_coord=lat, xcoord=x)
+for _ in range(int(os.environ.get("WARM", "2"))):
     ts.step()
 torch.cuda.synchronize()
 lib.gaot_debug_split_redo_count(1)
