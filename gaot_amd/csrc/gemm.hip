@@ -365,8 +365,10 @@ extern "C" int gaot_debug_set_gemm_pieces(int n) {
 }
 int gaot_forced_pieces() { return g_split_pieces_forced ? g_split_pieces : 0; }
 
+static int g_use_ad = 1;         // all-DMA fp16-piece tiles: 0 off, 1 per the heuristic, 2 / 3: 64- / 128-row tiles wherever eligible (A/B switch)
+extern "C" int gaot_debug_set_gemm_ad(int on) { const int old = g_use_ad; g_use_ad = on; return old; }
 static int g_use_planes = 1;     // 0: ignore gaot_gemm_desc.b_planes (A/B switch)
-extern "C" unsigned gaot_debug_split_redo_count(int reset) { return gaot::split_redo_count(reset != 0); }
+extern "C" unsigned gaot_debug_split_redo_count(int reset) { return gaot::split_redo_count(reset != 0) + gaot::ad_redo_count(reset != 0); }
 extern "C" int gaot_debug_set_gemm_planes(int on) { const int old = g_use_planes; g_use_planes = on; return old; }
 static int g_ablate = 0;
 extern "C" int gaot_debug_set_gemm_ablate(int bits) { const int old = g_ablate; g_ablate = bits; return old; }
@@ -507,6 +509,17 @@ static int gemm_run(const gaot_gemm_desc* d, gaot_stream_t stream, const bool dr
         g_last_path = 3;
         // 256x128 (8-wave) tiles: measured +3-7 % on the NT / TN products that still give ~200 workgroups, -2 % on NN
         const bool big = split128 && a.M >= 512 && (g_split_bm256 == 2 || (g_split_bm256 == 1 && ak == bk && blocks(256, 128) >= 190));
+        // all-DMA tiles (gemm_ad.hip; tools/ad_bench.hip, same box, us staged -> all-DMA): outputs two tiles wide (N <= 256) on 64-row
+        // tiles: 8192 x 256 x 256 13.5 -> 11.8, x 768 26.7 -> 22.1, x 1024 32.8 -> 26.8; products whose 128-row tiles would not fill two
+        // workgroups per CU (the 4 096-token batches) on 64-row tiles as well, at exactly 512 tiles on 128-row ones; two rounds of
+        // 128-row tiles (8192 x 2048 x 256: 49 -> 51-54 us) stay on the staged kernel -- there the output stores decide.  Step level
+        // (tools/step_ab.py, same box): C2 2.3225 -> 2.2666 ms, C4-shaped 1.8169 -> 1.7888
+        const bool ad_ok = g_use_ad && pieces == 4 && a.Bpl != nullptr && ak && a.K % 32 == 0 && a.vec_epi && (a.A2 == nullptr || a.k_split % 32 == 0);
+        const bool ad64 = ad_ok && (g_use_ad == 2 || ((cdiv(a.N, 128) <= 2 || blocks(128, 128) < 512) && blocks(64, 128) >= 128));
+        const bool ad128 = ad_ok && !ad64 && !big && (g_use_ad == 3 || (split128 && blocks(128, 128) <= 512));
+        if (ad64) launch_ad(a, bk, st, 64);
+        else if (ad128) launch_ad(a, bk, st, 128);
+        else
         launch_split(a, ak, bk, st, split64 ? 64 : (big && pieces != 1 ? 256 : 128), pieces);
     }
     else if (glds_ok && g_tile_override >= 0 && g_tile_override <= 3) {

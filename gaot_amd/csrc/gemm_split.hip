@@ -469,8 +469,18 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
         // -- a massive token or channel, a quarter of the rows tiny -- raise (nearly) every thread; a few tiny rows among ordinary ones
         // (tokens of an almost empty latent patch: thousands per step on the skewed NACA meshes) do not: those rows keep the absolute
         // floor, 2^-39 of the tensor's largest magnitude, which only their own (tiny) outputs see.
-        const int votes = __syncthreads_count(bad);
-        if (__builtin_expect(__syncthreads_or(stale) || votes * 8 >= NT, 0)) {
+        // (one barrier: every wave leaves its count and its stale flag in LDS; __syncthreads_count + __syncthreads_or are six)
+        __shared__ int s_vote[8];
+        {
+            const int nb = __popcll(__ballot(bad != 0)), ns = __ballot(stale != 0) != 0ull ? 1 : 0;
+            if (lane == 0) s_vote[wave] = nb | (ns << 16);
+        }
+        __syncthreads();
+        int vsum = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) vsum += s_vote[w];
+        const int votes = vsum & 0xffff;
+        if (__builtin_expect((vsum >> 16) != 0 || votes * 8 >= NT, 0)) {
             // ---- the second pass: the operands as they are, fp32, through ONE LDS stage ([row][16 k], row stride 20 floats) into the
             // fp32 MFMA (v_mfma_f32_32x32x2_f32: the arithmetic of the fp32-MFMA tiles, gemm.hip) -- no pieces, no scales, nothing that
             // depends on the operands' range.  A plain loop (load -> store -> barrier -> MFMAs -> barrier); it shares the accumulators,

@@ -29,6 +29,8 @@ int gaot_debug_set_gemm_glds(int on);
 int gaot_debug_set_gemm_pieces(int pieces);
 /* 0: ignore gaot_gemm_desc.b_planes (same-box A/B of the pre-split weight planes; bit-identical results); returns the old value */
 int gaot_debug_set_gemm_planes(int on);
+/* all-DMA fp16-piece tiles (gemm_ad.hip): 0 off, 1 per the heuristic (default), 2 / 3: 64- / 128-row tiles wherever eligible; returns the old value */
+int gaot_debug_set_gemm_ad(int on);
 /* fp16-piece products: output tiles (of the split tile kernels and the grouped weight-gradient launch) that took the per-row second pass
  * since the counter was last reset -- a tile whose operand rows span more than 2^13 in magnitude is recomputed with one power-of-two
  * scale per row (gemm_split.hip).  Synchronises the device.  reset != 0: zero the counter after reading it. */
