@@ -510,13 +510,14 @@ static int gemm_run(const gaot_gemm_desc* d, gaot_stream_t stream, const bool dr
         // 256x128 (8-wave) tiles: measured +3-7 % on the NT / TN products that still give ~200 workgroups, -2 % on NN
         const bool big = split128 && a.M >= 512 && (g_split_bm256 == 2 || (g_split_bm256 == 1 && ak == bk && blocks(256, 128) >= 190));
         // all-DMA tiles (gemm_ad.hip; tools/ad_bench.hip, same box, us staged -> all-DMA): outputs two tiles wide (N <= 256) on 64-row
-        // tiles: 8192 x 256 x 256 13.5 -> 11.8, x 768 26.7 -> 22.1, x 1024 32.8 -> 26.8; products whose 128-row tiles would not fill two
-        // workgroups per CU (the 4 096-token batches) on 64-row tiles as well, at exactly 512 tiles on 128-row ones; two rounds of
-        // 128-row tiles (8192 x 2048 x 256: 49 -> 51-54 us) stay on the staged kernel -- there the output stores decide.  Step level
+        // tiles: 8192 x 256 x 256 13.5 -> 11.8, x 768 26.7 -> 22.1, x 1024 32.8 -> 26.8; wider outputs on 64-row tiles while those fit
+        // one round of two workgroups per CU (the 4 096-token batches), else on 128-row ones while THOSE fit one round; what needs more
+        // rounds (8192 x 2048 x 256: 49 -> 51-54 us; x 768: 23.2 -> 26.8 on 64-row tiles) and the K-slab products (8192 x 256 x 2048 in
+        // two slabs: 42.9 -> 42.6) stay on the staged kernel -- there the output stores / the slab count decide.  Step level
         // (tools/step_ab.py, same box): C2 2.3225 -> 2.2666 ms, C4-shaped 1.8169 -> 1.7888
         const bool ad_ok = g_use_ad && pieces == 4 && a.Bpl != nullptr && ak && a.K % 32 == 0 && a.vec_epi && (a.A2 == nullptr || a.k_split % 32 == 0);
-        const bool ad64 = ad_ok && (g_use_ad == 2 || ((cdiv(a.N, 128) <= 2 || blocks(128, 128) < 512) && blocks(64, 128) >= 128));
-        const bool ad128 = ad_ok && !ad64 && !big && (g_use_ad == 3 || (split128 && blocks(128, 128) <= 512));
+        const bool ad64 = ad_ok && (g_use_ad == 2 || (a.split_k <= 1 && (cdiv(a.N, 128) <= 2 || blocks(64, 128) <= 512) && blocks(64, 128) >= 128));
+        const bool ad128 = ad_ok && !ad64 && !big && (g_use_ad == 3 || (a.split_k <= 1 && split128 && blocks(128, 128) <= 512));
         if (ad64) launch_ad(a, bk, st, 64);
         else if (ad128) launch_ad(a, bk, st, 128);
         else

@@ -23,7 +23,7 @@ __global__ void ref_kernel(const float* A, const float* W, double* C, int M, int
 static float amax_of(const std::vector<float>& v) { float m = 0.f; for (float x : v) m = fmaxf(m, fabsf(x)); return m; }
 static float scale_of(float amax) { unsigned b; memcpy(&b, &amax, 4); const int e = (b >> 23) & 0xff; int se = 140 - e; se = se > 126 ? 126 : (se < -126 ? -126 : se); return ldexpf(1.f, se); }
 
-struct Case { int M, N, K, bm, act; const char* name; };
+struct Case { int M, N, K, bm, act; const char* name; int sk = 1; int bm_old = 0; };
 
 static void run_case(const Case& c, int iters) {
     const int M = c.M, N = c.N, K = c.K;
@@ -52,17 +52,20 @@ static void run_case(const Case& c, int iters) {
     hipMemcpy(wa, wordA.data(), 4096, hipMemcpyHostToDevice); hipMemcpy(ww, wordW.data(), 4096, hipMemcpyHostToDevice);
     hipMemset(C0, 0, (size_t)M * N * 4); hipMemset(C1, 0xff, (size_t)M * N * 4);
     GemmArgs a{}; a.M = M; a.N = N; a.K = K; a.A = A; a.lda = K; a.B = W; a.ldb = K; a.ldc = NO;
-    a.split_k = 1; a.ktiles_per_split = K / 32; a.vec_epi = 1; a.rb_period = 1; a.act = c.act;
+    a.split_k = c.sk; a.ktiles_per_split = cdiv(K / 32, c.sk); a.vec_epi = 1; a.rb_period = 1; a.act = c.act;
+    float* ws = nullptr; if (c.sk > 1) { hipMalloc(&ws, (size_t)c.sk * ((size_t)M * N + M) * 4); a.ws = ws; }
     a.a_amax = wa; a.b_amax = ww; a.Bpl = P; a.ld_bpl = 2 * K; a.bpl_stride = 16;
     if (c.act == GAOT_ACT_SWIGLU) { a.aux_out = aux; a.ld_aux = N; }
     hipEvent_t s, e; hipEventCreate(&s); hipEventCreate(&e);
     float t_old, t_new;
     {
         GemmArgs b = a; b.C = C0;
-        for (int i = 0; i < 5; ++i) launch_split(b, true, true, 0, c.bm, 4);
+        const int bmo = c.bm_old ? c.bm_old : c.bm;
+        for (int i = 0; i < 5; ++i) launch_split(b, true, true, 0, bmo, 4);
         hipEventRecord(s, 0);
-        for (int i = 0; i < iters; ++i) launch_split(b, true, true, 0, c.bm, 4);
+        for (int i = 0; i < iters; ++i) launch_split(b, true, true, 0, bmo, 4);
         hipEventRecord(e, 0); hipEventSynchronize(e); hipEventElapsedTime(&t_old, s, e);
+        if (c.sk > 1) hipMemcpy(C0, ws + (size_t)M * N, (size_t)M * N * 4, hipMemcpyDeviceToDevice);
     }
     {
         GemmArgs b = a; b.C = C1;
@@ -70,12 +73,14 @@ static void run_case(const Case& c, int iters) {
         hipEventRecord(s, 0);
         for (int i = 0; i < iters; ++i) launch_ad(b, true, 0, c.bm);
         hipEventRecord(e, 0); hipEventSynchronize(e); hipEventElapsedTime(&t_new, s, e);
+        if (c.sk > 1) hipMemcpy(C1, ws + (size_t)M * N, (size_t)M * N * 4, hipMemcpyDeviceToDevice);
     }
     float t_nd;
     {
         GemmArgs b = a; b.C = C1; b.tiles_m = cdiv(b.M, c.bm); b.tiles_n = cdiv(b.N, 128); b.bpl_flag = 1;
-        dim3 grid(b.tiles_m * b.tiles_n), block(256);
-        auto go = [&]() { if (c.bm == 64) hipLaunchKernelGGL((gemm_ad_kernel<64, 2, 2, true, 0>), grid, block, 0, 0, b); else hipLaunchKernelGGL((gemm_ad_kernel<128, 2, 2, true, 0>), grid, block, 0, 0, b); };
+        if (c.bm == 64) b.tiles_m = cdiv(b.M, 128);
+        dim3 grid(b.tiles_m * b.tiles_n, 1, c.sk), block(256);
+        auto go = [&]() { hipLaunchKernelGGL((gemm_ad_kernel<128, 4, 2, true, 0>), grid, block, 0, 0, b); };
         for (int i = 0; i < 5; ++i) go();
         hipEventRecord(s, 0);
         for (int i = 0; i < iters; ++i) go();
@@ -86,7 +91,7 @@ static void run_case(const Case& c, int iters) {
     hipMemcpy(h0.data(), C0, h0.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(h1.data(), C1, h1.size() * 4, hipMemcpyDeviceToHost);
     size_t diff = 0; for (size_t i = 0; i < h0.size(); ++i) diff += memcmp(&h0[i], &h1[i], 4) != 0;
     double e_old = -1, e_new = -1;
-    if (c.act == 0) {
+    if (c.act == 0 && c.sk == 1) {
         ref_kernel<<<dim3((N + 255) / 256, M), 256>>>(A, W, R, M, N, K);
         std::vector<double> hr((size_t)M * N);
         hipMemcpy(hr.data(), R, hr.size() * 8, hipMemcpyDeviceToHost);
@@ -95,7 +100,7 @@ static void run_case(const Case& c, int iters) {
         e_old = d0 / mx; e_new = d1 / mx;
     }
     const double gf = 2.0 * M * N * K * 1e-6;
-    printf("%-10s M=%5d N=%5d K=%5d bm=%3d act=%d | staged %.1f us (%.0f TF) | direct %.1f us (%.0f TF) | x%.2f | variant (128: 2x2 waves; 64: two slots) %.1f us | differing outputs %zu of %zu | err vs f64: staged %.2e direct %.2e | redo %u/%u | %s\n",
+    printf("%-10s M=%5d N=%5d K=%5d bm=%3d act=%d | staged %.1f us (%.0f TF) | direct %.1f us (%.0f TF) | x%.2f | all-DMA 128-row 4x1 %.1f us | differing outputs %zu of %zu | err vs f64: staged %.2e direct %.2e | redo %u/%u | %s\n",
            c.name, M, N, K, c.bm, c.act, t_old * 1e3 / iters, gf / (t_old * 1e3 / iters), t_new * 1e3 / iters, gf / (t_new * 1e3 / iters), t_old / t_new, t_nd * 1e3 / iters,
            diff, h0.size(), e_old, e_new, split_redo_count(true), ad_redo_count(true), hipGetErrorString(err));
     hipFree(A); hipFree(W); hipFree(P); hipFree(C0); hipFree(C1); hipFree(R); hipFree(aux); hipFree(wa); hipFree(ww);
@@ -156,6 +161,11 @@ int main(int argc, char** argv) {
         {4096, 256, 256, 64, 0, "c4-o"},
         {8000, 200, 96, 64, 0, "ragged"},
         {300, 136, 32, 128, 0, "tiny"},
+        {8192, 256, 2048, 64, 0, "w13b-sk2", 2, 128},
+        {8192, 256, 2048, 64, 0, "w13b-sk2", 2, 64},
+        {8192, 256, 2048, 64, 0, "w13b-sk4", 4, 128},
+        {8192, 256, 1024, 64, 0, "w2-sk2", 2, 64},
+        {8192, 768, 256, 64, 0, "qkv", 1, 64},
     };
     for (const Case& c : cases) run_case(c, iters);
     return 0;
