@@ -130,6 +130,12 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
     constexpr int PA = G::PA, PB = G::PB, STAGE = G::STAGE;
     constexpr bool A_FULL = BM * 2 == NT;        // two float4 per thread (else one / half the threads)
     constexpr bool B_FULL = 128 * 2 == NT;
+    // LANES4: with pre-split weight planes, 128-row tiles fetch both operands with FOUR lanes per row (64 contiguous bytes: a row's whole
+    // k-tile) and two rows 64 apart per thread, instead of two lanes per row and 32 bytes each: a wave instruction then covers 16 rows x 64 B
+    // instead of 64 separate 16-byte pieces, which the texture addresser takes one at a time (tools/ad_bench.hip: that address path, not
+    // the LDS or the matrix pipe, is what these tiles wait for at K = 256).  Same planes in LDS, same products: bit-identical.
+    constexpr bool A4 = AK && A_FULL && BPL && NT == 256;
+    constexpr bool B4 = BPL && B_FULL && NT == 256;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -160,16 +166,19 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
     // workgroup's life -- at K = 256 a workgroup lives for sixteen k-tiles)
     const float* a_src[2]; const float* b_src[2];
     // concatenated input (k-contiguous A only): columns k >= k_split come from A2 -- as an element offset from this thread's A row
-    long a2_delta = 0;
+    long a2_delta = 0, a2_delta1 = 0;          // (a2_delta1: the second row of a LANES4 thread)
     if (AK && p.A2 != nullptr) {
-        const long row = min(m0 + (A_FULL ? tid >> 1 : tid >> 2), p.M - 1);
+        const long row = min(m0 + (A4 ? tid >> 2 : (A_FULL ? tid >> 1 : tid >> 2)), p.M - 1);
         a2_delta = (reinterpret_cast<long>(p.A2) - reinterpret_cast<long>(p.A)) / 4 + row * (p.lda2 - p.lda) - p.k_split;
+        if (A4) a2_delta1 = (reinterpret_cast<long>(p.A2) - reinterpret_cast<long>(p.A)) / 4 + min(m0 + 64 + (tid >> 2), p.M - 1) * (long)(p.lda2 - p.lda) - p.k_split;
     }
     const unsigned short* bp_src = nullptr;
+    const unsigned short* bp_src4[2] = {nullptr, nullptr};
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         if (AK) {
-            if (A_FULL) a_src[q] = p.A + (long)min(m0 + (tid >> 1), p.M - 1) * p.lda + (tid & 1) * 8 + q * 4;
+            if (A4) a_src[q] = p.A + (long)min(m0 + 64 * q + (tid >> 2), p.M - 1) * p.lda + (tid & 3) * 4;
+            else if (A_FULL) a_src[q] = p.A + (long)min(m0 + (tid >> 1), p.M - 1) * p.lda + (tid & 1) * 8 + q * 4;
             else        a_src[q] = p.A + (long)min(m0 + (tid >> 2), p.M - 1) * p.lda + (tid & 3) * 4;      // one float4 per thread (q = 0)
         } else {
             if (A_FULL) a_src[q] = p.A + (long)(2 * (tid & 7) + q) * p.lda + min(m0 + (tid >> 3) * 4, p.M - 4);
@@ -185,6 +194,16 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
             }
             b_src[q] = B_FULL ? p.B + (long)nrow * p.ldb + (tid & 1) * 8 + q * 4 : p.B + (long)nrow * p.ldb + (tid & 3) * 4;
             if (BPL) bp_src = B_FULL ? p.Bpl + (long)nrow * p.ld_bpl + (tid & 1) * 8 : p.Bpl + (long)nrow * p.ld_bpl + (tid & 3) * 4;
+            if (B4) {          // row 64 q + (tid >> 2), 16-byte chunk tid & 3 of the k-group's [h 16 | m 16]
+                const int row4 = 64 * q + (tid >> 2);
+                int nrow4 = min(n0 + row4, p.N - 1);
+                if (p.act == GAOT_ACT_SWIGLU) {
+                    const int F = p.N >> 1, within = row4 % WN;
+                    const int gcol = (n0 >> 1) + (row4 / WN) * (WN / 2) + within % (WN / 2);
+                    nrow4 = (within / (WN / 2)) * F + min(gcol, F - 1);
+                }
+                bp_src4[q] = p.Bpl + (long)nrow4 * p.ld_bpl + (tid & 3) * 8;
+            }
         } else {      // 128 rows: (k pair = tid & 7, row quad = tid >> 3) for the first 256 threads
             b_src[q] = p.B + (long)(2 * (tid & 7) + q) * p.ldb + min(n0 + ((tid >> 3) & 31) * 4, p.N - 4);
         }
@@ -199,7 +218,7 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
         for (int q = 0; q < 2; ++q) {
             const bool a_live = A_FULL || (AK ? q == 0 : tid < 128);
             const bool b_live = B_FULL || (BKM ? q == 0 : tid < 256);
-            if (a_live) xa[q] = *reinterpret_cast<const f32x4*>(AK ? a_src[q] + k0 + ((p.A2 != nullptr && k0 >= p.k_split) ? a2_delta : 0L) : a_src[q] + k0 * p.lda);
+            if (a_live) xa[q] = *reinterpret_cast<const f32x4*>(AK ? a_src[q] + k0 + ((p.A2 != nullptr && k0 >= p.k_split) ? ((A4 && q == 1) ? a2_delta1 : a2_delta) : 0L) : a_src[q] + k0 * p.lda);
             else xa[q] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (!BPL) {
                 if (b_live) xb.f[q] = *reinterpret_cast<const f32x4*>(BKM ? b_src[q] + k0 : b_src[q] + k0 * p.ldb);
@@ -209,7 +228,8 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
         if (BPL) {
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) {
-                if (B_FULL) xb.pl[pl] = *reinterpret_cast<const u32x4*>(bp_src + pl * 16 + k0 * 2);
+                if (B4) xb.pl[pl] = *reinterpret_cast<const u32x4*>(bp_src4[pl] + k0 * 2);
+                else if (B_FULL) xb.pl[pl] = *reinterpret_cast<const u32x4*>(bp_src + pl * 16 + k0 * 2);
                 else { const u32x2 v = *reinterpret_cast<const u32x2*>(bp_src + pl * 16 + k0 * 2); xb.pl[pl] = u32x4{v[0], v[1], 0u, 0u}; }
             }
         }
@@ -296,10 +316,26 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
                 if (!BPL) track(ec_b, xb.f);
             }
         }
+        if (A4) {          // rows (tid >> 2) and 64 + (tid >> 2), k = 4 (tid & 3) .. + 3: one 8-byte write per row and plane
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                u32x2 h, m;
+                unsigned a_, b_, c_;
+                split_pair<NP, ABL>(xa[q][0], xa[q][1], a_, b_, c_, sc_a); h[0] = a_; m[0] = b_;
+                split_pair<NP, ABL>(xa[q][2], xa[q][3], a_, b_, c_, sc_a); h[1] = a_; m[1] = b_;
+                unsigned char* dst = sa + (64 * q + (tid >> 2)) * 48 + (tid & 3) * 8;
+                *reinterpret_cast<u32x2*>(dst) = h;
+                *reinterpret_cast<u32x2*>(dst + PA) = m;
+            }
+        } else
         stage_store(sa, xa, AK, A_FULL, PA, 128, BM == 64, sc_a);
         if (BPL) {
             unsigned char* sb = sa + NPL * PA;
-            if (B_FULL) {
+            if (B4) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    *reinterpret_cast<u32x4*>(sb + ((tid & 3) >> 1) * PB + (64 * q + (tid >> 2)) * 48 + (tid & 1) * 16) = xb.pl[q];
+            } else if (B_FULL) {
                 unsigned char* dst = sb + (tid >> 1) * 48 + (tid & 1) * 16;
                 *reinterpret_cast<u32x4*>(dst) = xb.pl[0];
                 *reinterpret_cast<u32x4*>(dst + PB) = xb.pl[1];
@@ -509,9 +545,10 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
                 const long k0 = (long)kt * SBK;
                 f32x4 xa0 = {0.f, 0.f, 0.f, 0.f}, xa1 = xa0, xb0 = xa0, xb1 = xa0;
                 if (AK) {
-                    const long d = (p.A2 != nullptr && k0 >= p.k_split) ? a2_delta : 0L;
+                    const bool sec = p.A2 != nullptr && k0 >= p.k_split;
+                    const long d = sec ? a2_delta : 0L, d1 = sec ? (A4 ? a2_delta1 : a2_delta) : 0L;
                     xa0 = *reinterpret_cast<const f32x4*>(a_src[0] + k0 + d);
-                    if (A_FULL) xa1 = *reinterpret_cast<const f32x4*>(a_src[1] + k0 + d);
+                    if (A_FULL) xa1 = *reinterpret_cast<const f32x4*>(a_src[1] + k0 + d1);
                 } else if (A_FULL || tid < 128) {
                     xa0 = *reinterpret_cast<const f32x4*>(a_src[0] + k0 * p.lda);
                     xa1 = *reinterpret_cast<const f32x4*>(a_src[1] + k0 * p.lda);
@@ -524,7 +561,10 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
                     xb1 = *reinterpret_cast<const f32x4*>(bf1 + k0 * p.ldb);
                 }
                 if (AK) {
-                    if (A_FULL) {
+                    if (A4) {
+                        *reinterpret_cast<f32x4*>(As + (tid >> 2) * LDS_S + (tid & 3) * 4) = xa0;
+                        *reinterpret_cast<f32x4*>(As + (64 + (tid >> 2)) * LDS_S + (tid & 3) * 4) = xa1;
+                    } else if (A_FULL) {
                         *reinterpret_cast<f32x4*>(As + (tid >> 1) * LDS_S + (tid & 1) * 8) = xa0;
                         *reinterpret_cast<f32x4*>(As + (tid >> 1) * LDS_S + (tid & 1) * 8 + 4) = xa1;
                     } else *reinterpret_cast<f32x4*>(As + (tid >> 2) * LDS_S + (tid & 3) * 4) = xa0;
