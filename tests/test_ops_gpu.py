@@ -754,6 +754,57 @@ def test_gemm_fp16_pieces_rows_of_any_magnitude(M, N, K):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(8192, 256, 256), (4096, 2048, 256), (4096, 768, 256), (1000, 200, 96), (8192, 256, 1024), (300, 136, 32)])
+def test_all_dma_tiles_equal_the_staged_tiles_bit_for_bit(M, N, K):
+    """gemm_ad.hip (both operands global -> LDS by DMA, A split in registers from its fp32 LDS image) forms the SAME piece products in the
+    SAME order as the staged tiles of gemm_split.hip: x W^T, dY W, the epilogues (bias + residual, SwiGLU gate with its saved pre-activations,
+    a concatenated input), on 64- and 128-row tiles -- equal to the last bit, through the library's A/B switch."""
+    from gaot_amd import ops, _lib
+    lib = _lib.load()
+    assert ops.precision() == "f32" and ops._F16_PIECES[0]
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).cuda()
+    dy = torch.randn(M, N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).cuda()
+    w = torch.nn.Parameter((torch.randn(N, K, generator=g) * 0.06).cuda())
+    wcat = torch.nn.Parameter((torch.randn(N, 2 * K, generator=g) * 0.06).cuda())
+    b = torch.randn(N, generator=g).cuda()
+    w1 = torch.nn.Parameter((torch.randn(N, K, generator=g) * 0.06).cuda())
+    w3 = torch.nn.Parameter((torch.randn(N, K, generator=g) * 0.06).cuda())
+    w2 = torch.nn.Parameter((torch.randn(K, N, generator=g) * 0.06).cuda())
+
+    def run(mode):
+        old = lib.gaot_debug_set_gemm_ad(mode)
+        try:
+            ops.begin_pass()
+            ops.adopt_adjacent_storage([w1, w3])
+            ops.refresh_weight_amax([w, wcat, w1, w3, w2])
+            out = {}
+            with torch.no_grad():
+                out["nt"] = ops.linear_nt(x, w.detach())
+                out["path"] = lib.gaot_debug_last_gemm_path()
+                out["nn"] = ops.matmul_nn(dy, w.detach())
+                out["lin"] = ops.linear(x, w, b, residual=res)
+                if K % 32 == 0:
+                    out["cat"] = ops.linear(x, wcat, b, x2=x * 0.5)
+                if N % 64 == 0 and K % 32 == 0:
+                    out["ffn"] = ops.swiglu_ffn(x, w1, w3, w2)
+            torch.cuda.synchronize()
+            return out
+        finally:
+            lib.gaot_debug_set_gemm_ad(old)
+
+    ref = run(0)
+    if ref.pop("path") != 3:
+        pytest.skip("this product does not run on the fp16-piece tiles")
+    for mode in (1, 2, 3):
+        got = run(mode)
+        got.pop("path")
+        for k, v in got.items():
+            assert torch.equal(v, ref[k]), (mode, k, float((v - ref[k]).abs().max()))
+
+
+@pytest.mark.gpu
 def test_captured_graph_does_not_bake_in_a_warmup_magnitude_word():
     """A persistent input buffer (TrainStep._x, autograph's e.p, the rollout's static x) is the SAME tensor object, at the same
     `_version`, in the eager warm-up pass and in the capture that follows.  A magnitude word remembered on it by the warm-up must not

@@ -150,6 +150,8 @@ int main(int argc, char** argv) {
     const Case cases[] = {
         {8192, 2048, 256, 128, GAOT_ACT_SWIGLU, "w1w3"},
         {8192, 2048, 256, 128, 0, "w1w3-lin"},
+        {8192, 2048, 256, 64, GAOT_ACT_SWIGLU, "w1w3-64"},
+        {8192, 2048, 256, 64, 0, "w1w3-lin64"},
         {8192, 768, 256, 64, 0, "qkv"},
         {8192, 768, 256, 128, 0, "qkv"},
         {8192, 256, 256, 64, 0, "o_proj"},
