@@ -1839,7 +1839,11 @@ constexpr int AB8_LDS = AB8_SHARED + 8 * AB8_WAVE;
 // F16 (with PP = OP = 2, TR): two fp16 pieces of the scaled operands -- Q, K, V by the power of two from the qkv magnitude word, dO by its
 // own word, P by 2^15, dS by a per-tile power of two from the wave's own maximum (the tile products join the running sums on the vector
 // pipe anyway: the inverse scales ride that fused multiply-add) -- three piece products per k-step on the f16 MFMA.  (P by 2^13, see P_SCALE.)
-template <int PP = 3, int OP = 3, bool TR = false, bool F16 = false>
+// QS = 2: the query tiles of a 256-key block are shared between TWO workgroups (even half / odd half of the sequence) -- batches that give
+// only 128 .. 255 workgroups (4 x 1 024 tokens x 8 heads: BASELINE configs[3]'s per-GPU shape) fill the chip again.  The dQ slabs do not
+// change (a query tile's slab row is still written by exactly one workgroup per key block); dK / dV get exactly TWO contributions per
+// element, added by atomics into zeroed memory: a + b in either order is the same fp32 number, so the result stays deterministic.
+template <int PP = 3, int OP = 3, bool TR = false, bool F16 = false, int QS = 1>
 __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs p) {
     constexpr int DP = 32, NW = 8;
     __shared__ __attribute__((aligned(16))) unsigned char smem[AB8_LDS];
@@ -1853,8 +1857,9 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
-    int bh, kblk;
-    xcd_group_decode(blockIdx.x, p.B * p.H, p.n_kblocks, bh, kblk);
+    int bh, kblk, qhalf = 0;
+    xcd_group_decode(blockIdx.x, p.B * p.H, p.n_kblocks * QS, bh, kblk);
+    if (QS > 1) { qhalf = kblk % QS; kblk /= QS; }
     const int b = bh / p.H, h = bh % p.H, hk = h / (p.H / p.Hkv);
     const int kv0 = kblk * 256 + wave * 32;
     static_assert(!F16 || (PP == 2 && OP == 2), "fp16 pieces come in twos");
@@ -1965,8 +1970,10 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
     const long part_stride = (long)p.B * p.H * p.S * DP;
     float* part = p.dq_part + (long)kblk * part_stride + ((long)b * p.H + h) * p.S * DP;
 
-    fetch(0);
-    for (int qt = 0; qt < nq; ++qt) {
+    const int nq_each = (nq + QS - 1) / QS;
+    const int qt_begin = qhalf * nq_each, qt_end = min(nq, qt_begin + nq_each);
+    fetch(qt_begin * 32);
+    for (int qt = qt_begin; qt < qt_end; ++qt) {
         const int q0 = qt * 32;
         {
             const int row = t8 >> 3, ch = tid & 7;
@@ -1998,7 +2005,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
             if ((tid & 7) == 0) del_s[t8 >> 3] = dsum;
         }
         __syncthreads();                                    // barrier A
-        if (qt + 1 < nq) fetch(q0 + 32);
+        if (qt + 1 < qt_end) fetch(q0 + 32);
 
         f32x16 s, dp;
 #pragma unroll
@@ -2200,8 +2207,9 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
             const int kv = kv0 + rr;
             if (kv < p.S) {
                 const float val = Smine[rr * 33 + li];
-                if (pass == 0) p.dk[((long)b * p.S + kv) * p.lddk + (long)h * 32 + li] = val;
-                else           p.dv[((long)b * p.S + kv) * p.lddv + (long)h * 32 + li] = val;
+                float* dst = pass == 0 ? p.dk + ((long)b * p.S + kv) * p.lddk + (long)h * 32 + li : p.dv + ((long)b * p.S + kv) * p.lddv + (long)h * 32 + li;
+                if (QS > 1) (void)__hip_atomic_fetch_add(dst, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else *dst = val;
                 am = fmaxf(am, fabsf(val));
             }
         }
@@ -2209,7 +2217,8 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    if (F16 && p.dqkv_amax) { __syncthreads(); amax_publish_block<8>(p.dqkv_amax, am, reinterpret_cast<float*>(smem)); }
+    // (QS contributions per element: QS times the largest one bounds the sum -- the word holds max |x| or a bound)
+    if (F16 && p.dqkv_amax) { __syncthreads(); amax_publish_block<8>(p.dqkv_amax, am * (float)QS, reinterpret_cast<float*>(smem)); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2497,6 +2506,8 @@ static int g_attn_op = -1;       // -1 (default): follow the call's `pieces` arg
 extern "C" int gaot_debug_set_attention_operand_pieces(int n) { const int old = g_attn_op; g_attn_op = n == 3 ? 3 : (n == 2 ? 2 : -1); return old; }
 static int g_attn_tr = 1;        // 1 (default): the two-piece 8-wave backward takes its transposed operands through transposing LDS reads
 extern "C" int gaot_debug_set_attention_tr(int on) { const int old = g_attn_tr; g_attn_tr = on ? 1 : 0; return old; }
+static int g_attn_qsplit = 1;    // 1 (default): the 8-wave fp16-piece backward shares a key block's query tiles between two workgroups when that fills the chip (A/B switch)
+extern "C" int gaot_debug_set_attention_qsplit(int on) { const int old = g_attn_qsplit; g_attn_qsplit = on ? 1 : 0; return old; }
 static int g_attn_pipe = 0;      // 1 = the software-pipelined 8-wave forward for S % 64 == 0 (same speed as the plain one since both keep the
                                  // tile product off the running accumulator: 57.6 vs 58.0 us; kept for tools/attn_ablate.hip and as a tested variant)
 extern "C" int gaot_debug_set_attention_pipe(int on) { const int old = g_attn_pipe; g_attn_pipe = on; return old; }
@@ -2671,7 +2682,10 @@ extern "C" int gaot_attention_bwd(const float* q, const float* k, const float* v
     bool dkdv_published = false;
     const int DP = head_dim <= 32 ? 32 : (head_dim <= 64 ? 64 : 128);
     const bool split_ok = head_dim == 32 && a.vec && g_attn_split && aligned16(dq) && aligned16(dk) && aligned16(dv);
-    const bool fused_delta = f16 && split_ok && aligned16(o) && g_attn_split != 3 && (g_attn_split == 2 || (long)cdiv(S, 256) * B * H >= 256);   // the fp16 8-wave kernel forms delta itself
+    // 128 .. 255 workgroups of 256 keys: the query tiles of a key block go to two workgroups (attn_bwd_split8_kernel QS = 2)
+    const long wg8 = (long)cdiv(S, 256) * B * H;
+    const bool qsplit = f16 && split_ok && aligned16(o) && g_attn_split == 1 && g_attn_qsplit && wg8 >= 128 && wg8 < 256 && cdiv(S, 32) >= 8;
+    const bool fused_delta = f16 && split_ok && aligned16(o) && g_attn_split != 3 && (g_attn_split == 2 || wg8 >= 256 || qsplit);   // the fp16 8-wave kernel forms delta itself
     if (fused_delta) {
     } else if (a.vec && aligned16(o)) {
         const int lpr = 8;
@@ -2680,7 +2694,14 @@ extern "C" int gaot_attention_bwd(const float* q, const float* k, const float* v
         hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv((long)B * S * H, 256)), dim3(256), 0, ST(stream), a);
     }
     dim3 grid(a.n_kblocks * B * H), block(256);
-    if (split_ok && g_attn_split != 3 && (g_attn_split == 2 || (long)cdiv(S, 256) * B * H >= 256)) {
+    if (qsplit) {
+        a.n_kblocks = cdiv(S, 256);
+        // dK / dV receive two atomic contributions per element: zero them first (column blocks of the fused dqkv buffer: pitched fills)
+        hipMemset2DAsync(dk, (size_t)lddk * 4, 0, (size_t)H * 32 * 4, (size_t)B * S, ST(stream));
+        hipMemset2DAsync(dv, (size_t)lddv * 4, 0, (size_t)H * 32 * 4, (size_t)B * S, ST(stream));
+        hipLaunchKernelGGL((attn_bwd_split8_kernel<2, 2, true, true, 2>), dim3(a.n_kblocks * B * H * 2), dim3(512), 0, ST(stream), a);
+        dkdv_published = true;
+    } else if (split_ok && g_attn_split != 3 && (g_attn_split == 2 || (long)cdiv(S, 256) * B * H >= 256)) {
         a.n_kblocks = cdiv(S, 256);          // 256 keys per workgroup: half the dQ slabs (the workspace is sized for 128)
         if (f16 && fused_delta) { hipLaunchKernelGGL((attn_bwd_split8_kernel<2, 2, true, true>), dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a); dkdv_published = true; }
         else if (g_attn_pp % 10 == 3) hipLaunchKernelGGL(attn_bwd_split8_kernel<3>, dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a);

@@ -31,6 +31,9 @@ int gaot_debug_set_gemm_pieces(int pieces);
 int gaot_debug_set_gemm_planes(int on);
 /* all-DMA fp16-piece tiles (gemm_ad.hip): 0 off, 1 per the heuristic (default), 2 / 3: 64- / 128-row tiles wherever eligible; returns the old value */
 int gaot_debug_set_gemm_ad(int on);
+/* attention backward, head_dim 32, fp16 pieces: 1 (default) lets two workgroups share the query tiles of a 256-key block when the launch
+ * would otherwise hold 128 .. 255 workgroups (4 x 1 024 tokens x 8 heads); 0: the 4-wave kernel as before (same-box A/B); returns the old value */
+int gaot_debug_set_attention_qsplit(int on);
 /* fp16-piece products: output tiles (of the split tile kernels and the grouped weight-gradient launch) that took the per-row second pass
  * since the counter was last reset -- a tile whose operand rows span more than 2^13 in magnitude is recomputed with one power-of-two
  * scale per row (gemm_split.hip).  Synchronises the device.  reset != 0: zero the counter after reading it. */

@@ -981,7 +981,10 @@ def test_attention_fp16_piece_products():
         return (rel(outs[0][0], ref), rel(outs[0][1], r.grad)), (rel(outs[2][0], ref), rel(outs[2][1], r.grad))
 
     g = torch.Generator().manual_seed(11)
-    for (B, S, H, D) in ((8, 1024, 8, 32), (2, 333, 4, 32), (1, 1024, 8, 48), (2, 333, 4, 36), (4, 2048, 8, 64)):      # head_dim 33..64: the DH = 64 kernels
+    # (4 x 1 024, 5 x 1 000, 4 x 1 056 tokens x 8 heads of 32: 128 .. 255 workgroups of 256 keys -- the backward shares a key block's query
+    # tiles between two workgroups and adds their dK / dV by atomics: two contributions per element, deterministic; odd tile counts and a
+    # ragged last tile included)
+    for (B, S, H, D) in ((8, 1024, 8, 32), (2, 333, 4, 32), (4, 1024, 8, 32), (5, 1000, 8, 32), (4, 1056, 8, 32), (1, 1024, 8, 48), (2, 333, 4, 36), (4, 2048, 8, 64)):      # head_dim 33..64: the DH = 64 kernels
         qkv, go = torch.randn(B, S, 3 * H * D, generator=g), torch.randn(B, S, H * D, generator=g)
         base = None
         for sq, sg in ((1.0, 1.0), (1e-3, 1e-9), (3.0, 1e6)):
