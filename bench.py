@@ -786,13 +786,16 @@ def main():
                               "re-copied per step (the PCIe-inclusive drop-in rate is `reference_loop`)",
                        "hipgraph": ts.use_graph, "staged_backward_phases": ts.bucket.n_phases, "stage_groups": ts.stage_groups, "final_loss": loss},
             "roofline": {"bound": "mfma", "pipe": "f16 / bf16 mfma (v_mfma_f32_32x32x16_f16 / _bf16: the same 2.5 PFLOP/s dense rate)",
-                         "kernel": "every launch of one step on the bf16 matrix pipe behind gaot_gemm_f32: gemm_split_kernel (NT / NN tiles) and the grouped "
+                         "kernel": "every launch of one step on the bf16 matrix pipe behind gaot_gemm_f32: gemm_split_kernel / gemm_ad_kernel (NT / NN tiles: operands staged through registers / both by LDS DMA) and the grouped "
                                    "weight-gradient launch gemm_tn_grouped_kernel; each f32 operand as "
                                    f"{ {'f32': 'two fp16 pieces of the power-of-two scaled operand (24 significant bits up to its last one), three piece products on v_mfma_f32_32x32x16_f16' if _ops._F16_PIECES[0] else 'three exact bf16 pieces, six piece products', 'bf16x2': 'two rounded bf16 pieces, three piece products', 'bf16': 'one bf16 piece, one product'}[args.dtype] }",
-                         "achieved": roof["piece_tflops"], "peak": PEAK_BF16_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                         "frac": roof["piece_tflops"] / PEAK_BF16_MATRIX_TFLOPS,
-                         "achieved_note": "piece-product FLOPs ISSUED on the matrix pipe (2MNK x piece products per product) / event-timed duration",
-                         "f32_equivalent_tflops": roof["tflops"], "f32_equivalent_frac_of_f32_matrix_peak": roof["tflops"] / PEAK_F32_MATRIX_TFLOPS,
+                         "achieved": roof["tflops"], "peak": PEAK_BF16_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                         "frac": roof["tflops"] / PEAK_BF16_MATRIX_TFLOPS,
+                         "achieved_note": "ALGORITHMIC FLOPs (2MNK per product, each counted once whatever the number of piece products) / event-timed "
+                                          "duration of the family's launches, against the dense f16 / bf16 matrix peak the kernels run on; the pipe "
+                                          "itself is issued three piece products per product: `issued_piece_tflops`",
+                         "issued_piece_tflops": roof["piece_tflops"], "issued_frac": roof["piece_tflops"] / PEAK_BF16_MATRIX_TFLOPS,
+                         "f32_equivalent_frac_of_f32_matrix_peak": roof["tflops"] / PEAK_F32_MATRIX_TFLOPS,
                          "traffic": traffic,
                          "traffic_note": "HBM bytes per launch, PMC FETCH_SIZE(x2, gfx950)+WRITE_SIZE, separate --pmc passes over the same "
                                          f"launches (eager step): {traffic_src}",

@@ -13,9 +13,9 @@ def dump(name, obj):
     with open(os.path.join(prof, f"{tag}_{name}_traffic.json"), "w") as f:
         json.dump(obj, f, indent=1)
 # GEMM tile kernels: launch-weighted mean bytes per launch
-gk = {k: v for k, v in d.items() if k.startswith(("gemm_split_kernel", "gemm_tn_grouped_kernel"))}       # the launches bench.py's `roofline` covers
+gk = {k: v for k, v in d.items() if k.startswith(("gemm_split_kernel", "gemm_ad_kernel", "gemm_tn_grouped_kernel"))}       # the launches bench.py's `roofline` covers
 n = sum(v["launches_seen"] for v in gk.values())
-dump("gemm", {"kernel_family": f"matrix-pipe GEMM kernels (gemm_split_kernel tiles, gemm_tn_grouped_kernel) over {steps} eager steps of the bench configuration",
+dump("gemm", {"kernel_family": f"matrix-pipe GEMM kernels (gemm_split_kernel / gemm_ad_kernel tiles, gemm_tn_grouped_kernel) over {steps} eager steps of the bench configuration",
               "launches": n, "hbm_bytes_per_launch": sum(v["hbm_bytes_per_launch"] * v["launches_seen"] for v in gk.values()) / max(n, 1),
               "source": f"{src} (FETCH_SIZE KiB x2 + WRITE_SIZE KiB per launch, launch-weighted mean)"})
 # integral-transform kernels: the family's launches of ONE step
