@@ -9,6 +9,7 @@ gemb.py:103-171); here they are device arrays built once per neighbour list and 
 import ctypes as C
 from typing import Dict, Optional, Tuple
 
+import os
 import torch
 
 from . import _lib as L
@@ -333,6 +334,16 @@ class MergedGeometry:
         self.plan = plan
         self._equal = len(set(self.n_dst_each)) == 1
 
+    def release(self) -> None:
+        """Drop the derived arrays of a union that left the cache.  They sit in reference cycles (an array's entry keeps the closure that
+        recomputes it, which keeps the plan; entry and coordinate group point at each other), so without this the device memory of an
+        evicted union waits for Python's cyclic collector -- generations later.  Anything still using the plan recomputes on demand."""
+        plan = self.plan
+        for grp in plan._groups.values():
+            grp["arrays"].clear()
+        plan._groups.clear()
+        plan._coord_cache.clear()
+
     def geo_stats(self) -> torch.Tensor:
         if not self._equal:
             raise ValueError("vx mode needs the same number of query points in every sample of a batch")
@@ -340,6 +351,7 @@ class MergedGeometry:
 
 
 _MERGE_CACHE = {}
+_MERGE_CACHE_MAX = max(2, int(os.environ.get("GAOT_MERGE_CACHE", "8")))          # unions kept (encoder and decoder count separately)
 
 
 def merged_geometry(nbr_dicts, src_coords, dst_coords, parents=()) -> MergedGeometry:
@@ -347,14 +359,19 @@ def merged_geometry(nbr_dicts, src_coords, dst_coords, parents=()) -> MergedGeom
     slices are new objects on every call).  A re-shuffled batch is a new combination: composed from the per-sample plans
     when the dicts carry them (their first use builds and caches them), else planned afresh over the union."""
     key = tuple(id(n) for n in nbr_dicts) + tuple((id(c), c._version) for c in parents)
-    hit = _MERGE_CACHE.get(key)
+    hit = _MERGE_CACHE.pop(key, None)          # (re-inserted below: the dict's order is the order of last use)
     if hit is None or any(a is not b for a, b in zip(hit[1], parents)) or any(a is not b for a, b in zip(hit[2], nbr_dicts)):
-        if len(_MERGE_CACHE) > 64:
-            _MERGE_CACHE.clear()
+        # A union holds tens of MB of derived arrays (edge rows, statistics, orders).  Under a SHUFFLING loader no composition ever comes
+        # back, and a cache that keeps the last 64 of them makes every step allocate fresh device memory until it is cleared (measured on
+        # the NACA configuration: one ~120 MB hipMalloc every third step at ~75 ms each -- 8 ms steps became 40 ms on average,
+        # tools/vx_shuffle_profile.py).  Keeping only the few most recently used lets the allocator hand the evicted union's blocks to the
+        # next one; loaders that cycle through a handful of fixed batches still hit.
+        while len(_MERGE_CACHE) >= _MERGE_CACHE_MAX:
+            _MERGE_CACHE.pop(next(iter(_MERGE_CACHE)))[0].release()
         # a dict seen before (it carries a marker) is worth a plan of its own: the next batch that contains it composes
         seen = all(n.get("_gaot_amd_seen") for n in nbr_dicts)
         for n in nbr_dicts:
             n["_gaot_amd_seen"] = True
         hit = (MergedGeometry(nbr_dicts, src_coords, dst_coords, build_parts=seen), tuple(parents), list(nbr_dicts))   # hold refs: ids stay unique
-        _MERGE_CACHE[key] = hit
+    _MERGE_CACHE[key] = hit
     return hit[0]

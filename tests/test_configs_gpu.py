@@ -776,6 +776,45 @@ def test_vx_union_composed_from_per_sample_plans_equals_union_planned_afresh():
     assert not m1.composed and m2.composed
 
 
+def test_vx_shuffling_loader_does_not_pile_up_unions():
+    """Under a shuffling loader (the reference's default, data_utils.py:272-294) every step brings a batch composition that never comes
+    back.  The union cache keeps only a few most recently used unions and releases what it evicts (the derived arrays sit in reference
+    cycles: without the release they wait for Python's cyclic collector), so device memory stays flat from step to step -- no
+    collector run needed."""
+    import gc, itertools
+    from gaot_amd import plan as P
+    from gaot_amd.model.layers.utils.neighbor_search import NeighborSearch
+    g = torch.Generator().manual_seed(5)
+    B, N = 4, 2048
+    lat = grid([32, 32]).to(dev())
+    xs = [naca_points(N, g, 0.12).to(dev()) for _ in range(B)]
+    ns = NeighborSearch("native")
+    dicts = [ns(xs[b], lat, 0.066) for b in range(B)]
+    x_all = torch.stack(xs)
+    perms = list(itertools.permutations(range(B)))
+
+    def step(perm):
+        xp = x_all[list(perm)]
+        mg = P.merged_geometry([dicts[i] for i in perm], [xp[i] for i in range(B)], [lat] * B, parents=(xp, lat))
+        mg.geo_stats(); mg.plan.edge_features(mg.src, mg.dst); mg.plan.cosine_attention(mg.src, mg.dst)
+        return mg
+    gc.collect()
+    gc.disable()
+    try:
+        for perm in perms[:P._MERGE_CACHE_MAX + 2]:
+            step(perm)
+        torch.cuda.synchronize()
+        m0 = torch.cuda.memory_allocated()
+        for perm in perms[P._MERGE_CACHE_MAX + 2:24]:
+            step(perm)
+        torch.cuda.synchronize()
+        grown = torch.cuda.memory_allocated() - m0
+    finally:
+        gc.enable()
+    assert len(P._MERGE_CACHE) <= P._MERGE_CACHE_MAX
+    assert grown < (1 << 20), grown          # flat (the old cache of 64 grew by one union per step)
+
+
 def test_auto_graph_reference_loop_equals_eager_loop():
     """autograph.py: the reference trainer's loop, unchanged (per-step uploads of batch and coordinates, zero_grad, eager call,
     nn.MSELoss, backward, torch.optim.AdamW), runs forward and backward as hipGraph replays from its third step on.  It must give
