@@ -83,6 +83,7 @@ PROTOTYPES = {
     "gaot_split_f16_planes_grouped": (C.c_int, [C.POINTER(F16PlanesItem), C.c_int32, _s]),
     "gaot_debug_set_gemm_planes": (C.c_int, [C.c_int]),
     "gaot_debug_set_gemm_ad": (C.c_int, [C.c_int]),
+    "gaot_debug_set_gemm_ad_narrow": (C.c_int, [C.c_int]),
     "gaot_debug_set_attention_qsplit": (C.c_int, [C.c_int]),
     "gaot_debug_split_redo_count": (C.c_uint, [C.c_int]),
     "gaot_debug_set_wgrad_kslab": (C.c_int, [C.c_int]),

@@ -47,13 +47,14 @@ template <int TN> __device__ __forceinline__ void ad_pin(AdFrag<TN>& f) {
     for (int j = 0; j < TN; ++j) { asm volatile("" : "+v"(f.h[j])); asm volatile("" : "+v"(f.m[j])); }
 }
 
-// BMT x 128 outputs per workgroup, 4 waves as WAVES_M x (4 / WAVES_M), NS ring slots.  BREAL: is W itself k-contiguous as stored (NT: the
+// BMT x BNT outputs per workgroup, 4 waves as WAVES_M x (4 / WAVES_M), NS ring slots (BNT = 64: 64 x 64 tiles, twice the workgroups for
+// outputs two 128-wide tiles across that would leave every CU with one wave per SIMD).  BREAL: is W itself k-contiguous as stored (NT: the
 // planes of W; NN: the planes of W^T) -- only the second pass reads it.
-template <int BMT, int WAVES_M, int NS, bool BREAL, int ABL = 0>
+template <int BMT, int WAVES_M, int NS, bool BREAL, int ABL = 0, int BNT = 128>
 __global__ __launch_bounds__(256, 2) void gemm_ad_kernel(const GemmArgs p) {
-    constexpr int WAVES_N = 4 / WAVES_M, WM = BMT / WAVES_M, WN = 128 / WAVES_N, TM = WM / 32, TN = WN / 32;
-    constexpr int A_ST = BMT * 128, B_ST = 128 * 128, STAGE = A_ST + B_ST;          // bytes
-    constexpr int LA = BMT / 32, LB = 4;                                            // 1-KB DMA pieces per wave and tile
+    constexpr int WAVES_N = 4 / WAVES_M, WM = BMT / WAVES_M, WN = BNT / WAVES_N, TM = WM / 32, TN = WN / 32;
+    constexpr int A_ST = BMT * 128, B_ST = BNT * 128, STAGE = A_ST + B_ST;          // bytes
+    constexpr int LA = BMT / 32, LB = BNT / 32;                                     // 1-KB DMA pieces per wave and tile
     constexpr int EPI_BYTES = 4 * 32 * (WN + 4) * 4;
     constexpr int SMEM = NS * STAGE > EPI_BYTES ? NS * STAGE : EPI_BYTES;
     static_assert(TM >= 1 && TN >= 1 && (NS == 2 || NS == 3), "layout");
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ad_kernel(const GemmArgs p) {
         logical = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + slot;
     }
     const int m0 = (logical / p.tiles_n) * BMT;
-    const int n0 = (logical % p.tiles_n) * 128;
+    const int n0 = (logical % p.tiles_n) * BNT;
     const int zs = blockIdx.z;
 
     const int nkt = p.K / AD_BK;
@@ -340,13 +341,16 @@ unsigned ad_redo_count(bool reset) {
     return v;
 }
 
-// bm: 128 or 64.  Needs: A k-contiguous (16-byte aligned rows), pre-split planes, K % 32 == 0, the vector epilogue
-void launch_ad(GemmArgs& a, bool b_kmajor, hipStream_t st, int bm) {
+// bm: 128 or 64; bn: 128, or 64 with bm = 64.  Needs: A k-contiguous (16-byte aligned rows), pre-split planes, K % 32 == 0, the vector epilogue
+void launch_ad(GemmArgs& a, bool b_kmajor, hipStream_t st, int bm, int bn) {
     a.tiles_m = cdiv(a.M, bm);
-    a.tiles_n = cdiv(a.N, 128);
+    a.tiles_n = cdiv(a.N, bn);
     a.bpl_flag = b_kmajor ? 1 : 2;
     dim3 grid(a.tiles_m * a.tiles_n, 1, a.split_k > 1 ? a.split_k : 1), block(256);
-    if (bm == 64) {
+    if (bm == 64 && bn == 64) {
+        if (b_kmajor) hipLaunchKernelGGL((gemm_ad_kernel<64, 2, 3, true, 0, 64>), grid, block, 0, st, a);
+        else          hipLaunchKernelGGL((gemm_ad_kernel<64, 2, 3, false, 0, 64>), grid, block, 0, st, a);
+    } else if (bm == 64) {
         if (b_kmajor) hipLaunchKernelGGL((gemm_ad_kernel<64, 2, 3, true>), grid, block, 0, st, a);
         else          hipLaunchKernelGGL((gemm_ad_kernel<64, 2, 3, false>), grid, block, 0, st, a);
     } else {

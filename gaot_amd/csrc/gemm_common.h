@@ -230,8 +230,8 @@ void launch_glds(GemmArgs& a, bool a_kmajor, bool b_kmajor, int tile, hipStream_
 
 // split-bf16 kernel (gemm_split.hip): fp32 product from six bf16 MFMA piece products, 128x128 tiles
 void launch_split(GemmArgs& a, bool a_kmajor, bool b_kmajor, hipStream_t st, int bm = 128, int pieces = 3);
-// all-DMA fp16-piece tiles (gemm_ad.hip): A k-contiguous, W pre-split into planes, K % 32 == 0, vector epilogue; bm = 128 or 64
-void launch_ad(GemmArgs& a, bool b_kmajor, hipStream_t st, int bm);
+// all-DMA fp16-piece tiles (gemm_ad.hip): A k-contiguous, W pre-split into planes, K % 32 == 0, vector epilogue; bm x bn = 128 x 128, 64 x 128 or 64 x 64
+void launch_ad(GemmArgs& a, bool b_kmajor, hipStream_t st, int bm, int bn = 128);
 unsigned ad_redo_count(bool reset);
 unsigned split_redo_count(bool reset);      // tiles that took the fp16 pieces' second (three-piece) pass: a device counter for tests / tools
 // grouped weight-gradient launch (gemm_split.hip): prefix table / workspace need of n items; the launch itself

@@ -78,9 +78,7 @@ static void run_case(const Case& c, int iters) {
     float t_nd;
     {
         GemmArgs b = a; b.C = C1; b.tiles_m = cdiv(b.M, c.bm); b.tiles_n = cdiv(b.N, 128); b.bpl_flag = 1;
-        if (c.bm == 64) b.tiles_m = cdiv(b.M, 128);
-        dim3 grid(b.tiles_m * b.tiles_n, 1, c.sk), block(256);
-        auto go = [&]() { hipLaunchKernelGGL((gemm_ad_kernel<128, 4, 2, true, 0>), grid, block, 0, 0, b); };
+        auto go = [&]() { launch_ad(b, true, 0, 64, 64); };
         for (int i = 0; i < 5; ++i) go();
         hipEventRecord(s, 0);
         for (int i = 0; i < iters; ++i) go();
@@ -100,7 +98,7 @@ static void run_case(const Case& c, int iters) {
         e_old = d0 / mx; e_new = d1 / mx;
     }
     const double gf = 2.0 * M * N * K * 1e-6;
-    printf("%-10s M=%5d N=%5d K=%5d bm=%3d act=%d | staged %.1f us (%.0f TF) | direct %.1f us (%.0f TF) | x%.2f | all-DMA 128-row 4x1 %.1f us | differing outputs %zu of %zu | err vs f64: staged %.2e direct %.2e | redo %u/%u | %s\n",
+    printf("%-10s M=%5d N=%5d K=%5d bm=%3d act=%d | staged %.1f us (%.0f TF) | direct %.1f us (%.0f TF) | x%.2f | all-DMA 64 x 64 %.1f us | differing outputs %zu of %zu | err vs f64: staged %.2e direct %.2e | redo %u/%u | %s\n",
            c.name, M, N, K, c.bm, c.act, t_old * 1e3 / iters, gf / (t_old * 1e3 / iters), t_new * 1e3 / iters, gf / (t_new * 1e3 / iters), t_old / t_new, t_nd * 1e3 / iters,
            diff, h0.size(), e_old, e_new, split_redo_count(true), ad_redo_count(true), hipGetErrorString(err));
     hipFree(A); hipFree(W); hipFree(P); hipFree(C0); hipFree(C1); hipFree(R); hipFree(aux); hipFree(wa); hipFree(ww);
