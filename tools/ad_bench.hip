@@ -43,9 +43,9 @@ static void run_case(const Case& c, int iters) {
     std::vector<float> wordA(1024, 0.f), wordW(1024, 0.f);
     wordA[0] = amA; wordW[0] = amW;
     float *A, *W, *C0, *C1, *wa, *ww, *aux; unsigned short* P; double* R;
-    const int NO = c.act == GAOT_ACT_SWIGLU ? N / 2 : N;
+    const int NO = c.act == GAOT_ACT_SWIGLU ? N / 2 : (c.act == GAOT_ACT_SWIGLU_BWD ? 2 * N : N);
     hipMalloc(&A, hA.size() * 4); hipMalloc(&W, hW.size() * 4); hipMalloc(&P, hP.size() * 2);
-    hipMalloc(&C0, (size_t)M * N * 4); hipMalloc(&C1, (size_t)M * N * 4); hipMalloc(&R, (size_t)M * N * 8); hipMalloc(&aux, (size_t)M * N * 4);
+    hipMalloc(&C0, (size_t)M * N * 8); hipMalloc(&C1, (size_t)M * N * 8); hipMalloc(&R, (size_t)M * N * 8); hipMalloc(&aux, (size_t)M * N * 8);
     hipMalloc(&wa, 4096); hipMalloc(&ww, 4096);
     hipMemcpy(A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice); hipMemcpy(W, hW.data(), hW.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(P, hP.data(), hP.size() * 2, hipMemcpyHostToDevice);
@@ -56,6 +56,7 @@ static void run_case(const Case& c, int iters) {
     float* ws = nullptr; if (c.sk > 1) { hipMalloc(&ws, (size_t)c.sk * ((size_t)M * N + M) * 4); a.ws = ws; }
     a.a_amax = wa; a.b_amax = ww; a.Bpl = P; a.ld_bpl = 2 * K; a.bpl_stride = 16;
     if (c.act == GAOT_ACT_SWIGLU) { a.aux_out = aux; a.ld_aux = N; }
+    if (c.act == GAOT_ACT_SWIGLU_BWD) { std::vector<float> hu((size_t)M * 2 * N); for (auto& v : hu) v = ((float)rand() / RAND_MAX - 0.5f) * 4.f; hipMemcpy(aux, hu.data(), hu.size() * 4, hipMemcpyHostToDevice); a.aux_in = aux; a.ld_aux = 2 * N; }
     hipEvent_t s, e; hipEventCreate(&s); hipEventCreate(&e);
     float t_old, t_new;
     {
@@ -148,6 +149,7 @@ int main(int argc, char** argv) {
     const Case cases[] = {
         {8192, 2048, 256, 128, GAOT_ACT_SWIGLU, "w1w3"},
         {8192, 2048, 256, 128, 0, "w1w3-lin"},
+        {8192, 1024, 256, 128, GAOT_ACT_SWIGLU_BWD, "w2b-swiglu"},
         {8192, 2048, 256, 64, GAOT_ACT_SWIGLU, "w1w3-64"},
         {8192, 2048, 256, 64, 0, "w1w3-lin64"},
         {8192, 768, 256, 64, 0, "qkv"},
