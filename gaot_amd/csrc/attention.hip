@@ -2472,6 +2472,16 @@ template <int DP> static size_t bwd_lds_bytes() {
     return sizeof(float) * (2 * 32 * (DP + 4) + 64 + 4 * 32 * DP + 4 * 32 * 33 + 4 * 32 * (DP < 64 ? DP : 64));
 }
 
+// zero two column blocks [rows][4 c4] of pitched fp32 arrays (the dK / dV targets of the query-split backward)
+__global__ void attn_zero_cols_kernel(float* a, long lda, float* b, long ldb, long rows, int c4) {
+    const long n = rows * c4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / c4; const int c = (int)(i - r * c4) * 4;
+        *reinterpret_cast<f32x4*>(a + r * lda + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(b + r * ldb + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
 static int fill_common(AttnArgs& a, const float* q, const float* k, const float* v, int64_t ldq, int64_t ldk, int64_t ldv,
                        int B, int S, int H, int Hkv, int D) {
     a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
@@ -2696,9 +2706,15 @@ extern "C" int gaot_attention_bwd(const float* q, const float* k, const float* v
     dim3 grid(a.n_kblocks * B * H), block(256);
     if (qsplit) {
         a.n_kblocks = cdiv(S, 256);
-        // dK / dV receive two atomic contributions per element: zero them first (column blocks of the fused dqkv buffer: pitched fills)
-        hipMemset2DAsync(dk, (size_t)lddk * 4, 0, (size_t)H * 32 * 4, (size_t)B * S, ST(stream));
-        hipMemset2DAsync(dv, (size_t)lddv * 4, 0, (size_t)H * 32 * 4, (size_t)B * S, ST(stream));
+        // dK / dV receive two atomic contributions per element: zero them first (column blocks of the fused dqkv buffer).  A KERNEL, not
+        // hipMemset2DAsync: inside a captured hipGraph the memset nodes did not reliably run before the attention kernel on every box
+        // (replays then added onto the previous step's dK / dV: the loss of the 4 096-token step went to 0.994 instead of 0.748 and the
+        // consumer's range watch fired on data twice its published maximum)
+        {
+            const long rows = (long)B * S;
+            const int c4 = H * 32 / 4;
+            hipLaunchKernelGGL(attn_zero_cols_kernel, dim3(cap_blocks(rows * c4, 256, 2048)), dim3(256), 0, ST(stream), dk, (long)lddk, dv, (long)lddv, rows, c4);
+        }
         hipLaunchKernelGGL((attn_bwd_split8_kernel<2, 2, true, true, 2>), dim3(a.n_kblocks * B * H * 2), dim3(512), 0, ST(stream), a);
         dkdv_published = true;
     } else if (split_ok && g_attn_split != 3 && (g_attn_split == 2 || (long)cdiv(S, 256) * B * H >= 256)) {

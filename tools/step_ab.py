@@ -33,6 +33,11 @@ for v in values:
     steps.append((v, ts, model))
     fn(old)
 res = {v: [] for v in values}
+redo = {}
+for v, ts, _ in steps:          # tiles that take the fp16 pieces' second pass in ONE step of each variant (benign data: none expected)
+    lib.gaot_debug_split_redo_count(1)
+    ts.step(); torch.cuda.synchronize()
+    redo[v] = int(lib.gaot_debug_split_redo_count(1))
 for rnd in range(3):
     for v, ts, _ in steps:
         for _ in range(5):
@@ -44,4 +49,4 @@ for rnd in range(3):
         torch.cuda.synchronize()
         res[v].append((time.perf_counter() - t0) / 60 * 1e3)
 for v in values:
-    print(f"{args[0]}({v}): " + "  ".join(f"{r:.4f}" for r in res[v]) + f"   best {min(res[v]):.4f} ms/step   loss {float(steps[values.index(v)][1]._loss):.6e}", flush=True)
+    print(f"{args[0]}({v}): " + "  ".join(f"{r:.4f}" for r in res[v]) + f"   best {min(res[v]):.4f} ms/step   loss {float(steps[values.index(v)][1]._loss):.6e}   redone tiles per step {redo[v]}", flush=True)
