@@ -411,6 +411,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 }
 
 // 16-byte patchify: one thread per 4 channels of a grid node (C % 4 == 0); a node's C channels stay contiguous on both sides
+// IDX = unsigned (everything below 2^31 elements: the index arithmetic is five divisions per 16 bytes moved, and 64-bit ones cost four
+// times the 32-bit ones) or long
+template <typename IDX>
 __global__ void patchify_vec_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int Dz, int P,
                                     int C, int inverse, float* __restrict__ out_amax) {
     __shared__ float amred[4];
@@ -418,29 +421,31 @@ __global__ void patchify_vec_kernel(const float* __restrict__ in, float* __restr
     const int dim = Dz > 0 ? 3 : 2;
     const int D1 = Dz > 0 ? Dz : 1;
     const int C4 = C / 4;
-    const long nodes = (long)H * W * D1;
-    const long total = (long)B * nodes * C4;
+    const IDX nodes = (IDX)H * W * D1;
+    const IDX total = (IDX)B * nodes * C4;
     const int pw = W / P, pd = D1 > 1 ? D1 / P : 1;
     const int pvol = dim == 3 ? P * P * P : P * P;
-    for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long)gridDim.x * blockDim.x) {
+    const IDX toks = nodes / pvol;
+    for (IDX gid = (IDX)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (IDX)gridDim.x * blockDim.x) {
         const int c = (int)(gid % C4) * 4;
-        const long node = (gid / C4) % nodes;
-        const long b = gid / (C4 * nodes);
+        const IDX nc = gid / C4;
+        const IDX node = nc % nodes;
+        const IDX b = nc / nodes;
         int h, w_, z = 0;
-        if (dim == 3) { z = (int)(node % D1); w_ = (int)((node / D1) % W); h = (int)(node / ((long)D1 * W)); }
+        if (dim == 3) { z = (int)(node % D1); w_ = (int)((node / D1) % W); h = (int)(node / ((IDX)D1 * W)); }
         else { w_ = (int)(node % W); h = (int)(node / W); }
         const int ph = h / P, i = h % P, pwi = w_ / P, j = w_ % P;
-        long s, k;
+        IDX s, k;
         if (dim == 3) {
             const int pz = z / P, l = z % P;
-            s = ((long)ph * pw + pwi) * pd + pz;
-            k = (((long)i * P + j) * P + l) * C + c;
+            s = ((IDX)ph * pw + pwi) * pd + pz;
+            k = (((IDX)i * P + j) * P + l) * C + c;
         } else {
-            s = (long)ph * pw + pwi;
-            k = ((long)i * P + j) * C + c;
+            s = (IDX)ph * pw + pwi;
+            k = ((IDX)i * P + j) * C + c;
         }
-        const long tok = (b * (nodes / pvol) + s) * ((long)pvol * C) + k;
-        const long g = (b * nodes + node) * C + c;
+        const IDX tok = (b * toks + s) * ((IDX)pvol * C) + k;
+        const IDX g = (b * nodes + node) * C + c;
         const f32x4 v = *reinterpret_cast<const f32x4*>(inverse ? in + tok : in + g);
         *reinterpret_cast<f32x4*>(inverse ? out + g : out + tok) = v;
         am = fmaxf(am, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
@@ -753,7 +758,10 @@ extern "C" int gaot_patchify(const float* in, int32_t B, int32_t H, int32_t W, i
     GAOT_REQUIRE(H % P == 0 && W % P == 0 && (Dz == 0 || Dz % P == 0), "patchify: grid %dx%dx%d not divisible by patch %d", H, W, Dz, P);
     const long total = (long)B * H * W * (Dz > 0 ? Dz : 1) * C;
     if (C % 4 == 0 && aligned16(in) && aligned16(out))
-        hipLaunchKernelGGL(patchify_vec_kernel, dim3(cap_blocks(total / 4, 256, 8192)), dim3(256), 0, ST(stream), in, out, B, H, W, Dz, P, C, inverse, out_absmax);
+    {
+        if (total < (1L << 31)) hipLaunchKernelGGL(patchify_vec_kernel<unsigned>, dim3(cap_blocks(total / 4, 256, 8192)), dim3(256), 0, ST(stream), in, out, B, H, W, Dz, P, C, inverse, out_absmax);
+        else hipLaunchKernelGGL(patchify_vec_kernel<long>, dim3(cap_blocks(total / 4, 256, 8192)), dim3(256), 0, ST(stream), in, out, B, H, W, Dz, P, C, inverse, out_absmax);
+    }
     else {
         hipLaunchKernelGGL(patchify_kernel, dim3(cap_blocks(total, 256, 8192)), dim3(256), 0, ST(stream), in, out, B, H, W, Dz, P, C, inverse);
         if (out_absmax) {           // the scalar kernel does not publish: one grouped-absmax launch over the output
