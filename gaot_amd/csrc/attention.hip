@@ -25,6 +25,7 @@ struct AttnArgs {
     // backward
     const float *oin, *dout; float *dq, *dk, *dv; long lddq, lddk, lddv;
     float* delta; float* dq_part; int n_kblocks;
+    float *dk2, *dv2;          // query-split backward (QS = 2): dense [B S][H 32] partials of the second half of the query tiles
     float scale; int vec;
     // attention dropout (attn.py:110-114, dropout_p of F.scaled_dot_product_attention in training): P is multiplied by
     // keep(b, h, q, k) / (1 - p) after the softmax; the mask is a counter-based hash of (*drop_seed, element index), so the
@@ -1839,10 +1840,13 @@ constexpr int AB8_LDS = AB8_SHARED + 8 * AB8_WAVE;
 // F16 (with PP = OP = 2, TR): two fp16 pieces of the scaled operands -- Q, K, V by the power of two from the qkv magnitude word, dO by its
 // own word, P by 2^15, dS by a per-tile power of two from the wave's own maximum (the tile products join the running sums on the vector
 // pipe anyway: the inverse scales ride that fused multiply-add) -- three piece products per k-step on the f16 MFMA.  (P by 2^13, see P_SCALE.)
-// QS = 2: the query tiles of a 256-key block are shared between TWO workgroups (even half / odd half of the sequence) -- batches that give
+// QS = 2: the query tiles of a 256-key block are shared between TWO workgroups (first half / second half of the sequence) -- batches that give
 // only 128 .. 255 workgroups (4 x 1 024 tokens x 8 heads: BASELINE configs[3]'s per-GPU shape) fill the chip again.  The dQ slabs do not
-// change (a query tile's slab row is still written by exactly one workgroup per key block); dK / dV get exactly TWO contributions per
-// element, added by atomics into zeroed memory: a + b in either order is the same fp32 number, so the result stays deterministic.
+// change (a query tile's slab row is still written by exactly one workgroup per key block); the first half writes its dK / dV where they
+// belong, the second half into two spare dQ slabs of the workspace (it is sized for 128-key blocks, this kernel uses 256-key ones), and a
+// small kernel adds them: dK = first + second in that order, no atomics.  (The first form added both halves by atomics into zeroed memory:
+// bit-reproducible on one box, but the SAME training run ended at 0.7481867 on one box and 0.7482677 on another -- wherever two float
+// atomics meet, the sum is not the same number on every chip.)
 template <int PP = 3, int OP = 3, bool TR = false, bool F16 = false, int QS = 1>
 __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs p) {
     constexpr int DP = 32, NW = 8;
@@ -2208,8 +2212,8 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
             if (kv < p.S) {
                 const float val = Smine[rr * 33 + li];
                 float* dst = pass == 0 ? p.dk + ((long)b * p.S + kv) * p.lddk + (long)h * 32 + li : p.dv + ((long)b * p.S + kv) * p.lddv + (long)h * 32 + li;
-                if (QS > 1) (void)__hip_atomic_fetch_add(dst, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else *dst = val;
+                if (QS > 1 && qhalf == 1) dst = (pass == 0 ? p.dk2 : p.dv2) + ((long)b * p.S + kv) * ((long)p.H * 32) + (long)h * 32 + li;
+                *dst = val;
                 am = fmaxf(am, fabsf(val));
             }
         }
@@ -2472,13 +2476,16 @@ template <int DP> static size_t bwd_lds_bytes() {
     return sizeof(float) * (2 * 32 * (DP + 4) + 64 + 4 * 32 * DP + 4 * 32 * 33 + 4 * 32 * (DP < 64 ? DP : 64));
 }
 
-// zero two column blocks [rows][4 c4] of pitched fp32 arrays (the dK / dV targets of the query-split backward)
-__global__ void attn_zero_cols_kernel(float* a, long lda, float* b, long ldb, long rows, int c4) {
+// a[r][c] += a2[r][c], b[r][c] += b2[r][c] over [rows][4 c4]: a, b pitched column blocks (dK / dV inside the fused dqkv buffer), a2, b2 dense
+// (the second half's partials of the query-split backward)
+__global__ void attn_add_cols_kernel(float* a, long lda, const float* a2, float* b, long ldb, const float* b2, long rows, int c4) {
     const long n = rows * c4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const long r = i / c4; const int c = (int)(i - r * c4) * 4;
-        *reinterpret_cast<f32x4*>(a + r * lda + c) = f32x4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(b + r * ldb + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4* pa = reinterpret_cast<f32x4*>(a + r * lda + c);
+        f32x4* pb = reinterpret_cast<f32x4*>(b + r * ldb + c);
+        *pa = *pa + *reinterpret_cast<const f32x4*>(a2 + r * (long)c4 * 4 + c);
+        *pb = *pb + *reinterpret_cast<const f32x4*>(b2 + r * (long)c4 * 4 + c);
     }
 }
 
@@ -2694,7 +2701,7 @@ extern "C" int gaot_attention_bwd(const float* q, const float* k, const float* v
     const bool split_ok = head_dim == 32 && a.vec && g_attn_split && aligned16(dq) && aligned16(dk) && aligned16(dv);
     // 128 .. 255 workgroups of 256 keys: the query tiles of a key block go to two workgroups (attn_bwd_split8_kernel QS = 2)
     const long wg8 = (long)cdiv(S, 256) * B * H;
-    const bool qsplit = f16 && split_ok && aligned16(o) && g_attn_split == 1 && g_attn_qsplit && wg8 >= 128 && wg8 < 256 && cdiv(S, 32) >= 8;
+    const bool qsplit = f16 && split_ok && aligned16(o) && g_attn_split == 1 && g_attn_qsplit && wg8 >= 128 && wg8 < 256 && cdiv(S, 32) >= 8 && cdiv(S, 128) - cdiv(S, 256) >= 2;          // (two spare dQ slabs for the second half's dK / dV)
     const bool fused_delta = f16 && split_ok && aligned16(o) && g_attn_split != 3 && (g_attn_split == 2 || wg8 >= 256 || qsplit);   // the fp16 8-wave kernel forms delta itself
     if (fused_delta) {
     } else if (a.vec && aligned16(o)) {
@@ -2706,16 +2713,14 @@ extern "C" int gaot_attention_bwd(const float* q, const float* k, const float* v
     dim3 grid(a.n_kblocks * B * H), block(256);
     if (qsplit) {
         a.n_kblocks = cdiv(S, 256);
-        // dK / dV receive two atomic contributions per element: zero them first (column blocks of the fused dqkv buffer).  A KERNEL, not
-        // hipMemset2DAsync: inside a captured hipGraph the memset nodes did not reliably run before the attention kernel on every box
-        // (replays then added onto the previous step's dK / dV: the loss of the 4 096-token step went to 0.994 instead of 0.748 and the
-        // consumer's range watch fired on data twice its published maximum)
+        a.dk2 = a.dq_part + (long)a.n_kblocks * B * H * S * 32;          // the first two slabs the 256-key blocks leave unused
+        a.dv2 = a.dk2 + (long)B * H * S * 32;
+        hipLaunchKernelGGL((attn_bwd_split8_kernel<2, 2, true, true, 2>), dim3(a.n_kblocks * B * H * 2), dim3(512), 0, ST(stream), a);
         {
             const long rows = (long)B * S;
             const int c4 = H * 32 / 4;
-            hipLaunchKernelGGL(attn_zero_cols_kernel, dim3(cap_blocks(rows * c4, 256, 2048)), dim3(256), 0, ST(stream), dk, (long)lddk, dv, (long)lddv, rows, c4);
+            hipLaunchKernelGGL(attn_add_cols_kernel, dim3(cap_blocks(rows * c4, 256, 2048)), dim3(256), 0, ST(stream), dk, (long)lddk, a.dk2, dv, (long)lddv, a.dv2, rows, c4);
         }
-        hipLaunchKernelGGL((attn_bwd_split8_kernel<2, 2, true, true, 2>), dim3(a.n_kblocks * B * H * 2), dim3(512), 0, ST(stream), a);
         dkdv_published = true;
     } else if (split_ok && g_attn_split != 3 && (g_attn_split == 2 || (long)cdiv(S, 256) * B * H >= 256)) {
         a.n_kblocks = cdiv(S, 256);          // 256 keys per workgroup: half the dQ slabs (the workspace is sized for 128)

@@ -242,7 +242,8 @@ __global__ void geo_stats_raw_kernel(const float* __restrict__ geom, const float
     o[0] = (float)n; o[1] = (float)mean; o[2] = (float)var;
     for (int d = 0; d < DIM; ++d) { o[3 + d] = (float)(cen[d] - x[d]); o[3 + DIM + d] = (float)ev[d]; }
 }
-// column sums (pass 0: sum x -> acc[f]; pass 1: sum (x-mean)^2 -> acc[F+f]) in fp64 via block reduce + atomics.
+// column sums (pass 0: sum x -> acc[f]; pass 1: sum (x-mean)^2 -> acc[F+f]) in fp64 via block reduce (launched with ONE workgroup per group: see
+// gaot_geo_stats; the atomicAdd then has a single contributor).
 // Rows come in `groups` equal groups of Q rows (vx mode: one group per sample of the block-diagonal union), each standardised
 // on its own (gemb.py:164-169 runs per sample there): blockIdx.y = group, acc = [group][2 * F].
 __global__ __launch_bounds__(256) void geo_colstat_kernel(const float* __restrict__ raw, int Q, int F, int pass,
@@ -503,7 +504,11 @@ extern "C" int gaot_geo_stats(const float* geom, const float* qry, int32_t dim, 
     else
         hipLaunchKernelGGL(geo_stats_raw_kernel<3>, dim3(cdiv(Q, 128)), dim3(128), 0, ST(stream), geom, qry, index32, splits32, Q, stats, guard);
     hipLaunchKernelGGL(zero_f64_kernel, dim3(cdiv(2 * F * groups, 64)), dim3(64), 0, ST(stream), scratch, 2 * F * groups);
-    int nb = cdiv(Qg, 256); if (nb > 256) nb = 256;
+    // ONE workgroup per group: the column sums are then formed in a fixed order.  (With several workgroups per group their fp64 partial sums met
+    // in an atomicAdd in arrival order, and once in a while a standardised statistic came out one fp32 ulp different from run to run and box to
+    // box -- enough for two trainings from the same seed to end ~1e-2 apart in loss after 100 steps, tools/det_batch.py.  Once per geometry:
+    // 16 384 rows x 7 columns take ~20 us this way.)
+    const int nb = 1;
     hipLaunchKernelGGL(geo_colstat_kernel, dim3(nb, groups), dim3(256), 0, ST(stream), stats, Qg, F, 0, scratch, guard);
     hipLaunchKernelGGL(geo_colstat_kernel, dim3(nb, groups), dim3(256), 0, ST(stream), stats, Qg, F, 1, scratch, guard);
     hipLaunchKernelGGL(geo_standardise_kernel, dim3(cdiv((long)Q * F, 256)), dim3(256), 0, ST(stream), stats, Qg, F, scratch, guard, groups);
