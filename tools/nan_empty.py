@@ -5,9 +5,10 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 _e, _el, _ne = torch.empty, torch.empty_like, torch.Tensor.new_empty
+FILL = float(sys.argv[3]) if len(sys.argv) > 3 else float('nan')          # (a huge finite value finds what max / compare paths swallow as NaN)
 def _fill(t):
     if t.is_cuda and t.numel():
-        if t.dtype.is_floating_point: t.fill_(float("nan"))
+        if t.dtype.is_floating_point: t.fill_(FILL)
         elif t.dtype in (torch.int32, torch.int64): t.fill_(0x7f7f7f7f)
     return t
 torch.empty = lambda *a, **k: _fill(_e(*a, **k))
@@ -31,5 +32,5 @@ for i in range(NSTEP):
     l = float(ts.step())
     torch.cuda.synchronize()
     bad = [n for n, q in zip(names, model.parameters()) if not bool(torch.isfinite(q).all())]
-    print("step", i, "loss", l, "non-finite parameters:", len(bad), bad[:6], flush=True)
+    print("step", i, "loss", repr(l), "redone tiles", int(_lib.load().gaot_debug_split_redo_count(1)), "non-finite parameters:", len(bad), bad[:6], flush=True)
     if l != l or bad: break
