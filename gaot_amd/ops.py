@@ -786,13 +786,20 @@ _GRAD_SLOTS: dict = {}
 
 def register_grad_slots(params, views):
     _GRAD_SLOTS.clear()
+    # the temporaries' entries went with the clear() -- and with them the references that kept their id()s unique: a stale id left in
+    # _TEMP_SLOT_IDS may by now be the id of a NEW parameter, whose registration the next release_grad_slots() would then drop (that
+    # parameter's gradient would take the ordinary path for the whole training: correct, but rounded differently from a training in
+    # which the id was not reused -- two trainings from one seed in one process then differ in the last bit)
+    _TEMP_SLOT_IDS.clear()
     for p, v in zip(params, views):
         _GRAD_SLOTS[id(p)] = [v, False, p]       # holding p keeps id(p) unique while registered
 
 
 def release_grad_slots():
     for k in _TEMP_SLOT_IDS:          # slices inherited by temporaries of the last forward pass (split_cols)
-        _GRAD_SLOTS.pop(k, None)
+        s = _GRAD_SLOTS.get(k)
+        if s is not None and len(s) == 4:         # (a temporary's entry, not a parameter's)
+            del _GRAD_SLOTS[k]
     _TEMP_SLOT_IDS.clear()
     for s in _GRAD_SLOTS.values():
         s[1] = False
@@ -1137,7 +1144,7 @@ def split_cols(w, c: int, param=None):
     a, b = _SplitCols.apply(w, c, s2)
     if s2 is not None:
         for v, blk in ((a, s2[:, :c]), (b, s2[:, c:])):
-            _GRAD_SLOTS[id(v)] = [blk, False, v]
+            _GRAD_SLOTS[id(v)] = [blk, False, v, True]          # 4th field: a temporary of this forward pass (release_grad_slots)
             _TEMP_SLOT_IDS.append(id(v))
     return a, b
 

@@ -1124,3 +1124,45 @@ def test_trainstep_one_launch_loss_equals_the_autograd_loss(graph):
     assert out[0][2] == out[1][2] == 5.0
     assert all(torch.equal(a, b) for a, b in zip(out[0][0], out[1][0]))
     assert all(torch.equal(a, b) for a, b in zip(out[0][1], out[1][1]))
+
+
+@pytest.mark.parametrize("graph", [True, False])
+def test_two_trainings_from_one_seed_in_one_process_end_bit_identical(graph):
+    """Every reduction on the path has a fixed order (slab sums, the query-split halves, the grouped launch's tickets), so a training
+    is a function of its seed -- also the SECOND one in a process, whose parameters' id()s may reuse those of the first one's
+    temporaries (tests/test_host_cpu.py: a stale id once took a parameter's gradient slot away, and with it the product's path).
+    Two trainings as history, then two compared: 30 steps of the 4 096-token batch (BASELINE configs[3]'s token count), weights equal
+    bit for bit, and every step's flat gradient buffer too."""
+    import bench
+    from gaot_amd import ops
+    from gaot_amd.trainer import TrainStep
+
+    def make(g):
+        ops.register_grad_slots([], [])
+        torch.manual_seed(0)
+        model = bench.build_model().to(dev()).train()
+        lat, x, p, t = bench.synthetic(1234, dev())
+        ts = TrainStep(model, lr=8e-4, weight_decay=1e-5, use_graph=g)
+        ts.bind(p[:4].contiguous(), t[:4].contiguous(), latent_tokens_coord=lat, xcoord=x)
+        return ts, model
+
+    for _ in range(2):                                   # history: allocator state and freed ids of earlier trainings
+        ts, model = make(True)
+        for _ in range(12):
+            ts.step()
+        torch.cuda.synchronize()
+        del ts, model
+    runs = []
+    for _ in range(2):
+        ts, model = make(graph)
+        grads = []
+        for _ in range(30):
+            ts.step()
+            grads.append(ts.bucket.flat.clone())
+        torch.cuda.synchronize()
+        runs.append((grads, [q.detach().clone() for q in model.parameters()]))
+        del ts, model
+    first = next((i for i, (a, b) in enumerate(zip(runs[0][0], runs[1][0])) if not torch.equal(a, b)), None)
+    assert first is None, f"flat gradients differ from step {first} on"
+    assert all(torch.equal(a, b) for a, b in zip(runs[0][1], runs[1][1]))
+    ops.register_grad_slots([], [])

@@ -272,3 +272,31 @@ def test_fp64_request_fails_at_the_module_and_leaves_fp32_parameters():
     assert m.type(torch.float32) is m and m.float() is m
     with pytest.raises(TypeError, match="float32 only"):
         m(latent_tokens_coord=g.t("in.latent"), xcoord=g.t("in.xcoord"), pndata=g.t("in.pndata").double())
+
+
+def test_a_stale_temporary_id_never_drops_a_parameters_gradient_slot():
+    """ops.split_cols registers the two column views of a weight under their id()s for ONE forward pass (ops._TEMP_SLOT_IDS);
+    register_grad_slots() drops those entries -- and with them the references that kept the ids unique.  CPython hands a freed id to
+    the next object of that size: a new model's Parameter may get it.  The next release_grad_slots() must not take that parameter's
+    registration away (its gradient would silently take the ordinary path for the whole training: two trainings from one seed in one
+    process then differed in the last bit)."""
+    from gaot_amd import ops
+    saved, saved_ids = dict(ops._GRAD_SLOTS), list(ops._TEMP_SLOT_IDS)
+    try:
+        p = torch.nn.Parameter(torch.zeros(4, 4))
+        v = torch.zeros(4, 4)
+        ops.register_grad_slots([p], [v])
+        ops._TEMP_SLOT_IDS.append(id(p))                     # a stale id that has become a parameter's
+        ops.release_grad_slots()
+        assert ops._GRAD_SLOTS.get(id(p), [None])[0] is v
+        t = torch.zeros(4, 2)
+        ops._GRAD_SLOTS[id(t)] = [v[:, :2], False, t, True]   # a temporary's entry, as split_cols leaves it
+        ops._TEMP_SLOT_IDS.append(id(t))
+        ops.release_grad_slots()
+        assert id(t) not in ops._GRAD_SLOTS and not ops._TEMP_SLOT_IDS and id(p) in ops._GRAD_SLOTS
+        ops._TEMP_SLOT_IDS.append(12345)
+        ops.register_grad_slots([], [])
+        assert not ops._TEMP_SLOT_IDS and not ops._GRAD_SLOTS
+    finally:
+        ops._GRAD_SLOTS.clear(); ops._GRAD_SLOTS.update(saved)
+        ops._TEMP_SLOT_IDS[:] = saved_ids
