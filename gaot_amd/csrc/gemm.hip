@@ -367,7 +367,7 @@ int gaot_forced_pieces() { return g_split_pieces_forced ? g_split_pieces : 0; }
 
 static int g_use_ad = 1;         // all-DMA fp16-piece tiles: 0 off, 1 per the heuristic, 2 / 3: 64- / 128-row tiles wherever eligible (A/B switch)
 extern "C" int gaot_debug_set_gemm_ad(int on) { const int old = g_use_ad; g_use_ad = on; return old; }
-static int g_ad_narrow = 0;     // 64 x 64 all-DMA tiles for narrow outputs: OFF by default (see the dispatcher), 1 = on (A/B switch)
+static int g_ad_narrow = 1;     // 64 x 64 all-DMA tiles (A/B switch, bits): 1 = half-filled launches of outputs two tiles wide (default), 2 = also N <= 256, K <= 256 at full launches
 extern "C" int gaot_debug_set_gemm_ad_narrow(int on) { const int old = g_ad_narrow; g_ad_narrow = on; return old; }
 static int g_use_planes = 1;     // 0: ignore gaot_gemm_desc.b_planes (A/B switch)
 extern "C" unsigned gaot_debug_split_redo_count(int reset) { return gaot::split_redo_count(reset != 0) + gaot::ad_redo_count(reset != 0); }
@@ -506,17 +506,22 @@ static int gemm_run(const gaot_gemm_desc* d, gaot_stream_t stream, const bool dr
     // fp32-MFMA tiles on the NN products too: 8192 x 256 x 768 37.4 -> 25.6 us, x 512 26.5 -> 19.0, x 256 15.5 -> 12.8, tools/gemm_modes_2p.py)
     const bool split64 = split_ok && !split128 && g_use_split != 5 && g_use_split != 2 &&
                          (g_use_split == 4 || prefer64 || ((ak && (bk || a.Bpl != nullptr || g_use_split == 6 || two_pl)) && blocks(64, 128) >= 250 && a.M >= 64 && a.N >= 128 && a.split_k <= 1));   // measured: NT +6-14 %, NN +-0
-    // 64 x 64 all-DMA tiles, OFF by default (gaot_debug_set_gemm_ad_narrow(1) turns both uses on): (a) half-filled launches of outputs two
-    // tiles wide (4 096 tokens x 256: 128 workgroups of 64 rows, which fall to the fp32-MFMA tiles) get 256 workgroups -- tools/ad_bench.hip:
-    // 4096 x 256 x 256 in 8.3 us against ~15; (b) N <= 256 with K <= 256 at 8 192 rows: 11.9 -> 11.2 us.  Bit-identical to the other tiles in
-    // every test (tests/test_ops_gpu.py, tools/ad_stress.py: 450 products), but at step level the gain did not hold up across boxes (seven
-    // same-box A/B runs: C2 -9 .. +14 us, 4 096-token batch -27 .. +22 us), and in two of those runs the variant's loss after ~200 steps
-    // was a DIFFERENT (repeatable) number from the one every other run of either variant gives -- not traced; until it is, the tiles stay off
-    const bool ad_narrow = g_use_ad == 1 && g_ad_narrow && split_ok && !split128 && !split64 && pieces == 4 && ak && a.K % 32 == 0 && a.vec_epi &&
-                           a.split_k <= 1 && a.A2 == nullptr && cdiv(a.N, 128) == 2 && blocks(64, 64) >= 128 && blocks(64, 128) < 250 &&
-                           a.K <= 1024 && (dry || a.Bpl != nullptr);
+    // 64 x 64 all-DMA tiles (gaot_debug_set_gemm_ad_narrow, bits): (1, default) half-filled launches of outputs two tiles wide (4 096 tokens x
+    // 256: 128 workgroups of 64 rows, which fall to the fp32-MFMA tiles) get 256 workgroups -- tools/ad_bench.hip: 4096 x 256 x 256 in 8.3 us
+    // against ~15; same-box step A/B at the 4 096-token batch (tools/step_ab.py --c4, twice): 1.6486 -> 1.6249, 1.6481 -> 1.6234 ms, C2
+    // untouched (its launches are full).  (2, off) N <= 256 with K <= 256 at 8 192 rows: 11.9 -> 11.2 us alone, but C2 2.1499 -> 2.1663,
+    // 2.1399 -> 2.1705 ms per step.  Bit-identical to the other fp16-piece tiles in every test (tests/test_ops_gpu.py, tools/ad_stress.py);
+    // a product that (1) moves off the fp32-MFMA tiles is rounded as the fp16-piece family rounds (same error class, other last bits).
+    // (An earlier series of A/B runs looked inconsistent and twice ended at an unexplained loss: that was the host-side slot bookkeeping,
+    // DESIGN 7, not these tiles.)
+    const bool narrow_shape = g_use_ad == 1 && (g_ad_narrow & 1) && split_ok && !split128 && !split64 && pieces == 4 && ak && a.K % 32 == 0 && a.vec_epi &&
+                              a.split_k <= 1 && a.A2 == nullptr && cdiv(a.N, 128) == 2 && blocks(64, 64) >= 128 && blocks(64, 128) < 250 && a.K <= 1024;
+    const bool ad_narrow = narrow_shape && (dry || a.Bpl != nullptr);
+    // planes handed in but switched off (gaot_debug_set_gemm_planes(0)): the same tile family on the staged 64-row kernel, so that the
+    // switch changes where B's pieces come from and nothing else (products WITHOUT planes -- B an activation -- stay where they were)
+    const bool narrow_staged = narrow_shape && !dry && a.Bpl == nullptr && d->b_planes != nullptr;
     if (dry) { g_last_path = (split128 || split64 || ad_narrow) ? 3 : 1; return GAOT_OK; }
-    if (split128 || split64 || ad_narrow) {
+    if (split128 || split64 || ad_narrow || narrow_staged) {
         g_last_path = 3;
         // 256x128 (8-wave) tiles: measured +3-7 % on the NT / TN products that still give ~200 workgroups, -2 % on NN
         const bool big = split128 && a.M >= 512 && (g_split_bm256 == 2 || (g_split_bm256 == 1 && ak == bk && blocks(256, 128) >= 190));
@@ -530,10 +535,10 @@ static int gemm_run(const gaot_gemm_desc* d, gaot_stream_t stream, const bool dr
         const bool ad64 = ad_ok && (g_use_ad == 2 || (a.split_k <= 1 && (cdiv(a.N, 128) <= 2 || blocks(64, 128) <= 512) && blocks(64, 128) >= 128));
         const bool ad128 = ad_ok && !ad64 && !big && (g_use_ad == 3 || (a.split_k <= 1 && split128 && blocks(128, 128) <= 512));
         if (ad_narrow) launch_ad(a, bk, st, 64, 64);
-        else if (ad64) launch_ad(a, bk, st, 64, (g_ad_narrow && a.K <= 256 && cdiv(a.N, 128) <= 2) ? 64 : 128);      // (8192 x 256 x 256: 11.9 -> 11.2 us on 64 x 64 tiles)
+        else if (ad64) launch_ad(a, bk, st, 64, ((g_ad_narrow & 2) && a.K <= 256 && cdiv(a.N, 128) <= 2) ? 64 : 128);      // (8192 x 256 x 256: 11.9 -> 11.2 us on 64 x 64 tiles)
         else if (ad128) launch_ad(a, bk, st, 128);
         else
-        launch_split(a, ak, bk, st, split64 ? 64 : (big && pieces != 1 ? 256 : 128), pieces);
+        launch_split(a, ak, bk, st, (split64 || narrow_staged) ? 64 : (big && pieces != 1 ? 256 : 128), pieces);
     }
     else if (glds_ok && g_tile_override >= 0 && g_tile_override <= 3) {
         int tile = g_tile_override;

@@ -31,8 +31,9 @@ int gaot_debug_set_gemm_pieces(int pieces);
 int gaot_debug_set_gemm_planes(int on);
 /* all-DMA fp16-piece tiles (gemm_ad.hip): 0 off, 1 per the heuristic (default), 2 / 3: 64- / 128-row tiles wherever eligible; returns the old value */
 int gaot_debug_set_gemm_ad(int on);
-/* 64 x 64 all-DMA tiles for narrow outputs (N <= 256; K <= 256, or launches that 64 x 128 tiles leave half filled): 0 (default) off, 1 on
- * (same-box A/B; see the dispatcher in gemm.hip for why they are off); returns the old value */
+/* 64 x 64 all-DMA tiles for narrow outputs (N <= 256), bits: 1 (default) launches that 64 x 128 tiles leave half filled (4 096-token
+ * batches), 2 also K <= 256 at full launches (off: slower at step level); 0 none (same-box A/B; see the dispatcher in gemm.hip);
+ * returns the old value */
 int gaot_debug_set_gemm_ad_narrow(int on);
 /* attention backward, head_dim 32, fp16 pieces: 1 (default) lets two workgroups share the query tiles of a 256-key block when the launch
  * would otherwise hold 128 .. 255 workgroups (4 x 1 024 tokens x 8 heads); 0: the 4-wave kernel as before (same-box A/B); returns the old value */

@@ -803,7 +803,7 @@ def test_all_dma_tiles_equal_the_staged_tiles_bit_for_bit(M, N, K):
         for k, v in got.items():
             assert torch.equal(v, ref[k]), (mode, k, float((v - ref[k]).abs().max()))
     if M >= 8000:          # the 64 x 64 tiles (off by default; at fewer rows their switch also moves products off the fp32-MFMA tiles)
-        old = lib.gaot_debug_set_gemm_ad_narrow(1)
+        old = lib.gaot_debug_set_gemm_ad_narrow(3)
         try:
             ops._PATH_CACHE.clear()
             got = run(1)

@@ -12,7 +12,7 @@ for it in range(150):
     w = torch.nn.Parameter((torch.randn(N, K, generator=g) * 0.06).cuda())
     w2 = torch.nn.Parameter((torch.randn(K, N, generator=g) * 0.06).cuda())
     outs = []
-    for mode in (0, 1, 1):
+    for mode in (0, 3, 3):
         old = lib.gaot_debug_set_gemm_ad_narrow(mode)
         ops._PATH_CACHE.clear()
         ops.begin_pass(); ops.refresh_weight_amax([w, w2])
