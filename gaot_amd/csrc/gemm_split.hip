@@ -736,7 +736,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const TnGroupAr
 }
 
 static int g_tn_kslab = 0;           // 0 = automatic (below); otherwise a fixed K slab (tuning hook)
-void set_tn_kslab(int k) { g_tn_kslab = k <= 0 ? 0 : (k < 256 ? 256 : (k / 32) * 32); }
+static int g_tn_cap_long = 4096;     // the same for node-level products (K = batch x nodes > 16 384)
+static int g_tn_cap = 4096;          // longest K slab of a product whose reduction is much longer than the rest (tuning hook: a negative argument sets it)
+void set_tn_kslab(int k) {
+    if (k <= -100000) { g_tn_cap_long = ((-k - 100000) < 256 ? 256 : ((-k - 100000) / 32) * 32); g_tn_kslab = 0; return; }      // -(100000 + cap): node-level products only
+    if (k < 0) { g_tn_cap = (-k < 256 ? 256 : (-k / 32) * 32); g_tn_kslab = 0; return; }
+    g_tn_kslab = k == 0 ? 0 : (k < 256 ? 256 : (k / 32) * 32);
+}
 // host side of the grouped launch: items -> prefix table; returns the workspace floats / counters it needs when `args` is null
 long plan_tn_grouped(const gaot_wgrad_item* items, int n, TnGroupArgs* args, int* n_counters, int* n_wg) {
     long ws = 0; int cnt = 0, wg = 0;
@@ -749,6 +755,20 @@ long plan_tn_grouped(const gaot_wgrad_item* items, int n, TnGroupArgs* args, int
     long tiles_total = 0;
     for (int i = 0; i < n; ++i) tiles_total += (long)cdiv(items[i].M, 128) * cdiv(items[i].N, 128);
     const int want = (int)((272 + tiles_total - 1) / (tiles_total > 0 ? tiles_total : 1));
+    // ONE slab length for the whole launch: the launch lasts as long as its longest K loop times the rounds, so a product with a longer
+    // reduction than the rest (the patch-level layers: K = 4 x tokens; node-level ones: batch x nodes) is cut to the slab of the shortest
+    // one, not to a fixed 4 096 -- 4 096-token batch, same box (tools/step_ab.py gaot_debug_set_wgrad_kslab ... --c4), slabs of
+    // token-level / longer products: 2 048 / 4 096 (the former rule) 1.5777 ms, 4 096 / 4 096 1.5332; on two other boxes 4 096 / 4 096
+    // 1.5421, 1.6240 against 2 048 / 2 048 1.5118, 1.5938.  K = 8 192 tokens keeps its 4 096 / 4 096 (2 048 / 2 048: 2.1076 -> 2.1505)
+    long kmin = 0;
+    for (int i = 0; i < n; ++i) kmin = (kmin == 0 || items[i].K < kmin) ? items[i].K : kmin;
+    int base_slab = 4096;
+    {
+        int s0 = want < 1 ? 1 : (want > 16 ? 16 : want);
+        if (s0 > kmin / 512) s0 = kmin / 512 > 0 ? (int)(kmin / 512) : 1;
+        const long b = (kmin + s0 - 1) / s0;
+        base_slab = b < 1024 ? 1024 : (b > 4096 ? 4096 : (int)b);
+    }
     for (int i = 0; i < n; ++i) {
         const gaot_wgrad_item& it = items[i];
         const int kt32 = it.K / 32;
@@ -757,7 +777,9 @@ long plan_tn_grouped(const gaot_wgrad_item* items, int n, TnGroupArgs* args, int
             int s_auto = want < 1 ? 1 : (want > 16 ? 16 : want);      // the last workgroup of a tile sums the slabs alone: keep them few
             if (s_auto > it.K / 512) s_auto = it.K / 512 > 0 ? it.K / 512 : 1;      // slabs of at least 512
             kslab = (it.K + s_auto - 1) / s_auto;
-            if (kslab > 4096) kslab = 4096;             // products with a much longer reduction than the rest (node-level layers: K = batch x nodes)
+            const int cap0 = it.K > 16384 ? g_tn_cap_long : g_tn_cap;
+            const int cap = cap0 < base_slab ? cap0 : base_slab;
+            if (kslab > cap) kslab = cap;               // products with a much longer reduction than the rest (node-level layers: K = batch x nodes)
         }
         int split = (it.K + kslab - 1) / kslab;
         int per = (kt32 + split - 1) / split;

@@ -43,6 +43,8 @@ int gaot_debug_set_attention_qsplit(int on);
  * scale per row (gemm_split.hip).  Synchronises the device.  reset != 0: zero the counter after reading it. */
 unsigned gaot_debug_split_redo_count(int reset);
 /* grouped weight gradients: values of k per workgroup (K slab length; multiple of 32, default 4096) */
+/* (k > 0: a fixed K slab for every product of the grouped launch; 0: automatic; -c: the cap of longer products' slabs (default 4 096);
+ * -(100000 + c): the same for node-level products, K > 16 384) */
 int gaot_debug_set_wgrad_kslab(int k);
 /* tuning hook: head_dim 32 attention, 1 = split-bf16 MFMA kernels (default), 0 = fp32-MFMA kernels, 2 / 3 = split with the
  * 8-wave / 4-wave forward workgroup forced.  Returns the previous value. */

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""A few training steps of a BASELINE configuration for the profiler.  usage: eager_steps.py c2|c3 N [graph] [staged]
-c2 = the bench configuration; c3 = NACA-shaped skewed meshes, vx mode, batch 16, 8192 nodes (tests/_workloads.naca_points)."""
+"""A few training steps of a BASELINE configuration for the profiler.  usage: eager_steps.py c2|c3|c4 N [graph] [staged]
+c2 = the bench configuration; c4 = its first 4 samples (the 4 096-token batch of BASELINE configs[3]); c3 = NACA-shaped skewed meshes, vx mode, batch 16, 8192 nodes (tests/_workloads.naca_points)."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from types import SimpleNamespace as NS
@@ -17,11 +17,14 @@ which, n = sys.argv[1], int(sys.argv[2])
 graph = len(sys.argv) > 3 and sys.argv[3] == "graph"
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-if which == "c2":
+if which in ("c2", "c4"):
     model = bench.build_model().to(dev).train()
     lat, x, p, t = bench.synthetic(1234, dev)
     kw = dict(latent_tokens_coord=lat, xcoord=x)
     B = bench.BATCH
+    if which == "c4":
+        B = 4
+        p, t = p[:4].contiguous(), t[:4].contiguous()
 else:
     B, N = 16, 8192
     mc = MAGNOConfig(radius=0.033, lifting_channels=64, precompute_edges=True)
