@@ -482,6 +482,7 @@ _GEMM_MODE = int(os.environ.get("GAOT_GEMM_MODE", "4"))
 # 1 = edge-partitioned everywhere, 0 = the row-parallel kernels of round 1 (A/B switch for tools and tests)
 _GNO_EP = int(os.environ.get("GAOT_GNO_EP", "2"))
 _NARROW_SPLIT = int(os.environ.get("GAOT_NARROW_SPLIT", "1"))        # A/B switch: split-K for narrow-output activation products
+_NARROW_TILES_1K = int(os.environ.get("GAOT_NARROW_TILES_1K", "1"))  # A/B switch: no K slabs where the 64 x 64 all-DMA tiles take a narrow product whole
 _NARROW_SPLIT_1K = int(os.environ.get("GAOT_NARROW_SPLIT_1K", "1"))  # A/B switch: K slabs of a narrow-output product with K = 1 024 (FFN down-projection)
 
 
@@ -547,6 +548,11 @@ def _split_for_narrow_output(Mo: int, No: int, K: int) -> int:
         # fp16 / two-piece tiles (tools/gemm_splitk_sweep.py, product + reduce): K = 2048: 76 / 51 / 47 us at 1 / 2 / 4 slabs on the
         # 128-row tiles (64-row tiles without slabs: 66); K = 1024: 34 (64-row, no slabs) / 31.5 (two slabs)
         return 4 if K >= 2048 else _NARROW_SPLIT_1K
+    if _NARROW_TILES_1K and 48 <= t128 < 100 and 128 < No <= 256 and K <= 1024 and Mo % 64 == 0:
+        # two tiles across, half a round of 64-row tiles (4 096 tokens x 256, the FFN down-projection at K = 1 024): the 64 x 64 all-DMA
+        # tiles (gemm.hip, 256 workgroups) take the whole reduction in one launch; two slabs on the fp32-MFMA tiles + the reduce were
+        # 24.8 + 5.3 us per launch (profiles/r5z_c4_kernel_stats.txt)
+        return 1
     if 48 <= t128 < 100 and Mo >= 128 and No >= 128:
         # fewer than 100 output tiles (4 096 tokens x 384 at the 3-D configuration): on the fp32-MFMA tiles 130 us at K = 3 072;
         # enough K slabs for ~256 workgroups on the split-bf16 tiles, each at most 1 024 deep (the accumulation cap of gemm.hip)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Same-box A/B of the bench step (C2, TrainStep under hipGraph) for an integer debug switch of the library:
+"""Same-box A/B of the bench step (C2, TrainStep under hipGraph) for an integer debug switch of the library (or `ops.<NAME>`, a module-level
+switch of gaot_amd.ops):
     python tools/step_ab.py gaot_debug_set_gemm_ad 0 1 [2 ...]
 builds one TrainStep per value (the graph is captured with the switch set), then times them in alternation (3 rounds x 60 steps each)
 and prints ms per step per value.  --c4: the 4 096-token batch of BASELINE configs[3] instead."""
@@ -12,7 +13,12 @@ from gaot_amd.trainer import TrainStep
 
 lib = _lib.load()
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
-fn = getattr(lib, args[0])
+if args[0].startswith("ops."):          # a module-level switch of gaot_amd.ops instead of a library function: python tools/step_ab.py ops._NARROW_TILES_1K 0 1
+    _name = args[0][4:]
+    def fn(v):
+        old = getattr(ops, _name); setattr(ops, _name, v); return old
+else:
+    fn = getattr(lib, args[0])
 values = [int(v) for v in args[1:]]
 dev = torch.device("cuda:0")
 steps = []
