@@ -551,7 +551,7 @@ def _split_for_narrow_output(Mo: int, No: int, K: int) -> int:
     if _NARROW_TILES_1K and 48 <= t128 < 100 and 128 < No <= 256 and K <= 1024 and Mo % 64 == 0:
         # two tiles across, half a round of 64-row tiles (4 096 tokens x 256, the FFN down-projection at K = 1 024): the 64 x 64 all-DMA
         # tiles (gemm.hip, 256 workgroups) take the whole reduction in one launch; two slabs on the fp32-MFMA tiles + the reduce were
-        # 24.8 + 5.3 us per launch (profiles/r5z_c4_kernel_stats.txt)
+        # 24.8 + 5.3 us per launch (profiles/r5z_c4_kernel_stats_before.txt, r5z_c4_step_sequence.txt)
         return 1
     if 48 <= t128 < 100 and Mo >= 128 and No >= 128:
         # fewer than 100 output tiles (4 096 tokens x 384 at the 3-D configuration): on the fp32-MFMA tiles 130 us at K = 3 072;
