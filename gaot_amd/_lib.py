@@ -60,6 +60,12 @@ class KmlpDesc(C.Structure):
                 ("dk", _f), ("grads", _f), ("workspace", _f)]
 
 
+class UnionPart(C.Structure):
+    """gaot_union_part: one sample of a block-diagonal union composed from a device-side table (gaot_union_compose)"""
+    _fields_ = [("index", _i), ("edge_query", _i), ("t_edge", _i), ("splits", _i), ("t_splits", _i), ("src", _f), ("dst", _f),
+                ("e_begin", C.c_int32), ("e_count", C.c_int32)]
+
+
 class ColsumItem(C.Structure):
     """gaot_colsum_item: out[n] = sum_m x[m * ld + n]"""
     _fields_ = [("x", _f), ("ld", C.c_int64), ("out", _f), ("M", C.c_int32), ("N", C.c_int32), ("out_cols", C.c_int32), ("out_ld", C.c_int64)]
@@ -89,6 +95,9 @@ PROTOTYPES = {
     "gaot_debug_set_wgrad_kslab": (C.c_int, [C.c_int]),
     "gaot_csr_prepare": (C.c_int, [_i, _i, C.c_int32, C.c_int32, C.c_int32, _i, _i, _i, _i, _s]),
     "gaot_csr_transpose": (C.c_int, [_i, C.c_int32, C.c_int32, _i, _i, _i, _s]),
+    "gaot_union_compose": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i, _i, _i, _i, _i, _f, _f, _i, _s]),
+    "gaot_edge_inv_degree": (C.c_int, [_i, _i, C.c_int32, _i, _f, _s]),
+    "gaot_edge_zero_pads": (C.c_int, [_f, C.c_int32, C.c_int32, C.c_int32, _i, C.c_int32, _s]),
     "gaot_guard_begin": (C.c_int, [_i, _s]),
     "gaot_guard_compare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _i, _s]),
     "gaot_guard_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _i, _s]),
@@ -160,8 +169,8 @@ PROTOTYPES = {
     "gaot_adamw_apply_dev": (C.c_int, [_f, _f, _f, _f, C.c_int64, _f, _f, _s]),
     "gaot_debug_set_ep_chunk": (C.c_int, [C.c_int]),
     "gaot_gno_ep_workspace": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
-    "gaot_gno_lift_gather_reduce_ep": (C.c_int, [_f, _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i, _i, _i, C.c_int32, C.c_int32, _f, _f, _f, _s]),
-    "gaot_gno_proj_gather_t_ep": (C.c_int, [_f, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i, _i, C.c_int32, _i, _i, _f, _f, _f, _s]),
+    "gaot_gno_lift_gather_reduce_ep": (C.c_int, [_f, _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i, _i, _i, C.c_int32, C.c_int32, _f, _f, _f, _i, _s]),
+    "gaot_gno_proj_gather_t_ep": (C.c_int, [_f, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i, _i, C.c_int32, _i, _i, _f, _f, _f, _i, _s]),
     "gaot_proj_fold_workspace": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
     "gaot_proj_fold_fwd": (C.c_int, [_f, C.c_int64, _f, _f, C.c_int64, _f, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f, _f, _s]),
     "gaot_proj_fold_bwd": (C.c_int, [_f, _f, _f, C.c_int64, _f, C.c_int64, _f, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f,

@@ -18,12 +18,12 @@ statistics) guarded by that flag: they recompute in place only if the bytes chan
 flag.  No host synchronisation, four extra launches per step.  Weights are read through their storage pointers: in-place optimizers (torch.optim.*) keep them; if a
 parameter's storage moves (or a shape, the batch size, the training flag changes) the step is captured again.
 
-vx (a different mesh per sample, caller-supplied neighbour lists: static_trainer.py:180-202).  A batch is replayed when it is the
-SAME COMPOSITION as a captured one: the same per-sample neighbour dict OBJECTS in the same order (a dataset kept on the device hands
-out the same dicts every epoch) and coordinates with the same content -- the same tensor object, or one whose bytes equal the captured
-ones (checked with one torch.equal, i.e. one host synchronisation per step; the reference loop synchronises at every upload anyway).
-The captured graphs read the block-diagonal union plan that was composed for that batch; any other composition runs eagerly (its
-first repeat captures it).  Dicts uploaded anew every step (the reference's default CPU-side dataset) are new objects: eager.
+vx (a different mesh per sample, caller-supplied neighbour lists: static_trainer.py:180-202).  ANY batch composition is replayed: the batch's
+block-diagonal unions live in static buffers padded to an edge-count bucket (plan.StaticUnion), and the captured forward BEGINS by composing
+them on the device from a small table of per-sample plan pointers that run() uploads before every replay, then recomputes the geometry-derived
+arrays from the static coordinate buffers.  A shuffling loader (the reference's default, data_utils.py:272-294) therefore replays from the
+third step of each bucket on -- a handful of buckets per dataset -- whether the per-sample dicts are kept on the device (their plans are built
+once) or uploaded anew every step (their plans are built per step, without a host synchronisation).
 
 Not eligible (the eager HIP path runs as before): evaluation / no_grad, neighbour sub-sampling, node_embedding, fx coordinates with
 caller-supplied neighbour lists, pndata that requires grad, host tensors, or `model.auto_graph = False` / GAOT_AUTO_GRAPH=0.
@@ -39,6 +39,7 @@ from . import ops
 
 ENABLED = os.environ.get("GAOT_AUTO_GRAPH", "1") != "0"
 MAX_ENTRIES = 3          # distinct (shape, mode) keys kept captured per model
+MAX_ENTRIES_VX = 6       # ... when vx entries are among them (one per combination of the unions' edge buckets)
 
 
 class _Entry:
@@ -55,6 +56,8 @@ def eligible(model, latent, xcoord, pndata, query_coord, encoder_nbrs, decoder_n
     if not (torch.is_tensor(pndata) and torch.is_tensor(xcoord) and torch.is_tensor(latent)):
         return False          # e.g. pndata=None (static_trainer.py:164-167 with an empty x_batch): the model's own validation answers
     vx = encoder_nbrs is not None or decoder_nbrs is not None
+    if vx and not _static_unions_on():
+        return False
     if vx and not (_vx_lists_ok(encoder_nbrs, pndata) and _vx_lists_ok(decoder_nbrs, pndata) and xcoord.dim() == 3):
         return False
     if not (pndata.is_cuda and xcoord.is_cuda and latent.is_cuda) or pndata.requires_grad or (not vx and xcoord.dim() != 2):
@@ -69,6 +72,11 @@ def eligible(model, latent, xcoord, pndata, query_coord, encoder_nbrs, decoder_n
         if side.sampling_strategy is not None or side.node_embedding or bool(side.precompute_edges) != vx:
             return False
     return True
+
+
+def _static_unions_on() -> bool:
+    from . import plan as P
+    return P.VX_STATIC
 
 
 def _vx_lists_ok(nbrs, pndata) -> bool:
@@ -107,8 +115,8 @@ def _param_list(model):
     return hit[1]
 
 
-def _key(model, latent, xcoord, pndata, condition, enc=None, dec=None):
-    comp = None if enc is None else (tuple(id(d) for row in enc for d in row), tuple(id(d) for row in dec for d in row))      # vx: the batch composition
+def _key(model, latent, xcoord, pndata, condition, unions=None):
+    comp = None if unions is None else tuple(u.uid for side in unions for u in side)      # vx: the static unions (one per scale and edge bucket)
     return (tuple(pndata.shape), pndata.dtype, tuple(xcoord.shape), tuple(latent.shape),
             None if condition is None else tuple(condition.shape), pndata.device.index, comp,
             tuple(p.data_ptr() if p.requires_grad else -p.data_ptr() for p in _param_list(model)))      # storage AND trainability
@@ -188,7 +196,15 @@ def _sync_coordinates(e, latent, xcoord):
     e.store[3] = (xcoord, xcoord._version, latent, latent._version)
 
 
-def _capture(model, latent, xcoord, pndata, condition, enc=None, dec=None) -> _Entry:
+def _vx_load(unions, x, lat):
+    """upload the tables of this batch's unions (found by run()); coordinate pointers into x [B, N, d] / lat [M, d]"""
+    for u in unions[0]:
+        u.load_pending(x, lat)
+    for u in unions[1]:
+        u.load_pending(lat, x)
+
+
+def _capture(model, latent, xcoord, pndata, condition, enc=None, dec=None, unions=None) -> _Entry:
     from . import plan as P
     from . import _lib as L
     e = _Entry()
@@ -198,13 +214,14 @@ def _capture(model, latent, xcoord, pndata, condition, enc=None, dec=None) -> _E
     e.vx = enc is not None
     e.gen, e.pending = 0, None
     if e.vx:
-        # private coordinate buffers (the union plan composed for THIS batch holds its own copy of the coordinates: nothing in the
-        # captured graphs follows later edits, so run() replays only for byte-identical coordinates) and the dict lists themselves
-        # (held: their ids are the key)
-        e.store = [latent.detach().clone(), xcoord.detach().clone(), torch.zeros(1, dtype=torch.int32, device=dev),
+        # private static coordinate buffers: the unions' tables point into them, the captured forward re-derives every geometry array from
+        # them on each replay (no content guard: the composition changes anyway); the dict lists handed to the model are this call's
+        e.store = [latent.detach().clone().contiguous(), xcoord.detach().clone().contiguous(), torch.zeros(1, dtype=torch.int32, device=dev),
                    (xcoord, xcoord._version, latent, latent._version)]
-        e.enc, e.dec = [list(r) for r in enc], [list(r) for r in dec]
+        e.enc, e.dec = enc, dec
         e.lat, e.x, e.flag = e.store[0], e.store[1], e.store[2]
+        e.unions = unions
+        _vx_load(unions, e.x, e.lat)
     else:
         e.enc = e.dec = None
         e.store = _static_coordinates(model, latent, xcoord)
@@ -231,6 +248,8 @@ def _capture(model, latent, xcoord, pndata, condition, enc=None, dec=None) -> _E
 
     def fwd():
         model._auto_graph_bypass = True
+        if e.vx:
+            model.encoder._vx_preloaded, model.decoder._vx_preloaded = (e.unions[0], e.enc), (e.unions[1], e.dec)
         try:
             return torch.func.functional_call(model, leaves, (), dict(latent_tokens_coord=e.lat, xcoord=e.x, pndata=e.p, condition=e.c,
                                                                       encoder_nbrs=e.enc, decoder_nbrs=e.dec))
@@ -291,6 +310,8 @@ def _capture(model, latent, xcoord, pndata, condition, enc=None, dec=None) -> _E
             if sl[2]:
                 sl[2] = next(reached)
         e.epochs = _plan_epochs(model)
+        if e.vx:
+            e.enc = e.dec = None          # the graphs read the unions' static buffers; this call's lists need not live on
     finally:
         owner.__exit__(None, None, None)
         P.FORCE_GUARD[0] = None
@@ -302,10 +323,24 @@ def _capture(model, latent, xcoord, pndata, condition, enc=None, dec=None) -> _E
 def run(model, latent, xcoord, pndata, condition, enc=None, dec=None) -> Optional[torch.Tensor]:
     """the training forward through captured graphs, or None when the step cannot be (or could not be) captured"""
     cache = model.__dict__.setdefault("_auto_graph_cache", {})
-    key = _key(model, latent, xcoord, pndata, condition, enc, dec)
+    vx = enc is not None
+    unions = None
+    if vx:
+        # this batch's unions (per scale and edge bucket: found or made, nothing uploaded yet -- the tables point at the coordinates of whoever
+        # runs the step: the replaying entry's static buffers, or the caller's tensors on an eager pass)
+        B = pndata.shape[0]
+        unions = (model.encoder.vx_unions(enc, xcoord, latent, B, load=False), model.decoder.vx_unions(dec, latent, xcoord, B, load=False))
+
+    def eager():
+        if vx:
+            xc, lc = xcoord.contiguous(), latent.contiguous()
+            _vx_load(unions, xc, lc)
+            model.encoder._vx_preloaded, model.decoder._vx_preloaded = (unions[0], enc), (unions[1], dec)
+        return None
+    key = _key(model, latent, xcoord, pndata, condition, unions)
     e = cache.get(key)
     if e is None:
-        if len(cache) >= MAX_ENTRIES:
+        if len(cache) >= (MAX_ENTRIES_VX if vx else MAX_ENTRIES):
             cache.pop(next(iter(cache)))
         # the first call with this key runs eagerly (it also builds the neighbour lists and plans, which synchronise);
         # the second one captures
@@ -313,21 +348,22 @@ def run(model, latent, xcoord, pndata, condition, enc=None, dec=None) -> Optiona
             model._auto_graph_seen.add(key)
             if len(model._auto_graph_seen) > 16:
                 model._auto_graph_seen.clear()
-            return None
-        e = _capture(model, latent, xcoord, pndata, condition, enc, dec)
+            return eager()
+        e = _capture(model, latent, xcoord, pndata, condition, enc, dec, unions)
         cache[key] = e
     # geometry: new coordinate tensors (a trainer that uploads them every step): compare with the static buffers (flag |= differ),
     # overwrite the buffers; the captured forward starts with the flag-guarded refresh of the plans' arrays and ends by clearing it
     pend = e.pending
     if pend is not None and pend() is not None and pend().gen == e.gen and not getattr(pend(), "_done", False):
-        return None        # a forward of this entry is still waiting for its backward: this call runs eagerly (correct, slower)
+        return eager()     # a forward of this entry is still waiting for its backward: this call runs eagerly (correct, slower)
     last = e.store[3]
     if e.vx:
-        if xcoord is not last[0] or xcoord._version != last[1] or latent is not last[2] or latent._version != last[3]:
-            # new coordinate tensors for the same dicts: replay only if their bytes are the captured ones (one host synchronisation)
-            if not (torch.equal(xcoord, e.x) and torch.equal(latent, e.lat)):
-                return None
-            e.store[3] = (xcoord, xcoord._version, latent, latent._version)
+        if xcoord is not last[0] or xcoord._version != last[1]:
+            e.x.copy_(xcoord, non_blocking=True)
+        if latent is not last[2] or latent._version != last[3]:
+            e.lat.copy_(latent, non_blocking=True)
+        e.store[3] = (xcoord, xcoord._version, latent, latent._version)
+        _vx_load(unions, e.x, e.lat)      # the tables of this batch, pointing at the static coordinates
         return _GraphedStep.apply(e, pndata, condition, *e.params)
     if (last is None or xcoord is not last[0] or xcoord._version != last[1] or latent is not last[2] or latent._version != last[3]):
         _sync_coordinates(e, latent, xcoord)      # new objects, or the same objects edited in place: compare bytes on the device

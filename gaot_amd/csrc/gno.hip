@@ -89,6 +89,59 @@ __global__ void concat_offset_kernel(ConcatParts p, int total, int* __restrict__
     out[i] = p.ptr[lo][i - p.begin[lo]] + p.off[lo];
 }
 
+// Block-diagonal union of per-sample plans from a DEVICE-side table (vx training under a shuffling loader: the batch composition changes
+// every step, the launch does not).  All arrays are static buffers sized for E_cap >= sum of the parts' edge counts; the edges past the
+// real count ("pads") are never referenced by a row of either CSR (splits[Q] = t_splits[n_src] = E_real), and the flat per-edge kernels
+// that do walk them see valid indices (source 0, query 0, t_edge = own id) and an edge scale of 0.
+__global__ __launch_bounds__(256) void union_compose_kernel(const gaot_union_part* __restrict__ parts, int B, int Qe, int Se, int dsrc, int ddst,
+                                                            int E_cap, int* __restrict__ index, int* __restrict__ eq, int* __restrict__ tedge,
+                                                            int* __restrict__ splits, int* __restrict__ tsplits, float* __restrict__ src,
+                                                            float* __restrict__ dst, int* __restrict__ e_real) {
+    __shared__ int begin[1025];
+    for (int b = threadIdx.x; b < B; b += 256) begin[b] = parts[b].e_begin;
+    if (threadIdx.x == 0) begin[B] = parts[B - 1].e_begin + parts[B - 1].e_count;
+    __syncthreads();
+    const int E = min(begin[B], E_cap);
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) *e_real = E;
+    if (i < E_cap) {
+        if (i < E) {
+            int lo = 0, hi = B;                       // begin[lo] <= i < begin[hi]
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (begin[mid] <= (int)i) lo = mid; else hi = mid; }
+            const gaot_union_part& p = parts[lo];
+            const int l = (int)i - begin[lo];
+            index[i] = p.index[l] + lo * Se;
+            eq[i] = p.edge_query[l] + lo * Qe;
+            tedge[i] = p.t_edge[l] + begin[lo];
+        } else {
+            index[i] = 0; eq[i] = 0; tedge[i] = (int)i;
+        }
+    }
+    const long Qt = (long)B * Qe, St = (long)B * Se;
+    if (i <= Qt) splits[i] = i == Qt ? E : min(parts[i / Qe].splits[i % Qe] + begin[i / Qe], E);
+    if (i <= St) tsplits[i] = i == St ? E : min(parts[i / Se].t_splits[i % Se] + begin[i / Se], E);
+    if (src && i < St * dsrc) { const long r = i / dsrc; src[i] = parts[r / Se].src[(r % Se) * dsrc + i % dsrc]; }
+    if (dst && i < Qt * ddst) { const long r = i / ddst; dst[i] = parts[r / Qe].dst[(r % Qe) * ddst + i % ddst]; }
+}
+// 1 / deg(query(e)) per edge, 0 on the pads ('mean' reduction of agno.py:264 as a per-edge scale)
+__global__ void edge_inv_degree_kernel(const int* __restrict__ sp, const int* __restrict__ eq, int E, const int* __restrict__ e_real,
+                                       float* __restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    if (e_real && e >= *e_real) { out[e] = 0.f; return; }
+    const int q = eq[e];
+    out[e] = 1.0f / (float)max(sp[q + 1] - sp[q], 1);
+}
+// a[b, e, :] = 0 for e >= *e_real (the pads of a padded union: whatever per-edge scale the transform uses must vanish there, and so must
+// per-edge gradient rows that a flat kernel filled before a reduction over all E rows reads them)
+__global__ void edge_zero_pads_kernel(float* __restrict__ a, int B, int E, int width, const int* __restrict__ e_real) {
+    const int er = *e_real;
+    const long n = (long)(E - er) * width;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    a[((long)blockIdx.y * E + er) * width + i] = 0.f;
+}
+
 // ---------------------------------------------------------------------------------------------
 // plan: cosine attention + segment softmax (agno.py:112-146,218-224).  One thread per query.
 // ---------------------------------------------------------------------------------------------
@@ -242,46 +295,74 @@ __global__ void geo_stats_raw_kernel(const float* __restrict__ geom, const float
     o[0] = (float)n; o[1] = (float)mean; o[2] = (float)var;
     for (int d = 0; d < DIM; ++d) { o[3 + d] = (float)(cen[d] - x[d]); o[3 + DIM + d] = (float)ev[d]; }
 }
-// column sums (pass 0: sum x -> acc[f]; pass 1: sum (x-mean)^2 -> acc[F+f]) in fp64 via block reduce (launched with ONE workgroup per group: see
-// gaot_geo_stats; the atomicAdd then has a single contributor).
-// Rows come in `groups` equal groups of Q rows (vx mode: one group per sample of the block-diagonal union), each standardised
-// on its own (gemb.py:164-169 runs per sample there): blockIdx.y = group, acc = [group][2 * F].
+// column statistics, deterministic and parallel: pass 0 = sum x, pass 1 = sum (x - mean)^2, every workgroup writes ITS fp64 partial sums to
+// part[group][pass][block][f] (no atomics); whoever needs a total adds the partials in block order.  Rows come in `groups` equal groups of Q
+// rows (vx mode: one group per sample of the block-diagonal union), each standardised on its own (gemb.py:164-169 runs per sample there):
+// blockIdx.y = group.  GEO_NB_MAX workgroups per group at most (the scratch is sized for that).
+#define GEO_NB_MAX 16
+#define GEO_F_MAX 9
 __global__ __launch_bounds__(256) void geo_colstat_kernel(const float* __restrict__ raw, int Q, int F, int pass,
-                                                          double* __restrict__ acc_all, const int* __restrict__ guard) {
-    __shared__ double red[4];
+                                                          double* __restrict__ part_all, const int* __restrict__ guard) {
+    __shared__ double red[4][GEO_F_MAX];
     if (guard && *guard == 0) return;
+    const int nb = gridDim.x;
     raw += (long)blockIdx.y * Q * F;
-    double* acc = acc_all + (long)blockIdx.y * 2 * F;
-    for (int f = 0; f < F; ++f) {
-        const double mean = pass ? acc[f] / Q : 0.0;
-        double s = 0.0;
-        for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < Q; q += gridDim.x * blockDim.x) {
-            const double v = raw[(long)q * F + f];
-            s += pass ? (v - mean) * (v - mean) : v;
+    double* part = part_all + (long)blockIdx.y * 2 * GEO_NB_MAX * F;
+    double mean[GEO_F_MAX], s[GEO_F_MAX];
+    for (int f = 0; f < GEO_F_MAX; ++f) { mean[f] = 0.0; s[f] = 0.0; }
+    if (pass) {
+        for (int f = 0; f < F; ++f) {
+            double t = 0.0;
+            for (int b = 0; b < nb; ++b) t += part[(long)b * F + f];
+            mean[f] = t / Q;
         }
-        s = wave_sum_d(s);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-        __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(&acc[pass * F + f], red[0] + red[1] + red[2] + red[3]);
-        __syncthreads();
+    }
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < Q; q += nb * 256) {
+#pragma unroll
+        for (int f = 0; f < GEO_F_MAX; ++f) {
+            if (f < F) {
+                const double v = raw[(long)q * F + f];
+                s[f] += pass ? (v - mean[f]) * (v - mean[f]) : v;
+            }
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < GEO_F_MAX; ++f) {
+        if (f < F) {
+            const double w = wave_sum_d(s[f]);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][f] = w;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < F) {
+        const int f = threadIdx.x;
+        part[((long)pass * GEO_NB_MAX + blockIdx.x) * F + f] = (red[0][f] + red[1][f]) + (red[2][f] + red[3][f]);
     }
 }
-__global__ void zero_f64_kernel(double* p, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = 0.0;
+// fin[group][0][f] = mean, fin[group][1][f] = the divisor (torch.std: unbiased; cast to fp32 before the 1e-6 test like the reference's
+// fp32 tensor, gemb.py:165-166)
+__global__ void geo_colstat_final_kernel(const double* __restrict__ part_all, double* __restrict__ fin_all, int Q, int F, int nb,
+                                         const int* __restrict__ guard) {
+    if (guard && *guard == 0) return;
+    const int f = threadIdx.x;
+    if (f >= F) return;
+    const double* part = part_all + (long)blockIdx.x * 2 * GEO_NB_MAX * F;
+    double m = 0.0, v = 0.0;
+    for (int b = 0; b < nb; ++b) m += part[(long)b * F + f];
+    for (int b = 0; b < nb; ++b) v += part[((long)GEO_NB_MAX + b) * F + f];
+    float sd = (float)sqrt(v / (double)(Q - 1));
+    if (sd < 1e-6f) sd = 1.0f;
+    fin_all[(long)blockIdx.x * 2 * F + f] = m / Q;
+    fin_all[(long)blockIdx.x * 2 * F + F + f] = (double)sd;
 }
-__global__ void geo_standardise_kernel(float* __restrict__ raw, int Q, int F, const double* __restrict__ acc_all,
+__global__ void geo_standardise_kernel(float* __restrict__ raw, int Q, int F, const double* __restrict__ fin_all,
                                        const int* __restrict__ guard, int groups) {
     if (guard && *guard == 0) return;
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long)groups * Q * F) return;
     const int f = (int)(gid % F);
-    const double* acc = acc_all + (gid / ((long)Q * F)) * 2 * F;
-    const double mean = acc[f] / Q;
-    // torch.std: unbiased; cast to fp32 before the 1e-6 test like the reference's fp32 tensor (gemb.py:165-166)
-    float sd = (float)sqrt(acc[F + f] / (double)(Q - 1));
-    if (sd < 1e-6f) sd = 1.0f;
-    raw[gid] = (float)(((double)raw[gid] - mean) / (double)sd);
+    const double* fin = fin_all + (gid / ((long)Q * F)) * 2 * F;
+    raw[gid] = (float)(((double)raw[gid] - fin[f]) / fin[F + f]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -503,15 +584,17 @@ extern "C" int gaot_geo_stats(const float* geom, const float* qry, int32_t dim, 
         hipLaunchKernelGGL(geo_stats_raw_kernel<2>, dim3(cdiv(Q, 128)), dim3(128), 0, ST(stream), geom, qry, index32, splits32, Q, stats, guard);
     else
         hipLaunchKernelGGL(geo_stats_raw_kernel<3>, dim3(cdiv(Q, 128)), dim3(128), 0, ST(stream), geom, qry, index32, splits32, Q, stats, guard);
-    hipLaunchKernelGGL(zero_f64_kernel, dim3(cdiv(2 * F * groups, 64)), dim3(64), 0, ST(stream), scratch, 2 * F * groups);
-    // ONE workgroup per group: the column sums are then formed in a fixed order.  (With several workgroups per group their fp64 partial sums met
-    // in an atomicAdd in arrival order, and once in a while a standardised statistic came out one fp32 ulp different from run to run and box to
-    // box -- enough for two trainings from the same seed to end ~1e-2 apart in loss after 100 steps, tools/det_batch.py.  Once per geometry:
-    // 16 384 rows x 7 columns take ~20 us this way.)
-    const int nb = 1;
+    // Column sums in a FIXED order, whatever the number of workgroups: every workgroup writes its fp64 partial sums, the consumers add them in
+    // block order.  (Partial sums that met in an atomicAdd in arrival order made a standardised statistic come out one fp32 ulp different from
+    // run to run once in a while -- enough for two trainings from the same seed to end ~1e-2 apart in loss after 100 steps, tools/det_batch.py;
+    // ONE workgroup per group, the first cure, is serial over 1e5..1e6 query rows and runs every step for the unions of a vx batch.)
+    double* fin = scratch + (long)groups * 2 * GEO_NB_MAX * F;
+    int nb = cdiv(Qg, 2048);
+    nb = nb < 1 ? 1 : (nb > GEO_NB_MAX ? GEO_NB_MAX : nb);
     hipLaunchKernelGGL(geo_colstat_kernel, dim3(nb, groups), dim3(256), 0, ST(stream), stats, Qg, F, 0, scratch, guard);
     hipLaunchKernelGGL(geo_colstat_kernel, dim3(nb, groups), dim3(256), 0, ST(stream), stats, Qg, F, 1, scratch, guard);
-    hipLaunchKernelGGL(geo_standardise_kernel, dim3(cdiv((long)Q * F, 256)), dim3(256), 0, ST(stream), stats, Qg, F, scratch, guard, groups);
+    hipLaunchKernelGGL(geo_colstat_final_kernel, dim3(groups), dim3(64), 0, ST(stream), scratch, fin, Qg, F, nb, guard);
+    hipLaunchKernelGGL(geo_standardise_kernel, dim3(cdiv((long)Q * F, 256)), dim3(256), 0, ST(stream), stats, Qg, F, fin, guard, groups);
     GAOT_CHECK_LAUNCH("gaot_geo_stats");
     return GAOT_OK;
 }
@@ -537,6 +620,44 @@ extern "C" int gaot_concat_offset(const int32_t* const* parts, const int32_t* le
         done += total;
     }
     GAOT_CHECK_LAUNCH("gaot_concat_offset");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_union_compose(const gaot_union_part* parts_dev, int32_t n_parts, int32_t q_each, int32_t n_src_each, int32_t dim_src,
+                                  int32_t dim_dst, int32_t e_cap, int32_t* index32, int32_t* edge_query, int32_t* t_edge, int32_t* splits32,
+                                  int32_t* t_splits, float* src, float* dst, int32_t* e_real, gaot_stream_t stream) {
+    GAOT_REQUIRE(parts_dev && n_parts >= 1 && n_parts <= 1024 && q_each > 0 && n_src_each > 0 && e_cap >= 1 && dim_src >= 0 && dim_dst >= 0,
+                 "union_compose: bad sizes (1 <= n_parts <= 1024, q_each, n_src_each, e_cap > 0)");
+    GAOT_REQUIRE(index32 && edge_query && t_edge && splits32 && t_splits && e_real, "union_compose: null output pointer");
+    long n = e_cap;
+    const long Qt = (long)n_parts * q_each, St = (long)n_parts * n_src_each;
+    if (Qt + 1 > n) n = Qt + 1;
+    if (St + 1 > n) n = St + 1;
+    if (src && St * dim_src > n) n = St * dim_src;
+    if (dst && Qt * dim_dst > n) n = Qt * dim_dst;
+    hipLaunchKernelGGL(union_compose_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ST(stream), parts_dev, n_parts, q_each, n_src_each, dim_src,
+                       dim_dst, e_cap, index32, edge_query, t_edge, splits32, t_splits, src, dst, e_real);
+    GAOT_CHECK_LAUNCH("gaot_union_compose");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_edge_inv_degree(const int32_t* splits32, const int32_t* edge_query, int32_t E, const int32_t* e_real, float* out,
+                                    gaot_stream_t stream) {
+    GAOT_REQUIRE(E >= 0, "edge_inv_degree: negative size");
+    if (E == 0) return GAOT_OK;
+    GAOT_REQUIRE(splits32 && edge_query && out, "edge_inv_degree: null pointer");
+    hipLaunchKernelGGL(edge_inv_degree_kernel, dim3(cdiv(E, 256)), dim3(256), 0, ST(stream), splits32, edge_query, E, e_real, out);
+    GAOT_CHECK_LAUNCH("gaot_edge_inv_degree");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_edge_zero_pads(float* a, int32_t B, int32_t E, int32_t width, const int32_t* e_real, int32_t max_pads, gaot_stream_t stream) {
+    GAOT_REQUIRE(B >= 1 && E >= 0 && width >= 1 && max_pads >= 0, "edge_zero_pads: bad sizes");
+    if (E == 0 || max_pads == 0) return GAOT_OK;
+    GAOT_REQUIRE(a && e_real, "edge_zero_pads: null pointer");
+    if (max_pads > E) max_pads = E;
+    hipLaunchKernelGGL(edge_zero_pads_kernel, dim3(cdiv((long)max_pads * width, 256), B), dim3(256), 0, ST(stream), a, B, E, width, e_real);
+    GAOT_CHECK_LAUNCH("gaot_edge_zero_pads");
     return GAOT_OK;
 }
 

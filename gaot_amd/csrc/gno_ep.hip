@@ -25,7 +25,8 @@ __global__ __launch_bounds__(256) void lift_ep_kernel(const float* __restrict__ 
                                                       const float* __restrict__ bl, int B, int n_src, int C, const int* __restrict__ sp,
                                                       const int* __restrict__ cols, const int* __restrict__ eq, int Q, int E,
                                                       const float* __restrict__ escale, float* __restrict__ out, float* __restrict__ ws,
-                                                      int lanes, int epc, int abl) {
+                                                      int lanes, int epc, int abl, const int* __restrict__ e_real) {
+    if (e_real) E = min(E, *e_real);          // a padded union (plan.StaticUnion): the launch is sized for the capacity, the list ends earlier
     const int groups_per_block = 256 / lanes;
     const int g = blockIdx.x * groups_per_block + threadIdx.x / lanes;
     const int c = (threadIdx.x % lanes) * 4;
@@ -118,7 +119,8 @@ __global__ __launch_bounds__(256) void proj_t_ep_kernel(const float* __restrict_
                                                         int B, int Q, int C, const int* __restrict__ tsp, const int* __restrict__ tedge,
                                                         const int* __restrict__ idx, const int* __restrict__ eq, int n_src, int E,
                                                         const float* __restrict__ escale, float* __restrict__ df, float* __restrict__ ws,
-                                                        int lanes, int epc) {
+                                                        int lanes, int epc, const int* __restrict__ e_real) {
+    if (e_real) E = min(E, *e_real);
     const int groups_per_block = 256 / lanes;
     const int g = blockIdx.x * groups_per_block + threadIdx.x / lanes;
     const int c = (threadIdx.x % lanes) * 4;
@@ -261,7 +263,8 @@ extern "C" int64_t gaot_gno_ep_workspace(int32_t E, int32_t C, int32_t B) {
 
 extern "C" int gaot_gno_lift_gather_reduce_ep(const float* k, const float* pn, const float* wl, const float* bl, int32_t B, int32_t n_src,
                                               int32_t c_in, int32_t C, const int32_t* splits, const int32_t* cols, const int32_t* edge_query,
-                                              int32_t Q, int32_t E, const float* escale, float* out, float* ws, gaot_stream_t stream) {
+                                              int32_t Q, int32_t E, const float* escale, float* out, float* ws, const int32_t* e_real,
+                                              gaot_stream_t stream) {
     GAOT_REQUIRE(B > 0 && n_src > 0 && Q >= 0 && E >= 0 && c_in >= 1 && c_in <= 4 && C > 0 && C % 4 == 0 && C <= 256,
                  "gno_lift_gather_reduce_ep: need 1 <= c_in <= 4, C %% 4 == 0, C <= 256 (got c_in %d, C %d)", c_in, C);
     if (Q == 0) return GAOT_OK;
@@ -274,9 +277,9 @@ extern "C" int gaot_gno_lift_gather_reduce_ep(const float* k, const float* pn, c
         const int BCH = B == 1 ? 1 : 2;
         dim3 grid(cdiv(cdiv(E, epc), gpb), cdiv(B, BCH)), block(256);
 #define LG(CI) do { if (B == 1) hipLaunchKernelGGL((lift_ep_kernel<CI, 1, 8>), grid, block, 0, ST(stream), k, pn, wl, bl, B, n_src, C, splits, cols, edge_query, Q, E, \
-                                  escale, out, ws, lanes, epc, ep_abl()); \
+                                  escale, out, ws, lanes, epc, ep_abl(), e_real); \
                     else hipLaunchKernelGGL((lift_ep_kernel<CI, 2, 4>), grid, block, 0, ST(stream), k, pn, wl, bl, B, n_src, C, splits, cols, edge_query, Q, E, \
-                                  escale, out, ws, lanes, epc, ep_abl()); } while (0)
+                                  escale, out, ws, lanes, epc, ep_abl(), e_real); } while (0)
         if (c_in == 1) LG(1); else if (c_in == 2) LG(2); else if (c_in == 3) LG(3); else LG(4);
 #undef LG
     }
@@ -288,7 +291,7 @@ extern "C" int gaot_gno_lift_gather_reduce_ep(const float* k, const float* pn, c
 extern "C" int gaot_gno_proj_gather_t_ep(const float* k, const float* dy, const float* weff, int32_t B, int32_t Q, int32_t n_src, int32_t C,
                                          int32_t out_channels, const int32_t* index32, const int32_t* edge_query, int32_t E,
                                          const int32_t* t_splits, const int32_t* t_edge, const float* escale, float* df, float* ws,
-                                         gaot_stream_t stream) {
+                                         const int32_t* e_real, gaot_stream_t stream) {
     GAOT_REQUIRE(B > 0 && out_channels >= 1 && out_channels <= 4 && C > 0 && C % 4 == 0 && C <= 256 && n_src > 0 && E >= 0,
                  "gno_proj_gather_t_ep: need 1 <= out_channels <= 4, C %% 4 == 0, C <= 256");
     GAOT_REQUIRE(k && dy && weff && t_splits && df && ws && aligned16(k) && aligned16(weff) && aligned16(df) && aligned16(ws) &&
@@ -298,7 +301,7 @@ extern "C" int gaot_gno_proj_gather_t_ep(const float* k, const float* dy, const 
     if (E > 0) {
         dim3 grid(cdiv(cdiv(E, epc), gpb), cdiv(B, BCH)), block(256);
 #define PT(OC) hipLaunchKernelGGL((proj_t_ep_kernel<OC, BCH>), grid, block, 0, ST(stream), k, dy, weff, B, Q, C, t_splits, t_edge, index32, edge_query, \
-                                  n_src, E, escale, df, ws, lanes, epc)
+                                  n_src, E, escale, df, ws, lanes, epc, e_real)
         if (out_channels == 1) PT(1); else if (out_channels == 2) PT(2); else if (out_channels == 3) PT(3); else PT(4);
 #undef PT
     }

@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
+from ... import plan as _plan
 from ...plan import merged_geometry
 from .agno import AGNO
 from .gemb import GeometricEmbedding, node_pos_encode
@@ -72,6 +73,8 @@ class _MAGNOBase(nn.Module):
         self.neighbor_cache = {}
         self._coord_enc_cache = {}
         self._infer_cache = {}       # no_grad only: geoembed row-bias per (plan, parameter versions) -- rollouts reuse it
+        self._static_unions = {}     # vx training: padded unions in static buffers per (scale, batch shape, edge bucket) -- plan.StaticUnion
+        self._vx_preloaded = None    # (unions, neighbour list object): tables already uploaded for the next forward (trainer.TrainStep, autograph)
         self.sampling_strategy = config.sampling_strategy
         self.max_neighbors = config.max_neighbors
         self.sample_ratio = config.sample_ratio
@@ -116,6 +119,39 @@ class _MAGNOBase(nn.Module):
                                     radius=self.config.radius * s) for s in self.scales] for b in range(B)]
         self.neighbor_cache[key] = nbrs
         return nbrs
+
+    # ---- vx training on static padded unions (plan.StaticUnion): the batch composition may change every step, the launches do not
+    MAX_STATIC_UNIONS = 12
+
+    def vx_static_ok(self, feats: torch.Tensor) -> bool:
+        """training passes over caller-supplied per-sample graphs (static_trainer.py:180-202) without neighbour sub-sampling or encoded kernel
+        coordinates; everything else (evaluation, rollouts, module-owned lists) keeps the composed unions of plan.merged_geometry"""
+        return (_plan.VX_STATIC and feats.is_cuda and torch.is_grad_enabled() and self.training and bool(self.precompute_edges)
+                and self.sampling_strategy is None and not self.node_embedding)
+
+    def vx_unions(self, nbrs, src: torch.Tensor, dst: torch.Tensor, B: int, load: bool = True):
+        """the static union of every scale for this batch, its table uploaded (not capturable).  src / dst: [B, n, d] or [n, d] coordinates.
+        load=False: only find (or make) the unions; `union.load_pending(src, dst)` uploads the tables later."""
+        if not isinstance(nbrs, (list, tuple)) or len(nbrs) != B:
+            raise ValueError(f"vx mode: expected {B} per-sample neighbour lists")
+        n_src, n_dst = int(src.shape[-2]), int(dst.shape[-2])
+        src, dst = src.contiguous(), dst.contiguous()
+        out = []
+        for si in range(len(self.scales)):
+            plans = [_plan.plan_for(nbrs[b][si], n_src, validate="lazy") for b in range(B)]
+            key = (si, B, n_src, n_dst, int(src.shape[-1]), int(dst.shape[-1]), _plan.edge_bucket(sum(p.E for p in plans)), src.device)
+            su = self._static_unions.pop(key, None)
+            if su is None:
+                while len(self._static_unions) >= self.MAX_STATIC_UNIONS:        # least recently used; graphs that captured it keep their reference
+                    self._static_unions.pop(next(iter(self._static_unions)))
+                su = _plan.StaticUnion(B, n_src, n_dst, key[4], key[5], key[6], src.device)
+            self._static_unions[key] = su
+            if load:
+                su.load(plans, src, dst)
+            else:
+                su.pending = plans
+            out.append(su)
+        return out
 
     def _kcoord(self, c: torch.Tensor) -> torch.Tensor:
         """kernel coordinates: raw or node_pos_encode()d (cached per tensor identity: geometry only)."""
@@ -204,6 +240,22 @@ class _MAGNOBase(nn.Module):
                 if lift is not None:
                     feats = lift[0]
                 B = feats.shape[0]
+                if self.vx_static_ok(feats):
+                    if si == 0:
+                        pre, self._vx_preloaded = self._vx_preloaded, None
+                        unions = pre[0] if (pre is not None and pre[1] is nbrs) else self.vx_unions(nbrs, src, dst, B)
+                    mg = unions[si]
+                    if mg.n_src != feats.shape[1]:
+                        raise ValueError("vx mode needs the same number of source / query points in every sample of a batch")
+                    mg.refresh()
+                    stats = mg.geo_stats() if (self.use_geoembed and self.geoembed.method == 'statistical') else None
+                    flat = feats.reshape(1, B * feats.shape[1], feats.shape[2])
+                    if lift is not None:
+                        out = self._transform(mg.src, mg.dst, None, mg.neighbors, stats, head=head, lift=(flat, lift[1], lift[2]), drop=False)
+                    else:
+                        out = self._transform(mg.src, mg.dst, flat, mg.neighbors, stats, head=head, drop=False)
+                    per_scale.append(out.reshape(B, mg.n_dst, out.shape[-1]))
+                    continue
                 srcs = [src[b] if src.ndim == 3 else src for b in range(B)]
                 dsts = [dst[b] if dst.ndim == 3 else dst for b in range(B)]
                 parts = [nbrs[b][si] for b in range(B)]

@@ -1655,7 +1655,7 @@ class _GNOLiftTransform(torch.autograd.Function):
             # degree-skewed rows: edge-partitioned kernel with segmented reductions (csrc/gno_ep.hip)
             ws = torch.empty(int(lib.gaot_gno_ep_workspace(plan.E, Cc, B)), device=k.device, dtype=torch.float32)
             L.check(lib.gaot_gno_lift_gather_reduce_ep(_p(k), _p(pn), _p(w2), _p(bl), B, n_src, ci, Cc, _p(plan.splits), _p(plan.index),
-                                                       _p(plan.edge_query), plan.Q, plan.E, _p(escale), _p(out), _p(ws), _stream()),
+                                                       _p(plan.edge_query), plan.Q, plan.E, _p(escale), _p(out), _p(ws), _p(plan.e_dev), _stream()),
                     "gaot_gno_lift_gather_reduce_ep")
         else:
             ow = _want_word(k.device)
@@ -1759,7 +1759,7 @@ class _GNOProjTransform(torch.autograd.Function):
                 ws = torch.empty(int(lib.gaot_gno_ep_workspace(plan.E, Cc, B)), device=k.device, dtype=torch.float32)
                 L.check(lib.gaot_gno_proj_gather_t_ep(_p(k), _p(dy), _p(weff), B, plan.Q, n_src, Cc, OC, _p(plan.index), _p(plan.edge_query),
                                                       plan.E, _p(plan.t_splits), _p(plan.t_edge), _p(esc) if has_e else None, _p(df), _p(ws),
-                                                      _stream()), "gaot_gno_proj_gather_t_ep")
+                                                      _p(plan.e_dev), _stream()), "gaot_gno_proj_gather_t_ep")
             dweff = colsum(part).reshape(OC, Cc)
         if rb_shape is not None and need[3]:
             drowb = batchsum(dy.reshape(B, -1), B).reshape(rb_shape)
@@ -1822,7 +1822,18 @@ class _SegmentSum(torch.autograd.Function):
         dx = torch.empty(B, ctx.E, Cc, device=dout.device, dtype=torch.float32)
         L.check(L.load().gaot_segment_broadcast(_p(dout), B, ctx.E, Cc, plan.Q, _p(plan.edge_query), _p(ctx.rowscale), _p(dx), _stream()),
                 "gaot_segment_broadcast")
+        zero_pad_rows(dx, plan)
         return dx, None, None
+
+
+def zero_pad_rows(x, plan):
+    """x [.., E, C] per-edge rows of a padded union (plan.StaticUnion): the rows past the union's real edge count are set to zero, so a
+    reduction over all E rows (the weight gradients of an MLP over the edge rows) sees exact zeros there.  No-op for ordinary plans."""
+    if plan.e_dev is None or x.numel() == 0:
+        return x
+    E, Cc = x.shape[-2], x.shape[-1]
+    L.check(L.load().gaot_edge_zero_pads(_p(x), x.numel() // (E * Cc), E, Cc, _p(plan.e_dev), E, _stream()), "gaot_edge_zero_pads")
+    return x
 
 
 def segment_sum(x, plan, rowscale=None):
@@ -1875,6 +1886,7 @@ class _SegmentMax(torch.autograd.Function):
     def backward(ctx, dout):
         h, out = ctx.saved_tensors
         dh = torch.empty_like(h)
+        zero_pad_rows(dh, ctx.plan)           # (the kernel below writes the rows' edges only)
         L.check(L.load().gaot_segment_max_bwd(_p(h), _p(out), _p(dout.contiguous()), h.shape[1], _p(ctx.plan.splits), ctx.plan.Q, _p(dh),
                                               _stream()), "gaot_segment_max_bwd")
         return dh, None

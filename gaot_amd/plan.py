@@ -7,9 +7,12 @@ gemb.py:103-171); here they are device arrays built once per neighbour list and 
   input rows, the cosine attention weights and the standardised geometry statistics.
 """
 import ctypes as C
-from typing import Dict, Optional, Tuple
+import itertools
+from collections import OrderedDict
+from typing import Dict, List, Optional, Tuple
 
 import os
+import numpy as np
 import torch
 
 from . import _lib as L
@@ -19,6 +22,7 @@ _PLAN_KEY = "_gaot_amd_plan"
 
 
 _PENDING: list = []          # (device flag, event) of plans built with validate="lazy"
+GEO_SCRATCH = 34             # doubles per (group, statistic) of gaot_geo_stats' scratch (include/gaot_hip.h)
 FORCE_GUARD = [None]         # set by autograph.py while it captures: a device flag that guards re-computation inside the graph
 
 
@@ -38,6 +42,8 @@ def _check_pending(block: bool = False):
 
 
 class GeometryPlan:
+    e_dev: Optional[torch.Tensor] = None      # padded unions only (StaticUnion): device scalar = the number of edges actually in the list (<= E)
+
     def __init__(self, index_i64: torch.Tensor, splits_i64: torch.Tensor, n_src: int, validate=True):
         if index_i64 is None:          # assembled by GeometryPlan.compose()
             return
@@ -90,6 +96,13 @@ class GeometryPlan:
         self.epoch = 0                # bumped whenever a coordinate-derived array may have been refreshed in place
 
     SKEW_DEGREE = 48      # rows longer than this (or unknown) go to the edge-partitioned kernels
+
+    def part_pointers(self):
+        """(index, edge_query, t_edge, splits, t_splits) device addresses: this plan as one gaot_union_part of a StaticUnion's table"""
+        pp = getattr(self, "_part_ptrs", None)
+        if pp is None:
+            pp = self._part_ptrs = (self.index.data_ptr(), self.edge_query.data_ptr(), self.t_edge.data_ptr(), self.splits.data_ptr(), self.t_splits.data_ptr())
+        return pp
 
     @property
     def rows_skewed(self) -> bool:
@@ -216,7 +229,7 @@ class GeometryPlan:
         def alloc(ts):
             F = 3 + 2 * ts[0].shape[1]
             stats = torch.empty(self.Q, F, device=ts[0].device, dtype=torch.float32)
-            return (stats, torch.empty(2 * F * groups, device=ts[0].device, dtype=torch.float64)), stats
+            return (stats, torch.empty(GEO_SCRATCH * F * groups, device=ts[0].device, dtype=torch.float64)), stats
 
         def compute(full, ts, guard):
             stats, scratch = full
@@ -225,14 +238,14 @@ class GeometryPlan:
         return self._cached(f"stats{groups}", (geom, qry), alloc, compute)
 
 
-def plan_for(neighbors: dict, n_src: int) -> GeometryPlan:
-    """Plan attached to (and cached on) a reference-style neighbour dict."""
+def plan_for(neighbors: dict, n_src: int, validate=True) -> GeometryPlan:
+    """Plan attached to (and cached on) a reference-style neighbour dict.  `validate`: as GeometryPlan (used when the plan is built)."""
     plan = neighbors.get(_PLAN_KEY)
     if plan is not None and plan._src_id is None:          # the union of a MergedGeometry: owned by it, nothing to re-derive
         return plan
     idx = neighbors["neighbors_index"]
     if plan is None or plan._src_id != (id(idx), idx._version) or plan.n_src != n_src:
-        plan = GeometryPlan(idx, neighbors["neighbors_row_splits"], n_src)
+        plan = GeometryPlan(idx, neighbors["neighbors_row_splits"], n_src, validate=validate)
         plan._src_id = (id(idx), idx._version)
         neighbors[_PLAN_KEY] = plan
     return plan
@@ -366,12 +379,206 @@ def merged_geometry(nbr_dicts, src_coords, dst_coords, parents=()) -> MergedGeom
         # the NACA configuration: one ~120 MB hipMalloc every third step at ~75 ms each -- 8 ms steps became 40 ms on average,
         # tools/vx_shuffle_profile.py).  Keeping only the few most recently used lets the allocator hand the evicted union's blocks to the
         # next one; loaders that cycle through a handful of fixed batches still hit.
-        while len(_MERGE_CACHE) >= _MERGE_CACHE_MAX:
-            _MERGE_CACHE.pop(next(iter(_MERGE_CACHE)))[0].release()
+        # (a union a captured graph reads by raw pointer is pinned: never evicted, never released)
+        for k in [k for k, v in _MERGE_CACHE.items() if not getattr(v[0], "pinned", False)][:max(0, len(_MERGE_CACHE) - _MERGE_CACHE_MAX + 1)]:
+            _MERGE_CACHE.pop(k)[0].release()
         # a dict seen before (it carries a marker) is worth a plan of its own: the next batch that contains it composes
         seen = all(n.get("_gaot_amd_seen") for n in nbr_dicts)
         for n in nbr_dicts:
             n["_gaot_amd_seen"] = True
         hit = (MergedGeometry(nbr_dicts, src_coords, dst_coords, build_parts=seen), tuple(parents), list(nbr_dicts))   # hold refs: ids stay unique
     _MERGE_CACHE[key] = hit
+    if torch.cuda.is_current_stream_capturing():
+        hit[0].pinned = True          # the graph being captured holds this union's arrays by address (a rollout's per-step forward)
     return hit[0]
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Static padded unions: vx TRAINING at hipGraph-replay speed while the batch composition changes every step
+# ------------------------------------------------------------------------------------------------------------------------------
+VX_STATIC = os.environ.get("GAOT_VX_STATIC", "1") != "0"       # 0: the training path composes a fresh union per batch composition (rounds 3-5)
+_UNION_SERIAL = itertools.count(1)
+
+
+def edge_bucket(E: int) -> int:
+    """edge capacity of the static union that serves a batch of E edges: E rounded up to 5 significant bits (steps of 3-6 %: a shuffling loader
+    over one dataset lands in a handful of buckets, each with its own buffers and captured graphs; the pads cost the per-edge kernels that share)"""
+    E = max(int(E), 1024)
+    sh = max(E.bit_length() - 5, 0)
+    return ((E + (1 << sh) - 1) >> sh) << sh
+
+
+class _StaticPlan(GeometryPlan):
+    """The plan of a StaticUnion: every array is a static buffer, (re)computed by StaticUnion.refresh() -- launches a captured step replays."""
+
+    def __init__(self, union: "StaticUnion"):
+        super().__init__(None, None, 0)
+        u = union
+        dev = u.device
+        self.Q, self.E, self.n_src = u.B * u.n_dst, u.e_cap, u.B * u.n_src
+        self.index = torch.zeros(self.E, dtype=torch.int32, device=dev)
+        self.edge_query = torch.zeros(self.E, dtype=torch.int32, device=dev)
+        self.t_edge = torch.zeros(self.E, dtype=torch.int32, device=dev)
+        self.splits = torch.zeros(self.Q + 1, dtype=torch.int32, device=dev)
+        self.t_splits = torch.zeros(self.n_src + 1, dtype=torch.int32, device=dev)
+        self.e_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.max_deg = self.max_t_deg = None          # unknown on the host: the edge-partitioned kernels serve any degree distribution
+        self._src_id = None
+        self._coord_cache, self._groups, self.epoch = {}, {}, 0
+        self._union = union
+        self._arrays: "OrderedDict[str, tuple]" = OrderedDict()      # name -> (value, compute): recomputed by every refresh, in this order
+
+    def _static(self, name, alloc, compute):
+        ent = self._arrays.get(name)
+        if ent is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError(f"gaot_amd: array {name!r} of a static union requested for the first time inside a graph capture "
+                                   "(the warm-up passes must run the same model path)")
+            ent = (alloc(), compute)
+            self._arrays[name] = ent
+            compute(ent[0])
+        return ent[0]
+
+    def refresh_derived(self):
+        for val, compute in self._arrays.values():
+            compute(val)
+
+    def _own(self, src, qry):
+        u = self._union
+        if src.data_ptr() != u.src.data_ptr() or qry.data_ptr() != u.dst.data_ptr():
+            raise RuntimeError("gaot_amd: a static union computes its geometry arrays from its own stacked coordinates only")
+        return u.src, u.dst
+
+    # ---- overrides: no identity-keyed caches, no host-side sizes
+    row_order = None
+
+    @property
+    def deg(self):
+        return self._static("deg", lambda: torch.zeros(self.Q, dtype=torch.int64, device=self.splits.device),
+                            lambda v: v.copy_(self.splits[1:] - self.splits[:-1]))
+
+    @property
+    def edge_query_long(self):
+        return self._static("eq64", lambda: torch.zeros(self.E, dtype=torch.int64, device=self.splits.device), lambda v: v.copy_(self.edge_query))
+
+    @property
+    def index_long(self):
+        return self._static("idx64", lambda: torch.zeros(self.E, dtype=torch.int64, device=self.splits.device), lambda v: v.copy_(self.index))
+
+    @property
+    def inv_deg_edge(self):
+        def compute(v):
+            L.check(L.load().gaot_edge_inv_degree(_p(self.splits), _p(self.edge_query), self.E, _p(self.e_dev), _p(v), _stream()), "gaot_edge_inv_degree")
+        return self._static("inv_deg", lambda: torch.zeros(self.E, dtype=torch.float32, device=self.splits.device), compute)
+
+    def edge_features(self, src, qry):
+        s, q = self._own(src, qry)
+
+        def compute(feat):
+            L.check(L.load().gaot_edge_features(_p(s), _p(q), s.shape[1], _p(self.index), _p(self.edge_query), self.E, _p(feat), None, _stream()),
+                    "gaot_edge_features")
+        return self._static("feat", lambda: torch.zeros(self.E, 2 * s.shape[1], device=s.device, dtype=torch.float32), compute)
+
+    def cosine_attention(self, src, qry):
+        s, q = self._own(src, qry)
+
+        def compute(attn):
+            lib = L.load()
+            L.check(lib.gaot_edge_attention_cosine(_p(s), _p(q), s.shape[1], _p(self.index), _p(self.splits), self.Q, _p(attn), None, _stream()),
+                    "gaot_edge_attention_cosine")
+            L.check(lib.gaot_edge_zero_pads(_p(attn), 1, self.E, 1, _p(self.e_dev), self.E, _stream()), "gaot_edge_zero_pads")
+        return self._static("cos", lambda: torch.zeros(self.E, device=s.device, dtype=torch.float32), compute)
+
+    def geo_stats(self, geom, qry, groups: int = 1):
+        s, q = self._own(geom, qry)
+        F = 3 + 2 * s.shape[1]
+
+        def alloc():
+            return (torch.zeros(self.Q, F, device=s.device, dtype=torch.float32), torch.zeros(GEO_SCRATCH * F * groups, device=s.device, dtype=torch.float64))
+
+        def compute(full):
+            L.check(L.load().gaot_geo_stats(_p(s), _p(q), s.shape[1], _p(self.index), _p(self.splits), self.Q, _p(full[0]), _p(full[1]), None, groups,
+                                            _stream()), "gaot_geo_stats")
+        return self._static(f"stats{groups}", alloc, compute)[0]
+
+
+class StaticUnion:
+    """Block-diagonal union of a vx batch in STATIC buffers padded to an edge capacity (`edge_bucket`), composed on the device from a small table
+    of per-sample plan pointers (csrc/gno.hip union_compose_kernel).  What changes from step to step under a shuffling loader (the reference's
+    default: data_utils.py:272-294, static_trainer.py:180-202) is only that table -- uploaded by `load()` from pinned memory, outside any graph --
+    while `refresh()` (compose + the geometry-derived arrays: kernel-MLP rows, cosine weights, per-sample standardised statistics) is a fixed
+    sequence of launches over fixed addresses: a captured training step begins with it and replays for ANY batch composition of the bucket.
+
+    Edges past the real count are pads: no CSR row references them, the edge-partitioned kernels stop at the device-side count (`plan.e_dev`), the
+    flat per-edge kernels (kernel MLP, edge gradients) do walk them and get an edge scale of exactly 0, so they add exact zeros."""
+
+    RING = 8          # pinned staging slots of the table: a slot is reused only after the copy that read it has completed
+
+    def __init__(self, B: int, n_src: int, n_dst: int, dim_src: int, dim_dst: int, e_cap: int, device):
+        self.uid = next(_UNION_SERIAL)
+        self.B, self.n_src, self.n_dst, self.e_cap, self.device = B, n_src, n_dst, int(e_cap), device
+        self.n_src_each, self.n_dst_each = [n_src] * B, [n_dst] * B
+        self.src = torch.zeros(B * n_src, dim_src, device=device, dtype=torch.float32)
+        self.dst = torch.zeros(B * n_dst, dim_dst, device=device, dtype=torch.float32)
+        self.plan = _StaticPlan(self)
+        self.neighbors = {"neighbors_index": None, "neighbors_row_splits": None, _PLAN_KEY: self.plan}
+        self.table = torch.zeros(B, 8, dtype=torch.int64, device=device)           # B x gaot_union_part (64 bytes each)
+        self._pinned = [torch.zeros(B, 8, dtype=torch.int64).pin_memory() for _ in range(self.RING)]
+        self._views = [t.numpy() for t in self._pinned]
+        self._events: List[Optional[torch.cuda.Event]] = [None] * self.RING
+        self._slot = 0
+        self._hold = None
+        self.pending = None
+        self.e_real = 0           # host copy of the last loaded edge count (diagnostics; the kernels read plan.e_dev)
+
+    def load(self, plans, src_parent: torch.Tensor, dst_parent: torch.Tensor) -> None:
+        """upload the table of this batch: per-sample plan arrays (any order of any samples whose edge counts fit the capacity) and coordinates
+        (`*_parent`: [B, n, d] per-sample or [n, d] shared by all samples, fp32 contiguous).  Not capturable; stream-ordered."""
+        B = self.B
+        if len(plans) != B:
+            raise ValueError(f"static union of {B} samples handed {len(plans)}")
+        counts = np.fromiter((p.E for p in plans), dtype=np.int64, count=B)
+        begins = np.concatenate(([0], np.cumsum(counts)[:-1]))
+        total = int(counts.sum())
+        if total > self.e_cap:
+            raise ValueError(f"batch of {total} edges does not fit the union's capacity {self.e_cap}")
+        for p in plans:
+            if p.Q != self.n_dst or p.n_src != self.n_src:
+                raise ValueError("vx mode needs the same number of source / query points in every sample of a batch")
+        slot = self._slot
+        self._slot = (slot + 1) % self.RING
+        ev = self._events[slot]
+        if ev is not None:
+            ev.synchronize()
+        tab = self._views[slot]
+        tab[:, :5] = [p.part_pointers() for p in plans]
+        for col, parent, n in ((5, src_parent, self.n_src), (6, dst_parent, self.n_dst)):
+            if parent.dtype != torch.float32 or not parent.is_contiguous() or parent.device != self.src.device:
+                raise TypeError("static union: coordinates must be contiguous float32 tensors on the union's device")
+            stride = n * parent.shape[-1] * 4 if parent.dim() == 3 else 0
+            tab[:, col] = parent.data_ptr() + stride * np.arange(B, dtype=np.int64)
+        tab[:, 7] = begins | (counts << 32)
+        self.table.copy_(self._pinned[slot], non_blocking=True)
+        if ev is None:
+            ev = self._events[slot] = torch.cuda.Event()
+        ev.record()
+        self._hold = (list(plans), src_parent, dst_parent)          # the arrays behind the table's pointers live until the next load
+        self.e_real = total
+
+    def load_pending(self, src_parent: torch.Tensor, dst_parent: torch.Tensor) -> None:
+        """load() with the plans a `vx_unions(..., load=False)` call left behind"""
+        plans, self.pending = self.pending, None
+        if plans is None:           # loaded already for this batch (the call that captured an entry replays it at once): the same plans again
+            plans = self._hold[0]
+        self.load(plans, src_parent, dst_parent)
+
+    def refresh(self) -> None:
+        """compose the union from the loaded table and recompute every derived array (capturable: fixed launches, fixed addresses)"""
+        pl = self.plan
+        L.check(L.load().gaot_union_compose(_p(self.table), self.B, self.n_dst, self.n_src, self.src.shape[1], self.dst.shape[1], self.e_cap,
+                                            _p(pl.index), _p(pl.edge_query), _p(pl.t_edge), _p(pl.splits), _p(pl.t_splits), _p(self.src), _p(self.dst),
+                                            _p(pl.e_dev), _stream()), "gaot_union_compose")
+        pl.refresh_derived()
+
+    def geo_stats(self) -> torch.Tensor:
+        return self.plan.geo_stats(self.src, self.dst, groups=self.B)

@@ -346,6 +346,9 @@ class TrainStep:
         self._g_opt: Optional[torch.cuda.CUDAGraph] = None
         self._x = self._y = self._loss = None
         self._kwargs: Dict = {}
+        self._vx = False              # bound to a vx batch whose geometry may change per step (bind)
+        self._vx_unions = None
+        self._graph_sets: Dict = {}
         self._cuts: Optional[_Cuts] = None
         self._checked_phases = False
         self._seed = None
@@ -361,6 +364,9 @@ class TrainStep:
         """forward + loss.  On the GPU the loss, its gradient (unit seed) and the optimizer's tick come from ONE launch; the pair
         (pred, dpred) waits in self._seed for _backward_loss()."""
         self.bucket.clear()
+        if self._vx_unions is not None:       # vx: the unions' tables were uploaded by _vx_load(); the forward only refreshes (capturable)
+            self.model.encoder._vx_preloaded = (self._vx_unions[0], self._kwargs["encoder_nbrs"])
+            self.model.decoder._vx_preloaded = (self._vx_unions[1], self._kwargs["decoder_nbrs"])
         pred = self.model(pndata=self._x, **self._kwargs)
         if pred.is_cuda:
             from . import ops
@@ -486,11 +492,49 @@ class TrainStep:
         return loss
 
     def bind(self, pndata: torch.Tensor, target: torch.Tensor, **forward_kwargs):
-        """Fix the static buffers (shapes) of the step; later `step()` calls copy new data into them."""
+        """Fix the static buffers (shapes) of the step; later `step()` calls copy new data into them.
+
+        vx (xcoord [B, N, d] with caller-supplied per-sample `encoder_nbrs` / `decoder_nbrs`, static_trainer.py:180-202): the coordinates
+        become a static buffer as well and the per-sample graphs may change with every `step(..., xcoord=, encoder_nbrs=, decoder_nbrs=)`:
+        the batch's unions live in static padded buffers (plan.StaticUnion) that the captured step re-composes on the device from a small
+        table uploaded per step -- one captured step per edge-count bucket serves every batch composition a shuffling loader produces."""
         self._x = pndata.clone()
         self._y = target.clone()
-        self._kwargs = forward_kwargs
+        self._kwargs = dict(forward_kwargs)
         self._graphs = self._g_opt = None
+        self._graph_sets = {}
+        self._vx_unions = None
+        xc = forward_kwargs.get("xcoord")
+        self._vx = bool(torch.is_tensor(xc) and xc.dim() == 3 and xc.is_cuda and forward_kwargs.get("encoder_nbrs") is not None
+                        and forward_kwargs.get("decoder_nbrs") is not None and forward_kwargs.get("query_coord") is None
+                        and all(hasattr(m, "vx_static_ok") for m in (getattr(self.model, "encoder", None), getattr(self.model, "decoder", None)))
+                        and self._vx_sides_ok())
+        if self._vx:
+            self._kwargs["xcoord"] = xc.detach().clone().contiguous()
+            self._kwargs["latent_tokens_coord"] = forward_kwargs["latent_tokens_coord"].detach().contiguous()
+
+    def _vx_sides_ok(self) -> bool:
+        from . import plan as P
+        return P.VX_STATIC and all(bool(m.precompute_edges) and m.sampling_strategy is None and not m.node_embedding
+                                   for m in (self.model.encoder, self.model.decoder))
+
+    MAX_GRAPH_SETS = 6      # vx: captured steps kept (one per combination of the unions' edge buckets), least recently used first out
+
+    def _vx_load(self):
+        """upload this step's union tables (per scale, encoder and decoder) and pick the captured step of their buckets"""
+        kw = self._kwargs
+        B = self._x.shape[0]
+        enc = self.model.encoder.vx_unions(kw["encoder_nbrs"], kw["xcoord"], kw["latent_tokens_coord"], B)
+        dec = self.model.decoder.vx_unions(kw["decoder_nbrs"], kw["latent_tokens_coord"], kw["xcoord"], B)
+        self._vx_unions = (enc, dec)
+        key = tuple(u.uid for u in enc + dec)
+        hit = self._graph_sets.pop(key, None)
+        if hit is None:
+            while len(self._graph_sets) >= self.MAX_GRAPH_SETS:
+                self._graph_sets.pop(next(iter(self._graph_sets)))
+            hit = {"graphs": None, "g_opt": None, "loss": None, "merged": False, "ticked": False, "unions": (enc, dec)}
+        self._graph_sets[key] = hit
+        return hit
 
     def _capture(self):
         from . import ops
@@ -532,20 +576,39 @@ class TrainStep:
         for dst, src in zip((self.opt.flat_p, self.opt.m, self.opt.v, self.opt.step_count), snap):
             dst.copy_(src)
 
-    def step(self, pndata: Optional[torch.Tensor] = None, target: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def step(self, pndata: Optional[torch.Tensor] = None, target: Optional[torch.Tensor] = None, xcoord: Optional[torch.Tensor] = None,
+             encoder_nbrs=None, decoder_nbrs=None) -> torch.Tensor:
+        """one training step on new fields and -- vx -- a new geometry: coordinates [B, N, d] and the per-sample neighbour lists of this batch
+        (what static_trainer.py:180-202 hands the model every step), any composition of samples of the bound shapes"""
         if pndata is not None:
             self._x.copy_(pndata, non_blocking=True)
         if target is not None:
             self._y.copy_(target, non_blocking=True)
+        if xcoord is not None or encoder_nbrs is not None or decoder_nbrs is not None:
+            if not self._vx:
+                raise RuntimeError("TrainStep.step: a new geometry per step needs a vx binding (xcoord [B, N, d] with encoder_nbrs / decoder_nbrs, "
+                                   "no neighbour sub-sampling, no node_embedding); bind() again for another fixed geometry")
+            if xcoord is not None:
+                self._kwargs["xcoord"].copy_(xcoord, non_blocking=True)
+            if encoder_nbrs is not None:
+                self._kwargs["encoder_nbrs"] = encoder_nbrs
+            if decoder_nbrs is not None:
+                self._kwargs["decoder_nbrs"] = decoder_nbrs
         return self._step()
 
     def _step(self) -> torch.Tensor:
+        gs = None
+        if self._vx:
+            gs = self._vx_load()
+            self._graphs, self._g_opt, self._loss, self._merged, self._ticked = gs["graphs"], gs["g_opt"], gs["loss"], gs["merged"], gs["ticked"]
         if not self.use_graph:
             return self._eager_step()
         if self._graphs is not None and self._merged and self.force_comm:
             self._graphs = None                  # the exchange was switched on after a one-graph capture: split the step again
         if self._graphs is None:
             self._capture()
+            if gs is not None:
+                gs.update(graphs=self._graphs, g_opt=self._g_opt, loss=self._loss, merged=self._merged, ticked=self._ticked)
         self.opt.sync_hyper()                    # a scheduler may have moved lr since the last step (device buffer, no re-capture)
         if not self.staged:
             self._graphs[0].replay()

@@ -166,6 +166,36 @@ int gaot_concat_offset(const int32_t* const* parts, const int32_t* lens, const i
                        gaot_stream_t stream);
 int gaot_csr_transpose(const int32_t* index32, int32_t E, int32_t n_src,
                        int32_t* t_splits, int32_t* t_edge, int32_t* scratch, gaot_stream_t stream);
+/* The same union from a DEVICE-side table, into STATIC buffers sized for a capacity e_cap >= the union's edge count: what a captured
+ * (hipGraph) vx training step replays while the batch composition changes every step -- the reference's shuffling loader,
+ * data_utils.py:272-294 with static_trainer.py:180-202; magno.py:356-413 / 694-751 loop over the samples in Python.  The caller uploads one
+ * gaot_union_part per sample (device pointers of that sample's plan arrays and coordinates, its first edge's position in the union and its
+ * edge count) before the launch; every sample has q_each query rows and n_src_each sources.  Writes index32 / edge_query / t_edge [e_cap],
+ * splits32 [n_parts * q_each + 1], t_splits [n_parts * n_src_each + 1], the stacked coordinates src [n_parts * n_src_each, dim_src] and
+ * dst [n_parts * q_each, dim_dst] (either may be NULL: not copied) and *e_real = the union's edge count.  The edges e_real..e_cap-1 ("pads")
+ * belong to no row of either CSR; they carry source 0, query 0 and t_edge = their own id, so kernels that walk the flat edge list over
+ * e_cap entries stay in bounds, and they must be given an edge scale of 0 (gaot_edge_zero_pads, gaot_edge_inv_degree). */
+typedef struct gaot_union_part {
+    const int32_t* index;        /* [e_count]  source ids of the sample's CSR                     */
+    const int32_t* edge_query;   /* [e_count]  query id per edge                                   */
+    const int32_t* t_edge;       /* [e_count]  edge ids of the transposed CSR                      */
+    const int32_t* splits;       /* [q_each + 1]                                                   */
+    const int32_t* t_splits;     /* [n_src_each + 1]                                               */
+    const float* src;            /* [n_src_each, dim_src] source coordinates (NULL with src = NULL) */
+    const float* dst;            /* [q_each, dim_dst]     query coordinates                        */
+    int32_t e_begin;             /* position of the sample's first edge in the union               */
+    int32_t e_count;
+} gaot_union_part;
+int gaot_union_compose(const gaot_union_part* parts_dev, int32_t n_parts, int32_t q_each, int32_t n_src_each, int32_t dim_src,
+                       int32_t dim_dst, int32_t e_cap, int32_t* index32, int32_t* edge_query, int32_t* t_edge, int32_t* splits32,
+                       int32_t* t_splits, float* src, float* dst, int32_t* e_real, gaot_stream_t stream);
+/* out[e] = 1 / max(deg(query(e)), 1) -- the 'mean' reduction of agno.py:264 as a per-edge scale -- and 0 for e >= *e_real (e_real may be NULL) */
+int gaot_edge_inv_degree(const int32_t* splits32, const int32_t* edge_query, int32_t E, const int32_t* e_real, float* out,
+                         gaot_stream_t stream);
+/* a[b, e, :] = 0 for *e_real <= e < E, a [B, E, width]: the pads of a padded union -- under whatever per-edge scale the transform uses, and in
+ * per-edge gradient rows a flat kernel filled before a reduction over all E rows reads them.  max_pads: an upper bound of E - *e_real known on
+ * the host (sizes the launch; E if unknown). */
+int gaot_edge_zero_pads(float* a, int32_t B, int32_t E, int32_t width, const int32_t* e_real, int32_t max_pads, gaot_stream_t stream);
 /* Content guard of the per-geometry caches.  The reference trainer uploads the (unchanged) coordinates anew every step
  * (static_trainer.py:167-170), i.e. NEW tensors with the OLD bytes.  The plan keeps a copy of the bytes its cached arrays were
  * computed from:
@@ -197,7 +227,8 @@ int gaot_edge_features(const float* src, const float* qry, int32_t dim,
                        float* feat, const int32_t* guard, gaot_stream_t stream);
 /* GeometricEmbedding statistics, standardised (gemb.py:83-171): stats[Q, 3+2*dim], dim in {2,3}.  The Q rows form `groups`
  * equal groups (vx mode: one per sample of a block-diagonal union), each standardised on its own as the reference does per
- * sample.  scratch: 2*(3+2*dim)*groups doubles. */
+ * sample.  scratch: 34*(3+2*dim)*groups doubles (per group: 2 x 16 per-workgroup partial column sums, added in a fixed order, + mean and
+ * divisor). */
 int gaot_geo_stats(const float* geom, const float* qry, int32_t dim,
                    const int32_t* index32, const int32_t* splits32, int32_t Q,
                    float* stats, double* scratch, const int32_t* guard, int32_t groups, gaot_stream_t stream);
@@ -433,6 +464,8 @@ int gaot_patchify(const float* in, int32_t B, int32_t H, int32_t W, int32_t Dz, 
  * rows).  ws: gaot_gno_ep_workspace(E, C, B) floats.
  *   gaot_gno_lift_gather_reduce_ep : as gaot_gno_lift_gather_reduce (+ edge_query[E])
  *   gaot_gno_proj_gather_t_ep      : the dF product of gaot_gno_proj_backward over the transposed CSR
+ *   (both: e_real, optional DEVICE scalar = the number of edges actually in the list, <= E: the launch, the chunking and the workspace
+ *    are sized for E, edges past *e_real are not walked -- the padded unions of gaot_union_compose)
  *   gaot_gno_proj_gather_reduce_bin: gaot_gno_proj_gather_reduce with the batch INSIDE the lane group (each kernel-value row is
  *                                    read once for 4 samples instead of once per sample).  row_order (optional, [Q]): a permutation
  *                                    of the rows that puts rows with common source rows next to each other (e.g. sorted by first
@@ -442,11 +475,12 @@ int gaot_patchify(const float* in, int32_t B, int32_t H, int32_t W, int32_t Dz, 
 int64_t gaot_gno_ep_workspace(int32_t E, int32_t C, int32_t B);
 int gaot_gno_lift_gather_reduce_ep(const float* k, const float* pn, const float* wl, const float* bl, int32_t B, int32_t n_src,
                                    int32_t c_in, int32_t C, const int32_t* splits, const int32_t* cols, const int32_t* edge_query,
-                                   int32_t Q, int32_t E, const float* escale, float* out, float* ws, gaot_stream_t stream);
+                                   int32_t Q, int32_t E, const float* escale, float* out, float* ws, const int32_t* e_real,
+                                   gaot_stream_t stream);
 int gaot_gno_proj_gather_t_ep(const float* k, const float* dy, const float* weff, int32_t B, int32_t Q, int32_t n_src, int32_t C,
                               int32_t out_channels, const int32_t* index32, const int32_t* edge_query, int32_t E,
                               const int32_t* t_splits, const int32_t* t_edge, const float* escale, float* df, float* ws,
-                              gaot_stream_t stream);
+                              const int32_t* e_real, gaot_stream_t stream);
 int gaot_gno_proj_gather_reduce_bin(const float* k, const float* f, const float* weff, const float* rowbias, const float* bias,
                                     int32_t B, int32_t n_src, int32_t C, int32_t out_channels, const int32_t* splits,
                                     const int32_t* cols, int32_t Q, const float* escale, float* y, const int32_t* row_order,

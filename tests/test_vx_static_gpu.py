@@ -1,0 +1,262 @@
+"""-m gpu: vx training on static padded unions (gaot_amd/plan.py StaticUnion, csrc/gno.hip union_compose_kernel).
+
+The reference trains vx datasets under a shuffling loader (data_utils.py:272-294 collate, static_trainer.py:180-202): every step brings another
+composition of per-sample graphs.  Here the batch's block-diagonal unions live in static buffers padded to an edge-count bucket and are composed
+on the device from a table of per-sample plan pointers, so ONE captured step per bucket replays for any composition.  Pinned below:
+  * the composed arrays equal the union composed by concatenation (plan.compose_plans) on the real edges, whatever was in the buffers before;
+    the pads are harmless (no row references them, their edge scale is exactly 0);
+  * model forward / loss / gradients on the static unions equal the composed-union path and the oracle (which loops over samples as the
+    reference does, magno.py:356-413) on the permuted batch;
+  * TrainStep: 8 shuffled steps replayed as hipGraphs equal 8 eager steps BIT FOR BIT (same kernels, same addresses) and track the oracle;
+  * the unchanged reference loop (autograph) replays shuffled compositions and follows edited coordinates.
+"""
+import itertools
+
+import pytest
+import torch
+
+from tests._golden import rel_l2
+from tests._workloads import grid, naca_points
+from tests.test_configs_gpu import GRAD_TOL, LOSS_TOL, OUT_TOL, check_step, csr_dict, dev, grad_errors, make_model
+
+pytestmark = pytest.mark.gpu
+
+
+def _dataset(n_samples, N, seed=0, lat_sizes=(64, 64), radius=0.033, spread=0.15):
+    """per-sample NACA-shaped meshes with their encoder / decoder radius graphs (oracle search = the reference's)"""
+    from oracle import gaot_oracle as O
+    g = torch.Generator().manual_seed(seed)
+    lat = grid(list(lat_sizes))
+    xs = [naca_points(N, g, spread) for _ in range(n_samples)]
+    enc = [[O.radius_csr(x, lat, radius)] for x in xs]
+    dec = [[O.radius_csr(lat, x, radius)] for x in xs]
+    return lat, xs, enc, dec
+
+
+def test_static_union_equals_composed_union_and_pads_are_inert():
+    from gaot_amd import plan as P
+    lat, xs, enc, dec = _dataset(6, 2048, seed=3, lat_sizes=(32, 32), radius=0.066)
+    latd = lat.to(dev())
+    xd = [x.to(dev()) for x in xs]
+    B = 3
+    for side in ("enc", "dec"):
+        dicts = [csr_dict((enc if side == "enc" else dec)[i][0]) for i in range(6)]
+        src_of = (lambda i: xd[i]) if side == "enc" else (lambda i: latd)
+        dst_of = (lambda i: latd) if side == "enc" else (lambda i: xd[i])
+        n_src, n_dst = src_of(0).shape[0], dst_of(0).shape[0]
+        plans = [P.plan_for(d, n_src) for d in dicts]
+        cap = P.edge_bucket(max(sum(plans[i].E for i in c) for c in itertools.combinations(range(6), B)))
+        su = P.StaticUnion(B, n_src, n_dst, 2, 2, cap, dev())
+        # poison the static buffers: nothing of an earlier batch (or of the allocation) may survive a refresh
+        for t in (su.plan.index, su.plan.edge_query, su.plan.t_edge, su.plan.splits, su.plan.t_splits):
+            t.fill_(-7)
+        for order in ([5, 0, 3], [1, 2, 4], [3, 3, 0], [2, 1, 0]):          # big batch first, smaller later (stale tails), a repeated sample
+            x_par = torch.stack([xd[i] for i in order])
+            src_par, dst_par = (x_par, latd) if side == "enc" else (latd, x_par)
+            su.load([plans[i] for i in order], src_par, dst_par)
+            su.refresh()
+            ref = P.MergedGeometry([dicts[i] for i in order], [src_of(i) for i in order], [dst_of(i) for i in order], build_parts=True)
+            a, b = su.plan, ref.plan
+            E = b.E
+            assert int(a.e_dev.item()) == E == su.e_real and E <= a.E == cap
+            for name in ("index", "edge_query", "t_edge"):
+                assert torch.equal(getattr(a, name)[:E], getattr(b, name)[:E]), (side, name)
+            assert torch.equal(a.splits, b.splits) and torch.equal(a.t_splits, b.t_splits)
+            assert torch.equal(su.src, ref.src) and torch.equal(su.dst, ref.dst)
+            # pads: valid indices, own ids in the transposed list
+            assert bool((a.index[E:] == 0).all()) and bool((a.edge_query[E:] == 0).all())
+            assert torch.equal(a.t_edge[E:], torch.arange(E, cap, device=dev(), dtype=torch.int32))
+            assert torch.equal(a.edge_features(su.src, su.dst)[:E], b.edge_features(ref.src, ref.dst))
+            cos = a.cosine_attention(su.src, su.dst)
+            assert torch.equal(cos[:E], b.cosine_attention(ref.src, ref.dst)[:E]) and bool((cos[E:] == 0).all())
+            assert torch.equal(su.geo_stats(), ref.geo_stats())
+            inv = a.inv_deg_edge
+            assert torch.equal(inv[:E], b.inv_deg_edge[:E]) and bool((inv[E:] == 0).all())
+            assert torch.equal(a.deg, b.deg)
+        with pytest.raises(ValueError):
+            su.load([plans[0]] * (B + 1), latd, latd)
+
+
+@pytest.mark.parametrize("variant", ["default", "no_attention", "no_geoembed", "dot_product", "multiscale", "pointnet", "pointnet_mean", "kernelonly",
+                                     "nonlinear", "nonlinear_kernelonly"])
+def test_vx_static_path_equals_composed_path_and_oracle(variant):
+    """forward, loss and every gradient of a vx batch: static padded unions vs composed unions (GAOT_VX_STATIC=0 path) vs the oracle"""
+    from gaot_amd import plan as P
+    from gaot_amd import ops
+    from oracle import gaot_oracle as O
+    kw = {"default": {}, "no_attention": dict(use_attention=False), "no_geoembed": dict(use_geoembed=False),
+          "dot_product": dict(attention_type="dot_product"), "multiscale": dict(scales=[1.0, 0.5], use_scale_weights=True),
+          "pointnet": dict(embedding_method="pointnet"), "pointnet_mean": dict(embedding_method="pointnet", pooling="mean"),
+          "kernelonly": dict(transform_type="linear_kernelonly"), "nonlinear": dict(transform_type="nonlinear"),
+          "nonlinear_kernelonly": dict(transform_type="nonlinear_kernelonly")}[variant]
+    B, N = 3, 2048
+    # ('nonlinear' kernels see f(y_j): the reference sizes their input by in_channels, magno.py:77-80, so lifting_channels == in_channels there)
+    cin = 8 if variant.startswith("nonlinear") else 3
+    model, sd, ocfg = make_model(cin, 1, [32, 32], radius=0.066, seed=11, **({"C": 8} if cin == 8 else {}), **kw)
+    lat, xs, _, _ = _dataset(B, N, seed=5, lat_sizes=(32, 32), radius=0.066)
+    scales = kw.get("scales", [1.0])
+    enc = [[O.radius_csr(x, lat, 0.066 * s) for s in scales] for x in xs]
+    dec = [[O.radius_csr(lat, x, 0.066 * s) for s in scales] for x in xs]
+    g = torch.Generator().manual_seed(2)
+    p, tgt = torch.randn(B, N, cin, generator=g), torch.randn(B, N, 1, generator=g)
+    x = torch.stack(xs)
+    model.to(dev()).train()
+    fk = dict(latent_tokens_coord=lat.to(dev()), xcoord=x.to(dev()),
+              encoder_nbrs=[[csr_dict(c) for c in row] for row in enc], decoder_nbrs=[[csr_dict(c) for c in row] for row in dec])
+    res = {}
+    for static in (True, False):
+        P.VX_STATIC = static
+        try:
+            for rep in range(2):          # twice: the second pass reuses the static buffers
+                model.zero_grad(set_to_none=True)
+                pred = model(pndata=p.to(dev()), **fk)
+                loss = ops.mse_loss(pred, tgt.to(dev()))
+                loss.backward()
+            torch.cuda.synchronize()
+            res[static] = (pred.detach().cpu(), float(loss), {k: q.grad.detach().cpu().clone() for k, q in model.named_parameters() if q.grad is not None})
+        finally:
+            P.VX_STATIC = True
+    assert len(model.encoder._static_unions) == len(scales) and len(model.decoder._static_unions) == len(scales)
+    (ya, la, ga), (yb, lb, gb) = res[True], res[False]
+    assert rel_l2(ya, yb) < 2e-6 and abs(la - lb) < 1e-6 * abs(lb)
+    top = max(float(v.double().norm()) for v in gb.values())
+    for k in gb:
+        assert float((ga[k].double() - gb[k].double()).norm()) <= 2e-5 * max(float(gb[k].double().norm()), 1e-3 * top), k
+    if variant == "default":
+        lo, go, _, _, po = O.train_step(sd, ocfg, dict(latent=lat, xcoord=x, pndata=p, target=tgt, encoder_nbrs=enc, decoder_nbrs=dec), return_pred=True)
+        assert rel_l2(ya, po) < OUT_TOL and abs(la - float(lo)) < LOSS_TOL * abs(float(lo))
+        topo = max(float(v.double().norm()) for v in go.values())
+        errs = {k: float((ga[k].double() - go[k].double()).norm()) / max(float(go[k].double().norm()), 1e-3 * topo) for k in ga}
+        assert max(errs.values()) < GRAD_TOL, max(errs, key=errs.get)
+
+
+def _shuffled_batches(n_samples, B, steps, seed):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randperm(n_samples, generator=g)[:B].tolist() for _ in range(steps)]
+
+
+def test_trainstep_vx_shuffled_replay_equals_eager_bit_for_bit_and_tracks_the_oracle():
+    """8 steps, every one a different composition drawn from a 10-sample dataset (edge totals spread over several buckets): TrainStep with
+    hipGraph replay == TrainStep eager, bit for bit (losses and final weights); the first steps' losses equal the oracle's on the same batches."""
+    from gaot_amd.model.gaot import GAOT
+    from gaot_amd.trainer import TrainStep
+    from oracle import gaot_oracle as O
+    nS, B, N, steps = 10, 4, 2048, 8
+    model, sd, ocfg = make_model(3, 1, [32, 32], radius=0.066, seed=4)
+    lat, xs, enc, dec = _dataset(nS, N, seed=9, lat_sizes=(32, 32), radius=0.066)
+    # a spread of mesh densities: the edge totals of the batches differ by more than one bucket
+    g = torch.Generator().manual_seed(1)
+    P_all, T_all = torch.randn(nS, N, 3, generator=g), torch.randn(nS, N, 1, generator=g)
+    batches = _shuffled_batches(nS, B, steps, seed=21)
+    latd = lat.to(dev())
+    xd = torch.stack(xs).to(dev())
+    encd = [[csr_dict(c) for c in row] for row in enc]
+    decd = [[csr_dict(c) for c in row] for row in dec]
+    runs = {}
+    for graph in (True, False):
+        m = GAOT(3, 1, _cfg_of(model))
+        m.load_state_dict(sd)
+        m.to(dev()).train()
+        ts = TrainStep(m, lr=2e-3, weight_decay=1e-4, use_graph=graph)
+        b0 = batches[0]
+        ts.bind(P_all[b0].to(dev()), T_all[b0].to(dev()), latent_tokens_coord=latd, xcoord=xd[b0], encoder_nbrs=[encd[i] for i in b0],
+                decoder_nbrs=[decd[i] for i in b0])
+        losses = []
+        for b in batches:
+            losses.append(ts.step(P_all[b].to(dev()), T_all[b].to(dev()), xcoord=xd[b], encoder_nbrs=[encd[i] for i in b],
+                                  decoder_nbrs=[decd[i] for i in b]).clone())
+        torch.cuda.synchronize()
+        runs[graph] = (torch.stack(losses).cpu(), torch.cat([q.detach().reshape(-1) for q in m.parameters()]).cpu(), ts)
+    (lg, wg, tsg), (le, we, _) = runs[True], runs[False]
+    assert torch.equal(lg, le), (lg, le)
+    assert torch.equal(wg, we)
+    n_sets = len(tsg._graph_sets)
+    totals = sorted({sum(int(enc[i][0][0].numel()) for i in b) for b in batches})
+    print(f"[vx shuffled] {steps} compositions, encoder edge totals {totals[0]}..{totals[-1]}, {n_sets} captured step(s)")
+    assert 1 <= n_sets <= TrainStep.MAX_GRAPH_SETS and all(v["graphs"] is not None for v in tsg._graph_sets.values())
+    # the oracle on the same sequence of batches (the reference loops over the samples of each batch)
+    w = {k: v.clone() for k, v in sd.items()}
+    mom = None
+    for i, b in enumerate(batches[:3]):
+        batch = dict(latent=lat, xcoord=torch.stack([xs[j] for j in b]), pndata=P_all[b], target=T_all[b], encoder_nbrs=[enc[j] for j in b],
+                     decoder_nbrs=[dec[j] for j in b])
+        lo, _, w, mom = O.train_step(w, ocfg, batch, lr=2e-3, weight_decay=1e-4, state=mom)
+        assert abs(float(lg[i]) - float(lo)) < (1e-5 if i == 0 else 2e-4) * abs(float(lo)), (i, float(lg[i]), float(lo))
+
+
+def _cfg_of(model):
+    from tests.test_configs_gpu import model_cfg
+    return model_cfg(model)
+
+
+def test_trainstep_vx_fresh_dicts_every_step():
+    """the reference's own loader keeps the graphs on the host and uploads them per step (move_to_device, static_trainer.py:192-193): new dict
+    objects, new tensors every step.  Their per-sample plans are built per step without a host synchronisation; the step still replays."""
+    from gaot_amd.trainer import TrainStep
+    nS, B, N = 6, 3, 2048
+    model, sd, _ = make_model(3, 1, [32, 32], radius=0.066, seed=4)
+    lat, xs, enc, dec = _dataset(nS, N, seed=13, lat_sizes=(32, 32), radius=0.066)
+    g = torch.Generator().manual_seed(1)
+    P_all, T_all = torch.randn(nS, N, 3, generator=g), torch.randn(nS, N, 1, generator=g)
+    batches = _shuffled_batches(nS, B, 5, seed=2)
+    latd, xd = lat.to(dev()), torch.stack(xs).to(dev())
+    out = {}
+    for fresh in (True, False):
+        from gaot_amd.model.gaot import GAOT
+        m = GAOT(3, 1, _cfg_of(model))
+        m.load_state_dict(sd)
+        m.to(dev()).train()
+        ts = TrainStep(m, lr=2e-3, weight_decay=1e-4, use_graph=True)
+        kept_e = [[csr_dict(c) for c in row] for row in enc]
+        kept_d = [[csr_dict(c) for c in row] for row in dec]
+        up = (lambda rows, kept, b: [[csr_dict(c) for c in rows[i]] for i in b]) if fresh else (lambda rows, kept, b: [kept[i] for i in b])
+        b0 = batches[0]
+        ts.bind(P_all[b0].to(dev()), T_all[b0].to(dev()), latent_tokens_coord=latd, xcoord=xd[b0], encoder_nbrs=up(enc, kept_e, b0), decoder_nbrs=up(dec, kept_d, b0))
+        ls = [ts.step(P_all[b].to(dev()), T_all[b].to(dev()), xcoord=xd[b], encoder_nbrs=up(enc, kept_e, b), decoder_nbrs=up(dec, kept_d, b)).clone() for b in batches]
+        torch.cuda.synchronize()
+        out[fresh] = torch.stack(ls).cpu()
+    assert torch.equal(out[True], out[False])
+
+
+def test_auto_graph_vx_replays_shuffled_compositions_and_follows_coordinates():
+    """autograph.py in vx mode (the reference's variable-coordinate loop, static_trainer.py:180-202 inside optimizers.py:247-257, unchanged):
+    from its third step on every batch -- any composition of the resident per-sample graphs, coordinates as new tensors each step, also EDITED
+    coordinates -- is served by the captured graphs and gives what the eager path gives."""
+    from gaot_amd.model.gaot import GAOT
+    nS, B, N, steps = 8, 4, 2048, 9
+    model, sd, _ = make_model(3, 1, [32, 32], radius=0.066, seed=6)
+    lat, xs, enc, dec = _dataset(nS, N, seed=17, lat_sizes=(32, 32), radius=0.066)
+    # one bucket for the whole dataset would hide nothing here; the test is about compositions, so keep the batches in ONE bucket by
+    # drawing permutations of the same 4 samples for the first steps and other samples later
+    batches = [[0, 1, 2, 3], [3, 1, 0, 2], [2, 0, 3, 1], [1, 3, 2, 0], [0, 2, 1, 3], [3, 2, 1, 0], [0, 1, 2, 3], [2, 3, 0, 1], [1, 0, 3, 2]]
+    g = torch.Generator().manual_seed(3)
+    P_all, T_all = torch.randn(nS, N, 3, generator=g), torch.randn(nS, N, 1, generator=g)
+    latd, xd = lat.to(dev()), torch.stack(xs).to(dev())
+    encd = [[csr_dict(c) for c in row] for row in enc]
+    decd = [[csr_dict(c) for c in row] for row in dec]
+    runs = {}
+    for auto in (True, False):
+        m = GAOT(3, 1, _cfg_of(model))
+        m.load_state_dict(sd)
+        m.to(dev()).train()
+        m.auto_graph = auto
+        opt = torch.optim.AdamW(m.parameters(), lr=2e-3, weight_decay=1e-4)
+        losses, which = [], []
+        for i, b in enumerate(batches):
+            xc = xd[b].clone()
+            if i == steps - 1:
+                xc = xc * 1.0001          # edited coordinates with the same graphs: the captured forward re-derives the geometry arrays
+            opt.zero_grad()
+            out = m(latent_tokens_coord=latd, pndata=P_all[b].to(dev()), xcoord=xc, encoder_nbrs=[encd[j] for j in b], decoder_nbrs=[decd[j] for j in b])
+            which.append(type(out.grad_fn).__name__)
+            loss = torch.nn.functional.mse_loss(out, T_all[b].to(dev()))
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        runs[auto] = (losses, torch.cat([q.detach().reshape(-1) for q in m.parameters()]).cpu(), sum(w == "_GraphedStepBackward" for w in which), which)
+    la, wa, ra, which = runs[True]
+    lb, wb, rb, _ = runs[False]
+    # the first forward re-homes the fused weights (new storage = new key), the second is that key's first sight, from the third on: graphs
+    assert rb == 0 and ra == steps - 2, (ra, which)
+    assert max(abs(a - b) / abs(b) for a, b in zip(la, lb)) < 1e-5, (la, lb)
+    assert float((wa - wb).abs().max()) < 2e-5

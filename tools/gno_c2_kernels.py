@@ -34,7 +34,7 @@ def bwd(with_df):
                                        _p(plan.t_splits), _p(plan.t_edge), _p(esc), _p(dk), _p(part), _p(df) if with_df else None, _stream()), "bwd")
 def t_ep():
     L.check(lib.gaot_gno_proj_gather_t_ep(_p(k), _p(dy), _p(weff), B, plan.Q, n_src, C, OC, _p(plan.index), _p(plan.edge_query), plan.E,
-                                          _p(plan.t_splits), _p(plan.t_edge), _p(esc), _p(df2), _p(ws), _stream()), "t_ep")
+                                          _p(plan.t_splits), _p(plan.t_edge), _p(esc), _p(df2), _p(ws), None, _stream()), "t_ep")
 bwd(True); t_ep(); torch.cuda.synchronize()
 print("max |dF row-parallel - dF edge-partitioned| / max |dF| =", float((df - df2).abs().max() / df.abs().max()))
 t_all, t_edge = timeit(lambda: bwd(True)), timeit(lambda: bwd(False))
