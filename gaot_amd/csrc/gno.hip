@@ -152,12 +152,32 @@ __device__ __forceinline__ float cos_score(const float* __restrict__ x, const fl
     for (int d = 0; d < dim; ++d) xy += (x[d] * xinv) * (y[d] * yinv);
     return xy;
 }
-__global__ void edge_attention_cosine_kernel(const float* __restrict__ src, const float* __restrict__ qry, int dim,
-                                             const int* __restrict__ idx, const int* __restrict__ sp, int Q,
-                                             float* __restrict__ attn, const int* __restrict__ guard) {
+// GEO_LANES lanes per query row (aligned lane groups of one wave): the rows of a skewed mesh reach 350+ edges next to thousands of empty ones,
+// and with a vx batch under a shuffling loader this runs every step (plan.StaticUnion.refresh), not once per geometry.  A lane strides its row's
+// edges, the group reduces by xor shuffles inside the group: fixed order, deterministic.
+#define GEO_LANES 8
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+    for (int off = GEO_LANES >> 1; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int off = GEO_LANES >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double group_sum_d(double v) {
+#pragma unroll
+    for (int off = GEO_LANES >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__global__ __launch_bounds__(256) void edge_attention_cosine_kernel(const float* __restrict__ src, const float* __restrict__ qry, int dim,
+                                                                    const int* __restrict__ idx, const int* __restrict__ sp, int Q,
+                                                                    float* __restrict__ attn, const int* __restrict__ guard) {
     if (guard && *guard == 0) return;
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= Q) return;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = gid / GEO_LANES, l = gid % GEO_LANES;
+    if (q >= Q) return;                         // (whole lane groups leave together)
     const int b = sp[q], e = sp[q + 1];
     if (b == e) return;
     const float* x = qry + (long)q * dim;
@@ -165,14 +185,16 @@ __global__ void edge_attention_cosine_kernel(const float* __restrict__ src, cons
     for (int d = 0; d < dim; ++d) xx += x[d] * x[d];
     const float xinv = 1.0f / fmaxf(sqrtf(xx), 1e-12f);
     float mx = -INFINITY;
-    for (int t = b; t < e; ++t) {
+    for (int t = b + l; t < e; t += GEO_LANES) {
         const float s = cos_score(x, src + (long)idx[t] * dim, dim, xinv);
         attn[t] = s;
         mx = fmaxf(mx, s);
     }
+    mx = group_max(mx);
     float den = 0.f;
-    for (int t = b; t < e; ++t) { const float v = expf(attn[t] - mx); attn[t] = v; den += v; }
-    for (int t = b; t < e; ++t) attn[t] = attn[t] / den;
+    for (int t = b + l; t < e; t += GEO_LANES) { const float v = expf(attn[t] - mx); attn[t] = v; den += v; }
+    den = group_sum(den);
+    for (int t = b + l; t < e; t += GEO_LANES) attn[t] = attn[t] / den;
 }
 __global__ void segment_softmax_fwd_kernel(const float* __restrict__ score, const int* __restrict__ sp, int Q,
                                            float* __restrict__ attn) {
@@ -255,38 +277,42 @@ __device__ void sym_eig_desc<3>(const double (&c)[3][3], double (&ev)[3]) {
 }
 
 template <int DIM>
-__global__ void geo_stats_raw_kernel(const float* __restrict__ geom, const float* __restrict__ qry,
-                                     const int* __restrict__ idx, const int* __restrict__ sp, int Q,
-                                     float* __restrict__ raw, const int* __restrict__ guard) {
+__global__ __launch_bounds__(256) void geo_stats_raw_kernel(const float* __restrict__ geom, const float* __restrict__ qry,
+                                                            const int* __restrict__ idx, const int* __restrict__ sp, int Q,
+                                                            float* __restrict__ raw, const int* __restrict__ guard) {
     constexpr int F = 3 + 2 * DIM;
     if (guard && *guard == 0) return;
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= Q) return;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = gid / GEO_LANES, l = gid % GEO_LANES;
+    if (q >= Q) return;                         // (whole lane groups leave together)
     float* o = raw + (long)q * F;
     const int b = sp[q], e = sp[q + 1];
     const int n = e - b;
-    if (n == 0) { for (int f = 0; f < F; ++f) o[f] = 0.f; return; }
+    if (n == 0) { if (l == 0) for (int f = 0; f < F; ++f) o[f] = 0.f; return; }
     double x[DIM], cen[DIM];
     for (int d = 0; d < DIM; ++d) { x[d] = qry[(long)q * DIM + d]; cen[d] = 0.0; }
     double sd = 0.0, sd2 = 0.0;
-    for (int t = b; t < e; ++t) {
+    for (int t = b + l; t < e; t += GEO_LANES) {
         const float* y = geom + (long)idx[t] * DIM;
         double d2 = 0.0;
         for (int d = 0; d < DIM; ++d) { const double dv = (double)y[d] - x[d]; d2 += dv * dv; cen[d] += y[d]; }
         sd += sqrt(d2);
         sd2 += d2;
     }
+    sd = group_sum_d(sd);
+    sd2 = group_sum_d(sd2);
     const double inv = 1.0 / n;
-    for (int d = 0; d < DIM; ++d) cen[d] *= inv;
+    for (int d = 0; d < DIM; ++d) cen[d] = group_sum_d(cen[d]) * inv;
     double cov[DIM][DIM];
     for (int i = 0; i < DIM; ++i) for (int j = 0; j < DIM; ++j) cov[i][j] = 0.0;
-    for (int t = b; t < e; ++t) {
+    for (int t = b + l; t < e; t += GEO_LANES) {
         const float* y = geom + (long)idx[t] * DIM;
         double c[DIM];
         for (int d = 0; d < DIM; ++d) c[d] = (double)y[d] - cen[d];
-        for (int i = 0; i < DIM; ++i) for (int j = 0; j < DIM; ++j) cov[i][j] += c[i] * c[j];
+        for (int i = 0; i < DIM; ++i) for (int j = i; j < DIM; ++j) cov[i][j] += c[i] * c[j];
     }
-    for (int i = 0; i < DIM; ++i) for (int j = 0; j < DIM; ++j) cov[i][j] *= inv;
+    for (int i = 0; i < DIM; ++i) for (int j = i; j < DIM; ++j) { cov[i][j] = group_sum_d(cov[i][j]) * inv; cov[j][i] = cov[i][j]; }
+    if (l != 0) return;
     double ev[DIM];
     sym_eig_desc<DIM>(cov, ev);
     const double mean = sd * inv;
@@ -536,7 +562,7 @@ extern "C" int gaot_edge_attention_cosine(const float* src, const float* qry, in
                                           gaot_stream_t stream) {
     GAOT_REQUIRE(src && qry && splits32 && dim > 0 && Q >= 0, "edge_attention_cosine: bad arguments");
     if (Q == 0) return GAOT_OK;
-    hipLaunchKernelGGL(edge_attention_cosine_kernel, dim3(cdiv(Q, 128)), dim3(128), 0, ST(stream), src, qry, dim,
+    hipLaunchKernelGGL(edge_attention_cosine_kernel, dim3(cdiv((long)Q * GEO_LANES, 256)), dim3(256), 0, ST(stream), src, qry, dim,
                        index32, splits32, Q, attn, guard);
     GAOT_CHECK_LAUNCH("gaot_edge_attention_cosine");
     return GAOT_OK;
@@ -581,9 +607,9 @@ extern "C" int gaot_geo_stats(const float* geom, const float* qry, int32_t dim, 
     const int F = 3 + 2 * dim;
     const int Qg = Q / groups;
     if (dim == 2)
-        hipLaunchKernelGGL(geo_stats_raw_kernel<2>, dim3(cdiv(Q, 128)), dim3(128), 0, ST(stream), geom, qry, index32, splits32, Q, stats, guard);
+        hipLaunchKernelGGL(geo_stats_raw_kernel<2>, dim3(cdiv((long)Q * GEO_LANES, 256)), dim3(256), 0, ST(stream), geom, qry, index32, splits32, Q, stats, guard);
     else
-        hipLaunchKernelGGL(geo_stats_raw_kernel<3>, dim3(cdiv(Q, 128)), dim3(128), 0, ST(stream), geom, qry, index32, splits32, Q, stats, guard);
+        hipLaunchKernelGGL(geo_stats_raw_kernel<3>, dim3(cdiv((long)Q * GEO_LANES, 256)), dim3(256), 0, ST(stream), geom, qry, index32, splits32, Q, stats, guard);
     // Column sums in a FIXED order, whatever the number of workgroups: every workgroup writes its fp64 partial sums, the consumers add them in
     // block order.  (Partial sums that met in an atomicAdd in arrival order made a standardised statistic come out one fp32 ulp different from
     // run to run once in a while -- enough for two trainings from the same seed to end ~1e-2 apart in loss after 100 steps, tools/det_batch.py;
