@@ -96,6 +96,9 @@ PROTOTYPES = {
     "gaot_csr_prepare": (C.c_int, [_i, _i, C.c_int32, C.c_int32, C.c_int32, _i, _i, _i, _i, _s]),
     "gaot_csr_transpose": (C.c_int, [_i, C.c_int32, C.c_int32, _i, _i, _i, _s]),
     "gaot_union_compose": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i, _i, _i, _i, _i, _f, _f, _i, _s]),
+    "gaot_edge_drop_scratch": (C.c_int64, [C.c_int32]),
+    "gaot_edge_drop": (C.c_int, [_i, _i, _i, _i, _i, C.c_int32, C.c_int32, C.c_int32, _i, C.c_int32, C.c_float, C.c_int32, C.c_void_p,
+                                 _i, _i, _i, _i, _i, _i, _i, _s]),
     "gaot_edge_inv_degree": (C.c_int, [_i, _i, C.c_int32, _i, _f, _s]),
     "gaot_edge_zero_pads": (C.c_int, [_f, C.c_int32, C.c_int32, C.c_int32, _i, C.c_int32, _s]),
     "gaot_guard_begin": (C.c_int, [_i, _s]),

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libgaot_hip.so")
-SOURCES = ["capi.cpp", "gemm.hip", "gemm_glds.hip", "gemm_split.hip", "gemm_ad.hip", "skinny.hip", "gno.hip", "gno_ep.hip", "kernel_mlp.hip", "radius.hip", "pointwise.hip", "glue.hip", "attention.hip"]
+SOURCES = ["capi.cpp", "gemm.hip", "gemm_glds.hip", "gemm_split.hip", "gemm_ad.hip", "skinny.hip", "gno.hip", "gno_ep.hip", "edge_drop.hip", "kernel_mlp.hip", "radius.hip", "pointwise.hip", "glue.hip", "attention.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "segsort.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(HERE, "..", "include", "gaot_hip.h"), os.path.join(HERE, "..", "include", "gaot_hip_debug.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-array-bounds"] + os.environ.get("GAOT_HIPCC_EXTRA", "").split()      # (extra: A/B builds, tools)
 

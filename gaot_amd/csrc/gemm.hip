@@ -492,7 +492,7 @@ static int gemm_run(const gaot_gemm_desc* d, gaot_stream_t stream, const bool dr
     const long k_per_wg = a.split_k > 1 ? (long)a.ktiles_per_split * 32 : a.K;
     const bool split_ok = g_use_split && g_use_split != 3 && glds_ok && (a.A2 == nullptr || (ak && a.k_split % 16 == 0)) && g_tile_override == 0 &&
                           (k_per_wg <= 1024 || pieces == 1 || g_use_split != 1);      // forced tuning modes bypass the cap
-    // measured (tools/gemm_split_test.py): the 128x128 split-bf16 tiles win once they fill the chip (>= 256 workgroups
+    // measured (round 2, tools/gemm_bench.py sweeps): the 128x128 split-bf16 tiles win once they fill the chip (>= 256 workgroups
     // counting split-K slabs) on outputs at least one tile wide; narrower / smaller products stay on the fp32 MFMA tiles
     // two-piece products, outputs at most six 128-wide tiles across (N <= 768): the 64-row tiles win although the 128-row ones would
     // fill the chip (8192 x 768 x 256 NT: 21.7 vs 24.2 us, NN x 512 x 256: 18.6 vs 19.5; N >= 1 024: the other way round)
@@ -516,7 +516,7 @@ static int gemm_run(const gaot_gemm_desc* d, gaot_stream_t stream, const bool dr
     // DESIGN 7, not these tiles.)
     const bool narrow_shape = g_use_ad == 1 && (g_ad_narrow & 1) && split_ok && !split128 && !split64 && pieces == 4 && ak && a.K % 32 == 0 && a.vec_epi &&
                               a.split_k <= 1 && a.A2 == nullptr && cdiv(a.N, 128) == 2 && blocks(64, 64) >= 128 && blocks(64, 128) < 250 && a.K <= 1024;
-    const bool ad_narrow = narrow_shape && (dry || a.Bpl != nullptr);
+    const bool ad_narrow = narrow_shape && (dry ? d->b_planes != nullptr : a.Bpl != nullptr);
     // planes handed in but switched off (gaot_debug_set_gemm_planes(0)): the same tile family on the staged 64-row kernel, so that the
     // switch changes where B's pieces come from and nothing else (products WITHOUT planes -- B an activation -- stay where they were)
     const bool narrow_staged = narrow_shape && !dry && a.Bpl == nullptr && d->b_planes != nullptr;
@@ -542,7 +542,7 @@ static int gemm_run(const gaot_gemm_desc* d, gaot_stream_t stream, const bool dr
     }
     else if (glds_ok && g_tile_override >= 0 && g_tile_override <= 3) {
         int tile = g_tile_override;
-        if (tile == 0) {      // from the on-box sweep (tools/gemm_glds_test.py, 2-stage ring)
+        if (tile == 0) {      // from the on-box sweep (round 2, tools/gemm_bench.py; 2-stage ring)
             if (!ak && !bk) tile = blocks(128, 128) >= 256 ? 1 : (blocks(128, 64) >= 256 && a.M >= 128 ? 2 : 3);
             else if (blocks(128, 128) >= 512) tile = 1;
             else if (blocks(128, 64) >= 512) tile = 2;

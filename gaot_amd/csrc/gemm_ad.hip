@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ad_kernel(const GemmArgs p) {
             const float mean_e = (float)es / (float)cn - 127.f + (float)((int)(__float_as_uint(sc_a) >> 23) - 127);
             la = (int)((13.5f - mean_e) * 16.f);
         }
-        const int lb_w = (int)(__uint_as_float(reinterpret_cast<const unsigned*>(p.b_amax)[p.bpl_flag]) * 16.f);
+        const int lb_w = (int)(fminf(fmaxf(__uint_as_float(reinterpret_cast<const unsigned*>(p.b_amax)[p.bpl_flag]), 0.f), 64.f) * 16.f);      // (clamped: a NaN or a garbage verdict is a number of binades, never an int overflow)
         const bool bad = la + lb_w > 17 * 16;
         bool stale = la < -24;          // a mean 1.5 binades above the claimed maximum: a stale word
         if ((kt_end - kt_begin) * TM >= 4096) stale = true;          // (a k range too long for the packed counters: play safe)

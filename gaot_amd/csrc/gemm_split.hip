@@ -488,7 +488,7 @@ __device__ __forceinline__ void split_tile(const GemmArgs& p, unsigned char* sme
         const int la = spread(ec_a, sc_a);
         int bad, stale;
         if (BPL) {          // the weight's L is uniform: every thread judges its own rows
-            const int lb_w = (int)(__uint_as_float(reinterpret_cast<const unsigned*>(p.b_amax)[p.bpl_flag]) * 16.f);
+            const int lb_w = (int)(fminf(fmaxf(__uint_as_float(reinterpret_cast<const unsigned*>(p.b_amax)[p.bpl_flag]), 0.f), 64.f) * 16.f);      // (clamped: a NaN or a garbage verdict is a number of binades, never an int overflow)
             bad = la + lb_w > 17 * 16 ? 1 : 0;
             stale = la < -24 ? 1 : 0;          // a mean 1.5 binades above the claimed maximum: a stale word
         } else if (PAIRED) {

@@ -1131,7 +1131,7 @@ extern "C" int32_t gaot_kernel_mlp_bwd_rows(int32_t E) { int grid = cdiv(E, 128)
 // Any other pair -- or the fp32-MFMA / two-piece modes -- runs as the two single launches.
 static bool km_pair_ok(const gaot_kmlp_desc* a, const gaot_kmlp_desc* b) {
     return g_km_split && !g_km_abl && a->n_layers == 4 && b->n_layers == 3 && a->act == GAOT_ACT_GELU && b->act == GAOT_ACT_RELU &&
-           (a->pieces == 0 || a->pieces == 3) && a->cin <= 8 && b->cin > 4 && a->E > 0 && b->E > 0;
+           (a->pieces == 0 || a->pieces == 3) && (b->pieces == 0 || b->pieces == 3) && a->cin <= 8 && b->cin > 4 && a->E > 0 && b->E > 0;
 }
 static int km_desc_fill(KMArgs& k, const gaot_kmlp_desc* d, bool bwd) {
     if (int rc = km_check(d->x, d->E, d->cin, d->n_layers, d->w, d->b)) return rc;

@@ -533,11 +533,11 @@ def linear_nt(x2: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = N
     if out is None:
         out = torch.empty(M, N, device=x2.device, dtype=torch.float32)
     if "split_k" not in epi and epi.get("act", L.ACT_NONE) == L.ACT_NONE and epi.get("aux_out") is None and epi.get("aux_in") is None:
-        epi["split_k"] = _split_for_narrow_output(M, N, K)
+        epi["split_k"] = _split_for_narrow_output(M, N, K, lambda: weight_operand(w, True)[1] is not None)
     return gemm(M, N, K, x2, lda, 1, w, ldb, 1, out, out.stride(0) if M > 1 else N, **epi)
 
 
-def _split_for_narrow_output(Mo: int, No: int, K: int) -> int:
+def _split_for_narrow_output(Mo: int, No: int, K: int, planes=None) -> int:
     """activation-side products whose output is only two 128-wide tiles across (N = 256) with a long reduction (K >= 2048,
     du @ [w1;w3]): 128 output tiles leave half the CUs idle; two K halves on the split-bf16 tiles + one reduce measured
     78 -> 61 us at 8192 x 256 x 2048 (tools/gemm_n256_sweep.py)"""
@@ -548,10 +548,12 @@ def _split_for_narrow_output(Mo: int, No: int, K: int) -> int:
         # fp16 / two-piece tiles (tools/gemm_splitk_sweep.py, product + reduce): K = 2048: 76 / 51 / 47 us at 1 / 2 / 4 slabs on the
         # 128-row tiles (64-row tiles without slabs: 66); K = 1024: 34 (64-row, no slabs) / 31.5 (two slabs)
         return 4 if K >= 2048 else _NARROW_SPLIT_1K
-    if _NARROW_TILES_1K and 48 <= t128 < 100 and 128 < No <= 256 and K <= 1024 and Mo % 64 == 0:
+    if _NARROW_TILES_1K and 48 <= t128 < 100 and 128 < No <= 256 and K <= 1024 and Mo % 64 == 0 and (planes is None or planes()):
         # two tiles across, half a round of 64-row tiles (4 096 tokens x 256, the FFN down-projection at K = 1 024): the 64 x 64 all-DMA
         # tiles (gemm.hip, 256 workgroups) take the whole reduction in one launch; two slabs on the fp32-MFMA tiles + the reduce were
-        # 24.8 + 5.3 us per launch (profiles/r5z_c4_kernel_stats_before.txt, r5z_c4_step_sequence.txt)
+        # 24.8 + 5.3 us per launch (profiles/r5z_c4_kernel_stats_before.txt, r5z_c4_step_sequence.txt).  `planes`: whether the B operand has
+        # pre-split weight planes -- those tiles need them (gemm.hip `ad_narrow`); without (GAOT_WEIGHT_PLANES=0, an unregistered or misaligned
+        # weight view, B an activation) the product keeps its K slabs below instead of running unsplit on ~128 fp32-MFMA workgroups
         return 1
     if 48 <= t128 < 100 and Mo >= 128 and No >= 128:
         # fewer than 100 output tiles (4 096 tokens x 384 at the 3-D configuration): on the fp32-MFMA tiles 130 us at K = 3 072;
@@ -578,7 +580,7 @@ def matmul_nn(g: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = No
     if out is None:
         out = torch.empty(M, K, device=g.device, dtype=torch.float32)
     if "split_k" not in epi:
-        epi["split_k"] = _split_for_narrow_output(M, K, N)
+        epi["split_k"] = _split_for_narrow_output(M, K, N, lambda: weight_operand(w, False)[1] is not None)
     return gemm(M, K, N, g, lda, 1, w, ldb, 0, out, out.stride(0) if M > 1 else K, **epi)
 
 
@@ -621,7 +623,7 @@ def matmul_tn(g: torch.Tensor, x2: torch.Tensor, out: Optional[torch.Tensor] = N
 # --------------------------------------------------------------------------------------------
 # Zero-initialised scratch that single-launch reductions leave zero again (last-workgroup tickets, the MSE partials): one set per
 # OWNER.  Launches of one owner are ordered on one stream; two owners in flight at once (an autograph replay overlapping a TrainStep, two
-# steps on two streams) must not share a ticket, so TrainStep / autograph entries / rollout runners run their launches inside
+# steps on two streams) must not share a ticket, so TrainStep / autograph entries run their launches inside
 # `with ops.scratch_owner(their dict)`; everything else shares the per-device default set (one stream at a time per device).
 _SCRATCH_DEFAULT: dict = {}
 _SCRATCH_STACK: list = []
@@ -2333,7 +2335,7 @@ class _NormedSwiGLUFFN(torch.autograd.Function):
             P = int(lib.gaot_rmsnorm_bwd_partials(M))
             part = torch.empty(P, K, device=xm.device, dtype=torch.float32)
             dxw = _want_word(xm.device)
-            split = _split_for_narrow_output(M, K, 2 * F)
+            split = _split_for_narrow_output(M, K, 2 * F, lambda: weight_operand(w13, False)[1] is not None)
             dd = d if ldd == K else d.contiguous()
             if split > 1 and K in (256, 512):
                 w13c, ldw13 = _rowmajor(w13)

@@ -121,7 +121,14 @@ int gaot_gemm_path(const gaot_gemm_desc* d);
  * by the power of two its magnitude word `absmax` selects, and writes piece q (0: h = rn16(s x), 1: m = rn16(s x - h)) of element (r, c)
  * to planes_k[r * 2 cols + (c / 16) * 32 + q * 16 + c % 16] (as stored: the k-contiguous B operand of x W^T, ld_bplanes = 2 cols) and to
  * planes_t[c * 2 rows + (r / 16) * 32 + q * 16 + r % 16] (transposed: the k-contiguous B operand of the input-gradient product dY W,
- * ld_bplanes = 2 rows); either may be NULL.  2 rows cols 16-bit words each; rows, cols multiples of 16. */
+ * ld_bplanes = 2 rows); either may be NULL.  2 rows cols 16-bit words each; rows, cols multiples of 16.
+ * The launch also writes the planes' RANGE VERDICT into the two floats that follow the head of the word's FIRST slot: float [1] (rows of the
+ * matrix as stored) and float [2] (its columns) = the eighth-largest, over the 64-wide groups of a 64 x 64 tile, of log2(tensor maximum /
+ * group maximum), maximised over tiles (an atomic max on the float's bits).  The fp16-piece tile kernels read both beside b_planes: a product
+ * whose operands' spread exceeds what one power of two per tensor carries is computed again on the fp32 MFMA (csrc/gemm_split.hip).  They
+ * must be ZERO before the launch -- zero the whole first slot line together with the slot heads; gaot_absmax_grouped never touches them -- and
+ * a word that is reused for another tensor must be zeroed again: stale verdicts cause needless second passes, garbage there is read as a
+ * (clamped) number of binades. */
 typedef struct gaot_f16_planes_item {
     const float* src; int64_t ld; int32_t rows, cols; const float* absmax; void* planes_k; void* planes_t;
 } gaot_f16_planes_item;
@@ -189,6 +196,19 @@ typedef struct gaot_union_part {
 int gaot_union_compose(const gaot_union_part* parts_dev, int32_t n_parts, int32_t q_each, int32_t n_src_each, int32_t dim_src,
                        int32_t dim_dst, int32_t e_cap, int32_t* index32, int32_t* edge_query, int32_t* t_edge, int32_t* splits32,
                        int32_t* t_splits, float* src, float* dst, int32_t* e_real, gaot_stream_t stream);
+/* Training-time neighbour sub-sampling on the device (edge_drop.py:54-99: 'ratio' = mode 1 keeps every edge with probability sample_ratio,
+ * 'max_neighbors' = mode 2 keeps a uniformly random subset of max_neighbors edges of every row that has more; the reference draws with torch's
+ * generator and rebuilds the CSR with boolean indexing / bincount / cumsum per step).  Here: a compaction of a plan's arrays (int32 CSR +
+ * transposed CSR as gaot_csr_prepare / gaot_csr_transpose / gaot_union_compose leave them; e_real_in = that plan's device edge count or NULL
+ * for E) into out_* buffers of the SAME capacity E, *e_real_out = the kept count, pads as gaot_union_compose writes them.  Nothing about the
+ * draw is a launch argument: `seed` is a device word (gaot_attention_seed_next advances it), so a captured step draws anew on every replay.
+ * Both CSRs stay sorted (order-preserving compaction).  scratch: gaot_edge_drop_scratch(E) int32. */
+int64_t gaot_edge_drop_scratch(int32_t E);
+int gaot_edge_drop(const int32_t* index32, const int32_t* edge_query, const int32_t* t_edge, const int32_t* splits32,
+                   const int32_t* t_splits, int32_t Q, int32_t n_src, int32_t E, const int32_t* e_real_in, int32_t mode,
+                   float sample_ratio, int32_t max_neighbors, const uint64_t* seed, int32_t* out_index, int32_t* out_edge_query,
+                   int32_t* out_t_edge, int32_t* out_splits, int32_t* out_t_splits, int32_t* e_real_out, int32_t* scratch,
+                   gaot_stream_t stream);
 /* out[e] = 1 / max(deg(query(e)), 1) -- the 'mean' reduction of agno.py:264 as a per-edge scale -- and 0 for e >= *e_real (e_real may be NULL) */
 int gaot_edge_inv_degree(const int32_t* splits32, const int32_t* edge_query, int32_t E, const int32_t* e_real, float* out,
                          gaot_stream_t stream);

@@ -21,7 +21,7 @@ from types import SimpleNamespace as NS
 import pytest
 import torch
 
-from tests._golden import rel_l2
+from tests._golden import fp32_noise, rel_l2, unfloored_ratio
 from tests._workloads import grid, naca_points, shell_points, uniform_points
 
 pytestmark = pytest.mark.gpu
@@ -52,8 +52,14 @@ def csr_dict(c):
     return {"neighbors_index": c[0].to(dev()), "neighbors_row_splits": c[1].to(dev())}
 
 
-def grad_errors(model, grads_ref):
-    """per-tensor rel-L2 of the gradients; the denominator is floored at 1e-3 of the largest reference gradient norm"""
+def grad_errors(model, grads_ref, noise=None):
+    """per-tensor error of the gradients, NO floor on the denominator (tests/_golden.py `unfloored_ratio`): with `noise` = the reference's own
+    fp32 rounding per tensor (`fp32_noise`) a tensor's figure is GRAD_TOL x (its error / its bar), the bar being max(GRAD_TOL x its norm,
+    3 x its fp32 rounding): for every tensor larger than its rounding that IS its relative L2 error; `< GRAD_TOL` passes.
+    noise=None (comparisons against a float64 evaluation that carry their own per-tensor bar): plain relative L2, floored as in rounds 1-5."""
+    if noise is not None:
+        got = {k: prm.grad for k, prm in model.named_parameters()}
+        return {k: GRAD_TOL * v for k, v in unfloored_ratio(got, {k: grads_ref[k] for k in got}, noise, GRAD_TOL).items()}
     top = max(float(g.double().norm()) for g in grads_ref.values())
     out = {}
     for k, prm in model.named_parameters():
@@ -63,8 +69,9 @@ def grad_errors(model, grads_ref):
     return out
 
 
-def check_step(model, oracle_out, fwd_kwargs, p, tgt, what=""):
-    """one eager forward + MSE + backward of the HIP path against (loss, grads, pred) of the oracle"""
+def check_step(model, oracle_out, fwd_kwargs, p, tgt, what="", noise=None):
+    """one eager forward + MSE + backward of the HIP path against (loss, grads, pred) of the oracle; `noise` = fp32_noise(...) of the same step"""
+    assert noise is not None, "check_step: pass noise=fp32_noise(sd, ocfg, batch, grads) (gradients are compared without a floor)"
     from gaot_amd import ops
     loss_ref, grads_ref, pred_ref = oracle_out
     model.zero_grad(set_to_none=True)
@@ -74,7 +81,7 @@ def check_step(model, oracle_out, fwd_kwargs, p, tgt, what=""):
     torch.cuda.synchronize()
     e_out = rel_l2(pred.detach().cpu(), pred_ref)
     e_loss = abs(float(loss.detach()) - float(loss_ref)) / abs(float(loss_ref))
-    errs = grad_errors(model, grads_ref)
+    errs = grad_errors(model, grads_ref, noise)
     worst = max(errs, key=errs.get)
     print(f"[{what}] out rel-L2 {e_out:.2e}  loss rel {e_loss:.2e}  worst grad rel-L2 {errs[worst]:.2e} ({worst})")
     assert e_out < OUT_TOL, (what, e_out)
@@ -106,8 +113,10 @@ def c2():
     # kernels' rounding from the fp32 reference's own
     dbl = lambda v: v.double() if torch.is_tensor(v) and v.is_floating_point() else v
     _, gradsd, _, _, predd = O.train_step({k: dbl(v) for k, v in sd.items()}, ocfg, {k: dbl(v) for k, v in batch.items()}, return_pred=True)
+    noise = {k: float((grads[k].double() - gradsd[k]).norm()) for k in gradsd}          # the reference's own fp32 rounding per tensor
+    noise64 = {k: max(noise[k], float((grads64[k].double() - gradsd[k]).norm())) for k in gradsd}
     return NS(sd=sd, lat=lat, x=x, p=p, t=t, enc=enc, dec=dec, loss=loss, grads=grads, new_sd=new_sd, pred=pred,
-              loss64=loss64, grads64=grads64, new_sd64=new_sd64, pred64=pred64, gradsd=gradsd, predd=predd)
+              loss64=loss64, grads64=grads64, new_sd64=new_sd64, pred64=pred64, gradsd=gradsd, predd=predd, noise=noise, noise64=noise64)
 
 
 def _c2_model(c2):
@@ -136,12 +145,11 @@ def test_c2_bench_config_forward_loss_grads_vs_oracle(c2, mode):
     try:
         m = _c2_model(c2)
         kw = dict(latent_tokens_coord=c2.lat.to(dev()), xcoord=c2.x.to(dev()))
-        check_step(m, (c2.loss64, c2.grads64, c2.pred64), kw, c2.p.to(dev()), c2.t.to(dev()), f"C2 {mode} vs oracle(f64 statistics)")
+        check_step(m, (c2.loss64, c2.grads64, c2.pred64), kw, c2.p.to(dev()), c2.t.to(dev()), f"C2 {mode} vs oracle(f64 statistics)", noise=c2.noise64)
         e_out = rel_l2(m(pndata=c2.p.to(dev()), **kw).detach().cpu(), c2.pred)
-        errs = grad_errors(m, c2.grads)
+        errs = grad_errors(m, c2.grads, c2.noise)
         top = max(float(g.double().norm()) for g in c2.grads.values())
-        own = {k: float((c2.grads[k].double() - c2.grads64[k].double()).norm()) / max(float(c2.grads[k].double().norm()), 1e-3 * top)
-               for k in STATS_GATED}
+        own = {k: float((c2.grads[k].double() - c2.grads64[k].double()).norm()) / float(c2.grads[k].double().norm()) for k in STATS_GATED}
         plain = {k: v for k, v in errs.items() if k not in STATS_GATED}
         worst = max(plain, key=plain.get)
         print(f"[C2 {mode} vs plain fp32 oracle] out rel-L2 {e_out:.2e}  worst grad rel-L2 {plain[worst]:.2e} ({worst}); statistics-gated: "
@@ -189,9 +197,13 @@ def test_c2_default_gradients_stay_within_the_reference_fp32_rounding(c2):
         pred = m(pndata=c2.p.to(dev()), latent_tokens_coord=c2.lat.to(dev()), xcoord=c2.x.to(dev()))
     ts._forward_backward()
     torch.cuda.synchronize()
-    hip = grad_errors(m, c2.gradsd)
-    topd = max(float(g.norm()) for g in c2.gradsd.values())
-    own = {k: float((c2.grads[k].double() - g).norm()) / max(float(g.norm()), 1e-3 * topd) for k, g in c2.gradsd.items()}
+    # per tensor, relative to ITS OWN norm (no floor): the HIP path's distance from float64 against the fp32 oracle's
+    named = dict(m.named_parameters())
+    nrm = {k: float(g.norm()) for k, g in c2.gradsd.items()}
+    topd = max(nrm.values())
+    rel = lambda a, k: float((a.detach().cpu().double() - c2.gradsd[k]).norm()) / max(nrm[k], 1e-9 * topd)
+    hip = {k: rel(named[k].grad if named[k].grad is not None else torch.zeros_like(named[k]), k) for k in c2.gradsd}
+    own = {k: rel(c2.grads[k], k) for k in c2.gradsd}
     e_out = float((pred.detach().cpu().double() - c2.predd).norm() / c2.predd.norm())
     ratio = {k: hip[k] / (3 * own[k] + 1e-6) for k in hip}
     worst = max(ratio, key=ratio.get)
@@ -291,7 +303,7 @@ def test_c3_naca_vx_degree_skew_vs_oracle():
     model.to(dev()).train()
     kw = dict(latent_tokens_coord=lat.to(dev()), xcoord=x.to(dev()),
               encoder_nbrs=[[csr_dict(c) for c in row] for row in enc], decoder_nbrs=[[csr_dict(c) for c in row] for row in dec])
-    check_step(model, (loss, grads, pred), kw, p.to(dev()), tgt.to(dev()), f"C3 vx B=4 max degree {int(deg.max())}")
+    check_step(model, (loss, grads, pred), kw, p.to(dev()), tgt.to(dev()), f"C3 vx B=4 max degree {int(deg.max())}", noise=fp32_noise(sd, ocfg, batch, grads))
     # a re-shuffled batch (what a shuffling DataLoader hands over next step): permuted samples give permuted outputs
     perm = [2, 0, 3, 1]
     kw2 = dict(latent_tokens_coord=kw["latent_tokens_coord"], xcoord=x[perm].to(dev()),
@@ -317,7 +329,8 @@ def test_c3_named_size_batch16_of_8192_nodes_vs_oracle():
     model.to(dev()).train()
     kw = dict(latent_tokens_coord=lat.to(dev()), xcoord=x.to(dev()),
               encoder_nbrs=[[csr_dict(c) for c in row] for row in enc], decoder_nbrs=[[csr_dict(c) for c in row] for row in dec])
-    check_step(model, (loss, grads, pred), kw, p.to(dev()), tgt.to(dev()), f"C3 vx B=16 x 8192, {E} encoder edges, max degree {int(deg.max())}")
+    check_step(model, (loss, grads, pred), kw, p.to(dev()), tgt.to(dev()), f"C3 vx B=16 x 8192, {E} encoder edges, max degree {int(deg.max())}",
+               noise=fp32_noise(sd, ocfg, batch, grads))
     from gaot_amd.trainer import TrainStep
     ts = TrainStep(model, lr=8e-4, weight_decay=1e-5, use_graph=True)
     ts.bind(p.to(dev()), tgt.to(dev()), **kw)
@@ -366,7 +379,7 @@ def test_c3_max_neighbors_sampling_on_gpu(vx, monkeypatch):
     loss_ref, grads_ref, _, _, pred_ref = O.train_step(sd, ocfg, batch, return_pred=True)
     assert rel_l2(pred.detach().cpu(), pred_ref) < OUT_TOL
     assert abs(float(loss) - float(loss_ref)) < LOSS_TOL * abs(float(loss_ref))
-    errs = grad_errors(model, grads_ref)
+    errs = grad_errors(model, grads_ref, fp32_noise(sd, ocfg, batch, grads_ref))
     assert max(errs.values()) < GRAD_TOL, max(errs, key=errs.get)
     # TrainStep notices the sampling and stays eager (a captured graph would replay one fixed draw)
     from gaot_amd.trainer import TrainStep
@@ -422,7 +435,7 @@ def test_c3_ratio_sampling_on_gpu(vx, monkeypatch):
     loss_ref, grads_ref, _, _, pred_ref = O.train_step(sd, ocfg, batch, return_pred=True)
     assert rel_l2(pred.detach().cpu(), pred_ref) < OUT_TOL
     assert abs(float(loss) - float(loss_ref)) < LOSS_TOL * abs(float(loss_ref))
-    errs = grad_errors(model, grads_ref)
+    errs = grad_errors(model, grads_ref, fp32_noise(sd, ocfg, batch, grads_ref))
     assert max(errs.values()) < GRAD_TOL, max(errs, key=errs.get)
     # a second pass draws another subset; eval mode draws none (the full graph: edge_drop.py `if not training`)
     with torch.no_grad():
@@ -527,11 +540,11 @@ def test_c1_poisson_1k_nodes_batch4_many_empty_tokens():
     enc, dec = [O.radius_csr(x, lat, 0.033)], [O.radius_csr(lat, x, 0.033)]
     deg = enc[0][1][1:] - enc[0][1][:-1]
     assert 0.35 < float((deg == 0).float().mean()) < 0.5
-    loss, grads, _, _, pred = O.train_step(sd, ocfg, dict(latent=lat, xcoord=x, pndata=p, target=tgt, encoder_nbrs=enc, decoder_nbrs=dec),
-                                           return_pred=True)
+    batch = dict(latent=lat, xcoord=x, pndata=p, target=tgt, encoder_nbrs=enc, decoder_nbrs=dec)
+    loss, grads, _, _, pred = O.train_step(sd, ocfg, batch, return_pred=True)
     model.to(dev()).train()
     kw = dict(latent_tokens_coord=lat.to(dev()), xcoord=x.to(dev()), encoder_nbrs=[csr_dict(enc[0])], decoder_nbrs=[csr_dict(dec[0])])
-    check_step(model, (loss, grads, pred), kw, p.to(dev()), tgt.to(dev()), "C1 1k nodes B=4")
+    check_step(model, (loss, grads, pred), kw, p.to(dev()), tgt.to(dev()), "C1 1k nodes B=4", noise=fp32_noise(sd, ocfg, batch, grads))
 
 
 @pytest.mark.parametrize("n_points", [16384, 65536])
@@ -565,7 +578,8 @@ def test_c5_3d_cloud_4096_tokens_headdim48(n_points):
     torch.cuda.synchronize()
     assert rel_l2(out.detach().cpu(), pred) < OUT_TOL
     assert abs(float(l.detach()) - float(loss)) < LOSS_TOL * abs(float(loss))
-    e32, e64 = grad_errors(model, grads), grad_errors(model, grads64)
+    noise = {k: float((grads[k].double() - grads64[k]).norm()) for k in grads64}
+    e32, e64 = grad_errors(model, grads, noise), grad_errors(model, grads64, noise)
     worst = max(e32, key=lambda k: min(e32[k], e64[k]))
     print(f"[C5 3-D {n_points} points, {int(enc[0][0].numel())} edges, 4096 tokens head_dim 48] worst gradient tensor {worst}: {e32[worst]:.2e} vs the fp32 oracle, {e64[worst]:.2e} vs its float64 evaluation; "
           + ", ".join(f"{k.split('.')[0][:3]}.{k.split('.')[-1][0]} {e32[k]:.1e}/{e64[k]:.1e}" for k in STATS_GATED))
@@ -951,7 +965,7 @@ def test_c4_ns_gauss_16k_pair_step_and_10_step_rollout_vs_oracle():
     l = ops.mse_loss(out, tgt.to(dev()))
     l.backward()
     assert rel_l2(out.detach().cpu(), pred) < OUT_TOL and abs(float(l.detach()) - float(loss)) < LOSS_TOL * abs(float(loss))
-    errs = grad_errors(model, grads)
+    errs = grad_errors(model, grads, fp32_noise(sd, ocfg_pre, dict(latent=lat, xcoord=x, pndata=p, target=tgt, encoder_nbrs=enc, decoder_nbrs=dec), grads))
     gated = ("encoder.geoembed.mlp.0.weight", "encoder.geoembed.mlp.0.bias", "decoder.geoembed.mlp.0.weight", "decoder.geoembed.mlp.0.bias")
     assert max(v for k, v in errs.items() if k not in gated) < GRAD_TOL
     assert max(errs[k] for k in gated) < 1e-3          # statistics-gated tensors: the reference's own fp32 conditioning (see the C2 test)
@@ -1012,12 +1026,12 @@ def test_head_dim_128_model_vs_oracle():
     lat, x = grid([16, 16]), uniform_points(900, 2, g)
     p, tgt = torch.randn(2, 900, 2, generator=g), torch.randn(2, 900, 1, generator=g)
     enc, dec = [O.radius_csr(x, lat, 0.12)], [O.radius_csr(lat, x, 0.12)]
-    loss, grads, _, _, pred = O.train_step(sd, ocfg, dict(latent=lat, xcoord=x, pndata=p, target=tgt, encoder_nbrs=enc, decoder_nbrs=dec),
-                                           return_pred=True)
+    batch = dict(latent=lat, xcoord=x, pndata=p, target=tgt, encoder_nbrs=enc, decoder_nbrs=dec)
+    loss, grads, _, _, pred = O.train_step(sd, ocfg, batch, return_pred=True)
     model.to(dev()).train()
     assert model.processor.blocks_in_order()[0].attn.head_dim == 128
     kw = dict(latent_tokens_coord=lat.to(dev()), xcoord=x.to(dev()), encoder_nbrs=[csr_dict(enc[0])], decoder_nbrs=[csr_dict(dec[0])])
-    check_step(model, (loss, grads, pred), kw, p.to(dev()), tgt.to(dev()), "head_dim 128")
+    check_step(model, (loss, grads, pred), kw, p.to(dev()), tgt.to(dev()), "head_dim 128", noise=fp32_noise(sd, ocfg, batch, grads))
 
 
 @pytest.mark.parametrize("graph", [False, True])

@@ -155,6 +155,27 @@ def test_bench_plain_command_self_launches_two_ranks():
     assert line["comm"]["n_ranks_seen"] == 2 and line["comm"]["param_checksums_identical"] is True
 
 
+def test_bench_plain_command_eight_ranks_on_one_gpu():
+    """the driver's 8-GPU command shape on ONE GPU (eight processes share cuda:0, gloo for the exchange): `python bench.py --gpus 8` must
+    come back with one JSON line of eight ranks, identical parameters on every rank after the timed steps, the per-slice exchange and the
+    exposed communication printed -- so the first run on a real 8-GPU node cannot fail on plumbing (rendezvous, rank -> device, the staged
+    backward's two stage groups, max-over-ranks timing, whole-job throughput)."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update({"GAOT_BENCH_FORCE_DEVICE": "0", "GAOT_BENCH_BACKEND": "gloo"})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "2"],
+                       capture_output=True, text=True, timeout=1500, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["config"]["global_batch"] == 64 and line["value"] > 0
+    assert line["comm"]["n_ranks_seen"] == 8 and line["comm"]["param_checksums_identical"] is True
+    assert "exposed_ms_per_step" in line["comm"] and len(line["comm"]["slices"]) == len(line["config"]["stage_groups"]) == 2
+    assert abs(line["value"] - 64 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
 def test_bench_two_gpus_rccl_line():
     """bench.py exactly as the driver launches it for N = 2: one JSON line with n_gpus 2, weak scaling, and the `comm` object
