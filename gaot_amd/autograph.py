@@ -25,7 +25,7 @@ arrays from the static coordinate buffers.  A shuffling loader (the reference's 
 third step of each bucket on -- a handful of buckets per dataset -- whether the per-sample dicts are kept on the device (their plans are built
 once) or uploaded anew every step (their plans are built per step, without a host synchronisation).
 
-Not eligible (the eager HIP path runs as before): evaluation / no_grad, neighbour sub-sampling, node_embedding, fx coordinates with
+Not eligible (the eager HIP path runs as before): evaluation / no_grad, node_embedding, fx coordinates with
 caller-supplied neighbour lists, pndata that requires grad, host tensors, or `model.auto_graph = False` / GAOT_AUTO_GRAPH=0.
 trainer.TrainStep switches it off for its model (it captures the whole step itself).
 """
@@ -69,7 +69,7 @@ def eligible(model, latent, xcoord, pndata, query_coord, encoder_nbrs, decoder_n
     if torch.cuda.is_current_stream_capturing():
         return False
     for side in (model.encoder, model.decoder):
-        if side.sampling_strategy is not None or side.node_embedding or bool(side.precompute_edges) != vx:
+        if side.node_embedding or bool(side.precompute_edges) != vx:
             return False
     return True
 

@@ -124,10 +124,10 @@ class _MAGNOBase(nn.Module):
     MAX_STATIC_UNIONS = 12
 
     def vx_static_ok(self, feats: torch.Tensor) -> bool:
-        """training passes over caller-supplied per-sample graphs (static_trainer.py:180-202) without neighbour sub-sampling or encoded kernel
-        coordinates; everything else (evaluation, rollouts, module-owned lists) keeps the composed unions of plan.merged_geometry"""
+        """training passes over caller-supplied per-sample graphs (static_trainer.py:180-202) without encoded kernel coordinates; everything
+        else (evaluation, rollouts, module-owned lists) keeps the composed unions of plan.merged_geometry"""
         return (_plan.VX_STATIC and feats.is_cuda and torch.is_grad_enabled() and self.training and bool(self.precompute_edges)
-                and self.sampling_strategy is None and not self.node_embedding)
+                and not self.node_embedding)
 
     def vx_unions(self, nbrs, src: torch.Tensor, dst: torch.Tensor, B: int, load: bool = True):
         """the static union of every scale for this batch, its table uploaded (not capturable).  src / dst: [B, n, d] or [n, d] coordinates.
@@ -173,8 +173,15 @@ class _MAGNOBase(nn.Module):
             agno @ (W Wr1)^T + (rowb @ W^T + b)
         and the [B, n_dst, C] recovery output (33.5 MB at 16k nodes x 8) is never produced."""
         nb = neighbors
-        if drop:
-            nb = apply_edge_drop_csr(neighbors, self.sampling_strategy, self.max_neighbors, self.sample_ratio, self.training)
+        if drop and self.training and self.sampling_strategy is not None:
+            if src_coord.is_cuda:
+                # neighbour sub-sampling on the device: the sub-sampled graph lives in static buffers of the full graph's capacity, re-drawn per
+                # pass by kernels with a device-resident seed (plan.DropPlan) -- no host value depends on the draw, a captured step draws anew
+                base = _plan.plan_for(neighbors, src_coord.shape[0])
+                dp = _plan.dropped_plan(base, self.sampling_strategy, self.max_neighbors, self.sample_ratio)
+                nb = neighbors if dp is base else dp.neighbors
+            else:
+                nb = apply_edge_drop_csr(neighbors, self.sampling_strategy, self.max_neighbors, self.sample_ratio, self.training)
         proj = rowb = w_agno = kvals = None
         if self.use_geoembed:
             w = self.recovery.fcs[0].weight.squeeze(-1)                                             # [C, 2C]
@@ -248,12 +255,18 @@ class _MAGNOBase(nn.Module):
                     if mg.n_src != feats.shape[1]:
                         raise ValueError("vx mode needs the same number of source / query points in every sample of a batch")
                     mg.refresh()
-                    stats = mg.geo_stats() if (self.use_geoembed and self.geoembed.method == 'statistical') else None
+                    pl, nbu = mg.plan, mg.neighbors
+                    if self.sampling_strategy is not None:
+                        # drawn per edge / per row, so drawing on the union IS drawing per sample (magno.py:372-378); the statistics of the
+                        # sub-sampled graph are standardised per sample (gemb.py:164-169) like the full graph's
+                        pl = _plan.dropped_plan(mg.plan, self.sampling_strategy, self.max_neighbors, self.sample_ratio)
+                        nbu = mg.neighbors if pl is mg.plan else pl.neighbors
+                    stats = pl.geo_stats(mg.src, mg.dst, groups=B) if (self.use_geoembed and self.geoembed.method == 'statistical') else None
                     flat = feats.reshape(1, B * feats.shape[1], feats.shape[2])
                     if lift is not None:
-                        out = self._transform(mg.src, mg.dst, None, mg.neighbors, stats, head=head, lift=(flat, lift[1], lift[2]), drop=False)
+                        out = self._transform(mg.src, mg.dst, None, nbu, stats, head=head, lift=(flat, lift[1], lift[2]), drop=False)
                     else:
-                        out = self._transform(mg.src, mg.dst, flat, mg.neighbors, stats, head=head, drop=False)
+                        out = self._transform(mg.src, mg.dst, flat, nbu, stats, head=head, drop=False)
                     per_scale.append(out.reshape(B, mg.n_dst, out.shape[-1]))
                     continue
                 srcs = [src[b] if src.ndim == 3 else src for b in range(B)]

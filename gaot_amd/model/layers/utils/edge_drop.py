@@ -1,7 +1,9 @@
-"""Training-time neighbour sub-sampling (edge_drop.py:8-106 semantics), vectorised on device.
+"""Training-time neighbour sub-sampling (edge_drop.py:8-106 semantics): the reference's FUNCTION, for callers that want a CSR dict back.
 
-Off by default (MAGNOConfig.sampling_strategy=None).  Produces a fresh CSR dict, so the GNO kernels see it as a
-new geometry (a new GeometryPlan per step); it stays a host-side torch pre-step."""
+Off by default (MAGNOConfig.sampling_strategy=None).  The function returns tensors whose sizes depend on the draw, so it reads sizes back to
+the host; the MODEL does not call it on the GPU: MAGNO's training passes draw on the device into static buffers with a device-resident seed
+(plan.DropPlan, csrc/edge_drop.hip: no host value depends on the draw, a captured step draws a fresh subset on every replay).  This function
+serves host tensors (CPU plumbing tests) and vx batches that cannot use static unions (node_embedding)."""
 from typing import Dict, Optional
 
 import torch

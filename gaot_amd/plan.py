@@ -409,13 +409,16 @@ def edge_bucket(E: int) -> int:
 
 
 class _StaticPlan(GeometryPlan):
-    """The plan of a StaticUnion: every array is a static buffer, (re)computed by StaticUnion.refresh() -- launches a captured step replays."""
+    """A plan whose arrays are STATIC buffers rewritten in place by device kernels (a StaticUnion re-composed from its table, a DropPlan re-drawn):
+    launches a captured step replays.  Geometry-derived arrays (kernel-MLP rows, cosine weights, statistics, ...) are static buffers too, computed on
+    REQUEST, once per version of the plan's arrays (`touch()` after every rewrite): in program order, so inside a capture they become graph nodes
+    right where the eager pass would launch them.  The coordinates are whatever the caller passes at that moment (a union passes its own stacked
+    buffers; a fixed mesh's coordinate tensors may be new objects every step)."""
 
-    def __init__(self, union: "StaticUnion"):
+    def __init__(self, Q: int, E: int, n_src: int, device):
         super().__init__(None, None, 0)
-        u = union
-        dev = u.device
-        self.Q, self.E, self.n_src = u.B * u.n_dst, u.e_cap, u.B * u.n_src
+        self.Q, self.E, self.n_src = int(Q), int(E), int(n_src)
+        dev = device
         self.index = torch.zeros(self.E, dtype=torch.int32, device=dev)
         self.edge_query = torch.zeros(self.E, dtype=torch.int32, device=dev)
         self.t_edge = torch.zeros(self.E, dtype=torch.int32, device=dev)
@@ -425,29 +428,24 @@ class _StaticPlan(GeometryPlan):
         self.max_deg = self.max_t_deg = None          # unknown on the host: the edge-partitioned kernels serve any degree distribution
         self._src_id = None
         self._coord_cache, self._groups, self.epoch = {}, {}, 0
-        self._union = union
-        self._arrays: "OrderedDict[str, tuple]" = OrderedDict()      # name -> (value, compute): recomputed by every refresh, in this order
+        self._version = 0
+        self._arrays: Dict[str, list] = {}      # name -> [value, version it was computed at]
+
+    def touch(self):
+        """the plan's arrays were rewritten: every derived array is stale"""
+        self._version += 1
 
     def _static(self, name, alloc, compute):
         ent = self._arrays.get(name)
         if ent is None:
             if torch.cuda.is_current_stream_capturing():
-                raise RuntimeError(f"gaot_amd: array {name!r} of a static union requested for the first time inside a graph capture "
+                raise RuntimeError(f"gaot_amd: array {name!r} of a static plan requested for the first time inside a graph capture "
                                    "(the warm-up passes must run the same model path)")
-            ent = (alloc(), compute)
-            self._arrays[name] = ent
+            ent = self._arrays[name] = [alloc(), -1]
+        if ent[1] != self._version:
             compute(ent[0])
+            ent[1] = self._version
         return ent[0]
-
-    def refresh_derived(self):
-        for val, compute in self._arrays.values():
-            compute(val)
-
-    def _own(self, src, qry):
-        u = self._union
-        if src.data_ptr() != u.src.data_ptr() or qry.data_ptr() != u.dst.data_ptr():
-            raise RuntimeError("gaot_amd: a static union computes its geometry arrays from its own stacked coordinates only")
-        return u.src, u.dst
 
     # ---- overrides: no identity-keyed caches, no host-side sizes
     row_order = None
@@ -472,25 +470,25 @@ class _StaticPlan(GeometryPlan):
         return self._static("inv_deg", lambda: torch.zeros(self.E, dtype=torch.float32, device=self.splits.device), compute)
 
     def edge_features(self, src, qry):
-        s, q = self._own(src, qry)
+        s, q = src.contiguous(), qry.contiguous()
 
         def compute(feat):
             L.check(L.load().gaot_edge_features(_p(s), _p(q), s.shape[1], _p(self.index), _p(self.edge_query), self.E, _p(feat), None, _stream()),
                     "gaot_edge_features")
-        return self._static("feat", lambda: torch.zeros(self.E, 2 * s.shape[1], device=s.device, dtype=torch.float32), compute)
+        return self._static(f"feat{s.shape[1]}", lambda: torch.zeros(self.E, 2 * s.shape[1], device=s.device, dtype=torch.float32), compute)
 
     def cosine_attention(self, src, qry):
-        s, q = self._own(src, qry)
+        s, q = src.contiguous(), qry.contiguous()
 
         def compute(attn):
             lib = L.load()
             L.check(lib.gaot_edge_attention_cosine(_p(s), _p(q), s.shape[1], _p(self.index), _p(self.splits), self.Q, _p(attn), None, _stream()),
                     "gaot_edge_attention_cosine")
             L.check(lib.gaot_edge_zero_pads(_p(attn), 1, self.E, 1, _p(self.e_dev), self.E, _stream()), "gaot_edge_zero_pads")
-        return self._static("cos", lambda: torch.zeros(self.E, device=s.device, dtype=torch.float32), compute)
+        return self._static(f"cos{s.shape[1]}", lambda: torch.zeros(self.E, device=s.device, dtype=torch.float32), compute)
 
     def geo_stats(self, geom, qry, groups: int = 1):
-        s, q = self._own(geom, qry)
+        s, q = geom.contiguous(), qry.contiguous()
         F = 3 + 2 * s.shape[1]
 
         def alloc():
@@ -500,6 +498,66 @@ class _StaticPlan(GeometryPlan):
             L.check(L.load().gaot_geo_stats(_p(s), _p(q), s.shape[1], _p(self.index), _p(self.splits), self.Q, _p(full[0]), _p(full[1]), None, groups,
                                             _stream()), "gaot_geo_stats")
         return self._static(f"stats{groups}", alloc, compute)[0]
+
+
+DROP_RECORD: Optional[list] = None      # tests: a list here receives (index [kept] int64, row_splits [Q + 1] int64) on the HOST after every draw
+
+
+class DropPlan(_StaticPlan):
+    """Training-time neighbour sub-sampling on the device (reference edge_drop.py:54-99; MAGNOConfig.sampling_strategy 'ratio' / 'max_neighbors'):
+    the sub-sampled graph of `base` -- any plan, also the padded union of a vx batch -- in static buffers of the base's capacity, re-drawn by
+    `redraw()` with a device-resident seed (csrc/edge_drop.hip).  No host value depends on the draw, so a captured step draws a fresh subset on
+    every replay; the kept edge count is `e_dev`, the rest of the buffers are pads (see StaticUnion)."""
+
+    def __init__(self, base: GeometryPlan, strategy: str, max_neighbors, sample_ratio):
+        super().__init__(base.Q, max(base.E, 1), base.n_src, base.splits.device)
+        self.base = base
+        self.mode = {"ratio": 1, "max_neighbors": 2}[strategy]
+        self.max_neighbors = int(max_neighbors or 0)
+        self.sample_ratio = float(sample_ratio or 0.0)
+        dev = base.splits.device
+        self._scratch = torch.zeros(int(L.load().gaot_edge_drop_scratch(self.E)), dtype=torch.int32, device=dev)
+        self._seed = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.neighbors = {"neighbors_index": None, "neighbors_row_splits": None, _PLAN_KEY: self}
+
+    def redraw(self) -> None:
+        from . import ops
+        lib = L.load()
+        b = self.base
+        if b.E == 0:
+            self.splits.zero_(); self.t_splits.zero_(); self.e_dev.zero_()
+            self.touch()
+            return
+        L.check(lib.gaot_attention_seed_next(_p(ops.dropout_state(self.splits.device)), 0x6564676564726f70, _p(self._seed), _stream()), "gaot_attention_seed_next")
+        L.check(lib.gaot_edge_drop(_p(b.index), _p(b.edge_query), _p(b.t_edge), _p(b.splits), _p(b.t_splits), b.Q, b.n_src, b.E, _p(b.e_dev), self.mode,
+                                   self.sample_ratio if self.mode == 1 else 1.0, self.max_neighbors if self.mode == 2 else 1, _p(self._seed),
+                                   _p(self.index), _p(self.edge_query), _p(self.t_edge), _p(self.splits), _p(self.t_splits), _p(self.e_dev), _p(self._scratch),
+                                   _stream()), "gaot_edge_drop")
+        self.touch()
+        if DROP_RECORD is not None and not torch.cuda.is_current_stream_capturing():
+            e = int(self.e_dev.item())
+            DROP_RECORD.append((self.index[:e].long().cpu(), self.splits.long().cpu()))
+
+
+def dropped_plan(base: GeometryPlan, strategy: Optional[str], max_neighbors=None, sample_ratio=None) -> GeometryPlan:
+    """`base` sub-sampled for this training pass (a fresh draw), or `base` itself where the reference returns the graph untouched: no strategy,
+    'ratio' with sample_ratio None or >= 1, 'max_neighbors' without a limit (edge_drop.py:54-58, 74-76)"""
+    if strategy == "ratio":
+        if sample_ratio is None or sample_ratio >= 1.0:
+            return base
+        key = ("ratio", float(sample_ratio))
+    elif strategy == "max_neighbors":
+        if max_neighbors is None:
+            return base
+        key = ("max_neighbors", int(max_neighbors))
+    else:
+        return base
+    drops = base.__dict__.setdefault("_drops", {})
+    dp = drops.get(key)
+    if dp is None:
+        dp = drops[key] = DropPlan(base, strategy, max_neighbors, sample_ratio)
+    dp.redraw()
+    return dp
 
 
 class StaticUnion:
@@ -520,7 +578,7 @@ class StaticUnion:
         self.n_src_each, self.n_dst_each = [n_src] * B, [n_dst] * B
         self.src = torch.zeros(B * n_src, dim_src, device=device, dtype=torch.float32)
         self.dst = torch.zeros(B * n_dst, dim_dst, device=device, dtype=torch.float32)
-        self.plan = _StaticPlan(self)
+        self.plan = _StaticPlan(B * n_dst, int(e_cap), B * n_src, device)
         self.neighbors = {"neighbors_index": None, "neighbors_row_splits": None, _PLAN_KEY: self.plan}
         self.table = torch.zeros(B, 8, dtype=torch.int64, device=device)           # B x gaot_union_part (64 bytes each)
         self._pinned = [torch.zeros(B, 8, dtype=torch.int64).pin_memory() for _ in range(self.RING)]
@@ -573,12 +631,12 @@ class StaticUnion:
         self.load(plans, src_parent, dst_parent)
 
     def refresh(self) -> None:
-        """compose the union from the loaded table and recompute every derived array (capturable: fixed launches, fixed addresses)"""
+        """compose the union from the loaded table (capturable: a fixed launch over fixed addresses); the derived arrays follow on request"""
         pl = self.plan
         L.check(L.load().gaot_union_compose(_p(self.table), self.B, self.n_dst, self.n_src, self.src.shape[1], self.dst.shape[1], self.e_cap,
                                             _p(pl.index), _p(pl.edge_query), _p(pl.t_edge), _p(pl.splits), _p(pl.t_splits), _p(self.src), _p(self.dst),
                                             _p(pl.e_dev), _stream()), "gaot_union_compose")
-        pl.refresh_derived()
+        pl.touch()
 
     def geo_stats(self) -> torch.Tensor:
         return self.plan.geo_stats(self.src, self.dst, groups=self.B)

@@ -339,9 +339,9 @@ class TrainStep:
             self.opt = FlatAdamW(self.bucket, lr=lr, weight_decay=weight_decay)
         else:           # CPU (gloo tests of the data-parallel plumbing): torch's own AdamW, parameters in MODEL order
             self.opt = torch.optim.AdamW(self.bucket.model_order, lr=lr, weight_decay=weight_decay)
-        # per-step random neighbour sub-sampling (MAGNOConfig.sampling_strategy) draws masks and syncs: not capturable
-        sampling = any(getattr(m, "sampling_strategy", None) is not None for m in model.modules())
-        self.use_graph = use_graph and on_gpu and not sampling
+        # (per-step random neighbour sub-sampling, MAGNOConfig.sampling_strategy, is drawn on the device with a device-resident seed --
+        # plan.DropPlan -- so a captured step draws a fresh subset on every replay)
+        self.use_graph = use_graph and on_gpu
         self._graphs: Optional[List[torch.cuda.CUDAGraph]] = None
         self._g_opt: Optional[torch.cuda.CUDAGraph] = None
         self._x = self._y = self._loss = None
@@ -515,8 +515,7 @@ class TrainStep:
 
     def _vx_sides_ok(self) -> bool:
         from . import plan as P
-        return P.VX_STATIC and all(bool(m.precompute_edges) and m.sampling_strategy is None and not m.node_embedding
-                                   for m in (self.model.encoder, self.model.decoder))
+        return P.VX_STATIC and all(bool(m.precompute_edges) and not m.node_embedding for m in (self.model.encoder, self.model.decoder))
 
     MAX_GRAPH_SETS = 6      # vx: captured steps kept (one per combination of the unions' edge buckets), least recently used first out
 
@@ -587,7 +586,7 @@ class TrainStep:
         if xcoord is not None or encoder_nbrs is not None or decoder_nbrs is not None:
             if not self._vx:
                 raise RuntimeError("TrainStep.step: a new geometry per step needs a vx binding (xcoord [B, N, d] with encoder_nbrs / decoder_nbrs, "
-                                   "no neighbour sub-sampling, no node_embedding); bind() again for another fixed geometry")
+                                   "no node_embedding); bind() again for another fixed geometry")
             if xcoord is not None:
                 self._kwargs["xcoord"].copy_(xcoord, non_blocking=True)
             if encoder_nbrs is not None:

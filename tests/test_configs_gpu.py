@@ -338,6 +338,24 @@ def test_c3_named_size_batch16_of_8192_nodes_vs_oracle():
     assert abs(l0 - float(loss)) < LOSS_TOL * abs(float(loss))
 
 
+def _drawn_lists(drawn, vx, B, N, M):
+    """plan.DROP_RECORD entries of ONE training pass (encoder draw, then decoder draw) as the oracle's neighbour lists.  vx: the draw is made on
+    the batch's block-diagonal union (per edge / per row, i.e. per sample); split it back into the per-sample graphs."""
+    assert len(drawn) == 2
+    if not vx:
+        return [drawn[0]], [drawn[1]]
+
+    def split(rec, n_src, q_each):
+        idx, sp = rec
+        out = []
+        for b in range(B):
+            lo, hi = int(sp[b * q_each]), int(sp[(b + 1) * q_each])
+            out.append([(idx[lo:hi] - b * n_src, sp[b * q_each:(b + 1) * q_each + 1] - lo)])
+            assert int(out[-1][0][0].min()) >= 0 and int(out[-1][0][0].max()) < n_src
+        return out
+    return split(drawn[0], N, M), split(drawn[1], M, N)
+
+
 @pytest.mark.parametrize("vx", [False, True])
 def test_c3_max_neighbors_sampling_on_gpu(vx, monkeypatch):
     """row A12 on the device: training-time neighbour sub-sampling (sampling_strategy='max_neighbors') runs inside the
@@ -349,15 +367,9 @@ def test_c3_max_neighbors_sampling_on_gpu(vx, monkeypatch):
     if not vx:
         x = x[0]
         enc, dec = [enc[0][0]], [dec[0][0]]
+    from gaot_amd import plan as P
     drawn = []
-    real = M.apply_edge_drop_csr
-
-    def recording(nb, *a, **k):
-        out = real(nb, *a, **k)
-        drawn.append((out["neighbors_index"].cpu(), out["neighbors_row_splits"].cpu()))
-        return out
-
-    monkeypatch.setattr(M, "apply_edge_drop_csr", recording)
+    monkeypatch.setattr(P, "DROP_RECORD", drawn)
     model.to(dev()).train()
     todev = (lambda rows: [[csr_dict(c) for c in row] for row in rows]) if vx else (lambda rows: [csr_dict(c) for c in rows])
     kw = dict(latent_tokens_coord=lat.to(dev()), xcoord=x.to(dev()), encoder_nbrs=todev(enc), decoder_nbrs=todev(dec))
@@ -365,15 +377,12 @@ def test_c3_max_neighbors_sampling_on_gpu(vx, monkeypatch):
     pred = model(pndata=p.to(dev()), **kw)
     loss = ops.mse_loss(pred, tgt.to(dev()))
     loss.backward()
-    if vx:                                      # drawn per sample (magno.py:372-378): B encoder graphs, then B decoder graphs
-        assert len(drawn) == 2 * B
-        enc_d, dec_d = [[c] for c in drawn[:B]], [[c] for c in drawn[B:]]
+    enc_d, dec_d = _drawn_lists(drawn, vx, B, N, lat.shape[0])
+    if vx:                                      # drawn on the union = per sample (magno.py:372-378)
         full = torch.cat([e[0][1][1:] - e[0][1][:-1] for e in enc])
         kept = torch.cat([e[0][1][1:] - e[0][1][:-1] for e in enc_d])
     else:
-        assert len(drawn) == 2
-        enc_d, dec_d = [drawn[0]], [drawn[1]]
-        full, kept = enc[0][1][1:] - enc[0][1][:-1], drawn[0][1][1:] - drawn[0][1][:-1]
+        full, kept = enc[0][1][1:] - enc[0][1][:-1], enc_d[0][1][1:] - enc_d[0][1][:-1]
     assert int(full.max()) > 6 and int(kept.max()) == 6 and torch.equal(kept, full.clamp(max=6))
     batch = dict(latent=lat, xcoord=x, pndata=p, target=tgt, encoder_nbrs=enc_d, decoder_nbrs=dec_d)
     loss_ref, grads_ref, _, _, pred_ref = O.train_step(sd, ocfg, batch, return_pred=True)
@@ -381,9 +390,17 @@ def test_c3_max_neighbors_sampling_on_gpu(vx, monkeypatch):
     assert abs(float(loss) - float(loss_ref)) < LOSS_TOL * abs(float(loss_ref))
     errs = grad_errors(model, grads_ref, fp32_noise(sd, ocfg, batch, grads_ref))
     assert max(errs.values()) < GRAD_TOL, max(errs, key=errs.get)
-    # TrainStep notices the sampling and stays eager (a captured graph would replay one fixed draw)
+    # TrainStep keeps its hipGraph: the draw happens on the device inside the captured step, a fresh subset on every replay
+    # (the plain pass's autograd graph must be gone first: its AccumulateGrad nodes live on the default stream and would be pulled into the capture)
     from gaot_amd.trainer import TrainStep
-    assert TrainStep(model, use_graph=True).use_graph is False
+    monkeypatch.setattr(P, "DROP_RECORD", None)
+    del pred, loss
+    model.zero_grad(set_to_none=True)
+    ts = TrainStep(model, lr=0.0, weight_decay=0.0, use_graph=True)
+    assert ts.use_graph is True
+    ts.bind(p.to(dev()), tgt.to(dev()), **kw)
+    losses = [float(ts.step()) for _ in range(4)]
+    assert ts._graphs is not None and len(set(losses)) == 4, losses           # same weights (lr = 0), same batch: only the draw differs
 
 
 @pytest.mark.parametrize("vx", [False, True])
@@ -399,15 +416,9 @@ def test_c3_ratio_sampling_on_gpu(vx, monkeypatch):
     if not vx:
         x = x[0]
         enc, dec = [enc[0][0]], [dec[0][0]]
+    from gaot_amd import plan as P
     drawn = []
-    real = M.apply_edge_drop_csr
-
-    def recording(nb, *a, **k):
-        out = real(nb, *a, **k)
-        drawn.append((out["neighbors_index"].cpu(), out["neighbors_row_splits"].cpu()))
-        return out
-
-    monkeypatch.setattr(M, "apply_edge_drop_csr", recording)
+    monkeypatch.setattr(P, "DROP_RECORD", drawn)
     model.to(dev()).train()
     todev = (lambda rows: [[csr_dict(c) for c in row] for row in rows]) if vx else (lambda rows: [csr_dict(c) for c in rows])
     kw = dict(latent_tokens_coord=lat.to(dev()), xcoord=x.to(dev()), encoder_nbrs=todev(enc), decoder_nbrs=todev(dec))
@@ -415,15 +426,15 @@ def test_c3_ratio_sampling_on_gpu(vx, monkeypatch):
     pred = model(pndata=p.to(dev()), **kw)
     loss = ops.mse_loss(pred, tgt.to(dev()))
     loss.backward()
-    n_graphs = 2 * B if vx else 2
-    assert len(drawn) == n_graphs
+    first = list(drawn)
+    enc_d, dec_d = _drawn_lists(first, vx, B, N, lat.shape[0])
     if vx:
-        enc_d, dec_d = [[c] for c in drawn[:B]], [[c] for c in drawn[B:]]
         full_graphs = [e[0] for e in enc] + [d[0] for d in dec]
+        drawn_graphs = [e[0] for e in enc_d] + [d[0] for d in dec_d]
     else:
-        enc_d, dec_d = [drawn[0]], [drawn[1]]
         full_graphs = [enc[0], dec[0]]
-    for (fi, fs), (ki, ks) in zip(full_graphs, drawn):
+        drawn_graphs = [enc_d[0], dec_d[0]]
+    for (fi, fs), (ki, ks) in zip(full_graphs, drawn_graphs):
         E, Ek = int(fi.numel()), int(ki.numel())
         assert abs(Ek / E - ratio) < 0.03, (Ek, E)                        # ~55 k draws per graph: 3 sigma is 0.006
         assert int(ks[-1]) == Ek and ks.numel() == fs.numel() and bool(((ks[1:] - ks[:-1]) <= (fs[1:] - fs[:-1])).all())
@@ -438,18 +449,30 @@ def test_c3_ratio_sampling_on_gpu(vx, monkeypatch):
     errs = grad_errors(model, grads_ref, fp32_noise(sd, ocfg, batch, grads_ref))
     assert max(errs.values()) < GRAD_TOL, max(errs, key=errs.get)
     # a second pass draws another subset; eval mode draws none (the full graph: edge_drop.py `if not training`)
-    with torch.no_grad():
-        model(pndata=p.to(dev()), **kw)
-    assert len(drawn) == 2 * n_graphs and not torch.equal(drawn[0][1], drawn[n_graphs][1])
+    model(pndata=p.to(dev()), **kw)
+    assert len(drawn) == 4 and not torch.equal(drawn[0][1], drawn[2][1])
     model.eval()
     with torch.no_grad():
         y_eval = model(pndata=p.to(dev()), **kw)
-    assert all(torch.equal(d[0], f[0]) and torch.equal(d[1], f[1]) for d, f in zip(drawn[2 * n_graphs:], full_graphs)) or len(drawn) == 2 * n_graphs
+    assert len(drawn) == 4
     pred_full = O.gaot_forward(sd, ocfg, lat, x, p, encoder_nbrs=enc, decoder_nbrs=dec)
     assert rel_l2(y_eval.cpu(), pred_full) < OUT_TOL
+    # TrainStep keeps its hipGraph: a fresh subset on every replay (same weights, same batch: only the draw moves the loss), about the stated share
     from gaot_amd.trainer import TrainStep
+    monkeypatch.setattr(P, "DROP_RECORD", None)
     model.train()
-    assert TrainStep(model, use_graph=True).use_graph is False
+    del pred, loss          # (the plain pass's autograd graph must be gone: its AccumulateGrad nodes live on the default stream)
+    model.zero_grad(set_to_none=True)
+    ts = TrainStep(model, lr=0.0, weight_decay=0.0, use_graph=True)
+    assert ts.use_graph is True
+    ts.bind(p.to(dev()), tgt.to(dev()), **kw)
+    losses = [float(ts.step()) for _ in range(4)]
+    assert ts._graphs is not None and len(set(losses)) == 4, losses
+    side = model.encoder
+    base = (side._static_unions[next(iter(side._static_unions))].plan if vx else P.plan_for(kw["encoder_nbrs"][0], x.shape[0]))
+    dp = next(iter(base._drops.values()))
+    e_full = sum(int(f[0].numel()) for f in full_graphs[:len(full_graphs) // 2])
+    assert abs(int(dp.e_dev.item()) / e_full - ratio) < 0.03
 
 
 @pytest.mark.parametrize("stress", ["token_1e4", "token_1e6", "channel_1e4", "channel_1e6", "weight_row_1e-6", "all"])
