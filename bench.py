@@ -489,7 +489,7 @@ def secondary_configs(dev, which=("C3", "C4", "C5"), steps: int = 20, warmup: in
         # ---- the reference's variable-coordinate loop (static_trainer.py:180-202 inside optimizers.py:247-257), UNCHANGED -- per-step upload of the
         # fields from host memory, zero_grad, eager call with coordinates and per-sample graphs, nn.MSELoss, backward, torch.optim.AdamW -- under
         # autograph: (a) one fixed batch, (b) a shuffling loader over the resident dataset, (c) the same with the graphs uploaded anew every step
-        # from host memory (what move_to_device does there: new dict objects, new tensors, per-sample plans rebuilt each step)
+        # from host memory (what move_to_device does there: new dict objects, new tensors every step)
         from gaot_amd import ops as _o
         _o.register_grad_slots([], [])
         torch.manual_seed(0)
@@ -533,7 +533,8 @@ def secondary_configs(dev, which=("C3", "C4", "C5"), steps: int = 20, warmup: in
                  "the captured forward re-composes the unions on the device from a per-step table (plan.StaticUnion)"),
                 ("reference_loop_vx_uploaded", [host_batch(draw()) for _ in range(6 + steps)], 6, {"upload": True},
                  "... with the per-sample graphs uploaded anew from host memory every step (move_to_device, static_trainer.py:192-193: 32 new "
-                 "dicts per step): their plans are rebuilt per step (no host synchronisation), the step itself still replays")):
+                 "dicts per step): nothing is built per sample -- the captured forward composes the unions from the raw int64 lists and derives the "
+                 "decoder's transposed CSR on the device; what remains above the shuffled leg is the 64 uploads themselves")):
             dt_, graphed = timed(batches, n_warm, **kw)
             out["C3"][key] = {"value": B / dt_, "unit": "samples/s", "ms_per_step": 1e3 * dt_, "steps": steps, "graphed_steps": graphed,
                               "frac_of_trainstep": (B / dt_) / out["C3"]["samples_per_s"], "what": what}

@@ -66,6 +66,11 @@ class UnionPart(C.Structure):
                 ("e_begin", C.c_int32), ("e_count", C.c_int32)]
 
 
+class UnionPartRaw(C.Structure):
+    """gaot_union_part_raw: one sample of a union composed straight from int64 CSR lists (gaot_union_compose_raw)"""
+    _fields_ = [("index", _i), ("splits", _i), ("src", _f), ("dst", _f), ("e_begin", C.c_int32), ("e_count", C.c_int32), ("reserved", C.c_int64 * 3)]
+
+
 class ColsumItem(C.Structure):
     """gaot_colsum_item: out[n] = sum_m x[m * ld + n]"""
     _fields_ = [("x", _f), ("ld", C.c_int64), ("out", _f), ("M", C.c_int32), ("N", C.c_int32), ("out_cols", C.c_int32), ("out_ld", C.c_int64)]
@@ -96,6 +101,9 @@ PROTOTYPES = {
     "gaot_csr_prepare": (C.c_int, [_i, _i, C.c_int32, C.c_int32, C.c_int32, _i, _i, _i, _i, _s]),
     "gaot_csr_transpose": (C.c_int, [_i, C.c_int32, C.c_int32, _i, _i, _i, _s]),
     "gaot_union_compose": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i, _i, _i, _i, _i, _f, _f, _i, _s]),
+    "gaot_union_compose_raw": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i, _i, _i, _f, _f, _i, _i, _s]),
+    "gaot_csr_transpose_dev_scratch": (C.c_int64, [C.c_int32, C.c_int32]),
+    "gaot_csr_transpose_dev": (C.c_int, [_i, C.c_int32, _i, C.c_int32, _i, _i, _i, _s]),
     "gaot_edge_drop_scratch": (C.c_int64, [C.c_int32]),
     "gaot_edge_drop": (C.c_int, [_i, _i, _i, _i, _i, C.c_int32, C.c_int32, C.c_int32, _i, C.c_int32, C.c_float, C.c_int32, C.c_void_p,
                                  _i, _i, _i, _i, _i, _i, _i, _s]),

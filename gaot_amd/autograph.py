@@ -116,7 +116,7 @@ def _param_list(model):
 
 
 def _key(model, latent, xcoord, pndata, condition, unions=None):
-    comp = None if unions is None else tuple(u.uid for side in unions for u in side)      # vx: the static unions (one per scale and edge bucket)
+    comp = None if unions is None else tuple((u.uid, u.pending_raw) for side in unions for u in side)      # vx: the static unions (one per scale and edge bucket)
     return (tuple(pndata.shape), pndata.dtype, tuple(xcoord.shape), tuple(latent.shape),
             None if condition is None else tuple(condition.shape), pndata.device.index, comp,
             tuple(p.data_ptr() if p.requires_grad else -p.data_ptr() for p in _param_list(model)))      # storage AND trainability

@@ -11,6 +11,7 @@
 //   compact   index', edge_query' at pa[e];  t_edge'[pt[p]] = pa[t_edge[p]];  splits'[r] = pa[splits[r]];  t_splits'[j] = pt[t_splits[j]]
 // Both CSRs stay sorted (a compaction preserves order), so no sort is needed and the backward stays deterministic.
 #include "common.h"
+#include "segsort.h"
 
 namespace gaot {
 
@@ -127,6 +128,69 @@ __global__ void drop_compact_kernel(const int* __restrict__ index, const int* __
     if (i <= n_src) o_tsp[i] = pt[min(tsp[i], E)];
 }
 
+// ---- block-diagonal union straight from the callers' int64 CSR lists (gaot_union_compose_raw) + its transposed CSR with a device-side edge count
+__global__ __launch_bounds__(256) void union_compose_raw_kernel(const gaot_union_part_raw* __restrict__ parts, int B, int Qe, int Se, int dsrc, int ddst,
+                                                                int E_cap, int* __restrict__ index, int* __restrict__ eq, int* __restrict__ splits,
+                                                                float* __restrict__ src, float* __restrict__ dst, int* __restrict__ e_real,
+                                                                int* __restrict__ flag) {
+    __shared__ int begin[1025];
+    for (int b = threadIdx.x; b < B; b += 256) begin[b] = parts[b].e_begin;
+    if (threadIdx.x == 0) begin[B] = parts[B - 1].e_begin + parts[B - 1].e_count;
+    __syncthreads();
+    const int E = min(begin[B], E_cap);
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) *e_real = E;
+    if (i < E_cap) {
+        if (i < E) {
+            int lo = 0, hi = B;                       // begin[lo] <= i < begin[hi]
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (begin[mid] <= (int)i) lo = mid; else hi = mid; }
+            const gaot_union_part_raw& p = parts[lo];
+            const long l = i - begin[lo];
+            const int64_t j = p.index[l];
+            if (j < 0 || j >= Se) atomicOr(flag, 2);          // (clamped: the kernels that run before the host reads the flag stay in bounds)
+            index[i] = (int)(j < 0 ? 0 : (j >= Se ? Se - 1 : j)) + lo * Se;
+            int a = 0, c = Qe;                        // upper_bound(splits, l) - 1: sp[a] <= l < sp[c] on a valid list
+            while (c - a > 1) { const int mid = (a + c) >> 1; if (p.splits[mid] <= l) a = mid; else c = mid; }
+            eq[i] = a + lo * Qe;
+        } else {
+            index[i] = 0; eq[i] = 0;
+        }
+    }
+    const long Qt = (long)B * Qe, St = (long)B * Se;
+    if (i <= Qt) {
+        if (i == Qt) splits[i] = E;
+        else {
+            const gaot_union_part_raw& p = parts[i / Qe];
+            const int r = (int)(i % Qe);
+            const int64_t v = p.splits[r], nx = p.splits[r + 1];
+            if (v < 0 || v > p.e_count || nx < v || (r == 0 && v != 0) || (r == Qe - 1 && nx != p.e_count)) atomicOr(flag, 1);
+            splits[i] = min((int)(v < 0 ? 0 : (v > p.e_count ? p.e_count : v)) + begin[i / Qe], E);
+        }
+    }
+    if (src && i < St * dsrc) { const long r = i / dsrc; src[i] = parts[r / Se].src[(r % Se) * dsrc + i % dsrc]; }
+    if (dst && i < Qt * ddst) { const long r = i / ddst; dst[i] = parts[r / Qe].dst[(r % Qe) * ddst + i % ddst]; }
+}
+__global__ void tdev_zero_kernel(int* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+__global__ void tdev_count_kernel(const int* __restrict__ idx, int E, const int* __restrict__ e_real, int* __restrict__ cnt) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < min(E, *e_real)) atomicAdd(&cnt[idx[e]], 1);
+}
+__global__ void tdev_fill_kernel(const int* __restrict__ idx, int E, const int* __restrict__ e_real, const int* __restrict__ tsp, int* __restrict__ cnt,
+                                 int* __restrict__ tedge) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    if (e < *e_real) {
+        const int j = idx[e];
+        const int slot = atomicSub(&cnt[j], 1) - 1;
+        tedge[tsp[j] + slot] = e;
+    } else {
+        tedge[e] = e;
+    }
+}
+
 }  // namespace gaot
 
 using namespace gaot;
@@ -172,5 +236,44 @@ extern "C" int gaot_edge_drop(const int32_t* index32, const int32_t* edge_query,
     hipLaunchKernelGGL(drop_compact_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ST(stream), index32, edge_query, t_edge, splits32, t_splits, Q, n_src,
                        E, fa, ft, pa, pt, out_index, out_edge_query, out_t_edge, out_splits, out_t_splits, e_real_out);
     GAOT_CHECK_LAUNCH("gaot_edge_drop");
+    return GAOT_OK;
+}
+
+extern "C" int gaot_union_compose_raw(const gaot_union_part_raw* parts_dev, int32_t n_parts, int32_t q_each, int32_t n_src_each, int32_t dim_src,
+                                      int32_t dim_dst, int32_t e_cap, int32_t* index32, int32_t* edge_query, int32_t* splits32, float* src,
+                                      float* dst, int32_t* e_real, int32_t* status_flag, gaot_stream_t stream) {
+    GAOT_REQUIRE(parts_dev && n_parts >= 1 && n_parts <= 1024 && q_each > 0 && n_src_each > 0 && e_cap >= 1 && dim_src >= 0 && dim_dst >= 0,
+                 "union_compose_raw: bad sizes (1 <= n_parts <= 1024, q_each, n_src_each, e_cap > 0)");
+    GAOT_REQUIRE(index32 && edge_query && splits32 && e_real && status_flag, "union_compose_raw: null output pointer");
+    long n = e_cap;
+    const long Qt = (long)n_parts * q_each, St = (long)n_parts * n_src_each;
+    if (Qt + 1 > n) n = Qt + 1;
+    if (src && St * dim_src > n) n = St * dim_src;
+    if (dst && Qt * dim_dst > n) n = Qt * dim_dst;
+    hipLaunchKernelGGL(union_compose_raw_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ST(stream), parts_dev, n_parts, q_each, n_src_each, dim_src,
+                       dim_dst, e_cap, index32, edge_query, splits32, src, dst, e_real, status_flag);
+    GAOT_CHECK_LAUNCH("gaot_union_compose_raw");
+    return GAOT_OK;
+}
+
+extern "C" int64_t gaot_csr_transpose_dev_scratch(int32_t E, int32_t n_src) {
+    return (int64_t)(n_src + 1) + 2L * (cdiv(n_src > 0 ? n_src : 1, SCAN_PER) + 1) + (E > 0 ? E : 1);
+}
+
+extern "C" int gaot_csr_transpose_dev(const int32_t* index32, int32_t E, const int32_t* e_real, int32_t n_src, int32_t* t_splits, int32_t* t_edge,
+                                      int32_t* scratch, gaot_stream_t stream) {
+    GAOT_REQUIRE(index32 && e_real && t_splits && t_edge && scratch && n_src > 0 && E >= 1, "csr_transpose_dev: bad arguments");
+    const int nb = cdiv(n_src, SCAN_PER);
+    int* cnt = scratch;
+    int* bsum = cnt + (n_src + 1);
+    int* sortbuf = bsum + 2 * (nb + 1);
+    hipLaunchKernelGGL(tdev_zero_kernel, dim3(cdiv(n_src + 1, 256)), dim3(256), 0, ST(stream), cnt, n_src + 1);
+    hipLaunchKernelGGL(tdev_count_kernel, dim3(cdiv(E, 256)), dim3(256), 0, ST(stream), index32, E, e_real, cnt);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(nb, 1), dim3(256), 0, ST(stream), cnt, cnt, n_src, bsum, nb);
+    hipLaunchKernelGGL(scan_mid_kernel, dim3(1), dim3(1024), 0, ST(stream), bsum, nb);
+    hipLaunchKernelGGL(scan_final_kernel, dim3(cdiv(n_src + 1, SCAN_PER), 1), dim3(256), 0, ST(stream), cnt, cnt, n_src, bsum, nb, t_splits, t_splits);
+    hipLaunchKernelGGL(tdev_fill_kernel, dim3(cdiv(E, 256)), dim3(256), 0, ST(stream), index32, E, e_real, t_splits, cnt, t_edge);
+    sort_segments<int, int>(t_splits, n_src, t_edge, sortbuf, ST(stream));      // ascending edge ids per source: deterministic backward
+    GAOT_CHECK_LAUNCH("gaot_csr_transpose_dev");
     return GAOT_OK;
 }

@@ -465,55 +465,67 @@ struct KmFwdSmem {
     static constexpr int BYTES = WP + W1 + BS;
 };
 template <int NL, int CM, int ACT, int NP = 3>
-__device__ __forceinline__ void km_fwd_split_body(const KMArgs& p, const int block, unsigned char* smem) {
+__device__ __forceinline__ void km_fwd_split_body(const KMArgs& p, const int block, const int nblocks, unsigned char* smem) {
     using S = KmFwdSmem<NL, CM, NP>;
     unsigned char* Wp = smem;
     float* W1s = reinterpret_cast<float*>(smem + S::WP);
     float* Bs = reinterpret_cast<float*>(smem + S::WP + S::W1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, hi = lane >> 5;
-    // the edge coordinates are requested before the weights are staged: their latency hides behind the staging
-    const int e0 = (block * 4 + wave) * 32;
-    const int e = min(e0 + li, p.E - 1);
+    // Workgroup `block` of `nblocks` walks the 128-edge tiles block, block + nblocks, ...: the weights are staged (read, split into planes,
+    // written to LDS) ONCE per workgroup.  With a workgroup per tile the staging -- 48 KB of fp32 weights through the L2, 12 288 splits -- was
+    // paid for every 128 edges: 3 578 times on the 458 k-edge unions of a vx batch, seven rounds of workgroups on the chip.
+    // The edge coordinates are requested before the weights are staged (and a tile ahead after that): their latency hides behind the work.
+    int e0 = (block * 4 + wave) * 32;
     float xr[CM];
-    km_load_x<CM>(p, e, xr);
+    km_load_x<CM>(p, min(e0 + li, p.E - 1), xr);
     km_stage_weights_split<NL, CM, NP>(p, Wp, W1s, Bs, tid);
     __syncthreads();
-    if (e0 >= p.E) return;
-    f32x16 z[2], h[2];
-    km_layer0<CM>(W1s, Bs, xr, p.cin, hi, z);
+    for (int tile = block; tile < p.ntiles; tile += nblocks) {
+        e0 = (tile * 4 + wave) * 32;
+        float xn[CM];
+        const int en = ((tile + nblocks) * 4 + wave) * 32 + li;
+        km_load_x<CM>(p, min(en, p.E - 1), xn);
+        if (e0 < p.E) {
+            f32x16 z[2], h[2];
+            km_layer0<CM>(W1s, Bs, xr, p.cin, hi, z);
 #pragma unroll
-    for (int m = 0; m < NL; ++m) {
+            for (int m = 0; m < NL; ++m) {
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+                for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int t = 0; t < 16; ++t) h[kt][t] = act_f<ACT>(z[kt][t]);
-        km_layer_split<NP>(Wp + m * NP * KS_PLANE, Bs + 64 * (m + 1), h, li, hi, z);
-    }
-    if (e0 + li < p.E) {
-        float* dst = p.out + (long)(e0 + li) * p.cout;
+                    for (int t = 0; t < 16; ++t) h[kt][t] = act_f<ACT>(z[kt][t]);
+                km_layer_split<NP>(Wp + m * NP * KS_PLANE, Bs + 64 * (m + 1), h, li, hi, z);
+            }
+            if (e0 + li < p.E) {
+                float* dst = p.out + (long)(e0 + li) * p.cout;
 #pragma unroll
-        for (int io = 0; io < 2; ++io)
+                for (int io = 0; io < 2; ++io)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (io * 32 + 8 * q + 4 * hi < p.cout)
-                    *reinterpret_cast<f32x4*>(dst + io * 32 + 8 * q + 4 * hi) = f32x4{z[io][4 * q], z[io][4 * q + 1], z[io][4 * q + 2], z[io][4 * q + 3]};
+                    for (int q = 0; q < 4; ++q)
+                        if (io * 32 + 8 * q + 4 * hi < p.cout)
+                            *reinterpret_cast<f32x4*>(dst + io * 32 + 8 * q + 4 * hi) = f32x4{z[io][4 * q], z[io][4 * q + 1], z[io][4 * q + 2], z[io][4 * q + 3]};
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CM; ++c) xr[c] = xn[c];
     }
 }
 template <int NL, int CM, int ACT, int NP = 3>
 __global__ __launch_bounds__(256, 2) void kernel_mlp_fwd_split_kernel(const KMArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[KmFwdSmem<NL, CM, NP>::BYTES];
-    km_fwd_split_body<NL, CM, ACT, NP>(p, blockIdx.x, smem);
+    km_fwd_split_body<NL, CM, ACT, NP>(p, blockIdx.x, gridDim.x, smem);
 }
 // TWO chains in one launch (exact products): the kernel MLP of an integral transform (GELU, over the E edge rows: 435 workgroups at the
 // bench configuration) and the geometry-embedding chain of the same transform (ReLU, over the Q query rows: 32 .. 128 workgroups) --
-// neither depends on the other, and alone the second is a 12-14 us launch of a few dozen workgroups on 256 CUs.
+// neither depends on the other, and alone the second is a 12-14 us launch of a few dozen workgroups on 256 CUs.  Workgroups 0 .. na - 1
+// walk chain A's tiles, the nb behind them chain B's.
 template <int NLA, int CMA, int NLB, int CMB>
-__global__ __launch_bounds__(256, 2) void kernel_mlp_fwd_pair_kernel(const KMArgs a, const KMArgs b) {
+__global__ __launch_bounds__(256, 2) void kernel_mlp_fwd_pair_kernel(const KMArgs a, const KMArgs b, const int na, const int nb) {
     constexpr int BYTES = KmFwdSmem<NLA, CMA, 3>::BYTES > KmFwdSmem<NLB, CMB, 3>::BYTES ? KmFwdSmem<NLA, CMA, 3>::BYTES : KmFwdSmem<NLB, CMB, 3>::BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[BYTES];
-    if ((int)blockIdx.x < a.ntiles) km_fwd_split_body<NLA, CMA, GAOT_ACT_GELU, 3>(a, blockIdx.x, smem);
-    else km_fwd_split_body<NLB, CMB, GAOT_ACT_RELU, 3>(b, (int)blockIdx.x - a.ntiles, smem);
+    if ((int)blockIdx.x < na) km_fwd_split_body<NLA, CMA, GAOT_ACT_GELU, 3>(a, blockIdx.x, na, smem);
+    else km_fwd_split_body<NLB, CMB, GAOT_ACT_RELU, 3>(b, (int)blockIdx.x - na, nb, smem);
 }
 
 template <int NL>
@@ -1006,6 +1018,7 @@ static int km_check(const float* x, int E, int cin, int n_layers, const float* c
 }
 
 static int g_km_abl = 0;
+constexpr int KM_FWD_WGS = 512;     // resident workgroups of the split forward kernels: two per CU on 256 CUs
 static int g_km_split = 1;      // 1: bf16-split kernels (default), 0: the fp32-MFMA kernels (gaot_debug_set_kernel_mlp_split)
 static void km_fill(KMArgs& a, const float* x, int E, int cin, int n_layers, const float* const* w, const float* const* b, const int* widths,
                     const int* ldw = nullptr) {
@@ -1062,7 +1075,8 @@ extern "C" int gaot_kernel_mlp_fwd_w(const float* x, int32_t E, int32_t cin, int
     GAOT_REQUIRE(out && aligned16(out), "kernel_mlp_fwd: out must be non-null and 16-byte aligned");
     KMArgs a{}; km_fill(a, x, E, cin, n_layers, w, b, widths, ldw); a.out = out;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const dim3 grid(a.ntiles), block(256);
+    // split kernels: persistent workgroups, two per CU (the weights are staged once per workgroup); the fp32-MFMA kernel: one per tile
+    const dim3 grid((g_km_split && !a.abl && a.ntiles > KM_FWD_WGS) ? KM_FWD_WGS : a.ntiles), block(256);
 #define KM_FWD3(K, NL, ...) do { if (cin == 4) hipLaunchKernelGGL((K<NL, 4, __VA_ARGS__>), grid, block, 0, st, a); \
                                  else if (cin <= 8) hipLaunchKernelGGL((K<NL, 8, __VA_ARGS__>), grid, block, 0, st, a); \
                                  else hipLaunchKernelGGL((K<NL, KM_MAXC, __VA_ARGS__>), grid, block, 0, st, a); } while (0)
@@ -1154,8 +1168,17 @@ extern "C" int gaot_kernel_mlp_fwd_pair(const gaot_kmlp_desc* a, const gaot_kmlp
     if (int rc = km_desc_fill(ka, a, false)) return rc;
     if (int rc = km_desc_fill(kb, b, false)) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const dim3 grid(ka.ntiles + kb.ntiles), block(256);
-#define KM_PAIR(CA, CB) hipLaunchKernelGGL((kernel_mlp_fwd_pair_kernel<3, CA, 2, CB>), grid, block, 0, st, ka, kb)
+    // one resident round (two workgroups per CU) shared in proportion to the chains' tiles; fewer tiles than that: a workgroup per tile
+    int na = ka.ntiles, nb = kb.ntiles;
+    if (na + nb > KM_FWD_WGS) {
+        na = (int)((long)KM_FWD_WGS * ka.ntiles / (ka.ntiles + kb.ntiles));
+        na = na < 1 ? 1 : (na > KM_FWD_WGS - 1 ? KM_FWD_WGS - 1 : na);
+        nb = KM_FWD_WGS - na;
+        if (na > ka.ntiles) na = ka.ntiles;
+        if (nb > kb.ntiles) nb = kb.ntiles;
+    }
+    const dim3 grid(na + nb), block(256);
+#define KM_PAIR(CA, CB) hipLaunchKernelGGL((kernel_mlp_fwd_pair_kernel<3, CA, 2, CB>), grid, block, 0, st, ka, kb, na, nb)
     if (a->cin == 4) { if (b->cin <= 8) KM_PAIR(4, 8); else KM_PAIR(4, KM_MAXC); }
     else             { if (b->cin <= 8) KM_PAIR(8, 8); else KM_PAIR(8, KM_MAXC); }
 #undef KM_PAIR

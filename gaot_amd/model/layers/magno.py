@@ -138,8 +138,24 @@ class _MAGNOBase(nn.Module):
         src, dst = src.contiguous(), dst.contiguous()
         out = []
         for si in range(len(self.scales)):
-            plans = [_plan.plan_for(nbrs[b][si], n_src, validate="lazy") for b in range(B)]
-            key = (si, B, n_src, n_dst, int(src.shape[-1]), int(dst.shape[-1]), _plan.edge_bucket(sum(p.E for p in plans)), src.device)
+            parts = [nbrs[b][si] for b in range(B)]
+            # Dicts that come back (a dataset kept on the device) get a plan of their own on their SECOND sight and the union is composed from the
+            # plans (one 9 us launch); dicts seen for the first time -- every step, when the trainer uploads the graphs per step as the reference's
+            # does (move_to_device, static_trainer.py:192-193) -- are described to the compose kernel as they are (raw int64 lists): no plan is
+            # built for a sample that never returns, the transposed CSR is derived on the device if a kernel asks for it.
+            planned = all(_plan.has_plan(nb, n_src) for nb in parts)
+            if not planned:
+                seen = all(nb.get("_gaot_amd_seen") for nb in parts)
+                for nb in parts:
+                    nb["_gaot_amd_seen"] = True
+                planned = seen
+            if planned:
+                items = [_plan.plan_for(nb, n_src, validate="lazy") for nb in parts]
+                total = sum(p.E for p in items)
+            else:
+                items = parts
+                total = sum(int(nb["neighbors_index"].numel()) for nb in parts)
+            key = (si, B, n_src, n_dst, int(src.shape[-1]), int(dst.shape[-1]), _plan.edge_bucket(total), src.device)
             su = self._static_unions.pop(key, None)
             if su is None:
                 while len(self._static_unions) >= self.MAX_STATIC_UNIONS:        # least recently used; graphs that captured it keep their reference
@@ -147,9 +163,10 @@ class _MAGNOBase(nn.Module):
                 su = _plan.StaticUnion(B, n_src, n_dst, key[4], key[5], key[6], src.device)
             self._static_unions[key] = su
             if load:
-                su.load(plans, src, dst)
+                (su.load if planned else su.load_raw)(items, src, dst)
             else:
-                su.pending = plans
+                su.pending = items
+            su.pending_raw = not planned
             out.append(su)
         return out
 

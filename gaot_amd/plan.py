@@ -251,6 +251,17 @@ def plan_for(neighbors: dict, n_src: int, validate=True) -> GeometryPlan:
     return plan
 
 
+def has_plan(neighbors: dict, n_src: int) -> bool:
+    """whether plan_for(neighbors, n_src) would return a cached plan (nothing to build)"""
+    plan = neighbors.get(_PLAN_KEY)
+    if plan is None:
+        return False
+    if plan._src_id is None:
+        return True
+    idx = neighbors["neighbors_index"]
+    return plan._src_id == (id(idx), idx._version) and plan.n_src == n_src
+
+
 def _i32_array(vals):
     arr = (C.c_int32 * len(vals))()
     for i, v in enumerate(vals):
@@ -421,9 +432,11 @@ class _StaticPlan(GeometryPlan):
         dev = device
         self.index = torch.zeros(self.E, dtype=torch.int32, device=dev)
         self.edge_query = torch.zeros(self.E, dtype=torch.int32, device=dev)
-        self.t_edge = torch.zeros(self.E, dtype=torch.int32, device=dev)
+        self._t_edge = torch.zeros(self.E, dtype=torch.int32, device=dev)
         self.splits = torch.zeros(self.Q + 1, dtype=torch.int32, device=dev)
-        self.t_splits = torch.zeros(self.n_src + 1, dtype=torch.int32, device=dev)
+        self._t_splits = torch.zeros(self.n_src + 1, dtype=torch.int32, device=dev)
+        self._tcsr = None             # raw-composed unions: derives the transposed CSR from `index` on first request per version
+        self._t_version = -1
         self.e_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self.max_deg = self.max_t_deg = None          # unknown on the host: the edge-partitioned kernels serve any degree distribution
         self._src_id = None
@@ -434,6 +447,23 @@ class _StaticPlan(GeometryPlan):
     def touch(self):
         """the plan's arrays were rewritten: every derived array is stale"""
         self._version += 1
+
+    # the transposed CSR: written by whoever fills the plan (a union composed from per-sample plans, a DropPlan), or -- a union composed from raw
+    # int64 lists -- derived from `index` the first time a kernel asks for it after a rewrite (the encoder's fused transform never does)
+    def _need_t(self):
+        if self._tcsr is not None and self._t_version != self._version:
+            self._t_version = self._version
+            self._tcsr()
+
+    @property
+    def t_splits(self):
+        self._need_t()
+        return self._t_splits
+
+    @property
+    def t_edge(self):
+        self._need_t()
+        return self._t_edge
 
     def _static(self, name, alloc, compute):
         ent = self._arrays.get(name)
@@ -580,13 +610,18 @@ class StaticUnion:
         self.dst = torch.zeros(B * n_dst, dim_dst, device=device, dtype=torch.float32)
         self.plan = _StaticPlan(B * n_dst, int(e_cap), B * n_src, device)
         self.neighbors = {"neighbors_index": None, "neighbors_row_splits": None, _PLAN_KEY: self.plan}
-        self.table = torch.zeros(B, 8, dtype=torch.int64, device=device)           # B x gaot_union_part (64 bytes each)
+        self.table = torch.zeros(B, 8, dtype=torch.int64, device=device)           # B x gaot_union_part (64 bytes each), or B x gaot_union_part_raw in its first 5 B words
+        self.raw = False              # how the last load described the samples: per-sample plans, or the callers' raw int64 lists
+        self.flag = torch.zeros(1, dtype=torch.int32, device=device)              # raw lists: CSR contract violations seen by the compose kernel
+        self._tscratch = None
+        self._since_check = 0
         self._pinned = [torch.zeros(B, 8, dtype=torch.int64).pin_memory() for _ in range(self.RING)]
         self._views = [t.numpy() for t in self._pinned]
         self._events: List[Optional[torch.cuda.Event]] = [None] * self.RING
         self._slot = 0
         self._hold = None
         self.pending = None
+        self.pending_raw = False      # what the next load will be (set by whoever found this union for a batch): part of a captured step's identity
         self.e_real = 0           # host copy of the last loaded edge count (diagnostics; the kernels read plan.e_dev)
 
     def load(self, plans, src_parent: torch.Tensor, dst_parent: torch.Tensor) -> None:
@@ -622,20 +657,87 @@ class StaticUnion:
         ev.record()
         self._hold = (list(plans), src_parent, dst_parent)          # the arrays behind the table's pointers live until the next load
         self.e_real = total
+        self.raw = False
+
+    CHECK_EVERY = 64      # raw lists: the device-side validity flag is read back (one host synchronisation) every so many loads
+
+    def load_raw(self, dicts, src_parent: torch.Tensor, dst_parent: torch.Tensor) -> None:
+        """as load(), from the callers' neighbour dicts themselves (int64 `neighbors_index` / `neighbors_row_splits` on the device): nothing is
+        built per sample -- the compose kernel converts, offsets and validates, the transposed CSR is derived on the device when a kernel needs
+        it.  For dicts that are new objects every step (the reference's trainer uploads them per step: move_to_device, static_trainer.py:192-193)."""
+        B = self.B
+        if len(dicts) != B:
+            raise ValueError(f"static union of {B} samples handed {len(dicts)}")
+        idx = [d["neighbors_index"] for d in dicts]
+        sps = [d["neighbors_row_splits"] for d in dicts]
+        for i_, s_ in zip(idx, sps):
+            if i_.dtype != torch.int64 or s_.dtype != torch.int64 or not i_.is_contiguous() or not s_.is_contiguous() or i_.device != self.src.device:
+                raise TypeError("static union: neighbour lists must be contiguous int64 tensors on the union's device")
+            if s_.numel() != self.n_dst + 1:
+                raise ValueError("vx mode needs the same number of source / query points in every sample of a batch")
+        counts = np.fromiter((t.numel() for t in idx), dtype=np.int64, count=B)
+        begins = np.concatenate(([0], np.cumsum(counts)[:-1]))
+        total = int(counts.sum())
+        if total > self.e_cap:
+            raise ValueError(f"batch of {total} edges does not fit the union's capacity {self.e_cap}")
+        self._since_check += 1
+        if self._since_check >= self.CHECK_EVERY:
+            self._since_check = 0
+            _raise_if_bad(int(self.flag.item()))
+        slot = self._slot
+        self._slot = (slot + 1) % self.RING
+        ev = self._events[slot]
+        if ev is not None:
+            ev.synchronize()
+        tab = self._views[slot]
+        tab[:, 0] = [t.data_ptr() for t in idx]
+        tab[:, 1] = [t.data_ptr() for t in sps]
+        for col, parent, n in ((2, src_parent, self.n_src), (3, dst_parent, self.n_dst)):
+            if parent.dtype != torch.float32 or not parent.is_contiguous() or parent.device != self.src.device:
+                raise TypeError("static union: coordinates must be contiguous float32 tensors on the union's device")
+            stride = n * parent.shape[-1] * 4 if parent.dim() == 3 else 0
+            tab[:, col] = parent.data_ptr() + stride * np.arange(B, dtype=np.int64)
+        tab[:, 4] = begins | (counts << 32)
+        self.table.copy_(self._pinned[slot], non_blocking=True)
+        if ev is None:
+            ev = self._events[slot] = torch.cuda.Event()
+        ev.record()
+        self._hold = (list(dicts), src_parent, dst_parent, idx, sps)
+        self.e_real = total
+        self.raw = True
+
+    def _transpose(self):
+        pl = self.plan
+        if self._tscratch is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("gaot_amd: the transposed CSR of a raw-composed union requested for the first time inside a graph capture")
+            self._tscratch = torch.zeros(int(L.load().gaot_csr_transpose_dev_scratch(pl.E, pl.n_src)), dtype=torch.int32, device=self.device)
+        L.check(L.load().gaot_csr_transpose_dev(_p(pl.index), pl.E, _p(pl.e_dev), pl.n_src, _p(pl._t_splits), _p(pl._t_edge), _p(self._tscratch), _stream()),
+                "gaot_csr_transpose_dev")
 
     def load_pending(self, src_parent: torch.Tensor, dst_parent: torch.Tensor) -> None:
         """load() with the plans a `vx_unions(..., load=False)` call left behind"""
         plans, self.pending = self.pending, None
-        if plans is None:           # loaded already for this batch (the call that captured an entry replays it at once): the same plans again
+        if plans is None:           # loaded already for this batch (the call that captured an entry replays it at once): the same samples again
             plans = self._hold[0]
-        self.load(plans, src_parent, dst_parent)
+        if isinstance(plans[0], dict):
+            self.load_raw(plans, src_parent, dst_parent)
+        else:
+            self.load(plans, src_parent, dst_parent)
 
     def refresh(self) -> None:
         """compose the union from the loaded table (capturable: a fixed launch over fixed addresses); the derived arrays follow on request"""
         pl = self.plan
-        L.check(L.load().gaot_union_compose(_p(self.table), self.B, self.n_dst, self.n_src, self.src.shape[1], self.dst.shape[1], self.e_cap,
-                                            _p(pl.index), _p(pl.edge_query), _p(pl.t_edge), _p(pl.splits), _p(pl.t_splits), _p(self.src), _p(self.dst),
-                                            _p(pl.e_dev), _stream()), "gaot_union_compose")
+        if self.raw:
+            L.check(L.load().gaot_union_compose_raw(_p(self.table), self.B, self.n_dst, self.n_src, self.src.shape[1], self.dst.shape[1], self.e_cap,
+                                                    _p(pl.index), _p(pl.edge_query), _p(pl.splits), _p(self.src), _p(self.dst), _p(pl.e_dev), _p(self.flag),
+                                                    _stream()), "gaot_union_compose_raw")
+            pl._tcsr = self._transpose
+        else:
+            pl._tcsr = None
+            L.check(L.load().gaot_union_compose(_p(self.table), self.B, self.n_dst, self.n_src, self.src.shape[1], self.dst.shape[1], self.e_cap,
+                                                _p(pl.index), _p(pl.edge_query), _p(pl._t_edge), _p(pl.splits), _p(pl._t_splits), _p(self.src), _p(self.dst),
+                                                _p(pl.e_dev), _stream()), "gaot_union_compose")
         pl.touch()
 
     def geo_stats(self) -> torch.Tensor:

@@ -526,7 +526,7 @@ class TrainStep:
         enc = self.model.encoder.vx_unions(kw["encoder_nbrs"], kw["xcoord"], kw["latent_tokens_coord"], B)
         dec = self.model.decoder.vx_unions(kw["decoder_nbrs"], kw["latent_tokens_coord"], kw["xcoord"], B)
         self._vx_unions = (enc, dec)
-        key = tuple(u.uid for u in enc + dec)
+        key = tuple((u.uid, u.pending_raw) for u in enc + dec)          # (raw lists or per-sample plans: other launches)
         hit = self._graph_sets.pop(key, None)
         if hit is None:
             while len(self._graph_sets) >= self.MAX_GRAPH_SETS:

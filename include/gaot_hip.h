@@ -209,6 +209,28 @@ int gaot_edge_drop(const int32_t* index32, const int32_t* edge_query, const int3
                    float sample_ratio, int32_t max_neighbors, const uint64_t* seed, int32_t* out_index, int32_t* out_edge_query,
                    int32_t* out_t_edge, int32_t* out_splits, int32_t* out_t_splits, int32_t* e_real_out, int32_t* scratch,
                    gaot_stream_t stream);
+/* The same union straight from the callers' int64 CSR lists -- the per-sample dicts the reference's trainer uploads anew every step
+ * (move_to_device, static_trainer.py:192-193) -- without building a plan per sample first: index32 / edge_query [e_cap] (edge_query by a
+ * binary search in the sample's row splits), splits32, stacked coordinates, *e_real, pads as above.  *status_flag |= 1 (row splits not
+ * monotone 0..e_count) | 2 (index outside [0, n_src_each)): the contract of gaot_csr_prepare, checked on the device (what is stored is clamped);
+ * zero it once, read it whenever convenient.  The transposed CSR of the result: gaot_csr_transpose_dev. */
+typedef struct gaot_union_part_raw {
+    const int64_t* index;        /* [e_count]     neighbors_index of the sample        */
+    const int64_t* splits;       /* [q_each + 1]  neighbors_row_splits of the sample   */
+    const float* src;            /* [n_src_each, dim_src]                              */
+    const float* dst;            /* [q_each, dim_dst]                                  */
+    int32_t e_begin;
+    int32_t e_count;
+    int64_t reserved[3];         /* (64 bytes per entry, like gaot_union_part: one table serves both)  */
+} gaot_union_part_raw;
+int gaot_union_compose_raw(const gaot_union_part_raw* parts_dev, int32_t n_parts, int32_t q_each, int32_t n_src_each, int32_t dim_src,
+                           int32_t dim_dst, int32_t e_cap, int32_t* index32, int32_t* edge_query, int32_t* splits32, float* src, float* dst,
+                           int32_t* e_real, int32_t* status_flag, gaot_stream_t stream);
+/* gaot_csr_transpose for a padded list: only the first *e_real of the E entries are edges (t_splits[n_src] = *e_real), the pads get
+ * t_edge = their own id.  scratch: gaot_csr_transpose_dev_scratch(E, n_src) int32. */
+int64_t gaot_csr_transpose_dev_scratch(int32_t E, int32_t n_src);
+int gaot_csr_transpose_dev(const int32_t* index32, int32_t E, const int32_t* e_real, int32_t n_src, int32_t* t_splits, int32_t* t_edge,
+                           int32_t* scratch, gaot_stream_t stream);
 /* out[e] = 1 / max(deg(query(e)), 1) -- the 'mean' reduction of agno.py:264 as a per-edge scale -- and 0 for e >= *e_real (e_real may be NULL) */
 int gaot_edge_inv_degree(const int32_t* splits32, const int32_t* edge_query, int32_t E, const int32_t* e_real, float* out,
                          gaot_stream_t stream);

@@ -300,3 +300,16 @@ def test_a_stale_temporary_id_never_drops_a_parameters_gradient_slot():
     finally:
         ops._GRAD_SLOTS.clear(); ops._GRAD_SLOTS.update(saved)
         ops._TEMP_SLOT_IDS[:] = saved_ids
+
+
+def test_union_part_layouts_match_header():
+    """the device-side tables of gaot_union_compose / gaot_union_compose_raw: 64 bytes per entry, fields in the header's order"""
+    import ctypes as C
+    from gaot_amd._lib import UnionPart, UnionPartRaw
+    header = open(os.path.join(ROOT, "include", "gaot_hip.h")).read()
+    for name, cls in (("gaot_union_part", UnionPart), ("gaot_union_part_raw", UnionPartRaw)):
+        body = header[header.index(f"typedef struct {name} {{"):header.index(f"}} {name};")]
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = re.findall(r"(?:\*|\s)([A-Za-z_][A-Za-z0-9_]*)\s*(?:\[\d+\])?\s*;", body)
+        assert names == [f[0] for f in cls._fields_], (name, names)
+        assert C.sizeof(cls) == 64, (name, C.sizeof(cls))

@@ -22,14 +22,17 @@ from tests.test_configs_gpu import GRAD_TOL, LOSS_TOL, OUT_TOL, check_step, csr_
 pytestmark = pytest.mark.gpu
 
 
-def _dataset(n_samples, N, seed=0, lat_sizes=(64, 64), radius=0.033, spread=0.15):
-    """per-sample NACA-shaped meshes with their encoder / decoder radius graphs (oracle search = the reference's)"""
+def _dataset(n_samples, N, seed=0, lat_sizes=(64, 64), radius=0.033, spread=0.15, radius_jitter=0.0):
+    """per-sample NACA-shaped meshes with their encoder / decoder radius graphs (oracle search = the reference's).  On a uniform latent grid a
+    mesh of N points has ~N pi r^2 rho_latent edges whatever its shape, so batches of one dataset share one edge bucket; `radius_jitter` builds
+    the graphs of sample i with radius * (1 + jitter * (i % 3)) -- caller-supplied lists may be anything -- to spread the batches over buckets."""
     from oracle import gaot_oracle as O
     g = torch.Generator().manual_seed(seed)
     lat = grid(list(lat_sizes))
     xs = [naca_points(N, g, spread) for _ in range(n_samples)]
-    enc = [[O.radius_csr(x, lat, radius)] for x in xs]
-    dec = [[O.radius_csr(lat, x, radius)] for x in xs]
+    rs = [radius * (1.0 + radius_jitter * (i % 3)) for i in range(n_samples)]
+    enc = [[O.radius_csr(x, lat, r)] for x, r in zip(xs, rs)]
+    dec = [[O.radius_csr(lat, x, r)] for x, r in zip(xs, rs)]
     return lat, xs, enc, dec
 
 
@@ -73,8 +76,27 @@ def test_static_union_equals_composed_union_and_pads_are_inert():
             inv = a.inv_deg_edge
             assert torch.equal(inv[:E], b.inv_deg_edge[:E]) and bool((inv[E:] == 0).all())
             assert torch.equal(a.deg, b.deg)
+            # the same batch described by its raw int64 lists (dicts the trainer uploads per step): same CSR, same derived arrays; the
+            # transposed CSR is derived on the device on request
+            su.load_raw([dicts[i] for i in order], src_par, dst_par)
+            su.refresh()
+            assert int(a.e_dev.item()) == E
+            for name in ("index", "edge_query", "t_edge"):
+                assert torch.equal(getattr(a, name)[:E], getattr(b, name)[:E]), (side, "raw", name)
+            assert torch.equal(a.splits, b.splits) and torch.equal(a.t_splits, b.t_splits)
+            assert torch.equal(a.t_edge[E:], torch.arange(E, cap, device=dev(), dtype=torch.int32))
+            assert torch.equal(su.geo_stats(), ref.geo_stats())
+            assert torch.equal(a.cosine_attention(su.src, su.dst)[:E], b.cosine_attention(ref.src, ref.dst)[:E])
+            assert int(su.flag.item()) == 0
         with pytest.raises(ValueError):
             su.load([plans[0]] * (B + 1), latd, latd)
+        # a broken list is flagged on the device (and what is stored is clamped)
+        bad = dict(dicts[0])
+        bad["neighbors_index"] = dicts[0]["neighbors_index"].clone()
+        bad["neighbors_index"][3] = n_src + 5
+        su.load_raw([bad, dicts[1], dicts[2]], (torch.stack([xd[0], xd[1], xd[2]]) if side == "enc" else latd), (latd if side == "enc" else torch.stack([xd[0], xd[1], xd[2]])))
+        su.refresh()
+        assert int(su.flag.item()) == 2 and int(su.plan.index.max()) < B * n_src
 
 
 @pytest.mark.parametrize("variant", ["default", "no_attention", "no_geoembed", "dot_product", "multiscale", "pointnet", "pointnet_mean", "kernelonly",
@@ -144,8 +166,8 @@ def test_trainstep_vx_shuffled_replay_equals_eager_bit_for_bit_and_tracks_the_or
     from oracle import gaot_oracle as O
     nS, B, N, steps = 10, 4, 2048, 8
     model, sd, ocfg = make_model(3, 1, [32, 32], radius=0.066, seed=4)
-    lat, xs, enc, dec = _dataset(nS, N, seed=9, lat_sizes=(32, 32), radius=0.066)
-    # a spread of mesh densities: the edge totals of the batches differ by more than one bucket
+    lat, xs, enc, dec = _dataset(nS, N, seed=9, lat_sizes=(32, 32), radius=0.066, radius_jitter=0.12)
+    # graphs of three different radii: the edge totals of the batches differ by more than one bucket
     g = torch.Generator().manual_seed(1)
     P_all, T_all = torch.randn(nS, N, 3, generator=g), torch.randn(nS, N, 1, generator=g)
     batches = _shuffled_batches(nS, B, steps, seed=21)
@@ -174,7 +196,7 @@ def test_trainstep_vx_shuffled_replay_equals_eager_bit_for_bit_and_tracks_the_or
     n_sets = len(tsg._graph_sets)
     totals = sorted({sum(int(enc[i][0][0].numel()) for i in b) for b in batches})
     print(f"[vx shuffled] {steps} compositions, encoder edge totals {totals[0]}..{totals[-1]}, {n_sets} captured step(s)")
-    assert 1 <= n_sets <= TrainStep.MAX_GRAPH_SETS and all(v["graphs"] is not None for v in tsg._graph_sets.values())
+    assert 2 <= n_sets <= TrainStep.MAX_GRAPH_SETS and all(v["graphs"] is not None for v in tsg._graph_sets.values())
     # the oracle on the same sequence of batches (the reference loops over the samples of each batch)
     w = {k: v.clone() for k, v in sd.items()}
     mom = None
