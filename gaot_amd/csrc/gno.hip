@@ -152,10 +152,13 @@ __device__ __forceinline__ float cos_score(const float* __restrict__ x, const fl
     for (int d = 0; d < dim; ++d) xy += (x[d] * xinv) * (y[d] * yinv);
     return xy;
 }
-// GEO_LANES lanes per query row (aligned lane groups of one wave): the rows of a skewed mesh reach 350+ edges next to thousands of empty ones,
-// and with a vx batch under a shuffling loader this runs every step (plan.StaticUnion.refresh), not once per geometry.  A lane strides its row's
-// edges, the group reduces by xor shuffles inside the group: fixed order, deterministic.
+// GEO_LANES lanes per query row (aligned lane groups of one wave): with a vx batch under a shuffling loader this runs every step
+// (plan.StaticUnion), not once per geometry.  A lane strides its row's edges, the group reduces by xor shuffles inside the group.  Rows longer
+// than GEO_LONG edges (the latent tokens next to an airfoil contour reach 350+, beside thousands of empty rows) are taken by the WHOLE WAVE, one
+// after the other: 64 lanes stride the row, wave-wide reductions.  How a row is summed depends on its own length only -- not on the launch, not
+// on its neighbours -- so a row of a block-diagonal union and the same row of the sample alone give the same bits.
 #define GEO_LANES 8
+#define GEO_LONG 64
 __device__ __forceinline__ float group_max(float v) {
 #pragma unroll
     for (int off = GEO_LANES >> 1; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
@@ -171,30 +174,70 @@ __device__ __forceinline__ double group_sum_d(double v) {
     for (int off = GEO_LANES >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
-__global__ __launch_bounds__(256) void edge_attention_cosine_kernel(const float* __restrict__ src, const float* __restrict__ qry, int dim,
-                                                                    const int* __restrict__ idx, const int* __restrict__ sp, int Q,
-                                                                    float* __restrict__ attn, const int* __restrict__ guard) {
-    if (guard && *guard == 0) return;
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int q = gid / GEO_LANES, l = gid % GEO_LANES;
-    if (q >= Q) return;                         // (whole lane groups leave together)
-    const int b = sp[q], e = sp[q + 1];
-    if (b == e) return;
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+// softmax of the cosine scores of row q = edges [b, e), walked by `n` lanes (this lane is number l of them); rmax / rsum reduce over those lanes.
+// Up to 8 edges per lane stay in registers (one store per edge); longer rows go through `attn` itself.
+template <typename RMAX, typename RSUM>
+__device__ __forceinline__ void cosine_row(const float* __restrict__ src, const float* __restrict__ qry, int dim, const int* __restrict__ idx,
+                                           float* __restrict__ attn, int q, int b, int e, int l, int n, RMAX rmax, RSUM rsum) {
     const float* x = qry + (long)q * dim;
     float xx = 0.f;
     for (int d = 0; d < dim; ++d) xx += x[d] * x[d];
     const float xinv = 1.0f / fmaxf(sqrtf(xx), 1e-12f);
     float mx = -INFINITY;
-    for (int t = b + l; t < e; t += GEO_LANES) {
+    if (e - b <= 8 * n) {
+        float sv[8];
+        int j[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const int t = b + l + i * n; j[i] = t < e ? idx[t] : 0; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int t = b + l + i * n;
+            sv[i] = t < e ? cos_score(x, src + (long)j[i] * dim, dim, xinv) : -INFINITY;
+            mx = fmaxf(mx, sv[i]);
+        }
+        mx = rmax(mx);
+        float den = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { sv[i] = b + l + i * n < e ? expf(sv[i] - mx) : 0.f; den += sv[i]; }
+        den = rsum(den);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const int t = b + l + i * n; if (t < e) attn[t] = sv[i] / den; }
+        return;
+    }
+    for (int t = b + l; t < e; t += n) {
         const float s = cos_score(x, src + (long)idx[t] * dim, dim, xinv);
         attn[t] = s;
         mx = fmaxf(mx, s);
     }
-    mx = group_max(mx);
+    mx = rmax(mx);
     float den = 0.f;
-    for (int t = b + l; t < e; t += GEO_LANES) { const float v = expf(attn[t] - mx); attn[t] = v; den += v; }
-    den = group_sum(den);
-    for (int t = b + l; t < e; t += GEO_LANES) attn[t] = attn[t] / den;
+    for (int t = b + l; t < e; t += n) { const float v = expf(attn[t] - mx); attn[t] = v; den += v; }
+    den = rsum(den);
+    for (int t = b + l; t < e; t += n) attn[t] = attn[t] / den;
+}
+__global__ __launch_bounds__(256) void edge_attention_cosine_kernel(const float* __restrict__ src, const float* __restrict__ qry, int dim,
+                                                                    const int* __restrict__ idx, const int* __restrict__ sp, int Q,
+                                                                    float* __restrict__ attn, const int* __restrict__ guard) {
+    if (guard && *guard == 0) return;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int q = gid / GEO_LANES, l = gid % GEO_LANES;
+    const int b = q < Q ? sp[q] : 0, e = q < Q ? sp[q + 1] : 0;
+    const bool is_long = e - b > GEO_LONG;
+    if (e > b && !is_long)
+        cosine_row(src, qry, dim, idx, attn, q, b, e, l, GEO_LANES, [](float v) { return group_max(v); }, [](float v) { return group_sum(v); });
+    unsigned long long todo = __ballot(is_long && l == 0);          // one bit per long row of this wave (the first lane of its group)
+    while (todo) {
+        const int first = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int qq = __shfl(q, first, 64), bb = __shfl(b, first, 64), ee = __shfl(e, first, 64);
+        cosine_row(src, qry, dim, idx, attn, qq, bb, ee, lane, 64, [](float v) { return wave_max(v); }, [](float v) { return wave_sum(v); });
+    }
 }
 __global__ void segment_softmax_fwd_kernel(const float* __restrict__ score, const int* __restrict__ sp, int Q,
                                            float* __restrict__ attn) {
@@ -276,6 +319,46 @@ __device__ void sym_eig_desc<3>(const double (&c)[3][3], double (&ev)[3]) {
     ev[0] = e0; ev[1] = e1; ev[2] = e2;
 }
 
+// raw statistics of row q = edges [b, e), walked by `n` lanes (this lane is number l of them); rsum reduces a double over those lanes; the lane with
+// l == 0 writes the row
+template <int DIM, typename RSUM>
+__device__ __forceinline__ void geo_stats_row(const float* __restrict__ geom, const float* __restrict__ qry, const int* __restrict__ idx,
+                                              float* __restrict__ raw, int q, int b, int e, int l, int n, RSUM rsum) {
+    constexpr int F = 3 + 2 * DIM;
+    float* o = raw + (long)q * F;
+    const int cnt = e - b;
+    double x[DIM], cen[DIM];
+    for (int d = 0; d < DIM; ++d) { x[d] = qry[(long)q * DIM + d]; cen[d] = 0.0; }
+    double sd = 0.0, sd2 = 0.0;
+    for (int t = b + l; t < e; t += n) {
+        const float* y = geom + (long)idx[t] * DIM;
+        double d2 = 0.0;
+        for (int d = 0; d < DIM; ++d) { const double dv = (double)y[d] - x[d]; d2 += dv * dv; cen[d] += y[d]; }
+        sd += sqrt(d2);
+        sd2 += d2;
+    }
+    sd = rsum(sd);
+    sd2 = rsum(sd2);
+    const double inv = 1.0 / cnt;
+    for (int d = 0; d < DIM; ++d) cen[d] = rsum(cen[d]) * inv;
+    double cov[DIM][DIM];
+    for (int i = 0; i < DIM; ++i) for (int j = 0; j < DIM; ++j) cov[i][j] = 0.0;
+    for (int t = b + l; t < e; t += n) {
+        const float* y = geom + (long)idx[t] * DIM;
+        double c[DIM];
+        for (int d = 0; d < DIM; ++d) c[d] = (double)y[d] - cen[d];
+        for (int i = 0; i < DIM; ++i) for (int j = i; j < DIM; ++j) cov[i][j] += c[i] * c[j];
+    }
+    for (int i = 0; i < DIM; ++i) for (int j = i; j < DIM; ++j) { cov[i][j] = rsum(cov[i][j]) * inv; cov[j][i] = cov[i][j]; }
+    if (l != 0) return;
+    double ev[DIM];
+    sym_eig_desc<DIM>(cov, ev);
+    const double mean = sd * inv;
+    double var = sd2 * inv - mean * mean;
+    if (var < 0.0) var = 0.0;
+    o[0] = (float)cnt; o[1] = (float)mean; o[2] = (float)var;
+    for (int d = 0; d < DIM; ++d) { o[3 + d] = (float)(cen[d] - x[d]); o[3 + DIM + d] = (float)ev[d]; }
+}
 template <int DIM>
 __global__ __launch_bounds__(256) void geo_stats_raw_kernel(const float* __restrict__ geom, const float* __restrict__ qry,
                                                             const int* __restrict__ idx, const int* __restrict__ sp, int Q,
@@ -283,43 +366,19 @@ __global__ __launch_bounds__(256) void geo_stats_raw_kernel(const float* __restr
     constexpr int F = 3 + 2 * DIM;
     if (guard && *guard == 0) return;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int q = gid / GEO_LANES, l = gid % GEO_LANES;
-    if (q >= Q) return;                         // (whole lane groups leave together)
-    float* o = raw + (long)q * F;
-    const int b = sp[q], e = sp[q + 1];
-    const int n = e - b;
-    if (n == 0) { if (l == 0) for (int f = 0; f < F; ++f) o[f] = 0.f; return; }
-    double x[DIM], cen[DIM];
-    for (int d = 0; d < DIM; ++d) { x[d] = qry[(long)q * DIM + d]; cen[d] = 0.0; }
-    double sd = 0.0, sd2 = 0.0;
-    for (int t = b + l; t < e; t += GEO_LANES) {
-        const float* y = geom + (long)idx[t] * DIM;
-        double d2 = 0.0;
-        for (int d = 0; d < DIM; ++d) { const double dv = (double)y[d] - x[d]; d2 += dv * dv; cen[d] += y[d]; }
-        sd += sqrt(d2);
-        sd2 += d2;
+    const int b = q < Q ? sp[q] : 0, e = q < Q ? sp[q + 1] : 0;
+    const bool is_long = e - b > GEO_LONG;
+    if (q < Q && e == b && l == 0) for (int f = 0; f < F; ++f) raw[(long)q * F + f] = 0.f;
+    if (e > b && !is_long) geo_stats_row<DIM>(geom, qry, idx, raw, q, b, e, l, GEO_LANES, [](double v) { return group_sum_d(v); });
+    unsigned long long todo = __ballot(is_long && l == 0);
+    while (todo) {
+        const int first = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int qq = __shfl(q, first, 64), bb = __shfl(b, first, 64), ee = __shfl(e, first, 64);
+        geo_stats_row<DIM>(geom, qry, idx, raw, qq, bb, ee, lane, 64, [](double v) { return wave_sum_d(v); });
     }
-    sd = group_sum_d(sd);
-    sd2 = group_sum_d(sd2);
-    const double inv = 1.0 / n;
-    for (int d = 0; d < DIM; ++d) cen[d] = group_sum_d(cen[d]) * inv;
-    double cov[DIM][DIM];
-    for (int i = 0; i < DIM; ++i) for (int j = 0; j < DIM; ++j) cov[i][j] = 0.0;
-    for (int t = b + l; t < e; t += GEO_LANES) {
-        const float* y = geom + (long)idx[t] * DIM;
-        double c[DIM];
-        for (int d = 0; d < DIM; ++d) c[d] = (double)y[d] - cen[d];
-        for (int i = 0; i < DIM; ++i) for (int j = i; j < DIM; ++j) cov[i][j] += c[i] * c[j];
-    }
-    for (int i = 0; i < DIM; ++i) for (int j = i; j < DIM; ++j) { cov[i][j] = group_sum_d(cov[i][j]) * inv; cov[j][i] = cov[i][j]; }
-    if (l != 0) return;
-    double ev[DIM];
-    sym_eig_desc<DIM>(cov, ev);
-    const double mean = sd * inv;
-    double var = sd2 * inv - mean * mean;
-    if (var < 0.0) var = 0.0;
-    o[0] = (float)n; o[1] = (float)mean; o[2] = (float)var;
-    for (int d = 0; d < DIM; ++d) { o[3 + d] = (float)(cen[d] - x[d]); o[3 + DIM + d] = (float)ev[d]; }
 }
 // column statistics, deterministic and parallel: pass 0 = sum x, pass 1 = sum (x - mean)^2, every workgroup writes ITS fp64 partial sums to
 // part[group][pass][block][f] (no atomics); whoever needs a total adds the partials in block order.  Rows come in `groups` equal groups of Q

@@ -283,3 +283,46 @@ def test_auto_graph_vx_replays_shuffled_compositions_and_follows_coordinates():
     assert rb == 0 and ra == steps - 2, (ra, which)
     assert max(abs(a - b) / abs(b) for a, b in zip(la, lb)) < 1e-5, (la, lb)
     assert float((wa - wb).abs().max()) < 2e-5
+
+
+def test_a_captured_no_grad_vx_forward_keeps_its_unions_through_cache_eviction():
+    """A hipGraph captured over an EVALUATION-mode vx forward (what a rollout runner does per step) reads the composed unions of
+    plan.merged_geometry by raw address.  Those unions are pinned at capture: more than _MERGE_CACHE_MAX other compositions passing through the
+    cache afterwards (validation batches, a shuffling loader) must neither evict nor release them -- the replay still gives the captured
+    composition's result."""
+    from gaot_amd import plan as P
+    nS, B, N = 12, 3, 2048
+    model, sd, _ = make_model(3, 1, [32, 32], radius=0.066, seed=8)
+    lat, xs, enc, dec = _dataset(nS, N, seed=23, lat_sizes=(32, 32), radius=0.066)
+    latd, xd = lat.to(dev()), torch.stack(xs).to(dev())
+    encd = [[csr_dict(c) for c in row] for row in enc]
+    decd = [[csr_dict(c) for c in row] for row in dec]
+    model.to(dev()).eval()
+    g = torch.Generator().manual_seed(5)
+    p = torch.randn(B, N, 3, generator=g).to(dev())
+    b0 = [0, 1, 2]
+    x0 = xd[b0].contiguous()
+    kw0 = dict(latent_tokens_coord=latd, xcoord=x0, encoder_nbrs=[encd[i] for i in b0], decoder_nbrs=[decd[i] for i in b0])
+    with torch.no_grad():
+        want = model(pndata=p, **kw0).clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            model(pndata=p, **kw0)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, capture_error_mode="thread_local"):
+            y = model(pndata=p, **kw0)
+        pinned = [v[0] for v in P._MERGE_CACHE.values() if getattr(v[0], "pinned", False)]
+        assert len(pinned) == 2                      # the encoder's and the decoder's union of the captured composition
+        # many other compositions pass through the cache
+        for k in range(P._MERGE_CACHE_MAX + 3):
+            b = [(k + 3) % nS, (k + 5) % nS, (k + 8) % nS]
+            model(pndata=p, latent_tokens_coord=latd, xcoord=xd[b].contiguous(), encoder_nbrs=[encd[i] for i in b], decoder_nbrs=[decd[i] for i in b])
+        assert all(any(v[0] is u for v in P._MERGE_CACHE.values()) for u in pinned)
+        assert all(u.plan._coord_cache for u in pinned)          # not released
+        p2 = p * 1.0
+        gr.replay()
+        torch.cuda.synchronize()
+    assert torch.equal(y, want)
