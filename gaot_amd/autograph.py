@@ -272,7 +272,7 @@ def _capture(model, latent, xcoord, pndata, condition, enc=None, dec=None, union
             elif g.data_ptr() != v.data_ptr() and not ops.deferred_dest(v.data_ptr(), v.numel() * 4):
                 v.copy_(g)          # (a slice the grouped launches wrote is final already: ops._DEFERRED_DESTS)
 
-    saved_slots = dict(ops._GRAD_SLOTS)
+    saved_slots = ops.save_grad_slots()
     e.scratch = {}            # this entry's own tickets / counters (ops.scratch_owner): its replays may overlap another owner's launches
     owner = ops.scratch_owner(e.scratch)
     owner.__enter__()
@@ -315,8 +315,7 @@ def _capture(model, latent, xcoord, pndata, condition, enc=None, dec=None, union
     finally:
         owner.__exit__(None, None, None)
         P.FORCE_GUARD[0] = None
-        ops._GRAD_SLOTS.clear()
-        ops._GRAD_SLOTS.update(saved_slots)
+        ops.restore_grad_slots(saved_slots)
     return e
 
 

@@ -117,6 +117,8 @@ class AGNO(nn.Module):
                 hit = getattr(self, "_infer_k", None)
                 if hit is not None and hit[0] == key and hit[1] is feat:
                     k = hit[2]
+                    if torch.cuda.is_current_stream_capturing():      # read by address from the graph being captured: keep it past the cache entry
+                        self.__dict__.setdefault("_graph_keep", []).append(hit)
             if k is None:
                 k = self.channel_mlp(feat)                                   # [E, C]
                 if not torch.is_grad_enabled():

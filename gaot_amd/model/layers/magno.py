@@ -181,6 +181,8 @@ class _MAGNOBase(nn.Module):
                 self._coord_enc_cache.clear()
             hit = (c, node_pos_encode(c))
             self._coord_enc_cache[key] = hit
+        if torch.cuda.is_current_stream_capturing():          # (read by address from the graph being captured: keep it past the cache entry)
+            self.__dict__.setdefault("_graph_keep", []).append(hit)
         return hit[1]
 
     def _transform(self, src_coord, dst_coord, feats, neighbors, stats=None, head=None, lift=None, drop=True):
@@ -215,6 +217,10 @@ class _MAGNOBase(nn.Module):
                 hit = self._infer_cache.get("rowb")
                 if hit is not None and hit[0] == key and hit[1] is nb:
                     rowb = hit[2]
+                    if torch.cuda.is_current_stream_capturing():
+                        # the graph being captured reads this cached tensor by address: it must outlive the cache entry (another geometry's
+                        # evaluation pass replaces the entry; the replay would read freed memory)
+                        self.__dict__.setdefault("_graph_keep", []).append(hit)
             if rowb is None:
                 # embedding MLP and the geoembed half of the recovery block as one chain: [n_dst, C] -- in training together with the kernel
                 # MLP of this transform, ONE launch each way (ops.mlp_chain_pair: the chain alone is a few dozen workgroups on 256 CUs)

@@ -193,7 +193,7 @@ def begin_pass(keep_weights: bool = False) -> None:
         _WEIGHT_TABLE_FOR[0] = None
 
 
-_WEIGHT_TABLE_FOR = [None]        # id of the parameter list the table was built for
+_WEIGHT_TABLE_FOR = [None]        # the parameter list OBJECT the table was built for (held: an id() alone could be reused by another list)
 _PINNED_TABLES: list = []         # tables a captured inference graph reads without refreshing them itself: kept alive for good
 
 
@@ -202,7 +202,7 @@ def weights_current(params) -> bool:
     weights_generation(): nothing wrote a weight since refresh_weight_amax built it).  Writes that bypass both counters -- `p.data.copy_(ema)`,
     raw-pointer kernels -- must be followed by ops.bump_weights_generation() (trainer.FlatAdamW does; load_state_dict moves Parameter._version): the table
     holds the B operand itself (fp16 planes), not just a cache key."""
-    if not _WEIGHT_AMAX or _WEIGHT_TABLE_FOR[0] != id(params):
+    if not _WEIGHT_AMAX or _WEIGHT_TABLE_FOR[0] is not params:
         return False
     gen = weights_generation()
     for e in _WEIGHT_AMAX:
@@ -348,7 +348,7 @@ def refresh_weight_amax(params, groups=()) -> None:
     if pl_items:
         arr = (L.F16PlanesItem * len(pl_items))(*pl_items)
         L.check(L.load().gaot_split_f16_planes_grouped(arr, len(pl_items), _stream()), "gaot_split_f16_planes_grouped")
-    _WEIGHT_TABLE_FOR[0] = id(params)
+    _WEIGHT_TABLE_FOR[0] = params
 
 
 def _weight_entry(w2d: torch.Tensor):
@@ -789,30 +789,50 @@ def batchsum(x: torch.Tensor, B: int) -> torch.Tensor:
 # backward writes the weight gradient straight into it (no per-parameter temporary + pack copy); any further use of the
 # same parameter before the next FlatGradBucket.clear() takes the ordinary path and autograd accumulates as usual.
 # --------------------------------------------------------------------------------------------
-_GRAD_SLOTS: dict = {}
+# The slot lives ON its owner -- an attribute of the parameter (or of the forward-pass temporary that inherited a column block of it:
+# split_cols) -- not in a table keyed by id(): rounds 3-5 kept `{id(tensor): slot}` and paid for it with a silent path change when CPython
+# handed a freed temporary's id to a new model's Parameter.  An attribute cannot outlive or be confused with another object;
+# temporaries take theirs with them when the autograd graph dies.  `_SLOT_OWNERS` only lists the registered parameters (to reset and to
+# clear them).
+_SLOT_ATTR = "_gaot_grad_slot"          # [view of the flat gradient buffer, claimed in this forward pass]
+_SLOT_OWNERS: list = []
 
 
 def register_grad_slots(params, views):
-    _GRAD_SLOTS.clear()
-    # the temporaries' entries went with the clear() -- and with them the references that kept their id()s unique: a stale id left in
-    # _TEMP_SLOT_IDS may by now be the id of a NEW parameter, whose registration the next release_grad_slots() would then drop (that
-    # parameter's gradient would take the ordinary path for the whole training: correct, but rounded differently from a training in
-    # which the id was not reused -- two trainings from one seed in one process then differ in the last bit)
-    _TEMP_SLOT_IDS.clear()
+    for q in _SLOT_OWNERS:
+        if hasattr(q, _SLOT_ATTR):
+            delattr(q, _SLOT_ATTR)
+    _SLOT_OWNERS[:] = list(params)
     for p, v in zip(params, views):
-        _GRAD_SLOTS[id(p)] = [v, False, p]       # holding p keeps id(p) unique while registered
+        setattr(p, _SLOT_ATTR, [v, False])
 
 
 def release_grad_slots():
-    for k in _TEMP_SLOT_IDS:          # slices inherited by temporaries of the last forward pass (split_cols)
-        s = _GRAD_SLOTS.get(k)
-        if s is not None and len(s) == 4:         # (a temporary's entry, not a parameter's)
-            del _GRAD_SLOTS[k]
-    _TEMP_SLOT_IDS.clear()
-    for s in _GRAD_SLOTS.values():
-        s[1] = False
+    for q in _SLOT_OWNERS:
+        s = getattr(q, _SLOT_ATTR, None)
+        if s is not None:
+            s[1] = False
     _DEFERRED_DESTS.clear()
     _SHARED_SLOTS.clear()
+
+
+def grad_slot_of(t) -> Optional[torch.Tensor]:
+    """the registered gradient slice of a tensor (None: not registered)"""
+    s = getattr(t, _SLOT_ATTR, None)
+    return None if s is None else s[0]
+
+
+def save_grad_slots():
+    """the current registration, for a scope that registers its own (autograph's capture): restore_grad_slots puts it back"""
+    return [(q, getattr(q, _SLOT_ATTR, None)) for q in _SLOT_OWNERS]
+
+
+def restore_grad_slots(saved) -> None:
+    register_grad_slots([], [])
+    _SLOT_OWNERS[:] = [q for q, _ in saved]
+    for q, s in saved:
+        if s is not None:
+            setattr(q, _SLOT_ATTR, s)
 
 
 # Slots of parameters used MORE THAN ONCE in a forward pass (the reference shares agno / geoembed / lifting / recovery / projection
@@ -857,8 +877,8 @@ def _note_deferred(t: torch.Tensor) -> None:
 def _claim(w) -> Optional[torch.Tensor]:
     if w is None or not w.requires_grad:
         return None
-    s = _GRAD_SLOTS.get(id(w))
-    if s is None or s[2] is not w or s[0].device != w.device:
+    s = getattr(w, _SLOT_ATTR, None)
+    if s is None or s[0].device != w.device:
         return None
     if s[1]:
         _mark_shared(s[0])       # second use in this forward pass: the holder of the slot must not defer (see _SHARED_SLOTS)
@@ -872,13 +892,12 @@ def _claim_view(t) -> Optional[torch.Tensor]:
     squeezed): same storage address and element count"""
     if t is None or not t.requires_grad:
         return None
-    s = _GRAD_SLOTS.get(id(t))
-    if s is not None:
+    if getattr(t, _SLOT_ATTR, None) is not None:
         return _claim(t)
     ptr, n = t.data_ptr(), t.numel()
-    for s in _GRAD_SLOTS.values():
-        p = s[2]
-        if p.data_ptr() == ptr and p.numel() == n and s[0].device == t.device and t.is_contiguous():
+    for p in _SLOT_OWNERS:
+        s = getattr(p, _SLOT_ATTR, None)
+        if s is not None and p.data_ptr() == ptr and p.numel() == n and s[0].device == t.device and t.is_contiguous():
             if s[1]:
                 _mark_shared(s[0])
                 return None
@@ -1135,9 +1154,6 @@ class _SplitCols(torch.autograd.Function):
         return torch.cat([g1, g2], dim=1), None, None
 
 
-_TEMP_SLOT_IDS: list = []
-
-
 def split_cols(w, c: int, param=None):
     """(w[:, :c], w[:, c:]).  `param`: the nn.Parameter w is a reshaped view of (a Conv1d weight with its trailing singleton
     dimension squeezed).  When that parameter's gradient slice is registered, the two views inherit its column blocks as THEIR
@@ -1148,12 +1164,11 @@ def split_cols(w, c: int, param=None):
     s2 = slot.detach().view(w.shape[0], -1) if (slot is not None and w.dim() == 2 and slot.numel() == w.numel()
                                                  and c % 4 == 0 and (w.shape[1] - c) % 4 == 0) else None
     if slot is not None and s2 is None:
-        _GRAD_SLOTS[id(owner)][1] = False         # not forwarded: give the claim back
+        getattr(owner, _SLOT_ATTR)[1] = False         # not forwarded: give the claim back
     a, b = _SplitCols.apply(w, c, s2)
     if s2 is not None:
         for v, blk in ((a, s2[:, :c]), (b, s2[:, c:])):
-            _GRAD_SLOTS[id(v)] = [blk, False, v, True]          # 4th field: a temporary of this forward pass (release_grad_slots)
-            _TEMP_SLOT_IDS.append(id(v))
+            setattr(v, _SLOT_ATTR, [blk, False])          # a temporary of this forward pass: its slot dies with it
     return a, b
 
 

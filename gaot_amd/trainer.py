@@ -96,7 +96,7 @@ class FlatGradBucket:
             p.grad = None
         if self.flat.is_cuda:         # weight-gradient GEMMs of the HIP ops write straight into their views (ops._claim)
             from . import ops
-            if ops._GRAD_SLOTS.get(id(self.params[0]), [None])[0] is not self.views[0]:
+            if ops.grad_slot_of(self.params[0]) is not self.views[0]:
                 ops.register_grad_slots(self.params, self.views)
             ops.release_grad_slots()
 

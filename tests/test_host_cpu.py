@@ -274,32 +274,39 @@ def test_fp64_request_fails_at_the_module_and_leaves_fp32_parameters():
         m(latent_tokens_coord=g.t("in.latent"), xcoord=g.t("in.xcoord"), pndata=g.t("in.pndata").double())
 
 
-def test_a_stale_temporary_id_never_drops_a_parameters_gradient_slot():
-    """ops.split_cols registers the two column views of a weight under their id()s for ONE forward pass (ops._TEMP_SLOT_IDS);
-    register_grad_slots() drops those entries -- and with them the references that kept the ids unique.  CPython hands a freed id to
-    the next object of that size: a new model's Parameter may get it.  The next release_grad_slots() must not take that parameter's
-    registration away (its gradient would silently take the ordinary path for the whole training: two trainings from one seed in one
-    process then differed in the last bit)."""
+def test_gradient_slots_live_on_their_owners_not_under_ids():
+    """Rounds 3-5 kept gradient slots in a table keyed by id(tensor); a freed temporary's id, reused by a new model's Parameter, once made that
+    parameter's slot vanish (its gradient took the ordinary path for a whole training: two trainings from one seed then differed in the last
+    bit).  The slot is now an attribute of its owner: registering, claiming, releasing and re-registering involve no id at all, a temporary's
+    slot dies with the temporary, and a new registration clears the previous owners."""
+    import gc
     from gaot_amd import ops
-    saved, saved_ids = dict(ops._GRAD_SLOTS), list(ops._TEMP_SLOT_IDS)
+    saved = ops.save_grad_slots()
     try:
-        p = torch.nn.Parameter(torch.zeros(4, 4))
-        v = torch.zeros(4, 4)
-        ops.register_grad_slots([p], [v])
-        ops._TEMP_SLOT_IDS.append(id(p))                     # a stale id that has become a parameter's
+        p, q = torch.nn.Parameter(torch.zeros(4, 4)), torch.nn.Parameter(torch.zeros(2))
+        v, w = torch.zeros(4, 4), torch.zeros(2)
+        ops.register_grad_slots([p, q], [v, w])
+        assert ops.grad_slot_of(p) is v and ops.grad_slot_of(q) is w
+        assert ops._claim(p) is v and ops._claim(p) is None          # the first use of a forward pass holds the slot, the second does not
+        # temporaries come and go (their ids are reused freely): the parameters' slots do not move
+        for _ in range(200):
+            t = torch.zeros(4, 2)
+            setattr(t, ops._SLOT_ATTR, [v[:, :2], False])
+            del t
+        gc.collect()
         ops.release_grad_slots()
-        assert ops._GRAD_SLOTS.get(id(p), [None])[0] is v
-        t = torch.zeros(4, 2)
-        ops._GRAD_SLOTS[id(t)] = [v[:, :2], False, t, True]   # a temporary's entry, as split_cols leaves it
-        ops._TEMP_SLOT_IDS.append(id(t))
+        assert ops.grad_slot_of(p) is v and ops._claim(p) is v and ops._claim(q) is w
+        # a view of the parameter with the same storage claims through it (Conv1d weights with the trailing dimension squeezed)
         ops.release_grad_slots()
-        assert id(t) not in ops._GRAD_SLOTS and not ops._TEMP_SLOT_IDS and id(p) in ops._GRAD_SLOTS
-        ops._TEMP_SLOT_IDS.append(12345)
+        assert ops._claim_view(p.view(16)) is v
+        # another registration: the old owners are clean
+        p2 = torch.nn.Parameter(torch.zeros(4, 4))
+        ops.register_grad_slots([p2], [v])
+        assert ops.grad_slot_of(p) is None and ops.grad_slot_of(q) is None and ops.grad_slot_of(p2) is v
         ops.register_grad_slots([], [])
-        assert not ops._TEMP_SLOT_IDS and not ops._GRAD_SLOTS
+        assert ops.grad_slot_of(p2) is None and not ops._SLOT_OWNERS
     finally:
-        ops._GRAD_SLOTS.clear(); ops._GRAD_SLOTS.update(saved)
-        ops._TEMP_SLOT_IDS[:] = saved_ids
+        ops.restore_grad_slots(saved)
 
 
 def test_union_part_layouts_match_header():
