@@ -116,6 +116,90 @@ def test_gaot_two_ranks_two_gpus_over_rccl(graph, staged):
     _two_ranks(graph, staged, "nccl")
 
 
+# ---- vx under two ranks: every rank composes ITS OWN shard of a shuffled global batch (static padded unions, one captured step per edge bucket)
+def _vx_data():
+    from gaot_amd.model.layers.utils.neighbor_search import NeighborSearch
+    g = torch.Generator().manual_seed(33)
+    ax = torch.linspace(-1, 1, 32)
+    lat = torch.stack(torch.meshgrid(ax, ax, indexing="ij"), -1).reshape(-1, 2)
+    xs = torch.rand(8, 1500, 2, generator=g) * 2 - 1                     # a dataset of 8 meshes
+    return lat, xs, torch.randn(8, 1500, 2, generator=g), torch.randn(8, 1500, 1, generator=g)
+
+
+def _vx_model(seed):
+    m = _build(seed)
+    m.encoder.precompute_edges = m.decoder.precompute_edges = True
+    return m
+
+
+_VX_BATCHES = [[0, 5, 2, 7], [3, 1, 6, 4], [7, 2, 0, 3]]                 # three global batches of 4, every one another composition
+
+
+def _vx_graphs(lat, xs, dev):
+    from gaot_amd.model.layers.utils.neighbor_search import NeighborSearch
+    ns = NeighborSearch("native")
+    latd, xd = lat.to(dev), xs.to(dev)
+    return latd, xd, [[ns(xd[i], latd, 0.08)] for i in range(8)], [[ns(latd, xd[i], 0.08)] for i in range(8)]
+
+
+def _vx_worker(rank, world, port, out, graph):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gaot_amd.trainer import TrainStep
+    model = _vx_model(seed=300 + rank).to(dev).train()
+    lat, xs, p, t = _vx_data()
+    latd, xd, enc, dec = _vx_graphs(lat, xs, dev)
+    ts = TrainStep(model, lr=2e-3, weight_decay=1e-4, use_graph=graph)
+    mine = lambda b: b[rank::world]                                       # DistributedSampler-style strided shard of the global batch
+    b = mine(_VX_BATCHES[0])
+    ts.bind(p[b].to(dev), t[b].to(dev), latent_tokens_coord=latd, xcoord=xd[b], encoder_nbrs=[enc[i] for i in b], decoder_nbrs=[dec[i] for i in b])
+    for gb in _VX_BATCHES:
+        b = mine(gb)
+        ts.step(p[b].to(dev), t[b].to(dev), xcoord=xd[b], encoder_nbrs=[enc[i] for i in b], decoder_nbrs=[dec[i] for i in b])
+    torch.cuda.synchronize()
+    assert ts._vx and (ts._graphs is not None) == graph
+    flat = _flat(model).cpu()
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    if rank == 0:
+        out.put((gathered[0].tolist(), gathered[1].tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("graph", [True, False])
+def test_gaot_vx_two_ranks_shuffled_batches_equal_single_process_global_batch(graph):
+    """vx training sharded over two ranks (both on cuda:0, gloo): three shuffled global batches of four meshes, every rank composing its own
+    two samples per step on static padded unions (hipGraph replay per stage group when `graph`), gradients averaged -- ranks end bit-identical
+    and equal to single-process training on the global batches."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_vx_worker, args=(r, 2, port, q, graph)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    p0, p1 = q.get(timeout=600)
+    for p_ in procs:
+        p_.join(timeout=120)
+        assert p_.exitcode == 0
+    p0, p1 = torch.tensor(p0), torch.tensor(p1)
+    assert torch.equal(p0, p1)
+    from gaot_amd.trainer import TrainStep
+    dev = torch.device("cuda:0")
+    model = _vx_model(seed=300).to(dev).train()
+    lat, xs, p, t = _vx_data()
+    latd, xd, enc, dec = _vx_graphs(lat, xs, dev)
+    ts = TrainStep(model, lr=2e-3, weight_decay=1e-4, use_graph=False)
+    b = _VX_BATCHES[0]
+    ts.bind(p[b].to(dev), t[b].to(dev), latent_tokens_coord=latd, xcoord=xd[b], encoder_nbrs=[enc[i] for i in b], decoder_nbrs=[dec[i] for i in b])
+    for b in _VX_BATCHES:
+        ts.step(p[b].to(dev), t[b].to(dev), xcoord=xd[b], encoder_nbrs=[enc[i] for i in b], decoder_nbrs=[dec[i] for i in b])
+    ref = _flat(model).cpu()
+    assert float((p0 - ref).abs().max()) < 2e-5, float((p0 - ref).abs().max())
+
+
 def _bench_line_two_ranks(env_extra):
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
