@@ -25,5 +25,6 @@ python tools/pmc_report.py $OUT/pmc_c2.json $(ls $OUT/pmc_c2_*/*.db) >> $OUT/pmc
 python tools/pmc_report.py $OUT/pmc_c3.json $(ls $OUT/pmc_c3_*/*.db) >> $OUT/pmc.err 2>&1
 $P --kernel-trace -d $OUT/trace_c3 -o c3 -- python tools/eager_steps.py c3 10 graph > $OUT/c3_line.json 2>> $OUT/bench.err
 python tools/rocpd_stats.py $(ls $OUT/trace_c3/*.db | head -1) > $OUT/c3_kernel_stats.txt 2>> $OUT/bench.err
+python tools/step_sequence.py $(ls $OUT/trace_c3/*.db | head -1) > $OUT/c3_step_sequence.txt 2>> $OUT/bench.err
 rm -rf $OUT/trace $OUT/trace_c3 $OUT/pmc_c2_* $OUT/pmc_c3_*
 ls -la $OUT
