@@ -10,8 +10,9 @@
       10-step autoregressive rollout (stepper 'time_der'; hipGraph-replayed forward, fused stepper kernels) against the oracle
 
 Tolerances (north_star: <= 1e-5 relative output error, fp32): output rel-L2 <= 1e-5, loss <= 1e-5 relative, every gradient
-tensor rel-L2 <= 1e-4 (denominator floored at 1e-3 of the largest gradient norm of the model: a tensor whose true gradient
-is zero up to rounding -- e.g. the key bias under a softmax -- is compared absolutely, at 1e-7 of the model's gradient scale).
+tensor rel-L2 <= 1e-4 WITHOUT a floor on the denominator: a tensor at or below its own fp32 rounding -- e.g. the key bias under a
+softmax, zero in exact arithmetic -- is held to 3x the distance the reference's own fp32 arithmetic keeps from float64 on that
+tensor (one float64 oracle pass per test: tests/_golden.py `fp32_noise` / `unfloored_ratio`).
 Radius graphs: the oracle's `exact=True` search (explicit differences, the reference's `grid` backend = method 'auto') is the
 graph the HIP cell list must reproduce bit for bit; the cdist-based `native` backend differs from it only in pairs within
 rounding of the radius (checked below), so numeric parity is always taken on ONE graph.
