@@ -326,3 +326,43 @@ def test_a_captured_no_grad_vx_forward_keeps_its_unions_through_cache_eviction()
         gr.replay()
         torch.cuda.synchronize()
     assert torch.equal(y, want)
+
+
+def test_vx_static_path_3d_clouds_equal_composed_path_and_oracle():
+    """the same check on 3-D point clouds (coord_dim 3: three-coordinate rows in the compose kernel, the 3 x 3 covariance eigenvalues per row)"""
+    from gaot_amd import plan as P
+    from gaot_amd import ops
+    from oracle import gaot_oracle as O
+    from tests._golden import fp32_noise, unfloored_ratio
+    from tests._workloads import shell_points
+    B, N = 3, 3000
+    model, sd, ocfg = make_model(3, 1, [8, 8, 8], d=3, C=48, hidden=192, heads=4, radius=0.3, seed=12)
+    g = torch.Generator().manual_seed(12)
+    lat = grid([8, 8, 8])
+    xs = [shell_points(N, g) for _ in range(B)]
+    enc = [[O.radius_csr(x, lat, 0.3)] for x in xs]
+    dec = [[O.radius_csr(lat, x, 0.3)] for x in xs]
+    p, tgt = torch.randn(B, N, 3, generator=g), torch.randn(B, N, 1, generator=g)
+    x = torch.stack(xs)
+    model.to(dev()).train()
+    fk = dict(latent_tokens_coord=lat.to(dev()), xcoord=x.to(dev()),
+              encoder_nbrs=[[csr_dict(c) for c in row] for row in enc], decoder_nbrs=[[csr_dict(c) for c in row] for row in dec])
+    res = {}
+    for static in (True, False):
+        P.VX_STATIC = static
+        try:
+            model.zero_grad(set_to_none=True)
+            pred = model(pndata=p.to(dev()), **fk)
+            loss = ops.mse_loss(pred, tgt.to(dev()))
+            loss.backward()
+            torch.cuda.synchronize()
+            res[static] = (pred.detach().cpu(), float(loss.detach()), {k: q.grad.detach().cpu().clone() for k, q in model.named_parameters() if q.grad is not None})
+        finally:
+            P.VX_STATIC = True
+    (ya, la, ga), (yb, lb, gb) = res[True], res[False]
+    assert rel_l2(ya, yb) < 2e-6 and abs(la - lb) < 1e-6 * abs(lb)
+    batch = dict(latent=lat, xcoord=x, pndata=p, target=tgt, encoder_nbrs=enc, decoder_nbrs=dec)
+    lo, go, _, _, po = O.train_step(sd, ocfg, batch, return_pred=True)
+    assert rel_l2(ya, po) < OUT_TOL and abs(la - float(lo)) < LOSS_TOL * abs(float(lo))
+    ratio = unfloored_ratio(ga, {k: go[k] for k in ga}, fp32_noise(sd, ocfg, batch, go), GRAD_TOL)
+    assert max(ratio.values()) <= 1.0, max(ratio, key=ratio.get)
