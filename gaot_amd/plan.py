@@ -727,6 +727,8 @@ class StaticUnion:
 
     def refresh(self) -> None:
         """compose the union from the loaded table (capturable: a fixed launch over fixed addresses); the derived arrays follow on request"""
+        if self._hold is None:
+            raise RuntimeError("gaot_amd: StaticUnion.refresh() before any load(): the device table holds no sample pointers yet")
         pl = self.plan
         if self.raw:
             L.check(L.load().gaot_union_compose_raw(_p(self.table), self.B, self.n_dst, self.n_src, self.src.shape[1], self.dst.shape[1], self.e_cap,
