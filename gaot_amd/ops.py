@@ -439,21 +439,29 @@ def gemm(M: int, N: int, K: int, A, lda, a_kmajor, B, ldb, b_kmajor, out, ldc, *
                    pc, None, None, None, 0, 0, None, None, int(raw_slabs))
     gemm.last_c_amax = None
     if pc == 3 and _F16_PIECES[0]:
+        # whether B comes with pre-split planes is part of the dispatcher's answer (the 64 x 64 all-DMA tiles of narrow outputs need them):
+        # looked up BEFORE the dry run, part of the cache key
+        is_w = b_is_weight if b_is_weight is not None else kind != "tn"
+        wop = weight_operand(B, bool(b_kmajor)) if is_w else None
+        has_planes = wop is not None and wop[1] is not None and (b_amax is None or b_amax is wop[0])
         key = (M, N, K, int(a_kmajor), int(b_kmajor), act, split_k, colsum is None, bias is None, rowbias is None, rowscale is None,
                aux_in is None, aux_out is None, residual is None, lda % 4, ldb % 4, ldc % 4, ld_aux % 4, ldr % 4,
                (A.data_ptr() | B.data_ptr() | (0 if out is None else out.data_ptr())) & 15, _GEMM_MODE,
-               None if A2 is None else (k_split, lda2 % 4, A2.data_ptr() & 15), raw_slabs)
+               None if A2 is None else (k_split, lda2 % 4, A2.data_ptr() & 15), raw_slabs, has_planes)
         d.pieces, d.a_absmax, d.b_absmax = 4, A.data_ptr(), B.data_ptr()      # (placeholders: the dry run reads no memory)
         d.a2_absmax = None if A2 is None else A2.data_ptr()
+        if has_planes:
+            d.b_planes, d.ld_bplanes, d.b_plane_stride = wop[1], wop[2], wop[3]
         path = _gemm_path(d, key)
         d.pieces, d.a_absmax, d.b_absmax, d.a2_absmax = 3, None, None, None
+        d.b_planes, d.ld_bplanes, d.b_plane_stride = None, 0, 0
         if path == 3:
             if a_amax is None:
                 a_amax = amax_for(A)
             if A2 is not None:
                 d.a2_absmax = (a2_amax if a2_amax is not None else amax_for(A2)).data_ptr()
-            if b_is_weight if b_is_weight is not None else kind != "tn":
-                wword, pl, pl_ld, pl_stride = weight_operand(B, bool(b_kmajor))
+            if is_w:
+                wword, pl, pl_ld, pl_stride = wop
                 if b_amax is None:
                     b_amax = wword
                 if pl is not None and b_amax is wword:
