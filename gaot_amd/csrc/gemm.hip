@@ -367,7 +367,7 @@ int gaot_forced_pieces() { return g_split_pieces_forced ? g_split_pieces : 0; }
 
 static int g_use_ad = 1;         // all-DMA fp16-piece tiles: 0 off, 1 per the heuristic, 2 / 3: 64- / 128-row tiles wherever eligible (A/B switch)
 extern "C" int gaot_debug_set_gemm_ad(int on) { const int old = g_use_ad; g_use_ad = on; return old; }
-static int g_ad_narrow = 5;     // 64 x 64 all-DMA tiles (A/B switch, bits): 1 = half-filled launches of outputs two tiles wide (default), 2 = also N <= 256, K <= 256 at full launches, 4 = also outputs THREE tiles wide (4 096 tokens x 384: the 3-D configuration's o_proj-shaped products, which fell to the fp32-MFMA tiles; default), 8 = K slabs of such products too (4 096 x 384 x 1 152 in two slabs: C5 5.20 -> 5.27 ms same-box, tools/c45_ab.py 5 13: off)
+static int g_ad_narrow = 5;     // 64 x 64 all-DMA tiles (A/B switch, bits): 1 = half-filled launches of outputs two tiles wide (default), 2 = also N <= 256, K <= 256 at full launches, 4 = also outputs THREE tiles wide (4 096 tokens x 384: the 3-D configuration's o_proj-shaped products, which fell to the fp32-MFMA tiles; default), 8 = K slabs of such products too (4 096 x 384 x 1 152 in two slabs: C5 5.20 -> 5.27 ms same-box, tools/c45_ab.py 5 13: off), 16 = the concatenated-input (A2) product of the skip block too (C4 1.498 -> 1.500, C5 5.12 -> 5.09: nothing: off)
 extern "C" int gaot_debug_set_gemm_ad_narrow(int on) { const int old = g_ad_narrow; g_ad_narrow = on; return old; }
 static int g_use_planes = 1;     // 0: ignore gaot_gemm_desc.b_planes (A/B switch)
 extern "C" unsigned gaot_debug_split_redo_count(int reset) { return gaot::split_redo_count(reset != 0) + gaot::ad_redo_count(reset != 0); }
@@ -515,7 +515,7 @@ static int gemm_run(const gaot_gemm_desc* d, gaot_stream_t stream, const bool dr
     // (An earlier series of A/B runs looked inconsistent and twice ended at an unexplained loss: that was the host-side slot bookkeeping,
     // DESIGN 7, not these tiles.)
     const bool narrow_shape = g_use_ad == 1 && (g_ad_narrow & 1) && split_ok && !split128 && !split64 && pieces == 4 && ak && a.K % 32 == 0 && a.vec_epi &&
-                              (a.split_k <= 1 || ((g_ad_narrow & 8) && !raw)) && a.A2 == nullptr && (cdiv(a.N, 128) == 2 || ((g_ad_narrow & 4) && cdiv(a.N, 128) == 3)) && blocks(64, 64) >= 128 && (long)cdiv(a.M, 64) * cdiv(a.N, 128) < 250 &&
+                              (a.split_k <= 1 || ((g_ad_narrow & 8) && !raw)) && (a.A2 == nullptr || ((g_ad_narrow & 16) && a.k_split % 32 == 0)) && (cdiv(a.N, 128) == 2 || ((g_ad_narrow & 4) && cdiv(a.N, 128) == 3)) && blocks(64, 64) >= 128 && (long)cdiv(a.M, 64) * cdiv(a.N, 128) < 250 &&
                               (a.split_k <= 1 ? a.K : cdiv(cdiv(a.K, 32), a.split_k) * 32) <= 1024;          // (bit 8: K slabs of such a product too -- 4 096 x 384 x 1 152 in two slabs)
     const bool ad_narrow = narrow_shape && (dry ? d->b_planes != nullptr : a.Bpl != nullptr);
     // planes handed in but switched off (gaot_debug_set_gemm_planes(0)): the same tile family on the staged 64-row kernel, so that the
