@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""same-box A/B of gaot_debug_set_gemm_ad_narrow on the 4 096-token configurations: C4 (N = 256 products) and C5 (N = 384): ms per TrainStep step"""
+"""same-box A/B of an integer debug switch of the library (default gaot_debug_set_gemm_ad_narrow; or: c45_ab.py gaot_debug_set_X v1 v2) on the 4 096-token configurations: C4 (N = 256 products) and C5 (N = 384): ms per TrainStep step"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,11 +8,16 @@ lib = _lib.load()
 import tools.bench_configs as BC
 import bench
 from gaot_amd.trainer import TrainStep
-vals = [int(v) for v in sys.argv[1:]] or [1, 5]
+fname = "gaot_debug_set_gemm_ad_narrow"
+argv = sys.argv[1:]
+if argv and argv[0].startswith("gaot_"):
+    fname, argv = argv[0], argv[1:]
+vals = [int(v) for v in argv] or [1, 5]
+setter = getattr(lib, fname)
 dev = torch.device("cuda:0")
 res = {}
 for v in vals:
-    old = lib.gaot_debug_set_gemm_ad_narrow(v)
+    old = setter(v)
     ops._PATH_CACHE.clear(); ops.register_grad_slots([], [])
     ts5 = BC.c5(build_only=True)
     ops.register_grad_slots([], [])
@@ -26,7 +31,7 @@ for v in vals:
             ts.step()
     torch.cuda.synchronize()
     res[v] = (ts5, ts4)
-    lib.gaot_debug_set_gemm_ad_narrow(old)
+    setter(old)
 for rnd in range(3):
     for v in vals:
         out = []
@@ -36,4 +41,4 @@ for rnd in range(3):
                 ts.step()
             torch.cuda.synchronize()
             out.append((time.perf_counter() - t0) / n * 1e3)
-        print(f"ad_narrow={v}: C5 {out[0]:.4f} ms  C4 {out[1]:.4f} ms   losses {float(res[v][0]._loss):.6e} {float(res[v][1]._loss):.6e}", flush=True)
+        print(f"{fname}({v}): C5 {out[0]:.4f} ms  C4 {out[1]:.4f} ms   losses {float(res[v][0]._loss):.6e} {float(res[v][1]._loss):.6e}", flush=True)
