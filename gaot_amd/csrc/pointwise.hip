@@ -77,12 +77,13 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
         dwp[(long)blockIdx.x * D + d] = red[0][d] + red[1][d] + red[2][d] + red[3][d];
 }
 
-// 16-byte variants for D = 256 * NV: a lane owns float4 columns lane*4 + 256*v; one pass over x / dy.
-template <int NV>
+// 16-byte variants for D <= 256 * NV, D % 4 == 0 (256, 384, 512): a lane owns float4 columns lane*4 + 256*v where those lie inside the
+// row; one pass over x / dy.
+template <int NV, int D = 256 * NV>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ w, int M,
                                                               float eps, float* __restrict__ y, float* __restrict__ rstd,
                                                               float* __restrict__ y_amax) {
-    constexpr int D = 256 * NV;
+    static_assert(D % 4 == 0 && D > 256 * (NV - 1) && D <= 256 * NV, "row width");
     __shared__ float amred[4];
     const int row_ = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -92,7 +93,8 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_vec_kernel(const float* __res
     float ss = 0.f;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-        xv[v] = *reinterpret_cast<const f32x4*>(x + (long)row * D + v * 256 + lane * 4);
+        const bool on = v * 256 + lane * 4 < D;
+        xv[v] = on ? *reinterpret_cast<const f32x4*>(x + (long)row * D + v * 256 + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         ss += xv[v][0] * xv[v][0] + xv[v][1] * xv[v][1] + xv[v][2] * xv[v][2] + xv[v][3] * xv[v][3];
     }
     ss = wave_sum(ss);
@@ -101,6 +103,8 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_vec_kernel(const float* __res
     float am = 0.f;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
+        const bool on = v * 256 + lane * 4 < D;
+        if (!on) continue;
         const f32x4 wv = *reinterpret_cast<const f32x4*>(w + v * 256 + lane * 4);
         const f32x4 o = xv[v] * r * wv;
         if (live) *reinterpret_cast<f32x4*>(y + (long)row * D + v * 256 + lane * 4) = o;
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_vec_kernel(const float* __res
     }
     if (y_amax) amax_publish_block<4>(y_amax, am, amred);
 }
-template <int NV>
+template <int NV, int D = 256 * NV>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ rstd, const float* __restrict__ dy,
                                                               const float* __restrict__ dx_add, const float* __restrict__ dx_add2, int M,
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_vec_kernel(const float* __res
                                                               int nz, long zstride, const float* __restrict__ dy_add) {
     // nz > 1: dy arrives as the K slabs of the split-K product that computed it (zstride apart; gaot_gemm_desc.raw_slabs), summed here in
     // slab order instead of by a reduce launch of its own; dy_add: a further addend of dy (that product's fused residual)
-    constexpr int D = 256 * NV;
+    static_assert(D % 4 == 0 && D > 256 * (NV - 1) && D <= 256 * NV, "row width");
     __shared__ f32x4 red[4][NV][64];
     __shared__ float amred[4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_vec_kernel(const float* __res
     f32x4 wv[NV], dwacc[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-        wv[v] = *reinterpret_cast<const f32x4*>(w + v * 256 + lane * 4);
+        wv[v] = v * 256 + lane * 4 < D ? *reinterpret_cast<const f32x4*>(w + v * 256 + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         dwacc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int row_base = blockIdx.x * RMS_ROWS_PER_BLOCK;
@@ -135,6 +139,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_vec_kernel(const float* __res
         float dot = 0.f;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
+            if (v * 256 + lane * 4 >= D) { xv[v] = gv[v] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
             xv[v] = *reinterpret_cast<const f32x4*>(x + (long)row * D + v * 256 + lane * 4);
             gv[v] = *reinterpret_cast<const f32x4*>(dy + (long)row * D + v * 256 + lane * 4);
             for (int z = 1; z < nz; ++z) gv[v] += *reinterpret_cast<const f32x4*>(dy + z * zstride + (long)row * D + v * 256 + lane * 4);
@@ -147,6 +152,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_vec_kernel(const float* __res
         const float coef = r * r * r * dot / (float)D;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
+            if (v * 256 + lane * 4 >= D) continue;
             f32x4 o = wv[v] * gv[v] * r - xv[v] * coef;
             if (dx_add) o += *reinterpret_cast<const f32x4*>(dx_add + (long)row * D + v * 256 + lane * 4);
             if (dx_add2) o += *reinterpret_cast<const f32x4*>(dx_add2 + (long)row * D + v * 256 + lane * 4);
@@ -162,8 +168,9 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_vec_kernel(const float* __res
     if (wave == 0) {
 #pragma unroll
         for (int v = 0; v < NV; ++v)
-            *reinterpret_cast<f32x4*>(dwp + (long)blockIdx.x * D + v * 256 + lane * 4) =
-                red[0][v][lane] + red[1][v][lane] + red[2][v][lane] + red[3][v][lane];
+            if (v * 256 + lane * 4 < D)
+                *reinterpret_cast<f32x4*>(dwp + (long)blockIdx.x * D + v * 256 + lane * 4) =
+                    red[0][v][lane] + red[1][v][lane] + red[2][v][lane] + red[3][v][lane];
     }
 }
 
@@ -464,6 +471,7 @@ extern "C" int gaot_rmsnorm_fwd(const float* x, const float* w, int32_t M, int32
     const bool v16 = aligned16(x) && aligned16(w) && aligned16(y);
     if (v16 && D == 256)      hipLaunchKernelGGL(rmsnorm_fwd_vec_kernel<1>, dim3(cdiv(M, 4)), dim3(256), 0, ST(stream), x, w, M, eps, y, rstd, y_absmax);
     else if (v16 && D == 512) hipLaunchKernelGGL(rmsnorm_fwd_vec_kernel<2>, dim3(cdiv(M, 4)), dim3(256), 0, ST(stream), x, w, M, eps, y, rstd, y_absmax);
+    else if (v16 && D == 384) hipLaunchKernelGGL((rmsnorm_fwd_vec_kernel<2, 384>), dim3(cdiv(M, 4)), dim3(256), 0, ST(stream), x, w, M, eps, y, rstd, y_absmax);
     else hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, ST(stream), x, w, M, D, eps, y, rstd, y_absmax);
     GAOT_CHECK_LAUNCH("gaot_rmsnorm_fwd");
     return GAOT_OK;
@@ -481,6 +489,7 @@ extern "C" int gaot_rmsnorm_bwd(const float* x, const float* w, const float* rst
     const dim3 grid(cdiv(M, RMS_ROWS_PER_BLOCK));
     if (v16 && D == 256)      hipLaunchKernelGGL(rmsnorm_bwd_vec_kernel<1>, grid, dim3(256), 0, ST(stream), x, w, rstd, dy, dx_add, dx_add2, M, dx, dw_partial, dx_absmax, 1, 0L, (const float*)nullptr);
     else if (v16 && D == 512) hipLaunchKernelGGL(rmsnorm_bwd_vec_kernel<2>, grid, dim3(256), 0, ST(stream), x, w, rstd, dy, dx_add, dx_add2, M, dx, dw_partial, dx_absmax, 1, 0L, (const float*)nullptr);
+    else if (v16 && D == 384) hipLaunchKernelGGL((rmsnorm_bwd_vec_kernel<2, 384>), grid, dim3(256), 0, ST(stream), x, w, rstd, dy, dx_add, dx_add2, M, dx, dw_partial, dx_absmax, 1, 0L, (const float*)nullptr);
     else hipLaunchKernelGGL(rmsnorm_bwd_kernel, grid, dim3(256), 0, ST(stream), x, w, rstd, dy, dx_add, dx_add2, M, D, dx, dw_partial, dx_absmax);
     GAOT_CHECK_LAUNCH("gaot_rmsnorm_bwd");
     return GAOT_OK;
@@ -491,11 +500,12 @@ extern "C" int gaot_rmsnorm_bwd_slabs(const float* x, const float* w, const floa
                                       float* dw_partial, float* dx_absmax, gaot_stream_t stream) {
     GAOT_REQUIRE(x && w && rstd && dy_slabs && dx && dw_partial && M > 0 && n_slabs >= 1 && (n_slabs == 1 || slab_stride >= (int64_t)M * D),
                  "rmsnorm_bwd_slabs: bad arguments");
-    GAOT_REQUIRE((D == 256 || D == 512) && slab_stride % 4 == 0 && aligned16(x) && aligned16(w) && aligned16(dy_slabs) && aligned16(dx) && aligned16(dw_partial) &&
+    GAOT_REQUIRE((D == 256 || D == 384 || D == 512) && slab_stride % 4 == 0 && aligned16(x) && aligned16(w) && aligned16(dy_slabs) && aligned16(dx) && aligned16(dw_partial) &&
                  (!dy_add || aligned16(dy_add)) && (!dx_add || aligned16(dx_add)) && (!dx_add2 || aligned16(dx_add2)),
-                 "rmsnorm_bwd_slabs: D must be 256 or 512 (got %d) and every pointer 16-byte aligned", D);
+                 "rmsnorm_bwd_slabs: D must be 256, 384 or 512 (got %d) and every pointer 16-byte aligned", D);
     const dim3 grid(cdiv(M, RMS_ROWS_PER_BLOCK));
     if (D == 256) hipLaunchKernelGGL(rmsnorm_bwd_vec_kernel<1>, grid, dim3(256), 0, ST(stream), x, w, rstd, dy_slabs, dx_add, dx_add2, M, dx, dw_partial, dx_absmax, n_slabs, (long)slab_stride, dy_add);
+    else if (D == 384) hipLaunchKernelGGL((rmsnorm_bwd_vec_kernel<2, 384>), grid, dim3(256), 0, ST(stream), x, w, rstd, dy_slabs, dx_add, dx_add2, M, dx, dw_partial, dx_absmax, n_slabs, (long)slab_stride, dy_add);
     else          hipLaunchKernelGGL(rmsnorm_bwd_vec_kernel<2>, grid, dim3(256), 0, ST(stream), x, w, rstd, dy_slabs, dx_add, dx_add2, M, dx, dw_partial, dx_absmax, n_slabs, (long)slab_stride, dy_add);
     GAOT_CHECK_LAUNCH("gaot_rmsnorm_bwd_slabs");
     return GAOT_OK;

@@ -2360,7 +2360,7 @@ class _NormedSwiGLUFFN(torch.autograd.Function):
             dxw = _want_word(xm.device)
             split = _split_for_narrow_output(M, K, 2 * F, lambda: weight_operand(w13, False)[1] is not None)
             dd = d if ldd == K else d.contiguous()
-            if split > 1 and K in (256, 512):
+            if split > 1 and K in (256, 384, 512):
                 w13c, ldw13 = _rowmajor(w13)
                 ws, nz = gemm(M, K, 2 * F, du, 2 * F, 1, w13c, ldw13, 0, None, K, split_k=split, raw_slabs=True, a_amax=duw)
                 L.check(lib.gaot_rmsnorm_bwd_slabs(_p(xm), _p(wn), _p(rstd), _p(ws), nz, M * K, _p(dd), None, None, M, K, _p(dxm), _p(part), _p(dxw),

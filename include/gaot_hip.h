@@ -360,7 +360,7 @@ int gaot_rmsnorm_bwd(const float* x, const float* w, const float* rstd, const fl
                      int32_t M, int32_t D, float* dx, float* dw_partial, float* dx_absmax /* optional, as y_absmax */, gaot_stream_t stream);
 /* The same with dy = dy_slabs[0] + ... + dy_slabs[n_slabs - 1] (slab_stride floats apart) (+ dy_add): dy is the output of a split-K
  * product left as raw K slabs (gaot_gemm_desc.raw_slabs) and of its fused residual -- the slab sum happens here, in slab order,
- * instead of in a reduce launch of its own.  D = 256 or 512, 16-byte aligned pointers (else GAOT_ERR_INVALID: reduce, then
+ * instead of in a reduce launch of its own.  D = 256, 384 or 512, 16-byte aligned pointers (else GAOT_ERR_INVALID: reduce, then
  * gaot_rmsnorm_bwd). */
 int gaot_rmsnorm_bwd_slabs(const float* x, const float* w, const float* rstd, const float* dy_slabs, int32_t n_slabs, int64_t slab_stride,
                            const float* dy_add, const float* dx_add, const float* dx_add2, int32_t M, int32_t D, float* dx,

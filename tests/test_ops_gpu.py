@@ -235,7 +235,7 @@ def test_segment_softmax_and_sum():
 
 
 # ------------------------------------------------------------------ processor kernels
-@pytest.mark.parametrize("M,D", [(1000, 256), (37, 48), (8192, 64)])
+@pytest.mark.parametrize("M,D", [(1000, 256), (37, 48), (8192, 64), (4099, 384), (513, 512)])
 def test_rmsnorm(M, D):
     from gaot_amd import ops
     from oracle import gaot_oracle as O
@@ -1832,7 +1832,7 @@ def test_one_launch_mse_loss_and_gradient():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,K,F", [(8192, 256, 1024), (2048, 512, 1024), (1000, 256, 512)])
+@pytest.mark.parametrize("M,K,F", [(8192, 256, 1024), (2048, 512, 1024), (1000, 256, 512), (4096, 384, 1536)])
 def test_normed_swiglu_ffn_is_the_composition_of_its_parts(M, K, F):
     """ops.normed_swiglu_ffn (one node: the norm-gradient kernel sums the K slabs of du [w1; w3] itself, gaot_gemm_desc.raw_slabs +
     gaot_rmsnorm_bwd_slabs) against rms_norm followed by swiglu_ffn with the residual on the normalised stream: the same forward
