@@ -366,3 +366,45 @@ def test_vx_static_path_3d_clouds_equal_composed_path_and_oracle():
     assert rel_l2(ya, po) < OUT_TOL and abs(la - float(lo)) < LOSS_TOL * abs(float(lo))
     ratio = unfloored_ratio(ga, {k: go[k] for k in ga}, fp32_noise(sd, ocfg, batch, go), GRAD_TOL)
     assert max(ratio.values()) <= 1.0, max(ratio, key=ratio.get)
+
+
+@pytest.mark.parametrize("vx", [True, False])
+def test_auto_graph_keeps_replaying_with_neighbour_sub_sampling(vx):
+    """The unchanged reference loop on a model with `sampling_strategy='ratio'`: autograph captures the step WITH the device-side draw inside
+    (plan.DropPlan), replays it from the third sight on, and every replay trains on another subset -- the kept edge count moves from step to
+    step, the loss stays finite and close to the full-graph model's on the same data.  vx: caller-supplied per-sample lists (static unions);
+    fx: module-owned lists."""
+    from gaot_amd.model.gaot import GAOT
+    from gaot_amd import plan as P
+    B, N = 3, 2048
+    model, sd, _ = make_model(3, 1, [32, 32], radius=0.066, seed=14, precompute=vx, sampling_strategy="ratio", sample_ratio=0.7)
+    lat, xs, enc, dec = _dataset(B, N, seed=19, lat_sizes=(32, 32), radius=0.066)
+    latd = lat.to(dev())
+    xd = torch.stack(xs).to(dev()) if vx else xs[0].to(dev())
+    kw = dict(encoder_nbrs=[[csr_dict(c) for c in row] for row in enc], decoder_nbrs=[[csr_dict(c) for c in row] for row in dec]) if vx else {}
+    g = torch.Generator().manual_seed(4)
+    data = [(torch.randn(B, N, 3, generator=g).to(dev()), torch.randn(B, N, 1, generator=g).to(dev())) for _ in range(7)]
+    m = GAOT(3, 1, _cfg_of(model))
+    m.load_state_dict(sd)
+    m.to(dev()).train()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-4)
+    which, losses, kept = [], [], []
+    for p_, t_ in data:
+        opt.zero_grad()
+        out = m(latent_tokens_coord=latd, pndata=p_, xcoord=xd.clone(), **kw)
+        which.append(type(out.grad_fn).__name__)
+        loss = torch.nn.functional.mse_loss(out, t_)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+        if vx:
+            base = next(iter(m.encoder._static_unions.values())).plan
+        else:
+            base = P.plan_for(next(iter(m.encoder.neighbor_cache.values()))[0], N)
+        kept.append(int(next(iter(base._drops.values())).e_dev.item()))
+    replays = sum(w == "_GraphedStepBackward" for w in which)
+    assert replays == len(data) - 2, which
+    assert all(l == l and l < 10 for l in losses), losses
+    assert len(set(kept[2:])) >= 3, kept                       # every replay draws anew
+    full = sum(int(e[0][0].numel()) for e in enc) if vx else int(next(iter(m.encoder.neighbor_cache.values()))[0]["neighbors_index"].numel())
+    assert all(abs(k / full - 0.7) < 0.03 for k in kept), (kept, full)
