@@ -772,10 +772,20 @@ def colsum(x2: torch.Tensor, out: Optional[torch.Tensor] = None, final: bool = F
             _COLSUM_QUEUE.append((x2, ld, out.detach(), M, N, out.shape[1], out.stride(0)))
             _note_deferred(out)
             return out
+    strided = None
     if out is None:
         out = torch.empty(N, device=x2.device, dtype=torch.float32)
+    elif not out.is_contiguous():
+        # a column block of a wider gradient matrix outside the grouped launch (a parameter used twice in the pass -- the scales of a
+        # multiscale MAGNO share their weights -- never defers): gaot_colsum writes N contiguous floats, so sum into a temporary first
+        if out.numel() != N:
+            raise ValueError("colsum: a strided destination must hold exactly N elements")
+        strided, out = out, torch.empty(N, device=x2.device, dtype=torch.float32)
     scratch = torch.empty(int(lib.gaot_colsum_scratch(M, N)), device=x2.device, dtype=torch.float32)
     L.check(lib.gaot_colsum(_p(x2), ld, M, N, _p(out), _p(scratch), _stream()), "gaot_colsum")
+    if strided is not None:
+        strided.copy_(out.view(strided.shape))
+        return strided
     return out
 
 

@@ -408,3 +408,88 @@ def test_auto_graph_keeps_replaying_with_neighbour_sub_sampling(vx):
     assert len(set(kept[2:])) >= 3, kept                       # every replay draws anew
     full = sum(int(e[0][0].numel()) for e in enc) if vx else int(next(iter(m.encoder.neighbor_cache.values()))[0]["neighbors_index"].numel())
     assert all(abs(k / full - 0.7) < 0.03 for k in kept), (kept, full)
+
+
+def test_trainstep_vx_multiscale_shuffled_replay_equals_eager():
+    """two scales with learned scale weights: four static unions per batch (encoder and decoder x two radii), the decoder's scale weights read
+    the FIRST sample's coordinates of every batch (magno.py:610-612) from the step's static coordinate buffer -- replay == eager bit for bit
+    over shuffled compositions, staged backward (the data-parallel schedule) included."""
+    from gaot_amd.model.gaot import GAOT
+    from gaot_amd.trainer import TrainStep
+    from oracle import gaot_oracle as O
+    nS, B, N = 6, 3, 2048
+    model, sd, _ = make_model(3, 1, [32, 32], radius=0.066, seed=15, scales=[1.0, 0.5], use_scale_weights=True)
+    g = torch.Generator().manual_seed(15)
+    lat = grid([32, 32])
+    xs = [naca_points(N, g, 0.15) for _ in range(nS)]
+    enc = [[O.radius_csr(x, lat, 0.066 * s) for s in (1.0, 0.5)] for x in xs]
+    dec = [[O.radius_csr(lat, x, 0.066 * s) for s in (1.0, 0.5)] for x in xs]
+    P_all, T_all = torch.randn(nS, N, 3, generator=g), torch.randn(nS, N, 1, generator=g)
+    batches = _shuffled_batches(nS, B, 5, seed=8)
+    latd, xd = lat.to(dev()), torch.stack(xs).to(dev())
+    encd = [[csr_dict(c) for c in row] for row in enc]
+    decd = [[csr_dict(c) for c in row] for row in dec]
+    runs = {}
+    for graph, staged in ((True, False), (False, False), (True, True)):
+        m = GAOT(3, 1, _cfg_of(model))
+        m.load_state_dict(sd)
+        m.to(dev()).train()
+        ts = TrainStep(m, lr=2e-3, weight_decay=1e-4, use_graph=graph, staged=staged)
+        b0 = batches[0]
+        ts.bind(P_all[b0].to(dev()), T_all[b0].to(dev()), latent_tokens_coord=latd, xcoord=xd[b0], encoder_nbrs=[encd[i] for i in b0],
+                decoder_nbrs=[decd[i] for i in b0])
+        ls = [ts.step(P_all[b].to(dev()), T_all[b].to(dev()), xcoord=xd[b], encoder_nbrs=[encd[i] for i in b], decoder_nbrs=[decd[i] for i in b]).clone()
+              for b in batches]
+        torch.cuda.synchronize()
+        assert len(m.encoder._static_unions) >= 2 and len(m.decoder._static_unions) >= 2
+        runs[(graph, staged)] = (torch.stack(ls).cpu(), torch.cat([q.detach().reshape(-1) for q in m.parameters()]).cpu())
+    assert torch.equal(runs[(True, False)][0], runs[(False, False)][0]) and torch.equal(runs[(True, False)][1], runs[(False, False)][1])
+    # the staged schedule groups the weight-gradient launches differently: fp32 rounding, not bits
+    assert float((runs[(True, True)][1] - runs[(True, False)][1]).abs().max()) < 2e-5
+    assert float((runs[(True, True)][0] - runs[(True, False)][0]).abs().max()) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["vx", "fx"])
+def test_trainstep_multiscale_gradients_equal_plain_autograd(mode):
+    """the scales of a multiscale MAGNO share every weight: the second use of a parameter in a pass takes autograd's ordinary accumulation and
+    the first use must then write its registered slice at once, column blocks handed out by split_cols included (a strided block outside the
+    grouped launch).  The flat buffer after one TrainStep pass (eager and captured) == the gradients of a plain loss.backward()."""
+    from gaot_amd.model.gaot import GAOT
+    from gaot_amd.trainer import TrainStep
+    from gaot_amd import ops
+    from oracle import gaot_oracle as O
+    B, N = 2, 2048
+    model, sd, _ = make_model(3, 1, [32, 32], radius=0.066, seed=16, scales=[1.0, 0.5], use_scale_weights=True)
+    g = torch.Generator().manual_seed(16)
+    lat = grid([32, 32])
+    xs = [naca_points(N, g, 0.15) for _ in range(B)]
+    p, t = torch.randn(B, N, 3, generator=g).to(dev()), torch.randn(B, N, 1, generator=g).to(dev())
+    if mode == "vx":
+        kw = dict(latent_tokens_coord=lat.to(dev()), xcoord=torch.stack(xs).to(dev()),
+                  encoder_nbrs=[[csr_dict(O.radius_csr(x, lat, 0.066 * s)) for s in (1.0, 0.5)] for x in xs],
+                  decoder_nbrs=[[csr_dict(O.radius_csr(lat, x, 0.066 * s)) for s in (1.0, 0.5)] for x in xs])
+    else:
+        kw = dict(latent_tokens_coord=lat.to(dev()), xcoord=xs[0].to(dev()),
+                  encoder_nbrs=[csr_dict(O.radius_csr(xs[0], lat, 0.066 * s)) for s in (1.0, 0.5)],
+                  decoder_nbrs=[csr_dict(O.radius_csr(lat, xs[0], 0.066 * s)) for s in (1.0, 0.5)])
+    ref = GAOT(3, 1, _cfg_of(model))
+    ref.load_state_dict(sd)
+    ref.to(dev()).train()
+    loss = ops.mse_loss(ref(pndata=p, **kw), t)
+    loss.backward()
+    want = {k: q.grad.clone() for k, q in ref.named_parameters()}
+    del loss
+    ref.zero_grad(set_to_none=True)
+    for graph in (False, True):
+        m = GAOT(3, 1, _cfg_of(model))
+        m.load_state_dict(sd)
+        m.to(dev()).train()
+        ts = TrainStep(m, lr=0.0, weight_decay=0.0, use_graph=graph)
+        ts.bind(p, t, **kw)
+        for _ in range(2):          # (the second pass finds the buffer as the first left it: nothing may carry over)
+            ts.step()
+        torch.cuda.synchronize()
+        for k, q in m.named_parameters():
+            err = float((q.grad - want[k]).norm()) / max(float(want[k].norm()), 1e-30)
+            assert err < 2e-5, (mode, graph, k, err)
