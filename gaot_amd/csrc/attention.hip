@@ -2004,7 +2004,8 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
         }
         if (tid < 32) { lse_s[tid] = rl; if (!F16) del_s[tid] = rd; }
         if (F16 && kind == 1) {          // rows of the dO tile: eight consecutive lanes hold one row's 32 d
-            float dsum = (rk1[0] * ro[0] + rk1[1] * ro[1]) + (rk1[2] * ro[2] + rk1[3] * ro[3]);
+            // (explicit fused multiply-adds: left to the compiler, which products it contracts differs from one instantiation to the next)
+            float dsum = fmaf(rk1[0], ro[0], fmaf(rk1[1], ro[1], fmaf(rk1[2], ro[2], rk1[3] * ro[3])));
             dsum += __shfl_xor(dsum, 1, 64); dsum += __shfl_xor(dsum, 2, 64); dsum += __shfl_xor(dsum, 4, 64);
             if ((tid & 7) == 0) del_s[t8 >> 3] = dsum;
         }
@@ -2226,6 +2227,322 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
 }
 
 // ---------------------------------------------------------------------------------------------
+// [r6] the fp16-piece backward of attn_bwd_split8_kernel<2, 2, true, true, QS> (same arithmetic per wave, same fragments, bit-identical dK /
+// dV and dQ slabs at NW = 8) re-cut around ONE workgroup barrier per query tile instead of two, with a loop body that is one basic block:
+//   * the Q / dO tile planes, lse / delta and the waves' dQ partial tiles are double-buffered: after barrier t every wave (a) splits tile
+//     t + 1 (in its prefetch registers since the iteration before) into the other plane buffer and fetches tile t + 2, (b) sums the eight
+//     partials of tile t - 1 into the dQ slab, (c) computes tile t -- three independent streams the scheduler interleaves; the former
+//     barrier A (tile staged) and the serial reduce phase behind barrier B are gone;
+//   * the wave maximum of |dS| (the tile's fp16 scale) and the delta row sums run on the DPP path (common.h wave_max_nonneg / oct_sum)
+//     instead of six + three dependent ds_bpermute round trips per tile;
+//   * the K^T fragments of the dQ product stay in registers (16) instead of four LDS reads per tile: the per-wave LDS is the dS^T planes and
+//     two dQ partial tiles; LDS cut to what the mode uses: 20.5 KB shared + 13 KB per wave (NW = 8: 124.5 KB; NW = 4: 72.5 KB, two per CU);
+//   * no predicated stores or loads in the loop: rows past the sequence end and the reduce of "tile -1" store to a dump line at the head of
+//     the workspace (the delta array this mode does not use), every lane of a row writes the row's lse / delta word.
+// ---------------------------------------------------------------------------------------------
+template <int NW> struct AH16 {
+    static constexpr int QG = 2 * 2 * AB_KPL;                        // one buffer: Q and dO, two pieces each, k-major
+    static constexpr int SHARED = 2 * QG + 2 * 64 * 4;               // two buffers + two x (lse | delta)
+    static constexpr int PM = 32 * 32 * 4;                           // a wave's dQ partial tile
+    static constexpr int WAVE = 2 * AB_KPL + 2 * PM;                 // dS^T planes (K^T planes while the prologue builds its fragments; epilogue tile) + 2 partial tiles
+    static constexpr int LDS = SHARED + NW * WAVE;
+};
+#define SPLIT2H(x0, x1, sc, a, b) do { if (VAR & 1) split2h_pair_mix(x0, x1, sc, a, b); else split2h_pair(x0, x1, sc, a, b); } while (0)
+// VAR (tuning): bit 0 = second pieces through v_fma_mix{lo,hi}_f16, bit 1 = P masked and scaled by one multiply
+template <int NW, int QS = 1, int VAR = 0>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_h16_kernel(const AttnArgs p) {
+    constexpr int DP = 32, NT = 64 * NW, KPT = 512 / NT;          // KPT: staged tensors (Q, dO) per thread
+    static_assert(NW == 4 || NW == 8, "four or eight waves");
+    using G = AH16<NW>;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS];
+    float* aux = reinterpret_cast<float*>(smem + 2 * G::QG);       // [buffer][lse 32 | delta 32]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    int bh, kblk, qhalf = 0;
+    xcd_group_decode(blockIdx.x, p.B * p.H, p.n_kblocks * QS, bh, kblk);
+    if (QS > 1) { qhalf = kblk % QS; kblk /= QS; }
+    const int b = bh / p.H, h = bh % p.H, hk = h / (p.H / p.Hkv);
+    const int kv0 = kblk * (32 * NW) + wave * 32;
+    f32x4 kraw[2][2], vraw[2][2];
+    {
+        const float* krow = p.k + ((long)b * p.S + min(kv0 + li, p.S - 1)) * p.ldk + (long)hk * 32;
+        const float* vrow = p.v + ((long)b * p.S + min(kv0 + li, p.S - 1)) * p.ldv + (long)hk * 32;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            kraw[u][0] = *reinterpret_cast<const f32x4*>(krow + 16 * u + 8 * lh); kraw[u][1] = *reinterpret_cast<const f32x4*>(krow + 16 * u + 8 * lh + 4);
+            vraw[u][0] = *reinterpret_cast<const f32x4*>(vrow + 16 * u + 8 * lh); vraw[u][1] = *reinterpret_cast<const f32x4*>(vrow + 16 * u + 8 * lh + 4);
+        }
+    }
+    float sc_in = 1.f, so_in = 1.f, sc_g = 1.f, so_g = 1.f;
+    {
+        const unsigned w_in = amax_peek(p.qkv_amax), w_g = amax_peek(p.dout_amax);
+        amax_finish(w_in, sc_in, so_in);
+        amax_finish(w_g, sc_g, so_g);
+    }
+    const float c = p.scale * LOG2E * so_in * so_in;
+    const float dp_inv = so_g * so_in;
+    const float dv_inv = so_g * P_INV;
+    unsigned char* dSp = smem + G::SHARED + wave * G::WAVE;                      // 2 planes [kv][32 q]
+    unsigned char* Pm = dSp + 2 * AB_KPL;                                        // 2 x [32 q][32 d] fp32
+    const int tr_off = lds_tr_lane_offset(lane, AB_KROW);
+
+    bf16x8 kf[2][2], vf[2][2], kb[2][2];
+    const bool kv_ok = kv0 + li < p.S;
+    const float p_mask = kv_ok ? P_SCALE : 0.f;
+    {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const f32x4 a0 = kraw[u][0], a1 = kraw[u][1];
+            const f32x4 w0 = vraw[u][0], w1 = vraw[u][1];
+            u32x4 ph, pm, vh, vm;
+            unsigned a_, b_;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                SPLIT2H(a0[2 * e], a0[2 * e + 1], sc_in, a_, b_); ph[e] = a_; pm[e] = b_;
+                SPLIT2H(a1[2 * e], a1[2 * e + 1], sc_in, a_, b_); ph[2 + e] = a_; pm[2 + e] = b_;
+                SPLIT2H(w0[2 * e], w0[2 * e + 1], sc_in, a_, b_); vh[e] = a_; vm[e] = b_;
+                SPLIT2H(w1[2 * e], w1[2 * e + 1], sc_in, a_, b_); vh[2 + e] = a_; vm[2 + e] = b_;
+            }
+            kf[0][u] = __builtin_bit_cast(bf16x8, ph); kf[1][u] = __builtin_bit_cast(bf16x8, pm);
+            vf[0][u] = __builtin_bit_cast(bf16x8, vh); vf[1][u] = __builtin_bit_cast(bf16x8, vm);
+        }
+        // K^T planes [d][32 kv] of this wave's keys through its dS^T region, then the dQ product's B fragments for good
+        unsigned char* Ktp = dSp;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int item = lane + 64 * it, kp = item >> 3, d0 = (item & 7) * 4;
+            f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
+            if (kv0 + 2 * kp < p.S) r0 = *reinterpret_cast<const f32x4*>(p.k + ((long)b * p.S + kv0 + 2 * kp) * p.ldk + (long)hk * 32 + d0);
+            if (kv0 + 2 * kp + 1 < p.S) r1 = *reinterpret_cast<const f32x4*>(p.k + ((long)b * p.S + kv0 + 2 * kp + 1) * p.ldk + (long)hk * 32 + d0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned a_, b_;
+                SPLIT2H(r0[e], r1[e], sc_in, a_, b_);
+                unsigned char* dst = Ktp + (d0 + e) * AB_KROW + kp * 4;
+                *reinterpret_cast<unsigned*>(dst) = a_;
+                *reinterpret_cast<unsigned*>(dst + AB_KPL) = b_;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int pl_ = 0; pl_ < 2; ++pl_) {
+                const unsigned char* kr = Ktp + pl_ * AB_KPL + li * AB_KROW + (16 * u + 4 * lh) * 2;
+                kb[u][pl_] = __builtin_bit_cast(bf16x8, join8(*reinterpret_cast<const u32x2*>(kr), *reinterpret_cast<const u32x2*>(kr + 16)));
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                     // the fragments are in registers: the region is the dS^T planes from here on
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    f32x16 dvacc, dkacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dvacc[r] = 0.f; dkacc[r] = 0.f; }
+
+    const float* qbase = p.q + (long)b * p.S * p.ldq + (long)h * 32;
+    const float* gbase = p.dout + (long)b * p.S * p.ldo + (long)h * 32;
+    const float* obase = p.oin + (long)b * p.S * p.ldo + (long)h * 32;
+    const float* lse_b = p.lse + ((long)b * p.H + h) * p.S;
+    // staging: row = (tid & 255) >> 3, 4-d chunk = tid & 7; 512 threads: kind = tid >> 8 (0: Q, 1: dO; wave-uniform); 256 threads: every thread both
+    const int t8 = tid & 255, srow = t8 >> 3, sch = tid & 7;
+    f32x4 rk[KPT], ro = {0.f, 0.f, 0.f, 0.f};
+    float rl = 0.f;
+    auto fetch = [&](int q0) {
+        const long r_ = min(q0 + srow, p.S - 1);
+        const bool ok = q0 + srow < p.S;
+#pragma unroll
+        for (int kk = 0; kk < KPT; ++kk) {
+            const int kind = KPT == 2 ? kk : (tid >> 8);
+            rk[kk] = *reinterpret_cast<const f32x4*>((kind == 0 ? qbase + r_ * p.ldq : gbase + r_ * p.ldo) + sch * 4);
+            if (!ok) rk[kk] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        // (512 threads: the Q-staging waves load a line they have just asked for in place of O -- no branch in the loop)
+        ro = *reinterpret_cast<const f32x4*>(((KPT == 2 || (tid >> 8) == 1) ? obase + r_ * p.ldo : qbase + r_ * p.ldq) + sch * 4);
+        const float lv = lse_b[r_];          // (unconditional: a predicated load would put a branch and a full wait into the loop)
+        rl = ok ? lv * LOG2E : INFINITY;
+    };
+    // split the prefetched tile into plane buffer `buf`; every lane of a row writes the row's lse (Q side) / delta (dO side) word
+    auto stage = [&](int buf) {
+        unsigned char* Qk = smem + buf * G::QG;
+        unsigned char* Gk = Qk + 2 * AB_KPL;
+        float* ax = aux + buf * 64;
+#pragma unroll
+        for (int kk = 0; kk < KPT; ++kk) {
+            const int kind = KPT == 2 ? kk : (tid >> 8);
+            const float sc_st = kind == 0 ? sc_in : sc_g;
+            u32x2 h2, m2;
+            unsigned a_, b_;
+            SPLIT2H(rk[kk][0], rk[kk][1], sc_st, a_, b_); h2[0] = a_; m2[0] = b_;
+            SPLIT2H(rk[kk][2], rk[kk][3], sc_st, a_, b_); h2[1] = a_; m2[1] = b_;
+            unsigned char* dk_ = (kind == 0 ? Qk : Gk) + srow * AB_KROW + sch * 8;
+            *reinterpret_cast<u32x2*>(dk_) = h2; *reinterpret_cast<u32x2*>(dk_ + AB_KPL) = m2;
+            // delta[q] = sum_d dO[q][d] O[q][d]: eight consecutive lanes hold one row's 32 d
+            const float dsum = oct_sum(fmaf(rk[kk][0], ro[0], fmaf(rk[kk][1], ro[1], fmaf(rk[kk][2], ro[2], rk[kk][3] * ro[3]))));          // (as attn_bwd_split8_kernel: explicit, not the compiler's choice of contractions)
+            ax[kind * 32 + srow] = kind == 0 ? rl : dsum;
+        }
+    };
+    const int nq = (p.S + 31) / 32;
+    const long part_stride = (long)p.B * p.H * p.S * DP;
+    float* part = p.dq_part + (long)kblk * part_stride + ((long)b * p.H + h) * p.S * DP;
+    float* dump = p.delta;          // the head of the workspace: this mode keeps no delta array (>= 1 024 floats: checked by the launcher)
+    // fixed-order sum of the waves' partials of the tile at q0 -> this key block's slice of the dQ workspace
+    auto reduce = [&](int buf, int q0, bool live) {
+#pragma unroll
+        for (int i = 0; i < 1024 / NT; ++i) {
+            const int t = tid + i * NT;
+            const int row = t / DP;
+            float acc = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+                acc += reinterpret_cast<const float*>(smem + G::SHARED + w * G::WAVE + 2 * AB_KPL + buf * G::PM)[t];
+            float* dst = (live && q0 + row < p.S) ? part + (long)(q0 + row) * DP + (t % DP) : dump + t;
+            *dst = acc;
+        }
+    };
+    const int nq_each = (nq + QS - 1) / QS;
+    const int qt_begin = qhalf * nq_each, qt_end = min(nq, qt_begin + nq_each);
+    fetch(qt_begin * 32);
+    stage(0);
+    fetch(qt_begin * 32 + 32);
+    __syncthreads();
+    for (int qt = qt_begin; qt < qt_end; ++qt) {
+        const int cur = (qt - qt_begin) & 1;
+        const unsigned char* Qk = smem + cur * G::QG;
+        const unsigned char* Gk = Qk + 2 * AB_KPL;
+        const float* lse_s = aux + cur * 64;
+        const float* del_s = lse_s + 32;
+        stage(cur ^ 1);                         // tile qt + 1 (past the end: zeros / a clamped row, never read)
+        fetch(qt * 32 + 64);
+        reduce(cur ^ 1, qt * 32 - 32, qt > qt_begin);
+
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const unsigned char* qr = Qk + li * AB_KROW + u * 32 + lh * 16;
+            const unsigned char* gr = Gk + li * AB_KROW + u * 32 + lh * 16;
+            const bf16x8 q0_ = *reinterpret_cast<const bf16x8*>(qr), q1_ = *reinterpret_cast<const bf16x8*>(qr + AB_KPL);
+            const bf16x8 g0_ = *reinterpret_cast<const bf16x8*>(gr), g1_ = *reinterpret_cast<const bf16x8*>(gr + AB_KPL);
+            s = mfma16<true>(q1_, kf[0][u], s);
+            dp = mfma16<true>(g1_, vf[0][u], dp);
+            s = mfma16<true>(q0_, kf[1][u], s);
+            dp = mfma16<true>(g0_, vf[1][u], dp);
+            s = mfma16<true>(q0_, kf[0][u], s);
+            dp = mfma16<true>(g0_, vf[0][u], dp);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qr = crow(r, lh);
+            // P arrives masked (keys past the sequence end) AND scaled by 2^13 from one multiply; dS = P (dP - delta) carries the same factor
+            // into its own power-of-two tile scale (exact: the scale is formed from the scaled values)
+            float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c, -lse_s[qr]));
+            if (VAR & 2) pv *= p_mask; else if (!kv_ok) pv = 0.f;
+            s[r] = pv;
+            dp[r] = pv * fmaf(dp[r], dp_inv, -del_s[qr]);
+        }
+        float sc_ds = 1.f, ds_inv = 1.f;
+        {
+            float mx = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(dp[r]));
+            pow2_scale(wave_max_nonneg(mx), sc_ds, ds_inv);
+        }
+        const float dk_inv = (VAR & 2) ? ds_inv * so_in * P_INV : ds_inv * so_in, dq_inv = dk_inv;          // (ds_inv undoes sc_ds, formed from 2^13 dS: the pieces are those of sc dS)
+        f32x16 dvt, dkt;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dvt[r] = 0.f; dkt[r] = 0.f; }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            u32x4 ph, pm, sh, sm;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned a_, b_;
+                if (VAR & 2) { if (VAR & 1) split2h_pre(s[8 * u + 2 * e], s[8 * u + 2 * e + 1], a_, b_); else split2h_pair(s[8 * u + 2 * e], s[8 * u + 2 * e + 1], 1.f, a_, b_); } else SPLIT2H(s[8 * u + 2 * e], s[8 * u + 2 * e + 1], P_SCALE, a_, b_); ph[e] = a_; pm[e] = b_;
+                SPLIT2H(dp[8 * u + 2 * e], dp[8 * u + 2 * e + 1], sc_ds, a_, b_); sh[e] = a_; sm[e] = b_;
+            }
+            {   // dS^T pieces [kv = li][q]: registers 8u .. 8u + 3 are queries 16u + 4hi + 0..3, 8u + 4 .. 8u + 7 the same, eight up
+                unsigned char* dst = dSp + li * AB_KROW + (16 * u + 4 * lh) * 2;
+                *reinterpret_cast<u32x2*>(dst) = u32x2{sh[0], sh[1]};
+                *reinterpret_cast<u32x2*>(dst + 16) = u32x2{sh[2], sh[3]};
+                *reinterpret_cast<u32x2*>(dst + AB_KPL) = u32x2{sm[0], sm[1]};
+                *reinterpret_cast<u32x2*>(dst + AB_KPL + 16) = u32x2{sm[2], sm[3]};
+            }
+            const bf16x8 p0 = __builtin_bit_cast(bf16x8, ph), p1 = __builtin_bit_cast(bf16x8, pm);
+            const bf16x8 d0 = __builtin_bit_cast(bf16x8, sh), d1 = __builtin_bit_cast(bf16x8, sm);
+            bf16x8 ga[2], qa[2];
+#pragma unroll
+            for (int pl_ = 0; pl_ < 2; ++pl_) {
+                ga[pl_] = __builtin_bit_cast(bf16x8, join8(lds_tr(Gk + pl_ * AB_KPL + (16 * u) * AB_KROW + tr_off), lds_tr(Gk + pl_ * AB_KPL + (16 * u + 8) * AB_KROW + tr_off)));
+                qa[pl_] = __builtin_bit_cast(bf16x8, join8(lds_tr(Qk + pl_ * AB_KPL + (16 * u) * AB_KROW + tr_off), lds_tr(Qk + pl_ * AB_KPL + (16 * u + 8) * AB_KROW + tr_off)));
+            }
+            dvt = mfma16<true>(ga[1], p0, dvt);
+            dkt = mfma16<true>(qa[1], d0, dkt);
+            dvt = mfma16<true>(ga[0], p1, dvt);
+            dkt = mfma16<true>(qa[0], d1, dkt);
+            dvt = mfma16<true>(ga[0], p0, dvt);
+            dkt = mfma16<true>(qa[0], d0, dkt);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        f32x16 dq;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            bf16x8 da[2];
+#pragma unroll
+            for (int pl_ = 0; pl_ < 2; ++pl_)
+                da[pl_] = __builtin_bit_cast(bf16x8, join8(lds_tr(dSp + pl_ * AB_KPL + (16 * u) * AB_KROW + tr_off), lds_tr(dSp + pl_ * AB_KPL + (16 * u + 8) * AB_KROW + tr_off)));
+            dq = mfma16<true>(da[1], kb[u][0], dq);
+            dq = mfma16<true>(da[0], kb[u][1], dq);
+            dq = mfma16<true>(da[0], kb[u][0], dq);
+        }
+        float* Pmine = reinterpret_cast<float*>(Pm + cur * G::PM);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Pmine[crow(r, lh) * 32 + li] = dq[r] * dq_inv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            dvacc[r] = fmaf(dvt[r], dv_inv, dvacc[r]);
+            dkacc[r] = fmaf(dkt[r], dk_inv, dkacc[r]);
+        }
+        __syncthreads();          // the tile's partials are written, tile qt + 1 is staged, everyone is done with tile qt's planes and tile qt - 1's partials
+    }
+    reduce((qt_end - 1 - qt_begin) & 1, qt_end * 32 - 32, qt_end > qt_begin);
+    // ---- epilogue: dK^T, dV^T -> [kv][d] through the wave's (now free) dS region, coalesced row stores
+    float* Smine = reinterpret_cast<float*>(dSp);            // [32][33] floats = 4 224 B <= 5 120
+    float am = 0.f;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Smine[li * 33 + crow(r, lh)] = (pass == 0 ? dkacc[r] * p.scale : dvacc[r]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int rr = lh; rr < 32; rr += 2) {
+            const int kv = kv0 + rr;
+            if (kv < p.S) {
+                const float val = Smine[rr * 33 + li];
+                float* dst = pass == 0 ? p.dk + ((long)b * p.S + kv) * p.lddk + (long)h * 32 + li : p.dv + ((long)b * p.S + kv) * p.lddv + (long)h * 32 + li;
+                if (QS > 1 && qhalf == 1) dst = (pass == 0 ? p.dk2 : p.dv2) + ((long)b * p.S + kv) * ((long)p.H * 32) + (long)h * 32 + li;
+                *dst = val;
+                am = fmaxf(am, fabsf(val));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (p.dqkv_amax) { __syncthreads(); amax_publish_block<NW>(p.dqkv_amax, am * (float)QS, reinterpret_cast<float*>(smem)); }
+}
+
+// ---------------------------------------------------------------------------------------------
+#undef SPLIT2H
 // backward for 32 < head_dim <= 64 with two rounded pieces of everything, 8 waves x 32 keys = 256 keys per workgroup (one workgroup
 // per CU, two waves per SIMD -- the 4-wave kernel above runs one; half the Q / dO tile staging per key and half the dQ slabs).
 // Everything a wave keeps per key lives in LDS except V: K as two bf16 planes [32 kv][64 d] (B operand of S through 16-byte row
@@ -2503,6 +2820,7 @@ static int fill_common(AttnArgs& a, const float* q, const float* k, const float*
 using namespace gaot;
 #define ST(s) reinterpret_cast<hipStream_t>(s)
 
+static int g_attn_h16 = 0x18;    // [r6] the fp16-piece backward (256-key blocks, one workgroup per key block): 8 + 16 VAR = attn_bwd_h16_kernel<8, 1, VAR> (default VAR 1), 4 = <4>, 0 = attn_bwd_split8_kernel
 static int g_attn_split = 1;     // head_dim 32: 1 = split-bf16 kernels (default; 8-wave forward when it fills the chip), 0 = fp32-MFMA kernels,
                                  // 2 = split with the 8-wave forward always, 3 = split with the 4-wave forward always
 // pieces of P (forward) and of P / dS (backward) in the head_dim-32 split kernels, as 10 * forward + backward: 22 (default) = two ROUNDED
@@ -2528,6 +2846,7 @@ extern "C" int gaot_debug_set_attention_qsplit(int on) { const int old = g_attn_
 static int g_attn_pipe = 0;      // 1 = the software-pipelined 8-wave forward for S % 64 == 0 (same speed as the plain one since both keep the
                                  // tile product off the running accumulator: 57.6 vs 58.0 us; kept for tools/attn_ablate.hip and as a tested variant)
 extern "C" int gaot_debug_set_attention_pipe(int on) { const int old = g_attn_pipe; g_attn_pipe = on; return old; }
+extern "C" int gaot_debug_set_attention_h16(int nw) { const int old = g_attn_h16; g_attn_h16 = nw; return old; }
 extern "C" int gaot_debug_set_attention_split(int on) { const int old = g_attn_split; g_attn_split = on; return old; }
 
 extern "C" int gaot_attention_fwd(const float* q, const float* k, const float* v, int64_t ldq, int64_t ldk, int64_t ldv,
@@ -2715,6 +3034,8 @@ extern "C" int gaot_attention_bwd(const float* q, const float* k, const float* v
         a.n_kblocks = cdiv(S, 256);
         a.dk2 = a.dq_part + (long)a.n_kblocks * B * H * S * 32;          // the first two slabs the 256-key blocks leave unused
         a.dv2 = a.dk2 + (long)B * H * S * 32;
+        // (attn_bwd_h16_kernel<8, 2> measured equal here -- 76.5 against 77.2 us at 4 x 1 024 tokens: sixteen query tiles per workgroup -- so this
+        // shape stays on the kernel its tests were written against)
         hipLaunchKernelGGL((attn_bwd_split8_kernel<2, 2, true, true, 2>), dim3(a.n_kblocks * B * H * 2), dim3(512), 0, ST(stream), a);
         {
             const long rows = (long)B * S;
@@ -2724,7 +3045,18 @@ extern "C" int gaot_attention_bwd(const float* q, const float* k, const float* v
         dkdv_published = true;
     } else if (split_ok && g_attn_split != 3 && (g_attn_split == 2 || (long)cdiv(S, 256) * B * H >= 256)) {
         a.n_kblocks = cdiv(S, 256);          // 256 keys per workgroup: half the dQ slabs (the workspace is sized for 128)
-        if (f16 && fused_delta) { hipLaunchKernelGGL((attn_bwd_split8_kernel<2, 2, true, true>), dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a); dkdv_published = true; }
+        if (f16 && fused_delta && g_attn_h16 == 4 && (long)B * H * S >= 1024) { a.n_kblocks = cdiv(S, 128); hipLaunchKernelGGL((attn_bwd_h16_kernel<4>), dim3(a.n_kblocks * B * H), dim3(256), 0, ST(stream), a); dkdv_published = true; }
+        else if (f16 && fused_delta && (g_attn_h16 & 15) == 8 && (long)B * H * S >= 1024) {
+            const dim3 g8(a.n_kblocks * B * H);
+            switch (g_attn_h16 >> 4) {
+                case 1: hipLaunchKernelGGL((attn_bwd_h16_kernel<8, 1, 1>), g8, dim3(512), 0, ST(stream), a); break;
+                case 2: hipLaunchKernelGGL((attn_bwd_h16_kernel<8, 1, 2>), g8, dim3(512), 0, ST(stream), a); break;
+                case 3: hipLaunchKernelGGL((attn_bwd_h16_kernel<8, 1, 3>), g8, dim3(512), 0, ST(stream), a); break;
+                default: hipLaunchKernelGGL((attn_bwd_h16_kernel<8>), g8, dim3(512), 0, ST(stream), a); break;
+            }
+            dkdv_published = true;
+        }
+        else if (f16 && fused_delta) { hipLaunchKernelGGL((attn_bwd_split8_kernel<2, 2, true, true>), dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a); dkdv_published = true; }
         else if (g_attn_pp % 10 == 3) hipLaunchKernelGGL(attn_bwd_split8_kernel<3>, dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a);
         else if (g_attn_op == 3) hipLaunchKernelGGL(attn_bwd_split8_kernel<2>, dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a);
         else if (g_attn_tr) hipLaunchKernelGGL((attn_bwd_split8_kernel<2, 2, true>), dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a);

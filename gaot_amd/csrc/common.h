@@ -127,6 +127,28 @@ __device__ __forceinline__ void split2h_pair(float x0, float x1, float sc, unsig
     pm = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2_t));
 }
 
+// [r6] the same two pieces with the second one from v_fma_mixlo_f16 / v_fma_mixhi_f16: m = rn16(y - (float)h) in ONE instruction per element
+// (the fp16 operand is read in place, the difference is exact in fp32, one rounding to fp16) instead of v_cvt_f32_f16 + v_sub_f32 + half a
+// v_cvt_pk_f16_f32: five instructions per pair instead of eight, bit-identical (tools/probe/mix_split.hip: 10^7 pairs, five scales, zeros,
+// subnormals, overflow).  The mix instructions issue at half rate but, unlike the fp32 VOP2 ops, overlap with the matrix pipe
+// (tools/pipe_overlap.hip).  split2h_pre: the operand arrives already scaled (a compiler-generated multiply did it).
+__device__ __forceinline__ unsigned mix_residual(unsigned ph, float y0, float y1) {
+    unsigned m = 0u;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(m) : "v"(ph), "v"(y0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(m) : "v"(ph), "v"(y1));
+    return m;
+}
+__device__ __forceinline__ void split2h_pair_mix(float x0, float x1, float sc, unsigned& ph, unsigned& pm) {
+    const f32x2 x = {mul_scalar(x0, sc), mul_scalar(x1, sc)};
+    ph = __builtin_bit_cast(unsigned, __builtin_convertvector(x, f16x2_t));
+    pm = mix_residual(ph, x[0], x[1]);
+}
+__device__ __forceinline__ void split2h_pre(float y0, float y1, unsigned& ph, unsigned& pm) {
+    const f32x2 x = {y0, y1};
+    ph = __builtin_bit_cast(unsigned, __builtin_convertvector(x, f16x2_t));
+    pm = mix_residual(ph, y0, y1);
+}
+
 // transposing LDS read (gfx950 ds_read_b64_tr_b16): within each 16-lane group, lane t supplies the address of 4 consecutive 16-bit
 // COLUMNS of one row and receives 4 consecutive ROWS of one column: with lane t addressing row rbase + (t >> 2), columns
 // cbase + 4 (t & 3) .. + 3 it gets rows rbase .. rbase + 3 of column cbase + t (tools/probe/tr_read.hip prints the map).  Two of them
@@ -202,6 +224,25 @@ __device__ __forceinline__ void amax_finish(unsigned b, float& sc, float& inv) {
     se = se > 126 ? 126 : (se < -126 ? -126 : se);
     sc = __uint_as_float((unsigned)(127 + se) << 23);
     inv = __uint_as_float((unsigned)(127 - se) << 23);
+}
+
+// ---- cross-lane reductions on the DPP path (no LDS round trips: a ds_bpermute chain is six dependent ~100-cycle waits per 64-lane reduction)
+template <int CTRL> __device__ __forceinline__ int dpp_mov(int x) { return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xF, 0xF, true); }
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;          // quad_perm [1,0,3,2], [2,3,0,1]
+// maximum over the wave of NON-NEGATIVE floats (they order like their bit patterns), returned wave-uniform (scalar registers)
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+    int x = __float_as_int(v);
+    x = max(x, dpp_mov<DPP_XOR1>(x)); x = max(x, dpp_mov<DPP_XOR2>(x));
+    x = max(x, dpp_mov<DPP_HALF_MIRROR>(x)); x = max(x, dpp_mov<DPP_ROW_MIRROR>(x));          // every lane: its row's (16 lanes) maximum
+    const int a = __builtin_amdgcn_readlane(x, 0), b = __builtin_amdgcn_readlane(x, 16), c = __builtin_amdgcn_readlane(x, 32), d = __builtin_amdgcn_readlane(x, 48);
+    return __int_as_float(max(max(a, b), max(c, d)));
+}
+// sum over each group of eight consecutive lanes, in every lane of the group: the same additions as the __shfl_xor 1, 2, 4 butterfly (bit-identical)
+__device__ __forceinline__ float oct_sum(float v) {
+    v += __int_as_float(dpp_mov<DPP_XOR1>(__float_as_int(v)));
+    v += __int_as_float(dpp_mov<DPP_XOR2>(__float_as_int(v)));
+    v += __int_as_float(dpp_mov<DPP_HALF_MIRROR>(__float_as_int(v)));
+    return v;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

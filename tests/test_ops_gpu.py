@@ -1010,6 +1010,49 @@ def test_attention_fp16_piece_products():
 
 
 @pytest.mark.gpu
+def test_attention_backward_one_barrier_kernel_equals_the_two_barrier_one():
+    """[r6] attn_bwd_h16_kernel<8> (one workgroup barrier per query tile, double-buffered tile planes and dQ partials, DPP reductions, the second
+    pieces through v_fma_mix) computes what attn_bwd_split8_kernel<2, 2, true, true> does, in the same order: dQ, dK and dV are bit-identical --
+    full tiles, a ragged last query tile / key block (S = 1 000, 1 056 + 8), GQA, tiny and huge operands -- and within 1.2e-6 of float64.  The
+    4-wave form (two workgroups per CU, twice the dQ slabs) has bit-identical dK / dV and a dQ within fp32 rounding.  Shapes below the fused
+    kernel's reach (fewer than 256 key blocks) are untouched by the switch."""
+    from gaot_amd import ops, _lib
+    lib = _lib.load()
+    assert ops.precision() == "f32" and ops._F16_PIECES[0]
+    g = torch.Generator().manual_seed(21)
+
+    def grads(qkv, go, H, Hkv, mode):
+        old = lib.gaot_debug_set_attention_h16(mode)
+        try:
+            ops.begin_pass()
+            d = qkv.clone().requires_grad_(True)
+            out = ops.attention(d, H, Hkv, 32)
+            out.backward(go)
+        finally:
+            lib.gaot_debug_set_attention_h16(old)
+        return d.grad
+
+    assert lib.gaot_debug_set_attention_h16(0x18) == 0x18          # the default
+    for (B, S, H, Hkv, sq, sg) in ((8, 1024, 8, 8, 1.0, 1.0), (8, 1000, 8, 8, 1.0, 1.0), (9, 1064, 8, 4, 1.0, 1.0), (8, 2048, 8, 8, 1e-3, 1e-9), (16, 512, 8, 8, 3.0, 1e6)):
+        qkv = (torch.randn(B, S, (H + 2 * Hkv) * 32, generator=g) * sq).to(dev())
+        go = (torch.randn(B, S, H * 32, generator=g) * sg).to(dev())
+        want = grads(qkv, go, H, Hkv, 0)
+        for mode in (0x18, 0x08):
+            got = grads(qkv, go, H, Hkv, mode)
+            assert torch.equal(got, want), (B, S, hex(mode), float((got - want).abs().max()))
+        got4 = grads(qkv, go, H, Hkv, 4)
+        nq = H * 32
+        assert torch.equal(got4[..., nq:], want[..., nq:]) and rel(got4[..., :nq], want[..., :nq].double().cpu()) < 2e-7, (B, S)
+        if sq == 1.0:
+            r = qkv.double().cpu().requires_grad_(True)
+            q = r[..., :nq].reshape(B, S, H, 32).transpose(1, 2)
+            k, v = [r[..., nq + i * Hkv * 32:nq + (i + 1) * Hkv * 32].reshape(B, S, Hkv, 32).transpose(1, 2).repeat_interleave(H // Hkv, dim=1) for i in range(2)]
+            ref = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(32), -1) @ v).transpose(1, 2).reshape(B, S, nq)
+            ref.backward(go.double().cpu())
+            assert rel(want, r.grad) < 1.2e-6, (B, S, rel(want, r.grad))
+
+
+@pytest.mark.gpu
 def test_attention_two_piece_variant(bf16x2):
     """the "bf16x2" attention (`pieces` = 2 per call): P / dS and the Q / K / V / dO operands as two rounded bf16 pieces (three piece products per
     k-step in all seven products).  Random normal data (the worst case for a per-term relative error): output within 1e-5 and

@@ -4,7 +4,10 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from gaot_amd import ops
+from gaot_amd import _lib as L
 dev = torch.device("cuda:0")
+if "--h16" in sys.argv:          # 4 / 8: the fp16-piece backward as attn_bwd_h16_kernel<4 / 8>
+    L.load().gaot_debug_set_attention_h16(int(sys.argv[sys.argv.index("--h16") + 1]))
 def timeit(fn, iters=30):
     for _ in range(5): fn()
     torch.cuda.synchronize()

@@ -22,6 +22,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define MULF(x) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x) : "v"(y))
 #define ADDU(x) asm volatile("v_add_u32 %0, %0, %1" : "+v"(x) : "v"(m))
 #define FMAC(x) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(x) : "v"(y), "v"(z))
+#define MIXLO(x) asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(x) : "v"(m), "v"(y))
+#define MIXHI(x) asm volatile("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(x) : "v"(m), "v"(y))
 #define EXP(x) asm volatile("v_exp_f32 %0, %0" : "+v"(x))
 
 // MODE bit 0: MFMAs; bit 1: VALU ops; KIND: 0 fma, 1 and, 2 perm, 3 pk_add, 4 exp; NV = vector ops per MFMA slot
@@ -62,6 +64,7 @@ __global__ __launch_bounds__(512) void k(float* out, int iters) {
                     if (KIND == 10) BFI(xi[v & 7]);
                     if (KIND == 11) MAX3(x[v & 7]);
                     if (KIND == 12) PKFMA16(xi[v & 7]);
+                    if (KIND == 16) { if (v & 1) MIXHI(xi[v & 7]); else MIXLO(xi[v & 7]); }
                     if (KIND == 20) { asm volatile("ds_read_b128 %0, %1" : "=v"(ld[v & 3]) : "v"(laddr)); }
                     if (KIND == 21) { asm volatile("ds_read_b64 %0, %1" : "=v"(ld2[v & 3]) : "v"(laddr)); }
                     if (KIND == 22) { asm volatile("ds_write_b32 %0, %1" : : "v"(laddr), "v"(xi[v & 7]) : "memory"); }
@@ -109,6 +112,7 @@ __global__ __launch_bounds__(512) void k_opposed(float* out, int iters, int who)
                     if (KIND == 13) MULF(x[v & 7]);
                     if (KIND == 14) ADDU(xi[v & 7]);
                     if (KIND == 15) FMAC(x[v & 7]);
+                    if (KIND == 16) { if (v & 1) MIXHI(xi[v & 7]); else MIXLO(xi[v & 7]); }
                 }
         }
     }
@@ -158,7 +162,8 @@ int main() {
     float* out; hipMalloc(&out, 4);
     opposed<0, 4>("fma", out); opposed<0, 8>("fma", out); opposed<0, 12>("fma", out); opposed<1, 8>("and", out); opposed<2, 8>("perm", out);
     opposed<4, 4>("exp", out); opposed<6, 8>("sub_f32", out); opposed<7, 8>("cvt_pk_bf16", out); opposed<11, 8>("max3", out); opposed<13, 8>("mul_f32", out);
-    opposed<14, 8>("add_u32", out); opposed<15, 8>("fmac_f32 (VOP2)", out);
+    opposed<14, 8>("add_u32", out); opposed<15, 8>("fmac_f32 (VOP2)", out); opposed<16, 8>("fma_mixlo/hi_f16", out);
+    row<16, 8>("fma_mix", out);
     row<20, 1>("ds_read_b128", out); row<20, 2>("ds_read_b128", out); row<21, 2>("ds_read_b64", out); row<22, 2>("ds_write_b32", out);
     row<0, 8>("fma", out); row<3, 8>("pk_add", out); row<5, 8>("1pk+7fma", out); row<6, 8>("sub", out); row<7, 8>("cvt_pk_bf16", out);
     row<8, 8>("pk_mov", out); row<9, 8>("lshl", out); row<10, 8>("bfi", out); row<11, 8>("max3", out); row<1, 8>("and", out); row<2, 8>("perm", out);
