@@ -605,8 +605,9 @@ extern "C" int gaot_gemm_path(const gaot_gemm_desc* d) {
 }
 
 // ---- grouped weight-gradient products (kernel: gemm_split.hip)
-namespace gaot { void set_tn_kslab(int k); }
+namespace gaot { void set_tn_kslab(int k); void set_tn_bm(int bm); }
 extern "C" int gaot_debug_set_wgrad_kslab(int k) { gaot::set_tn_kslab(k); return 0; }
+extern "C" int gaot_debug_set_wgrad_tile_rows(int bm) { gaot::set_tn_bm(bm); return 0; }
 static int check_wgrad_items(const gaot_wgrad_item* items, int n) {
     GAOT_REQUIRE(items != nullptr && n > 0, "gemm_tn_grouped: no items");
     for (int i = 0; i < n; ++i) {
@@ -625,9 +626,11 @@ extern "C" int64_t gaot_gemm_tn_grouped_workspace(const gaot_wgrad_item* items, 
     if (check_wgrad_items(items, n) != GAOT_OK) return -1;
     long ws = 0; int cnt = 0;
     for (int i0 = 0; i0 < n; i0 += TN_GROUP_MAX) {          // launches of at most TN_GROUP_MAX products share the buffers: sizes add up
-        int c = 0;
-        ws += plan_tn_grouped(items + i0, n - i0 < TN_GROUP_MAX ? n - i0 : TN_GROUP_MAX, nullptr, &c, nullptr);
-        cnt += c;
+        int c = 0, c2 = 0;          // sized for either tile height (the launch picks by `pieces`, which this query does not know)
+        const int m = n - i0 < TN_GROUP_MAX ? n - i0 : TN_GROUP_MAX;
+        const long w1 = plan_tn_grouped(items + i0, m, nullptr, &c, nullptr, 128), w2 = plan_tn_grouped(items + i0, m, nullptr, &c2, nullptr);
+        ws += w1 > w2 ? w1 : w2;
+        cnt += c > c2 ? c : c2;
     }
     if (n_counters) *n_counters = cnt;
     return ws;
@@ -646,8 +649,10 @@ extern "C" int gaot_gemm_tn_grouped(const gaot_wgrad_item* items, int32_t n, int
     long ws_off = 0; int cnt_off = 0;
     for (int i0 = 0; i0 < n; i0 += TN_GROUP_MAX) {
         const int m = n - i0 < TN_GROUP_MAX ? n - i0 : TN_GROUP_MAX;
-        int c = 0;
-        const long w = plan_tn_grouped(items + i0, m, nullptr, &c, nullptr);
+        int c = 0, c2 = 0;
+        const long w1 = plan_tn_grouped(items + i0, m, nullptr, &c, nullptr, 128), w2 = plan_tn_grouped(items + i0, m, nullptr, &c2, nullptr);
+        const long w = w1 > w2 ? w1 : w2;
+        c = c > c2 ? c : c2;
         launch_tn_grouped(items + i0, m, workspace + ws_off, counters + cnt_off, pieces >= 4 ? 4 : (pieces == 2 ? 2 : 3), st);
         GAOT_CHECK_LAUNCH("gaot_gemm_tn_grouped");
         ws_off += w; cnt_off += c;

@@ -236,7 +236,7 @@ unsigned ad_redo_count(bool reset);
 unsigned split_redo_count(bool reset);      // tiles that took the fp16 pieces' second (three-piece) pass: a device counter for tests / tools
 // grouped weight-gradient launch (gemm_split.hip): prefix table / workspace need of n items; the launch itself
 struct TnGroupArgs;
-long plan_tn_grouped(const gaot_wgrad_item* items, int n, TnGroupArgs* args, int* n_counters, int* n_wg);
+long plan_tn_grouped(const gaot_wgrad_item* items, int n, TnGroupArgs* args, int* n_counters, int* n_wg, int force_bm = 0);
 void launch_tn_grouped(const gaot_wgrad_item* items, int n, float* ws, int* counters, int pieces, hipStream_t st);
 constexpr int TN_GROUP_MAX = 24;          // products per launch (the table travels in the kernel arguments)
 

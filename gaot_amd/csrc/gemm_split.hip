@@ -665,9 +665,11 @@ struct TnGroupArgs { int n; float* ws; int* counters; TnProb p[TNG_MAX]; };
 // 4 096, 364 us): without the split arithmetic 345, without MFMAs 269, without LDS fragment reads 297, without in-loop global loads
 // 304, without LDS plane writes 282, without the barrier 351 -- every part costs 20-100 us and the parts ADD UP (the k-loop's
 // load -> split -> plane write -> barrier -> fragment read -> MFMA chain is not overlapped across the two resident workgroups of a CU).
-template <int ABL = 0, int NP = 3>
-__global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const TnGroupArgs g) {      // (three per CU: 168 registers, 94 spilled)
-    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SplitGeom<128, NP>::SMEM_BYTES];
+// BM = 256 [r6]: 256 x 128 tiles on eight waves, ONE workgroup per CU (the same eight waves and register budget as two 128 x 128
+// workgroups): 384 operand rows per k-tile and CU instead of 512 for the same products
+template <int ABL = 0, int NP = 3, int BM = 128>
+__global__ __launch_bounds__(BM == 256 ? 512 : 256, BM == 256 ? 1 : 2) void gemm_tn_grouped_kernel(const TnGroupArgs g) {      // (three per CU: 168 registers, 94 spilled)
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SplitGeom<BM, NP>::SMEM_BYTES];
     // XCD-aware order (workgroup b runs on XCD b % 8): every XCD takes a CONTIGUOUS range of the logical work list, and inside
     // a product the list runs K slab by K slab, tile row by tile row -- so the workgroups an XCD's L2 serves at the same time
     // share the A panel of one (tile row, K slab) and walk the B panels of neighbouring tile columns
@@ -694,7 +696,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const TnGroupAr
     a.a_amax = g.p[i].a_amax; a.b_amax = g.p[i].b_amax; a.c_amax = nullptr; a.a2_amax = nullptr;
     a.Bpl = nullptr; a.ld_bpl = 0; a.bpl_stride = 0;
     a.bpl_flag = 0;
-    split_tile<false, false, 128, ABL, NP, 64, false>(a, smem_raw, tile, z);
+    split_tile<false, false, BM, ABL, NP, 64, false>(a, smem_raw, tile, z);
     if (split <= 1) return;
 
     const int tid = threadIdx.x;
@@ -715,10 +717,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const TnGroupAr
     }
     __syncthreads();
     if (!*flag) return;
-    const int m0 = (tile / a.tiles_n) * 128, n0 = (tile % a.tiles_n) * 128;
+    const int m0 = (tile / a.tiles_n) * BM, n0 = (tile % a.tiles_n) * 128;
     const long slab = (long)a.M * a.N;
 #pragma unroll 4
-    for (int idx = tid; idx < 128 * 32; idx += 256) {
+    for (int idx = tid; idx < BM * 32; idx += (BM == 256 ? 512 : 256)) {
         const int m = m0 + (idx >> 5), n = n0 + (idx & 31) * 4;
         if (m < a.M && n < a.N) {
             const float* src = a.ws + (long)m * a.N + n;
@@ -727,7 +729,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const TnGroupAr
             *reinterpret_cast<f32x4*>(a.C + (long)m * a.ldc + n) = s;
         }
     }
-    if (a.colsum != nullptr && (tile % a.tiles_n) == 0 && tid < 128 && m0 + tid < a.M) {
+    if (a.colsum != nullptr && (tile % a.tiles_n) == 0 && tid < BM && m0 + tid < a.M) {
         const float* src = a.ws + (long)split * slab + m0 + tid;
         float s = src[0];
         for (int zz = 1; zz < split; ++zz) s += src[(long)zz * a.M];
@@ -735,6 +737,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const TnGroupAr
     }
 }
 
+static int g_tn_bm = 128;            // tile rows of the grouped launch: 128, or 256 when every product's M is a multiple of 256 (tuning hook)
+void set_tn_bm(int bm) { g_tn_bm = bm == 256 ? 256 : 128; }
+static int tn_tile_rows(const gaot_wgrad_item* items, int n) {
+    if (g_tn_bm != 256) return 128;
+    for (int i = 0; i < n; ++i) if (items[i].M % 256 != 0) return 128;
+    return 256;
+}
 static int g_tn_kslab = 0;           // 0 = automatic (below); otherwise a fixed K slab (tuning hook)
 static int g_tn_cap_long = 4096;     // the same for node-level products (K = batch x nodes > 16 384)
 static int g_tn_cap = 4096;          // longest K slab of a product whose reduction is much longer than the rest (tuning hook: a negative argument sets it)
@@ -744,7 +753,7 @@ void set_tn_kslab(int k) {
     g_tn_kslab = k == 0 ? 0 : (k < 256 ? 256 : (k / 32) * 32);
 }
 // host side of the grouped launch: items -> prefix table; returns the workspace floats / counters it needs when `args` is null
-long plan_tn_grouped(const gaot_wgrad_item* items, int n, TnGroupArgs* args, int* n_counters, int* n_wg) {
+long plan_tn_grouped(const gaot_wgrad_item* items, int n, TnGroupArgs* args, int* n_counters, int* n_wg, int force_bm) {
     long ws = 0; int cnt = 0, wg = 0;
     // K slab per workgroup: the accumulators are flushed to the vector pipe every 1 024 values of k inside the kernel, so the slab
     // length is a load-balance / slab-traffic choice.  A launch lasts as long as one workgroup's K loop, whatever the number of work
@@ -752,9 +761,11 @@ long plan_tn_grouped(const gaot_wgrad_item* items, int n, TnGroupArgs* args, int
     // than one workgroup per CU (272).  Measured (tools/wgrad_kslab_sweep.py, K = 8 192): the 14-15 products of a whole backward pass
     // (204 tiles): 314 / 340 / 387 us at slabs of 4 096 / 2 048 / 1 024 -> 2 slabs; the 4 products of ONE phase of a staged backward
     // (68 tiles): 160 / 108 / 123 us -> 4 slabs.
+    const int BMr = force_bm ? force_bm : tn_tile_rows(items, n);
     long tiles_total = 0;
-    for (int i = 0; i < n; ++i) tiles_total += (long)cdiv(items[i].M, 128) * cdiv(items[i].N, 128);
-    const int want = (int)((272 + tiles_total - 1) / (tiles_total > 0 ? tiles_total : 1));
+    for (int i = 0; i < n; ++i) tiles_total += (long)cdiv(items[i].M, BMr) * cdiv(items[i].N, 128);
+    const int want = BMr == 256 ? (int)(256 / (tiles_total > 0 ? tiles_total : 1))          // one workgroup per CU: not more than one round
+                                : (int)((272 + tiles_total - 1) / (tiles_total > 0 ? tiles_total : 1));
     // ONE slab length for the whole launch: the launch lasts as long as its longest K loop times the rounds, so a product with a longer
     // reduction than the rest (the patch-level layers: K = 4 x tokens; node-level ones: batch x nodes) is cut to the slab of the shortest
     // one, not to a fixed 4 096 -- 4 096-token batch, same box (tools/step_ab.py gaot_debug_set_wgrad_kslab ... --c4), slabs of
@@ -784,7 +795,7 @@ long plan_tn_grouped(const gaot_wgrad_item* items, int n, TnGroupArgs* args, int
         int split = (it.K + kslab - 1) / kslab;
         int per = (kt32 + split - 1) / split;
         split = (kt32 + per - 1) / per;
-        const int tm = cdiv(it.M, 128), tn = cdiv(it.N, 128);
+        const int tm = cdiv(it.M, BMr), tn = cdiv(it.N, 128);
         if (args) {
             TnProb& q = args->p[i];
             q.A = it.g; q.B = it.x; q.C = it.out; q.colsum = it.colsum;
@@ -806,8 +817,10 @@ void launch_tn_grouped(const gaot_wgrad_item* items, int n, float* ws, int* coun
     TnGroupArgs args;
     args.n = n; args.ws = ws; args.counters = counters;
     int wg = 0;
-    plan_tn_grouped(items, n, &args, nullptr, &wg);
-    if (pieces == 4) hipLaunchKernelGGL((gemm_tn_grouped_kernel<0, 4>), dim3(wg), dim3(256), 0, st, args);
+    const int bm = pieces == 4 ? tn_tile_rows(items, n) : 128;          // (the 256-row tiles exist for the fp16 pieces only)
+    plan_tn_grouped(items, n, &args, nullptr, &wg, bm);
+    if (bm == 256) hipLaunchKernelGGL((gemm_tn_grouped_kernel<0, 4, 256>), dim3(wg), dim3(512), 0, st, args);
+    else if (pieces == 4) hipLaunchKernelGGL((gemm_tn_grouped_kernel<0, 4>), dim3(wg), dim3(256), 0, st, args);
     else if (pieces == 2) hipLaunchKernelGGL((gemm_tn_grouped_kernel<0, 2>), dim3(wg), dim3(256), 0, st, args);
     else hipLaunchKernelGGL((gemm_tn_grouped_kernel<0, 3>), dim3(wg), dim3(256), 0, st, args);
 }

@@ -46,6 +46,9 @@ unsigned gaot_debug_split_redo_count(int reset);
 /* (k > 0: a fixed K slab for every product of the grouped launch; 0: automatic; -c: the cap of longer products' slabs (default 4 096);
  * -(100000 + c): the same for node-level products, K > 16 384) */
 int gaot_debug_set_wgrad_kslab(int k);
+/* [r6] grouped weight gradients on fp16 pieces: 256 = 256 x 128 tiles on eight waves (one workgroup per CU) when every product's M is a
+ * multiple of 256; 128 = 128 x 128 tiles, two workgroups per CU */
+int gaot_debug_set_wgrad_tile_rows(int bm);
 /* tuning hook: head_dim 32 attention, 1 = split-bf16 MFMA kernels (default), 0 = fp32-MFMA kernels, 2 / 3 = split with the
  * 8-wave / 4-wave forward workgroup forced.  Returns the previous value. */
 int gaot_debug_set_attention_split(int on);

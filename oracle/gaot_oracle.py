@@ -72,6 +72,9 @@ class OracleConfig:
     # embedding MLP.  "float64" separates the CONDITIONING of a result w.r.t. the reference's fp32 rounding of those
     # statistics (ReLU gates of geoembed.mlp.0 sit right behind them) from an implementation error.
     stats_dtype: str = "float32"
+    # baseline option (bench.py's torch-on-the-GPU leg): call F.scaled_dot_product_attention, the library op the reference itself
+    # calls (attn.py:114), instead of the written-out softmax -- the same function up to rounding (tests/test_oracle_golden.py)
+    library_attention: bool = False
 
 
 def as_csr(n) -> CSR:
@@ -495,6 +498,9 @@ def attention(sd, prefix: str, cfg: OracleConfig, x: Tensor, condition, drop_fac
     if cfg.positional_embedding == "rope":                              # attn.py:106-108
         q = rotate_queries_or_keys(q, sd[f"{prefix}.rotary_emb.freqs"])
         k = rotate_queries_or_keys(k, sd[f"{prefix}.rotary_emb.freqs"])
+    if cfg.library_attention and drop_factor is None:                   # attn.py:114 as the reference calls it (no dropout draw to inject)
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=None, dropout_p=0.0).transpose(1, 2).reshape(B, S, H * dh)
+        return o @ sd[f"{prefix}.o_proj.weight"].t()
     p = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(dh), dim=-1)
     if drop_factor is not None:
         p = p * drop_factor

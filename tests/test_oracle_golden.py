@@ -59,6 +59,25 @@ def test_train_step(case):
         assert (new_sd[k] - ref).abs().max().item() < 2e-6, k
 
 
+@pytest.mark.parametrize("case", ["fx2d_base", "fx2d_headdim32", "rope", "vx2d"])
+def test_library_attention_option_is_the_same_function(case):
+    """`library_attention` (bench.py's torch-on-the-GPU baseline leg: F.scaled_dot_product_attention, the op the reference calls at
+    attn.py:114) against the reference's vectors: prediction, loss and gradients within the bars of the written-out form"""
+    import dataclasses
+    g = Golden(case)
+    cfg = dataclasses.replace(g.oracle_config(), library_attention=True)
+    enc, dec = g.csr_lists()
+    batch = {"latent": g.t("in.latent"), "xcoord": g.t("in.xcoord"), "pndata": g.t("in.pndata"), "target": g.t("in.target")}
+    if cfg.precompute_edges:
+        batch.update(encoder_nbrs=enc, decoder_nbrs=dec)
+    loss, grads, _, _, pred = O.train_step(g.state_dict, cfg, batch, lr=8e-4, weight_decay=1e-5, return_pred=True)
+    assert rel_l2(pred, g.t("out.pred")) < TOL
+    assert abs(float(loss) - float(g.t("out.loss"))) < 1e-6 * max(1.0, abs(float(g.t("out.loss"))))
+    for k, ref in g.group("g.").items():
+        scale = max(ref.abs().max().item(), 1e-4)
+        assert (grads[k] - ref).abs().max().item() / scale < GRAD_TOL, k
+
+
 def test_condnorm_pair_forward_and_rollouts():
     g = Golden("condnorm_rollout")
     cfg = g.oracle_config()

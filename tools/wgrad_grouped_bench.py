@@ -51,12 +51,21 @@ def timed(fn, n=30):
 
 single()
 ref = [o.clone() for _, _, o in ops_in]
-grouped()
-torch.cuda.synchronize()
-err = max(float((o.double() - r.double()).norm() / r.double().norm()) for (_, _, o), r in zip(ops_in, ref))
 from gaot_amd import _lib
-for rep, kslab in enumerate((2048, 2752, 4096, 8192, 2048, 2752, 4096, 8192)):
-    _lib.load().gaot_debug_set_wgrad_kslab(kslab)
-    us_s, us_g = (timed(single) if rep == 0 else us_s), timed(grouped)
-    print(f"kslab {kslab}: single launches {us_s:8.1f} us ({flops / us_s / 1e6:6.1f} TF/s)   grouped {us_g:8.1f} us ({flops / us_g / 1e6:6.1f} TF/s)   "
-          f"max rel diff {err:.2e}", flush=True)
+lib = _lib.load()
+us_s = timed(single)
+for rep in range(2):
+    for bm in (128, 256):
+        for kslab in (2048, 2752, 4096, 8192):
+            lib.gaot_debug_set_wgrad_tile_rows(bm)
+            lib.gaot_debug_set_wgrad_kslab(kslab)
+            for _, _, o in ops_in:
+                o.zero_()
+            grouped()
+            torch.cuda.synchronize()
+            err = max(float((o.double() - r.double()).norm() / r.double().norm()) for (_, _, o), r in zip(ops_in, ref))
+            us_g = timed(grouped)
+            print(f"tile rows {bm} kslab {kslab}: single launches {us_s:8.1f} us ({flops / us_s / 1e6:6.1f} TF/s)   grouped {us_g:8.1f} us ({flops / us_g / 1e6:6.1f} TF/s)   "
+                  f"max rel diff vs single launches {err:.2e}", flush=True)
+lib.gaot_debug_set_wgrad_tile_rows(128)
+lib.gaot_debug_set_wgrad_kslab(0)
