@@ -269,6 +269,48 @@ def cpu_baseline(sd, tensors, hip, steps: int = 3):
     return base, parity, {"pred": predd, "grads": gradsd}
 
 
+def _to_dev(o, dev):
+    if torch.is_tensor(o):
+        return o.to(dev)
+    if isinstance(o, (list, tuple)):
+        return type(o)(_to_dev(v, dev) for v in o)
+    if isinstance(o, dict):
+        return {k: _to_dev(v, dev) for k, v in o.items()}
+    return o
+
+
+def torch_gpu_steps(sd, ocfg, okw, target, dev, B, steps: int = 8, warmup: int = 3):
+    """`steps` training steps of the reference's algorithm as plain eager PyTorch-ROCm ops on `dev` (see torch_gpu_baseline), driven the way
+    the reference trainer drives it (optimizers.py:247-257); returns (samples/s, ms per step, first prediction, first loss)"""
+    import dataclasses
+    from oracle import gaot_oracle as O
+    cfg = dataclasses.replace(ocfg, library_attention=True)
+    kw = _to_dev(okw, dev)
+    tgt = target.to(dev)
+    params = {k: torch.nn.Parameter(v.to(dev).clone(), requires_grad=not k.endswith("rotary_emb.freqs")) for k, v in sd.items()}
+    opt = torch.optim.AdamW([q for q in params.values() if q.requires_grad], lr=8e-4, weight_decay=1e-5)
+
+    def one():
+        opt.zero_grad()
+        pred = O.gaot_forward(params, cfg, **kw)
+        loss = torch.mean((pred - tgt) ** 2)
+        loss.backward()
+        opt.step()
+        return pred.detach(), loss.detach()
+
+    with torch.device(dev):          # the restatement creates its scratch tensors on the default device
+        pred0, loss0 = one()
+        for _ in range(warmup - 1):
+            one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    return B / dt, 1e3 * dt, pred0, float(loss0)
+
+
 def torch_gpu_baseline(sd, tensors, hip, dev, steps: int = 8, warmup: int = 3):
     """The SAME-NODE denominator of the north_star's ">= 5x the reference's single-GPU PyTorch": the reference's algorithm in plain
     eager PyTorch-ROCm ops on this GPU -- the parity-checked restatement (oracle/gaot_oracle.py: matmuls through rocBLAS / hipBLASLt,
@@ -277,36 +319,14 @@ def torch_gpu_baseline(sd, tensors, hip, dev, steps: int = 8, warmup: int = 3):
     torch.optim.AdamW), same weights, same batch, same neighbour lists, fp32.  A reported baseline, not the product: nothing here is
     on the HIP path, and the HIP path never touches it."""
     from oracle import gaot_oracle as O
-    lat, x, p, t = [v.to(dev) for v in tensors]
+    lat, x, p, t = tensors
     cfg = O.OracleConfig(radius=RADIUS, hidden_size=64, lifting_channels=C_LIFT, patch_size=PATCH, tf_hidden_size=HIDDEN,
-                         latent_tokens_size=LATENT, precompute_edges=True, library_attention=True)
-    enc = [tuple(v.to(dev) for v in hip["enc_csr"])]
-    dec = [tuple(v.to(dev) for v in hip["dec_csr"])]
-    params = {k: torch.nn.Parameter(v.to(dev).clone(), requires_grad=not k.endswith("rotary_emb.freqs")) for k, v in sd.items()}
-    opt = torch.optim.AdamW([q for q in params.values() if q.requires_grad], lr=8e-4, weight_decay=1e-5)
-    out = {}
-
-    def one():
-        opt.zero_grad()
-        pred = O.gaot_forward(params, cfg, lat, x, p, encoder_nbrs=enc, decoder_nbrs=dec)
-        loss = torch.mean((pred - t) ** 2)
-        loss.backward()
-        opt.step()
-        return pred, loss
-
-    with torch.device(dev):          # the restatement creates its scratch tensors on the default device
-        pred0, loss0 = one()
-        out["output_vs_hip"] = float((pred0.detach().double() - hip["pred"].to(dev).double()).norm() / hip["pred"].to(dev).double().norm())
-        out["loss_vs_hip"] = abs(float(loss0.detach()) - hip["loss"]) / abs(hip["loss"])
-        for _ in range(warmup - 1):
-            one()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            one()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-    return {"value": BATCH * steps / dt, "unit": "samples/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "kind": "port",
+                         latent_tokens_size=LATENT, precompute_edges=True)
+    rate, ms, pred0, loss0 = torch_gpu_steps(sd, cfg, dict(latent=lat, xcoord=x, pndata=p, encoder_nbrs=[hip["enc_csr"]], decoder_nbrs=[hip["dec_csr"]]),
+                                             t, dev, BATCH, steps, warmup)
+    ref = hip["pred"].to(dev).double()
+    out = {"output_vs_hip": float((pred0.double() - ref).norm() / ref.norm()), "loss_vs_hip": abs(loss0 - hip["loss"]) / abs(hip["loss"])}
+    return {"value": rate, "unit": "samples/s", "ms_per_step": ms, "steps": steps, "kind": "port",
             "what": "the reference's algorithm as plain eager PyTorch-ROCm ops on the same MI355X (oracle/gaot_oracle.py on cuda:0 with "
                     "F.scaled_dot_product_attention and torch.optim.AdamW as the reference calls them; ATen index_add_ / scatter_reduce "
                     "stand in for torch_scatter, absent from the image), same weights / batch / neighbour lists, fp32, fwd + MSE + bwd + AdamW",
@@ -465,6 +485,14 @@ def secondary_configs(dev, which=("C3", "C4", "C5"), steps: int = 20, warmup: in
                 ref = O.gaot_forward(sd, ocfg, **okw)
             row["rel_l2_vs_oracle"] = {"output": float((y0.double() - ref.double()).norm() / ref.double().norm()),
                                        "what": "HIP forward vs the CPU oracle's forward, same initial weights and batch"}
+            try:          # the same-node PyTorch baseline of this configuration (torch_gpu_baseline's leg, 5 steps)
+                rate, ms, _, _ = torch_gpu_steps(sd, ocfg, okw, t, dev, B, steps=5, warmup=2)
+                row["torch_gpu_baseline"] = {"value": rate, "unit": "samples/s", "ms_per_step": ms, "steps": 5, "kind": "port",
+                                             "this_config_over_it": row["samples_per_s"] / rate,
+                                             "what": "the reference's algorithm as plain eager PyTorch-ROCm ops on the same GPU (see the line's torch_gpu_baseline)"}
+            except Exception as e:
+                row["torch_gpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            torch.cuda.empty_cache()
         out[name] = row
         return ts
 
