@@ -23,9 +23,9 @@ nk = {k: v for k, v in d.items() if k.startswith(("lift_", "proj_", "ep_fixup", 
 dump("gno", {"kernel_family": "integral-transform kernels of one step: " + ", ".join(sorted(nk)),
              "hbm_bytes_per_launch": sum(v["hbm_bytes_per_launch"] * v["launches_seen"] / min(w["launches_seen"] for w in nk.values()) for v in nk.values()),
              "note": "sum over the family's launches of ONE step", "source": src})
-ab = [v for k, v in d.items() if k.startswith("attn_bwd_split8")]
+ab = [(k, v) for k, v in d.items() if k.startswith(("attn_bwd_h16", "attn_bwd_split8"))]
 if ab:
-    dump("attn_bwd", {"kernel_family": "attn_bwd_split8_kernel", "launches": ab[0]["launches_seen"], "hbm_bytes_per_launch": ab[0]["hbm_bytes_per_launch"], "source": src})
+    dump("attn_bwd", {"kernel_family": ab[0][0], "launches": ab[0][1]["launches_seen"], "hbm_bytes_per_launch": ab[0][1]["hbm_bytes_per_launch"], "source": src})
 cur = {"gemm": {"file": f"{tag}_gemm_traffic.json", "commit": commit}, "gno": {"file": f"{tag}_gno_traffic.json", "commit": commit}}
 if ab:
     cur["attn_bwd"] = {"file": f"{tag}_attn_bwd_traffic.json", "commit": commit}
