@@ -143,6 +143,13 @@ __device__ __forceinline__ void split2h_pair_mix(float x0, float x1, float sc, u
     ph = __builtin_bit_cast(unsigned, __builtin_convertvector(x, f16x2_t));
     pm = mix_residual(ph, x[0], x[1]);
 }
+// what the tile GEMMs call (GAOT_GEMM_SPLIT_MIX = 0: the eight-instruction form, for A/B builds): bit-identical either way
+#ifndef GAOT_GEMM_SPLIT_MIX
+#define GAOT_GEMM_SPLIT_MIX 1
+#endif
+__device__ __forceinline__ void split2h_pair_gemm(float x0, float x1, float sc, unsigned& ph, unsigned& pm) {
+    if (GAOT_GEMM_SPLIT_MIX) split2h_pair_mix(x0, x1, sc, ph, pm); else split2h_pair(x0, x1, sc, ph, pm);
+}
 __device__ __forceinline__ void split2h_pre(float y0, float y1, unsigned& ph, unsigned& pm) {
     const f32x2 x = {y0, y1};
     ph = __builtin_bit_cast(unsigned, __builtin_convertvector(x, f16x2_t));

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ad_kernel(const GemmArgs p) {
                 for (int e = 0; e < 2; ++e) {
                     unsigned h_, m_;
                     if (ABL & 1) { h_ = __float_as_uint(r.v[i][c][2 * e]); m_ = __float_as_uint(r.v[i][c][2 * e + 1]); }
-                    else split2h_pair(r.v[i][c][2 * e], r.v[i][c][2 * e + 1], sc_a, h_, m_);
+                    else split2h_pair_gemm(r.v[i][c][2 * e], r.v[i][c][2 * e + 1], sc_a, h_, m_);
                     o.h[i][2 * c + e] = h_; o.m[i][2 * c + e] = m_;
                 }
             if (DETECT && track) {          // (every other group of 8: the mean over half the groups is as good a typical magnitude)

@@ -38,7 +38,7 @@ template <int NP, int ABL>
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& ph, unsigned& pm, unsigned& pl, float sc = 1.f) {
     if (NP == 1) { ph = rne_pair(x0, x1); pm = pl = 0u; }
     else if (NP == 2) { split2_pair(x0, x1, ph, pm); pl = 0u; }       // two ROUNDED pieces: x = h + m + e, |e| <= 2^-18 |x|, unbiased
-    else if (NP >= 4) { split2h_pair(x0, x1, sc, ph, pm); pl = 0u; }
+    else if (NP >= 4) { split2h_pair_gemm(x0, x1, sc, ph, pm); pl = 0u; }
     else split3_pair<ABL>(x0, x1, ph, pm, pl);
 }
 
