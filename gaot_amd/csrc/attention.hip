@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void attn_fwd_glds_kernel(const AttnArgs p) {
 // F16: two fp16 pieces of sc * x (common.h split2h_pair: x carried up to its last bit once sc puts the operand's largest magnitude at ~2^14)
 template <int OP, bool F16 = false>
 __device__ __forceinline__ void split_op(float x0, float x1, unsigned& a, unsigned& b, unsigned& c, float sc = 1.f) {
-    if (F16) { split2h_pair(x0, x1, sc, a, b); c = 0u; }
+    if (F16) { split2h_pair_gemm(x0, x1, sc, a, b); c = 0u; }
     else if (OP == 3) split3_pair(x0, x1, a, b, c);
     else { split2_pair(x0, x1, a, b); c = 0u; }
 }
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && DH == 32) ? 2 : 1) void attn_f
                 for (int e = 0; e < 4; ++e) {
                     unsigned a_, b_, c_ = 0u;
                     if (PP == 3) split3_pair(s[t][8 * u + 2 * e], s[t][8 * u + 2 * e + 1], a_, b_, c_);
-                    else if (F16) split2h_pair(s[t][8 * u + 2 * e], s[t][8 * u + 2 * e + 1], P_SCALE, a_, b_);
+                    else if (F16) split2h_pair_gemm(s[t][8 * u + 2 * e], s[t][8 * u + 2 * e + 1], P_SCALE, a_, b_);
                     else split2_pair(s[t][8 * u + 2 * e], s[t][8 * u + 2 * e + 1], a_, b_);
                     ph[e] = a_; pm[e] = b_; pl[e] = c_;
                 }
@@ -1531,7 +1531,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_split_dh_kernel(const AttnArg
             const f32x4 a = load4(p.k + ((long)b * p.S + min(kv0 + row, p.S - 1)) * p.ldk + (long)hk * D, d, D, kv0 + row < p.S, true);
             if (DQ16) {
                 unsigned h0, m0, h1, m1;
-                if (F16) { split2h_pair(a[0], a[1], sc_in, h0, m0); split2h_pair(a[2], a[3], sc_in, h1, m1); }
+                if (F16) { split2h_pair_gemm(a[0], a[1], sc_in, h0, m0); split2h_pair_gemm(a[2], a[3], sc_in, h1, m1); }
                 else { split2_pair(a[0], a[1], h0, m0); split2_pair(a[2], a[3], h1, m1); }
                 *reinterpret_cast<u32x2*>(Kpl + row * KPROW + d * 2) = u32x2{h0, h1};
                 *reinterpret_cast<u32x2*>(Kpl + KPPL + row * KPROW + d * 2) = u32x2{m0, m1};
@@ -1739,7 +1739,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_split_dh_kernel(const AttnArg
                 unsigned h_[4], m_[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    if (F16) split2h_pair(dp[8 * u + 2 * e], dp[8 * u + 2 * e + 1], sc_ds, h_[e], m_[e]);
+                    if (F16) split2h_pair_gemm(dp[8 * u + 2 * e], dp[8 * u + 2 * e + 1], sc_ds, h_[e], m_[e]);
                     else split2_pair(dp[8 * u + 2 * e], dp[8 * u + 2 * e + 1], h_[e], m_[e]);
                 }
                 unsigned char* dst = dSp + li * AB_KROW + (16 * u + 4 * lh) * 2;
@@ -2069,11 +2069,11 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_kernel(const AttnArgs 
             for (int e = 0; e < 4; ++e) {
                 unsigned a_, b_, c_ = 0u;
                 if (PP == 3) split3_pair(s[8 * u + 2 * e], s[8 * u + 2 * e + 1], a_, b_, c_);
-                else if (F16) split2h_pair(s[8 * u + 2 * e], s[8 * u + 2 * e + 1], P_SCALE, a_, b_);
+                else if (F16) split2h_pair_gemm(s[8 * u + 2 * e], s[8 * u + 2 * e + 1], P_SCALE, a_, b_);
                 else split2_pair(s[8 * u + 2 * e], s[8 * u + 2 * e + 1], a_, b_);
                 ph[e] = a_; pm[e] = b_; pl[e] = c_;
                 if (PP == 3) split3_pair(dp[8 * u + 2 * e], dp[8 * u + 2 * e + 1], a_, b_, c_);
-                else if (F16) split2h_pair(dp[8 * u + 2 * e], dp[8 * u + 2 * e + 1], sc_ds, a_, b_);
+                else if (F16) split2h_pair_gemm(dp[8 * u + 2 * e], dp[8 * u + 2 * e + 1], sc_ds, a_, b_);
                 else split2_pair(dp[8 * u + 2 * e], dp[8 * u + 2 * e + 1], a_, b_);
                 sh[e] = a_; sm[e] = b_; sl[e] = c_;
                 if (!TR) {
