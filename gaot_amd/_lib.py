@@ -161,6 +161,7 @@ PROTOTYPES = {
     "gaot_debug_set_kernel_mlp_split": (C.c_int, [C.c_int]),
     "gaot_debug_set_attention_split": (C.c_int, [C.c_int]),
     "gaot_debug_set_attention_h16": (C.c_int, [C.c_int]),
+    "gaot_debug_set_attention_dh8": (C.c_int, [C.c_int]),
     "gaot_debug_set_attention_pipe": (C.c_int, [C.c_int]),
     "gaot_debug_set_attention_p_pieces": (C.c_int, [C.c_int]),
     "gaot_debug_set_attention_operand_pieces": (C.c_int, [C.c_int]),

@@ -2553,6 +2553,12 @@ constexpr int AD8_KROW = 64 * 2 + 16, AD8_KPL = 32 * AD8_KROW;                  
 constexpr int AD8_SHARED = 2 * 2 * AD8_KPL + 64 * 4;                                // Q and dO, two pieces each + lse / delta
 constexpr int AD8_WAVE = 2 * AD8_KPL + 32 * 64 * 4;                                 // K planes + (dS^T planes | dQ partial [32][64] fp32)
 constexpr int AD8_LDS = AD8_SHARED + 8 * AD8_WAVE;
+// [r6] F16: two fp16 pieces of the scaled operands (as attn_bwd_split_dh_kernel<64, 2, 2, true>: the same scales, the same per-tile
+// scale of dS, the inverse scales on the fused multiply-adds that join the tile products to the running sums).  QS = 2: the query tiles
+// of a 256-key block go to two workgroups (as attn_bwd_split8_kernel<.., QS = 2>): batch x heads x key blocks of 128 .. 255 fill the chip
+// with eight waves per CU (the 3-D configuration: 1 x 8 heads x 16 blocks); the second half's dK / dV go to two spare dQ slabs and
+// attn_add_cols_kernel adds them in a fixed order.
+template <bool F16 = false, int QS = 1>
 __global__ __launch_bounds__(512, 1) void attn_bwd_split8_dh_kernel(const AttnArgs p) {
     constexpr int DH = 64, NU = 4, NDT = 2, CPR = 16, NW = 8;
     __shared__ __attribute__((aligned(16))) unsigned char smem[AD8_LDS];
@@ -2563,12 +2569,16 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_dh_kernel(const AttnAr
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
-    int bh, kblk;
-    xcd_group_decode(blockIdx.x, p.B * p.H, p.n_kblocks, bh, kblk);
+    int bh, kblk, qhalf = 0;
+    xcd_group_decode(blockIdx.x, p.B * p.H, p.n_kblocks * QS, bh, kblk);
+    if (QS > 1) { qhalf = kblk % QS; kblk /= QS; }
     const int b = bh / p.H, h = bh % p.H, hk = h / (p.H / p.Hkv);
     const int kv0 = kblk * 256 + wave * 32;
     const int D = p.D;
-    const float c = p.scale * LOG2E;
+    float sc_in = 1.f, so_in = 1.f, sc_g = 1.f, so_g = 1.f;
+    if (F16) { amax_scale(p.qkv_amax, sc_in, so_in); amax_scale(p.dout_amax, sc_g, so_g); }
+    const float c = p.scale * LOG2E * so_in * so_in;
+    const float dp_inv = so_g * so_in, dv_inv = F16 ? so_g * P_INV : 1.f;
     unsigned char* Kpl = smem + AD8_SHARED + wave * AD8_WAVE;         // two planes [32 kv][64 d]
     unsigned char* dSp = Kpl + 2 * AD8_KPL;                            // two planes [32 kv][32 q] (row stride AB_KROW); dQ partial after the MFMAs
     float* Pmine = reinterpret_cast<float*>(dSp);
@@ -2586,8 +2596,8 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_dh_kernel(const AttnAr
             unsigned a_, b_;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                split2_pair(w0[2 * e], w0[2 * e + 1], a_, b_); vh[e] = a_; vm[e] = b_;
-                split2_pair(w1[2 * e], w1[2 * e + 1], a_, b_); vh[2 + e] = a_; vm[2 + e] = b_;
+                if (F16) { split2h_pair_gemm(w0[2 * e], w0[2 * e + 1], sc_in, a_, b_); vh[e] = a_; vm[e] = b_; split2h_pair_gemm(w1[2 * e], w1[2 * e + 1], sc_in, a_, b_); vh[2 + e] = a_; vm[2 + e] = b_; }
+                else { split2_pair(w0[2 * e], w0[2 * e + 1], a_, b_); vh[e] = a_; vm[e] = b_; split2_pair(w1[2 * e], w1[2 * e + 1], a_, b_); vh[2 + e] = a_; vm[2 + e] = b_; }
             }
             vf[0][u] = __builtin_bit_cast(bf16x8, vh); vf[1][u] = __builtin_bit_cast(bf16x8, vm);
         }
@@ -2595,8 +2605,8 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_dh_kernel(const AttnAr
             const int row = t / CPR, d = (t % CPR) * 4;
             const f32x4 a = load4(p.k + ((long)b * p.S + min(kv0 + row, p.S - 1)) * p.ldk + (long)hk * D, d, D, kv0 + row < p.S, true);
             unsigned h0, m0, h1, m1;
-            split2_pair(a[0], a[1], h0, m0);
-            split2_pair(a[2], a[3], h1, m1);
+            if (F16) { split2h_pair_gemm(a[0], a[1], sc_in, h0, m0); split2h_pair_gemm(a[2], a[3], sc_in, h1, m1); }
+            else { split2_pair(a[0], a[1], h0, m0); split2_pair(a[2], a[3], h1, m1); }
             *reinterpret_cast<u32x2*>(Kpl + row * AD8_KROW + d * 2) = u32x2{h0, h1};
             *reinterpret_cast<u32x2*>(Kpl + AD8_KPL + row * AD8_KROW + d * 2) = u32x2{m0, m1};
         }
@@ -2630,24 +2640,26 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_dh_kernel(const AttnAr
     const long part_stride = (long)p.B * p.H * p.S * DH;
     float* part = p.dq_part + (long)kblk * part_stride + ((long)b * p.H + h) * p.S * DH;
 
-    fetch(0);
-    for (int qt = 0; qt < nq; ++qt) {
+    const int nq_each = (nq + QS - 1) / QS;
+    const int qt_begin = qhalf * nq_each, qt_end = min(nq, qt_begin + nq_each);
+    fetch(qt_begin * 32);
+    for (int qt = qt_begin; qt < qt_end; ++qt) {
         const int q0 = qt * 32;
         {
             const int row = tid >> 4, ch = tid & 15;
             unsigned h0, m0, h1, m1;
-            split2_pair(rq[0], rq[1], h0, m0);
-            split2_pair(rq[2], rq[3], h1, m1);
+            if (F16) { split2h_pair_gemm(rq[0], rq[1], sc_in, h0, m0); split2h_pair_gemm(rq[2], rq[3], sc_in, h1, m1); }
+            else { split2_pair(rq[0], rq[1], h0, m0); split2_pair(rq[2], rq[3], h1, m1); }
             *reinterpret_cast<u32x2*>(Qk + row * AD8_KROW + ch * 8) = u32x2{h0, h1};
             *reinterpret_cast<u32x2*>(Qk + AD8_KPL + row * AD8_KROW + ch * 8) = u32x2{m0, m1};
-            split2_pair(rg[0], rg[1], h0, m0);
-            split2_pair(rg[2], rg[3], h1, m1);
+            if (F16) { split2h_pair_gemm(rg[0], rg[1], sc_g, h0, m0); split2h_pair_gemm(rg[2], rg[3], sc_g, h1, m1); }
+            else { split2_pair(rg[0], rg[1], h0, m0); split2_pair(rg[2], rg[3], h1, m1); }
             *reinterpret_cast<u32x2*>(Gk + row * AD8_KROW + ch * 8) = u32x2{h0, h1};
             *reinterpret_cast<u32x2*>(Gk + AD8_KPL + row * AD8_KROW + ch * 8) = u32x2{m0, m1};
         }
         if (tid < 32) { lse_s[tid] = rl; del_s[tid] = rd; }
         __syncthreads();                                    // barrier A
-        if (qt + 1 < nq) fetch(q0 + 32);
+        if (qt + 1 < qt_end) fetch(q0 + 32);
 
         // ---- S[q][kv] and dP[q][kv]: A = Q / dO planes (lane -> query row), B = K planes (LDS) / V^T (registers)
         f32x16 s, dp;
@@ -2661,12 +2673,12 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_dh_kernel(const AttnAr
             const bf16x8 q0_ = *reinterpret_cast<const bf16x8*>(qr), q1_ = *reinterpret_cast<const bf16x8*>(qr + AD8_KPL);
             const bf16x8 g0_ = *reinterpret_cast<const bf16x8*>(gr), g1_ = *reinterpret_cast<const bf16x8*>(gr + AD8_KPL);
             const bf16x8 k0_ = *reinterpret_cast<const bf16x8*>(kr), k1_ = *reinterpret_cast<const bf16x8*>(kr + AD8_KPL);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q1_, k0_, s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1_, vf[0][u], dp, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0_, k1_, s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0_, vf[1][u], dp, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0_, k0_, s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0_, vf[0][u], dp, 0, 0, 0);
+            s = mfma16<F16>(q1_, k0_, s);
+            dp = mfma16<F16>(g1_, vf[0][u], dp);
+            s = mfma16<F16>(q0_, k1_, s);
+            dp = mfma16<F16>(g0_, vf[1][u], dp);
+            s = mfma16<F16>(q0_, k0_, s);
+            dp = mfma16<F16>(g0_, vf[0][u], dp);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -2674,22 +2686,28 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_dh_kernel(const AttnAr
             float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c, -lse_s[qr]));
             if (!kv_ok) pv = 0.f;
             s[r] = pv;
-            dp[r] = pv * (dp[r] - del_s[qr]);
+            dp[r] = F16 ? pv * fmaf(dp[r], dp_inv, -del_s[qr]) : pv * (dp[r] - del_s[qr]);
         }
-        // ---- dV^T / dK^T: the tile's contributions start from zero on the matrix pipe and join the running sums on the vector pipe
-        f32x16 dvt[NDT], dkt[NDT];
+        float sc_ds = 1.f, ds_inv = 1.f;          // fp16 pieces: the tile's own power-of-two scale for dS
+        if (F16) {
+            float mx = 0.f;
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { dvt[dt][r] = 0.f; dkt[dt][r] = 0.f; }
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(dp[r]));
+            pow2_scale(wave_max_nonneg(mx), sc_ds, ds_inv);
+        }
+        const float dk_inv = ds_inv * so_in;
+        // ---- dV^T / dK^T: the tile's contributions start from zero on the matrix pipe and join the running sums on the vector pipe.
+        // All pieces first (P and dS die with them), then one 32-row d tile at a time: 32 accumulator registers live instead of 64, the
+        // same MFMA order per accumulator
+        bf16x8 pp[2][2], dd[2][2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             u32x4 ph, pm, sh, sm;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 unsigned a_, b_;
-                split2_pair(s[8 * u + 2 * e], s[8 * u + 2 * e + 1], a_, b_); ph[e] = a_; pm[e] = b_;
-                split2_pair(dp[8 * u + 2 * e], dp[8 * u + 2 * e + 1], a_, b_); sh[e] = a_; sm[e] = b_;
+                if (F16) { split2h_pair_gemm(s[8 * u + 2 * e], s[8 * u + 2 * e + 1], P_SCALE, a_, b_); ph[e] = a_; pm[e] = b_; split2h_pair_gemm(dp[8 * u + 2 * e], dp[8 * u + 2 * e + 1], sc_ds, a_, b_); sh[e] = a_; sm[e] = b_; }
+                else { split2_pair(s[8 * u + 2 * e], s[8 * u + 2 * e + 1], a_, b_); ph[e] = a_; pm[e] = b_; split2_pair(dp[8 * u + 2 * e], dp[8 * u + 2 * e + 1], a_, b_); sh[e] = a_; sm[e] = b_; }
             }
             // dS^T pieces [kv = li][q]: registers 8u .. 8u + 3 are queries 16u + 4hi + 0..3, 8u + 4 .. 8u + 7 the same, eight up
             unsigned char* dst = dSp + li * AB_KROW + (16 * u + 4 * lh) * 2;
@@ -2697,10 +2715,16 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_dh_kernel(const AttnAr
             *reinterpret_cast<u32x2*>(dst + 16) = u32x2{sh[2], sh[3]};
             *reinterpret_cast<u32x2*>(dst + AB_KPL) = u32x2{sm[0], sm[1]};
             *reinterpret_cast<u32x2*>(dst + AB_KPL + 16) = u32x2{sm[2], sm[3]};
-            const bf16x8 p0 = __builtin_bit_cast(bf16x8, ph), p1 = __builtin_bit_cast(bf16x8, pm);
-            const bf16x8 d0 = __builtin_bit_cast(bf16x8, sh), d1 = __builtin_bit_cast(bf16x8, sm);
+            pp[u][0] = __builtin_bit_cast(bf16x8, ph); pp[u][1] = __builtin_bit_cast(bf16x8, pm);
+            dd[u][0] = __builtin_bit_cast(bf16x8, sh); dd[u][1] = __builtin_bit_cast(bf16x8, sm);
+        }
 #pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) {
+        for (int dt = 0; dt < NDT; ++dt) {
+            f32x16 dvt, dkt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dvt[r] = 0.f; dkt[r] = 0.f; }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
                 // dO^T / Q^T fragments from the k-major planes: column d = 32dt + li, rows q = 16u + 4hi + 0..3 and + 8
                 const unsigned char* gb = Gk + (16 * u) * AD8_KROW + 32 * dt * 2 + tr_k;
                 const unsigned char* qb = Qk + (16 * u) * AD8_KROW + 32 * dt * 2 + tr_k;
@@ -2708,18 +2732,19 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_dh_kernel(const AttnAr
                 const bf16x8 ga1 = __builtin_bit_cast(bf16x8, join8(lds_tr(gb + AD8_KPL), lds_tr(gb + AD8_KPL + 8 * AD8_KROW)));
                 const bf16x8 qa0 = __builtin_bit_cast(bf16x8, join8(lds_tr(qb), lds_tr(qb + 8 * AD8_KROW)));
                 const bf16x8 qa1 = __builtin_bit_cast(bf16x8, join8(lds_tr(qb + AD8_KPL), lds_tr(qb + AD8_KPL + 8 * AD8_KROW)));
-                dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga1, p0, dvt[dt], 0, 0, 0);
-                dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa1, d0, dkt[dt], 0, 0, 0);
-                dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga0, p1, dvt[dt], 0, 0, 0);
-                dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa0, d1, dkt[dt], 0, 0, 0);
-                dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga0, p0, dvt[dt], 0, 0, 0);
-                dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa0, d0, dkt[dt], 0, 0, 0);
+                dvt = mfma16<F16>(ga1, pp[u][0], dvt);
+                dkt = mfma16<F16>(qa1, dd[u][0], dkt);
+                dvt = mfma16<F16>(ga0, pp[u][1], dvt);
+                dkt = mfma16<F16>(qa0, dd[u][1], dkt);
+                dvt = mfma16<F16>(ga0, pp[u][0], dvt);
+                dkt = mfma16<F16>(qa0, dd[u][0], dkt);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dvacc[dt][r] = F16 ? fmaf(dvt[r], dv_inv, dvacc[dt][r]) : dvacc[dt][r] + dvt[r];
+                dkacc[dt][r] = F16 ? fmaf(dkt[r], dk_inv, dkacc[dt][r]) : dkacc[dt][r] + dkt[r];
             }
         }
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { dvacc[dt][r] += dvt[dt][r]; dkacc[dt][r] += dkt[dt][r]; }
         // ---- dQ[q][d] partial = sum_kv dS[q][kv] K[kv][d]: both operands through transposing reads (k-slot e = key 16u + 8 (e >> 2) + 4 hi + (e & 3))
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -2738,9 +2763,9 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_dh_kernel(const AttnAr
                 const unsigned char* kb = Kpl + (16 * u) * AD8_KROW + 32 * dt * 2 + tr_k;
                 const bf16x8 kb0 = __builtin_bit_cast(bf16x8, join8(lds_tr(kb), lds_tr(kb + 8 * AD8_KROW)));
                 const bf16x8 kb1 = __builtin_bit_cast(bf16x8, join8(lds_tr(kb + AD8_KPL), lds_tr(kb + AD8_KPL + 8 * AD8_KROW)));
-                dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1, kb0, dq[dt], 0, 0, 0);
-                dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da0, kb1, dq[dt], 0, 0, 0);
-                dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da0, kb0, dq[dt], 0, 0, 0);
+                dq[dt] = mfma16<F16>(da1, kb0, dq[dt]);
+                dq[dt] = mfma16<F16>(da0, kb1, dq[dt]);
+                dq[dt] = mfma16<F16>(da0, kb0, dq[dt]);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -2749,7 +2774,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_dh_kernel(const AttnAr
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) Pmine[crow(r, lh) * DH + 32 * dt + li] = dq[dt][r];
+            for (int r = 0; r < 16; ++r) Pmine[crow(r, lh) * DH + 32 * dt + li] = F16 ? dq[dt][r] * dk_inv : dq[dt][r];
         __syncthreads();                                    // barrier B
         // fixed-order sum of the eight waves' partials -> this key block's slice of the dQ workspace
 #pragma unroll
@@ -2768,6 +2793,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_dh_kernel(const AttnAr
     // ---- epilogue: dK^T, dV^T -> [kv][d] through the wave's (now free) dS region, coalesced row stores
     __syncthreads();
     float* Smine = reinterpret_cast<float*>(dSp);            // [32][33] floats
+    float am = 0.f;
 #pragma unroll
     for (int pass = 0; pass < 2 * NDT; ++pass) {
         const int dt = pass >> 1;
@@ -2779,14 +2805,19 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_split8_dh_kernel(const AttnAr
         for (int rr = lh; rr < 32; rr += 2) {
             const int kv = kv0 + rr;
             if (kv < p.S && 32 * dt + li < D) {
-                if ((pass & 1) == 0) p.dk[((long)b * p.S + kv) * p.lddk + (long)h * D + 32 * dt + li] = Smine[rr * 33 + li];
-                else                 p.dv[((long)b * p.S + kv) * p.lddv + (long)h * D + 32 * dt + li] = Smine[rr * 33 + li];
+                const float val = Smine[rr * 33 + li];
+                float* dst = (pass & 1) == 0 ? p.dk + ((long)b * p.S + kv) * p.lddk + (long)h * D + 32 * dt + li : p.dv + ((long)b * p.S + kv) * p.lddv + (long)h * D + 32 * dt + li;
+                if (QS > 1 && qhalf == 1) dst = ((pass & 1) == 0 ? p.dk2 : p.dv2) + ((long)b * p.S + kv) * ((long)p.H * D) + (long)h * D + 32 * dt + li;
+                *dst = val;
+                am = fmaxf(am, fabsf(val));
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    // (QS contributions per element: QS times the largest one bounds the sum -- the word holds max |x| or a bound)
+    if (F16 && p.dqkv_amax) { __syncthreads(); amax_publish_block<8>(p.dqkv_amax, am * (float)QS, reinterpret_cast<float*>(smem)); }
 }
 
 template <int DP> static size_t bwd_lds_bytes() {
@@ -2820,6 +2851,7 @@ static int fill_common(AttnArgs& a, const float* q, const float* k, const float*
 using namespace gaot;
 #define ST(s) reinterpret_cast<hipStream_t>(s)
 
+static int g_attn_dh8 = 1;       // [r6] 32 < head_dim <= 64, fp16 pieces: the 8-wave 256-key backward (query-split at 128 .. 255 blocks); 0 = the 4-wave kernel
 static int g_attn_h16 = 0x18;    // [r6] the fp16-piece backward (256-key blocks, one workgroup per key block): 8 + 16 VAR = attn_bwd_h16_kernel<8, 1, VAR> (default VAR 1), 4 = <4>, 0 = attn_bwd_split8_kernel
 static int g_attn_split = 1;     // head_dim 32: 1 = split-bf16 kernels (default; 8-wave forward when it fills the chip), 0 = fp32-MFMA kernels,
                                  // 2 = split with the 8-wave forward always, 3 = split with the 4-wave forward always
@@ -2846,6 +2878,7 @@ extern "C" int gaot_debug_set_attention_qsplit(int on) { const int old = g_attn_
 static int g_attn_pipe = 0;      // 1 = the software-pipelined 8-wave forward for S % 64 == 0 (same speed as the plain one since both keep the
                                  // tile product off the running accumulator: 57.6 vs 58.0 us; kept for tools/attn_ablate.hip and as a tested variant)
 extern "C" int gaot_debug_set_attention_pipe(int on) { const int old = g_attn_pipe; g_attn_pipe = on; return old; }
+extern "C" int gaot_debug_set_attention_dh8(int on) { const int old = g_attn_dh8; g_attn_dh8 = on; return old; }
 extern "C" int gaot_debug_set_attention_h16(int nw) { const int old = g_attn_h16; g_attn_h16 = nw; return old; }
 extern "C" int gaot_debug_set_attention_split(int on) { const int old = g_attn_split; g_attn_split = on; return old; }
 
@@ -3064,9 +3097,26 @@ extern "C" int gaot_attention_bwd(const float* q, const float* k, const float* v
     } else if (split_ok) {
         hipLaunchKernelGGL(attn_bwd_split_kernel, grid, block, 0, ST(stream), a);
     } else if (head_dim > 32 && head_dim <= 64 && a.vec && g_attn_split && aligned16(dq) && aligned16(dk) && aligned16(dv)) {
-        if (g_attn_pp % 10 == 2 && g_attn_op == 2 && g_attn_tr && g_attn_split != 3 && (g_attn_split == 2 || (long)cdiv(S, 256) * B * H >= 256)) {      // (C5: 128 such workgroups: stays on the 4-wave kernel, 800 vs 822 us)
+        const long wg8d = (long)cdiv(S, 256) * B * H;
+        // [r6] fp16 pieces on eight waves: 256-key blocks when they fill the chip, shared between two workgroups (QS = 2) at 128 .. 255 blocks
+        const bool f16_qs = f16 && g_attn_dh8 && g_attn_split != 3 && wg8d >= 128 && wg8d < 256 && cdiv(S, 32) >= 8 && cdiv(S, 128) - cdiv(S, 256) >= 2;
+        if (f16 && g_attn_dh8 && g_attn_split != 3 && wg8d >= 256) {
+            a.n_kblocks = cdiv(S, 256);
+            hipLaunchKernelGGL((attn_bwd_split8_dh_kernel<true, 1>), dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a);
+            dkdv_published = true;
+        } else if (f16_qs) {
+            a.n_kblocks = cdiv(S, 256);
+            a.dk2 = a.dq_part + (long)a.n_kblocks * B * H * S * 64;          // the first two slabs the 256-key blocks leave unused
+            a.dv2 = a.dk2 + (long)B * H * S * 64;
+            hipLaunchKernelGGL((attn_bwd_split8_dh_kernel<true, 2>), dim3(a.n_kblocks * B * H * 2), dim3(512), 0, ST(stream), a);
+            const long rows = (long)B * S;
+            const int c4 = H * head_dim / 4;
+            hipLaunchKernelGGL(attn_add_cols_kernel, dim3(cap_blocks(rows * c4, 256, 2048)), dim3(256), 0, ST(stream), dk, (long)lddk, a.dk2, dv, (long)lddv, a.dv2, rows, c4);
+            dkdv_published = true;
+        }
+        else if (g_attn_pp % 10 == 2 && g_attn_op == 2 && g_attn_tr && g_attn_split != 3 && (g_attn_split == 2 || (long)cdiv(S, 256) * B * H >= 256)) {      // (C5: 128 such workgroups: stays on the 4-wave kernel, 800 vs 822 us)
             a.n_kblocks = cdiv(S, 256);          // 256 keys per workgroup: half the dQ slabs (the workspace is sized for 128)
-            hipLaunchKernelGGL(attn_bwd_split8_dh_kernel, dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a);
+            hipLaunchKernelGGL((attn_bwd_split8_dh_kernel<false, 1>), dim3(a.n_kblocks * B * H), dim3(512), 0, ST(stream), a);
         }
         else if (f16) hipLaunchKernelGGL((attn_bwd_split_dh_kernel<64, 2, 2, true>), grid, block, 0, ST(stream), a);
         else if (g_attn_pp % 10 == 2 && g_attn_op == 2) hipLaunchKernelGGL((attn_bwd_split_dh_kernel<64, 2, 2>), grid, block, 0, ST(stream), a);

@@ -1010,6 +1010,39 @@ def test_attention_fp16_piece_products():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,S,H,D", [(2, 2048, 8, 64), (3, 1500, 8, 36), (1, 4096, 8, 48), (4, 2048, 8, 48)])
+def test_attention_head_dim_64_eight_wave_backward(B, S, H, D):
+    """32 < head_dim <= 64 on fp16 pieces: the 8-wave 256-key backward (attn_bwd_split8_dh_kernel<true, QS>) -- query-split between two
+    workgroups at 128 .. 255 key blocks x batch x heads (the first three shapes: the 3-D configuration's 1 x 4 096 x 8 x 48 among them, a
+    ragged last tile and an odd tile count in the second), whole key blocks per workgroup from 256 on (the last) -- against float64 and
+    against the 4-wave 128-key kernel it replaces there: the same error level, deterministic, the published magnitude word bounds dK / dV"""
+    from gaot_amd import ops, _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(S + D)
+    qkv, go = torch.randn(B, S, 3 * H * D, generator=g), torch.randn(B, S, H * D, generator=g)
+    r = qkv.clone().double().requires_grad_(True)
+    q, k, v = [r[..., i * H * D:(i + 1) * H * D].reshape(B, S, H, D).transpose(1, 2) for i in range(3)]
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(D), -1) @ v).transpose(1, 2).reshape(B, S, H * D)
+    ref.backward(go.double())
+
+    def run(dh8):
+        old = lib.gaot_debug_set_attention_dh8(dh8)
+        try:
+            d = qkv.to(dev()).requires_grad_(True)
+            out = ops.attention(d, H, H, D)
+            out.backward(go.to(dev()))
+        finally:
+            lib.gaot_debug_set_attention_dh8(old)
+        return d.grad
+
+    g8, g8b, g4 = run(1), run(1), run(0)
+    assert torch.equal(g8, g8b)                                   # deterministic (no atomics: the halves are added in a fixed order)
+    e8, e4 = rel(g8, r.grad), rel(g4, r.grad)
+    assert e8 < 1.2e-6 and e8 < 1.5 * e4 + 2e-8, (e8, e4)
+    assert rel(g8, g4.double().cpu()) < 2e-6
+
+
+@pytest.mark.gpu
 def test_attention_backward_one_barrier_kernel_equals_the_two_barrier_one():
     """[r6] attn_bwd_h16_kernel<8> (one workgroup barrier per query tile, double-buffered tile planes and dQ partials, DPP reductions, the second
     pieces through v_fma_mix) computes what attn_bwd_split8_kernel<2, 2, true, true> does, in the same order: dQ, dK and dV are bit-identical --
