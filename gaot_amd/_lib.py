@@ -137,6 +137,9 @@ PROTOTYPES = {
     "gaot_act_bwd": (C.c_int, [_f, _f, C.c_int64, C.c_int32, _f, _s]),
     "gaot_attention_fwd": (C.c_int, [_f, _f, _f, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_int32, _f, C.c_int64, _f, C.c_int32, _f, _s]),
+    "gaot_attention_fwd_workspace": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "gaot_attention_fwd_ws": (C.c_int, [_f, _f, _f, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                        C.c_int32, C.c_int32, _f, C.c_int64, _f, C.c_int32, _f, _f, _s]),
     "gaot_attention_bwd_workspace": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "gaot_attention_bwd": (C.c_int, [_f, _f, _f, C.c_int64, C.c_int64, C.c_int64, _f, _f, C.c_int64, _f,
                                      C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
@@ -162,6 +165,7 @@ PROTOTYPES = {
     "gaot_debug_set_attention_split": (C.c_int, [C.c_int]),
     "gaot_debug_set_attention_h16": (C.c_int, [C.c_int]),
     "gaot_debug_set_attention_dh8": (C.c_int, [C.c_int]),
+    "gaot_debug_set_attention_keysplit": (C.c_int, [C.c_int]),
     "gaot_debug_set_attention_pipe": (C.c_int, [C.c_int]),
     "gaot_debug_set_attention_p_pieces": (C.c_int, [C.c_int]),
     "gaot_debug_set_attention_operand_pieces": (C.c_int, [C.c_int]),

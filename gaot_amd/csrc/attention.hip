@@ -26,6 +26,7 @@ struct AttnArgs {
     const float *oin, *dout; float *dq, *dk, *dv; long lddq, lddk, lddv;
     float* delta; float* dq_part; int n_kblocks;
     float *dk2, *dv2;          // query-split backward (QS = 2): dense [B S][H 32] partials of the second half of the query tiles
+    float *o_part, *lse_part;  // key-split forward (KS = 2): per half the normalised output [B S][H D] (dense) and its log-sum-exp [B H S]
     float scale; int vec;
     // attention dropout (attn.py:110-114, dropout_p of F.scaled_dot_product_attention in training): P is multiplied by
     // keep(b, h, q, k) / (1 - p) after the softmax; the mask is a counter-based hash of (*drop_seed, element index), so the
@@ -404,7 +405,11 @@ constexpr int AS_STAGE = 3 * AS_KPL + 3 * AS_VPL;          // bytes
 // dropped part is <= 2^-17 of each probability and unbiased
 // F16 (with PP = OP = 2): two fp16 pieces of the scaled operands (Q, K, V by the power of two from their magnitude word, P by 2^15), three
 // piece products per k-step on the f16 MFMA: fp32-level products at the two-piece kernels' cost.
-template <int NW, int DH = 32, int PP = 3, int OP = 3, bool F16 = false>
+// KS = 2 [r6]: the KEYS of a query block are shared between two workgroups (first half / second half of the key tiles): shapes whose
+// 256-query blocks x batch x heads number 128 .. 255 (the 3-D configuration's 1 x 4 096 tokens x 8 heads of 48) fill the chip with
+// eight waves per CU.  Each half leaves its own normalised output and log-sum-exp in the workspace; attn_fwd_combine_kernel joins them
+// (o = w1 o1 + w2 o2, w_i = exp(lse_i - lse): the same softmax, two partial sums per row instead of one running sum).
+template <int NW, int DH = 32, int PP = 3, int OP = 3, bool F16 = false, int KS = 1>
 __global__ __launch_bounds__(64 * NW, (NW == 4 && DH == 32) ? 2 : 1) void attn_fwd_split_kernel(const AttnArgs p) {
     constexpr int KT = 64, NT = 64 * NW, QB = 32 * NW;
     constexpr int NU = DH / 16, NDT = DH / 32, CPR = DH / 4;            // d steps, O tiles, 4-float chunks per row
@@ -415,8 +420,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && DH == 32) ? 2 : 1) void attn_f
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
-    int bh, blk;
-    xcd_group_decode(blockIdx.x, p.B * p.H, (p.S + QB - 1) / QB, bh, blk);
+    int bh, blk, khalf = 0;
+    xcd_group_decode(blockIdx.x, p.B * p.H, ((p.S + QB - 1) / QB) * KS, bh, blk);
+    if (KS > 1) { khalf = blk % KS; blk /= KS; }
     const int b = bh / p.H, h = bh % p.H, hk = h / (p.H / p.Hkv);
     const int q0 = blk * QB + wave * 32;
     const int D = DH == 32 ? 32 : p.D;
@@ -520,13 +526,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && DH == 32) ? 2 : 1) void attn_f
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
-    const int ntiles = (p.S + KT - 1) / KT;
-    fetch(0);
+    const int ntiles_all = (p.S + KT - 1) / KT;
+    const int kt_per = (ntiles_all + KS - 1) / KS;
+    const int kt_begin = khalf * kt_per, ntiles = min(ntiles_all, kt_begin + kt_per);          // this workgroup's key tiles: kt_begin .. ntiles - 1
+    fetch(kt_begin);
     stage(0);
-    if (ntiles > 1) fetch(1);
+    if (kt_begin + 1 < ntiles) fetch(kt_begin + 1);
     __syncthreads();
-    for (int kt = 0; kt < ntiles; ++kt) {
-        const int stg = kt & 1;
+    for (int kt = kt_begin; kt < ntiles; ++kt) {
+        const int stg = (kt - kt_begin) & 1;
         const unsigned char* Kp = smem + stg * STAGE;
         const unsigned char* Vp = Kp + 3 * KPL;
         // ---- S^T for 64 keys: two 32-key fragments, d in 16-wide steps, six piece products each
@@ -643,15 +651,40 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && DH == 32) ? 2 : 1) void attn_f
 #pragma unroll
         for (int r = 0; r < 16; ++r) Os[li * (DH + 1) + 32 * dt + crow(r, lh)] = oacc[dt][r] * inv_l;
     __syncthreads();
+    float* o_dst = KS > 1 ? p.o_part + (long)khalf * p.B * p.S * p.H * D : p.o;
+    const long o_ld = KS > 1 ? (long)p.H * D : p.ldo;
     for (int rr = lh; rr < 32; rr += 2) {
         const int qi = q0 + rr;
         if (qi >= p.S) break;
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt)
-            if (32 * dt + li < D) p.o[((long)b * p.S + qi) * p.ldo + (long)h * D + 32 * dt + li] = Os[rr * (DH + 1) + 32 * dt + li];
+            if (32 * dt + li < D) o_dst[((long)b * p.S + qi) * o_ld + (long)h * D + 32 * dt + li] = Os[rr * (DH + 1) + 32 * dt + li];
     }
     if (lh == 0 && q0 + li < p.S)
-        p.lse[((long)b * p.H + h) * p.S + q0 + li] = m_run * sm_scale + logf(l_run);
+        (KS > 1 ? p.lse_part + (long)khalf * p.B * p.H * p.S : p.lse)[((long)b * p.H + h) * p.S + q0 + li] = m_run * sm_scale + logf(l_run);
+}
+
+// joins the two halves of the key-split forward: per (row, head) w_i = exp(lse_i - lse), o = w1 o1 + w2 o2 (four columns per thread)
+__global__ __launch_bounds__(256) void attn_fwd_combine_kernel(const AttnArgs p) {
+    const int D = p.D, c4n = D >> 2;
+    const long total = (long)p.B * p.S * p.H * c4n;
+    const long half_o = (long)p.B * p.S * p.H * D, half_l = (long)p.B * p.H * p.S;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        const long rh = i / c4n;
+        const int h = (int)(rh % p.H);
+        const long row = rh / p.H;                 // b * S + s
+        const long b = row / p.S, sq = row - b * p.S;
+        const long li_ = (b * p.H + h) * p.S + sq;
+        const float l1 = p.lse_part[li_], l2 = p.lse_part[half_l + li_];
+        const float m = fmaxf(l1, l2);
+        const float w1 = expf(l1 - m), w2 = expf(l2 - m);
+        const float inv = 1.f / (w1 + w2);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p.o_part + row * ((long)p.H * D) + (long)h * D + c);
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(p.o_part + half_o + row * ((long)p.H * D) + (long)h * D + c);
+        *reinterpret_cast<f32x4*>(p.o + row * p.ldo + (long)h * D + c) = (a * (w1 * inv)) + (bb * (w2 * inv));
+        if (c == 0) p.lse[li_] = m + logf(w1 + w2);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2851,6 +2884,7 @@ static int fill_common(AttnArgs& a, const float* q, const float* k, const float*
 using namespace gaot;
 #define ST(s) reinterpret_cast<hipStream_t>(s)
 
+static int g_attn_ks = 1;        // [r6] key-split forward (128 .. 255 blocks of 256 queries x batch x heads, with a workspace): 0 = off
 static int g_attn_dh8 = 1;       // [r6] 32 < head_dim <= 64, fp16 pieces: the 8-wave 256-key backward (query-split at 128 .. 255 blocks); 0 = the 4-wave kernel
 static int g_attn_h16 = 0x18;    // [r6] the fp16-piece backward (256-key blocks, one workgroup per key block): 8 + 16 VAR = attn_bwd_h16_kernel<8, 1, VAR> (default VAR 1), 4 = <4>, 0 = attn_bwd_split8_kernel
 static int g_attn_split = 1;     // head_dim 32: 1 = split-bf16 kernels (default; 8-wave forward when it fills the chip), 0 = fp32-MFMA kernels,
@@ -2882,9 +2916,31 @@ extern "C" int gaot_debug_set_attention_dh8(int on) { const int old = g_attn_dh8
 extern "C" int gaot_debug_set_attention_h16(int nw) { const int old = g_attn_h16; g_attn_h16 = nw; return old; }
 extern "C" int gaot_debug_set_attention_split(int on) { const int old = g_attn_split; g_attn_split = on; return old; }
 
+// key-split forward (attn_fwd_split_kernel<8, 64, .., KS = 2>): shapes it is for -- 128 .. 255 blocks of 256 queries x batch x heads, at least eight
+// key tiles, head_dim 36 .. 64 in steps of 4.  (head_dim 32 stays on the 4-wave kernel, which already runs two workgroups per CU there:
+// 4 x 1 024 x 8 x 32 measured 28.7 us against 30.2 with the split; g_attn_ks = 2 forces it on for the tests.)
+static bool fwd_key_split_shape(int B, int S, int H, int head_dim) {
+    const long wg8 = (long)cdiv(S, 256) * B * H;
+    return g_attn_ks && g_attn_split == 1 && wg8 >= 128 && wg8 < 256 && cdiv(S, 64) >= 8 && head_dim >= (g_attn_ks == 2 ? 32 : 36) && head_dim <= 64 && head_dim % 4 == 0;
+}
+extern "C" int64_t gaot_attention_fwd_workspace(int32_t B, int32_t S, int32_t H, int32_t head_dim) {
+    if (B <= 0 || S <= 0 || H <= 0 || head_dim <= 0) return -1;
+    return fwd_key_split_shape(B, S, H, head_dim) ? 2 * ((int64_t)B * S * H * head_dim + (int64_t)B * H * S) : 0;
+}
+extern "C" int gaot_debug_set_attention_keysplit(int on) { const int old = g_attn_ks; g_attn_ks = on; return old; }
+
+extern "C" int gaot_attention_fwd_ws(const float* q, const float* k, const float* v, int64_t ldq, int64_t ldk, int64_t ldv,
+                                     int32_t B, int32_t S, int32_t H, int32_t Hkv, int32_t head_dim, float* o, int64_t ldo,
+                                     float* lse, int32_t pieces, const float* qkv_absmax, float* workspace, gaot_stream_t stream);
 extern "C" int gaot_attention_fwd(const float* q, const float* k, const float* v, int64_t ldq, int64_t ldk, int64_t ldv,
                                   int32_t B, int32_t S, int32_t H, int32_t Hkv, int32_t head_dim, float* o, int64_t ldo,
                                   float* lse, int32_t pieces, const float* qkv_absmax, gaot_stream_t stream) {
+    return gaot_attention_fwd_ws(q, k, v, ldq, ldk, ldv, B, S, H, Hkv, head_dim, o, ldo, lse, pieces, qkv_absmax, nullptr, stream);
+}
+
+extern "C" int gaot_attention_fwd_ws(const float* q, const float* k, const float* v, int64_t ldq, int64_t ldk, int64_t ldv,
+                                     int32_t B, int32_t S, int32_t H, int32_t Hkv, int32_t head_dim, float* o, int64_t ldo,
+                                     float* lse, int32_t pieces, const float* qkv_absmax, float* workspace, gaot_stream_t stream) {
     GAOT_REQUIRE(q && k && v && o && lse, "attention_fwd: null pointer");
     GAOT_REQUIRE(pieces == 0 || (pieces >= 2 && pieces <= 4), "attention_fwd: pieces %d not in {0, 2, 3, 4}", pieces);
     const bool f16 = pieces == 4 && qkv_absmax != nullptr && ::g_attn_pp < 0 && ::g_attn_op < 0;      // fp16 pieces where a kernel takes them; else exact
@@ -2896,6 +2952,16 @@ extern "C" int gaot_attention_fwd(const float* q, const float* k, const float* v
     fill_common(a, q, k, v, ldq, ldk, ldv, B, S, H, Hkv, head_dim);
     a.o = o; a.ldo = ldo; a.lse = lse; a.qkv_amax = qkv_absmax;
     dim3 grid(cdiv(S, 128) * B * H), block(256);
+    if (workspace != nullptr && f16 && a.vec && aligned16(workspace) && aligned16(o) && ldo % 4 == 0 && fwd_key_split_shape(B, S, H, head_dim)) {
+        a.o_part = workspace;
+        a.lse_part = workspace + 2 * (int64_t)B * S * H * head_dim;
+        const dim3 g2(cdiv(S, 256) * B * H * 2);
+        if (head_dim == 32) hipLaunchKernelGGL((attn_fwd_split_kernel<8, 32, 2, 2, true, 2>), g2, dim3(512), 0, ST(stream), a);
+        else                hipLaunchKernelGGL((attn_fwd_split_kernel<8, 64, 2, 2, true, 2>), g2, dim3(512), 0, ST(stream), a);
+        hipLaunchKernelGGL(attn_fwd_combine_kernel, dim3(cap_blocks((long)B * S * H * (head_dim / 4), 256, 2048)), dim3(256), 0, ST(stream), a);
+        GAOT_CHECK_LAUNCH("gaot_attention_fwd_ws");
+        return GAOT_OK;
+    }
     // 256-query workgroups once they still fill the chip (one per CU): half the K / V tile splits per head
     if (head_dim == 32 && a.vec && g_attn_split && g_attn_split != 3 && (g_attn_split == 2 || (long)cdiv(S, 256) * B * H >= 256)) {
         if (f16) hipLaunchKernelGGL((attn_fwd_split_kernel<8, 32, 2, 2, true>), dim3(cdiv(S, 256) * B * H), dim3(512), 0, ST(stream), a);

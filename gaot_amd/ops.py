@@ -2442,8 +2442,11 @@ class _Attention(torch.autograd.Function):
             if pc == 3 and _F16_PIECES[0] and 32 <= D <= 64 and D % 4 == 0:       # fp16 pieces: the operands' magnitude word (published by the projection's epilogue)
                 qw = amax_for(qkv.view(B * S, W), qkv, qkv_in)
                 pc = 4
-            L.check(lib.gaot_attention_fwd(_p(q), _p(kq), _p(vq), W, W, W, B, S, H, Hkv, D, _p(o), H * D, _p(lse), pc, _p(qw), _stream()),
-                    "gaot_attention_fwd")
+            # (a workspace where the shape takes the key-split forward: two halves of the keys per query block, joined by a second launch)
+            nws = int(lib.gaot_attention_fwd_workspace(B, S, H, D)) if pc == 4 else 0
+            ws = torch.empty(nws, device=qkv.device, dtype=torch.float32) if nws > 0 else None
+            L.check(lib.gaot_attention_fwd_ws(_p(q), _p(kq), _p(vq), W, W, W, B, S, H, Hkv, D, _p(o), H * D, _p(lse), pc, _p(qw), _p(ws), _stream()),
+                    "gaot_attention_fwd_ws")
             ctx.qkv_amax = qw
         ctx.save_for_backward(qkv, o, lse, seed if seed is not None else qkv.new_empty(0))
         ctx.dims = (B, S, H, Hkv, D, float(p_drop))

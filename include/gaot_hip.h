@@ -383,6 +383,14 @@ int gaot_act_bwd(const float* g, const float* z, int64_t n, int32_t act, float* 
 int gaot_attention_fwd(const float* q, const float* k, const float* v, int64_t ldq, int64_t ldk, int64_t ldv,
                        int32_t B, int32_t S, int32_t H, int32_t Hkv, int32_t head_dim,
                        float* o, int64_t ldo, float* lse, int32_t pieces, const float* qkv_absmax, gaot_stream_t stream);
+/* [ABI 9] the same with a workspace (gaot_attention_fwd_workspace floats, 16-byte aligned; 0 floats / a null pointer: exactly
+ * gaot_attention_fwd).  With pieces = 4, 32 < head_dim <= 64 and 128 .. 255 blocks of 256 queries x batch x heads (1 x 4 096 tokens x 8
+ * heads of 48) the keys of a query block are shared between two workgroups and a second launch joins the halves
+ * (o = w1 o1 + w2 o2 with w_i = exp(lse_i - lse)): the same softmax, eight waves per CU instead of four. */
+int64_t gaot_attention_fwd_workspace(int32_t B, int32_t S, int32_t H, int32_t head_dim);
+int gaot_attention_fwd_ws(const float* q, const float* k, const float* v, int64_t ldq, int64_t ldk, int64_t ldv,
+                          int32_t B, int32_t S, int32_t H, int32_t Hkv, int32_t head_dim,
+                          float* o, int64_t ldo, float* lse, int32_t pieces, const float* qkv_absmax, float* workspace, gaot_stream_t stream);
 /* workspace floats needed by gaot_attention_bwd */
 /* attention dropout (attn.py:110-114: dropout_p of F.scaled_dot_product_attention while training): the softmax output is
  * multiplied by keep(b,h,q,k) / (1 - p) before the product with V.  keep = (splitmix64(seed + ((b*H + h)*S + q)*S + k) >> 32) <

@@ -52,6 +52,7 @@ int gaot_debug_set_wgrad_tile_rows(int bm);
 /* tuning hook: head_dim 32 attention, 1 = split-bf16 MFMA kernels (default), 0 = fp32-MFMA kernels, 2 / 3 = split with the
  * 8-wave / 4-wave forward workgroup forced.  Returns the previous value. */
 int gaot_debug_set_attention_split(int on);
+int gaot_debug_set_attention_keysplit(int on);  /* [r6] the key-split forward of gaot_attention_fwd_ws: 1 (default) = on for the shapes it is for (head_dim 36 .. 64), 2 = head_dim 32 too (tests), 0 = off (the workspace query then answers 0); returns the old value */
 int gaot_debug_set_attention_dh8(int on);       /* [r6] 32 < head_dim <= 64 on fp16 pieces: 1 (default) = the 8-wave 256-key backward (attn_bwd_split8_dh_kernel<true, QS>: query-split at 128 .. 255 key blocks x batch x heads), 0 = the 4-wave 128-key kernel; returns the old value */
 int gaot_debug_set_attention_h16(int mode);     /* [r6] the fp16-piece backward at >= 256 key blocks: 8 + 16 VAR = attn_bwd_h16_kernel<8, 1, VAR> (default 0x18), 4 = <4> (two workgroups per CU), 0 = attn_bwd_split8_kernel; returns the old mode */
 /* head_dim-32 split attention: pieces of P in the forward and of P / dS in the backward products, as 10 * forward + backward:

@@ -1010,6 +1010,43 @@ def test_attention_fp16_piece_products():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,S,H,D", [(4, 1024, 8, 32), (5, 1000, 8, 32), (1, 4096, 8, 48), (3, 1500, 8, 36), (2, 2048, 8, 64)])
+def test_attention_key_split_forward(B, S, H, D):
+    """the key-split forward (gaot_attention_fwd_ws with a workspace: 128 .. 255 blocks of 256 queries x batch x heads -- the 4 x 1 024-token
+    batch, the 3-D configuration's 1 x 4 096 x 8 x 48, ragged and odd tile counts): two workgroups per query block, each over half the key
+    tiles, joined by attn_fwd_combine_kernel -- against float64 (output, and the gradients the backward forms from its log-sum-exp) and
+    against the one-pass forward it replaces there: same error level, deterministic"""
+    from gaot_amd import ops, _lib
+    lib = _lib.load()
+    on = 2 if D == 32 else 1          # (head_dim 32 is not taken by default -- its 4-wave kernel already runs two workgroups per CU -- but the kernel is the same template)
+    assert lib.gaot_attention_fwd_workspace(B, S, H, D) == (0 if D == 32 else 2 * (B * S * H * D + B * H * S))
+    g = torch.Generator().manual_seed(S + D + B)
+    qkv, go = torch.randn(B, S, 3 * H * D, generator=g), torch.randn(B, S, H * D, generator=g)
+    r = qkv.clone().double().requires_grad_(True)
+    q, k, v = [r[..., i * H * D:(i + 1) * H * D].reshape(B, S, H, D).transpose(1, 2) for i in range(3)]
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(D), -1) @ v).transpose(1, 2).reshape(B, S, H * D)
+    ref.backward(go.double())
+
+    def run(ks):
+        old = lib.gaot_debug_set_attention_keysplit(ks)
+        try:
+            assert (lib.gaot_attention_fwd_workspace(B, S, H, D) > 0) == bool(ks)
+            d = qkv.to(dev()).requires_grad_(True)
+            out = ops.attention(d, H, H, D)
+            out.backward(go.to(dev()))
+        finally:
+            lib.gaot_debug_set_attention_keysplit(old)
+        return out.detach(), d.grad
+
+    (o2, g2), (o2b, g2b), (o1, g1) = run(on), run(on), run(0)
+    assert torch.equal(o2, o2b) and torch.equal(g2, g2b)
+    e2, e1 = rel(o2, ref), rel(o1, ref)
+    assert e2 < 6e-7 and e2 < 1.5 * e1 + 2e-8, (e2, e1)
+    eg2, eg1 = rel(g2, r.grad), rel(g1, r.grad)
+    assert eg2 < 1.2e-6 and eg2 < 1.5 * eg1 + 2e-8, (eg2, eg1)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,S,H,D", [(2, 2048, 8, 64), (3, 1500, 8, 36), (1, 4096, 8, 48), (4, 2048, 8, 48)])
 def test_attention_head_dim_64_eight_wave_backward(B, S, H, D):
     """32 < head_dim <= 64 on fp16 pieces: the 8-wave 256-key backward (attn_bwd_split8_dh_kernel<true, QS>) -- query-split between two
