@@ -1047,6 +1047,40 @@ def test_attention_key_split_forward(B, S, H, D):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,S,H,Hkv,D", [(2, 2048, 8, 4, 64), (3, 1400, 8, 2, 48)])
+def test_attention_key_split_and_query_split_with_grouped_kv_heads(B, S, H, Hkv, D):
+    """both [r6] chip-filling paths of 32 < head_dim <= 64 (key-split forward, query-split 8-wave backward) with FEWER kv heads than query
+    heads (attn.py:100-104 repeat_interleave): output and the gradient of the fused q | k | v projection against float64, and against the
+    one-pass / 4-wave kernels"""
+    from gaot_amd import ops, _lib
+    lib = _lib.load()
+    assert lib.gaot_attention_fwd_workspace(B, S, H, D) > 0
+    g = torch.Generator().manual_seed(S + D)
+    W = (H + 2 * Hkv) * D
+    qkv, go = torch.randn(B, S, W, generator=g), torch.randn(B, S, H * D, generator=g)
+    r = qkv.clone().double().requires_grad_(True)
+    q = r[..., :H * D].reshape(B, S, H, D).transpose(1, 2)
+    k = r[..., H * D:(H + Hkv) * D].reshape(B, S, Hkv, D).transpose(1, 2).repeat_interleave(H // Hkv, dim=1)
+    v = r[..., (H + Hkv) * D:].reshape(B, S, Hkv, D).transpose(1, 2).repeat_interleave(H // Hkv, dim=1)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(D), -1) @ v).transpose(1, 2).reshape(B, S, H * D)
+    ref.backward(go.double())
+
+    def run(on):
+        o1, o2 = lib.gaot_debug_set_attention_keysplit(on), lib.gaot_debug_set_attention_dh8(on)
+        try:
+            d = qkv.to(dev()).requires_grad_(True)
+            out = ops.attention(d, H, Hkv, D)
+            out.backward(go.to(dev()))
+        finally:
+            lib.gaot_debug_set_attention_keysplit(o1); lib.gaot_debug_set_attention_dh8(o2)
+        return out.detach(), d.grad
+
+    (oa, ga), (ob, gb) = run(1), run(0)
+    assert rel(oa, ref) < 6e-7 and rel(oa, ref) < 1.5 * rel(ob, ref) + 2e-8
+    assert rel(ga, r.grad) < 1.2e-6 and rel(ga, r.grad) < 1.5 * rel(gb, r.grad) + 2e-8, (rel(ga, r.grad), rel(gb, r.grad))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,S,H,D", [(2, 2048, 8, 64), (3, 1500, 8, 36), (1, 4096, 8, 48), (4, 2048, 8, 48)])
 def test_attention_head_dim_64_eight_wave_backward(B, S, H, D):
     """32 < head_dim <= 64 on fp16 pieces: the 8-wave 256-key backward (attn_bwd_split8_dh_kernel<true, QS>) -- query-split between two
