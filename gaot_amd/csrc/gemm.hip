@@ -605,7 +605,8 @@ extern "C" int gaot_gemm_path(const gaot_gemm_desc* d) {
 }
 
 // ---- grouped weight-gradient products (kernel: gemm_split.hip)
-namespace gaot { void set_tn_kslab(int k); void set_tn_bm(int bm); }
+namespace gaot { void set_tn_kslab(int k); void set_tn_bm(int bm); void set_tn_rule(int r); }
+extern "C" int gaot_debug_set_wgrad_slab_rule(int r) { gaot::set_tn_rule(r); return 0; }
 extern "C" int gaot_debug_set_wgrad_kslab(int k) { gaot::set_tn_kslab(k); return 0; }
 extern "C" int gaot_debug_set_wgrad_tile_rows(int bm) { gaot::set_tn_bm(bm); return 0; }
 static int check_wgrad_items(const gaot_wgrad_item* items, int n) {

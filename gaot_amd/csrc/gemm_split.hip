@@ -744,6 +744,8 @@ static int tn_tile_rows(const gaot_wgrad_item* items, int n) {
     for (int i = 0; i < n; ++i) if (items[i].M % 256 != 0) return 128;
     return 256;
 }
+static int g_tn_rule = 0;            // automatic K slabs: 0 = the rule of rounds 3-5 (default), 1 = the cost model below [r6: measured, not kept] (tuning hook)
+void set_tn_rule(int r) { g_tn_rule = r; }
 static int g_tn_kslab = 0;           // 0 = automatic (below); otherwise a fixed K slab (tuning hook)
 static int g_tn_cap_long = 4096;     // the same for node-level products (K = batch x nodes > 16 384)
 static int g_tn_cap = 4096;          // longest K slab of a product whose reduction is much longer than the rest (tuning hook: a negative argument sets it)
@@ -780,10 +782,44 @@ long plan_tn_grouped(const gaot_wgrad_item* items, int n, TnGroupArgs* args, int
         const long b = (kmin + s0 - 1) / s0;
         base_slab = b < 1024 ? 1024 : (b > 4096 ? 4096 : (int)b);
     }
+    // [r6, measured and NOT kept: g_tn_rule = 1 only] same-box steps, rule -> model: C2 2.1152 -> 2.1242 ms, C3 4.763 -> 4.804, C4 / C5
+    // within noise -- a round that is 80 % full is not 20 % wasted (the CUs that hold one workgroup instead of two run it faster), so
+    // slab counts that land just under a whole number of rounds buy nothing and pay their extra slabs.
+    // the slab length by a cost model instead of the rule above: a launch lasts  rounds x (longest K loop) + a x slabs,
+    // rounds = ceil(workgroups / resident slots) -- 512 slots at two 128-row workgroups per CU -- and a ~ 185 values of k per slab (the slab
+    // stores and the last arriver's sum; from the sweep above: 314 / 340 us at 2 / 4 slabs of the 204-tile launch).  The model reproduces
+    // that sweep's 387 us at 8 slabs and the 68-tile launch's 160 / 108 / 123 us, and finds what the rule misses: slab counts that land
+    // just under a whole number of rounds (204 tiles x 5 slabs = 1 020 workgroups = two full rounds of 1 664 instead of one 80 %-full
+    // round of 4 096; K = 16 384: 5 x 3 296 instead of 4 x 4 096).
+    int model_slab = 0;
+    if (g_tn_rule == 1 && g_tn_kslab == 0 && kmin >= 1024) {
+        const long slots = BMr == 256 ? 256 : 512;
+        double best = 1e30;
+        for (int L = 512; L <= 4096; L += 32) {
+            long total = 0, lmax = 0; int smin_k = 1;
+            for (int i = 0; i < n; ++i) {
+                const int kt32 = items[i].K / 32;
+                int sp = (int)((items[i].K + L - 1) / L);
+                if (sp > 16 && items[i].K > 4 * kmin) sp = 16;          // (node-level reductions: many slabs would queue on one tile's last arriver)
+                const int per = (kt32 + sp - 1) / sp;
+                sp = (kt32 + per - 1) / per;
+                total += (long)cdiv(items[i].M, BMr) * cdiv(items[i].N, 128) * sp;
+                lmax = per * 32L > lmax ? per * 32L : lmax;
+                if (items[i].K == kmin) smin_k = sp;
+            }
+            const long rounds = (total + slots - 1) / slots;
+            const double cost = (double)rounds * lmax + 185.0 * smin_k;
+            if (cost < best - 1e-9 || (cost < best + 1e-9 && L > model_slab)) { best = cost; model_slab = L; }
+        }
+    }
     for (int i = 0; i < n; ++i) {
         const gaot_wgrad_item& it = items[i];
         const int kt32 = it.K / 32;
         int kslab = g_tn_kslab;
+        if (kslab == 0 && model_slab > 0) {
+            kslab = model_slab;
+            if ((it.K + kslab - 1) / kslab > 16 && it.K > 4 * kmin) kslab = (int)((it.K + 15) / 16);
+        } else
         if (kslab == 0) {
             int s_auto = want < 1 ? 1 : (want > 16 ? 16 : want);      // the last workgroup of a tile sums the slabs alone: keep them few
             if (s_auto > it.K / 512) s_auto = it.K / 512 > 0 ? it.K / 512 : 1;      // slabs of at least 512

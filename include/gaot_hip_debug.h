@@ -49,6 +49,8 @@ int gaot_debug_set_wgrad_kslab(int k);
 /* [r6] grouped weight gradients on fp16 pieces: 256 = 256 x 128 tiles on eight waves (one workgroup per CU) when every product's M is a
  * multiple of 256; 128 = 128 x 128 tiles, two workgroups per CU */
 int gaot_debug_set_wgrad_tile_rows(int bm);
+/* [r6] grouped weight gradients, automatic K slabs: 0 (default) = the rule of rounds 3-5, 1 = a cost model (rounds x longest K loop + a per-slab term: measured slower, gemm_split.hip) */
+int gaot_debug_set_wgrad_slab_rule(int r);
 /* tuning hook: head_dim 32 attention, 1 = split-bf16 MFMA kernels (default), 0 = fp32-MFMA kernels, 2 / 3 = split with the
  * 8-wave / 4-wave forward workgroup forced.  Returns the previous value. */
 int gaot_debug_set_attention_split(int on);
