@@ -99,6 +99,7 @@ PROTOTYPES = {
     "gaot_debug_split_redo_count": (C.c_uint, [C.c_int]),
     "gaot_debug_set_wgrad_kslab": (C.c_int, [C.c_int]),
     "gaot_debug_set_wgrad_tile_rows": (C.c_int, [C.c_int]),
+    "gaot_debug_set_gemm_ad_flush": (C.c_int, [C.c_int]),
     "gaot_debug_set_wgrad_slab_rule": (C.c_int, [C.c_int]),
     "gaot_csr_prepare": (C.c_int, [_i, _i, C.c_int32, C.c_int32, C.c_int32, _i, _i, _i, _i, _s]),
     "gaot_csr_transpose": (C.c_int, [_i, C.c_int32, C.c_int32, _i, _i, _i, _s]),

@@ -367,6 +367,8 @@ int gaot_forced_pieces() { return g_split_pieces_forced ? g_split_pieces : 0; }
 
 static int g_use_ad = 1;         // all-DMA fp16-piece tiles: 0 off, 1 per the heuristic, 2 / 3: 64- / 128-row tiles wherever eligible (A/B switch)
 extern "C" int gaot_debug_set_gemm_ad(int on) { const int old = g_use_ad; g_use_ad = on; return old; }
+static int g_ad_flush = 1;      // [r6] unsplit reductions of 1 025 .. 2 048 on the 64 x 64 all-DMA tiles with the in-kernel flush (gemm_ad.hip FL); 0 = off (K slabs as before)
+extern "C" int gaot_debug_set_gemm_ad_flush(int on) { const int old = g_ad_flush; if (on >= 0) g_ad_flush = on; return old; }      // (on < 0: query)
 static int g_ad_narrow = 5;     // 64 x 64 all-DMA tiles (A/B switch, bits): 1 = half-filled launches of outputs two tiles wide (default), 2 = also N <= 256, K <= 256 at full launches, 4 = also outputs THREE tiles wide (4 096 tokens x 384: the 3-D configuration's o_proj-shaped products, which fell to the fp32-MFMA tiles; default), 8 = K slabs of such products too (4 096 x 384 x 1 152 in two slabs: C5 5.20 -> 5.27 ms same-box, tools/c45_ab.py 5 13: off), 16 = the concatenated-input (A2) product of the skip block too (C4 1.498 -> 1.500, C5 5.12 -> 5.09: nothing: off)
 extern "C" int gaot_debug_set_gemm_ad_narrow(int on) { const int old = g_ad_narrow; g_ad_narrow = on; return old; }
 static int g_use_planes = 1;     // 0: ignore gaot_gemm_desc.b_planes (A/B switch)
@@ -490,21 +492,25 @@ static int gemm_run(const gaot_gemm_desc* d, gaot_stream_t stream, const bool dr
     // values of k on that pipe; longer reductions either arrive split (the slabs are summed on the vector pipe) or stay on the
     // fp32-MFMA tiles
     const long k_per_wg = a.split_k > 1 ? (long)a.ktiles_per_split * 32 : a.K;
+    // [r6] unsplit reductions of 1 025 .. 2 048 on the 64 x 64 all-DMA tiles, which flush their accumulators every 1 024 values of k in the
+    // kernel (gemm_ad.hip FL): the narrow outputs whose K slabs would not fill the split tiles and fell to the fp32-MFMA tiles (4 096 x 384 x
+    // 1 152, the 3-D configuration's q|k|v input gradient: two slabs of 39 us + a reduce)
+    const bool long_k = g_ad_flush && pieces == 4 && a.split_k <= 1 && a.K > 1024 && a.K <= 2048 && !raw;
     const bool split_ok = g_use_split && g_use_split != 3 && glds_ok && (a.A2 == nullptr || (ak && a.k_split % 16 == 0)) && g_tile_override == 0 &&
-                          (k_per_wg <= 1024 || pieces == 1 || g_use_split != 1);      // forced tuning modes bypass the cap
+                          (k_per_wg <= 1024 || pieces == 1 || g_use_split != 1 || long_k);      // forced tuning modes bypass the cap
     // measured (round 2, tools/gemm_bench.py sweeps): the 128x128 split-bf16 tiles win once they fill the chip (>= 256 workgroups
     // counting split-K slabs) on outputs at least one tile wide; narrower / smaller products stay on the fp32 MFMA tiles
     // two-piece products, outputs at most six 128-wide tiles across (N <= 768): the 64-row tiles win although the 128-row ones would
     // fill the chip (8192 x 768 x 256 NT: 21.7 vs 24.2 us, NN x 512 x 256: 18.6 vs 19.5; N >= 1 024: the other way round)
     const bool two_pl = pieces == 2 || pieces >= 4;       // two planes per operand in LDS
-    const bool prefer64 = split_ok && g_use_split == 1 && two_pl && ak && cdiv(a.N, 128) <= 6 && blocks(64, 128) >= 250 && a.M >= 64 &&
+    const bool prefer64 = split_ok && !long_k && g_use_split == 1 && two_pl && ak && cdiv(a.N, 128) <= 6 && blocks(64, 128) >= 250 && a.M >= 64 &&
                           a.N >= 128 && a.split_k <= 1;
-    const bool split128 = split_ok && g_use_split != 4 && !prefer64 &&
+    const bool split128 = split_ok && !long_k && g_use_split != 4 && !prefer64 &&
                           (g_use_split == 2 || (blocks(128, 128) >= 250 && a.M >= 128 && a.N >= 128 && (long)cdiv(a.M, 128) * cdiv(a.N, 128) >= 8));
     // outputs only a few 128-wide tiles across (N = 256): 64-row tiles double the workgroup count
     // (with pre-split B planes an NN product stages B exactly like an NT one; with two-piece products the 64-row split tiles beat the
     // fp32-MFMA tiles on the NN products too: 8192 x 256 x 768 37.4 -> 25.6 us, x 512 26.5 -> 19.0, x 256 15.5 -> 12.8, tools/gemm_modes_2p.py)
-    const bool split64 = split_ok && !split128 && g_use_split != 5 && g_use_split != 2 &&
+    const bool split64 = split_ok && !long_k && !split128 && g_use_split != 5 && g_use_split != 2 &&
                          (g_use_split == 4 || prefer64 || ((ak && (bk || a.Bpl != nullptr || g_use_split == 6 || two_pl)) && blocks(64, 128) >= 250 && a.M >= 64 && a.N >= 128 && a.split_k <= 1));   // measured: NT +6-14 %, NN +-0
     // 64 x 64 all-DMA tiles (gaot_debug_set_gemm_ad_narrow, bits): (1, default) half-filled launches of outputs two tiles wide (4 096 tokens x
     // 256: 128 workgroups of 64 rows, which fall to the fp32-MFMA tiles) get 256 workgroups -- tools/ad_bench.hip: 4096 x 256 x 256 in 8.3 us
@@ -516,11 +522,11 @@ static int gemm_run(const gaot_gemm_desc* d, gaot_stream_t stream, const bool dr
     // DESIGN 7, not these tiles.)
     const bool narrow_shape = g_use_ad == 1 && (g_ad_narrow & 1) && split_ok && !split128 && !split64 && pieces == 4 && ak && a.K % 32 == 0 && a.vec_epi &&
                               (a.split_k <= 1 || ((g_ad_narrow & 8) && !raw)) && (a.A2 == nullptr || ((g_ad_narrow & 16) && a.k_split % 32 == 0)) && (cdiv(a.N, 128) == 2 || ((g_ad_narrow & 4) && cdiv(a.N, 128) == 3)) && blocks(64, 64) >= 128 && (long)cdiv(a.M, 64) * cdiv(a.N, 128) < 250 &&
-                              (a.split_k <= 1 ? a.K : cdiv(cdiv(a.K, 32), a.split_k) * 32) <= 1024;          // (bit 8: K slabs of such a product too -- 4 096 x 384 x 1 152 in two slabs)
+                              (a.split_k <= 1 ? a.K : cdiv(cdiv(a.K, 32), a.split_k) * 32) <= (long_k ? 2048 : 1024);          // (bit 8: K slabs of such a product too -- 4 096 x 384 x 1 152 in two slabs)
     const bool ad_narrow = narrow_shape && (dry ? d->b_planes != nullptr : a.Bpl != nullptr);
     // planes handed in but switched off (gaot_debug_set_gemm_planes(0)): the same tile family on the staged 64-row kernel, so that the
     // switch changes where B's pieces come from and nothing else (products WITHOUT planes -- B an activation -- stay where they were)
-    const bool narrow_staged = narrow_shape && !dry && a.Bpl == nullptr && d->b_planes != nullptr;
+    const bool narrow_staged = narrow_shape && !long_k && !dry && a.Bpl == nullptr && d->b_planes != nullptr;
     if (dry) { g_last_path = (split128 || split64 || ad_narrow) ? 3 : 1; return GAOT_OK; }
     if (split128 || split64 || ad_narrow || narrow_staged) {
         g_last_path = 3;

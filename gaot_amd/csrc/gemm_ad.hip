@@ -50,7 +50,10 @@ template <int TN> __device__ __forceinline__ void ad_pin(AdFrag<TN>& f) {
 // BMT x BNT outputs per workgroup, 4 waves as WAVES_M x (4 / WAVES_M), NS ring slots (BNT = 64: 64 x 64 tiles, twice the workgroups for
 // outputs two 128-wide tiles across that would leave every CU with one wave per SIMD).  BREAL: is W itself k-contiguous as stored (NT: the
 // planes of W; NN: the planes of W^T) -- only the second pass reads it.
-template <int BMT, int WAVES_M, int NS, bool BREAL, int ABL = 0, int BNT = 128>
+// FL [r6]: reductions longer than the accumulation cap of the f16 / bf16 MFMA (1 024 values of k: its accumulator does not round to nearest)
+// in ONE pass: every 32 k-tiles the accumulators join running sums on the vector pipe and start from zero again -- what K slabs + a reduce
+// launch do, without the slabs (the 64 x 64 tiles only: 16 more registers).
+template <int BMT, int WAVES_M, int NS, bool BREAL, int ABL = 0, int BNT = 128, bool FL = false>
 __global__ __launch_bounds__(256, 2) void gemm_ad_kernel(const GemmArgs p) {
     constexpr int WAVES_N = 4 / WAVES_M, WM = BMT / WAVES_M, WN = BNT / WAVES_N, TM = WM / 32, TN = WN / 32;
     constexpr int A_ST = BMT * 128, B_ST = BNT * 128, STAGE = A_ST + B_ST;          // bytes
@@ -225,6 +228,15 @@ __global__ __launch_bounds__(256, 2) void gemm_ad_kernel(const GemmArgs p) {
         amax_finish(wb, sc_b, so_b);
     }
 
+    f32x16 tot[FL ? TM : 1][FL ? TN : 1];
+    if (FL) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
+    }
     int slot = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         // tile kt has landed (this wave's pieces; with three slots tile kt + 1 may still be in flight)
@@ -258,6 +270,22 @@ __global__ __launch_bounds__(256, 2) void gemm_ad_kernel(const GemmArgs p) {
         mfmas(pc1, bf1, 0, NMF);
         __builtin_amdgcn_sched_barrier(0);
         slot = slot == NS - 1 ? 0 : slot + 1;
+        if (FL && ((kt - kt_begin) & 31) == 31) {          // wave-uniform: 32 k-tiles of 32 = the accumulation cap
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { tot[i][j][r] += acc[i][j][r]; acc[i][j][r] = 0.f; }
+        }
+    }
+    if (FL) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += tot[i][j][r];
     }
     // The range watch's verdict rides on the barrier the epilogue needs anyway: every wave leaves its count of threads that saw the
     // spread (and whether any saw a stale word) in LDS BEFORE it, everyone reads the four entries after it (__syncthreads_count +
@@ -347,6 +375,11 @@ void launch_ad(GemmArgs& a, bool b_kmajor, hipStream_t st, int bm, int bn) {
     a.tiles_n = cdiv(a.N, bn);
     a.bpl_flag = b_kmajor ? 1 : 2;
     dim3 grid(a.tiles_m * a.tiles_n, 1, a.split_k > 1 ? a.split_k : 1), block(256);
+    const long k_per_wg = a.split_k > 1 ? (long)a.ktiles_per_split * AD_BK : a.K;
+    if (bm == 64 && bn == 64 && k_per_wg > 1024) {          // (the dispatcher sends reductions past the cap here only: gemm.hip ad_narrow)
+        if (b_kmajor) hipLaunchKernelGGL((gemm_ad_kernel<64, 2, 3, true, 0, 64, true>), grid, block, 0, st, a);
+        else          hipLaunchKernelGGL((gemm_ad_kernel<64, 2, 3, false, 0, 64, true>), grid, block, 0, st, a);
+    } else
     if (bm == 64 && bn == 64) {
         if (b_kmajor) hipLaunchKernelGGL((gemm_ad_kernel<64, 2, 3, true, 0, 64>), grid, block, 0, st, a);
         else          hipLaunchKernelGGL((gemm_ad_kernel<64, 2, 3, false, 0, 64>), grid, block, 0, st, a);

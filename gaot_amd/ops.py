@@ -396,6 +396,8 @@ def weight_operand(w2d: torch.Tensor, b_kmajor: bool):
     return word, ptr, ld, 16
 
 
+_GEMM_TRACE = os.environ.get("GAOT_GEMM_TRACE", "0") == "1"      # tools: print every distinct product of gemm() with its tile family
+_GEMM_TRACE_SEEN = set()
 _AMAX_TRACE = os.environ.get("GAOT_AMAX_TRACE", "0") == "1"      # tools: print every fallback absmax launch with its call site
 _PATH_CACHE: dict = {}
 _PUBLISH_C = os.environ.get("GAOT_NO_CAMAX", "0") != "1"       # A/B switch (tools): GEMM epilogues publish the output's magnitude word
@@ -453,6 +455,10 @@ def gemm(M: int, N: int, K: int, A, lda, a_kmajor, B, ldb, b_kmajor, out, ldc, *
         if has_planes:
             d.b_planes, d.ld_bplanes, d.b_plane_stride = wop[1], wop[2], wop[3]
         path = _gemm_path(d, key)
+        if _GEMM_TRACE and key not in _GEMM_TRACE_SEEN:          # tools: every distinct product once, with the tile family the dispatcher answers
+            _GEMM_TRACE_SEEN.add(key)
+            print(f"[gemm] {kind} M={M} N={N} K={K} split_k={split_k} raw={int(raw_slabs)} act={act} planes={int(has_planes)} A2={int(A2 is not None)} -> "
+                  f"{ {1: 'fp32-MFMA tiles', 2: 'skinny', 3: 'fp16-piece tiles'}.get(path, path) }", flush=True)
         d.pieces, d.a_absmax, d.b_absmax, d.a2_absmax = 3, None, None, None
         d.b_planes, d.ld_bplanes, d.b_plane_stride = None, 0, 0
         if path == 3:
@@ -569,7 +575,14 @@ def _split_for_narrow_output(Mo: int, No: int, K: int, planes=None) -> int:
         s = min(-(-256 // t128), K // 512)
         while s > 0 and K / s > 1024 and s < K // 256:
             s += 1
-        return max(1, s)
+        s = max(1, s)
+        # [r6] slabs that would not fill the split tiles either (s x tiles < 250: they ran on the fp32-MFMA tiles -- 4 096 x 384 x 1 152 in two
+        # slabs of 39 us + a reduce) with a reduction of at most 2 048: unsplit on the 64 x 64 all-DMA tiles, whose kernel flushes its
+        # accumulators every 1 024 values of k (gemm.hip `long_k`; needs the weight planes like every product on those tiles)
+        if s > 1 and s * t128 < 250 and 1024 < K <= 2048 and K % 32 == 0 and Mo % 64 == 0 and 128 < No <= 384 and planes is not None and planes() \
+                and int(L.load().gaot_debug_set_gemm_ad_flush(-1)) == 1:          # (-1: query)
+            return 1
+        return s
     if t128 >= 200 and K > 1024 and Mo >= 128 and No >= 128:
         # plenty of tiles, long reduction (C3: 16 384 x 256 x 2 048): the split-bf16 tiles accumulate at most 1 024 values of k per
         # workgroup (gemm.hip), so the reduction arrives in slabs of that depth rather than falling back to the fp32-MFMA tiles

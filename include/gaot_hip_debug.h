@@ -48,6 +48,7 @@ unsigned gaot_debug_split_redo_count(int reset);
 int gaot_debug_set_wgrad_kslab(int k);
 /* [r6] grouped weight gradients on fp16 pieces: 256 = 256 x 128 tiles on eight waves (one workgroup per CU) when every product's M is a
  * multiple of 256; 128 = 128 x 128 tiles, two workgroups per CU */
+int gaot_debug_set_gemm_ad_flush(int on);        /* [r6] narrow outputs with a reduction of 1 025 .. 2 048: 1 (default) = unsplit on the 64 x 64 all-DMA tiles, which flush their accumulators every 1 024 values of k; 0 = K slabs as before; negative = query; returns the old value */
 int gaot_debug_set_wgrad_tile_rows(int bm);
 /* [r6] grouped weight gradients, automatic K slabs: 0 (default) = the rule of rounds 3-5, 1 = a cost model (rounds x longest K loop + a per-slab term: measured slower, gemm_split.hip) */
 int gaot_debug_set_wgrad_slab_rule(int r);

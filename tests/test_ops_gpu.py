@@ -1010,6 +1010,48 @@ def test_attention_fp16_piece_products():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(4096, 384, 1152), (4096, 256, 2048), (4096, 384, 1056), (3200, 384, 1536)])
+def test_gemm_narrow_output_long_reduction_in_one_pass(M, N, K):
+    """narrow outputs (two or three 128-wide tiles across, half-filled launches) with a reduction of 1 025 .. 2 048 and a weight with planes:
+    ONE launch of the 64 x 64 all-DMA tiles, which flush their accumulators every 1 024 values of k (gemm_ad.hip FL) -- the 3-D configuration's
+    q|k|v input gradient, 4 096 x 384 x 1 152, ran as two K slabs on the fp32-MFMA tiles + a reduce.  Both layouts (x W^T, dY W) against float64
+    and against the K-slab path; same-signed operands (the accumulator drift the cap exists for) stay at fp32 level"""
+    from gaot_amd import ops, _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    for positive in (False, True):
+        x = torch.randn(M, K, generator=g)
+        w = torch.randn(N, K, generator=g) * 0.05
+        dy = torch.randn(M, K, generator=g)            # dY of a Linear whose weight is w2 [K, N]
+        w2 = torch.randn(K, N, generator=g) * 0.05
+        if positive:
+            x, w, dy, w2 = x.abs(), w.abs(), dy.abs(), w2.abs()
+        res = {}
+        for on in (1, 0):
+            old = lib.gaot_debug_set_gemm_ad_flush(on)
+            try:
+                ops._PATH_CACHE.clear()
+                ops.begin_pass()
+                wd, w2d = torch.nn.Parameter(w.cuda()), torch.nn.Parameter(w2.cuda())
+                ops.refresh_weight_amax([wd, w2d])
+                with torch.no_grad():
+                    nt = ops.linear_nt(x.cuda(), wd.detach())
+                    p_nt = lib.gaot_debug_last_gemm_path()
+                    nn = ops.matmul_nn(dy.cuda(), w2d.detach())
+                    p_nn = lib.gaot_debug_last_gemm_path()
+                torch.cuda.synchronize()
+                res[on] = (nt, nn, p_nt, p_nn)
+            finally:
+                lib.gaot_debug_set_gemm_ad_flush(old)
+                ops._PATH_CACHE.clear()
+        r_nt, r_nn = x.double() @ w.double().t(), dy.double() @ w2.double()
+        assert res[1][2] == 3 and res[1][3] == 3          # the fp16-piece family, in one launch
+        for i, r in ((0, r_nt), (1, r_nn)):
+            e1, e0 = rel(res[1][i], r), rel(res[0][i], r)
+            assert e1 < 6e-7 and e1 < 1.5 * e0 + 5e-8, (positive, i, e1, e0)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,S,H,D", [(4, 1024, 8, 32), (5, 1000, 8, 32), (1, 4096, 8, 48), (3, 1500, 8, 36), (2, 2048, 8, 64)])
 def test_attention_key_split_forward(B, S, H, D):
     """the key-split forward (gaot_attention_fwd_ws with a workspace: 128 .. 255 blocks of 256 queries x batch x heads -- the 4 x 1 024-token
