@@ -2,6 +2,7 @@
 (reference src/model/gaot.py: constructor, forward / encode / process / decode / autoregressive_predict, and
 state_dict keys), running on libgaot_hip.so."""
 import math
+import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -100,13 +101,19 @@ class GAOT(nn.Module):
     def encode(self, x_coord, pndata, latent_tokens_coord, encoder_nbrs):
         return self.encoder(x_coord=x_coord, pndata=pndata, latent_tokens_coord=latent_tokens_coord, encoder_nbrs=encoder_nbrs)
 
-    def process(self, rndata: Optional[torch.Tensor] = None, condition: Optional[float] = None) -> torch.Tensor:
+    def process(self, rndata: Optional[torch.Tensor] = None, condition: Optional[float] = None, patch_major: bool = False) -> torch.Tensor:
+        """`patch_major` (internal, _forward_eager): the rows of `rndata` are the latent points in patch-major order already (and the result
+        is expected in it), so the two permutes of gaot.py:182-186 / 222-229 are reshapes"""
         B, n, C = rndata.shape
         P = self.patch_size
         sizes = self._grid_sizes()
         assert n == math.prod(sizes), f"n_regional_nodes ({n}) != {'*'.join(map(str, sizes))}"
         assert all(s % P == 0 for s in sizes), f"latent grid {sizes} must be divisible by P({P})"
-        tok = ops.patchify(rndata, sizes, P)                                      # [B, S, P^d C]
+        pvol = P ** self.coord_dim
+        if patch_major:
+            tok = ops.reshaped(rndata.contiguous(), (B, n // pvol, pvol * C))
+        else:
+            tok = ops.patchify(rndata, sizes, P)                                  # [B, S, P^d C]
         if self.positional_embedding_name == 'absolute':
             tok = ops.linear(tok, self.patch_linear.weight, self.patch_linear.bias, rowbias=self._pos_emb(tok.device, tok.shape[-1]))
             rel = None
@@ -116,7 +123,68 @@ class GAOT(nn.Module):
         else:
             raise ValueError(f"unknown positional_embedding {self.positional_embedding_name!r}")
         tok = self.processor(tok, condition=condition, relative_positions=rel)
+        if patch_major:
+            return ops.reshaped(tok.contiguous(), (B, n, C))
         return ops.unpatchify(tok, sizes, P)
+
+    # ---- the latent grid in patch-major order.  patchify / unpatchify move whole C-wide rows (the channel axis stays innermost in both
+    # permutes), i.e. they are a fixed permutation of the latent points -- and which latent point carries which number is nobody's business
+    # but the caller's neighbour lists'.  So a forward over caller-supplied fx graphs (precompute_edges: the reference's fx trainers build them
+    # once, static_trainer.py:120-160) renumbers the latent grid once per graph (plan.renumbered: the encoder's CSR rows re-ordered, the
+    # decoder's source indices relabelled, coordinates gathered; all cached) and the four permuting launches of a training step are gone.
+    # Every per-row sum keeps its terms and their order, so the forward result is the same bits.
+    _PATCH_MAJOR = [os.environ.get("GAOT_PATCH_MAJOR", "1") != "0"]        # A/B switch (tools, tests)
+
+    def _latent_order(self, device):
+        """(perm, inv): patch-major row r' holds the caller's latent point perm[r']"""
+        c = self.__dict__.get("_latent_order_cache")
+        if c is None or c[0].device != device:
+            sizes, P, d = self._grid_sizes(), self.patch_size, self.coord_dim
+            ids = torch.arange(math.prod(sizes)).view(*[v for s in sizes for v in (s // P, P)])
+            perm = ids.permute(*range(0, 2 * d, 2), *range(1, 2 * d, 2)).reshape(-1).to(device)
+            inv = torch.empty_like(perm)
+            inv[perm] = torch.arange(perm.numel(), device=device)
+            c = self.__dict__["_latent_order_cache"] = (perm, inv)
+        return c
+
+    def _patch_major(self, latent, xcoord, query_coord, encoder_nbrs, decoder_nbrs):
+        """(latent coordinates, encoder lists, decoder lists) over the renumbered grid, or None when the forward keeps the caller's numbering:
+        vx batches (per-sample lists composed on the device every step), autograph's captured forward (its module-owned plans are refreshed
+        in place from the caller's coordinate buffer), a patch size of 1.  fx graphs handed in by the caller (precompute_edges) and the
+        module's own (magno.py:177-180, found over the CALLER's coordinates and cached by shape as ever) are renumbered alike."""
+        if not (self._PATCH_MAJOR[0] and self.patch_size > 1 and latent.is_cuda and xcoord.is_cuda and xcoord.dim() == 2
+                and (query_coord is None or query_coord.dim() == 2) and latent.dim() == 2
+                and latent.shape[0] == math.prod(self._grid_sizes()) and not getattr(self, "_auto_graph_bypass", False)):
+            return None
+        enc, dec = self.encoder, self.decoder
+        if bool(enc.precompute_edges) != bool(dec.precompute_edges):
+            return None
+        if self.training and (enc.sampling_strategy is not None or dec.sampling_strategy is not None):
+            return None              # neighbour sub-sampling draws per edge POSITION: the draws (and plan.DROP_RECORD) stay in the caller's numbering
+        if not enc.precompute_edges:
+            if latent.shape[1] != self.coord_dim or xcoord.shape[1] != self.coord_dim:
+                return None          # (the stages raise the reference's errors)
+            encoder_nbrs = enc._compute_neighbors(xcoord, latent, 'fx')
+            decoder_nbrs = dec._compute_neighbors(latent, xcoord if query_coord is None else query_coord, 'fx')
+        ns = len(enc.scales)
+        for nb in (encoder_nbrs, decoder_nbrs):
+            if not (isinstance(nb, (list, tuple)) and len(nb) == ns
+                    and all(isinstance(d, dict) and torch.is_tensor(d.get("neighbors_index")) and d["neighbors_index"].is_cuda
+                            and torch.is_tensor(d.get("neighbors_row_splits")) and d["neighbors_row_splits"].is_cuda for d in nb)):
+                return None
+        if any(int(d["neighbors_row_splits"].numel()) != latent.shape[0] + 1 for d in encoder_nbrs):
+            return None              # (not this latent grid's list: the encoder raises as ever)
+        from ..plan import renumbered
+        from .layers.magno import RenumberedLists
+        perm, inv = self._latent_order(latent.device)
+        key = (latent._version, id(perm))
+        hit = self.__dict__.get("_latent_pm")
+        if hit is None or hit[0] is not latent or hit[1] != key:
+            hit = self.__dict__["_latent_pm"] = (latent, key, latent.detach()[perm].contiguous(), perm)
+        if torch.cuda.is_current_stream_capturing():          # read by address from the graph being captured: keep it past the cache entry
+            self.__dict__.setdefault("_graph_keep", []).append(hit)
+        return (hit[2], RenumberedLists(renumbered(d, "queries", perm, inv) for d in encoder_nbrs),
+                RenumberedLists(renumbered(d, "sources", perm, inv) for d in decoder_nbrs))
 
     def decode(self, latent_tokens_coord, rndata, query_coord, decoder_nbrs):
         return self.decoder(latent_tokens_coord=latent_tokens_coord, rndata=rndata, query_coord=query_coord, decoder_nbrs=decoder_nbrs)
@@ -148,9 +216,12 @@ class GAOT(nn.Module):
             else:
                 ops.begin_pass()
                 ops.refresh_weight_amax(*self._amax_lists)
+        pm = self._patch_major(latent_tokens_coord, xcoord, query_coord, encoder_nbrs, decoder_nbrs)
+        if pm is not None:
+            latent_tokens_coord, encoder_nbrs, decoder_nbrs = pm
         rn = self.encode(x_coord=xcoord, pndata=pndata, latent_tokens_coord=latent_tokens_coord, encoder_nbrs=encoder_nbrs)
         rn = ops.cut(rn)                      # staged backward (data-parallel training): encoder gradients complete last
-        rn = self.process(rndata=rn, condition=condition)
+        rn = self.process(rndata=rn, condition=condition, patch_major=pm is not None)
         if query_coord is None:
             query_coord = xcoord
         return self.decode(latent_tokens_coord=latent_tokens_coord, rndata=rn, query_coord=query_coord, decoder_nbrs=decoder_nbrs)

@@ -58,6 +58,11 @@ class MAGNOConfig:
             raise ValueError("max_neighbors must be > 0 when using 'max_neighbors' sampling")
 
 
+class RenumberedLists(list):
+    """fx neighbour lists over the latent grid in patch-major order (model/gaot.py GAOT._patch_major, plan.renumbered): used as given,
+    whether the module owns its lists or the caller handed them in"""
+
+
 class _MAGNOBase(nn.Module):
     """Pieces shared by encoder and decoder: neighbour cache, per-(geometry, scale) transform, scale mixing."""
 
@@ -246,7 +251,7 @@ class _MAGNOBase(nn.Module):
         if proj is not None:
             return out if self.agno.applied_proj else ops.linear(out, proj[0], proj[2], rowbias=proj[1])
         if self.use_geoembed:
-            out = ops.linear(out, w_agno, rowbias=rowb)
+            out = ops.linear(out, w_agno, rowbias=rowb, publish=True)      # (the encoder's tokens: the patch embedding reads them through a reshape)
         return out
 
     def _scale_mix_weights(self, coords: torch.Tensor) -> torch.Tensor:
@@ -350,6 +355,8 @@ class MAGNOEncoder(_MAGNOBase):
             if encoder_nbrs is None:
                 raise ValueError("encoder_nbrs required when precompute_edges=True")
             nbrs = encoder_nbrs
+        elif isinstance(encoder_nbrs, RenumberedLists):
+            nbrs = encoder_nbrs
         else:
             nbrs = self._compute_neighbors(x_coord, latent_tokens_coord, mode)
         w = self._scale_mix_weights(self._kcoord(latent_tokens_coord)) if self.use_scale_weights else None
@@ -392,6 +399,8 @@ class MAGNODecoder(_MAGNOBase):
         if self.precompute_edges:
             if decoder_nbrs is None:
                 raise ValueError("decoder_nbrs required when precompute_edges=True")
+            nbrs = decoder_nbrs
+        elif isinstance(decoder_nbrs, RenumberedLists):
             nbrs = decoder_nbrs
         else:
             nbrs = self._compute_neighbors(latent_tokens_coord, query_coord, mode)

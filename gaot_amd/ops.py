@@ -419,10 +419,13 @@ def _gemm_path(d, key) -> int:
 def gemm(M: int, N: int, K: int, A, lda, a_kmajor, B, ldb, b_kmajor, out, ldc, *, bias=None, rowbias=None,
          rowbias_period=0, ld_rowbias=0, rowscale=None, act=L.ACT_NONE, aux_in=None, aux_out=None, ld_aux=0,
          residual=None, ldr=0, A2=None, lda2=0, k_split=0, split_k=0, colsum=None, pieces: Optional[int] = None,
-         a_amax=None, b_amax=None, b_is_weight: Optional[bool] = None, a2_amax=None, raw_slabs: bool = False):
+         a_amax=None, b_amax=None, b_is_weight: Optional[bool] = None, a2_amax=None, raw_slabs: bool = False,
+         want_c_amax: bool = False):
     """`a_amax` / `b_amax`: magnitude words of the operands where the caller has them (fp16-piece products); missing ones are looked up /
     computed here.  `b_is_weight` (default: every product but the transposed-A one): B is a parameter (or a view of one).
     The output's own word, when the kernel published it, is left in `gemm.last_c_amax` (None otherwise).
+    `want_c_amax`: publish the output's word from the fp32-MFMA tiles too (their vector epilogue does it for free; the fp16-piece tiles
+    always do): for outputs whose consumer is an fp16-piece product reached through a reshape.
     `raw_slabs` (with split_k > 1, `out` may be None): no reduce launch; returns (workspace, n_slabs): the product is the sum of the
     [M, N] slabs workspace[z * M * N:], z < n_slabs, for a consumer that adds them itself (gaot_rmsnorm_bwd_slabs)."""
     _dev(A, B, out, bias, rowbias, rowscale, aux_in, aux_out, residual, A2, colsum)
@@ -479,6 +482,10 @@ def gemm(M: int, N: int, K: int, A, lda, a_kmajor, B, ldb, b_kmajor, out, ldc, *
                 cw = _amax_words(1, out.device)[0]
                 d.c_absmax = cw.data_ptr()
                 gemm.last_c_amax = cw
+        elif want_c_amax and path == 1 and colsum is None and _PUBLISH_C and not raw_slabs and split_k <= 1 and 3 in _PIECES.values():
+            cw = _amax_words(1, out.device)[0]
+            d.c_absmax = cw.data_ptr()
+            gemm.last_c_amax = cw
     L.check(L.load().gaot_gemm_f32(C.byref(d), _stream()), "gaot_gemm_f32")
     if raw_slabs:
         return ws, int(L.load().gaot_gemm_slab_count(K, split_k))
@@ -941,7 +948,7 @@ class _Linear(torch.autograd.Function):
     """y = x @ w[:, :K]^T (+ x2 @ w[:, K:]^T) + b + rowbias[m % P] + residual"""
 
     @staticmethod
-    def forward(ctx, x, w, b, residual, rowbias, x2):
+    def forward(ctx, x, w, b, residual, rowbias, x2, publish=False):
         _dev(x, w)
         shp = x.shape
         K = shp[-1]
@@ -951,6 +958,8 @@ class _Linear(torch.autograd.Function):
         w2d = w.reshape(N, -1)            # Conv1d weights carry a trailing singleton dim
         res2 = residual.reshape(M, N) if residual is not None else None
         epi = dict(bias=b)
+        if publish:
+            epi["want_c_amax"] = True
         if res2 is not None:
             res2, ldr = _rowmajor(res2)
             epi.update(residual=res2, ldr=ldr)
@@ -1032,11 +1041,12 @@ class _Linear(torch.autograd.Function):
             for s in rb_shape[:-1]:
                 P *= s
             drb = batchsum(g.reshape(-1, P * N), g.shape[0] // P).reshape(rb_shape)
-        return dx, dw, db, dres, drb, dx2
+        return dx, dw, db, dres, drb, dx2, None
 
 
-def linear(x, w, b=None, residual=None, rowbias=None, x2=None):
-    return _Linear.apply(x, w, b, residual, rowbias, x2)
+def linear(x, w, b=None, residual=None, rowbias=None, x2=None, publish: bool = False):
+    """`publish`: the output's magnitude word is wanted whichever tile family runs the product (gemm(want_c_amax=))"""
+    return _Linear.apply(x, w, b, residual, rowbias, x2, publish)
 
 
 class _MatMul(torch.autograd.Function):
@@ -2561,6 +2571,28 @@ class _Patchify(torch.autograd.Function):
     def backward(ctx, g):
         sizes, P, inverse = ctx.args
         return _Patchify.apply(g, sizes, P, not inverse), None, None, None
+
+
+class _Reshaped(torch.autograd.Function):
+    """x.view(shape) -- and its gradient's view back -- that keep the magnitude word of what they alias (words travel on tensor OBJECTS, a
+    plain reshape drops them and the next fp16-piece product would spend a launch on the maximum)"""
+
+    @staticmethod
+    def forward(ctx, x, shape):
+        ctx.shape = x.shape
+        out = x.view(shape)
+        _publish(_amax_get(x), out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        gi = g.contiguous().view(ctx.shape)
+        _publish(_amax_get(g), gi)
+        return gi, None
+
+
+def reshaped(x, shape):
+    return _Reshaped.apply(x, tuple(shape))
 
 
 def patchify(x, sizes, P):

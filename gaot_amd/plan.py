@@ -262,6 +262,40 @@ def has_plan(neighbors: dict, n_src: int) -> bool:
     return plan._src_id == (id(idx), idx._version) and plan.n_src == n_src
 
 
+_RENUM_KEY = "_gaot_amd_renumbered"
+
+
+def renumbered(neighbors: dict, role: str, perm: torch.Tensor, inv: torch.Tensor) -> dict:
+    """The caller's graph over a RENUMBERED latent grid: latent point perm[r] of the caller becomes point r (inv[perm[r]] = r).
+    model/gaot.py runs encoder and decoder on the latent grid in patch-major order, which turns the processor's patchify / unpatchify
+    permutes (gaot.py:182-186, 222-229) into reshapes.  role 'queries' (encoder: the latent points are the CSR's rows -- rows taken in `perm`
+    order, every row keeps its edges in the caller's order) or 'sources' (decoder: the latent points are what neighbors_index names --
+    relabelled through `inv`, rows and edge order untouched).  Every per-row reduction sums the same terms in the same order as over the
+    caller's list.  Cached on the caller's dict for as long as its two tensors are the same objects at the same versions."""
+    idx, sp = neighbors["neighbors_index"], neighbors["neighbors_row_splits"]
+    key = (role, id(idx), idx._version, id(sp), sp._version, id(perm))
+    hit = neighbors.get(_RENUM_KEY)
+    if hit is not None and hit[0] == key and hit[2] is perm:
+        return hit[1]
+    if role == "sources":
+        out = {"neighbors_index": inv[idx.long()].to(idx.dtype), "neighbors_row_splits": sp}
+    elif role == "queries":
+        spl = sp.long()
+        Q, E = int(spl.numel() - 1), int(idx.numel())
+        if Q != int(perm.numel()):
+            raise ValueError(f"renumbered: {Q} CSR rows for a latent grid of {int(perm.numel())} points")
+        cnt = (spl[1:] - spl[:-1])[perm]
+        nsp = torch.zeros_like(spl)
+        nsp[1:] = torch.cumsum(cnt, 0)
+        rows = torch.repeat_interleave(torch.arange(Q, device=spl.device), cnt, output_size=E)
+        pos = spl[:-1][perm][rows] + (torch.arange(E, device=spl.device) - nsp[:-1][rows])
+        out = {"neighbors_index": idx[pos], "neighbors_row_splits": nsp.to(sp.dtype)}
+    else:
+        raise ValueError(f"renumbered: role {role!r}")
+    neighbors[_RENUM_KEY] = (key, out, perm, idx, sp)          # (hold the tensors: their ids stay unique)
+    return out
+
+
 def _i32_array(vals):
     arr = (C.c_int32 * len(vals))()
     for i, v in enumerate(vals):

@@ -741,10 +741,14 @@ def test_geometry_caches_hit_by_content_not_identity():
     p = torch.randn(2, 2000, 1, generator=g).to(dev())
     y1 = model(latent_tokens_coord=lat.to(dev()), xcoord=x.to(dev()), pndata=p)
     nb = list(model.encoder.neighbor_cache.values())[0][0]
+    # the forward runs over the module's list renumbered to the patch-major latent order (GAOT._patch_major): that list's plan holds the arrays
+    assert "_gaot_amd_renumbered" in nb
+    nb = nb["_gaot_amd_renumbered"][1]
+    lat = lat[model._latent_order(dev())[0].cpu()]
     plan = plan_for(nb, 2000)
     ptrs = {k: v["val"].data_ptr() for k, v in plan._coord_cache.items()}
     assert set(ptrs) == {"feat", "cos", "stats1"}
-    y2 = model(latent_tokens_coord=lat.to(dev()), xcoord=x.to(dev()), pndata=p)           # fresh uploads, same bytes
+    y2 = model(latent_tokens_coord=grid([32, 32]).to(dev()), xcoord=x.to(dev()), pndata=p)           # fresh uploads, same bytes
     assert torch.equal(y1, y2)
     assert {k: v["val"].data_ptr() for k, v in plan._coord_cache.items()} == ptrs and plan_for(nb, 2000) is plan
     # same shapes, different bytes: the guarded kernels recompute in place
@@ -763,9 +767,10 @@ def test_geometry_caches_hit_by_content_not_identity():
     # eval-mode kernel values follow the refreshed geometry (they are cached on the host under no_grad)
     model.eval()
     with torch.no_grad():
-        e_old = model.encode(x.to(dev()), p, lat.to(dev()), None)
-        e_new = model.encode(x2.to(dev()), p, lat.to(dev()), None)
-        e_new2 = model.encode(x2.to(dev()), p, lat.to(dev()), None)
+        lat0 = grid([32, 32]).to(dev())
+        e_old = model.encode(x.to(dev()), p, lat0, None)
+        e_new = model.encode(x2.to(dev()), p, lat0, None)
+        e_new2 = model.encode(x2.to(dev()), p, lat0, None)
     assert rel_l2(e_new.cpu(), e_old.cpu()) > 1e-4 and torch.equal(e_new, e_new2)
 
 

@@ -320,3 +320,39 @@ def test_union_part_layouts_match_header():
         names = re.findall(r"(?:\*|\s)([A-Za-z_][A-Za-z0-9_]*)\s*(?:\[\d+\])?\s*;", body)
         assert names == [f[0] for f in cls._fields_], (name, names)
         assert C.sizeof(cls) == 64, (name, C.sizeof(cls))
+
+
+def test_renumbered_graphs_are_the_same_graph_over_relabelled_latent_points():
+    """plan.renumbered (the latent grid in patch-major order, model/gaot.py): 'queries' re-orders CSR rows and keeps each row's edges in the
+    caller's order; 'sources' relabels the index; cached on the caller's dict until one of its tensors changes"""
+    from gaot_amd.plan import renumbered
+    g = torch.Generator().manual_seed(0)
+    Q, n_src = 24, 40
+    deg = torch.randint(0, 6, (Q,), generator=g)
+    deg[3] = 0
+    sp = torch.zeros(Q + 1, dtype=torch.int64)
+    sp[1:] = torch.cumsum(deg, 0)
+    idx = torch.randint(0, n_src, (int(sp[-1]),), generator=g)
+    perm = torch.randperm(Q, generator=g)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(Q)
+    nb = {"neighbors_index": idx, "neighbors_row_splits": sp}
+    out = renumbered(nb, "queries", perm, inv)
+    nsp, nidx = out["neighbors_row_splits"], out["neighbors_index"]
+    assert int(nsp[-1]) == idx.numel() and nsp.dtype == sp.dtype
+    for r in range(Q):
+        o = int(perm[r])
+        assert torch.equal(nidx[nsp[r]:nsp[r + 1]], idx[sp[o]:sp[o + 1]])
+    assert renumbered(nb, "queries", perm, inv) is out                     # cached
+    idx.add_(0)                                                            # a write to the caller's tensor: rebuilt
+    assert renumbered(nb, "queries", perm, inv) is not out
+    # sources: latent points are what the index names
+    permS = torch.randperm(n_src, generator=g)
+    invS = torch.empty_like(permS)
+    invS[permS] = torch.arange(n_src)
+    nb2 = {"neighbors_index": idx.clone(), "neighbors_row_splits": sp}
+    out2 = renumbered(nb2, "sources", permS, invS)
+    assert out2["neighbors_row_splits"] is sp
+    assert torch.equal(permS[out2["neighbors_index"]], nb2["neighbors_index"])      # new label r names the caller's point perm[r]
+    with pytest.raises(ValueError):
+        renumbered({"neighbors_index": idx, "neighbors_row_splits": sp}, "queries", perm[:-1], inv)
