@@ -191,6 +191,7 @@ PROTOTYPES = {
     "gaot_gno_ep_workspace": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "gaot_gno_lift_gather_reduce_ep": (C.c_int, [_f, _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i, _i, _i, C.c_int32, C.c_int32, _f, _f, _f, _i, _s]),
     "gaot_gno_proj_gather_t_ep": (C.c_int, [_f, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i, _i, C.c_int32, _i, _i, _f, _f, _f, _i, _s]),
+    "gaot_gno_proj_gather_t_ep_w": (C.c_int, [_f, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i, _i, C.c_int32, _i, _i, _f, _f, _f, _i, _f, _s]),
     "gaot_proj_fold_workspace": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
     "gaot_proj_fold_fwd": (C.c_int, [_f, C.c_int64, _f, _f, C.c_int64, _f, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f, _f, _s]),
     "gaot_proj_fold_bwd": (C.c_int, [_f, _f, _f, C.c_int64, _f, C.c_int64, _f, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f,

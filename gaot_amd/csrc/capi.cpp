@@ -13,5 +13,5 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace gaot
 
-extern "C" int gaot_abi_version(void) { return 9; }
+extern "C" int gaot_abi_version(void) { return 10; }
 extern "C" const char* gaot_last_error(void) { return gaot::g_err; }

@@ -96,20 +96,27 @@ __global__ __launch_bounds__(256) void lift_ep_kernel(const float* __restrict__ 
 // rows that span chunks: out[b,row,:] = carry(last slot of the chunk the row starts in) + sum of the first slots of the chunks it
 // continues into; empty rows: 0.  One lane group per row, grid.y = batch.
 __global__ __launch_bounds__(256) void ep_fixup_kernel(const int* __restrict__ sp, int R, int B, int C, const float* __restrict__ ws,
-                                                       float* __restrict__ out, int lanes, int epc) {
+                                                       float* __restrict__ out, int lanes, int epc, float* __restrict__ out_amax) {
     const int rows_per_block = 256 / lanes;
     const int r = blockIdx.x * rows_per_block + threadIdx.x / lanes;
     const int c = (threadIdx.x % lanes) * 4;
     const int b = blockIdx.y;
-    if (r >= R || c >= C) return;
-    const int t0 = sp[r], t1 = sp[r + 1];
-    float* o = out + ((long)b * R + r) * C + c;
-    if (t1 == t0) { *reinterpret_cast<f32x4*>(o) = f32x4{0.f, 0.f, 0.f, 0.f}; return; }
-    const int g0 = t0 / epc, g1 = (t1 - 1) / epc;
-    if (g0 == g1) return;                                   // finished by the chunk that contains it
-    f32x4 acc = *reinterpret_cast<const f32x4*>(ws + (((long)g0 * 2 + 1) * B + b) * C + c);
-    for (int g = g0 + 1; g <= g1; ++g) acc += *reinterpret_cast<const f32x4*>(ws + (((long)g * 2 + 0) * B + b) * C + c);
-    *reinterpret_cast<f32x4*>(o) = acc;
+    float am = 0.f;          // max |x| of what this thread stores (out_amax: every lane of a wave stays to the end)
+    if (r < R && c < C) {
+        const int t0 = sp[r], t1 = sp[r + 1];
+        float* o = out + ((long)b * R + r) * C + c;
+        if (t1 == t0) *reinterpret_cast<f32x4*>(o) = f32x4{0.f, 0.f, 0.f, 0.f};
+        else {
+            const int g0 = t0 / epc, g1 = (t1 - 1) / epc;
+            if (g0 != g1) {                                  // (else: finished by the chunk that contains it)
+                f32x4 acc = *reinterpret_cast<const f32x4*>(ws + (((long)g0 * 2 + 1) * B + b) * C + c);
+                for (int g = g0 + 1; g <= g1; ++g) acc += *reinterpret_cast<const f32x4*>(ws + (((long)g * 2 + 0) * B + b) * C + c);
+                *reinterpret_cast<f32x4*>(o) = acc;
+                am = fmaxf(fmaxf(fabsf(acc[0]), fabsf(acc[1])), fmaxf(fabsf(acc[2]), fabsf(acc[3])));
+            }
+        }
+    }
+    if (out_amax != nullptr) amax_publish(out_amax, am, (int)threadIdx.x & 63, (int)(blockIdx.x + blockIdx.y * gridDim.x) * 4 + ((int)threadIdx.x >> 6));
 }
 
 // ---------------------------------------------------------------- decoder backward: dF over the TRANSPOSED CSR, edge-partitioned
@@ -119,14 +126,15 @@ __global__ __launch_bounds__(256) void proj_t_ep_kernel(const float* __restrict_
                                                         int B, int Q, int C, const int* __restrict__ tsp, const int* __restrict__ tedge,
                                                         const int* __restrict__ idx, const int* __restrict__ eq, int n_src, int E,
                                                         const float* __restrict__ escale, float* __restrict__ df, float* __restrict__ ws,
-                                                        int lanes, int epc, const int* __restrict__ e_real) {
+                                                        int lanes, int epc, const int* __restrict__ e_real, float* __restrict__ df_amax) {
     if (e_real) E = min(E, *e_real);
     const int groups_per_block = 256 / lanes;
     const int g = blockIdx.x * groups_per_block + threadIdx.x / lanes;
     const int c = (threadIdx.x % lanes) * 4;
     const int b0 = blockIdx.y * BCH;
     const int begin = g * epc, end = min(begin + epc, E);
-    if (begin >= E || c >= C) return;
+    float am = 0.f;          // max |x| of the COMPLETE rows this thread stores (df_amax; the rows ep_fixup_kernel finishes are published there)
+    if (begin < E && c < C) {
     f32x4 wq[OC];
 #pragma unroll
     for (int o = 0; o < OC; ++o) wq[o] = *reinterpret_cast<const f32x4*>(weff + (long)o * C + c);
@@ -144,7 +152,10 @@ __global__ __launch_bounds__(256) void proj_t_ep_kernel(const float* __restrict_
 #pragma unroll
         for (int b = 0; b < BCH; ++b) {
             if (b0 + b >= B) break;
-            if (complete) *reinterpret_cast<f32x4*>(df + ((long)(b0 + b) * n_src + row) * C + c) = acc[b];
+            if (complete) {
+                *reinterpret_cast<f32x4*>(df + ((long)(b0 + b) * n_src + row) * C + c) = acc[b];
+                am = fmaxf(am, fmaxf(fmaxf(fabsf(acc[b][0]), fabsf(acc[b][1])), fmaxf(fabsf(acc[b][2]), fabsf(acc[b][3]))));
+            }
             else *reinterpret_cast<f32x4*>(ws + (((long)g * 2 + slot) * B + (b0 + b)) * C + c) = acc[b];
             acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -180,6 +191,8 @@ __global__ __launch_bounds__(256) void proj_t_ep_kernel(const float* __restrict_
         }
     }
     flush(cur, true);
+    }
+    if (df_amax != nullptr) amax_publish(df_amax, am, (int)threadIdx.x & 63, (int)(blockIdx.x + blockIdx.y * gridDim.x) * 4 + ((int)threadIdx.x >> 6));
 }
 
 // ---------------------------------------------------------------- decoder forward with the batch inside the lane group
@@ -283,7 +296,7 @@ extern "C" int gaot_gno_lift_gather_reduce_ep(const float* k, const float* pn, c
         if (c_in == 1) LG(1); else if (c_in == 2) LG(2); else if (c_in == 3) LG(3); else LG(4);
 #undef LG
     }
-    hipLaunchKernelGGL(ep_fixup_kernel, dim3(cdiv(Q, gpb), B), dim3(256), 0, ST(stream), splits, Q, B, C, ws, out, lanes, epc);
+    hipLaunchKernelGGL(ep_fixup_kernel, dim3(cdiv(Q, gpb), B), dim3(256), 0, ST(stream), splits, Q, B, C, ws, out, lanes, epc, (float*)nullptr);
     GAOT_CHECK_LAUNCH("gaot_gno_lift_gather_reduce_ep");
     return GAOT_OK;
 }
@@ -292,6 +305,13 @@ extern "C" int gaot_gno_proj_gather_t_ep(const float* k, const float* dy, const 
                                          int32_t out_channels, const int32_t* index32, const int32_t* edge_query, int32_t E,
                                          const int32_t* t_splits, const int32_t* t_edge, const float* escale, float* df, float* ws,
                                          const int32_t* e_real, gaot_stream_t stream) {
+    return gaot_gno_proj_gather_t_ep_w(k, dy, weff, B, Q, n_src, C, out_channels, index32, edge_query, E, t_splits, t_edge, escale, df, ws, e_real, nullptr, stream);
+}
+
+extern "C" int gaot_gno_proj_gather_t_ep_w(const float* k, const float* dy, const float* weff, int32_t B, int32_t Q, int32_t n_src, int32_t C,
+                                           int32_t out_channels, const int32_t* index32, const int32_t* edge_query, int32_t E,
+                                           const int32_t* t_splits, const int32_t* t_edge, const float* escale, float* df, float* ws,
+                                           const int32_t* e_real, float* df_absmax, gaot_stream_t stream) {
     GAOT_REQUIRE(B > 0 && out_channels >= 1 && out_channels <= 4 && C > 0 && C % 4 == 0 && C <= 256 && n_src > 0 && E >= 0,
                  "gno_proj_gather_t_ep: need 1 <= out_channels <= 4, C %% 4 == 0, C <= 256");
     GAOT_REQUIRE(k && dy && weff && t_splits && df && ws && aligned16(k) && aligned16(weff) && aligned16(df) && aligned16(ws) &&
@@ -301,11 +321,11 @@ extern "C" int gaot_gno_proj_gather_t_ep(const float* k, const float* dy, const 
     if (E > 0) {
         dim3 grid(cdiv(cdiv(E, epc), gpb), cdiv(B, BCH)), block(256);
 #define PT(OC) hipLaunchKernelGGL((proj_t_ep_kernel<OC, BCH>), grid, block, 0, ST(stream), k, dy, weff, B, Q, C, t_splits, t_edge, index32, edge_query, \
-                                  n_src, E, escale, df, ws, lanes, epc, e_real)
+                                  n_src, E, escale, df, ws, lanes, epc, e_real, df_absmax)
         if (out_channels == 1) PT(1); else if (out_channels == 2) PT(2); else if (out_channels == 3) PT(3); else PT(4);
 #undef PT
     }
-    hipLaunchKernelGGL(ep_fixup_kernel, dim3(cdiv(n_src, gpb), B), dim3(256), 0, ST(stream), t_splits, n_src, B, C, ws, df, lanes, epc);
+    hipLaunchKernelGGL(ep_fixup_kernel, dim3(cdiv(n_src, gpb), B), dim3(256), 0, ST(stream), t_splits, n_src, B, C, ws, df, lanes, epc, df_absmax);
     GAOT_CHECK_LAUNCH("gaot_gno_proj_gather_t_ep");
     return GAOT_OK;
 }

@@ -1815,9 +1815,11 @@ class _GNOProjTransform(torch.autograd.Function):
                     "gaot_gno_proj_backward")
             if ep:      # dF over the (skewed) transposed CSR: edge-partitioned, segmented
                 ws = torch.empty(int(lib.gaot_gno_ep_workspace(plan.E, Cc, B)), device=k.device, dtype=torch.float32)
-                L.check(lib.gaot_gno_proj_gather_t_ep(_p(k), _p(dy), _p(weff), B, plan.Q, n_src, Cc, OC, _p(plan.index), _p(plan.edge_query),
-                                                      plan.E, _p(plan.t_splits), _p(plan.t_edge), _p(esc) if has_e else None, _p(df), _p(ws),
-                                                      _p(plan.e_dev), _stream()), "gaot_gno_proj_gather_t_ep")
+                ow = _want_word(k.device)          # dF's magnitude word: the processor's last input-gradient product reads dF as its A operand
+                L.check(lib.gaot_gno_proj_gather_t_ep_w(_p(k), _p(dy), _p(weff), B, plan.Q, n_src, Cc, OC, _p(plan.index), _p(plan.edge_query),
+                                                        plan.E, _p(plan.t_splits), _p(plan.t_edge), _p(esc) if has_e else None, _p(df), _p(ws),
+                                                        _p(plan.e_dev), _p(ow), _stream()), "gaot_gno_proj_gather_t_ep_w")
+                _publish(ow, df)
             dweff = colsum(part).reshape(OC, Cc)
         if rb_shape is not None and need[3]:
             drowb = batchsum(dy.reshape(B, -1), B).reshape(rb_shape)

@@ -514,6 +514,9 @@ int gaot_patchify(const float* in, int32_t B, int32_t H, int32_t W, int32_t Dz, 
  * rows).  ws: gaot_gno_ep_workspace(E, C, B) floats.
  *   gaot_gno_lift_gather_reduce_ep : as gaot_gno_lift_gather_reduce (+ edge_query[E])
  *   gaot_gno_proj_gather_t_ep      : the dF product of gaot_gno_proj_backward over the transposed CSR
+ *   gaot_gno_proj_gather_t_ep_w    : [ABI 10] the same, publishing dF's magnitude word (df_absmax: gaot_gemm_desc.c_absmax conventions, zero
+ *                                    before the launch; NULL = the plain form) -- dF is the A operand of the processor's last input-gradient
+ *                                    product, which otherwise spends a launch on its maximum
  *   (both: e_real, optional DEVICE scalar = the number of edges actually in the list, <= E: the launch, the chunking and the workspace
  *    are sized for E, edges past *e_real are not walked -- the padded unions of gaot_union_compose)
  *   gaot_gno_proj_gather_reduce_bin: gaot_gno_proj_gather_reduce with the batch INSIDE the lane group (each kernel-value row is
@@ -531,6 +534,10 @@ int gaot_gno_proj_gather_t_ep(const float* k, const float* dy, const float* weff
                               int32_t out_channels, const int32_t* index32, const int32_t* edge_query, int32_t E,
                               const int32_t* t_splits, const int32_t* t_edge, const float* escale, float* df, float* ws,
                               const int32_t* e_real, gaot_stream_t stream);
+int gaot_gno_proj_gather_t_ep_w(const float* k, const float* dy, const float* weff, int32_t B, int32_t Q, int32_t n_src, int32_t C,
+                                int32_t out_channels, const int32_t* index32, const int32_t* edge_query, int32_t E,
+                                const int32_t* t_splits, const int32_t* t_edge, const float* escale, float* df, float* ws,
+                                const int32_t* e_real, float* df_absmax, gaot_stream_t stream);
 int gaot_gno_proj_gather_reduce_bin(const float* k, const float* f, const float* weff, const float* rowbias, const float* bias,
                                     int32_t B, int32_t n_src, int32_t C, int32_t out_channels, const int32_t* splits,
                                     const int32_t* cols, int32_t Q, const float* escale, float* y, const int32_t* row_order,

@@ -30,7 +30,7 @@ def test_library_builds_loads_and_exports_header_symbols():
     from gaot_amd import _lib
     build(verbose=False)
     lib = _lib.load()
-    assert lib.gaot_abi_version() == 9
+    assert lib.gaot_abi_version() == 10
     header = open(os.path.join(ROOT, "include", "gaot_hip.h")).read()
     debug = open(os.path.join(ROOT, "include", "gaot_hip_debug.h")).read()
     declared = set(re.findall(r"\b(gaot_[a-z0-9_]+)\s*\(", header))

@@ -1403,6 +1403,10 @@ def test_projected_gno_transform_matches_unfused(B, n_src, Q, OC, C, rb, bias):
     for u, v, w in zip(gf, g0, gd):
         assert u.shape == w.shape
         assert rel(u, w) < 1e-5, (rel(u, w), rel(v, w))
+    # the edge-partitioned dF kernels (batches of four and more) publish dF's magnitude word (gaot_gno_proj_gather_t_ep_w): exactly max |dF|
+    aw = getattr(gf[1], "_gaot_amax", None)
+    if B >= 4 and ops.wants_amax():
+        assert aw is not None and float(aw[0].max()) == float(gf[1].abs().max())
 
 
 @pytest.mark.parametrize("B,OC", [(8, 1), (5, 2)])
