@@ -67,7 +67,7 @@ def synthetic(seed: int, device):
 GNO_CALLS = {"gaot_gno_lift_gather_reduce": "encoder fwd", "gaot_gno_lift_gather_reduce_ep": "encoder fwd",
              "gaot_gno_lift_edge_grad": "encoder bwd",
              "gaot_gno_proj_gather_reduce": "decoder fwd", "gaot_gno_proj_gather_reduce_bin": "decoder fwd",
-             "gaot_gno_proj_backward": "decoder bwd", "gaot_gno_proj_gather_t_ep": "decoder bwd",
+             "gaot_gno_proj_backward": "decoder bwd", "gaot_gno_proj_gather_t_ep": "decoder bwd", "gaot_gno_proj_gather_t_ep_w": "decoder bwd",
              "gaot_gno_gather_reduce": "unfused transform", "gaot_gno_edge_grad": "unfused edge grad"}
 
 
