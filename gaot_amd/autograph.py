@@ -175,12 +175,16 @@ def _static_coordinates(model, latent, xcoord):
 def _plan_epochs(model):
     """epochs of every GeometryPlan behind the model's module-owned neighbour lists: a plan whose coordinate-derived arrays were
     refreshed in place by an EAGER call (evaluation with other coordinates of the same shapes) has moved on"""
-    from .plan import _PLAN_KEY
+    from .plan import _PLAN_KEY, _RENUM_KEY
     ep = []
     for side in (model.encoder, model.decoder):
         for nbrs in side.neighbor_cache.values():
             for nb in nbrs:
                 plan = nb.get(_PLAN_KEY) if isinstance(nb, dict) else None
+                ep.append(-1 if plan is None else plan.epoch)
+                # the list the forward actually runs over: renumbered to the patch-major latent order (model/gaot.py GAOT._patch_major)
+                ren = nb.get(_RENUM_KEY) if isinstance(nb, dict) else None
+                plan = ren[1].get(_PLAN_KEY) if ren is not None else None
                 ep.append(-1 if plan is None else plan.epoch)
     return tuple(ep)
 

@@ -149,12 +149,11 @@ class GAOT(nn.Module):
 
     def _patch_major(self, latent, xcoord, query_coord, encoder_nbrs, decoder_nbrs):
         """(latent coordinates, encoder lists, decoder lists) over the renumbered grid, or None when the forward keeps the caller's numbering:
-        vx batches (per-sample lists composed on the device every step), autograph's captured forward (its module-owned plans are refreshed
-        in place from the caller's coordinate buffer), a patch size of 1.  fx graphs handed in by the caller (precompute_edges) and the
+        vx batches (per-sample lists composed on the device every step), a patch size of 1.  fx graphs handed in by the caller (precompute_edges) and the
         module's own (magno.py:177-180, found over the CALLER's coordinates and cached by shape as ever) are renumbered alike."""
         if not (self._PATCH_MAJOR[0] and self.patch_size > 1 and latent.is_cuda and xcoord.is_cuda and xcoord.dim() == 2
                 and (query_coord is None or query_coord.dim() == 2) and latent.dim() == 2
-                and latent.shape[0] == math.prod(self._grid_sizes()) and not getattr(self, "_auto_graph_bypass", False)):
+                and latent.shape[0] == math.prod(self._grid_sizes())):
             return None
         enc, dec = self.encoder, self.decoder
         if bool(enc.precompute_edges) != bool(dec.precompute_edges):
@@ -177,13 +176,30 @@ class GAOT(nn.Module):
         from ..plan import renumbered
         from .layers.magno import RenumberedLists
         perm, inv = self._latent_order(latent.device)
-        key = (latent._version, id(perm))
-        hit = self.__dict__.get("_latent_pm")
-        if hit is None or hit[0] is not latent or hit[1] != key:
-            hit = self.__dict__["_latent_pm"] = (latent, key, latent.detach()[perm].contiguous(), perm)
-        if torch.cuda.is_current_stream_capturing():          # read by address from the graph being captured: keep it past the cache entry
-            self.__dict__.setdefault("_graph_keep", []).append(hit)
-        return (hit[2], RenumberedLists(renumbered(d, "queries", perm, inv) for d in encoder_nbrs),
+        if getattr(self, "_auto_graph_bypass", False):
+            # autograph's forward (warm-up, capture): `latent` is its static coordinate buffer, whose BYTES follow the caller's at the same object
+            # and version (autograph._sync_coordinates raises the plans' refresh flag when they change).  The renumbered coordinates live in a
+            # static buffer of their own, re-gathered by a launch that is part of the captured forward (ahead of the flag-guarded refresh
+            # kernels that read it); written through .data, so the plans' identity-keyed arrays see one object at one version
+            store = self.__dict__.setdefault("_latent_pm_static", {})
+            ent = store.get(id(latent))
+            if ent is None or ent[0] is not latent:
+                if len(store) > 8:
+                    store.clear()
+                ent = store[id(latent)] = (latent, torch.empty_like(latent, memory_format=torch.contiguous_format))
+            torch.index_select(latent.detach(), 0, perm, out=ent[1].data)
+            lat_pm = ent[1]
+            if torch.cuda.is_current_stream_capturing():
+                self.__dict__.setdefault("_graph_keep", []).append(ent)
+        else:
+            key = (latent._version, id(perm))
+            hit = self.__dict__.get("_latent_pm")
+            if hit is None or hit[0] is not latent or hit[1] != key:
+                hit = self.__dict__["_latent_pm"] = (latent, key, latent.detach()[perm].contiguous(), perm)
+            if torch.cuda.is_current_stream_capturing():          # read by address from the graph being captured: keep it past the cache entry
+                self.__dict__.setdefault("_graph_keep", []).append(hit)
+            lat_pm = hit[2]
+        return (lat_pm, RenumberedLists(renumbered(d, "queries", perm, inv) for d in encoder_nbrs),
                 RenumberedLists(renumbered(d, "sources", perm, inv) for d in decoder_nbrs))
 
     def decode(self, latent_tokens_coord, rndata, query_coord, decoder_nbrs):
