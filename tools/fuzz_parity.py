@@ -112,6 +112,14 @@ def run(c, dev):
     torch.cuda.synchronize()
     e_out = rel_l2(pred.detach().cpu(), pred_ref)
     e_loss = abs(float(loss.detach()) - float(loss_ref)) / abs(float(loss_ref))
+    out_bar = OUT_TOL
+    if e_out >= OUT_TOL:
+        # the reference's own fp32 rounding on the prediction can exceed 1e-5 (seed 649: five blocks without an attention norm; the fp32 oracle
+        # is 1.2e-5 off its float64 evaluation, the HIP path 6.4e-7): the prediction is then held to the float64 oracle at 1e-5 instead
+        dbl = lambda v: v.double() if torch.is_tensor(v) and v.is_floating_point() else v
+        pred64 = O.train_step({k: dbl(v) for k, v in sd.items()}, ocfg, {k: dbl(v) for k, v in batch.items()}, return_pred=True)[4]
+        if rel_l2(pred_ref.double(), pred64) > 0.5 * OUT_TOL:
+            e_out = rel_l2(pred.detach().cpu().double(), pred64)
     got = {k: prm.grad for k, prm in model.named_parameters()}
     errs = {k: GRAD_TOL * v for k, v in unfloored_ratio(got, {k: grads_ref[k] for k in got}, noise, GRAD_TOL).items()}
     # a tensor that is ZERO in exact arithmetic (a key bias under a softmax: the fp32 reference's value is its own rounding, |g32| ~ |g32 - g64|)
@@ -137,7 +145,11 @@ def run(c, dev):
         rest = {k: v for k, v in errs.items() if k not in failing}
         worst = max(rest, key=rest.get)
     ok = e_out < OUT_TOL and e_loss < LOSS_TOL and errs[worst] < GRAD_TOL
-    if os.environ.get("FUZZ_DUMP"):          # the eight worst tensors of the seed with their norms
+    if os.environ.get("FUZZ_DUMP"):          # the reference's own fp32 rounding on the prediction, the eight worst tensors of the seed with their norms
+        dbl = lambda v: v.double() if torch.is_tensor(v) and v.is_floating_point() else v
+        pred64 = O.train_step({k: dbl(v) for k, v in sd.items()}, ocfg, {k: dbl(v) for k, v in batch.items()}, return_pred=True)[4]
+        print(json.dumps({"prediction": {"hip_vs_fp32_oracle": e_out, "hip_vs_fp64_oracle": rel_l2(pred.detach().cpu().double(), pred64),
+                                         "fp32_oracle_vs_fp64_oracle": rel_l2(pred_ref.double(), pred64), "absmax": float(pred_ref.abs().max())}}), flush=True)
         for k in sorted(errs, key=errs.get, reverse=True)[:8]:
             print(json.dumps({"tensor": k, "figure": errs[k], "norm": float(grads_ref[k].norm()), "noise": noise[k],
                               "err": float((got[k].detach().cpu().double() - grads_ref[k].double()).norm()) if got[k] is not None else None}), flush=True)
@@ -174,6 +186,60 @@ def run(c, dev):
     return ok, info
 
 
+def run_rollout(c, dev):
+    """autoregressive_predict (gaot.py:307-476) of a random fx configuration against the oracle's: 3-6 steps, a random stepper mode, +- one
+    constant channel, +- conditional norm; udim = c.cout state channels, the model's input = state (+ constant) + the two time columns
+    (conditional norm: the last time column is the condition instead, gaot.py:403-408)."""
+    import numpy as np
+    from gaot_amd.model.gaot import GAOT
+    from gaot_amd.model.layers.attn import AttentionConfig, TransformerConfig
+    from gaot_amd.model.layers.magno import MAGNOConfig
+    r = random.Random(7000 + c.seed)
+    g = torch.Generator().manual_seed(5000 + c.seed)
+    torch.manual_seed(c.seed)
+    udim, cdim = c.cout, r.choice([0, 1])
+    cn = c.attn["use_conditional_norm"]
+    cin = udim + cdim + (1 if cn else 2)
+    pre = c.mode != "fx_own_search"
+    model = GAOT(cin, udim, NS(args=NS(magno=MAGNOConfig(precompute_edges=pre, **c.magno),
+                                       transformer=TransformerConfig(attn_config=AttentionConfig(**c.attn), **c.tf)), latent_tokens_size=c.sizes))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    m, t, a = c.magno, c.tf, c.attn
+    ocfg = O.OracleConfig(coord_dim=c.d, radius=m["radius"], hidden_size=m["hidden_size"], mlp_layers=m["mlp_layers"],
+                          lifting_channels=m["lifting_channels"], scales=m["scales"], use_scale_weights=m["use_scale_weights"],
+                          use_attention=m["use_attention"], attention_type=m["attention_type"], use_geoembed=m["use_geoembed"],
+                          embedding_method=m["embedding_method"], pooling=m["pooling"], transform_type=m["transform_type"],
+                          node_embedding=m["node_embedding"], precompute_edges=True, patch_size=t["patch_size"], tf_hidden_size=t["hidden_size"],
+                          use_attn_norm=t["use_attn_norm"], use_ffn_norm=t["use_ffn_norm"], num_layers=t["num_layers"],
+                          positional_embedding=t["positional_embedding"], use_long_range_skip=t["use_long_range_skip"],
+                          ffn_multiplier=t["ffn_multiplier"], num_heads=a["num_heads"], num_kv_heads=a["num_kv_heads"],
+                          use_conditional_norm=cn, latent_tokens_size=c.sizes)
+    lat = O.latent_grid(c.sizes)
+    x = torch.rand(c.N, c.d, generator=g) * 2 - 1
+    rs = [m["radius"] * s for s in m["scales"]]
+    enc = [O.radius_csr(x, lat, rad, exact=True) for rad in rs]
+    dec = [O.radius_csr(lat, x, rad, exact=True) for rad in rs]
+    steps = r.choice([3, 4, 6])
+    mode = r.choice(["output", "residual", "time_der"])
+    vec = lambda n, lo, hi: torch.tensor([r.uniform(lo, hi) for _ in range(n)])
+    stats = {"u": {"mean": vec(udim, -0.3, 0.3), "std": vec(udim, 0.6, 1.6)}, "res": {"mean": vec(udim, -0.1, 0.1), "std": vec(udim, 0.5, 1.2)},
+             "der": {"mean": vec(udim, -0.1, 0.1), "std": vec(udim, 0.5, 1.2)}, "start_time": {"mean": 0.4, "std": 0.25},
+             "time_diffs": {"mean": 0.1, "std": 0.05}}
+    if cdim:
+        stats["c"] = {"mean": vec(cdim, -0.1, 0.1), "std": vec(cdim, 0.8, 1.2)}
+    tv = np.linspace(0.0, 1.0, 4 * steps + 1)
+    ti = np.arange(0, 2 * steps + 2, 2)[:steps + 1]
+    xb = torch.randn(c.B, c.N, udim + cdim, generator=g)
+    ref = O.autoregressive_predict(sd, ocfg, xb, ti, tv, stats, mode, lat, x, use_conditional_norm=cn, encoder_nbrs=enc, decoder_nbrs=dec)
+    model = model.to(dev).eval()
+    one = lambda cs: {"neighbors_index": cs[0].to(dev), "neighbors_row_splits": cs[1].to(dev)}
+    kw = dict(encoder_nbrs=[one(s_) for s_ in enc], decoder_nbrs=[one(s_) for s_ in dec]) if pre else {}
+    got = model.autoregressive_predict(x_batch=xb.to(dev), time_indices=ti, t_values=tv, stats=stats, stepper_mode=mode,
+                                       latent_tokens_coord=lat.to(dev), fixed_coord=x.to(dev), use_conditional_norm=cn, **kw)
+    per = [rel_l2(got[:, i].cpu(), ref[:, i]) for i in range(steps)]
+    return per[0] < OUT_TOL and max(per) < 5e-5, dict(rollout_mode=mode, rollout_steps=steps, rollout_first=per[0], rollout_worst=max(per))
+
+
 def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
@@ -191,6 +257,13 @@ def main():
             ok, info = run(c, dev)
         except Exception as e:          # an unsupported combination must raise the reference's error, not crash: printed for a look
             ok, info = False, {"exception": f"{type(e).__name__}: {e}"[:400], "trace": traceback.format_exc().splitlines()[-6:]}
+        if ok and c.mode in ("fx", "fx_own_search") and c.magno["transform_type"] == "linear" and not os.environ.get("FUZZ_ORACLE_ONLY"):
+            try:
+                ok2, info2 = run_rollout(c, dev)
+            except Exception as e:
+                ok2, info2 = False, {"rollout_exception": f"{type(e).__name__}: {e}"[:400], "trace": traceback.format_exc().splitlines()[-6:]}
+            ok = ok and ok2
+            info.update(info2)
         bad += 0 if ok else 1
         cfg = {**c.magno, **c.tf, **c.attn, "mode": c.mode, "sizes": c.sizes, "B": c.B, "N": c.N, "cin": c.cin, "cout": c.cout}
         print(json.dumps({"seed": seed, "ok": ok, **info, **({} if ok else {"config": cfg})}), flush=True)
