@@ -1,0 +1,48 @@
+"""not gpu: the host side of the randomised parity sweep (tools/fuzz_parity.py).  For 60 random configurations of the operator API the
+module tree built by gaot_amd has exactly the reference's parameters -- names, order within the state_dict and shapes as
+oracle.make_state_dict lays them out from gaot.py:21-90, magno.py:87-156 / 423-492, attn.py:239-288 -- so a checkpoint of the reference loads
+whatever options it was trained with; and the oracle (the checker's half of the sweep) runs a train step on the configurations
+tests/test_fuzz_gpu.py holds the HIP path to."""
+import os
+from types import SimpleNamespace as NS
+
+import pytest
+
+from oracle import gaot_oracle as O
+from tools import fuzz_parity as F
+
+
+def _pair(c):
+    from gaot_amd.model.gaot import GAOT
+    from gaot_amd.model.layers.attn import AttentionConfig, TransformerConfig
+    from gaot_amd.model.layers.magno import MAGNOConfig
+    m, t, a = c.magno, c.tf, c.attn
+    model = GAOT(c.cin, c.cout, NS(args=NS(magno=MAGNOConfig(precompute_edges=True, **m),
+                                           transformer=TransformerConfig(attn_config=AttentionConfig(**a), **t)), latent_tokens_size=c.sizes))
+    ocfg = O.OracleConfig(coord_dim=c.d, radius=m["radius"], hidden_size=m["hidden_size"], mlp_layers=m["mlp_layers"],
+                          lifting_channels=m["lifting_channels"], scales=m["scales"], use_scale_weights=m["use_scale_weights"],
+                          use_attention=m["use_attention"], attention_type=m["attention_type"], use_geoembed=m["use_geoembed"],
+                          embedding_method=m["embedding_method"], pooling=m["pooling"], transform_type=m["transform_type"],
+                          node_embedding=m["node_embedding"], precompute_edges=True, patch_size=t["patch_size"], tf_hidden_size=t["hidden_size"],
+                          use_attn_norm=t["use_attn_norm"], use_ffn_norm=t["use_ffn_norm"], num_layers=t["num_layers"],
+                          positional_embedding=t["positional_embedding"], use_long_range_skip=t["use_long_range_skip"],
+                          ffn_multiplier=t["ffn_multiplier"], num_heads=a["num_heads"], num_kv_heads=a["num_kv_heads"],
+                          use_conditional_norm=a["use_conditional_norm"], latent_tokens_size=c.sizes)
+    return model, ocfg
+
+
+def test_random_configurations_have_the_reference_parameters():
+    for seed in range(60):
+        c = F.draw(seed)
+        model, ocfg = _pair(c)
+        mine = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        ref = {k: tuple(v.shape) for k, v in O.make_state_dict(ocfg, c.cin, c.cout).items()}
+        assert mine == ref, (seed, sorted(set(mine) ^ set(ref))[:6], [(k, mine[k], ref[k]) for k in mine if k in ref and mine[k] != ref[k]][:4])
+
+
+@pytest.mark.parametrize("seed", [42, 49, 58])
+def test_the_oracle_runs_the_sweeps_regression_seeds(seed, monkeypatch):
+    import torch
+    monkeypatch.setenv("FUZZ_ORACLE_ONLY", "1")
+    ok, info = F.run(F.draw(seed), torch.device("cpu"))
+    assert ok and info["loss_ref"] == info["loss_ref"] and 0.0 < info["loss_ref"] < 100.0, info
