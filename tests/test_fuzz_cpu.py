@@ -31,6 +31,21 @@ def _pair(c):
     return model, ocfg
 
 
+def test_random_configurations_have_the_imported_references_state_dict():
+    """names IN ORDER and shapes against tests/golden/fuzz_state_dicts.json = the state_dict of the imported reference's own GAOT for the same 60
+    configurations (tests/golden/make_fuzz_state_dicts.py wrote it in the build container)"""
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_state_dicts.json")) as f:
+        ref_all = json.load(f)
+    assert len(ref_all) == 60
+    for seed in range(60):
+        model, _ = _pair(F.draw(seed))
+        mine = [[k, list(v.shape)] for k, v in model.state_dict().items()]
+        ref = ref_all[str(seed)]
+        assert [k for k, _ in mine] == [k for k, _ in ref], (seed, [a for a, b in zip(mine, ref) if a[0] != b[0]][:4])
+        assert mine == ref, (seed, [(a, b) for a, b in zip(mine, ref) if a != b][:4])
+
+
 def test_random_configurations_have_the_reference_parameters():
     for seed in range(60):
         c = F.draw(seed)
