@@ -61,3 +61,33 @@ def test_the_oracle_runs_the_sweeps_regression_seeds(seed, monkeypatch):
     monkeypatch.setenv("FUZZ_ORACLE_ONLY", "1")
     ok, info = F.run(F.draw(seed), torch.device("cpu"))
     assert ok and info["loss_ref"] == info["loss_ref"] and 0.0 < info["loss_ref"] < 100.0, info
+
+
+def _proj(g):
+    import torch
+    v = g.detach().double().reshape(-1)
+    return float((v * torch.cos(0.37 * torch.arange(v.numel(), dtype=torch.float64))).sum())
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_the_oracle_reproduces_the_imported_references_step_on_random_configurations(seed):
+    """tests/golden/fuzz_reference_steps.npz = one trainer step of the imported reference's GAOT per configuration (make_fuzz_reference_steps.py):
+    the oracle, with the same seeded weights and the same batch, must give its prediction, loss and every parameter gradient (norm and a fixed
+    cosine projection).  Pins the sweep's checker to the reference across the sweep's option space."""
+    import numpy as np
+    import torch
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_reference_steps.npz"), allow_pickle=False)
+    c = F.draw(seed)
+    ocfg = F.oracle_config(c)
+    sd = O.make_state_dict(ocfg, c.cin, c.cout, seed=seed)
+    loss, grads, _, _, pred = O.train_step(sd, ocfg, F.make_batch(c), return_pred=True)
+    ref_pred = torch.from_numpy(z[f"{seed}.pred"])
+    assert float((pred - ref_pred).norm() / ref_pred.norm()) < 5e-6
+    assert abs(float(loss) - float(z[f"{seed}.loss"])) < 5e-6 * abs(float(z[f"{seed}.loss"]))
+    names, gnorm, gproj = [str(k) for k in z[f"{seed}.names"]], z[f"{seed}.gnorm"], z[f"{seed}.gproj"]
+    assert set(names) == set(grads)
+    top = float(gnorm.max())
+    for k, n_ref, p_ref in zip(names, gnorm, gproj):
+        scale = max(float(n_ref), 1e-4 * top)
+        assert abs(float(grads[k].double().norm()) - float(n_ref)) < 2e-4 * scale, (k, float(grads[k].norm()), float(n_ref))
+        assert abs(_proj(grads[k]) - float(p_ref)) < 2e-4 * scale, (k, _proj(grads[k]), float(p_ref))

@@ -51,12 +51,50 @@ def draw(seed):
               Nq=r.randrange(100, 400), cin=cin, cout=r.choice([1, 2]))
 
 
+def oracle_config(c):
+    m, t, a = c.magno, c.tf, c.attn
+    return O.OracleConfig(coord_dim=c.d, radius=m["radius"], hidden_size=m["hidden_size"], mlp_layers=m["mlp_layers"],
+                          lifting_channels=m["lifting_channels"], scales=m["scales"], use_scale_weights=m["use_scale_weights"],
+                          use_attention=m["use_attention"], attention_type=m["attention_type"], use_geoembed=m["use_geoembed"],
+                          embedding_method=m["embedding_method"], pooling=m["pooling"], transform_type=m["transform_type"],
+                          node_embedding=m["node_embedding"], precompute_edges=True, patch_size=t["patch_size"], tf_hidden_size=t["hidden_size"],
+                          use_attn_norm=t["use_attn_norm"], use_ffn_norm=t["use_ffn_norm"], num_layers=t["num_layers"],
+                          positional_embedding=t["positional_embedding"], use_long_range_skip=t["use_long_range_skip"],
+                          ffn_multiplier=t["ffn_multiplier"], num_heads=a["num_heads"], num_kv_heads=a["num_kv_heads"],
+                          use_conditional_norm=a["use_conditional_norm"], latent_tokens_size=c.sizes)
+
+
+def make_batch(c):
+    """the seed's geometry, fields and exact radius graphs (CPU tensors, the oracle's batch layout)"""
+    g = torch.Generator().manual_seed(1000 + c.seed)
+    m = c.magno
+    lat = O.latent_grid(c.sizes)
+    vx = c.mode == "vx"
+    x = (torch.rand(c.B, c.N, c.d, generator=g) if vx else torch.rand(c.N, c.d, generator=g)) * 2 - 1
+    q = torch.rand(c.Nq, c.d, generator=g) * 2 - 1 if c.mode == "fx_query" else None
+    Nout = c.Nq if q is not None else c.N
+    p, tgt = torch.randn(c.B, c.N, c.cin, generator=g), torch.randn(c.B, Nout, c.cout, generator=g)
+    cond = torch.rand(c.B, 1, generator=g) if c.attn["use_conditional_norm"] else None
+    rs = [m["radius"] * s for s in m["scales"]]
+    if vx:
+        enc = [[O.radius_csr(x[b], lat, r, exact=True) for r in rs] for b in range(c.B)]
+        dec = [[O.radius_csr(lat, x[b], r, exact=True) for r in rs] for b in range(c.B)]
+    else:
+        enc = [O.radius_csr(x, lat, r, exact=True) for r in rs]
+        dec = [O.radius_csr(lat, x if q is None else q, r, exact=True) for r in rs]
+    batch = dict(latent=lat, xcoord=x, pndata=p, target=tgt, encoder_nbrs=enc, decoder_nbrs=dec)
+    if q is not None:
+        batch["query_coord"] = q
+    if cond is not None:
+        batch["condition"] = cond
+    return batch
+
+
 def run(c, dev):
     from gaot_amd.model.gaot import GAOT
     from gaot_amd.model.layers.attn import AttentionConfig, TransformerConfig
     from gaot_amd.model.layers.magno import MAGNOConfig
     from gaot_amd import ops
-    g = torch.Generator().manual_seed(1000 + c.seed)
     torch.manual_seed(c.seed)
     pre = c.mode != "fx_own_search"
     model = GAOT(c.cin, c.cout, NS(args=NS(magno=MAGNOConfig(precompute_edges=pre, **c.magno),
@@ -73,25 +111,9 @@ def run(c, dev):
                           positional_embedding=t["positional_embedding"], use_long_range_skip=t["use_long_range_skip"],
                           ffn_multiplier=t["ffn_multiplier"], num_heads=a["num_heads"], num_kv_heads=a["num_kv_heads"],
                           use_conditional_norm=a["use_conditional_norm"], latent_tokens_size=c.sizes)
-    lat = O.latent_grid(c.sizes)
-    vx = c.mode == "vx"
-    x = (torch.rand(c.B, c.N, c.d, generator=g) if vx else torch.rand(c.N, c.d, generator=g)) * 2 - 1
-    q = torch.rand(c.Nq, c.d, generator=g) * 2 - 1 if c.mode == "fx_query" else None
-    Nout = c.Nq if q is not None else c.N
-    p, tgt = torch.randn(c.B, c.N, c.cin, generator=g), torch.randn(c.B, Nout, c.cout, generator=g)
-    cond = torch.rand(c.B, 1, generator=g) if a["use_conditional_norm"] else None
-    rs = [m["radius"] * s for s in m["scales"]]
-    if vx:
-        enc = [[O.radius_csr(x[b], lat, r, exact=True) for r in rs] for b in range(c.B)]
-        dec = [[O.radius_csr(lat, x[b], r, exact=True) for r in rs] for b in range(c.B)]
-    else:
-        enc = [O.radius_csr(x, lat, r, exact=True) for r in rs]
-        dec = [O.radius_csr(lat, x if q is None else q, r, exact=True) for r in rs]
-    batch = dict(latent=lat, xcoord=x, pndata=p, target=tgt, encoder_nbrs=enc, decoder_nbrs=dec)
-    if q is not None:
-        batch["query_coord"] = q
-    if cond is not None:
-        batch["condition"] = cond
+    batch = make_batch(c)
+    lat, x, p, tgt, enc, dec = (batch[k] for k in ("latent", "xcoord", "pndata", "target", "encoder_nbrs", "decoder_nbrs"))
+    q, cond, vx = batch.get("query_coord"), batch.get("condition"), c.mode == "vx"
     loss_ref, grads_ref, _, _, pred_ref = O.train_step(sd, ocfg, batch, return_pred=True)
     noise = fp32_noise(sd, ocfg, batch, grads_ref)
     if os.environ.get("FUZZ_ORACLE_ONLY"):          # (CPU dry run of the checker's half)
