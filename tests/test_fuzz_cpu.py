@@ -91,3 +91,27 @@ def test_the_oracle_reproduces_the_imported_references_step_on_random_configurat
         scale = max(float(n_ref), 1e-4 * top)
         assert abs(float(grads[k].double().norm()) - float(n_ref)) < 2e-4 * scale, (k, float(grads[k].norm()), float(n_ref))
         assert abs(_proj(grads[k]) - float(p_ref)) < 2e-4 * scale, (k, _proj(grads[k]), float(p_ref))
+
+
+def _rollout_seeds():
+    return [s for s in range(40) if F.draw(s).mode in ("fx", "fx_own_search") and F.draw(s).magno["transform_type"] == "linear"]
+
+
+@pytest.mark.parametrize("seed", _rollout_seeds())
+def test_the_oracle_reproduces_the_imported_references_rollout_on_random_configurations(seed):
+    """tests/golden/fuzz_reference_rollouts.npz = autoregressive_predict of the imported reference's GAOT (make_fuzz_reference_rollouts.py): the
+    oracle's rollout -- the checker of the GPU sweep's rollouts -- gives every step of it (3-6 steps, all three stepper modes, +- a constant
+    channel, +- conditional norm)"""
+    import numpy as np
+    import torch
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_reference_rollouts.npz"), allow_pickle=False)
+    c = F.draw(seed)
+    ro = F.rollout_setup(c)
+    ocfg = F.oracle_config(c)
+    sd = O.make_state_dict(ocfg, ro.cin, ro.udim, seed=seed)
+    got = O.autoregressive_predict(sd, ocfg, ro.xb, ro.ti, ro.tv, ro.stats, ro.mode, ro.lat, ro.x, use_conditional_norm=ro.cn,
+                                   encoder_nbrs=ro.enc, decoder_nbrs=ro.dec)
+    ref = torch.from_numpy(z[f"{seed}.rollout"])
+    assert got.shape == ref.shape == (c.B, ro.steps, c.N, ro.udim)
+    for i in range(ro.steps):
+        assert float((got[:, i] - ref[:, i]).norm() / ref[:, i].norm()) < 1e-5, (seed, i)

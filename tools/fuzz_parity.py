@@ -208,6 +208,34 @@ def run(c, dev):
     return ok, info
 
 
+def rollout_setup(c):
+    """the rollout case run_rollout draws for a configuration (same draws, CPU tensors): what the reference-side generator
+    (tests/golden/make_fuzz_reference_rollouts.py) and the oracle-side test share"""
+    import numpy as np
+    r = random.Random(7000 + c.seed)
+    g = torch.Generator().manual_seed(5000 + c.seed)
+    udim, cdim = c.cout, r.choice([0, 1])
+    cn = c.attn["use_conditional_norm"]
+    cin = udim + cdim + (1 if cn else 2)
+    lat = O.latent_grid(c.sizes)
+    x = torch.rand(c.N, c.d, generator=g) * 2 - 1
+    rs = [c.magno["radius"] * s for s in c.magno["scales"]]
+    enc = [O.radius_csr(x, lat, rad, exact=True) for rad in rs]
+    dec = [O.radius_csr(lat, x, rad, exact=True) for rad in rs]
+    steps = r.choice([3, 4, 6])
+    mode = r.choice(["output", "residual", "time_der"])
+    vec = lambda n, lo, hi: torch.tensor([r.uniform(lo, hi) for _ in range(n)])
+    stats = {"u": {"mean": vec(udim, -0.3, 0.3), "std": vec(udim, 0.6, 1.6)}, "res": {"mean": vec(udim, -0.1, 0.1), "std": vec(udim, 0.5, 1.2)},
+             "der": {"mean": vec(udim, -0.1, 0.1), "std": vec(udim, 0.5, 1.2)}, "start_time": {"mean": 0.4, "std": 0.25},
+             "time_diffs": {"mean": 0.1, "std": 0.05}}
+    if cdim:
+        stats["c"] = {"mean": vec(cdim, -0.1, 0.1), "std": vec(cdim, 0.8, 1.2)}
+    tv = np.linspace(0.0, 1.0, 4 * steps + 1)
+    ti = np.arange(0, 2 * steps + 2, 2)[:steps + 1]
+    xb = torch.randn(c.B, c.N, udim + cdim, generator=g)
+    return NS(udim=udim, cdim=cdim, cn=cn, cin=cin, lat=lat, x=x, enc=enc, dec=dec, steps=steps, mode=mode, stats=stats, tv=tv, ti=ti, xb=xb)
+
+
 def run_rollout(c, dev):
     """autoregressive_predict (gaot.py:307-476) of a random fx configuration against the oracle's: 3-6 steps, a random stepper mode, +- one
     constant channel, +- conditional norm; udim = c.cout state channels, the model's input = state (+ constant) + the two time columns
