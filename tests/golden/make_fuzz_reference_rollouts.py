@@ -28,6 +28,7 @@ def seeds():
 
 
 def main():
+    torch.set_num_threads(1)          # one thread: the scatter-adds of the reference's CPU backward sum in arrival order across threads (run-to-run differences of 3e-7 relative with 8)
     MG.install_standins()
     from src.model.gaot import GAOT
     from src.model.layers.attn import AttentionConfig, TransformerConfig
